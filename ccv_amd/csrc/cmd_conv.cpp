@@ -1,0 +1,186 @@
+// CCV_NNC_CONVOLUTION_FORWARD / BACKWARD on gfx950: implicit-GEMM on the fp32 MFMA contraction core.
+// Semantics follow the reference CPU backend (the oracle):
+//   forward   lib/nnc/cmd/convolution/ccv_nnc_conv_cpu_ref.c:13-172   b = bias + sum_{i,j,c} w[k,i,j,c] * a[n, y*s-p+i*d, x*s-p+j*d, g*Cg+c]
+//   backward  lib/nnc/cmd/convolution/ccv_nnc_conv_cpu_ref.c:174-345  inputs (g, a, w) -> outputs (h, dw, dbias); CCV_NNC_ACCUMULATE_OUTPUT
+//             accumulates into dw / dbias (:186-192); h is always overwritten (:286)
+// and replace the cuDNN calls of lib/nnc/cmd/convolution/gpu/ccv_nnc_conv_gpu_cudnn.cu:24-114, 204-367.
+// Layout on device: NHWC activations (n, y, x, c) with c innermost, weights [K][kh][kw][Cg]; tensor views are accepted for
+// the inputs as long as the channel stride is 1.  NCHW tensors are routed through the layout kernels of cmd_util (workspace).
+#include "gemm_launch.h"
+
+using namespace nnc;
+
+namespace {
+
+struct conv_geom_t {
+	int N, H, W, C;     // input
+	int OH, OW, K;      // output
+	int kh, kw, Cg, Kg, groups;
+	int sy, sx, pby, pbx, dy, dx;
+};
+
+static bool conv_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, const Image4& a, const Image4& b, const ccv_nnc_tensor_t* w, conv_geom_t* g)
+{
+	g->N = a.n; g->H = a.h; g->W = a.w; g->C = a.c;
+	g->OH = b.h; g->OW = b.w; g->K = b.c;
+	g->groups = cmd.info.convolution.groups > 0 ? cmd.info.convolution.groups : 1;
+	g->kh = cmd.info.size.dim[0]; g->kw = cmd.info.size.dim[1];
+	if (g->K != cmd.info.convolution.count || g->K % g->groups || g->C % g->groups || a.n != b.n) return false;
+	g->Cg = g->C / g->groups; g->Kg = g->K / g->groups;
+	g->sy = hint.stride.dim[0] > 0 ? hint.stride.dim[0] : 1;
+	g->sx = hint.stride.dim[1] > 0 ? hint.stride.dim[1] : 1;
+	g->pby = hint.border.begin[0]; g->pbx = hint.border.begin[1];
+	g->dy = cmd.info.convolution.dilation[0] > 1 ? cmd.info.convolution.dilation[0] : 1;
+	g->dx = cmd.info.convolution.dilation[1] > 1 ? cmd.info.convolution.dilation[1] : 1;
+	if (w) { // NHWC weights: [K][kh][kw][Cg]
+		if (tensor_nd(w->info.dim) != 4 || w->info.dim[0] != g->K || w->info.dim[1] != g->kh || w->info.dim[2] != g->kw || w->info.dim[3] != g->Cg) return false;
+		if (!tensor_contiguous(w)) return false;
+	}
+	return true;
+}
+
+static bool pixel_linear(const Image4& t)
+{ // pixels (n, y, x) form one arithmetic progression with step sw and channels are dense
+	return t.sc == 1 && t.sh == (long)t.w * t.sw && (t.n == 1 || t.sn == (long)t.h * t.sh);
+}
+
+static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	if (a.sc != 1 || !pixel_linear(b)) return CCV_NNC_EXEC_INVALID;
+	const long M = (long)g.N * g.OH * g.OW;
+	const int Kred = g.kh * g.kw * g.Cg;
+	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	const bool vec = (g.Cg % 4 == 0) && aligned16(a.p) && aligned16(w) && a.sw % 4 == 0 && a.sh % 4 == 0 && (a.n == 1 || a.sn % 4 == 0);
+	GemmOut out = { b.p, b.sw, 1, bias, 1.f, 0 };
+#define CONV_FWD(VEC) do { \
+		Im2colKC<VEC> la; \
+		la.p = a.p; la.s_n = a.sn; la.s_h = (int)a.sh; la.s_w = (int)a.sw; la.H = g.H; la.W = g.W; \
+		la.OW = g.OW; la.OHW = g.OH * g.OW; la.M = (int)M; la.C = g.Cg; la.KWC = g.kw * g.Cg; la.K = Kred; \
+		la.my = g.sy; la.mx = g.sx; la.oy_off = -g.pby; la.ox_off = -g.pbx; la.ty = g.dy; la.tx = g.dx; la.dv_y = 1; la.dv_x = 1; \
+		MatLoader<true, VEC> lb; \
+		lb.p = w; lb.ldr = Kred; lb.ldk = 1; lb.R = g.Kg; lb.K = Kred; \
+		return gemm_run("conv_fwd", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, 1, flags, ctx); \
+	} while (0)
+	if (vec) CONV_FWD(true); else CONV_FWD(false);
+#undef CONV_FWD
+}
+
+// h = sum_{k,i,j} g[n, (y+p-i*d)/s, (x+p-j*d)/s, k] * w[k,i,j,c]
+static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	if (gr.sc != 1 || !pixel_linear(h)) return CCV_NNC_EXEC_INVALID;
+	const long M = (long)g.N * g.H * g.W;
+	const int Kred = g.kh * g.kw * g.Kg;
+	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	const bool vec = (g.Kg % 4 == 0) && (g.Cg % 4 == 0) && aligned16(gr.p) && aligned16(w) && gr.sw % 4 == 0 && gr.sh % 4 == 0 && (gr.n == 1 || gr.sn % 4 == 0);
+	GemmOut out = { h.p, h.sw, 1, 0, 1.f, 0 };
+#define CONV_DGRAD(VEC) do { \
+		Im2colKC<VEC> la; \
+		la.p = gr.p; la.s_n = gr.sn; la.s_h = (int)gr.sh; la.s_w = (int)gr.sw; la.H = g.OH; la.W = g.OW; \
+		la.OW = g.W; la.OHW = g.H * g.W; la.M = (int)M; la.C = g.Kg; la.KWC = g.kw * g.Kg; la.K = Kred; \
+		la.my = 1; la.mx = 1; la.oy_off = g.pby; la.ox_off = g.pbx; la.ty = -g.dy; la.tx = -g.dx; la.dv_y = g.sy; la.dv_x = g.sx; \
+		WgtDgradNC<VEC> lb; \
+		lb.p = w; lb.ko_stride = (long)g.kh * g.kw * g.Cg; lb.C = g.Cg; lb.Ko = g.Kg; lb.K = Kred; \
+		return gemm_run("conv_dgrad", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, 1, flags, ctx); \
+	} while (0)
+	if (vec) CONV_DGRAD(true); else CONV_DGRAD(false);
+#undef CONV_DGRAD
+}
+
+// dw[k,i,j,c] (+)= sum_{n,y,x} g[n,y,x,k] * a[n, y*s-p+i*d, x*s-p+j*d, c]
+static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4& a, float* dw, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	if (a.sc != 1 || !pixel_linear(gr)) return CCV_NNC_EXEC_INVALID;
+	const long P = (long)g.N * g.OH * g.OW;
+	if (P > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	const int NN = g.kh * g.kw * g.Cg;
+	const bool vec = (g.Cg % 4 == 0) && (g.Kg % 4 == 0) && aligned16(a.p) && aligned16(gr.p) && a.sw % 4 == 0 && a.sh % 4 == 0 && (a.n == 1 || a.sn % 4 == 0) && gr.sw % 4 == 0;
+	GemmOut out = { dw, (long)NN, 1, 0, 1.f, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0 };
+#define CONV_WGRAD(VEC) do { \
+		MatLoader<false, VEC> la; \
+		la.p = gr.p; la.ldr = 1; la.ldk = gr.sw; la.R = g.Kg; la.K = (int)P; \
+		Im2colNC<VEC> lb; \
+		lb.p = a.p; lb.s_n = a.sn; lb.s_h = (int)a.sh; lb.s_w = (int)a.sw; lb.H = g.H; lb.W = g.W; lb.OW = g.OW; lb.OHW = g.OH * g.OW; \
+		lb.C = g.Cg; lb.KWC = g.kw * g.Cg; lb.NN = NN; lb.K = (int)P; lb.sy = g.sy; lb.sx = g.sx; lb.py = g.pby; lb.px = g.pbx; lb.dy = g.dy; lb.dx = g.dx; \
+		return gemm_run("conv_wgrad", la, lb, out, g.Kg, NN, (int)P, g.groups, (long)g.Kg, (long)g.Cg, (long)g.Kg * NN, 0L, 0, flags, ctx); \
+	} while (0)
+	if (vec) CONV_WGRAD(true); else CONV_WGRAD(false);
+#undef CONV_WGRAD
+}
+
+static int _conv_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 2 || output_size < 1 || !inputs[0] || !inputs[1] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* a = inputs[0];
+	const ccv_nnc_tensor_t* w = inputs[1];
+	const ccv_nnc_tensor_t* bias = input_size > 2 ? inputs[2] : 0;
+	ccv_nnc_tensor_t* b = outputs[0];
+	if (CCV_GET_DATA_TYPE(a->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
+	if (a->info.format != CCV_TENSOR_FORMAT_NHWC || b->info.format != CCV_TENSOR_FORMAT_NHWC) return CCV_NNC_EXEC_INVALID;
+	Image4 ai, bi;
+	if (!image4(a, &ai) || !image4(b, &bi)) return CCV_NNC_EXEC_INVALID;
+	conv_geom_t g;
+	if (!conv_geometry(cmd, hint, ai, bi, w, &g)) return CCV_NNC_EXEC_INVALID;
+	if (bias && (bias->info.dim[0] != g.K || !tensor_contiguous(bias))) return CCV_NNC_EXEC_INVALID;
+	return conv_forw_nhwc(g, ai, w->data.f32, bias ? bias->data.f32 : 0, bi, flags, stream_context);
+}
+
+static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	// inputs: gradient g, forward input a, [w]; outputs: [h], [dw], [dbias]   (ccv_nnc_convolution.c:16-37)
+	if (input_size < 2 || output_size < 1 || !inputs[0]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* gt = inputs[0];
+	const ccv_nnc_tensor_t* a = inputs[1];
+	const ccv_nnc_tensor_t* w = input_size > 2 ? inputs[2] : 0;
+	ccv_nnc_tensor_t* h = outputs[0];
+	ccv_nnc_tensor_t* dw = output_size > 1 ? outputs[1] : 0;
+	ccv_nnc_tensor_t* dbias = output_size > 2 ? outputs[2] : 0;
+	if (gt->info.format != CCV_TENSOR_FORMAT_NHWC || CCV_GET_DATA_TYPE(gt->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
+	Image4 gi;
+	if (!image4(gt, &gi)) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* shape_src = a ? a : h; // the forward input's shape
+	if (!shape_src) return CCV_NNC_EXEC_INVALID;
+	Image4 ai;
+	if (!image4(shape_src, &ai)) return CCV_NNC_EXEC_INVALID;
+	conv_geom_t g;
+	const ccv_nnc_tensor_t* wshape = dw ? dw : w;
+	if (!wshape || !conv_geometry(cmd, hint, ai, gi, wshape, &g)) return CCV_NNC_EXEC_INVALID;
+	hipStream_t stream = stream_of(stream_context);
+	int ret;
+	if (dw) {
+		if (!a) return CCV_NNC_EXEC_INVALID;
+		if ((ret = conv_wgrad_nhwc(g, gi, ai, dw->data.f32, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	}
+	if (dbias) {
+		if (!pixel_linear(gi) || !tensor_contiguous(dbias) || dbias->info.dim[0] != g.K) return CCV_NNC_EXEC_INVALID;
+		if ((ret = colsum_f32(gi.p, (long)g.N * g.OH * g.OW, g.K, gi.sw, dbias->data.f32, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	}
+	if (h) {
+		if (!w || !tensor_contiguous(w)) return CCV_NNC_EXEC_INVALID;
+		Image4 hi;
+		if (!image4(h, &hi) || hi.h != g.H || hi.w != g.W || hi.c != g.C || hi.n != g.N) return CCV_NNC_EXEC_INVALID;
+		if ((ret = conv_dgrad_nhwc(g, gi, w->data.f32, hi, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	}
+	(void)stream;
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+} // namespace
+
+extern "C" void _register_command_CCV_NNC_CONVOLUTION_FORWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
+{
+	registry->tensor_formats = CCV_TENSOR_FORMAT_NHWC;
+	registry->tensor_datatypes = CCV_32F;
+	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
+	registry->algorithms = 1;
+	registry->exec = _conv_forw;
+}
+
+extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
+{
+	registry->tensor_formats = CCV_TENSOR_FORMAT_NHWC;
+	registry->tensor_datatypes = CCV_32F;
+	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
+	registry->algorithms = 1;
+	registry->exec = _conv_back;
+}

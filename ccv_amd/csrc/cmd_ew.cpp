@@ -1,0 +1,338 @@
+// Bandwidth-bound element-wise commands on gfx950: RELU, EWSUM, SCALAR_MUL, SGD, SET, DATA_TRANSFER, plus the
+// column-sum used for bias gradients.  All kernels are grid-stride, 16 bytes per lane where the tensors allow it
+// (coalesced dwordx4), otherwise 4 bytes per lane.  Roofline for every kernel here is HBM (8 TB/s spec);
+// algorithmic bytes are listed per kernel.
+// Oracle semantics:
+//   relu      lib/nnc/cmd/relu/ccv_nnc_relu_cpu_ref.c:13-55            (gpu: relu/gpu/ccv_nnc_relu_gpu_cudnn.cu)
+//   ewsum     lib/nnc/cmd/ew/ccv_nnc_ew_cpu_ref.c:15-233               (gpu: ew/gpu/ccv_nnc_ew_gpu_cudnn.cu:13-130)
+//   sgd       lib/nnc/cmd/sgd/ccv_nnc_sgd_cpu_ref.c:16-126             (gpu: sgd/gpu/ccv_nnc_sgd_gpu_ref.cu:13-100)
+//   set/xfer  lib/nnc/cmd/util/ccv_nnc_util_cpu_ref.c:596-664          (gpu: util/gpu/ccv_nnc_util_gpu_ref.cu:13-62)
+//   scalar    lib/nnc/cmd/blas/ccv_nnc_mul_cpu_ref.c:417-430
+#include "common.h"
+
+using namespace nnc;
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+// ---- generic contiguous map: out[i] = f(in0[i], in1[i], in2[i]) ----------------------------------------------
+template <class F, int NIN>
+__global__ void __launch_bounds__(EW_THREADS) ew_map_kernel(F f, float* out, const float* in0, const float* in1, const float* in2, const size_t n4, const size_t n)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	for (size_t i = tid; i < n4; i += stride) {
+		const float4 a = NIN > 0 ? ((const float4*)in0)[i] : make_float4(0, 0, 0, 0);
+		const float4 b = NIN > 1 ? ((const float4*)in1)[i] : make_float4(0, 0, 0, 0);
+		const float4 c = NIN > 2 ? ((const float4*)in2)[i] : make_float4(0, 0, 0, 0);
+		((float4*)out)[i] = make_float4(f(a.x, b.x, c.x), f(a.y, b.y, c.y), f(a.z, b.z, c.z), f(a.w, b.w, c.w));
+	}
+	for (size_t i = n4 * 4 + tid; i < n; i += stride)
+		out[i] = f(NIN > 0 ? in0[i] : 0.f, NIN > 1 ? in1[i] : 0.f, NIN > 2 ? in2[i] : 0.f);
+}
+
+template <class F, int NIN>
+static int ew_map(F f, float* out, const float* in0, const float* in1, const float* in2, size_t n, ccv_nnc_stream_context_t* ctx)
+{
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	const bool vec = aligned16(out) && (NIN < 1 || aligned16(in0)) && (NIN < 2 || aligned16(in1)) && (NIN < 3 || aligned16(in2));
+	const size_t n4 = vec ? n / 4 : 0;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(ew_map_kernel<F, NIN>), dim3(grid_for(vec ? n4 + 3 : n, EW_THREADS)), dim3(EW_THREADS), 0, stream_of(ctx), f, out, in0, in1, in2, n4, n);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+struct OpRelu { __device__ float operator()(float a, float, float) const { return a > 0.f ? a : 0.f; } };                  // 2|x| bytes
+struct OpReluBack { __device__ float operator()(float g, float b, float) const { return b > 0.f ? g : 0.f; } };           // 3|x|
+struct OpReluBackOnes { __device__ float operator()(float b, float, float) const { return b > 0.f ? 1.f : 0.f; } };
+struct OpFill { float v; __device__ float operator()(float, float, float) const { return v; } };                           // |x|
+struct OpScale { float s; __device__ float operator()(float a, float, float) const { return s * a; } };                    // 2|x|
+struct OpAdd2 { __device__ float operator()(float a, float b, float) const { return a + b; } };                            // 3|x|
+struct OpAdd3 { __device__ float operator()(float a, float b, float c) const { return a + b + c; } };
+struct OpCopy { __device__ float operator()(float a, float, float) const { return a; } };
+
+// ---- SGD: n = mu*m + (1-damp)*(scale*g + decay*a); b = a - rate*n   (5|p| bytes: g, a, m in; b, n out) --------
+__global__ void __launch_bounds__(EW_THREADS) sgd_kernel(const float* g, const float* a, const float* m, float* b, float* nm, const size_t n, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const float av = a[i];
+		if (nesterov) {
+			float grad = scale * g[i];
+			const float mom = momentum * m[i] + grad + decay * av;
+			nm[i] = mom;
+			grad += momentum * mom;
+			b[i] = av - rate * grad;
+		} else {
+			const float mom = momentum * m[i] + inv_dampening * (scale * g[i] + decay * av);
+			nm[i] = mom;
+			b[i] = av - rate * mom;
+		}
+	}
+}
+__global__ void __launch_bounds__(EW_THREADS) sgd_kernel_v4(const float4* g, const float4* a, const float4* m, float4* b, float4* nm, const size_t n4, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+		const float4 gv = g[i], av = a[i], mv = m[i];
+		const float gs[4] = { gv.x, gv.y, gv.z, gv.w }, as[4] = { av.x, av.y, av.z, av.w }, ms[4] = { mv.x, mv.y, mv.z, mv.w };
+		float bo[4], no[4];
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			if (nesterov) {
+				float grad = scale * gs[e];
+				const float mom = momentum * ms[e] + grad + decay * as[e];
+				no[e] = mom;
+				grad += momentum * mom;
+				bo[e] = as[e] - rate * grad;
+			} else {
+				const float mom = momentum * ms[e] + inv_dampening * (scale * gs[e] + decay * as[e]);
+				no[e] = mom;
+				bo[e] = as[e] - rate * mom;
+			}
+		}
+		nm[i] = make_float4(no[0], no[1], no[2], no[3]);
+		b[i] = make_float4(bo[0], bo[1], bo[2], bo[3]);
+	}
+}
+
+// ---- column sum: out[c] (+)= sum_r x[r*ld + c].  Stage 1: grid (col tiles of 64, row slices); each wave owns one
+// row phase, lanes = 64 consecutive columns (256-byte coalesced rows); stage 2 folds the slices in fixed order. ------
+constexpr int CS_COLS = 64, CS_PHASES = 4;
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* x, const long rows, const int cols, const long ld, const long rows_per_slice, float* partial)
+{
+	__shared__ float red[CS_PHASES][CS_COLS];
+	const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+	const int c = blockIdx.x * CS_COLS + lane;
+	const long r0 = (long)blockIdx.y * rows_per_slice;
+	long r1 = r0 + rows_per_slice;
+	if (r1 > rows) r1 = rows;
+	float s = 0.f;
+	if (c < cols)
+		for (long r = r0 + phase; r < r1; r += CS_PHASES) s += x[r * ld + c];
+	red[phase][lane] = s;
+	__syncthreads();
+	if (phase == 0 && c < cols) partial[(long)blockIdx.y * cols + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* partial, const int slices, const int cols, float* out, const int accumulate)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= cols) return;
+	float s = 0.f;
+	for (int i = 0; i < slices; i++) s += partial[(long)i * cols + c];
+	out[c] = accumulate ? out[c] + s : s;
+}
+
+static int _relu_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* a = inputs[0];
+	ccv_nnc_tensor_t* b = outputs[0];
+	if (!tensor_contiguous(a) || !tensor_contiguous(b) || tensor_count(a->info) != tensor_count(b->info)) return CCV_NNC_EXEC_INVALID;
+	return ew_map<OpRelu, 1>(OpRelu(), b->data.f32, a->data.f32, 0, 0, tensor_count(a->info), stream_context);
+}
+
+static int _relu_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	// inputs (g, a [unused], b); output h = b > 0 ? g : 0; a null g means ones (reference cuDNN path passes ones)
+	if (input_size < 3 || output_size < 1 || !inputs[2] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* g = inputs[0];
+	const ccv_nnc_tensor_t* b = inputs[2];
+	ccv_nnc_tensor_t* h = outputs[0];
+	if ((g && !tensor_contiguous(g)) || !tensor_contiguous(b) || !tensor_contiguous(h)) return CCV_NNC_EXEC_INVALID;
+	const size_t n = tensor_count(b->info);
+	if (tensor_count(h->info) != n || (g && tensor_count(g->info) != n)) return CCV_NNC_EXEC_INVALID;
+	if (!g) return ew_map<OpReluBackOnes, 1>(OpReluBackOnes(), h->data.f32, b->data.f32, 0, 0, n, stream_context);
+	return ew_map<OpReluBack, 2>(OpReluBack(), h->data.f32, g->data.f32, b->data.f32, 0, n, stream_context);
+}
+
+static int _ewsum_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 1 || output_size < 1 || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	ccv_nnc_tensor_t* c = outputs[0];
+	if (CCV_GET_DATA_TYPE(c->info.datatype) != CCV_32F || !tensor_contiguous(c)) return CCV_NNC_EXEC_INVALID;
+	const size_t n = tensor_count(c->info);
+	for (int i = 0; i < input_size; i++)
+		if (!inputs[i] || !tensor_contiguous(inputs[i]) || tensor_count(inputs[i]->info) != n) return CCV_NNC_EXEC_INVALID;
+	float* cp = c->data.f32;
+	// Fold left to right, exactly the association order of the reference: ((in0 + in1) + in2) + ...
+	if (input_size == 1) {
+		if (inputs[0]->data.f32 == cp) return CCV_NNC_EXEC_SUCCESS;
+		return ew_map<OpCopy, 1>(OpCopy(), cp, inputs[0]->data.f32, 0, 0, n, stream_context);
+	}
+	int ret, i = 0;
+	if (input_size >= 3) { ret = ew_map<OpAdd3, 3>(OpAdd3(), cp, inputs[0]->data.f32, inputs[1]->data.f32, inputs[2]->data.f32, n, stream_context); i = 3; }
+	else { ret = ew_map<OpAdd2, 2>(OpAdd2(), cp, inputs[0]->data.f32, inputs[1]->data.f32, 0, n, stream_context); i = 2; }
+	for (; ret == CCV_NNC_EXEC_SUCCESS && i < input_size; ) {
+		if (i + 1 < input_size) { ret = ew_map<OpAdd3, 3>(OpAdd3(), cp, cp, inputs[i]->data.f32, inputs[i + 1]->data.f32, n, stream_context); i += 2; }
+		else { ret = ew_map<OpAdd2, 2>(OpAdd2(), cp, cp, inputs[i]->data.f32, 0, n, stream_context); i += 1; }
+	}
+	return ret;
+}
+
+static int _ewsum_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	// D[x + y + z, x] = 1: every output gradient is a copy of g (or ones when g is null). ew_cpu_ref.c:216-233
+	int ret = CCV_NNC_EXEC_SUCCESS;
+	const ccv_nnc_tensor_t* g = input_size > 0 ? inputs[0] : 0;
+	for (int i = 0; i < output_size && ret == CCV_NNC_EXEC_SUCCESS; i++) {
+		ccv_nnc_tensor_t* o = outputs[i];
+		if (!o) continue;
+		if (!tensor_contiguous(o)) return CCV_NNC_EXEC_INVALID;
+		const size_t n = tensor_count(o->info);
+		if (!g) { OpFill f; f.v = 1.f; ret = ew_map<OpFill, 0>(f, o->data.f32, 0, 0, 0, n, stream_context); }
+		else if (g->data.f32 != o->data.f32) {
+			if (!tensor_contiguous(g) || tensor_count(g->info) != n) return CCV_NNC_EXEC_INVALID;
+			ret = ew_map<OpCopy, 1>(OpCopy(), o->data.f32, g->data.f32, 0, 0, n, stream_context);
+		}
+	}
+	return ret;
+}
+
+static int _scalar_mul_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	if (!tensor_contiguous(inputs[0]) || !tensor_contiguous(outputs[0]) || tensor_count(inputs[0]->info) != tensor_count(outputs[0]->info)) return CCV_NNC_EXEC_INVALID;
+	OpScale f; f.s = cmd.info.blas.a[0];
+	return ew_map<OpScale, 1>(f, outputs[0]->data.f32, inputs[0]->data.f32, 0, 0, tensor_count(inputs[0]->info), stream_context);
+}
+
+static int _scalar_mul_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (output_size < 1 || !outputs[0] || !tensor_contiguous(outputs[0])) return CCV_NNC_EXEC_INVALID;
+	const size_t n = tensor_count(outputs[0]->info);
+	if (input_size > 0 && inputs[0]) {
+		if (!tensor_contiguous(inputs[0]) || tensor_count(inputs[0]->info) != n) return CCV_NNC_EXEC_INVALID;
+		OpScale f; f.s = cmd.info.blas.a[0];
+		return ew_map<OpScale, 1>(f, outputs[0]->data.f32, inputs[0]->data.f32, 0, 0, n, stream_context);
+	}
+	OpFill f; f.v = cmd.info.blas.a[0];
+	return ew_map<OpFill, 0>(f, outputs[0]->data.f32, 0, 0, 0, n, stream_context);
+}
+
+static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size != 3 || output_size != 2) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* g = inputs[0];
+	const ccv_nnc_tensor_t* a = inputs[1];
+	const ccv_nnc_tensor_t* m = inputs[2];
+	ccv_nnc_tensor_t* b = outputs[0];
+	ccv_nnc_tensor_t* n = outputs[1];
+	if (!g || !a || !m || !b || !n) return CCV_NNC_EXEC_INVALID;
+	if (!tensor_contiguous(g) || !tensor_contiguous(a) || !tensor_contiguous(m) || !tensor_contiguous(b) || !tensor_contiguous(n)) return CCV_NNC_EXEC_INVALID;
+	const size_t cnt = tensor_count(a->info);
+	if (tensor_count(g->info) != cnt || tensor_count(m->info) != cnt || tensor_count(b->info) != cnt || tensor_count(n->info) != cnt) return CCV_NNC_EXEC_INVALID;
+	if (cmd.info.sgd.nesterov && cmd.info.sgd.dampening != 0) return CCV_NNC_EXEC_INVALID;
+	if (cnt == 0) return CCV_NNC_EXEC_SUCCESS;
+	const float inv_dampening = 1 - cmd.info.sgd.dampening;
+	hipStream_t stream = stream_of(stream_context);
+	const bool vec = (cnt % 4 == 0) && aligned16(g->data.f32) && aligned16(a->data.f32) && aligned16(m->data.f32) && aligned16(b->data.f32) && aligned16(n->data.f32);
+	if (vec)
+		hipLaunchKernelGGL(sgd_kernel_v4, dim3(grid_for(cnt / 4, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float4*)g->data.f32, (const float4*)a->data.f32, (const float4*)m->data.f32, (float4*)b->data.f32, (float4*)n->data.f32, cnt / 4, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
+	else
+		hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(cnt, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)g->data.f32, (const float*)a->data.f32, (const float*)m->data.f32, b->data.f32, n->data.f32, cnt, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static int _set_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	for (int i = 0; i < output_size; i++) {
+		ccv_nnc_tensor_t* o = outputs[i];
+		if (!o) continue;
+		if (!tensor_contiguous(o)) return CCV_NNC_EXEC_INVALID;
+		const size_t n = tensor_count(o->info);
+		const int dt = CCV_GET_DATA_TYPE(o->info.datatype);
+		if (cmd.info.blas.a[0] == 0) { HIP_ENFORCE(hipMemsetAsync(o->data.u8, 0, n * datatype_size(dt), stream_of(stream_context))); continue; }
+		if (dt == CCV_32F) { const int r = fill_f32(o->data.f32, n, cmd.info.blas.a[0], stream_context); if (r) return r; }
+		else if (dt == CCV_32S) { union { int i; float f; } u; u.i = (int)cmd.info.blas.a[0]; const int r = fill_f32(o->data.f32, n, u.f, stream_context); if (r) return r; }
+		else return CCV_NNC_EXEC_INVALID;
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static int _set_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	for (int i = 0; i < output_size; i++) {
+		ccv_nnc_tensor_t* o = outputs[i];
+		if (!o) continue;
+		if (!tensor_contiguous(o)) return CCV_NNC_EXEC_INVALID;
+		HIP_ENFORCE(hipMemsetAsync(o->data.u8, 0, tensor_count(o->info) * datatype_size(o->info.datatype), stream_of(stream_context)));
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static int _data_transfer(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	const int cnt = input_size < output_size ? input_size : output_size;
+	for (int i = 0; i < cnt; i++) {
+		const ccv_nnc_tensor_t* a = inputs[i];
+		ccv_nnc_tensor_t* b = outputs[i];
+		if (!a || !b || a == b) continue;
+		if (!tensor_contiguous(a) || !tensor_contiguous(b) || tensor_count(a->info) != tensor_count(b->info)) return CCV_NNC_EXEC_INVALID;
+		if (datatype_size(a->info.datatype) != datatype_size(b->info.datatype)) return CCV_NNC_EXEC_INVALID;
+		const size_t size = tensor_count(a->info) * datatype_size(a->info.datatype);
+		const int am = CCV_TENSOR_GET_MEMORY(a->info.type), bm = CCV_TENSOR_GET_MEMORY(b->info.type);
+		const int da = CCV_TENSOR_GET_DEVICE_ID(a->info.type), db = CCV_TENSOR_GET_DEVICE_ID(b->info.type);
+		if (stream_context) {
+			hipStream_t stream = stream_of(stream_context);
+			if (am == CCV_TENSOR_CPU_MEMORY && bm == CCV_TENSOR_GPU_MEMORY) HIP_ENFORCE(hipMemcpyAsync(b->data.u8, a->data.u8, size, hipMemcpyHostToDevice, stream));
+			else if (am == CCV_TENSOR_GPU_MEMORY && bm == CCV_TENSOR_CPU_MEMORY) HIP_ENFORCE(hipMemcpyAsync(b->data.u8, a->data.u8, size, hipMemcpyDeviceToHost, stream));
+			else if (am == CCV_TENSOR_CPU_MEMORY && bm == CCV_TENSOR_CPU_MEMORY) HIP_ENFORCE(hipMemcpyAsync(b->data.u8, a->data.u8, size, hipMemcpyHostToHost, stream));
+			else if (da == db) HIP_ENFORCE(hipMemcpyAsync(b->data.u8, a->data.u8, size, hipMemcpyDeviceToDevice, stream));
+			else HIP_ENFORCE(hipMemcpyPeerAsync(b->data.u8, db, a->data.u8, da, size, stream));
+		} else
+			nnc_mi355x_memcpy(b->data.u8, b->info.type, a->data.u8, a->info.type, size);
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+} // namespace
+
+namespace nnc {
+
+int fill_f32(float* p, size_t n, float v, ccv_nnc_stream_context_t* ctx)
+{
+	OpFill f; f.v = v;
+	return ew_map<OpFill, 0>(f, p, 0, 0, 0, n, ctx);
+}
+
+int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int accumulate, ccv_nnc_stream_context_t* ctx)
+{
+	if (cols <= 0) return CCV_NNC_EXEC_SUCCESS;
+	hipStream_t stream = stream_of(ctx);
+	const int col_tiles = (cols + CS_COLS - 1) / CS_COLS;
+	long slices = ((long)device_cu_count() * 4 + col_tiles - 1) / col_tiles;
+	const long max_slices = (rows + 63) / 64;
+	if (slices > max_slices) slices = max_slices;
+	if (slices < 1) slices = 1;
+	const long rows_per_slice = (rows + slices - 1) / slices;
+	slices = rows > 0 ? (rows + rows_per_slice - 1) / rows_per_slice : 1;
+	float* partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * cols);
+	if (!partial) return CCV_NNC_EXEC_OOM;
+	hipLaunchKernelGGL(colsum_partial_kernel, dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, x, rows, cols, ld, rows_per_slice > 0 ? rows_per_slice : 1, partial);
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, (const float*)partial, (int)slices, cols, out, accumulate);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+} // namespace nnc
+
+#define NNC_REG(CMD, BACKEND, FORMATS, DATATYPES, MEMORY, EXEC) \
+	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
+	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = (MEMORY); registry->algorithms = 1; registry->exec = EXEC; }
+#define ALL_FORMATS (CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN)
+
+NNC_REG(CCV_NNC_RELU_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _relu_forw)
+NNC_REG(CCV_NNC_RELU_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _relu_back)
+NNC_REG(CCV_NNC_EWSUM_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _ewsum_forw)
+NNC_REG(CCV_NNC_EWSUM_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _ewsum_back)
+NNC_REG(CCV_NNC_SCALAR_MUL_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _scalar_mul_forw)
+NNC_REG(CCV_NNC_SCALAR_MUL_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _scalar_mul_back)
+NNC_REG(CCV_NNC_SGD_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _sgd_forw)
+NNC_REG(CCV_NNC_SET_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_forw)
+NNC_REG(CCV_NNC_SET_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_back)
+NNC_REG(CCV_NNC_DATA_TRANSFER_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
+NNC_REG(CCV_NNC_DATA_TRANSFER_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)

@@ -1,0 +1,199 @@
+// CCV_NNC_MAX_POOL / AVERAGE_POOL FORWARD + BACKWARD on gfx950.  HBM-bound (algorithmic bytes |a| + |b| forward,
+// |g| + |a| + |b| + |h| max-pool backward, |g| + |h| avg-pool backward); one lane per element with the innermost
+// (memory-contiguous) index on consecutive lanes, so every wave touches whole 256-byte rows.
+// The results are BIT-EXACT with the reference CPU backend because each lane replays the oracle's float operation
+// order for its element:
+//   max fwd   lib/nnc/cmd/pool/ccv_nnc_max_pool_cpu_ref.c:13-61    running max over the border-clipped window, raster order
+//   max bwd   lib/nnc/cmd/pool/ccv_nnc_max_pool_cpu_ref.c:63-141   h[p] += g[o] for EVERY p in the window with a[p] == b[o]
+//             (the oracle scatters over outputs in raster order; we gather per input position over the same outputs in
+//              the same raster order, starting from 0 -- the identical addition sequence)
+//   avg fwd   lib/nnc/cmd/pool/ccv_nnc_avg_pool_cpu_ref.c:13-60    sum / (clipped window element count)
+//   avg bwd   lib/nnc/cmd/pool/ccv_nnc_avg_pool_cpu_ref.c:62-109   h[p] += g[o] / count(o)
+// (The CPU oracle only walks image 0 of a batch; on device every image is processed the same way.)
+// Replaces cudnnPoolingForward/Backward of lib/nnc/cmd/pool/gpu/ccv_nnc_{max,avg}_pool_gpu_cudnn.cu.
+#include "common.h"
+
+using namespace nnc;
+
+namespace {
+
+struct pool_geom_t {
+	int N, H, W, C, OH, OW;
+	int kh, kw, sy, sx, pby, pbx;
+	long a_sn, a_sh, a_sw, a_sc; // input-shaped tensors (a, h)
+	long b_sn, b_sh, b_sw, b_sc; // output-shaped tensors (b, g)
+};
+
+// idx -> (n, y, x, c) with the memory-contiguous index fastest.
+template <bool NHWC>
+__device__ __forceinline__ void unflatten(size_t idx, const int d1, const int d2, const int C, int& n, int& y, int& x, int& c)
+{
+	if (NHWC) {
+		c = (int)(idx % C); idx /= C;
+		x = (int)(idx % d2); idx /= d2;
+		y = (int)(idx % d1); n = (int)(idx / d1);
+	} else {
+		x = (int)(idx % d2); idx /= d2;
+		y = (int)(idx % d1); idx /= d1;
+		c = (int)(idx % C); n = (int)(idx / C);
+	}
+}
+
+template <bool NHWC, bool IS_MAX>
+__global__ void __launch_bounds__(256) pool_forw_kernel(const pool_geom_t g, const float* a, float* b, const size_t total)
+{
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		int n, oy, ox, c;
+		unflatten<NHWC>(idx, g.OH, g.OW, g.C, n, oy, ox, c);
+		int y0 = oy * g.sy - g.pby, x0 = ox * g.sx - g.pbx;
+		int y1 = y0 + g.kh, x1 = x0 + g.kw;
+		if (y0 < 0) y0 = 0;
+		if (x0 < 0) x0 = 0;
+		if (y1 > g.H) y1 = g.H;
+		if (x1 > g.W) x1 = g.W;
+		const float* ap = a + n * g.a_sn + c * g.a_sc;
+		float v;
+		if (IS_MAX) {
+			v = ap[y0 * g.a_sh + x0 * g.a_sw];
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++) {
+					const float u = ap[y * g.a_sh + x * g.a_sw];
+					if (u > v) v = u;
+				}
+		} else {
+			v = 0.f;
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++) v += ap[y * g.a_sh + x * g.a_sw];
+			v = v / (float)((y1 - y0) * (x1 - x0));
+		}
+		b[n * g.b_sn + oy * g.b_sh + ox * g.b_sw + c * g.b_sc] = v;
+	}
+}
+
+// ceil(a / b) for b > 0 and any sign of a
+__device__ __forceinline__ int ceil_div(int a, int b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); }
+__device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+template <bool NHWC, bool IS_MAX>
+__global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, const float* gr, const float* a, const float* b, float* h, const size_t total)
+{
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		int n, y, x, c;
+		unflatten<NHWC>(idx, g.H, g.W, g.C, n, y, x, c);
+		int oy0 = ceil_div(y + g.pby - g.kh + 1, g.sy), oy1 = floor_div(y + g.pby, g.sy);
+		int ox0 = ceil_div(x + g.pbx - g.kw + 1, g.sx), ox1 = floor_div(x + g.pbx, g.sx);
+		if (oy0 < 0) oy0 = 0;
+		if (ox0 < 0) ox0 = 0;
+		if (oy1 > g.OH - 1) oy1 = g.OH - 1;
+		if (ox1 > g.OW - 1) ox1 = g.OW - 1;
+		const long ob = n * g.b_sn + c * g.b_sc;
+		float acc = 0.f;
+		float av = 0.f;
+		if (IS_MAX) av = a[n * g.a_sn + y * g.a_sh + x * g.a_sw + c * g.a_sc];
+		for (int oy = oy0; oy <= oy1; oy++)
+			for (int ox = ox0; ox <= ox1; ox++) {
+				const long o = ob + oy * g.b_sh + ox * g.b_sw;
+				if (IS_MAX) {
+					if (av == b[o]) acc += gr[o];
+				} else {
+					int wy0 = oy * g.sy - g.pby, wx0 = ox * g.sx - g.pbx;
+					int wy1 = wy0 + g.kh, wx1 = wx0 + g.kw;
+					if (wy0 < 0) wy0 = 0;
+					if (wx0 < 0) wx0 = 0;
+					if (wy1 > g.H) wy1 = g.H;
+					if (wx1 > g.W) wx1 = g.W;
+					acc += gr[o] / (float)((wy1 - wy0) * (wx1 - wx0));
+				}
+			}
+		h[n * g.a_sn + y * g.a_sh + x * g.a_sw + c * g.a_sc] = acc;
+	}
+}
+
+static bool pool_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, const ccv_nnc_tensor_t* in_like, const ccv_nnc_tensor_t* out_like, pool_geom_t* g, bool* nhwc)
+{
+	Image4 a, b;
+	if (!image4(in_like, &a) || !image4(out_like, &b)) return false;
+	if (in_like->info.format != out_like->info.format) return false;
+	if (a.n != b.n || a.c != b.c) return false;
+	*nhwc = in_like->info.format == CCV_TENSOR_FORMAT_NHWC;
+	g->N = a.n; g->H = a.h; g->W = a.w; g->C = a.c; g->OH = b.h; g->OW = b.w;
+	// a window size of 0 means "the whole map" (global pooling, bin/nnc/imagenet.c:92)
+	g->kh = cmd.info.size.dim[0] > 0 ? cmd.info.size.dim[0] : a.h;
+	g->kw = cmd.info.size.dim[1] > 0 ? cmd.info.size.dim[1] : a.w;
+	g->sy = hint.stride.dim[0] > 0 ? hint.stride.dim[0] : 1;
+	g->sx = hint.stride.dim[1] > 0 ? hint.stride.dim[1] : 1;
+	g->pby = hint.border.begin[0]; g->pbx = hint.border.begin[1];
+	g->a_sn = a.sn; g->a_sh = a.sh; g->a_sw = a.sw; g->a_sc = a.sc;
+	g->b_sn = b.sn; g->b_sh = b.sh; g->b_sw = b.sw; g->b_sc = b.sc;
+	return true;
+}
+
+static bool same_layout(const ccv_nnc_tensor_t* x, const ccv_nnc_tensor_t* like)
+{ // dims and strides equal
+	Image4 a, b;
+	if (!image4(x, &a) || !image4(like, &b) || x->info.format != like->info.format) return false;
+	return a.n == b.n && a.h == b.h && a.w == b.w && a.c == b.c && (a.n == 1 || a.sn == b.sn) && a.sh == b.sh && a.sw == b.sw && a.sc == b.sc;
+}
+
+template <bool IS_MAX>
+static int pool_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	pool_geom_t g;
+	bool nhwc;
+	if (!pool_geometry(cmd, hint, inputs[0], outputs[0], &g, &nhwc)) return CCV_NNC_EXEC_INVALID;
+	const size_t total = (size_t)g.N * g.OH * g.OW * g.C;
+	if (total == 0) return CCV_NNC_EXEC_SUCCESS;
+	hipStream_t stream = stream_of(stream_context);
+	if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, (const float*)inputs[0]->data.f32, outputs[0]->data.f32, total);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, (const float*)inputs[0]->data.f32, outputs[0]->data.f32, total);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+template <bool IS_MAX>
+static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	// max: inputs (g, a, b) -> h ; avg: inputs (g, ...) -> h
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* gt = inputs[0];
+	ccv_nnc_tensor_t* h = outputs[0];
+	const ccv_nnc_tensor_t* a = 0;
+	const ccv_nnc_tensor_t* b = 0;
+	if (IS_MAX) {
+		if (input_size < 3 || !inputs[1] || !inputs[2]) return CCV_NNC_EXEC_INVALID;
+		a = inputs[1]; b = inputs[2];
+		if (!same_layout(a, h) || !same_layout(b, gt)) return CCV_NNC_EXEC_INVALID;
+	}
+	pool_geom_t g;
+	bool nhwc;
+	if (!pool_geometry(cmd, hint, h, gt, &g, &nhwc)) return CCV_NNC_EXEC_INVALID;
+	const size_t total = (size_t)g.N * g.H * g.W * g.C;
+	if (total == 0) return CCV_NNC_EXEC_SUCCESS;
+	hipStream_t stream = stream_of(stream_context);
+	const float* ap = a ? a->data.f32 : 0;
+	const float* bp = b ? b->data.f32 : 0;
+	if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, (const float*)gt->data.f32, ap, bp, h->data.f32, total);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, (const float*)gt->data.f32, ap, bp, h->data.f32, total);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static int _max_pool_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{ return pool_forw<true>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context); }
+static int _max_pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{ return pool_back<true>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context); }
+static int _avg_pool_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{ return pool_forw<false>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context); }
+static int _avg_pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{ return pool_back<false>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context); }
+
+} // namespace
+
+#define NNC_REG(CMD, BACKEND, EXEC) \
+	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
+	{ registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC; registry->tensor_datatypes = CCV_32F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = EXEC; }
+NNC_REG(CCV_NNC_MAX_POOL_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, _max_pool_forw)
+NNC_REG(CCV_NNC_MAX_POOL_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, _max_pool_back)
+NNC_REG(CCV_NNC_AVERAGE_POOL_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, _avg_pool_forw)
+NNC_REG(CCV_NNC_AVERAGE_POOL_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, _avg_pool_back)

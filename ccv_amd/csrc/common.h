@@ -1,0 +1,122 @@
+// Host-side helpers shared by the command implementations (C-style C++, compiled by hipcc).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <assert.h>
+#include "../../include/nnc_mi355x.h"
+
+// Device faults are fatal, exactly like the reference's *_ENFORCE macros (lib/nnc/gpu/ccv_nnc_compat.h:107-135):
+// command exec functions only ever return CCV_NNC_EXEC_* codes.
+#define HIP_ENFORCE(expr) do { \
+	const hipError_t _st = (expr); \
+	if (_st != hipSuccess) { \
+		fprintf(stderr, "[%s:%d]:HIP - Error: %d (%s)\n", __FILE__, __LINE__, (int)_st, hipGetErrorString(_st)); \
+		abort(); \
+	} \
+} while (0)
+
+namespace nnc {
+
+static inline int tensor_nd(const int dim[CCV_NNC_MAX_DIM_ALLOC])
+{ // lib/nnc/ccv_nnc.h:558
+	int i;
+	for (i = 0; i < CCV_NNC_MAX_DIM_ALLOC; i++)
+		if (dim[i] == 0) return i;
+	return CCV_NNC_MAX_DIM_ALLOC;
+}
+static inline size_t tensor_count(const ccv_nnc_tensor_param_t& p)
+{ // lib/nnc/ccv_nnc_easy.h ccv_nnc_tensor_count
+	if (p.dim[0] == 0) return 0;
+	size_t c = 1;
+	for (int i = 0; i < CCV_NNC_MAX_DIM_ALLOC && p.dim[i] > 0; i++) c *= (size_t)p.dim[i];
+	return c;
+}
+static inline size_t datatype_size(int datatype)
+{
+	switch (CCV_GET_DATA_TYPE(datatype)) {
+		case CCV_8U: return 1;
+		case CCV_16F: return 2;
+		case CCV_32S: case CCV_32F: return 4;
+		case CCV_64S: case CCV_64F: return 8;
+	}
+	return 0;
+}
+// Element strides of a tensor or tensor view (lib/nnc/ccv_nnc_easy.h:315 ccv_nnc_tensor_view_get_stride).
+static inline void tensor_strides(const ccv_nnc_tensor_t* t, int stride[CCV_NNC_MAX_DIM_ALLOC])
+{
+	const int nd = tensor_nd(t->info.dim);
+	if (CCV_IS_TENSOR_VIEW(t)) {
+		const ccv_nnc_tensor_view_t* tv = (const ccv_nnc_tensor_view_t*)t;
+		for (int i = 0; i < CCV_NNC_MAX_DIM_ALLOC; i++) stride[i] = i < nd ? tv->stride[i] : 0;
+		return;
+	}
+	int s = 1;
+	for (int i = nd - 1; i >= 0; i--) { stride[i] = s; s *= t->info.dim[i]; }
+	for (int i = nd; i < CCV_NNC_MAX_DIM_ALLOC; i++) stride[i] = 0;
+}
+static inline bool tensor_contiguous(const ccv_nnc_tensor_t* t)
+{
+	if (!CCV_IS_TENSOR_VIEW(t)) return true;
+	int st[CCV_NNC_MAX_DIM_ALLOC];
+	tensor_strides(t, st);
+	const int nd = tensor_nd(t->info.dim);
+	int s = 1;
+	for (int i = nd - 1; i >= 0; i--) { if (t->info.dim[i] != 1 && st[i] != s) return false; s *= t->info.dim[i]; }
+	return true;
+}
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// A 4-d (N, H, W, C) logical view of an image-like tensor in either layout, with element strides.
+struct Image4 {
+	float* p;
+	int n, h, w, c;
+	long sn, sh, sw, sc;
+};
+// 3-d tensors have no batch dimension (lib/nnc/ccv_nnc_internal.h:44-55 ccv_nnc_tensor_hw).
+static inline bool image4(const ccv_nnc_tensor_t* t, Image4* o)
+{
+	const int nd = tensor_nd(t->info.dim);
+	if (nd != 3 && nd != 4) return false;
+	int st[CCV_NNC_MAX_DIM_ALLOC];
+	tensor_strides(t, st);
+	const int* d = t->info.dim;
+	const int b = (nd == 4);
+	o->p = t->data.f32;
+	o->n = b ? d[0] : 1;
+	o->sn = b ? st[0] : 0;
+	if (t->info.format == CCV_TENSOR_FORMAT_NHWC) {
+		o->h = d[b]; o->w = d[b + 1]; o->c = d[b + 2];
+		o->sh = st[b]; o->sw = st[b + 1]; o->sc = st[b + 2];
+	} else if (t->info.format == CCV_TENSOR_FORMAT_NCHW) {
+		o->c = d[b]; o->h = d[b + 1]; o->w = d[b + 2];
+		o->sc = st[b]; o->sh = st[b + 1]; o->sw = st[b + 2];
+	} else
+		return false;
+	return true;
+}
+
+// The HIP stream a command must enqueue on, and that stream's scratch memory.
+hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx);
+void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size);
+int device_cu_count(void);
+void note_kernel(const char* name);
+
+static inline int grid_for(size_t n, int threads)
+{ // memory-bound kernels: grid-stride, capped at 8 workgroups of 256 per CU (cdna guide, Guideline 11)
+	size_t b = (n + threads - 1) / threads;
+	const size_t cap = (size_t)device_cu_count() * 8;
+	if (b > cap) b = cap;
+	if (b < 1) b = 1;
+	return (int)b;
+}
+
+// Shared device helpers (cmd_ew.cpp).
+int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int accumulate, ccv_nnc_stream_context_t* ctx); // out[c] (+)= sum_r x[r*ld + c]
+int fill_f32(float* p, size_t n, float v, ccv_nnc_stream_context_t* ctx);
+
+// Registration table (registry.cpp).
+typedef void (*register_fn_t)(ccv_nnc_cmd_backend_registry_t* const);
+
+} // namespace nnc

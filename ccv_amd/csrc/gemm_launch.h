@@ -1,0 +1,104 @@
+// Host-side launcher for the MFMA contraction template: tile grid, split-K policy, workspace, reduce pass.
+#pragma once
+#include "common.h"
+#include "mfma_gemm.h"
+
+namespace nnc {
+
+struct GemmOut {
+	float* c;
+	long ldm, ldn;
+	const float* bias; // per output column n (may be null)
+	float alpha;
+	int accumulate; // c += result (CCV_NNC_ACCUMULATE_OUTPUT)
+};
+
+// Split the reduction so that a contraction with few output tiles still fills 256 CUs (2 workgroups per CU fit by
+// LDS).  Every slice keeps >= 8 K-steps; slices are multiples of BK so only the last one is ragged.
+static inline int gemm_auto_splits(long tiles, int K)
+{
+	const long target = (long)device_cu_count() * 3;
+	if (tiles >= target) return 1;
+	long s = (target + tiles - 1) / tiles;
+	const long max_s = K / (GEMM_BK * 8);
+	if (s > max_s) s = max_s;
+	if (s > 512) s = 512;
+	return s < 1 ? 1 : (int)s;
+}
+
+// zcount > 1 (batched GEMM / grouped conv): every z applies the given element offsets to A, B, C and bias.
+template <class LA, class LB>
+static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
+	hipStream_t stream = stream_of(ctx);
+	const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+	const long tiles = (long)tiles_m * tiles_n;
+	if (tiles > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
+	if (zcount > 1) splits = 1;
+	int k_per_split = K;
+	if (splits > 1) {
+		k_per_split = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+		splits = (K + k_per_split - 1) / k_per_split;
+	}
+	note_kernel(name);
+	if (K <= 0) splits = 1;
+	if (splits <= 1) {
+		EpiStore epi;
+		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, a_z, b_z, c_z, bias_z);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
+	const long slab = (long)M * N;
+	float* ws = (float*)workspace_of(ctx, sizeof(float) * (size_t)slab * splits);
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	EpiPartial epi;
+	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial>), dim3((unsigned)tiles, (unsigned)splits, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, 0L, 0L, 0L, 0L);
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256)), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.alpha, out.accumulate, M, N);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+} // namespace nnc
+
+namespace nnc {
+
+// One strided matrix operand of a contraction: element(r, k) = p[r * ldr + k * ldk], r in [0,R), k in [0,K).
+struct MatOperand { const float* p; long ldr, ldk; int R, K; };
+
+static inline bool mat_vec_ok(const MatOperand& m, bool kc, long zoff, int zcount)
+{
+	if (!aligned16(m.p)) return false;
+	if (zcount > 1 && zoff % 4) return false;
+	return kc ? (m.K % 4 == 0 && m.ldr % 4 == 0) : (m.R % 4 == 0 && m.ldk % 4 == 0);
+}
+
+// C(m, n) = alpha * sum_k A(m, k) * B(n, k) for arbitrary (unit-stride-in-one-dimension) operands.
+static int gemm_strided(const char* name, const MatOperand A, const MatOperand B, const GemmOut out, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	const int M = A.R, N = B.R, K = A.K;
+	if (B.K != K) return CCV_NNC_EXEC_INVALID;
+	const bool a_kc = (A.ldk == 1 || K == 1), b_kc = (B.ldk == 1 || K == 1);
+	if (!a_kc && A.ldr != 1 && M != 1) return CCV_NNC_EXEC_INVALID;
+	if (!b_kc && B.ldr != 1 && N != 1) return CCV_NNC_EXEC_INVALID;
+	const bool a_vec = mat_vec_ok(A, a_kc, a_z, zcount) && (a_kc ? A.ldk == 1 : A.ldr == 1);
+	const bool b_vec = mat_vec_ok(B, b_kc, b_z, zcount) && (b_kc ? B.ldk == 1 : B.ldr == 1);
+	const bool vec = a_vec && b_vec;
+#define NNC_GEMM_CASE(AKC, BKC, VEC) do { \
+		MatLoader<AKC, VEC> la; la.p = A.p; la.ldr = A.ldr; la.ldk = A.ldk; la.R = M; la.K = K; \
+		MatLoader<BKC, VEC> lb; lb.p = B.p; lb.ldr = B.ldr; lb.ldk = B.ldk; lb.R = N; lb.K = K; \
+		return gemm_run(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, 0, flags, ctx); \
+	} while (0)
+	// A degenerate (length-1) dimension makes both views legal; prefer the vectorisable one.
+	if (a_kc && b_kc) { if (vec) NNC_GEMM_CASE(true, true, true); else NNC_GEMM_CASE(true, true, false); }
+	else if (a_kc && !b_kc) { if (vec) NNC_GEMM_CASE(true, false, true); else NNC_GEMM_CASE(true, false, false); }
+	else if (!a_kc && b_kc) { if (vec) NNC_GEMM_CASE(false, true, true); else NNC_GEMM_CASE(false, true, false); }
+	else { if (vec) NNC_GEMM_CASE(false, false, true); else NNC_GEMM_CASE(false, false, false); }
+#undef NNC_GEMM_CASE
+}
+
+} // namespace nnc

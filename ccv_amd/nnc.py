@@ -1,0 +1,491 @@
+"""ctypes mirror of the nnc plugin surface (struct layouts: include/nnc_mi355x.h; reference: lib/nnc/ccv_nnc.h,
+lib/nnc/ccv_nnc_tfb.h) and of the command builders in lib/nnc/cmd/ccv_nnc_cmd_easy.h.
+
+The same structs drive three libraries through the same call signature
+(ccv_nnc_cmd_exec, lib/nnc/ccv_nnc_cmd.c:651):
+  * libnnc_mi355x.so          -- the product (entry point nnc_mi355x_cmd_exec)
+  * oracle/_ref/libccv_ref.so -- the reference's own CPU backend (tests only; entry point ccv_nnc_cmd_exec)
+  * tests/emu/_build/libnnc_mi355x_emu.so -- the product sources on the CPU HIP emulator (tests only)
+"""
+import ctypes as C
+import os
+import numpy as np
+
+MAX_DIM_ALLOC = 12
+
+# ---- constants (include/nnc_mi355x.h) -------------------------------------------------------------------------
+NCHW, NHWC, CHWN = 0x01, 0x02, 0x04
+CPU_MEMORY, GPU_MEMORY = 0x1, 0x2
+TENSOR_VIEW = 0x01000000
+CCV_8U, CCV_32S, CCV_32F, CCV_64S, CCV_64F, CCV_16F = 0x01000, 0x02000, 0x04000, 0x08000, 0x10000, 0x20000
+ACCUMULATE_OUTPUT, ZERO_MEMORY_ALLOC = 0x01, 0x02
+EXEC_SUCCESS, EXEC_INVALID, EXEC_NO_KERNEL, EXEC_OOM = 0, -1, -2, -3
+STREAM_CONTEXT_CPU, STREAM_CONTEXT_GPU = 0x1, 0x2
+NO_BACKEND = 0
+BACKEND_CPU_OPT, BACKEND_CPU_REF = 0x46deb194, 0x3d9883e5
+BACKEND_GPU_CUBLAS, BACKEND_GPU_CUDNN, BACKEND_GPU_NCCL, BACKEND_GPU_REF = 0x9b8cfed, 0x854b679a, 0x7afed9c7, 0x5f19790a
+
+CMD = dict(
+    ADD_FORWARD=0x58fb3664, ADD_BACKWARD=0x58fb3665,
+    AVERAGE_POOL_FORWARD=0x51267ab8, AVERAGE_POOL_BACKWARD=0x51267ab9,
+    BATCH_NORM_FORWARD=0x5419819c, BATCH_NORM_BACKWARD=0x5419819d,
+    CLAMP_FORWARD=0x2640d854, CLAMP_BACKWARD=0x2640d855,
+    COMM_ALLREDUCE_FORWARD=0x75c8d340, COMM_BROADCAST_FORWARD=0x830eee, COMM_REDUCE_FORWARD=0x3434ead8,
+    CONVOLUTION_FORWARD=0x254d05f4, CONVOLUTION_BACKWARD=0x254d05f5,
+    DATATYPE_CONVERSION_FORWARD=0xd873e38c, DATA_TRANSFER_FORWARD=0x12d21e1a, DATA_TRANSFER_BACKWARD=0x12d21e1b,
+    EWDIV_FORWARD=0x1cd2fa18, EWDIV_BACKWARD=0x1cd2fa19, EWEXP_FORWARD=0xd784b170, EWEXP_BACKWARD=0xd784b171,
+    EWLOG_FORWARD=0xf4191bf2, EWLOG_BACKWARD=0xf4191bf3, EWPROD_FORWARD=0xee07e8fe, EWPROD_BACKWARD=0xee07e8ff,
+    EWSQRT_FORWARD=0x8870a61e, EWSQRT_BACKWARD=0x8870a61f, EWSUM_FORWARD=0xe21a2c4c, EWSUM_BACKWARD=0xe21a2c4d,
+    FORMAT_TRANSFORM_FORWARD=0xe4a2b192, FORMAT_TRANSFORM_BACKWARD=0xe4a2b193,
+    GEMM_FORWARD=0x7e87d00c, GEMM_BACKWARD=0x7e87d00d,
+    MAX_POOL_FORWARD=0x7bec9360, MAX_POOL_BACKWARD=0x7bec9361,
+    MUL_FORWARD=0x24721a46, MUL_BACKWARD=0x24721a47,
+    REDUCE_MEAN_FORWARD=0xf23556c6, REDUCE_MEAN_BACKWARD=0xf23556c7,
+    REDUCE_SUM_FORWARD=0x52970f06, REDUCE_SUM_BACKWARD=0x52970f07,
+    RELU_FORWARD=0xc51eaa80, RELU_BACKWARD=0xc51eaa81,
+    SCALAR_MUL_FORWARD=0x8b4d86aa, SCALAR_MUL_BACKWARD=0x8b4d86ab,
+    SET_FORWARD=0x2b070804, SET_BACKWARD=0x2b070805,
+    SGD_FORWARD=0xe650ad26,
+    SOFTMAX_CROSSENTROPY_FORWARD=0xc26b7b5e, SOFTMAX_CROSSENTROPY_BACKWARD=0xc26b7b5f,
+    TRANSPOSE_FORWARD=0xb4d506e0, TRANSPOSE_BACKWARD=0xb4d506e1,
+)
+
+_DT_NP = {CCV_32F: np.float32, CCV_32S: np.int32, CCV_64F: np.float64, CCV_16F: np.float16, CCV_8U: np.uint8, CCV_64S: np.int64}
+_NP_DT = {np.dtype(v): k for k, v in _DT_NP.items()}
+
+
+# ---- struct mirrors -----------------------------------------------------------------------------------------
+class TensorParam(C.Structure):
+    _fields_ = [("type", C.c_int), ("format", C.c_int), ("datatype", C.c_int), ("reserved", C.c_int), ("dim", C.c_int * MAX_DIM_ALLOC)]
+
+
+class TensorStruct(C.Structure):
+    _fields_ = [("type", C.c_int), ("refcount", C.c_int), ("data", C.c_void_p), ("dataof", C.c_long), ("alias_ref", C.c_size_t),
+                ("data_size", C.c_uint64), ("sig", C.c_uint64), ("info", TensorParam)]
+
+
+class TensorViewStruct(C.Structure):
+    _fields_ = TensorStruct._fields_ + [("contiguous", C.c_int), ("off", C.c_long), ("stride", C.c_int * MAX_DIM_ALLOC)]
+
+
+class _Size(C.Structure):
+    _fields_ = [("dim", C.c_int * MAX_DIM_ALLOC)]
+
+
+class _Conv(C.Structure):
+    _fields_ = [("count", C.c_int), ("groups", C.c_int), ("dilation", C.c_int * MAX_DIM_ALLOC)]
+
+
+class _Bnorm(C.Structure):
+    _fields_ = [("axis", C.c_int * MAX_DIM_ALLOC), ("count", C.c_int), ("epsilon", C.c_float), ("is_test", C.c_int), ("momentum", C.c_float)]
+
+
+class _Sgd(C.Structure):
+    _fields_ = [("nesterov", C.c_int), ("rate", C.c_float), ("scale", C.c_float), ("decay", C.c_float), ("momentum", C.c_float), ("dampening", C.c_float)]
+
+
+class _Blas(C.Structure):
+    _fields_ = [("transpose_a", C.c_int * 2), ("transpose_b", C.c_int * 2), ("a", C.c_float * 3), ("flags", C.c_int)]
+
+
+class _LabelSmoothing(C.Structure):
+    _fields_ = [("trim0", C.c_float), ("trim1", C.c_float)]
+
+
+class _Reduce(C.Structure):
+    _fields_ = [("axis", C.c_int * MAX_DIM_ALLOC), ("count", C.c_int)]
+
+
+class _Transpose(C.Structure):
+    _fields_ = [("axis", C.c_int * 2)]
+
+
+class _Clamp(C.Structure):
+    _fields_ = [("min", C.c_float), ("max", C.c_float)]
+
+
+class _CmdUnion(C.Union):
+    _fields_ = [("convolution", _Conv), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
+                ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+
+
+class CmdParam(C.Structure):
+    _anonymous_ = ("u",)
+    _fields_ = [("size", _Size), ("u", _CmdUnion)]
+
+
+class Cmd(C.Structure):
+    _fields_ = [("cmd", C.c_uint32), ("backend", C.c_uint32), ("algorithm", C.c_int), ("info", CmdParam), ("isa", C.c_void_p), ("data", C.c_void_p)]
+
+
+class _Stride(C.Structure):
+    _fields_ = [("dim", C.c_int * MAX_DIM_ALLOC)]
+
+
+class _Border(C.Structure):
+    _fields_ = [("begin", C.c_int * MAX_DIM_ALLOC), ("end", C.c_int * MAX_DIM_ALLOC)]
+
+
+class Hint(C.Structure):
+    _fields_ = [("stride", _Stride), ("border", _Border)]
+
+
+class BackendRegistry(C.Structure):
+    _fields_ = [("tensor_formats", C.c_int), ("tensor_datatypes", C.c_int), ("tensor_memory", C.c_int), ("algorithms", C.c_int),
+                ("exec", C.c_void_p), ("autotune", C.c_void_p), ("aux", C.c_void_p)]
+
+
+assert C.sizeof(TensorParam) == 64 and C.sizeof(TensorStruct) == 112 and C.sizeof(TensorViewStruct) == 176
+assert C.sizeof(CmdParam) == 120 and C.sizeof(Cmd) == 152 and C.sizeof(Hint) == 144 and C.sizeof(BackendRegistry) == 40
+
+NO_HINT = Hint()
+
+
+# ---- command builders (lib/nnc/cmd/ccv_nnc_cmd_easy.h) --------------------------------------------------------
+def _cmd(name, size=(1, 1, 1), backend=NO_BACKEND):
+    c = Cmd()
+    c.cmd = CMD[name]
+    c.backend = backend
+    c.algorithm = -1
+    for i, v in enumerate(size):
+        c.info.size.dim[i] = v
+    return c
+
+
+def CMD_CONVOLUTION_FORWARD(groups, count, *size, dilation=None):
+    c = _cmd("CONVOLUTION_FORWARD", size)
+    c.info.convolution.count, c.info.convolution.groups = count, groups
+    if dilation:
+        c.info.convolution.dilation[0], c.info.convolution.dilation[1] = dilation
+    return c
+
+
+def CMD_CONVOLUTION_BACKWARD(groups, count, *size, dilation=None):
+    c = CMD_CONVOLUTION_FORWARD(groups, count, *size, dilation=dilation)
+    c.cmd = CMD["CONVOLUTION_BACKWARD"]
+    return c
+
+
+def _gemm(name, ta, tb):
+    c = _cmd(name)
+    c.info.blas.a[0] = c.info.blas.a[1] = 1
+    c.info.blas.transpose_a[0], c.info.blas.transpose_a[1] = ta
+    c.info.blas.transpose_b[0], c.info.blas.transpose_b[1] = tb
+    return c
+
+
+NO_TRANSPOSE = (0, 0)
+
+
+def TRANSPOSE(x, y):
+    return (x, y)
+
+
+def CMD_GEMM_FORWARD(ta=NO_TRANSPOSE, tb=NO_TRANSPOSE):
+    return _gemm("GEMM_FORWARD", ta, tb)
+
+
+def CMD_GEMM_BACKWARD(ta=NO_TRANSPOSE, tb=NO_TRANSPOSE):
+    return _gemm("GEMM_BACKWARD", ta, tb)
+
+
+def CMD_MAX_POOL_FORWARD(rows, cols): return _cmd("MAX_POOL_FORWARD", (rows, cols, 1))
+def CMD_MAX_POOL_BACKWARD(rows, cols): return _cmd("MAX_POOL_BACKWARD", (rows, cols, 1))
+def CMD_AVERAGE_POOL_FORWARD(rows, cols): return _cmd("AVERAGE_POOL_FORWARD", (rows, cols, 1))
+def CMD_AVERAGE_POOL_BACKWARD(rows, cols): return _cmd("AVERAGE_POOL_BACKWARD", (rows, cols, 1))
+def CMD_RELU_FORWARD(): return _cmd("RELU_FORWARD", (0, 0, 0))
+def CMD_RELU_BACKWARD(): return _cmd("RELU_BACKWARD", (0, 0, 0))
+def CMD_EWSUM_FORWARD(): return _cmd("EWSUM_FORWARD", (0, 0, 0))
+def CMD_EWSUM_BACKWARD(): return _cmd("EWSUM_BACKWARD", (0, 0, 0))
+def CMD_DATA_TRANSFER_FORWARD(): return _cmd("DATA_TRANSFER_FORWARD", (0, 0, 0))
+def CMD_FORMAT_TRANSFORM_FORWARD(): return _cmd("FORMAT_TRANSFORM_FORWARD", (0, 0, 0))
+
+
+def CMD_SOFTMAX_CROSSENTROPY_FORWARD(trim0=0.0, trim1=1.0):
+    c = _cmd("SOFTMAX_CROSSENTROPY_FORWARD")
+    c.info.label_smoothing.trim0, c.info.label_smoothing.trim1 = trim0, trim1
+    return c
+
+
+def CMD_SOFTMAX_CROSSENTROPY_BACKWARD(trim0=0.0, trim1=1.0):
+    c = CMD_SOFTMAX_CROSSENTROPY_FORWARD(trim0, trim1)
+    c.cmd = CMD["SOFTMAX_CROSSENTROPY_BACKWARD"]
+    return c
+
+
+def CMD_SGD_FORWARD(nesterov, rate, scale, decay, momentum, dampening):
+    c = _cmd("SGD_FORWARD")
+    s = c.info.sgd
+    s.nesterov, s.rate, s.scale, s.decay, s.momentum, s.dampening = nesterov, rate, scale, decay, momentum, dampening
+    return c
+
+
+def _blas_a(name, *a):
+    c = _cmd(name)
+    for i, v in enumerate(a):
+        c.info.blas.a[i] = v
+    return c
+
+
+def CMD_SET_FORWARD(val): return _blas_a("SET_FORWARD", val)
+def CMD_SCALAR_MUL_FORWARD(a): return _blas_a("SCALAR_MUL_FORWARD", a)
+def CMD_SCALAR_MUL_BACKWARD(a): return _blas_a("SCALAR_MUL_BACKWARD", a)
+def CMD_ADD_FORWARD(p, q): return _blas_a("ADD_FORWARD", p, q)
+def CMD_ADD_BACKWARD(p, q): return _blas_a("ADD_BACKWARD", p, q)
+def CMD_MUL_FORWARD(p): return _blas_a("MUL_FORWARD", p)
+def CMD_MUL_BACKWARD(p): return _blas_a("MUL_BACKWARD", p)
+
+
+def CMD_BATCH_NORM_FORWARD(epsilon, is_test, momentum, *axis):
+    c = _cmd("BATCH_NORM_FORWARD")
+    b = c.info.bnorm
+    b.epsilon, b.is_test, b.momentum, b.count = epsilon, is_test, momentum, len(axis)
+    for i, a in enumerate(axis):
+        b.axis[i] = a
+    return c
+
+
+def CMD_BATCH_NORM_BACKWARD(epsilon, is_test, momentum, *axis):
+    c = CMD_BATCH_NORM_FORWARD(epsilon, is_test, momentum, *axis)
+    c.cmd = CMD["BATCH_NORM_BACKWARD"]
+    return c
+
+
+def _reduce(name, *axis):
+    c = _cmd(name)
+    c.info.reduce.count = len(axis)
+    for i, a in enumerate(axis):
+        c.info.reduce.axis[i] = a
+    return c
+
+
+def CMD_REDUCE_SUM_FORWARD(*axis): return _reduce("REDUCE_SUM_FORWARD", *axis)
+def CMD_REDUCE_SUM_BACKWARD(*axis): return _reduce("REDUCE_SUM_BACKWARD", *axis)
+def CMD_REDUCE_MEAN_FORWARD(*axis): return _reduce("REDUCE_MEAN_FORWARD", *axis)
+def CMD_REDUCE_MEAN_BACKWARD(*axis): return _reduce("REDUCE_MEAN_BACKWARD", *axis)
+
+
+def generic_cmd(name, size=(0, 0, 0)):
+    return _cmd(name, size)
+
+
+def HINT(stride=(1, 1), border=(0, 0), border_end=None):
+    """HINT((sy, sx), (by, bx)) as in lib/nnc/ccv_nnc_easy.h."""
+    h = Hint()
+    for i, s in enumerate(stride):
+        h.stride.dim[i] = s
+    for i, b in enumerate(border):
+        h.border.begin[i] = b
+    for i, b in enumerate(border_end if border_end is not None else border):
+        h.border.end[i] = b
+    return h
+
+
+def hint_auto(cmd, a_dim_hw, b_dim_hw):
+    """ccv_nnc_hint_auto (lib/nnc/ccv_nnc_cmd.c:178-217) for the 2 spatial dims: the stride/border mapping a onto b."""
+    h = Hint()
+    for i in range(2):
+        a, b, k = a_dim_hw[i], b_dim_hw[i], cmd.info.size.dim[i]
+        stride = (a + b // 2) // b
+        border = (b - 1) * stride - a + k
+        begin = int((border + 1) / 2)  # C division truncates toward zero
+        h.stride.dim[i], h.border.begin[i], h.border.end[i] = stride, begin, border - begin
+    return h
+
+
+# ---- tensors ------------------------------------------------------------------------------------------------
+def tensor_param(memory, fmt, datatype, dims, device=0):
+    p = TensorParam()
+    p.type = memory | (device << 8)
+    p.format, p.datatype = fmt, datatype
+    for i, d in enumerate(dims):
+        p.dim[i] = d
+    return p
+
+
+def CPU_TENSOR_NHWC(datatype, *dims): return tensor_param(CPU_MEMORY, NHWC, datatype, dims)
+def CPU_TENSOR_NCHW(datatype, *dims): return tensor_param(CPU_MEMORY, NCHW, datatype, dims)
+def GPU_TENSOR_NHWC(device, datatype, *dims): return tensor_param(GPU_MEMORY, NHWC, datatype, dims, device)
+def GPU_TENSOR_NCHW(device, datatype, *dims): return tensor_param(GPU_MEMORY, NCHW, datatype, dims, device)
+
+
+def param_dims(p):
+    out = []
+    for i in range(MAX_DIM_ALLOC):
+        if p.dim[i] == 0:
+            break
+        out.append(p.dim[i])
+    return tuple(out)
+
+
+class Tensor:
+    """A ccv_nnc_tensor_t (or tensor view) plus the memory behind it."""
+
+    def __init__(self, lib, params, array=None, view_of=None, strides=None, offset=0):
+        self.lib = lib
+        self.dims = param_dims(params)
+        self.datatype = params.datatype
+        self.np_dtype = np.dtype(_DT_NP[params.datatype & 0xFF000])
+        self.memory = params.type & 0x3
+        self.device = (params.type & 0xfff00) >> 8
+        self.owner = None
+        self._dptr = None
+        if view_of is not None:  # ccv_nnc_tensor_view_new: same memory, explicit element strides
+            self.struct = TensorViewStruct()
+            self.owner = view_of
+            base = view_of.ptr + offset * self.np_dtype.itemsize
+            self.struct.type = params.type | TENSOR_VIEW
+            self.struct.contiguous = 0
+            self.struct.off = offset * self.np_dtype.itemsize
+            for i, s in enumerate(strides):
+                self.struct.stride[i] = s
+            self.struct.data = base
+            self.ptr = base
+        else:
+            self.struct = TensorStruct()
+            n = int(np.prod(self.dims)) if self.dims else 0
+            nbytes = max(n * self.np_dtype.itemsize, 16)
+            self.nbytes = n * self.np_dtype.itemsize
+            if self.memory == CPU_MEMORY:
+                self.array = np.zeros(self.dims, dtype=self.np_dtype) if array is None else np.ascontiguousarray(array, dtype=self.np_dtype).reshape(self.dims)
+                self.ptr = self.array.ctypes.data
+            else:
+                self._dptr = lib.malloc(self.device, (nbytes + 127) & ~127)  # GPU tensors round to 128 B (ccv_nnc_easy.h:238-244)
+                if not self._dptr:
+                    raise MemoryError("device allocation of %d bytes failed" % nbytes)
+                self.ptr = self._dptr
+                if array is not None:
+                    self.upload(array)
+            self.struct.type = params.type
+            self.struct.data = self.ptr
+        self.struct.info = params
+        self.struct.refcount = 1
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array, dtype=self.np_dtype).reshape(self.dims)
+        self.lib.memcpy(self.ptr, GPU_MEMORY | (self.device << 8), a.ctypes.data, CPU_MEMORY, a.nbytes)
+
+    def numpy(self):
+        """Contents as a fresh numpy array (device tensors are copied back, blocking)."""
+        if self.owner is not None:
+            raise ValueError("read the owner tensor of a view")
+        if self.memory == CPU_MEMORY:
+            return self.array.copy()
+        out = np.empty(self.dims, dtype=self.np_dtype)
+        if out.nbytes:
+            self.lib.memcpy(out.ctypes.data, CPU_MEMORY, self.ptr, GPU_MEMORY | (self.device << 8), out.nbytes)
+        return out
+
+    def view(self, dims, strides, offset=0, fmt=None):
+        p = TensorParam()
+        C.memmove(C.byref(p), C.byref(self.struct.info), C.sizeof(p))
+        for i in range(MAX_DIM_ALLOC):
+            p.dim[i] = dims[i] if i < len(dims) else 0
+        if fmt is not None:
+            p.format = fmt
+        return Tensor(self.lib, p, view_of=self, strides=strides, offset=offset)
+
+    def free(self):
+        if self._dptr:
+            self.lib.free(self.device, self._dptr)
+            self._dptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def c(self):
+        return C.cast(C.pointer(self.struct), C.POINTER(TensorStruct))
+
+
+def _tensor_array(tensors):
+    arr = (C.POINTER(TensorStruct) * max(1, len(tensors)))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.c if t is not None else None
+    return arr
+
+
+class Lib:
+    """A loaded implementation of the command interface."""
+    _EXEC_ARGS = [Cmd, Hint, C.c_int, C.POINTER(C.POINTER(TensorStruct)), C.c_int, C.POINTER(C.POINTER(TensorStruct)), C.c_int, C.c_void_p]
+
+    def __init__(self, path, kind):
+        self.path, self.kind = path, kind
+        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        d = self.dll
+        if kind == "reference":
+            d.ccv_nnc_init()
+            self._exec = d.ccv_nnc_cmd_exec
+        else:
+            self._exec = d.nnc_mi355x_cmd_exec
+            d.nnc_mi355x_malloc.restype = C.c_void_p
+            d.nnc_mi355x_malloc.argtypes = [C.c_int, C.c_size_t]
+            d.nnc_mi355x_free.argtypes = [C.c_int, C.c_void_p]
+            d.nnc_mi355x_memcpy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t]
+            d.nnc_mi355x_stream_context_new.restype = C.c_void_p
+            d.nnc_mi355x_stream_context_new.argtypes = [C.c_int]
+            d.nnc_mi355x_stream_context_free.argtypes = [C.c_void_p]
+            d.nnc_mi355x_stream_context_wait.argtypes = [C.c_void_p]
+            d.nnc_mi355x_event_new.restype = C.c_void_p
+            d.nnc_mi355x_event_record.argtypes = [C.c_void_p, C.c_void_p]
+            d.nnc_mi355x_event_elapsed_ms.restype = C.c_float
+            d.nnc_mi355x_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p]
+            d.nnc_mi355x_event_free.argtypes = [C.c_void_p]
+            d.nnc_mi355x_last_kernel_name.restype = C.c_char_p
+            d.nnc_mi355x_registry_name.restype = C.c_char_p
+            d.nnc_mi355x_registry_get.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(BackendRegistry)]
+            d.nnc_mi355x_cmd_ok.argtypes = [C.c_uint32, C.c_uint32]
+            d.nnc_mi355x_version.restype = C.c_char_p
+        self._exec.restype = C.c_int
+        self._exec.argtypes = self._EXEC_ARGS
+
+    # device runtime (product / emulator only)
+    def malloc(self, device, size): return self.dll.nnc_mi355x_malloc(device, size)
+    def free(self, device, ptr): self.dll.nnc_mi355x_free(device, ptr)
+    def memcpy(self, dst, dst_type, src, src_type, n): self.dll.nnc_mi355x_memcpy(dst, dst_type, src, src_type, n)
+    def device_count(self): return self.dll.nnc_mi355x_device_count()
+    def set_device(self, d): self.dll.nnc_mi355x_set_device(d)
+    def stream_new(self, device=0): return self.dll.nnc_mi355x_stream_context_new(STREAM_CONTEXT_GPU | (device << 8))
+    def stream_free(self, s): self.dll.nnc_mi355x_stream_context_free(s)
+    def stream_wait(self, s): self.dll.nnc_mi355x_stream_context_wait(s)
+    def cmd_ok(self, cmd, backend): return bool(self.dll.nnc_mi355x_cmd_ok(cmd, backend))
+
+    def registry(self):
+        rows = []
+        for i in range(self.dll.nnc_mi355x_registry_count()):
+            c, b, r = C.c_uint32(), C.c_uint32(), BackendRegistry()
+            self.dll.nnc_mi355x_registry_get(i, C.byref(c), C.byref(b), C.byref(r))
+            rows.append((self.dll.nnc_mi355x_registry_name(i).decode(), c.value, b.value, r))
+        return rows
+
+    def tensor(self, params, array=None):
+        return Tensor(self, params, array)
+
+    def cmd_exec(self, cmd, hint, flags, inputs, outputs, stream=None):
+        """ccv_nnc_cmd_exec(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context)."""
+        ia, oa = _tensor_array(inputs), _tensor_array(outputs)
+        return self._exec(cmd, hint, flags, ia, len(inputs), oa, len(outputs), stream)
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnnc_mi355x.so")
+_lib = None
+
+
+def load(path=None):
+    """Load the MI355X backend.  Fails loudly (no CPU fallback) when the HIP library or a GPU is missing."""
+    global _lib
+    if path is None and _lib is not None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("libnnc_mi355x.so not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % p)
+    lib = Lib(p, "mi355x")
+    if path is None:
+        if lib.device_count() <= 0:
+            raise RuntimeError("libnnc_mi355x.so loaded but no HIP device is visible; this backend has no CPU fallback")
+        _lib = lib
+    return lib

@@ -1,0 +1,310 @@
+/*
+ * nnc_mi355x.h -- C-ABI of libnnc_mi355x.so, the MI355X (gfx950) compute backend for
+ * ccv's nnc tensor engine.
+ *
+ * This header is the DROP-IN BOUNDARY.  It declares, in plain C (no HIP, no torch types):
+ *
+ *   1. ABI mirrors of the reference's plugin-surface structs.  They are re-stated here
+ *      (field order / sizes identical, only the members this path touches are named) so the
+ *      library builds without the reference tree.  tests/test_abi_layout.py compiles a
+ *      sizeof/offsetof probe against the real headers whenever /root/reference is present.
+ *        ccv_nnc_tensor_param_t / ccv_nnc_tensor_t / ccv_nnc_tensor_view_t
+ *                                         <- lib/nnc/ccv_nnc_tfb.h:79-111
+ *        ccv_nnc_cmd_param_t / ccv_nnc_hint_t / ccv_nnc_cmd_t / exec_f / autotune_f
+ *                                         <- lib/nnc/ccv_nnc.h:111-323
+ *        ccv_nnc_cmd_backend_registry_t   <- lib/nnc/ccv_nnc_internal.h:34-42
+ *        ccv_nnc_stream_context_s / ccv_nnc_stream_signal_s (base part the host allocates)
+ *                                         <- lib/nnc/_ccv_nnc_stream.h:17-46
+ *
+ *   2. The backend registration entry points.  The reference host calls one function per
+ *      (command, backend slot) from its generated _ccv_nnc_cmd_init()
+ *      (lib/nnc/cmd/ccv_nnc_cmd.inc:464-, :944-).  The slot names (GPU_REF / GPU_CUDNN /
+ *      GPU_CUBLAS / GPU_NCCL) are the reference registry's names for "the GPU backends";
+ *      nothing from those vendor libraries is used: every exec function launches a
+ *      hand-written gfx950 HIP kernel from this library.
+ *
+ *   3. The device "compat" ABI the unmodified host .c files call for memory, streams,
+ *      events and workspace (lib/nnc/gpu/ccv_nnc_compat.h:23-59).  Native names are
+ *      nnc_mi355x_*; the reference-spelled aliases (cumalloc, ...) live in
+ *      ccv_amd/csrc/ref_abi_aliases.cpp and simply forward.
+ *
+ *   4. A standalone dispatch (nnc_mi355x_cmd_exec) mirroring ccv_nnc_cmd_exec
+ *      (lib/nnc/ccv_nnc_cmd.c:651-693) for callers that do not link the reference host
+ *      (our tests, bench.py, smoke()).
+ */
+#ifndef NNC_MI355X_H
+#define NNC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/types.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ constants ---- */
+/* lib/nnc/ccv_nnc_tfb.h:26-58 */
+enum { CCV_TENSOR_FORMAT_NCHW = 0x01, CCV_TENSOR_FORMAT_NHWC = 0x02, CCV_TENSOR_FORMAT_CHWN = 0x04 };
+enum { CCV_TENSOR_CPU_MEMORY = 0x1, CCV_TENSOR_GPU_MEMORY = 0x2 };
+enum { CCV_COMPUTE_DEVICE_ANY = 0xfff00 };
+#define CCV_TENSOR_GET_MEMORY(type) ((type) & 0x3)
+#define CCV_TENSOR_GET_DEVICE(type) ((type) & 0xfff00)
+#define CCV_TENSOR_GET_DEVICE_ID(type) (CCV_TENSOR_GET_DEVICE(type) >> 8)
+enum { CCV_TENSOR_VIEW = 0x01000000, CCV_TENSOR_MULTIVIEW = 0x02000000, CCV_TENSOR_PINNED_MEM = 0x04000000 };
+/* lib/ccv.h:46-52,73 */
+enum { CCV_8U = 0x01000, CCV_32S = 0x02000, CCV_32F = 0x04000, CCV_64S = 0x08000, CCV_64F = 0x10000, CCV_16F = 0x20000, CCV_QX = 0x40000 };
+#define CCV_GET_DATA_TYPE(x) ((x) & 0xFF000)
+/* lib/nnc/ccv_nnc.h:69-79 */
+enum { CCV_NNC_ACCUMULATE_OUTPUT = 0x01, CCV_NNC_ZERO_MEMORY_ALLOC = 0x02 };
+enum { CCV_NNC_EXEC_SUCCESS = 0, CCV_NNC_EXEC_INVALID = -1, CCV_NNC_EXEC_NO_KERNEL = -2, CCV_NNC_EXEC_OOM = -3 };
+/* lib/nnc/ccv_nnc.h:928-933 */
+enum { CCV_STREAM_CONTEXT_CPU = 0x1, CCV_STREAM_CONTEXT_GPU = 0x2 };
+#define CCV_STREAM_GET_CONTEXT(type) ((type) & 0x3)
+#define CCV_STREAM_GET_DEVICE_ID(type) CCV_TENSOR_GET_DEVICE_ID(type)
+
+#define CCV_NNC_MAX_DIM_ALLOC (12)
+#define CCV_NNC_MAX_DIM (2)
+
+/* Command ids on this path (lib/nnc/cmd/ccv_nnc_cmd.h; SHA-256 prefixes, must not change). */
+enum {
+	CCV_NNC_NOOP = 0,
+	CCV_NNC_ADD_FORWARD = 0x58fb3664, CCV_NNC_ADD_BACKWARD = 0x58fb3665,
+	CCV_NNC_AVERAGE_POOL_FORWARD = 0x51267ab8, CCV_NNC_AVERAGE_POOL_BACKWARD = 0x51267ab9,
+	CCV_NNC_BATCH_NORM_FORWARD = 0x5419819c, CCV_NNC_BATCH_NORM_BACKWARD = 0x5419819d,
+	CCV_NNC_CLAMP_FORWARD = 0x2640d854, CCV_NNC_CLAMP_BACKWARD = 0x2640d855,
+	CCV_NNC_COMM_ALLREDUCE_FORWARD = 0x75c8d340, CCV_NNC_COMM_ALLREDUCE_BACKWARD = 0x75c8d341,
+	CCV_NNC_COMM_BROADCAST_FORWARD = 0x830eee, CCV_NNC_COMM_BROADCAST_BACKWARD = 0x830eef,
+	CCV_NNC_COMM_REDUCE_FORWARD = 0x3434ead8, CCV_NNC_COMM_REDUCE_BACKWARD = 0x3434ead9,
+	CCV_NNC_CONVOLUTION_FORWARD = 0x254d05f4, CCV_NNC_CONVOLUTION_BACKWARD = 0x254d05f5,
+	CCV_NNC_DATATYPE_CONVERSION_FORWARD = 0xd873e38c, CCV_NNC_DATATYPE_CONVERSION_BACKWARD = 0xd873e38d,
+	CCV_NNC_DATA_TRANSFER_FORWARD = 0x12d21e1a, CCV_NNC_DATA_TRANSFER_BACKWARD = 0x12d21e1b,
+	CCV_NNC_DROPOUT_FORWARD = 0x7f2dc3e4, CCV_NNC_DROPOUT_BACKWARD = 0x7f2dc3e5,
+	CCV_NNC_EWDIV_FORWARD = 0x1cd2fa18, CCV_NNC_EWDIV_BACKWARD = 0x1cd2fa19,
+	CCV_NNC_EWEXP_FORWARD = 0xd784b170, CCV_NNC_EWEXP_BACKWARD = 0xd784b171,
+	CCV_NNC_EWLOG_FORWARD = 0xf4191bf2, CCV_NNC_EWLOG_BACKWARD = 0xf4191bf3,
+	CCV_NNC_EWPROD_FORWARD = 0xee07e8fe, CCV_NNC_EWPROD_BACKWARD = 0xee07e8ff,
+	CCV_NNC_EWSQRT_FORWARD = 0x8870a61e, CCV_NNC_EWSQRT_BACKWARD = 0x8870a61f,
+	CCV_NNC_EWSUM_FORWARD = 0xe21a2c4c, CCV_NNC_EWSUM_BACKWARD = 0xe21a2c4d,
+	CCV_NNC_FORMAT_TRANSFORM_FORWARD = 0xe4a2b192, CCV_NNC_FORMAT_TRANSFORM_BACKWARD = 0xe4a2b193,
+	CCV_NNC_GEMM_FORWARD = 0x7e87d00c, CCV_NNC_GEMM_BACKWARD = 0x7e87d00d,
+	CCV_NNC_MAX_POOL_FORWARD = 0x7bec9360, CCV_NNC_MAX_POOL_BACKWARD = 0x7bec9361,
+	CCV_NNC_MUL_FORWARD = 0x24721a46, CCV_NNC_MUL_BACKWARD = 0x24721a47,
+	CCV_NNC_REDUCE_MEAN_FORWARD = 0xf23556c6, CCV_NNC_REDUCE_MEAN_BACKWARD = 0xf23556c7,
+	CCV_NNC_REDUCE_SUM_FORWARD = 0x52970f06, CCV_NNC_REDUCE_SUM_BACKWARD = 0x52970f07,
+	CCV_NNC_RELU_FORWARD = 0xc51eaa80, CCV_NNC_RELU_BACKWARD = 0xc51eaa81,
+	CCV_NNC_SCALAR_MUL_FORWARD = 0x8b4d86aa, CCV_NNC_SCALAR_MUL_BACKWARD = 0x8b4d86ab,
+	CCV_NNC_SET_FORWARD = 0x2b070804, CCV_NNC_SET_BACKWARD = 0x2b070805,
+	CCV_NNC_SGD_FORWARD = 0xe650ad26, CCV_NNC_SGD_BACKWARD = 0xe650ad27,
+	CCV_NNC_SOFTMAX_CROSSENTROPY_FORWARD = 0xc26b7b5e, CCV_NNC_SOFTMAX_CROSSENTROPY_BACKWARD = 0xc26b7b5f,
+	CCV_NNC_TRANSPOSE_FORWARD = 0xb4d506e0, CCV_NNC_TRANSPOSE_BACKWARD = 0xb4d506e1,
+};
+
+/* Backend slot ids (lib/nnc/cmd/ccv_nnc_backend.h). */
+enum {
+	CCV_NNC_NO_BACKEND = 0,
+	CCV_NNC_BACKEND_CPU_OPT = 0x46deb194,
+	CCV_NNC_BACKEND_CPU_REF = 0x3d9883e5,
+	CCV_NNC_BACKEND_GPU_CUBLAS = 0x9b8cfed,
+	CCV_NNC_BACKEND_GPU_CUDNN = 0x854b679a,
+	CCV_NNC_BACKEND_GPU_NCCL = 0x7afed9c7,
+	CCV_NNC_BACKEND_GPU_REF = 0x5f19790a,
+	CCV_NNC_BACKEND_MPS = 0xb2f325e2,
+};
+
+/* ---------------------------------------------------------------- ABI mirrors ---- */
+typedef struct { short v; } ccv_float16_t;
+
+typedef union ccv_numeric_data_u {
+	char* i8;
+	unsigned char* u8;
+	int* i32;
+	ccv_float16_t* f16;
+	float* f32;
+	int64_t* i64;
+	uint64_t* u64;
+	double* f64;
+	void* ptr;
+} ccv_numeric_data_t;
+
+typedef struct { /* 64 bytes */
+	int type;     /* memory | device id << 8 */
+	int format;   /* CCV_TENSOR_FORMAT_* */
+	int datatype; /* CCV_32F ... */
+	int reserved;
+	int dim[CCV_NNC_MAX_DIM_ALLOC]; /* zero terminated */
+} ccv_nnc_tensor_param_t;
+
+typedef struct { /* 112 bytes */
+	int type;
+	int refcount;
+	ccv_numeric_data_t data; /* raw device pointer for GPU tensors */
+	off_t dataof;
+	uintptr_t alias_ref;
+	uint64_t data_size;
+	uint64_t sig;
+	ccv_nnc_tensor_param_t info;
+} ccv_nnc_tensor_t;
+
+typedef struct { /* 176 bytes; valid when (type & CCV_TENSOR_VIEW) */
+	int type;
+	int refcount;
+	ccv_numeric_data_t data;
+	off_t dataof;
+	uintptr_t alias_ref;
+	uint64_t data_size;
+	uint64_t sig;
+	ccv_nnc_tensor_param_t info;
+	int contiguous;
+	off_t off;
+	int stride[CCV_NNC_MAX_DIM_ALLOC]; /* in elements */
+} ccv_nnc_tensor_view_t;
+
+#define CCV_IS_TENSOR_VIEW(x) ((*(const int*)(x)) & CCV_TENSOR_VIEW)
+#define CCV_IS_TENSOR_CONTIGUOUS(x) (!CCV_IS_TENSOR_VIEW(x) || (((const ccv_nnc_tensor_view_t*)(x))->contiguous == 1))
+
+typedef struct { /* 120 bytes */
+	struct { int dim[CCV_NNC_MAX_DIM_ALLOC]; } size;
+	union {
+		struct { int count; int groups; int dilation[CCV_NNC_MAX_DIM_ALLOC]; } convolution;
+		struct { int reserved; } pool;
+		struct { int axis[CCV_NNC_MAX_DIM_ALLOC]; int count; float epsilon; int is_test; float momentum; } bnorm;
+		struct { int nesterov; float rate; float scale; float decay; float momentum; float dampening; } sgd;
+		struct { int transpose_a[2]; int transpose_b[2]; float a[3]; int flags; } blas;
+		struct { float trim0; float trim1; } label_smoothing;
+		struct { int axis[CCV_NNC_MAX_DIM_ALLOC]; int count; } reduce;
+		struct { int axis[2]; } transpose;
+		struct { float p; int entirety; } dropout;
+		struct { float min; float max; } clamp;
+		char _widest[68]; /* gnorm is the widest member in the reference (68 B) */
+		void* userdata;
+	};
+} ccv_nnc_cmd_param_t;
+
+typedef struct { /* 144 bytes */
+	struct { int dim[CCV_NNC_MAX_DIM_ALLOC]; } stride;
+	struct { int begin[CCV_NNC_MAX_DIM_ALLOC]; int end[CCV_NNC_MAX_DIM_ALLOC]; } border;
+} ccv_nnc_hint_t;
+
+typedef struct ccv_nnc_stream_context_s ccv_nnc_stream_context_t;
+typedef struct ccv_nnc_stream_signal_s ccv_nnc_stream_signal_t;
+typedef struct ccv_nnc_cmd_vtab_s ccv_nnc_cmd_vtab_t;
+
+typedef struct ccv_nnc_cmd_s { /* 152 bytes */
+	uint32_t cmd;
+	uint32_t backend;
+	int algorithm;
+	ccv_nnc_cmd_param_t info;
+	ccv_nnc_cmd_vtab_t* isa;
+	void* data;
+} ccv_nnc_cmd_t;
+
+typedef int (*ccv_nnc_cmd_exec_f)(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
+typedef int (*ccv_nnc_cmd_autotune_f)(const ccv_nnc_cmd_t cmd, const size_t max_workspace_size, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
+
+typedef struct { /* 40 bytes */
+	int tensor_formats;
+	int tensor_datatypes;
+	int tensor_memory;
+	int algorithms;
+	ccv_nnc_cmd_exec_f exec;
+	ccv_nnc_cmd_autotune_f autotune;
+	void* aux;
+} ccv_nnc_cmd_backend_registry_t;
+
+/* Base part of a stream context: allocated by the HOST (ccv_nnc_stream_context_new,
+ * lib/nnc/ccv_nnc_stream.c:27-37) and grown in place by nnc_mi355x_init_stream_context().
+ * Only `type` is read by this library; the rest belongs to the host's coroutine scheduler. */
+struct ccv_nnc_stream_context_s { /* 88 bytes */
+	int type;
+	void* _host_private[10];
+};
+struct ccv_nnc_stream_signal_s { /* 16 bytes */
+	int type;
+	ccv_nnc_stream_context_t* emit_context;
+};
+
+typedef void (*ccv_nnc_callback_f)(void* const callback_context); /* lib/nnc/ccv_nnc.h:1005 */
+typedef struct { ccv_nnc_callback_f fn; void* callback_context; } ccv_nnc_async_callback_t; /* _ccv_nnc_stream.h:57-60 */
+typedef void (*ccv_nnc_async_callback_f)(ccv_nnc_async_callback_t* const async);
+typedef void (*nnc_mi355x_mem_pressure_f)(int device_id, void* const context); /* cump_f, compat.h:33 */
+
+/* ---------------------------------------------------- 3. device compat ABI -------- */
+/* Each entry names the reference symbol it replaces (lib/nnc/gpu/ccv_nnc_compat.h:LINE). */
+void* nnc_mi355x_malloc(int device, size_t size);                 /* cumalloc   :24 */
+void  nnc_mi355x_free(int device, void* ptr);                     /* cufree     :25 */
+void  nnc_mi355x_set_device(int device);                          /* cudevice   :26 */
+void  nnc_mi355x_memcpy(void* dest, const int dest_type, const void* src, const int src_type, size_t n); /* cumemcpy :27, blocking */
+void* nnc_mi355x_host_alloc(size_t size);                         /* cuhostalloc:28 */
+void  nnc_mi355x_host_free(void* ptr);                            /* cuhostfree :29 */
+int   nnc_mi355x_host_register(void* ptr, size_t size);           /* curegister :30 */
+void  nnc_mi355x_host_unregister(void* ptr);                      /* cuunregister:31 */
+int   nnc_mi355x_register_mem_pressure(int device_id, nnc_mi355x_mem_pressure_f func, void* const context); /* curegmp :34 */
+void  nnc_mi355x_unregister_mem_pressure(const int id);           /* cuunregmp  :35 */
+void  nnc_mi355x_set_profiler(int state);                         /* cusetprofiler:36 (roctx range on/off) */
+int   nnc_mi355x_device_count(void);                              /* ccv_nnc_gpu_device_count :59 */
+
+/* Stream contexts / signals: same names as the reference because the host calls exactly these. */
+ccv_nnc_stream_context_t* ccv_nnc_init_stream_context(ccv_nnc_stream_context_t* const stream_context);   /* :39 (reallocs) */
+void  ccv_nnc_deinit_stream_context(ccv_nnc_stream_context_t* const stream_context);                     /* :43 */
+void  ccv_nnc_synchronize_stream_context(const ccv_nnc_stream_context_t* const stream_context);          /* :40 */
+void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const stream_context, const size_t workspace_size, const int mem); /* :44 */
+void  ccv_nnc_stream_compat_drain(ccv_nnc_stream_context_t* const stream_context);                       /* :45 */
+void  ccv_nnc_stream_compat_add_callback(ccv_nnc_stream_context_t* const stream, const ccv_nnc_callback_f callback, const ccv_nnc_async_callback_f async_callback, void* const callback_context); /* :41 */
+ccv_nnc_stream_signal_t* ccv_nnc_init_stream_signal(ccv_nnc_stream_signal_t* const signal);              /* :46 (reallocs) */
+void  ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal);                               /* :49 */
+void  ccv_nnc_stream_compat_emit_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal); /* :47 */
+void  ccv_nnc_stream_compat_wait_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal); /* :48 */
+int   ccv_nnc_stream_context_get_device(const ccv_nnc_stream_context_t* const stream_context);           /* :95 */
+/* Returns the hipStream_t (as void*) a context launches on; NULL context = per-thread default context of the current device. */
+void* nnc_mi355x_stream_context_get_stream(const ccv_nnc_stream_context_t* const stream_context);        /* ccv_nnc_stream_context_get_stream :96 */
+
+/* Standalone constructors for callers without the reference host (mirror ccv_nnc_stream_context_new/free,
+ * ccv_nnc_stream_signal_new/free: lib/nnc/ccv_nnc_stream.c:27,222,304,342). */
+ccv_nnc_stream_context_t* nnc_mi355x_stream_context_new(const int type);
+void nnc_mi355x_stream_context_free(ccv_nnc_stream_context_t* const stream_context);
+void nnc_mi355x_stream_context_wait(const ccv_nnc_stream_context_t* const stream_context);
+ccv_nnc_stream_signal_t* nnc_mi355x_stream_signal_new(const int type);
+void nnc_mi355x_stream_signal_free(ccv_nnc_stream_signal_t* const signal);
+
+/* --------------------------------------------- 2. backend registration ------------ */
+/* Generic enumeration of every (cmd, backend-slot) row implemented by this library. */
+int nnc_mi355x_registry_count(void);
+/* Fills *cmd, *backend, *registry for row i; returns 0 on success, -1 if i is out of range. */
+int nnc_mi355x_registry_get(int i, uint32_t* cmd, uint32_t* backend, ccv_nnc_cmd_backend_registry_t* registry);
+/* Symbolic name of row i, e.g. "CCV_NNC_CONVOLUTION_FORWARD/CCV_NNC_BACKEND_GPU_CUDNN". */
+const char* nnc_mi355x_registry_name(int i);
+
+/* 4. Standalone dispatch: same contract as ccv_nnc_cmd_exec (lib/nnc/ccv_nnc_cmd.c:651-693):
+ * cmd.backend == CCV_NNC_NO_BACKEND picks the first row whose masks cover the tensors' bits. */
+int nnc_mi355x_cmd_exec(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
+int nnc_mi355x_cmd_ok(const uint32_t cmd, const uint32_t backend); /* ccv_nnc_cmd_ok, ccv_nnc_cmd.c:117 */
+
+/* Multi-process data parallel (one process per GPU): join an RCCL communicator created from a
+ * 128-byte unique id that rank 0 obtained from nnc_mi355x_comm_unique_id() and shipped to the other
+ * ranks out of band (torch.distributed store in bench.py).  After this, the COMM_* commands operate
+ * across processes with one tensor per process.  The single-process N-device form (the reference's
+ * ncclCommInitAll, lib/nnc/gpu/ccv_nnc_compat.cu:1404-1445) needs no call. */
+int nnc_mi355x_comm_unique_id(void* id_out_128_bytes);
+int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size);
+void nnc_mi355x_comm_destroy(void);
+
+/* HIP-event timing on the stream a context launches on (bench.py roofline leg). */
+void* nnc_mi355x_event_new(void);
+void  nnc_mi355x_event_record(void* event, const ccv_nnc_stream_context_t* const stream_context);
+float nnc_mi355x_event_elapsed_ms(void* start, void* stop); /* synchronizes on stop */
+void  nnc_mi355x_event_free(void* event);
+/* Name of the device kernel the last command on this thread launched for its dominant work
+ * (conv/gemm contraction), for matching against rocprofv3 kernel-trace rows. */
+const char* nnc_mi355x_last_kernel_name(void);
+const char* nnc_mi355x_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+/* The registration entry points themselves (one per row) are declared in
+ * nnc_mi355x_registry.h, generated from ccv_amd/csrc/registry.def. */
+#include "nnc_mi355x_registry.h"
+
+#endif

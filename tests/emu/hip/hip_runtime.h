@@ -1,0 +1,194 @@
+// TEST INFRASTRUCTURE: a single-threaded, fiber-based emulator of the subset of the HIP device
+// language + runtime API that ccv_amd/csrc uses, so the *unmodified* kernel sources can be compiled
+// for x86 (clang++ -I tests/emu) and checked against the oracle inside the CPU-only test tier.
+// Every workgroup runs as N cooperative fibers (ucontext); __syncthreads / wave-level ops
+// (__shfl*, MFMA builtins) are rendezvous points between fibers.  Wavefront = 64 lanes.
+// The MFMA builtins are modelled exactly as the CDNA4 guide specifies them: a k-ordered fmaf
+// chain with the documented lane->element maps.  This file is never part of the product
+// library: libnnc_mi355x.so is built by hipcc against the real <hip/hip_runtime.h>.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <cmath>
+#include <functional>
+#include <algorithm>
+
+#define NNC_HIP_EMULATOR 1
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::dyn_smem();
+#define warpSize 64
+
+struct dim3 { unsigned x, y, z; constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+struct uint3_emu { unsigned x, y, z; };
+extern uint3_emu threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+typedef struct emu_stream_s* hipStream_t;
+typedef struct emu_event_s* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostRegisterDefault = 0 };
+typedef void (*hipHostFn_t)(void*);
+struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; int major, minor; size_t sharedMemPerBlock; };
+
+namespace emu {
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void syncthreads();
+void wave_sync();
+int lane();
+int wave();
+void* xbuf(int lane); // 16 B per lane exchange slot of the calling fiber's wave
+void* dyn_smem();
+int wave_width();
+}
+
+template <typename K, typename... Args>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args)
+{
+	emu::launch(grid, block, shmem, [&]() { kernel(args...); });
+}
+
+static inline void __syncthreads() { emu::syncthreads(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+template <typename T> static inline T emu_shfl_from(T v, int src)
+{
+	static_assert(sizeof(T) <= 16, "shfl payload");
+	memcpy(emu::xbuf(emu::lane()), &v, sizeof(T));
+	emu::wave_sync();
+	T r;
+	if (src < 0 || src >= emu::wave_width()) src = emu::lane();
+	memcpy(&r, emu::xbuf(src), sizeof(T));
+	emu::wave_sync();
+	return r;
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) { const int l = emu::lane(); return emu_shfl_from(v, (l / width) * width + (src % width)); }
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) { return emu_shfl_from(v, emu::lane() ^ mask); }
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) { const int l = emu::lane(); const int s = l + (int)d; return emu_shfl_from(v, ((s / width) == (l / width)) ? s : l); }
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) { const int l = emu::lane(); const int s = l - (int)d; return emu_shfl_from(v, (s >= 0 && (s / width) == (l / width)) ? s : l); }
+static inline unsigned long long __ballot(int pred)
+{
+	unsigned long long r = 0;
+	for (int i = 0; i < 64; i++) { int p = emu_shfl_from(pred, i); if (i < emu::wave_width() && p) r |= 1ull << i; }
+	return r;
+}
+
+typedef float emu_floatx16 __attribute__((ext_vector_type(16)));
+typedef float emu_floatx4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+static inline emu_floatx16 emu_mfma_f32_32x32x2f32(float a, float b, emu_floatx16 c, int, int, int)
+{
+	struct ab { float a, b; } mine = { a, b };
+	memcpy(emu::xbuf(emu::lane()), &mine, sizeof(mine));
+	emu::wave_sync();
+	const int l = emu::lane(), j = l & 31, hi = l >> 5;
+	for (int r = 0; r < 16; r++) {
+		const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+		float acc = c[r];
+		for (int k = 0; k < 2; k++) {
+			ab A, B;
+			memcpy(&A, emu::xbuf(i + 32 * k), sizeof(A));
+			memcpy(&B, emu::xbuf(j + 32 * k), sizeof(B));
+			acc = fmaf(A.a, B.b, acc);
+		}
+		c[r] = acc;
+	}
+	emu::wave_sync();
+	return c;
+}
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+r
+static inline emu_floatx4 emu_mfma_f32_16x16x4f32(float a, float b, emu_floatx4 c, int, int, int)
+{
+	struct ab { float a, b; } mine = { a, b };
+	memcpy(emu::xbuf(emu::lane()), &mine, sizeof(mine));
+	emu::wave_sync();
+	const int l = emu::lane(), j = l & 15, q = l >> 4;
+	for (int r = 0; r < 4; r++) {
+		const int i = q * 4 + r;
+		float acc = c[r];
+		for (int k = 0; k < 4; k++) {
+			ab A, B;
+			memcpy(&A, emu::xbuf(i + 16 * k), sizeof(A));
+			memcpy(&B, emu::xbuf(j + 16 * k), sizeof(B));
+			acc = fmaf(A.a, B.b, acc);
+		}
+		c[r] = acc;
+	}
+	emu::wave_sync();
+	return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_f32_32x32x2f32
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+
+// ---------------------------------------------------------------- runtime API (host memory)
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
+hipError_t hipHostFree(void* p);
+hipError_t hipHostRegister(void* p, size_t n, unsigned flags);
+hipError_t hipHostUnregister(void* p);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = 0);
+hipError_t hipMemcpyPeer(void* d, int dd, const void* s, int sd, size_t n);
+hipError_t hipMemcpyPeerAsync(void* d, int dd, const void* s, int sd, size_t n, hipStream_t st = 0);
+hipError_t hipMemset(void* d, int v, size_t n);
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = 0);
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
+hipError_t hipDeviceSynchronize();
+hipError_t hipDeviceCanAccessPeer(int* can, int a, int b);
+hipError_t hipDeviceEnablePeerAccess(int peer, unsigned flags);
+hipError_t hipMemGetInfo(size_t* free_, size_t* total);
+hipError_t hipStreamCreate(hipStream_t* s);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
+hipError_t hipStreamQuery(hipStream_t s);
+hipError_t hipLaunchHostFunc(hipStream_t s, hipHostFn_t fn, void* ud);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = 0);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipGetLastError();
+hipError_t hipPeekAtLastError();
+const char* hipGetErrorString(hipError_t e);
