@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: images/sec, VGG-D forward+backward(+SGD), fp32, batch 256 per GPU, on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU.  A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: every forward command, every backward command, (N > 1: RCCL all-reduce of every parameter gradient over xGMI),
+one SGD command per parameter tensor.  Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around
+every launch of the contraction kernel (in-library, on the launching stream); `cpu_baseline` times the reference's own
+lib/nnc CPU backend (oracle/_ref) on one image of the same network on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+from ccv_amd import nnc  # noqa: E402
+from ccv_amd.vgg import VGGD, vgg_d_flops_per_image  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+
+
+def cpu_baseline():
+    """The reference's own CPU path on this host: VGG-D fwd+bwd+SGD of ONE image (batch 1), all host cores (OpenMP)."""
+    from oracle_bind import oracle_lib
+    O, backend, per_image = oracle_lib()
+    kind = "reference" if O.kind == "reference" else "port"
+    net = VGGD(O, 1, memory=nnc.CPU_MEMORY, backend=backend, pool_per_image=per_image, seed=0)
+    rng = np.random.default_rng(0)
+    net.set_input(rng.random((1, 225, 225, 3), dtype=np.float32), [1])
+    t0 = time.time()
+    net.step()
+    dt = time.time() - t0
+    cores = os.cpu_count() if kind == "reference" else 1
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": kind,
+            "sample": "1 image, full VGG-D fwd+bwd+SGD through lib/nnc CPU_REF (oracle/_ref, clang -O3 -fopenmp, no BLAS); %.2f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+
+    L = nnc.load()  # raises without the HIP library / a GPU: there is no fallback path
+    L.set_device(local_rank)
+    dist = None
+    comm = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only (rendezvous, barrier, max-reduce of the timing)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from ccv_amd.comm import ProcessComm
+        comm = ProcessComm(L, dist, rank, world)
+
+    net = VGGD(L, args.batch, device=local_rank, seed=0, flat_grads=(world > 1),
+               sgd=(0, 0.001, 1.0 / (args.batch * world), 0.0005, 0.9, 0.9))
+    rng = np.random.default_rng(1234 + rank)
+    chunk = 32
+    imgs = np.empty((args.batch, 225, 225, 3), dtype=np.float32)
+    for i in range(0, args.batch, chunk):
+        imgs[i:i + chunk] = rng.random((min(chunk, args.batch - i), 225, 225, 3), dtype=np.float32)
+    net.set_input(imgs, rng.integers(0, 1000, args.batch))
+    del imgs
+    stream = L.stream_new(local_rank)
+    L.stream_wait(None)  # construction-time SET commands ran on the default stream
+    if comm:
+        comm.broadcast_params(net, stream)
+
+    def step():
+        net.forward(stream)
+        net.backward(stream)
+        if comm:
+            comm.allreduce_grads(net, stream)
+        net.update(stream)
+
+    def barrier():
+        L.stream_wait(stream)
+        if dist:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(net.loss.numpy().mean())
+
+    # roofline leg: one more step with every contraction launch bracketed by HIP events on its stream
+    L.profile_enable(1)
+    step()
+    L.stream_wait(stream)
+    recs = L.profile_records()
+    L.profile_enable(0)
+    by = {}
+    for name, fl, _by, ms, dims in recs:
+        k = by.setdefault(name, [0.0, 0.0, 0])
+        k[0] += fl
+        k[1] += ms
+        k[2] += 1
+    dom = max(by.items(), key=lambda kv: kv[1][1]) if by else None
+    total_fl = sum(v[0] for v in by.values())
+    total_ms = sum(v[1] for v in by.values())
+
+    if rank == 0:
+        _, fb = vgg_d_flops_per_image()
+        value = world * args.batch * args.steps / dt
+        out = {
+            "metric": "images/sec fwd+bwd VGG-D 224x224 bs256",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VGG-D (ccv vgg_d_params, 225x225x3 crop, NHWC) forward+backward+SGD, batch %d per GPU, random-init weights" % args.batch,
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "gflop_per_image": fb / 1e9, "whole_step_tflops_per_gpu": value / world * fb / 1e12, "final_loss": loss},
+        }
+        if dom:
+            name, (fl, ms, cnt) = dom
+            ach = fl / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                               "traffic": None, "kernel": name, "launches": cnt, "avg_ms": ms / cnt,
+                               "all_contractions": {"achieved": total_fl / (total_ms * 1e-3) / 1e12, "ms": total_ms,
+                                                    "by_kernel": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the checker is optional for the bench line, never for the parity tests
+                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "reference", "sample": "unavailable: %s" % e}
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,15 @@ static inline int grid_for(size_t n, int threads)
 int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int accumulate, ccv_nnc_stream_context_t* ctx); // out[c] (+)= sum_r x[r*ld + c]
 int fill_f32(float* p, size_t n, float v, ccv_nnc_stream_context_t* ctx);
 
+// Optional in-library kernel timing (bench.py roofline leg): when enabled, a ProfScope brackets ONE kernel launch with
+// HIP events on the stream the kernel is launched on and files (name, algorithmic flops/bytes, problem dims).
+struct ProfScope {
+	void* rec;
+	hipStream_t stream;
+	ProfScope(const char* name, double flops, double bytes, int M, int N, int K, int Z, int S, hipStream_t stream);
+	~ProfScope();
+};
+
 // Registration table (registry.cpp).
 typedef void (*register_fn_t)(ccv_nnc_cmd_backend_registry_t* const);
 

@@ -87,6 +87,33 @@ int device_cu_count(void)
 
 void note_kernel(const char* name) { tl_last_kernel = name; }
 
+struct prof_rec_t { char name[192]; double flops, bytes; int dims[5]; hipEvent_t e0, e1; };
+static pthread_mutex_t g_prof_mutex = PTHREAD_MUTEX_INITIALIZER;
+static std::vector<prof_rec_t*> g_prof;
+static volatile int g_prof_on = 0;
+
+ProfScope::ProfScope(const char* name, double flops, double bytes, int M, int N, int K, int Z, int S, hipStream_t st) : rec(0), stream(st)
+{
+	if (!g_prof_on) return;
+	prof_rec_t* r = new prof_rec_t;
+	snprintf(r->name, sizeof(r->name), "%s", name);
+	r->flops = flops; r->bytes = bytes;
+	r->dims[0] = M; r->dims[1] = N; r->dims[2] = K; r->dims[3] = Z; r->dims[4] = S;
+	HIP_ENFORCE(hipEventCreate(&r->e0));
+	HIP_ENFORCE(hipEventCreate(&r->e1));
+	HIP_ENFORCE(hipEventRecord(r->e0, st));
+	rec = r;
+}
+ProfScope::~ProfScope()
+{
+	if (!rec) return;
+	prof_rec_t* r = (prof_rec_t*)rec;
+	HIP_ENFORCE(hipEventRecord(r->e1, stream));
+	pthread_mutex_lock(&g_prof_mutex);
+	g_prof.push_back(r);
+	pthread_mutex_unlock(&g_prof_mutex);
+}
+
 } // namespace nnc
 
 extern "C" {
@@ -374,6 +401,29 @@ float nnc_mi355x_event_elapsed_ms(void* start, void* stop)
 }
 void nnc_mi355x_event_free(void* event) { HIP_ENFORCE(hipEventDestroy((hipEvent_t)event)); }
 const char* nnc_mi355x_last_kernel_name(void) { return tl_last_kernel; }
+
+void nnc_mi355x_profile_enable(int on)
+{
+	pthread_mutex_lock(&nnc::g_prof_mutex);
+	if (on) {
+		for (size_t i = 0; i < nnc::g_prof.size(); i++) { (void)hipEventDestroy(nnc::g_prof[i]->e0); (void)hipEventDestroy(nnc::g_prof[i]->e1); delete nnc::g_prof[i]; }
+		nnc::g_prof.clear();
+	}
+	nnc::g_prof_on = on;
+	pthread_mutex_unlock(&nnc::g_prof_mutex);
+}
+int nnc_mi355x_profile_count(void) { return (int)nnc::g_prof.size(); }
+int nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5])
+{
+	if (i < 0 || i >= (int)nnc::g_prof.size()) return -1;
+	nnc::prof_rec_t* r = nnc::g_prof[i];
+	snprintf(name, name_len, "%s", r->name);
+	*flops = r->flops; *bytes = r->bytes;
+	for (int k = 0; k < 5; k++) dims[k] = r->dims[k];
+	HIP_ENFORCE(hipEventSynchronize(r->e1));
+	HIP_ENFORCE(hipEventElapsedTime(ms, r->e0, r->e1));
+	return 0;
+}
 const char* nnc_mi355x_version(void) { return "nnc-mi355x 0.1 (gfx950)"; }
 
 } // extern "C"

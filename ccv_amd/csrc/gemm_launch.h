@@ -44,9 +44,14 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	}
 	note_kernel(name);
 	if (K <= 0) splits = 1;
+	// Kernel symbol as rocprofv3 prints it: nnc::mfma_gemm_f32_kernel<LA, LB, EpiStore|EpiPartial>; __PRETTY_FUNCTION__ carries LA / LB.
+	char prof_name[192];
+	snprintf(prof_name, sizeof(prof_name), "%s|%s", name, __PRETTY_FUNCTION__ + (sizeof(__PRETTY_FUNCTION__) > 120 ? sizeof(__PRETTY_FUNCTION__) - 120 : 0));
+	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
 	if (splits <= 1) {
 		EpiStore epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N;
+		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
@@ -56,7 +61,10 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	if (!ws) return CCV_NNC_EXEC_OOM;
 	EpiPartial epi;
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial>), dim3((unsigned)tiles, (unsigned)splits, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, 0L, 0L, 0L, 0L);
+	{
+		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial>), dim3((unsigned)tiles, (unsigned)splits, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, 0L, 0L, 0L, 0L);
+	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256)), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.alpha, out.accumulate, M, N);
 	HIP_ENFORCE(hipGetLastError());

@@ -330,7 +330,13 @@ class Tensor:
         self.device = (params.type & 0xfff00) >> 8
         self.owner = None
         self._dptr = None
-        if view_of is not None:  # ccv_nnc_tensor_view_new: same memory, explicit element strides
+        if view_of is not None and strides is None:  # ccv_nnc_tensor(ptr, params, 0): a plain dense tensor over part of another one
+            self.struct = TensorStruct()
+            self.owner = view_of.owner if view_of.owner is not None else view_of
+            self.ptr = view_of.ptr + offset * self.np_dtype.itemsize
+            self.struct.type = params.type
+            self.struct.data = self.ptr
+        elif view_of is not None:  # ccv_nnc_tensor_view_new: same memory, explicit element strides
             self.struct = TensorViewStruct()
             self.owner = view_of
             base = view_of.ptr + offset * self.np_dtype.itemsize
@@ -347,7 +353,7 @@ class Tensor:
             nbytes = max(n * self.np_dtype.itemsize, 16)
             self.nbytes = n * self.np_dtype.itemsize
             if self.memory == CPU_MEMORY:
-                self.array = np.zeros(self.dims, dtype=self.np_dtype) if array is None else np.ascontiguousarray(array, dtype=self.np_dtype).reshape(self.dims)
+                self.array = np.zeros(self.dims, dtype=self.np_dtype) if array is None else np.array(array, dtype=self.np_dtype, order="C", copy=True).reshape(self.dims)
                 self.ptr = self.array.ctypes.data
             else:
                 self._dptr = lib.malloc(self.device, (nbytes + 127) & ~127)  # GPU tensors round to 128 B (ccv_nnc_easy.h:238-244)
@@ -367,14 +373,24 @@ class Tensor:
 
     def numpy(self):
         """Contents as a fresh numpy array (device tensors are copied back, blocking)."""
-        if self.owner is not None:
-            raise ValueError("read the owner tensor of a view")
+        if self.owner is not None:  # contiguous views only: slice the owner's flat contents
+            flat = self.owner.numpy().reshape(-1)
+            off = (self.ptr - self.owner.ptr) // self.np_dtype.itemsize
+            return flat[off:off + int(np.prod(self.dims))].reshape(self.dims).copy()
         if self.memory == CPU_MEMORY:
             return self.array.copy()
         out = np.empty(self.dims, dtype=self.np_dtype)
         if out.nbytes:
             self.lib.memcpy(out.ctypes.data, CPU_MEMORY, self.ptr, GPU_MEMORY | (self.device << 8), out.nbytes)
         return out
+
+    def alias(self, dims, offset=0):
+        """A dense tensor of `dims` over this tensor's memory starting at element `offset` (no view flag)."""
+        p = TensorParam()
+        C.memmove(C.byref(p), C.byref(self.struct.info), C.sizeof(p))
+        for i in range(MAX_DIM_ALLOC):
+            p.dim[i] = dims[i] if i < len(dims) else 0
+        return Tensor(self.lib, p, view_of=self, strides=None, offset=offset)
 
     def view(self, dims, strides, offset=0, fmt=None):
         p = TensorParam()
@@ -439,6 +455,7 @@ class Lib:
             d.nnc_mi355x_registry_get.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(BackendRegistry)]
             d.nnc_mi355x_cmd_ok.argtypes = [C.c_uint32, C.c_uint32]
             d.nnc_mi355x_version.restype = C.c_char_p
+            d.nnc_mi355x_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         self._exec.restype = C.c_int
         self._exec.argtypes = self._EXEC_ARGS
 
@@ -452,6 +469,18 @@ class Lib:
     def stream_free(self, s): self.dll.nnc_mi355x_stream_context_free(s)
     def stream_wait(self, s): self.dll.nnc_mi355x_stream_context_wait(s)
     def cmd_ok(self, cmd, backend): return bool(self.dll.nnc_mi355x_cmd_ok(cmd, backend))
+
+    def profile_enable(self, on): self.dll.nnc_mi355x_profile_enable(int(on))
+
+    def profile_records(self):
+        """[(name, flops, bytes, ms, (M, N, K, Z, splits))] for every contraction launch since profile_enable(1)."""
+        out = []
+        for i in range(self.dll.nnc_mi355x_profile_count()):
+            name = C.create_string_buffer(256)
+            fl, by, ms, dims = C.c_double(), C.c_double(), C.c_float(), (C.c_int * 5)()
+            self.dll.nnc_mi355x_profile_get(i, name, 256, C.byref(fl), C.byref(by), C.byref(ms), dims)
+            out.append((name.value.decode(), fl.value, by.value, ms.value, tuple(dims)))
+        return out
 
     def registry(self):
         rows = []

@@ -294,6 +294,12 @@ void* nnc_mi355x_event_new(void);
 void  nnc_mi355x_event_record(void* event, const ccv_nnc_stream_context_t* const stream_context);
 float nnc_mi355x_event_elapsed_ms(void* start, void* stop); /* synchronizes on stop */
 void  nnc_mi355x_event_free(void* event);
+/* Per-kernel timing: while enabled, every contraction (conv / GEMM) kernel launch is bracketed by a HIP event pair on
+ * its own stream and filed with its algorithmic FLOPs and problem dims (M, N, K, groups/batch, split-K slices).
+ * enable(1) clears the table; get() synchronizes on the record's stop event. */
+void nnc_mi355x_profile_enable(int on);
+int  nnc_mi355x_profile_count(void);
+int  nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5]);
 /* Name of the device kernel the last command on this thread launched for its dominant work
  * (conv/gemm contraction), for matching against rocprofv3 kernel-trace rows. */
 const char* nnc_mi355x_last_kernel_name(void);

@@ -1,0 +1,303 @@
+"""Parity of every hot-path command with the reference's own CPU backend (oracle/_ref/libccv_ref.so) on identical
+seeded inputs.  Runs on the CPU HIP emulator in the `not gpu` tier and on the MI355X in the `gpu` tier.
+Tolerances: fp32 conv/GEMM 1e-4 relative (north_star); pooling, relu, transfers bit-exact."""
+import numpy as np
+import pytest
+from ccv_amd import nnc
+from harness import exec_pair, exec_on, out_hw, tensor_eq
+
+F = np.float32
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (rng.random(shape, dtype=F) * scale).astype(F)
+
+
+def srnd(rng, *shape, scale=1.0):
+    return ((rng.random(shape, dtype=F) - 0.5) * 2 * scale).astype(F)
+
+
+CONV_CASES = [
+    # n, h, w, c, k, kh, kw, stride, border, groups, dilation, bias
+    (2, 9, 10, 8, 16, 3, 3, (1, 1), (1, 1), 1, None, True),      # vectorised gather, ragged M
+    (1, 12, 11, 3, 5, 5, 5, (2, 2), (2, 2), 1, None, True),      # C=3 scalar gather, stride 2, ragged K
+    (2, 7, 7, 12, 8, 1, 1, (1, 1), (0, 0), 1, None, False),      # 1x1, no bias
+    (1, 15, 13, 4, 6, 7, 7, (2, 2), (3, 3), 1, None, True),      # 7x7 s2 (ResNet stem shape class)
+    (2, 8, 8, 8, 8, 3, 3, (1, 1), (1, 1), 2, None, True),        # groups
+    (1, 11, 11, 4, 4, 3, 3, (1, 1), (2, 2), 1, (2, 2), True),    # dilation
+    (3, 6, 20, 40, 130, 3, 3, (1, 1), (1, 1), 1, None, True),    # several K-steps, two N tiles, >1 M tile
+]
+
+
+def _conv_inputs(case, seed=0):
+    n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case
+    rng = np.random.default_rng(seed)
+    a = srnd(rng, n, h, w, c)
+    wt = srnd(rng, k, kh, kw, c // groups, scale=1.0 / (kh * kw * (c // groups)))
+    b = srnd(rng, k) if bias else None
+    hint = nnc.HINT(stride, border)
+    ekh, ekw = ((kh - 1) * dil[0] + 1, (kw - 1) * dil[1] + 1) if dil else (kh, kw)
+    oh, ow = out_hw(h, w, ekh, ekw, hint)
+    return a, wt, b, hint, oh, ow
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(backend, ref_lib, case):
+    n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case
+    a, wt, b, hint, oh, ow = _conv_inputs(case)
+    cmd = nnc.CMD_CONVOLUTION_FORWARD(groups, k, kh, kw, c // groups, dilation=dil)
+    ins = [a, wt] + ([b] if bias else [])
+    got, want = exec_pair(backend, ref_lib, cmd, hint, 0, ins, [np.zeros((n, oh, ow, k), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("flags", [0, nnc.ACCUMULATE_OUTPUT])
+def test_conv_backward(backend, ref_lib, case, flags):
+    n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case
+    a, wt, b, hint, oh, ow = _conv_inputs(case)
+    rng = np.random.default_rng(7)
+    g = srnd(rng, n, oh, ow, k)
+    g[g < -0.6] = 0  # exercise the oracle's v == 0 shortcut
+    dw0 = srnd(rng, *wt.shape)
+    db0 = srnd(rng, k)
+    cmd = nnc.CMD_CONVOLUTION_BACKWARD(groups, k, kh, kw, c // groups, dilation=dil)
+    got, want = exec_pair(backend, ref_lib, cmd, hint, flags, [g, a, wt], [np.zeros_like(a), dw0, db0])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5)
+    if flags & nnc.ACCUMULATE_OUTPUT:
+        # Quirk: the CPU oracle OVERWRITES dbias even under CCV_NNC_ACCUMULATE_OUTPUT (conv_cpu_ref.c:262-263, `bias[k] = biasval`),
+        # while the GPU backend being replaced accumulates it (conv_gpu_cudnn.cu:264-271, beta = 1).  We follow the GPU
+        # backend: expected = initial + the oracle's plain bias gradient.
+        np.testing.assert_allclose(got[2], db0 + want[2], rtol=1e-4, atol=2e-5)
+    else:
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-4, atol=2e-5)
+
+
+def test_conv_backward_partial_outputs(backend, ref_lib):
+    case = CONV_CASES[0]
+    n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case
+    a, wt, b, hint, oh, ow = _conv_inputs(case)
+    g = srnd(np.random.default_rng(3), n, oh, ow, k)
+    cmd = nnc.CMD_CONVOLUTION_BACKWARD(groups, k, kh, kw, c)
+    got, want = exec_pair(backend, ref_lib, cmd, hint, 0, [g, a, wt], [None, np.zeros_like(wt), np.zeros(k, F)])  # no dgrad (conv1_1)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-4, atol=2e-5)
+    got, want = exec_pair(backend, ref_lib, cmd, hint, 0, [g, a, wt], [np.zeros_like(a), np.zeros_like(wt)])  # no bias grad
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5)
+
+
+def test_conv_forward_3d_no_batch(backend, ref_lib):
+    rng = np.random.default_rng(1)
+    a = srnd(rng, 10, 9, 4)
+    wt = srnd(rng, 8, 3, 3, 4, scale=1 / 36)
+    b = srnd(rng, 8)
+    hint = nnc.HINT((1, 1), (1, 1))
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_CONVOLUTION_FORWARD(1, 8, 3, 3, 4), hint, 0, [a, wt, b], [np.zeros((10, 9, 8), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-5)
+
+
+GEMM_CASES = [
+    # (a shape, w shape, transpose_a, transpose_b, bias)
+    ((5, 3), (3, 7), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, True),
+    ((6, 20), (9, 20), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True),      # cnnp dense layer: w [out][in]
+    ((20, 6), (20, 9), nnc.TRANSPOSE(0, 1), nnc.NO_TRANSPOSE, False),
+    ((12, 4), (8, 12), nnc.TRANSPOSE(0, 1), nnc.TRANSPOSE(0, 1), True),
+    ((130, 100), (257, 100), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True),  # several tiles, ragged
+    ((8, 2048), (16, 2048), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True),   # split-K path
+    ((3, 4, 5), (3, 5, 6), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, False),      # batched
+    ((3, 4, 5), (6, 5), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True),       # batched a, shared w
+]
+
+
+def _gemm_shapes(ashape, wshape, ta, tb):
+    ar, ac = ashape[-2:]
+    if ta[0] != ta[1]:
+        ar, ac = ac, ar
+    wr, wc = wshape[-2:]
+    if tb[0] != tb[1]:
+        wr, wc = wc, wr
+    assert ac == wr
+    batch = ashape[:-2] if len(ashape) > 2 else (wshape[:-2] if len(wshape) > 2 else ())
+    return batch + (ar, wc)
+
+
+def _t(t, nd):
+    """transpose axes are absolute indices: (0,1) for 2-d, (1,2) for 3-d."""
+    return t if t[0] == t[1] or nd == 2 else (nd - 2, nd - 1)
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_forward(backend, ref_lib, case):
+    ashape, wshape, ta, tb, bias = case
+    rng = np.random.default_rng(0)
+    a, w = srnd(rng, *ashape), srnd(rng, *wshape)
+    ta, tb = _t(ta, len(ashape)), _t(tb, len(wshape))
+    bshape = _gemm_shapes(ashape, wshape, ta, tb)
+    ins = [a, w] + ([srnd(rng, bshape[-1])] if bias else [])
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_GEMM_FORWARD(ta, tb), nnc.NO_HINT, 0, ins, [np.zeros(bshape, F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+@pytest.mark.parametrize("flags", [0, nnc.ACCUMULATE_OUTPUT])
+def test_gemm_backward(backend, ref_lib, case, flags):
+    ashape, wshape, ta, tb, bias = case
+    rng = np.random.default_rng(1)
+    a, w = srnd(rng, *ashape), srnd(rng, *wshape)
+    ta, tb = _t(ta, len(ashape)), _t(tb, len(wshape))
+    bshape = _gemm_shapes(ashape, wshape, ta, tb)
+    g = srnd(rng, *bshape)
+    outs = [srnd(rng, *ashape), srnd(rng, *wshape)] + ([srnd(rng, bshape[-1])] if bias else [])
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_GEMM_BACKWARD(ta, tb), nnc.NO_HINT, flags, [g, a, w], outs)
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-4)
+
+
+POOL_CASES = [
+    # h, w, c, kh, kw, stride, border
+    (9, 9, 5, 3, 3, (2, 2), (0, 0)),     # VGG-D pool
+    (10, 12, 7, 3, 3, (2, 2), (1, 1)),   # ResNet stem pool
+    (8, 8, 4, 2, 2, (2, 2), (0, 0)),
+    (7, 7, 6, 7, 7, (1, 1), (0, 0)),     # global
+    (6, 5, 3, 3, 3, (1, 1), (1, 1)),     # overlapping, stride 1
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_pool_forward_backward_bit_exact(backend, ref_lib, case, kind):
+    h, w, c, kh, kw, stride, border = case
+    rng = np.random.default_rng(2)
+    a = np.round(srnd(rng, h, w, c) * 4) / 4  # ties on purpose: the max-pool gradient goes to every tied position
+    hint = nnc.HINT(stride, border)
+    oh, ow = out_hw(h, w, kh, kw, hint)
+    fcmd = nnc.CMD_MAX_POOL_FORWARD(kh, kw) if kind == "max" else nnc.CMD_AVERAGE_POOL_FORWARD(kh, kw)
+    bcmd = nnc.CMD_MAX_POOL_BACKWARD(kh, kw) if kind == "max" else nnc.CMD_AVERAGE_POOL_BACKWARD(kh, kw)
+    got, want = exec_pair(backend, ref_lib, fcmd, hint, 0, [a], [np.zeros((oh, ow, c), F)])
+    assert np.array_equal(got[0].view(np.int32), want[0].view(np.int32))
+    g = srnd(rng, oh, ow, c)
+    got, want = exec_pair(backend, ref_lib, bcmd, hint, 0, [g, a, want[0]], [np.zeros_like(a)])
+    assert np.array_equal(got[0].view(np.int32), want[0].view(np.int32))
+
+
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_pool_batched_and_nchw(backend, ref_lib, kind):
+    """The CPU oracle walks only image 0 of a batch and is NHWC-only: check a batch image by image, and NCHW against
+    the transposed NHWC result."""
+    rng = np.random.default_rng(3)
+    n, h, w, c, kh, kw = 3, 9, 8, 5, 3, 3
+    hint = nnc.HINT((2, 2), (1, 1))
+    oh, ow = out_hw(h, w, kh, kw, hint)
+    a = np.round(srnd(rng, n, h, w, c) * 4) / 4
+    g = srnd(rng, n, oh, ow, c)
+    fcmd = nnc.CMD_MAX_POOL_FORWARD(kh, kw) if kind == "max" else nnc.CMD_AVERAGE_POOL_FORWARD(kh, kw)
+    bcmd = nnc.CMD_MAX_POOL_BACKWARD(kh, kw) if kind == "max" else nnc.CMD_AVERAGE_POOL_BACKWARD(kh, kw)
+    r, (b,) = exec_on(backend, nnc.GPU_MEMORY, fcmd, hint, 0, [a], [np.zeros((n, oh, ow, c), F)])
+    assert r == 0
+    r, (hg,) = exec_on(backend, nnc.GPU_MEMORY, bcmd, hint, 0, [g, a, b], [np.zeros_like(a)])
+    assert r == 0
+    for i in range(n):
+        _, (bw,) = exec_on(ref_lib, nnc.CPU_MEMORY, fcmd, hint, 0, [a[i]], [np.zeros((oh, ow, c), F)], backend=nnc.BACKEND_CPU_REF)
+        _, (hw,) = exec_on(ref_lib, nnc.CPU_MEMORY, bcmd, hint, 0, [g[i], a[i], bw], [np.zeros((h, w, c), F)], backend=nnc.BACKEND_CPU_REF)
+        assert np.array_equal(b[i].view(np.int32), bw.view(np.int32))
+        assert np.array_equal(hg[i].view(np.int32), hw.view(np.int32))
+    ac, gc = np.ascontiguousarray(a.transpose(0, 3, 1, 2)), np.ascontiguousarray(g.transpose(0, 3, 1, 2))
+    r, (bc,) = exec_on(backend, nnc.GPU_MEMORY, fcmd, hint, 0, [ac], [np.zeros((n, c, oh, ow), F)], fmt="NCHW")
+    assert r == 0 and np.array_equal(bc.transpose(0, 2, 3, 1), b)
+    r, (hc,) = exec_on(backend, nnc.GPU_MEMORY, bcmd, hint, 0, [gc, ac, bc], [np.zeros_like(ac)], fmt="NCHW")
+    assert r == 0 and np.array_equal(hc.transpose(0, 2, 3, 1), hg)
+
+
+@pytest.mark.parametrize("shape", [(1,), (7,), (4, 5, 6, 3), (2, 1027)])
+def test_relu(backend, ref_lib, shape):
+    rng = np.random.default_rng(4)
+    a = srnd(rng, *shape)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_RELU_FORWARD(), nnc.NO_HINT, 0, [a], [np.zeros(shape, F)])
+    assert np.array_equal(got[0], want[0])
+    g = srnd(rng, *shape)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_RELU_BACKWARD(), nnc.NO_HINT, 0, [g, None, want[0]], [np.zeros(shape, F)])
+    assert np.array_equal(got[0], want[0])
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 4, 5])
+def test_ewsum(backend, ref_lib, count):
+    rng = np.random.default_rng(5)
+    ins = [srnd(rng, 3, 5, 7) for _ in range(count)]
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_EWSUM_FORWARD(), nnc.NO_HINT, 0, ins, [np.zeros((3, 5, 7), F)])
+    assert np.array_equal(got[0], want[0])
+    g = srnd(rng, 3, 5, 7)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_EWSUM_BACKWARD(), nnc.NO_HINT, 0, [g] + ins + [want[0]], [np.zeros((3, 5, 7), F) for _ in range(count)])
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+
+
+def test_scalar_mul_and_set(backend, ref_lib):
+    rng = np.random.default_rng(6)
+    a = srnd(rng, 33, 5)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_SCALAR_MUL_FORWARD(0.3), nnc.NO_HINT, 0, [a], [np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0])
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_SET_FORWARD(1.5), nnc.NO_HINT, 0, [], [srnd(rng, 9, 3)])
+    assert np.array_equal(got[0], want[0])
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_SET_FORWARD(0), nnc.NO_HINT, 0, [], [srnd(rng, 9, 3)])
+    assert np.array_equal(got[0], want[0])
+
+
+@pytest.mark.parametrize("nesterov,damp", [(0, 0.9), (0, 0.0), (1, 0.0)])
+@pytest.mark.parametrize("shape", [(10,), (64, 3, 3, 3), (5, 7)])
+def test_sgd(backend, ref_lib, nesterov, damp, shape):
+    rng = np.random.default_rng(8)
+    g, a, m = srnd(rng, *shape), srnd(rng, *shape), srnd(rng, *shape)
+    cmd = nnc.CMD_SGD_FORWARD(nesterov, 0.001, 1.0 / 32, 0.0005, 0.9, damp)
+    got, want = exec_pair(backend, ref_lib, cmd, nnc.NO_HINT, 0, [g, a, m], [np.zeros(shape, F), np.zeros(shape, F)])
+    for x, y in zip(got, want):
+        assert tensor_eq(x, y)  # fma contraction may differ by an ulp between compilers
+
+
+def test_data_transfer_roundtrip(backend):
+    rng = np.random.default_rng(9)
+    a = srnd(rng, 3, 4, 5)
+    L = backend
+    src = L.tensor(nnc.CPU_TENSOR_NHWC(nnc.CCV_32F, 3, 4, 5), a)
+    dev = L.tensor(nnc.GPU_TENSOR_NHWC(0, nnc.CCV_32F, 3, 4, 5))
+    dev2 = L.tensor(nnc.GPU_TENSOR_NHWC(0, nnc.CCV_32F, 3, 4, 5))
+    back = L.tensor(nnc.CPU_TENSOR_NHWC(nnc.CCV_32F, 3, 4, 5))
+    t = nnc.CMD_DATA_TRANSFER_FORWARD()
+    assert L.cmd_exec(t, nnc.NO_HINT, 0, [src], [dev]) == 0
+    assert L.cmd_exec(t, nnc.NO_HINT, 0, [dev], [dev2]) == 0
+    assert L.cmd_exec(t, nnc.NO_HINT, 0, [dev2], [back]) == 0
+    assert np.array_equal(back.numpy(), a)
+
+
+@pytest.mark.parametrize("label_kind", ["f32", "i32", "dense"])
+@pytest.mark.parametrize("trim", [(0.0, 1.0), (0.1, 0.9)])
+@pytest.mark.parametrize("with_g", [True, False])
+def test_softmax_crossentropy(backend, ref_lib, label_kind, trim, with_g):
+    rng = np.random.default_rng(10)
+    n, c = 6, 37
+    a = srnd(rng, n, c, scale=3)
+    idx = rng.integers(0, c, n)
+    if label_kind == "f32":
+        label = idx.astype(F)
+    elif label_kind == "i32":
+        label = idx.astype(np.int32)
+    else:
+        label = rnd(rng, n, c)
+        label /= label.sum(1, keepdims=True)
+    fcmd = nnc.CMD_SOFTMAX_CROSSENTROPY_FORWARD(*trim)
+    got, want = exec_pair(backend, ref_lib, fcmd, nnc.NO_HINT, 0, [a, label], [np.zeros(n, F), np.zeros((n, c), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-5, atol=1e-7)
+    g = srnd(rng, n) if with_g else None
+    bcmd = nnc.CMD_SOFTMAX_CROSSENTROPY_BACKWARD(*trim)
+    got, want = exec_pair(backend, ref_lib, bcmd, nnc.NO_HINT, 0, [g, None, None, label, None, want[1]], [np.zeros((n, c), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-7)
+
+
+def test_softmax_only(backend, ref_lib):
+    rng = np.random.default_rng(11)
+    a = srnd(rng, 5, 1000, scale=4)
+    label = rng.integers(0, 1000, 5).astype(F)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_SOFTMAX_CROSSENTROPY_FORWARD(), nnc.NO_HINT, 0, [a, label], [None, np.zeros((5, 1000), F)])
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-5, atol=1e-8)
