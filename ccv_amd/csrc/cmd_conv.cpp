@@ -39,6 +39,11 @@ static bool conv_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, 
 	return true;
 }
 
+static bool image_fits_int(const Image4& t)
+{ // the gathers index inside one image with 32-bit arithmetic
+	return (long)t.h * t.sh < 0x7fffffffL && (long)t.w * t.sw < 0x7fffffffL && (long)(t.h - 1) * t.sh + (long)(t.w - 1) * t.sw + t.c < 0x7fffffffL;
+}
+
 static bool pixel_linear(const Image4& t)
 { // pixels (n, y, x) form one arithmetic progression with step sw and channels are dense
 	return t.sc == 1 && t.sh == (long)t.w * t.sw && (t.n == 1 || t.sn == (long)t.h * t.sh);
@@ -46,7 +51,7 @@ static bool pixel_linear(const Image4& t)
 
 static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
-	if (a.sc != 1 || !pixel_linear(b)) return CCV_NNC_EXEC_INVALID;
+	if (a.sc != 1 || !pixel_linear(b) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
 	const long M = (long)g.N * g.OH * g.OW;
 	const int Kred = g.kh * g.kw * g.Cg;
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
@@ -68,7 +73,7 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 // h = sum_{k,i,j} g[n, (y+p-i*d)/s, (x+p-j*d)/s, k] * w[k,i,j,c]
 static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
-	if (gr.sc != 1 || !pixel_linear(h)) return CCV_NNC_EXEC_INVALID;
+	if (gr.sc != 1 || !pixel_linear(h) || !image_fits_int(gr)) return CCV_NNC_EXEC_INVALID;
 	const long M = (long)g.N * g.H * g.W;
 	const int Kred = g.kh * g.kw * g.Kg;
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
@@ -90,7 +95,7 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 // dw[k,i,j,c] (+)= sum_{n,y,x} g[n,y,x,k] * a[n, y*s-p+i*d, x*s-p+j*d, c]
 static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4& a, float* dw, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
-	if (a.sc != 1 || !pixel_linear(gr)) return CCV_NNC_EXEC_INVALID;
+	if (a.sc != 1 || !pixel_linear(gr) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
 	const long P = (long)g.N * g.OH * g.OW;
 	if (P > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const int NN = g.kh * g.kw * g.Cg;

@@ -12,6 +12,7 @@
 // (The CPU oracle only walks image 0 of a batch; on device every image is processed the same way.)
 // Replaces cudnnPoolingForward/Backward of lib/nnc/cmd/pool/gpu/ccv_nnc_{max,avg}_pool_gpu_cudnn.cu.
 #include "common.h"
+#include "mfma_gemm.h" // FastDiv
 
 using namespace nnc;
 
@@ -22,29 +23,30 @@ struct pool_geom_t {
 	int kh, kw, sy, sx, pby, pbx;
 	long a_sn, a_sh, a_sw, a_sc; // input-shaped tensors (a, h)
 	long b_sn, b_sh, b_sw, b_sc; // output-shaped tensors (b, g)
+	FastDiv d_c, d_w, d_h, d_ow, d_oh; // index decomposition without hardware division
 };
 
-// idx -> (n, y, x, c) with the memory-contiguous index fastest.
+// idx -> (n, y, x, c) with the memory-contiguous index fastest; idx < 2^31 (the host splits larger tensors per image).
 template <bool NHWC>
-__device__ __forceinline__ void unflatten(size_t idx, const int d1, const int d2, const int C, int& n, int& y, int& x, int& c)
+__device__ __forceinline__ void unflatten(int idx, const FastDiv& d1, const FastDiv& d2, const FastDiv& dc, int& n, int& y, int& x, int& c)
 {
 	if (NHWC) {
-		c = (int)(idx % C); idx /= C;
-		x = (int)(idx % d2); idx /= d2;
-		y = (int)(idx % d1); n = (int)(idx / d1);
+		int q = dc.div(idx); c = idx - q * dc.d; idx = q;
+		q = d2.div(idx); x = idx - q * d2.d; idx = q;
+		q = d1.div(idx); y = idx - q * d1.d; n = q;
 	} else {
-		x = (int)(idx % d2); idx /= d2;
-		y = (int)(idx % d1); idx /= d1;
-		c = (int)(idx % C); n = (int)(idx / C);
+		int q = d2.div(idx); x = idx - q * d2.d; idx = q;
+		q = d1.div(idx); y = idx - q * d1.d; idx = q;
+		q = dc.div(idx); c = idx - q * dc.d; n = q;
 	}
 }
 
 template <bool NHWC, bool IS_MAX>
 __global__ void __launch_bounds__(256) pool_forw_kernel(const pool_geom_t g, const float* a, float* b, const size_t total)
 {
-	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, oy, ox, c;
-		unflatten<NHWC>(idx, g.OH, g.OW, g.C, n, oy, ox, c);
+		unflatten<NHWC>((int)idx64, g.d_oh, g.d_ow, g.d_c, n, oy, ox, c);
 		int y0 = oy * g.sy - g.pby, x0 = ox * g.sx - g.pbx;
 		int y1 = y0 + g.kh, x1 = x0 + g.kw;
 		if (y0 < 0) y0 = 0;
@@ -77,9 +79,9 @@ __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b :
 template <bool NHWC, bool IS_MAX>
 __global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, const float* gr, const float* a, const float* b, float* h, const size_t total)
 {
-	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, y, x, c;
-		unflatten<NHWC>(idx, g.H, g.W, g.C, n, y, x, c);
+		unflatten<NHWC>((int)idx64, g.d_h, g.d_w, g.d_c, n, y, x, c);
 		int oy0 = ceil_div(y + g.pby - g.kh + 1, g.sy), oy1 = floor_div(y + g.pby, g.sy);
 		int ox0 = ceil_div(x + g.pbx - g.kw + 1, g.sx), ox1 = floor_div(x + g.pbx, g.sx);
 		if (oy0 < 0) oy0 = 0;
@@ -125,6 +127,7 @@ static bool pool_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, 
 	g->pby = hint.border.begin[0]; g->pbx = hint.border.begin[1];
 	g->a_sn = a.sn; g->a_sh = a.sh; g->a_sw = a.sw; g->a_sc = a.sc;
 	g->b_sn = b.sn; g->b_sh = b.sh; g->b_sw = b.sw; g->b_sc = b.sc;
+	g->d_c.init(g->C); g->d_w.init(g->W); g->d_h.init(g->H); g->d_ow.init(g->OW); g->d_oh.init(g->OH);
 	return true;
 }
 
@@ -142,12 +145,20 @@ static int pool_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	pool_geom_t g;
 	bool nhwc;
 	if (!pool_geometry(cmd, hint, inputs[0], outputs[0], &g, &nhwc)) return CCV_NNC_EXEC_INVALID;
-	const size_t total = (size_t)g.N * g.OH * g.OW * g.C;
-	if (total == 0) return CCV_NNC_EXEC_SUCCESS;
+	const size_t per_image = (size_t)g.OH * g.OW * g.C;
+	if (per_image == 0 || g.N == 0) return CCV_NNC_EXEC_SUCCESS;
+	if (per_image >= 0x7fffffffUL) return CCV_NNC_EXEC_INVALID;
 	hipStream_t stream = stream_of(stream_context);
-	if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, (const float*)inputs[0]->data.f32, outputs[0]->data.f32, total);
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, (const float*)inputs[0]->data.f32, outputs[0]->data.f32, total);
-	HIP_ENFORCE(hipGetLastError());
+	const int nchunk = (int)(0x7fffffffUL / per_image) < g.N ? (int)(0x7fffffffUL / per_image) : g.N; // images per launch (index < 2^31)
+	for (int n0 = 0; n0 < g.N; n0 += nchunk) {
+		const int nn = g.N - n0 < nchunk ? g.N - n0 : nchunk;
+		const size_t total = per_image * nn;
+		const float* ap = inputs[0]->data.f32 + (long)n0 * g.a_sn;
+		float* bp = outputs[0]->data.f32 + (long)n0 * g.b_sn;
+		if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
+		HIP_ENFORCE(hipGetLastError());
+	}
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
@@ -168,14 +179,22 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	pool_geom_t g;
 	bool nhwc;
 	if (!pool_geometry(cmd, hint, h, gt, &g, &nhwc)) return CCV_NNC_EXEC_INVALID;
-	const size_t total = (size_t)g.N * g.H * g.W * g.C;
-	if (total == 0) return CCV_NNC_EXEC_SUCCESS;
+	const size_t per_image = (size_t)g.H * g.W * g.C;
+	if (per_image == 0 || g.N == 0) return CCV_NNC_EXEC_SUCCESS;
+	if (per_image >= 0x7fffffffUL) return CCV_NNC_EXEC_INVALID;
 	hipStream_t stream = stream_of(stream_context);
-	const float* ap = a ? a->data.f32 : 0;
-	const float* bp = b ? b->data.f32 : 0;
-	if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, (const float*)gt->data.f32, ap, bp, h->data.f32, total);
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, (const float*)gt->data.f32, ap, bp, h->data.f32, total);
-	HIP_ENFORCE(hipGetLastError());
+	const int nchunk = (int)(0x7fffffffUL / per_image) < g.N ? (int)(0x7fffffffUL / per_image) : g.N;
+	for (int n0 = 0; n0 < g.N; n0 += nchunk) {
+		const int nn = g.N - n0 < nchunk ? g.N - n0 : nchunk;
+		const size_t total = per_image * nn;
+		const float* gp = gt->data.f32 + (long)n0 * g.b_sn;
+		const float* ap = a ? a->data.f32 + (long)n0 * g.a_sn : 0;
+		const float* bp = b ? b->data.f32 + (long)n0 * g.b_sn : 0;
+		float* hp = h->data.f32 + (long)n0 * g.a_sn;
+		if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
+		HIP_ENFORCE(hipGetLastError());
+	}
 	return CCV_NNC_EXEC_SUCCESS;
 }
 

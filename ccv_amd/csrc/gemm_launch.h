@@ -26,13 +26,28 @@ static inline int gemm_auto_splits(long tiles, int K)
 	return s < 1 ? 1 : (int)s;
 }
 
-// zcount > 1 (batched GEMM / grouped conv): every z applies the given element offsets to A, B, C and bias.
-template <class LA, class LB>
-static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+// Pick the block tile: 128x128 unless an output dimension would be mostly padding (64-channel layers), where the
+// narrower tile keeps the MFMA pipe on useful work.  Score = useful / issued work x a mild preference for big tiles.
+static inline void gemm_pick_tile(const int M, const int N, int* wm, int* wn)
 {
-	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
+	static const int shapes[3][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 } };
+	static const double eff[3] = { 1.0, 0.93, 0.93 };
+	double best = -1;
+	for (int i = 0; i < 3; i++) {
+		const long bm = 64 * shapes[i][0], bn = 64 * shapes[i][1];
+		const double padded = (double)((M + bm - 1) / bm * bm) * (double)((N + bn - 1) / bn * bn);
+		const double score = (double)M * N / padded * eff[i];
+		if (score > best + 1e-9) { best = score; *wm = shapes[i][0]; *wn = shapes[i][1]; }
+	}
+}
+
+// zcount > 1 (batched GEMM / grouped conv): every z applies the given element offsets to A, B, C and bias.
+template <class LA, class LB, int WM, int WN>
+static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	constexpr int BM = 64 * WM, BN = 64 * WN;
 	hipStream_t stream = stream_of(ctx);
-	const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+	const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
 	const long tiles = (long)tiles_m * tiles_n;
 	if (tiles > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
@@ -44,15 +59,15 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	}
 	note_kernel(name);
 	if (K <= 0) splits = 1;
-	// Kernel symbol as rocprofv3 prints it: nnc::mfma_gemm_f32_kernel<LA, LB, EpiStore|EpiPartial>; __PRETTY_FUNCTION__ carries LA / LB.
+	// Kernel symbol as rocprofv3 prints it: nnc::mfma_gemm_f32_kernel<LA, LB, EpiStore|EpiPartial, WM, WN>; __PRETTY_FUNCTION__ carries LA / LB / WM / WN.
 	char prof_name[192];
-	snprintf(prof_name, sizeof(prof_name), "%s|%s", name, __PRETTY_FUNCTION__ + (sizeof(__PRETTY_FUNCTION__) > 120 ? sizeof(__PRETTY_FUNCTION__) - 120 : 0));
+	snprintf(prof_name, sizeof(prof_name), "%s|%s", name, __PRETTY_FUNCTION__ + (sizeof(__PRETTY_FUNCTION__) > 110 ? sizeof(__PRETTY_FUNCTION__) - 110 : 0));
 	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
 	if (splits <= 1) {
 		EpiStore epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N;
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, a_z, b_z, c_z, bias_z);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -63,12 +78,25 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial>), dim3((unsigned)tiles, (unsigned)splits, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)tiles, (unsigned)splits, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, 0L, 0L, 0L, 0L);
 	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256)), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.alpha, out.accumulate, M, N);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
+}
+
+template <class LA, class LB>
+static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
+	la.finish();
+	lb.finish();
+	int wm = 2, wn = 2;
+	gemm_pick_tile(M, N, &wm, &wn);
+	if (wm == 2 && wn == 2) return gemm_run_tile<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+	if (wm == 2) return gemm_run_tile<LA, LB, 2, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+	return gemm_run_tile<LA, LB, 1, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 }
 
 } // namespace nnc

@@ -8,13 +8,17 @@
 //   conv wgrad     A = g viewed ko x pixel (m-contiguous)       B = im2col(a) pixel x (tap,c) (n-contiguous)
 //   GEMM fwd/bwd   plain strided matrices in any of the four transpose combinations
 //
-// Geometry: 128x128 block tile, BK = 32, 256 threads = 4 waves (2x2), each wave owns 64x64 = 2x2 MFMA tiles
-// (64 accumulator registers).  Operand tiles are staged HBM -> registers -> LDS (double buffered, one barrier per
+// Geometry: (64*WM) x (64*WN) block tile (WM, WN in {1, 2}: 128x128 for the bulk, 128x64 / 64x128 when an output
+// dimension is 64 channels so no MFMA issues on padding), BK = 32, 256 threads = 4 waves (2x2), each wave owns
+// WM x WN MFMA tiles of 32x32.  Operand tiles are staged HBM -> registers -> LDS (double buffered, one barrier per
 // K-step; the global loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them).
+// Gathers are BRANCH-FREE: every lane always issues its 16-byte load (address clamped to the operand base when the
+// element is padding / out of range) and selects zero afterwards, so the compiler can batch all loads of a K-step in
+// front of the MFMA block; integer divisions by runtime geometry use precomputed multiply-shift constants.
 // LDS images:
-//   k-contiguous operand:   [128 rows][36]  (row stride 36 floats: ds_read_b128 by 16-lane groups is conflict free,
+//   k-contiguous operand:   [rows][36]      (row stride 36 floats: ds_read_b128 by 16-lane groups is conflict free,
 //                                            36*r mod 64 hits 16 distinct 4-bank slots for 16 distinct rows)
-//   row-contiguous operand: [32 k][128]     (ds_read_b32, lanes 0-31 read 32 consecutive banks, the other half-wave
+//   row-contiguous operand: [32 k][rows]    (ds_read_b32, lanes 0-31 read 32 consecutive banks, the other half-wave
 //                                            is a different k row: no conflicts)
 // Both images feed the same k permutation: MFMA number (q,e) of a K-step consumes k = 8q+e (lanes 0-31) and
 // k = 8q+4+e (lanes 32-63), so a k-contiguous operand needs ONE ds_read_b128 per four MFMAs.
@@ -27,18 +31,35 @@ namespace nnc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_THREADS = 256;
-constexpr int GEMM_LDK = 36;  // row stride of a k-contiguous LDS image
-constexpr int GEMM_LDR = 128; // k-row stride of a row-contiguous LDS image
-constexpr int GEMM_TILE_FLOATS = GEMM_BM * GEMM_LDK; // 4608 >= 32 * 128
+constexpr int GEMM_BK = 32, GEMM_THREADS = 256;
+constexpr int GEMM_LDK = 36; // row stride of a k-contiguous LDS image
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4sel(bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); }
+
+// Exact n / d for 0 <= n < 2^31, d >= 1 as multiply + shift (Granlund-Montgomery): m = ceil(2^(31+s) / d), s = ceil(log2 d).
+struct FastDiv {
+	unsigned m;
+	int sh, d;
+	void init(int divisor)
+	{
+		d = divisor < 1 ? 1 : divisor;
+		int s = 0;
+		while ((1ll << s) < d) s++;
+		sh = 31 + s;
+		m = (unsigned)(((1ull << sh) + (unsigned long long)d - 1) / (unsigned long long)d);
+	}
+	__host__ __device__ __forceinline__ int div(int n) const { return (int)(((unsigned long long)(unsigned)n * m) >> sh); }
+};
 
 // ---------------------------------------------------------------------------------------------- loaders
-// Concept:  static constexpr bool KCONTIG;  const float* p;  Ctx make(int r) const;  float4 load(const Ctx&, int k) const;
-//   KCONTIG:  load() returns elements (r, k..k+3)          (k is a multiple of 4)
-//   !KCONTIG: load() returns elements (r..r+3, k)          (r is a multiple of 4)
-// Out-of-range rows / k and im2col padding read as zero.  VEC = one 16-byte global load per chunk (needs the
+// Concept:
+//   static constexpr bool KCONTIG;  const float* p;
+//   Ctx  make(int r) const;                 per-row state (KCONTIG) or per-row-chunk state (!KCONTIG), computed once
+//   KCtx kctx(int k, int klimit) const;     per-k state, computed once per K-step (KCONTIG) / per chunk (!KCONTIG)
+//   float4 load(const Ctx&, const KCtx&) const;
+//     KCONTIG:  elements (r, k..k+3)   (k multiple of 4);   !KCONTIG: elements (r..r+3, k)   (r multiple of 4)
+// Rows >= R, k >= klimit and im2col padding read as zero.  VEC = one 16-byte global load per chunk (needs the
 // alignment / divisibility the host checks before picking it); !VEC = four guarded scalar loads.
 
 // Plain matrix: element(r, k) = p[r * ldr + k * ldk].  KC => ldk == 1, otherwise ldr == 1.
@@ -48,36 +69,35 @@ struct MatLoader {
 	const float* p;
 	long ldr, ldk;
 	int R, K;
-	struct Ctx { const float* base; int r; };
+	void finish() {}
+	struct Ctx { long off; int r; };
+	struct KCtx { long off; int k, klimit; };
 	__device__ __forceinline__ Ctx make(int r) const
 	{
 		Ctx c;
 		c.r = r;
-		c.base = p + (KC ? (long)r * ldr : (long)r);
+		c.off = KC ? (long)r * ldr : (long)r;
 		return c;
 	}
-	__device__ __forceinline__ float4 load(const Ctx& c, int k) const
+	__device__ __forceinline__ KCtx kctx(int k, int klimit) const
 	{
-		if (KC) {
-			if (c.r >= R || k >= K) return f4zero();
-			if (VEC) return *(const float4*)(c.base + k);
-			float4 v = f4zero();
-			v.x = c.base[k];
-			if (k + 1 < K) v.y = c.base[k + 1];
-			if (k + 2 < K) v.z = c.base[k + 2];
-			if (k + 3 < K) v.w = c.base[k + 3];
-			return v;
-		} else {
-			if (c.r >= R || k >= K) return f4zero();
-			const float* q = c.base + (long)k * ldk;
-			if (VEC) return *(const float4*)q;
-			float4 v = f4zero();
-			v.x = q[0];
-			if (c.r + 1 < R) v.y = q[1];
-			if (c.r + 2 < R) v.z = q[2];
-			if (c.r + 3 < R) v.w = q[3];
-			return v;
+		KCtx x;
+		x.k = k; x.klimit = klimit;
+		x.off = KC ? (long)k : (long)k * ldk;
+		return x;
+	}
+	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
+	{
+		const bool ok = c.r < R && x.k < x.klimit;
+		if (VEC) return f4sel(ok, *(const float4*)(p + (ok ? c.off + x.off : 0)));
+		float v[4];
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			const bool oke = ok && (KC ? x.k + e < x.klimit : c.r + e < R);
+			const float u = p[oke ? c.off + x.off + e : 0];
+			v[e] = oke ? u : 0.f;
 		}
+		return make_float4(v[0], v[1], v[2], v[3]);
 	}
 };
 
@@ -86,6 +106,8 @@ struct MatLoader {
 //   t_y = oy * my + oy_off + i * ty ;  source y = t_y / dv_y, valid iff t_y >= 0, t_y % dv_y == 0, y < H   (same for x)
 //   forward: my = stride, oy_off = -border, ty = +dilation, dv = 1
 //   dgrad:   my = 1, oy_off = +border, ty = -dilation, dv = stride
+// VEC: one 16-byte load per chunk (C % 4 == 0 keeps a chunk inside one tap); !VEC: the four k's of a chunk are resolved
+// one by one (they may straddle taps: conv1_1 has C = 3).
 template <bool VEC>
 struct Im2colKC {
 	static constexpr bool KCONTIG = true;
@@ -96,51 +118,74 @@ struct Im2colKC {
 	int OW, OHW, M;
 	int C, KWC, K;
 	int my, mx, oy_off, ox_off, ty, tx, dv_y, dv_x;
-	struct Ctx { const float* base; int iy0, ix0; };
+	FastDiv d_ohw, d_ow, d_kwc, d_c, d_dvy, d_dvx;
+	void finish() { d_ohw.init(OHW); d_ow.init(OW); d_kwc.init(KWC); d_c.init(C); d_dvy.init(dv_y); d_dvx.init(dv_x); }
+	struct Ctx { long base; int iy0, ix0; };
+	struct K1 { int dy, dx, ch; bool ok; };
+	struct KCtx { K1 e[VEC ? 1 : 4]; };
 	__device__ __forceinline__ Ctx make(int m) const
 	{
 		Ctx c;
-		if (m >= M) { c.base = 0; c.iy0 = 0; c.ix0 = 0; return c; }
-		const int n = m / OHW;
+		if (m >= M) { c.base = 0; c.iy0 = -(1 << 28); c.ix0 = -(1 << 28); return c; } // every tap fails the y >= 0 test
+		const int n = d_ohw.div(m);
 		const int rem = m - n * OHW;
-		const int oy = rem / OW;
+		const int oy = d_ow.div(rem);
 		const int ox = rem - oy * OW;
-		c.base = p + (long)n * s_n;
+		c.base = (long)n * s_n;
 		c.iy0 = oy * my + oy_off;
 		c.ix0 = ox * mx + ox_off;
 		return c;
 	}
-	__device__ __forceinline__ float elem(const Ctx& c, int k) const
+	__device__ __forceinline__ K1 k1(int k, int klimit) const
 	{
-		if (k >= K) return 0.f;
-		const int i = k / KWC;
-		const int r = k - i * KWC;
-		const int j = r / C;
-		const int ch = r - j * C;
-		int y = c.iy0 + i * ty, x = c.ix0 + j * tx;
-		if (y < 0 || x < 0) return 0.f;
-		if (dv_y != 1) { if (y % dv_y) return 0.f; y /= dv_y; }
-		if (dv_x != 1) { if (x % dv_x) return 0.f; x /= dv_x; }
-		if (y >= H || x >= W) return 0.f;
-		return c.base[(long)y * s_h + (long)x * s_w + ch];
+		K1 x;
+		x.ok = k < klimit;
+		const int kk = x.ok ? k : 0;
+		const int i = d_kwc.div(kk);
+		const int r = kk - i * KWC;
+		const int j = d_c.div(r);
+		x.ch = r - j * C;
+		x.dy = i * ty;
+		x.dx = j * tx;
+		return x;
 	}
-	__device__ __forceinline__ float4 load(const Ctx& c, int k) const
+	__device__ __forceinline__ KCtx kctx(int k, int klimit) const
 	{
-		if (!c.base) return f4zero();
-		if (VEC) {
-			if (k >= K) return f4zero();
-			const int i = k / KWC;
-			const int r = k - i * KWC;
-			const int j = r / C;
-			const int ch = r - j * C;
-			int y = c.iy0 + i * ty, x = c.ix0 + j * tx;
-			if (y < 0 || x < 0) return f4zero();
-			if (dv_y != 1) { if (y % dv_y) return f4zero(); y /= dv_y; }
-			if (dv_x != 1) { if (x % dv_x) return f4zero(); x /= dv_x; }
-			if (y >= H || x >= W) return f4zero();
-			return *(const float4*)(c.base + (long)y * s_h + (long)x * s_w + ch);
+		KCtx x;
+#pragma unroll
+		for (int e = 0; e < (VEC ? 1 : 4); e++) x.e[e] = k1(k + e, klimit);
+		return x;
+	}
+	__device__ __forceinline__ bool locate(const Ctx& c, const K1& x, long& off) const
+	{
+		int y = c.iy0 + x.dy, xx = c.ix0 + x.dx;
+		bool ok = x.ok && y >= 0 && xx >= 0;
+		if (dv_y != 1 || dv_x != 1) { // wave-uniform: strided dgrad only
+			const int yy = ok ? y : 0, xq = ok ? xx : 0;
+			const int qy = d_dvy.div(yy), qx = d_dvx.div(xq);
+			ok = ok && qy * dv_y == yy && qx * dv_x == xq;
+			y = qy; xx = qx;
 		}
-		return make_float4(elem(c, k), elem(c, k + 1), elem(c, k + 2), elem(c, k + 3));
+		ok = ok && y < H && xx < W;
+		off = ok ? c.base + (long)(y * s_h + xx * s_w + x.ch) : 0; // one image spans < 2^31 elements (host-checked)
+		return ok;
+	}
+	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
+	{
+		if (VEC) {
+			long off;
+			const bool ok = locate(c, x.e[0], off);
+			return f4sel(ok, *(const float4*)(p + off));
+		}
+		float v[4];
+#pragma unroll
+		for (int e = 0; e < (VEC ? 1 : 4); e++) {
+			long off;
+			const bool ok = locate(c, x.e[e], off);
+			const float u = p[off];
+			v[e] = ok ? u : 0.f;
+		}
+		return make_float4(v[0], v[1], v[2], v[3]);
 	}
 };
 
@@ -151,21 +196,33 @@ struct WgtDgradNC {
 	const float* p;
 	long ko_stride; // kh*kw*C
 	int C, Ko, K;   // K = kh*kw*Ko
+	FastDiv d_ko;
+	void finish() { d_ko.init(Ko); }
 	struct Ctx { int c; };
+	struct KCtx { long off; bool ok; };
 	__device__ __forceinline__ Ctx make(int c) const { Ctx x; x.c = c; return x; }
-	__device__ __forceinline__ float4 load(const Ctx& c, int k) const
+	__device__ __forceinline__ KCtx kctx(int k, int klimit) const
 	{
-		if (k >= K || c.c >= C) return f4zero();
-		const int tap = k / Ko;
-		const int ko = k - tap * Ko;
-		const float* q = p + (long)ko * ko_stride + (long)tap * C + c.c;
-		if (VEC) return *(const float4*)q;
-		float4 v = f4zero();
-		v.x = q[0];
-		if (c.c + 1 < C) v.y = q[1];
-		if (c.c + 2 < C) v.z = q[2];
-		if (c.c + 3 < C) v.w = q[3];
-		return v;
+		KCtx x;
+		x.ok = k < klimit;
+		const int kk = x.ok ? k : 0;
+		const int tap = d_ko.div(kk);
+		const int ko = kk - tap * Ko;
+		x.off = (long)ko * ko_stride + (long)tap * C;
+		return x;
+	}
+	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
+	{
+		const bool ok = x.ok && c.c < C;
+		if (VEC) return f4sel(ok, *(const float4*)(p + (ok ? x.off + c.c : 0)));
+		float v[4];
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			const bool oke = ok && c.c + e < C;
+			const float u = p[oke ? x.off + c.c + e : 0];
+			v[e] = oke ? u : 0.f;
+		}
+		return make_float4(v[0], v[1], v[2], v[3]);
 	}
 };
 
@@ -180,13 +237,16 @@ struct Im2colNC {
 	int OW, OHW;
 	int C, KWC, NN, K; // NN = kh*kw*C, K = N*OH*OW
 	int sy, sx, py, px, dy, dx;
-	struct Ctx { int nn; int off_y[4], off_x[4], ch[4]; }; // per column (i*dy - py, j*dx - px, c)
+	FastDiv d_ohw, d_ow;
+	void finish() { d_ohw.init(OHW); d_ow.init(OW); }
+	struct Ctx { int nn; int off_y[VEC ? 1 : 4], off_x[VEC ? 1 : 4], ch[VEC ? 1 : 4]; }; // per column (i*dy - py, j*dx - px, c)
+	struct KCtx { long base; int by, bx; bool ok; };
 	__device__ __forceinline__ Ctx make(int nn) const
 	{
 		Ctx c;
 		c.nn = nn;
 #pragma unroll
-		for (int e = 0; e < 4; e++) {
+		for (int e = 0; e < (VEC ? 1 : 4); e++) { // VEC: the four columns share a tap and are channel-consecutive
 			const int q = nn + e;
 			const int i = q / KWC;
 			const int r = q - i * KWC;
@@ -194,29 +254,37 @@ struct Im2colNC {
 			c.off_y[e] = i * dy - py;
 			c.off_x[e] = j * dx - px;
 			c.ch[e] = r - j * C;
-			if (VEC) break; // VEC: the four columns share a tap and are channel-consecutive
 		}
 		return c;
 	}
-	__device__ __forceinline__ float4 load(const Ctx& c, int k) const
+	__device__ __forceinline__ KCtx kctx(int k, int klimit) const
 	{
-		if (k >= K || c.nn >= NN) return f4zero();
-		const int n = k / OHW;
-		const int rem = k - n * OHW;
-		const int oy = rem / OW;
+		KCtx x;
+		x.ok = k < klimit;
+		const int kk = x.ok ? k : 0;
+		const int n = d_ohw.div(kk);
+		const int rem = kk - n * OHW;
+		const int oy = d_ow.div(rem);
 		const int ox = rem - oy * OW;
-		const float* base = p + (long)n * s_n;
-		const int by = oy * sy, bx = ox * sx;
+		x.base = (long)n * s_n;
+		x.by = oy * sy;
+		x.bx = ox * sx;
+		return x;
+	}
+	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
+	{
 		if (VEC) {
-			const int y = by + c.off_y[0], x = bx + c.off_x[0];
-			if (y < 0 || x < 0 || y >= H || x >= W) return f4zero();
-			return *(const float4*)(base + (long)y * s_h + (long)x * s_w + c.ch[0]);
+			const int y = x.by + c.off_y[0], xx = x.bx + c.off_x[0];
+			const bool ok = x.ok && c.nn < NN && y >= 0 && xx >= 0 && y < H && xx < W;
+			return f4sel(ok, *(const float4*)(p + (ok ? x.base + (long)(y * s_h + xx * s_w + c.ch[0]) : 0)));
 		}
 		float v[4];
 #pragma unroll
-		for (int e = 0; e < 4; e++) {
-			const int y = by + c.off_y[e], x = bx + c.off_x[e];
-			v[e] = (c.nn + e < NN && y >= 0 && x >= 0 && y < H && x < W) ? base[(long)y * s_h + (long)x * s_w + c.ch[e]] : 0.f;
+		for (int e = 0; e < (VEC ? 1 : 4); e++) {
+			const int y = x.by + c.off_y[e], xx = x.bx + c.off_x[e];
+			const bool ok = x.ok && c.nn + e < NN && y >= 0 && xx >= 0 && y < H && xx < W;
+			const float u = p[ok ? x.base + (long)(y * s_h + xx * s_w + c.ch[e]) : 0];
+			v[e] = ok ? u : 0.f;
 		}
 		return make_float4(v[0], v[1], v[2], v[3]);
 	}
@@ -255,27 +323,54 @@ struct EpiPartial {
 };
 
 // ---------------------------------------------------------------------------------------------- kernel
-template <class L>
-__device__ __forceinline__ void gemm_stage_store(float* lds, const float4 (&r)[4], int t)
-{
+// The NCH chunks (of 4 floats) one thread stages for an operand tile of ROWS = 32 * NCH rows at K offset kbase.
+//   KCONTIG:  chunk id = t + 256*jj -> row = id >> 3 (differs per jj), k chunk = (id & 7) * 4 (same for all jj)
+//   !KCONTIG: chunk id = t + 256*jj -> k = id / (ROWS/4) (differs per jj), row chunk = (id % (ROWS/4)) * 4 (same for all jj)
+template <class L, int NCH>
+struct TileFetch {
+	static constexpr int ROWS = NCH * 32;
+	static constexpr int NCTX = L::KCONTIG ? NCH : 1;
+	typename L::Ctx ctx[NCTX];
+	int koff[NCH];
+	__device__ __forceinline__ void init(const L& l, int row0, int t)
+	{
 #pragma unroll
-	for (int jj = 0; jj < 4; jj++) {
-		const int id = t + GEMM_THREADS * jj;
-		if (L::KCONTIG) {
-			const int row = id >> 3, kc = (id & 7) << 2;
-			*(float4*)(lds + row * GEMM_LDK + kc) = r[jj];
-		} else {
-			const int k = id >> 5, rc = (id & 31) << 2;
-			*(float4*)(lds + k * GEMM_LDR + rc) = r[jj];
+		for (int jj = 0; jj < NCH; jj++) {
+			const int id = t + GEMM_THREADS * jj;
+			if (L::KCONTIG) { ctx[jj % NCTX] = l.make(row0 + (id >> 3)); koff[jj] = (id & 7) << 2; }
+			else { if (jj == 0) ctx[0] = l.make(row0 + ((id % (ROWS / 4)) << 2)); koff[jj] = id / (ROWS / 4); }
 		}
 	}
-}
+	__device__ __forceinline__ void fetch(const L& l, int kbase, int klimit, float4 (&r)[NCH]) const
+	{
+		if (L::KCONTIG) {
+			const typename L::KCtx kc = l.kctx(kbase + koff[0], klimit);
+#pragma unroll
+			for (int jj = 0; jj < NCH; jj++) r[jj] = l.load(ctx[jj % NCTX], kc);
+		} else {
+#pragma unroll
+			for (int jj = 0; jj < NCH; jj++) r[jj] = l.load(ctx[0], l.kctx(kbase + koff[jj], klimit));
+		}
+	}
+	__device__ __forceinline__ void store(float* lds, const float4 (&r)[NCH], int t) const
+	{
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) {
+			const int id = t + GEMM_THREADS * jj;
+			if (L::KCONTIG) *(float4*)(lds + (id >> 3) * GEMM_LDK + ((id & 7) << 2)) = r[jj];
+			else *(float4*)(lds + (id / (ROWS / 4)) * ROWS + ((id % (ROWS / 4)) << 2)) = r[jj];
+		}
+	}
+};
 
-// grid: x = tiles (XCD-swizzled), y = split-K slices, z = batch / conv group.
-template <class LA, class LB, class EPI>
+// grid: x = tiles (XCD-swizzled), y = split-K slices, z = batch / conv group.  WM / WN = 32x32 MFMA tiles per wave.
+template <class LA, class LB, class EPI, int WM, int WN>
 __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff)
 {
-	__shared__ __attribute__((aligned(16))) float lds[2][2][GEMM_TILE_FLOATS]; // [buffer][A|B]
+	constexpr int BM = 64 * WM, BN = 64 * WN;
+	constexpr int A_FLOATS = LA::KCONTIG ? BM * GEMM_LDK : GEMM_BK * BM;
+	constexpr int B_FLOATS = LB::KCONTIG ? BN * GEMM_LDK : GEMM_BK * BN;
+	__shared__ __attribute__((aligned(16))) float lds[2][A_FLOATS + B_FLOATS]; // [buffer][A | B]
 	const int t = threadIdx.x;
 	const int lane = t & 63, wave = t >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
@@ -291,7 +386,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	}
 	const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 	(void)tiles_m;
-	const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
+	const int m0 = tile_m * BM, n0 = tile_n * BN;
 	la.p += (long)blockIdx.z * a_zoff;
 	lb.p += (long)blockIdx.z * b_zoff;
 	epi.c += (long)blockIdx.z * c_zoff;
@@ -299,98 +394,83 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
 	const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
 
-	// Per-thread gather contexts. KCONTIG: 4 rows (id>>3), one k chunk (id&7). !KCONTIG: one row chunk (id&31), 4 k's (id>>5).
-	constexpr int NCA = LA::KCONTIG ? 4 : 1, NCB = LB::KCONTIG ? 4 : 1;
-	typename LA::Ctx ca[NCA];
-	typename LB::Ctx cb[NCB];
-	int ka[4], kb[4];
+	TileFetch<LA, WM * 2> fa;
+	TileFetch<LB, WN * 2> fb;
+	fa.init(la, m0, t);
+	fb.init(lb, n0, t);
+	floatx16 acc[WM][WN];
 #pragma unroll
-	for (int jj = 0; jj < 4; jj++) {
-		const int id = t + GEMM_THREADS * jj;
-		if (LA::KCONTIG) { ca[jj % NCA] = la.make(m0 + (id >> 3)); ka[jj] = (id & 7) << 2; }
-		else { if (jj == 0) ca[0] = la.make(m0 + ((id & 31) << 2)); ka[jj] = id >> 5; }
-		if (LB::KCONTIG) { cb[jj % NCB] = lb.make(n0 + (id >> 3)); kb[jj] = (id & 7) << 2; }
-		else { if (jj == 0) cb[0] = lb.make(n0 + ((id & 31) << 2)); kb[jj] = id >> 5; }
-	}
-	floatx16 acc[2][2];
+	for (int i = 0; i < WM; i++)
 #pragma unroll
-	for (int i = 0; i < 2; i++)
-#pragma unroll
-		for (int j = 0; j < 2; j++)
+		for (int j = 0; j < WN; j++)
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-	float4 ra[4], rb[4];
-	// k beyond this split's range must read as zero: loaders only know the global K, so clamp here.
-#define NNC_GEMM_FETCH(kt) \
-	do { \
-		const int kbase = k_begin + (kt) * GEMM_BK; \
-		_Pragma("unroll") for (int jj = 0; jj < 4; jj++) { \
-			const int kk_a = kbase + ka[jj]; \
-			const int kk_b = kbase + kb[jj]; \
-			ra[jj] = (kk_a < k_end) ? la.load(ca[jj % NCA], kk_a) : f4zero(); \
-			rb[jj] = (kk_b < k_end) ? lb.load(cb[jj % NCB], kk_b) : f4zero(); \
-		} \
-	} while (0)
-
+	float4 ra[WM * 2], rb[WN * 2];
 	if (nk > 0) {
-		NNC_GEMM_FETCH(0);
-		gemm_stage_store<LA>(lds[0][0], ra, t);
-		gemm_stage_store<LB>(lds[0][1], rb, t);
+		fa.fetch(la, k_begin, k_end, ra);
+		fb.fetch(lb, k_begin, k_end, rb);
+		fa.store(lds[0], ra, t);
+		fb.store(lds[0] + A_FLOATS, rb, t);
 	}
 	__syncthreads();
 	for (int kt = 0; kt < nk; kt++) {
 		const int cur = kt & 1;
-		if (kt + 1 < nk) NNC_GEMM_FETCH(kt + 1);
-		const float* sa = lds[cur][0];
-		const float* sb = lds[cur][1];
+		if (kt + 1 < nk) {
+			fa.fetch(la, k_begin + (kt + 1) * GEMM_BK, k_end, ra);
+			fb.fetch(lb, k_begin + (kt + 1) * GEMM_BK, k_end, rb);
+		}
+		const float* sa = lds[cur];
+		const float* sb = lds[cur] + A_FLOATS;
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
-			float fa[2][4], fb[2][4];
+			float fa_[WM][4], fb_[WN][4];
 #pragma unroll
-			for (int ti = 0; ti < 2; ti++) {
-				const int row = wm * 64 + ti * 32 + li;
+			for (int ti = 0; ti < WM; ti++) {
+				const int row = wm * (32 * WM) + ti * 32 + li;
 				if (LA::KCONTIG) {
 					const float4 v = *(const float4*)(sa + row * GEMM_LDK + 8 * q + 4 * lh);
-					fa[ti][0] = v.x; fa[ti][1] = v.y; fa[ti][2] = v.z; fa[ti][3] = v.w;
+					fa_[ti][0] = v.x; fa_[ti][1] = v.y; fa_[ti][2] = v.z; fa_[ti][3] = v.w;
 				} else {
 #pragma unroll
-					for (int e = 0; e < 4; e++) fa[ti][e] = sa[(8 * q + 4 * lh + e) * GEMM_LDR + row];
+					for (int e = 0; e < 4; e++) fa_[ti][e] = sa[(8 * q + 4 * lh + e) * BM + row];
 				}
-				const int col = wn * 64 + ti * 32 + li;
+			}
+#pragma unroll
+			for (int tj = 0; tj < WN; tj++) {
+				const int col = wn * (32 * WN) + tj * 32 + li;
 				if (LB::KCONTIG) {
 					const float4 v = *(const float4*)(sb + col * GEMM_LDK + 8 * q + 4 * lh);
-					fb[ti][0] = v.x; fb[ti][1] = v.y; fb[ti][2] = v.z; fb[ti][3] = v.w;
+					fb_[tj][0] = v.x; fb_[tj][1] = v.y; fb_[tj][2] = v.z; fb_[tj][3] = v.w;
 				} else {
 #pragma unroll
-					for (int e = 0; e < 4; e++) fb[ti][e] = sb[(8 * q + 4 * lh + e) * GEMM_LDR + col];
+					for (int e = 0; e < 4; e++) fb_[tj][e] = sb[(8 * q + 4 * lh + e) * BN + col];
 				}
 			}
 #pragma unroll
 			for (int e = 0; e < 4; e++)
 #pragma unroll
-				for (int ti = 0; ti < 2; ti++)
+				for (int ti = 0; ti < WM; ti++)
 #pragma unroll
-					for (int tj = 0; tj < 2; tj++)
-						acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ti][e], fb[tj][e], acc[ti][tj], 0, 0, 0);
+					for (int tj = 0; tj < WN; tj++)
+						acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[ti][e], fb_[tj][e], acc[ti][tj], 0, 0, 0);
 		}
 		if (kt + 1 < nk) {
-			gemm_stage_store<LA>(lds[cur ^ 1][0], ra, t);
-			gemm_stage_store<LB>(lds[cur ^ 1][1], rb, t);
+			fa.store(lds[cur ^ 1], ra, t);
+			fb.store(lds[cur ^ 1] + A_FLOATS, rb, t);
 		}
 		__syncthreads();
 	}
-#undef NNC_GEMM_FETCH
 	// D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
 #pragma unroll
-	for (int ti = 0; ti < 2; ti++)
+	for (int ti = 0; ti < WM; ti++)
 #pragma unroll
-		for (int tj = 0; tj < 2; tj++) {
-			const int n = n0 + wn * 64 + tj * 32 + li;
+		for (int tj = 0; tj < WN; tj++) {
+			const int n = n0 + wn * (32 * WN) + tj * 32 + li;
 #pragma unroll
 			for (int r = 0; r < 16; r++) {
-				const int m = m0 + wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+				const int m = m0 + wm * (32 * WM) + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
 				epi(m, n, acc[ti][tj][r]);
 			}
 		}
