@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--records", default=None, help="also write the per-launch contraction records (name, dims, ms, TFLOP/s) of the roofline leg to this file")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,6 +115,10 @@ def main():
     L.stream_wait(stream)
     recs = L.profile_records()
     L.profile_enable(0)
+    if args.records and rank == 0:
+        with open(args.records, "w") as f:
+            for name, fl, _by, ms, dims in recs:
+                f.write("%-12s M=%-8d N=%-6d K=%-8d Z=%d S=%-3d %9.3f ms %7.2f TFLOP/s  %s\n" % (name.split("|")[0], dims[0], dims[1], dims[2], dims[3], dims[4], ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, name.split("|")[-1][-60:]))
     by = {}
     for name, fl, _by, ms, dims in recs:
         k = by.setdefault(name, [0.0, 0.0, 0])

@@ -58,7 +58,7 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 	const bool vec = (g.Cg % 4 == 0) && aligned16(a.p) && aligned16(w) && a.sw % 4 == 0 && a.sh % 4 == 0 && (a.n == 1 || a.sn % 4 == 0);
 	GemmOut out = { b.p, b.sw, 1, bias, 1.f, 0 };
 #define CONV_FWD(VEC) do { \
-		Im2colKC<VEC> la; \
+		Im2colKC<VEC, false> la; \
 		la.p = a.p; la.s_n = a.sn; la.s_h = (int)a.sh; la.s_w = (int)a.sw; la.H = g.H; la.W = g.W; \
 		la.OW = g.OW; la.OHW = g.OH * g.OW; la.M = (int)M; la.C = g.Cg; la.KWC = g.kw * g.Cg; la.K = Kred; \
 		la.my = g.sy; la.mx = g.sx; la.oy_off = -g.pby; la.ox_off = -g.pbx; la.ty = g.dy; la.tx = g.dx; la.dv_y = 1; la.dv_x = 1; \
@@ -79,8 +79,8 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const bool vec = (g.Kg % 4 == 0) && (g.Cg % 4 == 0) && aligned16(gr.p) && aligned16(w) && gr.sw % 4 == 0 && gr.sh % 4 == 0 && (gr.n == 1 || gr.sn % 4 == 0);
 	GemmOut out = { h.p, h.sw, 1, 0, 1.f, 0 };
-#define CONV_DGRAD(VEC) do { \
-		Im2colKC<VEC> la; \
+#define CONV_DGRAD(VEC, STRIDED) do { \
+		Im2colKC<VEC, STRIDED> la; \
 		la.p = gr.p; la.s_n = gr.sn; la.s_h = (int)gr.sh; la.s_w = (int)gr.sw; la.H = g.OH; la.W = g.OW; \
 		la.OW = g.W; la.OHW = g.H * g.W; la.M = (int)M; la.C = g.Kg; la.KWC = g.kw * g.Kg; la.K = Kred; \
 		la.my = 1; la.mx = 1; la.oy_off = g.pby; la.ox_off = g.pbx; la.ty = -g.dy; la.tx = -g.dx; la.dv_y = g.sy; la.dv_x = g.sx; \
@@ -88,7 +88,8 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 		lb.p = w; lb.ko_stride = (long)g.kh * g.kw * g.Cg; lb.C = g.Cg; lb.Ko = g.Kg; lb.K = Kred; \
 		return gemm_run("conv_dgrad", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, 1, flags, ctx); \
 	} while (0)
-	if (vec) CONV_DGRAD(true); else CONV_DGRAD(false);
+	if (g.sy != 1 || g.sx != 1) { if (vec) CONV_DGRAD(true, true); else CONV_DGRAD(false, true); }
+	else { if (vec) CONV_DGRAD(true, false); else CONV_DGRAD(false, false); }
 #undef CONV_DGRAD
 }
 

@@ -100,6 +100,7 @@ static inline bool image4(const ccv_nnc_tensor_t* t, Image4* o)
 // The HIP stream a command must enqueue on, and that stream's scratch memory.
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx);
 void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size);
+const float* zero_page_of(const ccv_nnc_stream_context_t* ctx); // 256 zero bytes in the HBM of the device `ctx` launches on
 int device_cu_count(void);
 void note_kernel(const char* name);
 

@@ -74,6 +74,29 @@ void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size)
 	return ccv_nnc_stream_compat_get_workspace(ctx, size, CCV_TENSOR_GPU_MEMORY);
 }
 
+const float* zero_page_of(const ccv_nnc_stream_context_t* ctx)
+{
+	static void* pages[MAX_DEVICES];
+	static pthread_mutex_t mutex = PTHREAD_MUTEX_INITIALIZER;
+	const int device = (ctx && CCV_STREAM_GET_CONTEXT(ctx->type) == CCV_STREAM_CONTEXT_GPU) ? bind(ctx)->device : current_device();
+	assert(device >= 0 && device < MAX_DEVICES);
+	if (!pages[device]) {
+		pthread_mutex_lock(&mutex);
+		if (!pages[device]) {
+			const int prev = current_device();
+			void* ptr = 0;
+			HIP_ENFORCE(hipSetDevice(device));
+			HIP_ENFORCE(hipMalloc(&ptr, 256));
+			HIP_ENFORCE(hipMemset(ptr, 0, 256));
+			HIP_ENFORCE(hipDeviceSynchronize());
+			HIP_ENFORCE(hipSetDevice(prev));
+			pages[device] = ptr;
+		}
+		pthread_mutex_unlock(&mutex);
+	}
+	return (const float*)pages[device];
+}
+
 int device_cu_count(void)
 {
 	static int cus = 0;

@@ -92,6 +92,10 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
 	la.finish();
 	lb.finish();
+	// masked lanes read this device's page of zeros, addressed relative to each operand's own base (mfma_gemm.h)
+	const float* zp = zero_page_of(ctx);
+	la.zoff = zp - la.p;
+	lb.zoff = zp - lb.p;
 	int wm = 2, wn = 2;
 	gemm_pick_tile(M, N, &wm, &wn);
 	if (wm == 2 && wn == 2) return gemm_run_tile<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);

@@ -12,9 +12,11 @@
 // dimension is 64 channels so no MFMA issues on padding), BK = 32, 256 threads = 4 waves (2x2), each wave owns
 // WM x WN MFMA tiles of 32x32.  Operand tiles are staged HBM -> registers -> LDS (double buffered, one barrier per
 // K-step; the global loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them).
-// Gathers are BRANCH-FREE: every lane always issues its 16-byte load (address clamped to the operand base when the
-// element is padding / out of range) and selects zero afterwards, so the compiler can batch all loads of a K-step in
-// front of the MFMA block; integer divisions by runtime geometry use precomputed multiply-shift constants.
+// Gathers are BRANCH-FREE and SELECT-FREE: every lane always issues its 16-byte load; a lane whose element is padding /
+// out of range points its load at a 16-byte page of zeros instead, so nothing consumes the loaded registers until the
+// LDS store AFTER the MFMA block -- the HBM/L2 latency of tile t+1 hides behind the 64 MFMAs of tile t (a select on the
+// loaded value would force the s_waitcnt in front of the MFMAs).  Integer divisions by runtime geometry use precomputed
+// multiply-shift constants; per-row and per-k address parts are computed once and added per chunk.
 // LDS images:
 //   k-contiguous operand:   [rows][36]      (row stride 36 floats: ds_read_b128 by 16-lane groups is conflict free,
 //                                            36*r mod 64 hits 16 distinct 4-bank slots for 16 distinct rows)
@@ -34,8 +36,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int GEMM_BK = 32, GEMM_THREADS = 256;
 constexpr int GEMM_LDK = 36; // row stride of a k-contiguous LDS image
 
-__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ float4 f4sel(bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); }
+// What a masked-off lane loads instead of its element (see "SELECT-FREE" above): every loader carries `zoff`, the element
+// offset from its own base pointer `p` to a 16-byte-aligned page of zeros in the same device's HBM (device_rt.cpp), so a
+// masked lane only swaps the OFFSET and the access stays a plain global_load off `p`.
+__device__ __forceinline__ float4 ld16(const float* q) { return *(const float4*)q; }
 
 // Exact n / d for 0 <= n < 2^31, d >= 1 as multiply + shift (Granlund-Montgomery): m = ceil(2^(31+s) / d), s = ceil(log2 d).
 struct FastDiv {
@@ -57,16 +61,18 @@ struct FastDiv {
 //   static constexpr bool KCONTIG;  const float* p;
 //   Ctx  make(int r) const;                 per-row state (KCONTIG) or per-row-chunk state (!KCONTIG), computed once
 //   KCtx kctx(int k, int klimit) const;     per-k state, computed once per K-step (KCONTIG) / per chunk (!KCONTIG)
-//   float4 load(const Ctx&, const KCtx&) const;
+//   long   offset(const Ctx&, const KCtx&) const;   VEC only: element offset from p of the chunk (or zoff when masked)
+//   float4 load(const Ctx&, const KCtx&) const;     !VEC only: the chunk gathered by four scalar loads
 //     KCONTIG:  elements (r, k..k+3)   (k multiple of 4);   !KCONTIG: elements (r..r+3, k)   (r multiple of 4)
-// Rows >= R, k >= klimit and im2col padding read as zero.  VEC = one 16-byte global load per chunk (needs the
-// alignment / divisibility the host checks before picking it); !VEC = four guarded scalar loads.
+// Rows >= R, k >= klimit and im2col padding read as zero (from the page of zeros).  VEC = one 16-byte global load per chunk
+// (needs the alignment / divisibility the host checks before picking it); !VEC = four scalar loads.
 
 // Plain matrix: element(r, k) = p[r * ldr + k * ldk].  KC => ldk == 1, otherwise ldr == 1.
 template <bool KC, bool VEC>
 struct MatLoader {
-	static constexpr bool KCONTIG = KC;
+	static constexpr bool KCONTIG = KC, VECTOR = VEC;
 	const float* p;
+	long zoff;
 	long ldr, ldk;
 	int R, K;
 	void finish() {}
@@ -86,16 +92,19 @@ struct MatLoader {
 		x.off = KC ? (long)k : (long)k * ldk;
 		return x;
 	}
+	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const
+	{
+		const bool ok = (c.r < R) & (x.k < x.klimit);
+		return ok ? c.off + x.off : zoff;
+	}
 	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
 	{
-		const bool ok = c.r < R && x.k < x.klimit;
-		if (VEC) return f4sel(ok, *(const float4*)(p + (ok ? c.off + x.off : 0)));
+		const bool ok = (c.r < R) & (x.k < x.klimit);
 		float v[4];
 #pragma unroll
 		for (int e = 0; e < 4; e++) {
-			const bool oke = ok && (KC ? x.k + e < x.klimit : c.r + e < R);
-			const float u = p[oke ? c.off + x.off + e : 0];
-			v[e] = oke ? u : 0.f;
+			const bool oke = ok & (KC ? x.k + e < x.klimit : c.r + e < R);
+			v[e] = p[oke ? c.off + x.off + e : zoff];
 		}
 		return make_float4(v[0], v[1], v[2], v[3]);
 	}
@@ -105,13 +114,15 @@ struct MatLoader {
 // pixels m = (n, oy, ox).  Serves conv forward (source = a) and conv dgrad (source = g, taps walked backwards).
 //   t_y = oy * my + oy_off + i * ty ;  source y = t_y / dv_y, valid iff t_y >= 0, t_y % dv_y == 0, y < H   (same for x)
 //   forward: my = stride, oy_off = -border, ty = +dilation, dv = 1
-//   dgrad:   my = 1, oy_off = +border, ty = -dilation, dv = stride
+//   dgrad:   my = 1, oy_off = +border, ty = -dilation, dv = stride          (STRIDED <=> some dv != 1)
+// Address = row part (n, oy, ox: once per tile) + tap part (i, j, ch: once per K-step) when !STRIDED.
 // VEC: one 16-byte load per chunk (C % 4 == 0 keeps a chunk inside one tap); !VEC: the four k's of a chunk are resolved
 // one by one (they may straddle taps: conv1_1 has C = 3).
-template <bool VEC>
+template <bool VEC, bool STRIDED>
 struct Im2colKC {
-	static constexpr bool KCONTIG = true;
+	static constexpr bool KCONTIG = true, VECTOR = VEC;
 	const float* p;
+	long zoff;
 	long s_n;
 	int s_h, s_w;
 	int H, W;
@@ -120,8 +131,8 @@ struct Im2colKC {
 	int my, mx, oy_off, ox_off, ty, tx, dv_y, dv_x;
 	FastDiv d_ohw, d_ow, d_kwc, d_c, d_dvy, d_dvx;
 	void finish() { d_ohw.init(OHW); d_ow.init(OW); d_kwc.init(KWC); d_c.init(C); d_dvy.init(dv_y); d_dvx.init(dv_x); }
-	struct Ctx { long base; int iy0, ix0; };
-	struct K1 { int dy, dx, ch; bool ok; };
+	struct Ctx { long base; int iy0, ix0; }; // !STRIDED: base already includes iy0 * s_h + ix0 * s_w
+	struct K1 { int dy, dx, off; bool ok; }; // !STRIDED: off = dy * s_h + dx * s_w + ch;  STRIDED: off = ch
 	struct KCtx { K1 e[VEC ? 1 : 4]; };
 	__device__ __forceinline__ Ctx make(int m) const
 	{
@@ -131,9 +142,10 @@ struct Im2colKC {
 		const int rem = m - n * OHW;
 		const int oy = d_ow.div(rem);
 		const int ox = rem - oy * OW;
-		c.base = (long)n * s_n;
 		c.iy0 = oy * my + oy_off;
 		c.ix0 = ox * mx + ox_off;
+		c.base = (long)n * s_n;
+		if (!STRIDED) c.base += (long)(c.iy0 * s_h + c.ix0 * s_w); // one image spans < 2^31 elements (host-checked)
 		return c;
 	}
 	__device__ __forceinline__ K1 k1(int k, int klimit) const
@@ -144,9 +156,10 @@ struct Im2colKC {
 		const int i = d_kwc.div(kk);
 		const int r = kk - i * KWC;
 		const int j = d_c.div(r);
-		x.ch = r - j * C;
+		const int ch = r - j * C;
 		x.dy = i * ty;
 		x.dx = j * tx;
+		x.off = STRIDED ? ch : x.dy * s_h + x.dx * s_w + ch;
 		return x;
 	}
 	__device__ __forceinline__ KCtx kctx(int k, int klimit) const
@@ -156,35 +169,25 @@ struct Im2colKC {
 		for (int e = 0; e < (VEC ? 1 : 4); e++) x.e[e] = k1(k + e, klimit);
 		return x;
 	}
-	__device__ __forceinline__ bool locate(const Ctx& c, const K1& x, long& off) const
+	__device__ __forceinline__ long locate(const Ctx& c, const K1& x) const
 	{
-		int y = c.iy0 + x.dy, xx = c.ix0 + x.dx;
-		bool ok = x.ok && y >= 0 && xx >= 0;
-		if (dv_y != 1 || dv_x != 1) { // wave-uniform: strided dgrad only
-			const int yy = ok ? y : 0, xq = ok ? xx : 0;
-			const int qy = d_dvy.div(yy), qx = d_dvx.div(xq);
-			ok = ok && qy * dv_y == yy && qx * dv_x == xq;
-			y = qy; xx = qx;
+		const int y = c.iy0 + x.dy, xx = c.ix0 + x.dx;
+		if (!STRIDED) {
+			const bool ok = x.ok & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+			return ok ? c.base + x.off : zoff;
 		}
-		ok = ok && y < H && xx < W;
-		off = ok ? c.base + (long)(y * s_h + xx * s_w + x.ch) : 0; // one image spans < 2^31 elements (host-checked)
-		return ok;
+		bool ok = x.ok & (y >= 0) & (xx >= 0);
+		const int yy = ok ? y : 0, xq = ok ? xx : 0;
+		const int qy = d_dvy.div(yy), qx = d_dvx.div(xq);
+		ok = ok & (qy * dv_y == yy) & (qx * dv_x == xq) & (qy < H) & (qx < W);
+		return ok ? c.base + (long)(qy * s_h + qx * s_w + x.off) : zoff;
 	}
+	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const { return locate(c, x.e[0]); }
 	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
 	{
-		if (VEC) {
-			long off;
-			const bool ok = locate(c, x.e[0], off);
-			return f4sel(ok, *(const float4*)(p + off));
-		}
 		float v[4];
 #pragma unroll
-		for (int e = 0; e < (VEC ? 1 : 4); e++) {
-			long off;
-			const bool ok = locate(c, x.e[e], off);
-			const float u = p[off];
-			v[e] = ok ? u : 0.f;
-		}
+		for (int e = 0; e < (VEC ? 1 : 4); e++) v[e] = p[locate(c, x.e[e])];
 		return make_float4(v[0], v[1], v[2], v[3]);
 	}
 };
@@ -192,8 +195,9 @@ struct Im2colKC {
 // conv dgrad weights: B(k = (tap, ko), n = c) = w[ko][tap][c]  (n contiguous).
 template <bool VEC>
 struct WgtDgradNC {
-	static constexpr bool KCONTIG = false;
+	static constexpr bool KCONTIG = false, VECTOR = VEC;
 	const float* p;
+	long zoff;
 	long ko_stride; // kh*kw*C
 	int C, Ko, K;   // K = kh*kw*Ko
 	FastDiv d_ko;
@@ -211,26 +215,31 @@ struct WgtDgradNC {
 		x.off = (long)ko * ko_stride + (long)tap * C;
 		return x;
 	}
+	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const
+	{
+		const bool ok = x.ok & (c.c < C);
+		return ok ? x.off + c.c : zoff;
+	}
 	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
 	{
-		const bool ok = x.ok && c.c < C;
-		if (VEC) return f4sel(ok, *(const float4*)(p + (ok ? x.off + c.c : 0)));
+		const bool ok = x.ok & (c.c < C);
 		float v[4];
 #pragma unroll
 		for (int e = 0; e < 4; e++) {
-			const bool oke = ok && c.c + e < C;
-			const float u = p[oke ? x.off + c.c + e : 0];
-			v[e] = oke ? u : 0.f;
+			const bool oke = ok & (c.c + e < C);
+			v[e] = p[oke ? x.off + c.c + e : zoff];
 		}
 		return make_float4(v[0], v[1], v[2], v[3]);
 	}
 };
 
 // conv wgrad activations: B(k = pixel (n, oy, ox), nn = (tap_y, tap_x, c)) = a[n, oy*sy - py + i*dy, ox*sx - px + j*dx, c].
+// Address = pixel part (once per k) + column part (tap and channel: once per tile).
 template <bool VEC>
 struct Im2colNC {
-	static constexpr bool KCONTIG = false;
+	static constexpr bool KCONTIG = false, VECTOR = VEC;
 	const float* p;
+	long zoff;
 	long s_n;
 	int s_h, s_w;
 	int H, W;
@@ -239,12 +248,11 @@ struct Im2colNC {
 	int sy, sx, py, px, dy, dx;
 	FastDiv d_ohw, d_ow;
 	void finish() { d_ohw.init(OHW); d_ow.init(OW); }
-	struct Ctx { int nn; int off_y[VEC ? 1 : 4], off_x[VEC ? 1 : 4], ch[VEC ? 1 : 4]; }; // per column (i*dy - py, j*dx - px, c)
-	struct KCtx { long base; int by, bx; bool ok; };
+	struct Ctx { int off_y[VEC ? 1 : 4], off_x[VEC ? 1 : 4], off[VEC ? 1 : 4]; bool ok[VEC ? 1 : 4]; }; // per column: i*dy - py, j*dx - px, their offset + c
+	struct KCtx { long base; int by, bx; bool ok; }; // base = n * s_n + by * s_h + bx * s_w
 	__device__ __forceinline__ Ctx make(int nn) const
 	{
 		Ctx c;
-		c.nn = nn;
 #pragma unroll
 		for (int e = 0; e < (VEC ? 1 : 4); e++) { // VEC: the four columns share a tap and are channel-consecutive
 			const int q = nn + e;
@@ -253,7 +261,8 @@ struct Im2colNC {
 			const int j = r / C;
 			c.off_y[e] = i * dy - py;
 			c.off_x[e] = j * dx - px;
-			c.ch[e] = r - j * C;
+			c.off[e] = c.off_y[e] * s_h + c.off_x[e] * s_w + (r - j * C);
+			c.ok[e] = q < NN;
 		}
 		return c;
 	}
@@ -266,26 +275,23 @@ struct Im2colNC {
 		const int rem = kk - n * OHW;
 		const int oy = d_ow.div(rem);
 		const int ox = rem - oy * OW;
-		x.base = (long)n * s_n;
 		x.by = oy * sy;
 		x.bx = ox * sx;
+		x.base = (long)n * s_n + (long)(x.by * s_h + x.bx * s_w);
 		return x;
 	}
+	__device__ __forceinline__ long locate(const Ctx& c, const KCtx& x, const int e) const
+	{
+		const int y = x.by + c.off_y[e], xx = x.bx + c.off_x[e];
+		const bool ok = x.ok & c.ok[e] & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+		return ok ? x.base + c.off[e] : zoff;
+	}
+	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const { return locate(c, x, 0); }
 	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
 	{
-		if (VEC) {
-			const int y = x.by + c.off_y[0], xx = x.bx + c.off_x[0];
-			const bool ok = x.ok && c.nn < NN && y >= 0 && xx >= 0 && y < H && xx < W;
-			return f4sel(ok, *(const float4*)(p + (ok ? x.base + (long)(y * s_h + xx * s_w + c.ch[0]) : 0)));
-		}
 		float v[4];
 #pragma unroll
-		for (int e = 0; e < (VEC ? 1 : 4); e++) {
-			const int y = x.by + c.off_y[e], xx = x.bx + c.off_x[e];
-			const bool ok = x.ok && c.nn + e < NN && y >= 0 && xx >= 0 && y < H && xx < W;
-			const float u = p[ok ? x.base + (long)(y * s_h + xx * s_w + c.ch[e]) : 0];
-			v[e] = ok ? u : 0.f;
-		}
+		for (int e = 0; e < (VEC ? 1 : 4); e++) v[e] = p[locate(c, x, e)];
 		return make_float4(v[0], v[1], v[2], v[3]);
 	}
 };
@@ -332,6 +338,8 @@ struct TileFetch {
 	static constexpr int NCTX = L::KCONTIG ? NCH : 1;
 	typename L::Ctx ctx[NCTX];
 	int koff[NCH];
+	long off[L::VECTOR ? NCH : 1]; // VECTOR: the chunk offsets prep() resolved for the tile issue() will load
+	int kb, kl;
 	__device__ __forceinline__ void init(const L& l, int row0, int t)
 	{
 #pragma unroll
@@ -341,15 +349,33 @@ struct TileFetch {
 			else { if (jj == 0) ctx[0] = l.make(row0 + ((id % (ROWS / 4)) << 2)); koff[jj] = id / (ROWS / 4); }
 		}
 	}
-	__device__ __forceinline__ void fetch(const L& l, int kbase, int klimit, float4 (&r)[NCH]) const
+	// Address phase of the tile at K offset kbase (pure integer VALU: scheduled into the shadow of the previous tile's MFMAs).
+	__device__ __forceinline__ void prep(const L& l, int kbase, int klimit)
 	{
+		kb = kbase; kl = klimit;
+		if (!L::VECTOR) return;
 		if (L::KCONTIG) {
 			const typename L::KCtx kc = l.kctx(kbase + koff[0], klimit);
+#pragma unroll
+			for (int jj = 0; jj < NCH; jj++) off[L::VECTOR ? jj : 0] = l.offset(ctx[jj % NCTX], kc);
+		} else {
+#pragma unroll
+			for (int jj = 0; jj < NCH; jj++) off[L::VECTOR ? jj : 0] = l.offset(ctx[0], l.kctx(kbase + koff[jj], klimit));
+		}
+	}
+	// Load phase: VECTOR = NCH 16-byte global loads off the prepared offsets and nothing else.
+	__device__ __forceinline__ void issue(const L& l, float4 (&r)[NCH]) const
+	{
+		if (L::VECTOR) {
+#pragma unroll
+			for (int jj = 0; jj < NCH; jj++) r[jj] = ld16(l.p + off[L::VECTOR ? jj : 0]);
+		} else if (L::KCONTIG) {
+			const typename L::KCtx kc = l.kctx(kb + koff[0], kl);
 #pragma unroll
 			for (int jj = 0; jj < NCH; jj++) r[jj] = l.load(ctx[jj % NCTX], kc);
 		} else {
 #pragma unroll
-			for (int jj = 0; jj < NCH; jj++) r[jj] = l.load(ctx[0], l.kctx(kbase + koff[jj], klimit));
+			for (int jj = 0; jj < NCH; jj++) r[jj] = l.load(ctx[0], l.kctx(kb + koff[jj], kl));
 		}
 	}
 	__device__ __forceinline__ void store(float* lds, const float4 (&r)[NCH], int t) const
@@ -362,6 +388,46 @@ struct TileFetch {
 		}
 	}
 };
+
+// One K-step (32 deep) of the wave's WM x WN tiles out of the LDS images sa / sb: 16 * WM * WN MFMAs.
+template <bool AKC, bool BKC, int WM, int WN>
+__device__ __forceinline__ void mfma_kstep(const float* sa, const float* sb, const int row_a, const int col_b, const int lh, floatx16 (&acc)[WM][WN])
+{
+	constexpr int BM = 64 * WM, BN = 64 * WN;
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		float fa_[WM][4], fb_[WN][4];
+#pragma unroll
+		for (int ti = 0; ti < WM; ti++) {
+			const int row = row_a + ti * 32;
+			if (AKC) {
+				const float4 v = *(const float4*)(sa + row * GEMM_LDK + 8 * q + 4 * lh);
+				fa_[ti][0] = v.x; fa_[ti][1] = v.y; fa_[ti][2] = v.z; fa_[ti][3] = v.w;
+			} else {
+#pragma unroll
+				for (int e = 0; e < 4; e++) fa_[ti][e] = sa[(8 * q + 4 * lh + e) * BM + row];
+			}
+		}
+#pragma unroll
+		for (int tj = 0; tj < WN; tj++) {
+			const int col = col_b + tj * 32;
+			if (BKC) {
+				const float4 v = *(const float4*)(sb + col * GEMM_LDK + 8 * q + 4 * lh);
+				fb_[tj][0] = v.x; fb_[tj][1] = v.y; fb_[tj][2] = v.z; fb_[tj][3] = v.w;
+			} else {
+#pragma unroll
+				for (int e = 0; e < 4; e++) fb_[tj][e] = sb[(8 * q + 4 * lh + e) * BN + col];
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < 4; e++)
+#pragma unroll
+			for (int ti = 0; ti < WM; ti++)
+#pragma unroll
+				for (int tj = 0; tj < WN; tj++)
+					acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[ti][e], fb_[tj][e], acc[ti][tj], 0, 0, 0);
+	}
+}
 
 // grid: x = tiles (XCD-swizzled), y = split-K slices, z = batch / conv group.  WM / WN = 32x32 MFMA tiles per wave.
 template <class LA, class LB, class EPI, int WM, int WN>
@@ -387,8 +453,8 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 	(void)tiles_m;
 	const int m0 = tile_m * BM, n0 = tile_n * BN;
-	la.p += (long)blockIdx.z * a_zoff;
-	lb.p += (long)blockIdx.z * b_zoff;
+	la.p += (long)blockIdx.z * a_zoff; la.zoff -= (long)blockIdx.z * a_zoff;
+	lb.p += (long)blockIdx.z * b_zoff; lb.zoff -= (long)blockIdx.z * b_zoff;
 	epi.c += (long)blockIdx.z * c_zoff;
 	const int k_begin = blockIdx.y * k_per_split;
 	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
@@ -406,60 +472,39 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+	const int row_a = wm * (32 * WM) + li, col_b = wn * (32 * WN) + li;
 	float4 ra[WM * 2], rb[WN * 2];
 	if (nk > 0) {
-		fa.fetch(la, k_begin, k_end, ra);
-		fb.fetch(lb, k_begin, k_end, rb);
+		fa.prep(la, k_begin, k_end);
+		fb.prep(lb, k_begin, k_end);
+		fa.issue(la, ra);
+		fb.issue(lb, rb);
 		fa.store(lds[0], ra, t);
 		fb.store(lds[0] + A_FLOATS, rb, t);
+		fa.prep(la, k_begin + GEMM_BK, k_end);
+		fb.prep(lb, k_begin + GEMM_BK, k_end);
 	}
 	__syncthreads();
-	for (int kt = 0; kt < nk; kt++) {
+	// Steady state, three fenced phases per K-step (the fences keep hipcc from sinking the loads below the MFMAs):
+	//   1. issue the global loads of tile kt+1 (addresses already resolved)      -> in flight across phase 2
+	//   2. MFMAs of tile kt out of LDS, with the address VALU of tile kt+2 scheduled into their shadow
+	//   3. wait for the loads, write tile kt+1 to the other LDS buffer, barrier
+	for (int kt = 0; kt + 1 < nk; kt++) {
 		const int cur = kt & 1;
-		if (kt + 1 < nk) {
-			fa.fetch(la, k_begin + (kt + 1) * GEMM_BK, k_end, ra);
-			fb.fetch(lb, k_begin + (kt + 1) * GEMM_BK, k_end, rb);
-		}
-		const float* sa = lds[cur];
-		const float* sb = lds[cur] + A_FLOATS;
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			float fa_[WM][4], fb_[WN][4];
-#pragma unroll
-			for (int ti = 0; ti < WM; ti++) {
-				const int row = wm * (32 * WM) + ti * 32 + li;
-				if (LA::KCONTIG) {
-					const float4 v = *(const float4*)(sa + row * GEMM_LDK + 8 * q + 4 * lh);
-					fa_[ti][0] = v.x; fa_[ti][1] = v.y; fa_[ti][2] = v.z; fa_[ti][3] = v.w;
-				} else {
-#pragma unroll
-					for (int e = 0; e < 4; e++) fa_[ti][e] = sa[(8 * q + 4 * lh + e) * BM + row];
-				}
-			}
-#pragma unroll
-			for (int tj = 0; tj < WN; tj++) {
-				const int col = wn * (32 * WN) + tj * 32 + li;
-				if (LB::KCONTIG) {
-					const float4 v = *(const float4*)(sb + col * GEMM_LDK + 8 * q + 4 * lh);
-					fb_[tj][0] = v.x; fb_[tj][1] = v.y; fb_[tj][2] = v.z; fb_[tj][3] = v.w;
-				} else {
-#pragma unroll
-					for (int e = 0; e < 4; e++) fb_[tj][e] = sb[(8 * q + 4 * lh + e) * BN + col];
-				}
-			}
-#pragma unroll
-			for (int e = 0; e < 4; e++)
-#pragma unroll
-				for (int ti = 0; ti < WM; ti++)
-#pragma unroll
-					for (int tj = 0; tj < WN; tj++)
-						acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[ti][e], fb_[tj][e], acc[ti][tj], 0, 0, 0);
-		}
-		if (kt + 1 < nk) {
-			fa.store(lds[cur ^ 1], ra, t);
-			fb.store(lds[cur ^ 1] + A_FLOATS, rb, t);
-		}
+		fa.issue(la, ra);
+		fb.issue(lb, rb);
+		__builtin_amdgcn_sched_barrier(0);
+		fa.prep(la, k_begin + (kt + 2) * GEMM_BK, k_end);
+		fb.prep(lb, k_begin + (kt + 2) * GEMM_BK, k_end);
+		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN>(lds[cur], lds[cur] + A_FLOATS, row_a, col_b, lh, acc);
+		__builtin_amdgcn_sched_barrier(0);
+		fa.store(lds[cur ^ 1], ra, t);
+		fb.store(lds[cur ^ 1] + A_FLOATS, rb, t);
 		__syncthreads();
+	}
+	if (nk > 0) {
+		const int cur = (nk - 1) & 1;
+		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN>(lds[cur], lds[cur] + A_FLOATS, row_a, col_b, lh, acc);
 	}
 	// D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
