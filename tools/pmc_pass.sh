@@ -1,0 +1,24 @@
+#!/bin/bash
+# PMC counter passes (rocprofv3 --pmc, one small counter group per pass; never combined with sys/runtime tracing) over a
+# reduced VGG-D step.  Output: gpurun_out/pmc/<group>/... csv + gpurun_out/pmc_summary.md (per-kernel sums).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/pmc
+mkdir -p $OUT
+BATCH=${PMC_BATCH:-64}
+(cd /tmp && rocprofv3 -L > $OUT/counters_list.txt 2>&1; true)
+run_pass() {
+  name=$1; shift
+  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $OLDPWD/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline > $OUT/$name.log 2>&1; echo "exit $?" >> $OUT/$name.log)
+}
+run_pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE
+run_pass wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES
+run_pass inst SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU
+run_pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM
+run_pass fetch FETCH_SIZE
+run_pass write WRITE_SIZE
+run_pass l2 TCC_HIT_sum TCC_MISS_sum
+python tools/pmc_summary.py $OUT > gpurun_out/pmc_summary.md 2>&1
+find $OUT -name "*kernel_trace*" -size +8M -delete
+find $OUT -name "*counter_collection*" -size +24M -delete
+tail -40 gpurun_out/pmc_summary.md
