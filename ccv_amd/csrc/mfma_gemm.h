@@ -11,7 +11,7 @@
 // Geometry: (64*WM) x (64*WN) block tile (WM, WN in {1, 2}: 128x128 for the bulk, 128x64 / 64x128 when an output
 // dimension is 64 channels so no MFMA issues on padding), BK = 32, 256 threads = 4 waves (2x2), each wave owns
 // WM x WN MFMA tiles of 32x32.  Operand tiles are staged HBM -> registers -> LDS (double buffered, one barrier per
-// K-step; the global loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them).
+// K-step; the global loads run two tiles ahead of the MFMAs, the LDS writes one tile ahead, all issued between MFMAs).
 // Gathers are BRANCH-FREE and SELECT-FREE: every lane always issues its 16-byte load; a lane whose element is padding /
 // out of range points its load at a 16-byte page of zeros instead, so nothing consumes the loaded registers until the
 // LDS store AFTER the MFMA block -- the HBM/L2 latency of tile t+1 hides behind the 64 MFMAs of tile t (a select on the
@@ -40,6 +40,17 @@ constexpr int GEMM_LDK = 36; // row stride of a k-contiguous LDS image
 // offset from its own base pointer `p` to a 16-byte-aligned page of zeros in the same device's HBM (device_rt.cpp), so a
 // masked lane only swaps the OFFSET and the access stays a plain global_load off `p`.
 __device__ __forceinline__ float4 ld16(const float* q) { return *(const float4*)q; }
+
+// Pin a value to its position in the instruction stream: an empty volatile asm that "rewrites" x is ordered against the
+// sched_barrier fences, so arithmetic that consumes x cannot be hoisted above the fence in front of it (pure address
+// arithmetic otherwise floats to the top of the loop body, in front of the first MFMA).  No instruction is emitted.
+#ifdef NNC_HIP_EMULATOR
+#define NNC_PIN_V(x) ((void)0)
+#define NNC_PIN_S(x) ((void)0)
+#else
+#define NNC_PIN_V(x) asm volatile("" : "+v"(x))
+#define NNC_PIN_S(x) asm volatile("" : "+s"(x))
+#endif
 
 // Exact n / d for 0 <= n < 2^31, d >= 1 as multiply + shift (Granlund-Montgomery): m = ceil(2^(31+s) / d), s = ceil(log2 d).
 struct FastDiv {
@@ -92,6 +103,7 @@ struct MatLoader {
 		x.off = KC ? (long)k : (long)k * ldk;
 		return x;
 	}
+	__device__ __forceinline__ void pin(Ctx& c) const { NNC_PIN_V(c.r); }
 	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const
 	{
 		const bool ok = (c.r < R) & (x.k < x.klimit);
@@ -182,6 +194,7 @@ struct Im2colKC {
 		ok = ok & (qy * dv_y == yy) & (qx * dv_x == xq) & (qy < H) & (qx < W);
 		return ok ? c.base + (long)(qy * s_h + qx * s_w + x.off) : zoff;
 	}
+	__device__ __forceinline__ void pin(Ctx& c) const { NNC_PIN_V(c.iy0); }
 	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const { return locate(c, x.e[0]); }
 	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
 	{
@@ -215,6 +228,7 @@ struct WgtDgradNC {
 		x.off = (long)ko * ko_stride + (long)tap * C;
 		return x;
 	}
+	__device__ __forceinline__ void pin(Ctx& c) const { NNC_PIN_V(c.c); }
 	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const
 	{
 		const bool ok = x.ok & (c.c < C);
@@ -286,6 +300,7 @@ struct Im2colNC {
 		const bool ok = x.ok & c.ok[e] & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
 		return ok ? x.base + c.off[e] : zoff;
 	}
+	__device__ __forceinline__ void pin(Ctx& c) const { NNC_PIN_V(c.off_y[0]); }
 	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const { return locate(c, x, 0); }
 	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
 	{
@@ -338,7 +353,8 @@ struct TileFetch {
 	static constexpr int NCTX = L::KCONTIG ? NCH : 1;
 	typename L::Ctx ctx[NCTX];
 	int koff[NCH];
-	long off[L::VECTOR ? NCH : 1]; // VECTOR: the chunk offsets prep() resolved for the tile issue() will load
+	long off[L::VECTOR ? NCH : 1]; // VECTOR: the chunk offsets prep_*() resolved for the tile issue() will load
+	typename L::KCtx kc;           // VECTOR && KCONTIG: the K-step's k state shared by all chunks
 	int kb, kl;
 	__device__ __forceinline__ void init(const L& l, int row0, int t)
 	{
@@ -349,88 +365,112 @@ struct TileFetch {
 			else { if (jj == 0) ctx[0] = l.make(row0 + ((id % (ROWS / 4)) << 2)); koff[jj] = id / (ROWS / 4); }
 		}
 	}
-	// Address phase of the tile at K offset kbase (pure integer VALU: scheduled into the shadow of the previous tile's MFMAs).
+	// Address phase of the tile at K offset kbase: pure integer VALU, cut into 1 + NCH pieces so the kernel can slot
+	// them between the MFMAs of the previous tile.  prep_k first, then prep_chunk(jj) in any order.
+	__device__ __forceinline__ void prep_k(const L& l, int kbase, int klimit)
+	{
+		NNC_PIN_S(kbase);
+		kb = kbase; kl = klimit;
+		if (L::VECTOR && L::KCONTIG) kc = l.kctx(kbase + koff[0], klimit);
+	}
+	__device__ __forceinline__ void prep_chunk(const L& l, const int jj)
+	{
+		if (!L::VECTOR) return;
+		if (L::KCONTIG) { l.pin(ctx[jj % NCTX]); off[L::VECTOR ? jj : 0] = l.offset(ctx[jj % NCTX], kc); }
+		else { NNC_PIN_V(koff[jj]); off[L::VECTOR ? jj : 0] = l.offset(ctx[0], l.kctx(kb + koff[jj], kl)); }
+	}
 	__device__ __forceinline__ void prep(const L& l, int kbase, int klimit)
 	{
-		kb = kbase; kl = klimit;
-		if (!L::VECTOR) return;
-		if (L::KCONTIG) {
-			const typename L::KCtx kc = l.kctx(kbase + koff[0], klimit);
+		prep_k(l, kbase, klimit);
 #pragma unroll
-			for (int jj = 0; jj < NCH; jj++) off[L::VECTOR ? jj : 0] = l.offset(ctx[jj % NCTX], kc);
-		} else {
-#pragma unroll
-			for (int jj = 0; jj < NCH; jj++) off[L::VECTOR ? jj : 0] = l.offset(ctx[0], l.kctx(kbase + koff[jj], klimit));
-		}
+		for (int jj = 0; jj < NCH; jj++) prep_chunk(l, jj);
 	}
-	// Load phase: VECTOR = NCH 16-byte global loads off the prepared offsets and nothing else.
-	__device__ __forceinline__ void issue(const L& l, float4 (&r)[NCH]) const
+	// Load phase of chunk jj of the tile at K offset kbase: VECTOR = ONE 16-byte global load off the offset prep_chunk(jj)
+	// resolved for that tile (kbase is not looked at); !VECTOR = address arithmetic + four scalar loads on the spot.
+	__device__ __forceinline__ void issue_chunk(const L& l, float4 (&r)[NCH], const int jj, const int kbase, const int klimit) const
 	{
-		if (L::VECTOR) {
+		if (L::VECTOR) r[jj] = ld16(l.p + off[L::VECTOR ? jj : 0]);
+		else if (L::KCONTIG) r[jj] = l.load(ctx[jj % NCTX], l.kctx(kbase + koff[0], klimit));
+		else r[jj] = l.load(ctx[0], l.kctx(kbase + koff[jj], klimit));
+	}
+	__device__ __forceinline__ void issue(const L& l, float4 (&r)[NCH], const int kbase, const int klimit) const
+	{
 #pragma unroll
-			for (int jj = 0; jj < NCH; jj++) r[jj] = ld16(l.p + off[L::VECTOR ? jj : 0]);
-		} else if (L::KCONTIG) {
-			const typename L::KCtx kc = l.kctx(kb + koff[0], kl);
-#pragma unroll
-			for (int jj = 0; jj < NCH; jj++) r[jj] = l.load(ctx[jj % NCTX], kc);
-		} else {
-#pragma unroll
-			for (int jj = 0; jj < NCH; jj++) r[jj] = l.load(ctx[0], l.kctx(kb + koff[jj], kl));
-		}
+		for (int jj = 0; jj < NCH; jj++) issue_chunk(l, r, jj, kbase, klimit);
+	}
+	__device__ __forceinline__ void store_chunk(float* lds, const float4 (&r)[NCH], int t, const int jj) const
+	{
+		const int id = t + GEMM_THREADS * jj;
+		if (L::KCONTIG) *(float4*)(lds + (id >> 3) * GEMM_LDK + ((id & 7) << 2)) = r[jj];
+		else *(float4*)(lds + (id / (ROWS / 4)) * ROWS + ((id % (ROWS / 4)) << 2)) = r[jj];
 	}
 	__device__ __forceinline__ void store(float* lds, const float4 (&r)[NCH], int t) const
 	{
 #pragma unroll
-		for (int jj = 0; jj < NCH; jj++) {
-			const int id = t + GEMM_THREADS * jj;
-			if (L::KCONTIG) *(float4*)(lds + (id >> 3) * GEMM_LDK + ((id & 7) << 2)) = r[jj];
-			else *(float4*)(lds + (id / (ROWS / 4)) * ROWS + ((id % (ROWS / 4)) << 2)) = r[jj];
-		}
+		for (int jj = 0; jj < NCH; jj++) store_chunk(lds, r, t, jj);
 	}
 };
 
-// One K-step (32 deep) of the wave's WM x WN tiles out of the LDS images sa / sb: 16 * WM * WN MFMAs.
-template <bool AKC, bool BKC, int WM, int WN>
-__device__ __forceinline__ void mfma_kstep(const float* sa, const float* sb, const int row_a, const int col_b, const int lh, floatx16 (&acc)[WM][WN])
+// Fragment reads of quarter q (k = 8q .. 8q+7) of a K-step for W tiles of 32 rows starting at `row`.
+template <bool KC, int W, int ROWS>
+__device__ __forceinline__ void read_frags(const float* s, const int row, const int q, const int lh, float (&f)[W][4])
+{
+#pragma unroll
+	for (int ti = 0; ti < W; ti++) {
+		if (KC) {
+			const float4 v = *(const float4*)(s + (row + ti * 32) * GEMM_LDK + 8 * q + 4 * lh);
+			f[ti][0] = v.x; f[ti][1] = v.y; f[ti][2] = v.z; f[ti][3] = v.w;
+		} else {
+#pragma unroll
+			for (int e = 0; e < 4; e++) f[ti][e] = s[(8 * q + 4 * lh + e) * ROWS + row + ti * 32];
+		}
+	}
+}
+
+template <int G> struct GroupId { static constexpr int value = G; };
+struct NoSideWork { template <class G> __device__ __forceinline__ void operator()(G) const {} };
+
+// One K-step (32 deep) of the wave's WM x WN tiles out of the LDS images sa / sb: 16 groups of WM * WN MFMAs (one group
+// per k pair), hand-ordered.  A wave's MFMA occupies the SIMD's matrix pipe for 64 cycles while the wave itself is free to
+// issue other instructions, so everything else the K-step needs is slotted BETWEEN the groups and fenced there
+// (sched_barrier) so hipcc can neither hoist it in front of the first MFMA nor sink it behind the last one:
+//   * the fragment ds_reads of quarter q+1 go out with the first group of quarter q (double-buffered fragment registers)
+//   * side(GroupId<g>) carries the caller's other work for group g = 0..15 (address VALU of tile kt+2, LDS writes of
+//     tile kt+1): what remains outside the MFMA stream of a K-step is the barrier and the first fragment read.
+template <bool AKC, bool BKC, int WM, int WN, bool NO_MFMA, class SIDE>
+__device__ __forceinline__ void mfma_kstep(const float* sa, const float* sb, const int row_a, const int col_b, const int lh, floatx16 (&acc)[WM][WN], const SIDE& side)
 {
 	constexpr int BM = 64 * WM, BN = 64 * WN;
+	float fa_[2][WM][4], fb_[2][WN][4];
+	read_frags<AKC, WM, BM>(sa, row_a, 0, lh, fa_[0]);
+	read_frags<BKC, WN, BN>(sb, col_b, 0, lh, fb_[0]);
 #pragma unroll
 	for (int q = 0; q < 4; q++) {
-		float fa_[WM][4], fb_[WN][4];
-#pragma unroll
-		for (int ti = 0; ti < WM; ti++) {
-			const int row = row_a + ti * 32;
-			if (AKC) {
-				const float4 v = *(const float4*)(sa + row * GEMM_LDK + 8 * q + 4 * lh);
-				fa_[ti][0] = v.x; fa_[ti][1] = v.y; fa_[ti][2] = v.z; fa_[ti][3] = v.w;
-			} else {
-#pragma unroll
-				for (int e = 0; e < 4; e++) fa_[ti][e] = sa[(8 * q + 4 * lh + e) * BM + row];
-			}
+		if (q < 3) {
+			read_frags<AKC, WM, BM>(sa, row_a, q + 1, lh, fa_[(q + 1) & 1]);
+			read_frags<BKC, WN, BN>(sb, col_b, q + 1, lh, fb_[(q + 1) & 1]);
 		}
 #pragma unroll
-		for (int tj = 0; tj < WN; tj++) {
-			const int col = col_b + tj * 32;
-			if (BKC) {
-				const float4 v = *(const float4*)(sb + col * GEMM_LDK + 8 * q + 4 * lh);
-				fb_[tj][0] = v.x; fb_[tj][1] = v.y; fb_[tj][2] = v.z; fb_[tj][3] = v.w;
-			} else {
-#pragma unroll
-				for (int e = 0; e < 4; e++) fb_[tj][e] = sb[(8 * q + 4 * lh + e) * BN + col];
-			}
-		}
-#pragma unroll
-		for (int e = 0; e < 4; e++)
+		for (int e = 0; e < 4; e++) {
 #pragma unroll
 			for (int ti = 0; ti < WM; ti++)
 #pragma unroll
 				for (int tj = 0; tj < WN; tj++)
-					acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[ti][e], fb_[tj][e], acc[ti][tj], 0, 0, 0);
+					if (NO_MFMA) acc[ti][tj][0] += fa_[q & 1][ti][e] * fb_[q & 1][tj][e];
+					else acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[q & 1][ti][e], fb_[q & 1][tj][e], acc[ti][tj], 0, 0, 0);
+			if (q == 0 && e == 0) side(GroupId<0>()); else if (q == 0 && e == 1) side(GroupId<1>()); else if (q == 0 && e == 2) side(GroupId<2>()); else if (q == 0 && e == 3) side(GroupId<3>());
+			else if (q == 1 && e == 0) side(GroupId<4>()); else if (q == 1 && e == 1) side(GroupId<5>()); else if (q == 1 && e == 2) side(GroupId<6>()); else if (q == 1 && e == 3) side(GroupId<7>());
+			else if (q == 2 && e == 0) side(GroupId<8>()); else if (q == 2 && e == 1) side(GroupId<9>()); else if (q == 2 && e == 2) side(GroupId<10>()); else if (q == 2 && e == 3) side(GroupId<11>());
+			else if (q == 3 && e == 0) side(GroupId<12>()); else if (q == 3 && e == 1) side(GroupId<13>()); else if (q == 3 && e == 2) side(GroupId<14>()); else side(GroupId<15>());
+			__builtin_amdgcn_sched_barrier(0);
+		}
 	}
 }
 
 // grid: x = tiles (XCD-swizzled), y = split-K slices, z = batch / conv group.  WM / WN = 32x32 MFMA tiles per wave.
-template <class LA, class LB, class EPI, int WM, int WN>
+// DBG (tools/kprobe.cpp only; the library always instantiates DBG = 0): knock out parts of the steady state to attribute time.
+//   1 no global loads, 2 no LDS writes, 4 no barrier, 8 no address prep, 16 no MFMAs, 32 no A loads, 64 no B loads
+template <class LA, class LB, class EPI, int WM, int WN, int DBG = 0>
 __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff)
 {
 	constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -473,38 +513,79 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
 	const int row_a = wm * (32 * WM) + li, col_b = wn * (32 * WN) + li;
-	float4 ra[WM * 2], rb[WN * 2];
+	// Software pipeline, prefetch distance TWO tiles: while tile kt is multiplied out of LDS buffer kt & 1, the chunks of
+	// tile kt+1 (register set (kt+1) & 1, loaded during the previous K-step) are written to the other LDS buffer, the
+	// chunks of tile kt+2 are loaded into register set kt & 1, and the addresses of tile kt+3 are computed -- every one
+	// of these instructions is issued BETWEEN two MFMA groups, at most one global load per group:
+	//   * a wave that issues its 8 loads back to back queues behind the other 7 waves' bursts in the CU's address
+	//     pipeline and stalls at the issue for ~1000 cycles per K-step, MFMAs blocked behind it (measured: 121 vs 146
+	//     TFLOP/s with the loads knocked out, independent of the prefetch distance); one load per >= 256 MFMA-cycles
+	//     never finds the queue occupied;
+	//   * a load has a full K-step (>= 4000 cycles) to land before its LDS write waits for it.
+	constexpr int NA = WM * 2, NB = WN * 2;
+	float4 ra[2][NA], rb[2][NB];
 	if (nk > 0) {
 		fa.prep(la, k_begin, k_end);
 		fb.prep(lb, k_begin, k_end);
-		fa.issue(la, ra);
-		fb.issue(lb, rb);
-		fa.store(lds[0], ra, t);
-		fb.store(lds[0] + A_FLOATS, rb, t);
+		fa.issue(la, ra[0], k_begin, k_end);
+		fb.issue(lb, rb[0], k_begin, k_end);
 		fa.prep(la, k_begin + GEMM_BK, k_end);
 		fb.prep(lb, k_begin + GEMM_BK, k_end);
+		fa.issue(la, ra[1], k_begin + GEMM_BK, k_end); // past-the-end tiles are fully masked: they load the page of zeros
+		fb.issue(lb, rb[1], k_begin + GEMM_BK, k_end);
+		fa.store(lds[0], ra[0], t);
+		fb.store(lds[0] + A_FLOATS, rb[0], t);
+		fa.prep(la, k_begin + 2 * GEMM_BK, k_end);
+		fb.prep(lb, k_begin + 2 * GEMM_BK, k_end);
 	}
 	__syncthreads();
-	// Steady state, three fenced phases per K-step (the fences keep hipcc from sinking the loads below the MFMAs):
-	//   1. issue the global loads of tile kt+1 (addresses already resolved)      -> in flight across phase 2
-	//   2. MFMAs of tile kt out of LDS, with the address VALU of tile kt+2 scheduled into their shadow
-	//   3. wait for the loads, write tile kt+1 to the other LDS buffer, barrier
-	for (int kt = 0; kt + 1 < nk; kt++) {
-		const int cur = kt & 1;
-		fa.issue(la, ra);
-		fb.issue(lb, rb);
-		__builtin_amdgcn_sched_barrier(0);
-		fa.prep(la, k_begin + (kt + 2) * GEMM_BK, k_end);
-		fb.prep(lb, k_begin + (kt + 2) * GEMM_BK, k_end);
-		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN>(lds[cur], lds[cur] + A_FLOATS, row_a, col_b, lh, acc);
-		__builtin_amdgcn_sched_barrier(0);
-		fa.store(lds[cur ^ 1], ra, t);
-		fb.store(lds[cur ^ 1] + A_FLOATS, rb, t);
-		__syncthreads();
+	// One steady-state K-step (S = kt & 1, a compile-time constant so the register sets stay in fixed registers).
+	// Side work of MFMA group g (operand A in groups 0-7, operand B in groups 8-15; chunk jj of an operand with NCH chunks
+	// owns the group pair 2 * jj * 4 / NCH):
+	//   even group of the pair:  load chunk jj of tile kt+2 into set S          (uses the offset resolved one K-step ago)
+	//   odd group of the pair:   LDS-write chunk jj of tile kt+1 from set S^1, then resolve chunk jj's offset of tile kt+3
+	//   group 0 / 8 additionally: the per-K-step k state of tile kt+3 (prep_k)
+	auto kstep = [&](auto sid, const int kt) {
+		constexpr int S = decltype(sid)::value;
+		float* const da = lds[S ^ 1];
+		float* const db = da + A_FLOATS;
+		const int kb2 = k_begin + (kt + 2) * GEMM_BK, kb3 = kb2 + GEMM_BK;
+		auto side = [&](auto gid) {
+			constexpr int g = decltype(gid)::value;
+#pragma unroll
+			for (int jj = 0; jj < NA; jj++) {
+				if (g == jj * 8 / NA && !(DBG & 1) && !(DBG & 32)) fa.issue_chunk(la, ra[S], jj, kb2, k_end);
+				if (g == jj * 8 / NA + 1) {
+					if (!(DBG & 2)) fa.store_chunk(da, ra[S ^ 1], t, jj);
+					if (!(DBG & 8)) fa.prep_chunk(la, jj);
+				}
+			}
+#pragma unroll
+			for (int jj = 0; jj < NB; jj++) {
+				if (g == 8 + jj * 8 / NB && !(DBG & 1) && !(DBG & 64)) fb.issue_chunk(lb, rb[S], jj, kb2, k_end);
+				if (g == 8 + jj * 8 / NB + 1) {
+					if (!(DBG & 2)) fb.store_chunk(db, rb[S ^ 1], t, jj);
+					if (!(DBG & 8)) fb.prep_chunk(lb, jj);
+				}
+			}
+			if (g == 0 && !(DBG & 8)) fa.prep_k(la, kb3, k_end);
+			if (g == 8 && !(DBG & 8)) fb.prep_k(lb, kb3, k_end);
+		};
+		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN, (DBG & 16) != 0>(lds[S], lds[S] + A_FLOATS, row_a, col_b, lh, acc, side);
+		if (!(DBG & 4)) __syncthreads();
+	};
+	{ // pairs of K-steps with no control flow between them (a branch in the middle makes hipcc copy the in-flight register
+	  // set at the merge, and a copy of a register a load is still writing costs an s_waitcnt vmcnt(0))
+		int kt = 0;
+		for (; kt + 2 < nk; kt += 2) {
+			kstep(GroupId<0>(), kt);
+			kstep(GroupId<1>(), kt + 1);
+		}
+		if (kt + 1 < nk) kstep(GroupId<0>(), kt);
 	}
 	if (nk > 0) {
 		const int cur = (nk - 1) & 1;
-		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN>(lds[cur], lds[cur] + A_FLOATS, row_a, col_b, lh, acc);
+		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN, false>(lds[cur], lds[cur] + A_FLOATS, row_a, col_b, lh, acc, NoSideWork());
 	}
 	// D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;

@@ -144,6 +144,7 @@ static inline emu_floatx4 emu_mfma_f32_16x16x4f32(float a, float b, emu_floatx4 
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 
