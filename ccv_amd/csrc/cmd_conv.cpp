@@ -32,10 +32,7 @@ static bool conv_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, 
 	g->pby = hint.border.begin[0]; g->pbx = hint.border.begin[1];
 	g->dy = cmd.info.convolution.dilation[0] > 1 ? cmd.info.convolution.dilation[0] : 1;
 	g->dx = cmd.info.convolution.dilation[1] > 1 ? cmd.info.convolution.dilation[1] : 1;
-	if (w) { // NHWC weights: [K][kh][kw][Cg]
-		if (tensor_nd(w->info.dim) != 4 || w->info.dim[0] != g->K || w->info.dim[1] != g->kh || w->info.dim[2] != g->kw || w->info.dim[3] != g->Cg) return false;
-		if (!tensor_contiguous(w)) return false;
-	}
+	(void)w; // weight layout / shape: weights_shape()
 	return true;
 }
 
@@ -114,6 +111,37 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 #undef CONV_WGRAD
 }
 
+// ---- layout staging ---------------------------------------------------------------------------------------------------
+// The kernels read NHWC activations and [K][kh][kw][Cg] weights.  NCHW activations (the reference's ResNet trainer) and
+// NCHW-format weights [K][Cg][kh][kw] (what the reference's GPU tests hand over, test/int/nnc/cudnn.tests.c:50,65) are
+// re-laid-out through the stream workspace by the tiled transpose of cmd_util.cpp: one extra read + write of the tensor,
+// HBM-bound, instead of a second family of gather kernels whose channel-strided loads could not be 16-byte vectors.
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static bool weights_shape(const ccv_nnc_tensor_t* w, int* K, int* kh, int* kw, int* Cg)
+{
+	if (!w || tensor_nd(w->info.dim) != 4 || !tensor_contiguous(w)) return false;
+	const int* d = w->info.dim;
+	if (w->info.format == CCV_TENSOR_FORMAT_NCHW) { *K = d[0]; *Cg = d[1]; *kh = d[2]; *kw = d[3]; }
+	else if (w->info.format == CCV_TENSOR_FORMAT_NHWC) { *K = d[0]; *kh = d[1]; *kw = d[2]; *Cg = d[3]; }
+	else return false;
+	return true;
+}
+
+// A dense NHWC tensor header over `data` with the logical shape of `like` (which is NCHW or NHWC, 3-d or 4-d).
+static void dense_nhwc_like(const ccv_nnc_tensor_t* like, const Image4& li, float* data, ccv_nnc_tensor_t* out)
+{
+	memset(out, 0, sizeof(*out));
+	out->type = like->info.type & ~CCV_TENSOR_VIEW;
+	out->info = like->info;
+	out->info.format = CCV_TENSOR_FORMAT_NHWC;
+	const int b = tensor_nd(like->info.dim) == 4;
+	memset(out->info.dim, 0, sizeof(out->info.dim));
+	if (b) out->info.dim[0] = li.n;
+	out->info.dim[b] = li.h; out->info.dim[b + 1] = li.w; out->info.dim[b + 2] = li.c;
+	out->data.f32 = data;
+}
+
 static int _conv_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	if (input_size < 2 || output_size < 1 || !inputs[0] || !inputs[1] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
@@ -122,13 +150,36 @@ static int _conv_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	const ccv_nnc_tensor_t* bias = input_size > 2 ? inputs[2] : 0;
 	ccv_nnc_tensor_t* b = outputs[0];
 	if (CCV_GET_DATA_TYPE(a->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
-	if (a->info.format != CCV_TENSOR_FORMAT_NHWC || b->info.format != CCV_TENSOR_FORMAT_NHWC) return CCV_NNC_EXEC_INVALID;
+	if (a->info.format != b->info.format) return CCV_NNC_EXEC_INVALID;
 	Image4 ai, bi;
 	if (!image4(a, &ai) || !image4(b, &bi)) return CCV_NNC_EXEC_INVALID;
+	int K, kh, kw, Cg;
+	if (!weights_shape(w, &K, &kh, &kw, &Cg)) return CCV_NNC_EXEC_INVALID;
 	conv_geom_t g;
-	if (!conv_geometry(cmd, hint, ai, bi, w, &g)) return CCV_NNC_EXEC_INVALID;
+	if (!conv_geometry(cmd, hint, ai, bi, 0, &g) || K != g.K || kh != g.kh || kw != g.kw || Cg != g.Cg) return CCV_NNC_EXEC_INVALID;
 	if (bias && (bias->info.dim[0] != g.K || !tensor_contiguous(bias))) return CCV_NNC_EXEC_INVALID;
-	return conv_forw_nhwc(g, ai, w->data.f32, bias ? bias->data.f32 : 0, bi, flags, stream_context);
+	const bool stage_io = a->info.format == CCV_TENSOR_FORMAT_NCHW, stage_w = w->info.format == CCV_TENSOR_FORMAT_NCHW;
+	if (!stage_io && !stage_w) return conv_forw_nhwc(g, ai, w->data.f32, bias ? bias->data.f32 : 0, bi, flags, stream_context);
+	const size_t na = stage_io ? align256(sizeof(float) * tensor_count(a->info)) : 0, nb = stage_io ? align256(sizeof(float) * tensor_count(b->info)) : 0;
+	const size_t nw = stage_w ? align256(sizeof(float) * tensor_count(w->info)) : 0;
+	WorkspaceScope ws(stream_context, na + nb + nw, gemm_workspace_bound((long)g.N * g.OH * g.OW, g.Kg, (long)g.kh * g.kw * g.Cg));
+	char* p = (char*)ws.prefix();
+	if (!p) return CCV_NNC_EXEC_OOM;
+	int ret;
+	const float* wp = w->data.f32;
+	if (stage_w) {
+		if ((ret = weights_nchw_to_nhwc(w->data.f32, (float*)(p + na + nb), g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		wp = (const float*)(p + na + nb);
+	}
+	if (!stage_io) return conv_forw_nhwc(g, ai, wp, bias ? bias->data.f32 : 0, bi, flags, stream_context);
+	ccv_nnc_tensor_t at, bt;
+	dense_nhwc_like(a, ai, (float*)p, &at);
+	dense_nhwc_like(b, bi, (float*)(p + na), &bt);
+	if ((ret = format_transform(a, &at, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	Image4 as, bs;
+	image4(&at, &as); image4(&bt, &bs);
+	if ((ret = conv_forw_nhwc(g, as, wp, bias ? bias->data.f32 : 0, bs, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	return format_transform(&bt, b, stream_context);
 }
 
 static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
@@ -141,33 +192,76 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	ccv_nnc_tensor_t* h = outputs[0];
 	ccv_nnc_tensor_t* dw = output_size > 1 ? outputs[1] : 0;
 	ccv_nnc_tensor_t* dbias = output_size > 2 ? outputs[2] : 0;
-	if (gt->info.format != CCV_TENSOR_FORMAT_NHWC || CCV_GET_DATA_TYPE(gt->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
+	if (CCV_GET_DATA_TYPE(gt->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
 	Image4 gi;
 	if (!image4(gt, &gi)) return CCV_NNC_EXEC_INVALID;
 	const ccv_nnc_tensor_t* shape_src = a ? a : h; // the forward input's shape
-	if (!shape_src) return CCV_NNC_EXEC_INVALID;
+	if (!shape_src || shape_src->info.format != gt->info.format) return CCV_NNC_EXEC_INVALID;
 	Image4 ai;
 	if (!image4(shape_src, &ai)) return CCV_NNC_EXEC_INVALID;
-	conv_geom_t g;
 	const ccv_nnc_tensor_t* wshape = dw ? dw : w;
-	if (!wshape || !conv_geometry(cmd, hint, ai, gi, wshape, &g)) return CCV_NNC_EXEC_INVALID;
-	hipStream_t stream = stream_of(stream_context);
+	int K, kh, kw, Cg;
+	if (!weights_shape(wshape, &K, &kh, &kw, &Cg)) return CCV_NNC_EXEC_INVALID;
+	if (w && dw && w->info.format != dw->info.format) return CCV_NNC_EXEC_INVALID;
+	conv_geom_t g;
+	if (!conv_geometry(cmd, hint, ai, gi, 0, &g) || K != g.K || kh != g.kh || kw != g.kw || Cg != g.Cg) return CCV_NNC_EXEC_INVALID;
+	if (dw && !a) return CCV_NNC_EXEC_INVALID;
+	if (h && (!w || !tensor_contiguous(w))) return CCV_NNC_EXEC_INVALID;
+	Image4 hi;
+	if (h && (!image4(h, &hi) || hi.h != g.H || hi.w != g.W || hi.c != g.C || hi.n != g.N || h->info.format != gt->info.format)) return CCV_NNC_EXEC_INVALID;
+	if (dbias && (!tensor_contiguous(dbias) || dbias->info.dim[0] != g.K)) return CCV_NNC_EXEC_INVALID;
+	const int acc = (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0;
+	const bool stage_io = gt->info.format == CCV_TENSOR_FORMAT_NCHW, stage_w = wshape->info.format == CCV_TENSOR_FORMAT_NCHW;
+	const size_t wbytes = align256(sizeof(float) * (size_t)g.K * g.kh * g.kw * g.Cg);
+	const size_t ng = stage_io ? align256(sizeof(float) * tensor_count(gt->info)) : 0;
+	const size_t na = stage_io && a && dw ? align256(sizeof(float) * tensor_count(a->info)) : 0;
+	const size_t nh = stage_io && h ? align256(sizeof(float) * tensor_count(h->info)) : 0;
+	const size_t nw = stage_w && h ? wbytes : 0, ndw = stage_w && dw ? wbytes : 0;
+	const long P = (long)g.N * g.OH * g.OW;
+	size_t inner = gemm_workspace_bound(g.Kg, (long)g.kh * g.kw * g.Cg, P);
+	const size_t inner_d = gemm_workspace_bound((long)g.N * g.H * g.W, g.Cg, (long)g.kh * g.kw * g.Kg), inner_b = sizeof(float) * (size_t)g.K * 4096;
+	if (inner_d > inner) inner = inner_d;
+	if (inner_b > inner) inner = inner_b;
+	WorkspaceScope ws(stream_context, ng + na + nh + nw + ndw, inner);
+	char* p = (char*)ws.prefix();
+	if ((ng + na + nh + nw + ndw) && !p) return CCV_NNC_EXEC_OOM;
 	int ret;
+	// stage the NCHW inputs
+	ccv_nnc_tensor_t gs, as, hs;
+	Image4 gim = gi, aim = ai, him = hi;
+	if (stage_io) {
+		dense_nhwc_like(gt, gi, (float*)p, &gs);
+		if ((ret = format_transform(gt, &gs, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		image4(&gs, &gim);
+		if (na) {
+			dense_nhwc_like(a, ai, (float*)(p + ng), &as);
+			if ((ret = format_transform(a, &as, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			image4(&as, &aim);
+		}
+		if (nh) { dense_nhwc_like(h, hi, (float*)(p + ng + na), &hs); image4(&hs, &him); }
+	}
 	if (dw) {
-		if (!a) return CCV_NNC_EXEC_INVALID;
-		if ((ret = conv_wgrad_nhwc(g, gi, ai, dw->data.f32, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		float* dwp = dw->data.f32;
+		if (stage_w) {
+			dwp = (float*)(p + ng + na + nh + nw);
+			if (acc && (ret = weights_nchw_to_nhwc(dw->data.f32, dwp, g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		}
+		if ((ret = conv_wgrad_nhwc(g, gim, aim, dwp, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if (stage_w && (ret = weights_nhwc_to_nchw(dwp, dw->data.f32, g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
 	if (dbias) {
-		if (!pixel_linear(gi) || !tensor_contiguous(dbias) || dbias->info.dim[0] != g.K) return CCV_NNC_EXEC_INVALID;
-		if ((ret = colsum_f32(gi.p, (long)g.N * g.OH * g.OW, g.K, gi.sw, dbias->data.f32, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if (!pixel_linear(gim)) return CCV_NNC_EXEC_INVALID;
+		if ((ret = colsum_f32(gim.p, P, g.K, gim.sw, dbias->data.f32, acc, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
 	if (h) {
-		if (!w || !tensor_contiguous(w)) return CCV_NNC_EXEC_INVALID;
-		Image4 hi;
-		if (!image4(h, &hi) || hi.h != g.H || hi.w != g.W || hi.c != g.C || hi.n != g.N) return CCV_NNC_EXEC_INVALID;
-		if ((ret = conv_dgrad_nhwc(g, gi, w->data.f32, hi, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		const float* wp = w->data.f32;
+		if (stage_w) {
+			if ((ret = weights_nchw_to_nhwc(w->data.f32, (float*)(p + ng + na + nh), g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			wp = (const float*)(p + ng + na + nh);
+		}
+		if ((ret = conv_dgrad_nhwc(g, gim, wp, him, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if (stage_io && (ret = format_transform(&hs, h, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
-	(void)stream;
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
@@ -175,7 +269,7 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 
 extern "C" void _register_command_CCV_NNC_CONVOLUTION_FORWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
 {
-	registry->tensor_formats = CCV_TENSOR_FORMAT_NHWC;
+	registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC;
 	registry->tensor_datatypes = CCV_32F;
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
 	registry->algorithms = 1;
@@ -184,7 +278,7 @@ extern "C" void _register_command_CCV_NNC_CONVOLUTION_FORWARD_backend_CCV_NNC_BA
 
 extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
 {
-	registry->tensor_formats = CCV_TENSOR_FORMAT_NHWC;
+	registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC;
 	registry->tensor_datatypes = CCV_32F;
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
 	registry->algorithms = 1;

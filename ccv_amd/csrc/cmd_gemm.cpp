@@ -9,16 +9,25 @@ using namespace nnc;
 
 namespace {
 
-struct matp_t { int batch, rows, cols; long batch_inc, rows_inc, cols_inc; };
+struct matp_t {
+	int batch, rows, cols;          // inner batch = dim[nd-3]
+	long batch_inc, rows_inc, cols_inc;
+	int outer_nd;                   // leading dims in front of the inner batch (generalized batched GEMM, gemm_cpu_ref.c _ccv_nnc_gbmm)
+	int outer_dim[CCV_NNC_MAX_DIM_ALLOC];
+	long outer_inc[CCV_NNC_MAX_DIM_ALLOC];
+	float* p;
+};
 
-// ccv_nnc_tensor_get_matrix_params: the trailing two dims are the matrix, dim[nd-3] (if any) the batch.
+// ccv_nnc_tensor_get_matrix_params (lib/nnc/ccv_nnc_easy.h:421-444): the trailing two dims are the matrix, dim[nd-3]
+// (if any) the batch, anything in front of that an outer batch that is walked (and broadcast when 1) by the caller.
 static bool matrix_params(const ccv_nnc_tensor_t* t, const int transpose[2], matp_t* m)
 {
 	const int nd = tensor_nd(t->info.dim);
-	if (nd < 1 || nd > 3) return false; // deeper broadcast batches are not on this path
+	if (nd < 1) return false;
 	int st[CCV_NNC_MAX_DIM_ALLOC];
 	tensor_strides(t, st);
 	const int* d = t->info.dim;
+	m->p = t->data.f32;
 	m->batch = nd < 3 ? 1 : d[nd - 3];
 	m->batch_inc = nd < 3 ? 0 : st[nd - 3];
 	int rows = nd == 1 ? 1 : d[nd - 2];
@@ -33,10 +42,43 @@ static bool matrix_params(const ccv_nnc_tensor_t* t, const int transpose[2], mat
 		long tl = rows_inc; rows_inc = cols_inc; cols_inc = tl;
 	}
 	m->rows = rows; m->cols = cols; m->rows_inc = rows_inc; m->cols_inc = cols_inc;
+	m->outer_nd = nd > 3 ? nd - 3 : 0;
+	for (int i = 0; i < m->outer_nd; i++) { m->outer_dim[i] = d[i]; m->outer_inc[i] = st[i]; }
 	return true;
 }
 
 static const int no_transpose[2] = { 0, 0 };
+
+// Walks the outer batch index space of `ref` (the operand that carries every outer dim at full extent) and hands the
+// callback each operand's element offset; operands with fewer outer dims are right-aligned, extent-1 dims broadcast.
+struct outer_walk_t {
+	int nd;
+	int dim[CCV_NNC_MAX_DIM_ALLOC];
+	int idx[CCV_NNC_MAX_DIM_ALLOC];
+	void init(const matp_t& ref) { nd = ref.outer_nd; for (int i = 0; i < nd; i++) { dim[i] = ref.outer_dim[i]; idx[i] = 0; } }
+	bool compatible(const matp_t& m) const
+	{
+		if (m.outer_nd > nd) return false;
+		for (int i = 0; i < m.outer_nd; i++) { const int e = m.outer_dim[i], r = dim[nd - m.outer_nd + i]; if (e != r && e != 1) return false; }
+		return true;
+	}
+	long offset(const matp_t& m) const
+	{
+		long o = 0;
+		for (int i = 0; i < m.outer_nd; i++) if (m.outer_dim[i] != 1) o += (long)idx[nd - m.outer_nd + i] * m.outer_inc[i];
+		return o;
+	}
+	// true when this operand is broadcast over some outer axis (an output then accumulates over that axis)
+	bool revisits(const matp_t& m) const
+	{
+		for (int i = 0; i < nd; i++) {
+			const int j = i - (nd - m.outer_nd);
+			if ((j < 0 || m.outer_dim[j] == 1) && dim[i] > 1 && idx[i] > 0) return true;
+		}
+		return false;
+	}
+	bool next() { for (int i = nd - 1; i >= 0; i--) { if (++idx[i] < dim[i]) return true; idx[i] = 0; } return false; }
+};
 
 static int _gemm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
@@ -46,25 +88,30 @@ static int _gemm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	const ccv_nnc_tensor_t* bias = input_size > 2 ? inputs[2] : 0;
 	ccv_nnc_tensor_t* b = outputs[0];
 	if (CCV_GET_DATA_TYPE(a->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
-	matp_t am, wm, bm;
+	matp_t am, wm, bm, sm;
 	if (!matrix_params(a, cmd.info.blas.transpose_a, &am) || !matrix_params(w, cmd.info.blas.transpose_b, &wm) || !matrix_params(b, no_transpose, &bm)) return CCV_NNC_EXEC_INVALID;
 	if ((am.batch > wm.batch ? am.batch : wm.batch) != bm.batch || am.rows != bm.rows || am.cols != wm.rows || wm.cols != bm.cols) return CCV_NNC_EXEC_INVALID;
 	if ((am.batch != bm.batch && am.batch != 1) || (wm.batch != bm.batch && wm.batch != 1)) return CCV_NNC_EXEC_INVALID;
 	if (am.batch == 1) am.batch_inc = 0;
 	if (wm.batch == 1) wm.batch_inc = 0;
-	const float* biasp = 0;
-	long bias_z = 0;
-	if (bias) {
-		matp_t sm;
-		if (!matrix_params(bias, no_transpose, &sm) || sm.cols != bm.cols || sm.cols_inc != 1 || sm.rows != 1) return CCV_NNC_EXEC_INVALID;
-		if (sm.batch != 1 && sm.batch != bm.batch) return CCV_NNC_EXEC_INVALID;
-		biasp = bias->data.f32;
+	long bias_z = 0, bias_ldm = 0;
+	if (bias) { // a row vector, or a full rows x cols matrix, optionally batched (gemm_cpu_ref.c:158-172)
+		if (!matrix_params(bias, no_transpose, &sm) || sm.cols != bm.cols || sm.cols_inc != 1) return CCV_NNC_EXEC_INVALID;
+		if ((sm.batch != 1 && sm.batch != bm.batch) || (sm.rows != 1 && sm.rows != bm.rows)) return CCV_NNC_EXEC_INVALID;
 		bias_z = sm.batch == 1 ? 0 : sm.batch_inc;
+		bias_ldm = sm.rows == 1 ? 0 : sm.rows_inc;
 	}
-	const MatOperand A = { a->data.f32, am.rows_inc, am.cols_inc, am.rows, am.cols };
-	const MatOperand B = { w->data.f32, wm.cols_inc, wm.rows_inc, wm.cols, wm.rows }; // rows of B-as-loader are output columns
-	const GemmOut out = { b->data.f32, bm.rows_inc, bm.cols_inc, biasp, 1.f, 0 };
-	return gemm_strided("gemm_fwd", A, B, out, bm.batch, am.batch_inc, wm.batch_inc, bm.batch_inc, bias_z, flags, stream_context);
+	outer_walk_t walk;
+	walk.init(bm);
+	if (!walk.compatible(am) || !walk.compatible(wm) || (bias && !walk.compatible(sm))) return CCV_NNC_EXEC_INVALID;
+	do {
+		const MatOperand A = { am.p + walk.offset(am), am.rows_inc, am.cols_inc, am.rows, am.cols };
+		const MatOperand B = { wm.p + walk.offset(wm), wm.cols_inc, wm.rows_inc, wm.cols, wm.rows }; // rows of B-as-loader are output columns
+		const GemmOut out = { bm.p + walk.offset(bm), bm.rows_inc, bm.cols_inc, bias ? sm.p + walk.offset(sm) : 0, 1.f, 0, bias_ldm };
+		const int ret = gemm_strided("gemm_fwd", A, B, out, bm.batch, am.batch_inc, wm.batch_inc, bm.batch_inc, bias_z, flags, stream_context);
+		if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
+	} while (walk.next());
+	return CCV_NNC_EXEC_SUCCESS;
 }
 
 static int _gemm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
@@ -79,63 +126,73 @@ static int _gemm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	ccv_nnc_tensor_t* dbias = output_size > 2 ? outputs[2] : 0;
 	if (CCV_GET_DATA_TYPE(g->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
 	const int acc = (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0;
-	matp_t gm;
+	matp_t gm, am, dm, hm, wm, sm;
 	if (!matrix_params(g, no_transpose, &gm)) return CCV_NNC_EXEC_INVALID;
-	int ret;
-	if (dbias) {
-		matp_t sm;
-		if (!matrix_params(dbias, no_transpose, &sm) || sm.cols != gm.cols || sm.cols_inc != 1 || sm.rows != 1 || gm.cols_inc != 1) return CCV_NNC_EXEC_INVALID;
-		if (sm.batch != 1 && sm.batch != gm.batch) return CCV_NNC_EXEC_INVALID;
-		for (int z = 0; z < gm.batch; z++) {
-			float* dst = dbias->data.f32 + (sm.batch == 1 ? 0 : (long)z * sm.batch_inc);
-			const int accz = acc || (sm.batch == 1 && z > 0);
-			if ((ret = colsum_f32(g->data.f32 + (long)z * gm.batch_inc, gm.rows, gm.cols, gm.rows_inc, dst, accz, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
-		}
-	}
+	if (dbias && (!matrix_params(dbias, no_transpose, &sm) || sm.cols != gm.cols || sm.cols_inc != 1 || sm.rows != 1 || gm.cols_inc != 1 || (sm.batch != 1 && sm.batch != gm.batch))) return CCV_NNC_EXEC_INVALID;
 	if (dw) {
-		if (!a) return CCV_NNC_EXEC_INVALID;
-		matp_t am, dm;
-		if (!matrix_params(a, cmd.info.blas.transpose_a, &am) || !matrix_params(dw, cmd.info.blas.transpose_b, &dm)) return CCV_NNC_EXEC_INVALID;
+		if (!a || !matrix_params(a, cmd.info.blas.transpose_a, &am) || !matrix_params(dw, cmd.info.blas.transpose_b, &dm)) return CCV_NNC_EXEC_INVALID;
 		if (am.rows != gm.rows || am.cols != dm.rows || dm.cols != gm.cols) return CCV_NNC_EXEC_INVALID;
 		if ((am.batch != gm.batch && am.batch != 1) || (dm.batch != gm.batch && dm.batch != 1)) return CCV_NNC_EXEC_INVALID;
 		if (am.batch == 1) am.batch_inc = 0;
-		// dw(k, n) = sum_m a(m, k) * g(m, n)
-		const MatOperand A = { a->data.f32, am.cols_inc, am.rows_inc, am.cols, am.rows };
-		const MatOperand B = { g->data.f32, gm.cols_inc, gm.rows_inc, gm.cols, gm.rows };
-		if (dm.batch == gm.batch) {
-			const GemmOut out = { dw->data.f32, dm.rows_inc, dm.cols_inc, 0, 1.f, acc };
-			if ((ret = gemm_strided("gemm_dw", A, B, out, gm.batch, am.batch_inc, gm.batch_inc, dm.batch_inc, 0, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
-		} else { // shared weight across the batch: accumulate every batch entry into the single dw
-			for (int z = 0; z < gm.batch; z++) {
-				MatOperand Az = A, Bz = B;
-				Az.p += (long)z * am.batch_inc; Bz.p += (long)z * gm.batch_inc;
-				const GemmOut out = { dw->data.f32, dm.rows_inc, dm.cols_inc, 0, 1.f, acc || z > 0 };
-				if ((ret = gemm_strided("gemm_dw", Az, Bz, out, 1, 0, 0, 0, 0, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
-			}
-		}
 	}
 	if (h) {
-		if (!w) return CCV_NNC_EXEC_INVALID;
-		matp_t hm, wm;
-		if (!matrix_params(h, cmd.info.blas.transpose_a, &hm) || !matrix_params(w, cmd.info.blas.transpose_b, &wm)) return CCV_NNC_EXEC_INVALID;
+		if (!w || !matrix_params(h, cmd.info.blas.transpose_a, &hm) || !matrix_params(w, cmd.info.blas.transpose_b, &wm)) return CCV_NNC_EXEC_INVALID;
 		if (hm.cols != wm.rows || wm.cols != gm.cols || hm.rows != gm.rows) return CCV_NNC_EXEC_INVALID;
 		if ((hm.batch != gm.batch && hm.batch != 1) || (wm.batch != gm.batch && wm.batch != 1)) return CCV_NNC_EXEC_INVALID;
 		if (wm.batch == 1) wm.batch_inc = 0;
-		// h(m, k) = sum_n g(m, n) * w(k, n)
-		const MatOperand A = { g->data.f32, gm.rows_inc, gm.cols_inc, gm.rows, gm.cols };
-		const MatOperand B = { w->data.f32, wm.rows_inc, wm.cols_inc, wm.rows, wm.cols };
-		if (hm.batch == gm.batch) {
-			const GemmOut out = { h->data.f32, hm.rows_inc, hm.cols_inc, 0, 1.f, acc };
-			if ((ret = gemm_strided("gemm_dx", A, B, out, gm.batch, gm.batch_inc, wm.batch_inc, hm.batch_inc, 0, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
-		} else {
+	}
+	outer_walk_t walk;
+	walk.init(gm);
+	if ((dbias && !walk.compatible(sm)) || (dw && (!walk.compatible(am) || !walk.compatible(dm))) || (h && (!walk.compatible(hm) || !walk.compatible(wm)))) return CCV_NNC_EXEC_INVALID;
+	int ret;
+	do {
+		const float* gp = gm.p + walk.offset(gm);
+		if (dbias) {
+			float* sp = sm.p + walk.offset(sm);
+			const int acc_o = acc || walk.revisits(sm);
 			for (int z = 0; z < gm.batch; z++) {
-				MatOperand Az = A, Bz = B;
-				Az.p += (long)z * gm.batch_inc; Bz.p += (long)z * wm.batch_inc;
-				const GemmOut out = { h->data.f32, hm.rows_inc, hm.cols_inc, 0, 1.f, acc || z > 0 };
-				if ((ret = gemm_strided("gemm_dx", Az, Bz, out, 1, 0, 0, 0, 0, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+				float* dst = sp + (sm.batch == 1 ? 0 : (long)z * sm.batch_inc);
+				const int accz = acc_o || (sm.batch == 1 && z > 0);
+				if ((ret = colsum_f32(gp + (long)z * gm.batch_inc, gm.rows, gm.cols, gm.rows_inc, dst, accz, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 			}
 		}
-	}
+		if (dw) {
+			// dw(k, n) = sum_m a(m, k) * g(m, n)
+			const int acc_o = acc || walk.revisits(dm);
+			const MatOperand A = { am.p + walk.offset(am), am.cols_inc, am.rows_inc, am.cols, am.rows };
+			const MatOperand B = { gp, gm.cols_inc, gm.rows_inc, gm.cols, gm.rows };
+			float* dp = dm.p + walk.offset(dm);
+			if (dm.batch == gm.batch) {
+				const GemmOut out = { dp, dm.rows_inc, dm.cols_inc, 0, 1.f, acc_o, 0 };
+				if ((ret = gemm_strided("gemm_dw", A, B, out, gm.batch, am.batch_inc, gm.batch_inc, dm.batch_inc, 0, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			} else { // shared weight across the batch: accumulate every batch entry into the single dw
+				for (int z = 0; z < gm.batch; z++) {
+					MatOperand Az = A, Bz = B;
+					Az.p += (long)z * am.batch_inc; Bz.p += (long)z * gm.batch_inc;
+					const GemmOut out = { dp, dm.rows_inc, dm.cols_inc, 0, 1.f, acc_o || z > 0, 0 };
+					if ((ret = gemm_strided("gemm_dw", Az, Bz, out, 1, 0, 0, 0, 0, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+				}
+			}
+		}
+		if (h) {
+			// h(m, k) = sum_n g(m, n) * w(k, n)
+			const int acc_o = acc || walk.revisits(hm);
+			const MatOperand A = { gp, gm.rows_inc, gm.cols_inc, gm.rows, gm.cols };
+			const MatOperand B = { wm.p + walk.offset(wm), wm.rows_inc, wm.cols_inc, wm.rows, wm.cols };
+			float* hp = hm.p + walk.offset(hm);
+			if (hm.batch == gm.batch) {
+				const GemmOut out = { hp, hm.rows_inc, hm.cols_inc, 0, 1.f, acc_o, 0 };
+				if ((ret = gemm_strided("gemm_dx", A, B, out, gm.batch, gm.batch_inc, wm.batch_inc, hm.batch_inc, 0, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			} else {
+				for (int z = 0; z < gm.batch; z++) {
+					MatOperand Az = A, Bz = B;
+					Az.p += (long)z * gm.batch_inc; Bz.p += (long)z * wm.batch_inc;
+					const GemmOut out = { hp, hm.rows_inc, hm.cols_inc, 0, 1.f, acc_o || z > 0, 0 };
+					if ((ret = gemm_strided("gemm_dx", Az, Bz, out, 1, 0, 0, 0, 0, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+				}
+			}
+		}
+	} while (walk.next());
 	return CCV_NNC_EXEC_SUCCESS;
 }
 

@@ -1,0 +1,278 @@
+// Layout / type commands on gfx950: FORMAT_TRANSFORM (NCHW <-> NHWC, strided views), TRANSPOSE, DATATYPE_CONVERSION.
+// All are pure data movement, bound by HBM (algorithmic bytes = |in| + |out|).
+// Oracle semantics: lib/nnc/cmd/util/ccv_nnc_util_cpu_ref.c:996-1082 (format transform), :1102-1180 (transpose),
+// :1200-1260 (datatype conversion).  Replaces util/gpu/ccv_nnc_util_gpu_cudnn.cu:13-60,160-222 and
+// util/gpu/ccv_nnc_util_gpu_ref.cu (cudnnTransformTensor / element kernels).
+//
+// Two kernels do the work:
+//   * permute4_kernel: generic 4-d gather, one element per lane in OUTPUT memory order (coalesced stores, strided loads);
+//     serves views, small tensors and every odd case.
+//   * transpose_tile_kernel: [batch][R][C] -> [batch][C][R] through a 64 x 65 LDS tile so that BOTH the global loads and
+//     the global stores are 256-byte-per-wavefront coalesced; picked for dense NCHW <-> NHWC (R = channels, C = H*W or
+//     the reverse), the layout change conv uses for NCHW tensors.
+#include "common.h"
+#include <stdint.h>
+
+using namespace nnc;
+
+namespace {
+
+typedef _Float16 half_t;
+
+struct perm4_t {
+	int dim[4];      // extents in output memory order (outer .. inner)
+	long is[4], os[4]; // element strides of input / output for those axes
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) permute4_kernel(const T* in, T* out, const perm4_t p, const size_t n)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+		size_t r = idx;
+		const int i3 = (int)(r % p.dim[3]); r /= p.dim[3];
+		const int i2 = (int)(r % p.dim[2]); r /= p.dim[2];
+		const int i1 = (int)(r % p.dim[1]); r /= p.dim[1];
+		const int i0 = (int)r;
+		out[i0 * p.os[0] + i1 * p.os[1] + i2 * p.os[2] + i3 * p.os[3]] = in[i0 * p.is[0] + i1 * p.is[1] + i2 * p.is[2] + i3 * p.is[3]];
+	}
+}
+
+constexpr int TT = 64;
+// in[b][r][c] (c contiguous) -> out[b][c][r] (r contiguous).  grid (ceil(C/64), ceil(R/64), batch), 256 threads.
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_tile_kernel(const T* in, T* out, const int R, const int C)
+{
+	__shared__ T tile[TT][TT + 1];
+	const int c0 = blockIdx.x * TT, r0 = blockIdx.y * TT;
+	const size_t base = (size_t)blockIdx.z * R * C;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	for (int j = ty; j < TT; j += 4) {
+		const int r = r0 + j, c = c0 + tx;
+		if (r < R && c < C) tile[j][tx] = in[base + (size_t)r * C + c];
+	}
+	__syncthreads();
+	for (int j = ty; j < TT; j += 4) {
+		const int c = c0 + j, r = r0 + tx;
+		if (r < R && c < C) out[base + (size_t)c * R + r] = tile[tx][j];
+	}
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) convert_kernel(const TI* in, TO* out, const size_t n)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (TO)in[i];
+}
+
+// Logical (n, h, w, c) extents + element strides of an up-to-4-d tensor / view in any of the three formats.
+struct logical4_t { int d[4]; long s[4]; };
+static bool logical4(const ccv_nnc_tensor_t* t, logical4_t* o)
+{
+	const int nd = tensor_nd(t->info.dim);
+	int st[CCV_NNC_MAX_DIM_ALLOC];
+	tensor_strides(t, st);
+	const int* dim = t->info.dim;
+	for (int i = 0; i < 4; i++) { o->d[i] = 1; o->s[i] = 0; }
+	if (nd > 4 || nd < 1) return false;
+	// positions of (n, h, w, c) inside a full 4-d tensor of this format
+	int pos[4];
+	switch (t->info.format) {
+		case CCV_TENSOR_FORMAT_NHWC: pos[0] = 0; pos[1] = 1; pos[2] = 2; pos[3] = 3; break;
+		case CCV_TENSOR_FORMAT_NCHW: pos[0] = 0; pos[3] = 1; pos[1] = 2; pos[2] = 3; break;
+		case CCV_TENSOR_FORMAT_CHWN: pos[3] = 0; pos[1] = 1; pos[2] = 2; pos[0] = 3; break;
+		default: return false;
+	}
+	// fewer than 4 dims: the batch axis is the one that is missing first (ccv_nnc_tensor_get_n / _c conventions:
+	// 3-d = no batch; 2-d = [h? ..] treated as trailing axes)
+	const int missing = 4 - nd;
+	for (int l = 0; l < 4; l++) {
+		int ppos = pos[l];
+		if (t->info.format == CCV_TENSOR_FORMAT_CHWN) { // batch is LAST: drop trailing axes
+			if (ppos >= nd) continue;
+		} else { // batch is FIRST: drop leading axes
+			ppos -= missing;
+			if (ppos < 0) continue;
+		}
+		o->d[l] = dim[ppos];
+		o->s[l] = st[ppos];
+	}
+	return true;
+}
+
+template <typename T>
+static int launch_permute(const void* in, void* out, const perm4_t& p, ccv_nnc_stream_context_t* ctx)
+{
+	const size_t n = (size_t)p.dim[0] * p.dim[1] * p.dim[2] * p.dim[3];
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(permute4_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, stream_of(ctx), (const T*)in, (T*)out, p, n);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+template <typename T>
+static int launch_transpose(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
+{
+	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_tile_kernel<T>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const T*)in, (T*)out, R, C);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static int by_size_permute(size_t es, const void* in, void* out, const perm4_t& p, ccv_nnc_stream_context_t* ctx)
+{
+	switch (es) {
+		case 1: return launch_permute<uint8_t>(in, out, p, ctx);
+		case 2: return launch_permute<uint16_t>(in, out, p, ctx);
+		case 4: return launch_permute<uint32_t>(in, out, p, ctx);
+		case 8: return launch_permute<uint64_t>(in, out, p, ctx);
+	}
+	return CCV_NNC_EXEC_INVALID;
+}
+static int by_size_transpose(size_t es, const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
+{
+	switch (es) {
+		case 2: return launch_transpose<uint16_t>(in, out, batch, R, C, ctx);
+		case 4: return launch_transpose<uint32_t>(in, out, batch, R, C, ctx);
+		case 8: return launch_transpose<uint64_t>(in, out, batch, R, C, ctx);
+	}
+	return CCV_NNC_EXEC_INVALID;
+}
+
+} // namespace
+
+namespace nnc {
+
+// b = a re-laid-out: same logical (n, h, w, c) contents, each tensor in its own format / strides.
+int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx)
+{
+	logical4_t la, lb;
+	if (!logical4(a, &la) || !logical4(b, &lb)) return CCV_NNC_EXEC_INVALID;
+	for (int i = 0; i < 4; i++) if (la.d[i] != lb.d[i]) return CCV_NNC_EXEC_INVALID;
+	const size_t es = datatype_size(a->info.datatype);
+	if (es != datatype_size(b->info.datatype) || es == 0) return CCV_NNC_EXEC_INVALID;
+	const bool dense = tensor_contiguous(a) && tensor_contiguous(b);
+	const int N = la.d[0], HW = la.d[1] * la.d[2], C = la.d[3];
+	if (dense && es >= 2 && a->info.format != b->info.format && HW > 1 && C > 1) {
+		if (a->info.format == CCV_TENSOR_FORMAT_NCHW && b->info.format == CCV_TENSOR_FORMAT_NHWC) return by_size_transpose(es, a->data.u8, b->data.u8, N, C, HW, ctx);
+		if (a->info.format == CCV_TENSOR_FORMAT_NHWC && b->info.format == CCV_TENSOR_FORMAT_NCHW) return by_size_transpose(es, a->data.u8, b->data.u8, N, HW, C, ctx);
+	}
+	// generic: iterate in b's memory order (axes sorted by b's stride, largest first)
+	int order[4] = { 0, 1, 2, 3 };
+	for (int i = 0; i < 4; i++)
+		for (int j = i + 1; j < 4; j++) {
+			const long si = lb.d[order[i]] == 1 ? -1 : lb.s[order[i]], sj = lb.d[order[j]] == 1 ? -1 : lb.s[order[j]];
+			if (sj > si) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+		}
+	perm4_t p;
+	int k = 0;
+	for (int i = 0; i < 4; i++) if (lb.d[order[i]] != 1) { p.dim[k] = lb.d[order[i]]; p.is[k] = la.s[order[i]]; p.os[k] = lb.s[order[i]]; k++; }
+	for (; k < 4; k++) { // pad on the OUTER side with unit axes
+		for (int m = 3; m > 0; m--) { p.dim[m] = p.dim[m - 1]; p.is[m] = p.is[m - 1]; p.os[m] = p.os[m - 1]; }
+		p.dim[0] = 1; p.is[0] = 0; p.os[0] = 0;
+	}
+	return by_size_permute(es, a->data.u8, b->data.u8, p, ctx);
+}
+
+// Dense weight layout change [K][C][kh][kw] (NCHW-format weights) -> [K][kh][kw][C] (the layout the kernels read).
+int weights_nchw_to_nhwc(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx)
+{
+	return launch_transpose<uint32_t>(w, out, K, C, khw, ctx);
+}
+int weights_nhwc_to_nchw(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx)
+{
+	return launch_transpose<uint32_t>(w, out, K, khw, C, ctx);
+}
+
+} // namespace nnc
+
+namespace {
+
+static int _format_transform(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (output_size > input_size) return CCV_NNC_EXEC_INVALID;
+	for (int i = 0; i < output_size; i++) {
+		const ccv_nnc_tensor_t* a = inputs[i];
+		ccv_nnc_tensor_t* b = outputs[i];
+		if (!a || !b || a == b) return CCV_NNC_EXEC_INVALID; // no in-place transform (util_cpu_ref.c:1005)
+		if (a->info.dim[0] == 0 || b->info.dim[0] == 0) continue;
+		const int r = format_transform(a, b, stream_context);
+		if (r != CCV_NNC_EXEC_SUCCESS) return r;
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static int _transpose(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (output_size > input_size) return CCV_NNC_EXEC_INVALID;
+	const int ax0 = cmd.info.transpose.axis[0], ax1 = cmd.info.transpose.axis[1];
+	for (int k = 0; k < output_size; k++) {
+		const ccv_nnc_tensor_t* a = inputs[k];
+		ccv_nnc_tensor_t* b = outputs[k];
+		if (!a || !b) return CCV_NNC_EXEC_INVALID;
+		const int nd = tensor_nd(a->info.dim);
+		if (nd != tensor_nd(b->info.dim) || nd < 2 || nd > 4 || ax0 < 0 || ax1 < 0 || ax0 >= nd || ax1 >= nd) return CCV_NNC_EXEC_INVALID;
+		int as[CCV_NNC_MAX_DIM_ALLOC], bs[CCV_NNC_MAX_DIM_ALLOC];
+		tensor_strides(a, as);
+		tensor_strides(b, bs);
+		perm4_t p;
+		for (int x = 0; x < 4; x++) { p.dim[x] = 1; p.is[x] = 0; p.os[x] = 0; }
+		for (int x = 0; x < nd; x++) { // b's axis x reads a's axis (x swapped)
+			const int ax = x == ax0 ? ax1 : x == ax1 ? ax0 : x;
+			if (b->info.dim[x] != a->info.dim[ax]) return CCV_NNC_EXEC_INVALID;
+			p.dim[4 - nd + x] = b->info.dim[x]; p.os[4 - nd + x] = bs[x]; p.is[4 - nd + x] = as[ax];
+		}
+		const size_t es = datatype_size(a->info.datatype);
+		if (es != datatype_size(b->info.datatype)) return CCV_NNC_EXEC_INVALID;
+		const int r = by_size_permute(es, a->data.u8, b->data.u8, p, stream_context);
+		if (r != CCV_NNC_EXEC_SUCCESS) return r;
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+template <typename TI, typename TO>
+static int convert(const void* in, void* out, size_t n, ccv_nnc_stream_context_t* ctx)
+{
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(convert_kernel<TI, TO>), dim3(grid_for(n, 256)), dim3(256), 0, stream_of(ctx), (const TI*)in, (TO*)out, n);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static int _datatype_conversion(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (output_size > input_size) return CCV_NNC_EXEC_INVALID;
+	for (int i = 0; i < output_size; i++) {
+		const ccv_nnc_tensor_t* a = inputs[i];
+		ccv_nnc_tensor_t* b = outputs[i];
+		if (!a || !b || a == b) return CCV_NNC_EXEC_INVALID;
+		const int da = CCV_GET_DATA_TYPE(a->info.datatype), db = CCV_GET_DATA_TYPE(b->info.datatype);
+		if (da == db) { const int r = format_transform(a, b, stream_context); if (r) return r; continue; } // plain (possibly strided) copy
+		if (!tensor_contiguous(a) || !tensor_contiguous(b)) return CCV_NNC_EXEC_INVALID;
+		const size_t n = tensor_count(a->info);
+		if (n != tensor_count(b->info)) return CCV_NNC_EXEC_INVALID;
+		int r = CCV_NNC_EXEC_INVALID;
+		if (da == CCV_32F && db == CCV_16F) r = convert<float, half_t>(a->data.u8, b->data.u8, n, stream_context);
+		else if (da == CCV_16F && db == CCV_32F) r = convert<half_t, float>(a->data.u8, b->data.u8, n, stream_context);
+		else if (da == CCV_64F && db == CCV_32F) r = convert<double, float>(a->data.u8, b->data.u8, n, stream_context);
+		else if (da == CCV_32F && db == CCV_64F) r = convert<float, double>(a->data.u8, b->data.u8, n, stream_context);
+		else if (da == CCV_64F && db == CCV_16F) r = convert<double, half_t>(a->data.u8, b->data.u8, n, stream_context);
+		else if (da == CCV_16F && db == CCV_64F) r = convert<half_t, double>(a->data.u8, b->data.u8, n, stream_context);
+		if (r != CCV_NNC_EXEC_SUCCESS) return r;
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+} // namespace
+
+#define NNC_REG(CMD, BACKEND, FORMATS, DATATYPES, MEMORY, EXEC) \
+	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
+	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = (MEMORY); registry->algorithms = 1; registry->exec = EXEC; }
+#define ALL_FORMATS (CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN)
+#define MOVABLE_TYPES (CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U)
+
+NNC_REG(CCV_NNC_FORMAT_TRANSFORM_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, MOVABLE_TYPES, CCV_TENSOR_GPU_MEMORY, _format_transform)
+NNC_REG(CCV_NNC_FORMAT_TRANSFORM_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, MOVABLE_TYPES, CCV_TENSOR_GPU_MEMORY, _format_transform)
+NNC_REG(CCV_NNC_TRANSPOSE_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, MOVABLE_TYPES, CCV_TENSOR_GPU_MEMORY, _transpose)
+NNC_REG(CCV_NNC_TRANSPOSE_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, MOVABLE_TYPES, CCV_TENSOR_GPU_MEMORY, _transpose)
+NNC_REG(CCV_NNC_DATATYPE_CONVERSION_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F, CCV_TENSOR_GPU_MEMORY, _datatype_conversion)
+NNC_REG(CCV_NNC_DATATYPE_CONVERSION_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F, CCV_TENSOR_GPU_MEMORY, _datatype_conversion)

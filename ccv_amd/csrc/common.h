@@ -113,6 +113,23 @@ static inline int grid_for(size_t n, int threads)
 	return (int)b;
 }
 
+// Carve a caller-owned prefix out of the stream's single grow-only workspace for the lifetime of the object: the whole
+// (prefix + inner) size is requested up front so the base cannot move, and workspace_of() calls made underneath (the
+// contraction launcher's split-K slabs) are handed the region behind the prefix.
+struct WorkspaceScope {
+	char* base;
+	size_t prev;
+	WorkspaceScope(const ccv_nnc_stream_context_t* ctx, size_t prefix_bytes, size_t inner_bytes);
+	~WorkspaceScope();
+	void* prefix() const { return base; }
+};
+size_t gemm_workspace_bound(long M, long N, long K); // most bytes gemm_run() can ask of workspace_of() for one contraction
+
+// Layout helpers (cmd_util.cpp).
+int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx);
+int weights_nchw_to_nhwc(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx);
+int weights_nhwc_to_nchw(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx);
+
 // Shared device helpers (cmd_ew.cpp).
 int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int accumulate, ccv_nnc_stream_context_t* ctx); // out[c] (+)= sum_r x[r*ld + c]
 int fill_f32(float* p, size_t n, float v, ccv_nnc_stream_context_t* ctx);

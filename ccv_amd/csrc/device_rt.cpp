@@ -7,12 +7,28 @@
 
 namespace {
 
-struct stream_gpu_t {
-	ccv_nnc_stream_context_s super; // host-allocated base (lib/nnc/_ccv_nnc_stream.h:29-46)
-	int device;                     // -1 until bound (CCV_COMPUTE_DEVICE_ANY binds at first use)
+// What a stream context owns per device: a HIP stream and a grow-only scratch buffer (no vendor-library handles).
+struct device_local_t {
 	hipStream_t stream;
 	void* workspace;
 	size_t workspace_size;
+	int device;
+};
+// Layout contract with the reference host (lib/nnc/ccv_nnc_stream.c:15-20, lib/nnc/gpu/ccv_nnc_compat.cu:286-299):
+// the host allocates `super` + a {size_t, void*} CPU-workspace tail for EVERY context (CPU contexts included) and, under
+// its GPU configuration, routes every workspace request -- CPU memory too -- to ccv_nnc_stream_compat_get_workspace, so
+// the CPU scratch lives right behind `super` in both kinds; ccv_nnc_init_stream_context() grows GPU contexts by the rest.
+struct stream_cpu_t {
+	ccv_nnc_stream_context_s super;
+	size_t workspace_size;
+	void* workspace;
+};
+struct stream_gpu_t {
+	ccv_nnc_stream_context_s super; // host-allocated base (lib/nnc/_ccv_nnc_stream.h:29-46)
+	struct { size_t workspace_size; void* workspace; } cpu;
+	device_local_t one;             // contexts created for a fixed device
+	device_local_t* any;            // CCV_COMPUTE_DEVICE_ANY contexts: one slot per device, created at first use there
+	int any_size;
 };
 struct signal_gpu_t {
 	ccv_nnc_stream_signal_s super;
@@ -20,9 +36,9 @@ struct signal_gpu_t {
 };
 // stream_context == NULL: the device's default stream + a per-thread, per-device workspace
 // (lib/nnc/gpu/ccv_nnc_compat.cu:301-340).
-struct default_ctx_t { void* workspace; size_t workspace_size; };
 constexpr int MAX_DEVICES = 64;
-thread_local default_ctx_t tl_default[MAX_DEVICES];
+thread_local device_local_t tl_default[MAX_DEVICES];
+thread_local struct { size_t workspace_size; void* workspace; } tl_default_cpu;
 thread_local const char* tl_last_kernel = "";
 
 struct mem_pressure_t { int device_id; nnc_mi355x_mem_pressure_f func; void* ctx; };
@@ -47,14 +63,31 @@ int current_device()
 	return d;
 }
 
-stream_gpu_t* bind(const ccv_nnc_stream_context_t* ctx)
+bool is_any(const ccv_nnc_stream_context_t* ctx) { return (ctx->type & CCV_COMPUTE_DEVICE_ANY) == CCV_COMPUTE_DEVICE_ANY; }
+
+// The per-device state a command launched through `ctx` uses right now.  A CCV_COMPUTE_DEVICE_ANY context follows the
+// calling thread's current device (lib/nnc/gpu/ccv_nnc_compat.cu:319-340); a fixed-device context makes its device
+// current (the host's single scheduler thread relies on that when it walks a multi-GPU graph), but only when it is
+// not already -- hipGetDevice is a thread-local read, hipSetDevice per launch would be host overhead.
+device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 {
 	stream_gpu_t* s = (stream_gpu_t*)ctx;
-	if (s->device < 0) { // CCV_COMPUTE_DEVICE_ANY: bind to whatever device is current at first use
-		s->device = current_device();
-		HIP_ENFORCE(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+	if (!is_any(ctx)) {
+		if (current_device() != s->one.device) HIP_ENFORCE(hipSetDevice(s->one.device)); // one host thread may drive all 8 GPUs
+		return &s->one;
 	}
-	return s;
+	const int device = current_device();
+	if (device >= s->any_size) {
+		s->any = (device_local_t*)realloc(s->any, sizeof(device_local_t) * (device + 1));
+		memset(s->any + s->any_size, 0, sizeof(device_local_t) * (device + 1 - s->any_size));
+		s->any_size = device + 1;
+	}
+	device_local_t* l = s->any + device;
+	if (!l->stream) {
+		l->device = device;
+		HIP_ENFORCE(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+	}
+	return l;
 }
 
 } // namespace
@@ -65,14 +98,26 @@ hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
 {
 	if (!ctx) return (hipStream_t)0;
 	if (CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU) return (hipStream_t)0;
-	stream_gpu_t* s = bind(ctx);
-	return s->stream;
+	return bind(ctx)->stream;
 }
+
+static thread_local size_t tl_ws_prefix = 0;
 
 void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size)
 {
-	return ccv_nnc_stream_compat_get_workspace(ctx, size, CCV_TENSOR_GPU_MEMORY);
+	char* p = (char*)ccv_nnc_stream_compat_get_workspace(ctx, tl_ws_prefix + size, CCV_TENSOR_GPU_MEMORY);
+	return p ? p + tl_ws_prefix : 0;
 }
+
+WorkspaceScope::WorkspaceScope(const ccv_nnc_stream_context_t* ctx, size_t prefix_bytes, size_t inner_bytes)
+{
+	prefix_bytes = (prefix_bytes + 255) & ~(size_t)255;
+	char* p = (char*)ccv_nnc_stream_compat_get_workspace(ctx, tl_ws_prefix + prefix_bytes + inner_bytes, CCV_TENSOR_GPU_MEMORY);
+	base = p ? p + tl_ws_prefix : 0;
+	prev = tl_ws_prefix;
+	tl_ws_prefix += prefix_bytes;
+}
+WorkspaceScope::~WorkspaceScope() { tl_ws_prefix = prev; }
 
 const float* zero_page_of(const ccv_nnc_stream_context_t* ctx)
 {
@@ -229,86 +274,111 @@ int nnc_mi355x_device_count(void)
 }
 
 ccv_nnc_stream_context_t* ccv_nnc_init_stream_context(ccv_nnc_stream_context_t* const stream_context)
-{ // the host allocated only the base struct: grow it in place into our subclass (compat.cu:426-436)
+{ // the host allocated base + CPU-workspace tail: grow it in place into our subclass (compat.cu:426-436)
 	stream_gpu_t* s = (stream_gpu_t*)realloc(stream_context, sizeof(stream_gpu_t));
-	s->workspace = 0;
-	s->workspace_size = 0;
-	s->stream = 0;
-	const int dev = CCV_STREAM_GET_DEVICE_ID(s->super.type);
-	if ((s->super.type & CCV_COMPUTE_DEVICE_ANY) == CCV_COMPUTE_DEVICE_ANY) s->device = -1;
-	else {
-		s->device = dev;
-		HIP_ENFORCE(hipSetDevice(dev));
-		HIP_ENFORCE(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+	memset(&s->cpu, 0, sizeof(stream_gpu_t) - offsetof(stream_gpu_t, cpu));
+	if (!is_any(&s->super)) {
+		s->one.device = CCV_STREAM_GET_DEVICE_ID(s->super.type);
+		const int prev = current_device();
+		HIP_ENFORCE(hipSetDevice(s->one.device));
+		HIP_ENFORCE(hipStreamCreateWithFlags(&s->one.stream, hipStreamNonBlocking));
+		HIP_ENFORCE(hipSetDevice(prev));
 	}
 	return (ccv_nnc_stream_context_t*)s;
+}
+
+static void local_release(device_local_t* l)
+{
+	if (!l->stream && !l->workspace) return;
+	const int prev = current_device();
+	HIP_ENFORCE(hipSetDevice(l->device));
+	if (l->stream) HIP_ENFORCE(hipStreamSynchronize(l->stream));
+	if (l->workspace) HIP_ENFORCE(hipFree(l->workspace));
+	if (l->stream) HIP_ENFORCE(hipStreamDestroy(l->stream));
+	l->workspace = 0; l->workspace_size = 0; l->stream = 0;
+	HIP_ENFORCE(hipSetDevice(prev));
 }
 
 void ccv_nnc_deinit_stream_context(ccv_nnc_stream_context_t* const stream_context)
 {
 	stream_gpu_t* s = (stream_gpu_t*)stream_context;
-	if (s->device < 0) return;
-	HIP_ENFORCE(hipSetDevice(s->device));
-	if (s->workspace) HIP_ENFORCE(hipFree(s->workspace));
-	s->workspace = 0;
-	s->workspace_size = 0;
-	if (s->stream) HIP_ENFORCE(hipStreamDestroy(s->stream));
-	s->stream = 0;
+	if (s->cpu.workspace) free(s->cpu.workspace);
+	s->cpu.workspace = 0; s->cpu.workspace_size = 0;
+	local_release(&s->one);
+	for (int i = 0; i < s->any_size; i++) local_release(s->any + i);
+	free(s->any);
+	s->any = 0; s->any_size = 0;
 }
 
 void ccv_nnc_synchronize_stream_context(const ccv_nnc_stream_context_t* const stream_context)
 {
 	if (!stream_context) { HIP_ENFORCE(hipStreamSynchronize((hipStream_t)0)); return; }
-	stream_gpu_t* s = bind(stream_context);
-	HIP_ENFORCE(hipSetDevice(s->device));
-	HIP_ENFORCE(hipStreamSynchronize(s->stream));
+	HIP_ENFORCE(hipStreamSynchronize(bind(stream_context)->stream));
 }
 
 void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const stream_context, const size_t workspace_size, const int mem)
-{ // grow-only scratch, one per stream; commands on one stream are ordered so they may share it (compat.cu:438-471)
+{ // grow-only scratch, one per stream (and per device for ANY streams); commands on one stream are ordered so they may
+  // share it (compat.cu:438-471).  NULL context = this thread's default context.
+	if (workspace_size == 0) return 0;
+	if (mem == CCV_TENSOR_CPU_MEMORY) {
+		size_t* size = &tl_default_cpu.workspace_size;
+		void** ws = &tl_default_cpu.workspace;
+		if (stream_context) { stream_cpu_t* c = (stream_cpu_t*)stream_context; size = &c->workspace_size; ws = &c->workspace; }
+		if (*size >= workspace_size) return *ws;
+		free(*ws);
+		*ws = 0; *size = 0;
+		if (posix_memalign(ws, 64, workspace_size) != 0) { *ws = 0; return 0; }
+		*size = workspace_size;
+		return *ws;
+	}
 	if (mem != CCV_TENSOR_GPU_MEMORY) return 0;
-	void** ws;
-	size_t* ws_size;
-	int device;
-	if (stream_context) {
-		stream_gpu_t* s = bind(stream_context);
-		ws = &s->workspace; ws_size = &s->workspace_size; device = s->device;
-	} else {
-		device = current_device();
+	device_local_t* l;
+	hipStream_t st = 0;
+	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = l->stream; }
+	else {
+		const int device = current_device();
 		if (device >= MAX_DEVICES) return 0;
-		ws = &tl_default[device].workspace; ws_size = &tl_default[device].workspace_size;
+		l = &tl_default[device];
+		l->device = device;
 	}
-	if (*ws_size >= workspace_size && *ws) return *ws;
-	if (*ws) {
-		// queued kernels may still read the old buffer
-		HIP_ENFORCE(hipStreamSynchronize(stream_context ? ((stream_gpu_t*)stream_context)->stream : (hipStream_t)0));
-		HIP_ENFORCE(hipFree(*ws));
+	if (l->workspace_size >= workspace_size && l->workspace) return l->workspace;
+	if (l->workspace) {
+		HIP_ENFORCE(hipStreamSynchronize(st)); // queued kernels may still read the old buffer
+		HIP_ENFORCE(hipFree(l->workspace));
 	}
-	*ws = nnc_mi355x_malloc(device, workspace_size);
-	*ws_size = *ws ? workspace_size : 0;
-	return *ws;
+	l->workspace = nnc_mi355x_malloc(st ? l->device : current_device(), workspace_size);
+	l->workspace_size = l->workspace ? workspace_size : 0;
+	return l->workspace;
+}
+
+static void local_drain(device_local_t* l, hipStream_t st)
+{
+	if (!l->workspace) return;
+	HIP_ENFORCE(hipStreamSynchronize(st));
+	HIP_ENFORCE(hipFree(l->workspace));
+	l->workspace = 0;
+	l->workspace_size = 0;
 }
 
 void ccv_nnc_stream_compat_drain(ccv_nnc_stream_context_t* const stream_context)
-{
-	void** ws;
-	size_t* ws_size;
-	hipStream_t st = 0;
-	if (stream_context) {
-		stream_gpu_t* s = (stream_gpu_t*)stream_context;
-		if (s->device < 0) return;
-		ws = &s->workspace; ws_size = &s->workspace_size; st = s->stream;
-	} else {
+{ // drop the scratch buffers (the host calls this under memory pressure, ccv_nnc_stream.c:70-86)
+	if (!stream_context) {
+		free(tl_default_cpu.workspace);
+		tl_default_cpu.workspace = 0; tl_default_cpu.workspace_size = 0;
 		const int device = current_device();
-		if (device >= MAX_DEVICES) return;
-		ws = &tl_default[device].workspace; ws_size = &tl_default[device].workspace_size;
+		if (device < MAX_DEVICES) local_drain(&tl_default[device], (hipStream_t)0);
+		return;
 	}
-	if (*ws) {
-		HIP_ENFORCE(hipStreamSynchronize(st));
-		HIP_ENFORCE(hipFree(*ws));
-		*ws = 0;
-		*ws_size = 0;
-	}
+	stream_cpu_t* c = (stream_cpu_t*)stream_context;
+	free(c->workspace);
+	c->workspace = 0; c->workspace_size = 0;
+	if (CCV_STREAM_GET_CONTEXT(stream_context->type) != CCV_STREAM_CONTEXT_GPU) return;
+	stream_gpu_t* s = (stream_gpu_t*)stream_context;
+	const int prev = current_device();
+	if (s->one.workspace) { HIP_ENFORCE(hipSetDevice(s->one.device)); local_drain(&s->one, s->one.stream); }
+	for (int i = 0; i < s->any_size; i++)
+		if (s->any[i].workspace) { HIP_ENFORCE(hipSetDevice(s->any[i].device)); local_drain(s->any + i, s->any[i].stream); }
+	HIP_ENFORCE(hipSetDevice(prev));
 }
 
 static void host_callback_trampoline(void* userdata)
@@ -326,11 +396,10 @@ static void host_async_trampoline(void* userdata)
 }
 void ccv_nnc_stream_compat_add_callback(ccv_nnc_stream_context_t* const stream, const ccv_nnc_callback_f callback, const ccv_nnc_async_callback_f async_callback, void* const callback_context)
 {
-	stream_gpu_t* s = bind(stream);
+	device_local_t* s = bind(stream);
 	ccv_nnc_async_callback_t* async = (ccv_nnc_async_callback_t*)malloc(sizeof(ccv_nnc_async_callback_t));
 	async->fn = callback;
 	async->callback_context = callback_context;
-	HIP_ENFORCE(hipSetDevice(s->device));
 	if (async_callback) {
 		async_trampoline_t* t = (async_trampoline_t*)malloc(sizeof(async_trampoline_t));
 		t->async_callback = async_callback;
@@ -355,19 +424,15 @@ void ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal)
 }
 void ccv_nnc_stream_compat_emit_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
-	stream_gpu_t* s = bind(stream);
-	HIP_ENFORCE(hipSetDevice(s->device));
-	HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, s->stream));
+	HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, bind(stream)->stream));
 }
 void ccv_nnc_stream_compat_wait_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
-	stream_gpu_t* s = bind(stream);
-	HIP_ENFORCE(hipSetDevice(s->device));
-	HIP_ENFORCE(hipStreamWaitEvent(s->stream, ((const signal_gpu_t*)signal)->event, 0));
+	HIP_ENFORCE(hipStreamWaitEvent(bind(stream)->stream, ((const signal_gpu_t*)signal)->event, 0));
 }
 int ccv_nnc_stream_context_get_device(const ccv_nnc_stream_context_t* const stream_context)
 {
-	if (!stream_context) return current_device();
+	if (!stream_context || CCV_STREAM_GET_CONTEXT(stream_context->type) != CCV_STREAM_CONTEXT_GPU) return current_device();
 	return bind(stream_context)->device;
 }
 void* nnc_mi355x_stream_context_get_stream(const ccv_nnc_stream_context_t* const stream_context)
@@ -377,7 +442,7 @@ void* nnc_mi355x_stream_context_get_stream(const ccv_nnc_stream_context_t* const
 
 ccv_nnc_stream_context_t* nnc_mi355x_stream_context_new(const int type)
 {
-	ccv_nnc_stream_context_t* base = (ccv_nnc_stream_context_t*)calloc(1, sizeof(ccv_nnc_stream_context_s));
+	ccv_nnc_stream_context_t* base = (ccv_nnc_stream_context_t*)calloc(1, sizeof(stream_cpu_t)); // base + CPU-workspace tail, like the host
 	base->type = type;
 	if (CCV_STREAM_GET_CONTEXT(type) == CCV_STREAM_CONTEXT_GPU) return ccv_nnc_init_stream_context(base);
 	return base;
@@ -386,6 +451,7 @@ void nnc_mi355x_stream_context_free(ccv_nnc_stream_context_t* const stream_conte
 {
 	if (!stream_context) return;
 	if (CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) ccv_nnc_deinit_stream_context(stream_context);
+	else free(((stream_cpu_t*)stream_context)->workspace);
 	free(stream_context);
 }
 void nnc_mi355x_stream_context_wait(const ccv_nnc_stream_context_t* const stream_context)

@@ -11,6 +11,7 @@ struct GemmOut {
 	const float* bias; // per output column n (may be null)
 	float alpha;
 	int accumulate; // c += result (CCV_NNC_ACCUMULATE_OUTPUT)
+	long bias_ldm;  // row stride of bias (0 = a single row broadcast over the output rows)
 };
 
 // Split the reduction so that a contraction with few output tiles still fills 256 CUs (2 workgroups per CU fit by
@@ -24,6 +25,20 @@ static inline int gemm_auto_splits(long tiles, int K)
 	if (s > max_s) s = max_s;
 	if (s > 512) s = 512;
 	return s < 1 ? 1 : (int)s;
+}
+
+// Upper bound of the split-K scratch gemm_run() requests for an M x N x K contraction (any tile shape it may pick).
+inline size_t gemm_workspace_bound(long M, long N, long K)
+{
+	size_t worst = 0;
+	static const int shapes[3][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 } };
+	for (int i = 0; i < 3; i++) {
+		const long tiles = ((M + 64 * shapes[i][0] - 1) / (64 * shapes[i][0])) * ((N + 64 * shapes[i][1] - 1) / (64 * shapes[i][1]));
+		const int s = gemm_auto_splits(tiles, (int)(K > 0x7fffffffL ? 0x7fffffffL : K));
+		const size_t b = s > 1 ? sizeof(float) * (size_t)M * N * s : 0;
+		if (b > worst) worst = b;
+	}
+	return worst;
 }
 
 // Pick the block tile: 128x128 unless an output dimension would be mostly padding (64-channel layers), where the
@@ -65,7 +80,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
 	if (splits <= 1) {
 		EpiStore epi;
-		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N;
+		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm;
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
@@ -81,7 +96,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)tiles, (unsigned)splits, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, 0L, 0L, 0L, 0L);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256)), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.alpha, out.accumulate, M, N);
+	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256)), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

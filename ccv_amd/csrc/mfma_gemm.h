@@ -316,16 +316,17 @@ struct Im2colNC {
 struct EpiStore {
 	float* c;
 	long ldm, ldn;
-	const float* bias; // per n, may be null
+	const float* bias; // bias[m * bias_ldm + n]; bias_ldm == 0: one row broadcast over m; may be null
 	float alpha;
 	int accumulate;
 	int M, N;
+	long bias_ldm;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) {
 			const long o = (long)m * ldm + (long)n * ldn;
 			v *= alpha;
-			if (bias) v += bias[n];
+			if (bias) v += bias[(long)m * bias_ldm + n];
 			if (accumulate) v += c[o];
 			c[o] = v;
 		}
@@ -603,14 +604,14 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 }
 
 // Finish a split-K contraction: c = alpha * sum_s slab[s] (+ bias[n]) (+ old c). Fixed summation order => deterministic.
-static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, const int splits, const long slab, float* c, const long ldm, const long ldn, const float* bias, const float alpha, const int accumulate, const int M, const int N)
+static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, const int splits, const long slab, float* c, const long ldm, const long ldn, const float* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N)
 {
 	for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < slab; idx += (long)gridDim.x * blockDim.x) {
 		const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
 		float v = 0.f;
 		for (int s = 0; s < splits; s++) v += ws[(long)s * slab + idx];
 		v *= alpha;
-		if (bias) v += bias[n];
+		if (bias) v += bias[(long)m * bias_ldm + n];
 		const long o = (long)m * ldm + (long)n * ldn;
 		if (accumulate) v += c[o];
 		c[o] = v;

@@ -430,11 +430,13 @@ class Lib:
 
     def __init__(self, path, kind):
         self.path, self.kind = path, kind
-        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL if kind != "oracle" else C.RTLD_LOCAL)
         d = self.dll
         if kind == "reference":
             d.ccv_nnc_init()
             self._exec = d.ccv_nnc_cmd_exec
+        elif kind == "oracle":  # oracle/libnnc_oracle.so: CPU tensors only, no device runtime
+            self._exec = d.nnc_oracle_cmd_exec
         else:
             self._exec = d.nnc_mi355x_cmd_exec
             d.nnc_mi355x_malloc.restype = C.c_void_p

@@ -1,0 +1,43 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY.  The drop-in proof: the reference's OWN host (lib/ + lib/nnc/*.c, unmodified, compiled from
+# where it lies under $REF with its GPU configuration macros) linked against libnnc_mi355x.so, plus the reference's OWN
+# GPU integration tests (test/int/nnc/*.tests.c, compiled from where they lie) linked against that host.
+#   oracle/_ref/libccv_host_gpu.so   host + product library          (runs on the MI355X box)
+#   oracle/_ref/libccv_host_emu.so   host + CPU-emulator build       (runs in this container: CPU test tier)
+#   oracle/_ref/int/<name>.gpu|.emu  the reference's int tests; argv[1] = substring filter on the test-case name
+# The macro names (-DHAVE_CUDA ...) are the reference host's spelling of "a GPU backend is linked in"; no vendor library
+# or header is involved: the host's GPU half is pure C (lib/nnc/gpu/ccv_nnc_compat.h:17-62) and every symbol it needs
+# comes from ccv_amd/csrc (INTEGRATION.md lists them).  Nothing from $REF is copied into the repo.
+set -e
+REF=${REF:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+ROOT=$(dirname "$HERE")
+[ -d "$REF/lib/nnc" ] || { echo "reference not present at $REF; keeping prebuilt files"; exit 0; }
+CC=${CC:-/opt/rocm/lib/llvm/bin/clang}
+OUT=$HERE/_ref
+# 1. host objects (shared by both links)
+OUT=$OUT/hostgpu NAME=host_objs_only.so EXTRA_LINK="-Wl,--unresolved-symbols=ignore-all" "$HERE/build_ref.sh" -DHAVE_CUDA -DHAVE_CUDNN -DHAVE_NCCL > /dev/null
+rm -f $OUT/hostgpu/host_objs_only.so
+OBJS="$OUT/hostgpu/obj/*.o"
+LIBS="/usr/lib/x86_64-linux-gnu/libsqlite3.so.0 -lm -lrt -lpthread"
+# 2. the two host libraries
+$CC -shared -fopenmp -o $OUT/libccv_host_gpu.so $OBJS -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib
+if [ -f $ROOT/tests/emu/_build/libnnc_mi355x_emu.so ]; then
+  cp $ROOT/tests/emu/_build/libnnc_mi355x_emu.so $OUT/libnnc_mi355x_emu.so
+  $CC -shared -fopenmp -o $OUT/libccv_host_emu.so $OBJS -L$OUT -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib
+fi
+# 3. the reference's int tests
+mkdir -p $OUT/int
+TESTS=${TESTS:-"cudnn cublas sgd tensor schedule datatype transform loss reduce"}
+TFLAGS="-O2 -fopenmp -I$REF/lib -I$REF/test -DHAVE_SSE2 -DHAVE_PTHREAD -DUSE_OPENMP -DHAVE_CUDA -DHAVE_CUDNN -DHAVE_NCCL -Wno-everything"
+for t in $TESTS; do
+  src=$REF/test/int/nnc/$t.tests.c
+  [ -f $src ] || continue
+  $CC $TFLAGS $src -o $OUT/int/$t.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
+  if [ -f $OUT/libccv_host_emu.so ]; then
+    $CC $TFLAGS $src -o $OUT/int/$t.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
+  fi
+done
+wait
+ls $OUT/int | tr '\n' ' '; echo
+echo "built $OUT/libccv_host_gpu.so"

@@ -48,7 +48,7 @@ int main(int argc, char** argv)
 	MatLoader<true, true> lb;
 	lb.p = w; lb.zoff = zp - w; lb.ldr = K; lb.ldk = 1; lb.R = KO; lb.K = K;
 	EpiStore epi;
-	epi.c = b; epi.ldm = KO; epi.ldn = 1; epi.bias = 0; epi.alpha = 1.f; epi.accumulate = 0; epi.M = M; epi.N = KO;
+	epi.c = b; epi.ldm = KO; epi.ldn = 1; epi.bias = 0; epi.alpha = 1.f; epi.accumulate = 0; epi.M = M; epi.N = KO; epi.bias_ldm = 0;
 	printf("conv fwd 3x3 N=%d %dx%dx%d -> %d : M=%d N=%d K=%d\n", NB, H, W, C, KO, M, KO, K);
 	const int reps = 10;
 	run<0>(la, lb, epi, M, KO, K, reps);
