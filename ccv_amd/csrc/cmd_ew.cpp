@@ -147,10 +147,35 @@ static int _relu_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	return ew_map<OpReluBack, 2>(OpReluBack(), h->data.f32, g->data.f32, b->data.f32, 0, n, stream_context);
 }
 
+// int32 n-ary sum (the reference sums index tensors with it, ew_gpu_cudnn.cu:13-130): out = in0 + in1 + ...
+struct i32_ptrs_t { const int* p[8]; };
+__global__ void __launch_bounds__(EW_THREADS) ewsum_i32_kernel8(int* out, const i32_ptrs_t in, const int count, const size_t n)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		int v = in.p[0][i];
+		for (int k = 1; k < count; k++) v += in.p[k][i];
+		out[i] = v;
+	}
+}
+
 static int _ewsum_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	if (input_size < 1 || output_size < 1 || !outputs[0]) return CCV_NNC_EXEC_INVALID;
 	ccv_nnc_tensor_t* c = outputs[0];
+	if (CCV_GET_DATA_TYPE(c->info.datatype) == CCV_32S) {
+		if (!tensor_contiguous(c) || input_size > 8) return CCV_NNC_EXEC_INVALID;
+		const size_t n = tensor_count(c->info);
+		i32_ptrs_t ptrs;
+		for (int i = 0; i < input_size; i++) {
+			if (!inputs[i] || !tensor_contiguous(inputs[i]) || tensor_count(inputs[i]->info) != n || CCV_GET_DATA_TYPE(inputs[i]->info.datatype) != CCV_32S) return CCV_NNC_EXEC_INVALID;
+			ptrs.p[i] = inputs[i]->data.i32;
+		}
+		if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+		hipLaunchKernelGGL(ewsum_i32_kernel8, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream_of(stream_context), c->data.i32, ptrs, input_size, n);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
 	if (CCV_GET_DATA_TYPE(c->info.datatype) != CCV_32F || !tensor_contiguous(c)) return CCV_NNC_EXEC_INVALID;
 	const size_t n = tensor_count(c->info);
 	for (int i = 0; i < input_size; i++)
@@ -236,6 +261,12 @@ static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+__global__ void __launch_bounds__(EW_THREADS) fill_f64_kernel(double* p, const size_t n, const double v)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
 static int _set_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	for (int i = 0; i < output_size; i++) {
@@ -247,7 +278,11 @@ static int _set_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 		if (cmd.info.blas.a[0] == 0) { HIP_ENFORCE(hipMemsetAsync(o->data.u8, 0, n * datatype_size(dt), stream_of(stream_context))); continue; }
 		if (dt == CCV_32F) { const int r = fill_f32(o->data.f32, n, cmd.info.blas.a[0], stream_context); if (r) return r; }
 		else if (dt == CCV_32S) { union { int i; float f; } u; u.i = (int)cmd.info.blas.a[0]; const int r = fill_f32(o->data.f32, n, u.f, stream_context); if (r) return r; }
-		else return CCV_NNC_EXEC_INVALID;
+		else if (dt == CCV_64F) { // a double is two 32-bit halves: fill pairs
+			union { double d; float f[2]; } u; u.d = (double)cmd.info.blas.a[0];
+			if (u.f[0] == u.f[1]) { const int r = fill_f32(o->data.f32, n * 2, u.f[0], stream_context); if (r) return r; }
+			else { hipLaunchKernelGGL(fill_f64_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream_of(stream_context), o->data.f64, n, u.d); HIP_ENFORCE(hipGetLastError()); }
+		} else return CCV_NNC_EXEC_INVALID;
 	}
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -327,12 +362,12 @@ int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int acc
 
 NNC_REG(CCV_NNC_RELU_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _relu_forw)
 NNC_REG(CCV_NNC_RELU_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _relu_back)
-NNC_REG(CCV_NNC_EWSUM_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _ewsum_forw)
+NNC_REG(CCV_NNC_EWSUM_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _ewsum_forw)
 NNC_REG(CCV_NNC_EWSUM_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _ewsum_back)
 NNC_REG(CCV_NNC_SCALAR_MUL_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _scalar_mul_forw)
 NNC_REG(CCV_NNC_SCALAR_MUL_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _scalar_mul_back)
 NNC_REG(CCV_NNC_SGD_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _sgd_forw)
-NNC_REG(CCV_NNC_SET_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_forw)
-NNC_REG(CCV_NNC_SET_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_back)
+NNC_REG(CCV_NNC_SET_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_forw)
+NNC_REG(CCV_NNC_SET_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_back)
 NNC_REG(CCV_NNC_DATA_TRANSFER_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
 NNC_REG(CCV_NNC_DATA_TRANSFER_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)

@@ -1,0 +1,252 @@
+// CCV_NNC_BATCH_NORM_FORWARD / BACKWARD on gfx950.  HBM-bound: forward (training) = two reads + one write of x
+// (algorithmic 2|x|: the second read of x is the price of the reference's mean -> centred-variance order, which parity
+// requires); backward = 2 reads of (x, g) + 1 write of h.
+// Oracle semantics: lib/nnc/cmd/norm/ccv_nnc_batch_norm_cpu_ref.c:16-297 (forward: train :44-232, test :233-) and :300-470
+// (backward); I/O contract lib/nnc/cmd/norm/ccv_nnc_norm.c:5-82 (running mean / var are updated IN PLACE).
+// Replaces norm/gpu/ccv_nnc_batch_norm_gpu_cudnn.cu:13-100.
+//
+// x is viewed as [outer][C][inner] around the one axis the statistics keep (NHWC: inner = 1, outer = N*H*W; NCHW:
+// outer = N, inner = H*W).  Per-channel reductions run in two deterministic stages (slice partials in the stream
+// workspace, fixed-order fold), wavefront-coalesced in whichever of C / inner is contiguous.
+#include "common.h"
+
+using namespace nnc;
+
+namespace {
+
+struct chan_view_t { long outer; int C; long inner; };
+
+// which reduction: value contributed by element (x, g) of channel c
+struct RSum { __device__ float operator()(float x, float, int) const { return x; } };
+struct RCenteredSq { const float* mean; __device__ float operator()(float x, float, int c) const { const float w = x - mean[c]; return w * w; } };
+struct RXhatG { const float* mean; const float* inv_std; __device__ float operator()(float x, float g, int c) const { return (x - mean[c]) * inv_std[c] * g; } };
+
+constexpr int RC_COLS = 64, RC_PHASES = 4;
+// inner == 1: rows of C contiguous channels.  grid (ceil(C/64), slices); lanes = 64 consecutive channels.
+template <class F, bool USE_G>
+__global__ void __launch_bounds__(256) chan_reduce_rows_kernel(F f, const float* x, const float* g, const long rows, const int C, const long rows_per_slice, float* partial)
+{
+	__shared__ float red[RC_PHASES][RC_COLS];
+	const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+	const int c = blockIdx.x * RC_COLS + lane;
+	const long r0 = (long)blockIdx.y * rows_per_slice;
+	long r1 = r0 + rows_per_slice;
+	if (r1 > rows) r1 = rows;
+	float s = 0.f;
+	if (c < C)
+		for (long r = r0 + phase; r < r1; r += RC_PHASES) s += f(x[r * C + c], USE_G ? g[r * C + c] : 0.f, c);
+	red[phase][lane] = s;
+	__syncthreads();
+	if (phase == 0 && c < C) partial[(long)blockIdx.y * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+// inner > 1: planes of `inner` contiguous elements.  grid (C, outer): one block per plane, partial[o][c].
+template <class F, bool USE_G>
+__global__ void __launch_bounds__(256) chan_reduce_planes_kernel(F f, const float* x, const float* g, const int C, const long inner, float* partial)
+{
+	__shared__ float red[4];
+	const int c = blockIdx.x;
+	const long base = ((long)blockIdx.y * C + c) * inner;
+	float s = 0.f;
+	for (long i = threadIdx.x; i < inner; i += 256) s += f(x[base + i], USE_G ? g[base + i] : 0.f, c);
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) partial[(long)blockIdx.y * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) chan_fold_kernel(const float* partial, const long slices, const int C, float* out)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	float s = 0.f;
+	for (long i = 0; i < slices; i++) s += partial[i * C + c];
+	out[c] = s;
+}
+
+template <class F, bool USE_G>
+static int chan_reduce(F f, const float* x, const float* g, const chan_view_t& v, float* out, ccv_nnc_stream_context_t* ctx)
+{
+	hipStream_t stream = stream_of(ctx);
+	long slices;
+	float* partial;
+	if (v.inner == 1) {
+		const int col_tiles = (v.C + RC_COLS - 1) / RC_COLS;
+		slices = ((long)device_cu_count() * 4 + col_tiles - 1) / col_tiles;
+		const long max_slices = (v.outer + 63) / 64;
+		if (slices > max_slices) slices = max_slices;
+		if (slices < 1) slices = 1;
+		const long rps = (v.outer + slices - 1) / slices;
+		slices = v.outer > 0 ? (v.outer + rps - 1) / rps : 1;
+		partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * v.C);
+		if (!partial) return CCV_NNC_EXEC_OOM;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_rows_kernel<F, USE_G>), dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, f, x, g, v.outer, v.C, rps > 0 ? rps : 1, partial);
+	} else {
+		slices = v.outer;
+		partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * v.C);
+		if (!partial) return CCV_NNC_EXEC_OOM;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_planes_kernel<F, USE_G>), dim3(v.C, (unsigned)v.outer), dim3(256), 0, stream, f, x, g, v.C, v.inner, partial);
+	}
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 255) / 256), dim3(256), 0, stream, (const float*)partial, slices, v.C, out);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+// ---- per-channel finishing steps (C elements each) ---------------------------------------------------------------------
+// after the sum pass: saved_mean = sum / B; running mean = m * mean + (1 - m) * saved_mean      (batch_norm_cpu_ref.c:67-72)
+__global__ void bn_mean_kernel(float* saved_mean, float* mean, const int C, const float inv_b, const float m)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	const float mu = inv_b * saved_mean[c];
+	saved_mean[c] = mu;
+	mean[c] = m * mean[c] + (1.f - m) * mu;
+}
+// after the centred-square pass: var_b = sum / B (biased); running var; inv_std = 1 / sqrt(var_b + eps); affine y = x * ns + nb  (:107-118,:163-232)
+__global__ void bn_var_kernel(float* saved_inv_std, float* var, const float* saved_mean, const float* scale, const float* bias, float* nscale, float* nbias, const int C, const float inv_b, const float m, const float eps)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	const float v = inv_b * saved_inv_std[c];
+	var[c] = m * var[c] + (1.f - m) * v;
+	const float is = 1.f / sqrtf(v + eps);
+	saved_inv_std[c] = is;
+	const float w = is * scale[c];
+	nscale[c] = w;
+	nbias[c] = bias[c] - saved_mean[c] * w;
+}
+__global__ void bn_test_affine_kernel(const float* mean, const float* var, const float* scale, const float* bias, float* nscale, float* nbias, const int C, const float eps)
+{ // :233-297.  Reference quirk kept for parity: test mode divides by (sqrt(var) + eps), eps OUTSIDE the root (:277)
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	const float w = scale[c] / (sqrtf(var[c]) + eps);
+	nscale[c] = w;
+	nbias[c] = bias[c] - mean[c] * w;
+}
+// y = x * nscale[c] + nbias[c]
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* x, float* y, const float* nscale, const float* nbias, const size_t n, const int C, const long inner)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const int c = (int)((inner == 1 ? i : i / inner) % C);
+		y[i] = x[i] * nscale[c] + nbias[c];
+	}
+}
+// h = (scale * inv_std / B) * (B * g - dbias - xhat * dscale)      (:440-470)
+__global__ void __launch_bounds__(256) bn_back_kernel(const float* x, const float* g, float* h, const float* scale, const float* mean, const float* inv_std, const float* dscale, const float* dbias, const size_t n, const int C, const long inner, const float B)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const int c = (int)((inner == 1 ? i : i / inner) % C);
+		const float is = inv_std[c];
+		const float xhat = (x[i] - mean[c]) * is;
+		h[i] = (1.f / B * scale[c] * is) * (B * g[i] - dbias[c] - xhat * dscale[c]);
+	}
+}
+
+// Derive the [outer][C][inner] view: the statistics tensor (right-aligned against x) keeps exactly one axis.
+static bool chan_view(const ccv_nnc_tensor_t* x, const ccv_nnc_tensor_t* stat, chan_view_t* v)
+{
+	const int nd = tensor_nd(x->info.dim), snd = tensor_nd(stat->info.dim);
+	if (nd < 1 || nd > 4 || snd > nd || !tensor_contiguous(x) || !tensor_contiguous(stat)) return false;
+	int kept = -1;
+	for (int k = 0; k < nd; k++) {
+		const int sd = k - (nd - snd) >= 0 ? stat->info.dim[k - (nd - snd)] : 1;
+		if (sd == 1) continue;
+		if (sd != x->info.dim[k] || kept >= 0) return false;
+		kept = k;
+	}
+	if (kept < 0) { // every axis reduced: one "channel"
+		v->outer = (long)tensor_count(x->info); v->C = 1; v->inner = 1;
+		return true;
+	}
+	v->outer = 1; v->inner = 1;
+	for (int k = 0; k < kept; k++) v->outer *= x->info.dim[k];
+	for (int k = kept + 1; k < nd; k++) v->inner *= x->info.dim[k];
+	v->C = x->info.dim[kept];
+	return true;
+}
+
+static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size != 5 || output_size < 1) return CCV_NNC_EXEC_INVALID;
+	for (int i = 0; i < 5; i++) if (!inputs[i] || CCV_GET_DATA_TYPE(inputs[i]->info.datatype) != CCV_32F || !tensor_contiguous(inputs[i])) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* x = inputs[0];
+	ccv_nnc_tensor_t* y = outputs[0];
+	if (!y || !tensor_contiguous(y) || tensor_count(y->info) != tensor_count(x->info)) return CCV_NNC_EXEC_INVALID;
+	chan_view_t v;
+	if (!chan_view(x, inputs[1], &v)) return CCV_NNC_EXEC_INVALID;
+	for (int i = 1; i < 5; i++) if ((int)tensor_count(inputs[i]->info) != v.C) return CCV_NNC_EXEC_INVALID;
+	const size_t n = tensor_count(x->info);
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	hipStream_t stream = stream_of(stream_context);
+	const float* scale = inputs[1]->data.f32;
+	const float* bias = inputs[2]->data.f32;
+	float* mean = inputs[3]->data.f32;
+	float* var = inputs[4]->data.f32;
+	const int cb = (v.C + 255) / 256;
+	// per-channel affine lives in front of the reduction partials in the workspace
+	WorkspaceScope ws(stream_context, sizeof(float) * 2 * (size_t)v.C, sizeof(float) * (size_t)v.C * (size_t)(v.inner == 1 ? (long)device_cu_count() * 4 + 64 : v.outer));
+	float* nscale = (float*)ws.prefix();
+	if (!nscale) return CCV_NNC_EXEC_OOM;
+	float* nbias = nscale + v.C;
+	int ret;
+	if (!cmd.info.bnorm.is_test) {
+		if (output_size != 5 || !outputs[3] || !outputs[4]) return CCV_NNC_EXEC_INVALID;
+		// running statistics are updated in place (ccv_nnc_norm.c:19-26)
+		if (outputs[1] && outputs[1]->data.f32 != mean) return CCV_NNC_EXEC_INVALID;
+		if (outputs[2] && outputs[2]->data.f32 != var) return CCV_NNC_EXEC_INVALID;
+		float* saved_mean = outputs[3]->data.f32;
+		float* saved_inv_std = outputs[4]->data.f32;
+		if ((int)tensor_count(outputs[3]->info) != v.C || (int)tensor_count(outputs[4]->info) != v.C) return CCV_NNC_EXEC_INVALID;
+		const float inv_b = 1.f / (float)(n / v.C);
+		if ((ret = chan_reduce<RSum, false>(RSum(), x->data.f32, 0, v, saved_mean, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		hipLaunchKernelGGL(bn_mean_kernel, dim3(cb), dim3(256), 0, stream, saved_mean, mean, v.C, inv_b, cmd.info.bnorm.momentum);
+		RCenteredSq f; f.mean = saved_mean;
+		if ((ret = chan_reduce<RCenteredSq, false>(f, x->data.f32, 0, v, saved_inv_std, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		hipLaunchKernelGGL(bn_var_kernel, dim3(cb), dim3(256), 0, stream, saved_inv_std, var, (const float*)saved_mean, scale, bias, nscale, nbias, v.C, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon);
+	} else
+		hipLaunchKernelGGL(bn_test_affine_kernel, dim3(cb), dim3(256), 0, stream, (const float*)mean, (const float*)var, scale, bias, nscale, nbias, v.C, cmd.info.bnorm.epsilon);
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, (const float*)x->data.f32, y->data.f32, (const float*)nscale, (const float*)nbias, n, v.C, v.inner);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	// inputs 0 (g), 5 (x), 6 (scale), 13 (saved_mean), 14 (saved_inv_std) of 15; outputs (h, dscale, dbias)   (ccv_nnc_norm.c:28-36)
+	if (input_size != 15 || output_size < 3) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* g = inputs[0];
+	const ccv_nnc_tensor_t* x = inputs[5];
+	const ccv_nnc_tensor_t* scale = inputs[6];
+	const ccv_nnc_tensor_t* saved_mean = inputs[13];
+	const ccv_nnc_tensor_t* saved_inv_std = inputs[14];
+	ccv_nnc_tensor_t* h = outputs[0];
+	ccv_nnc_tensor_t* dscale = outputs[1];
+	ccv_nnc_tensor_t* dbias = outputs[2];
+	if (!g || !x || !scale || !saved_mean || !saved_inv_std || !h || !dscale || !dbias) return CCV_NNC_EXEC_INVALID;
+	if (CCV_GET_DATA_TYPE(x->info.datatype) != CCV_32F || !tensor_contiguous(g) || !tensor_contiguous(h)) return CCV_NNC_EXEC_INVALID;
+	chan_view_t v;
+	if (!chan_view(x, scale, &v)) return CCV_NNC_EXEC_INVALID;
+	const size_t n = tensor_count(x->info);
+	if (tensor_count(g->info) != n || tensor_count(h->info) != n) return CCV_NNC_EXEC_INVALID;
+	if ((int)tensor_count(saved_mean->info) != v.C || (int)tensor_count(saved_inv_std->info) != v.C || (int)tensor_count(dscale->info) != v.C || (int)tensor_count(dbias->info) != v.C) return CCV_NNC_EXEC_INVALID;
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	int ret;
+	if ((ret = chan_reduce<RSum, false>(RSum(), g->data.f32, 0, v, dbias->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	RXhatG f; f.mean = saved_mean->data.f32; f.inv_std = saved_inv_std->data.f32;
+	if ((ret = chan_reduce<RXhatG, true>(f, x->data.f32, g->data.f32, v, dscale->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	hipLaunchKernelGGL(bn_back_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream_of(stream_context), (const float*)x->data.f32, (const float*)g->data.f32, h->data.f32, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, n, v.C, v.inner, (float)(n / v.C));
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+} // namespace
+
+#define NNC_REG(CMD, BACKEND, FORMATS, DATATYPES, MEMORY, EXEC) \
+	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
+	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = (MEMORY); registry->algorithms = 1; registry->exec = EXEC; }
+#define ALL_FORMATS (CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN)
+
+NNC_REG(CCV_NNC_BATCH_NORM_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _bnorm_forw)
+NNC_REG(CCV_NNC_BATCH_NORM_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _bnorm_back)

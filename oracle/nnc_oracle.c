@@ -332,6 +332,39 @@ static int addmul_forw(const ccv_nnc_cmd_t cmd, int is_mul, ccv_nnc_tensor_t* co
 	}
 	return CCV_NNC_EXEC_SUCCESS;
 }
+/* add backward ccv_nnc_add_cpu_ref.c:200-300: da = p * g, db = q * g, each summed over the axes it was broadcast along;
+ * mul backward ccv_nnc_mul_cpu_ref.c:192-415: inputs (g, a, b): da = p * g * b, db = p * g * a, summed likewise.
+ * A NULL g stands for ones of the broadcast shape of (a, b). */
+static int addmul_back(const ccv_nnc_cmd_t cmd, int is_mul, ccv_nnc_tensor_t* const* in, int nin, ccv_nnc_tensor_t* const* out, int nout)
+{
+	const ccv_nnc_tensor_t* g = in[0];
+	int full[4], od[2][4], xd[2][4], idx[4];
+	int k, o;
+	const ccv_nnc_tensor_t* ops[2] = { nin > 1 ? in[1] : 0, nin > 2 ? in[2] : 0 };
+	for (k = 0; k < 4; k++) full[k] = 1;
+	for (o = 0; o < 2; o++) {
+		const ccv_nnc_tensor_t* shp = (o < nout && out[o]) ? out[o] : ops[o];
+		const int nd = shp ? nd_of(shp->info.dim) : 0;
+		for (k = 0; k < 4; k++) { od[o][k] = shp && k - (4 - nd) >= 0 ? shp->info.dim[k - (4 - nd)] : 1; if (od[o][k] > full[k]) full[k] = od[o][k]; }
+		(void)xd;
+	}
+	if (g) { const int nd = nd_of(g->info.dim); for (k = 0; k < 4; k++) { const int d = k - (4 - nd) >= 0 ? g->info.dim[k - (4 - nd)] : 1; if (d > full[k]) full[k] = d; } }
+	for (o = 0; o < 2 && o < nout; o++) {
+		const float p = is_mul ? cmd.info.blas.a[0] : cmd.info.blas.a[o];
+		const ccv_nnc_tensor_t* other = ops[1 - o];
+		size_t n = 1, i;
+		if (!out[o]) continue;
+		memset(out[o]->data.f32, 0, sizeof(float) * count_of(out[o]));
+		for (k = 0; k < 4; k++) { n *= full[k]; idx[k] = 0; }
+		for (i = 0; i < n; i++) {
+			size_t oi = 0, xi = 0;
+			for (k = 0; k < 4; k++) { oi = oi * od[o][k] + (od[o][k] == 1 ? 0 : idx[k]); xi = xi * od[1 - o][k] + (od[1 - o][k] == 1 ? 0 : idx[k]); }
+			out[o]->data.f32[oi] += p * (g ? g->data.f32[i] : 1.f) * (is_mul ? other->data.f32[xi] : 1.f);
+			for (k = 3; k >= 0; k--) { if (++idx[k] < full[k]) break; idx[k] = 0; }
+		}
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
 /* set / data transfer lib/nnc/cmd/util/ccv_nnc_util_cpu_ref.c:637-664 / :596-617. */
 static int set_forw(const ccv_nnc_cmd_t cmd, ccv_nnc_tensor_t* const* out, int nout)
 {
@@ -455,7 +488,7 @@ static size_t bn_stat_index(const ccv_nnc_tensor_t* x, const ccv_nnc_tensor_t* s
  * (y, mean, var, saved_mean, saved_inv_std) with running mean / var updated IN PLACE (ccv_nnc_norm.c:19-26).
  * train (:44-232): mean_b = sum x / B; var_b = sum (x - mean_b)^2 / B (biased); running = m*running + (1-m)*batch;
  * inv_std = 1/sqrt(var_b + eps); y = x*(inv_std*scale) + (bias - mean_b*inv_std*scale).  test (:233-): the same affine
- * form with the running statistics. */
+ * form with the running statistics, except that the reference divides by (sqrt(var) + eps), eps outside the root (:277). */
 static int bnorm_forw(const ccv_nnc_cmd_t cmd, ccv_nnc_tensor_t* const* in, ccv_nnc_tensor_t* const* out, int nout)
 {
 	const ccv_nnc_tensor_t* x = in[0];
@@ -481,7 +514,7 @@ static int bnorm_forw(const ccv_nnc_cmd_t cmd, ccv_nnc_tensor_t* const* in, ccv_
 		for (i = 0; i < rc; i++) { sistd[i] = inv_b * sistd[i]; var[i] = m * var[i] + (1.f - m) * sistd[i]; sistd[i] = 1.f / sqrtf(sistd[i] + eps); }
 		for (i = 0; i < rc; i++) { nscale[i] = sistd[i] * scale[i]; nbias[i] = bias[i] - smean[i] * nscale[i]; }
 	} else
-		for (i = 0; i < rc; i++) { nscale[i] = scale[i] / sqrtf(var[i] + eps); nbias[i] = bias[i] - mean[i] * nscale[i]; }
+		for (i = 0; i < rc; i++) { nscale[i] = scale[i] / (sqrtf(var[i]) + eps); nbias[i] = bias[i] - mean[i] * nscale[i]; } /* sic: eps OUTSIDE the root in test mode (:277) */
 	for (i = 0; i < n; i++) { const size_t r = bn_stat_index(x, in[1], i); y[i] = x->data.f32[i] * nscale[r] + nbias[r]; }
 	free(nscale);
 	return CCV_NNC_EXEC_SUCCESS;
@@ -532,6 +565,8 @@ int nnc_oracle_cmd_exec(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 		case CCV_NNC_SCALAR_MUL_FORWARD: return scalar_mul_forw(cmd, inputs, outputs);
 		case CCV_NNC_ADD_FORWARD: return addmul_forw(cmd, 0, inputs, input_size, outputs);
 		case CCV_NNC_MUL_FORWARD: return addmul_forw(cmd, 1, inputs, input_size, outputs);
+		case CCV_NNC_ADD_BACKWARD: return addmul_back(cmd, 0, inputs, input_size, outputs, output_size);
+		case CCV_NNC_MUL_BACKWARD: return addmul_back(cmd, 1, inputs, input_size, outputs, output_size);
 		case CCV_NNC_SET_FORWARD: case CCV_NNC_SET_BACKWARD: return set_forw(cmd, outputs, output_size);
 		case CCV_NNC_DATA_TRANSFER_FORWARD: case CCV_NNC_DATA_TRANSFER_BACKWARD: return transfer_forw(inputs, input_size, outputs, output_size);
 		case CCV_NNC_SGD_FORWARD: return sgd_forw(cmd, inputs, outputs);

@@ -116,6 +116,42 @@ def _simple(name, kind):
     return build
 
 
+def _bnorm(name, shape, fmt, is_test=False, backward=False):
+    def build():
+        rng = _rng(name)
+        x = _u(rng, *shape, scale=2.0)
+        caxis = 3 if fmt == "NHWC" else 1
+        C = shape[caxis]
+        sshape = tuple(C if k == caxis else 1 for k in range(4))
+        axes = tuple(k for k in range(4) if k != caxis)
+        scale, bias = _u(rng, *sshape) + 1.5, _u(rng, *sshape)
+        mean, var = _u(rng, *sshape), rng.random(sshape, dtype=F) + 0.5
+        if not backward:
+            outs = [np.zeros_like(x)] if is_test else [np.zeros_like(x), "in3", "in4", np.zeros(sshape, F), np.zeros(sshape, F)]
+            return dict(cmd=nnc.CMD_BATCH_NORM_FORWARD(1e-4, int(is_test), 0.9, *axes), hint=nnc.HINT(), flags=0, fmt=fmt, inputs=[x, scale, bias, mean, var], outputs=outs)
+        red = tuple(axes)
+        mu = x.mean(axis=red, keepdims=True).astype(F)
+        istd = (1.0 / np.sqrt(((x - mu) ** 2).mean(axis=red, keepdims=True) + 1e-4)).astype(F)
+        g = _u(rng, *shape)
+        ins = [g] + [None] * 4 + [x, scale] + [None] * 6 + [mu, istd]
+        return dict(cmd=nnc.CMD_BATCH_NORM_BACKWARD(1e-4, 0, 0.9, *axes), hint=nnc.HINT(), flags=0, fmt=fmt, inputs=ins, outputs=[np.zeros_like(x), np.zeros(sshape, F), np.zeros(sshape, F)])
+    return build
+
+
+def _bcast(name, kind, ashape, bshape, backward=False, with_g=True):
+    def build():
+        rng = _rng(name)
+        a, b = _u(rng, *ashape), _u(rng, *bshape)
+        cshape = np.broadcast_shapes(ashape, bshape)
+        if not backward:
+            cmd = nnc.CMD_ADD_FORWARD(0.5, 0.3) if kind == "add" else nnc.CMD_MUL_FORWARD(0.7)
+            return dict(cmd=cmd, hint=nnc.HINT(), flags=0, fmt="NHWC", inputs=[a, b], outputs=[np.zeros(cshape, F)])
+        g = _u(rng, *cshape) if with_g else None
+        cmd = nnc.CMD_ADD_BACKWARD(0.5, 0.3) if kind == "add" else nnc.CMD_MUL_BACKWARD(0.7)
+        return dict(cmd=cmd, hint=nnc.HINT(), flags=0, fmt="NHWC", inputs=[g, a, b], outputs=[np.zeros(ashape, F), np.zeros(bshape, F)])
+    return build
+
+
 CASES = {}
 
 
@@ -160,12 +196,37 @@ _add("smce_fwd_onehot", _smce("smce_fwd_onehot", 5, 20, label="dense"))
 _add("smce_fwd_smooth", _smce("smce_fwd_smooth", 6, 50, smooth=(0.002, 0.9)))
 _add("smce_bwd_f32label", _smce("smce_bwd_f32label", 6, 50, backward=True))
 _add("smce_bwd_smooth", _smce("smce_bwd_smooth", 6, 50, smooth=(0.002, 0.9), backward=True))
+_add("bnorm_fwd_nhwc", _bnorm("bnorm_fwd_nhwc", (3, 5, 4, 10), "NHWC"))
+_add("bnorm_fwd_nchw", _bnorm("bnorm_fwd_nchw", (3, 6, 5, 4), "NCHW"))
+_add("bnorm_fwd_test_nhwc", _bnorm("bnorm_fwd_test_nhwc", (2, 4, 4, 70), "NHWC", is_test=True))
+_add("bnorm_bwd_nhwc", _bnorm("bnorm_bwd_nhwc", (3, 5, 4, 10), "NHWC", backward=True))
+_add("bnorm_bwd_nchw", _bnorm("bnorm_bwd_nchw", (3, 6, 5, 4), "NCHW", backward=True))
+_add("add_fwd_bcast", _bcast("add_fwd_bcast", "add", (2, 3, 4), (4,)))
+_add("add_fwd_same", _bcast("add_fwd_same", "add", (2, 3, 4, 5), (2, 3, 4, 5)))
+_add("mul_fwd_bcast", _bcast("mul_fwd_bcast", "mul", (4, 1), (2,)))
+_add("add_bwd_bcast", _bcast("add_bwd_bcast", "add", (2, 3, 4), (4,), backward=True))
+_add("mul_bwd_bcast", _bcast("mul_bwd_bcast", "mul", (4, 1), (1, 2), backward=True))
+_add("mul_bwd_same", _bcast("mul_bwd_same", "mul", (2, 3, 4), (2, 3, 4), backward=True))
 for _k in ("relu", "relu_back", "ewsum", "scalar_mul", "sgd", "sgd_nesterov"):
     _add(_k, _simple(_k, _k))
 
 
 def build_case(name):
     return CASES[name]()
+
+
+def _exec_inplace(lib, mem, case, backend):
+    """Like harness.exec_on, but outputs given as "inN" alias input N's tensor (batch norm updates its running statistics in place)."""
+    from harness import make_tensors
+    c = nnc.Cmd()
+    nnc.C.memmove(nnc.C.byref(c), nnc.C.byref(case["cmd"]), nnc.C.sizeof(c))
+    if backend is not None:
+        c.backend = backend
+    it = make_tensors(lib, mem, case["inputs"], case["fmt"])
+    ot = [it[int(o[2:])] if isinstance(o, str) else make_tensors(lib, mem, [o], case["fmt"])[0] for o in case["outputs"]]
+    ret = lib.cmd_exec(c, case["hint"], case["flags"], it, ot)
+    assert ret == 0, "exec returned %d" % ret
+    return [t.numpy() for t in ot]
 
 
 def run_case(lib, mem, case, backend=None, per_image_pool=False):
@@ -175,6 +236,8 @@ def run_case(lib, mem, case, backend=None, per_image_pool=False):
         ret, res = exec_on(lib, mem, cmd, case["hint"], case["flags"], inputs, outputs, fmt, backend=backend)
         assert ret == 0, "exec returned %d" % ret
         return res
+    if any(isinstance(o, str) for o in case["outputs"]):
+        return _exec_inplace(lib, mem, case, backend)
     if not case.get("pool"):
         return one(case["cmd"], case["inputs"], case["outputs"], case["fmt"])
     n = case["inputs"][0].shape[0]
