@@ -75,28 +75,20 @@ static bool logical4(const ccv_nnc_tensor_t* t, logical4_t* o)
 	const int* dim = t->info.dim;
 	for (int i = 0; i < 4; i++) { o->d[i] = 1; o->s[i] = 0; }
 	if (nd > 4 || nd < 1) return false;
-	// positions of (n, h, w, c) inside a full 4-d tensor of this format
-	int pos[4];
-	switch (t->info.format) {
-		case CCV_TENSOR_FORMAT_NHWC: pos[0] = 0; pos[1] = 1; pos[2] = 2; pos[3] = 3; break;
-		case CCV_TENSOR_FORMAT_NCHW: pos[0] = 0; pos[3] = 1; pos[1] = 2; pos[2] = 3; break;
-		case CCV_TENSOR_FORMAT_CHWN: pos[3] = 0; pos[1] = 1; pos[2] = 2; pos[0] = 3; break;
-		default: return false;
+	// Which logical axis each stored dim is, by rank (ccv_nnc_tensor_get_n / _c, lib/nnc/ccv_nnc_easy.h:340-403):
+	//   4-d: the full format;  3-d: no batch;  2-d: (n, c);  1-d: (c)
+	int axis[4]; // logical axis (0 n, 1 h, 2 w, 3 c) of stored dim i
+	if (nd == 1) axis[0] = 3;
+	else if (nd == 2) { axis[0] = 0; axis[1] = 3; if (t->info.format == CCV_TENSOR_FORMAT_CHWN) { axis[0] = 3; axis[1] = 0; } }
+	else {
+		const int full[3][4] = { { 0, 1, 2, 3 } /* NHWC */, { 0, 3, 1, 2 } /* NCHW */, { 3, 1, 2, 0 } /* CHWN */ };
+		const int* f = t->info.format == CCV_TENSOR_FORMAT_NHWC ? full[0] : t->info.format == CCV_TENSOR_FORMAT_NCHW ? full[1] : t->info.format == CCV_TENSOR_FORMAT_CHWN ? full[2] : 0;
+		if (!f) return false;
+		if (nd == 4) for (int i = 0; i < 4; i++) axis[i] = f[i];
+		else { int k = 0; for (int i = 0; i < 4; i++) if (f[i] != 0) axis[k++] = f[i]; } // drop the batch axis
 	}
-	// fewer than 4 dims: the batch axis is the one that is missing first (ccv_nnc_tensor_get_n / _c conventions:
-	// 3-d = no batch; 2-d = [h? ..] treated as trailing axes)
-	const int missing = 4 - nd;
-	for (int l = 0; l < 4; l++) {
-		int ppos = pos[l];
-		if (t->info.format == CCV_TENSOR_FORMAT_CHWN) { // batch is LAST: drop trailing axes
-			if (ppos >= nd) continue;
-		} else { // batch is FIRST: drop leading axes
-			ppos -= missing;
-			if (ppos < 0) continue;
-		}
-		o->d[l] = dim[ppos];
-		o->s[l] = st[ppos];
-	}
+	if (t->info.format != CCV_TENSOR_FORMAT_NHWC && t->info.format != CCV_TENSOR_FORMAT_NCHW && t->info.format != CCV_TENSOR_FORMAT_CHWN) return false;
+	for (int i = 0; i < nd; i++) { o->d[axis[i]] = dim[i]; o->s[axis[i]] = st[i]; }
 	return true;
 }
 

@@ -1,0 +1,45 @@
+"""The reference's OWN GPU integration tests (test/int/nnc/*.tests.c), compiled from where they lie against the
+reference's OWN unmodified host linked to libnnc_mi355x.so (oracle/build_ref_host.sh), run one case per process.
+tests/golden/ref_int_expected_pass.txt is the set of cases this backend claims; every one must print PASS.
+  gpu tier: all of them on the MI355X (oracle/_ref/int/*.gpu)
+  CPU tier: the quick ones on the CPU HIP emulator build of the same kernels (oracle/_ref/int/*.emu)"""
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_int_tests as R  # noqa: E402
+
+
+def _expected():
+    rows = []
+    for line in open(os.path.join(ROOT, "tests", "golden", "ref_int_expected_pass.txt")):
+        if line.strip():
+            s, n = line.rstrip("\n").split("\t", 1)
+            rows.append((s, n))
+    return rows
+
+
+EXPECTED = _expected()
+# convolutions at the reference tests' sizes (64 x 224 x 224 images) take minutes on the emulator
+QUICK = [(s, n) for s, n in EXPECTED if "convolution" not in n]
+
+
+def _run(flavor, suite, name, timeout):
+    b = os.path.join(R.BIN, "%s.%s" % (suite, flavor))
+    if not os.path.exists(b):
+        pytest.skip("%s not built (oracle/build_ref_host.sh needs /root/reference)" % os.path.basename(b))
+    status, detail = R.run_case(b, name, timeout)
+    assert status == "PASS", "%s: %s %s" % (name, status, detail)
+
+
+@pytest.mark.parametrize("suite,name", QUICK[::4], ids=[n for _, n in QUICK[::4]])
+def test_reference_int_case_on_emulator(suite, name):
+    _run("emu", suite, name, 120)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("suite,name", EXPECTED, ids=[n for _, n in EXPECTED])
+def test_reference_int_case_on_gpu(suite, name):
+    _run("gpu", suite, name, 180)
