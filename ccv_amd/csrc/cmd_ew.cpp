@@ -115,6 +115,30 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* x, con
 	__syncthreads();
 	if (phase == 0 && c < cols) partial[(long)blockIdx.y * cols + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
+// 16-byte variant (cols % 4 == 0, ld % 4 == 0, 16-byte aligned): 16 lanes x float4 cover the 64 columns of a tile, the
+// other 16 lane groups of the block walk 16 row phases; fixed-order fold of the phases through LDS.
+__global__ void __launch_bounds__(256) colsum_partial_v4_kernel(const float* x, const long rows, const int cols, const long ld, const long rows_per_slice, float* partial)
+{
+	__shared__ float4 red[16][16];
+	const int q = threadIdx.x & 15, phase = threadIdx.x >> 4;
+	const int c = blockIdx.x * CS_COLS + q * 4;
+	const long r0 = (long)blockIdx.y * rows_per_slice;
+	long r1 = r0 + rows_per_slice;
+	if (r1 > rows) r1 = rows;
+	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (c < cols)
+		for (long r = r0 + phase; r < r1; r += 16) {
+			const float4 v = *(const float4*)(x + r * ld + c);
+			s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+		}
+	red[phase][q] = s;
+	__syncthreads();
+	if (phase == 0 && c < cols) {
+		float4 t = red[0][q];
+		for (int p = 1; p < 16; p++) { const float4 u = red[p][q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+		*(float4*)(partial + (long)blockIdx.y * cols + c) = t;
+	}
+}
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* partial, const int slices, const int cols, float* out, const int accumulate)
 {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,7 +370,10 @@ int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int acc
 	slices = rows > 0 ? (rows + rows_per_slice - 1) / rows_per_slice : 1;
 	float* partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * cols);
 	if (!partial) return CCV_NNC_EXEC_OOM;
-	hipLaunchKernelGGL(colsum_partial_kernel, dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, x, rows, cols, ld, rows_per_slice > 0 ? rows_per_slice : 1, partial);
+	if (cols % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(partial))
+		hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, x, rows, cols, ld, rows_per_slice > 0 ? rows_per_slice : 1, partial);
+	else
+		hipLaunchKernelGGL(colsum_partial_kernel, dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, x, rows, cols, ld, rows_per_slice > 0 ? rows_per_slice : 1, partial);
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, (const float*)partial, (int)slices, cols, out, accumulate);
 	HIP_ENFORCE(hipGetLastError());

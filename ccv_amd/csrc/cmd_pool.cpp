@@ -24,6 +24,7 @@ struct pool_geom_t {
 	long a_sn, a_sh, a_sw, a_sc; // input-shaped tensors (a, h)
 	long b_sn, b_sh, b_sw, b_sc; // output-shaped tensors (b, g)
 	FastDiv d_c, d_w, d_h, d_ow, d_oh; // index decomposition without hardware division
+	FastDiv d_c4, d_sy, d_sx;          // float4 kernels: C / 4 channel groups; strides for the window bounds
 };
 
 // idx -> (n, y, x, c) with the memory-contiguous index fastest; idx < 2^31 (the host splits larger tensors per image).
@@ -111,6 +112,101 @@ __global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, con
 	}
 }
 
+// ---- NHWC, C % 4 == 0, dense channels: one lane per FOUR channels (16-byte loads / stores, a quarter of the index
+// arithmetic per byte), window bounds by multiply-shift instead of hardware division.  Same per-element operation order
+// as the scalar kernels above, so the result is bit-identical.
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ void st4(float* p, const float4 v) { *(float4*)p = v; }
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(256) pool_forw_v4_kernel(const pool_geom_t g, const float* a, float* b, const size_t total)
+{
+	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+		int n, oy, ox, c4;
+		unflatten<true>((int)idx64, g.d_oh, g.d_ow, g.d_c4, n, oy, ox, c4);
+		int y0 = oy * g.sy - g.pby, x0 = ox * g.sx - g.pbx;
+		int y1 = y0 + g.kh, x1 = x0 + g.kw;
+		if (y0 < 0) y0 = 0;
+		if (x0 < 0) x0 = 0;
+		if (y1 > g.H) y1 = g.H;
+		if (x1 > g.W) x1 = g.W;
+		const float* ap = a + n * g.a_sn + c4 * 4;
+		float4 v;
+		if (IS_MAX) {
+			v = ld4(ap + y0 * g.a_sh + x0 * g.a_sw);
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++) {
+					const float4 u = ld4(ap + y * g.a_sh + x * g.a_sw);
+					if (u.x > v.x) v.x = u.x;
+					if (u.y > v.y) v.y = u.y;
+					if (u.z > v.z) v.z = u.z;
+					if (u.w > v.w) v.w = u.w;
+				}
+		} else {
+			v = make_float4(0.f, 0.f, 0.f, 0.f);
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++) {
+					const float4 u = ld4(ap + y * g.a_sh + x * g.a_sw);
+					v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+				}
+			const float cnt = (float)((y1 - y0) * (x1 - x0));
+			v.x = v.x / cnt; v.y = v.y / cnt; v.z = v.z / cnt; v.w = v.w / cnt;
+		}
+		st4(b + n * g.b_sn + oy * g.b_sh + ox * g.b_sw + c4 * 4, v);
+	}
+}
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(256) pool_back_v4_kernel(const pool_geom_t g, const float* gr, const float* a, const float* b, float* h, const size_t total)
+{
+	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+		int n, y, x, c4;
+		unflatten<true>((int)idx64, g.d_h, g.d_w, g.d_c4, n, y, x, c4);
+		// outputs whose window covers (y, x): oy in [ceil((y + p - k + 1) / s), floor((y + p) / s)].  The numerators are
+		// shifted by k * s to stay non-negative for the multiply-shift division.
+		const int ty = y + g.pby, tx = x + g.pbx;
+		int oy0 = g.d_sy.div(ty - g.kh + g.kh * g.sy + g.sy) - g.kh, oy1 = g.d_sy.div(ty);   // ceil(a / s) = floor((a + s - 1) / s)
+		int ox0 = g.d_sx.div(tx - g.kw + g.kw * g.sx + g.sx) - g.kw, ox1 = g.d_sx.div(tx);
+		if (oy0 < 0) oy0 = 0;
+		if (ox0 < 0) ox0 = 0;
+		if (oy1 > g.OH - 1) oy1 = g.OH - 1;
+		if (ox1 > g.OW - 1) ox1 = g.OW - 1;
+		const long ob = n * g.b_sn + c4 * 4;
+		float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+		float4 av = acc;
+		if (IS_MAX) av = ld4(a + n * g.a_sn + y * g.a_sh + x * g.a_sw + c4 * 4);
+		for (int oy = oy0; oy <= oy1; oy++)
+			for (int ox = ox0; ox <= ox1; ox++) {
+				const long o = ob + oy * g.b_sh + ox * g.b_sw;
+				const float4 gv = ld4(gr + o);
+				if (IS_MAX) {
+					const float4 bv = ld4(b + o);
+					if (av.x == bv.x) acc.x += gv.x;
+					if (av.y == bv.y) acc.y += gv.y;
+					if (av.z == bv.z) acc.z += gv.z;
+					if (av.w == bv.w) acc.w += gv.w;
+				} else {
+					int wy0 = oy * g.sy - g.pby, wx0 = ox * g.sx - g.pbx;
+					int wy1 = wy0 + g.kh, wx1 = wx0 + g.kw;
+					if (wy0 < 0) wy0 = 0;
+					if (wx0 < 0) wx0 = 0;
+					if (wy1 > g.H) wy1 = g.H;
+					if (wx1 > g.W) wx1 = g.W;
+					const float cnt = (float)((wy1 - wy0) * (wx1 - wx0));
+					acc.x += gv.x / cnt; acc.y += gv.y / cnt; acc.z += gv.z / cnt; acc.w += gv.w / cnt;
+				}
+			}
+		st4(h + n * g.a_sn + y * g.a_sh + x * g.a_sw + c4 * 4, acc);
+	}
+}
+
+static bool pool_vec4_ok(const pool_geom_t& g, bool nhwc, const void* p0, const void* p1, const void* p2, const void* p3)
+{
+	if (!nhwc || g.C % 4 || g.a_sc != 1 || g.b_sc != 1) return false;
+	if ((g.a_sn | g.a_sh | g.a_sw | g.b_sn | g.b_sh | g.b_sw) % 4) return false;
+	return aligned16(p0) && aligned16(p1) && (!p2 || aligned16(p2)) && (!p3 || aligned16(p3));
+}
+
 static bool pool_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, const ccv_nnc_tensor_t* in_like, const ccv_nnc_tensor_t* out_like, pool_geom_t* g, bool* nhwc)
 {
 	Image4 a, b;
@@ -128,6 +224,7 @@ static bool pool_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, 
 	g->a_sn = a.sn; g->a_sh = a.sh; g->a_sw = a.sw; g->a_sc = a.sc;
 	g->b_sn = b.sn; g->b_sh = b.sh; g->b_sw = b.sw; g->b_sc = b.sc;
 	g->d_c.init(g->C); g->d_w.init(g->W); g->d_h.init(g->H); g->d_ow.init(g->OW); g->d_oh.init(g->OH);
+	g->d_c4.init(g->C / 4 > 0 ? g->C / 4 : 1); g->d_sy.init(g->sy); g->d_sx.init(g->sx);
 	return true;
 }
 
@@ -155,7 +252,8 @@ static int pool_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 		const size_t total = per_image * nn;
 		const float* ap = inputs[0]->data.f32 + (long)n0 * g.a_sn;
 		float* bp = outputs[0]->data.f32 + (long)n0 * g.b_sn;
-		if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
+		if (pool_vec4_ok(g, nhwc, ap, bp, 0, 0)) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_v4_kernel<IS_MAX>), dim3(grid_for(total / 4, 256)), dim3(256), 0, stream, g, ap, bp, total / 4);
+		else if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
 		HIP_ENFORCE(hipGetLastError());
 	}
@@ -191,7 +289,8 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 		const float* ap = a ? a->data.f32 + (long)n0 * g.a_sn : 0;
 		const float* bp = b ? b->data.f32 + (long)n0 * g.b_sn : 0;
 		float* hp = h->data.f32 + (long)n0 * g.a_sn;
-		if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
+		if (pool_vec4_ok(g, nhwc, gp, hp, ap, bp)) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_v4_kernel<IS_MAX>), dim3(grid_for(total / 4, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total / 4);
+		else if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
 		HIP_ENFORCE(hipGetLastError());
 	}

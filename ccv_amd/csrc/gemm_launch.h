@@ -34,7 +34,8 @@ inline size_t gemm_workspace_bound(long M, long N, long K)
 	static const int shapes[3][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 } };
 	for (int i = 0; i < 3; i++) {
 		const long tiles = ((M + 64 * shapes[i][0] - 1) / (64 * shapes[i][0])) * ((N + 64 * shapes[i][1] - 1) / (64 * shapes[i][1]));
-		const int s = gemm_auto_splits(tiles, (int)(K > 0x7fffffffL ? 0x7fffffffL : K));
+		int s = gemm_auto_splits(tiles, (int)(K > 0x7fffffffL ? 0x7fffffffL : K));
+		if (s > 1) s = ((s < 8 ? 8 : s) + 7) & ~7;
 		const size_t b = s > 1 ? sizeof(float) * (size_t)M * N * s : 0;
 		if (b > worst) worst = b;
 	}
@@ -69,8 +70,11 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	if (zcount > 1) splits = 1;
 	int k_per_split = K;
 	if (splits > 1) {
+		// whole K-slices per XCD (see the kernel's block -> (slice, tile) map): the slice count is a multiple of 8;
+		// trailing slices may be empty (they write zero slabs), never more than 7 of them
+		if (splits < 8) splits = 8;
+		splits = (splits + 7) & ~7;
 		k_per_split = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
-		splits = (K + k_per_split - 1) / k_per_split;
 	}
 	note_kernel(name);
 	if (K <= 0) splits = 1;
@@ -82,7 +86,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 		EpiStore epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm;
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, a_z, b_z, c_z, bias_z);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -93,7 +97,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)tiles, (unsigned)splits, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)(tiles * splits), 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, 0L, 0L, 0L, 0L);
 	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256)), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N);

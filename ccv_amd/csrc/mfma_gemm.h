@@ -334,13 +334,13 @@ struct EpiStore {
 };
 // Split-K partial: slab[blockIdx.y][m][n] = acc; splitk_reduce_kernel finishes (deterministic order).
 struct EpiPartial {
-	float* c; // workspace
+	float* c; // workspace; the kernel advances it to this block's slab
 	const float* bias; // unused (applied by splitk_reduce_kernel); keeps the epilogue concept uniform
 	long slab; // M*N
 	int M, N;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
-		if (m < M && n < N) c[(long)blockIdx.y * slab + (long)m * N + n] = v;
+		if (m < M && n < N) c[(long)m * N + n] = v;
 	}
 };
 
@@ -468,11 +468,14 @@ __device__ __forceinline__ void mfma_kstep(const float* sa, const float* sb, con
 	}
 }
 
-// grid: x = tiles (XCD-swizzled), y = split-K slices, z = batch / conv group.  WM / WN = 32x32 MFMA tiles per wave.
+__device__ __forceinline__ long M_N_slab(const EpiStore&) { return 0; }
+__device__ __forceinline__ long M_N_slab(const EpiPartial& e) { return e.slab; }
+
+// grid: x = tiles (* split-K slices), XCD-swizzled; z = batch / conv group.  WM / WN = 32x32 MFMA tiles per wave.
 // DBG (tools/kprobe.cpp only; the library always instantiates DBG = 0): knock out parts of the steady state to attribute time.
 //   1 no global loads, 2 no LDS writes, 4 no barrier, 8 no address prep, 16 no MFMAs, 32 no A loads, 64 no B loads
 template <class LA, class LB, class EPI, int WM, int WN, int DBG = 0>
-__global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff)
+__global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff)
 {
 	constexpr int BM = 64 * WM, BN = 64 * WN;
 	constexpr int A_FLOATS = LA::KCONTIG ? BM * GEMM_LDK : GEMM_BK * BM;
@@ -482,14 +485,25 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	const int lane = t & 63, wave = t >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
 	const int li = lane & 31, lh = lane >> 5;
-	// XCD-aware, bijective remap of the linear workgroup id (cdna_hip_programming.md T1).
+	// XCD-aware, bijective remap of the linear workgroup id (cdna_hip_programming.md T1): workgroup b runs on XCD b % 8.
+	//   no split-K : each XCD gets a contiguous run of tiles (neighbours share im2col halos / weight panels in its L2)
+	//   split-K    : (grid = tiles * splits, splits % 8 == 0) each XCD gets WHOLE K-slices -- slice s = xcd + 8 * j with all
+	//                of its tiles resident together, so the slice's pixel range of both operands streams through that
+	//                XCD's L2 once while every tile of the slice reads it in lockstep (wgrad: 36-144 tiles per slice)
 	const int nwg = gridDim.x;
 	const int bid = blockIdx.x;
-	int tile;
+	int tile, slice = 0;
 	{
 		const int xcd = bid & 7, idx = bid >> 3;
-		const int q = nwg >> 3, r = nwg & 7;
-		tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+		if (splits > 1) {
+			const int tiles = tiles_m * tiles_n;
+			const int j = idx / tiles;
+			tile = idx - j * tiles;
+			slice = xcd + 8 * j;
+		} else {
+			const int q = nwg >> 3, r = nwg & 7;
+			tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+		}
 	}
 	const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 	(void)tiles_m;
@@ -497,7 +511,8 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	la.p += (long)blockIdx.z * a_zoff; la.zoff -= (long)blockIdx.z * a_zoff;
 	lb.p += (long)blockIdx.z * b_zoff; lb.zoff -= (long)blockIdx.z * b_zoff;
 	epi.c += (long)blockIdx.z * c_zoff;
-	const int k_begin = blockIdx.y * k_per_split;
+	if (splits > 1) epi.c += (long)slice * M_N_slab(epi);
+	const int k_begin = slice * k_per_split;
 	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
 	const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
 

@@ -14,10 +14,10 @@ static float run(Im2colKC<true, false> la, MatLoader<true, true> lb, EpiStore ep
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
 	for (int i = 0; i < 2; i++)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0;
