@@ -347,6 +347,87 @@ static int _data_transfer(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// ---- DROPOUT (lib/nnc/cmd/dropout/ccv_nnc_dropout_cpu_ref.c:17-147 / :149-275; replaces dropout/gpu/ccv_nnc_dropout_gpu_cudnn.cu)
+// outputs (b, mask): mask[i] = 1 when element i is dropped (one byte per element in the reserved-space tensor the host sizes,
+// ccv_nnc_dropout.c:21-45), b = mask ? 0 : a / (1 - p); `entirety` draws ONE decision for the whole tensor (int32 in mask[0]).
+// The draw is a counter-based hash of (per-call seed, element index): parity with the reference is statistical by
+// construction (its tests check the drop rate and the 1/(1-p) scaling, test/int/nnc/cudnn.tests.c:3186-3464).
+__host__ __device__ __forceinline__ unsigned mix32(unsigned x)
+{
+	x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+	return x;
+}
+__global__ void __launch_bounds__(EW_THREADS) dropout_forw_kernel(const float* a, float* b, unsigned char* mask, const size_t n, const unsigned seed, const float p, const float inv_p)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const unsigned r = mix32(mix32((unsigned)i ^ seed) + (unsigned)(i >> 32) + 0x9e3779b9U);
+		const int drop = (float)(r >> 8) * (1.f / 16777216.f) <= p;
+		mask[i] = (unsigned char)drop;
+		b[i] = drop ? 0.f : a[i] * inv_p;
+	}
+}
+__global__ void __launch_bounds__(EW_THREADS) dropout_back_kernel(const float* g, float* h, const unsigned char* mask, const size_t n, const float inv_p)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) h[i] = mask[i] ? 0.f : g[i] * inv_p;
+}
+__global__ void __launch_bounds__(EW_THREADS) dropout_entire_kernel(const float* a, float* b, const int* decision, const size_t n, const float inv_p)
+{
+	const int drop = decision[0];
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) b[i] = drop ? 0.f : a[i] * inv_p;
+}
+
+// The host's per-stream generator when the reference host is linked in (lib/nnc/ccv_nnc_stream.c:262), else a process counter.
+extern "C" uint32_t ccv_nnc_stream_context_genrand_uint32(ccv_nnc_stream_context_t* const stream_context) __attribute__((weak));
+static unsigned dropout_seed(ccv_nnc_stream_context_t* ctx)
+{
+	if (ccv_nnc_stream_context_genrand_uint32) return ccv_nnc_stream_context_genrand_uint32(ctx);
+	static unsigned counter = 0x243f6a88U;
+	return __sync_add_and_fetch(&counter, 0x9e3779b9U);
+}
+
+static int _dropout_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 1 || output_size < 2 || !inputs[0] || !outputs[0] || !outputs[1]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* a = inputs[0];
+	if (CCV_GET_DATA_TYPE(a->info.datatype) != CCV_32F || !tensor_contiguous(a) || !tensor_contiguous(outputs[0])) return CCV_NNC_EXEC_INVALID;
+	const size_t n = tensor_count(a->info);
+	if (tensor_count(outputs[0]->info) != n) return CCV_NNC_EXEC_INVALID;
+	const float p = cmd.info.dropout.p, inv_p = 1.f / (1.f - p);
+	const size_t mask_bytes = tensor_count(outputs[1]->info) * datatype_size(outputs[1]->info.datatype);
+	hipStream_t stream = stream_of(stream_context);
+	const unsigned seed = dropout_seed(stream_context);
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	if (cmd.info.dropout.entirety) {
+		if (mask_bytes < sizeof(int)) return CCV_NNC_EXEC_INVALID;
+		const int drop = (float)(mix32(seed) >> 8) * (1.f / 16777216.f) <= p;
+		HIP_ENFORCE(hipMemcpyAsync(outputs[1]->data.u8, &drop, sizeof(int), hipMemcpyHostToDevice, stream)); // pageable source: copied before return
+		hipLaunchKernelGGL(dropout_entire_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)a->data.f32, outputs[0]->data.f32, (const int*)outputs[1]->data.i32, n, inv_p);
+	} else {
+		if (mask_bytes < n) return CCV_NNC_EXEC_INVALID;
+		hipLaunchKernelGGL(dropout_forw_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)a->data.f32, outputs[0]->data.f32, outputs[1]->data.u8, n, seed, p, inv_p);
+	}
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+static int _dropout_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{ // inputs (g, _, _, _, mask), output h   (dropout_cpu_ref.c:149-)
+	if (input_size < 5 || output_size < 1 || !inputs[0] || !inputs[4] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* g = inputs[0];
+	if (CCV_GET_DATA_TYPE(g->info.datatype) != CCV_32F || !tensor_contiguous(g) || !tensor_contiguous(outputs[0])) return CCV_NNC_EXEC_INVALID;
+	const size_t n = tensor_count(g->info);
+	if (tensor_count(outputs[0]->info) != n) return CCV_NNC_EXEC_INVALID;
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	const float inv_p = 1.f / (1.f - cmd.info.dropout.p);
+	hipStream_t stream = stream_of(stream_context);
+	if (cmd.info.dropout.entirety) hipLaunchKernelGGL(dropout_entire_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)g->data.f32, outputs[0]->data.f32, (const int*)inputs[4]->data.i32, n, inv_p);
+	else hipLaunchKernelGGL(dropout_back_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)g->data.f32, outputs[0]->data.f32, (const unsigned char*)inputs[4]->data.u8, n, inv_p);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 } // namespace
 
 namespace nnc {
@@ -393,6 +474,8 @@ NNC_REG(CCV_NNC_EWSUM_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F |
 NNC_REG(CCV_NNC_EWSUM_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _ewsum_back)
 NNC_REG(CCV_NNC_SCALAR_MUL_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _scalar_mul_forw)
 NNC_REG(CCV_NNC_SCALAR_MUL_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _scalar_mul_back)
+NNC_REG(CCV_NNC_DROPOUT_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _dropout_forw)
+NNC_REG(CCV_NNC_DROPOUT_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _dropout_back)
 NNC_REG(CCV_NNC_SGD_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _sgd_forw)
 NNC_REG(CCV_NNC_SET_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_forw)
 NNC_REG(CCV_NNC_SET_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_back)
