@@ -1,0 +1,424 @@
+// The classic image pre-process loops that feed the trainer, as batch HIP kernels behind a C-ABI:
+//   nnc_mi355x_resample_batch  <- ccv_resample   lib/ccv_resample.c:433-478 (dispatch), :11-133 (area, 8-bit fixed point),
+//                                                :135-248 (area, float), :266-431 (bicubic, float / integer)
+//   nnc_mi355x_filter_batch    <- ccv_filter     lib/ccv_numeric.c:1036-1061 (dispatch), :960-1034 (direct 8-bit path)
+// A whole batch of same-sized images resident in HBM is processed by ONE launch (the reference walks one image at a time on
+// a CPU worker thread of the dataframe); both are HBM-bound byte / float streaming kernels: one lane per output element,
+// consecutive lanes on consecutive output elements (channel fastest), source taps gathered through L2.
+//
+// Parity: the reference's row-sequential state machines are restated as per-output-row / per-output-column TAP TABLES built
+// on the host with the reference's own double -> fixed-point formulas, so that
+//   * area 8u -> 8u is integer-only on the device and BIT-EXACT (uint32 sums are order-independent);
+//   * float area / bicubic replay the reference's accumulation order per element (horizontal taps first, then rows);
+//   * the direct 8-bit filter is integer-only and bit-exact (replicated border, 2^14 fixed-point coefficients).
+// The float filter path of the reference goes through a tiled FFT whose border values are artefacts of its tiling; here it is
+// the same correlation computed directly with a replicated border -- identical in the interior (tests compare the interior).
+#include "common.h"
+#include <math.h>
+#include <vector>
+
+using namespace nnc;
+
+namespace {
+
+struct tap_u32_t { int si; unsigned w; };  // source index (element offset within a row, or a row number) and weight
+struct tap_f32_t { int si; float w; };
+
+// ------------------------------------------------------------------------------------------------ area, 8u -> 8u
+// out[dy][dx*ch + c] = min(255, (sum_{(sy, wy) in Y[dy]} wy * (sum_{(sx, wx) in X[dx]} wx * a[sy][sx + c])) / inv_scale_256)
+__global__ void __launch_bounds__(256) area_8u_kernel(const unsigned char* a, unsigned char* b, const long a_step, const long a_image, const long b_step, const long b_image,
+	const int b_rows, const int b_cols_ch, const int ch, const int* xstart, const tap_u32_t* xtaps, const int* ystart, const tap_u32_t* ytaps, const unsigned inv_scale_256, const size_t total)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+		const int e = (int)(idx % b_cols_ch);
+		const size_t r = idx / b_cols_ch;
+		const int dy = (int)(r % b_rows);
+		const size_t img = r / b_rows;
+		const int dx = e / ch, c = e - dx * ch;
+		const unsigned char* ai = a + img * a_image;
+		unsigned acc = 0;
+		for (int ky = ystart[dy]; ky < ystart[dy + 1]; ky++) {
+			const unsigned char* row = ai + (long)ytaps[ky].si * a_step + c;
+			unsigned h = 0;
+			for (int kx = xstart[dx]; kx < xstart[dx + 1]; kx++) h += row[xtaps[kx].si] * xtaps[kx].w;
+			acc += h * ytaps[ky].w;
+		}
+		const unsigned v = acc / inv_scale_256;
+		b[img * b_image + (long)dy * b_step + e] = (unsigned char)(v > 255 ? 255 : v);
+	}
+}
+
+template <typename T> __device__ __forceinline__ float ld_as_float(const void* p, long i) { return (float)((const T*)p)[i]; }
+__device__ __forceinline__ void st_from_float(unsigned char* p, long i, float v) { int t = (int)v; p[i] = (unsigned char)(t < 0 ? 0 : t > 255 ? 255 : t); } // _ccv_set_8u_value: truncate, clamp
+__device__ __forceinline__ void st_from_float(float* p, long i, float v) { p[i] = v; }
+
+// ------------------------------------------------------------------------------------------------ area, float accumulate
+template <typename TA, typename TB>
+__global__ void __launch_bounds__(256) area_f32_kernel(const unsigned char* a, unsigned char* b, const long a_step, const long a_image, const long b_step, const long b_image,
+	const int b_rows, const int b_cols_ch, const int ch, const int* xstart, const tap_f32_t* xtaps, const int* ystart, const tap_f32_t* ytaps, const size_t total)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+		const int e = (int)(idx % b_cols_ch);
+		const size_t r = idx / b_cols_ch;
+		const int dy = (int)(r % b_rows);
+		const size_t img = r / b_rows;
+		const int dx = e / ch, c = e - dx * ch;
+		const unsigned char* ai = a + img * a_image;
+		float acc = 0.f;
+		for (int ky = ystart[dy]; ky < ystart[dy + 1]; ky++) {
+			const unsigned char* row = ai + (long)ytaps[ky].si * a_step;
+			float h = 0.f;
+			for (int kx = xstart[dx]; kx < xstart[dx + 1]; kx++) h += ld_as_float<TA>(row, xtaps[kx].si + c) * xtaps[kx].w;
+			acc += h * ytaps[ky].w;
+		}
+		st_from_float((TB*)(b + img * b_image + (long)dy * b_step), e, acc);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ bicubic
+struct cubic_f_t { int si[4]; float w[4]; };
+struct cubic_i_t { int si[4]; int w[4]; };
+// float-only variant (output 32F): rows are first reduced horizontally into the output type, then combined vertically
+template <typename TA>
+__global__ void __launch_bounds__(256) cubic_f32_kernel(const unsigned char* a, unsigned char* b, const long a_step, const long a_image, const long b_step, const long b_image,
+	const int b_rows, const int b_cols_ch, const int ch, const cubic_f_t* xofs, const cubic_f_t* yofs, const size_t total)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+		const int e = (int)(idx % b_cols_ch);
+		const size_t r = idx / b_cols_ch;
+		const int dy = (int)(r % b_rows);
+		const size_t img = r / b_rows;
+		const int dx = e / ch, c = e - dx * ch;
+		const cubic_f_t xo = xofs[dx], yo = yofs[dy];
+		const unsigned char* ai = a + img * a_image;
+		float rows[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const unsigned char* row = ai + (long)yo.si[k] * a_step;
+			rows[k] = ld_as_float<TA>(row, xo.si[0] * ch + c) * xo.w[0] + ld_as_float<TA>(row, xo.si[1] * ch + c) * xo.w[1] + ld_as_float<TA>(row, xo.si[2] * ch + c) * xo.w[2] + ld_as_float<TA>(row, xo.si[3] * ch + c) * xo.w[3];
+		}
+		((float*)(b + img * b_image + (long)dy * b_step))[e] = rows[0] * yo.w[0] + rows[1] * yo.w[1] + rows[2] * yo.w[2] + rows[3] * yo.w[3];
+	}
+}
+// integer-only variant (8u source, 8u output): 6-bit coefficients both ways, descale by 12, clamp
+__global__ void __launch_bounds__(256) cubic_8u_kernel(const unsigned char* a, unsigned char* b, const long a_step, const long a_image, const long b_step, const long b_image,
+	const int b_rows, const int b_cols_ch, const int ch, const cubic_i_t* xofs, const cubic_i_t* yofs, const size_t total)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+		const int e = (int)(idx % b_cols_ch);
+		const size_t r = idx / b_cols_ch;
+		const int dy = (int)(r % b_rows);
+		const size_t img = r / b_rows;
+		const int dx = e / ch, c = e - dx * ch;
+		const cubic_i_t xo = xofs[dx], yo = yofs[dy];
+		const unsigned char* ai = a + img * a_image;
+		int v = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const unsigned char* row = ai + (long)yo.si[k] * a_step + c;
+			const int h = row[xo.si[0] * ch] * xo.w[0] + row[xo.si[1] * ch] * xo.w[1] + row[xo.si[2] * ch] * xo.w[2] + row[xo.si[3] * ch] * xo.w[3];
+			v += h * yo.w[k];
+		}
+		v = (v + (1 << 11)) >> 12; // ccv_descale(x, 12)
+		b[img * b_image + (long)dy * b_step + e] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ direct 8-bit filter
+// d[y][x] = clamp((sum_{i,j} a[clamp(y + i - kh/2)][clamp(x + j - kw/2)] * coeff[i][j]) >> 14), single channel
+__global__ void __launch_bounds__(256) filter_8u_kernel(const unsigned char* a, unsigned char* d, const long a_step, const long a_image, const long d_step, const long d_image,
+	const int rows, const int cols, const int* coeff, const int kh, const int kw, const size_t total)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+		const int x = (int)(idx % cols);
+		const size_t r = idx / cols;
+		const int y = (int)(r % rows);
+		const size_t img = r / rows;
+		const unsigned char* ai = a + img * a_image;
+		int z = 0;
+		for (int i = 0; i < kh; i++) {
+			int sy = y + i - kh / 2;
+			sy = sy < 0 ? 0 : sy > rows - 1 ? rows - 1 : sy;
+			const unsigned char* row = ai + (long)sy * a_step;
+			for (int j = 0; j < kw; j++) {
+				int sx = x + j - kw / 2;
+				sx = sx < 0 ? 0 : sx > cols - 1 ? cols - 1 : sx;
+				z += row[sx] * coeff[i * kw + j];
+			}
+		}
+		z >>= 14;
+		d[img * d_image + (long)y * d_step + x] = (unsigned char)(z < 0 ? 0 : z > 255 ? 255 : z);
+	}
+}
+// float correlation, replicated border, any channel count (the kernel b has the image's channel count or 1)
+__global__ void __launch_bounds__(256) filter_f32_kernel(const float* a, float* d, const long a_step, const long a_image, const long d_step, const long d_image,
+	const int rows, const int cols, const int ch, const float* coeff, const int kh, const int kw, const int kch, const size_t total)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+		const int e = (int)(idx % ((size_t)cols * ch));
+		const size_t r = idx / ((size_t)cols * ch);
+		const int y = (int)(r % rows);
+		const size_t img = r / rows;
+		const int x = e / ch, c = e - x * ch;
+		const float* ai = (const float*)((const char*)a + img * a_image);
+		float z = 0.f;
+		for (int i = 0; i < kh; i++) {
+			int sy = y + i - kh / 2;
+			sy = sy < 0 ? 0 : sy > rows - 1 ? rows - 1 : sy;
+			const float* row = (const float*)((const char*)ai + (long)sy * a_step);
+			for (int j = 0; j < kw; j++) {
+				int sx = x + j - kw / 2;
+				sx = sx < 0 ? 0 : sx > cols - 1 ? cols - 1 : sx;
+				z += row[sx * ch + c] * coeff[(i * kw + j) * kch + (kch > 1 ? c : 0)];
+			}
+		}
+		((float*)((char*)d + img * d_image + (long)y * d_step))[e] = z;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ host: tap tables
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+// Horizontal taps of the area resample (lib/ccv_resample.c:35-63 / :157-184): left partial, full columns, right partial.
+template <class TAP, class W>
+static void area_x_taps(int a_cols, int b_cols, int ch, double scale_x, W full, double unit, std::vector<int>& start, std::vector<TAP>& taps)
+{
+	start.assign(b_cols + 1, 0);
+	for (int dx = 0; dx < b_cols; dx++) {
+		start[dx] = (int)taps.size();
+		const double fsx1 = dx * scale_x, fsx2 = fsx1 + scale_x;
+		const int sx1 = (int)(fsx1 + 1.0 - 1e-6), sx2 = (int)(fsx2);
+		if (sx1 > fsx1) { TAP t; t.si = imin(sx1 - 1, a_cols - 1) * ch; t.w = (W)((sx1 - fsx1) * unit); taps.push_back(t); }
+		for (int sx = sx1; sx < sx2; sx++) { TAP t; t.si = imin(sx, a_cols - 1) * ch; t.w = full; taps.push_back(t); }
+		if (fsx2 - sx2 > 1e-3) { TAP t; t.si = imin(sx2, a_cols - 1) * ch; t.w = (W)((fsx2 - sx2) * unit); taps.push_back(t); }
+	}
+	start[b_cols] = (int)taps.size();
+}
+
+// Vertical taps of the 8-bit area resample: the reference's row-sequential state machine (lib/ccv_resample.c:68-131) replayed
+// symbolically -- `sum` is kept as a list of (source row, weight) instead of a value.
+static void area_y_taps_8u(int a_rows, int b_rows, double scale_y, std::vector<int>& start, std::vector<tap_u32_t>& taps)
+{
+	std::vector<std::vector<tap_u32_t> > out(b_rows);
+	std::vector<tap_u32_t> sum;
+	int dy = 0, dy_weight_256 = 0;
+	for (int sy = 0; sy < a_rows; sy++) {
+		if (dy < b_rows && (dy + 1) * scale_y <= sy + 1) {
+			unsigned beta = (unsigned)(int)(fmax(sy + 1 - (dy + 1) * scale_y, 0.f) * 256);
+			const unsigned beta1 = 256 - beta;
+			if (sy == a_rows - 1) beta = (unsigned)(int)(scale_y * 256);
+			else dy_weight_256 = (int)beta;
+			out[dy] = sum;
+			tap_u32_t t; t.si = sy;
+			if ((int)beta <= 0) { t.w = 256; out[dy].push_back(t); sum.clear(); }
+			else { t.w = beta1; out[dy].push_back(t); sum.clear(); t.w = beta; sum.push_back(t); }
+			dy++;
+		} else if (dy >= b_rows) {
+			// the reference would write past b here; cannot happen for the scales it is called with (rows_scale = b/a)
+			break;
+		} else {
+			tap_u32_t t; t.si = sy;
+			if (sy == a_rows - 1) { dy_weight_256 = (int)(scale_y * 256) - dy_weight_256; t.w = (unsigned)dy_weight_256; }
+			else { dy_weight_256 += 256; t.w = 256; }
+			sum.push_back(t);
+		}
+	}
+	for (; dy < b_rows; dy++) out[dy] = sum; // :125-130
+	start.assign(b_rows + 1, 0);
+	for (int i = 0; i < b_rows; i++) { start[i] = (int)taps.size(); taps.insert(taps.end(), out[i].begin(), out[i].end()); }
+	start[b_rows] = (int)taps.size();
+}
+// The float variant (lib/ccv_resample.c:186-243): weights 1 for full rows, beta carried into the next output row.
+static void area_y_taps_f32(int a_rows, int b_rows, double scale_y, std::vector<int>& start, std::vector<tap_f32_t>& taps)
+{
+	std::vector<std::vector<tap_f32_t> > out(b_rows);
+	std::vector<tap_f32_t> sum;
+	int dy = 0;
+	float dy_weight = 0;
+	for (int sy = 0; sy < a_rows; sy++) {
+		if (dy < b_rows && (dy + 1) * scale_y <= sy + 1) {
+			float beta = (float)fmax(sy + 1 - (dy + 1) * scale_y, 0.f);
+			const float beta1 = 1 - beta;
+			if (sy == a_rows - 1) beta = (float)scale_y;
+			else dy_weight = beta;
+			out[dy] = sum;
+			tap_f32_t t; t.si = sy;
+			if (fabsf(beta) < 1e-3f) { t.w = 1.f; out[dy].push_back(t); sum.clear(); }
+			else { t.w = beta1; out[dy].push_back(t); sum.clear(); t.w = beta; sum.push_back(t); }
+			dy++;
+		} else if (dy >= b_rows) break;
+		else {
+			tap_f32_t t; t.si = sy;
+			if (sy == a_rows - 1) { dy_weight = (float)(scale_y - dy_weight); t.w = dy_weight; }
+			else { dy_weight += 1; t.w = 1.f; }
+			sum.push_back(t);
+		}
+	}
+	for (; dy < b_rows; dy++) out[dy] = sum;
+	start.assign(b_rows + 1, 0);
+	for (int i = 0; i < b_rows; i++) { start[i] = (int)taps.size(); taps.insert(taps.end(), out[i].begin(), out[i].end()); }
+	start[b_rows] = (int)taps.size();
+}
+
+// Bicubic coefficients, A = -0.75 (lib/ccv_resample.c:266-279 float, :343-357 6-bit integer).
+static void cubic_f(int si, int sz, float s, cubic_f_t* c)
+{
+	const float A = -0.75f;
+	c->si[0] = imin(imax(si - 1, 0), sz - 1); c->si[1] = imin(imax(si, 0), sz - 1); c->si[2] = imin(imax(si + 1, 0), sz - 1); c->si[3] = imin(imax(si + 2, 0), sz - 1);
+	const float x = s - si;
+	c->w[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+	c->w[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+	c->w[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+	c->w[3] = 1.f - c->w[0] - c->w[1] - c->w[2];
+}
+static void cubic_i(int si, int sz, float s, cubic_i_t* c)
+{
+	const float A = -0.75f;
+	c->si[0] = imin(imax(si - 1, 0), sz - 1); c->si[1] = imin(imax(si, 0), sz - 1); c->si[2] = imin(imax(si + 1, 0), sz - 1); c->si[3] = imin(imax(si + 2, 0), sz - 1);
+	const float x = s - si;
+	const int W_BITS = 1 << 6;
+	c->w[0] = (int)((((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A) * W_BITS + 0.5);
+	c->w[1] = (int)((((A + 2) * x - (A + 3)) * x * x + 1) * W_BITS + 0.5);
+	c->w[2] = (int)((((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1) * W_BITS + 0.5);
+	c->w[3] = W_BITS - c->w[0] - c->w[1] - c->w[2];
+}
+
+// Tables are tiny (a few KB): packed behind each other in the stream workspace and uploaded with one async copy from a
+// pinned staging buffer that lives until the stream has consumed it.
+struct upload_t {
+	std::vector<char> host;
+	size_t add(const void* p, size_t bytes) { const size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + bytes); memcpy(host.data() + off, p, bytes); return off; }
+};
+static void staged_free(void* p) { (void)hipHostFree(p); }
+static char* upload(upload_t& u, ccv_nnc_stream_context_t* ctx)
+{
+	char* dev = (char*)workspace_of(ctx, u.host.size());
+	if (!dev) return 0;
+	void* pinned = 0;
+	HIP_ENFORCE(hipHostMalloc(&pinned, u.host.size(), hipHostMallocDefault));
+	memcpy(pinned, u.host.data(), u.host.size());
+	hipStream_t st = stream_of(ctx);
+	HIP_ENFORCE(hipMemcpyAsync(dev, pinned, u.host.size(), hipMemcpyHostToDevice, st));
+	HIP_ENFORCE(hipLaunchHostFunc(st, staged_free, pinned));
+	return dev;
+}
+
+} // namespace
+
+extern "C" {
+
+int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, void* b, const nnc_mi355x_image_batch_t bd, const int count, const double rows_scale, const double cols_scale, const int type, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (!a || !b || count < 0 || rows_scale <= 0 || cols_scale <= 0) return CCV_NNC_EXEC_INVALID;
+	if (ad.channels != bd.channels || ad.channels < 1 || ad.rows < 1 || ad.cols < 1 || bd.rows < 1 || bd.cols < 1) return CCV_NNC_EXEC_INVALID;
+	const int adt = CCV_GET_DATA_TYPE(ad.datatype), bdt = CCV_GET_DATA_TYPE(bd.datatype);
+	if ((adt != CCV_8U && adt != CCV_32F) || (bdt != CCV_8U && bdt != CCV_32F)) return CCV_NNC_EXEC_INVALID;
+	if (count == 0) return CCV_NNC_EXEC_SUCCESS;
+	const int ch = ad.channels;
+	hipStream_t stream = stream_of(stream_context);
+	const size_t total = (size_t)count * bd.rows * bd.cols * ch;
+	const int grid = grid_for(total, 256);
+	const double scale_x = 1.0 / cols_scale, scale_y = 1.0 / rows_scale;
+	if (ad.rows == bd.rows && ad.cols == bd.cols && adt == bdt) { // same size: plain copy (ccv_resample.c:450-458)
+		for (int i = 0; i < count; i++)
+			HIP_ENFORCE(hipMemcpy2DAsync((char*)b + i * bd.image_stride, bd.step, (const char*)a + i * ad.image_stride, ad.step, (size_t)bd.cols * ch * datatype_size(bdt), (size_t)bd.rows, hipMemcpyDeviceToDevice, stream));
+		return CCV_NNC_EXEC_SUCCESS;
+	}
+	upload_t u;
+	if ((type & 0x01 /* CCV_INTER_AREA */) && ad.rows >= bd.rows && ad.cols >= bd.cols) {
+		if (adt == CCV_8U && bdt == CCV_8U && (long)ad.rows * ad.cols / ((long)bd.rows * bd.cols) < 0x100) {
+			if (ch > 4) return CCV_NNC_EXEC_INVALID; // the reference clamps the channel count to 4 on this path (:14)
+			std::vector<int> xs, ys;
+			std::vector<tap_u32_t> xt, yt;
+			area_x_taps<tap_u32_t, unsigned>(ad.cols, bd.cols, ch, scale_x, 256u, 256.0, xs, xt);
+			// NB the reference's left tap uses 0x100 and the right one 256: the same number
+			area_y_taps_8u(ad.rows, bd.rows, scale_y, ys, yt);
+			const unsigned inv_scale_256 = (unsigned)(int)(scale_x * scale_y * 0x10000);
+			if (inv_scale_256 == 0) return CCV_NNC_EXEC_INVALID;
+			const size_t oxs = u.add(xs.data(), xs.size() * sizeof(int)), oxt = u.add(xt.data(), xt.size() * sizeof(tap_u32_t)), oys = u.add(ys.data(), ys.size() * sizeof(int)), oyt = u.add(yt.data(), yt.size() * sizeof(tap_u32_t));
+			char* dev = upload(u, stream_context);
+			if (!dev) return CCV_NNC_EXEC_OOM;
+			hipLaunchKernelGGL(area_8u_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, ch,
+				(const int*)(dev + oxs), (const tap_u32_t*)(dev + oxt), (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), inv_scale_256, total);
+		} else {
+			std::vector<int> xs, ys;
+			std::vector<tap_f32_t> xt, yt;
+			const double scale = 1.f / (scale_x * scale_y);
+			area_x_taps<tap_f32_t, float>(ad.cols, bd.cols, ch, scale_x, (float)scale, scale, xs, xt);
+			area_y_taps_f32(ad.rows, bd.rows, scale_y, ys, yt);
+			const size_t oxs = u.add(xs.data(), xs.size() * sizeof(int)), oxt = u.add(xt.data(), xt.size() * sizeof(tap_f32_t)), oys = u.add(ys.data(), ys.size() * sizeof(int)), oyt = u.add(yt.data(), yt.size() * sizeof(tap_f32_t));
+			char* dev = upload(u, stream_context);
+			if (!dev) return CCV_NNC_EXEC_OOM;
+#define AREA_F32(TA, TB) hipLaunchKernelGGL(HIP_KERNEL_NAME(area_f32_kernel<TA, TB>), dim3(grid), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, ch, \
+				(const int*)(dev + oxs), (const tap_f32_t*)(dev + oxt), (const int*)(dev + oys), (const tap_f32_t*)(dev + oyt), total)
+			if (adt == CCV_8U && bdt == CCV_8U) AREA_F32(unsigned char, unsigned char);
+			else if (adt == CCV_8U) AREA_F32(unsigned char, float);
+			else if (bdt == CCV_8U) AREA_F32(float, unsigned char);
+			else AREA_F32(float, float);
+#undef AREA_F32
+		}
+	} else if (type & 0x04 /* CCV_INTER_CUBIC */) {
+		if (bdt == CCV_32F) {
+			std::vector<cubic_f_t> xo(bd.cols), yo(bd.rows);
+			for (int i = 0; i < bd.cols; i++) { const double sx = (i + 0.5) * scale_x - 0.5; cubic_f((int)sx, ad.cols, (float)sx, &xo[i]); }
+			for (int i = 0; i < bd.rows; i++) { const double sy = (i + 0.5) * scale_y - 0.5; cubic_f((int)sy, ad.rows, (float)sy, &yo[i]); }
+			const size_t ox = u.add(xo.data(), xo.size() * sizeof(cubic_f_t)), oy = u.add(yo.data(), yo.size() * sizeof(cubic_f_t));
+			char* dev = upload(u, stream_context);
+			if (!dev) return CCV_NNC_EXEC_OOM;
+			if (adt == CCV_8U) hipLaunchKernelGGL(HIP_KERNEL_NAME(cubic_f32_kernel<unsigned char>), dim3(grid), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, ch, (const cubic_f_t*)(dev + ox), (const cubic_f_t*)(dev + oy), total);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(cubic_f32_kernel<float>), dim3(grid), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, ch, (const cubic_f_t*)(dev + ox), (const cubic_f_t*)(dev + oy), total);
+		} else {
+			if (adt != CCV_8U) return CCV_NNC_EXEC_INVALID;
+			std::vector<cubic_i_t> xo(bd.cols), yo(bd.rows);
+			for (int i = 0; i < bd.cols; i++) { const double sx = (i + 0.5) * scale_x - 0.5; cubic_i((int)sx, ad.cols, (float)sx, &xo[i]); }
+			for (int i = 0; i < bd.rows; i++) { const double sy = (i + 0.5) * scale_y - 0.5; cubic_i((int)sy, ad.rows, (float)sy, &yo[i]); }
+			const size_t ox = u.add(xo.data(), xo.size() * sizeof(cubic_i_t)), oy = u.add(yo.data(), yo.size() * sizeof(cubic_i_t));
+			char* dev = upload(u, stream_context);
+			if (!dev) return CCV_NNC_EXEC_OOM;
+			hipLaunchKernelGGL(cubic_8u_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, ch, (const cubic_i_t*)(dev + ox), (const cubic_i_t*)(dev + oy), total);
+		}
+	} else
+		return CCV_NNC_EXEC_INVALID; // the reference asserts: LINEAR / LANCZOS are not implemented there either (:470-476)
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+int nnc_mi355x_filter_batch(const void* a, const nnc_mi355x_image_batch_t ad, const void* kernel_host, const int kernel_rows, const int kernel_cols, const int kernel_channels, void* d, const nnc_mi355x_image_batch_t dd, const int count, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (!a || !d || !kernel_host || count < 0 || kernel_rows < 1 || kernel_cols < 1) return CCV_NNC_EXEC_INVALID;
+	if (ad.rows != dd.rows || ad.cols != dd.cols || ad.channels != dd.channels) return CCV_NNC_EXEC_INVALID;
+	const int adt = CCV_GET_DATA_TYPE(ad.datatype), ddt = CCV_GET_DATA_TYPE(dd.datatype);
+	if (count == 0) return CCV_NNC_EXEC_SUCCESS;
+	hipStream_t stream = stream_of(stream_context);
+	const float* kf = (const float*)kernel_host; // the kernel is a small host-side 32F matrix, as in the reference's callers
+	upload_t u;
+	if (adt == CCV_8U && ddt == CCV_8U) { // _ccv_filter_direct_8u (ccv_numeric.c:960-1034): single channel, 2^14 fixed point
+		if (ad.channels != 1 || kernel_channels != 1) return CCV_NNC_EXEC_INVALID;
+		std::vector<int> coeff(kernel_rows * kernel_cols);
+		for (int i = 0; i < kernel_rows * kernel_cols; i++) coeff[i] = (int)(kf[i] * (1 << 14) + 0.5);
+		const size_t oc = u.add(coeff.data(), coeff.size() * sizeof(int));
+		char* dev = upload(u, stream_context);
+		if (!dev) return CCV_NNC_EXEC_OOM;
+		const size_t total = (size_t)count * ad.rows * ad.cols;
+		hipLaunchKernelGGL(filter_8u_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)d, ad.step, ad.image_stride, dd.step, dd.image_stride, ad.rows, ad.cols, (const int*)(dev + oc), kernel_rows, kernel_cols, total);
+	} else if (adt == CCV_32F && ddt == CCV_32F) {
+		if (kernel_channels != 1 && kernel_channels != ad.channels) return CCV_NNC_EXEC_INVALID;
+		const size_t oc = u.add(kf, sizeof(float) * kernel_rows * kernel_cols * kernel_channels);
+		char* dev = upload(u, stream_context);
+		if (!dev) return CCV_NNC_EXEC_OOM;
+		const size_t total = (size_t)count * ad.rows * ad.cols * ad.channels;
+		hipLaunchKernelGGL(filter_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const float*)a, (float*)d, ad.step, ad.image_stride, dd.step, dd.image_stride, ad.rows, ad.cols, ad.channels, (const float*)(dev + oc), kernel_rows, kernel_cols, kernel_channels, total);
+	} else
+		return CCV_NNC_EXEC_INVALID;
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+} // extern "C"

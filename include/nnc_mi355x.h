@@ -289,6 +289,25 @@ int nnc_mi355x_comm_unique_id(void* id_out_128_bytes);
 int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size);
 void nnc_mi355x_comm_destroy(void);
 
+/* ------------------------------------------------ 5. classic image pre-process loops (batch form) -------------------- */
+/* A batch of `count` same-sized images resident in HBM: image i starts at base + i * image_stride; rows are `step` bytes
+ * apart; pixels are `channels` interleaved elements of `datatype` (CCV_8U or CCV_32F) -- ccv_dense_matrix_t's raster
+ * (lib/nnc/ccv_nnc_tfb.h:118-153) without the header. */
+typedef struct {
+	int rows, cols, channels;
+	int datatype;
+	long step;         /* bytes between rows   */
+	long image_stride; /* bytes between images */
+} nnc_mi355x_image_batch_t;
+/* ccv_resample (lib/ccv.h:1294, lib/ccv_resample.c:433-478) over a batch: `type` is CCV_INTER_AREA (0x01, down-scaling) or
+ * CCV_INTER_CUBIC (0x04); rows_scale / cols_scale as in the reference (the output size is b's).  8u -> 8u area is
+ * bit-exact with the reference; the float paths replay its accumulation order.  Returns CCV_NNC_EXEC_*. */
+int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t a_desc, void* b, const nnc_mi355x_image_batch_t b_desc, const int count, const double rows_scale, const double cols_scale, const int type, ccv_nnc_stream_context_t* const stream_context);
+/* ccv_filter (lib/ccv.h, lib/ccv_numeric.c:1036-1061) over a batch: correlation of every image with a small HOST-side 32F
+ * kernel (kernel_rows x kernel_cols x kernel_channels, channels = 1 or the image's), same-size output, replicated border.
+ * 8u -> 8u follows the reference's direct fixed-point path bit for bit (ccv_numeric.c:960-1034). */
+int nnc_mi355x_filter_batch(const void* a, const nnc_mi355x_image_batch_t a_desc, const void* kernel_host, const int kernel_rows, const int kernel_cols, const int kernel_channels, void* d, const nnc_mi355x_image_batch_t d_desc, const int count, ccv_nnc_stream_context_t* const stream_context);
+
 /* HIP-event timing on the stream a context launches on (bench.py roofline leg). */
 void* nnc_mi355x_event_new(void);
 void  nnc_mi355x_event_record(void* event, const ccv_nnc_stream_context_t* const stream_context);

@@ -118,6 +118,7 @@ hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void*) { return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) { for (size_t y = 0; y < height; y++) memmove((char*)d + y * dpitch, (const char*)s + y * spitch, width); return hipSuccess; }
 hipError_t hipMemcpyPeer(void* d, int, const void* s, int, size_t n) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

@@ -164,6 +164,7 @@ hipError_t hipHostRegister(void* p, size_t n, unsigned flags);
 hipError_t hipHostUnregister(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = 0);
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind k, hipStream_t st = 0);
 hipError_t hipMemcpyPeer(void* d, int dd, const void* s, int sd, size_t n);
 hipError_t hipMemcpyPeerAsync(void* d, int dd, const void* s, int sd, size_t n, hipStream_t st = 0);
 hipError_t hipMemset(void* d, int v, size_t n);
