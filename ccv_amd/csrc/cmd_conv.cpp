@@ -54,8 +54,8 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const bool vec = (g.Cg % 4 == 0) && aligned16(a.p) && aligned16(w) && a.sw % 4 == 0 && a.sh % 4 == 0 && (a.n == 1 || a.sn % 4 == 0);
 	GemmOut out = { b.p, b.sw, 1, bias, 1.f, 0 };
-#define CONV_FWD(VEC) do { \
-		Im2colKC<VEC, false> la; \
+#define CONV_FWD(VEC, INC) do { \
+		Im2colKC<VEC, false, INC> la; \
 		la.p = a.p; la.s_n = a.sn; la.s_h = (int)a.sh; la.s_w = (int)a.sw; la.H = g.H; la.W = g.W; \
 		la.OW = g.OW; la.OHW = g.OH * g.OW; la.M = (int)M; la.C = g.Cg; la.KWC = g.kw * g.Cg; la.K = Kred; \
 		la.my = g.sy; la.mx = g.sx; la.oy_off = -g.pby; la.ox_off = -g.pbx; la.ty = g.dy; la.tx = g.dx; la.dv_y = 1; la.dv_x = 1; \
@@ -63,7 +63,9 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 		lb.p = w; lb.ldr = Kred; lb.ldk = 1; lb.R = g.Kg; lb.K = Kred; \
 		return gemm_run("conv_fwd", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, 1, flags, ctx); \
 	} while (0)
-	if (vec) CONV_FWD(true); else CONV_FWD(false);
+	if (vec && Im2colKC<true, false, true>::incr_ok(g.Cg)) CONV_FWD(true, true);
+	else if (vec) CONV_FWD(true, false);
+	else CONV_FWD(false, false);
 #undef CONV_FWD
 }
 
@@ -76,17 +78,18 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const bool vec = (g.Kg % 4 == 0) && (g.Cg % 4 == 0) && aligned16(gr.p) && aligned16(w) && gr.sw % 4 == 0 && gr.sh % 4 == 0 && (gr.n == 1 || gr.sn % 4 == 0);
 	GemmOut out = { h.p, h.sw, 1, 0, 1.f, 0 };
-#define CONV_DGRAD(VEC, STRIDED) do { \
-		Im2colKC<VEC, STRIDED> la; \
+#define CONV_DGRAD(VEC, STRIDED, INC) do { \
+		Im2colKC<VEC, STRIDED, INC> la; \
 		la.p = gr.p; la.s_n = gr.sn; la.s_h = (int)gr.sh; la.s_w = (int)gr.sw; la.H = g.OH; la.W = g.OW; \
 		la.OW = g.W; la.OHW = g.H * g.W; la.M = (int)M; la.C = g.Kg; la.KWC = g.kw * g.Kg; la.K = Kred; \
 		la.my = 1; la.mx = 1; la.oy_off = g.pby; la.ox_off = g.pbx; la.ty = -g.dy; la.tx = -g.dx; la.dv_y = g.sy; la.dv_x = g.sx; \
-		WgtDgradNC<VEC> lb; \
+		WgtDgradNC<VEC, INC> lb; \
 		lb.p = w; lb.ko_stride = (long)g.kh * g.kw * g.Cg; lb.C = g.Cg; lb.Ko = g.Kg; lb.K = Kred; \
 		return gemm_run("conv_dgrad", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, 1, flags, ctx); \
 	} while (0)
-	if (g.sy != 1 || g.sx != 1) { if (vec) CONV_DGRAD(true, true); else CONV_DGRAD(false, true); }
-	else { if (vec) CONV_DGRAD(true, false); else CONV_DGRAD(false, false); }
+	const bool inc = vec && Im2colKC<true, false, true>::incr_ok(g.Kg) && WgtDgradNC<true, true>::incr_ok(g.Kg);
+	if (g.sy != 1 || g.sx != 1) { if (inc) CONV_DGRAD(true, true, true); else if (vec) CONV_DGRAD(true, true, false); else CONV_DGRAD(false, true, false); }
+	else { if (inc) CONV_DGRAD(true, false, true); else if (vec) CONV_DGRAD(true, false, false); else CONV_DGRAD(false, false, false); }
 #undef CONV_DGRAD
 }
 
@@ -99,15 +102,17 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 	const int NN = g.kh * g.kw * g.Cg;
 	const bool vec = (g.Cg % 4 == 0) && (g.Kg % 4 == 0) && aligned16(a.p) && aligned16(gr.p) && a.sw % 4 == 0 && a.sh % 4 == 0 && (a.n == 1 || a.sn % 4 == 0) && gr.sw % 4 == 0;
 	GemmOut out = { dw, (long)NN, 1, 0, 1.f, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0 };
-#define CONV_WGRAD(VEC) do { \
+#define CONV_WGRAD(VEC, INC) do { \
 		MatLoader<false, VEC> la; \
 		la.p = gr.p; la.ldr = 1; la.ldk = gr.sw; la.R = g.Kg; la.K = (int)P; \
-		Im2colNC<VEC> lb; \
+		Im2colNC<VEC, INC> lb; \
 		lb.p = a.p; lb.s_n = a.sn; lb.s_h = (int)a.sh; lb.s_w = (int)a.sw; lb.H = g.H; lb.W = g.W; lb.OW = g.OW; lb.OHW = g.OH * g.OW; \
 		lb.C = g.Cg; lb.KWC = g.kw * g.Cg; lb.NN = NN; lb.K = (int)P; lb.sy = g.sy; lb.sx = g.sx; lb.py = g.pby; lb.px = g.pbx; lb.dy = g.dy; lb.dx = g.dx; \
 		return gemm_run("conv_wgrad", la, lb, out, g.Kg, NN, (int)P, g.groups, (long)g.Kg, (long)g.Cg, (long)g.Kg * NN, 0L, 0, flags, ctx); \
 	} while (0)
-	if (vec) CONV_WGRAD(true); else CONV_WGRAD(false);
+	if (vec && Im2colNC<true, true>::incr_ok(g.OH, g.OW)) CONV_WGRAD(true, true);
+	else if (vec) CONV_WGRAD(true, false);
+	else CONV_WGRAD(false, false);
 #undef CONV_WGRAD
 }
 

@@ -290,23 +290,23 @@ static void cubic_i(int si, int sz, float s, cubic_i_t* c)
 	c->w[3] = W_BITS - c->w[0] - c->w[1] - c->w[2];
 }
 
-// Tables are tiny (a few KB): packed behind each other in the stream workspace and uploaded with one async copy from a
-// pinned staging buffer that lives until the stream has consumed it.
+// Tables are tiny (a few KB): packed behind each other in the stream workspace and uploaded with ONE stream-ordered copy
+// (ordered behind the kernels still reading the previous tables).  The source is ordinary host memory kept alive in a small
+// ring until long after the runtime has staged it -- no host callback, no free from a HIP callback thread (HIP API calls
+// from stream callbacks deadlock).
 struct upload_t {
 	std::vector<char> host;
 	size_t add(const void* p, size_t bytes) { const size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + bytes); memcpy(host.data() + off, p, bytes); return off; }
 };
-static void staged_free(void* p) { (void)hipHostFree(p); }
 static char* upload(upload_t& u, ccv_nnc_stream_context_t* ctx)
 {
+	static thread_local std::vector<char> ring[16];
+	static thread_local unsigned ring_at = 0;
 	char* dev = (char*)workspace_of(ctx, u.host.size());
 	if (!dev) return 0;
-	void* pinned = 0;
-	HIP_ENFORCE(hipHostMalloc(&pinned, u.host.size(), hipHostMallocDefault));
-	memcpy(pinned, u.host.data(), u.host.size());
-	hipStream_t st = stream_of(ctx);
-	HIP_ENFORCE(hipMemcpyAsync(dev, pinned, u.host.size(), hipMemcpyHostToDevice, st));
-	HIP_ENFORCE(hipLaunchHostFunc(st, staged_free, pinned));
+	std::vector<char>& keep = ring[ring_at++ & 15];
+	keep.swap(u.host);
+	HIP_ENFORCE(hipMemcpyAsync(dev, keep.data(), keep.size(), hipMemcpyHostToDevice, stream_of(ctx)));
 	return dev;
 }
 

@@ -73,6 +73,11 @@ struct FastDiv {
 //   Ctx  make(int r) const;                 per-row state (KCONTIG) or per-row-chunk state (!KCONTIG), computed once
 //   KCtx kctx(int k, int klimit) const;     per-k state, computed once per K-step (KCONTIG) / per chunk (!KCONTIG)
 //   long   offset(const Ctx&, const KCtx&) const;   VEC only: element offset from p of the chunk (or zoff when masked)
+//   static constexpr bool INCR; void advance(KCtx&, int klimit) const;   INCR: step a k state by one K-step (BK = 32) with
+//     adds, compares and selects only -- the steady state then carries NO integer multiply or division (on gfx950
+//     v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate and their issue time is NOT hidden behind a wave's own MFMAs: the
+//     division-based wgrad loop spent 56 of them per K-step).  The host picks INCR only when one step wraps each counter
+//     at most once (channels >= 32 per tap, images at least 32/OW + 1 rows, ...).
 //   float4 load(const Ctx&, const KCtx&) const;     !VEC only: the chunk gathered by four scalar loads
 //     KCONTIG:  elements (r, k..k+3)   (k multiple of 4);   !KCONTIG: elements (r..r+3, k)   (r multiple of 4)
 // Rows >= R, k >= klimit and im2col padding read as zero (from the page of zeros).  VEC = one 16-byte global load per chunk
@@ -81,7 +86,7 @@ struct FastDiv {
 // Plain matrix: element(r, k) = p[r * ldr + k * ldk].  KC => ldk == 1, otherwise ldr == 1.
 template <bool KC, bool VEC>
 struct MatLoader {
-	static constexpr bool KCONTIG = KC, VECTOR = VEC;
+	static constexpr bool KCONTIG = KC, VECTOR = VEC, INCR = true;
 	const float* p;
 	long zoff;
 	long ldr, ldk;
@@ -89,6 +94,12 @@ struct MatLoader {
 	void finish() {}
 	struct Ctx { long off; int r; };
 	struct KCtx { long off; int k, klimit; };
+	__device__ __forceinline__ void advance(KCtx& x, int klimit) const
+	{
+		NNC_PIN_V(x.k);
+		x.k += GEMM_BK; x.klimit = klimit;
+		x.off += KC ? (long)GEMM_BK : (long)GEMM_BK * ldk; // one wave-uniform 64-bit product, hoisted out of the loop by hipcc
+	}
 	__device__ __forceinline__ Ctx make(int r) const
 	{
 		Ctx c;
@@ -130,9 +141,9 @@ struct MatLoader {
 // Address = row part (n, oy, ox: once per tile) + tap part (i, j, ch: once per K-step) when !STRIDED.
 // VEC: one 16-byte load per chunk (C % 4 == 0 keeps a chunk inside one tap); !VEC: the four k's of a chunk are resolved
 // one by one (they may straddle taps: conv1_1 has C = 3).
-template <bool VEC, bool STRIDED>
+template <bool VEC, bool STRIDED, bool INC = false>
 struct Im2colKC {
-	static constexpr bool KCONTIG = true, VECTOR = VEC;
+	static constexpr bool KCONTIG = true, VECTOR = VEC, INCR = INC;
 	const float* p;
 	long zoff;
 	long s_n;
@@ -142,9 +153,18 @@ struct Im2colKC {
 	int C, KWC, K;
 	int my, mx, oy_off, ox_off, ty, tx, dv_y, dv_x;
 	FastDiv d_ohw, d_ow, d_kwc, d_c, d_dvy, d_dvx;
-	void finish() { d_ohw.init(OHW); d_ow.init(OW); d_kwc.init(KWC); d_c.init(C); d_dvy.init(dv_y); d_dvx.init(dv_x); }
+	int KWt, w1_off, w2_off; // INC: kw * tx; offset corrections when the channel / the tap column wraps
+	void finish()
+	{
+		d_ohw.init(OHW); d_ow.init(OW); d_kwc.init(KWC); d_c.init(C); d_dvy.init(dv_y); d_dvx.init(dv_x);
+		const int KW = KWC / (C > 0 ? C : 1);
+		KWt = KW * tx;
+		w1_off = STRIDED ? -C : tx * s_w - C;
+		w2_off = STRIDED ? 0 : ty * s_h - KW * tx * s_w;
+	}
+	static bool incr_ok(int C) { return C >= GEMM_BK; } // at most one tap wrap per K-step
 	struct Ctx { long base; int iy0, ix0; }; // !STRIDED: base already includes iy0 * s_h + ix0 * s_w
-	struct K1 { int dy, dx, off; bool ok; }; // !STRIDED: off = dy * s_h + dx * s_w + ch;  STRIDED: off = ch
+	struct K1 { int dy, dx, off; bool ok; int ch, k; }; // !STRIDED: off = dy * s_h + dx * s_w + ch;  STRIDED: off = ch
 	struct KCtx { K1 e[VEC ? 1 : 4]; };
 	__device__ __forceinline__ Ctx make(int m) const
 	{
@@ -169,10 +189,29 @@ struct Im2colKC {
 		const int r = kk - i * KWC;
 		const int j = d_c.div(r);
 		const int ch = r - j * C;
+		x.ch = ch; x.k = k;
 		x.dy = i * ty;
 		x.dx = j * tx;
 		x.off = STRIDED ? ch : x.dy * s_h + x.dx * s_w + ch;
 		return x;
+	}
+	// k += 32 with at most one wrap of the channel counter into the next tap column and of the column into the next tap row
+	__device__ __forceinline__ void advance(KCtx& kc, int klimit) const
+	{
+		K1& x = kc.e[0];
+		NNC_PIN_V(x.k);
+		x.k += GEMM_BK;
+		x.ok = x.k < klimit;
+		x.ch += GEMM_BK;
+		x.off += GEMM_BK;
+		const bool w1 = x.ch >= C;
+		x.ch -= w1 ? C : 0;
+		x.dx += w1 ? tx : 0;
+		x.off += w1 ? w1_off : 0;
+		const bool w2 = tx > 0 ? x.dx >= KWt : x.dx <= KWt; // tx < 0 for dgrad (taps walked backwards)
+		x.dx -= w2 ? KWt : 0;
+		x.dy += w2 ? ty : 0;
+		x.off += w2 ? w2_off : 0;
 	}
 	__device__ __forceinline__ KCtx kctx(int k, int klimit) const
 	{
@@ -206,17 +245,29 @@ struct Im2colKC {
 };
 
 // conv dgrad weights: B(k = (tap, ko), n = c) = w[ko][tap][c]  (n contiguous).
-template <bool VEC>
+template <bool VEC, bool INC = false>
 struct WgtDgradNC {
-	static constexpr bool KCONTIG = false, VECTOR = VEC;
+	static constexpr bool KCONTIG = false, VECTOR = VEC, INCR = INC;
 	const float* p;
 	long zoff;
 	long ko_stride; // kh*kw*C
 	int C, Ko, K;   // K = kh*kw*Ko
 	FastDiv d_ko;
 	void finish() { d_ko.init(Ko); }
+	static bool incr_ok(int Ko) { return Ko >= GEMM_BK; }
 	struct Ctx { int c; };
-	struct KCtx { long off; bool ok; };
+	struct KCtx { long off; bool ok; int ko, k; };
+	__device__ __forceinline__ void advance(KCtx& x, int klimit) const
+	{
+		NNC_PIN_V(x.k);
+		x.k += GEMM_BK;
+		x.ok = x.k < klimit;
+		x.ko += GEMM_BK;
+		x.off += (long)GEMM_BK * ko_stride;
+		const bool w = x.ko >= Ko;
+		x.ko -= w ? Ko : 0;
+		x.off += w ? (long)C - (long)Ko * ko_stride : 0L;
+	}
 	__device__ __forceinline__ Ctx make(int c) const { Ctx x; x.c = c; return x; }
 	__device__ __forceinline__ KCtx kctx(int k, int klimit) const
 	{
@@ -225,6 +276,7 @@ struct WgtDgradNC {
 		const int kk = x.ok ? k : 0;
 		const int tap = d_ko.div(kk);
 		const int ko = kk - tap * Ko;
+		x.ko = ko; x.k = k;
 		x.off = (long)ko * ko_stride + (long)tap * C;
 		return x;
 	}
@@ -249,9 +301,9 @@ struct WgtDgradNC {
 
 // conv wgrad activations: B(k = pixel (n, oy, ox), nn = (tap_y, tap_x, c)) = a[n, oy*sy - py + i*dy, ox*sx - px + j*dx, c].
 // Address = pixel part (once per k) + column part (tap and channel: once per tile).
-template <bool VEC>
+template <bool VEC, bool INC = false>
 struct Im2colNC {
-	static constexpr bool KCONTIG = false, VECTOR = VEC;
+	static constexpr bool KCONTIG = false, VECTOR = VEC, INCR = INC;
 	const float* p;
 	long zoff;
 	long s_n;
@@ -261,9 +313,34 @@ struct Im2colNC {
 	int C, KWC, NN, K; // NN = kh*kw*C, K = N*OH*OW
 	int sy, sx, py, px, dy, dx;
 	FastDiv d_ohw, d_ow;
-	void finish() { d_ohw.init(OHW); d_ow.init(OW); }
+	// INC: one K-step = 32 pixels further = q32 rows and r32 columns, then at most one column wrap and one image wrap
+	int OH, q32, r32, st_by, st_bx, w1_by, w1_bx, w2_by;
+	long st_base, w1_base, w2_base;
+	void finish()
+	{
+		d_ohw.init(OHW); d_ow.init(OW);
+		OH = OHW / (OW > 0 ? OW : 1);
+		q32 = GEMM_BK / OW; r32 = GEMM_BK % OW;
+		st_by = q32 * sy; st_bx = r32 * sx; st_base = (long)st_by * s_h + (long)st_bx * s_w;
+		w1_by = sy; w1_bx = -OW * sx; w1_base = (long)sy * s_h - (long)OW * sx * s_w;
+		w2_by = -OH * sy; w2_base = s_n - (long)OH * sy * s_h;
+	}
+	static bool incr_ok(int OH, int OW) { return GEMM_BK / OW + 1 <= OH; }
 	struct Ctx { int off_y[VEC ? 1 : 4], off_x[VEC ? 1 : 4], off[VEC ? 1 : 4]; bool ok[VEC ? 1 : 4]; }; // per column: i*dy - py, j*dx - px, their offset + c
-	struct KCtx { long base; int by, bx; bool ok; }; // base = n * s_n + by * s_h + bx * s_w
+	struct KCtx { long base; int by, bx; bool ok; int ox, oy, k; }; // base = n * s_n + by * s_h + bx * s_w
+	__device__ __forceinline__ void advance(KCtx& x, int klimit) const
+	{
+		NNC_PIN_V(x.k);
+		x.k += GEMM_BK;
+		x.ok = x.k < klimit;
+		x.ox += r32; x.oy += q32; x.bx += st_bx; x.by += st_by; x.base += st_base;
+		const bool w1 = x.ox >= OW;
+		x.ox -= w1 ? OW : 0; x.oy += w1 ? 1 : 0;
+		x.bx += w1 ? w1_bx : 0; x.by += w1 ? w1_by : 0; x.base += w1 ? w1_base : 0L;
+		const bool w2 = x.oy >= OH;
+		x.oy -= w2 ? OH : 0;
+		x.by += w2 ? w2_by : 0; x.base += w2 ? w2_base : 0L;
+	}
 	__device__ __forceinline__ Ctx make(int nn) const
 	{
 		Ctx c;
@@ -289,6 +366,7 @@ struct Im2colNC {
 		const int rem = kk - n * OHW;
 		const int oy = d_ow.div(rem);
 		const int ox = rem - oy * OW;
+		x.ox = ox; x.oy = oy; x.k = k;
 		x.by = oy * sy;
 		x.bx = ox * sx;
 		x.base = (long)n * s_n + (long)(x.by * s_h + x.bx * s_w);
@@ -355,7 +433,8 @@ struct TileFetch {
 	typename L::Ctx ctx[NCTX];
 	int koff[NCH];
 	long off[L::VECTOR ? NCH : 1]; // VECTOR: the chunk offsets prep_*() resolved for the tile issue() will load
-	typename L::KCtx kc;           // VECTOR && KCONTIG: the K-step's k state shared by all chunks
+	static constexpr int NKC = L::VECTOR ? (L::KCONTIG ? 1 : NCH) : 1;
+	typename L::KCtx kcs[NKC];     // VECTOR: the k state of the tile being prepared: one shared by all chunks (KCONTIG) or one per chunk
 	int kb, kl;
 	__device__ __forceinline__ void init(const L& l, int row0, int t)
 	{
@@ -368,23 +447,36 @@ struct TileFetch {
 	}
 	// Address phase of the tile at K offset kbase: pure integer VALU, cut into 1 + NCH pieces so the kernel can slot
 	// them between the MFMAs of the previous tile.  prep_k first, then prep_chunk(jj) in any order.
+	// FIRST = the tile's k states are computed from scratch (multiply-shift divisions); otherwise INCR loaders step the
+	// states of the previously prepared tile by one K-step (the caller prepares tiles strictly in order).
+	template <bool FIRST>
 	__device__ __forceinline__ void prep_k(const L& l, int kbase, int klimit)
 	{
 		NNC_PIN_S(kbase);
 		kb = kbase; kl = klimit;
-		if (L::VECTOR && L::KCONTIG) kc = l.kctx(kbase + koff[0], klimit);
+		if (L::VECTOR && L::KCONTIG) {
+			if (L::INCR && !FIRST) l.advance(kcs[0], klimit);
+			else kcs[0] = l.kctx(kbase + koff[0], klimit);
+		}
 	}
+	template <bool FIRST>
 	__device__ __forceinline__ void prep_chunk(const L& l, const int jj)
 	{
 		if (!L::VECTOR) return;
-		if (L::KCONTIG) { l.pin(ctx[jj % NCTX]); off[L::VECTOR ? jj : 0] = l.offset(ctx[jj % NCTX], kc); }
-		else { NNC_PIN_V(koff[jj]); off[L::VECTOR ? jj : 0] = l.offset(ctx[0], l.kctx(kb + koff[jj], kl)); }
+		if (L::KCONTIG) { l.pin(ctx[jj % NCTX]); off[L::VECTOR ? jj : 0] = l.offset(ctx[jj % NCTX], kcs[0]); }
+		else {
+			typename L::KCtx& kc = kcs[L::VECTOR && !L::KCONTIG ? jj : 0];
+			if (L::INCR && !FIRST) l.advance(kc, kl);
+			else { NNC_PIN_V(koff[jj]); kc = l.kctx(kb + koff[jj], kl); }
+			off[L::VECTOR ? jj : 0] = l.offset(ctx[0], kc);
+		}
 	}
+	template <bool FIRST>
 	__device__ __forceinline__ void prep(const L& l, int kbase, int klimit)
 	{
-		prep_k(l, kbase, klimit);
+		prep_k<FIRST>(l, kbase, klimit);
 #pragma unroll
-		for (int jj = 0; jj < NCH; jj++) prep_chunk(l, jj);
+		for (int jj = 0; jj < NCH; jj++) prep_chunk<FIRST>(l, jj);
 	}
 	// Load phase of chunk jj of the tile at K offset kbase: VECTOR = ONE 16-byte global load off the offset prep_chunk(jj)
 	// resolved for that tile (kbase is not looked at); !VECTOR = address arithmetic + four scalar loads on the spot.
@@ -541,18 +633,18 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	constexpr int NA = WM * 2, NB = WN * 2;
 	float4 ra[2][NA], rb[2][NB];
 	if (nk > 0) {
-		fa.prep(la, k_begin, k_end);
-		fb.prep(lb, k_begin, k_end);
+		fa.template prep<true>(la, k_begin, k_end);
+		fb.template prep<true>(lb, k_begin, k_end);
 		fa.issue(la, ra[0], k_begin, k_end);
 		fb.issue(lb, rb[0], k_begin, k_end);
-		fa.prep(la, k_begin + GEMM_BK, k_end);
-		fb.prep(lb, k_begin + GEMM_BK, k_end);
+		fa.template prep<false>(la, k_begin + GEMM_BK, k_end);
+		fb.template prep<false>(lb, k_begin + GEMM_BK, k_end);
 		fa.issue(la, ra[1], k_begin + GEMM_BK, k_end); // past-the-end tiles are fully masked: they load the page of zeros
 		fb.issue(lb, rb[1], k_begin + GEMM_BK, k_end);
 		fa.store(lds[0], ra[0], t);
 		fb.store(lds[0] + A_FLOATS, rb[0], t);
-		fa.prep(la, k_begin + 2 * GEMM_BK, k_end);
-		fb.prep(lb, k_begin + 2 * GEMM_BK, k_end);
+		fa.template prep<false>(la, k_begin + 2 * GEMM_BK, k_end);
+		fb.template prep<false>(lb, k_begin + 2 * GEMM_BK, k_end);
 	}
 	__syncthreads();
 	// One steady-state K-step (S = kt & 1, a compile-time constant so the register sets stay in fixed registers).
@@ -573,7 +665,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 				if (g == jj * 8 / NA && !(DBG & 1) && !(DBG & 32)) fa.issue_chunk(la, ra[S], jj, kb2, k_end);
 				if (g == jj * 8 / NA + 1) {
 					if (!(DBG & 2)) fa.store_chunk(da, ra[S ^ 1], t, jj);
-					if (!(DBG & 8)) fa.prep_chunk(la, jj);
+					if (!(DBG & 8)) fa.template prep_chunk<false>(la, jj);
 				}
 			}
 #pragma unroll
@@ -581,11 +673,11 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 				if (g == 8 + jj * 8 / NB && !(DBG & 1) && !(DBG & 64)) fb.issue_chunk(lb, rb[S], jj, kb2, k_end);
 				if (g == 8 + jj * 8 / NB + 1) {
 					if (!(DBG & 2)) fb.store_chunk(db, rb[S ^ 1], t, jj);
-					if (!(DBG & 8)) fb.prep_chunk(lb, jj);
+					if (!(DBG & 8)) fb.template prep_chunk<false>(lb, jj);
 				}
 			}
-			if (g == 0 && !(DBG & 8)) fa.prep_k(la, kb3, k_end);
-			if (g == 8 && !(DBG & 8)) fb.prep_k(lb, kb3, k_end);
+			if (g == 0 && !(DBG & 8)) fa.template prep_k<false>(la, kb3, k_end);
+			if (g == 8 && !(DBG & 8)) fb.template prep_k<false>(lb, kb3, k_end);
 		};
 		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN, (DBG & 16) != 0>(lds[S], lds[S] + A_FLOATS, row_a, col_b, lh, acc, side);
 		if (!(DBG & 4)) __syncthreads();

@@ -26,6 +26,9 @@ CONV_CASES = [
     (2, 8, 8, 8, 8, 3, 3, (1, 1), (1, 1), 2, None, True),        # groups
     (1, 11, 11, 4, 4, 3, 3, (1, 1), (2, 2), 1, (2, 2), True),    # dilation
     (3, 6, 20, 40, 130, 3, 3, (1, 1), (1, 1), 1, None, True),    # several K-steps, two N tiles, >1 M tile
+    (2, 12, 13, 32, 64, 3, 3, (2, 2), (1, 1), 1, None, True),    # stride 2 with >= 32 channels: the division-free (incremental) strided dgrad
+    (2, 9, 9, 64, 32, 3, 3, (1, 1), (2, 2), 1, (2, 2), False),   # dilation 2 on the incremental path
+    (5, 4, 3, 32, 32, 3, 3, (1, 1), (1, 1), 1, None, True),      # tiny maps: several image wraps per K-step (incremental wgrad must fall back)
 ]
 
 

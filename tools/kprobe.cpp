@@ -8,16 +8,16 @@
 using namespace nnc;
 
 template <int DBG>
-static float run(Im2colKC<true, false> la, MatLoader<true, true> lb, EpiStore epi, int M, int N, int K, int reps)
+static float run(Im2colKC<true, false, true> la, MatLoader<true, true> lb, EpiStore epi, int M, int N, int K, int reps)
 {
 	const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
 	for (int i = 0; i < 2; i++)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false, true>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false, true>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0;
@@ -41,7 +41,7 @@ int main(int argc, char** argv)
 	for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
 	CHECK(hipMemcpy(a, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
 	CHECK(hipMemcpy(w, h.data(), sizeof(float) * (size_t)KO * K, hipMemcpyHostToDevice));
-	Im2colKC<true, false> la;
+	Im2colKC<true, false, true> la;
 	la.p = a; la.zoff = zp - a; la.s_n = (long)H * W * C; la.s_h = W * C; la.s_w = C; la.H = H; la.W = W; la.OW = W; la.OHW = H * W; la.M = M; la.C = C; la.KWC = 3 * C; la.K = K;
 	la.my = 1; la.mx = 1; la.oy_off = -1; la.ox_off = -1; la.ty = 1; la.tx = 1; la.dv_y = 1; la.dv_x = 1;
 	la.finish();
