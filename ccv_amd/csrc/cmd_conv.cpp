@@ -63,8 +63,10 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 		lb.p = w; lb.ldr = Kred; lb.ldk = 1; lb.R = g.Kg; lb.K = Kred; \
 		return gemm_run("conv_fwd", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, 1, flags, ctx); \
 	} while (0)
-	if (vec && Im2colKC<true, false, true>::incr_ok(g.Cg)) CONV_FWD(true, true);
-	else if (vec) CONV_FWD(true, false);
+	// (INC = the division-free incremental k state of mfma_gemm.h: measured SLOWER on MI355X -- it trades ~56 quarter-rate
+	// multiplies per K-step for ~80 more selects / 64-bit adds, and what the K-loop pays for is instruction COUNT.  Kept as
+	// a template switch, not instantiated.)
+	if (vec) CONV_FWD(true, false);
 	else CONV_FWD(false, false);
 #undef CONV_FWD
 }
@@ -87,9 +89,8 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 		lb.p = w; lb.ko_stride = (long)g.kh * g.kw * g.Cg; lb.C = g.Cg; lb.Ko = g.Kg; lb.K = Kred; \
 		return gemm_run("conv_dgrad", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, 1, flags, ctx); \
 	} while (0)
-	const bool inc = vec && Im2colKC<true, false, true>::incr_ok(g.Kg) && WgtDgradNC<true, true>::incr_ok(g.Kg);
-	if (g.sy != 1 || g.sx != 1) { if (inc) CONV_DGRAD(true, true, true); else if (vec) CONV_DGRAD(true, true, false); else CONV_DGRAD(false, true, false); }
-	else { if (inc) CONV_DGRAD(true, false, true); else if (vec) CONV_DGRAD(true, false, false); else CONV_DGRAD(false, false, false); }
+	if (g.sy != 1 || g.sx != 1) { if (vec) CONV_DGRAD(true, true, false); else CONV_DGRAD(false, true, false); }
+	else { if (vec) CONV_DGRAD(true, false, false); else CONV_DGRAD(false, false, false); }
 #undef CONV_DGRAD
 }
 
@@ -110,8 +111,7 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 		lb.C = g.Cg; lb.KWC = g.kw * g.Cg; lb.NN = NN; lb.K = (int)P; lb.sy = g.sy; lb.sx = g.sx; lb.py = g.pby; lb.px = g.pbx; lb.dy = g.dy; lb.dx = g.dx; \
 		return gemm_run("conv_wgrad", la, lb, out, g.Kg, NN, (int)P, g.groups, (long)g.Kg, (long)g.Cg, (long)g.Kg * NN, 0L, 0, flags, ctx); \
 	} while (0)
-	if (vec && Im2colNC<true, true>::incr_ok(g.OH, g.OW)) CONV_WGRAD(true, true);
-	else if (vec) CONV_WGRAD(true, false);
+	if (vec) CONV_WGRAD(true, false);
 	else CONV_WGRAD(false, false);
 #undef CONV_WGRAD
 }

@@ -143,6 +143,9 @@ struct ProfScope {
 	~ProfScope();
 };
 
+// nnc_mi355x_debug_force_tile (device_rt.cpp): wm | wn << 8, 0 = built-in choice.
+extern int g_force_tile;
+
 // Registration table (registry.cpp).
 typedef void (*register_fn_t)(ccv_nnc_cmd_backend_registry_t* const);
 

@@ -92,6 +92,7 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 
 } // namespace
 
+namespace nnc { int g_force_tile = 0; }
 namespace nnc {
 
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
@@ -490,6 +491,11 @@ float nnc_mi355x_event_elapsed_ms(void* start, void* stop)
 }
 void nnc_mi355x_event_free(void* event) { HIP_ENFORCE(hipEventDestroy((hipEvent_t)event)); }
 const char* nnc_mi355x_last_kernel_name(void) { return tl_last_kernel; }
+void nnc_mi355x_debug_force_tile(int wm, int wn)
+{
+	const bool known = (wm == 2 && wn == 2) || (wm == 2 && wn == 1) || (wm == 1 && wn == 2) || (wm == 4 && wn == 2) || (wm == 2 && wn == 4);
+	nnc::g_force_tile = known ? (wm | wn << 8) : 0;
+}
 
 void nnc_mi355x_profile_enable(int on)
 {

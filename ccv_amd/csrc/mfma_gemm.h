@@ -76,8 +76,11 @@ struct FastDiv {
 //   static constexpr bool INCR; void advance(KCtx&, int klimit) const;   INCR: step a k state by one K-step (BK = 32) with
 //     adds, compares and selects only -- the steady state then carries NO integer multiply or division (on gfx950
 //     v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate and their issue time is NOT hidden behind a wave's own MFMAs: the
-//     division-based wgrad loop spent 56 of them per K-step).  The host picks INCR only when one step wraps each counter
+//     division-based wgrad loop spent 56 of them per K-step).  The host may pick INCR only when one step wraps each counter
 //     at most once (channels >= 32 per tap, images at least 32/OW + 1 rows, ...).
+//     MEASURED NEGATIVE (round 1): the incremental form needs more instructions (selects on 64-bit offsets) and ran
+//     98 vs 107 TFLOP/s on wgrad, 114 vs 124 on dgrad -- instruction count, not multiply latency, is what the loop pays.
+//     The launchers therefore instantiate INC = false; the code stays as the record of the experiment.
 //   float4 load(const Ctx&, const KCtx&) const;     !VEC only: the chunk gathered by four scalar loads
 //     KCONTIG:  elements (r, k..k+3)   (k multiple of 4);   !KCONTIG: elements (r..r+3, k)   (r multiple of 4)
 // Rows >= R, k >= klimit and im2col padding read as zero (from the page of zeros).  VEC = one 16-byte global load per chunk
@@ -86,7 +89,7 @@ struct FastDiv {
 // Plain matrix: element(r, k) = p[r * ldr + k * ldk].  KC => ldk == 1, otherwise ldr == 1.
 template <bool KC, bool VEC>
 struct MatLoader {
-	static constexpr bool KCONTIG = KC, VECTOR = VEC, INCR = true;
+	static constexpr bool KCONTIG = KC, VECTOR = VEC, INCR = false;
 	const float* p;
 	long zoff;
 	long ldr, ldk;
@@ -648,7 +651,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	}
 	__syncthreads();
 	// One steady-state K-step (S = kt & 1, a compile-time constant so the register sets stay in fixed registers).
-	// Side work of MFMA group g (operand A in groups 0-7, operand B in groups 8-15; chunk jj of an operand with NCH chunks
+	// Side work of MFMA group g (operand A in groups 0-7(8), operand B in groups 8(7)-15; chunk jj of an operand with NCH chunks
 	// owns the group pair 2 * jj * 4 / NCH):
 	//   even group of the pair:  load chunk jj of tile kt+2 into set S          (uses the offset resolved one K-step ago)
 	//   odd group of the pair:   LDS-write chunk jj of tile kt+1 from set S^1, then resolve chunk jj's offset of tile kt+3
@@ -660,6 +663,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 		const int kb2 = k_begin + (kt + 2) * GEMM_BK, kb3 = kb2 + GEMM_BK;
 		auto side = [&](auto gid) {
 			constexpr int g = decltype(gid)::value;
+			constexpr int GB = NB == 8 ? 7 : 8; // eight B chunks: loads in groups 7-14, LDS writes in 8-15
 #pragma unroll
 			for (int jj = 0; jj < NA; jj++) {
 				if (g == jj * 8 / NA && !(DBG & 1) && !(DBG & 32)) fa.issue_chunk(la, ra[S], jj, kb2, k_end);
@@ -670,14 +674,14 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 			}
 #pragma unroll
 			for (int jj = 0; jj < NB; jj++) {
-				if (g == 8 + jj * 8 / NB && !(DBG & 1) && !(DBG & 64)) fb.issue_chunk(lb, rb[S], jj, kb2, k_end);
-				if (g == 8 + jj * 8 / NB + 1) {
+				if (g == GB + jj * 8 / NB && !(DBG & 1) && !(DBG & 64)) fb.issue_chunk(lb, rb[S], jj, kb2, k_end);
+				if (g == GB + jj * 8 / NB + 1) {
 					if (!(DBG & 2)) fb.store_chunk(db, rb[S ^ 1], t, jj);
 					if (!(DBG & 8)) fb.template prep_chunk<false>(lb, jj);
 				}
 			}
 			if (g == 0 && !(DBG & 8)) fa.template prep_k<false>(la, kb3, k_end);
-			if (g == 8 && !(DBG & 8)) fb.template prep_k<false>(lb, kb3, k_end);
+			if (g == GB && !(DBG & 8)) fb.template prep_k<false>(lb, kb3, k_end);
 		};
 		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN, (DBG & 16) != 0>(lds[S], lds[S] + A_FLOATS, row_a, col_b, lh, acc, side);
 		if (!(DBG & 4)) __syncthreads();

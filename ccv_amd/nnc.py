@@ -473,6 +473,7 @@ class Lib:
     def cmd_ok(self, cmd, backend): return bool(self.dll.nnc_mi355x_cmd_ok(cmd, backend))
 
     def profile_enable(self, on): self.dll.nnc_mi355x_profile_enable(int(on))
+    def force_tile(self, wm, wn): self.dll.nnc_mi355x_debug_force_tile(int(wm), int(wn))
 
     def profile_records(self):
         """[(name, flops, bytes, ms, (M, N, K, Z, splits))] for every contraction launch since profile_enable(1)."""

@@ -77,6 +77,28 @@ def test_conv_backward(backend, ref_lib, case, flags):
         np.testing.assert_allclose(got[2], want[2], rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("tile", [(2, 1), (1, 2), (4, 2), (2, 4)])
+@pytest.mark.parametrize("idx", [1, 6, 7])
+def test_conv_every_block_tile(backend, ref_lib, tile, idx):
+    """The launcher picks the block tile from the problem size; the 256x128 / 128x256 shapes only trigger on grids far
+    beyond what the oracle finishes, so force each shape over forward, dgrad and wgrad (incl. split-K) at small sizes."""
+    case = CONV_CASES[idx]
+    n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case
+    a, wt, b, hint, oh, ow = _conv_inputs(case)
+    g = srnd(np.random.default_rng(11), n, oh, ow, k)
+    backend.force_tile(*tile)
+    try:
+        fwd = nnc.CMD_CONVOLUTION_FORWARD(groups, k, kh, kw, c // groups, dilation=dil)
+        got, want = exec_pair(backend, ref_lib, fwd, hint, 0, [a, wt, b], [np.zeros((n, oh, ow, k), F)])
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-5)
+        bwd = nnc.CMD_CONVOLUTION_BACKWARD(groups, k, kh, kw, c // groups, dilation=dil)
+        got, want = exec_pair(backend, ref_lib, bwd, hint, 0, [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, F)])
+        for i in range(3):
+            np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=2e-5)
+    finally:
+        backend.force_tile(0, 0)
+
+
 def test_conv_backward_partial_outputs(backend, ref_lib):
     case = CONV_CASES[0]
     n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case

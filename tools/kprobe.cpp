@@ -7,23 +7,23 @@
 #define CHECK(e) do { hipError_t s_ = (e); if (s_ != hipSuccess) { printf("HIP error %d at %d\n", (int)s_, __LINE__); return 1; } } while (0)
 using namespace nnc;
 
-template <int DBG>
-static float run(Im2colKC<true, false, true> la, MatLoader<true, true> lb, EpiStore epi, int M, int N, int K, int reps)
+template <int DBG, int WM = 2, int WN = 2>
+static float run(Im2colKC<true, false> la, MatLoader<true, true> lb, EpiStore epi, int M, int N, int K, int reps)
 {
-	const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+	const int tiles_m = (M + 64 * WM - 1) / (64 * WM), tiles_n = (N + 64 * WN - 1) / (64 * WN);
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
 	for (int i = 0; i < 2; i++)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false, true>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, WM, WN, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false, true>, MatLoader<true, true>, EpiStore, 2, 2, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, WM, WN, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0;
 	hipEventElapsedTime(&ms, e0, e1);
 	const double tf = 2.0 * M * N * (double)K * reps / (ms * 1e-3) / 1e12;
-	printf("DBG=%2d  %8.3f ms/launch  %7.1f TFLOP/s-equivalent%s\n", DBG, ms / reps, tf, hipGetLastError() == hipSuccess ? "" : "  (launch error)");
+	printf("tile %dx%d DBG=%2d  %8.3f ms/launch  %7.1f TFLOP/s-equivalent%s\n", 64 * WM, 64 * WN, DBG, ms / reps, tf, hipGetLastError() == hipSuccess ? "" : "  (launch error)");
 	return ms;
 }
 
@@ -41,7 +41,7 @@ int main(int argc, char** argv)
 	for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
 	CHECK(hipMemcpy(a, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
 	CHECK(hipMemcpy(w, h.data(), sizeof(float) * (size_t)KO * K, hipMemcpyHostToDevice));
-	Im2colKC<true, false, true> la;
+	Im2colKC<true, false> la;
 	la.p = a; la.zoff = zp - a; la.s_n = (long)H * W * C; la.s_h = W * C; la.s_w = C; la.H = H; la.W = W; la.OW = W; la.OHW = H * W; la.M = M; la.C = C; la.KWC = 3 * C; la.K = K;
 	la.my = 1; la.mx = 1; la.oy_off = -1; la.ox_off = -1; la.ty = 1; la.tx = 1; la.dv_y = 1; la.dv_x = 1;
 	la.finish();
@@ -62,6 +62,10 @@ int main(int argc, char** argv)
 	run<16>(la, lb, epi, M, KO, K, reps);  // no MFMAs: the memory/LDS/VALU side alone
 	run<32>(la, lb, epi, M, KO, K, reps);  // no A (activation gather) loads
 	run<64>(la, lb, epi, M, KO, K, reps);  // no B (weight) loads
+	run<0, 4, 2>(la, lb, epi, M, KO, K, reps); // 256 x 128 block tile: 4 waves of 128 x 64, one workgroup per CU
+	run<1, 4, 2>(la, lb, epi, M, KO, K, reps);
+	run<15, 4, 2>(la, lb, epi, M, KO, K, reps);
+	run<0, 2, 4>(la, lb, epi, M, KO, K, reps); // 128 x 256
 	la.s_n = 0;                            // every image aliases image 0: the activation gather becomes L2-resident
 	printf("aliased images (A operand L2-resident):\n");
 	run<0>(la, lb, epi, M, KO, K, reps);
