@@ -43,6 +43,26 @@ def cpu_baseline():
             "sample": "1 image, full VGG-D fwd+bwd+SGD through lib/nnc CPU_REF (oracle/_ref, clang -O3 -fopenmp, no BLAS); %.2f s" % dt}
 
 
+def pmc_traffic(record_name, batch):
+    """HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/pmc_traffic_bs<batch>.json, written
+    by tools/pmc_pass.sh + tools/pmc_traffic.py from `rocprofv3 --pmc` runs of this same command: counters cannot be
+    collected inside the timed run).  None when no pass exists for this batch size."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_bs%d.json" % batch)
+    if not os.path.exists(path):
+        return None
+    m = re.search(r"LA = (nnc::\w+<[^>]*>), LB = nnc::(\w+)<.*WM = (\d), WN = (\d)", record_name)
+    if not m:
+        return None
+    la, lb, wm, wn = m.groups()
+    tot, n = 0.0, 0
+    for k, v in json.load(open(path))["kernels"].items():
+        if k.startswith("nnc::mfma_gemm_f32_kernel<" + la.replace(">", "")) and ("nnc::" + lb + "<") in k and k.endswith("%s, %s, 0>" % (wm, wn)):
+            tot += (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+            n += v["launches"]
+    return tot / n if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,9 +163,10 @@ def main():
         }
         if dom:
             name, (fl, ms, cnt) = dom
+            traffic = pmc_traffic(name, args.batch)
             ach = fl / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                               "traffic": None, "kernel": name, "launches": cnt, "avg_ms": ms / cnt,
+                               "traffic": traffic, "kernel": name, "launches": cnt, "avg_ms": ms / cnt,
                                "all_contractions": {"achieved": total_fl / (total_ms * 1e-3) / 1e12, "ms": total_ms,
                                                     "by_kernel": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
         if not args.no_cpu_baseline:

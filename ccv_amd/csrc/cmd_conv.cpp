@@ -54,6 +54,8 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const bool vec = (g.Cg % 4 == 0) && aligned16(a.p) && aligned16(w) && a.sw % 4 == 0 && a.sh % 4 == 0 && (a.n == 1 || a.sn % 4 == 0);
 	GemmOut out = { b.p, b.sw, 1, bias, 1.f, 0 };
+	KOrder ko; // taps of one 32-channel chunk in consecutive K-steps (L2 reuse of the re-read pixels), see mfma_gemm.h
+	if (g.kh * g.kw > 1 && g.Cg % GEMM_BK == 0) ko.init(g.kh * g.kw, g.Cg);
 #define CONV_FWD(VEC, INC) do { \
 		Im2colKC<VEC, false, INC> la; \
 		la.p = a.p; la.s_n = a.sn; la.s_h = (int)a.sh; la.s_w = (int)a.sw; la.H = g.H; la.W = g.W; \
@@ -61,7 +63,7 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 		la.my = g.sy; la.mx = g.sx; la.oy_off = -g.pby; la.ox_off = -g.pbx; la.ty = g.dy; la.tx = g.dx; la.dv_y = 1; la.dv_x = 1; \
 		MatLoader<true, VEC> lb; \
 		lb.p = w; lb.ldr = Kred; lb.ldk = 1; lb.R = g.Kg; lb.K = Kred; \
-		return gemm_run("conv_fwd", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, 1, flags, ctx); \
+		return gemm_run("conv_fwd", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, 1, flags, ctx, ko); \
 	} while (0)
 	// (INC = the division-free incremental k state of mfma_gemm.h: measured SLOWER on MI355X -- it trades ~56 quarter-rate
 	// multiplies per K-step for ~80 more selects / 64-bit adds, and what the K-loop pays for is instruction COUNT.  Kept as
@@ -80,6 +82,8 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const bool vec = (g.Kg % 4 == 0) && (g.Cg % 4 == 0) && aligned16(gr.p) && aligned16(w) && gr.sw % 4 == 0 && gr.sh % 4 == 0 && (gr.n == 1 || gr.sn % 4 == 0);
 	GemmOut out = { h.p, h.sw, 1, 0, 1.f, 0 };
+	KOrder ko;
+	if (g.kh * g.kw > 1 && g.Kg % GEMM_BK == 0) ko.init(g.kh * g.kw, g.Kg);
 #define CONV_DGRAD(VEC, STRIDED, INC) do { \
 		Im2colKC<VEC, STRIDED, INC> la; \
 		la.p = gr.p; la.s_n = gr.sn; la.s_h = (int)gr.sh; la.s_w = (int)gr.sw; la.H = g.OH; la.W = g.OW; \
@@ -87,7 +91,7 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 		la.my = 1; la.mx = 1; la.oy_off = g.pby; la.ox_off = g.pbx; la.ty = -g.dy; la.tx = -g.dx; la.dv_y = g.sy; la.dv_x = g.sx; \
 		WgtDgradNC<VEC, INC> lb; \
 		lb.p = w; lb.ko_stride = (long)g.kh * g.kw * g.Cg; lb.C = g.Cg; lb.Ko = g.Kg; lb.K = Kred; \
-		return gemm_run("conv_dgrad", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, 1, flags, ctx); \
+		return gemm_run("conv_dgrad", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, 1, flags, ctx, ko); \
 	} while (0)
 	if (g.sy != 1 || g.sx != 1) { if (vec) CONV_DGRAD(true, true, false); else CONV_DGRAD(false, true, false); }
 	else { if (vec) CONV_DGRAD(true, false, false); else CONV_DGRAD(false, false, false); }

@@ -31,8 +31,8 @@ static inline int gemm_auto_splits(long tiles, int K)
 inline size_t gemm_workspace_bound(long M, long N, long K)
 {
 	size_t worst = 0;
-	static const int shapes[5][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 }, { 4, 2 }, { 2, 4 } };
-	for (int i = 0; i < 5; i++) {
+	static const int shapes[3][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 } };
+	for (int i = 0; i < 3; i++) {
 		const long tiles = ((M + 64 * shapes[i][0] - 1) / (64 * shapes[i][0])) * ((N + 64 * shapes[i][1] - 1) / (64 * shapes[i][1]));
 		int s = gemm_auto_splits(tiles, (int)(K > 0x7fffffffL ? 0x7fffffffL : K));
 		if (s > 1) s = ((s < 8 ? 8 : s) + 7) & ~7;
@@ -49,12 +49,9 @@ static inline void gemm_pick_tile(const int M, const int N, int* wm, int* wn)
 	static const int shapes[3][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 } };
 	static const double eff[3] = { 1.0, 0.93, 0.93 };
 	if (g_force_tile) { *wm = g_force_tile & 0xff; *wn = g_force_tile >> 8; return; }
-	// 256 x 128 / 128 x 256 (four waves of 128 x 64, ONE workgroup per CU): 25 % fewer loaded bytes and LDS writes per MFMA,
-	// measured +4..5 % on the large layers (tools/kprobe.cpp); only when the grid still has >= 6 full rounds of 256 tiles,
-	// because halving the tile count doubles the tail.
-	if ((long)(M / 256) * (N / 128) >= 6 * 256 && M % 256 == 0 && N % 128 == 0 && N % 256 != 0) { *wm = 4; *wn = 2; return; }
-	if ((long)(M / 128) * (N / 256) >= 6 * 256 && N % 256 == 0) { *wm = 2; *wn = 4; return; }
-	if ((long)(M / 256) * (N / 128) >= 6 * 256 && N % 128 == 0) { *wm = 4; *wn = 2; return; }
+	// 256 x 128 / 128 x 256 tiles (WM, WN = 4, 2 / 2, 4: one workgroup per CU) were measured on the whole VGG-D step: 4x2
+	// 108 vs 127 TFLOP/s and 2x4 121 vs 127 for the 128 x 128 tile on the same layers (profiles/r01_v6_bigtile_bench.json),
+	// although an isolated probe of one layer had them 4 % ahead; the kernel template still supports them (tools/kprobe.cpp).
 	double best = -1;
 	for (int i = 0; i < 3; i++) {
 		const long bm = 64 * shapes[i][0], bn = 64 * shapes[i][1];
@@ -66,7 +63,7 @@ static inline void gemm_pick_tile(const int M, const int N, int* wm, int* wn)
 
 // zcount > 1 (batched GEMM / grouped conv): every z applies the given element offsets to A, B, C and bias.
 template <class LA, class LB, int WM, int WN>
-static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko)
 {
 	constexpr int BM = 64 * WM, BN = 64 * WN;
 	hipStream_t stream = stream_of(ctx);
@@ -93,7 +90,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 		EpiStore epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm;
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -104,7 +101,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)(tiles * splits), 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)(tiles * splits), 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, 0L, 0L, 0L, 0L, ko);
 	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256)), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N);
@@ -113,7 +110,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 }
 
 template <class LA, class LB>
-static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko = KOrder())
 {
 	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
 	la.finish();
@@ -124,11 +121,9 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	lb.zoff = zp - lb.p;
 	int wm = 2, wn = 2;
 	gemm_pick_tile(M, N, &wm, &wn);
-	if (wm == 4) return gemm_run_tile<LA, LB, 4, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
-	if (wn == 4) return gemm_run_tile<LA, LB, 2, 4>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
-	if (wm == 2 && wn == 2) return gemm_run_tile<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
-	if (wm == 2) return gemm_run_tile<LA, LB, 2, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
-	return gemm_run_tile<LA, LB, 1, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+	if (wm == 2 && wn == 2) return gemm_run_tile<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+	if (wm == 2) return gemm_run_tile<LA, LB, 2, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+	return gemm_run_tile<LA, LB, 1, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 }
 
 } // namespace nnc

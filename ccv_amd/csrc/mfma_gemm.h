@@ -67,6 +67,19 @@ struct FastDiv {
 	__host__ __device__ __forceinline__ int div(int n) const { return (int)(((unsigned long long)(unsigned)n * m) >> sh); }
 };
 
+// Order in which a conv contraction walks its reduction index k = (tap, channel), in K-steps of GEMM_BK channels.
+//   natural (taps == 0): tap-major -- a workgroup streams ALL channels of tap 0, then of tap 1, ...; the nine taps re-read
+//     the same pixels, but a tap apart lie channels/32 K-steps of the XCD's 64 resident workgroups, i.e. > 4 MB of other
+//     lines: every tap misses the XCD's L2 (PMC FETCH_SIZE: 3-4x the algorithmic bytes for forward / dgrad)
+//   chunk-major (taps = kh * kw, channels % 32 == 0): k' = (channel chunk, tap, channel in chunk): the taps of one
+//     32-channel chunk are consecutive K-steps, so the re-reads come out of L2.  Pure re-association of the sum; both
+//     operands' loaders are handed the mapped K offset, nothing in them changes.
+struct KOrder {
+	int taps = 0, C = 0, K = 0;
+	FastDiv d;
+	void init(int taps_, int C_) { taps = taps_; C = C_; K = taps_ * C_; d.init(taps_); }
+};
+
 // ---------------------------------------------------------------------------------------------- loaders
 // Concept:
 //   static constexpr bool KCONTIG;  const float* p;
@@ -507,18 +520,34 @@ struct TileFetch {
 	}
 };
 
-// Fragment reads of quarter q (k = 8q .. 8q+7) of a K-step for W tiles of 32 rows starting at `row`.
+// Fragment reads of quarter q (k = 8q .. 8q+7) of a K-step for the W 32-row MFMA tiles of a wave whose rows start at `base`.
+// Which row of the wave's span an MFMA tile's lane stands for is free as long as the epilogue agrees (frag_row below):
+//   KC  ([row][k] image): tile ti, lane li = row 32 * ti + li; its four k values are ONE ds_read_b128
+//   !KC ([k][row] image): tile ti, lane li = row W * li + ti, so that the W tiles' values of one k are adjacent in LDS and
+//        come in ONE ds_read_b32 * W (b64 for the 2-tile wave) instead of W scalar reads -- the fragment reads of a
+//        row-contiguous operand are 4 * W per quarter otherwise, and every non-MFMA instruction costs issue cycles.
+template <bool KC, int W>
+__device__ __forceinline__ int frag_row(const int ti, const int li) { return KC ? 32 * ti + li : W * li + ti; }
 template <bool KC, int W, int ROWS>
-__device__ __forceinline__ void read_frags(const float* s, const int row, const int q, const int lh, float (&f)[W][4])
+__device__ __forceinline__ void read_frags(const float* s, const int base, const int li, const int q, const int lh, float (&f)[W][4])
 {
+	if (KC) {
 #pragma unroll
-	for (int ti = 0; ti < W; ti++) {
-		if (KC) {
-			const float4 v = *(const float4*)(s + (row + ti * 32) * GEMM_LDK + 8 * q + 4 * lh);
+		for (int ti = 0; ti < W; ti++) {
+			const float4 v = *(const float4*)(s + (base + ti * 32 + li) * GEMM_LDK + 8 * q + 4 * lh);
 			f[ti][0] = v.x; f[ti][1] = v.y; f[ti][2] = v.z; f[ti][3] = v.w;
-		} else {
+		}
+	} else {
+		typedef float vecw __attribute__((ext_vector_type(W)));
 #pragma unroll
-			for (int e = 0; e < 4; e++) f[ti][e] = s[(8 * q + 4 * lh + e) * ROWS + row + ti * 32];
+		for (int e = 0; e < 4; e++) {
+			const float* const a = s + (8 * q + 4 * lh + e) * ROWS + base + W * li;
+			if (W == 1) f[0][e] = *a;
+			else {
+				const vecw v = *(const vecw*)a;
+#pragma unroll
+				for (int ti = 0; ti < W; ti++) f[ti][e] = v[ti];
+			}
 		}
 	}
 }
@@ -534,17 +563,17 @@ struct NoSideWork { template <class G> __device__ __forceinline__ void operator(
 //   * side(GroupId<g>) carries the caller's other work for group g = 0..15 (address VALU of tile kt+2, LDS writes of
 //     tile kt+1): what remains outside the MFMA stream of a K-step is the barrier and the first fragment read.
 template <bool AKC, bool BKC, int WM, int WN, bool NO_MFMA, class SIDE>
-__device__ __forceinline__ void mfma_kstep(const float* sa, const float* sb, const int row_a, const int col_b, const int lh, floatx16 (&acc)[WM][WN], const SIDE& side)
+__device__ __forceinline__ void mfma_kstep(const float* sa, const float* sb, const int row_a, const int col_b, const int li, const int lh, floatx16 (&acc)[WM][WN], const SIDE& side)
 {
 	constexpr int BM = 64 * WM, BN = 64 * WN;
 	float fa_[2][WM][4], fb_[2][WN][4];
-	read_frags<AKC, WM, BM>(sa, row_a, 0, lh, fa_[0]);
-	read_frags<BKC, WN, BN>(sb, col_b, 0, lh, fb_[0]);
+	read_frags<AKC, WM, BM>(sa, row_a, li, 0, lh, fa_[0]);
+	read_frags<BKC, WN, BN>(sb, col_b, li, 0, lh, fb_[0]);
 #pragma unroll
 	for (int q = 0; q < 4; q++) {
 		if (q < 3) {
-			read_frags<AKC, WM, BM>(sa, row_a, q + 1, lh, fa_[(q + 1) & 1]);
-			read_frags<BKC, WN, BN>(sb, col_b, q + 1, lh, fb_[(q + 1) & 1]);
+			read_frags<AKC, WM, BM>(sa, row_a, li, q + 1, lh, fa_[(q + 1) & 1]);
+			read_frags<BKC, WN, BN>(sb, col_b, li, q + 1, lh, fb_[(q + 1) & 1]);
 		}
 #pragma unroll
 		for (int e = 0; e < 4; e++) {
@@ -570,7 +599,7 @@ __device__ __forceinline__ long M_N_slab(const EpiPartial& e) { return e.slab; }
 // DBG (tools/kprobe.cpp only; the library always instantiates DBG = 0): knock out parts of the steady state to attribute time.
 //   1 no global loads, 2 no LDS writes, 4 no barrier, 8 no address prep, 16 no MFMAs, 32 no A loads, 64 no B loads
 template <class LA, class LB, class EPI, int WM, int WN, int DBG = 0>
-__global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff)
+__global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff, const KOrder ko)
 {
 	constexpr int BM = 64 * WM, BN = 64 * WN;
 	constexpr int A_FLOATS = LA::KCONTIG ? BM * GEMM_LDK : GEMM_BK * BM;
@@ -611,6 +640,15 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
 	const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
 
+	// K offset (wave-uniform, a multiple of GEMM_BK) of the loop's position kb -> the operands' k (see KOrder)
+	auto kmap = [&](const int kb) -> int {
+		if (!ko.taps) return kb;
+		if (kb >= k_end) return ko.K; // past-the-end prefetch: fully masked
+		const int s = kb / GEMM_BK;
+		const int cc = ko.d.div(s);
+		return (s - cc * ko.taps) * ko.C + cc * GEMM_BK;
+	};
+	const int klim = ko.taps ? ko.K : k_end;
 	TileFetch<LA, WM * 2> fa;
 	TileFetch<LB, WN * 2> fb;
 	fa.init(la, m0, t);
@@ -623,7 +661,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-	const int row_a = wm * (32 * WM) + li, col_b = wn * (32 * WN) + li;
+	const int row_a = wm * (32 * WM), col_b = wn * (32 * WN); // first row / column of the wave's span inside the block tile
 	// Software pipeline, prefetch distance TWO tiles: while tile kt is multiplied out of LDS buffer kt & 1, the chunks of
 	// tile kt+1 (register set (kt+1) & 1, loaded during the previous K-step) are written to the other LDS buffer, the
 	// chunks of tile kt+2 are loaded into register set kt & 1, and the addresses of tile kt+3 are computed -- every one
@@ -636,18 +674,19 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	constexpr int NA = WM * 2, NB = WN * 2;
 	float4 ra[2][NA], rb[2][NB];
 	if (nk > 0) {
-		fa.template prep<true>(la, k_begin, k_end);
-		fb.template prep<true>(lb, k_begin, k_end);
-		fa.issue(la, ra[0], k_begin, k_end);
-		fb.issue(lb, rb[0], k_begin, k_end);
-		fa.template prep<false>(la, k_begin + GEMM_BK, k_end);
-		fb.template prep<false>(lb, k_begin + GEMM_BK, k_end);
-		fa.issue(la, ra[1], k_begin + GEMM_BK, k_end); // past-the-end tiles are fully masked: they load the page of zeros
-		fb.issue(lb, rb[1], k_begin + GEMM_BK, k_end);
+		const int k0 = kmap(k_begin), k1 = kmap(k_begin + GEMM_BK), k2 = kmap(k_begin + 2 * GEMM_BK);
+		fa.template prep<true>(la, k0, klim);
+		fb.template prep<true>(lb, k0, klim);
+		fa.issue(la, ra[0], k0, klim);
+		fb.issue(lb, rb[0], k0, klim);
+		fa.template prep<false>(la, k1, klim);
+		fb.template prep<false>(lb, k1, klim);
+		fa.issue(la, ra[1], k1, klim); // past-the-end tiles are fully masked: they load the page of zeros
+		fb.issue(lb, rb[1], k1, klim);
 		fa.store(lds[0], ra[0], t);
 		fb.store(lds[0] + A_FLOATS, rb[0], t);
-		fa.template prep<false>(la, k_begin + 2 * GEMM_BK, k_end);
-		fb.template prep<false>(lb, k_begin + 2 * GEMM_BK, k_end);
+		fa.template prep<false>(la, k2, klim);
+		fb.template prep<false>(lb, k2, klim);
 	}
 	__syncthreads();
 	// One steady-state K-step (S = kt & 1, a compile-time constant so the register sets stay in fixed registers).
@@ -660,13 +699,13 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 		constexpr int S = decltype(sid)::value;
 		float* const da = lds[S ^ 1];
 		float* const db = da + A_FLOATS;
-		const int kb2 = k_begin + (kt + 2) * GEMM_BK, kb3 = kb2 + GEMM_BK;
+		const int kb2 = kmap(k_begin + (kt + 2) * GEMM_BK), kb3 = kmap(k_begin + (kt + 3) * GEMM_BK);
 		auto side = [&](auto gid) {
 			constexpr int g = decltype(gid)::value;
 			constexpr int GB = NB == 8 ? 7 : 8; // eight B chunks: loads in groups 7-14, LDS writes in 8-15
 #pragma unroll
 			for (int jj = 0; jj < NA; jj++) {
-				if (g == jj * 8 / NA && !(DBG & 1) && !(DBG & 32)) fa.issue_chunk(la, ra[S], jj, kb2, k_end);
+				if (g == jj * 8 / NA && !(DBG & 1) && !(DBG & 32)) fa.issue_chunk(la, ra[S], jj, kb2, klim);
 				if (g == jj * 8 / NA + 1) {
 					if (!(DBG & 2)) fa.store_chunk(da, ra[S ^ 1], t, jj);
 					if (!(DBG & 8)) fa.template prep_chunk<false>(la, jj);
@@ -674,16 +713,16 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 			}
 #pragma unroll
 			for (int jj = 0; jj < NB; jj++) {
-				if (g == GB + jj * 8 / NB && !(DBG & 1) && !(DBG & 64)) fb.issue_chunk(lb, rb[S], jj, kb2, k_end);
+				if (g == GB + jj * 8 / NB && !(DBG & 1) && !(DBG & 64)) fb.issue_chunk(lb, rb[S], jj, kb2, klim);
 				if (g == GB + jj * 8 / NB + 1) {
 					if (!(DBG & 2)) fb.store_chunk(db, rb[S ^ 1], t, jj);
 					if (!(DBG & 8)) fb.template prep_chunk<false>(lb, jj);
 				}
 			}
-			if (g == 0 && !(DBG & 8)) fa.template prep_k<false>(la, kb3, k_end);
-			if (g == GB && !(DBG & 8)) fb.template prep_k<false>(lb, kb3, k_end);
+			if (g == 0 && !(DBG & 8)) fa.template prep_k<false>(la, kb3, klim);
+			if (g == GB && !(DBG & 8)) fb.template prep_k<false>(lb, kb3, klim);
 		};
-		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN, (DBG & 16) != 0>(lds[S], lds[S] + A_FLOATS, row_a, col_b, lh, acc, side);
+		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN, (DBG & 16) != 0>(lds[S], lds[S] + A_FLOATS, row_a, col_b, li, lh, acc, side);
 		if (!(DBG & 4)) __syncthreads();
 	};
 	{ // pairs of K-steps with no control flow between them (a branch in the middle makes hipcc copy the in-flight register
@@ -697,18 +736,19 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	}
 	if (nk > 0) {
 		const int cur = (nk - 1) & 1;
-		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN, false>(lds[cur], lds[cur] + A_FLOATS, row_a, col_b, lh, acc, NoSideWork());
+		mfma_kstep<LA::KCONTIG, LB::KCONTIG, WM, WN, false>(lds[cur], lds[cur] + A_FLOATS, row_a, col_b, li, lh, acc, NoSideWork());
 	}
-	// D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+	// D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), both in fragment-lane terms
+	// (frag_row maps a tile's lane to the row / column of the wave's span it stands for).
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
 #pragma unroll
 	for (int ti = 0; ti < WM; ti++)
 #pragma unroll
 		for (int tj = 0; tj < WN; tj++) {
-			const int n = n0 + wn * (32 * WN) + tj * 32 + li;
+			const int n = n0 + col_b + frag_row<LB::KCONTIG, WN>(tj, li);
 #pragma unroll
 			for (int r = 0; r < 16; r++) {
-				const int m = m0 + wm * (32 * WM) + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+				const int m = m0 + row_a + frag_row<LA::KCONTIG, WM>(ti, (r & 3) + 8 * (r >> 2) + 4 * lh);
 				epi(m, n, acc[ti][tj][r]);
 			}
 		}

@@ -77,11 +77,11 @@ def test_conv_backward(backend, ref_lib, case, flags):
         np.testing.assert_allclose(got[2], want[2], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("tile", [(2, 1), (1, 2), (4, 2), (2, 4)])
+@pytest.mark.parametrize("tile", [(2, 2), (2, 1), (1, 2)])
 @pytest.mark.parametrize("idx", [1, 6, 7])
 def test_conv_every_block_tile(backend, ref_lib, tile, idx):
-    """The launcher picks the block tile from the problem size; the 256x128 / 128x256 shapes only trigger on grids far
-    beyond what the oracle finishes, so force each shape over forward, dgrad and wgrad (incl. split-K) at small sizes."""
+    """The launcher picks the block tile from the problem size; force each shape over forward, dgrad and wgrad (incl.
+    split-K) so every (loader, tile) instantiation is checked, not only the one the size heuristic lands on."""
     case = CONV_CASES[idx]
     n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case
     a, wt, b, hint, oh, ow = _conv_inputs(case)

@@ -8,16 +8,16 @@
 using namespace nnc;
 
 template <int DBG, int WM = 2, int WN = 2>
-static float run(Im2colKC<true, false> la, MatLoader<true, true> lb, EpiStore epi, int M, int N, int K, int reps)
+static float run(Im2colKC<true, false> la, MatLoader<true, true> lb, EpiStore epi, int M, int N, int K, int reps, KOrder ko = KOrder())
 {
 	const int tiles_m = (M + 64 * WM - 1) / (64 * WM), tiles_n = (N + 64 * WN - 1) / (64 * WN);
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
 	for (int i = 0; i < 2; i++)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, WM, WN, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, WM, WN, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L, ko);
 	hipEventRecord(e0, 0);
 	for (int i = 0; i < reps; i++)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, WM, WN, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<Im2colKC<true, false>, MatLoader<true, true>, EpiStore, WM, WN, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, la, lb, epi, tiles_m, tiles_n, K, K, 1, 0L, 0L, 0L, 0L, ko);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0;
@@ -62,10 +62,11 @@ int main(int argc, char** argv)
 	run<16>(la, lb, epi, M, KO, K, reps);  // no MFMAs: the memory/LDS/VALU side alone
 	run<32>(la, lb, epi, M, KO, K, reps);  // no A (activation gather) loads
 	run<64>(la, lb, epi, M, KO, K, reps);  // no B (weight) loads
-	run<0, 4, 2>(la, lb, epi, M, KO, K, reps); // 256 x 128 block tile: 4 waves of 128 x 64, one workgroup per CU
-	run<1, 4, 2>(la, lb, epi, M, KO, K, reps);
-	run<15, 4, 2>(la, lb, epi, M, KO, K, reps);
-	run<0, 2, 4>(la, lb, epi, M, KO, K, reps); // 128 x 256
+	{
+		KOrder ko; ko.init(9, C);
+		printf("channel-chunk-major K order:\n");
+		run<0>(la, lb, epi, M, KO, K, reps, ko);
+	}
 	la.s_n = 0;                            // every image aliases image 0: the activation gather becomes L2-resident
 	printf("aliased images (A operand L2-resident):\n");
 	run<0>(la, lb, epi, M, KO, K, reps);

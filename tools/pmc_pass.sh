@@ -7,8 +7,10 @@ OUT=$PWD/gpurun_out/pmc
 mkdir -p $OUT
 BATCH=${PMC_BATCH:-64}
 (cd /tmp && rocprofv3 -L > $OUT/counters_list.txt 2>&1; true)
+GROUPS_WANTED=${PMC_GROUPS:-mfma wait inst lds fetch write l2}
 run_pass() {
   name=$1; shift
+  case " $GROUPS_WANTED " in *" $name "*) ;; *) return;; esac
   (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $OLDPWD/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline > $OUT/$name.log 2>&1; echo "exit $?" >> $OUT/$name.log)
 }
 run_pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE
@@ -19,6 +21,7 @@ run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
 run_pass l2 TCC_HIT_sum TCC_MISS_sum
 python tools/pmc_summary.py $OUT > gpurun_out/pmc_summary.md 2>&1
+python tools/pmc_traffic.py $OUT gpurun_out/pmc_traffic_bs$BATCH.json $BATCH > gpurun_out/pmc_traffic.txt 2>&1
 find $OUT -name "*kernel_trace*" -size +8M -delete
 find $OUT -name "*counter_collection*" -size +24M -delete
-tail -40 gpurun_out/pmc_summary.md
+tail -30 gpurun_out/pmc_traffic.txt
