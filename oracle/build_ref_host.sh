@@ -40,4 +40,22 @@ for t in $TESTS; do
 done
 wait
 ls $OUT/int | tr '\n' ' '; echo
+# 4. the reference's CPU unit tests (test/unit/nnc/*.tests.c) against the SAME host + backend libraries: linking the GPU
+#    backend in must leave every CPU-tensor code path of the host (graphs, autograd, cnnp, CPU backends) as it was.
+#    They run from $OUT/unit/run/test/unit/nnc, a scratch mirror whose data/ and samples/ point back into $REF.
+mkdir -p $OUT/unit/run/test/unit/nnc/gen
+ln -sfn $REF/test/unit/nnc/data $OUT/unit/run/test/unit/nnc/data
+ln -sfn $REF/samples $OUT/unit/run/samples
+UNIT_SKIP=${UNIT_SKIP:-"cblas"}
+for src in $REF/test/unit/nnc/*.tests.c; do
+  t=$(basename $src .tests.c)
+  case " $UNIT_SKIP " in *" $t "*) continue;; esac
+  $CC $TFLAGS $src -o $OUT/unit/$t.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib 2> $OUT/unit/$t.gpu.log &
+  if [ -f $OUT/libccv_host_emu.so ]; then
+    $CC $TFLAGS $src -o $OUT/unit/$t.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib/llvm/lib 2> $OUT/unit/$t.emu.log &
+  fi
+done
+wait
+find $OUT/unit -name "*.log" -size 0 -delete
+echo "unit tests built: $(ls $OUT/unit/*.emu 2>/dev/null | wc -l) emu, $(ls $OUT/unit/*.gpu 2>/dev/null | wc -l) gpu"
 echo "built $OUT/libccv_host_gpu.so"
