@@ -7,6 +7,7 @@
 // Layout on device: NHWC activations (n, y, x, c) with c innermost, weights [K][kh][kw][Cg]; tensor views are accepted for
 // the inputs as long as the channel stride is 1.  NCHW tensors are routed through the layout kernels of cmd_util (workspace).
 #include "gemm_launch.h"
+#include "winograd.h"
 
 using namespace nnc;
 
@@ -46,9 +47,84 @@ static bool pixel_linear(const Image4& t)
 	return t.sc == 1 && t.sh == (long)t.w * t.sw && (t.n == 1 || t.sn == (long)t.h * t.sh);
 }
 
-static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, const int flags, ccv_nnc_stream_context_t* const ctx)
+// ---- Winograd F(4x4, 3x3) (winograd.h) --------------------------------------------------------------------------------
+// Algorithm numbers of the two conv rows (ccv_nnc_cmd_t.algorithm; -1 = the backend's own choice; what autotune returns).
+enum { CONV_ALGO_IMPLICIT_GEMM = 0, CONV_ALGO_WINOGRAD = 1, CONV_ALGO_COUNT = 2 };
+
+struct wino_plan_t {
+	int TH, TW, T;
+	size_t u_bytes, v_bytes, m_bytes;
+	size_t total() const { return u_bytes + v_bytes + m_bytes; }
+};
+
+// `src` = the tensor the 6x6 tiles are cut from (C_src channels), `dst` = the tensor the 4x4 tiles are written to (C_dst).
+static bool wino_plan(const conv_geom_t& g, const int dst_h, const int dst_w, const int C_src, const int C_dst, wino_plan_t* p)
+{
+	if (g.kh != 3 || g.kw != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.groups != 1) return false;
+	if (C_src % 4 || C_dst % 4 || g.pby < 0 || g.pby > 2 || g.pbx < 0 || g.pbx > 2) return false;
+	p->TH = (dst_h + 3) / 4; p->TW = (dst_w + 3) / 4;
+	const long T = (long)g.N * p->TH * p->TW;
+	if (T <= 0 || T * (C_src > C_dst ? C_src : C_dst) > 0x7fffffffL) return false;
+	p->T = (int)T;
+	p->u_bytes = (sizeof(float) * 36 * (size_t)C_src * C_dst + 255) & ~(size_t)255;
+	p->v_bytes = (sizeof(float) * 36 * (size_t)T * C_src + 255) & ~(size_t)255;
+	p->m_bytes = (sizeof(float) * 36 * (size_t)T * C_dst + 255) & ~(size_t)255;
+	return true;
+}
+
+// dst (+ bias) = conv3x3(src, w), stride 1, source padding (pad_y, pad_x);  FLIP: dgrad's mirrored / role-swapped weights.
+template <bool FLIP>
+static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan_t& p, const Image4& src, const float* w, const float* bias, const Image4& dst, const int pad_y, const int pad_x, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	const int Cs = src.c, Cd = dst.c;
+	char* ws = (char*)workspace_of(ctx, p.total());
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	float* const U = (float*)ws;
+	float* const V = (float*)(ws + p.u_bytes);
+	float* const M = (float*)(ws + p.u_bytes + p.v_bytes);
+	hipStream_t stream = stream_of(ctx);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_weight_kernel<FLIP>), dim3(grid_for((size_t)Cs * Cd, 256)), dim3(256), 0, stream, w, U, g.K, g.C);
+	HIP_ENFORCE(hipGetLastError());
+	WinoTiles ti;
+	ti.TH = p.TH; ti.TW = p.TW; ti.T = p.T;
+	ti.H = src.h; ti.W = src.w; ti.sn = src.sn; ti.sh = src.sh; ti.sw = src.sw; ti.oy = -pad_y; ti.ox = -pad_x; ti.C4 = Cs / 4;
+	ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
+	hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for((size_t)p.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)src.p, V, ti);
+	HIP_ENFORCE(hipGetLastError());
+	// 36 GEMMs M[z] (T x Cd) = V[z] (T x Cs) * U[z]^T (Cd x Cs), both operands reduction-contiguous, one launch (grid z)
+	MatLoader<true, true> la, lb;
+	la.p = V; la.ldr = Cs; la.ldk = 1; la.R = p.T; la.K = Cs;
+	lb.p = U; lb.ldr = Cs; lb.ldk = 1; lb.R = Cd; lb.K = Cs;
+	GemmOut out = { M, Cd, 1, 0, 1.f, 0 };
+	const int ret = gemm_run(name, la, lb, out, p.T, Cd, Cs, 36, (long)p.T * Cs, (long)Cd * Cs, (long)p.T * Cd, 0L, 1, flags, ctx);
+	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
+	ti.H = dst.h; ti.W = dst.w; ti.sn = dst.sn; ti.sh = dst.sh; ti.sw = dst.sw; ti.C4 = Cd / 4;
+	ti.d_c4.init(ti.C4);
+	hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for((size_t)p.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)M, bias, dst.p, ti);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static bool wino_images_ok(const Image4& src, const Image4& dst, const float* w, const float* bias)
+{
+	return src.sc == 1 && dst.sc == 1 && aligned16(src.p) && aligned16(dst.p) && aligned16(w) && (!bias || aligned16(bias)) &&
+		src.sw % 4 == 0 && src.sh % 4 == 0 && (src.n == 1 || src.sn % 4 == 0) && dst.sw % 4 == 0 && dst.sh % 4 == 0 && (dst.n == 1 || dst.sn % 4 == 0);
+}
+
+// The backend's own choice (algorithm -1).  Measured on the MI355X at batch 256 (tools/conv_algo_sweep.py): Winograd
+// is 2.1-3.2x faster than the implicit GEMM on EVERY 3x3 VGG-D layer from 64 channels up, so it is taken whenever the
+// geometry allows and there are enough channels for the 36 GEMMs to have a K-step (32) of depth and a full N tile.
+static bool wino_preferred(const wino_plan_t& p, const int C_src, const int C_dst)
+{
+	return C_src >= 32 && C_dst >= 32 && p.T >= 32;
+}
+
+static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, const int algo, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	if (a.sc != 1 || !pixel_linear(b) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
+	wino_plan_t wp;
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.OH, g.OW, g.C, g.K, &wp) && wino_images_ok(a, b, w, bias) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp, g.C, g.K)))
+		return conv_wino_run<false>("conv_fwd_wino", g, wp, a, w, bias, b, g.pby, g.pbx, flags, ctx);
 	const long M = (long)g.N * g.OH * g.OW;
 	const int Kred = g.kh * g.kw * g.Cg;
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
@@ -74,9 +150,12 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 }
 
 // h = sum_{k,i,j} g[n, (y+p-i*d)/s, (x+p-j*d)/s, k] * w[k,i,j,c]
-static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx)
+static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* w, const Image4& h, const int algo, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	if (gr.sc != 1 || !pixel_linear(h) || !image_fits_int(gr)) return CCV_NNC_EXEC_INVALID;
+	wino_plan_t wp;
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wp) && wino_images_ok(gr, h, w, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp, g.K, g.C)))
+		return conv_wino_run<true>("conv_dgrad_wino", g, wp, gr, w, 0, h, 2 - g.pby, 2 - g.pbx, flags, ctx);
 	const long M = (long)g.N * g.H * g.W;
 	const int Kred = g.kh * g.kw * g.Kg;
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
@@ -168,10 +247,13 @@ static int _conv_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	if (!conv_geometry(cmd, hint, ai, bi, 0, &g) || K != g.K || kh != g.kh || kw != g.kw || Cg != g.Cg) return CCV_NNC_EXEC_INVALID;
 	if (bias && (bias->info.dim[0] != g.K || !tensor_contiguous(bias))) return CCV_NNC_EXEC_INVALID;
 	const bool stage_io = a->info.format == CCV_TENSOR_FORMAT_NCHW, stage_w = w->info.format == CCV_TENSOR_FORMAT_NCHW;
-	if (!stage_io && !stage_w) return conv_forw_nhwc(g, ai, w->data.f32, bias ? bias->data.f32 : 0, bi, flags, stream_context);
+	if (!stage_io && !stage_w) return conv_forw_nhwc(g, ai, w->data.f32, bias ? bias->data.f32 : 0, bi, cmd.algorithm, flags, stream_context);
 	const size_t na = stage_io ? align256(sizeof(float) * tensor_count(a->info)) : 0, nb = stage_io ? align256(sizeof(float) * tensor_count(b->info)) : 0;
 	const size_t nw = stage_w ? align256(sizeof(float) * tensor_count(w->info)) : 0;
-	WorkspaceScope ws(stream_context, na + nb + nw, gemm_workspace_bound((long)g.N * g.OH * g.OW, g.Kg, (long)g.kh * g.kw * g.Cg));
+	size_t inner = gemm_workspace_bound((long)g.N * g.OH * g.OW, g.Kg, (long)g.kh * g.kw * g.Cg);
+	wino_plan_t wpl;
+	if (cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.OH, g.OW, g.C, g.K, &wpl) && wpl.total() > inner) inner = wpl.total();
+	WorkspaceScope ws(stream_context, na + nb + nw, inner);
 	char* p = (char*)ws.prefix();
 	if (!p) return CCV_NNC_EXEC_OOM;
 	int ret;
@@ -180,14 +262,14 @@ static int _conv_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 		if ((ret = weights_nchw_to_nhwc(w->data.f32, (float*)(p + na + nb), g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		wp = (const float*)(p + na + nb);
 	}
-	if (!stage_io) return conv_forw_nhwc(g, ai, wp, bias ? bias->data.f32 : 0, bi, flags, stream_context);
+	if (!stage_io) return conv_forw_nhwc(g, ai, wp, bias ? bias->data.f32 : 0, bi, cmd.algorithm, flags, stream_context);
 	ccv_nnc_tensor_t at, bt;
 	dense_nhwc_like(a, ai, (float*)p, &at);
 	dense_nhwc_like(b, bi, (float*)(p + na), &bt);
 	if ((ret = format_transform(a, &at, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	Image4 as, bs;
 	image4(&at, &as); image4(&bt, &bs);
-	if ((ret = conv_forw_nhwc(g, as, wp, bias ? bias->data.f32 : 0, bs, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	if ((ret = conv_forw_nhwc(g, as, wp, bias ? bias->data.f32 : 0, bs, cmd.algorithm, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	return format_transform(&bt, b, stream_context);
 }
 
@@ -231,6 +313,8 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	const size_t inner_d = gemm_workspace_bound((long)g.N * g.H * g.W, g.Cg, (long)g.kh * g.kw * g.Kg), inner_b = sizeof(float) * (size_t)g.K * 4096;
 	if (inner_d > inner) inner = inner_d;
 	if (inner_b > inner) inner = inner_b;
+	wino_plan_t wpl;
+	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wpl) && wpl.total() > inner) inner = wpl.total();
 	WorkspaceScope ws(stream_context, ng + na + nh + nw + ndw, inner);
 	char* p = (char*)ws.prefix();
 	if ((ng + na + nh + nw + ndw) && !p) return CCV_NNC_EXEC_OOM;
@@ -268,10 +352,43 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 			if ((ret = weights_nchw_to_nhwc(w->data.f32, (float*)(p + ng + na + nh), g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 			wp = (const float*)(p + ng + na + nh);
 		}
-		if ((ret = conv_dgrad_nhwc(g, gim, wp, him, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = conv_dgrad_nhwc(g, gim, wp, him, cmd.algorithm, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		if (stage_io && (ret = format_transform(&hs, h, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
 	return CCV_NNC_EXEC_SUCCESS;
+}
+
+// autotune (ccv_nnc.h:323; what lib/nnc/cmd/convolution/gpu/ccv_nnc_conv_gpu_cudnn.cu:116-202 does with cudnnFind*): run the
+// command under every algorithm on the caller's tensors, HIP-event timed on its stream, and return the fastest.  Outputs
+// are overwritten with the same values each time (the host autotunes before the first real execution, ccv_nnc_cmd.c:344-578).
+static int _conv_autotune(const ccv_nnc_cmd_t cmd, const size_t max_workspace_size, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	(void)max_workspace_size;
+	const bool fwd = cmd.cmd == CCV_NNC_CONVOLUTION_FORWARD;
+	hipStream_t stream = stream_of(stream_context);
+	hipEvent_t e0, e1;
+	HIP_ENFORCE(hipEventCreate(&e0));
+	HIP_ENFORCE(hipEventCreate(&e1));
+	int best = 0;
+	float best_ms = 0;
+	for (int algo = 0; algo < CONV_ALGO_COUNT; algo++) {
+		ccv_nnc_cmd_t c = cmd;
+		c.algorithm = algo;
+		float ms = 0;
+		int ok = 1;
+		for (int trial = 0; trial < 2 && ok; trial++) { // first trial warms the workspace up
+			HIP_ENFORCE(hipEventRecord(e0, stream));
+			const int ret = fwd ? _conv_forw(c, hint, flags, inputs, input_size, outputs, output_size, stream_context) : _conv_back(c, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+			HIP_ENFORCE(hipEventRecord(e1, stream));
+			HIP_ENFORCE(hipEventSynchronize(e1));
+			if (ret != CCV_NNC_EXEC_SUCCESS) ok = 0;
+			else HIP_ENFORCE(hipEventElapsedTime(&ms, e0, e1));
+		}
+		if (ok && (algo == 0 || ms < best_ms)) { best = algo; best_ms = ms; }
+	}
+	HIP_ENFORCE(hipEventDestroy(e0));
+	HIP_ENFORCE(hipEventDestroy(e1));
+	return best;
 }
 
 } // namespace
@@ -281,8 +398,9 @@ extern "C" void _register_command_CCV_NNC_CONVOLUTION_FORWARD_backend_CCV_NNC_BA
 	registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC;
 	registry->tensor_datatypes = CCV_32F;
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
-	registry->algorithms = 1;
+	registry->algorithms = CONV_ALGO_COUNT;
 	registry->exec = _conv_forw;
+	registry->autotune = _conv_autotune;
 }
 
 extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
@@ -290,6 +408,7 @@ extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_B
 	registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC;
 	registry->tensor_datatypes = CCV_32F;
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
-	registry->algorithms = 1;
+	registry->algorithms = CONV_ALGO_COUNT; // applies to the data gradient; the filter gradient is always the split-K implicit GEMM
 	registry->exec = _conv_back;
+	registry->autotune = _conv_autotune;
 }

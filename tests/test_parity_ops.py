@@ -99,6 +99,90 @@ def test_conv_every_block_tile(backend, ref_lib, tile, idx):
         backend.force_tile(0, 0)
 
 
+WINO_CASES = [
+    # n, h, w, c, k, border  (3x3, stride 1): F(4x4, 3x3) tiles incl. ragged edge tiles and every legal padding
+    (2, 8, 8, 8, 16, (1, 1)),      # exact 2x2 tiles
+    (1, 13, 13, 32, 32, (1, 1)),   # VGG conv5 geometry: 13 -> 4 tiles of 4 with 3 clipped rows / columns
+    (3, 9, 14, 12, 20, (0, 0)),    # no padding: output 7 x 12
+    (2, 5, 7, 8, 8, (2, 2)),       # full padding: output 7 x 9
+    (1, 27, 27, 64, 48, (1, 1)),   # several GEMM K-steps, more than one 128-row tile of tiles
+    (2, 6, 6, 4, 4, (1, 0)),       # asymmetric begin padding
+]
+
+
+def _wino_pair(backend, ref_lib, cmd, hint, ins, outs):
+    """ours under algorithm 1 (Winograd), the reference's CPU_REF direct loops under its default"""
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, ins, outs, backend=nnc.BACKEND_CPU_REF)
+    cmd.algorithm = 1
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, hint, 0, ins, outs)
+    cmd.algorithm = -1
+    assert r1 == 0 and r2 == 0, (r1, r2)
+    return got, want
+
+
+def _wino_inputs(case, seed=0):
+    n, h, w, c, k, border = case
+    rng = np.random.default_rng(seed)
+    a = srnd(rng, n, h, w, c)
+    wt = srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c))
+    b = srnd(rng, k)
+    hint = nnc.HINT((1, 1), border)
+    oh, ow = out_hw(h, w, 3, 3, hint)
+    return a, wt, b, hint, oh, ow
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_forward_winograd(backend, ref_lib, case):
+    """cmd.algorithm = 1: the Winograd F(4x4, 3x3) path against the reference's direct convolution (1e-4 relative: the
+    reference holds its own CPU Winograd to the same REQUIRE_TENSOR_EQ, test/unit/nnc/winograd.tests.c:37-130)."""
+    n, h, w, c, k, border = case
+    a, wt, b, hint, oh, ow = _wino_inputs(case)
+    cmd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
+    got, want = _wino_pair(backend, ref_lib, cmd, hint, [a, wt, b], [np.zeros((n, oh, ow, k), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-5)
+    got, want = _wino_pair(backend, ref_lib, cmd, hint, [a, wt], [np.full((n, oh, ow, k), 7, F)])  # no bias; stale output must be overwritten
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_backward_winograd_dgrad(backend, ref_lib, case):
+    """cmd.algorithm = 1 on the backward row: the data gradient through Winograd (mirrored taps, padding 2 - p), the filter
+    and bias gradients through the usual split-K path, all against the reference."""
+    n, h, w, c, k, border = case
+    a, wt, b, hint, oh, ow = _wino_inputs(case)
+    g = srnd(np.random.default_rng(5), n, oh, ow, k)
+    cmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+    got, want = _wino_pair(backend, ref_lib, cmd, hint, [g, a, wt], [np.full_like(a, 3), np.zeros_like(wt), np.zeros(k, F)])
+    for i in range(3):
+        np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 55, 55, 256, 256), (4, 111, 111, 64, 128), (16, 13, 13, 512, 512)])
+def test_conv_winograd_matches_implicit_gemm_at_vgg_sizes(gpu_lib, shape):
+    """At VGG-D layer sizes (beyond what the CPU oracle finishes): the two algorithms of the conv rows agree to 1e-4 of the
+    output scale, forward and data gradient -- the implicit GEMM being the path the oracle pins at small sizes."""
+    n, h, w, c, k = shape
+    rng = np.random.default_rng(2)
+    a, wt, b = srnd(rng, n, h, w, c), srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c) ** 0.5), srnd(rng, k)
+    g = srnd(rng, n, h, w, k)
+    hint = nnc.HINT((1, 1), (1, 1))
+    res = {}
+    for algo in (0, 1):
+        f = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
+        f.algorithm = algo
+        r, out = exec_on(gpu_lib, nnc.GPU_MEMORY, f, hint, 0, [a, wt, b], [np.zeros((n, h, w, k), F)])
+        assert r == 0
+        bw = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+        bw.algorithm = algo
+        r, outb = exec_on(gpu_lib, nnc.GPU_MEMORY, bw, hint, 0, [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, F)])
+        assert r == 0
+        res[algo] = (out[0], outb[0])
+    for i in range(2):
+        scale = float(np.abs(res[0][i]).max())
+        assert float(np.abs(res[0][i] - res[1][i]).max()) <= 1e-4 * scale, (i, scale)
+
+
 def test_conv_backward_partial_outputs(backend, ref_lib):
     case = CONV_CASES[0]
     n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case
