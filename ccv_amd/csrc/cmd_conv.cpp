@@ -105,6 +105,62 @@ static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// dw (+)= sum over tiles: the F(3x3, 4x4) form -- V = B^T a B exactly as in forward, W = G' g G'^T on the output gradient,
+// 36 contractions dU[z] (K x C) = W[z]^T V[z] over the T tiles (batched split-K: both operands are read along their
+// contiguous channel rows, the reduction index strides over tiles), then dw = A'^T dU A'.
+struct wino_wgrad_plan_t {
+	wino_plan_t t;
+	int splits;
+	size_t w_bytes, du_bytes, part_bytes;
+	size_t total() const { return t.v_bytes + w_bytes + du_bytes + part_bytes; }
+};
+
+static bool wino_wgrad_plan(const conv_geom_t& g, wino_wgrad_plan_t* p)
+{
+	if (!wino_plan(g, g.OH, g.OW, g.C, g.K, &p->t)) return false;
+	// enough K-slices that 36 x tiles x slices fills the chip ~4 times over, each slice keeping >= 8 K-steps of tiles
+	const long tiles = (long)((g.K + 127) / 128) * ((g.C + 127) / 128) * 36;
+	long s = ((long)device_cu_count() * 8 + tiles - 1) / tiles;
+	const long max_s = p->t.T / (GEMM_BK * 8);
+	if (s > max_s) s = max_s;
+	if (s > 64) s = 64;
+	p->splits = s <= 1 ? 1 : (int)(((s < 8 ? 8 : s) + 7) & ~7);
+	p->w_bytes = p->t.m_bytes; // 36 x T x K, like forward's M
+	p->du_bytes = (sizeof(float) * 36 * (size_t)g.K * g.C + 255) & ~(size_t)255;
+	p->part_bytes = p->splits > 1 ? sizeof(float) * 36 * (size_t)g.K * g.C * p->splits : 0;
+	return true;
+}
+
+static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, const Image4& gr, const Image4& a, float* dw, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	// [ gemm_run's own slab sets (it calls workspace_of itself) | V | W | dU ]
+	char* ws = (char*)workspace_of(ctx, p.total());
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	float* const V = (float*)(ws + p.part_bytes);
+	float* const W = (float*)(ws + p.part_bytes + p.t.v_bytes);
+	float* const dU = (float*)(ws + p.part_bytes + p.t.v_bytes + p.w_bytes);
+	hipStream_t stream = stream_of(ctx);
+	WinoTiles ti;
+	ti.TH = p.t.TH; ti.TW = p.t.TW; ti.T = p.t.T;
+	ti.H = a.h; ti.W = a.w; ti.sn = a.sn; ti.sh = a.sh; ti.sw = a.sw; ti.oy = -g.pby; ti.ox = -g.pbx; ti.C4 = g.C / 4;
+	ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
+	hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for((size_t)p.t.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)a.p, V, ti);
+	HIP_ENFORCE(hipGetLastError());
+	ti.H = gr.h; ti.W = gr.w; ti.sn = gr.sn; ti.sh = gr.sh; ti.sw = gr.sw; ti.oy = 0; ti.ox = 0; ti.C4 = g.K / 4;
+	ti.d_c4.init(ti.C4);
+	hipLaunchKernelGGL(wino_outgrad_kernel, dim3(grid_for((size_t)p.t.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)gr.p, W, ti);
+	HIP_ENFORCE(hipGetLastError());
+	MatLoader<false, true> la, lb; // rows = channels (contiguous), reduction index = tile (stride = channel count)
+	la.p = W; la.ldr = 1; la.ldk = g.K; la.R = g.K; la.K = p.t.T;
+	lb.p = V; lb.ldr = 1; lb.ldk = g.C; lb.R = g.C; lb.K = p.t.T;
+	GemmOut out = { dU, g.C, 1, 0, 1.f, 0 };
+	const int ret = gemm_run("conv_wgrad_wino", la, lb, out, g.K, g.C, p.t.T, 36, (long)p.t.T * g.K, (long)p.t.T * g.C, (long)g.K * g.C, 0L, p.splits, flags, ctx);
+	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
+	hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3(grid_for((size_t)g.K * g.C, 256)), dim3(256), 0, stream, (const float*)dU, dw, g.K, g.C, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 static bool wino_images_ok(const Image4& src, const Image4& dst, const float* w, const float* bias)
 {
 	return src.sc == 1 && dst.sc == 1 && aligned16(src.p) && aligned16(dst.p) && aligned16(w) && (!bias || aligned16(bias)) &&
@@ -178,9 +234,12 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 }
 
 // dw[k,i,j,c] (+)= sum_{n,y,x} g[n,y,x,k] * a[n, y*s-p+i*d, x*s-p+j*d, c]
-static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4& a, float* dw, const int flags, ccv_nnc_stream_context_t* const ctx)
+static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4& a, float* dw, const int algo, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	if (a.sc != 1 || !pixel_linear(gr) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
+	wino_wgrad_plan_t wp;
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wp) && wino_images_ok(a, gr, dw, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp.t, g.C, g.K)))
+		return conv_wino_wgrad(g, wp, gr, a, dw, flags, ctx);
 	const long P = (long)g.N * g.OH * g.OW;
 	if (P > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const int NN = g.kh * g.kw * g.Cg;
@@ -315,6 +374,8 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	if (inner_b > inner) inner = inner_b;
 	wino_plan_t wpl;
 	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wpl) && wpl.total() > inner) inner = wpl.total();
+	wino_wgrad_plan_t wgp;
+	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wgp) && wgp.total() > inner) inner = wgp.total();
 	WorkspaceScope ws(stream_context, ng + na + nh + nw + ndw, inner);
 	char* p = (char*)ws.prefix();
 	if ((ng + na + nh + nw + ndw) && !p) return CCV_NNC_EXEC_OOM;
@@ -339,7 +400,7 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 			dwp = (float*)(p + ng + na + nh + nw);
 			if (acc && (ret = weights_nchw_to_nhwc(dw->data.f32, dwp, g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		}
-		if ((ret = conv_wgrad_nhwc(g, gim, aim, dwp, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = conv_wgrad_nhwc(g, gim, aim, dwp, cmd.algorithm, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		if (stage_w && (ret = weights_nhwc_to_nchw(dwp, dw->data.f32, g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
 	if (dbias) {
@@ -408,7 +469,7 @@ extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_B
 	registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC;
 	registry->tensor_datatypes = CCV_32F;
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
-	registry->algorithms = CONV_ALGO_COUNT; // applies to the data gradient; the filter gradient is always the split-K implicit GEMM
+	registry->algorithms = CONV_ALGO_COUNT; // one choice for both gradients
 	registry->exec = _conv_back;
 	registry->autotune = _conv_autotune;
 }

@@ -70,8 +70,9 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
 	const long tiles = (long)tiles_m * tiles_n;
 	if (tiles > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	// the automatic choice never splits a batched contraction (callers size their workspace for one slab set); an
+	// explicit splits > 1 with zcount > 1 is the batched split-K of the Winograd filter gradient: z slab sets back to back
 	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
-	if (zcount > 1) splits = 1;
 	int k_per_split = K;
 	if (splits > 1) {
 		// whole K-slices per XCD (see the kernel's block -> (slice, tile) map): the slice count is a multiple of 8;
@@ -95,16 +96,16 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 		return CCV_NNC_EXEC_SUCCESS;
 	}
 	const long slab = (long)M * N;
-	float* ws = (float*)workspace_of(ctx, sizeof(float) * (size_t)slab * splits);
+	float* ws = (float*)workspace_of(ctx, sizeof(float) * (size_t)slab * splits * zcount);
 	if (!ws) return CCV_NNC_EXEC_OOM;
 	EpiPartial epi;
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)(tiles * splits), 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, 0L, 0L, 0L, 0L, ko);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256)), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N);
+	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

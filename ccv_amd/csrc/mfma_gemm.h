@@ -755,8 +755,12 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 }
 
 // Finish a split-K contraction: c = alpha * sum_s slab[s] (+ bias[n]) (+ old c). Fixed summation order => deterministic.
-static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, const int splits, const long slab, float* c, const long ldm, const long ldn, const float* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N)
+// grid.y = batch entry z: its slab set starts at ws + z * splits * slab, its output at c + z * c_zoff.
+static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, const int splits, const long slab, float* c, const long ldm, const long ldn, const float* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff)
 {
+	ws += (long)blockIdx.y * splits * slab;
+	c += (long)blockIdx.y * c_zoff;
+	if (bias) bias += (long)blockIdx.y * bias_zoff;
 	for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < slab; idx += (long)gridDim.x * blockDim.x) {
 		const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
 		float v = 0.f;

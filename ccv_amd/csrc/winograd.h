@@ -51,6 +51,29 @@ __device__ __forceinline__ void wino_at(const T (&x)[6], T (&y)[4])
 	y[3] = d1 + 8.f * d2 + x[5];
 }
 
+// F(3x3, 4x4) (filter gradient: 3x3 outputs from a 6x6 input tile and a 4x4 output-gradient tile; same points, same B^T):
+// y = G' x (4 -> 6) on the output-gradient tile, y = A'^T x (6 -> 3) on the products.
+template <class T>
+__device__ __forceinline__ void wino_g4(const T (&x)[4], T (&y)[6])
+{
+	const T e = x[0] + x[2], o = x[1] + x[3];
+	const T e2 = x[0] * (1.f / 24.f) + x[2] * (1.f / 6.f), o2 = x[1] * (1.f / 12.f) + x[3] * (1.f / 3.f);
+	y[0] = x[0] * 0.25f;
+	y[1] = (e + o) * (-1.f / 6.f);
+	y[2] = (e - o) * (-1.f / 6.f);
+	y[3] = e2 + o2;
+	y[4] = e2 - o2;
+	y[5] = x[3];
+}
+template <class T>
+__device__ __forceinline__ void wino_at3(const T (&x)[6], T (&y)[3])
+{
+	const T s1 = x[1] + x[2], d1 = x[1] - x[2], s2 = x[3] + x[4], d2 = x[3] - x[4];
+	y[0] = x[0] + s1 + s2;
+	y[1] = d1 + 2.f * d2;
+	y[2] = s1 + 4.f * s2 + x[5];
+}
+
 struct f4 {
 	float x, y, z, w;
 	__device__ __forceinline__ f4() {}
@@ -178,6 +201,70 @@ static __global__ void __launch_bounds__(256) wino_output_kernel(const float* __
 		for (int j = 0; j < 4; j++) {
 			const int ox = tx * 4 + j;
 			if ((oy < g.H) & (ox < g.W)) *(float4*)(dst + (long)oy * g.sh + (long)ox * g.sw) = (float4)(y[j] + bv);
+		}
+	}
+}
+
+// W[z][t][k] = (G' dy G'^T)[zy][zx], dy = the 4x4 output-gradient tile t (zero past the image edge).  One thread per (t, k4).
+static __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restrict__ gr, float* __restrict__ wt, const WinoTiles g)
+{
+	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (long)g.T * g.C4) return;
+	const int t = g.d_c4.div((int)idx), k4 = (int)(idx - (long)t * g.C4);
+	const int tn = g.d_tw.div(t), tx = t - tn * g.TW;
+	const int n = g.d_th.div(tn), ty = tn - n * g.TH;
+	const float* const src = gr + (long)n * g.sn + (long)k4 * 4;
+	f4 s[4][6]; // rows transformed horizontally: s[r] = dy[r] G'^T
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const int y = ty * 4 + r;
+		f4 d[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const int x = tx * 4 + q;
+			const bool ok = (y < g.H) & (x < g.W);
+			d[q] = ok ? f4(*(const float4*)(src + (long)y * g.sh + (long)x * g.sw)) : f4(0.f, 0.f, 0.f, 0.f);
+		}
+		wino_g4(d, s[r]);
+	}
+	const long plane = (long)g.T * g.C4 * 4;
+	float* const dst = wt + idx * 4;
+#pragma unroll
+	for (int q = 0; q < 6; q++) {
+		const f4 col[4] = { s[0][q], s[1][q], s[2][q], s[3][q] };
+		f4 y[6];
+		wino_g4(col, y);
+#pragma unroll
+		for (int r = 0; r < 6; r++) *(float4*)(dst + (long)(r * 6 + q) * plane) = y[r];
+	}
+}
+
+// dw[k][i][j][c] (+)= (A'^T du A')[i][j], du = dU[.][k][c].  One thread per (k, c), c fastest.
+static __global__ void __launch_bounds__(256) wino_wgrad_final_kernel(const float* __restrict__ du, float* __restrict__ dw, const int K, const int C, const int accumulate)
+{
+	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const long plane = (long)K * C;
+	if (idx >= plane) return;
+	const int k = (int)(idx / C), c = (int)(idx - (long)k * C);
+	float s[3][6];
+#pragma unroll
+	for (int q = 0; q < 6; q++) {
+		float col[6];
+#pragma unroll
+		for (int r = 0; r < 6; r++) col[r] = du[(long)(r * 6 + q) * plane + idx];
+		float y[3];
+		wino_at3(col, y);
+#pragma unroll
+		for (int i = 0; i < 3; i++) s[i][q] = y[i];
+	}
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		float y[3];
+		wino_at3(s[i], y);
+#pragma unroll
+		for (int j = 0; j < 3; j++) {
+			float* const o = dw + ((long)k * 9 + i * 3 + j) * C + c;
+			*o = accumulate ? *o + y[j] : y[j];
 		}
 	}
 }

@@ -146,15 +146,26 @@ def test_conv_forward_winograd(backend, ref_lib, case):
 
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv_backward_winograd_dgrad(backend, ref_lib, case):
-    """cmd.algorithm = 1 on the backward row: the data gradient through Winograd (mirrored taps, padding 2 - p), the filter
-    and bias gradients through the usual split-K path, all against the reference."""
+    """cmd.algorithm = 1 on the backward row: the data gradient through Winograd F(4x4,3x3) (mirrored taps, padding 2 - p),
+    the filter gradient through F(3x3,4x4) with the batched split-K contraction over tiles, against the reference."""
     n, h, w, c, k, border = case
     a, wt, b, hint, oh, ow = _wino_inputs(case)
     g = srnd(np.random.default_rng(5), n, oh, ow, k)
     cmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
     got, want = _wino_pair(backend, ref_lib, cmd, hint, [g, a, wt], [np.full_like(a, 3), np.zeros_like(wt), np.zeros(k, F)])
+    # 1e-4 relative; the absolute floor scales with the tensor: the Winograd transforms add and subtract terms weighted up
+    # to 8x before the products, so the error follows the magnitude of the TERMS, not of a sum that cancelled to ~0 (the
+    # signed random gradients here cancel heavily in dw; observed worst case 1.1e-5 of the tensor's scale)
+    tol = lambda ref: dict(rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
     for i in range(3):
-        np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(got[i], want[i], **tol(want[i]))
+    # CCV_NNC_ACCUMULATE_OUTPUT: dw accumulates on top of its previous contents
+    dw0 = srnd(np.random.default_rng(6), *wt.shape)
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, nnc.ACCUMULATE_OUTPUT, [g, a, wt], [np.zeros_like(a), dw0.copy(), np.zeros(k, F)], backend=nnc.BACKEND_CPU_REF)
+    cmd.algorithm = 1
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, hint, nnc.ACCUMULATE_OUTPUT, [g, a, wt], [np.zeros_like(a), dw0.copy(), np.zeros(k, F)])
+    assert r1 == 0 and r2 == 0
+    np.testing.assert_allclose(got[1], want[1], **tol(want[1]))
 
 
 @pytest.mark.gpu
@@ -177,8 +188,8 @@ def test_conv_winograd_matches_implicit_gemm_at_vgg_sizes(gpu_lib, shape):
         bw.algorithm = algo
         r, outb = exec_on(gpu_lib, nnc.GPU_MEMORY, bw, hint, 0, [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, F)])
         assert r == 0
-        res[algo] = (out[0], outb[0])
-    for i in range(2):
+        res[algo] = (out[0], outb[0], outb[1])
+    for i in range(3):
         scale = float(np.abs(res[0][i]).max())
         assert float(np.abs(res[0][i] - res[1][i]).max()) <= 1e-4 * scale, (i, scale)
 

@@ -21,6 +21,8 @@ NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(UNIT, "*
 # unseeded draws checked against a +-0.02 window on the sample mean (rand.tests.c:71): about one run in fifteen misses it
 # in the plain CPU build of the reference as well; retried
 STATISTICAL = ("rand",)
+# the host's OpenMP loops over tiny test tensors crawl when spread over the GPU box's 256 cores (two binaries ran > 280 s)
+ENV = dict(os.environ, OMP_NUM_THREADS="8")
 HAVE_REF_DATA = os.path.isdir("/root/reference/test/unit/nnc/data")
 
 
@@ -32,7 +34,7 @@ def _run(flavor, name):
         pytest.skip("needs the reference's test/unit/nnc/data files")
     os.makedirs(os.path.join(RUN, "gen"), exist_ok=True)
     for attempt in range(3 if name in STATISTICAL else 1):
-        p = subprocess.run([b], capture_output=True, text=True, timeout=280, cwd=RUN)
+        p = subprocess.run([b], capture_output=True, text=True, timeout=150, cwd=RUN, env=ENV)
         out = p.stdout + p.stderr
         npass, nfail = len(re.findall(r"\[PASS\]", out)), len(re.findall(r"\[FAIL\]", out))
         if nfail == 0:
