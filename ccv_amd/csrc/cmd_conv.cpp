@@ -51,6 +51,9 @@ static bool pixel_linear(const Image4& t)
 // Algorithm numbers of the two conv rows (ccv_nnc_cmd_t.algorithm; -1 = the backend's own choice; what autotune returns).
 enum { CONV_ALGO_IMPLICIT_GEMM = 0, CONV_ALGO_WINOGRAD = 1, CONV_ALGO_COUNT = 2 };
 
+// the Winograd transform kernels are one-thread-per-item (no grid-stride loop): launch exactly ceil(n / threads) blocks
+static unsigned blocks_exact(const size_t n, const int threads) { return (unsigned)((n + threads - 1) / threads); }
+
 struct wino_plan_t {
 	int TH, TW, T;
 	size_t u_bytes, v_bytes, m_bytes;
@@ -83,13 +86,13 @@ static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan
 	float* const V = (float*)(ws + p.u_bytes);
 	float* const M = (float*)(ws + p.u_bytes + p.v_bytes);
 	hipStream_t stream = stream_of(ctx);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_weight_kernel<FLIP>), dim3(grid_for((size_t)Cs * Cd, 256)), dim3(256), 0, stream, w, U, g.K, g.C);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_weight_kernel<FLIP>), dim3(blocks_exact((size_t)Cs * Cd, 256)), dim3(256), 0, stream, w, U, g.K, g.C);
 	HIP_ENFORCE(hipGetLastError());
 	WinoTiles ti;
 	ti.TH = p.TH; ti.TW = p.TW; ti.T = p.T;
 	ti.H = src.h; ti.W = src.w; ti.sn = src.sn; ti.sh = src.sh; ti.sw = src.sw; ti.oy = -pad_y; ti.ox = -pad_x; ti.C4 = Cs / 4;
 	ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
-	hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for((size_t)p.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)src.p, V, ti);
+	hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_exact((size_t)p.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)src.p, V, ti);
 	HIP_ENFORCE(hipGetLastError());
 	// 36 GEMMs M[z] (T x Cd) = V[z] (T x Cs) * U[z]^T (Cd x Cs), both operands reduction-contiguous, one launch (grid z)
 	MatLoader<true, true> la, lb;
@@ -100,7 +103,7 @@ static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan
 	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
 	ti.H = dst.h; ti.W = dst.w; ti.sn = dst.sn; ti.sh = dst.sh; ti.sw = dst.sw; ti.C4 = Cd / 4;
 	ti.d_c4.init(ti.C4);
-	hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for((size_t)p.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)M, bias, dst.p, ti);
+	hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_exact((size_t)p.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)M, bias, dst.p, ti);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -144,11 +147,11 @@ static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, con
 	ti.TH = p.t.TH; ti.TW = p.t.TW; ti.T = p.t.T;
 	ti.H = a.h; ti.W = a.w; ti.sn = a.sn; ti.sh = a.sh; ti.sw = a.sw; ti.oy = -g.pby; ti.ox = -g.pbx; ti.C4 = g.C / 4;
 	ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
-	hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for((size_t)p.t.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)a.p, V, ti);
+	hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_exact((size_t)p.t.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)a.p, V, ti);
 	HIP_ENFORCE(hipGetLastError());
 	ti.H = gr.h; ti.W = gr.w; ti.sn = gr.sn; ti.sh = gr.sh; ti.sw = gr.sw; ti.oy = 0; ti.ox = 0; ti.C4 = g.K / 4;
 	ti.d_c4.init(ti.C4);
-	hipLaunchKernelGGL(wino_outgrad_kernel, dim3(grid_for((size_t)p.t.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)gr.p, W, ti);
+	hipLaunchKernelGGL(wino_outgrad_kernel, dim3(blocks_exact((size_t)p.t.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)gr.p, W, ti);
 	HIP_ENFORCE(hipGetLastError());
 	MatLoader<false, true> la, lb; // rows = channels (contiguous), reduction index = tile (stride = channel count)
 	la.p = W; la.ldr = 1; la.ldk = g.K; la.R = g.K; la.K = p.t.T;
@@ -156,7 +159,7 @@ static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, con
 	GemmOut out = { dU, g.C, 1, 0, 1.f, 0 };
 	const int ret = gemm_run("conv_wgrad_wino", la, lb, out, g.K, g.C, p.t.T, 36, (long)p.t.T * g.K, (long)p.t.T * g.C, (long)g.K * g.C, 0L, p.splits, flags, ctx);
 	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
-	hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3(grid_for((size_t)g.K * g.C, 256)), dim3(256), 0, stream, (const float*)dU, dw, g.K, g.C, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
+	hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3(blocks_exact((size_t)g.K * g.C, 256)), dim3(256), 0, stream, (const float*)dU, dw, g.K, g.C, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
