@@ -83,6 +83,9 @@ def main():
     dist = None
     comm = None
     if world > 1:
+        # one node: RCCL's bootstrap sockets go over loopback, no InfiniBand probing (the boxes have no external network)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
         import torch.distributed as dist  # control plane only (rendezvous, barrier, max-reduce of the timing)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from ccv_amd.comm import ProcessComm
@@ -99,14 +102,20 @@ def main():
     del imgs
     stream = L.stream_new(local_rank)
     L.stream_wait(None)  # construction-time SET commands ran on the default stream
+    comm_stream = None
     if comm:
         comm.broadcast_params(net, stream)
+        L.stream_wait(stream)
+        comm_stream = L.stream_new(local_rank)  # the exchange overlaps backward on its own HIP stream
+        comm.plan_overlap(net, comm_stream)
 
     def step():
         net.forward(stream)
-        net.backward(stream)
         if comm:
-            comm.allreduce_grads(net, stream)
+            net.backward(stream, after_node=lambda i: comm.after_backward_node(net, i, stream))
+            comm.finish_overlap(stream)
+        else:
+            net.backward(stream)
         net.update(stream)
 
     def barrier():

@@ -40,7 +40,9 @@ class ProcessComm:
         else:
             import torch
             base = t.owner if t.owner is not None else t
-            x = torch.from_numpy(base.array.reshape(-1))
+            flat = base.array.reshape(-1)
+            first = (t.ptr - base.ptr) // flat.itemsize   # a dense alias covers [first, first + count) of its owner
+            x = torch.from_numpy(flat[first:first + int(np.prod(t.dims))])
             if op == "sum":
                 self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
             else:
@@ -50,6 +52,50 @@ class ProcessComm:
         """Replicas start from rank 0's weights (_ccv_cnnp_model_copy_tensors, ccv_cnnp_model.c:1451-1452)."""
         for p, _, _ in net.params:
             self._collective(self._broadcast, p, stream, "bcast")
+
+    # ---- overlapped form: the exchange rides a second stream while backward is still running -------------------------------
+    # Backward produces the gradients last-layer first.  VGG-D's three fc layers hold 385 of the 444 MB and are finished a
+    # few milliseconds into backward, so the arena is cut into buckets of consecutive layers (default: the fc block | the
+    # conv block); a bucket's all-reduce is issued on `comm_stream` as soon as the bucket's earliest layer has been
+    # enqueued on the compute stream (signal: compute -> comm), and the SGD commands wait for the last one (comm -> compute).
+    # Few large collectives, because a ring over point-to-point xGMI links is bandwidth-bound only for large messages.
+    def plan_overlap(self, net, comm_stream, bucket_bytes=64 << 20):
+        nodes = [(i, n["arena"]) for i, n in enumerate(net.nodes) if "arena" in n]
+        self._buckets = []   # (trigger node index, arena tensor slice), in backward order
+        hi = None
+        for i, (lo_off, hi_off) in reversed(nodes):
+            if hi is None:
+                hi = hi_off
+            if (hi - lo_off) * 4 >= bucket_bytes or i == nodes[0][0]:
+                self._buckets.append((i, net.grad_arena.alias((hi - lo_off,), lo_off)))
+                hi = None
+        self._comm_stream = comm_stream
+        if self.transport == "rccl":
+            self._sig_ready = [self.lib.signal_new(net.device) for _ in self._buckets]
+            self._sig_done = self.lib.signal_new(net.device)
+        self._next = 0
+
+    def after_backward_node(self, net, i, stream):
+        """pass as VGGD.backward(after_node=...)"""
+        while self._next < len(self._buckets) and self._buckets[self._next][0] >= i:
+            trigger, t = self._buckets[self._next]
+            if trigger != i:
+                break
+            if self.transport == "rccl":
+                self.lib.signal_emit(stream, self._sig_ready[self._next])
+                self.lib.signal_wait(self._comm_stream, self._sig_ready[self._next])
+                self._collective(self._allreduce, t, self._comm_stream, "sum")
+            else:
+                self._collective(self._allreduce, t, None, "sum")
+            self._next += 1
+
+    def finish_overlap(self, stream):
+        """every bucket issued; the compute stream (SGD) continues once the comm stream has drained them"""
+        assert self._next == len(self._buckets), "backward did not reach every bucket"
+        if self.transport == "rccl":
+            self.lib.signal_emit(self._comm_stream, self._sig_done)
+            self.lib.signal_wait(stream, self._sig_done)
+        self._next = 0
 
     def allreduce_grads(self, net, stream=None):
         if getattr(net, "grad_arena", None) is not None:

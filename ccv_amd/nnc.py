@@ -447,6 +447,11 @@ class Lib:
             d.nnc_mi355x_stream_context_new.argtypes = [C.c_int]
             d.nnc_mi355x_stream_context_free.argtypes = [C.c_void_p]
             d.nnc_mi355x_stream_context_wait.argtypes = [C.c_void_p]
+            d.nnc_mi355x_stream_signal_new.restype = C.c_void_p
+            d.nnc_mi355x_stream_signal_new.argtypes = [C.c_int]
+            d.nnc_mi355x_stream_signal_free.argtypes = [C.c_void_p]
+            d.ccv_nnc_stream_compat_emit_signal.argtypes = [C.c_void_p, C.c_void_p]
+            d.ccv_nnc_stream_compat_wait_signal.argtypes = [C.c_void_p, C.c_void_p]
             d.nnc_mi355x_event_new.restype = C.c_void_p
             d.nnc_mi355x_event_record.argtypes = [C.c_void_p, C.c_void_p]
             d.nnc_mi355x_event_elapsed_ms.restype = C.c_float
@@ -470,6 +475,11 @@ class Lib:
     def stream_new(self, device=0): return self.dll.nnc_mi355x_stream_context_new(STREAM_CONTEXT_GPU | (device << 8))
     def stream_free(self, s): self.dll.nnc_mi355x_stream_context_free(s)
     def stream_wait(self, s): self.dll.nnc_mi355x_stream_context_wait(s)
+    # ccv_nnc_stream_signal_new / ccv_nnc_stream_context_emit_signal / _wait_signal (lib/nnc/ccv_nnc_stream.c:304-342)
+    def signal_new(self, device=0): return self.dll.nnc_mi355x_stream_signal_new(STREAM_CONTEXT_GPU | (device << 8))
+    def signal_free(self, sig): self.dll.nnc_mi355x_stream_signal_free(sig)
+    def signal_emit(self, stream, sig): self.dll.ccv_nnc_stream_compat_emit_signal(stream, sig)
+    def signal_wait(self, stream, sig): self.dll.ccv_nnc_stream_compat_wait_signal(stream, sig)
     def cmd_ok(self, cmd, backend): return bool(self.dll.nnc_mi355x_cmd_ok(cmd, backend))
 
     def profile_enable(self, on): self.dll.nnc_mi355x_profile_enable(int(on))

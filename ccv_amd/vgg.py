@@ -125,7 +125,9 @@ class VGGD:
                         p = n[key]
                         if flat_grads:
                             dp = self._flat_at(self.grad_arena, arena_off, *p.dims)
+                            n.setdefault("arena", [arena_off, arena_off])
                             arena_off += (int(np.prod(p.dims)) + 31) // 32 * 32
+                            n["arena"][1] = arena_off
                         else:
                             dp = lib.tensor(nnc.tensor_param(memory, nnc.NHWC, F, p.dims, device))
                         mom = lib.tensor(nnc.tensor_param(memory, nnc.NHWC, F, p.dims, device))
@@ -197,7 +199,9 @@ class VGGD:
                     self._exec(relu, nnc.NO_HINT, 0, [n["b"]], [n["b"]], stream, "relu_fwd/%d" % i, hook)
         self._exec(nnc.CMD_SOFTMAX_CROSSENTROPY_FORWARD(), nnc.NO_HINT, 0, [self.logits, self.label], [self.loss, self.softmax], stream, "softmax_ce_fwd", hook)
 
-    def backward(self, stream=None, hook=None):
+    def backward(self, stream=None, hook=None, after_node=None):
+        """after_node(i): called once node i's backward command has been enqueued (its parameter gradients are then ordered on
+        `stream`) -- the data-parallel exchange hangs its bucketed all-reduce on this (ccv_amd/comm.py)."""
         relub = nnc.CMD_RELU_BACKWARD()
         g_logits = self.grads[id(self.logits)]
         self._exec(nnc.CMD_SOFTMAX_CROSSENTROPY_BACKWARD(), nnc.NO_HINT, 0, [None, None, None, self.label, None, self.softmax], [g_logits], stream, "softmax_ce_bwd", hook)
@@ -211,6 +215,8 @@ class VGGD:
                 self._exec(relub, nnc.NO_HINT, 0, [gb, None, n["b"]], [gb], stream, "relu_bwd/%d" % i, hook)
             h = None if n["first"] else self.grads[id(n["a"])]
             self._exec(n["bcmd"], n["hint"], 0, [gb, n["a"], n["w"]], [h, n["dw"], n["dbias"]], stream, "%s_bwd/%d" % (n["kind"], i), hook)
+            if after_node is not None:
+                after_node(i)
 
     def update(self, stream=None, hook=None):
         for j, (p, dp, mom) in enumerate(self.params):

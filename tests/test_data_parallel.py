@@ -28,12 +28,19 @@ net = VGGD(O, B // world, memory=nnc.CPU_MEMORY, input_hw=19, layers=%(layers)r,
            flat_grads=True, sgd=(0, 0.01, 1.0 / B, 0.0005, 0.9, 0.9))
 comm = ProcessComm(O, dist, rank, world, transport="gloo")
 comm.broadcast_params(net)   # rank 1 was seeded differently on purpose
+comm.plan_overlap(net, None, bucket_bytes=2048)   # several buckets even on this tiny net
+assert len(comm._buckets) >= 2
 rng = np.random.default_rng(11)
 for step in range(2):
     x, y = rng.random((B, 19, 19, 3), dtype=np.float32), rng.integers(0, 10, B)
     s = slice(rank * B // world, (rank + 1) * B // world)
     net.set_input(x[s], y[s])
-    net.forward(); net.backward(); comm.allreduce_grads(net); net.update()
+    net.forward()
+    if step == 0:   # the bucketed, backward-interleaved exchange bench.py uses ...
+        net.backward(after_node=lambda i: comm.after_backward_node(net, i, None)); comm.finish_overlap(None)
+    else:           # ... and the single flat collective: same result
+        net.backward(); comm.allreduce_grads(net)
+    net.update()
 if rank == 0:
     np.savez(sys.argv[1], *[p.numpy() for p, _, _ in net.params])
 dist.barrier(); dist.destroy_process_group()
