@@ -114,8 +114,9 @@ static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan
 struct wino_wgrad_plan_t {
 	wino_plan_t t;
 	int splits;
-	size_t w_bytes, du_bytes, part_bytes;
-	size_t total() const { return t.v_bytes + w_bytes + du_bytes + part_bytes; }
+	size_t w_bytes, du_bytes, head_bytes, bp_bytes;
+	long blocks; // of the output-gradient transform
+	size_t total() const { return head_bytes + t.v_bytes + w_bytes + du_bytes + bp_bytes; }
 };
 
 static bool wino_wgrad_plan(const conv_geom_t& g, wino_wgrad_plan_t* p)
@@ -130,18 +131,28 @@ static bool wino_wgrad_plan(const conv_geom_t& g, wino_wgrad_plan_t* p)
 	p->splits = s <= 1 ? 1 : (int)(((s < 8 ? 8 : s) + 7) & ~7);
 	p->w_bytes = p->t.m_bytes; // 36 x T x K, like forward's M
 	p->du_bytes = (sizeof(float) * 36 * (size_t)g.K * g.C + 255) & ~(size_t)255;
-	p->part_bytes = p->splits > 1 ? sizeof(float) * 36 * (size_t)g.K * g.C * p->splits : 0;
+	// head: what the calls made underneath take from the base of the workspace -- gemm_run's slab sets, colsum_f32's partials
+	p->head_bytes = p->splits > 1 ? sizeof(float) * 36 * (size_t)g.K * g.C * p->splits : 0;
+	const size_t colsum_bound = sizeof(float) * (size_t)device_cu_count() * 4 * g.K;
+	if (p->head_bytes < colsum_bound) p->head_bytes = colsum_bound;
+	p->head_bytes = (p->head_bytes + 255) & ~(size_t)255;
+	p->blocks = ((long)p->t.T * (g.K / 4) + 255) / 256;
+	p->bp_bytes = sizeof(float) * (size_t)p->blocks * g.K;
 	return true;
 }
 
-static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, const Image4& gr, const Image4& a, float* dw, const int flags, ccv_nnc_stream_context_t* const ctx)
+// dbias != 0: also produce the bias gradient (column sums of gr) inside the output-gradient transform; *bias_done tells the
+// caller whether that happened (it needs (K / 4) | 256).
+static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, const Image4& gr, const Image4& a, float* dw, float* dbias, bool* bias_done, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
-	// [ gemm_run's own slab sets (it calls workspace_of itself) | V | W | dU ]
+	// [ head: nested calls' scratch (they take the workspace base) | V | W | dU | per-block column sums ]
 	char* ws = (char*)workspace_of(ctx, p.total());
 	if (!ws) return CCV_NNC_EXEC_OOM;
-	float* const V = (float*)(ws + p.part_bytes);
-	float* const W = (float*)(ws + p.part_bytes + p.t.v_bytes);
-	float* const dU = (float*)(ws + p.part_bytes + p.t.v_bytes + p.w_bytes);
+	float* const V = (float*)(ws + p.head_bytes);
+	float* const W = (float*)(ws + p.head_bytes + p.t.v_bytes);
+	float* const dU = (float*)(ws + p.head_bytes + p.t.v_bytes + p.w_bytes);
+	float* const BP = (float*)(ws + p.head_bytes + p.t.v_bytes + p.w_bytes + p.du_bytes);
+	const bool fuse_bias = dbias && 256 % (g.K / 4) == 0;
 	hipStream_t stream = stream_of(ctx);
 	WinoTiles ti;
 	ti.TH = p.t.TH; ti.TW = p.t.TW; ti.T = p.t.T;
@@ -151,7 +162,8 @@ static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, con
 	HIP_ENFORCE(hipGetLastError());
 	ti.H = gr.h; ti.W = gr.w; ti.sn = gr.sn; ti.sh = gr.sh; ti.sw = gr.sw; ti.oy = 0; ti.ox = 0; ti.C4 = g.K / 4;
 	ti.d_c4.init(ti.C4);
-	hipLaunchKernelGGL(wino_outgrad_kernel, dim3(blocks_exact((size_t)p.t.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)gr.p, W, ti);
+	if (fuse_bias) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_outgrad_kernel<true>), dim3((unsigned)p.blocks), dim3(256), 0, stream, (const float*)gr.p, W, ti, BP);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_outgrad_kernel<false>), dim3((unsigned)p.blocks), dim3(256), 0, stream, (const float*)gr.p, W, ti, (float*)0);
 	HIP_ENFORCE(hipGetLastError());
 	MatLoader<false, true> la, lb; // rows = channels (contiguous), reduction index = tile (stride = channel count)
 	la.p = W; la.ldr = 1; la.ldk = g.K; la.R = g.K; la.K = p.t.T;
@@ -161,6 +173,11 @@ static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, con
 	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
 	hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3(blocks_exact((size_t)g.K * g.C, 256)), dim3(256), 0, stream, (const float*)dU, dw, g.K, g.C, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
 	HIP_ENFORCE(hipGetLastError());
+	if (fuse_bias) { // fold the per-block rows; its own partials land in the head region, V / W are dead by now
+		const int r = colsum_f32(BP, p.blocks, g.K, g.K, dbias, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0, ctx);
+		if (r != CCV_NNC_EXEC_SUCCESS) return r;
+	}
+	if (bias_done) *bias_done = fuse_bias;
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
@@ -237,12 +254,13 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 }
 
 // dw[k,i,j,c] (+)= sum_{n,y,x} g[n,y,x,k] * a[n, y*s-p+i*d, x*s-p+j*d, c]
-static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4& a, float* dw, const int algo, const int flags, ccv_nnc_stream_context_t* const ctx)
+static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4& a, float* dw, float* dbias, bool* bias_done, const int algo, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
+	if (bias_done) *bias_done = false;
 	if (a.sc != 1 || !pixel_linear(gr) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
 	wino_wgrad_plan_t wp;
 	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wp) && wino_images_ok(a, gr, dw, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp.t, g.C, g.K)))
-		return conv_wino_wgrad(g, wp, gr, a, dw, flags, ctx);
+		return conv_wino_wgrad(g, wp, gr, a, dw, dbias, bias_done, flags, ctx);
 	const long P = (long)g.N * g.OH * g.OW;
 	if (P > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const int NN = g.kh * g.kw * g.Cg;
@@ -397,16 +415,17 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 		}
 		if (nh) { dense_nhwc_like(h, hi, (float*)(p + ng + na), &hs); image4(&hs, &him); }
 	}
+	bool bias_done = false;
 	if (dw) {
 		float* dwp = dw->data.f32;
 		if (stage_w) {
 			dwp = (float*)(p + ng + na + nh + nw);
 			if (acc && (ret = weights_nchw_to_nhwc(dw->data.f32, dwp, g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		}
-		if ((ret = conv_wgrad_nhwc(g, gim, aim, dwp, cmd.algorithm, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = conv_wgrad_nhwc(g, gim, aim, dwp, dbias ? dbias->data.f32 : 0, &bias_done, cmd.algorithm, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		if (stage_w && (ret = weights_nhwc_to_nchw(dwp, dw->data.f32, g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
-	if (dbias) {
+	if (dbias && !bias_done) {
 		if (!pixel_linear(gim)) return CCV_NNC_EXEC_INVALID;
 		if ((ret = colsum_f32(gim.p, P, g.K, gim.sw, dbias->data.f32, acc, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}

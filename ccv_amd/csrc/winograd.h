@@ -206,36 +206,55 @@ static __global__ void __launch_bounds__(256) wino_output_kernel(const float* __
 }
 
 // W[z][t][k] = (G' dy G'^T)[zy][zx], dy = the 4x4 output-gradient tile t (zero past the image edge).  One thread per (t, k4).
-static __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restrict__ gr, float* __restrict__ wt, const WinoTiles g)
+// COLSUM: the kernel reads every element of the output gradient exactly once, so the bias gradient's column sums ride
+// along: each thread adds up its 16 pixels, the block folds the tiles it covers through LDS (fixed order) and writes one
+// row of partial sums per block (blockpart[block][K]); colsum_f32 over those rows finishes -- the separate pass over g
+// (3.4 ms of the VGG-D step) is gone.  Needs a whole number of tiles per block: (K / 4) divides 256.
+template <bool COLSUM>
+static __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restrict__ gr, float* __restrict__ wt, const WinoTiles g, float* __restrict__ blockpart)
 {
+	__shared__ float4 red[COLSUM ? 256 : 1];
 	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= (long)g.T * g.C4) return;
-	const int t = g.d_c4.div((int)idx), k4 = (int)(idx - (long)t * g.C4);
-	const int tn = g.d_tw.div(t), tx = t - tn * g.TW;
-	const int n = g.d_th.div(tn), ty = tn - n * g.TH;
-	const float* const src = gr + (long)n * g.sn + (long)k4 * 4;
-	f4 s[4][6]; // rows transformed horizontally: s[r] = dy[r] G'^T
+	const bool live = idx < (long)g.T * g.C4;
+	f4 sum(0.f, 0.f, 0.f, 0.f);
+	if (live) {
+		const int t = g.d_c4.div((int)idx), k4 = (int)(idx - (long)t * g.C4);
+		const int tn = g.d_tw.div(t), tx = t - tn * g.TW;
+		const int n = g.d_th.div(tn), ty = tn - n * g.TH;
+		const float* const src = gr + (long)n * g.sn + (long)k4 * 4;
+		f4 s[4][6]; // rows transformed horizontally: s[r] = dy[r] G'^T
 #pragma unroll
-	for (int r = 0; r < 4; r++) {
-		const int y = ty * 4 + r;
-		f4 d[4];
+		for (int r = 0; r < 4; r++) {
+			const int y = ty * 4 + r;
+			f4 d[4];
 #pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const int x = tx * 4 + q;
-			const bool ok = (y < g.H) & (x < g.W);
-			d[q] = ok ? f4(*(const float4*)(src + (long)y * g.sh + (long)x * g.sw)) : f4(0.f, 0.f, 0.f, 0.f);
+			for (int q = 0; q < 4; q++) {
+				const int x = tx * 4 + q;
+				const bool ok = (y < g.H) & (x < g.W);
+				d[q] = ok ? f4(*(const float4*)(src + (long)y * g.sh + (long)x * g.sw)) : f4(0.f, 0.f, 0.f, 0.f);
+				if (COLSUM) sum = sum + d[q];
+			}
+			wino_g4(d, s[r]);
 		}
-		wino_g4(d, s[r]);
+		const long plane = (long)g.T * g.C4 * 4;
+		float* const dst = wt + idx * 4;
+#pragma unroll
+		for (int q = 0; q < 6; q++) {
+			const f4 col[4] = { s[0][q], s[1][q], s[2][q], s[3][q] };
+			f4 y[6];
+			wino_g4(col, y);
+#pragma unroll
+			for (int r = 0; r < 6; r++) *(float4*)(dst + (long)(r * 6 + q) * plane) = y[r];
+		}
 	}
-	const long plane = (long)g.T * g.C4 * 4;
-	float* const dst = wt + idx * 4;
-#pragma unroll
-	for (int q = 0; q < 6; q++) {
-		const f4 col[4] = { s[0][q], s[1][q], s[2][q], s[3][q] };
-		f4 y[6];
-		wino_g4(col, y);
-#pragma unroll
-		for (int r = 0; r < 6; r++) *(float4*)(dst + (long)(r * 6 + q) * plane) = y[r];
+	if (COLSUM) {
+		red[threadIdx.x] = (float4)sum;
+		__syncthreads();
+		if ((int)threadIdx.x < g.C4) { // 256 % C4 == 0 and block bases are multiples of 256: thread k4 owns channel group k4
+			f4 acc(0.f, 0.f, 0.f, 0.f);
+			for (int j = threadIdx.x; j < 256; j += g.C4) acc = acc + f4(red[j]);
+			*(float4*)(blockpart + ((long)blockIdx.x * g.C4 + threadIdx.x) * 4) = (float4)acc;
+		}
 	}
 }
 
