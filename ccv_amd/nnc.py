@@ -48,6 +48,22 @@ CMD = dict(
     SGD_FORWARD=0xe650ad26,
     SOFTMAX_CROSSENTROPY_FORWARD=0xc26b7b5e, SOFTMAX_CROSSENTROPY_BACKWARD=0xc26b7b5f,
     TRANSPOSE_FORWARD=0xb4d506e0, TRANSPOSE_BACKWARD=0xb4d506e1,
+    # element-wise / optimizer / loss rows of SURVEY.md section 8(f).1
+    ADAM_FORWARD=0xe30099dc, ADAM_BACKWARD=0xe30099dd, ADAMW_FORWARD=0x4f5d4870, ADAMW_BACKWARD=0x4f5d4871,
+    ARGMAX_FORWARD=0x68af2804, ARGMAX_BACKWARD=0x68af2805, ARGMIN_FORWARD=0xeb8747f2, ARGMIN_BACKWARD=0xeb8747f3,
+    BINARY_CROSSENTROPY_FORWARD=0xcd2107ec, BINARY_CROSSENTROPY_BACKWARD=0xcd2107ed,
+    CATEGORICAL_CROSSENTROPY_FORWARD=0x1eb327a2, CATEGORICAL_CROSSENTROPY_BACKWARD=0x1eb327a3,
+    GELU_FORWARD=0xb1527ab8, GELU_BACKWARD=0xb1527ab9, INDEX_SELECT_FORWARD=0x7ee7771e,
+    INDEX_SELECT_BACKWARD=0x7ee7771f, LAMB_FORWARD=0x450edb1a, LAMB_BACKWARD=0x450edb1b,
+    LEAKY_RELU_FORWARD=0x507144e0, LEAKY_RELU_BACKWARD=0x507144e1, MAX_FORWARD=0xdf6f014c, MAX_BACKWARD=0xdf6f014d,
+    MIN_FORWARD=0x972fbd26, MIN_BACKWARD=0x972fbd27, MSE_FORWARD=0x6904a9a2, MSE_BACKWARD=0x6904a9a3,
+    PAD_FORWARD=0xd8aaca60, PAD_BACKWARD=0xd8aaca61, REDUCE_MAX_FORWARD=0x80f1a506, REDUCE_MAX_BACKWARD=0x80f1a507,
+    REDUCE_MIN_FORWARD=0x6785ef96, REDUCE_MIN_BACKWARD=0x6785ef97, REDUCE_NORM2_FORWARD=0xb3034e16,
+    REDUCE_NORM2_BACKWARD=0xb3034e17, RMSPROP_FORWARD=0x9c886b1c, RMSPROP_BACKWARD=0x9c886b1d,
+    SIGMOID_FORWARD=0xf2f69650, SIGMOID_BACKWARD=0xf2f69651, SIGMOID_BINARY_CROSSENTROPY_FORWARD=0xd9e0e4a,
+    SIGMOID_BINARY_CROSSENTROPY_BACKWARD=0xd9e0e4b, SMOOTH_L1_FORWARD=0x4e428e, SMOOTH_L1_BACKWARD=0x4e428f,
+    SOFTMAX_FORWARD=0xc969a252, SOFTMAX_BACKWARD=0xc969a253, SWISH_FORWARD=0x583d90c2, SWISH_BACKWARD=0x583d90c3,
+    TANH_FORWARD=0x6a62be30, TANH_BACKWARD=0x6a62be31, UPSAMPLE_FORWARD=0x73875556, UPSAMPLE_BACKWARD=0x73875557,
 )
 
 _DT_NP = {CCV_32F: np.float32, CCV_32S: np.int32, CCV_64F: np.float64, CCV_16F: np.float16, CCV_8U: np.uint8, CCV_64S: np.int64}
@@ -104,9 +120,26 @@ class _Clamp(C.Structure):
     _fields_ = [("min", C.c_float), ("max", C.c_float)]
 
 
+class _Gelu(C.Structure):
+    _fields_ = [("tanh", C.c_int)]
+
+
+class _LeakyRelu(C.Structure):
+    _fields_ = [("negative_slope", C.c_float)]
+
+
+class _Adam(C.Structure):
+    _fields_ = [("step", C.c_int), ("rate", C.c_float), ("scale", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("decay", C.c_float), ("epsilon", C.c_float), ("amsgrad", C.c_int)]
+
+
+class _Rmsprop(C.Structure):
+    _fields_ = [("rate", C.c_float), ("scale", C.c_float), ("decay", C.c_float), ("alpha", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float)]
+
+
 class _CmdUnion(C.Union):
     _fields_ = [("convolution", _Conv), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
-                ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+                ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
+                ("adam", _Adam), ("rmsprop", _Rmsprop), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
 
 class CmdParam(C.Structure):
@@ -263,6 +296,31 @@ def CMD_REDUCE_SUM_FORWARD(*axis): return _reduce("REDUCE_SUM_FORWARD", *axis)
 def CMD_REDUCE_SUM_BACKWARD(*axis): return _reduce("REDUCE_SUM_BACKWARD", *axis)
 def CMD_REDUCE_MEAN_FORWARD(*axis): return _reduce("REDUCE_MEAN_FORWARD", *axis)
 def CMD_REDUCE_MEAN_BACKWARD(*axis): return _reduce("REDUCE_MEAN_BACKWARD", *axis)
+
+
+def CMD_GELU_FORWARD(tanh=0):
+    c = _cmd("GELU_FORWARD", (0, 0, 0)); c.info.gelu.tanh = tanh; return c
+def CMD_GELU_BACKWARD(tanh=0):
+    c = _cmd("GELU_BACKWARD", (0, 0, 0)); c.info.gelu.tanh = tanh; return c
+def CMD_LEAKY_RELU_FORWARD(slope):
+    c = _cmd("LEAKY_RELU_FORWARD", (0, 0, 0)); c.info.leaky_relu.negative_slope = slope; return c
+def CMD_LEAKY_RELU_BACKWARD(slope):
+    c = _cmd("LEAKY_RELU_BACKWARD", (0, 0, 0)); c.info.leaky_relu.negative_slope = slope; return c
+
+
+def CMD_ADAM_FORWARD(step, rate, beta1, beta2, decay, epsilon, amsgrad=0, scale=1.0, decoupled=False):
+    """CMD_ADAM_FORWARD / CMD_ADAMW_FORWARD(step, rate, beta1, beta2, decay, epsilon, amsgrad) (ccv_nnc_easy.h macro order; scale = 1)."""
+    c = _cmd("ADAMW_FORWARD" if decoupled else "ADAM_FORWARD", (0, 0, 0))
+    a = c.info.adam
+    a.step, a.rate, a.scale, a.beta1, a.beta2, a.decay, a.epsilon, a.amsgrad = step, rate, scale, beta1, beta2, decay, epsilon, amsgrad
+    return c
+
+
+def CMD_RMSPROP_FORWARD(rate, decay, alpha, momentum, epsilon, scale=1.0):
+    c = _cmd("RMSPROP_FORWARD", (0, 0, 0))
+    r = c.info.rmsprop
+    r.rate, r.scale, r.decay, r.alpha, r.momentum, r.epsilon = rate, scale, decay, alpha, momentum, epsilon
+    return c
 
 
 def generic_cmd(name, size=(0, 0, 0)):

@@ -98,6 +98,31 @@ enum {
 	CCV_NNC_SGD_FORWARD = 0xe650ad26, CCV_NNC_SGD_BACKWARD = 0xe650ad27,
 	CCV_NNC_SOFTMAX_CROSSENTROPY_FORWARD = 0xc26b7b5e, CCV_NNC_SOFTMAX_CROSSENTROPY_BACKWARD = 0xc26b7b5f,
 	CCV_NNC_TRANSPOSE_FORWARD = 0xb4d506e0, CCV_NNC_TRANSPOSE_BACKWARD = 0xb4d506e1,
+	CCV_NNC_ADAM_FORWARD = 0xe30099dc, CCV_NNC_ADAM_BACKWARD = 0xe30099dd,
+	CCV_NNC_ADAMW_FORWARD = 0x4f5d4870, CCV_NNC_ADAMW_BACKWARD = 0x4f5d4871,
+	CCV_NNC_ARGMAX_FORWARD = 0x68af2804, CCV_NNC_ARGMAX_BACKWARD = 0x68af2805,
+	CCV_NNC_ARGMIN_FORWARD = 0xeb8747f2, CCV_NNC_ARGMIN_BACKWARD = 0xeb8747f3,
+	CCV_NNC_BINARY_CROSSENTROPY_FORWARD = 0xcd2107ec, CCV_NNC_BINARY_CROSSENTROPY_BACKWARD = 0xcd2107ed,
+	CCV_NNC_CATEGORICAL_CROSSENTROPY_FORWARD = 0x1eb327a2, CCV_NNC_CATEGORICAL_CROSSENTROPY_BACKWARD = 0x1eb327a3,
+	CCV_NNC_GELU_FORWARD = 0xb1527ab8, CCV_NNC_GELU_BACKWARD = 0xb1527ab9,
+	CCV_NNC_INDEX_SELECT_FORWARD = 0x7ee7771e, CCV_NNC_INDEX_SELECT_BACKWARD = 0x7ee7771f,
+	CCV_NNC_LAMB_FORWARD = 0x450edb1a, CCV_NNC_LAMB_BACKWARD = 0x450edb1b,
+	CCV_NNC_LEAKY_RELU_FORWARD = 0x507144e0, CCV_NNC_LEAKY_RELU_BACKWARD = 0x507144e1,
+	CCV_NNC_MAX_FORWARD = 0xdf6f014c, CCV_NNC_MAX_BACKWARD = 0xdf6f014d,
+	CCV_NNC_MIN_FORWARD = 0x972fbd26, CCV_NNC_MIN_BACKWARD = 0x972fbd27,
+	CCV_NNC_MSE_FORWARD = 0x6904a9a2, CCV_NNC_MSE_BACKWARD = 0x6904a9a3,
+	CCV_NNC_PAD_FORWARD = 0xd8aaca60, CCV_NNC_PAD_BACKWARD = 0xd8aaca61,
+	CCV_NNC_REDUCE_MAX_FORWARD = 0x80f1a506, CCV_NNC_REDUCE_MAX_BACKWARD = 0x80f1a507,
+	CCV_NNC_REDUCE_MIN_FORWARD = 0x6785ef96, CCV_NNC_REDUCE_MIN_BACKWARD = 0x6785ef97,
+	CCV_NNC_REDUCE_NORM2_FORWARD = 0xb3034e16, CCV_NNC_REDUCE_NORM2_BACKWARD = 0xb3034e17,
+	CCV_NNC_RMSPROP_FORWARD = 0x9c886b1c, CCV_NNC_RMSPROP_BACKWARD = 0x9c886b1d,
+	CCV_NNC_SIGMOID_FORWARD = 0xf2f69650, CCV_NNC_SIGMOID_BACKWARD = 0xf2f69651,
+	CCV_NNC_SIGMOID_BINARY_CROSSENTROPY_FORWARD = 0xd9e0e4a, CCV_NNC_SIGMOID_BINARY_CROSSENTROPY_BACKWARD = 0xd9e0e4b,
+	CCV_NNC_SMOOTH_L1_FORWARD = 0x4e428e, CCV_NNC_SMOOTH_L1_BACKWARD = 0x4e428f,
+	CCV_NNC_SOFTMAX_FORWARD = 0xc969a252, CCV_NNC_SOFTMAX_BACKWARD = 0xc969a253,
+	CCV_NNC_SWISH_FORWARD = 0x583d90c2, CCV_NNC_SWISH_BACKWARD = 0x583d90c3,
+	CCV_NNC_TANH_FORWARD = 0x6a62be30, CCV_NNC_TANH_BACKWARD = 0x6a62be31,
+	CCV_NNC_UPSAMPLE_FORWARD = 0x73875556, CCV_NNC_UPSAMPLE_BACKWARD = 0x73875557,
 };
 
 /* Backend slot ids (lib/nnc/cmd/ccv_nnc_backend.h). */
@@ -176,6 +201,10 @@ typedef struct { /* 120 bytes */
 		struct { int axis[2]; } transpose;
 		struct { float p; int entirety; } dropout;
 		struct { float min; float max; } clamp;
+		struct { int tanh; } gelu;
+		struct { float negative_slope; } leaky_relu;
+		struct { int step; float rate; float scale; float beta1; float beta2; float decay; float epsilon; int amsgrad; } adam;
+		struct { float rate; float scale; float decay; float alpha; float momentum; float epsilon; } rmsprop;
 		char _widest[68]; /* gnorm is the widest member in the reference (68 B) */
 		void* userdata;
 	};
