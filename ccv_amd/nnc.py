@@ -136,10 +136,18 @@ class _Rmsprop(C.Structure):
     _fields_ = [("rate", C.c_float), ("scale", C.c_float), ("decay", C.c_float), ("alpha", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float)]
 
 
+class _F1(C.Structure):   # binary_crossentropy.pos_weight / smooth_l1.beta
+    _fields_ = [("v", C.c_float)]
+
+
+class _I1(C.Structure):   # mse.reduce_op
+    _fields_ = [("v", C.c_int)]
+
+
 class _CmdUnion(C.Union):
     _fields_ = [("convolution", _Conv), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
                 ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
-                ("adam", _Adam), ("rmsprop", _Rmsprop), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
 
 class CmdParam(C.Structure):
@@ -321,6 +329,22 @@ def CMD_RMSPROP_FORWARD(rate, decay, alpha, momentum, epsilon, scale=1.0):
     r = c.info.rmsprop
     r.rate, r.scale, r.decay, r.alpha, r.momentum, r.epsilon = rate, scale, decay, alpha, momentum, epsilon
     return c
+
+
+def _f1(name, v):
+    c = _cmd(name, (0, 0, 0)); c.info.f1.v = v; return c
+def CMD_MSE_FORWARD(reduce_op=0):     # 0 = CCV_NNC_MSE_REDUCE_MEAN, 1 = CCV_NNC_MSE_REDUCE_SUM
+    c = _cmd("MSE_FORWARD", (0, 0, 0)); c.info.i1.v = reduce_op; return c
+def CMD_MSE_BACKWARD(reduce_op=0):
+    c = _cmd("MSE_BACKWARD", (0, 0, 0)); c.info.i1.v = reduce_op; return c
+def CMD_SMOOTH_L1_FORWARD(beta): return _f1("SMOOTH_L1_FORWARD", beta)
+def CMD_SMOOTH_L1_BACKWARD(beta): return _f1("SMOOTH_L1_BACKWARD", beta)
+def CMD_BINARY_CROSSENTROPY_FORWARD(pos_weight=1.0): return _f1("BINARY_CROSSENTROPY_FORWARD", pos_weight)
+def CMD_BINARY_CROSSENTROPY_BACKWARD(pos_weight=1.0): return _f1("BINARY_CROSSENTROPY_BACKWARD", pos_weight)
+def CMD_CATEGORICAL_CROSSENTROPY_FORWARD(trim0=0.0, trim1=1.0):
+    c = _cmd("CATEGORICAL_CROSSENTROPY_FORWARD", (0, 0, 0)); c.info.label_smoothing.trim0, c.info.label_smoothing.trim1 = trim0, trim1; return c
+def CMD_CATEGORICAL_CROSSENTROPY_BACKWARD(trim0=0.0, trim1=1.0):
+    c = _cmd("CATEGORICAL_CROSSENTROPY_BACKWARD", (0, 0, 0)); c.info.label_smoothing.trim0, c.info.label_smoothing.trim1 = trim0, trim1; return c
 
 
 def generic_cmd(name, size=(0, 0, 0)):

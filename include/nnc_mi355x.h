@@ -202,6 +202,9 @@ typedef struct { /* 120 bytes */
 		struct { float p; int entirety; } dropout;
 		struct { float min; float max; } clamp;
 		struct { int tanh; } gelu;
+		struct { float pos_weight; } binary_crossentropy;
+		struct { float beta; } smooth_l1;
+		struct { int reduce_op; } mse;
 		struct { float negative_slope; } leaky_relu;
 		struct { int step; float rate; float scale; float beta1; float beta2; float decay; float epsilon; int amsgrad; } adam;
 		struct { float rate; float scale; float decay; float alpha; float momentum; float epsilon; } rmsprop;

@@ -72,3 +72,86 @@ def test_rmsprop(backend, ref_lib, shape):
     got, want = exec_pair(backend, ref_lib, cmd, nnc.NO_HINT, 0, [g, a, m, v], [np.zeros_like(a) for _ in range(3)])
     for x, y in zip(got, want):
         np.testing.assert_allclose(x, y, rtol=2e-6, atol=1e-8)
+
+
+# ---- row losses (ccv_amd/csrc/cmd_loss2.cpp) -----------------------------------------------------------------------------------
+LOSS_SHAPES = [(6, 10), (3, 1000), (17,)]
+
+
+def _rows(shape):
+    return (shape[0],) if len(shape) > 1 else (1,)
+
+
+@pytest.mark.parametrize("shape", LOSS_SHAPES)
+@pytest.mark.parametrize("reduce_op", [0, 1])
+def test_mse(backend, ref_lib, shape, reduce_op):
+    a, b, g = _x(shape, 1, 1.0), _x(shape, 2, 1.0), _x(_rows(shape), 3, 1.0)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_MSE_FORWARD(reduce_op), nnc.NO_HINT, 0, [a, b], [np.zeros(_rows(shape), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-7)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_MSE_BACKWARD(reduce_op), nnc.NO_HINT, 0, [g, a, b], [np.zeros_like(a), np.zeros_like(a)])
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-7)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_MSE_BACKWARD(reduce_op), nnc.NO_HINT, 0, [None, a, b], [np.zeros_like(a)])  # no incoming gradient, ha only
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", LOSS_SHAPES)
+@pytest.mark.parametrize("beta", [0.5, 300.0])   # rows on either side of the L1-sum threshold
+def test_smooth_l1(backend, ref_lib, shape, beta):
+    a, b, g = _x(shape, 4, 1.0), _x(shape, 5, 1.0), _x(_rows(shape), 6, 1.0)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_SMOOTH_L1_FORWARD(beta), nnc.NO_HINT, 0, [a, b], [np.zeros(_rows(shape), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-7)
+    c = want[0]
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_SMOOTH_L1_BACKWARD(beta), nnc.NO_HINT, 0, [g, a, b, c], [np.zeros_like(a)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", LOSS_SHAPES)
+@pytest.mark.parametrize("pos_weight", [1.0, 2.5])
+def test_binary_crossentropy(backend, ref_lib, shape, pos_weight):
+    rng = np.random.default_rng(7)
+    a = (rng.random(shape, dtype=F) * 0.98 + 0.01).astype(F)
+    b = (rng.random(shape) < 0.4).astype(F)
+    g = _x(_rows(shape), 8, 1.0)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_BINARY_CROSSENTROPY_FORWARD(pos_weight), nnc.NO_HINT, 0, [a, b], [np.zeros(_rows(shape), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=2e-5, atol=1e-6)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_BINARY_CROSSENTROPY_BACKWARD(pos_weight), nnc.NO_HINT, 0, [g, a, b], [np.zeros_like(a)])
+    np.testing.assert_allclose(got[0], want[0], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("label_kind", ["f32", "i32", "dense"])
+@pytest.mark.parametrize("trim", [(0.0, 1.0), (0.1, 0.9)])
+def test_categorical_crossentropy(backend, ref_lib, label_kind, trim):
+    rng = np.random.default_rng(9)
+    n, c = 6, 50
+    a = rng.random((n, c), dtype=F) + 0.05
+    a = (a / a.sum(axis=1, keepdims=True)).astype(F)
+    idx = rng.integers(0, c, n)
+    if label_kind == "dense":
+        if trim != (0.0, 1.0):
+            pytest.skip("dense labels carry their own smoothing")
+        label = rng.random((n, c), dtype=F)
+        label = (label / label.sum(axis=1, keepdims=True)).astype(F)
+    else:
+        label = idx.astype(F if label_kind == "f32" else np.int32)
+    g = _x((n,), 10, 1.0)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_CATEGORICAL_CROSSENTROPY_FORWARD(*trim), nnc.NO_HINT, 0, [a, label], [np.zeros((n,), F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=2e-5, atol=1e-6)
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_CATEGORICAL_CROSSENTROPY_BACKWARD(*trim), nnc.NO_HINT, 0, [g, a, label], [np.zeros_like(a)])
+    np.testing.assert_allclose(got[0], want[0], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", LOSS_SHAPES)
+@pytest.mark.parametrize("pos_weight", [1.0, 2.5])
+def test_sigmoid_binary_crossentropy(backend, ref_lib, shape, pos_weight):
+    rng = np.random.default_rng(12)
+    a, b, g = _x(shape, 13, 3.0), (rng.random(shape) < 0.4).astype(F), _x(_rows(shape), 14, 1.0)
+    fwd, bwd = nnc._f1("SIGMOID_BINARY_CROSSENTROPY_FORWARD", pos_weight), nnc._f1("SIGMOID_BINARY_CROSSENTROPY_BACKWARD", pos_weight)
+    got, want = exec_pair(backend, ref_lib, fwd, nnc.NO_HINT, 0, [a, b], [np.zeros(_rows(shape), F), np.zeros_like(a)])
+    np.testing.assert_allclose(got[0], want[0], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got[1], want[1], rtol=2e-6, atol=1e-7)
+    got, want = exec_pair(backend, ref_lib, fwd, nnc.NO_HINT, 0, [a, b], [None, np.zeros_like(a)])   # "no loss": the sigmoid only
+    np.testing.assert_allclose(got[1], want[1], rtol=2e-6, atol=1e-7)
+    d = want[1]
+    got, want = exec_pair(backend, ref_lib, bwd, nnc.NO_HINT, 0, [g, None, None, b, None, d], [np.zeros_like(a)])
+    np.testing.assert_allclose(got[0], want[0], rtol=2e-5, atol=1e-6)
