@@ -493,7 +493,7 @@ void nnc_mi355x_event_free(void* event) { HIP_ENFORCE(hipEventDestroy((hipEvent_
 const char* nnc_mi355x_last_kernel_name(void) { return tl_last_kernel; }
 void nnc_mi355x_debug_force_tile(int wm, int wn)
 {
-	const bool known = (wm == 2 && wn == 2) || (wm == 2 && wn == 1) || (wm == 1 && wn == 2);
+	const bool known = (wm == 2 && wn == 2) || (wm == 2 && wn == 1) || (wm == 1 && wn == 2) || (wm == 1 && wn == 1);
 	nnc::g_force_tile = known ? (wm | wn << 8) : 0;
 }
 

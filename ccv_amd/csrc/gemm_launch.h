@@ -31,8 +31,8 @@ static inline int gemm_auto_splits(long tiles, int K)
 inline size_t gemm_workspace_bound(long M, long N, long K)
 {
 	size_t worst = 0;
-	static const int shapes[3][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 } };
-	for (int i = 0; i < 3; i++) {
+	static const int shapes[4][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 }, { 1, 1 } };
+	for (int i = 0; i < 4; i++) {
 		const long tiles = ((M + 64 * shapes[i][0] - 1) / (64 * shapes[i][0])) * ((N + 64 * shapes[i][1] - 1) / (64 * shapes[i][1]));
 		int s = gemm_auto_splits(tiles, (int)(K > 0x7fffffffL ? 0x7fffffffL : K));
 		if (s > 1) s = ((s < 8 ? 8 : s) + 7) & ~7;
@@ -46,14 +46,14 @@ inline size_t gemm_workspace_bound(long M, long N, long K)
 // narrower tile keeps the MFMA pipe on useful work.  Score = useful / issued work x a mild preference for big tiles.
 static inline void gemm_pick_tile(const int M, const int N, int* wm, int* wn)
 {
-	static const int shapes[3][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 } };
-	static const double eff[3] = { 1.0, 0.93, 0.93 };
+	static const int shapes[4][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 }, { 1, 1 } };
+	static const double eff[4] = { 1.0, 0.93, 0.93, 0.8 }; // 64 x 64: both outputs 64 channels (the Winograd filter gradient of conv1_2)
 	if (g_force_tile) { *wm = g_force_tile & 0xff; *wn = g_force_tile >> 8; return; }
 	// 256 x 128 / 128 x 256 tiles (WM, WN = 4, 2 / 2, 4: one workgroup per CU) were measured on the whole VGG-D step: 4x2
 	// 108 vs 127 TFLOP/s and 2x4 121 vs 127 for the 128 x 128 tile on the same layers (profiles/r01_v6_bigtile_bench.json),
 	// although an isolated probe of one layer had them 4 % ahead; the kernel template still supports them (tools/kprobe.cpp).
 	double best = -1;
-	for (int i = 0; i < 3; i++) {
+	for (int i = 0; i < 4; i++) {
 		const long bm = 64 * shapes[i][0], bn = 64 * shapes[i][1];
 		const double padded = (double)((M + bm - 1) / bm * bm) * (double)((N + bn - 1) / bn * bn);
 		const double score = (double)M * N / padded * eff[i];
@@ -124,6 +124,7 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	gemm_pick_tile(M, N, &wm, &wn);
 	if (wm == 2 && wn == 2) return gemm_run_tile<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	if (wm == 2) return gemm_run_tile<LA, LB, 2, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+	if (wn == 1) return gemm_run_tile<LA, LB, 1, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	return gemm_run_tile<LA, LB, 1, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 }
 

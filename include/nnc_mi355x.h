@@ -352,7 +352,7 @@ void nnc_mi355x_profile_enable(int on);
 int  nnc_mi355x_profile_count(void);
 int  nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5]);
 /* Test hook: force the contraction block tile to (64*wm) x (64*wn) for every later conv / GEMM launch of the process
- * ((2,2) (2,1) (1,2) exist); (0,0) restores the built-in choice.  Used by the parity tests to cover every
+ * ((2,2) (2,1) (1,2) (1,1) exist); (0,0) restores the built-in choice.  Used by the parity tests to cover every
  * tile shape on every loader at sizes the oracle finishes. */
 void nnc_mi355x_debug_force_tile(int wm, int wn);
 /* Name of the device kernel the last command on this thread launched for its dominant work

@@ -77,7 +77,7 @@ def test_conv_backward(backend, ref_lib, case, flags):
         np.testing.assert_allclose(got[2], want[2], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("tile", [(2, 2), (2, 1), (1, 2)])
+@pytest.mark.parametrize("tile", [(2, 2), (2, 1), (1, 2), (1, 1)])
 @pytest.mark.parametrize("idx", [1, 6, 7])
 def test_conv_every_block_tile(backend, ref_lib, tile, idx):
     """The launcher picks the block tile from the problem size; force each shape over forward, dgrad and wgrad (incl.
