@@ -138,12 +138,21 @@ def main():
         dt = float(t.item())
     loss = float(net.loss.numpy().mean())
 
-    # roofline leg: one more step with every contraction launch bracketed by HIP events on its stream
+    # roofline leg: three more steps with every contraction launch bracketed by HIP events on its stream; per launch position
+    # the MEDIAN of the three (one stalled launch -- an allocator call, a clock dip -- would otherwise skew a kernel's average)
+    LEG = 3
     L.profile_enable(1)
-    step()
+    for _ in range(LEG):
+        step()
     L.stream_wait(stream)
-    recs = L.profile_records()
+    allrecs = L.profile_records()
     L.profile_enable(0)
+    per = len(allrecs) // LEG
+    recs = []
+    for i in range(per):
+        trio = [allrecs[j * per + i] for j in range(LEG)]
+        assert all(t[0] == trio[0][0] and t[4] == trio[0][4] for t in trio), "launch sequence differs between steps"
+        recs.append(sorted(trio, key=lambda t: t[3])[LEG // 2])
     if args.records and rank == 0:
         with open(args.records, "w") as f:
             for name, fl, _by, ms, dims in recs:
