@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(256) bcast_map_kernel(F f, const float* a, con
 
 struct reduce_args_t { int od[4]; int rd[4]; long sx[4], sy[4], so[4]; }; // od: output extents; rd: extents of the reduced sub-space (1 where kept)
 
-template <class F>
+enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2, RED_NORM2 = 3 }; // NORM2: sum of f() then square root
+template <class F, int RED = RED_SUM>
 __global__ void __launch_bounds__(256) bcast_reduce_kernel(F f, const float* x, const float* y, float* out, const reduce_args_t m, const size_t n)
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -68,14 +69,17 @@ __global__ void __launch_bounds__(256) bcast_reduce_kernel(F f, const float* x, 
 		o[2] = (int)(r % m.od[2]); r /= m.od[2];
 		o[1] = (int)(r % m.od[1]); r /= m.od[1];
 		o[0] = (int)r;
-		float s = 0.f;
+		float s = RED == RED_MAX ? -INFINITY : RED == RED_MIN ? INFINITY : 0.f;
 		for (int j0 = 0; j0 < m.rd[0]; j0++) for (int j1 = 0; j1 < m.rd[1]; j1++) for (int j2 = 0; j2 < m.rd[2]; j2++) for (int j3 = 0; j3 < m.rd[3]; j3++) {
 			const int i0 = o[0] + j0, i1 = o[1] + j1, i2 = o[2] + j2, i3 = o[3] + j3; // a reduced axis has od == 1 -> o == 0
 			const float xv = x[i0 * m.sx[0] + i1 * m.sx[1] + i2 * m.sx[2] + i3 * m.sx[3]];
 			const float yv = y ? y[i0 * m.sy[0] + i1 * m.sy[1] + i2 * m.sy[2] + i3 * m.sy[3]] : 0.f;
-			s += f(xv, yv);
+			const float v = f(xv, yv);
+			if (RED == RED_MAX) s = v > s ? v : s;
+			else if (RED == RED_MIN) s = v < s ? v : s;
+			else s += v;
 		}
-		out[o[0] * m.so[0] + o[1] * m.so[1] + o[2] * m.so[2] + o[3] * m.so[3]] = s;
+		out[o[0] * m.so[0] + o[1] * m.so[1] + o[2] * m.so[2] + o[3] * m.so[3]] = RED == RED_NORM2 ? sqrtf(s) : s;
 	}
 }
 
@@ -120,7 +124,7 @@ static int bcast_map(F f, const ccv_nnc_tensor_t* a, const ccv_nnc_tensor_t* b, 
 
 // out[o] = sum_{reduced axes} f(x, y) over the FULL shape = the broadcast of x, y and out; x / y broadcast into it (stride 0
 // on their extent-1 axes), out has extent 1 exactly on the axes that are summed away.
-template <class F>
+template <class F, int RED = RED_SUM>
 static int bcast_reduce(F f, const ccv_nnc_tensor_t* x, const ccv_nnc_tensor_t* y, ccv_nnc_tensor_t* out, ccv_nnc_stream_context_t* ctx)
 {
 	shape4_t sx, sy, so;
@@ -137,7 +141,7 @@ static int bcast_reduce(F f, const ccv_nnc_tensor_t* x, const ccv_nnc_tensor_t* 
 	}
 	const size_t n = (size_t)m.od[0] * m.od[1] * m.od[2] * m.od[3];
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(bcast_reduce_kernel<F>), dim3(grid_for(n, 256)), dim3(256), 0, stream_of(ctx), f, (const float*)x->data.f32, y ? (const float*)y->data.f32 : 0, out->data.f32, m, n);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(bcast_reduce_kernel<F, RED>), dim3(grid_for(n, 256)), dim3(256), 0, stream_of(ctx), f, (const float*)x->data.f32, y ? (const float*)y->data.f32 : 0, out->data.f32, m, n);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -324,7 +328,155 @@ static int _clamp_back(EXEC_ARGS)
 	return bcast_map(f, outputs[0], inputs[2], outputs[0], stream_context);
 }
 
+// ---- REDUCE_MAX / MIN / NORM2, element-wise MIN / MAX, ARGMAX / ARGMIN --------------------------------
+//   reduce max/min  lib/nnc/cmd/reduce/ccv_nnc_reduce_max_cpu_ref.c, _min_: forward = extremum over the reduced axes; backward
+//                   (g, a, b) -> h = (a == b) ? g : 0 with b, g broadcast back (every position that ties receives the gradient); g absent = 1
+//   reduce norm2    lib/nnc/cmd/reduce/ccv_nnc_reduce_norm2_cpu_ref.c: b = sqrt(sum a^2); backward h = g a / b
+//   min / max       lib/nnc/cmd/compare/ccv_nnc_min_cpu_ref.c, _max_: c = min(a, b); backward (g, a, b) -> (ha, hb): the smaller
+//                   (larger) operand takes g, a tie gives g to both
+//   argmax / argmin lib/nnc/cmd/reduce/ccv_nnc_argmax_cpu_ref.c:16-80: index of the FIRST extremum along one axis, int32 or fp32
+struct FSquare { __device__ float operator()(float a, float) const { return a * a; } };
+struct FMin { __device__ float operator()(float a, float b) const { return a < b ? a : b; } };
+struct FMax { __device__ float operator()(float a, float b) const { return a > b ? a : b; } };
+
+static int _reduce_max_forw(EXEC_ARGS)
+{
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0] || !f32(inputs[0])) return CCV_NNC_EXEC_INVALID;
+	return bcast_reduce<FCopy, RED_MAX>(FCopy(), inputs[0], 0, outputs[0], stream_context);
+}
+static int _reduce_min_forw(EXEC_ARGS)
+{
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0] || !f32(inputs[0])) return CCV_NNC_EXEC_INVALID;
+	return bcast_reduce<FCopy, RED_MIN>(FCopy(), inputs[0], 0, outputs[0], stream_context);
+}
+static int _reduce_norm2_forw(EXEC_ARGS)
+{
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0] || !f32(inputs[0])) return CCV_NNC_EXEC_INVALID;
+	return bcast_reduce<FSquare, RED_NORM2>(FSquare(), inputs[0], 0, outputs[0], stream_context);
+}
+
+// h = f(g, a, b) over h's shape, every operand broadcast into it; g may be absent (= 1)
+struct map3_args_t { int d[4]; long sg[4], sa[4], sb[4], so[4]; };
+template <class F>
+__global__ void __launch_bounds__(256) bcast_map3_kernel(F f, const float* g, const float* a, const float* b, float* out, float* out2, const map3_args_t m, const size_t n)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+		size_t r = idx;
+		const int i3 = (int)(r % m.d[3]); r /= m.d[3];
+		const int i2 = (int)(r % m.d[2]); r /= m.d[2];
+		const int i1 = (int)(r % m.d[1]); r /= m.d[1];
+		const int i0 = (int)r;
+		const float gv = g ? g[i0 * m.sg[0] + i1 * m.sg[1] + i2 * m.sg[2] + i3 * m.sg[3]] : 1.f;
+		const float av = a[i0 * m.sa[0] + i1 * m.sa[1] + i2 * m.sa[2] + i3 * m.sa[3]];
+		const float bv = b[i0 * m.sb[0] + i1 * m.sb[1] + i2 * m.sb[2] + i3 * m.sb[3]];
+		const long o = i0 * m.so[0] + i1 * m.so[1] + i2 * m.so[2] + i3 * m.so[3];
+		float second;
+		const float first = f(gv, av, bv, second);
+		if (out) out[o] = first;
+		if (out2) out2[o] = second;
+	}
+}
+template <class F>
+static int bcast_map3(F f, const ccv_nnc_tensor_t* g, const ccv_nnc_tensor_t* a, const ccv_nnc_tensor_t* b, ccv_nnc_tensor_t* out, ccv_nnc_tensor_t* out2, ccv_nnc_stream_context_t* ctx)
+{
+	ccv_nnc_tensor_t* const ref = out ? out : out2;
+	if (!ref || !a || !b || !f32(g) || !f32(a) || !f32(b) || !f32(ref)) return CCV_NNC_EXEC_INVALID;
+	shape4_t so, sg, sa, sb, s2;
+	if (!shape4(ref, &so) || !shape4(a, &sa) || !shape4(b, &sb) || (g && !shape4(g, &sg))) return CCV_NNC_EXEC_INVALID;
+	if (out && out2) { if (!shape4(out2, &s2)) return CCV_NNC_EXEC_INVALID; for (int k = 0; k < 4; k++) if (s2.d[k] != so.d[k] || s2.s[k] != so.s[k]) return CCV_NNC_EXEC_INVALID; }
+	map3_args_t m;
+	for (int k = 0; k < 4; k++) {
+		m.d[k] = so.d[k];
+		if ((sa.d[k] != so.d[k] && sa.d[k] != 1) || (sb.d[k] != so.d[k] && sb.d[k] != 1) || (g && sg.d[k] != so.d[k] && sg.d[k] != 1)) return CCV_NNC_EXEC_INVALID;
+		m.sg[k] = g ? sg.s[k] : 0; m.sa[k] = sa.s[k]; m.sb[k] = sb.s[k]; m.so[k] = so.s[k];
+	}
+	const size_t n = (size_t)m.d[0] * m.d[1] * m.d[2] * m.d[3];
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(bcast_map3_kernel<F>), dim3(grid_for(n, 256)), dim3(256), 0, stream_of(ctx), f, g ? (const float*)g->data.f32 : 0, (const float*)a->data.f32, (const float*)b->data.f32,
+		out ? out->data.f32 : 0, out2 ? out2->data.f32 : 0, m, n);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+struct F3Select { __device__ float operator()(float g, float a, float b, float& second) const { second = 0.f; return a == b ? g : 0.f; } };
+struct F3Norm2Back { __device__ float operator()(float g, float a, float b, float& second) const { second = 0.f; return g * a / b; } };
+struct F3MinBack { __device__ float operator()(float g, float a, float b, float& second) const { second = a < b ? 0.f : g; return a > b ? 0.f : g; } };
+struct F3MaxBack { __device__ float operator()(float g, float a, float b, float& second) const { second = a > b ? 0.f : g; return a < b ? 0.f : g; } };
+
+static int _reduce_extremum_back(EXEC_ARGS)
+{ // (g, a, b) -> h
+	if (input_size < 3 || output_size < 1) return CCV_NNC_EXEC_INVALID;
+	return bcast_map3(F3Select(), inputs[0], inputs[1], inputs[2], outputs[0], 0, stream_context);
+}
+static int _reduce_norm2_back(EXEC_ARGS)
+{
+	if (input_size < 3 || output_size < 1) return CCV_NNC_EXEC_INVALID;
+	return bcast_map3(F3Norm2Back(), inputs[0], inputs[1], inputs[2], outputs[0], 0, stream_context);
+}
+static int _min_forw(EXEC_ARGS)
+{
+	if (input_size < 2 || output_size < 1 || !inputs[0] || !inputs[1] || !outputs[0] || !f32(inputs[0]) || !same_shape(inputs[0], inputs[1]) || !same_shape(inputs[0], outputs[0])) return CCV_NNC_EXEC_INVALID;
+	return bcast_map(FMin(), inputs[0], inputs[1], outputs[0], stream_context);
+}
+static int _max_forw(EXEC_ARGS)
+{
+	if (input_size < 2 || output_size < 1 || !inputs[0] || !inputs[1] || !outputs[0] || !f32(inputs[0]) || !same_shape(inputs[0], inputs[1]) || !same_shape(inputs[0], outputs[0])) return CCV_NNC_EXEC_INVALID;
+	return bcast_map(FMax(), inputs[0], inputs[1], outputs[0], stream_context);
+}
+static int _min_back(EXEC_ARGS)
+{ // (g, a, b) -> (ha, hb)
+	if (input_size < 3 || output_size < 1) return CCV_NNC_EXEC_INVALID;
+	return bcast_map3(F3MinBack(), inputs[0], inputs[1], inputs[2], outputs[0], output_size > 1 ? outputs[1] : 0, stream_context);
+}
+static int _max_back(EXEC_ARGS)
+{
+	if (input_size < 3 || output_size < 1) return CCV_NNC_EXEC_INVALID;
+	return bcast_map3(F3MaxBack(), inputs[0], inputs[1], inputs[2], outputs[0], output_size > 1 ? outputs[1] : 0, stream_context);
+}
+
+template <bool MAXIMUM, class OUT>
+__global__ void __launch_bounds__(256) argext_kernel(const float* a, OUT* b, const int before, const int axis_dim, const int after)
+{
+	const size_t n = (size_t)before * after, stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+		const size_t i = idx / after, j = idx - i * after;
+		const float* const p = a + i * (size_t)axis_dim * after + j;
+		float best = p[0];
+		int at = 0;
+		for (int k = 1; k < axis_dim; k++) {
+			const float v = p[(size_t)k * after];
+			if (MAXIMUM ? v > best : v < best) { best = v; at = k; }
+		}
+		b[idx] = (OUT)at;
+	}
+}
+template <bool MAXIMUM>
+static int argext(const ccv_nnc_cmd_t& cmd, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
+{
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0] || !tensor_contiguous(inputs[0]) || !tensor_contiguous(outputs[0]) || CCV_GET_DATA_TYPE(inputs[0]->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* a = inputs[0];
+	const int axis = cmd.info.reduce.axis[0], nd = tensor_nd(a->info.dim);
+	if (cmd.info.reduce.count != 1 || axis < 0 || axis >= nd) return CCV_NNC_EXEC_INVALID;
+	const int axis_dim = a->info.dim[axis];
+	long after = 1;
+	for (int i = axis + 1; i < nd; i++) after *= a->info.dim[i];
+	const size_t total = tensor_count(a->info);
+	if (axis_dim <= 0 || total == 0) return CCV_NNC_EXEC_SUCCESS;
+	const long before = (long)(total / axis_dim / after);
+	if (tensor_count(outputs[0]->info) != total / axis_dim) return CCV_NNC_EXEC_INVALID;
+	const int odt = CCV_GET_DATA_TYPE(outputs[0]->info.datatype);
+	const unsigned grid = grid_for((size_t)before * after, 256);
+	if (odt == CCV_32S) hipLaunchKernelGGL(HIP_KERNEL_NAME(argext_kernel<MAXIMUM, int>), dim3(grid), dim3(256), 0, stream_of(ctx), (const float*)a->data.f32, outputs[0]->data.i32, (int)before, axis_dim, (int)after);
+	else if (odt == CCV_32F) hipLaunchKernelGGL(HIP_KERNEL_NAME(argext_kernel<MAXIMUM, float>), dim3(grid), dim3(256), 0, stream_of(ctx), (const float*)a->data.f32, outputs[0]->data.f32, (int)before, axis_dim, (int)after);
+	else return CCV_NNC_EXEC_INVALID;
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+static int _argmax_forw(EXEC_ARGS) { return argext<true>(cmd, inputs, input_size, outputs, output_size, stream_context); }
+static int _argmin_forw(EXEC_ARGS) { return argext<false>(cmd, inputs, input_size, outputs, output_size, stream_context); }
+
 } // namespace
+
 
 #define NNC_REG(CMD, BACKEND, FORMATS, DATATYPES, MEMORY, EXEC) \
 	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
@@ -349,3 +501,13 @@ NNC_REG(CCV_NNC_EWSQRT_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, C
 NNC_REG(CCV_NNC_EWSQRT_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _ewsqrt_back)
 NNC_REG(CCV_NNC_CLAMP_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _clamp_forw)
 NNC_REG(CCV_NNC_CLAMP_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _clamp_back)
+/* REDUCE_MAX / REDUCE_MIN have no GPU row in the reference host's table (lib/nnc/cmd/ccv_nnc_cmd.inc:944-1075): their exec
+ * functions above are reachable through nnc_mi355x_cmd_exec only once a host registers them; not registered here. */
+NNC_REG(CCV_NNC_REDUCE_NORM2_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _reduce_norm2_forw)
+NNC_REG(CCV_NNC_REDUCE_NORM2_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _reduce_norm2_back)
+NNC_REG(CCV_NNC_MIN_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _min_forw)
+NNC_REG(CCV_NNC_MIN_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _min_back)
+NNC_REG(CCV_NNC_MAX_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _max_forw)
+NNC_REG(CCV_NNC_MAX_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _max_back)
+NNC_REG(CCV_NNC_ARGMAX_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _argmax_forw)
+NNC_REG(CCV_NNC_ARGMIN_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _argmin_forw)

@@ -155,3 +155,50 @@ def test_sigmoid_binary_crossentropy(backend, ref_lib, shape, pos_weight):
     d = want[1]
     got, want = exec_pair(backend, ref_lib, bwd, nnc.NO_HINT, 0, [g, None, None, b, None, d], [np.zeros_like(a)])
     np.testing.assert_allclose(got[0], want[0], rtol=2e-5, atol=1e-6)
+
+
+# ---- reduce norm2, element-wise min / max, argmax / argmin (ccv_amd/csrc/cmd_bcast.cpp) -----------------------------------------
+def _reduce_cmd(name, *axis):
+    c = nnc.generic_cmd(name)
+    for i, a in enumerate(axis):
+        c.info.reduce.axis[i] = a
+    c.info.reduce.count = len(axis)
+    return c
+
+
+@pytest.mark.parametrize("shape,axis", [((4, 5, 6), (1,)), ((3, 7), (0,)), ((2, 3, 4, 5), (0, 2)), ((6, 9), (0, 1))])
+def test_reduce_norm2(backend, ref_lib, shape, axis):
+    a = _x(shape, 21, 2.0)
+    oshape = tuple(1 if i in axis else d for i, d in enumerate(shape))
+    g = _x(oshape, 22, 1.0)
+    got, want = exec_pair(backend, ref_lib, _reduce_cmd("REDUCE_NORM2_FORWARD", *axis), nnc.NO_HINT, 0, [a], [np.zeros(oshape, F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-6)
+    b = want[0]
+    got, want = exec_pair(backend, ref_lib, _reduce_cmd("REDUCE_NORM2_BACKWARD", *axis), nnc.NO_HINT, 0, [g, a, b], [np.zeros_like(a)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-6)
+    got, want = exec_pair(backend, ref_lib, _reduce_cmd("REDUCE_NORM2_BACKWARD", *axis), nnc.NO_HINT, 0, [None, a, b], [np.zeros_like(a)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["MIN", "MAX"])
+@pytest.mark.parametrize("shape", [(7,), (4, 5, 6, 3)])
+def test_elementwise_min_max(backend, ref_lib, name, shape):
+    a, b, g = _x(shape, 23, 1.0), _x(shape, 24, 1.0), _x(shape, 25, 1.0)
+    b.flat[::5] = a.flat[::5]   # ties: the gradient goes to both
+    got, want = exec_pair(backend, ref_lib, nnc.generic_cmd(name + "_FORWARD"), nnc.NO_HINT, 0, [a, b], [np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0])
+    got, want = exec_pair(backend, ref_lib, nnc.generic_cmd(name + "_BACKWARD"), nnc.NO_HINT, 0, [g, a, b], [np.zeros_like(a), np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    got, want = exec_pair(backend, ref_lib, nnc.generic_cmd(name + "_BACKWARD"), nnc.NO_HINT, 0, [None, a, b], [np.zeros_like(a), np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("name", ["ARGMAX", "ARGMIN"])
+@pytest.mark.parametrize("shape,axis", [((5, 1000), 1), ((4, 6, 7), 1), ((9, 3), 0)])
+@pytest.mark.parametrize("odt", [np.int32, F])
+def test_argmax_argmin(backend, ref_lib, name, shape, axis, odt):
+    a = _x(shape, 26, 1.0)
+    a[tuple(0 for _ in shape)] = a.max() + 1 if name == "ARGMAX" else a.min() - 1
+    oshape = tuple(1 if i == axis else d for i, d in enumerate(shape))
+    got, want = exec_pair(backend, ref_lib, _reduce_cmd(name + "_FORWARD", axis), nnc.NO_HINT, 0, [a], [np.zeros(oshape, odt)])
+    assert np.array_equal(got[0], want[0])
