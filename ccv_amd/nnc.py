@@ -136,6 +136,10 @@ class _Rmsprop(C.Structure):
     _fields_ = [("rate", C.c_float), ("scale", C.c_float), ("decay", C.c_float), ("alpha", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float)]
 
 
+class _Pad(C.Structure):
+    _fields_ = [("type", C.c_int), ("end", C.c_int * MAX_DIM_ALLOC)]
+
+
 class _F1(C.Structure):   # binary_crossentropy.pos_weight / smooth_l1.beta
     _fields_ = [("v", C.c_float)]
 
@@ -147,7 +151,7 @@ class _I1(C.Structure):   # mse.reduce_op
 class _CmdUnion(C.Union):
     _fields_ = [("convolution", _Conv), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
                 ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
-                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
 
 class CmdParam(C.Structure):
@@ -345,6 +349,15 @@ def CMD_CATEGORICAL_CROSSENTROPY_FORWARD(trim0=0.0, trim1=1.0):
     c = _cmd("CATEGORICAL_CROSSENTROPY_FORWARD", (0, 0, 0)); c.info.label_smoothing.trim0, c.info.label_smoothing.trim1 = trim0, trim1; return c
 def CMD_CATEGORICAL_CROSSENTROPY_BACKWARD(trim0=0.0, trim1=1.0):
     c = _cmd("CATEGORICAL_CROSSENTROPY_BACKWARD", (0, 0, 0)); c.info.label_smoothing.trim0, c.info.label_smoothing.trim1 = trim0, trim1; return c
+
+
+def CMD_PAD(name, pad_type, begin, end):
+    """CMD_PAD_FORWARD(type, (begin...), (end...)): begin goes to info.size.dim, end to info.pad.end (ccv_nnc_easy.h)"""
+    c = _cmd(name, tuple(begin))
+    c.info.pad.type = pad_type
+    for i, e in enumerate(end):
+        c.info.pad.end[i] = e
+    return c
 
 
 def generic_cmd(name, size=(0, 0, 0)):

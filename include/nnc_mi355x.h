@@ -202,6 +202,7 @@ typedef struct { /* 120 bytes */
 		struct { float p; int entirety; } dropout;
 		struct { float min; float max; } clamp;
 		struct { int tanh; } gelu;
+		struct { int type; int end[CCV_NNC_MAX_DIM_ALLOC]; } pad;
 		struct { float pos_weight; } binary_crossentropy;
 		struct { float beta; } smooth_l1;
 		struct { int reduce_op; } mse;

@@ -202,3 +202,35 @@ def test_argmax_argmin(backend, ref_lib, name, shape, axis, odt):
     oshape = tuple(1 if i == axis else d for i, d in enumerate(shape))
     got, want = exec_pair(backend, ref_lib, _reduce_cmd(name + "_FORWARD", axis), nnc.NO_HINT, 0, [a], [np.zeros(oshape, odt)])
     assert np.array_equal(got[0], want[0])
+
+
+# ---- index select, pad (ccv_amd/csrc/cmd_index_pad.cpp) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(20, 16), (50,), (7, 130)])
+def test_index_select(backend, ref_lib, shape):
+    rng = np.random.default_rng(31)
+    a = _x(shape, 32, 1.0)
+    n = 11
+    idx = rng.integers(0, shape[0], n).astype(np.int32)
+    idx[3] = idx[7]   # repeated index: the scatter-add must accumulate
+    oshape = (n,) + tuple(shape[1:])
+    got, want = exec_pair(backend, ref_lib, nnc.generic_cmd("INDEX_SELECT_FORWARD"), nnc.NO_HINT, 0, [a, idx], [np.zeros(oshape, F)])
+    assert np.array_equal(got[0], want[0])
+    fidx = (rng.random(n) * (shape[0] - 1)).astype(F)   # fractional indices interpolate between neighbouring rows
+    got, want = exec_pair(backend, ref_lib, nnc.generic_cmd("INDEX_SELECT_FORWARD"), nnc.NO_HINT, 0, [a, fidx], [np.zeros(oshape, F)])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-6, atol=1e-7)
+    g = _x(oshape, 33, 1.0)
+    got, want = exec_pair(backend, ref_lib, nnc.generic_cmd("INDEX_SELECT_BACKWARD"), nnc.NO_HINT, 0, [g, None, idx], [np.full(shape, 5, F)])
+    assert np.array_equal(got[0], want[0])
+
+
+@pytest.mark.parametrize("pad_type", [0, 1])
+@pytest.mark.parametrize("shape,begin,end", [((5,), (2,), (3,)), ((3, 4), (1, 0), (0, 2)), ((2, 3, 4), (0, 1, 2), (1, 0, 1)), ((2, 3, 4, 5), (1, 1, 0, 2), (0, 2, 1, 1))])
+def test_pad(backend, ref_lib, pad_type, shape, begin, end):
+    a = _x(shape, 34, 1.0)
+    oshape = tuple(d + b + e for d, b, e in zip(shape, begin, end))
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_PAD("PAD_FORWARD", pad_type, begin, end), nnc.NO_HINT, 0, [a], [np.full(oshape, 9, F)])
+    assert np.array_equal(got[0], want[0])
+    if pad_type == 0:   # the reference's backward is the crop of the zero-pad (pad_cpu_ref.c:88-138)
+        g = _x(oshape, 35, 1.0)
+        got, want = exec_pair(backend, ref_lib, nnc.CMD_PAD("PAD_BACKWARD", pad_type, begin, end), nnc.NO_HINT, 0, [g], [np.zeros(shape, F)])
+        assert np.array_equal(got[0], want[0])
