@@ -49,6 +49,7 @@ CMD = dict(
     SOFTMAX_CROSSENTROPY_FORWARD=0xc26b7b5e, SOFTMAX_CROSSENTROPY_BACKWARD=0xc26b7b5f,
     TRANSPOSE_FORWARD=0xb4d506e0, TRANSPOSE_BACKWARD=0xb4d506e1,
     # element-wise / optimizer / loss rows of SURVEY.md section 8(f).1
+    LAYER_NORM_FORWARD=0xbed3c264, LAYER_NORM_BACKWARD=0xbed3c265, RMSNORM_FORWARD=0x6889e9d0, RMSNORM_BACKWARD=0x6889e9d1,
     ADAM_FORWARD=0xe30099dc, ADAM_BACKWARD=0xe30099dd, ADAMW_FORWARD=0x4f5d4870, ADAMW_BACKWARD=0x4f5d4871,
     ARGMAX_FORWARD=0x68af2804, ARGMAX_BACKWARD=0x68af2805, ARGMIN_FORWARD=0xeb8747f2, ARGMIN_BACKWARD=0xeb8747f3,
     BINARY_CROSSENTROPY_FORWARD=0xcd2107ec, BINARY_CROSSENTROPY_BACKWARD=0xcd2107ed,
@@ -136,6 +137,10 @@ class _Rmsprop(C.Structure):
     _fields_ = [("rate", C.c_float), ("scale", C.c_float), ("decay", C.c_float), ("alpha", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float)]
 
 
+class _Lnorm(C.Structure):
+    _fields_ = [("axis", C.c_int * MAX_DIM_ALLOC), ("count", C.c_int), ("epsilon", C.c_float), ("elementwise_affine", C.c_int)]
+
+
 class _Pad(C.Structure):
     _fields_ = [("type", C.c_int), ("end", C.c_int * MAX_DIM_ALLOC)]
 
@@ -151,7 +156,7 @@ class _I1(C.Structure):   # mse.reduce_op
 class _CmdUnion(C.Union):
     _fields_ = [("convolution", _Conv), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
                 ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
-                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("lnorm", _Lnorm), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
 
 class CmdParam(C.Structure):
@@ -349,6 +354,15 @@ def CMD_CATEGORICAL_CROSSENTROPY_FORWARD(trim0=0.0, trim1=1.0):
     c = _cmd("CATEGORICAL_CROSSENTROPY_FORWARD", (0, 0, 0)); c.info.label_smoothing.trim0, c.info.label_smoothing.trim1 = trim0, trim1; return c
 def CMD_CATEGORICAL_CROSSENTROPY_BACKWARD(trim0=0.0, trim1=1.0):
     c = _cmd("CATEGORICAL_CROSSENTROPY_BACKWARD", (0, 0, 0)); c.info.label_smoothing.trim0, c.info.label_smoothing.trim1 = trim0, trim1; return c
+
+
+def CMD_NORM(name, epsilon, affine, *axis):
+    """CMD_LAYER_NORM_*(epsilon, elementwise_affine, axis...) / CMD_RMSNORM_*(epsilon, axis...): rmsnorm shares lnorm's leading fields"""
+    c = _cmd(name, (0, 0, 0))
+    for i, a in enumerate(axis):
+        c.info.lnorm.axis[i] = a
+    c.info.lnorm.count, c.info.lnorm.epsilon, c.info.lnorm.elementwise_affine = len(axis), epsilon, affine
+    return c
 
 
 def CMD_PAD(name, pad_type, begin, end):

@@ -98,6 +98,9 @@ enum {
 	CCV_NNC_SGD_FORWARD = 0xe650ad26, CCV_NNC_SGD_BACKWARD = 0xe650ad27,
 	CCV_NNC_SOFTMAX_CROSSENTROPY_FORWARD = 0xc26b7b5e, CCV_NNC_SOFTMAX_CROSSENTROPY_BACKWARD = 0xc26b7b5f,
 	CCV_NNC_TRANSPOSE_FORWARD = 0xb4d506e0, CCV_NNC_TRANSPOSE_BACKWARD = 0xb4d506e1,
+	CCV_NNC_LAYER_NORM_FORWARD = 0xbed3c264, CCV_NNC_LAYER_NORM_BACKWARD = 0xbed3c265,
+	CCV_NNC_RMSNORM_FORWARD = 0x6889e9d0, CCV_NNC_RMSNORM_BACKWARD = 0x6889e9d1,
+	CCV_NNC_GROUP_NORM_FORWARD = 0x17deb074, CCV_NNC_GROUP_NORM_BACKWARD = 0x17deb075,
 	CCV_NNC_ADAM_FORWARD = 0xe30099dc, CCV_NNC_ADAM_BACKWARD = 0xe30099dd,
 	CCV_NNC_ADAMW_FORWARD = 0x4f5d4870, CCV_NNC_ADAMW_BACKWARD = 0x4f5d4871,
 	CCV_NNC_ARGMAX_FORWARD = 0x68af2804, CCV_NNC_ARGMAX_BACKWARD = 0x68af2805,
@@ -202,6 +205,8 @@ typedef struct { /* 120 bytes */
 		struct { float p; int entirety; } dropout;
 		struct { float min; float max; } clamp;
 		struct { int tanh; } gelu;
+		struct { int axis[CCV_NNC_MAX_DIM_ALLOC]; int count; float epsilon; int elementwise_affine; } lnorm;
+		struct { int axis[CCV_NNC_MAX_DIM_ALLOC]; int count; float epsilon; } rmsnorm;
 		struct { int type; int end[CCV_NNC_MAX_DIM_ALLOC]; } pad;
 		struct { float pos_weight; } binary_crossentropy;
 		struct { float beta; } smooth_l1;

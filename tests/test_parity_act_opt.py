@@ -234,3 +234,45 @@ def test_pad(backend, ref_lib, pad_type, shape, begin, end):
         g = _x(oshape, 35, 1.0)
         got, want = exec_pair(backend, ref_lib, nnc.CMD_PAD("PAD_BACKWARD", pad_type, begin, end), nnc.NO_HINT, 0, [g], [np.zeros(shape, F)])
         assert np.array_equal(got[0], want[0])
+
+
+# ---- layer norm / rms norm over the trailing axes (ccv_amd/csrc/cmd_rownorm.cpp) -------------------------------------------------------
+NORM_SHAPES = [((6, 40), (1,)), ((2, 5, 300), (2,)), ((3, 4, 5, 6), (2, 3)), ((4, 1030), (1,))]
+
+
+@pytest.mark.parametrize("shape,axis", NORM_SHAPES)
+@pytest.mark.parametrize("affine", [1, 0])
+def test_layer_norm(backend, ref_lib, shape, axis, affine):
+    a, g = _x(shape, 41, 2.0), _x(shape, 42, 1.0)
+    sshape = tuple(1 if i in axis else d for i, d in enumerate(shape))       # statistics: one per row
+    pshape = tuple(d if i in axis else 1 for i, d in enumerate(shape))       # scale / bias: one per normalised element
+    scale, bias = _x(pshape, 43, 1.0) + 1.5, _x(pshape, 44, 1.0)
+    ins = [a, scale, bias] if affine else [a]
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_NORM("LAYER_NORM_FORWARD", 1e-5, affine, *axis), nnc.NO_HINT, 0, ins, [np.zeros_like(a), np.zeros(sshape, F), np.zeros(sshape, F)])
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=2e-5, atol=2e-6)
+    mean, istd = want[1], want[2]
+    if affine:
+        bins = [g, None, None, a, scale, None, None, mean, istd]
+        outs = [np.zeros_like(a), np.zeros(pshape, F), np.zeros(pshape, F)]
+    else:
+        bins = [g, None, None, a, None, mean, istd]
+        outs = [np.zeros_like(a)]
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_NORM("LAYER_NORM_BACKWARD", 1e-5, affine, *axis), nnc.NO_HINT, 0, bins, outs)
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,axis", NORM_SHAPES)
+def test_rmsnorm(backend, ref_lib, shape, axis):
+    a, g = _x(shape, 45, 2.0), _x(shape, 46, 1.0)
+    sshape = tuple(1 if i in axis else d for i, d in enumerate(shape))
+    pshape = tuple(d if i in axis else 1 for i, d in enumerate(shape))
+    scale = _x(pshape, 47, 1.0) + 1.5
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_NORM("RMSNORM_FORWARD", 1e-5, 0, *axis), nnc.NO_HINT, 0, [a, scale], [np.zeros_like(a), np.zeros(sshape, F)])
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=2e-5, atol=2e-6)
+    istd = want[1]
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_NORM("RMSNORM_BACKWARD", 1e-5, 0, *axis), nnc.NO_HINT, 0, [g, None, a, scale, None, istd], [np.zeros_like(a), np.zeros(pshape, F)])
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-5)
