@@ -428,6 +428,49 @@ static int _dropout_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, con
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// ---- RANDOM_UNIFORM / RANDOM_NORMAL: parameter initialisation of every cnnp model on the device (ccv_cnnp_model init runs
+// CMD_RANDOM_UNIFORM_FORWARD on the weights, lib/nnc/ccv_cnnp_model_addons.c) ---------------------------------------------------------
+//   uniform  lib/nnc/cmd/rand/ccv_nnc_rand_uniform_cpu_ref.c:17-33   a = r u + (1 - r) l, r in (0, 1), l = blas.a[0], u = blas.a[1]
+//   normal   lib/nnc/cmd/rand/ccv_nnc_rand_normal_cpu_ref.c:17-45    Box-Muller pairs, std = blas.a[0], mean = blas.a[1]
+// Same counter-based generator as dropout, seeded per call from the stream's generator: parity with the reference is
+// statistical by construction (its tests check mean / range, test/int/nnc/random.tests.c).
+__device__ __forceinline__ float unit_open(const unsigned r) { return ((float)(r >> 8) + 0.5f) * (1.f / 16777216.f); } // (0, 1)
+__global__ void __launch_bounds__(EW_THREADS) random_uniform_kernel(float* a, const size_t n, const unsigned seed, const float l, const float u)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const float r = unit_open(mix32(mix32((unsigned)i ^ seed) + (unsigned)(i >> 32) + 0x9e3779b9U));
+		a[i] = r * u + (1.f - r) * l;
+	}
+}
+__global__ void __launch_bounds__(EW_THREADS) random_normal_kernel(float* a, const size_t n, const unsigned seed, const float std, const float mean)
+{
+	const size_t pairs = (n + 1) / 2, stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+		const unsigned h = mix32(mix32((unsigned)i ^ seed) + (unsigned)(i >> 32) + 0x9e3779b9U);
+		const float r0 = unit_open(h), r1 = unit_open(mix32(h ^ 0x85ebca6bU));
+		const float mag = std * sqrtf(-2.f * logf(r0));
+		a[2 * i] = mag * cosf(6.283185307179586f * r1) + mean;
+		if (2 * i + 1 < n) a[2 * i + 1] = mag * sinf(6.283185307179586f * r1) + mean;
+	}
+}
+static int _random_exec(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	const bool normal = cmd.cmd == CCV_NNC_RANDOM_NORMAL_FORWARD || cmd.cmd == CCV_NNC_RANDOM_NORMAL_BACKWARD;
+	for (int k = 0; k < output_size; k++) {
+		ccv_nnc_tensor_t* const a = outputs[k];
+		if (!a) continue;
+		if (!tensor_contiguous(a) || CCV_GET_DATA_TYPE(a->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
+		const size_t n = tensor_count(a->info);
+		if (n == 0) continue;
+		const unsigned seed = dropout_seed(stream_context);
+		if (normal) hipLaunchKernelGGL(random_normal_kernel, dim3(grid_for((n + 1) / 2, EW_THREADS)), dim3(EW_THREADS), 0, stream_of(stream_context), a->data.f32, n, seed, cmd.info.blas.a[0], cmd.info.blas.a[1]);
+		else hipLaunchKernelGGL(random_uniform_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream_of(stream_context), a->data.f32, n, seed, cmd.info.blas.a[0], cmd.info.blas.a[1]);
+		HIP_ENFORCE(hipGetLastError());
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 } // namespace
 
 namespace nnc {
@@ -481,3 +524,7 @@ NNC_REG(CCV_NNC_SET_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | C
 NNC_REG(CCV_NNC_SET_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_back)
 NNC_REG(CCV_NNC_DATA_TRANSFER_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
 NNC_REG(CCV_NNC_DATA_TRANSFER_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
+NNC_REG(CCV_NNC_RANDOM_UNIFORM_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _random_exec)
+NNC_REG(CCV_NNC_RANDOM_UNIFORM_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _random_exec)
+NNC_REG(CCV_NNC_RANDOM_NORMAL_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _random_exec)
+NNC_REG(CCV_NNC_RANDOM_NORMAL_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _random_exec)

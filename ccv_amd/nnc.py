@@ -49,6 +49,7 @@ CMD = dict(
     SOFTMAX_CROSSENTROPY_FORWARD=0xc26b7b5e, SOFTMAX_CROSSENTROPY_BACKWARD=0xc26b7b5f,
     TRANSPOSE_FORWARD=0xb4d506e0, TRANSPOSE_BACKWARD=0xb4d506e1,
     # element-wise / optimizer / loss rows of SURVEY.md section 8(f).1
+    RANDOM_UNIFORM_FORWARD=0xa0cd1d5e, RANDOM_NORMAL_FORWARD=0x7062c8b4,
     LAYER_NORM_FORWARD=0xbed3c264, LAYER_NORM_BACKWARD=0xbed3c265, RMSNORM_FORWARD=0x6889e9d0, RMSNORM_BACKWARD=0x6889e9d1,
     ADAM_FORWARD=0xe30099dc, ADAM_BACKWARD=0xe30099dd, ADAMW_FORWARD=0x4f5d4870, ADAMW_BACKWARD=0x4f5d4871,
     ARGMAX_FORWARD=0x68af2804, ARGMAX_BACKWARD=0x68af2805, ARGMIN_FORWARD=0xeb8747f2, ARGMIN_BACKWARD=0xeb8747f3,

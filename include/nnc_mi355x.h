@@ -98,6 +98,8 @@ enum {
 	CCV_NNC_SGD_FORWARD = 0xe650ad26, CCV_NNC_SGD_BACKWARD = 0xe650ad27,
 	CCV_NNC_SOFTMAX_CROSSENTROPY_FORWARD = 0xc26b7b5e, CCV_NNC_SOFTMAX_CROSSENTROPY_BACKWARD = 0xc26b7b5f,
 	CCV_NNC_TRANSPOSE_FORWARD = 0xb4d506e0, CCV_NNC_TRANSPOSE_BACKWARD = 0xb4d506e1,
+	CCV_NNC_RANDOM_UNIFORM_FORWARD = 0xa0cd1d5e, CCV_NNC_RANDOM_UNIFORM_BACKWARD = 0xa0cd1d5f,
+	CCV_NNC_RANDOM_NORMAL_FORWARD = 0x7062c8b4, CCV_NNC_RANDOM_NORMAL_BACKWARD = 0x7062c8b5,
 	CCV_NNC_LAYER_NORM_FORWARD = 0xbed3c264, CCV_NNC_LAYER_NORM_BACKWARD = 0xbed3c265,
 	CCV_NNC_RMSNORM_FORWARD = 0x6889e9d0, CCV_NNC_RMSNORM_BACKWARD = 0x6889e9d1,
 	CCV_NNC_GROUP_NORM_FORWARD = 0x17deb074, CCV_NNC_GROUP_NORM_BACKWARD = 0x17deb075,

@@ -276,3 +276,20 @@ def test_rmsnorm(backend, ref_lib, shape, axis):
     got, want = exec_pair(backend, ref_lib, nnc.CMD_NORM("RMSNORM_BACKWARD", 1e-5, 0, *axis), nnc.NO_HINT, 0, [g, None, a, scale, None, istd], [np.zeros_like(a), np.zeros(pshape, F)])
     for x, y in zip(got, want):
         np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-5)
+
+
+# ---- random fills (ccv_amd/csrc/cmd_ew.cpp): statistical parity, as the reference's own tests (test/int/nnc/random.tests.c) ---------------
+def test_random_uniform_and_normal(backend):
+    from harness import exec_on
+    n = 200000
+    r, out = exec_on(backend, nnc.GPU_MEMORY, nnc._blas_a("RANDOM_UNIFORM_FORWARD", -8.0, 4.0), nnc.NO_HINT, 0, [], [np.zeros(n, F)])
+    assert r == 0
+    u = out[0]
+    assert u.min() > -8 and u.max() < 4 and abs(u.mean() + 2.0) < 0.05 and abs(u.std() - 12 / np.sqrt(12)) < 0.05
+    assert len(np.unique(u)) > n * 0.95
+    r, out2 = exec_on(backend, nnc.GPU_MEMORY, nnc._blas_a("RANDOM_UNIFORM_FORWARD", -8.0, 4.0), nnc.NO_HINT, 0, [], [np.zeros(n, F)])
+    assert not np.array_equal(out2[0], u)   # a new seed per call
+    r, out = exec_on(backend, nnc.GPU_MEMORY, nnc._blas_a("RANDOM_NORMAL_FORWARD", 2.0, 1.0), nnc.NO_HINT, 0, [], [np.zeros(n + 1, F)])  # odd count: last pair half used
+    z = out[0]
+    assert r == 0 and abs(z.mean() - 1.0) < 0.03 and abs(z.std() - 2.0) < 0.03
+    assert abs(np.mean(((z - 1.0) / 2.0) ** 3)) < 0.05 and abs(np.mean(((z - 1.0) / 2.0) ** 4) - 3.0) < 0.15   # skewness, kurtosis

@@ -26,11 +26,11 @@ EXPECTED = _expected()
 QUICK = [(s, n) for s, n in EXPECTED if "convolution" not in n]
 
 
-def _run(flavor, suite, name, timeout):
+def _run(flavor, suite, name, timeout, env=None):
     b = os.path.join(R.BIN, "%s.%s" % (suite, flavor))
     if not os.path.exists(b):
         pytest.skip("%s not built (oracle/build_ref_host.sh needs /root/reference)" % os.path.basename(b))
-    status, detail = R.run_case(b, name, timeout)
+    status, detail = R.run_case(b, name, timeout, env)
     assert status == "PASS", "%s: %s %s" % (name, status, detail)
 
 
@@ -43,3 +43,20 @@ def test_reference_int_case_on_emulator(suite, name):
 @pytest.mark.parametrize("suite,name", EXPECTED, ids=[n for _, n in EXPECTED])
 def test_reference_int_case_on_gpu(suite, name):
     _run("gpu", suite, name, 180)
+
+
+def _multidev():
+    p = os.path.join(ROOT, "tests", "golden", "ref_int_expected_pass_multidev.txt")
+    return [tuple(l.rstrip("\n").split("\t", 1)) for l in open(p) if l.strip()] if os.path.exists(p) else []
+
+
+MULTIDEV = _multidev()
+
+
+@pytest.mark.parametrize("suite,name", MULTIDEV, ids=[n for _, n in MULTIDEV])
+def test_reference_multi_device_case_on_emulator(suite, name):
+    """The reference's multi-GPU tests -- nccl.tests.c (allreduce / broadcast / reduce, blocking and not), parallel.tests.c (its own
+    data-parallel graph transformation with all-reduce) and the multi-device dynamic-graph cases -- through the unmodified host,
+    on the emulator build with FOUR emulated devices and its in-process stand-in for RCCL: the single-process N-device form of
+    section 8(e), which the one-GPU box cannot run."""
+    _run("emu", suite, name, 300, env=dict(os.environ, NNC_EMU_DEVICE_COUNT="4", OMP_NUM_THREADS="4"))
