@@ -199,8 +199,10 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 {
 	if (a.sc != 1 || !pixel_linear(b) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
 	wino_plan_t wp;
-	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.OH, g.OW, g.C, g.K, &wp) && wino_images_ok(a, b, w, bias) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp, g.C, g.K)))
-		return conv_wino_run<false>("conv_fwd_wino", g, wp, a, w, bias, b, g.pby, g.pbx, flags, ctx);
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.OH, g.OW, g.C, g.K, &wp) && wino_images_ok(a, b, w, bias) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp, g.C, g.K))) {
+		const int r = conv_wino_run<false>("conv_fwd_wino", g, wp, a, w, bias, b, g.pby, g.pbx, flags, ctx);
+		if (r != CCV_NNC_EXEC_OOM) return r; // the transformed images did not fit the device: the implicit GEMM needs no such scratch
+	}
 	const long M = (long)g.N * g.OH * g.OW;
 	const int Kred = g.kh * g.kw * g.Cg;
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
@@ -230,8 +232,10 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 {
 	if (gr.sc != 1 || !pixel_linear(h) || !image_fits_int(gr)) return CCV_NNC_EXEC_INVALID;
 	wino_plan_t wp;
-	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wp) && wino_images_ok(gr, h, w, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp, g.K, g.C)))
-		return conv_wino_run<true>("conv_dgrad_wino", g, wp, gr, w, 0, h, 2 - g.pby, 2 - g.pbx, flags, ctx);
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wp) && wino_images_ok(gr, h, w, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp, g.K, g.C))) {
+		const int r = conv_wino_run<true>("conv_dgrad_wino", g, wp, gr, w, 0, h, 2 - g.pby, 2 - g.pbx, flags, ctx);
+		if (r != CCV_NNC_EXEC_OOM) return r;
+	}
 	const long M = (long)g.N * g.H * g.W;
 	const int Kred = g.kh * g.kw * g.Kg;
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
@@ -259,8 +263,10 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 	if (bias_done) *bias_done = false;
 	if (a.sc != 1 || !pixel_linear(gr) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
 	wino_wgrad_plan_t wp;
-	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wp) && wino_images_ok(a, gr, dw, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp.t, g.C, g.K)))
-		return conv_wino_wgrad(g, wp, gr, a, dw, dbias, bias_done, flags, ctx);
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wp) && wino_images_ok(a, gr, dw, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp.t, g.C, g.K))) {
+		const int r = conv_wino_wgrad(g, wp, gr, a, dw, dbias, bias_done, flags, ctx);
+		if (r != CCV_NNC_EXEC_OOM) return r;
+	}
 	const long P = (long)g.N * g.OH * g.OW;
 	if (P > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const int NN = g.kh * g.kw * g.Cg;
