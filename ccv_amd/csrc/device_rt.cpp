@@ -85,7 +85,7 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 	device_local_t* l = s->any + device;
 	if (!l->stream) {
 		l->device = device;
-		HIP_ENFORCE(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+		HIP_ENFORCE(hipStreamCreateWithFlags(&l->stream, hipStreamDefault)); // blocking w.r.t. the NULL stream, see ccv_nnc_init_stream_context
 	}
 	return l;
 }
@@ -282,7 +282,11 @@ ccv_nnc_stream_context_t* ccv_nnc_init_stream_context(ccv_nnc_stream_context_t* 
 		s->one.device = CCV_STREAM_GET_DEVICE_ID(s->super.type);
 		const int prev = current_device();
 		HIP_ENFORCE(hipSetDevice(s->one.device));
-		HIP_ENFORCE(hipStreamCreateWithFlags(&s->one.stream, hipStreamNonBlocking));
+		// A BLOCKING stream, as the backend being replaced creates them (cudaStreamCreate, ccv_nnc_compat.cu:434): commands the host
+		// issues with stream_context == NULL go to the legacy NULL stream and must order against the graph's own streams in both
+		// directions -- cnnp initialises parameters and copies them between models on the NULL stream, then runs the compiled
+		// graph on its streams (a non-blocking stream let the first evaluate read uninitialised weights on the MI355X).
+		HIP_ENFORCE(hipStreamCreateWithFlags(&s->one.stream, hipStreamDefault));
 		HIP_ENFORCE(hipSetDevice(prev));
 	}
 	return (ccv_nnc_stream_context_t*)s;
