@@ -50,6 +50,7 @@ CMD = dict(
     TRANSPOSE_FORWARD=0xb4d506e0, TRANSPOSE_BACKWARD=0xb4d506e1,
     # element-wise / optimizer / loss rows of SURVEY.md section 8(f).1
     RANDOM_UNIFORM_FORWARD=0xa0cd1d5e, RANDOM_NORMAL_FORWARD=0x7062c8b4,
+    GROUP_NORM_FORWARD=0x17deb074, GROUP_NORM_BACKWARD=0x17deb075,
     LAYER_NORM_FORWARD=0xbed3c264, LAYER_NORM_BACKWARD=0xbed3c265, RMSNORM_FORWARD=0x6889e9d0, RMSNORM_BACKWARD=0x6889e9d1,
     ADAM_FORWARD=0xe30099dc, ADAM_BACKWARD=0xe30099dd, ADAMW_FORWARD=0x4f5d4870, ADAMW_BACKWARD=0x4f5d4871,
     ARGMAX_FORWARD=0x68af2804, ARGMAX_BACKWARD=0x68af2805, ARGMIN_FORWARD=0xeb8747f2, ARGMIN_BACKWARD=0xeb8747f3,
@@ -142,6 +143,10 @@ class _Lnorm(C.Structure):
     _fields_ = [("axis", C.c_int * MAX_DIM_ALLOC), ("count", C.c_int), ("epsilon", C.c_float), ("elementwise_affine", C.c_int)]
 
 
+class _Gnorm(C.Structure):
+    _fields_ = [("group_axis", C.c_int), ("reduce_axis", C.c_int * MAX_DIM_ALLOC), ("reduce_count", C.c_int), ("groups", C.c_int), ("epsilon", C.c_float), ("elementwise_affine", C.c_int)]
+
+
 class _Pad(C.Structure):
     _fields_ = [("type", C.c_int), ("end", C.c_int * MAX_DIM_ALLOC)]
 
@@ -157,7 +162,7 @@ class _I1(C.Structure):   # mse.reduce_op
 class _CmdUnion(C.Union):
     _fields_ = [("convolution", _Conv), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
                 ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
-                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("lnorm", _Lnorm), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("lnorm", _Lnorm), ("gnorm", _Gnorm), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
 
 class CmdParam(C.Structure):
@@ -363,6 +368,16 @@ def CMD_NORM(name, epsilon, affine, *axis):
     for i, a in enumerate(axis):
         c.info.lnorm.axis[i] = a
     c.info.lnorm.count, c.info.lnorm.epsilon, c.info.lnorm.elementwise_affine = len(axis), epsilon, affine
+    return c
+
+
+def CMD_GROUP_NORM(name, group_axis, groups, epsilon, affine, *reduce_axis):
+    """CMD_GROUP_NORM_*(group_axis, groups, epsilon, elementwise_affine, reduce axes...) (ccv_nnc_easy.h)"""
+    c = _cmd(name, (0, 0, 0))
+    gn = c.info.gnorm
+    gn.group_axis, gn.groups, gn.epsilon, gn.elementwise_affine, gn.reduce_count = group_axis, groups, epsilon, affine, len(reduce_axis)
+    for i, a in enumerate(reduce_axis):
+        gn.reduce_axis[i] = a
     return c
 
 

@@ -209,6 +209,7 @@ typedef struct { /* 120 bytes */
 		struct { int tanh; } gelu;
 		struct { int axis[CCV_NNC_MAX_DIM_ALLOC]; int count; float epsilon; int elementwise_affine; } lnorm;
 		struct { int axis[CCV_NNC_MAX_DIM_ALLOC]; int count; float epsilon; } rmsnorm;
+		struct { int group_axis; int reduce_axis[CCV_NNC_MAX_DIM_ALLOC]; int reduce_count; int groups; float epsilon; int elementwise_affine; } gnorm;
 		struct { int type; int end[CCV_NNC_MAX_DIM_ALLOC]; } pad;
 		struct { float pos_weight; } binary_crossentropy;
 		struct { float beta; } smooth_l1;

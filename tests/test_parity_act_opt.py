@@ -293,3 +293,32 @@ def test_random_uniform_and_normal(backend):
     z = out[0]
     assert r == 0 and abs(z.mean() - 1.0) < 0.03 and abs(z.std() - 2.0) < 0.03
     assert abs(np.mean(((z - 1.0) / 2.0) ** 3)) < 0.05 and abs(np.mean(((z - 1.0) / 2.0) ** 4) - 3.0) < 0.15   # skewness, kurtosis
+
+
+# ---- group norm (ccv_amd/csrc/cmd_groupnorm.cpp) ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt,shape,group_axis,groups,reduce_axis", [
+    ("NCHW", (2, 16, 5, 7), 1, 4, (2, 3)),    # the UNet layout: channels in 4 groups, statistics over (group, H, W)
+    ("NHWC", (2, 5, 7, 16), 3, 4, (1, 2)),
+    ("NCHW", (3, 12, 4, 4), 1, 3, (2,)),      # reduce H only: one statistic per (n, group, x)
+])
+@pytest.mark.parametrize("affine", [1, 0])
+def test_group_norm(backend, ref_lib, fmt, shape, group_axis, groups, reduce_axis, affine):
+    a, g = _x(shape, 51, 2.0), _x(shape, 52, 1.0)
+    sshape = tuple(groups if i == group_axis else (1 if i in reduce_axis else d) for i, d in enumerate(shape))
+    pshape = tuple(d if i == group_axis else 1 for i, d in enumerate(shape))   # scale / bias per channel
+    scale, bias = _x(pshape, 53, 1.0) + 1.5, _x(pshape, 54, 1.0)
+    fwd = nnc.CMD_GROUP_NORM("GROUP_NORM_FORWARD", group_axis, groups, 1e-5, affine, *reduce_axis)
+    bwd = nnc.CMD_GROUP_NORM("GROUP_NORM_BACKWARD", group_axis, groups, 1e-5, affine, *reduce_axis)
+    ins = [a, scale, bias] if affine else [a]
+    got, want = exec_pair(backend, ref_lib, fwd, nnc.NO_HINT, 0, ins, [np.zeros_like(a), np.zeros(sshape, F), np.zeros(sshape, F)], fmt=fmt)
+    # (both reference backends read their epsilon through the lnorm member of the parameter union, i.e. ~0: kept, see cmd_groupnorm.cpp)
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=2e-5, atol=2e-6)
+    mean, istd = want[1], want[2]
+    if affine:
+        bins, outs = [g, None, None, a, scale, None, None, mean, istd], [np.zeros_like(a), np.zeros(pshape, F), np.zeros(pshape, F)]
+    else:
+        bins, outs = [g, None, None, a, None, mean, istd], [np.zeros_like(a)]
+    got, want = exec_pair(backend, ref_lib, bwd, nnc.NO_HINT, 0, bins, outs, fmt=fmt)
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-5)
