@@ -10,6 +10,7 @@
 //   adam        lib/nnc/cmd/adam/ccv_nnc_adam_cpu_ref.c:16-175             inputs (g, a, m, v[, vm]) -> (b, n, u[, um]); L2 decay inside the gradient
 //   adamw       lib/nnc/cmd/adam/ccv_nnc_adamw_cpu_ref.c:16-174            decoupled decay: b = a - rate decay a - ...
 //   rmsprop     lib/nnc/cmd/rmsprop/ccv_nnc_rmsprop_cpu_ref.c:16-108       inputs (g, a, m, v) -> (b, n, u)
+//   lamb        lib/nnc/cmd/lamb/ccv_nnc_lamb_cpu_ref.c:16-140             Adam-style update scaled per TENSOR by |w| / |update| (norms in double)
 #include "common.h"
 
 using namespace nnc;
@@ -261,6 +262,77 @@ static int _rmsprop_forw(EXEC_ARGS)
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// ---- LAMB: update = mom^ / (sqrt(vel^) + eps) + decay w; b = a - rate (|w| / |update|) update.  Three launches: the element pass writes n, u
+// and the update (workspace) and one (sum w^2, sum update^2) pair per block in double; one block folds the pairs in order into the trust
+// ratio; the last pass applies it.  Deterministic; 9 |p| bytes. -------------------------------------------------------------------------
+struct LambP { float scale, beta1, beta2, decay, epsilon, inv_corr1, inv_corr2; };
+__global__ void __launch_bounds__(EW_THREADS) lamb_update_kernel(const LambP p, const float* g, const float* a, const float* m, const float* v, float* nm, float* u, float* update, double* partial, const size_t n)
+{
+	__shared__ double red[2][4];
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	double wn = 0, un = 0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const float grad = p.scale * g[i], w = a[i];
+		const float mom = p.beta1 * m[i] + (1.f - p.beta1) * grad;
+		const float vel = p.beta2 * v[i] + (1.f - p.beta2) * grad * grad;
+		nm[i] = mom;
+		u[i] = vel;
+		const float upd = (mom * p.inv_corr1) / (sqrtf(vel * p.inv_corr2) + p.epsilon) + w * p.decay;
+		update[i] = upd;
+		wn += (double)(w * w);
+		un += (double)(upd * upd);
+	}
+	for (int o = 32; o > 0; o >>= 1) { wn += __shfl_xor(wn, o); un += __shfl_xor(un, o); }
+	if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = wn; red[1][threadIdx.x >> 6] = un; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+		partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+	}
+}
+__global__ void lamb_trust_kernel(const double* partial, const int blocks, const float rate, float* rate_trust)
+{
+	double wn = 0, un = 0;
+	for (int i = 0; i < blocks; i++) { wn += partial[2 * i]; un += partial[2 * i + 1]; }
+	wn = sqrt(wn); un = sqrt(un);
+	const float trust = (wn > 0 && un > 0) ? (float)(wn / un) : 1.f;
+	*rate_trust = rate * trust;
+}
+__global__ void __launch_bounds__(EW_THREADS) lamb_apply_kernel(const float* a, const float* update, const float* rate_trust, float* b, const size_t n)
+{
+	const float rt = *rate_trust;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) b[i] = a[i] - rt * update[i];
+}
+static int _lamb_forw(EXEC_ARGS)
+{
+	if (input_size < 4 || output_size < 3) return CCV_NNC_EXEC_INVALID;
+	for (int i = 0; i < 4; i++) if (!dense_f32(inputs[i])) return CCV_NNC_EXEC_INVALID;
+	for (int i = 0; i < 3; i++) if (!dense_f32(outputs[i])) return CCV_NNC_EXEC_INVALID;
+	const size_t n = tensor_count(inputs[1]->info);
+	for (int i = 0; i < 4; i++) if (tensor_count(inputs[i]->info) != n) return CCV_NNC_EXEC_INVALID;
+	for (int i = 0; i < 3; i++) if (tensor_count(outputs[i]->info) != n) return CCV_NNC_EXEC_INVALID;
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	const int blocks = grid_for(n, EW_THREADS);
+	const size_t head = (sizeof(double) * 2 * (size_t)blocks + sizeof(float) + 255) & ~(size_t)255;
+	char* ws = (char*)workspace_of(stream_context, head + sizeof(float) * n);
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	double* const partial = (double*)ws;
+	float* const rate_trust = (float*)(ws + sizeof(double) * 2 * (size_t)blocks);
+	float* const update = (float*)(ws + head);
+	LambP p;
+	p.scale = cmd.info.lamb.scale; p.beta1 = cmd.info.lamb.beta1; p.beta2 = cmd.info.lamb.beta2; p.decay = cmd.info.lamb.decay; p.epsilon = cmd.info.lamb.epsilon;
+	p.inv_corr1 = 1.f / (1 - powf(p.beta1, (float)cmd.info.lamb.step));
+	p.inv_corr2 = 1.f / (1 - powf(p.beta2, (float)cmd.info.lamb.step));
+	hipStream_t stream = stream_of(stream_context);
+	hipLaunchKernelGGL(lamb_update_kernel, dim3(blocks), dim3(EW_THREADS), 0, stream, p, (const float*)inputs[0]->data.f32, (const float*)inputs[1]->data.f32, (const float*)inputs[2]->data.f32, (const float*)inputs[3]->data.f32,
+		outputs[1]->data.f32, outputs[2]->data.f32, update, partial, n);
+	hipLaunchKernelGGL(lamb_trust_kernel, dim3(1), dim3(1), 0, stream, (const double*)partial, blocks, cmd.info.lamb.rate, rate_trust);
+	hipLaunchKernelGGL(lamb_apply_kernel, dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)inputs[1]->data.f32, (const float*)update, (const float*)rate_trust, outputs[0]->data.f32, n);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 } // namespace
 
 #define NNC_REG(CMD, BACKEND, FORMATS, EXEC) \
@@ -283,3 +355,4 @@ NNC_REG(CCV_NNC_SOFTMAX_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, _softm
 NNC_REG(CCV_NNC_ADAM_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, _adam_forw)
 NNC_REG(CCV_NNC_ADAMW_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, _adamw_forw)
 NNC_REG(CCV_NNC_RMSPROP_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, _rmsprop_forw)
+NNC_REG(CCV_NNC_LAMB_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, _lamb_forw)

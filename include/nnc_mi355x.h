@@ -217,6 +217,7 @@ typedef struct { /* 120 bytes */
 		struct { float negative_slope; } leaky_relu;
 		struct { int step; float rate; float scale; float beta1; float beta2; float decay; float epsilon; int amsgrad; } adam;
 		struct { float rate; float scale; float decay; float alpha; float momentum; float epsilon; } rmsprop;
+		struct { int step; float rate; float scale; float beta1; float beta2; float decay; float epsilon; } lamb;
 		char _widest[68]; /* gnorm is the widest member in the reference (68 B) */
 		void* userdata;
 	};

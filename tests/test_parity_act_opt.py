@@ -322,3 +322,14 @@ def test_group_norm(backend, ref_lib, fmt, shape, group_axis, groups, reduce_axi
     got, want = exec_pair(backend, ref_lib, bwd, nnc.NO_HINT, 0, bins, outs, fmt=fmt)
     for x, y in zip(got, want):
         np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(10,), (64, 3, 3, 3), (300, 77)])
+def test_lamb(backend, ref_lib, shape):
+    g, a, m = _x(shape, 61, 1.0), _x(shape, 62, 1.0), _x(shape, 63, 0.1)
+    v = np.random.default_rng(64).random(shape, dtype=F) * 0.01
+    cmd = nnc.CMD_ADAM_FORWARD(3, 0.002, 0.9, 0.98, 0.01, 1e-6, scale=0.5)   # lamb's parameters are adam's without amsgrad
+    cmd.cmd = nnc.CMD["LAMB_FORWARD"]
+    got, want = exec_pair(backend, ref_lib, cmd, nnc.NO_HINT, 0, [g, a, m, v], [np.zeros_like(a) for _ in range(3)])
+    for x, y in zip(got, want):
+        np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-8)
