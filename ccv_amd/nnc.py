@@ -147,6 +147,10 @@ class _Gnorm(C.Structure):
     _fields_ = [("group_axis", C.c_int), ("reduce_axis", C.c_int * MAX_DIM_ALLOC), ("reduce_count", C.c_int), ("groups", C.c_int), ("epsilon", C.c_float), ("elementwise_affine", C.c_int)]
 
 
+class _Upsample(C.Structure):
+    _fields_ = [("type", C.c_int), ("width_scale", C.c_float), ("height_scale", C.c_float), ("align_corners", C.c_int)]
+
+
 class _Pad(C.Structure):
     _fields_ = [("type", C.c_int), ("end", C.c_int * MAX_DIM_ALLOC)]
 
@@ -162,7 +166,7 @@ class _I1(C.Structure):   # mse.reduce_op
 class _CmdUnion(C.Union):
     _fields_ = [("convolution", _Conv), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
                 ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
-                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("lnorm", _Lnorm), ("gnorm", _Gnorm), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("upsample", _Upsample), ("lnorm", _Lnorm), ("gnorm", _Gnorm), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
 
 class CmdParam(C.Structure):
@@ -378,6 +382,14 @@ def CMD_GROUP_NORM(name, group_axis, groups, epsilon, affine, *reduce_axis):
     gn.group_axis, gn.groups, gn.epsilon, gn.elementwise_affine, gn.reduce_count = group_axis, groups, epsilon, affine, len(reduce_axis)
     for i, a in enumerate(reduce_axis):
         gn.reduce_axis[i] = a
+    return c
+
+
+def CMD_UPSAMPLE(name, up_type, width_scale, height_scale, align_corners):
+    """CMD_UPSAMPLE_*(type, width_scale, height_scale, align_corners): 0 nearest, 1 bilinear"""
+    c = _cmd(name, (0, 0, 0))
+    u = c.info.upsample
+    u.type, u.width_scale, u.height_scale, u.align_corners = up_type, width_scale, height_scale, align_corners
     return c
 
 

@@ -207,6 +207,7 @@ typedef struct { /* 120 bytes */
 		struct { float p; int entirety; } dropout;
 		struct { float min; float max; } clamp;
 		struct { int tanh; } gelu;
+		struct { int type; float width_scale; float height_scale; int align_corners; } upsample;
 		struct { int axis[CCV_NNC_MAX_DIM_ALLOC]; int count; float epsilon; int elementwise_affine; } lnorm;
 		struct { int axis[CCV_NNC_MAX_DIM_ALLOC]; int count; float epsilon; } rmsnorm;
 		struct { int group_axis; int reduce_axis[CCV_NNC_MAX_DIM_ALLOC]; int reduce_count; int groups; float epsilon; int elementwise_affine; } gnorm;

@@ -333,3 +333,19 @@ def test_lamb(backend, ref_lib, shape):
     got, want = exec_pair(backend, ref_lib, cmd, nnc.NO_HINT, 0, [g, a, m, v], [np.zeros_like(a) for _ in range(3)])
     for x, y in zip(got, want):
         np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-8)
+
+
+# ---- upsample (ccv_amd/csrc/cmd_upsample.cpp): bit-exact, the taps and the summation order are the reference's ------------------------------
+@pytest.mark.parametrize("fmt", ["NCHW", "NHWC"])
+@pytest.mark.parametrize("up_type,align", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("src,dst", [((5, 7), (10, 14)), ((4, 6), (7, 9)), ((3, 3), (3, 3)), ((6, 5), (11, 10))])
+def test_upsample(backend, ref_lib, fmt, up_type, align, src, dst):
+    n, c = 2, 3
+    ashape = (n, c) + src if fmt == "NCHW" else (n,) + src + (c,)
+    bshape = (n, c) + dst if fmt == "NCHW" else (n,) + dst + (c,)
+    a, g = _x(ashape, 71, 1.0), _x(bshape, 72, 1.0)
+    ws, hs = dst[1] / src[1], dst[0] / src[0]
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_UPSAMPLE("UPSAMPLE_FORWARD", up_type, ws, hs, align), nnc.NO_HINT, 0, [a], [np.zeros(bshape, F)], fmt=fmt)
+    assert np.array_equal(got[0], want[0])
+    got, want = exec_pair(backend, ref_lib, nnc.CMD_UPSAMPLE("UPSAMPLE_BACKWARD", up_type, ws, hs, align), nnc.NO_HINT, 0, [g], [np.full(ashape, 5, F)], fmt=fmt)
+    assert np.array_equal(got[0], want[0])
