@@ -25,12 +25,14 @@ struct UpGeom {
 
 __device__ __forceinline__ int nearest_src(const int d, const float r, const int A, const int align)
 {
+#pragma clang fp contract(off)
 	const int s = align ? (int)((double)((float)d * r) + 0.5) : (int)(((double)d + 0.5) * (double)r);
 	return s < A - 1 ? s : A - 1;
 }
 struct Bi { int si0, si1; float sc0, sc1; };
 __device__ __forceinline__ Bi bi_coeff(const int i, const float s, const int A, const int align)
 {
+#pragma clang fp contract(off)
 	Bi c;
 	const float xs = align ? (float)i * s : (float)(((double)i + 0.5) * (double)s - 0.5);
 	c.si0 = (int)xs;
@@ -51,6 +53,7 @@ __device__ __forceinline__ void split4(size_t idx, const int d1, const int d2, c
 template <int TYPE>
 __global__ void __launch_bounds__(256) upsample_forw_kernel(const UpGeom g, const float* a, float* b, const size_t total)
 {
+#pragma clang fp contract(off) // the reference rounds every product and sum separately; hipcc would fuse them into FMAs (last-ulp differences)
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
 		int n, c, yd, xd;
@@ -82,6 +85,7 @@ __device__ __forceinline__ void window(const int s, const float r, const int B, 
 template <int TYPE>
 __global__ void __launch_bounds__(256) upsample_back_kernel(const UpGeom g, const float* b, float* a, const size_t total)
 {
+#pragma clang fp contract(off)
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
 		int n, c, ys, xs;
