@@ -27,20 +27,52 @@ from ccv_amd.vgg import VGGD, vgg_d_flops_per_image  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 
 
-def cpu_baseline():
-    """The reference's own CPU path on this host: VGG-D fwd+bwd+SGD of ONE image (batch 1), all host cores (OpenMP)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(image, label):
+    """The reference's own CPU path on this host: VGG-D at batch 1 on `image` (the GPU run's image 0,
+    same seed-0 weights), all host cores (OpenMP), one warm-up + three repetitions each of
+      * the whole step (forward + backward + SGD) through CPU_REF -- the reported `value` (median);
+      * forward only through CPU_REF, and forward only with the convolutions on CPU_OPT (the reference's Winograd / direct
+        fast paths, cpu_opt/_ccv_nnc_conv_cpu_opt.c) -- reported beside it.
+    The warm-up step runs on the initial weights: its loss is what bench.py checks the GPU's step-1 loss of image 0 against."""
     from oracle_bind import oracle_lib
     O, backend, per_image = oracle_lib()
     kind = "reference" if O.kind == "reference" else "port"
     net = VGGD(O, 1, memory=nnc.CPU_MEMORY, backend=backend, pool_per_image=per_image, seed=0)
-    rng = np.random.default_rng(0)
-    net.set_input(rng.random((1, 225, 225, 3), dtype=np.float32), [1])
-    t0 = time.time()
-    net.step()
-    dt = time.time() - t0
-    cores = os.cpu_count() if kind == "reference" else 1
-    return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": kind,
-            "sample": "1 image, full VGG-D fwd+bwd+SGD through lib/nnc CPU_REF (oracle/_ref, clang -O3 -fopenmp, no BLAS); %.2f s" % dt}
+    net.set_input(image[None], [label])
+    REPS = 3
+
+    def timed(fn):
+        t0 = time.time()
+        fn()
+        return time.time() - t0
+    net.step()  # warm-up (pages, OpenMP pool) on the initial weights
+    loss0 = float(net.loss.numpy()[0])
+    steps = sorted(timed(net.step) for _ in range(REPS))
+    fwd_ref = sorted(timed(net.forward) for _ in range(REPS))
+    out = {"value": 1.0 / steps[REPS // 2], "unit": "images/s", "cores": os.cpu_count() if kind == "reference" else 1, "kind": kind,
+           "cpu": cpu_model(), "forward_only_cpu_ref_images_per_s": 1.0 / fwd_ref[REPS // 2],
+           "sample": "1 image, full VGG-D fwd+bwd+SGD through lib/nnc CPU_REF (oracle/_ref, clang -O3 -fopenmp, no BLAS: the fc layers run "
+                     "the reference's own loops), warm-up + %d repetitions, median %.2f s (min %.2f, max %.2f)" % (REPS, steps[REPS // 2], steps[0], steps[-1])}
+    if kind == "reference":
+        net.conv_fwd_backend = nnc.BACKEND_CPU_OPT
+        try:
+            net.forward()
+            fwd_opt = sorted(timed(net.forward) for _ in range(REPS))
+            out["forward_only_cpu_opt_images_per_s"] = 1.0 / fwd_opt[REPS // 2]
+        except RuntimeError as e:
+            out["forward_only_cpu_opt_images_per_s"] = None
+            out["cpu_opt_note"] = str(e)
+    return out, loss0
 
 
 def pmc_traffic(record_name, batch):
@@ -98,7 +130,9 @@ def main():
     imgs = np.empty((args.batch, 225, 225, 3), dtype=np.float32)
     for i in range(0, args.batch, chunk):
         imgs[i:i + chunk] = rng.random((min(chunk, args.batch - i), 225, 225, 3), dtype=np.float32)
-    net.set_input(imgs, rng.integers(0, 1000, args.batch))
+    labels = rng.integers(0, 1000, args.batch)
+    net.set_input(imgs, labels)
+    image0, label0 = imgs[0].copy(), int(labels[0])
     del imgs
     stream = L.stream_new(local_rank)
     L.stream_wait(None)  # construction-time SET commands ran on the default stream
@@ -123,8 +157,14 @@ def main():
         if dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    # Step 1 runs on the initial (seed 0) weights: image 0's loss after it is checked against the oracle's further down
+    # (read back between warm-up steps, outside the timed region; with --warmup 0 there is no untimed step and no check).
+    step1_loss = None
+    for i in range(args.warmup):
         step()
+        if i == 0:
+            L.stream_wait(stream)
+            step1_loss = float(net.loss.numpy()[0])
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -189,9 +229,17 @@ def main():
                                                     "by_kernel": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"], oracle_loss = cpu_baseline(image0, label0)
             except Exception as e:  # the checker is optional for the bench line, never for the parity tests
-                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "reference", "sample": "unavailable: %s" % e}
+                out["cpu_baseline"], oracle_loss = {"value": None, "unit": "images/s", "cores": 0, "kind": "reference", "sample": "unavailable: %s" % e}, None
+            if oracle_loss is not None and step1_loss is not None:
+                # parity gate on the benchmarked configuration itself: image 0's loss after the first forward at batch 256 (the
+                # convolutions under the algorithms the timed steps use) vs the reference CPU backend on the same image and weights
+                rel = abs(step1_loss - oracle_loss) / max(abs(oracle_loss), 1e-30)
+                out["config"]["step1_loss_image0"] = {"gpu": step1_loss, "oracle": oracle_loss, "rel_err": rel, "bound": 1e-4}
+                if not rel <= 1e-4:
+                    print(json.dumps(out))
+                    raise SystemExit("bench.py: step-1 loss of image 0 differs from the oracle's: %r vs %r (rel %.3g > 1e-4)" % (step1_loss, oracle_loss, rel))
         print(json.dumps(out))
     if dist:
         dist.barrier()

@@ -50,6 +50,7 @@ class VGGD:
         self.lib, self.batch, self.memory, self.device, self.backend = lib, batch, memory, device, backend
         # The reference CPU pools only walk image 0 of a batch: when driving the oracle, issue them per image.
         self.pool_per_image = pool_per_image
+        self.conv_fwd_backend = None  # bench.py's CPU leg: route CONVOLUTION_FORWARD to another backend of the same library (CPU_OPT)
         self.layers = list(layers)
         self.train = train
         rng = np.random.default_rng(seed)
@@ -168,6 +169,8 @@ class VGGD:
             c = nnc.Cmd()
             nnc.C.memmove(nnc.C.byref(c), nnc.C.byref(cmd), nnc.C.sizeof(c))
             c.backend = self.backend
+            if self.conv_fwd_backend is not None and cmd.cmd == nnc.CMD["CONVOLUTION_FORWARD"]:
+                c.backend = self.conv_fwd_backend
         if hook:
             hook("begin", tag)
         r = self.lib.cmd_exec(c, hint, flags, ins, outs, stream)
