@@ -75,36 +75,58 @@ static bool wino_plan(const conv_geom_t& g, const int dst_h, const int dst_w, co
 	return true;
 }
 
+// Images per slice for the Winograd-via-HBM stages (TUNE_WINO_SLICE_KB): the transformed images V and M of the whole batch
+// are far beyond every cache (conv1_2 at batch 256: 7.4 GB each), so each is written to HBM and read back once.  Run per
+// slice of images instead, V + M of a slice stay within the 256 MB Infinity Cache and the same scratch addresses are
+// reused slice after slice: the contraction reads V, and the output transform reads M, from on-die memory.
+static int wino_slice_images(const int N, const int tiles_per_image, const int C_src, const int C_dst)
+{
+	const long kb = tune(TUNE_WINO_SLICE_KB);
+	if (kb <= 0) return N;
+	const double per_image = 36.0 * sizeof(float) * (double)tiles_per_image * (double)(C_src + C_dst);
+	long nb = (long)((double)kb * 1024.0 / per_image);
+	if (nb < 1) nb = 1;
+	return nb > N ? N : (int)nb;
+}
+
 // dst (+ bias) = conv3x3(src, w), stride 1, source padding (pad_y, pad_x);  FLIP: dgrad's mirrored / role-swapped weights.
 template <bool FLIP>
 static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan_t& p, const Image4& src, const float* w, const float* bias, const Image4& dst, const int pad_y, const int pad_x, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	const int Cs = src.c, Cd = dst.c;
-	char* ws = (char*)workspace_of(ctx, p.total());
+	const int per_image = p.TH * p.TW;
+	const int nb = wino_slice_images(g.N, per_image, Cs, Cd);
+	const size_t v_bytes = nb == g.N ? p.v_bytes : (sizeof(float) * 36 * (size_t)nb * per_image * Cs + 255) & ~(size_t)255;
+	const size_t m_bytes = nb == g.N ? p.m_bytes : (sizeof(float) * 36 * (size_t)nb * per_image * Cd + 255) & ~(size_t)255;
+	char* ws = (char*)workspace_of(ctx, p.u_bytes + v_bytes + m_bytes);
 	if (!ws) return CCV_NNC_EXEC_OOM;
 	float* const U = (float*)ws;
 	float* const V = (float*)(ws + p.u_bytes);
-	float* const M = (float*)(ws + p.u_bytes + p.v_bytes);
+	float* const M = (float*)(ws + p.u_bytes + v_bytes);
 	hipStream_t stream = stream_of(ctx);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_weight_kernel<FLIP>), dim3(blocks_exact((size_t)Cs * Cd, 256)), dim3(256), 0, stream, w, U, g.K, g.C);
 	HIP_ENFORCE(hipGetLastError());
-	WinoTiles ti;
-	ti.TH = p.TH; ti.TW = p.TW; ti.T = p.T;
-	ti.H = src.h; ti.W = src.w; ti.sn = src.sn; ti.sh = src.sh; ti.sw = src.sw; ti.oy = -pad_y; ti.ox = -pad_x; ti.C4 = Cs / 4;
-	ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
-	hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_exact((size_t)p.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)src.p, V, ti);
-	HIP_ENFORCE(hipGetLastError());
-	// 36 GEMMs M[z] (T x Cd) = V[z] (T x Cs) * U[z]^T (Cd x Cs), both operands reduction-contiguous, one launch (grid z)
-	MatLoader<true, true> la, lb;
-	la.p = V; la.ldr = Cs; la.ldk = 1; la.R = p.T; la.K = Cs;
-	lb.p = U; lb.ldr = Cs; lb.ldk = 1; lb.R = Cd; lb.K = Cs;
-	GemmOut out = { M, Cd, 1, 0, 1.f, 0 };
-	const int ret = gemm_run(name, la, lb, out, p.T, Cd, Cs, 36, (long)p.T * Cs, (long)Cd * Cs, (long)p.T * Cd, 0L, 1, flags, ctx);
-	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
-	ti.H = dst.h; ti.W = dst.w; ti.sn = dst.sn; ti.sh = dst.sh; ti.sw = dst.sw; ti.C4 = Cd / 4;
-	ti.d_c4.init(ti.C4);
-	hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_exact((size_t)p.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)M, bias, dst.p, ti);
-	HIP_ENFORCE(hipGetLastError());
+	for (int n0 = 0; n0 < g.N; n0 += nb) {
+		const int ns = g.N - n0 < nb ? g.N - n0 : nb;
+		const int T = ns * per_image;
+		WinoTiles ti;
+		ti.TH = p.TH; ti.TW = p.TW; ti.T = T;
+		ti.H = src.h; ti.W = src.w; ti.sn = src.sn; ti.sh = src.sh; ti.sw = src.sw; ti.oy = -pad_y; ti.ox = -pad_x; ti.C4 = Cs / 4;
+		ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
+		hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_exact((size_t)T * ti.C4, 256)), dim3(256), 0, stream, (const float*)src.p + (long)n0 * src.sn, V, ti);
+		HIP_ENFORCE(hipGetLastError());
+		// 36 GEMMs M[z] (T x Cd) = V[z] (T x Cs) * U[z]^T (Cd x Cs), both operands reduction-contiguous, one launch (grid z)
+		MatLoader<true, true> la, lb;
+		la.p = V; la.ldr = Cs; la.ldk = 1; la.R = T; la.K = Cs;
+		lb.p = U; lb.ldr = Cs; lb.ldk = 1; lb.R = Cd; lb.K = Cs;
+		GemmOut out = { M, Cd, 1, 0, 1.f, 0 };
+		const int ret = gemm_run(name, la, lb, out, T, Cd, Cs, 36, (long)T * Cs, (long)Cd * Cs, (long)T * Cd, 0L, 1, flags, ctx);
+		if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
+		ti.H = dst.h; ti.W = dst.w; ti.sn = dst.sn; ti.sh = dst.sh; ti.sw = dst.sw; ti.C4 = Cd / 4;
+		ti.d_c4.init(ti.C4);
+		hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_exact((size_t)T * ti.C4, 256)), dim3(256), 0, stream, (const float*)M, bias, dst.p + (long)n0 * dst.sn, ti);
+		HIP_ENFORCE(hipGetLastError());
+	}
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
@@ -146,6 +168,7 @@ static bool wino_wgrad_plan(const conv_geom_t& g, wino_wgrad_plan_t* p)
 static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, const Image4& gr, const Image4& a, float* dw, float* dbias, bool* bias_done, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	// [ head: nested calls' scratch (they take the workspace base) | V | W | dU | per-block column sums ]
+	// (sized for the whole batch: a slice -- TUNE_WINO_SLICE_KB -- uses the front of each region)
 	char* ws = (char*)workspace_of(ctx, p.total());
 	if (!ws) return CCV_NNC_EXEC_OOM;
 	float* const V = (float*)(ws + p.head_bytes);
@@ -153,30 +176,45 @@ static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, con
 	float* const dU = (float*)(ws + p.head_bytes + p.t.v_bytes + p.w_bytes);
 	float* const BP = (float*)(ws + p.head_bytes + p.t.v_bytes + p.w_bytes + p.du_bytes);
 	const bool fuse_bias = dbias && 256 % (g.K / 4) == 0;
+	const int acc = (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0;
 	hipStream_t stream = stream_of(ctx);
-	WinoTiles ti;
-	ti.TH = p.t.TH; ti.TW = p.t.TW; ti.T = p.t.T;
-	ti.H = a.h; ti.W = a.w; ti.sn = a.sn; ti.sh = a.sh; ti.sw = a.sw; ti.oy = -g.pby; ti.ox = -g.pbx; ti.C4 = g.C / 4;
-	ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
-	hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_exact((size_t)p.t.T * ti.C4, 256)), dim3(256), 0, stream, (const float*)a.p, V, ti);
-	HIP_ENFORCE(hipGetLastError());
-	ti.H = gr.h; ti.W = gr.w; ti.sn = gr.sn; ti.sh = gr.sh; ti.sw = gr.sw; ti.oy = 0; ti.ox = 0; ti.C4 = g.K / 4;
-	ti.d_c4.init(ti.C4);
-	if (fuse_bias) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_outgrad_kernel<true>), dim3((unsigned)p.blocks), dim3(256), 0, stream, (const float*)gr.p, W, ti, BP);
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_outgrad_kernel<false>), dim3((unsigned)p.blocks), dim3(256), 0, stream, (const float*)gr.p, W, ti, (float*)0);
-	HIP_ENFORCE(hipGetLastError());
-	MatLoader<false, true> la, lb; // rows = channels (contiguous), reduction index = tile (stride = channel count)
-	la.p = W; la.ldr = 1; la.ldk = g.K; la.R = g.K; la.K = p.t.T;
-	lb.p = V; lb.ldr = 1; lb.ldk = g.C; lb.R = g.C; lb.K = p.t.T;
-	GemmOut out = { dU, g.C, 1, 0, 1.f, 0 };
-	const int ret = gemm_run("conv_wgrad_wino", la, lb, out, g.K, g.C, p.t.T, 36, (long)p.t.T * g.K, (long)p.t.T * g.C, (long)g.K * g.C, 0L, p.splits, flags, ctx);
-	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
-	hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3(blocks_exact((size_t)g.K * g.C, 256)), dim3(256), 0, stream, (const float*)dU, dw, g.K, g.C, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
-	HIP_ENFORCE(hipGetLastError());
-	if (fuse_bias) { // fold the per-block rows; its own partials land in the head region, V / W are dead by now
-		const int r = colsum_f32(BP, p.blocks, g.K, g.K, dbias, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0, ctx);
-		if (r != CCV_NNC_EXEC_SUCCESS) return r;
+	const int per_image = p.t.TH * p.t.TW;
+	const int nb = wino_slice_images(g.N, per_image, g.C, g.K);
+	for (int n0 = 0; n0 < g.N; n0 += nb) {
+		const int ns = g.N - n0 < nb ? g.N - n0 : nb;
+		const int T = ns * per_image;
+		WinoTiles ti;
+		ti.TH = p.t.TH; ti.TW = p.t.TW; ti.T = T;
+		ti.H = a.h; ti.W = a.w; ti.sn = a.sn; ti.sh = a.sh; ti.sw = a.sw; ti.oy = -g.pby; ti.ox = -g.pbx; ti.C4 = g.C / 4;
+		ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
+		hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_exact((size_t)T * ti.C4, 256)), dim3(256), 0, stream, (const float*)a.p + (long)n0 * a.sn, V, ti);
+		HIP_ENFORCE(hipGetLastError());
+		ti.H = gr.h; ti.W = gr.w; ti.sn = gr.sn; ti.sh = gr.sh; ti.sw = gr.sw; ti.oy = 0; ti.ox = 0; ti.C4 = g.K / 4;
+		ti.d_c4.init(ti.C4);
+		const long blocks = ((long)T * (g.K / 4) + 255) / 256;
+		const float* const grs = (const float*)gr.p + (long)n0 * gr.sn;
+		if (fuse_bias) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_outgrad_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, stream, grs, W, ti, BP);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_outgrad_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, grs, W, ti, (float*)0);
+		HIP_ENFORCE(hipGetLastError());
+		MatLoader<false, true> la, lb; // rows = channels (contiguous), reduction index = tile (stride = channel count)
+		la.p = W; la.ldr = 1; la.ldk = g.K; la.R = g.K; la.K = T;
+		lb.p = V; lb.ldr = 1; lb.ldk = g.C; lb.R = g.C; lb.K = T;
+		GemmOut out = { dU, g.C, 1, 0, 1.f, n0 > 0 ? 1 : 0 }; // later slices add onto the first one's dU
+		int splits = p.splits;
+		if (nb < g.N) { // a slice has fewer tiles: keep >= 8 K-steps per K-slice
+			const long max_s = T / (GEMM_BK * 8);
+			if (splits > max_s) splits = max_s <= 1 ? 1 : (int)(max_s & ~7L);
+			if (splits < 8) splits = 1;
+		}
+		const int ret = gemm_run("conv_wgrad_wino", la, lb, out, g.K, g.C, T, 36, (long)T * g.K, (long)T * g.C, (long)g.K * g.C, 0L, splits, flags, ctx);
+		if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
+		if (fuse_bias) { // fold the per-block rows; its own partials land in the head region, the slice's W is dead by now
+			const int r = colsum_f32(BP, blocks, g.K, g.K, dbias, acc || n0 > 0, ctx);
+			if (r != CCV_NNC_EXEC_SUCCESS) return r;
+		}
 	}
+	hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3(blocks_exact((size_t)g.K * g.C, 256)), dim3(256), 0, stream, (const float*)dU, dw, g.K, g.C, acc);
+	HIP_ENFORCE(hipGetLastError());
 	if (bias_done) *bias_done = fuse_bias;
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -458,8 +496,11 @@ static int _conv_autotune(const ccv_nnc_cmd_t cmd, const size_t max_workspace_si
 	hipEvent_t e0, e1;
 	HIP_ENFORCE(hipEventCreate(&e0));
 	HIP_ENFORCE(hipEventCreate(&e1));
-	int best = 0;
+	int best = 0, have_best = 0;
 	float best_ms = 0;
+	// trials must not leave their mark: CCV_NNC_ACCUMULATE_OUTPUT would add dw / dbias once per trial, so the trials overwrite
+	// (the host autotunes before the first real execution and the real execution follows with the caller's flags)
+	const int trial_flags = flags & ~CCV_NNC_ACCUMULATE_OUTPUT;
 	for (int algo = 0; algo < CONV_ALGO_COUNT; algo++) {
 		ccv_nnc_cmd_t c = cmd;
 		c.algorithm = algo;
@@ -467,13 +508,13 @@ static int _conv_autotune(const ccv_nnc_cmd_t cmd, const size_t max_workspace_si
 		int ok = 1;
 		for (int trial = 0; trial < 2 && ok; trial++) { // first trial warms the workspace up
 			HIP_ENFORCE(hipEventRecord(e0, stream));
-			const int ret = fwd ? _conv_forw(c, hint, flags, inputs, input_size, outputs, output_size, stream_context) : _conv_back(c, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+			const int ret = fwd ? _conv_forw(c, hint, trial_flags, inputs, input_size, outputs, output_size, stream_context) : _conv_back(c, hint, trial_flags, inputs, input_size, outputs, output_size, stream_context);
 			HIP_ENFORCE(hipEventRecord(e1, stream));
 			HIP_ENFORCE(hipEventSynchronize(e1));
 			if (ret != CCV_NNC_EXEC_SUCCESS) ok = 0;
 			else HIP_ENFORCE(hipEventElapsedTime(&ms, e0, e1));
 		}
-		if (ok && (algo == 0 || ms < best_ms)) { best = algo; best_ms = ms; }
+		if (ok && (!have_best || ms < best_ms)) { best = algo; best_ms = ms; have_best = 1; }
 	}
 	HIP_ENFORCE(hipEventDestroy(e0));
 	HIP_ENFORCE(hipEventDestroy(e1));

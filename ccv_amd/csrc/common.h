@@ -146,6 +146,14 @@ struct ProfScope {
 // nnc_mi355x_debug_force_tile (device_rt.cpp): wm | wn << 8, 0 = built-in choice.
 extern int g_force_tile;
 
+// Tunables (nnc_mi355x_tune_set / environment NNC_MI355X_<NAME>, device_rt.cpp): performance policy only, never semantics.
+enum {
+	TUNE_WINO_SLICE_KB = 0, // Winograd via HBM: run the three stages per slice of images whose V + M scratch is at most this many KB (0 = whole batch)
+	TUNE_WINO_FUSED_MAX_C,  // algorithm -1 picks the fused Winograd kernel when the reduction channels are <= this (0 = never)
+	TUNE_COUNT
+};
+long tune(int key);
+
 // Registration table (registry.cpp).
 typedef void (*register_fn_t)(ccv_nnc_cmd_backend_registry_t* const);
 

@@ -92,7 +92,25 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 
 } // namespace
 
-namespace nnc { int g_force_tile = 0; }
+namespace nnc {
+int g_force_tile = 0;
+static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C" };
+static long g_tune_values[TUNE_COUNT] = { 0, 0 }; // defaults: the measured best on the MI355X
+static int g_tune_env_read = 0;
+long tune(int key)
+{
+	if (!g_tune_env_read) { // environment overrides, read once: NNC_MI355X_WINO_SLICE_KB=96 ...
+		for (int i = 0; i < TUNE_COUNT; i++) {
+			char name[64];
+			snprintf(name, sizeof(name), "NNC_MI355X_%s", g_tune_names[i]);
+			const char* v = getenv(name);
+			if (v && *v) g_tune_values[i] = atol(v);
+		}
+		g_tune_env_read = 1;
+	}
+	return key >= 0 && key < TUNE_COUNT ? g_tune_values[key] : 0;
+}
+}
 namespace nnc {
 
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
@@ -499,6 +517,20 @@ void nnc_mi355x_debug_force_tile(int wm, int wn)
 {
 	const bool known = (wm == 2 && wn == 2) || (wm == 2 && wn == 1) || (wm == 1 && wn == 2) || (wm == 1 && wn == 1);
 	nnc::g_force_tile = known ? (wm | wn << 8) : 0;
+}
+
+int nnc_mi355x_tune_set(const char* name, long value)
+{
+	(void)nnc::tune(0); // environment first, explicit calls override it
+	for (int i = 0; i < nnc::TUNE_COUNT; i++)
+		if (strcmp(name, nnc::g_tune_names[i]) == 0) { nnc::g_tune_values[i] = value; return 0; }
+	return -1;
+}
+long nnc_mi355x_tune_get(const char* name)
+{
+	for (int i = 0; i < nnc::TUNE_COUNT; i++)
+		if (strcmp(name, nnc::g_tune_names[i]) == 0) return nnc::tune(i);
+	return -1;
 }
 
 void nnc_mi355x_profile_enable(int on)

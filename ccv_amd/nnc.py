@@ -622,6 +622,16 @@ class Lib:
     def profile_enable(self, on): self.dll.nnc_mi355x_profile_enable(int(on))
     def force_tile(self, wm, wn): self.dll.nnc_mi355x_debug_force_tile(int(wm), int(wn))
 
+    def tune_set(self, name, value):
+        self.dll.nnc_mi355x_tune_set.argtypes = [C.c_char_p, C.c_long]
+        if self.dll.nnc_mi355x_tune_set(name.encode(), int(value)) != 0:
+            raise KeyError(name)
+
+    def tune_get(self, name):
+        self.dll.nnc_mi355x_tune_get.argtypes = [C.c_char_p]
+        self.dll.nnc_mi355x_tune_get.restype = C.c_long
+        return self.dll.nnc_mi355x_tune_get(name.encode())
+
     def profile_records(self):
         """[(name, flops, bytes, ms, (M, N, K, Z, splits))] for every contraction launch since profile_enable(1)."""
         out = []

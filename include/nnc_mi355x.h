@@ -366,6 +366,10 @@ int  nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, doub
  * ((2,2) (2,1) (1,2) (1,1) exist); (0,0) restores the built-in choice.  Used by the parity tests to cover every
  * tile shape on every loader at sizes the oracle finishes. */
 void nnc_mi355x_debug_force_tile(int wm, int wn);
+/* Performance tunables (policy only -- results do not depend on them beyond floating-point re-association): by name, e.g.
+ * "WINO_SLICE_KB"; the environment variable NNC_MI355X_<NAME> sets the same value at first use.  Returns 0 / -1 (unknown). */
+int  nnc_mi355x_tune_set(const char* name, long value);
+long nnc_mi355x_tune_get(const char* name);
 /* Name of the device kernel the last command on this thread launched for its dominant work
  * (conv/gemm contraction), for matching against rocprofv3 kernel-trace rows. */
 const char* nnc_mi355x_last_kernel_name(void);

@@ -423,3 +423,26 @@ def test_softmax_only(backend, ref_lib):
     label = rng.integers(0, 1000, 5).astype(F)
     got, want = exec_pair(backend, ref_lib, nnc.CMD_SOFTMAX_CROSSENTROPY_FORWARD(), nnc.NO_HINT, 0, [a, label], [None, np.zeros((5, 1000), F)])
     np.testing.assert_allclose(got[1], want[1], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("case", [WINO_CASES[2], WINO_CASES[3]])
+def test_conv_winograd_image_slices(backend, ref_lib, case):
+    """WINO_SLICE_KB: the Winograd stages run per slice of images (scratch of one slice sized to stay in the Infinity Cache).
+    Forced down to one image per slice (and an uneven last slice) here; forward, data and filter gradient (which then
+    accumulates its transformed-domain sums across slices) and the fused bias gradient must not change."""
+    n, h, w, c, k, border = case
+    a, wt, b, hint, oh, ow = _wino_inputs(case)
+    g = srnd(np.random.default_rng(5), n, oh, ow, k)
+    per_image_kb = 36 * 4 * ((oh + 3) // 4) * ((ow + 3) // 4) * (c + k) / 1024.0
+    try:
+        for images in (1, 2):
+            backend.tune_set("WINO_SLICE_KB", int(per_image_kb * images) + 1)
+            cmd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
+            got, want = _wino_pair(backend, ref_lib, cmd, hint, [a, wt, b], [np.zeros((n, oh, ow, k), F)])
+            np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-5)
+            cmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+            got, want = _wino_pair(backend, ref_lib, cmd, hint, [g, a, wt], [np.full_like(a, 3), np.zeros_like(wt), np.zeros(k, F)])
+            for i in range(3):
+                np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(want[i]).max())))
+    finally:
+        backend.tune_set("WINO_SLICE_KB", 0)
