@@ -8,6 +8,7 @@
 // the inputs as long as the channel stride is 1.  NCHW tensors are routed through the layout kernels of cmd_util (workspace).
 #include "gemm_launch.h"
 #include "winograd.h"
+#include "wino_fused.h"
 
 using namespace nnc;
 
@@ -49,7 +50,8 @@ static bool pixel_linear(const Image4& t)
 
 // ---- Winograd F(4x4, 3x3) (winograd.h) --------------------------------------------------------------------------------
 // Algorithm numbers of the two conv rows (ccv_nnc_cmd_t.algorithm; -1 = the backend's own choice; what autotune returns).
-enum { CONV_ALGO_IMPLICIT_GEMM = 0, CONV_ALGO_WINOGRAD = 1, CONV_ALGO_COUNT = 2 };
+// 2 = the fused Winograd kernel (wino_fused.h) for forward and the data gradient; the filter gradient under 2 is algorithm 1's.
+enum { CONV_ALGO_IMPLICIT_GEMM = 0, CONV_ALGO_WINOGRAD = 1, CONV_ALGO_WINOGRAD_FUSED = 2, CONV_ALGO_COUNT = 3 };
 
 // the Winograd transform kernels are one-thread-per-item (no grid-stride loop): launch exactly ceil(n / threads) blocks
 static unsigned blocks_exact(const size_t n, const int threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -129,6 +131,66 @@ static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan
 	}
 	return CCV_NNC_EXEC_SUCCESS;
 }
+
+// ---- fused Winograd (wino_fused.h): dst (+ bias) = conv3x3(src, w) with neither V nor M in HBM ------------------------------
+struct wino_fused_plan_t {
+	int GH, GW, GYn, GXn, groups, KB, CCn;
+	size_t uf_bytes;
+};
+
+static bool wino_fused_plan(const conv_geom_t& g, const Image4& src, const Image4& dst, wino_fused_plan_t* p)
+{
+	if (g.kh != 3 || g.kw != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.groups != 1) return false;
+	if (src.c % WF_CC || src.sc != 1 || dst.sc != 1 || !aligned16(src.p) || src.sw % 4 || src.sh % 4 || (src.n > 1 && src.sn % 4)) return false;
+	if (((long)(src.h - 1) * src.sh + (long)(src.w - 1) * src.sw + src.c) * 4 >= (long)WF_OOB) return false; // per-image buffer descriptor range
+	const int TH = (dst.h + 3) / 4, TW = (dst.w + 3) / 4;
+	static const int shapes[3][2] = { { 4, 4 }, { 2, 8 }, { 8, 2 } };
+	long best = -1;
+	for (int i = 0; i < 3; i++) { // least padding of the tile grid; ties go to the squarer group (smaller patch region)
+		const long cover = (long)((TH + shapes[i][0] - 1) / shapes[i][0]) * ((TW + shapes[i][1] - 1) / shapes[i][1]);
+		if (best < 0 || cover < best) { best = cover; p->GH = shapes[i][0]; p->GW = shapes[i][1]; }
+	}
+	p->GYn = (TH + p->GH - 1) / p->GH; p->GXn = (TW + p->GW - 1) / p->GW;
+	const long groups = (long)src.n * p->GYn * p->GXn;
+	p->KB = (dst.c + WF_KT - 1) / WF_KT; p->CCn = src.c / WF_CC;
+	if (groups <= 0 || (groups + 3) / 4 * p->KB > 0x7fffffffL || (size_t)p->CCn * WF_U_FLOATS * 4 > 0xffffffffUL) return false;
+	p->groups = (int)groups;
+	p->uf_bytes = (sizeof(float) * (size_t)p->KB * p->CCn * WF_U_FLOATS + 255) & ~(size_t)255;
+	return true;
+}
+
+template <bool FLIP>
+static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const wino_fused_plan_t& p, const Image4& src, const float* w, const float* bias, const Image4& dst, const int pad_y, const int pad_x, ccv_nnc_stream_context_t* const ctx)
+{
+	float* const UF = (float*)workspace_of(ctx, p.uf_bytes);
+	if (!UF) return CCV_NNC_EXEC_OOM;
+	hipStream_t stream = stream_of(ctx);
+	const int Kout = dst.c, Cred = src.c;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_weight_frag_kernel<FLIP>), dim3(blocks_exact((size_t)p.KB * WF_KT * Cred, 256)), dim3(256), 0, stream, w, UF, Kout, Cred, g.K, g.C);
+	HIP_ENFORCE(hipGetLastError());
+	WinoFusedArgs a;
+	a.src = src.p; a.dst = dst.p; a.uf = UF; a.bias = bias;
+	a.s_sn = src.sn; a.s_sh = src.sh; a.s_sw = src.sw; a.d_sn = dst.sn; a.d_sh = dst.sh; a.d_sw = dst.sw;
+	a.H = src.h; a.W = src.w; a.OH = dst.h; a.OW = dst.w; a.pad_y = pad_y; a.pad_x = pad_x;
+	a.GYn = p.GYn; a.GXn = p.GXn; a.groups = p.groups; a.C = Cred; a.K = Kout; a.CCn = p.CCn; a.KB = p.KB;
+	a.src_image_bytes = (unsigned)(((long)(src.h - 1) * src.sh + (long)(src.w - 1) * src.sw + src.c) * 4);
+	a.uf_kb_bytes = (unsigned)((size_t)p.CCn * WF_U_FLOATS * 4);
+	const unsigned grid = (unsigned)((p.groups + 3) / 4 * p.KB);
+	note_kernel(name);
+	char prof_name[96];
+	snprintf(prof_name, sizeof(prof_name), "%s|nnc::wino_fused_kernel<%d, %d>", name, p.GH, p.GW);
+	const long T = (long)src.n * ((dst.h + 3) / 4) * ((dst.w + 3) / 4);
+	ProfScope prof(prof_name, 2.0 * 36.0 * (double)T * Kout * Cred, 0, (int)T, Kout, Cred, 36, 1, stream);
+	if (p.GH == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4>), dim3(grid), dim3(256), 0, stream, a);
+	else if (p.GH == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<2, 8>), dim3(grid), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<8, 2>), dim3(grid), dim3(256), 0, stream, a);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+// algorithm -1: the fused kernel where its 64 x 32 block is the better trade -- few reduction channels (the via-HBM form is
+// bandwidth-bound there) -- up to TUNE_WINO_FUSED_MAX_C; measured per VGG-D layer on the MI355X.
+static bool wino_fused_preferred(const int C_red) { return C_red <= tune(TUNE_WINO_FUSED_MAX_C); }
 
 // dw (+)= sum over tiles: the F(3x3, 4x4) form -- V = B^T a B exactly as in forward, W = G' g G'^T on the output gradient,
 // 36 contractions dU[z] (K x C) = W[z]^T V[z] over the T tiles (batched split-K: both operands are read along their
@@ -237,7 +299,12 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 {
 	if (a.sc != 1 || !pixel_linear(b) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
 	wino_plan_t wp;
-	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.OH, g.OW, g.C, g.K, &wp) && wino_images_ok(a, b, w, bias) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp, g.C, g.K))) {
+	wino_fused_plan_t fp;
+	if ((algo == CONV_ALGO_WINOGRAD_FUSED || (algo < 0 && wino_fused_preferred(g.C))) && g.pby <= 2 && g.pbx <= 2 && g.pby >= 0 && g.pbx >= 0 && wino_fused_plan(g, a, b, &fp)) {
+		const int r = conv_wino_fused_run<false>("conv_fwd_wino_fused", g, fp, a, w, bias, b, g.pby, g.pbx, ctx);
+		if (r != CCV_NNC_EXEC_OOM) return r;
+	}
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.OH, g.OW, g.C, g.K, &wp) && wino_images_ok(a, b, w, bias) && (algo >= CONV_ALGO_WINOGRAD || wino_preferred(wp, g.C, g.K))) {
 		const int r = conv_wino_run<false>("conv_fwd_wino", g, wp, a, w, bias, b, g.pby, g.pbx, flags, ctx);
 		if (r != CCV_NNC_EXEC_OOM) return r; // the transformed images did not fit the device: the implicit GEMM needs no such scratch
 	}
@@ -270,7 +337,12 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 {
 	if (gr.sc != 1 || !pixel_linear(h) || !image_fits_int(gr)) return CCV_NNC_EXEC_INVALID;
 	wino_plan_t wp;
-	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wp) && wino_images_ok(gr, h, w, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp, g.K, g.C))) {
+	wino_fused_plan_t fp;
+	if ((algo == CONV_ALGO_WINOGRAD_FUSED || (algo < 0 && wino_fused_preferred(g.K))) && g.pby <= 2 && g.pbx <= 2 && g.pby >= 0 && g.pbx >= 0 && wino_fused_plan(g, gr, h, &fp)) {
+		const int r = conv_wino_fused_run<true>("conv_dgrad_wino_fused", g, fp, gr, w, 0, h, 2 - g.pby, 2 - g.pbx, ctx);
+		if (r != CCV_NNC_EXEC_OOM) return r;
+	}
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wp) && wino_images_ok(gr, h, w, 0) && (algo >= CONV_ALGO_WINOGRAD || wino_preferred(wp, g.K, g.C))) {
 		const int r = conv_wino_run<true>("conv_dgrad_wino", g, wp, gr, w, 0, h, 2 - g.pby, 2 - g.pbx, flags, ctx);
 		if (r != CCV_NNC_EXEC_OOM) return r;
 	}
@@ -301,7 +373,7 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 	if (bias_done) *bias_done = false;
 	if (a.sc != 1 || !pixel_linear(gr) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
 	wino_wgrad_plan_t wp;
-	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wp) && wino_images_ok(a, gr, dw, 0) && (algo == CONV_ALGO_WINOGRAD || wino_preferred(wp.t, g.C, g.K))) {
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wp) && wino_images_ok(a, gr, dw, 0) && (algo >= CONV_ALGO_WINOGRAD || wino_preferred(wp.t, g.C, g.K))) {
 		const int r = conv_wino_wgrad(g, wp, gr, a, dw, dbias, bias_done, flags, ctx);
 		if (r != CCV_NNC_EXEC_OOM) return r;
 	}

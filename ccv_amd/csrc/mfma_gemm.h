@@ -32,6 +32,7 @@
 namespace nnc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEMM_BK = 32, GEMM_THREADS = 256;
 constexpr int GEMM_LDK = 36; // row stride of a k-contiguous LDS image

@@ -1,0 +1,421 @@
+// Fused Winograd F(4x4, 3x3) convolution for gfx950, fp32: input transform, the 36 contractions and the output transform in
+// ONE kernel -- neither the transformed input V (2.25x the activations) nor the transformed output M ever exists in HBM.
+// The via-HBM form (winograd.h) moves ~5.6x a convolution's algorithmic bytes for the 64/128-channel VGG-D layers
+// (conv1_2 at batch 256: 36 GB for 6.6 GB of tensors) and its 64-channel contractions are HBM-bound at 60 TFLOP/s.
+//
+// What forces the shape of this kernel: the output transform needs all 36 transform-domain values of an (output tile,
+// channel) pair at once, so a workgroup must hold 36 accumulators per output element: 36 x tiles x channels fp32 in
+// registers.  With the CU's 128 K registers that is a 64 x 32 (tiles x channels) block at most, and the 160 KB LDS
+// cannot hold V for it beyond a few channels.  So:
+//   * MFMA v_mfma_f32_16x16x4_f32, one wave = 16 tiles x 32 channels x 36 positions = 72 accumulator tiles = 288 registers;
+//     4 waves (one per SIMD) = 64 tiles x 32 channels per workgroup, up to 512 registers per lane.
+//   * A operand (V) is never staged: lane (tile = l & 15, g = l >> 4) of the 16x16x4 A layout owns channels 2g, 2g+1 of an
+//     8-channel chunk of ITS tile, computes B^T d B for them in registers and feeds the 36 x 2 values straight to the MFMAs
+//     (the lane that transforms is the lane that supplies the fragment).
+//   * the raw 6x6 patches arrive by LDS-DMA (buffer_load ... lds, no VGPR round trip): the (4 GH + 2) x (4 GW + 2) pixel
+//     region of the wave's GH x GW tile group, 8 channels at a time, double buffered, private to the wave (no barrier);
+//     out-of-image pixels are out-of-range buffer offsets and land as zeros.  The region is stored space-to-depth
+//     (pixels with equal (y mod 4, x mod 4) adjacent) so the 16 tiles' reads of one patch position hit 16 distinct banks.
+//   * B operand (U = G w G^T) is pre-arranged in HBM in FRAGMENT order -- [k block][c chunk][z][j][lane][e] -- by the weight
+//     transform, so a chunk is one contiguous 36 KB piece: LDS-DMA copies it linearly (shared by the 4 waves, double
+//     buffered, one barrier per chunk) and every fragment read is a conflict-free linear ds_read_b64.
+//   * the epilogue applies A^T M A + bias in registers (each lane holds all 36 z of its (tile, channel) outputs) and stores.
+// Per 8-channel chunk a wave issues 144 MFMAs (4608 cycles) against 288 transform VALU, 108 LDS reads and 20 DMA issues.
+// Spec of the arithmetic: lib/nnc/cmd/convolution/cpu_opt/_ccv_nnc_conv_cpu_4x4_3x3_winograd.c:126- (same matrices as winograd.h).
+#pragma once
+#include <utility>
+#include "winograd.h"
+
+namespace nnc {
+
+constexpr int WF_KT = 32;                       // output channels per workgroup (2 MFMA column tiles per wave)
+constexpr int WF_CC = 8;                        // reduction channels per chunk
+constexpr int WF_U_FLOATS = 36 * 2 * 64 * 2;    // one chunk of U fragments: [z][j][lane][e], 36 KB
+constexpr int WF_HP = 352;                      // pixel slots per channel-half plane of a patch buffer (11 DMA pieces x 64 granules / 2)
+constexpr int WF_P_FLOATS = 2 * WF_HP * 4;      // one patch buffer: [h][slot][4 channels], 11 KB
+constexpr int WF_P_PIECES = 11;
+constexpr unsigned WF_OOB = 0x7ffff000u;        // a buffer offset beyond every image: the DMA writes zeros
+
+// compile-time loop: f(GroupId<0>()) ... f(GroupId<N - 1>()) -- every index a constant, whatever the unroller's budget says
+template <class F, int... I> __device__ __forceinline__ void wf_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(GroupId<I>()), ...); }
+template <int N, class F> __device__ __forceinline__ void wf_static_for(F&& f) { wf_static_for_impl(f, std::make_integer_sequence<int, N>()); }
+
+struct f2 {
+	float x, y;
+	__device__ __forceinline__ f2() {}
+	__device__ __forceinline__ f2(float a, float b) : x(a), y(b) {}
+};
+__device__ __forceinline__ f2 operator+(const f2 a, const f2 b) { return f2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ f2 operator-(const f2 a, const f2 b) { return f2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ f2 operator*(const float s, const f2 a) { return f2(s * a.x, s * a.y); }
+__device__ __forceinline__ f2 operator*(const f2 a, const float s) { return f2(s * a.x, s * a.y); }
+
+// Space-to-depth slot of region pixel (Y, X) for a GH x GW tile group: planes by (Y & 3, X & 3), plane (yy, xx) holds
+// (GH + (yy < 2)) x (GW + (xx < 2)) pixels row-major.  The 16 tiles of a wave read pixel (4 ty + r, 4 tx + c): same plane,
+// slots ty * pitch + tx + const -- 16 distinct 16-byte granules (pitch = GW), or 16 with three pairs colliding (pitch = GW + 1).
+template <int GH, int GW>
+struct WfGeom {
+	static constexpr int RH = 4 * GH + 2, RW = 4 * GW + 2, NPIX = RH * RW;
+	static_assert(GH * GW == 16 && NPIX <= WF_HP, "tile group must be 16 tiles whose patch region fits the buffer");
+	static constexpr __host__ __device__ int cy(int yy) { return GH + (yy < 2 ? 1 : 0); }
+	static constexpr __host__ __device__ int cx(int xx) { return GW + (xx < 2 ? 1 : 0); }
+	static constexpr __host__ __device__ int plane_off(int yy, int xx)
+	{
+		int o = 0;
+		for (int p = 0; p < yy * 4 + xx; p++) o += cy(p >> 2) * cx(p & 3);
+		return o;
+	}
+	static constexpr __host__ __device__ int slot(int Y, int X) { return plane_off(Y & 3, X & 3) + (Y >> 2) * cx(X & 3) + (X >> 2); }
+};
+// slot -> (Y << 8 | X), built at compile time; lives in the code object (no upload)
+template <int GH, int GW>
+struct WfSlotTab {
+	unsigned short yx[WF_HP];
+	constexpr WfSlotTab() : yx()
+	{
+		for (int i = 0; i < WF_HP; i++) yx[i] = 0xffff;
+		for (int Y = 0; Y < WfGeom<GH, GW>::RH; Y++)
+			for (int X = 0; X < WfGeom<GH, GW>::RW; X++) yx[WfGeom<GH, GW>::slot(Y, X)] = (unsigned short)(Y << 8 | X);
+	}
+};
+template <int GH, int GW> __device__ __constant__ const WfSlotTab<GH, GW> wf_slot_tab = WfSlotTab<GH, GW>();
+
+// U fragments: uf[((kb * CCn + cc) * 36 + z) * 2 + j][lane = g * 16 + n][e] = (G w G^T)[z] for output channel
+// k = kb * 32 + j * 16 + n (zero beyond K) and reduction channel c = cc * 8 + 2 g + e.   FLIP (dgrad): the roles of the
+// weight tensor's two channel dimensions swap and the taps mirror, as in wino_weight_kernel.
+// One thread per (k, c) of the PADDED k range.
+template <bool FLIP>
+static __global__ void __launch_bounds__(256) wino_weight_frag_kernel(const float* __restrict__ w, float* __restrict__ uf, const int Kout, const int Cred, const int Kw, const int Cw)
+{
+	// Kout / Cred: output and reduction channel counts of THIS convolution; w is [Kw][3][3][Cw] (forward: Kw = Kout, Cw = Cred; FLIP: Kw = Cred, Cw = Kout)
+	const int KB = (Kout + WF_KT - 1) / WF_KT, CCn = Cred / WF_CC;
+	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (long)KB * WF_KT * Cred) return;
+	const int k = (int)(idx / Cred), c = (int)(idx - (long)k * Cred);
+	float g[3][3];
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+#pragma unroll
+		for (int j = 0; j < 3; j++)
+			g[i][j] = k < Kout ? (FLIP ? w[((long)c * 9 + (2 - i) * 3 + (2 - j)) * Cw + k] : w[((long)k * 9 + i * 3 + j) * Cw + c]) : 0.f;
+	(void)Kw;
+	float t[6][3];
+#pragma unroll
+	for (int j = 0; j < 3; j++) {
+		const float col[3] = { g[0][j], g[1][j], g[2][j] };
+		float y[6];
+		wino_g(col, y);
+#pragma unroll
+		for (int i = 0; i < 6; i++) t[i][j] = y[i];
+	}
+	const int kb = k / WF_KT, j16 = (k % WF_KT) / 16, n = k % 16;
+	const int cc = c / WF_CC, gg = (c % WF_CC) / 2, e = c % 2;
+	float* const dst = uf + ((long)(kb * CCn + cc) * 36 * 2 + j16) * 128 + (gg * 16 + n) * 2 + e;
+#pragma unroll
+	for (int i = 0; i < 6; i++) {
+		float y[6];
+		wino_g(t[i], y);
+#pragma unroll
+		for (int jx = 0; jx < 6; jx++) dst[(long)(i * 6 + jx) * 256] = y[jx];
+	}
+}
+
+struct WinoFusedArgs {
+	const float* src;   // NHWC, channels dense
+	float* dst;
+	const float* uf;    // U fragments (wino_weight_frag_kernel)
+	const float* bias;  // [K] or null
+	long s_sn, s_sh, s_sw, d_sn, d_sh, d_sw; // element strides
+	int H, W, OH, OW;   // source / destination extents
+	int pad_y, pad_x;   // source padding (first tile's patch starts at -pad)
+	int GYn, GXn;       // tile groups per image column / row
+	int groups;         // N * GYn * GXn
+	int C, K;           // reduction / output channels
+	int CCn, KB;        // C / 8, ceil(K / 32)
+	unsigned src_image_bytes; // range of the per-image buffer descriptor
+	unsigned uf_kb_bytes;     // bytes of one k block of U fragments (CCn * 36 KB)
+};
+
+// s_waitcnt with only vmcnt counted (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+#define WF_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+
+// One MFMA, accumulating in place.  hipcc's builtin cannot be used here: the wave owns 72 accumulator tiles (288 registers)
+// while the accumulator file holds 256, and with the builtin hipcc keeps EVERY tile in VGPRs and copies it through a[0:7]
+// around each MFMA (measured: 554 v_accvgpr_write + 308 v_accvgpr_read per chunk).  As an asm statement the register
+// class is part of the operand: 64 tiles live in AGPRs ("+a"), the last 8 in VGPRs ("+v"), all in place.  What hipcc does not
+// do for an asm MFMA (cdna guide 5.7) is handled by construction: its A operand was computed at least a whole slot earlier
+// (VALU -> MFMA operand needs 2 wait states), its B operand comes from a ds_read hipcc waits for, and the epilogue's first
+// read of an accumulator sits behind explicit s_nops.
+#ifdef NNC_HIP_EMULATOR
+#define WF_MFMA(ACC, A, B, IN_AGPR) (ACC) = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (ACC), 0, 0, 0)
+#else
+#define WF_MFMA(ACC, A, B, IN_AGPR) do { \
+		if (IN_AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B)); \
+		else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B)); \
+	} while (0)
+#endif
+
+// One LDS-DMA piece: every lane copies 16 bytes from (descriptor base + VOFF + SOFF) to LDS byte address LDS_ADDR + 16 * lane; a
+// lane whose offset is out of the descriptor's range writes zeros.  As an asm statement for a different reason than the MFMA:
+// hipcc counts a builtin LDS-DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY part
+// of the array (measured: one per iteration) -- the pipeline would be synchronous.  Invisible to hipcc, the pieces are
+// waited for by the kernel's own counted WF_WAIT_VMCNT.  M0 (the LDS destination base) is written in the statement that
+// uses it and restored (cdna guide 5.7).
+typedef int wf_rsrc_t __attribute__((ext_vector_type(4)));
+#ifdef NNC_HIP_EMULATOR
+__device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned bytes)
+{
+	const unsigned long long b = (unsigned long long)base;
+	return wf_rsrc_t{ (int)(unsigned)b, (int)(unsigned)(b >> 32), (int)bytes, 0 };
+}
+__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_dst, unsigned voff, unsigned soff)
+{
+	const unsigned long long b = (unsigned long long)(unsigned)r[0] | (unsigned long long)(unsigned)r[1] << 32;
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (unsigned)r[2], 0), (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+#else
+__device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned bytes)
+{ // raw buffer descriptor (stride 0), word 3 = the gfx90a / gfx94x / gfx950 raw-buffer format word; all four words wave-uniform
+	const unsigned long long b = (unsigned long long)base;
+	return wf_rsrc_t{ __builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32) & 0xffff), __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000 };
+}
+__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_dst, unsigned voff, unsigned soff)
+{
+	const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds_dst);
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+		: "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+#endif
+
+// One third (PART) of the six-point transform y = B^T x on two channels at once, one f2 operation (K) at a time -- the kernel
+// slots exactly one such operation (2 VALU) behind every MFMA.  T: a, b, c, t, m, n of
+//   a = x4 - 4 x2, b = x3 - 4 x1, c = x4 - x2, t = x3 - x1, m = x4 - 5 x2, n = x5 - 5 x3
+//   y0 = 4 x0 + m, y1 = a + b, y2 = a - b, y3 = c + 2 t, y4 = c - 2 t, y5 = 4 x1 + n          (= wino_bt)
+// (each result is pinned where it is computed: hipcc otherwise sinks the whole transform to the end of the loop body, behind
+// the last MFMA, whatever the sched_barrier fences say -- they bind the machine scheduler, not the IR passes before it)
+#define WF_PIN2(v) do { NNC_PIN_V((v).x); NNC_PIN_V((v).y); } while (0)
+template <int PART, int K>
+__device__ __forceinline__ void wf_bt_op(const f2& x0, const f2& x1, const f2& x2, const f2& x3, const f2& x4, const f2& x5, f2& y0, f2& y1, f2& y2, f2& y3, f2& y4, f2& y5, f2 (&T)[6])
+{
+	if (PART == 0) {
+		if (K == 0) { T[0] = x4 - 4.f * x2; WF_PIN2(T[0]); }
+		else if (K == 1) { T[1] = x3 - 4.f * x1; WF_PIN2(T[1]); }
+		else if (K == 2) { T[2] = x4 - x2; WF_PIN2(T[2]); }
+		else { T[3] = x3 - x1; WF_PIN2(T[3]); }
+	} else if (PART == 1) {
+		if (K == 0) { T[4] = x4 - 5.f * x2; WF_PIN2(T[4]); }
+		else if (K == 1) { y0 = 4.f * x0 + T[4]; WF_PIN2(y0); }
+		else if (K == 2) { y1 = T[0] + T[1]; WF_PIN2(y1); }
+		else { y2 = T[0] - T[1]; WF_PIN2(y2); }
+	} else {
+		if (K == 0) { y3 = T[2] + 2.f * T[3]; WF_PIN2(y3); }
+		else if (K == 1) { y4 = T[2] - 2.f * T[3]; WF_PIN2(y4); }
+		else if (K == 2) { T[5] = x5 - 5.f * x3; WF_PIN2(T[5]); }
+		else { y5 = 4.f * x1 + T[5]; WF_PIN2(y5); }
+	}
+}
+
+template <int GH, int GW>
+__global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs a)
+{
+	typedef WfGeom<GH, GW> G;
+	constexpr int GWL = GW == 4 ? 2 : (GW == 8 ? 3 : (GW == 2 ? 1 : (GW == 16 ? 4 : 0)));
+	__shared__ __attribute__((aligned(16))) float lds[2 * WF_U_FLOATS + 8 * WF_P_FLOATS]; // 160 KB: [U ring x2][patch x2 per wave]
+	const int t = threadIdx.x;
+	const int lane = t & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	// XCD-aware bijection (cdna guide T1): consecutive work items run on one XCD back to back, and the KB k blocks of a
+	// group quad are consecutive work items -- their patch lines are served by that XCD's L2.
+	int work;
+	{
+		const int nwg = gridDim.x, bid = blockIdx.x;
+		const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+		work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+	}
+	const int gq = work / a.KB, kb = work - gq * a.KB;
+	int group = gq * 4 + wave;
+	const bool group_live = group < a.groups;
+	if (!group_live) group = a.groups - 1; // computes a duplicate, stores nothing
+	const int gpi = a.GYn * a.GXn;
+	const int n = group / gpi, gr = group - n * gpi;
+	const int gy = gr / a.GXn, gx = gr - gy * a.GXn;
+	const int Y0 = gy * GH * 4 - a.pad_y, X0 = gx * GW * 4 - a.pad_x; // region origin in source coordinates
+	const int ti = lane & 15, g = lane >> 4;
+	const int ty = ti >> GWL, tx = ti & (GW - 1);
+
+	float* const ubuf = lds;
+	float* const pbuf = lds + 2 * WF_U_FLOATS + wave * 2 * WF_P_FLOATS;
+
+	// ---- DMA descriptors
+	const wf_rsrc_t rs_src = wf_make_rsrc(a.src + (long)n * a.s_sn, a.src_image_bytes);
+	const wf_rsrc_t rs_u = wf_make_rsrc(a.uf + (long)kb * (a.uf_kb_bytes / 4), a.uf_kb_bytes);
+	unsigned pvoff[WF_P_PIECES];
+#pragma unroll
+	for (int q = 0; q < WF_P_PIECES; q++) {
+		const int s = q * 64 + lane;
+		const int hh = s >= WF_HP ? 1 : 0, slot = s - hh * WF_HP;
+		const unsigned yx = wf_slot_tab<GH, GW>.yx[slot];
+		const int Y = Y0 + (int)(yx >> 8), X = X0 + (int)(yx & 255);
+		const bool ok = (yx != 0xffffu) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+		pvoff[q] = ok ? (unsigned)(((long)Y * a.s_sh + (long)X * a.s_sw + 4 * hh) * 4) : WF_OOB;
+	}
+	const unsigned uvoff = (unsigned)lane * 16u;
+	// one LDS-DMA piece (1 KB): q < 11 a patch piece of chunk `cp` into patch buffer cp & 1, q >= 11 this wave's ninth of U chunk `cu`.
+	// Past the last chunk the piece is issued all the same with every lane out of range (zeros, no memory traffic): no branch
+	// cuts the hand-ordered instruction stream into basic blocks.
+	auto dma_piece = [&](auto qc, const int cp, const int cu) {
+		constexpr int q = decltype(qc)::value;
+		if constexpr (q < WF_P_PIECES) wf_dma16(rs_src, pbuf + (cp & 1) * WF_P_FLOATS + q * 256, cp < a.CCn ? pvoff[q] : WF_OOB, (unsigned)cp * (WF_CC * 4));
+		else {
+			const int piece = wave * 9 + (q - WF_P_PIECES);
+			wf_dma16(rs_u, ubuf + (cu & 1) * WF_U_FLOATS + piece * 256, cu < a.CCn ? uvoff : WF_OOB, (unsigned)cu * (WF_U_FLOATS * 4) + (unsigned)piece * 1024u);
+		}
+	};
+
+	floatx4 acc[36][2];
+#pragma unroll
+	for (int z = 0; z < 36; z++)
+#pragma unroll
+		for (int j = 0; j < 2; j++) acc[z][j] = floatx4{ 0.f, 0.f, 0.f, 0.f };
+
+	// per-lane read offsets (floats) into a patch buffer: slot(4 ty + r, 4 tx + c) = const(r, c) + ty * cx(c & 3) + tx
+	const int h = g >> 1;
+	const int pbase = h * WF_HP * 4 + 2 * (g & 1);
+	const int b5 = (ty * (GW + 1) + tx) * 4 + pbase, b4 = (ty * GW + tx) * 4 + pbase;
+	auto patch_read = [&](const float* const pb, const int r, const int c) -> f2 {
+		const int off = (G::plane_off(r & 3, c & 3) + (r >> 2) * G::cx(c & 3) + (c >> 2)) * 4 + ((c & 3) < 2 ? b5 : b4);
+		const float2 v = *(const float2*)(pb + off);
+		return f2(v.x, v.y);
+	};
+
+	// ---- prologue: chunk 0 transformed completely (S, then V columns 0..4; column 5 is the first work of the loop), chunk 1 in flight
+	f2 S[6][6], V[6][6], T[6]; // S[row][column] = d B; V[zy][zx] = B^T S
+#ifndef NNC_HIP_EMULATOR
+	asm volatile("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them (5 wait states)
+#endif
+	wf_static_for<WF_P_PIECES + 9>([&](auto qc) { dma_piece(qc, 0, 0); });
+	wf_static_for<WF_P_PIECES>([&](auto qc) { dma_piece(qc, 1, 0); });
+	WF_WAIT_VMCNT(WF_P_PIECES); // chunk 0's patch and this wave's share of U(0) have landed; chunk 1's patch may still fly
+#pragma unroll
+	for (int r = 0; r < 6; r++) {
+		f2 d[6];
+#pragma unroll
+		for (int c = 0; c < 6; c++) d[c] = patch_read(pbuf, r, c);
+		wino_bt(d, S[r]);
+	}
+#pragma unroll
+	for (int zx = 0; zx < 5; zx++) {
+		const f2 col[6] = { S[0][zx], S[1][zx], S[2][zx], S[3][zx], S[4][zx], S[5][zx] };
+		f2 y[6];
+		wino_bt(col, y);
+#pragma unroll
+		for (int zy = 0; zy < 6; zy++) V[zy][zx] = y[zy];
+	}
+
+#define WF_OPS(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5) do { \
+		if constexpr (part == 0 && k == 0) wf_bt_op<0, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 0 && k == 1) wf_bt_op<0, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 0 && k == 2) wf_bt_op<0, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 0 && k == 3) wf_bt_op<0, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 1 && k == 0) wf_bt_op<1, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 1 && k == 1) wf_bt_op<1, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 1 && k == 2) wf_bt_op<1, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 1 && k == 3) wf_bt_op<1, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 2 && k == 0) wf_bt_op<2, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 2 && k == 1) wf_bt_op<2, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 2 && k == 2) wf_bt_op<2, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		if constexpr (part == 2 && k == 3) wf_bt_op<2, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+	} while (0)
+	// ---- main loop: trip cc multiplies chunk cc (V) while it transforms chunk cc + 1 and fetches chunk cc + 2 / U(cc + 1).
+	// 36 iterations of 4 MFMAs (iteration it: position z = (it % 6) * 6 + it / 6, column by column); behind EVERY MFMA one f2
+	// operation of a transform, at most one LDS read and at most one DMA piece, fenced so hipcc keeps them there:
+	//   transform 0      (it 0-2)   V[.][5] of THIS chunk from S[.][5]            (its MFMAs are it 30-35)
+	//   transforms 1-6   (it 3-20)  S'[r] = d'[r] B of the NEXT chunk, row r's 6 patch reads issued in the 3 iterations before
+	//   transforms 7-11  (it 21-35) V'[.][c] of the next chunk, c = 0..4, each after column c's MFMAs of this chunk are done
+	for (int cc = 0; cc < a.CCn; cc++) {
+		const int cur = cc & 1;
+		WF_WAIT_VMCNT(0);             // everything this wave fetched during the previous trip: patch(cc + 1), its share of U(cc)
+		__builtin_amdgcn_s_barrier(); // => all of U(cc) is in LDS, and every wave is done reading U(cc - 1) / its patch(cc)
+		const float* const ub = ubuf + cur * WF_U_FLOATS + lane * 2;
+		const float* const pbn = pbuf + (cur ^ 1) * WF_P_FLOATS; // patch of chunk cc + 1
+		f2 d[2][6];
+		float2 u[2][2];
+		u[0][0] = *(const float2*)(ub + 0 * 128);
+		u[0][1] = *(const float2*)(ub + 1 * 128);
+		wf_static_for<36>([&](auto itc) {
+			constexpr int it = decltype(itc)::value;
+			constexpr int zx = it / 6, zy = it % 6, z = zy * 6 + zx;
+			constexpr int tr = it / 3, part = it % 3;
+			wf_static_for<4>([&](auto kc) {
+				constexpr int k = decltype(kc)::value;
+				if constexpr (k < 2) WF_MFMA(acc[z][k & 1], V[zy][zx].x, u[it & 1][k & 1].x, z < 32);
+				else WF_MFMA(acc[z][k & 1], V[zy][zx].y, u[it & 1][k & 1].y, z < 32);
+				// (a) the f2 operation
+				if constexpr (tr == 0) {
+					WF_OPS(S[0][5], S[1][5], S[2][5], S[3][5], S[4][5], S[5][5], V[0][5], V[1][5], V[2][5], V[3][5], V[4][5], V[5][5]);
+				} else if constexpr (tr <= 6) {
+					constexpr int r = tr - 1;
+					WF_OPS(d[r & 1][0], d[r & 1][1], d[r & 1][2], d[r & 1][3], d[r & 1][4], d[r & 1][5], S[r][0], S[r][1], S[r][2], S[r][3], S[r][4], S[r][5]);
+				} else {
+					constexpr int c = tr - 7;
+					WF_OPS(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], S[5][c], V[0][c], V[1][c], V[2][c], V[3][c], V[4][c], V[5][c]);
+				}
+				// (b) LDS reads: the NEXT iteration's two U fragments (slots 0, 1); the next chunk's patch, two elements per iteration (slots 2, 3)
+				if constexpr (k < 2 && it + 1 < 36) {
+					constexpr int itn = it + 1, zn = (itn % 6) * 6 + itn / 6;
+					u[itn & 1][k] = *(const float2*)(ub + (zn * 2 + k) * 128);
+				}
+				if constexpr (k >= 2 && it < 18) {
+					constexpr int e = it * 2 + (k - 2), r = e / 6, c = e % 6; // row r is transformed in iterations 3 + 3 r .. 5 + 3 r
+					d[r & 1][c] = patch_read(pbn, r, c);
+				}
+				// (c) DMA, one piece per iteration: this wave's share of U(cc + 1), then chunk cc + 2's patch (into the buffer of chunk cc's,
+				// read during the previous trip): both have the rest of this trip and the barrier to land
+				if constexpr (k == 3 && it < 9) dma_piece(GroupId<WF_P_PIECES + it>(), 0, cc + 1);
+				if constexpr (k == 3 && it >= 9 && it < 9 + WF_P_PIECES) dma_piece(GroupId<(it >= 9 ? it - 9 : 0)>(), cc + 2, 0);
+				__builtin_amdgcn_sched_barrier(0);
+			});
+		});
+	}
+#undef WF_OPS
+#ifndef NNC_HIP_EMULATOR
+	asm volatile("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
+#endif
+
+	// ---- epilogue: b = A^T M A (+ bias) for the lane's 4 tiles x 2 channels, straight from the accumulators
+	// D layout of 16x16x4: column (output channel) = lane & 15, row (tile) = 4 * (lane >> 4) + r
+#pragma unroll
+	for (int j = 0; j < 2; j++) {
+		const int k = kb * WF_KT + j * 16 + ti;
+		const float bv = (a.bias && k < a.K) ? a.bias[k] : 0.f;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int tile = 4 * g + r;
+			const int oy0 = (gy * GH + (tile >> GWL)) * 4, ox0 = (gx * GW + (tile & (GW - 1))) * 4;
+			float s[4][6]; // columns transformed vertically
+#pragma unroll
+			for (int zx = 0; zx < 6; zx++) {
+				const float col[6] = { acc[0 * 6 + zx][j][r], acc[1 * 6 + zx][j][r], acc[2 * 6 + zx][j][r], acc[3 * 6 + zx][j][r], acc[4 * 6 + zx][j][r], acc[5 * 6 + zx][j][r] };
+				float y[4];
+				wino_at(col, y);
+#pragma unroll
+				for (int i = 0; i < 4; i++) s[i][zx] = y[i];
+			}
+			float* const drow = a.dst + (long)n * a.d_sn + k;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				float y[4];
+				wino_at(s[i], y);
+				const int oy = oy0 + i;
+#pragma unroll
+				for (int jj = 0; jj < 4; jj++) {
+					const int ox = ox0 + jj;
+					if (group_live & (k < a.K) & (oy < a.OH) & (ox < a.OW)) drow[(long)oy * a.d_sh + (long)ox * a.d_sw] = y[jj] + bv;
+				}
+			}
+		}
+	}
+}
+
+} // namespace nnc

@@ -23,6 +23,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
+#define __constant__
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::dyn_smem();
 #define warpSize 64
@@ -140,6 +141,22 @@ static inline emu_floatx4 emu_mfma_f32_16x16x4f32(float a, float b, emu_floatx4 
 	emu::wave_sync();
 	return c;
 }
+// LDS-DMA (buffer_load ... lds): every lane copies `size` bytes from base + voffset + soffset + inst_offset to lds + lane * size;
+// a lane whose offset reaches past num_records writes zeros (raw-buffer range check).  Synchronous here: the emulator cannot
+// show a missing s_waitcnt vmcnt -- only the MI355X tier can.
+struct emu_buffer_rsrc { const char* base; unsigned num_records; };
+typedef emu_buffer_rsrc __amdgpu_buffer_rsrc_t;
+static inline emu_buffer_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, unsigned num_records, int) { return emu_buffer_rsrc{ (const char*)p, num_records }; }
+static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(emu_buffer_rsrc r, __attribute__((address_space(3))) void* lds, unsigned size, unsigned voffset, unsigned soffset, unsigned ioffset, unsigned)
+{
+	char* const d = (char*)lds + (size_t)emu::lane() * size;
+	const unsigned long long off = (unsigned long long)voffset + ioffset;
+	if (off + size > r.num_records || off + soffset + size > r.num_records) memset(d, 0, size);
+	else memcpy(d, r.base + off + soffset, size);
+}
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() emu::syncthreads()
+#define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

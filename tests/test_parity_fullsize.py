@@ -151,8 +151,16 @@ def test_baseline_config_1(backend, ref_lib, fmt):
 @pytest.mark.gpu
 def test_vgg_d_full_step_n2_vs_cpu_ref(gpu_lib, ref_lib):
     """One whole VGG-D training step (forward + backward + SGD, 225 x 225 x 3 input, the benchmark's command sequence and
-    its default algorithm choices) at batch 2: per-image loss, softmax, EVERY parameter gradient and EVERY updated parameter
-    against the reference's CPU backend driven through the same commands."""
+    its default algorithm choices) at batch 2 against the reference's CPU backend driven through the same commands.
+      forward : per-image loss and softmax, and EVERY activation (post-ReLU conv / fc outputs, pool outputs) to 1e-4 of the
+                tensor's scale;
+      backward: EVERY parameter gradient to 1e-4 of its scale and EVERY updated parameter -- with the oracle's backward pass
+                reading the SAME forward state as ours (the GPU's activations are copied into the oracle's tensors first).
+    Why the hand-over: ReLU and max-pool route gradients by comparisons on the forward values.  Two fp32 forward passes that
+    agree to 1e-5 still disagree on the sign / the arg-max of a few activations in a few million, and every such flip moves a
+    whole gradient element: run end to end, the two backward passes differ by ~sqrt(flipped fraction) ~ 0.5 % in L2 (measured
+    on the MI355X: 0.9 % at conv1_1 falling to 0.05 % at conv5_3; the loss agrees to 3e-6) -- a property of comparing ANY two
+    fp32 implementations through 16 ReLU layers, not of either one.  The count of disagreeing ReLU masks is reported."""
     from ccv_amd.vgg import VGGD
     rng = np.random.default_rng(17)
     x = rng.random((2, 225, 225, 3), dtype=F)
@@ -160,14 +168,30 @@ def test_vgg_d_full_step_n2_vs_cpu_ref(gpu_lib, ref_lib):
     net = VGGD(gpu_lib, 2, seed=0)
     net.set_input(x, y)
     gpu_lib.stream_wait(None)
-    net.step()
+    net.forward()
     gpu_lib.stream_wait(None)
     ref = VGGD(ref_lib, 2, memory=nnc.CPU_MEMORY, seed=0, backend=nnc.BACKEND_CPU_REF, pool_per_image=True)
     ref.set_input(x, y)
-    ref.step()
+    ref.forward()
     np.testing.assert_allclose(net.loss.numpy(), ref.loss.numpy(), rtol=1e-4, atol=0)
     np.testing.assert_allclose(net.softmax.numpy(), ref.softmax.numpy(), rtol=1e-3, atol=1e-7)
-    bad = []
+    bad, flips, total = [], 0, 0
+    for i, (n, m) in enumerate(zip(net.nodes, ref.nodes)):
+        got, want = n["b"].numpy(), m["b"].numpy()
+        err, scale = float(np.abs(got - want).max()), float(np.abs(want).max())
+        if not err <= 1e-4 * scale:
+            bad.append("activation of node %d (%s) %s: max |diff| %.3g vs scale %.3g" % (i, n["kind"], got.shape, err, scale))
+        if n.get("relu"):
+            flips += int(np.count_nonzero((got > 0) != (want > 0)))
+            total += got.size
+        m["b"].array[...] = got  # hand the forward state over: both backward passes now route through identical masks
+    ref.softmax.array[...] = net.softmax.numpy()
+    print("ReLU masks that differ between the two forward passes: %d of %d" % (flips, total))
+    net.backward()
+    net.update()
+    gpu_lib.stream_wait(None)
+    ref.backward()
+    ref.update()
     for i, ((p, d, _), (q, e, _)) in enumerate(zip(net.params, ref.params)):
         dg, de = d.numpy().astype(np.float64), e.numpy().astype(np.float64)
         err, scale = float(np.abs(dg - de).max()), float(np.abs(de).max())

@@ -446,3 +446,38 @@ def test_conv_winograd_image_slices(backend, ref_lib, case):
                 np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(want[i]).max())))
     finally:
         backend.tune_set("WINO_SLICE_KB", 0)
+
+
+FUSED_CASES = [
+    # n, h, w, c, k, border: fused Winograd (algorithm 2): reduction channels % 8 == 0
+    (1, 16, 16, 8, 32, (1, 1)),     # exactly one 4x4 tile group, one chunk, one k block
+    (2, 13, 13, 32, 32, (1, 1)),    # ragged tiles in a 4x4 group (13 -> 4 tiles, 3 clipped rows / columns), several chunks
+    (1, 27, 30, 16, 48, (1, 1)),    # 7 x 8 tiles: the 2x8 group shape, ragged K (48 -> two k blocks, the second half empty)
+    (3, 9, 14, 24, 20, (0, 0)),     # no padding, K < 32
+    (2, 5, 7, 8, 8, (2, 2)),        # full padding
+    (1, 33, 9, 8, 40, (1, 0)),      # tall image: the 8x2 group shape; asymmetric padding
+    (5, 20, 20, 16, 64, (1, 1)),    # more groups than one workgroup's four waves, two k blocks
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_conv_winograd_fused(backend, ref_lib, case):
+    """cmd.algorithm = 2: the fused Winograd kernel (wino_fused.h; LDS-DMA patches, in-register input and output transforms)
+    for forward and the data gradient, against the reference's direct convolution at 1e-4."""
+    n, h, w, c, k, border = case
+    a, wt, b, hint, oh, ow = _wino_inputs(case)
+    cmd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [a, wt, b], [np.zeros((n, oh, ow, k), F)], backend=nnc.BACKEND_CPU_REF)
+    cmd.algorithm = 2
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, hint, 0, [a, wt, b], [np.full((n, oh, ow, k), 7, F)])
+    assert r1 == 0 and r2 == 0
+    assert backend.dll.nnc_mi355x_last_kernel_name().decode() == "conv_fwd_wino_fused"
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-5)
+    g = srnd(np.random.default_rng(5), n, oh, ow, k)
+    bw = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, bw, hint, 0, [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, F)], backend=nnc.BACKEND_CPU_REF)
+    bw.algorithm = 2
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, bw, hint, 0, [g, a, wt], [np.full_like(a, 3), np.zeros_like(wt), np.zeros(k, F)])
+    assert r1 == 0 and r2 == 0
+    for i in range(3):
+        np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(want[i]).max())))

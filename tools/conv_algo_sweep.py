@@ -26,21 +26,22 @@ def main():
         L.dll.nnc_mi355x_event_record(e1, s)
         return L.dll.nnc_mi355x_event_elapsed_ms(e0, e1) / reps
 
-    print("%-22s %9s %9s %7s | %9s %9s %7s" % ("layer (hw, C->K)", "fwd gemm", "fwd wino", "x", "bwd gemm", "bwd wino", "x"))
+    algos = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2]
+    print("batch %d; ms per command under cmd.algorithm = %s (0 implicit GEMM, 1 Winograd via HBM, 2 fused Winograd fwd / dgrad); [..] = MFMA TFLOP/s of the Winograd forms (direct FLOPs / 4)" % (batch, algos))
     for hw, c, k in LAYERS:
         a, w, b, bias = mk(batch, hw, hw, c), mk(k, 3, 3, c), mk(batch, hw, hw, k), mk(k)
         g, h, dw, db = mk(batch, hw, hw, k), mk(batch, hw, hw, c), mk(k, 3, 3, c), mk(k)
         L.cmd_exec(nnc.CMD_SET_FORWARD(0.01), nnc.HINT(), 0, [], [a, w, bias, g], s)
         hint = nnc.HINT((1, 1), (1, 1))
-        row = []
+        direct = 2.0 * batch * hw * hw * k * 9 * c
         for fwd in (True, False):
-            t = []
-            for algo in (0, 1):
+            out = []
+            for algo in algos:
                 cmd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c) if fwd else nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
                 cmd.algorithm = algo
-                t.append(timed(cmd, hint, [a, w, bias] if fwd else [g, a, w], [b] if fwd else [h, dw, db]))
-            row += [t[0], t[1], t[0] / t[1]]
-        print("%-22s %9.3f %9.3f %7.2f | %9.3f %9.3f %7.2f" % ("%d, %d->%d" % (hw, c, k), *row), flush=True)
+                ms = timed(cmd, hint, [a, w, bias] if fwd else [g, a, w], [b] if fwd else [h, dw, db])
+                out.append("a%d %8.3f" % (algo, ms) + (" [%5.1f]" % ((1 if fwd else 2) * direct / 4 / (ms * 1e-3) / 1e12) if algo else ""))
+            print("%-18s %-4s " % ("%d, %d->%d" % (hw, c, k), "fwd" if fwd else "bwd") + "   ".join(out), flush=True)
         for t in (a, w, b, bias, g, h, dw, db):
             t.free()
 
