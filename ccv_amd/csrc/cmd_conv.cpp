@@ -173,6 +173,7 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	a.s_sn = src.sn; a.s_sh = src.sh; a.s_sw = src.sw; a.d_sn = dst.sn; a.d_sh = dst.sh; a.d_sw = dst.sw;
 	a.H = src.h; a.W = src.w; a.OH = dst.h; a.OW = dst.w; a.pad_y = pad_y; a.pad_x = pad_x;
 	a.GYn = p.GYn; a.GXn = p.GXn; a.groups = p.groups; a.C = Cred; a.K = Kout; a.CCn = p.CCn; a.KB = p.KB;
+	a.dst_vec = aligned16(dst.p) && dst.sw % 4 == 0 && dst.sh % 4 == 0 && (dst.n == 1 || dst.sn % 4 == 0);
 	a.src_image_bytes = (unsigned)(((long)(src.h - 1) * src.sh + (long)(src.w - 1) * src.sw + src.c) * 4);
 	a.uf_kb_bytes = (unsigned)((size_t)p.CCn * WF_U_FLOATS * 4);
 	const unsigned grid = (unsigned)((p.groups + 3) / 4 * p.KB);

@@ -16,9 +16,9 @@
 //     region of the wave's GH x GW tile group, 8 channels at a time, double buffered, private to the wave (no barrier);
 //     out-of-image pixels are out-of-range buffer offsets and land as zeros.  The region is stored space-to-depth
 //     (pixels with equal (y mod 4, x mod 4) adjacent) so the 16 tiles' reads of one patch position hit 16 distinct banks.
-//   * B operand (U = G w G^T) is pre-arranged in HBM in FRAGMENT order -- [k block][c chunk][z][j][lane][e] -- by the weight
+//   * B operand (U = G w G^T) is pre-arranged in HBM in FRAGMENT order -- [k block][c chunk][z][lane][j][e] -- by the weight
 //     transform, so a chunk is one contiguous 36 KB piece: LDS-DMA copies it linearly (shared by the 4 waves, double
-//     buffered, one barrier per chunk) and every fragment read is a conflict-free linear ds_read_b64.
+//     buffered, one barrier per chunk) and the four fragments of a position are ONE conflict-free linear ds_read_b128.
 //   * the epilogue applies A^T M A + bias in registers (each lane holds all 36 z of its (tile, channel) outputs) and stores.
 // Per 8-channel chunk a wave issues 144 MFMAs (4608 cycles) against 288 transform VALU, 108 LDS reads and 20 DMA issues.
 // Spec of the arithmetic: lib/nnc/cmd/convolution/cpu_opt/_ccv_nnc_conv_cpu_4x4_3x3_winograd.c:126- (same matrices as winograd.h).
@@ -30,7 +30,7 @@ namespace nnc {
 
 constexpr int WF_KT = 32;                       // output channels per workgroup (2 MFMA column tiles per wave)
 constexpr int WF_CC = 8;                        // reduction channels per chunk
-constexpr int WF_U_FLOATS = 36 * 2 * 64 * 2;    // one chunk of U fragments: [z][j][lane][e], 36 KB
+constexpr int WF_U_FLOATS = 36 * 64 * 2 * 2;    // one chunk of U fragments: [z][lane][j][e], 36 KB
 constexpr int WF_HP = 352;                      // pixel slots per channel-half plane of a patch buffer (11 DMA pieces x 64 granules / 2)
 constexpr int WF_P_FLOATS = 2 * WF_HP * 4;      // one patch buffer: [h][slot][4 channels], 11 KB
 constexpr int WF_P_PIECES = 11;
@@ -80,7 +80,7 @@ struct WfSlotTab {
 };
 template <int GH, int GW> __device__ __constant__ const WfSlotTab<GH, GW> wf_slot_tab = WfSlotTab<GH, GW>();
 
-// U fragments: uf[((kb * CCn + cc) * 36 + z) * 2 + j][lane = g * 16 + n][e] = (G w G^T)[z] for output channel
+// U fragments: uf[(kb * CCn + cc) * 36 + z][lane = g * 16 + n][j][e] = (G w G^T)[z] for output channel
 // k = kb * 32 + j * 16 + n (zero beyond K) and reduction channel c = cc * 8 + 2 g + e.   FLIP (dgrad): the roles of the
 // weight tensor's two channel dimensions swap and the taps mirror, as in wino_weight_kernel.
 // One thread per (k, c) of the PADDED k range.
@@ -110,7 +110,7 @@ static __global__ void __launch_bounds__(256) wino_weight_frag_kernel(const floa
 	}
 	const int kb = k / WF_KT, j16 = (k % WF_KT) / 16, n = k % 16;
 	const int cc = c / WF_CC, gg = (c % WF_CC) / 2, e = c % 2;
-	float* const dst = uf + ((long)(kb * CCn + cc) * 36 * 2 + j16) * 128 + (gg * 16 + n) * 2 + e;
+	float* const dst = uf + (long)(kb * CCn + cc) * 36 * 256 + (gg * 16 + n) * 4 + j16 * 2 + e;
 #pragma unroll
 	for (int i = 0; i < 6; i++) {
 		float y[6];
@@ -132,12 +132,17 @@ struct WinoFusedArgs {
 	int groups;         // N * GYn * GXn
 	int C, K;           // reduction / output channels
 	int CCn, KB;        // C / 8, ceil(K / 32)
+	int dst_vec;        // destination pointer and strides allow 16-byte stores
 	unsigned src_image_bytes; // range of the per-image buffer descriptor
 	unsigned uf_kb_bytes;     // bytes of one k block of U fragments (CCn * 36 KB)
 };
 
 // s_waitcnt with only vmcnt counted (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+#ifdef NNC_HIP_EMULATOR // a wave's wait covers the DMA pieces of ALL its lanes: on the emulator (lanes are fibers, DMA is synchronous) that is a wave rendezvous
+#define WF_WAIT_VMCNT(n) __builtin_amdgcn_wave_barrier()
+#else
 #define WF_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+#endif
 
 // One MFMA, accumulating in place.  hipcc's builtin cannot be used here: the wave owns 72 accumulator tiles (288 registers)
 // while the accumulator file holds 256, and with the builtin hipcc keeps EVERY tile in VGPRs and copies it through a[0:7]
@@ -168,10 +173,12 @@ __device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned byt
 	const unsigned long long b = (unsigned long long)base;
 	return wf_rsrc_t{ (int)(unsigned)b, (int)(unsigned)(b >> 32), (int)bytes, 0 };
 }
-__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_dst, unsigned voff, unsigned soff)
+__device__ __forceinline__ unsigned wf_lds_addr(float* p) { return (unsigned)(unsigned long long)p; } // emulator: low half of the host pointer; wf_dma16 gets the base again
+__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_base, unsigned lds_addr, unsigned voff, unsigned soff)
 {
 	const unsigned long long b = (unsigned long long)(unsigned)r[0] | (unsigned long long)(unsigned)r[1] << 32;
-	__builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (unsigned)r[2], 0), (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+	float* const dst = (float*)((char*)lds_base + (lds_addr - wf_lds_addr(lds_base)));
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (unsigned)r[2], 0), (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
 }
 #else
 __device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned bytes)
@@ -179,12 +186,12 @@ __device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned byt
 	const unsigned long long b = (unsigned long long)base;
 	return wf_rsrc_t{ __builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32) & 0xffff), __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000 };
 }
-__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_dst, unsigned voff, unsigned soff)
-{
-	const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds_dst);
-	unsigned keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-		: "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+__device__ __forceinline__ unsigned wf_lds_addr(float* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)p; } // LDS byte address
+__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float*, unsigned lds_addr, unsigned voff, unsigned soff)
+{ // lds_addr / soff: wave-uniform integers the caller keeps in SGPRs (plain integer arithmetic on the array's base address -- a
+  // pointer cast per piece costs hipcc's null check, four SALU).  M0 is not restored: nothing else in this kernel uses it
+  // (checked in the ISA: hipcc's LDS instructions do not read M0 on gfx950, the kernel has no other LDS-DMA and no s_movrel).
+	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 #endif
 
@@ -192,7 +199,7 @@ __device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_dst, unsi
 // slots exactly one such operation (2 VALU) behind every MFMA.  T: a, b, c, t, m, n of
 //   a = x4 - 4 x2, b = x3 - 4 x1, c = x4 - x2, t = x3 - x1, m = x4 - 5 x2, n = x5 - 5 x3
 //   y0 = 4 x0 + m, y1 = a + b, y2 = a - b, y3 = c + 2 t, y4 = c - 2 t, y5 = 4 x1 + n          (= wino_bt)
-// (each result is pinned where it is computed: hipcc otherwise sinks the whole transform to the end of the loop body, behind
+// (each result is pinned where it is computed: hipcc otherwise sinks every transform to the end of the loop body, behind
 // the last MFMA, whatever the sched_barrier fences say -- they bind the machine scheduler, not the IR passes before it)
 #define WF_PIN2(v) do { NNC_PIN_V((v).x); NNC_PIN_V((v).y); } while (0)
 template <int PART, int K>
@@ -216,7 +223,9 @@ __device__ __forceinline__ void wf_bt_op(const f2& x0, const f2& x1, const f2& x
 	}
 }
 
-template <int GH, int GW>
+// DBG (tools/wf_probe.cpp only; the library instantiates DBG = 0): knock parts of the loop out to attribute its time.
+//   1 no DMA in the loop, 2 no patch reads, 4 no U fragment reads, 8 no transform VALU, 16 no MFMAs, 32 no barrier, 64 no epilogue
+template <int GH, int GW, int DBG = 0>
 __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs a)
 {
 	typedef WfGeom<GH, GW> G;
@@ -246,6 +255,10 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 
 	float* const ubuf = lds;
 	float* const pbuf = lds + 2 * WF_U_FLOATS + wave * 2 * WF_P_FLOATS;
+	// LDS byte addresses of the DMA destinations, as integers (wave-uniform: SGPRs)
+	const unsigned lds0 = __builtin_amdgcn_readfirstlane(wf_lds_addr(lds));
+	const unsigned p_lds = lds0 + (2 * WF_U_FLOATS + wave * 2 * WF_P_FLOATS) * 4; // this wave's patch buffers
+	const unsigned u_lds = lds0 + wave * 9 * 1024;                               // this wave's ninth of a U buffer
 
 	// ---- DMA descriptors
 	const wf_rsrc_t rs_src = wf_make_rsrc(a.src + (long)n * a.s_sn, a.src_image_bytes);
@@ -261,17 +274,20 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		pvoff[q] = ok ? (unsigned)(((long)Y * a.s_sh + (long)X * a.s_sw + 4 * hh) * 4) : WF_OOB;
 	}
 	const unsigned uvoff = (unsigned)lane * 16u;
-	// one LDS-DMA piece (1 KB): q < 11 a patch piece of chunk `cp` into patch buffer cp & 1, q >= 11 this wave's ninth of U chunk `cu`.
-	// Past the last chunk the piece is issued all the same with every lane out of range (zeros, no memory traffic): no branch
-	// cuts the hand-ordered instruction stream into basic blocks.
-	auto dma_piece = [&](auto qc, const int cp, const int cu) {
+	// One LDS-DMA piece (1 KB): q < 11 a piece of the patch of chunk cp (soffset sp = cp * 32 bytes) into patch buffer cp & 1;
+	// q >= 11 one of this wave's nine pieces of U chunk cu (su = cu * 36 KB + wave * 9 KB) into U buffer cu & 1.  The caller
+	// clamps cp / cu to the last chunk: past the end the last chunk is simply fetched again into the buffer nobody reads any
+	// more -- no branch and no select in the hand-ordered stream, for two chunks of extra L2 reads per workgroup.
+	auto dma_piece = [&](auto qc, const unsigned p_dst, const unsigned sp, const unsigned u_dst, const unsigned su) {
 		constexpr int q = decltype(qc)::value;
-		if constexpr (q < WF_P_PIECES) wf_dma16(rs_src, pbuf + (cp & 1) * WF_P_FLOATS + q * 256, cp < a.CCn ? pvoff[q] : WF_OOB, (unsigned)cp * (WF_CC * 4));
-		else {
-			const int piece = wave * 9 + (q - WF_P_PIECES);
-			wf_dma16(rs_u, ubuf + (cu & 1) * WF_U_FLOATS + piece * 256, cu < a.CCn ? uvoff : WF_OOB, (unsigned)cu * (WF_U_FLOATS * 4) + (unsigned)piece * 1024u);
-		}
+		if constexpr (q < WF_P_PIECES) wf_dma16(rs_src, lds, p_dst + q * 1024, pvoff[q], sp);
+		else wf_dma16(rs_u, lds, u_dst + (q - WF_P_PIECES) * 1024, uvoff, su + (q - WF_P_PIECES) * 1024);
 	};
+	const int last = a.CCn - 1;
+	auto p_dst_of = [&](const int c) -> unsigned { return p_lds + (c & 1) * (WF_P_FLOATS * 4); };
+	auto u_dst_of = [&](const int c) -> unsigned { return u_lds + (c & 1) * (WF_U_FLOATS * 4); };
+	auto sp_of = [&](const int c) -> unsigned { return (unsigned)(c < last ? c : last) * (WF_CC * 4); };
+	auto su_of = [&](const int c) -> unsigned { return (unsigned)(c < last ? c : last) * (WF_U_FLOATS * 4) + (unsigned)wave * 9216u; };
 
 	floatx4 acc[36][2];
 #pragma unroll
@@ -294,8 +310,8 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 #ifndef NNC_HIP_EMULATOR
 	asm volatile("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them (5 wait states)
 #endif
-	wf_static_for<WF_P_PIECES + 9>([&](auto qc) { dma_piece(qc, 0, 0); });
-	wf_static_for<WF_P_PIECES>([&](auto qc) { dma_piece(qc, 1, 0); });
+	wf_static_for<WF_P_PIECES + 9>([&](auto qc) { dma_piece(qc, p_dst_of(0), sp_of(0), u_dst_of(0), su_of(0)); });
+	wf_static_for<WF_P_PIECES>([&](auto qc) { dma_piece(qc, p_dst_of(1), sp_of(1), 0, 0); });
 	WF_WAIT_VMCNT(WF_P_PIECES); // chunk 0's patch and this wave's share of U(0) have landed; chunk 1's patch may still fly
 #pragma unroll
 	for (int r = 0; r < 6; r++) {
@@ -313,107 +329,175 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		for (int zy = 0; zy < 6; zy++) V[zy][zx] = y[zy];
 	}
 
-#define WF_OPS(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5) do { \
-		if constexpr (part == 0 && k == 0) wf_bt_op<0, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 0 && k == 1) wf_bt_op<0, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 0 && k == 2) wf_bt_op<0, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 0 && k == 3) wf_bt_op<0, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 1 && k == 0) wf_bt_op<1, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 1 && k == 1) wf_bt_op<1, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 1 && k == 2) wf_bt_op<1, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 1 && k == 3) wf_bt_op<1, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 2 && k == 0) wf_bt_op<2, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 2 && k == 1) wf_bt_op<2, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 2 && k == 2) wf_bt_op<2, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
-		if constexpr (part == 2 && k == 3) wf_bt_op<2, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+#define WF_XFORM(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5) do { \
+		wf_bt_op<0, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<0, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		wf_bt_op<0, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<0, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		wf_bt_op<1, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<2, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		wf_bt_op<1, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<1, 2>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		wf_bt_op<1, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<2, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
+		wf_bt_op<2, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<2, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
 	} while (0)
 	// ---- main loop: trip cc multiplies chunk cc (V) while it transforms chunk cc + 1 and fetches chunk cc + 2 / U(cc + 1).
-	// 36 iterations of 4 MFMAs (iteration it: position z = (it % 6) * 6 + it / 6, column by column); behind EVERY MFMA one f2
-	// operation of a transform, at most one LDS read and at most one DMA piece, fenced so hipcc keeps them there:
+	// 36 iterations of 4 MFMAs (iteration it: position z = (it % 6) * 6 + it / 6, column by column); per iteration one U read
+	// (all four fragments of the next position: ds_read_b128), one pair of patch reads and one DMA piece between the MFMAs, and
+	// behind every third iteration one whole transform (24 VALU), fenced so hipcc keeps them there:
 	//   transform 0      (it 0-2)   V[.][5] of THIS chunk from S[.][5]            (its MFMAs are it 30-35)
 	//   transforms 1-6   (it 3-20)  S'[r] = d'[r] B of the NEXT chunk, row r's 6 patch reads issued in the 3 iterations before
 	//   transforms 7-11  (it 21-35) V'[.][c] of the next chunk, c = 0..4, each after column c's MFMAs of this chunk are done
 	for (int cc = 0; cc < a.CCn; cc++) {
 		const int cur = cc & 1;
 		WF_WAIT_VMCNT(0);             // everything this wave fetched during the previous trip: patch(cc + 1), its share of U(cc)
-		__builtin_amdgcn_s_barrier(); // => all of U(cc) is in LDS, and every wave is done reading U(cc - 1) / its patch(cc)
-		const float* const ub = ubuf + cur * WF_U_FLOATS + lane * 2;
+		if constexpr (!(DBG & 32)) __builtin_amdgcn_s_barrier(); // => all of U(cc) is in LDS, and every wave is done reading U(cc - 1) / its patch(cc)
+		const float* const ub = ubuf + cur * WF_U_FLOATS + lane * 4;
 		const float* const pbn = pbuf + (cur ^ 1) * WF_P_FLOATS; // patch of chunk cc + 1
+		const unsigned p_dst = p_dst_of(cc), sp = sp_of(cc + 2), u_dst = u_dst_of(cc + 1), su = su_of(cc + 1); // patch(cc + 2) goes where patch(cc) was
 		f2 d[2][6];
-		float2 u[2][2];
-		u[0][0] = *(const float2*)(ub + 0 * 128);
-		u[0][1] = *(const float2*)(ub + 1 * 128);
+		float4 u[2];
+		if constexpr (DBG & 2) for (int i = 0; i < 12; i++) d[i / 6][i % 6] = f2(1.f, 2.f);
+		if constexpr (DBG & 4) u[1] = make_float4(1.f, 2.f, 3.f, 4.f);
+		u[0] = *(const float4*)(ub);
 		wf_static_for<36>([&](auto itc) {
 			constexpr int it = decltype(itc)::value;
 			constexpr int zx = it / 6, zy = it % 6, z = zy * 6 + zx;
 			constexpr int tr = it / 3, part = it % 3;
 			wf_static_for<4>([&](auto kc) {
 				constexpr int k = decltype(kc)::value;
-				if constexpr (k < 2) WF_MFMA(acc[z][k & 1], V[zy][zx].x, u[it & 1][k & 1].x, z < 32);
-				else WF_MFMA(acc[z][k & 1], V[zy][zx].y, u[it & 1][k & 1].y, z < 32);
-				// (a) the f2 operation
-				if constexpr (tr == 0) {
-					WF_OPS(S[0][5], S[1][5], S[2][5], S[3][5], S[4][5], S[5][5], V[0][5], V[1][5], V[2][5], V[3][5], V[4][5], V[5][5]);
-				} else if constexpr (tr <= 6) {
-					constexpr int r = tr - 1;
-					WF_OPS(d[r & 1][0], d[r & 1][1], d[r & 1][2], d[r & 1][3], d[r & 1][4], d[r & 1][5], S[r][0], S[r][1], S[r][2], S[r][3], S[r][4], S[r][5]);
-				} else {
-					constexpr int c = tr - 7;
-					WF_OPS(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], S[5][c], V[0][c], V[1][c], V[2][c], V[3][c], V[4][c], V[5][c]);
+				// u = { (j0, e0), (j0, e1), (j1, e0), (j1, e1) }; MFMA order j0 e0, j1 e0, j0 e1, j1 e1: an accumulator recurs every 64 cycles (40 needed)
+				if constexpr (DBG & 16) { NNC_PIN_V(acc[z][k & 1][0]); }
+				else if constexpr (k == 0) WF_MFMA(acc[z][0], V[zy][zx].x, u[it & 1].x, z < 32);
+				else if constexpr (k == 1) WF_MFMA(acc[z][1], V[zy][zx].x, u[it & 1].z, z < 32);
+				else if constexpr (k == 2) WF_MFMA(acc[z][0], V[zy][zx].y, u[it & 1].y, z < 32);
+				else WF_MFMA(acc[z][1], V[zy][zx].y, u[it & 1].w, z < 32);
+				// (a) one whole six-point transform (12 f2 operations = 24 VALU) behind every twelfth MFMA.  NOT spread one
+				// operation per MFMA: v_mfma_f32_16x16x4_f32 and fp32 VALU do not overlap on gfx950 (tools/coissue_probe.cpp: 36 cycles
+				// per MFMA alone, 48 / 53 / 61 with 1 / 2 / 4 v_fma behind each, from one or two waves per SIMD alike -- the fp32
+				// matrix rate IS the fp32 vector rate), and the first VALU after an MFMA costs 12 cycles, the following ones 4.3.
+				if constexpr (k == 3 && part == 2 && !(DBG & 8)) {
+					if constexpr (tr == 0) {
+						WF_XFORM(S[0][5], S[1][5], S[2][5], S[3][5], S[4][5], S[5][5], V[0][5], V[1][5], V[2][5], V[3][5], V[4][5], V[5][5]);
+					} else if constexpr (tr <= 6) {
+						constexpr int r = tr - 1;
+						WF_XFORM(d[r & 1][0], d[r & 1][1], d[r & 1][2], d[r & 1][3], d[r & 1][4], d[r & 1][5], S[r][0], S[r][1], S[r][2], S[r][3], S[r][4], S[r][5]);
+					} else {
+						constexpr int c = tr - 7;
+						WF_XFORM(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], S[5][c], V[0][c], V[1][c], V[2][c], V[3][c], V[4][c], V[5][c]);
+					}
 				}
-				// (b) LDS reads: the NEXT iteration's two U fragments (slots 0, 1); the next chunk's patch, two elements per iteration (slots 2, 3)
-				if constexpr (k < 2 && it + 1 < 36) {
+				// (b) LDS reads: slot 0 the NEXT iteration's four U fragments; slot 2 two neighbouring elements of the next chunk's
+				// patch (same base register, so hipcc merges the pair into one ds_read2_b64)
+				if constexpr (k == 0 && it + 1 < 36 && !(DBG & 4)) {
 					constexpr int itn = it + 1, zn = (itn % 6) * 6 + itn / 6;
-					u[itn & 1][k] = *(const float2*)(ub + (zn * 2 + k) * 128);
+					u[itn & 1] = *(const float4*)(ub + zn * 256);
 				}
-				if constexpr (k >= 2 && it < 18) {
-					constexpr int e = it * 2 + (k - 2), r = e / 6, c = e % 6; // row r is transformed in iterations 3 + 3 r .. 5 + 3 r
+				if constexpr (k == 2 && it < 18 && !(DBG & 2)) {
+					constexpr int r = it / 3, c = (it % 3) * 2; // row r is transformed in iterations 3 + 3 r .. 5 + 3 r
 					d[r & 1][c] = patch_read(pbn, r, c);
+					d[r & 1][c + 1] = patch_read(pbn, r, c + 1);
 				}
-				// (c) DMA, one piece per iteration: this wave's share of U(cc + 1), then chunk cc + 2's patch (into the buffer of chunk cc's,
-				// read during the previous trip): both have the rest of this trip and the barrier to land
-				if constexpr (k == 3 && it < 9) dma_piece(GroupId<WF_P_PIECES + it>(), 0, cc + 1);
-				if constexpr (k == 3 && it >= 9 && it < 9 + WF_P_PIECES) dma_piece(GroupId<(it >= 9 ? it - 9 : 0)>(), cc + 2, 0);
+				// (c) DMA, one piece per iteration: this wave's share of U(cc + 1), then chunk cc + 2's patch: both have the rest of
+				// this trip and the barrier to land
+				if constexpr (k == 3 && it < 9 && !(DBG & 1)) dma_piece(GroupId<WF_P_PIECES + it>(), p_dst, sp, u_dst, su);
+				if constexpr (k == 3 && it >= 9 && it < 9 + WF_P_PIECES && !(DBG & 1)) dma_piece(GroupId<(it >= 9 ? it - 9 : 0)>(), p_dst, sp, u_dst, su);
 				__builtin_amdgcn_sched_barrier(0);
 			});
 		});
 	}
-#undef WF_OPS
+#undef WF_XFORM
 #ifndef NNC_HIP_EMULATOR
 	asm volatile("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
 #endif
+	if constexpr (DBG & 64) { if (a.bias == (const float*)1) a.dst[t] = acc[0][0][0] + acc[35][1][3] + acc[17][0][1]; return; }
 
-	// ---- epilogue: b = A^T M A (+ bias) for the lane's 4 tiles x 2 channels, straight from the accumulators
-	// D layout of 16x16x4: column (output channel) = lane & 15, row (tile) = 4 * (lane >> 4) + r
+	// ---- epilogue: b = A^T M A (+ bias) straight from the accumulators -- each lane holds all 36 positions of its 4 tiles x 2
+	// channels (D layout of 16x16x4: column (channel) = lane & 15, row (tile) = 4 * (lane >> 4) + r) -- then through LDS so
+	// that a lane stores 16 bytes and a wave whole 128-byte lines: 128 four-byte stores per lane straight from the registers
+	// were store-issue bound (1.7 ms of conv1_2's 5.4 at batch 256).  Staging: one round per r (the 4 tiles 4 g' + r, g' = 0..3:
+	// 4 tiles x 16 pixels x 32 channels + padding = 9 KB per wave, private: no barrier between rounds).
+	if constexpr (DBG & 128) { // direct stores from the registers (the first version; kept for the probe)
 #pragma unroll
-	for (int j = 0; j < 2; j++) {
-		const int k = kb * WF_KT + j * 16 + ti;
-		const float bv = (a.bias && k < a.K) ? a.bias[k] : 0.f;
+		for (int j = 0; j < 2; j++) {
+			const int k = kb * WF_KT + j * 16 + ti;
+			const float bv = (a.bias && k < a.K) ? a.bias[k] : 0.f;
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const int tile = 4 * g + r;
-			const int oy0 = (gy * GH + (tile >> GWL)) * 4, ox0 = (gx * GW + (tile & (GW - 1))) * 4;
-			float s[4][6]; // columns transformed vertically
+			for (int r = 0; r < 4; r++) {
+				const int tile = 4 * g + r;
+				const int oy0 = (gy * GH + (tile >> GWL)) * 4, ox0 = (gx * GW + (tile & (GW - 1))) * 4;
+				float s[4][6];
 #pragma unroll
-			for (int zx = 0; zx < 6; zx++) {
-				const float col[6] = { acc[0 * 6 + zx][j][r], acc[1 * 6 + zx][j][r], acc[2 * 6 + zx][j][r], acc[3 * 6 + zx][j][r], acc[4 * 6 + zx][j][r], acc[5 * 6 + zx][j][r] };
-				float y[4];
-				wino_at(col, y);
+				for (int zx = 0; zx < 6; zx++) {
+					const float col[6] = { acc[0 * 6 + zx][j][r], acc[1 * 6 + zx][j][r], acc[2 * 6 + zx][j][r], acc[3 * 6 + zx][j][r], acc[4 * 6 + zx][j][r], acc[5 * 6 + zx][j][r] };
+					float y[4];
+					wino_at(col, y);
 #pragma unroll
-				for (int i = 0; i < 4; i++) s[i][zx] = y[i];
-			}
-			float* const drow = a.dst + (long)n * a.d_sn + k;
+					for (int i = 0; i < 4; i++) s[i][zx] = y[i];
+				}
+				float* const drow = a.dst + (long)n * a.d_sn + k;
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				float y[4];
-				wino_at(s[i], y);
-				const int oy = oy0 + i;
+				for (int i = 0; i < 4; i++) {
+					float y[4];
+					wino_at(s[i], y);
 #pragma unroll
-				for (int jj = 0; jj < 4; jj++) {
-					const int ox = ox0 + jj;
-					if (group_live & (k < a.K) & (oy < a.OH) & (ox < a.OW)) drow[(long)oy * a.d_sh + (long)ox * a.d_sw] = y[jj] + bv;
+					for (int jj = 0; jj < 4; jj++)
+						if (group_live & (k < a.K) & (oy0 + i < a.OH) & (ox0 + jj < a.OW)) drow[(long)(oy0 + i) * a.d_sh + (long)(ox0 + jj) * a.d_sw] = y[jj] + bv;
 				}
 			}
+		}
+		return;
+	}
+	WF_WAIT_VMCNT(0);             // the last trip's (redundant) DMA pieces must not land on top of the staging area
+	__builtin_amdgcn_s_barrier(); // every wave is done with the U / patch buffers the staging overwrites
+	{
+		constexpr int TS = 16 * 32 + 16; // floats per tile in the staging area: the 4 tiles of a ds_write land on 2 x 16 banks
+		float* const st = lds + wave * (4 * TS);
+		float bv[2][4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) { // the read-back lane owns channels kq .. kq + 3 of 8 pixels per round
+			const int kq = kb * WF_KT + (lane & 7) * 4 + i;
+			bv[0][i] = (a.bias && kq < a.K) ? a.bias[kq] : 0.f;
+		}
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+#pragma unroll
+			for (int j = 0; j < 2; j++) {
+				float s[4][6]; // columns transformed vertically
+#pragma unroll
+				for (int zx = 0; zx < 6; zx++) {
+					const float col[6] = { acc[0 * 6 + zx][j][r], acc[1 * 6 + zx][j][r], acc[2 * 6 + zx][j][r], acc[3 * 6 + zx][j][r], acc[4 * 6 + zx][j][r], acc[5 * 6 + zx][j][r] };
+					float y[4];
+					wino_at(col, y);
+#pragma unroll
+					for (int i = 0; i < 4; i++) s[i][zx] = y[i];
+				}
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					float y[4];
+					wino_at(s[i], y);
+#pragma unroll
+					for (int jj = 0; jj < 4; jj++) st[g * TS + (i * 4 + jj) * 32 + j * 16 + ti] = y[jj];
+				}
+			}
+			__builtin_amdgcn_wave_barrier(); // the reads below are other lanes' writes: LDS serves a wave's accesses in order, hipcc must not reorder them
+			// read back: 4 tiles x 16 pixels x 8 channel quads = 512 float4 = 8 per lane; lane -> (channel quad = lane & 7, pixel-in-wave-instruction = lane >> 3)
+#pragma unroll
+			for (int e = 0; e < 8; e++) {
+				const int pid = e * 8 + (lane >> 3);   // 0..63: tile slot pid >> 4 (= g' of the writers), pixel pid & 15
+				const int gp = pid >> 4, px = pid & 15;
+				const int tile = 4 * gp + r;
+				const int oy = (gy * GH + (tile >> GWL)) * 4 + (px >> 2), ox = (gx * GW + (tile & (GW - 1))) * 4 + (px & 3);
+				const float4 v = *(const float4*)(st + gp * TS + px * 32 + (lane & 7) * 4);
+				const int kq = kb * WF_KT + (lane & 7) * 4;
+				float* const o = a.dst + (long)n * a.d_sn + (long)oy * a.d_sh + (long)ox * a.d_sw + kq;
+				if (group_live & (oy < a.OH) & (ox < a.OW)) {
+					if (kq + 3 < a.K && a.dst_vec) *(float4*)o = make_float4(v.x + bv[0][0], v.y + bv[0][1], v.z + bv[0][2], v.w + bv[0][3]);
+					else {
+						if (kq < a.K) o[0] = v.x + bv[0][0];
+						if (kq + 1 < a.K) o[1] = v.y + bv[0][1];
+						if (kq + 2 < a.K) o[2] = v.z + bv[0][2];
+						if (kq + 3 < a.K) o[3] = v.w + bv[0][3];
+					}
+				}
+			}
+			__builtin_amdgcn_wave_barrier(); // next round's writes after this round's reads
 		}
 	}
 }

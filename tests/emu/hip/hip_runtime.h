@@ -71,7 +71,7 @@ static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t sh
 	emu::launch(grid, block, shmem, [&]() { kernel(args...); });
 }
 
-static inline void __syncthreads() { emu::syncthreads(); }
+static inline void __syncthreads() { asm volatile("" ::: "memory"); emu::syncthreads(); asm volatile("" ::: "memory"); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
@@ -155,7 +155,11 @@ static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(emu_buffer_rsrc r, _
 	else memcpy(d, r.base + off + soffset, size);
 }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
-#define __builtin_amdgcn_s_barrier() emu::syncthreads()
+// (the "memory" clobbers: a workgroup's LDS is a function-local static whose address never leaves the kernel, so without them
+// the x86 compiler may move a lane's LDS reads above the rendezvous -- other fibers' writes are invisible to its analysis)
+static inline void emu_wave_barrier() { asm volatile("" ::: "memory"); emu::wave_sync(); asm volatile("" ::: "memory"); }
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
+#define __builtin_amdgcn_s_barrier() __syncthreads()
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32

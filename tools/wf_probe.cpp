@@ -1,0 +1,71 @@
+// Perf probe (not part of the library): times the fused Winograd kernel (ccv_amd/csrc/wino_fused.h) on one layer shape with
+// parts of its loop knocked out (DBG template bits), to attribute the time.  Built HERE (hipcc cross-compiles) into tools/bin/:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ccv_amd/csrc tools/wf_probe.cpp -o tools/bin/wf_probe
+//   tools/bin/wf_probe [batch] [hw] [C] [K]
+#include "wino_fused.h"
+#include <cstdio>
+#include <vector>
+#define CHECK(e) do { hipError_t s_ = (e); if (s_ != hipSuccess) { printf("HIP error %d at %d\n", (int)s_, __LINE__); return 1; } } while (0)
+using namespace nnc;
+
+template <int DBG>
+static void run(const WinoFusedArgs& a, unsigned grid, double flops, const char* what)
+{
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	const int reps = 5;
+	for (int i = 0; i < 2; i++) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4, DBG>), dim3(grid), dim3(256), 0, 0, a);
+	hipEventRecord(e0, 0);
+	for (int i = 0; i < reps; i++) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4, DBG>), dim3(grid), dim3(256), 0, 0, a);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	printf("DBG=%3d  %8.3f ms  %6.1f MFMA-TFLOP/s-equivalent  %s%s\n", DBG, ms / reps, flops * reps / (ms * 1e-3) / 1e12, what, hipGetLastError() == hipSuccess ? "" : "  (launch error)");
+}
+
+int main(int argc, char** argv)
+{
+	const int NB = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 223, C = argc > 3 ? atoi(argv[3]) : 64, K = argc > 4 ? atoi(argv[4]) : 64;
+	const int W = H;
+	float *src, *dst, *w, *uf, *bias;
+	const size_t ns = (size_t)NB * H * W * C, nd = (size_t)NB * H * W * K;
+	CHECK(hipMalloc(&src, sizeof(float) * ns));
+	CHECK(hipMalloc(&dst, sizeof(float) * nd));
+	CHECK(hipMalloc(&w, sizeof(float) * (size_t)K * 9 * C));
+	CHECK(hipMalloc(&bias, sizeof(float) * K));
+	const int KB = (K + WF_KT - 1) / WF_KT, CCn = C / WF_CC;
+	CHECK(hipMalloc(&uf, sizeof(float) * (size_t)KB * CCn * WF_U_FLOATS));
+	{
+		std::vector<float> h((size_t)1 << 24);
+		for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+		for (size_t o = 0; o < ns; o += h.size()) CHECK(hipMemcpy(src + o, h.data(), sizeof(float) * (ns - o < h.size() ? ns - o : h.size()), hipMemcpyHostToDevice));
+		CHECK(hipMemcpy(w, h.data(), sizeof(float) * (size_t)K * 9 * C, hipMemcpyHostToDevice));
+		CHECK(hipMemcpy(bias, h.data(), sizeof(float) * K, hipMemcpyHostToDevice));
+	}
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_weight_frag_kernel<false>), dim3((unsigned)(((size_t)KB * WF_KT * C + 255) / 256)), dim3(256), 0, 0, (const float*)w, uf, K, C, K, C);
+	WinoFusedArgs a;
+	a.src = src; a.dst = dst; a.uf = uf; a.bias = bias;
+	a.s_sn = (long)H * W * C; a.s_sh = (long)W * C; a.s_sw = C; a.d_sn = (long)H * W * K; a.d_sh = (long)W * K; a.d_sw = K;
+	a.H = H; a.W = W; a.OH = H; a.OW = W; a.pad_y = 1; a.pad_x = 1;
+	const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+	a.GYn = (TH + 3) / 4; a.GXn = (TW + 3) / 4; a.groups = NB * a.GYn * a.GXn; a.C = C; a.K = K; a.CCn = CCn; a.KB = KB;
+	a.dst_vec = 1;
+	a.src_image_bytes = (unsigned)(((long)(H - 1) * a.s_sh + (long)(W - 1) * a.s_sw + C) * 4);
+	a.uf_kb_bytes = (unsigned)((size_t)CCn * WF_U_FLOATS * 4);
+	const unsigned grid = (unsigned)((a.groups + 3) / 4 * KB);
+	const double flops = 2.0 * 36.0 * (double)a.groups * 16 * K * C; // issued MFMA work (padded tile groups included)
+	printf("fused Winograd 3x3: N=%d %dx%dx%d -> %d; %d workgroups, %d trips each; MFMA floor %.3f ms\n", NB, H, W, C, K, grid, CCn, flops / 157.3e12 * 1e3);
+	run<0>(a, grid, flops, "everything");
+	run<1>(a, grid, flops, "no DMA in the loop");
+	run<2>(a, grid, flops, "no patch reads");
+	run<4>(a, grid, flops, "no U fragment reads");
+	run<8>(a, grid, flops, "no transform VALU");
+	run<32>(a, grid, flops, "no barrier");
+	run<64>(a, grid, flops, "no epilogue");
+	run<65>(a, grid, flops, "no epilogue, no DMA");
+	run<1 + 2 + 4 + 8 + 32 + 64>(a, grid, flops, "MFMAs only");
+	run<16>(a, grid, flops, "no MFMAs");
+	run<16 + 64>(a, grid, flops, "no MFMAs, no epilogue");
+	return 0;
+}
