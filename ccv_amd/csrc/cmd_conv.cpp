@@ -141,7 +141,9 @@ struct wino_fused_plan_t {
 static bool wino_fused_plan(const conv_geom_t& g, const Image4& src, const Image4& dst, wino_fused_plan_t* p)
 {
 	if (g.kh != 3 || g.kw != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.groups != 1) return false;
-	if (src.c % WF_CC || src.sc != 1 || dst.sc != 1 || !aligned16(src.p) || src.sw % 4 || src.sh % 4 || (src.n > 1 && src.sn % 4)) return false;
+	if (src.c % WF_CC || src.c < 2 * WF_CC || src.sc != 1 || dst.sc != 1 || !aligned16(src.p) || src.sw % 4 || src.sh % 4 || (src.n > 1 && src.sn % 4)) return false;
+	if (dst.c % 4 || !aligned16(dst.p) || dst.sw % 4 || dst.sh % 4 || (dst.n > 1 && dst.sn % 4)) return false; // 16-byte stores
+	if (((long)(dst.h - 1) * dst.sh + (long)(dst.w - 1) * dst.sw + dst.c) * 4 >= (long)WF_OOB) return false;
 	if (((long)(src.h - 1) * src.sh + (long)(src.w - 1) * src.sw + src.c) * 4 >= (long)WF_OOB) return false; // per-image buffer descriptor range
 	const int TH = (dst.h + 3) / 4, TW = (dst.w + 3) / 4;
 	static const int shapes[3][2] = { { 4, 4 }, { 2, 8 }, { 8, 2 } };
@@ -173,10 +175,17 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	a.s_sn = src.sn; a.s_sh = src.sh; a.s_sw = src.sw; a.d_sn = dst.sn; a.d_sh = dst.sh; a.d_sw = dst.sw;
 	a.H = src.h; a.W = src.w; a.OH = dst.h; a.OW = dst.w; a.pad_y = pad_y; a.pad_x = pad_x;
 	a.GYn = p.GYn; a.GXn = p.GXn; a.groups = p.groups; a.C = Cred; a.K = Kout; a.CCn = p.CCn; a.KB = p.KB;
-	a.dst_vec = aligned16(dst.p) && dst.sw % 4 == 0 && dst.sh % 4 == 0 && (dst.n == 1 || dst.sn % 4 == 0);
+	a.dst_image_bytes = (unsigned)(((long)(dst.h - 1) * dst.sh + (long)(dst.w - 1) * dst.sw + dst.c) * 4);
 	a.src_image_bytes = (unsigned)(((long)(src.h - 1) * src.sh + (long)(src.w - 1) * src.sw + src.c) * 4);
 	a.uf_kb_bytes = (unsigned)((size_t)p.CCn * WF_U_FLOATS * 4);
-	const unsigned grid = (unsigned)((p.groups + 3) / 4 * p.KB);
+	// persistent: one workgroup per CU; teams of `team` workgroups (a divisor of KB, at most 4) share a range of tile-group quads
+	// on one XCD (see the kernel); the grid is a multiple of 8 * team, workgroups beyond the work exit at once
+	long wgs = tune(TUNE_WINO_FUSED_GRID) > 0 ? tune(TUNE_WINO_FUSED_GRID) : device_cu_count();
+	int team = p.KB % 4 == 0 ? 4 : (p.KB % 2 == 0 ? 2 : 1);
+	while (team > 1 && wgs < 8 * team) team >>= 1;
+	if (wgs < 8 * team) wgs = 8 * team;
+	const unsigned grid = (unsigned)(wgs / (8 * team) * (8 * team));
+	a.team = team;
 	note_kernel(name);
 	char prof_name[96];
 	snprintf(prof_name, sizeof(prof_name), "%s|nnc::wino_fused_kernel<%d, %d>", name, p.GH, p.GW);
@@ -189,9 +198,17 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
-// algorithm -1: the fused kernel where its 64 x 32 block is the better trade -- few reduction channels (the via-HBM form is
-// bandwidth-bound there) -- up to TUNE_WINO_FUSED_MAX_C; measured per VGG-D layer on the MI355X.
-static bool wino_fused_preferred(const int C_red) { return C_red <= tune(TUNE_WINO_FUSED_MAX_C); }
+// algorithm -1: the fused kernel where it measures faster on the MI355X (tools/conv_algo_sweep.py at batch 256):
+// few reduction channels -- the via-HBM form is bandwidth-bound there (conv1_2: 3.6 vs 7.8 ms, 128 -> 128 at 111^2: 3.1 vs 4.5) --
+// up to TUNE_WINO_FUSED_MAX_C (default 128), and up to twice that when the 16-tile groups pad the tile grid by less than a
+// fifth (256 -> 256 at 55^2: 2.9 vs 3.1 ms; at 27^2, 7 -> 8 tiles per side, the via-HBM form wins).
+static bool wino_fused_preferred(const int C_red, const wino_fused_plan_t& p, const Image4& dst)
+{
+	const long maxc = tune(TUNE_WINO_FUSED_MAX_C);
+	if (C_red <= maxc) return true;
+	const long tiles = (long)((dst.h + 3) / 4) * ((dst.w + 3) / 4), padded = (long)p.GYn * p.GH * p.GXn * p.GW;
+	return C_red <= 2 * maxc && padded * 5 < tiles * 6;
+}
 
 // dw (+)= sum over tiles: the F(3x3, 4x4) form -- V = B^T a B exactly as in forward, W = G' g G'^T on the output gradient,
 // 36 contractions dU[z] (K x C) = W[z]^T V[z] over the T tiles (batched split-K: both operands are read along their
@@ -301,7 +318,7 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 	if (a.sc != 1 || !pixel_linear(b) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
 	wino_plan_t wp;
 	wino_fused_plan_t fp;
-	if ((algo == CONV_ALGO_WINOGRAD_FUSED || (algo < 0 && wino_fused_preferred(g.C))) && g.pby <= 2 && g.pbx <= 2 && g.pby >= 0 && g.pbx >= 0 && wino_fused_plan(g, a, b, &fp)) {
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && algo != CONV_ALGO_WINOGRAD && g.pby <= 2 && g.pbx <= 2 && g.pby >= 0 && g.pbx >= 0 && wino_fused_plan(g, a, b, &fp) && (algo == CONV_ALGO_WINOGRAD_FUSED || wino_fused_preferred(g.C, fp, b))) {
 		const int r = conv_wino_fused_run<false>("conv_fwd_wino_fused", g, fp, a, w, bias, b, g.pby, g.pbx, ctx);
 		if (r != CCV_NNC_EXEC_OOM) return r;
 	}
@@ -339,7 +356,7 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 	if (gr.sc != 1 || !pixel_linear(h) || !image_fits_int(gr)) return CCV_NNC_EXEC_INVALID;
 	wino_plan_t wp;
 	wino_fused_plan_t fp;
-	if ((algo == CONV_ALGO_WINOGRAD_FUSED || (algo < 0 && wino_fused_preferred(g.K))) && g.pby <= 2 && g.pbx <= 2 && g.pby >= 0 && g.pbx >= 0 && wino_fused_plan(g, gr, h, &fp)) {
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && algo != CONV_ALGO_WINOGRAD && g.pby <= 2 && g.pbx <= 2 && g.pby >= 0 && g.pbx >= 0 && wino_fused_plan(g, gr, h, &fp) && (algo == CONV_ALGO_WINOGRAD_FUSED || wino_fused_preferred(g.K, fp, h))) {
 		const int r = conv_wino_fused_run<true>("conv_dgrad_wino_fused", g, fp, gr, w, 0, h, 2 - g.pby, 2 - g.pbx, ctx);
 		if (r != CCV_NNC_EXEC_OOM) return r;
 	}

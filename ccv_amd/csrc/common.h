@@ -150,6 +150,7 @@ extern int g_force_tile;
 enum {
 	TUNE_WINO_SLICE_KB = 0, // Winograd via HBM: run the three stages per slice of images whose V + M scratch is at most this many KB (0 = whole batch)
 	TUNE_WINO_FUSED_MAX_C,  // algorithm -1 picks the fused Winograd kernel when the reduction channels are <= this (0 = never)
+	TUNE_WINO_FUSED_GRID,   // persistent workgroups of the fused Winograd kernel (0 = one per CU)
 	TUNE_COUNT
 };
 long tune(int key);

@@ -94,8 +94,8 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 
 namespace nnc {
 int g_force_tile = 0;
-static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C" };
-static long g_tune_values[TUNE_COUNT] = { 0, 0 }; // defaults: the measured best on the MI355X
+static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C", "WINO_FUSED_GRID" };
+static long g_tune_values[TUNE_COUNT] = { 0, 128, 0 }; // defaults: the measured best on the MI355X
 static int g_tune_env_read = 0;
 long tune(int key)
 {

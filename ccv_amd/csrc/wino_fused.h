@@ -34,6 +34,7 @@ constexpr int WF_U_FLOATS = 36 * 64 * 2 * 2;    // one chunk of U fragments: [z]
 constexpr int WF_HP = 352;                      // pixel slots per channel-half plane of a patch buffer (11 DMA pieces x 64 granules / 2)
 constexpr int WF_P_FLOATS = 2 * WF_HP * 4;      // one patch buffer: [h][slot][4 channels], 11 KB
 constexpr int WF_P_PIECES = 11;
+constexpr int WF_Z_AGPR = 30;                     // positions whose two accumulator tiles live in AGPRs (60 tiles = 240 of the 256: hipcc needs slack there), the rest in VGPRs
 constexpr unsigned WF_OOB = 0x7ffff000u;        // a buffer offset beyond every image: the DMA writes zeros
 
 // compile-time loop: f(GroupId<0>()) ... f(GroupId<N - 1>()) -- every index a constant, whatever the unroller's budget says
@@ -132,7 +133,8 @@ struct WinoFusedArgs {
 	int groups;         // N * GYn * GXn
 	int C, K;           // reduction / output channels
 	int CCn, KB;        // C / 8, ceil(K / 32)
-	int dst_vec;        // destination pointer and strides allow 16-byte stores
+	unsigned dst_image_bytes; // range of the per-image destination descriptor (pointer and strides are multiples of 16 bytes, K of 4: host-checked)
+	int team;           // workgroups per team (divides KB; the grid is a multiple of 8 * team)
 	unsigned src_image_bytes; // range of the per-image buffer descriptor
 	unsigned uf_kb_bytes;     // bytes of one k block of U fragments (CCn * 36 KB)
 };
@@ -151,9 +153,17 @@ struct WinoFusedArgs {
 // do for an asm MFMA (cdna guide 5.7) is handled by construction: its A operand was computed at least a whole slot earlier
 // (VALU -> MFMA operand needs 2 wait states), its B operand comes from a ds_read hipcc waits for, and the epilogue's first
 // read of an accumulator sits behind explicit s_nops.
+// WF_MFMA0: the same with C = 0 -- a work item's first MFMA into each accumulator, so that the 288 registers are not zeroed per
+// item.  (Declared read-write all the same: as a pure output it would be a NEW value per item, and hipcc then spills every
+// accumulator to scratch around the loop to merge the two -- measured, 1.1 KB of scratch per lane.)
 #ifdef NNC_HIP_EMULATOR
 #define WF_MFMA(ACC, A, B, IN_AGPR) (ACC) = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (ACC), 0, 0, 0)
+#define WF_MFMA0(ACC, A, B, IN_AGPR) (ACC) = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (floatx4{ 0.f, 0.f, 0.f, 0.f }), 0, 0, 0)
 #else
+#define WF_MFMA0(ACC, A, B, IN_AGPR) do { \
+		if (IN_AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "+a"(ACC) : "v"(A), "v"(B)); \
+		else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "+v"(ACC) : "v"(A), "v"(B)); \
+	} while (0)
 #define WF_MFMA(ACC, A, B, IN_AGPR) do { \
 		if (IN_AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B)); \
 		else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B)); \
@@ -195,6 +205,14 @@ __device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float*, unsigned lds
 }
 #endif
 
+// DMA piece n = 0..19 of a trip is issued behind iteration 9 n / 5 (0, 1, 3, 5, 7, 9, 10, ...): -1 = none behind iteration `it`
+constexpr __host__ __device__ int wf_piece_at(int it)
+{
+	for (int n = 0; n < 20; n++)
+		if (n * 9 / 5 == it) return n;
+	return -1;
+}
+
 // One third (PART) of the six-point transform y = B^T x on two channels at once, one f2 operation (K) at a time -- the kernel
 // slots exactly one such operation (2 VALU) behind every MFMA.  T: a, b, c, t, m, n of
 //   a = x4 - 4 x2, b = x3 - 4 x1, c = x4 - x2, t = x3 - x1, m = x4 - 5 x2, n = x5 - 5 x3
@@ -224,7 +242,14 @@ __device__ __forceinline__ void wf_bt_op(const f2& x0, const f2& x1, const f2& x
 }
 
 // DBG (tools/wf_probe.cpp only; the library instantiates DBG = 0): knock parts of the loop out to attribute its time.
-//   1 no DMA in the loop, 2 no patch reads, 4 no U fragment reads, 8 no transform VALU, 16 no MFMAs, 32 no barrier, 64 no epilogue
+//   1 no DMA in the loop, 2 no patch reads, 4 no U fragment reads, 8 no transform VALU, 16 no MFMAs, 32 no barrier, 64 no epilogue,
+//   256 no wait for the DMA (racy: timing only), 512 no patch DMA, 1024 no U DMA
+//
+// PERSISTENT: one workgroup per CU walks a contiguous range of work items (tile-group quad x k block, the k blocks of a quad
+// consecutive: its patch lines stay in L1 / L2), and the chunk stream simply continues across items: the last two trips of an
+// item already fetch and transform the first chunks of the next one, so only the very first item of a workgroup pays the DMA
+// latency, the launch and the initial transform (measured before: 8-16 us per workgroup against 15 us of MFMAs for a
+// 64-channel item).  Between two items sits the epilogue alone.
 template <int GH, int GW, int DBG = 0>
 __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs a)
 {
@@ -234,22 +259,20 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 	const int t = threadIdx.x;
 	const int lane = t & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-	// XCD-aware bijection (cdna guide T1): consecutive work items run on one XCD back to back, and the KB k blocks of a
-	// group quad are consecutive work items -- their patch lines are served by that XCD's L2.
-	int work;
-	{
-		const int nwg = gridDim.x, bid = blockIdx.x;
-		const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-		work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-	}
-	const int gq = work / a.KB, kb = work - gq * a.KB;
-	int group = gq * 4 + wave;
-	const bool group_live = group < a.groups;
-	if (!group_live) group = a.groups - 1; // computes a duplicate, stores nothing
+	// Work items = (tile-group quad gq, k block kb).  A TEAM of a.team workgroups on ONE XCD (workgroup b runs on XCD b % 8)
+	// walks the same range of quads side by side, member m taking the k blocks m, m + team, ...: the members fetch the same
+	// patch lines at about the same time, so all but the first find them in that XCD's L2 (a workgroup walking the k blocks
+	// of a quad one after the other does not: the other 31 CUs of the XCD push 10 MB through its 4 MB L2 in between).
+	const int nquads = (a.groups + 3) / 4;
+	const int team = a.team, kpm = a.KB / team;              // k blocks per member
+	const int slot = (int)blockIdx.x >> 3, teams = ((int)gridDim.x >> 3) / team * 8; // (host: gridDim.x % (8 * team) == 0)
+	const int member = slot % team, team_id = ((int)blockIdx.x & 7) * (teams >> 3) + slot / team;
+	const int qper = (nquads + teams - 1) / teams;
+	const int q_first = team_id * qper;
+	const int q_count = nquads - q_first < qper ? nquads - q_first : qper;
+	const int first = 0, count = q_count * kpm;              // this workgroup's items, numbered 0 .. count - 1
+	if (count <= 0) return;
 	const int gpi = a.GYn * a.GXn;
-	const int n = group / gpi, gr = group - n * gpi;
-	const int gy = gr / a.GXn, gx = gr - gy * a.GXn;
-	const int Y0 = gy * GH * 4 - a.pad_y, X0 = gx * GW * 4 - a.pad_x; // region origin in source coordinates
 	const int ti = lane & 15, g = lane >> 4;
 	const int ty = ti >> GWL, tx = ti & (GW - 1);
 
@@ -260,36 +283,54 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 	const unsigned p_lds = lds0 + (2 * WF_U_FLOATS + wave * 2 * WF_P_FLOATS) * 4; // this wave's patch buffers
 	const unsigned u_lds = lds0 + wave * 9 * 1024;                               // this wave's ninth of a U buffer
 
-	// ---- DMA descriptors
-	const wf_rsrc_t rs_src = wf_make_rsrc(a.src + (long)n * a.s_sn, a.src_image_bytes);
-	const wf_rsrc_t rs_u = wf_make_rsrc(a.uf + (long)kb * (a.uf_kb_bytes / 4), a.uf_kb_bytes);
-	unsigned pvoff[WF_P_PIECES];
+	// ---- work items (everything wave-uniform)
+	struct Item { int kb, n, gy, gx, live; };
+	auto item_of = [&](const int idx) -> Item {
+		Item r;
+		const int gq = q_first + idx / kpm;
+		r.kb = member + (idx % kpm) * team;
+		int group = gq * 4 + wave;
+		r.live = group < a.groups;
+		if (!r.live) group = a.groups - 1; // computes a duplicate, stores nothing
+		r.n = group / gpi;
+		const int gr = group - r.n * gpi;
+		r.gy = gr / a.GXn;
+		r.gx = gr - r.gy * a.GXn;
+		return r;
+	};
+	// ---- DMA descriptors of the item whose chunks are being FETCHED (runs ahead of the item being multiplied)
+	wf_rsrc_t rs_src, rs_u;
+	unsigned pvoff[WF_P_PIECES]; // byte offset of the lane's 16 bytes of each patch piece inside the image (or WF_OOB)
+	int pyx[WF_P_PIECES];        // item-independent half of it: region pixel (Y << 8 | X) and channel half of the lane's granule, -1 = none
 #pragma unroll
 	for (int q = 0; q < WF_P_PIECES; q++) {
 		const int s = q * 64 + lane;
 		const int hh = s >= WF_HP ? 1 : 0, slot = s - hh * WF_HP;
 		const unsigned yx = wf_slot_tab<GH, GW>.yx[slot];
-		const int Y = Y0 + (int)(yx >> 8), X = X0 + (int)(yx & 255);
-		const bool ok = (yx != 0xffffu) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-		pvoff[q] = ok ? (unsigned)(((long)Y * a.s_sh + (long)X * a.s_sw + 4 * hh) * 4) : WF_OOB;
+		pyx[q] = yx == 0xffffu ? -1 : (int)(yx | (unsigned)hh << 16);
 	}
+	const int sh4 = (int)a.s_sh * 4, sw4 = (int)a.s_sw * 4; // an image spans < 2^31 bytes (host-checked): 32-bit offsets
+	auto set_patch = [&](const Item& it) {
+		rs_src = wf_make_rsrc(a.src + (long)it.n * a.s_sn, a.src_image_bytes);
+		const int Y0 = it.gy * GH * 4 - a.pad_y, X0 = it.gx * GW * 4 - a.pad_x; // region origin in source coordinates
+#pragma unroll
+		for (int q = 0; q < WF_P_PIECES; q++) {
+			const int Y = Y0 + ((pyx[q] >> 8) & 255), X = X0 + (pyx[q] & 255);
+			const bool ok = (pyx[q] >= 0) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+			pvoff[q] = ok ? (unsigned)(Y * sh4 + X * sw4 + ((pyx[q] >> 16) & 1) * 16) : WF_OOB;
+		}
+	};
+	auto set_u = [&](const Item& it) { rs_u = wf_make_rsrc(a.uf + (long)it.kb * (a.uf_kb_bytes / 4), a.uf_kb_bytes); };
 	const unsigned uvoff = (unsigned)lane * 16u;
-	// One LDS-DMA piece (1 KB): q < 11 a piece of the patch of chunk cp (soffset sp = cp * 32 bytes) into patch buffer cp & 1;
-	// q >= 11 one of this wave's nine pieces of U chunk cu (su = cu * 36 KB + wave * 9 KB) into U buffer cu & 1.  The caller
-	// clamps cp / cu to the last chunk: past the end the last chunk is simply fetched again into the buffer nobody reads any
-	// more -- no branch and no select in the hand-ordered stream, for two chunks of extra L2 reads per workgroup.
+	// One LDS-DMA piece (1 KB): q < 11 a piece of a patch chunk (soffset sp = chunk * 32 bytes) to LDS address p_dst + q KB;
+	// q >= 11 one of this wave's nine pieces of a U chunk (su = chunk * 36 KB + wave * 9 KB) to u_dst + (q - 11) KB.
 	auto dma_piece = [&](auto qc, const unsigned p_dst, const unsigned sp, const unsigned u_dst, const unsigned su) {
 		constexpr int q = decltype(qc)::value;
 		if constexpr (q < WF_P_PIECES) wf_dma16(rs_src, lds, p_dst + q * 1024, pvoff[q], sp);
 		else wf_dma16(rs_u, lds, u_dst + (q - WF_P_PIECES) * 1024, uvoff, su + (q - WF_P_PIECES) * 1024);
 	};
-	const int last = a.CCn - 1;
-	auto p_dst_of = [&](const int c) -> unsigned { return p_lds + (c & 1) * (WF_P_FLOATS * 4); };
-	auto u_dst_of = [&](const int c) -> unsigned { return u_lds + (c & 1) * (WF_U_FLOATS * 4); };
-	auto sp_of = [&](const int c) -> unsigned { return (unsigned)(c < last ? c : last) * (WF_CC * 4); };
-	auto su_of = [&](const int c) -> unsigned { return (unsigned)(c < last ? c : last) * (WF_U_FLOATS * 4) + (unsigned)wave * 9216u; };
 
-	floatx4 acc[36][2];
+	floatx4 acc[36][2]; // zeroed once (defined values for hipcc); every item's first chunk multiplies with C = 0
 #pragma unroll
 	for (int z = 0; z < 36; z++)
 #pragma unroll
@@ -305,29 +346,33 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		return f2(v.x, v.y);
 	};
 
-	// ---- prologue: chunk 0 transformed completely (S, then V columns 0..4; column 5 is the first work of the loop), chunk 1 in flight
-	f2 S[6][6], V[6][6], T[6]; // S[row][column] = d B; V[zy][zx] = B^T S
+	// ---- prologue (once per workgroup): the first item's chunk 0 transformed completely (S, then V columns 0..4; column 5 is
+	// the first work of the loop), its chunk 1 in flight
+	Item cur = item_of(first);
+	set_patch(cur);
+	set_u(cur);
+	f2 S[6][6], Vc[2][6], T[6]; // S[row][column] = d B of the chunk being multiplied; Vc[zx & 1][zy] = column zx of V = B^T S, two columns at a time
 #ifndef NNC_HIP_EMULATOR
 	asm volatile("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them (5 wait states)
 #endif
-	wf_static_for<WF_P_PIECES + 9>([&](auto qc) { dma_piece(qc, p_dst_of(0), sp_of(0), u_dst_of(0), su_of(0)); });
-	wf_static_for<WF_P_PIECES>([&](auto qc) { dma_piece(qc, p_dst_of(1), sp_of(1), 0, 0); });
+	wf_static_for<WF_P_PIECES + 9>([&](auto qc) { dma_piece(qc, p_lds, 0, u_lds, (unsigned)wave * 9216u); });
+	wf_static_for<WF_P_PIECES>([&](auto qc) { dma_piece(qc, p_lds + WF_P_FLOATS * 4, WF_CC * 4, 0, 0); });
 	WF_WAIT_VMCNT(WF_P_PIECES); // chunk 0's patch and this wave's share of U(0) have landed; chunk 1's patch may still fly
+	// the transform an item's FIRST trip starts from, out of patch buffer pb (S, and column 0 of V): at the start of the workgroup,
+	// and after every epilogue -- S is not carried across the epilogue (72 registers next to the epilogue's own temporaries); the
+	// item's last trip skips its share of transform work instead, so the count of VALU per item is unchanged
+	auto xform_first = [&](const float* const pb) {
 #pragma unroll
-	for (int r = 0; r < 6; r++) {
-		f2 d[6];
+		for (int r = 0; r < 6; r++) {
+			f2 d[6];
 #pragma unroll
-		for (int c = 0; c < 6; c++) d[c] = patch_read(pbuf, r, c);
-		wino_bt(d, S[r]);
-	}
-#pragma unroll
-	for (int zx = 0; zx < 5; zx++) {
-		const f2 col[6] = { S[0][zx], S[1][zx], S[2][zx], S[3][zx], S[4][zx], S[5][zx] };
-		f2 y[6];
-		wino_bt(col, y);
-#pragma unroll
-		for (int zy = 0; zy < 6; zy++) V[zy][zx] = y[zy];
-	}
+			for (int c = 0; c < 6; c++) d[c] = patch_read(pb, r, c);
+			wino_bt(d, S[r]);
+		}
+		const f2 col[6] = { S[0][0], S[1][0], S[2][0], S[3][0], S[4][0], S[5][0] };
+		wino_bt(col, Vc[0]);
+	};
+	xform_first(pbuf);
 
 #define WF_XFORM(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5) do { \
 		wf_bt_op<0, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<0, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
@@ -337,20 +382,26 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		wf_bt_op<1, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<2, 0>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
 		wf_bt_op<2, 1>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); wf_bt_op<2, 3>(X0, X1, X2, X3, X4, X5, Y0, Y1, Y2, Y3, Y4, Y5, T); \
 	} while (0)
-	// ---- main loop: trip cc multiplies chunk cc (V) while it transforms chunk cc + 1 and fetches chunk cc + 2 / U(cc + 1).
-	// 36 iterations of 4 MFMAs (iteration it: position z = (it % 6) * 6 + it / 6, column by column); per iteration one U read
-	// (all four fragments of the next position: ds_read_b128), one pair of patch reads and one DMA piece between the MFMAs, and
-	// behind every third iteration one whole transform (24 VALU), fenced so hipcc keeps them there:
-	//   transform 0      (it 0-2)   V[.][5] of THIS chunk from S[.][5]            (its MFMAs are it 30-35)
-	//   transforms 1-6   (it 3-20)  S'[r] = d'[r] B of the NEXT chunk, row r's 6 patch reads issued in the 3 iterations before
-	//   transforms 7-11  (it 21-35) V'[.][c] of the next chunk, c = 0..4, each after column c's MFMAs of this chunk are done
-	for (int cc = 0; cc < a.CCn; cc++) {
-		const int cur = cc & 1;
-		WF_WAIT_VMCNT(0);             // everything this wave fetched during the previous trip: patch(cc + 1), its share of U(cc)
-		if constexpr (!(DBG & 32)) __builtin_amdgcn_s_barrier(); // => all of U(cc) is in LDS, and every wave is done reading U(cc - 1) / its patch(cc)
-		const float* const ub = ubuf + cur * WF_U_FLOATS + lane * 4;
-		const float* const pbn = pbuf + (cur ^ 1) * WF_P_FLOATS; // patch of chunk cc + 1
-		const unsigned p_dst = p_dst_of(cc), sp = sp_of(cc + 2), u_dst = u_dst_of(cc + 1), su = su_of(cc + 1); // patch(cc + 2) goes where patch(cc) was
+	// ---- one trip: multiplies the current chunk (U buffer `par`; its S is in registers) while it fetches U of the next chunk of
+	// the stream (into U buffer par ^ 1) and the patch of the one after (into patch buffer par), and finally transforms the next
+	// chunk's patch (buffer par ^ 1) into S.  36 iterations of 4 MFMAs (iteration it: position z = (it % 6) * 6 + it / 6, column
+	// by column); between the MFMAs one U read per iteration (all four fragments of the next position: ds_read_b128), the patch
+	// reads and the DMA pieces; the VALU in twelve batches of one six-point transform (24 VALU) each, fenced so hipcc keeps
+	// them there -- fp32 MFMA and fp32 VALU do not overlap on gfx950 (tools/coissue_probe.cpp), so WHERE a batch sits costs
+	// nothing and registers decide: V exists two columns at a time, S is rewritten once its last column has been used:
+	//   it 1, 7, 13, 19, 25   column c + 1 of V from S, during column c's MFMAs (c = it / 6)
+	//   it 26 .. 33           S'[r] = d'[r] B of the NEXT chunk, row by row (S is dead after it 25), patch reads from it 23 on
+	//   it 34                 column 0 of the next chunk's V
+	// MODE (bit 0 FIRST: an item's first chunk multiplies with C = 0 instead of zeroed accumulators; bit 1 LAST: an item's last
+	// chunk transforms nothing) exists in the code but only MODE 0 is instantiated: with several trip variants behind a branch
+	// hipcc's register allocation falls apart (every accumulator tile spilled to scratch around the merges: 1.1 KB per lane, the
+	// kernel 2x slower), so the accumulators are zeroed after each epilogue and the last trip of an item transforms the NEXT
+	// item's first chunk -- its S and column 0 of V then live across the epilogue.
+	auto trip = [&](auto modec, const int par, const unsigned sp, const unsigned su) {
+		constexpr bool FIRST = (decltype(modec)::value & 1) != 0, LAST = (decltype(modec)::value & 2) != 0;
+		const float* const ub = ubuf + par * WF_U_FLOATS + lane * 4;
+		const float* const pbn = pbuf + (par ^ 1) * WF_P_FLOATS;
+		const unsigned p_dst = p_lds + par * (WF_P_FLOATS * 4), u_dst = u_lds + (par ^ 1) * (WF_U_FLOATS * 4);
 		f2 d[2][6];
 		float4 u[2];
 		if constexpr (DBG & 2) for (int i = 0; i < 12; i++) d[i / 6][i % 6] = f2(1.f, 2.f);
@@ -359,102 +410,87 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		wf_static_for<36>([&](auto itc) {
 			constexpr int it = decltype(itc)::value;
 			constexpr int zx = it / 6, zy = it % 6, z = zy * 6 + zx;
-			constexpr int tr = it / 3, part = it % 3;
+			// the row of the next chunk whose transform sits behind this iteration (-1: none), and the one whose patch reads do
+			constexpr int xrow = it == 26 ? 0 : it == 27 ? 1 : it == 29 ? 2 : it == 30 ? 3 : it == 32 ? 4 : it == 33 ? 5 : -1;
 			wf_static_for<4>([&](auto kc) {
 				constexpr int k = decltype(kc)::value;
 				// u = { (j0, e0), (j0, e1), (j1, e0), (j1, e1) }; MFMA order j0 e0, j1 e0, j0 e1, j1 e1: an accumulator recurs every 64 cycles (40 needed)
 				if constexpr (DBG & 16) { NNC_PIN_V(acc[z][k & 1][0]); }
-				else if constexpr (k == 0) WF_MFMA(acc[z][0], V[zy][zx].x, u[it & 1].x, z < 32);
-				else if constexpr (k == 1) WF_MFMA(acc[z][1], V[zy][zx].x, u[it & 1].z, z < 32);
-				else if constexpr (k == 2) WF_MFMA(acc[z][0], V[zy][zx].y, u[it & 1].y, z < 32);
-				else WF_MFMA(acc[z][1], V[zy][zx].y, u[it & 1].w, z < 32);
-				// (a) one whole six-point transform (12 f2 operations = 24 VALU) behind every twelfth MFMA.  NOT spread one
-				// operation per MFMA: v_mfma_f32_16x16x4_f32 and fp32 VALU do not overlap on gfx950 (tools/coissue_probe.cpp: 36 cycles
-				// per MFMA alone, 48 / 53 / 61 with 1 / 2 / 4 v_fma behind each, from one or two waves per SIMD alike -- the fp32
-				// matrix rate IS the fp32 vector rate), and the first VALU after an MFMA costs 12 cycles, the following ones 4.3.
-				if constexpr (k == 3 && part == 2 && !(DBG & 8)) {
-					if constexpr (tr == 0) {
-						WF_XFORM(S[0][5], S[1][5], S[2][5], S[3][5], S[4][5], S[5][5], V[0][5], V[1][5], V[2][5], V[3][5], V[4][5], V[5][5]);
-					} else if constexpr (tr <= 6) {
-						constexpr int r = tr - 1;
-						WF_XFORM(d[r & 1][0], d[r & 1][1], d[r & 1][2], d[r & 1][3], d[r & 1][4], d[r & 1][5], S[r][0], S[r][1], S[r][2], S[r][3], S[r][4], S[r][5]);
-					} else {
-						constexpr int c = tr - 7;
-						WF_XFORM(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], S[5][c], V[0][c], V[1][c], V[2][c], V[3][c], V[4][c], V[5][c]);
+				else if constexpr (k == 0 && FIRST) WF_MFMA0(acc[z][0], Vc[zx & 1][zy].x, u[it & 1].x, z < WF_Z_AGPR);
+				else if constexpr (k == 1 && FIRST) WF_MFMA0(acc[z][1], Vc[zx & 1][zy].x, u[it & 1].z, z < WF_Z_AGPR);
+				else if constexpr (k == 0) WF_MFMA(acc[z][0], Vc[zx & 1][zy].x, u[it & 1].x, z < WF_Z_AGPR);
+				else if constexpr (k == 1) WF_MFMA(acc[z][1], Vc[zx & 1][zy].x, u[it & 1].z, z < WF_Z_AGPR);
+				else if constexpr (k == 2) WF_MFMA(acc[z][0], Vc[zx & 1][zy].y, u[it & 1].y, z < WF_Z_AGPR);
+				else WF_MFMA(acc[z][1], Vc[zx & 1][zy].y, u[it & 1].w, z < WF_Z_AGPR);
+				// (a) the transform batches
+				if constexpr (k == 3 && !(DBG & 8)) {
+					if constexpr (it % 6 == 1 && it < 30) {
+						constexpr int c = it / 6 + 1;
+						WF_XFORM(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], S[5][c], Vc[c & 1][0], Vc[c & 1][1], Vc[c & 1][2], Vc[c & 1][3], Vc[c & 1][4], Vc[c & 1][5]);
+					} else if constexpr (xrow >= 0 && !LAST) {
+						WF_XFORM(d[xrow & 1][0], d[xrow & 1][1], d[xrow & 1][2], d[xrow & 1][3], d[xrow & 1][4], d[xrow & 1][5], S[xrow][0], S[xrow][1], S[xrow][2], S[xrow][3], S[xrow][4], S[xrow][5]);
+					} else if constexpr (it == 34 && !LAST) {
+						WF_XFORM(S[0][0], S[1][0], S[2][0], S[3][0], S[4][0], S[5][0], Vc[0][0], Vc[0][1], Vc[0][2], Vc[0][3], Vc[0][4], Vc[0][5]);
 					}
 				}
-				// (b) LDS reads: slot 0 the NEXT iteration's four U fragments; slot 2 two neighbouring elements of the next chunk's
-				// patch (same base register, so hipcc merges the pair into one ds_read2_b64)
+				// (b) LDS reads: slot 0 the NEXT iteration's four U fragments; slots 1, 2 the next chunk's patch, two neighbouring
+				// elements at a time (same base register, so hipcc merges the pair into one ds_read2_b64): row r's three pairs in
+				// three consecutive slots, the first one after the transform of row r - 2 has released the registers
 				if constexpr (k == 0 && it + 1 < 36 && !(DBG & 4)) {
 					constexpr int itn = it + 1, zn = (itn % 6) * 6 + itn / 6;
 					u[itn & 1] = *(const float4*)(ub + zn * 256);
 				}
-				if constexpr (k == 2 && it < 18 && !(DBG & 2)) {
-					constexpr int r = it / 3, c = (it % 3) * 2; // row r is transformed in iterations 3 + 3 r .. 5 + 3 r
-					d[r & 1][c] = patch_read(pbn, r, c);
-					d[r & 1][c + 1] = patch_read(pbn, r, c + 1);
+				if constexpr (k == 1 && it == 23 && !(DBG & 256)) WF_WAIT_VMCNT(13); // the next chunk's patch (previous trip's pieces): this trip has issued 13 pieces so far
+				if constexpr ((k == 1 || k == 2) && !(DBG & 2) && !LAST) {
+					constexpr int s = it * 2 + (k - 1); // read slot; rows start at slots 46, 49, 54, 57, 60, 63
+					constexpr int r = s >= 63 ? 5 : s >= 60 ? 4 : s >= 57 ? 3 : s >= 54 ? 2 : s >= 49 ? 1 : s >= 46 ? 0 : -1;
+					constexpr int s0 = r == 5 ? 63 : r == 4 ? 60 : r == 3 ? 57 : r == 2 ? 54 : r == 1 ? 49 : 46;
+					if constexpr (r >= 0 && s - s0 < 3) {
+						constexpr int c = (s - s0) * 2;
+						d[r & 1][c] = patch_read(pbn, r, c);
+						d[r & 1][c + 1] = patch_read(pbn, r, c + 1);
+					}
 				}
-				// (c) DMA, one piece per iteration: this wave's share of U(cc + 1), then chunk cc + 2's patch: both have the rest of
-				// this trip and the barrier to land
-				if constexpr (k == 3 && it < 9 && !(DBG & 1)) dma_piece(GroupId<WF_P_PIECES + it>(), p_dst, sp, u_dst, su);
-				if constexpr (k == 3 && it >= 9 && it < 9 + WF_P_PIECES && !(DBG & 1)) dma_piece(GroupId<(it >= 9 ? it - 9 : 0)>(), p_dst, sp, u_dst, su);
+				// (c) DMA: the 20 pieces spread evenly over the 36 iterations (piece n behind iteration 9 n / 5; U pieces and patch
+				// pieces alternating).  A patch piece gathers 32-byte runs out of 32 different cache lines and keeps the CU's address
+				// path busy for ~110 cycles; issued back to back by four waves they queue and the ISSUE blocks (measured: 450 cycles
+				// per piece, 1 ms of conv1_2's 4.2).
+				if constexpr (k == 3 && !(DBG & 1) && wf_piece_at(it) >= 0) {
+					constexpr int n = wf_piece_at(it);
+					constexpr int q = (n & 1) ? (n >> 1) : (n <= 16 ? WF_P_PIECES + (n >> 1) : WF_P_PIECES - 1); // even n <= 16: U piece n / 2; odd n: patch piece n / 2; n = 18: the eleventh patch piece
+					if constexpr (q < WF_P_PIECES ? !(DBG & 512) : !(DBG & 1024)) dma_piece(GroupId<q>(), p_dst, sp, u_dst, su);
+				}
 				__builtin_amdgcn_sched_barrier(0);
 			});
 		});
-	}
-#undef WF_XFORM
-#ifndef NNC_HIP_EMULATOR
-	asm volatile("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
-#endif
-	if constexpr (DBG & 64) { if (a.bias == (const float*)1) a.dst[t] = acc[0][0][0] + acc[35][1][3] + acc[17][0][1]; return; }
+	};
 
-	// ---- epilogue: b = A^T M A (+ bias) straight from the accumulators -- each lane holds all 36 positions of its 4 tiles x 2
-	// channels (D layout of 16x16x4: column (channel) = lane & 15, row (tile) = 4 * (lane >> 4) + r) -- then through LDS so
-	// that a lane stores 16 bytes and a wave whole 128-byte lines: 128 four-byte stores per lane straight from the registers
-	// were store-issue bound (1.7 ms of conv1_2's 5.4 at batch 256).  Staging: one round per r (the 4 tiles 4 g' + r, g' = 0..3:
-	// 4 tiles x 16 pixels x 32 channels + padding = 9 KB per wave, private: no barrier between rounds).
-	if constexpr (DBG & 128) { // direct stores from the registers (the first version; kept for the probe)
-#pragma unroll
-		for (int j = 0; j < 2; j++) {
-			const int k = kb * WF_KT + j * 16 + ti;
-			const float bv = (a.bias && k < a.K) ? a.bias[k] : 0.f;
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const int tile = 4 * g + r;
-				const int oy0 = (gy * GH + (tile >> GWL)) * 4, ox0 = (gx * GW + (tile & (GW - 1))) * 4;
-				float s[4][6];
-#pragma unroll
-				for (int zx = 0; zx < 6; zx++) {
-					const float col[6] = { acc[0 * 6 + zx][j][r], acc[1 * 6 + zx][j][r], acc[2 * 6 + zx][j][r], acc[3 * 6 + zx][j][r], acc[4 * 6 + zx][j][r], acc[5 * 6 + zx][j][r] };
-					float y[4];
-					wino_at(col, y);
-#pragma unroll
-					for (int i = 0; i < 4; i++) s[i][zx] = y[i];
-				}
-				float* const drow = a.dst + (long)n * a.d_sn + k;
-#pragma unroll
-				for (int i = 0; i < 4; i++) {
-					float y[4];
-					wino_at(s[i], y);
-#pragma unroll
-					for (int jj = 0; jj < 4; jj++)
-						if (group_live & (k < a.K) & (oy0 + i < a.OH) & (ox0 + jj < a.OW)) drow[(long)(oy0 + i) * a.d_sh + (long)(ox0 + jj) * a.d_sw] = y[jj] + bv;
-				}
-			}
-		}
-		return;
-	}
-	WF_WAIT_VMCNT(0);             // the last trip's (redundant) DMA pieces must not land on top of the staging area
-	__builtin_amdgcn_s_barrier(); // every wave is done with the U / patch buffers the staging overwrites
-	{
+	// ---- the epilogue of an item: b = A^T M A (+ bias) straight from the accumulators -- each lane holds all 36 positions of
+	// its 4 tiles x 2 channels (D layout of 16x16x4: column (channel) = lane & 15, row (tile) = 4 * (lane >> 4) + r) -- then
+	// through LDS so that a lane stores 16 bytes and a wave whole 128-byte lines: 128 four-byte stores per lane straight from
+	// the registers were store-issue bound (1.7 ms of conv1_2's 5.4 at batch 256).  Staging: the U buffer the item's last trip
+	// has just read (the DMA in flight targets the other one), one round per r (the 4 tiles 4 g' + r, g' = 0..3: 4 tiles x 16
+	// pixels x 32 channels + padding < 9 KB per wave, private: no barrier between rounds).
+	auto epilogue = [&](const Item& it, const int par) {
+#ifndef NNC_HIP_EMULATOR
+		asm volatile("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
+#endif
+		if constexpr (DBG & 64) { if (a.bias == (const float*)1) a.dst[t] = acc[0][0][0] + acc[35][1][3] + acc[17][0][1]; return; }
+		if constexpr (!(DBG & 32)) __builtin_amdgcn_s_barrier(); // every wave is done reading the U buffer the staging overwrites (the DMA in flight targets the other one)
 		constexpr int TS = 16 * 32 + 16; // floats per tile in the staging area: the 4 tiles of a ds_write land on 2 x 16 banks
-		float* const st = lds + wave * (4 * TS);
-		float bv[2][4];
+		float* const st = ubuf + par * WF_U_FLOATS + wave * 2304;
+		static_assert(4 * TS <= 2304, "staging area of a wave: a quarter of a U buffer");
+		// stores: a buffer descriptor over the item's destination image and per-lane byte offsets; a lane outside the image, the
+		// channel range or a dead tile group gets an out-of-range offset and the hardware drops its store -- no branch (the first
+		// version's bounds checks were 296 branches and 5 scalar-store fallbacks per store site: 3100 instructions per epilogue)
+		typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+		const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst + (long)it.n * a.d_sn), 0, a.dst_image_bytes, 0x00020000);
+		const int kq = it.kb * WF_KT + (lane & 7) * 4; // the read-back lane owns channels kq .. kq + 3 (K % 4 == 0: all in or all out) of 8 pixels per round
+		const bool kok = (it.live != 0) & (kq < a.K);
+		float bv[4];
 #pragma unroll
-		for (int i = 0; i < 4; i++) { // the read-back lane owns channels kq .. kq + 3 of 8 pixels per round
-			const int kq = kb * WF_KT + (lane & 7) * 4 + i;
-			bv[0][i] = (a.bias && kq < a.K) ? a.bias[kq] : 0.f;
-		}
+		for (int i = 0; i < 4; i++) bv[i] = (a.bias && kq < a.K) ? a.bias[kq + i] : 0.f;
+		const int dh4 = (int)a.d_sh * 4, dw4 = (int)a.d_sw * 4;
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -477,29 +513,50 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 				}
 			}
 			__builtin_amdgcn_wave_barrier(); // the reads below are other lanes' writes: LDS serves a wave's accesses in order, hipcc must not reorder them
+			if (r == 0) WF_WAIT_VMCNT(0);    // before the first store: every DMA piece of the item's last trip has landed, so the next trip
+			                                 // starts without a wait (a counted wait behind stores would not be safe)
 			// read back: 4 tiles x 16 pixels x 8 channel quads = 512 float4 = 8 per lane; lane -> (channel quad = lane & 7, pixel-in-wave-instruction = lane >> 3)
 #pragma unroll
 			for (int e = 0; e < 8; e++) {
 				const int pid = e * 8 + (lane >> 3);   // 0..63: tile slot pid >> 4 (= g' of the writers), pixel pid & 15
 				const int gp = pid >> 4, px = pid & 15;
 				const int tile = 4 * gp + r;
-				const int oy = (gy * GH + (tile >> GWL)) * 4 + (px >> 2), ox = (gx * GW + (tile & (GW - 1))) * 4 + (px & 3);
+				const int oy = (it.gy * GH + (tile >> GWL)) * 4 + (px >> 2), ox = (it.gx * GW + (tile & (GW - 1))) * 4 + (px & 3);
 				const float4 v = *(const float4*)(st + gp * TS + px * 32 + (lane & 7) * 4);
-				const int kq = kb * WF_KT + (lane & 7) * 4;
-				float* const o = a.dst + (long)n * a.d_sn + (long)oy * a.d_sh + (long)ox * a.d_sw + kq;
-				if (group_live & (oy < a.OH) & (ox < a.OW)) {
-					if (kq + 3 < a.K && a.dst_vec) *(float4*)o = make_float4(v.x + bv[0][0], v.y + bv[0][1], v.z + bv[0][2], v.w + bv[0][3]);
-					else {
-						if (kq < a.K) o[0] = v.x + bv[0][0];
-						if (kq + 1 < a.K) o[1] = v.y + bv[0][1];
-						if (kq + 2 < a.K) o[2] = v.z + bv[0][2];
-						if (kq + 3 < a.K) o[3] = v.w + bv[0][3];
-					}
-				}
+				const unsigned voff = (kok & (oy < a.OH) & (ox < a.OW)) ? (unsigned)(oy * dh4 + ox * dw4 + kq * 4) : WF_OOB;
+				const float o0 = v.x + bv[0], o1 = v.y + bv[1], o2 = v.z + bv[2], o3 = v.w + bv[3];
+				__builtin_amdgcn_raw_buffer_store_b128(u4{ __float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3) }, rs_dst, voff, 0, 0);
 			}
 			__builtin_amdgcn_wave_barrier(); // next round's writes after this round's reads
 		}
+#pragma unroll
+		for (int z = 0; z < 36; z++)
+#pragma unroll
+			for (int j = 0; j < 2; j++) acc[z][j] = floatx4{ 0.f, 0.f, 0.f, 0.f }; // the next item starts from zero (one trip variant: see trip)
+	};
+
+	// ---- the stream
+	int gtrip = 0;
+	for (int ii = 0; ii < count; ii++) {
+		const Item nxt = item_of(ii + 1 < count ? first + ii + 1 : first + ii); // (the last item fetches its own first chunks again: harmless)
+		for (int cc = 0; cc < a.CCn; cc++, gtrip++) {
+			const int par = gtrip & 1;
+			// The previous trip's U pieces (the next chunk's patch is waited for where the trip first reads it): its last four
+			// pieces (n = 17, 18, 19 and the eleventh patch piece) are patch pieces and may stay in flight.  Counted waits are used
+			// only where the newest outstanding operations are all loads -- loads retire in order, stores need not retire in order
+			// with them; after an epilogue (stores) there is nothing to wait for, the epilogue has confirmed every piece.
+			if constexpr (!(DBG & 256)) { if (ii == 0 && cc == 0) WF_WAIT_VMCNT(0); else if (cc != 0) WF_WAIT_VMCNT(4); }
+			if constexpr (!(DBG & 32)) __builtin_amdgcn_s_barrier(); // => all of this chunk's U is in LDS, and every wave is done with the buffers this trip's DMA overwrites
+			if (cc == a.CCn - 2) set_patch(nxt); // the patch fetched from now on (chunk cc + 2) belongs to the next item
+			if (cc == a.CCn - 1) set_u(nxt);     // and so does the U chunk
+			const int c2 = cc + 2 >= a.CCn ? cc + 2 - a.CCn : cc + 2, c1 = cc + 1 >= a.CCn ? 0 : cc + 1;
+			const unsigned sp = (unsigned)c2 * (WF_CC * 4), su = (unsigned)c1 * (WF_U_FLOATS * 4) + (unsigned)wave * 9216u;
+			trip(GroupId<0>(), par, sp, su);
+		}
+		epilogue(cur, (gtrip - 1) & 1); // (S and column 0 of V of the next item's first chunk, made by the last trip, stay in registers across it)
+		cur = nxt;
 	}
+#undef WF_XFORM
 }
 
 } // namespace nnc

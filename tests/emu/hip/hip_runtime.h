@@ -154,6 +154,12 @@ static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(emu_buffer_rsrc r, _
 	if (off + size > r.num_records || off + soffset + size > r.num_records) memset(d, 0, size);
 	else memcpy(d, r.base + off + soffset, size);
 }
+typedef unsigned int emu_u4 __attribute__((ext_vector_type(4)));
+static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u4 v, emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
+{ // out-of-range lanes are dropped
+	if ((unsigned long long)voffset + 16 > r.num_records || (unsigned long long)voffset + soffset + 16 > r.num_records) return;
+	memcpy((char*)r.base + voffset + soffset, &v, 16);
+}
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 // (the "memory" clobbers: a workgroup's LDS is a function-local static whose address never leaves the kernel, so without them
 // the x86 compiler may move a lane's LDS reads above the rendezvous -- other fibers' writes are invisible to its analysis)
@@ -172,6 +178,7 @@ static inline void emu_wave_barrier() { asm volatile("" ::: "memory"); emu::wave
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }

@@ -450,22 +450,34 @@ def test_conv_winograd_image_slices(backend, ref_lib, case):
 
 FUSED_CASES = [
     # n, h, w, c, k, border: fused Winograd (algorithm 2): reduction channels % 8 == 0
-    (1, 16, 16, 8, 32, (1, 1)),     # exactly one 4x4 tile group, one chunk, one k block
+    (1, 16, 16, 16, 32, (1, 1)),    # exactly one 4x4 tile group, two chunks, one k block
     (2, 13, 13, 32, 32, (1, 1)),    # ragged tiles in a 4x4 group (13 -> 4 tiles, 3 clipped rows / columns), several chunks
     (1, 27, 30, 16, 48, (1, 1)),    # 7 x 8 tiles: the 2x8 group shape, ragged K (48 -> two k blocks, the second half empty)
     (3, 9, 14, 24, 20, (0, 0)),     # no padding, K < 32
-    (2, 5, 7, 8, 8, (2, 2)),        # full padding
-    (1, 33, 9, 8, 40, (1, 0)),      # tall image: the 8x2 group shape; asymmetric padding
+    (2, 5, 7, 16, 8, (2, 2)),       # full padding
+    (1, 33, 9, 16, 40, (1, 0)),     # tall image: the 8x2 group shape; asymmetric padding
     (5, 20, 20, 16, 64, (1, 1)),    # more groups than one workgroup's four waves, two k blocks
+    (9, 30, 30, 24, 96, (1, 1)),    # many work items (9 x 4 groups / 4 x 3 k blocks = 27): every persistent workgroup of the emulator's device walks several
 ]
 
 
+@pytest.mark.parametrize("grid", [0, 2, 5])
 @pytest.mark.parametrize("case", FUSED_CASES)
-def test_conv_winograd_fused(backend, ref_lib, case):
-    """cmd.algorithm = 2: the fused Winograd kernel (wino_fused.h; LDS-DMA patches, in-register input and output transforms)
-    for forward and the data gradient, against the reference's direct convolution at 1e-4."""
+def test_conv_winograd_fused(backend, ref_lib, case, grid):
+    """cmd.algorithm = 2: the fused Winograd kernel (wino_fused.h; LDS-DMA patches, in-register input and output transforms,
+    persistent workgroups streaming over work items) for forward and the data gradient (reduction channels >= 16), against the
+    reference's direct convolution at 1e-4."""
     n, h, w, c, k, border = case
     a, wt, b, hint, oh, ow = _wino_inputs(case)
+    backend.tune_set("WINO_FUSED_GRID", grid)  # 2 / 5 workgroups: each walks several work items (the stream across items, uneven ranges)
+    try:
+        _fused_check(backend, ref_lib, case, a, wt, b, hint, oh, ow)
+    finally:
+        backend.tune_set("WINO_FUSED_GRID", 0)
+
+
+def _fused_check(backend, ref_lib, case, a, wt, b, hint, oh, ow):
+    n, h, w, c, k, border = case
     cmd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
     r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [a, wt, b], [np.zeros((n, oh, ow, k), F)], backend=nnc.BACKEND_CPU_REF)
     cmd.algorithm = 2

@@ -50,20 +50,24 @@ int main(int argc, char** argv)
 	a.H = H; a.W = W; a.OH = H; a.OW = W; a.pad_y = 1; a.pad_x = 1;
 	const int TH = (H + 3) / 4, TW = (W + 3) / 4;
 	a.GYn = (TH + 3) / 4; a.GXn = (TW + 3) / 4; a.groups = NB * a.GYn * a.GXn; a.C = C; a.K = K; a.CCn = CCn; a.KB = KB;
-	a.dst_vec = 1;
+	a.dst_image_bytes = (unsigned)(((long)(H - 1) * a.d_sh + (long)(W - 1) * a.d_sw + K) * 4);
 	a.src_image_bytes = (unsigned)(((long)(H - 1) * a.s_sh + (long)(W - 1) * a.s_sw + C) * 4);
 	a.uf_kb_bytes = (unsigned)((size_t)CCn * WF_U_FLOATS * 4);
-	const unsigned grid = (unsigned)((a.groups + 3) / 4 * KB);
+	const int items = (a.groups + 3) / 4 * KB;
+	const int team = argc > 5 ? atoi(argv[5]) : (KB % 4 == 0 ? 4 : (KB % 2 == 0 ? 2 : 1));
+	a.team = team;
+	const unsigned grid = 256;
 	const double flops = 2.0 * 36.0 * (double)a.groups * 16 * K * C; // issued MFMA work (padded tile groups included)
-	printf("fused Winograd 3x3: N=%d %dx%dx%d -> %d; %d workgroups, %d trips each; MFMA floor %.3f ms\n", NB, H, W, C, K, grid, CCn, flops / 157.3e12 * 1e3);
+	printf("fused Winograd 3x3: N=%d %dx%dx%d -> %d; %d work items of %d trips on %d persistent workgroups in teams of %d; MFMA floor %.3f ms\n", NB, H, W, C, K, items, CCn, grid, team, flops / 157.3e12 * 1e3);
 	run<0>(a, grid, flops, "everything");
 	run<1>(a, grid, flops, "no DMA in the loop");
-	run<2>(a, grid, flops, "no patch reads");
-	run<4>(a, grid, flops, "no U fragment reads");
 	run<8>(a, grid, flops, "no transform VALU");
 	run<32>(a, grid, flops, "no barrier");
 	run<64>(a, grid, flops, "no epilogue");
 	run<65>(a, grid, flops, "no epilogue, no DMA");
+	run<256>(a, grid, flops, "no wait for the DMA");
+	run<512>(a, grid, flops, "no patch DMA");
+	run<1024>(a, grid, flops, "no U DMA");
 	run<1 + 2 + 4 + 8 + 32 + 64>(a, grid, flops, "MFMAs only");
 	run<16>(a, grid, flops, "no MFMAs");
 	run<16 + 64>(a, grid, flops, "no MFMAs, no epilogue");
