@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 from ccv_amd import nnc  # noqa: E402
-from ccv_amd.vgg import VGGD, vgg_d_flops_per_image  # noqa: E402
+from ccv_amd.vgg import VGGD, vgg_d_flops_per_image, hash_unit  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 
@@ -47,7 +47,7 @@ def cpu_baseline(image, label):
     from oracle_bind import oracle_lib
     O, backend, per_image = oracle_lib()
     kind = "reference" if O.kind == "reference" else "port"
-    net = VGGD(O, 1, memory=nnc.CPU_MEMORY, backend=backend, pool_per_image=per_image, seed=0)
+    net = VGGD(O, 1, memory=nnc.CPU_MEMORY, backend=backend, pool_per_image=per_image, init="hash")
     net.set_input(image[None], [label])
     REPS = 3
 
@@ -73,6 +73,30 @@ def cpu_baseline(image, label):
             out["forward_only_cpu_opt_images_per_s"] = None
             out["cpu_opt_note"] = str(e)
     return out, loss0
+
+
+def via_host(args, losses, params):
+    """The same training step through the REFERENCE HOST (oracle/_ref/host_vgg_bench.gpu = tools/host_vgg_bench.c against the
+    unmodified reference host + this backend): symbolic graph, ccv_nnc_symbolic_graph_minimize, compile (tensor arena),
+    ccv_nnc_graph_autotune, static schedule -- timed there, and its first step compared with this process's."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_vgg_bench.gpu")
+    if not os.path.exists(exe):
+        return {"status": "oracle/_ref/host_vgg_bench.gpu not built"}
+    try:
+        r = subprocess.run([exe, str(args.batch), "225", str(min(args.steps, 6)), "2"], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            return {"status": "failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
+        h = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"status": "failed: %s" % e}
+    hl = np.array(h["loss"], dtype=np.float64)
+    loss_err = float(np.max(np.abs(hl - losses[:len(hl)]) / np.maximum(np.abs(losses[:len(hl)]), 1e-30)))
+    perr = max(abs(a - b[0]) / max(abs(b[0]), 1e-3 * b[1] ** 0.5, 1e-30) for a, b in zip(h["updated_param_sum"], params))
+    qerr = max(abs(a - b[1]) / max(b[1], 1e-30) for a, b in zip(h["updated_param_sumsq"], params))
+    return {"images_per_s": h["images_per_s"], "ms_per_step": h["ms_per_step"], "autotune_ms": h["autotune_ms"],
+            "step1_max_rel_err_vs_command_driver": {"loss": loss_err, "updated_param_sum": perr, "updated_param_sumsq": qerr},
+            "equal": bool(loss_err <= 1e-4 and qerr <= 1e-4), "driver": h["driver"]}
 
 
 def pmc_traffic(record_name, batch):
@@ -102,6 +126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-via-host", action="store_true", help="skip the second driver: the same step through the reference host's symbolic graph / autotune / static schedule (tools/host_vgg_bench.c)")
     ap.add_argument("--records", default=None, help="also write the per-launch contraction records (name, dims, ms, TFLOP/s) of the roofline leg to this file")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -123,14 +148,12 @@ def main():
         from ccv_amd.comm import ProcessComm
         comm = ProcessComm(L, dist, rank, world)
 
-    net = VGGD(L, args.batch, device=local_rank, seed=0, flat_grads=(world > 1),
+    # parameters, images and labels from the counter hash tools/host_vgg_bench.c uses too: the command driver (this process),
+    # the driver through the reference host (--via-host) and the CPU oracle all run on identical numbers
+    net = VGGD(L, args.batch, device=local_rank, init="hash", flat_grads=(world > 1),
                sgd=(0, 0.001, 1.0 / (args.batch * world), 0.0005, 0.9, 0.9))
-    rng = np.random.default_rng(1234 + rank)
-    chunk = 32
-    imgs = np.empty((args.batch, 225, 225, 3), dtype=np.float32)
-    for i in range(0, args.batch, chunk):
-        imgs[i:i + chunk] = rng.random((min(chunk, args.batch - i), 225, 225, 3), dtype=np.float32)
-    labels = rng.integers(0, 1000, args.batch)
+    imgs = hash_unit(args.batch * 225 * 225 * 3, 1000 + 2 * rank).reshape(args.batch, 225, 225, 3)
+    labels = (hash_unit(args.batch, 1001 + 2 * rank) * np.float32(1000)).astype(np.int32)
     net.set_input(imgs, labels)
     image0, label0 = imgs[0].copy(), int(labels[0])
     del imgs
@@ -160,11 +183,15 @@ def main():
     # Step 1 runs on the initial (seed 0) weights: image 0's loss after it is checked against the oracle's further down
     # (read back between warm-up steps, outside the timed region; with --warmup 0 there is no untimed step and no check).
     step1_loss = None
+    step1_losses = step1_params = None
     for i in range(args.warmup):
         step()
         if i == 0:
             L.stream_wait(stream)
-            step1_loss = float(net.loss.numpy()[0])
+            step1_losses = net.loss.numpy()[:8].astype(np.float64)
+            step1_loss = float(step1_losses[0])
+            if rank == 0 and world == 1 and not args.no_via_host:
+                step1_params = [(float(p.numpy().astype(np.float64).sum()), float((p.numpy().astype(np.float64) ** 2).sum())) for p, _, _ in net.params]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -227,6 +254,8 @@ def main():
                                "traffic": traffic, "kernel": name, "launches": cnt, "avg_ms": ms / cnt,
                                "all_contractions": {"achieved": total_fl / (total_ms * 1e-3) / 1e12, "ms": total_ms,
                                                     "by_kernel": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
+        if step1_params is not None:
+            out["config"]["via_host"] = via_host(args, step1_losses, step1_params)
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], oracle_loss = cpu_baseline(image0, label0)

@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 #include <pthread.h>
 #include <dlfcn.h>
+#include <vector>
 
 using namespace nnc;
 
@@ -29,25 +30,28 @@ namespace {
 
 constexpr int MAX_CLIQUE = 64;
 pthread_mutex_t g_comm_mutex = PTHREAD_MUTEX_INITIALIZER;
-ncclComm_t g_clique[MAX_CLIQUE + 1][MAX_CLIQUE]; // [device_count][device]
-bool g_clique_ready[MAX_CLIQUE + 1];
+// Single-process cliques: one communicator set per (stream context, device count), as the reference keeps them
+// (ccv_nnc_nccl_get_comm, lib/nnc/gpu/ccv_nnc_compat.cu:1415-1445: in the stream's resource container; a static set only for
+// the NULL stream).  The host's scheduler may place the all-reduce nodes of a data-parallel graph on different stream
+// contexts; through ONE communicator RCCL would serialise them and tie the streams together.  Released with the context.
+struct clique_t { const void* ctx; int device_count; ncclComm_t comm[MAX_CLIQUE]; };
+std::vector<clique_t*> g_cliques;
 ncclComm_t g_rank_comm = 0; // deployment (b)
 int g_rank = 0, g_world = 1;
 
-ncclComm_t clique_comm(int device_count, int device)
-{
-	pthread_mutex_lock(&g_comm_mutex);
-	if (!g_clique_ready[device_count]) {
-		int devs[MAX_CLIQUE];
-		for (int i = 0; i < device_count; i++) devs[i] = i;
-		int cur = 0;
-		HIP_ENFORCE(hipGetDevice(&cur));
-		RCCL_ENFORCE(ncclCommInitAll(g_clique[device_count], device_count, devs));
-		HIP_ENFORCE(hipSetDevice(cur));
-		g_clique_ready[device_count] = true;
-	}
-	ncclComm_t c = g_clique[device_count][device];
-	pthread_mutex_unlock(&g_comm_mutex);
+clique_t* clique_of(const void* ctx, int device_count)
+{ // g_comm_mutex held
+	for (size_t i = 0; i < g_cliques.size(); i++)
+		if (g_cliques[i]->ctx == ctx && g_cliques[i]->device_count == device_count) return g_cliques[i];
+	clique_t* c = new clique_t;
+	c->ctx = ctx; c->device_count = device_count;
+	int devs[MAX_CLIQUE];
+	for (int i = 0; i < device_count; i++) devs[i] = i;
+	int cur = 0;
+	HIP_ENFORCE(hipGetDevice(&cur));
+	RCCL_ENFORCE(ncclCommInitAll(c->comm, device_count, devs));
+	HIP_ENFORCE(hipSetDevice(cur));
+	g_cliques.push_back(c);
 	return c;
 }
 
@@ -66,6 +70,49 @@ hipStream_t neighbor_stream(ccv_nnc_stream_context_t* ctx, int device)
 	return ccv_nnc_stream_context_get_device(ctx) == device ? stream_of(ctx) : (hipStream_t)0;
 }
 
+// Coalescing.  The reference host issues ONE collective per parameter tensor (ccv_nnc_symbolic_graph_parallel.c:545-575): for
+// VGG-D 32 of them from 256 bytes up, each its own RCCL launch on every device.  xGMI is point-to-point, the small ones are
+// pure launch latency.  A COMM command therefore only RECORDS its collectives; they are issued -- all recorded ones inside
+// one ncclGroupStart / End, which RCCL aggregates into one launch per device -- the moment anything else could observe
+// the order: the next non-COMM launch of this library on any stream (stream_of), a synchronise, a signal, a host callback,
+// or MAX_PENDING records.  Back-to-back COMM nodes of a schedule (a layer's weight and bias, the tail of backward) thus
+// travel together; results and stream order are exactly those of immediate issue.
+struct pending_t { int op; const float* in; float* out; size_t count; int root; ncclComm_t comm; hipStream_t stream; int device; };
+constexpr int MAX_PENDING = 256;
+pending_t g_pending[MAX_PENDING];
+int g_pending_n = 0;
+long g_stat_collectives = 0, g_stat_groups = 0;
+thread_local int tl_in_comm = 0; // stream_of() calls made while recording / flushing must not recurse into the flush
+
+void flush_locked()
+{
+	if (!g_pending_n) return;
+	tl_in_comm++;
+	int cur = 0;
+	HIP_ENFORCE(hipGetDevice(&cur));
+	RCCL_ENFORCE(ncclGroupStart());
+	for (int i = 0; i < g_pending_n; i++) {
+		const pending_t& p = g_pending[i];
+		if (p.op == 0) RCCL_ENFORCE(ncclAllReduce(p.in, p.out, p.count, ncclFloat, ncclSum, p.comm, p.stream));
+		else if (p.op == 1) RCCL_ENFORCE(ncclBroadcast(p.in, p.out, p.count, ncclFloat, p.root, p.comm, p.stream));
+		else RCCL_ENFORCE(ncclReduce(p.in, p.out, p.count, ncclFloat, ncclSum, p.root, p.comm, p.stream));
+	}
+	RCCL_ENFORCE(ncclGroupEnd());
+	HIP_ENFORCE(hipSetDevice(cur));
+	g_stat_collectives += g_pending_n; g_stat_groups++;
+	g_pending_n = 0;
+	nnc::g_comm_pending = 0;
+	tl_in_comm--;
+}
+
+void record(const int op, const float* in, float* out, size_t count, int root, ncclComm_t comm, hipStream_t stream, int device)
+{ // g_comm_mutex held
+	if (g_pending_n == MAX_PENDING) flush_locked();
+	pending_t& p = g_pending[g_pending_n++];
+	p.op = op; p.in = in; p.out = out; p.count = count; p.root = root; p.comm = comm; p.stream = stream; p.device = device;
+	nnc::g_comm_pending = 1;
+}
+
 bool comm_tensor_ok(const ccv_nnc_tensor_t* t, size_t count)
 {
 	return t && tensor_contiguous(t) && tensor_count(t->info) == count && CCV_GET_DATA_TYPE(t->info.datatype) == CCV_32F;
@@ -80,43 +127,40 @@ int comm_exec(const int op, ccv_nnc_tensor_t* const* const inputs, const int inp
 	const ccv_nnc_tensor_t* first = op == OP_REDUCE ? outputs[0] : inputs[0];
 	if (!first) return CCV_NNC_EXEC_INVALID;
 	const size_t count = tensor_count(first->info);
+	tl_in_comm++;
+	pthread_mutex_lock(&g_comm_mutex);
+	int ret = CCV_NNC_EXEC_SUCCESS;
 	if (g_rank_comm) { // (b): one tensor per process
-		if (n != 1 || !comm_tensor_ok(inputs[0], count) || !comm_tensor_ok(outputs[0], count)) return CCV_NNC_EXEC_INVALID;
-		hipStream_t st = stream_of(ctx);
-		if (op == OP_ALLREDUCE) RCCL_ENFORCE(ncclAllReduce(inputs[0]->data.f32, outputs[0]->data.f32, count, ncclFloat, ncclSum, g_rank_comm, st));
-		else if (op == OP_BROADCAST) RCCL_ENFORCE(ncclBroadcast(inputs[0]->data.f32, outputs[0]->data.f32, count, ncclFloat, 0, g_rank_comm, st));
-		else RCCL_ENFORCE(ncclReduce(inputs[0]->data.f32, outputs[0]->data.f32, count, ncclFloat, ncclSum, 0, g_rank_comm, st));
-		return CCV_NNC_EXEC_SUCCESS;
+		if (n != 1 || !comm_tensor_ok(inputs[0], count) || !comm_tensor_ok(outputs[0], count)) ret = CCV_NNC_EXEC_INVALID;
+		else record(op == OP_ALLREDUCE ? 0 : op == OP_BROADCAST ? 1 : 2, inputs[0]->data.f32, outputs[0]->data.f32, count, 0, g_rank_comm, stream_of(ctx), -1);
+	} else {
+		int device_count = 0;
+		for (int i = 0; i < n && ret == CCV_NNC_EXEC_SUCCESS; i++) {
+			const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
+			if (!comm_tensor_ok(t, count)) ret = CCV_NNC_EXEC_INVALID;
+			else if (op == OP_ALLREDUCE && !comm_tensor_ok(inputs[i], count)) ret = CCV_NNC_EXEC_INVALID;
+			else {
+				const int d = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
+				if (d + 1 > device_count) device_count = d + 1;
+			}
+		}
+		if (device_count > MAX_CLIQUE) ret = CCV_NNC_EXEC_INVALID;
+		if (ret == CCV_NNC_EXEC_SUCCESS) {
+			const int root = op == OP_BROADCAST ? CCV_TENSOR_GET_DEVICE_ID(inputs[0]->info.type) : op == OP_REDUCE ? CCV_TENSOR_GET_DEVICE_ID(outputs[0]->info.type) : 0;
+			clique_t* const cl = clique_of(ctx, device_count);
+			for (int i = 0; i < n; i++) {
+				const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
+				const int d = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
+				hipStream_t st = neighbor_stream(ctx, d);
+				if (op == OP_ALLREDUCE) record(0, inputs[i]->data.f32, outputs[i]->data.f32, count, 0, cl->comm[d], st, d);
+				else if (op == OP_BROADCAST) record(1, inputs[0]->data.f32, outputs[i]->data.f32, count, root, cl->comm[d], st, d);
+				else record(2, inputs[i]->data.f32, outputs[0]->data.f32, count, root, cl->comm[d], st, d);
+			}
+		}
 	}
-	int device_count = 0;
-	for (int i = 0; i < n; i++) {
-		const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
-		if (!comm_tensor_ok(t, count)) return CCV_NNC_EXEC_INVALID;
-		if (op == OP_ALLREDUCE && !comm_tensor_ok(inputs[i], count)) return CCV_NNC_EXEC_INVALID;
-		const int d = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
-		if (d + 1 > device_count) device_count = d + 1;
-	}
-	if (device_count > MAX_CLIQUE) return CCV_NNC_EXEC_INVALID;
-	int cur = 0;
-	HIP_ENFORCE(hipGetDevice(&cur));
-	const int root = op == OP_BROADCAST ? CCV_TENSOR_GET_DEVICE_ID(inputs[0]->info.type) : op == OP_REDUCE ? CCV_TENSOR_GET_DEVICE_ID(outputs[0]->info.type) : 0;
-	for (int i = 0; i < n; i++) { // create (cache) the clique before the group
-		const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
-		clique_comm(device_count, CCV_TENSOR_GET_DEVICE_ID(t->info.type));
-	}
-	RCCL_ENFORCE(ncclGroupStart());
-	for (int i = 0; i < n; i++) {
-		const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
-		const int d = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
-		ncclComm_t comm = clique_comm(device_count, d);
-		hipStream_t st = neighbor_stream(ctx, d);
-		if (op == OP_ALLREDUCE) RCCL_ENFORCE(ncclAllReduce(inputs[i]->data.f32, outputs[i]->data.f32, count, ncclFloat, ncclSum, comm, st));
-		else if (op == OP_BROADCAST) RCCL_ENFORCE(ncclBroadcast(inputs[0]->data.f32, outputs[i]->data.f32, count, ncclFloat, root, comm, st));
-		else RCCL_ENFORCE(ncclReduce(inputs[i]->data.f32, outputs[0]->data.f32, count, ncclFloat, ncclSum, root, comm, st));
-	}
-	RCCL_ENFORCE(ncclGroupEnd());
-	HIP_ENFORCE(hipSetDevice(cur));
-	return CCV_NNC_EXEC_SUCCESS;
+	pthread_mutex_unlock(&g_comm_mutex);
+	tl_in_comm--;
+	return ret;
 }
 
 static int _allreduce(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
@@ -168,13 +212,44 @@ int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size
 	pthread_mutex_unlock(&g_comm_mutex);
 	return ret;
 }
+void nnc_mi355x_comm_stats(long* collectives, long* groups)
+{
+	pthread_mutex_lock(&g_comm_mutex);
+	*collectives = g_stat_collectives; *groups = g_stat_groups;
+	pthread_mutex_unlock(&g_comm_mutex);
+}
 void nnc_mi355x_comm_destroy(void)
 {
 	pthread_mutex_lock(&g_comm_mutex);
+	flush_locked();
 	if (g_rank_comm) { (void)ncclCommDestroy(g_rank_comm); g_rank_comm = 0; }
 	pthread_mutex_unlock(&g_comm_mutex);
 }
 
+}
+
+namespace nnc {
+volatile int g_comm_pending = 0;
+void comm_flush(void)
+{ // called (through the g_comm_pending check) by stream_of, synchronise, signals, callbacks: see "Coalescing" above
+	if (tl_in_comm) return;
+	pthread_mutex_lock(&g_comm_mutex);
+	flush_locked();
+	pthread_mutex_unlock(&g_comm_mutex);
+}
+void comm_release_context(const void* ctx)
+{ // the stream context is going away: its communicator sets with it
+	pthread_mutex_lock(&g_comm_mutex);
+	flush_locked();
+	for (size_t i = 0; i < g_cliques.size();) {
+		if (g_cliques[i]->ctx == ctx) {
+			for (int d = 0; d < g_cliques[i]->device_count; d++) (void)ncclCommDestroy(g_cliques[i]->comm[d]);
+			delete g_cliques[i];
+			g_cliques.erase(g_cliques.begin() + i);
+		} else i++;
+	}
+	pthread_mutex_unlock(&g_comm_mutex);
+}
 }
 
 #define NNC_REG(CMD, EXEC) \

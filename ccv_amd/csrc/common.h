@@ -97,6 +97,12 @@ static inline bool image4(const ccv_nnc_tensor_t* t, Image4* o)
 	return true;
 }
 
+// Recorded-but-not-yet-issued collectives (cmd_comm.cpp "Coalescing"): anything that could observe stream order flushes them first.
+extern volatile int g_comm_pending;
+void comm_flush(void);
+void comm_release_context(const void* ctx);
+static inline void comm_flush_if_pending(void) { if (g_comm_pending) comm_flush(); }
+
 // The HIP stream a command must enqueue on, and that stream's scratch memory.
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx);
 void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size);

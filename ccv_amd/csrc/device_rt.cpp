@@ -115,6 +115,7 @@ namespace nnc {
 
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
 {
+	comm_flush_if_pending(); // a launch is about to be ordered on a stream: recorded collectives go first (cmd_comm.cpp)
 	if (!ctx) return (hipStream_t)0;
 	if (CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU) return (hipStream_t)0;
 	return bind(ctx)->stream;
@@ -220,6 +221,7 @@ void* nnc_mi355x_malloc(int device, size_t size)
 
 void nnc_mi355x_free(int device, void* ptr)
 {
+	nnc::comm_flush_if_pending(); // a recorded collective may still name this memory
 	HIP_ENFORCE(hipSetDevice(device));
 	HIP_ENFORCE(hipFree(ptr));
 }
@@ -231,6 +233,7 @@ void nnc_mi355x_set_device(int device)
 
 void nnc_mi355x_memcpy(void* dest, const int dest_type, const void* src, const int src_type, size_t n)
 {
+	nnc::comm_flush_if_pending();
 	if (n == 0) return;
 	const int sm = CCV_TENSOR_GET_MEMORY(src_type), dm = CCV_TENSOR_GET_MEMORY(dest_type);
 	if (sm == CCV_TENSOR_CPU_MEMORY && dm == CCV_TENSOR_GPU_MEMORY) {
@@ -324,6 +327,7 @@ static void local_release(device_local_t* l)
 
 void ccv_nnc_deinit_stream_context(ccv_nnc_stream_context_t* const stream_context)
 {
+	nnc::comm_release_context(stream_context);
 	stream_gpu_t* s = (stream_gpu_t*)stream_context;
 	if (s->cpu.workspace) free(s->cpu.workspace);
 	s->cpu.workspace = 0; s->cpu.workspace_size = 0;
@@ -335,6 +339,7 @@ void ccv_nnc_deinit_stream_context(ccv_nnc_stream_context_t* const stream_contex
 
 void ccv_nnc_synchronize_stream_context(const ccv_nnc_stream_context_t* const stream_context)
 {
+	nnc::comm_flush_if_pending();
 	if (!stream_context) { HIP_ENFORCE(hipStreamSynchronize((hipStream_t)0)); return; }
 	HIP_ENFORCE(hipStreamSynchronize(bind(stream_context)->stream));
 }
@@ -384,7 +389,8 @@ static void local_drain(device_local_t* l, hipStream_t st)
 }
 
 void ccv_nnc_stream_compat_drain(ccv_nnc_stream_context_t* const stream_context)
-{ // drop the scratch buffers (the host calls this under memory pressure, ccv_nnc_stream.c:70-86)
+{
+	nnc::comm_flush_if_pending(); // drop the scratch buffers (the host calls this under memory pressure, ccv_nnc_stream.c:70-86)
 	if (!stream_context) {
 		free(tl_default_cpu.workspace);
 		tl_default_cpu.workspace = 0; tl_default_cpu.workspace_size = 0;
@@ -419,6 +425,7 @@ static void host_async_trampoline(void* userdata)
 }
 void ccv_nnc_stream_compat_add_callback(ccv_nnc_stream_context_t* const stream, const ccv_nnc_callback_f callback, const ccv_nnc_async_callback_f async_callback, void* const callback_context)
 {
+	nnc::comm_flush_if_pending();
 	device_local_t* s = bind(stream);
 	ccv_nnc_async_callback_t* async = (ccv_nnc_async_callback_t*)malloc(sizeof(ccv_nnc_async_callback_t));
 	async->fn = callback;
@@ -447,10 +454,12 @@ void ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal)
 }
 void ccv_nnc_stream_compat_emit_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
+	nnc::comm_flush_if_pending();
 	HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, bind(stream)->stream));
 }
 void ccv_nnc_stream_compat_wait_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
+	nnc::comm_flush_if_pending();
 	HIP_ENFORCE(hipStreamWaitEvent(bind(stream)->stream, ((const signal_gpu_t*)signal)->event, 0));
 }
 int ccv_nnc_stream_context_get_device(const ccv_nnc_stream_context_t* const stream_context)

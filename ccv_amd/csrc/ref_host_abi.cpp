@@ -62,6 +62,7 @@ static void co_resume_on_stream_done(void* userdata)
 // on the HIP stream re-schedules it once everything enqueued so far has completed.
 int co_stream_compat_await(co_routine_t* const self, ccv_nnc_stream_context_t* const stream)
 {
+	nnc::comm_flush_if_pending();
 	hipStream_t st = nnc::stream_of(stream);
 	const hipError_t q = hipStreamQuery(st);
 	if (q == hipSuccess) return 1;

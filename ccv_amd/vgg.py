@@ -44,6 +44,17 @@ def vgg_d_flops_per_image(input_hw=225, layers=VGG_D, in_channels=3):
     return fwd, fwd + bwd
 
 
+def hash_unit(n, stream):
+    """[0, 1) floats 0 .. n-1 of stream `stream`: the counter hash of tools/host_vgg_bench.c (splitmix64 finaliser), so that the
+    driver through the reference host and this one run on identical parameters / images / labels."""
+    with np.errstate(over="ignore"):
+        h = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(((stream + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF)
+        h ^= h >> np.uint64(30); h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(27); h *= np.uint64(0x94D049BB133111EB)
+        h ^= h >> np.uint64(31)
+    return (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
 class VGGD:
     def __init__(self, lib, batch, memory=nnc.GPU_MEMORY, device=0, input_hw=225, layers=VGG_D, classes=None, seed=0, backend=None,
                  sgd=(0, 0.001, None, 0.0005, 0.9, 0.9), train=True, init="numpy", pool_per_image=False, flat_grads=False):
@@ -54,6 +65,7 @@ class VGGD:
         self.layers = list(layers)
         self.train = train
         rng = np.random.default_rng(seed)
+        self._hash_stream = 0
         F = nnc.CCV_32F
         mk = lambda *dims: lib.tensor(nnc.tensor_param(memory, nnc.NHWC, F, dims, device))
         self.x = mk(batch, input_hw, input_hw, 3)
@@ -149,7 +161,14 @@ class VGGD:
 
     def _param(self, rng, dims, fan_in, init):
         # weights ~ U(-1, 1) * sqrt(6 / fan_in) (keeps activations O(1) through 16 ReLU layers); biases small positive
-        if fan_in:
+        if init == "hash":  # the counter hash of tools/host_vgg_bench.c: parameter tensor number = stream id, same float arithmetic
+            u = hash_unit(int(np.prod(dims)), self._hash_stream).reshape(dims)
+            self._hash_stream += 1
+            if fan_in:
+                arr = ((u - np.float32(0.5)) * np.float32(2) * np.float32(np.sqrt(np.float32(6.0) / np.float32(fan_in)))).astype(np.float32)
+            else:
+                arr = (u * np.float32(0.01)).astype(np.float32)
+        elif fan_in:
             arr = ((rng.random(dims, dtype=np.float32) - 0.5) * 2 * np.sqrt(6.0 / fan_in)).astype(np.float32)
         else:
             arr = (rng.random(dims, dtype=np.float32) * 0.01).astype(np.float32)

@@ -331,6 +331,9 @@ int nnc_mi355x_cmd_ok(const uint32_t cmd, const uint32_t backend); /* ccv_nnc_cm
 int nnc_mi355x_comm_unique_id(void* id_out_128_bytes);
 int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size);
 void nnc_mi355x_comm_destroy(void);
+/* Counters of the COMM commands' coalescing (cmd_comm.cpp): per-device collectives issued so far, and the RCCL groups they
+ * travelled in (consecutive COMM commands share one group). */
+void nnc_mi355x_comm_stats(long* collectives, long* groups);
 
 /* ------------------------------------------------ 5. classic image pre-process loops (batch form) -------------------- */
 /* A batch of `count` same-sized images resident in HBM: image i starts at base + i * image_stride; rows are `step` bytes

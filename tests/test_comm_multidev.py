@@ -1,0 +1,59 @@
+"""COMM_ALLREDUCE / BROADCAST / REDUCE in the reference's single-process N-device form on the 4-device CPU emulator (its
+in-process RCCL stand-in): collectives issued from TWO stream contexts (each gets its own communicator set, as the reference
+keeps them per stream: lib/nnc/gpu/ccv_nnc_compat.cu:1415-1445), consecutive commands coalesced into one RCCL group, results
+exact.  Runs in a subprocess (the device count of the emulator is fixed at load time)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = textwrap.dedent("""
+    import ctypes as C, sys, numpy as np
+    sys.path.insert(0, %r)
+    from ccv_amd import nnc
+    L = nnc.load(%r)
+    assert L.device_count() == 4
+    rng = np.random.default_rng(3)
+    F = nnc.CCV_32F
+    def on(dev, arr):
+        return L.tensor(nnc.GPU_TENSOR_NHWC(dev, F, *arr.shape), arr)
+    sA, sB = L.stream_new(0), L.stream_new(0)
+    xa = [rng.standard_normal(1000).astype(np.float32) for _ in range(4)]
+    xb = [rng.standard_normal((8, 16)).astype(np.float32) for _ in range(4)]
+    ta, tb = [on(d, xa[d]) for d in range(4)], [on(d, xb[d]) for d in range(4)]
+    ar = nnc.generic_cmd("COMM_ALLREDUCE_FORWARD")
+    c0, g0 = C.c_long(), C.c_long()
+    L.dll.nnc_mi355x_comm_stats(C.byref(c0), C.byref(g0))
+    assert L.cmd_exec(ar, nnc.NO_HINT, 0, ta, ta, sA) == 0          # two commands back to back, different stream contexts:
+    assert L.cmd_exec(ar, nnc.NO_HINT, 0, tb, tb, sB) == 0          # recorded, then issued together
+    L.stream_wait(sA); L.stream_wait(sB)
+    c1, g1 = C.c_long(), C.c_long()
+    L.dll.nnc_mi355x_comm_stats(C.byref(c1), C.byref(g1))
+    assert c1.value - c0.value == 8 and g1.value - g0.value == 1, (c1.value - c0.value, g1.value - g0.value)
+    sa, sb = sum(x.astype(np.float64) for x in xa), sum(x.astype(np.float64) for x in xb)
+    for d in range(4):
+        np.testing.assert_allclose(ta[d].numpy(), sa, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(tb[d].numpy(), sb, rtol=1e-6, atol=1e-6)
+    # broadcast from device 2, reduce to device 1; a non-COMM command in between is ordered after the recorded collective
+    src = on(2, xa[0]); outs = [on(d, np.zeros(1000, np.float32)) for d in range(4)]
+    assert L.cmd_exec(nnc.generic_cmd("COMM_BROADCAST_FORWARD"), nnc.NO_HINT, 0, [src], outs, sA) == 0
+    assert L.cmd_exec(nnc.CMD_SCALAR_MUL_FORWARD(2.0), nnc.NO_HINT, 0, [outs[0]], [outs[0]], sA) == 0
+    L.stream_wait(sA)
+    np.testing.assert_array_equal(outs[0].numpy(), 2 * xa[0])
+    np.testing.assert_array_equal(outs[3].numpy(), xa[0])
+    red = on(1, np.zeros(1000, np.float32))
+    assert L.cmd_exec(nnc.generic_cmd("COMM_REDUCE_FORWARD"), nnc.NO_HINT, 0, [on(d, xa[d]) for d in range(4)], [red], sB) == 0
+    L.stream_wait(sB)
+    np.testing.assert_allclose(red.numpy(), sa, rtol=1e-6, atol=1e-6)
+    L.stream_free(sA); L.stream_free(sB)   # releases the two contexts' communicator sets
+    print("OK")
+""")
+
+
+def test_comm_two_stream_contexts_coalesced(emu_lib):
+    env = dict(os.environ, NNC_EMU_DEVICE_COUNT="4")
+    so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    r = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, so)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
