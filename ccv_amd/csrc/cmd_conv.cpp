@@ -9,6 +9,7 @@
 #include "gemm_launch.h"
 #include "winograd.h"
 #include "wino_fused.h"
+#include "conv_c3.h"
 
 using namespace nnc;
 
@@ -313,9 +314,64 @@ static bool wino_preferred(const wino_plan_t& p, const int C_src, const int C_ds
 	return C_src >= 32 && C_dst >= 32 && p.T >= 32;
 }
 
+// ---- first-layer convolution (3 input channels): conv_c3.h ----------------------------------------------------------------
+static bool conv_c3_ok(const conv_geom_t& g, const Image4& a, const Image4& b)
+{
+	if (g.C != 3 || g.kh != 3 || g.kw != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.groups != 1) return false;
+	if (g.K != 16 && g.K != 32 && g.K != 64) return false;
+	if (a.sc != 1 || a.sw != 3 || b.sc != 1 || !aligned16(b.p) || b.sw % 4 || b.sh % 4 || (b.n > 1 && b.sn % 4)) return false;
+	return (long)b.n * b.h * ((b.w + 15) / 16) < 0x7fffffffL;
+}
+static void conv_c3_args(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, ConvC3Args* c)
+{
+	c->a = a.p; c->w = w; c->bias = bias; c->b = b.p;
+	c->a_sn = a.sn; c->a_sh = a.sh; c->b_sn = b.sn; c->b_sh = b.sh; c->b_sw = b.sw;
+	c->N = g.N; c->H = g.H; c->W = g.W; c->OH = g.OH; c->OW = g.OW; c->K = g.K; c->pad_y = g.pby; c->pad_x = g.pbx;
+	c->groups_per_row = (g.OW + 15) / 16; c->groups = g.N * g.OH * c->groups_per_row;
+}
+static int conv_c3_forw(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, ccv_nnc_stream_context_t* const ctx)
+{
+	ConvC3Args c;
+	conv_c3_args(g, a, w, bias, b, &c);
+	hipStream_t stream = stream_of(ctx);
+	const long want = ((long)c.groups + 3) / 4, cap = (long)device_cu_count() * 8;
+	const unsigned grid = (unsigned)(want < cap ? want : cap);
+	note_kernel("conv_fwd_c3");
+	ProfScope prof("conv_fwd_c3|nnc::conv3x3_c3_fwd_kernel", 2.0 * g.N * g.OH * g.OW * (double)g.K * 27, 0, g.N * g.OH * g.OW, g.K, 27, 1, 1, stream);
+	if (g.K == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_fwd_kernel<4>), dim3(grid), dim3(256), 0, stream, c);
+	else if (g.K == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_fwd_kernel<2>), dim3(grid), dim3(256), 0, stream, c);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_fwd_kernel<1>), dim3(grid), dim3(256), 0, stream, c);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+// dw (+)= and dbias (+)= in one pass over the output gradient
+static int conv_c3_wgrad(const conv_geom_t& g, const Image4& gr, const Image4& a, float* dw, float* dbias, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	ConvC3Args c;
+	conv_c3_args(g, a, 0, 0, gr, &c);
+	const long want = ((long)c.groups + 3) / 4, cap = (long)device_cu_count() * 4;
+	const unsigned grid = (unsigned)(want < cap ? want : cap);
+	const int waves = (int)grid * 4;
+	float* const part = (float*)workspace_of(ctx, sizeof(float) * (size_t)waves * g.K * 32);
+	if (!part) return CCV_NNC_EXEC_OOM;
+	hipStream_t stream = stream_of(ctx);
+	note_kernel("conv_wgrad_c3");
+	{
+		ProfScope prof("conv_wgrad_c3|nnc::conv3x3_c3_wgrad_kernel", 2.0 * g.N * g.OH * g.OW * (double)g.K * 27, 0, g.K, 27, g.N * g.OH * g.OW, 1, 1, stream);
+		if (g.K == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_wgrad_kernel<4>), dim3(grid), dim3(256), 0, stream, c, part);
+		else if (g.K == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_wgrad_kernel<2>), dim3(grid), dim3(256), 0, stream, c, part);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_wgrad_kernel<1>), dim3(grid), dim3(256), 0, stream, c, part);
+	}
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(convc3_wgrad_fold, dim3((unsigned)((g.K * 32 + 255) / 256)), dim3(256), 0, stream, (const float*)part, waves, g.K, dw, dbias, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, const int algo, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	if (a.sc != 1 || !pixel_linear(b) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && conv_c3_ok(g, a, b)) return conv_c3_forw(g, a, w, bias, b, ctx);
 	wino_plan_t wp;
 	wino_fused_plan_t fp;
 	if (algo != CONV_ALGO_IMPLICIT_GEMM && algo != CONV_ALGO_WINOGRAD && g.pby <= 2 && g.pbx <= 2 && g.pby >= 0 && g.pbx >= 0 && wino_fused_plan(g, a, b, &fp) && (algo == CONV_ALGO_WINOGRAD_FUSED || wino_fused_preferred(g.C, fp, b))) {
@@ -390,6 +446,11 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 {
 	if (bias_done) *bias_done = false;
 	if (a.sc != 1 || !pixel_linear(gr) || !image_fits_int(a)) return CCV_NNC_EXEC_INVALID;
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && conv_c3_ok(g, a, gr)) {
+		const int r = conv_c3_wgrad(g, gr, a, dw, dbias, flags, ctx);
+		if (r == CCV_NNC_EXEC_SUCCESS && bias_done) *bias_done = dbias != 0;
+		if (r != CCV_NNC_EXEC_OOM) return r;
+	}
 	wino_wgrad_plan_t wp;
 	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wp) && wino_images_ok(a, gr, dw, 0) && (algo >= CONV_ALGO_WINOGRAD || wino_preferred(wp.t, g.C, g.K))) {
 		const int r = conv_wino_wgrad(g, wp, gr, a, dw, dbias, bias_done, flags, ctx);

@@ -22,14 +22,29 @@ __global__ void __launch_bounds__(EW_THREADS) ew_map_kernel(F f, float* out, con
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	for (size_t i = tid; i < n4; i += stride) {
+	// four independent 16-byte loads per input in flight per thread (one per trip left the chip at 4.9-5.1 TB/s on the ReLU
+	// passes of VGG-D: 2048 workgroups x 256 threads x 16 bytes = 8 MB in flight against ~13 MB of bandwidth-delay product)
+	size_t i = tid;
+	for (; i + 3 * stride < n4; i += 4 * stride) {
+		float4 a[4], b[4], c[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			a[u] = NIN > 0 ? ((const float4*)in0)[i + u * stride] : make_float4(0, 0, 0, 0);
+			b[u] = NIN > 1 ? ((const float4*)in1)[i + u * stride] : make_float4(0, 0, 0, 0);
+			c[u] = NIN > 2 ? ((const float4*)in2)[i + u * stride] : make_float4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			((float4*)out)[i + u * stride] = make_float4(f(a[u].x, b[u].x, c[u].x), f(a[u].y, b[u].y, c[u].y), f(a[u].z, b[u].z, c[u].z), f(a[u].w, b[u].w, c[u].w));
+	}
+	for (; i < n4; i += stride) {
 		const float4 a = NIN > 0 ? ((const float4*)in0)[i] : make_float4(0, 0, 0, 0);
 		const float4 b = NIN > 1 ? ((const float4*)in1)[i] : make_float4(0, 0, 0, 0);
 		const float4 c = NIN > 2 ? ((const float4*)in2)[i] : make_float4(0, 0, 0, 0);
 		((float4*)out)[i] = make_float4(f(a.x, b.x, c.x), f(a.y, b.y, c.y), f(a.z, b.z, c.z), f(a.w, b.w, c.w));
 	}
-	for (size_t i = n4 * 4 + tid; i < n; i += stride)
-		out[i] = f(NIN > 0 ? in0[i] : 0.f, NIN > 1 ? in1[i] : 0.f, NIN > 2 ? in2[i] : 0.f);
+	for (size_t j = n4 * 4 + tid; j < n; j += stride)
+		out[j] = f(NIN > 0 ? in0[j] : 0.f, NIN > 1 ? in1[j] : 0.f, NIN > 2 ? in2[j] : 0.f);
 }
 
 template <class F, int NIN>

@@ -1,0 +1,148 @@
+// First-layer convolution: 3x3, stride 1, THREE input channels (VGG-D conv1_1, BASELINE config 1), forward and filter gradient.
+// On the general contraction kernel its 27-deep reduction is padded to a 32-deep K-step on 32x32x2 MFMAs and the wide
+// output tile is written behind a long epilogue: 19 TFLOP/s, 2.3 ms for a 3.26 GB store at batch 256 (1.4 TB/s).  These kernels
+// are shaped by the tensor instead:
+//   * the 27 inputs of an output pixel are three runs of 9 contiguous floats (3 pixels x 3 channels of NHWC rows), so the
+//     A fragment of v_mfma_f32_16x16x4_f32 -- lane (pixel = l & 15, k = 4 s + (l >> 4)) -- is seven scalar loads per lane out
+//     of lines the neighbouring lanes touch as well (L1), no staging;
+//   * the filters (27 x K floats) live in registers for the whole kernel, as B fragments with output channel N n + j in
+//     column n of channel tile j, so that a lane ends up with N CONSECUTIVE channels of a pixel and stores 16 bytes;
+//   * a wave turns 16 consecutive pixels of an output row into 16 x K outputs with 7 (k steps) x K / 16 MFMAs and four 16-byte
+//     stores per lane: the kernel is bound by the output store (forward) or the read of the output gradient (filter gradient).
+#pragma once
+#include "mfma_gemm.h"
+
+namespace nnc {
+
+struct ConvC3Args {
+	const float* a;   // [N][H][W][3]
+	const float* w;   // [K][3][3][3]
+	const float* bias;
+	float* b;         // forward: output [N][OH][OW][K];  filter gradient: the output GRADIENT (read)
+	long a_sn, a_sh, b_sn, b_sh, b_sw; // element strides (a: pixel stride 3)
+	int N, H, W, OH, OW, K;
+	int pad_y, pad_x;
+	int groups_per_row, groups; // 16-pixel groups per output row, total
+};
+
+// element k (0..26; 27 = padding) of the patch of output pixel (oy, ox): row dy = k / 9, offset k % 9 into the 9-float run
+__device__ __forceinline__ float convc3_patch(const float* const img, const ConvC3Args& g, const int oy, const int ox, const int k)
+{
+	const int dy = k / 9, r9 = k - dy * 9, dx = r9 / 3;
+	const int iy = oy - g.pad_y + dy, ix = ox - g.pad_x + dx;
+	const bool ok = (k < 27) & (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.W);
+	return ok ? img[(long)iy * g.a_sh + (ox - g.pad_x) * 3 + r9] : 0.f;
+}
+
+// NT = K / 16 (1, 2 or 4 channel tiles).  grid: as many workgroups as fit the chip; waves stride over the pixel groups.
+template <int NT>
+static __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const ConvC3Args g)
+{
+	const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+	float wf[7][NT]; // B fragments: k = 4 s + kq, channel NT * n + j
+#pragma unroll
+	for (int s = 0; s < 7; s++)
+#pragma unroll
+		for (int j = 0; j < NT; j++) {
+			const int k = 4 * s + kq;
+			wf[s][j] = k < 27 ? g.w[(long)(NT * n + j) * 27 + k] : 0.f;
+		}
+	float bv[NT];
+#pragma unroll
+	for (int j = 0; j < NT; j++) bv[j] = g.bias ? g.bias[NT * n + j] : 0.f;
+	const int waves = (gridDim.x * blockDim.x) >> 6;
+	for (int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; grp < g.groups; grp += waves) {
+		const int row = grp / g.groups_per_row, gx = grp - row * g.groups_per_row; // row = n * OH + oy
+		const int img = row / g.OH, oy = row - img * g.OH;
+		const int ox0 = gx * 16;
+		const float* const ap = g.a + (long)img * g.a_sn;
+		float av[7];
+#pragma unroll
+		for (int s = 0; s < 7; s++) av[s] = convc3_patch(ap, g, oy, ox0 + n, 4 * s + kq);
+		floatx4 acc[NT];
+#pragma unroll
+		for (int j = 0; j < NT; j++) acc[j] = floatx4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+		for (int s = 0; s < 7; s++)
+#pragma unroll
+			for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wf[s][j], acc[j], 0, 0, 0);
+		// D: column n (channels NT n .. NT n + NT - 1 across the tiles), rows 4 kq + r = pixels
+		float* const bp = g.b + (long)img * g.b_sn + (long)oy * g.b_sh + NT * n;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int ox = ox0 + 4 * kq + r;
+			if (ox < g.OW) {
+				float* const o = bp + (long)ox * g.b_sw;
+				if (NT == 4) *(float4*)o = make_float4(acc[0][r] + bv[0], acc[NT > 1 ? 1 : 0][r] + bv[NT > 1 ? 1 : 0], acc[NT > 2 ? 2 : 0][r] + bv[NT > 2 ? 2 : 0], acc[NT > 3 ? 3 : 0][r] + bv[NT > 3 ? 3 : 0]);
+				else if (NT == 2) *(float2*)o = make_float2(acc[0][r] + bv[0], acc[NT > 1 ? 1 : 0][r] + bv[NT > 1 ? 1 : 0]);
+				else o[0] = acc[0][r] + bv[0];
+			}
+		}
+	}
+}
+
+// Filter gradient: dw[k][27] = sum over pixels g[pixel][k] * patch[pixel][27], and -- column 27 of the B operand being the
+// constant 1 -- the bias gradient sum over pixels g[pixel][k] in the same contraction.  A = g (k x pixel): lane (m, kq) loads
+// g[pixel 4 step + kq][MT m .. MT m + MT - 1] (16 bytes for MT = 4: output channel MT m + i in row m of channel tile i);
+// B = patch (pixel x 32): two tiles.  Every wave accumulates MT x 2 tiles over its share of the pixels and writes them to
+// part[wave][K][32]; convc3_wgrad_fold adds the waves up in a fixed order (deterministic) and applies accumulate.
+template <int MT>
+static __global__ void __launch_bounds__(256) conv3x3_c3_wgrad_kernel(const ConvC3Args g, float* const part)
+{
+	const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+	floatx4 acc[MT][2];
+#pragma unroll
+	for (int i = 0; i < MT; i++) { acc[i][0] = floatx4{ 0.f, 0.f, 0.f, 0.f }; acc[i][1] = floatx4{ 0.f, 0.f, 0.f, 0.f }; }
+	const int waves = (gridDim.x * blockDim.x) >> 6, wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	for (int grp = wid; grp < g.groups; grp += waves) {
+		const int row = grp / g.groups_per_row, gx = grp - row * g.groups_per_row;
+		const int img = row / g.OH, oy = row - img * g.OH;
+		const int ox0 = gx * 16;
+		const float* const ap = g.a + (long)img * g.a_sn;
+		const float* const gp = g.b + (long)img * g.b_sn + (long)oy * g.b_sh;
+#pragma unroll
+		for (int s = 0; s < 4; s++) { // four k-steps of four pixels
+			const int ox = ox0 + 4 * s + kq;
+			const bool live = ox < g.OW;
+			float ga[MT];
+			if (MT == 4) {
+				const float4 v = live ? *(const float4*)(gp + (long)ox * g.b_sw + 4 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+				ga[0] = v.x; ga[MT > 1 ? 1 : 0] = v.y; ga[MT > 2 ? 2 : 0] = v.z; ga[MT > 3 ? 3 : 0] = v.w;
+			} else {
+#pragma unroll
+				for (int i = 0; i < MT; i++) ga[i] = live ? gp[(long)ox * g.b_sw + MT * n + i] : 0.f;
+			}
+			// B: lane (column n of tile t, pixel kq): patch element 16 t + n of pixel ox; element 27 = 1 (bias gradient), 28..31 = 0
+			const float p0 = convc3_patch(ap, g, oy, ox, n);
+			const float p1 = (16 + n) == 27 ? 1.f : convc3_patch(ap, g, oy, ox, 16 + n);
+#pragma unroll
+			for (int i = 0; i < MT; i++) {
+				acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i], live ? p0 : 0.f, acc[i][0], 0, 0, 0);
+				acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i], live ? p1 : 0.f, acc[i][1], 0, 0, 0);
+			}
+		}
+	}
+	// D of tile (i, t): row 4 kq + r = output channel MT (4 kq + r) + i, column n = patch element 16 t + n
+	float* const out = part + (long)wid * g.K * 32;
+#pragma unroll
+	for (int i = 0; i < MT; i++)
+#pragma unroll
+		for (int t = 0; t < 2; t++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) out[(long)(MT * (4 * kq + r) + i) * 32 + 16 * t + n] = acc[i][t][r];
+}
+
+// dw[k][0..26] (+)= sum_w part[w][k][0..26], dbias[k] (+)= sum_w part[w][k][27].  One thread per (k, column).
+static __global__ void __launch_bounds__(256) convc3_wgrad_fold(const float* const part, const int waves, const int K, float* const dw, float* const dbias, const int accumulate)
+{
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= K * 32) return;
+	const int k = idx >> 5, col = idx & 31;
+	if (col > 27) return;
+	float s = 0.f;
+	for (int w = 0; w < waves; w++) s += part[(long)w * K * 32 + idx];
+	if (col < 27) { float* const o = dw + (long)k * 27 + col; *o = accumulate ? *o + s : s; }
+	else if (dbias) dbias[k] = accumulate ? dbias[k] + s : s;
+}
+
+} // namespace nnc

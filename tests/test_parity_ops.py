@@ -493,3 +493,36 @@ def _fused_check(backend, ref_lib, case, a, wt, b, hint, oh, ow):
     assert r1 == 0 and r2 == 0
     for i in range(3):
         np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(want[i]).max())))
+
+
+C3_CASES = [
+    # n, h, w, k, border: 3x3 stride 1 on THREE input channels -> conv_c3.h (K = 16 / 32 / 64), under the backend's own choice
+    (2, 9, 21, 64, (0, 0)),     # VGG-D conv1_1 class: no padding, ragged 16-pixel groups (19 wide)
+    (1, 16, 16, 64, (1, 1)),    # BASELINE config 1 class: padding 1
+    (3, 7, 40, 32, (1, 1)),
+    (2, 5, 6, 16, (2, 2)),      # full padding, rows shorter than one group
+    (1, 18, 33, 64, (1, 0)),    # asymmetric padding
+]
+
+
+@pytest.mark.parametrize("case", C3_CASES)
+def test_conv_first_layer_direct(backend, ref_lib, case):
+    n, h, w, k, border = case
+    rng = np.random.default_rng(9)
+    a, wt, b = srnd(rng, n, h, w, 3), srnd(rng, k, 3, 3, 3, scale=1.0 / 27), srnd(rng, k)
+    hint = nnc.HINT((1, 1), border)
+    oh, ow = out_hw(h, w, 3, 3, hint)
+    fwd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, 3)
+    got, want = exec_pair(backend, ref_lib, fwd, hint, 0, [a, wt, b], [np.full((n, oh, ow, k), 7, F)])
+    assert backend.dll.nnc_mi355x_last_kernel_name().decode() == "conv_fwd_c3"
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=1e-5)
+    g = srnd(rng, n, oh, ow, k)
+    bwd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, 3)
+    dw0, db0 = srnd(rng, *wt.shape), srnd(rng, k)
+    for flags in (0, nnc.ACCUMULATE_OUTPUT):
+        got, want = exec_pair(backend, ref_lib, bwd, hint, flags, [g, a, wt], [np.zeros_like(a), dw0.copy(), db0.copy()])
+        assert backend.dll.nnc_mi355x_last_kernel_name().decode() in ("conv_wgrad_c3", "conv_dgrad", "conv_dgrad_wino", "conv_dgrad_wino_fused")
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5)
+        # the CPU oracle overwrites dbias under ACCUMULATE (see test_conv_backward): the GPU backend being replaced accumulates
+        np.testing.assert_allclose(got[2], (db0 + want[2]) if flags else want[2], rtol=1e-4, atol=2e-5)
