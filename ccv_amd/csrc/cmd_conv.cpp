@@ -363,7 +363,7 @@ static int conv_c3_wgrad(const conv_geom_t& g, const Image4& gr, const Image4& a
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_wgrad_kernel<1>), dim3(grid), dim3(256), 0, stream, c, part);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(convc3_wgrad_fold, dim3((unsigned)((g.K * 32 + 255) / 256)), dim3(256), 0, stream, (const float*)part, waves, g.K, dw, dbias, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
+	hipLaunchKernelGGL(convc3_wgrad_fold, dim3((unsigned)g.K), dim3(256), 0, stream, (const float*)part, waves, g.K, dw, dbias, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

@@ -132,15 +132,20 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_wgrad_kernel(const Conv
 			for (int r = 0; r < 4; r++) out[(long)(MT * (4 * kq + r) + i) * 32 + 16 * t + n] = acc[i][t][r];
 }
 
-// dw[k][0..26] (+)= sum_w part[w][k][0..26], dbias[k] (+)= sum_w part[w][k][27].  One thread per (k, column).
+// dw[k][0..26] (+)= sum_w part[w][k][0..26], dbias[k] (+)= sum_w part[w][k][27].  One workgroup per output channel k: thread
+// (slice = t >> 5, column = t & 31) adds waves slice, slice + 8, ... and the eight slices are folded through LDS in a fixed
+// order (deterministic).  (One thread per (k, column) over all waves -- the first version -- read 33 MB through 8 workgroups: 1.2 ms.)
 static __global__ void __launch_bounds__(256) convc3_wgrad_fold(const float* const part, const int waves, const int K, float* const dw, float* const dbias, const int accumulate)
 {
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= K * 32) return;
-	const int k = idx >> 5, col = idx & 31;
-	if (col > 27) return;
+	__shared__ float red[8][32];
+	const int k = blockIdx.x, col = threadIdx.x & 31, slice = threadIdx.x >> 5;
 	float s = 0.f;
-	for (int w = 0; w < waves; w++) s += part[(long)w * K * 32 + idx];
+	for (int w = slice; w < waves; w += 8) s += part[((long)w * K + k) * 32 + col];
+	red[slice][col] = s;
+	__syncthreads();
+	if (slice != 0 || col > 27) return;
+#pragma unroll
+	for (int i = 1; i < 8; i++) s += red[i][col];
 	if (col < 27) { float* const o = dw + (long)k * 27 + col; *o = accumulate ? *o + s : s; }
 	else if (dbias) dbias[k] = accumulate ? dbias[k] + s : s;
 }

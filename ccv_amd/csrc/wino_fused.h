@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 				// path busy for ~110 cycles; issued back to back by four waves they queue and the ISSUE blocks (measured: 450 cycles
 				// per piece, 1 ms of conv1_2's 4.2).
 				if constexpr (k == 3 && !(DBG & 1) && wf_piece_at(it) >= 0) {
-					constexpr int n = wf_piece_at(it);
+					constexpr int n = wf_piece_at(it) < 0 ? 0 : wf_piece_at(it); // (the clamp only matters in the discarded instantiation)
 					constexpr int q = (n & 1) ? (n >> 1) : (n <= 16 ? WF_P_PIECES + (n >> 1) : WF_P_PIECES - 1); // even n <= 16: U piece n / 2; odd n: patch piece n / 2; n = 18: the eleventh patch piece
 					if constexpr (q < WF_P_PIECES ? !(DBG & 512) : !(DBG & 1024)) dma_piece(GroupId<q>(), p_dst, sp, u_dst, su);
 				}
@@ -541,11 +541,13 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		const Item nxt = item_of(ii + 1 < count ? first + ii + 1 : first + ii); // (the last item fetches its own first chunks again: harmless)
 		for (int cc = 0; cc < a.CCn; cc++, gtrip++) {
 			const int par = gtrip & 1;
-			// The previous trip's U pieces (the next chunk's patch is waited for where the trip first reads it): its last four
-			// pieces (n = 17, 18, 19 and the eleventh patch piece) are patch pieces and may stay in flight.  Counted waits are used
+			// The previous trip's U pieces (the next chunk's patch is waited for where the trip first reads it): its last THREE
+			// pieces (n = 17, 18, 19: patch pieces 8, 10, 9) are patch pieces and may stay in flight; n = 16 is U piece 8 and must
+			// have landed (a count of 4 let it fly: wrong values whenever U came from HBM instead of L2 -- found by smoke() on the
+			// MI355X, first touch of freshly written fragments; the emulator's DMA is synchronous).  Counted waits are used
 			// only where the newest outstanding operations are all loads -- loads retire in order, stores need not retire in order
 			// with them; after an epilogue (stores) there is nothing to wait for, the epilogue has confirmed every piece.
-			if constexpr (!(DBG & 256)) { if (ii == 0 && cc == 0) WF_WAIT_VMCNT(0); else if (cc != 0) WF_WAIT_VMCNT(4); }
+			if constexpr (!(DBG & 256)) { if (ii == 0 && cc == 0) WF_WAIT_VMCNT(0); else if (cc != 0) WF_WAIT_VMCNT(3); }
 			if constexpr (!(DBG & 32)) __builtin_amdgcn_s_barrier(); // => all of this chunk's U is in LDS, and every wave is done with the buffers this trip's DMA overwrites
 			if (cc == a.CCn - 2) set_patch(nxt); // the patch fetched from now on (chunk cc + 2) belongs to the next item
 			if (cc == a.CCn - 1) set_u(nxt);     // and so does the U chunk

@@ -30,3 +30,9 @@ def test_conv_fwd_small(backend, ref_lib):
     assert L.cmd_exec(nnc.CMD_CONVOLUTION_FORWARD(1, 16, 3, 3, 8), hint, 0, [at, wt, bt], [ot]) == 0
     got = ot.numpy()
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+def test_graft_entry_smoke_body(emu_lib):
+    """__graft_entry__.smoke() itself (the driver runs it on the MI355X at round end), here on the emulator build."""
+    import __graft_entry__ as g
+    g.smoke(emu_lib)
