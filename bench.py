@@ -99,21 +99,25 @@ def via_host(args, losses, params):
             "equal": bool(loss_err <= 1e-4 and qerr <= 1e-4), "driver": h["driver"]}
 
 
-def pmc_traffic(record_name, batch):
+def pmc_traffic(symbol, batch):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/pmc_traffic_bs<batch>.json, written
     by tools/pmc_pass.sh + tools/pmc_traffic.py from `rocprofv3 --pmc` runs of this same command: counters cannot be
-    collected inside the timed run).  None when no pass exists for this batch size."""
+    collected inside the timed run).  `symbol` is the part of a record's name behind '|': the kernel symbol itself, or -- for
+    the contraction template -- the tail of its signature (LA, LB, WM, WN) plus the epilogue.  None when no pass exists."""
     import re
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_bs%d.json" % batch)
     if not os.path.exists(path):
         return None
-    m = re.search(r"LA = (nnc::\w+<[^>]*>), LB = nnc::(\w+)<.*WM = (\d), WN = (\d)", record_name)
-    if not m:
-        return None
-    la, lb, wm, wn = m.groups()
+    kernels = json.load(open(path))["kernels"]
+    m = re.search(r"LA = (nnc::\w+<[^>]*>), LB = nnc::(\w+)<.*WM = (\d), WN = (\d)\] EPI = (\w+)", symbol)
     tot, n = 0.0, 0
-    for k, v in json.load(open(path))["kernels"].items():
-        if k.startswith("nnc::mfma_gemm_f32_kernel<" + la.replace(">", "")) and ("nnc::" + lb + "<") in k and k.endswith("%s, %s, 0>" % (wm, wn)):
+    for k, v in kernels.items():
+        if m:
+            la, lb, wm, wn, epi = m.groups()
+            hit = k.startswith("nnc::mfma_gemm_f32_kernel<" + la.replace(">", "")) and ("nnc::" + lb + "<") in k and ("nnc::" + epi + ",") in k and k.endswith("%s, %s, 0>" % (wm, wn))
+        else:
+            hit = k.startswith(symbol.rstrip(">"))
+        if hit:
             tot += (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
             n += v["launches"]
     return tot / n if n else None
@@ -224,9 +228,10 @@ def main():
         with open(args.records, "w") as f:
             for name, fl, _by, ms, dims in recs:
                 f.write("%-12s M=%-8d N=%-6d K=%-8d Z=%d S=%-3d %9.3f ms %7.2f TFLOP/s  %s\n" % (name.split("|")[0], dims[0], dims[1], dims[2], dims[3], dims[4], ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, name.split("|")[-1][-60:]))
+    # per KERNEL (the symbol behind '|'): the fused Winograd kernel serves forward and the data gradient under two command names
     by = {}
     for name, fl, _by, ms, dims in recs:
-        k = by.setdefault(name, [0.0, 0.0, 0])
+        k = by.setdefault(name.split("|", 1)[-1], [0.0, 0.0, 0])
         k[0] += fl
         k[1] += ms
         k[2] += 1

@@ -85,7 +85,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	if (K <= 0) splits = 1;
 	// Kernel symbol as rocprofv3 prints it: nnc::mfma_gemm_f32_kernel<LA, LB, EpiStore|EpiPartial, WM, WN>; __PRETTY_FUNCTION__ carries LA / LB / WM / WN.
 	char prof_name[192];
-	snprintf(prof_name, sizeof(prof_name), "%s|%s", name, __PRETTY_FUNCTION__ + (sizeof(__PRETTY_FUNCTION__) > 110 ? sizeof(__PRETTY_FUNCTION__) - 110 : 0));
+	snprintf(prof_name, sizeof(prof_name), "%s|%s EPI = %s", name, __PRETTY_FUNCTION__ + (sizeof(__PRETTY_FUNCTION__) > 110 ? sizeof(__PRETTY_FUNCTION__) - 110 : 0), splits <= 1 ? "EpiStore" : "EpiPartial");
 	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
 	if (splits <= 1) {
 		EpiStore epi;
