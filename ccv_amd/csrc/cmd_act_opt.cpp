@@ -337,7 +337,7 @@ static int _lamb_forw(EXEC_ARGS)
 
 #define NNC_REG(CMD, BACKEND, FORMATS, EXEC) \
 	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
-	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = CCV_32F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = EXEC; }
+	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = CCV_32F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = EXEC; NNC_HALF_STAGED(registry, EXEC); }
 #define ALL_FORMATS (CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN)
 
 NNC_REG(CCV_NNC_SIGMOID_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, _sigmoid_forw)

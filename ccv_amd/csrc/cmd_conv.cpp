@@ -636,12 +636,153 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// ---- half precision: the three contractions as implicit GEMMs on the half-precision core (mfma_gemm_f16.h) ---------------------
+// CCV_16F activations (NHWC) and weights ([K][kh][kw][Cg]) with channel counts that are multiples of 4 (8-byte chunks); the same
+// loaders as the fp32 path -- they compute element offsets -- over half pointers.  Anything else in half precision (NCHW tensors,
+// NCHW-format weights, 3 input channels, odd strides) runs the fp32 kernels on fp32 images (half_stage.cpp).
+static bool aligned8(const void* p) { return (((uintptr_t)p) & 7) == 0; }
+static bool half_image_ok(const Image4& t) { return t.sc == 1 && aligned8(t.p) && t.sw % 4 == 0 && t.sh % 4 == 0 && (t.n == 1 || t.sn % 4 == 0) && image_fits_int(t); }
+
+static int conv_forw_h(const conv_geom_t& g, const Image4& a, const void* w, const void* bias, const Image4& b, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	const long M = (long)g.N * g.OH * g.OW;
+	const int Kred = g.kh * g.kw * g.Cg;
+	GemmOutH out = { (half_t*)b.p, b.sw, 1, (const half_t*)bias, 1.f, 0, 0 };
+	KOrder ko;
+	if (g.kh * g.kw > 1 && g.Cg % GEMM_BK == 0) ko.init(g.kh * g.kw, g.Cg);
+	Im2colKC<true, false, false> la;
+	la.p = a.p; la.s_n = a.sn; la.s_h = (int)a.sh; la.s_w = (int)a.sw; la.H = g.H; la.W = g.W;
+	la.OW = g.OW; la.OHW = g.OH * g.OW; la.M = (int)M; la.C = g.Cg; la.KWC = g.kw * g.Cg; la.K = Kred;
+	la.my = g.sy; la.mx = g.sx; la.oy_off = -g.pby; la.ox_off = -g.pbx; la.ty = g.dy; la.tx = g.dx; la.dv_y = 1; la.dv_x = 1;
+	MatLoader<true, true> lb;
+	lb.p = (const float*)w; lb.ldr = Kred; lb.ldk = 1; lb.R = g.Kg; lb.K = Kred;
+	return gemm_run_h("conv_fwd_h", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, 1, flags, ctx, ko);
+}
+
+static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	const long M = (long)g.N * g.H * g.W;
+	const int Kred = g.kh * g.kw * g.Kg;
+	GemmOutH out = { (half_t*)h.p, h.sw, 1, 0, 1.f, 0, 0 };
+	KOrder ko;
+	if (g.kh * g.kw > 1 && g.Kg % GEMM_BK == 0) ko.init(g.kh * g.kw, g.Kg);
+#define CONV_DGRAD_H(STRIDED) do { \
+		Im2colKC<true, STRIDED, false> la; \
+		la.p = gr.p; la.s_n = gr.sn; la.s_h = (int)gr.sh; la.s_w = (int)gr.sw; la.H = g.OH; la.W = g.OW; \
+		la.OW = g.W; la.OHW = g.H * g.W; la.M = (int)M; la.C = g.Kg; la.KWC = g.kw * g.Kg; la.K = Kred; \
+		la.my = 1; la.mx = 1; la.oy_off = g.pby; la.ox_off = g.pbx; la.ty = -g.dy; la.tx = -g.dx; la.dv_y = g.sy; la.dv_x = g.sx; \
+		WgtDgradNC<true, false> lb; \
+		lb.p = (const float*)w; lb.ko_stride = (long)g.kh * g.kw * g.Cg; lb.C = g.Cg; lb.Ko = g.Kg; lb.K = Kred; \
+		return gemm_run_h("conv_dgrad_h", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, 1, flags, ctx, ko); \
+	} while (0)
+	if (g.sy != 1 || g.sx != 1) CONV_DGRAD_H(true);
+	else CONV_DGRAD_H(false);
+#undef CONV_DGRAD_H
+}
+
+static int conv_wgrad_h(const conv_geom_t& g, const Image4& gr, const Image4& a, void* dw, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	const long P = (long)g.N * g.OH * g.OW;
+	const int NN = g.kh * g.kw * g.Cg;
+	GemmOutH out = { (half_t*)dw, (long)NN, 1, 0, 1.f, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0, 0 };
+	MatLoader<false, true> la;
+	la.p = gr.p; la.ldr = 1; la.ldk = gr.sw; la.R = g.Kg; la.K = (int)P;
+	Im2colNC<true, false> lb;
+	lb.p = a.p; lb.s_n = a.sn; lb.s_h = (int)a.sh; lb.s_w = (int)a.sw; lb.H = g.H; lb.W = g.W; lb.OW = g.OW; lb.OHW = g.OH * g.OW;
+	lb.C = g.Cg; lb.KWC = g.kw * g.Cg; lb.NN = NN; lb.K = (int)P; lb.sy = g.sy; lb.sx = g.sx; lb.py = g.pby; lb.px = g.pbx; lb.dy = g.dy; lb.dx = g.dx;
+	return gemm_run_h("conv_wgrad_h", la, lb, out, g.Kg, NN, (int)P, g.groups, (long)g.Kg, (long)g.Cg, (long)g.Kg * NN, 0L, 0, flags, ctx);
+}
+
+// CCV_NNC_EXEC_NO_KERNEL = "not this path": the caller runs the command on fp32 images instead.
+static int _conv_forw_half(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 2 || output_size < 1 || !inputs[0] || !inputs[1] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* a = inputs[0];
+	const ccv_nnc_tensor_t* w = inputs[1];
+	const ccv_nnc_tensor_t* bias = input_size > 2 ? inputs[2] : 0;
+	ccv_nnc_tensor_t* b = outputs[0];
+	if (a->info.format != CCV_TENSOR_FORMAT_NHWC || b->info.format != CCV_TENSOR_FORMAT_NHWC || w->info.format != CCV_TENSOR_FORMAT_NHWC) return CCV_NNC_EXEC_NO_KERNEL;
+	Image4 ai, bi;
+	if (!image4(a, &ai) || !image4(b, &bi)) return CCV_NNC_EXEC_NO_KERNEL;
+	int K, kh, kw, Cg;
+	if (!weights_shape(w, &K, &kh, &kw, &Cg)) return CCV_NNC_EXEC_NO_KERNEL;
+	conv_geom_t g;
+	if (!conv_geometry(cmd, hint, ai, bi, 0, &g) || K != g.K || kh != g.kh || kw != g.kw || Cg != g.Cg) return CCV_NNC_EXEC_INVALID;
+	if (bias && (bias->info.dim[0] != g.K || !tensor_contiguous(bias))) return CCV_NNC_EXEC_INVALID;
+	if (g.Cg % 4 || !half_image_ok(ai) || !pixel_linear(bi) || !aligned8(w->data.u8) || (long)g.N * g.OH * g.OW > 0x7fffffffL) return CCV_NNC_EXEC_NO_KERNEL;
+	return conv_forw_h(g, ai, w->data.u8, bias ? bias->data.u8 : 0, bi, flags, stream_context);
+}
+
+static int _conv_back_half(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 2 || output_size < 1 || !inputs[0]) return CCV_NNC_EXEC_INVALID;
+	const ccv_nnc_tensor_t* gt = inputs[0];
+	const ccv_nnc_tensor_t* a = inputs[1];
+	const ccv_nnc_tensor_t* w = input_size > 2 ? inputs[2] : 0;
+	ccv_nnc_tensor_t* h = outputs[0];
+	ccv_nnc_tensor_t* dw = output_size > 1 ? outputs[1] : 0;
+	ccv_nnc_tensor_t* dbias = output_size > 2 ? outputs[2] : 0;
+	const ccv_nnc_tensor_t* shape_src = a ? a : h;
+	const ccv_nnc_tensor_t* wshape = dw ? dw : w;
+	if (!shape_src || !wshape) return CCV_NNC_EXEC_INVALID;
+	if (gt->info.format != CCV_TENSOR_FORMAT_NHWC || shape_src->info.format != CCV_TENSOR_FORMAT_NHWC || wshape->info.format != CCV_TENSOR_FORMAT_NHWC || (w && w->info.format != CCV_TENSOR_FORMAT_NHWC) || (h && h->info.format != CCV_TENSOR_FORMAT_NHWC)) return CCV_NNC_EXEC_NO_KERNEL;
+	Image4 gi, ai, hi;
+	if (!image4(gt, &gi) || !image4(shape_src, &ai)) return CCV_NNC_EXEC_NO_KERNEL;
+	int K, kh, kw, Cg;
+	if (!weights_shape(wshape, &K, &kh, &kw, &Cg)) return CCV_NNC_EXEC_NO_KERNEL;
+	conv_geom_t g;
+	if (!conv_geometry(cmd, hint, ai, gi, 0, &g) || K != g.K || kh != g.kh || kw != g.kw || Cg != g.Cg) return CCV_NNC_EXEC_INVALID;
+	if (dw && !a) return CCV_NNC_EXEC_INVALID;
+	if (h && (!w || !tensor_contiguous(w))) return CCV_NNC_EXEC_INVALID;
+	if (h && (!image4(h, &hi) || hi.h != g.H || hi.w != g.W || hi.c != g.C || hi.n != g.N)) return CCV_NNC_EXEC_INVALID;
+	if (dbias && (!tensor_contiguous(dbias) || dbias->info.dim[0] != g.K)) return CCV_NNC_EXEC_INVALID;
+	if (g.Cg % 4 || g.Kg % 4 || !half_image_ok(gi) || !pixel_linear(gi) || (long)g.N * g.OH * g.OW > 0x7fffffffL || (long)g.N * g.H * g.W > 0x7fffffffL) return CCV_NNC_EXEC_NO_KERNEL;
+	if (dw && (!half_image_ok(ai) || !aligned8(dw->data.u8))) return CCV_NNC_EXEC_NO_KERNEL;
+	if (h && (!pixel_linear(hi) || !aligned8(w->data.u8) || !aligned8(hi.p))) return CCV_NNC_EXEC_NO_KERNEL;
+	int ret;
+	if (dw && (ret = conv_wgrad_h(g, gi, ai, dw->data.u8, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	if (dbias && (ret = colsum_f16(gi.p, (long)g.N * g.OH * g.OW, g.K, gi.sw, dbias->data.u8, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	if (h && (ret = conv_dgrad_h(g, gi, w->data.u8, hi, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+static bool all_half(ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size)
+{
+	for (int i = 0; i < input_size + output_size; i++) {
+		const ccv_nnc_tensor_t* t = i < input_size ? inputs[i] : outputs[i - input_size];
+		if (t && CCV_GET_DATA_TYPE(t->info.datatype) != CCV_16F) return false;
+	}
+	return true;
+}
+
+// The registered exec functions: fp32 tensors -> the fp32 paths above; half precision throughout and chunk-readable -> the
+// half-precision core; any other command with a half tensor -> the fp32 paths on fp32 images.
+static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (!any_half_tensor(inputs, input_size, outputs, output_size)) return _conv_forw(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (all_half(inputs, input_size, outputs, output_size)) {
+		const int r = _conv_forw_half(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+		if (r != CCV_NNC_EXEC_NO_KERNEL) return r;
+	}
+	return half_staged_exec(_conv_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+}
+static int _conv_back_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (!any_half_tensor(inputs, input_size, outputs, output_size)) return _conv_back(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (all_half(inputs, input_size, outputs, output_size)) {
+		const int r = _conv_back_half(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+		if (r != CCV_NNC_EXEC_NO_KERNEL) return r;
+	}
+	return half_staged_exec(_conv_back, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+}
+
 // autotune (ccv_nnc.h:323; what lib/nnc/cmd/convolution/gpu/ccv_nnc_conv_gpu_cudnn.cu:116-202 does with cudnnFind*): run the
 // command under every algorithm on the caller's tensors, HIP-event timed on its stream, and return the fastest.  Outputs
 // are overwritten with the same values each time (the host autotunes before the first real execution, ccv_nnc_cmd.c:344-578).
 static int _conv_autotune(const ccv_nnc_cmd_t cmd, const size_t max_workspace_size, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	(void)max_workspace_size;
+	if (any_half_tensor(inputs, input_size, outputs, output_size)) return -1; // half precision: the backend's own choice (the trials below time the fp32 kernels)
 	const bool fwd = cmd.cmd == CCV_NNC_CONVOLUTION_FORWARD;
 	hipStream_t stream = stream_of(stream_context);
 	hipEvent_t e0, e1;
@@ -677,19 +818,19 @@ static int _conv_autotune(const ccv_nnc_cmd_t cmd, const size_t max_workspace_si
 extern "C" void _register_command_CCV_NNC_CONVOLUTION_FORWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
 {
 	registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC;
-	registry->tensor_datatypes = CCV_32F;
+	registry->tensor_datatypes = CCV_32F | CCV_16F;
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
 	registry->algorithms = CONV_ALGO_COUNT;
-	registry->exec = _conv_forw;
+	registry->exec = _conv_forw_any;
 	registry->autotune = _conv_autotune;
 }
 
 extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
 {
 	registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC;
-	registry->tensor_datatypes = CCV_32F;
+	registry->tensor_datatypes = CCV_32F | CCV_16F;
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
 	registry->algorithms = CONV_ALGO_COUNT; // one choice for both gradients
-	registry->exec = _conv_back;
+	registry->exec = _conv_back_any;
 	registry->autotune = _conv_autotune;
 }

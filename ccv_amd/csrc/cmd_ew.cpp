@@ -523,7 +523,7 @@ int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int acc
 
 #define NNC_REG(CMD, BACKEND, FORMATS, DATATYPES, MEMORY, EXEC) \
 	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
-	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = (MEMORY); registry->algorithms = 1; registry->exec = EXEC; }
+	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = (MEMORY); registry->algorithms = 1; registry->exec = EXEC; NNC_HALF_STAGED(registry, EXEC); }
 #define ALL_FORMATS (CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN)
 
 NNC_REG(CCV_NNC_RELU_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _relu_forw)

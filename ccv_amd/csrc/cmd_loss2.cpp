@@ -263,7 +263,7 @@ static int _cce_back(EXEC_ARGS)
 
 #define NNC_REG(CMD, BACKEND, DATATYPES, EXEC) \
 	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
-	{ registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN; registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = EXEC; }
+	{ registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN; registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = EXEC; NNC_HALF_STAGED(registry, EXEC); }
 
 NNC_REG(CCV_NNC_MSE_FORWARD, CCV_NNC_BACKEND_GPU_REF, CCV_32F, _mse_forw)
 NNC_REG(CCV_NNC_MSE_BACKWARD, CCV_NNC_BACKEND_GPU_REF, CCV_32F, _mse_back)

@@ -258,7 +258,7 @@ static int _datatype_conversion(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hi
 
 #define NNC_REG(CMD, BACKEND, FORMATS, DATATYPES, MEMORY, EXEC) \
 	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
-	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = (MEMORY); registry->algorithms = 1; registry->exec = EXEC; }
+	{ registry->tensor_formats = (FORMATS); registry->tensor_datatypes = (DATATYPES); registry->tensor_memory = (MEMORY); registry->algorithms = 1; registry->exec = EXEC; NNC_HALF_STAGED(registry, EXEC); }
 #define ALL_FORMATS (CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN)
 #define MOVABLE_TYPES (CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U)
 

@@ -17,6 +17,8 @@
 	} \
 } while (0)
 
+extern "C" void* nnc_staging_of(const ccv_nnc_stream_context_t* stream_context, size_t size); // device_rt.cpp
+
 namespace nnc {
 
 static inline int tensor_nd(const int dim[CCV_NNC_MAX_DIM_ALLOC])
@@ -160,6 +162,22 @@ enum {
 	TUNE_COUNT
 };
 long tune(int key);
+
+// Half precision (half_stage.cpp): rows whose kernels compute in fp32 run CCV_16F tensors through fp32 images in the stream's
+// staging arena.  NNC_HALF_STAGED(registry, EXEC) -- used by every row's registration -- adds CCV_16F next to CCV_32F and routes
+// the row through the wrapper (which is a plain call of EXEC when no tensor is half precision).
+typedef int (*nnc_exec_f)(const ccv_nnc_cmd_t, const ccv_nnc_hint_t, const int, ccv_nnc_tensor_t* const* const, const int, ccv_nnc_tensor_t* const* const, const int, ccv_nnc_stream_context_t* const);
+int half_staged_exec(nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx);
+template <nnc_exec_f F>
+static int half_staged(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
+{
+	return half_staged_exec(F, cmd, hint, flags, inputs, input_size, outputs, output_size, ctx);
+}
+#define NNC_HALF_STAGED(registry, EXEC) do { if (((registry)->tensor_datatypes & CCV_32F) && !((registry)->tensor_datatypes & CCV_16F)) { /* rows that list CCV_16F themselves handle it natively */ (registry)->tensor_datatypes |= CCV_16F; (registry)->exec = nnc::half_staged<EXEC>; } } while (0)
+bool any_half_tensor(ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size);
+int half_to_float(const void* in, float* out, size_t n, ccv_nnc_stream_context_t* ctx);
+int float_to_half(const float* in, void* out, size_t n, ccv_nnc_stream_context_t* ctx);
+int colsum_f16(const void* x, long rows, int cols, long ld, void* out, int accumulate, ccv_nnc_stream_context_t* ctx); // halves: out[c] (+)= sum_r x[r * ld + c], fp32 sums
 
 // Registration table (registry.cpp).
 typedef void (*register_fn_t)(ccv_nnc_cmd_backend_registry_t* const);

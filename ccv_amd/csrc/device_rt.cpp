@@ -13,6 +13,8 @@ struct device_local_t {
 	void* workspace;
 	size_t workspace_size;
 	int device;
+	void* staging;        // second grow-only arena: the fp32 images of half-precision tensors (half_stage.cpp) -- they must survive
+	size_t staging_size;  // whatever the command underneath asks of the workspace (a growing workspace is freed and re-allocated)
 };
 // Layout contract with the reference host (lib/nnc/ccv_nnc_stream.c:15-20, lib/nnc/gpu/ccv_nnc_compat.cu:286-299):
 // the host allocates `super` + a {size_t, void*} CPU-workspace tail for EVERY context (CPU contexts included) and, under
@@ -315,13 +317,14 @@ ccv_nnc_stream_context_t* ccv_nnc_init_stream_context(ccv_nnc_stream_context_t* 
 
 static void local_release(device_local_t* l)
 {
-	if (!l->stream && !l->workspace) return;
+	if (!l->stream && !l->workspace && !l->staging) return;
 	const int prev = current_device();
 	HIP_ENFORCE(hipSetDevice(l->device));
 	if (l->stream) HIP_ENFORCE(hipStreamSynchronize(l->stream));
 	if (l->workspace) HIP_ENFORCE(hipFree(l->workspace));
+	if (l->staging) HIP_ENFORCE(hipFree(l->staging));
 	if (l->stream) HIP_ENFORCE(hipStreamDestroy(l->stream));
-	l->workspace = 0; l->workspace_size = 0; l->stream = 0;
+	l->workspace = 0; l->workspace_size = 0; l->staging = 0; l->staging_size = 0; l->stream = 0;
 	HIP_ENFORCE(hipSetDevice(prev));
 }
 
@@ -381,11 +384,36 @@ void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const 
 
 static void local_drain(device_local_t* l, hipStream_t st)
 {
-	if (!l->workspace) return;
+	if (!l->workspace && !l->staging) return;
 	HIP_ENFORCE(hipStreamSynchronize(st));
-	HIP_ENFORCE(hipFree(l->workspace));
-	l->workspace = 0;
-	l->workspace_size = 0;
+	if (l->workspace) HIP_ENFORCE(hipFree(l->workspace));
+	if (l->staging) HIP_ENFORCE(hipFree(l->staging));
+	l->workspace = 0; l->workspace_size = 0;
+	l->staging = 0; l->staging_size = 0;
+}
+
+// The staging arena of the stream `stream_context` launches on (NULL = this thread's default context): grow-only like the
+// workspace, separate from it.
+void* nnc_staging_of(const ccv_nnc_stream_context_t* const stream_context, const size_t size)
+{
+	if (size == 0) return 0;
+	device_local_t* l;
+	hipStream_t st = 0;
+	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = l->stream; }
+	else {
+		const int device = current_device();
+		if (device >= MAX_DEVICES) return 0;
+		l = &tl_default[device];
+		l->device = device;
+	}
+	if (l->staging_size >= size && l->staging) return l->staging;
+	if (l->staging) {
+		HIP_ENFORCE(hipStreamSynchronize(st)); // queued conversions may still read the old arena
+		HIP_ENFORCE(hipFree(l->staging));
+	}
+	l->staging = nnc_mi355x_malloc(st ? l->device : current_device(), size);
+	l->staging_size = l->staging ? size : 0;
+	return l->staging;
 }
 
 void ccv_nnc_stream_compat_drain(ccv_nnc_stream_context_t* const stream_context)
@@ -404,9 +432,9 @@ void ccv_nnc_stream_compat_drain(ccv_nnc_stream_context_t* const stream_context)
 	if (CCV_STREAM_GET_CONTEXT(stream_context->type) != CCV_STREAM_CONTEXT_GPU) return;
 	stream_gpu_t* s = (stream_gpu_t*)stream_context;
 	const int prev = current_device();
-	if (s->one.workspace) { HIP_ENFORCE(hipSetDevice(s->one.device)); local_drain(&s->one, s->one.stream); }
+	if (s->one.workspace || s->one.staging) { HIP_ENFORCE(hipSetDevice(s->one.device)); local_drain(&s->one, s->one.stream); }
 	for (int i = 0; i < s->any_size; i++)
-		if (s->any[i].workspace) { HIP_ENFORCE(hipSetDevice(s->any[i].device)); local_drain(s->any + i, s->any[i].stream); }
+		if (s->any[i].workspace || s->any[i].staging) { HIP_ENFORCE(hipSetDevice(s->any[i].device)); local_drain(s->any + i, s->any[i].stream); }
 	HIP_ENFORCE(hipSetDevice(prev));
 }
 

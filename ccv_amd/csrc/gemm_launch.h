@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "mfma_gemm.h"
+#include "mfma_gemm_f16.h"
 
 namespace nnc {
 
@@ -128,36 +129,138 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	return gemm_run_tile<LA, LB, 1, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 }
 
+// ---- half precision (mfma_gemm_f16.h): same policy (tile grid, split-K, workspace, reduce pass), CCV_16F operands and result ----
+struct GemmOutH {
+	half_t* c;
+	long ldm, ldn;
+	const half_t* bias;
+	float alpha;
+	int accumulate;
+	long bias_ldm;
+};
+
+template <class LA, class LB, int WM, int WN>
+static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko)
+{
+	constexpr int BM = 64 * WM, BN = 64 * WN;
+	hipStream_t stream = stream_of(ctx);
+	const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+	const long tiles = (long)tiles_m * tiles_n;
+	if (tiles > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
+	int k_per_split = K;
+	if (splits > 1) {
+		if (splits < 8) splits = 8;
+		splits = (splits + 7) & ~7;
+		k_per_split = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+	}
+	note_kernel(name);
+	if (K <= 0) splits = 1;
+	char prof_name[192];
+	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_kernel<%d, %d> EPI = %s", name, WM, WN, splits <= 1 ? "EpiStoreH" : "EpiPartialH");
+	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
+	if (splits <= 1) {
+		EpiStoreH epi;
+		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm;
+		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
+	const long slab = (long)M * N;
+	float* ws = (float*)workspace_of(ctx, sizeof(float) * (size_t)slab * splits * zcount);
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	EpiPartialH epi;
+	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
+	{
+		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiPartialH, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
+	}
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(splitk_reduce_half_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+// la.p / lb.p point at HALVES (cast to the loaders' float* type); every offset / stride / z offset is in elements.
+template <class LA, class LB>
+static int gemm_run_h(const char* name, LA la, LB lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko = KOrder())
+{
+	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
+	la.finish();
+	lb.finish();
+	const half_t* zp = (const half_t*)zero_page_of(ctx);
+	la.zoff = zp - (const half_t*)la.p;
+	lb.zoff = zp - (const half_t*)lb.p;
+	// two tile shapes: 128 x 128, and 64 x 64 when an output dimension is <= 64 (channels) or the tile grid would not fill the chip
+	const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+	if (M > 64 && N > 64 && (big_tiles * zcount >= device_cu_count() || K >= 4096)) return gemm_run_tile_h<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+	return gemm_run_tile_h<LA, LB, 1, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+}
+
 } // namespace nnc
 
 namespace nnc {
 
-// One strided matrix operand of a contraction: element(r, k) = p[r * ldr + k * ldk], r in [0,R), k in [0,K).
-struct MatOperand { const float* p; long ldr, ldk; int R, K; };
+// One strided matrix operand of a contraction: element(r, k) = p[r * ldr + k * ldk], r in [0,R), k in [0,K).  T = float or half_t.
+template <class T> struct MatOperandT { const T* p; long ldr, ldk; int R, K; };
+typedef MatOperandT<float> MatOperand;
+template <class T> struct gemm_out_of;
+template <> struct gemm_out_of<float> { typedef GemmOut type; };
+template <> struct gemm_out_of<half_t> { typedef GemmOutH type; };
 
-static inline bool mat_vec_ok(const MatOperand& m, bool kc, long zoff, int zcount)
-{
-	if (!aligned16(m.p)) return false;
+template <class T>
+static inline bool mat_vec_ok(const MatOperandT<T>& m, bool kc, long zoff, int zcount)
+{ // 4-element chunks: 16-byte loads of floats, 8-byte loads of halves
+	if (((uintptr_t)m.p) & (4 * sizeof(T) - 1)) return false;
 	if (zcount > 1 && zoff % 4) return false;
 	return kc ? (m.K % 4 == 0 && m.ldr % 4 == 0) : (m.R % 4 == 0 && m.ldk % 4 == 0);
 }
 
+// the launch of one loader pair, by element type: half precision has vector loaders only (callers check gemm_strided_ok first)
+template <class T> struct gemm_dispatch;
+template <> struct gemm_dispatch<float> {
+	template <bool AKC, bool BKC, bool VEC>
+	static int run(const char* name, const MatOperand& A, const MatOperand& B, const GemmOut& out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, const int flags, ccv_nnc_stream_context_t* const ctx)
+	{
+		MatLoader<AKC, VEC> la; la.p = A.p; la.ldr = A.ldr; la.ldk = A.ldk; la.R = M; la.K = K;
+		MatLoader<BKC, VEC> lb; lb.p = B.p; lb.ldr = B.ldr; lb.ldk = B.ldk; lb.R = N; lb.K = K;
+		return gemm_run(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, 0, flags, ctx);
+	}
+};
+template <> struct gemm_dispatch<half_t> {
+	template <bool AKC, bool BKC, bool VEC>
+	static int run(const char* name, const MatOperandT<half_t>& A, const MatOperandT<half_t>& B, const GemmOutH& out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, const int flags, ccv_nnc_stream_context_t* const ctx)
+	{
+		if (!VEC) return CCV_NNC_EXEC_INVALID;
+		MatLoader<AKC, true> la; la.p = (const float*)A.p; la.ldr = A.ldr; la.ldk = A.ldk; la.R = M; la.K = K;
+		MatLoader<BKC, true> lb; lb.p = (const float*)B.p; lb.ldr = B.ldr; lb.ldk = B.ldk; lb.R = N; lb.K = K;
+		return gemm_run_h(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, 0, flags, ctx);
+	}
+};
+
+// Can both operands be read in 4-element chunks (the only form the half-precision core has)?
+template <class T>
+static bool gemm_strided_vec(const MatOperandT<T>& A, const MatOperandT<T>& B, const int zcount, const long a_z, const long b_z)
+{
+	const int K = A.K;
+	const bool a_kc = (A.ldk == 1 || K == 1), b_kc = (B.ldk == 1 || K == 1);
+	if (!a_kc && A.ldr != 1 && A.R != 1) return false;
+	if (!b_kc && B.ldr != 1 && B.R != 1) return false;
+	return mat_vec_ok(A, a_kc, a_z, zcount) && (a_kc ? A.ldk == 1 : A.ldr == 1) && mat_vec_ok(B, b_kc, b_z, zcount) && (b_kc ? B.ldk == 1 : B.ldr == 1);
+}
+
 // C(m, n) = alpha * sum_k A(m, k) * B(n, k) for arbitrary (unit-stride-in-one-dimension) operands.
-static int gemm_strided(const char* name, const MatOperand A, const MatOperand B, const GemmOut out, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, const int flags, ccv_nnc_stream_context_t* const ctx)
+template <class T>
+static int gemm_strided(const char* name, const MatOperandT<T> A, const MatOperandT<T> B, const typename gemm_out_of<T>::type out, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	const int M = A.R, N = B.R, K = A.K;
 	if (B.K != K) return CCV_NNC_EXEC_INVALID;
 	const bool a_kc = (A.ldk == 1 || K == 1), b_kc = (B.ldk == 1 || K == 1);
 	if (!a_kc && A.ldr != 1 && M != 1) return CCV_NNC_EXEC_INVALID;
 	if (!b_kc && B.ldr != 1 && N != 1) return CCV_NNC_EXEC_INVALID;
-	const bool a_vec = mat_vec_ok(A, a_kc, a_z, zcount) && (a_kc ? A.ldk == 1 : A.ldr == 1);
-	const bool b_vec = mat_vec_ok(B, b_kc, b_z, zcount) && (b_kc ? B.ldk == 1 : B.ldr == 1);
-	const bool vec = a_vec && b_vec;
-#define NNC_GEMM_CASE(AKC, BKC, VEC) do { \
-		MatLoader<AKC, VEC> la; la.p = A.p; la.ldr = A.ldr; la.ldk = A.ldk; la.R = M; la.K = K; \
-		MatLoader<BKC, VEC> lb; lb.p = B.p; lb.ldr = B.ldr; lb.ldk = B.ldk; lb.R = N; lb.K = K; \
-		return gemm_run(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, 0, flags, ctx); \
-	} while (0)
+	const bool vec = gemm_strided_vec(A, B, zcount, a_z, b_z);
+#define NNC_GEMM_CASE(AKC, BKC, VEC) return gemm_dispatch<T>::template run<AKC, BKC, VEC>(name, A, B, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, flags, ctx)
 	// A degenerate (length-1) dimension makes both views legal; prefer the vectorisable one.
 	if (a_kc && b_kc) { if (vec) NNC_GEMM_CASE(true, true, true); else NNC_GEMM_CASE(true, true, false); }
 	else if (a_kc && !b_kc) { if (vec) NNC_GEMM_CASE(true, false, true); else NNC_GEMM_CASE(true, false, false); }

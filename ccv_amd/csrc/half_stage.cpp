@@ -1,0 +1,215 @@
+// CCV_16F tensors on rows whose kernels compute in fp32: the command runs on fp32 IMAGES of its half-precision tensors.
+//
+// The reference's GPU rows register CCV_32F | CCV_16F (e.g. lib/nnc/cmd/convolution/gpu/ccv_nnc_conv_gpu_cudnn.cu:478-500,
+// lib/nnc/cmd/sgd/gpu/ccv_nnc_sgd_gpu_ref.cu:13-100 with its mixed fp16 / fp32 variants) and its trainers store activations and
+// gradients in half precision (test/int/nnc/cifar.tests.c:473).  Rows with a native half-precision kernel (the contraction core:
+// GEMM and convolution on v_mfma_f32_32x32x16_f16, cmd_gemm.cpp / cmd_conv.cpp) handle CCV_16F themselves; every other row
+// takes this route, so that a half-precision graph never meets a row that cannot run it:
+//   1. every distinct CCV_16F tensor of the command gets an fp32 image in the stream's staging arena (device_rt.cpp; separate
+//      from the workspace, which the command underneath may grow and thereby move);
+//   2. inputs are converted up (exact); outputs that are views, accumulated into, or alias an input are converted up too;
+//   3. the fp32 exec function runs on shadow tensor structs (same shape / strides / view flags, datatype CCV_32F);
+//   4. outputs are converted down (round to nearest even, as the reference's ccv_float_to_half_precision does).
+// Storage is half precision, arithmetic fp32: at least the accuracy the reference's own half-precision kernels have (they
+// accumulate in fp32 as well), so its GPU-vs-CPU tolerances hold.  Cost: one extra read + write of each half tensor -- this is
+// the coverage path, not the fast one.
+#include "common.h"
+
+namespace nnc {
+
+typedef _Float16 half_t;
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// n elements, contiguous.  Four per thread where the alignment allows (8-byte / 16-byte accesses).
+static __global__ void __launch_bounds__(256) half_up_kernel(const half_t* __restrict__ in, float* __restrict__ out, const size_t n, const int vec)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	if (vec) {
+		const size_t n4 = n >> 2;
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+			const half4_t v = ((const half4_t*)in)[i];
+			((f32x4_t*)out)[i] = f32x4_t{ (float)v[0], (float)v[1], (float)v[2], (float)v[3] };
+		}
+		for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)in[i];
+	} else
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)in[i];
+}
+static __global__ void __launch_bounds__(256) half_down_kernel(const float* __restrict__ in, half_t* __restrict__ out, const size_t n, const int vec)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	if (vec) {
+		const size_t n4 = n >> 2;
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+			const f32x4_t v = ((const f32x4_t*)in)[i];
+			((half4_t*)out)[i] = half4_t{ (half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3] };
+		}
+		for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (half_t)in[i];
+	} else
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (half_t)in[i];
+}
+
+int half_to_float(const void* in, float* out, size_t n, ccv_nnc_stream_context_t* ctx)
+{
+	if (!n) return CCV_NNC_EXEC_SUCCESS;
+	const int vec = (((uintptr_t)in & 7) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+	hipLaunchKernelGGL(half_up_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256)), dim3(256), 0, stream_of(ctx), (const half_t*)in, out, n, vec);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+int float_to_half(const float* in, void* out, size_t n, ccv_nnc_stream_context_t* ctx)
+{
+	if (!n) return CCV_NNC_EXEC_SUCCESS;
+	const int vec = (((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0) ? 1 : 0;
+	hipLaunchKernelGGL(half_down_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256)), dim3(256), 0, stream_of(ctx), in, (half_t*)out, n, vec);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+// Bias gradients of the half-precision contraction commands.
+// dbias for half precision: out[c] (+)= sum_r x[r * ld + c], fp32 partial sums over row slices, folded in a fixed order
+static __global__ void __launch_bounds__(256) colsum_h_partial_kernel(const half_t* x, const long rows, const int cols, const long ld, const long rows_per_slice, float* partial)
+{
+	__shared__ float red[4][64];
+	const int c = blockIdx.x * 64 + (threadIdx.x & 63), rs = threadIdx.x >> 6;
+	const long r0 = (long)blockIdx.y * rows_per_slice, r1 = r0 + rows_per_slice < rows ? r0 + rows_per_slice : rows;
+	float s = 0.f;
+	if (c < cols) for (long r = r0 + rs; r < r1; r += 4) s += (float)x[r * ld + c];
+	red[rs][threadIdx.x & 63] = s;
+	__syncthreads();
+	if (rs == 0 && c < cols) partial[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+static __global__ void __launch_bounds__(256) colsum_h_final_kernel(const float* partial, const int slices, const int cols, half_t* out, const int accumulate)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= cols) return;
+	float s = 0.f;
+	for (int i = 0; i < slices; i++) s += partial[(long)i * cols + c];
+	out[c] = (half_t)(accumulate ? (float)out[c] + s : s);
+}
+int colsum_f16(const void* xv, long rows, int cols, long ld, void* outv, int accumulate, ccv_nnc_stream_context_t* ctx)
+{
+	if (cols <= 0) return CCV_NNC_EXEC_SUCCESS;
+	const half_t* x = (const half_t*)xv;
+	half_t* out = (half_t*)outv;
+	const int col_tiles = (cols + 63) / 64;
+	long slices = ((long)device_cu_count() * 4 + col_tiles - 1) / col_tiles;
+	const long max_slices = (rows + 63) / 64;
+	if (slices > max_slices) slices = max_slices;
+	if (slices < 1) slices = 1;
+	const long rows_per_slice = (rows + slices - 1) / slices;
+	slices = rows > 0 ? (rows + rows_per_slice - 1) / rows_per_slice : 1;
+	float* partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * cols);
+	if (!partial) return CCV_NNC_EXEC_OOM;
+	hipStream_t stream = stream_of(ctx);
+	hipLaunchKernelGGL(colsum_h_partial_kernel, dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, x, rows, cols, ld, rows_per_slice > 0 ? rows_per_slice : 1, partial);
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(colsum_h_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, (const float*)partial, (int)slices, cols, out, accumulate);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+bool any_half_tensor(ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size)
+{
+	for (int i = 0; i < input_size; i++)
+		if (inputs[i] && CCV_GET_DATA_TYPE(inputs[i]->info.datatype) == CCV_16F) return true;
+	for (int i = 0; i < output_size; i++)
+		if (outputs[i] && CCV_GET_DATA_TYPE(outputs[i]->info.datatype) == CCV_16F) return true;
+	return false;
+}
+
+namespace {
+
+// elements from the tensor's first element to one past its last (views: by their strides)
+size_t tensor_span(const ccv_nnc_tensor_t* t)
+{
+	if (!CCV_IS_TENSOR_VIEW(t)) return tensor_count(t->info);
+	int st[CCV_NNC_MAX_DIM_ALLOC];
+	tensor_strides(t, st);
+	const int nd = tensor_nd(t->info.dim);
+	if (nd == 0) return 0;
+	size_t last = 0;
+	for (int i = 0; i < nd; i++) {
+		if (t->info.dim[i] <= 0) return 0;
+		last += (size_t)(t->info.dim[i] - 1) * (size_t)st[i];
+	}
+	return last + 1;
+}
+
+struct staged_t {
+	void* half;   // the tensor's own (half-precision) memory
+	size_t span;  // elements
+	float* image; // its fp32 image in the arena
+	bool is_output, is_input, load;
+};
+
+constexpr int MAX_STAGED = 64;
+
+} // namespace
+
+int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
+{
+	if (!any_half_tensor(inputs, input_size, outputs, output_size)) return inner(cmd, hint, flags, inputs, input_size, outputs, output_size, ctx);
+	if (input_size + output_size > MAX_STAGED) return CCV_NNC_EXEC_INVALID;
+	staged_t st[MAX_STAGED];
+	int nst = 0;
+	// shadow tensor structs: a view keeps its stride block, so the larger struct is copied for every tensor
+	ccv_nnc_tensor_view_t shadow[MAX_STAGED];
+	ccv_nnc_tensor_t* in_s[MAX_STAGED];
+	ccv_nnc_tensor_t* out_s[MAX_STAGED];
+	int which[MAX_STAGED]; // staged entry of shadow i, -1 = the tensor itself is passed on
+	size_t total = 0;
+	auto visit = [&](ccv_nnc_tensor_t* t, const bool is_output, const int slot) {
+		which[slot] = -1;
+		if (!t || CCV_GET_DATA_TYPE(t->info.datatype) != CCV_16F) return;
+		const size_t span = tensor_span(t);
+		int e = -1;
+		for (int i = 0; i < nst; i++)
+			if (st[i].half == (void*)t->data.u8) { e = i; break; } // the same memory through two tensor structs (in-place commands): one image
+		if (e < 0) {
+			e = nst++;
+			st[e].half = t->data.u8; st[e].span = span; st[e].image = 0; st[e].is_output = st[e].is_input = st[e].load = false;
+		} else if (span > st[e].span) st[e].span = span;
+		if (is_output) {
+			st[e].is_output = true;
+			// what the command does not write must survive the round trip: the gaps of a view, the old value under accumulation
+			if (CCV_IS_TENSOR_VIEW(t) || (flags & CCV_NNC_ACCUMULATE_OUTPUT)) st[e].load = true;
+		} else { st[e].is_input = true; st[e].load = true; }
+		which[slot] = e;
+	};
+	// opaque tensors keep their own memory: the dropout mask is a byte buffer the host merely SIZES through a tensor of the data's
+	// type (ccv_nnc_dropout.c:21-45) -- output 1 of the forward command, input 4 of the backward one
+	const int opaque_in = cmd.cmd == CCV_NNC_DROPOUT_BACKWARD ? 4 : -1, opaque_out = cmd.cmd == CCV_NNC_DROPOUT_FORWARD ? 1 : -1;
+	for (int i = 0; i < input_size; i++) { if (i == opaque_in) which[i] = -1; else visit(inputs[i], false, i); }
+	for (int i = 0; i < output_size; i++) { if (i == opaque_out) which[input_size + i] = -1; else visit(outputs[i], true, input_size + i); }
+	for (int i = 0; i < nst; i++) total += (st[i].span * sizeof(float) + 255) & ~(size_t)255;
+	char* arena = (char*)nnc_staging_of(ctx, total);
+	if (total && !arena) return CCV_NNC_EXEC_OOM;
+	size_t off = 0;
+	for (int i = 0; i < nst; i++) {
+		st[i].image = (float*)(arena + off);
+		off += (st[i].span * sizeof(float) + 255) & ~(size_t)255;
+		if (st[i].load) half_to_float(st[i].half, st[i].image, st[i].span, ctx);
+	}
+	auto make_shadow = [&](ccv_nnc_tensor_t* t, const int slot) -> ccv_nnc_tensor_t* {
+		if (!t || which[slot] < 0) return t;
+		if (CCV_IS_TENSOR_VIEW(t)) memcpy(&shadow[slot], t, sizeof(ccv_nnc_tensor_view_t));
+		else { memset(&shadow[slot], 0, sizeof(ccv_nnc_tensor_view_t)); memcpy(&shadow[slot], t, sizeof(ccv_nnc_tensor_t)); }
+		ccv_nnc_tensor_t* s = (ccv_nnc_tensor_t*)&shadow[slot];
+		s->info.datatype = CCV_32F;
+		s->data.f32 = st[which[slot]].image;
+		s->dataof = 0;
+		s->data_size = 0;
+		s->alias_ref = 0;
+		return s;
+	};
+	for (int i = 0; i < input_size; i++) in_s[i] = make_shadow(inputs[i], i);
+	for (int i = 0; i < output_size; i++) out_s[i] = make_shadow(outputs[i], input_size + i);
+	const int ret = inner(cmd, hint, flags, in_s, input_size, out_s, output_size, ctx);
+	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
+	for (int i = 0; i < nst; i++)
+		if (st[i].is_output) float_to_half(st[i].image, st[i].half, st[i].span, ctx);
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+} // namespace nnc

@@ -1,0 +1,226 @@
+// Half-precision MFMA contraction core for gfx950: C[M][N] = sum_k A(m,k) * B(k,n), CCV_16F operands, fp32 accumulation on
+// v_mfma_f32_32x32x16_f16 (the double-K f16 form of gfx950: 8 halves per lane per operand, ~2.2 PFLOP/s peak -- 14x the fp32
+// form), CCV_16F result.  The reference's trainers run in half precision (lib/nnc/cmd/convolution/gpu/
+// ccv_nnc_conv_gpu_cudnn.cu:478-500 registers CCV_32F | CCV_16F; test/int/nnc/cifar.tests.c:473); this is that datapath for the
+// contraction commands: GEMM forward / backward and convolution forward / data gradient / filter gradient as implicit GEMMs.
+//
+// It reuses the ADDRESS half of the fp32 core (mfma_gemm.h): the loader functors (plain matrix, im2col, dgrad weights, wgrad
+// im2col) compute ELEMENT offsets and are indifferent to the element size, and TileFetch's chunk schedule (4 elements per
+// chunk, BK = 32) carries over -- a chunk of halves is an 8-byte load.  What differs is everything after the load:
+//   * both operands are staged in ONE LDS image shape, [rows][40 halves] (k contiguous, row stride 80 bytes): a lane's
+//     fragment -- 8 consecutive k of its row -- is one 16-byte ds_read_b128, conflict-free across 16-lane groups (20-word row
+//     stride).  A row-contiguous operand (4 rows x 1 k per chunk) is transposed on its way in: four ds_write_b16.
+//   * one K-step (32 deep) is two MFMAs per 32x32 tile instead of sixteen; with 14x the MFMA rate the kernel is bound by
+//     operand traffic (HBM / L2 -> LDS), not by MFMA issue, so the steady state is left to hipcc's scheduler: global loads
+//     of tile kt+1 are issued before the MFMAs of tile kt and written to the other LDS buffer after them.
+// The lane -> k map of the instruction does not matter for correctness as long as A and B use the same one (the sum over
+// k is symmetric): lane (row = l & 31, half = l >> 5) supplies k = 16 s + 8 half + 0..7 of K-sub-step s for both operands.
+#pragma once
+#include "mfma_gemm.h"
+
+namespace nnc {
+
+typedef _Float16 half_t;
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+
+constexpr int GEMM16_LDK = 40; // halves per LDS row: 32 of a K-step + 8 of padding (80 bytes: 16-byte aligned rows, 20-word stride)
+
+#ifdef NNC_HIP_EMULATOR
+static inline floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return emu_mfma_f32_32x32x16_f16(a, b, c); }
+#else
+__device__ __forceinline__ floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+#endif
+
+// Epilogues.  Direct store: c[m * ldm + n * ldn] = alpha * acc (+ bias[n]) (+ old c when accumulating), rounded to half.
+struct EpiStoreH {
+	half_t* c;
+	long ldm, ldn;
+	const half_t* bias; // bias[m * bias_ldm + n]; may be null
+	float alpha;
+	int accumulate;
+	int M, N;
+	long bias_ldm;
+	__device__ __forceinline__ void operator()(int m, int n, float v) const
+	{
+		if (m < M && n < N) {
+			const long o = (long)m * ldm + (long)n * ldn;
+			v *= alpha;
+			if (bias) v += (float)bias[(long)m * bias_ldm + n];
+			if (accumulate) v += (float)c[o];
+			c[o] = (half_t)v;
+		}
+	}
+};
+// Split-K partial (fp32 slabs, exactly as the fp32 core's): splitk_reduce_half_kernel finishes.
+struct EpiPartialH {
+	float* c;
+	const half_t* bias; // unused
+	long slab;
+	int M, N;
+	__device__ __forceinline__ void operator()(int m, int n, float v) const
+	{
+		if (m < M && n < N) c[(long)m * N + n] = v;
+	}
+};
+__device__ __forceinline__ long M_N_slab(const EpiStoreH&) { return 0; }
+__device__ __forceinline__ long M_N_slab(const EpiPartialH& e) { return e.slab; }
+
+// The chunks one thread stages for an operand tile, on top of TileFetch's address schedule.
+template <class L, int NCH>
+struct TileFetchH : TileFetch<L, NCH> {
+	typedef TileFetch<L, NCH> Base;
+	static_assert(L::VECTOR, "the half-precision core takes vector loaders only (4-element chunks: 8-byte loads)");
+	__device__ __forceinline__ void issue(const L& l, uint2 (&r)[NCH]) const
+	{
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) r[jj] = *(const uint2*)((const half_t*)l.p + this->off[jj]);
+	}
+	__device__ __forceinline__ void store(half_t* lds, const uint2 (&r)[NCH], const int t) const
+	{
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) {
+			const int id = t + GEMM_THREADS * jj;
+			if (L::KCONTIG) *(uint2*)(lds + (id >> 3) * GEMM16_LDK + ((id & 7) << 2)) = r[jj]; // row id >> 3, k (id & 7) * 4 .. + 3
+			else { // k = id / (ROWS / 4), rows (id % (ROWS / 4)) * 4 .. + 3: transposed into the [rows][k] image
+				const int k = id / (Base::ROWS / 4), r0 = (id % (Base::ROWS / 4)) << 2;
+				const unsigned short h0 = (unsigned short)(r[jj].x & 0xffff), h1 = (unsigned short)(r[jj].x >> 16), h2 = (unsigned short)(r[jj].y & 0xffff), h3 = (unsigned short)(r[jj].y >> 16);
+				unsigned short* const d = (unsigned short*)lds + r0 * GEMM16_LDK + k;
+				d[0] = h0; d[GEMM16_LDK] = h1; d[2 * GEMM16_LDK] = h2; d[3 * GEMM16_LDK] = h3;
+			}
+		}
+	}
+};
+
+// grid: x = tiles (* split-K slices), XCD-swizzled exactly as the fp32 core; z = batch / conv group.
+template <class LA, class LB, class EPI, int WM, int WN>
+__global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff, const KOrder ko)
+{
+	constexpr int BM = 64 * WM, BN = 64 * WN;
+	constexpr int A_HALVES = BM * GEMM16_LDK, B_HALVES = BN * GEMM16_LDK;
+	__shared__ __attribute__((aligned(16))) half_t lds[2][A_HALVES + B_HALVES];
+	const int t = threadIdx.x;
+	const int lane = t & 63, wave = t >> 6;
+	const int wm = wave >> 1, wn = wave & 1;
+	const int li = lane & 31, lh = lane >> 5;
+	const int nwg = gridDim.x;
+	const int bid = blockIdx.x;
+	int tile, slice = 0;
+	{
+		const int xcd = bid & 7, idx = bid >> 3;
+		if (splits > 1) {
+			const int tiles = tiles_m * tiles_n;
+			const int j = idx / tiles;
+			tile = idx - j * tiles;
+			slice = xcd + 8 * j;
+		} else {
+			const int q = nwg >> 3, r = nwg & 7;
+			tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+		}
+	}
+	const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+	(void)tiles_m;
+	const int m0 = tile_m * BM, n0 = tile_n * BN;
+	// the loaders' base pointers are typed float* (mfma_gemm.h) but address halves here: offsets are in ELEMENTS
+	la.p = (const float*)((const half_t*)la.p + (long)blockIdx.z * a_zoff); la.zoff -= (long)blockIdx.z * a_zoff;
+	lb.p = (const float*)((const half_t*)lb.p + (long)blockIdx.z * b_zoff); lb.zoff -= (long)blockIdx.z * b_zoff;
+	epi.c += (long)blockIdx.z * c_zoff;
+	if (splits > 1) epi.c += (long)slice * M_N_slab(epi);
+	const int k_begin = slice * k_per_split;
+	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
+	const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+	auto kmap = [&](const int kb) -> int {
+		if (!ko.taps) return kb;
+		if (kb >= k_end) return ko.K;
+		const int s = kb / GEMM_BK;
+		const int cc = ko.d.div(s);
+		return (s - cc * ko.taps) * ko.C + cc * GEMM_BK;
+	};
+	const int klim = ko.taps ? ko.K : k_end;
+	TileFetchH<LA, WM * 2> fa;
+	TileFetchH<LB, WN * 2> fb;
+	fa.init(la, m0, t);
+	fb.init(lb, n0, t);
+	floatx16 acc[WM][WN];
+#pragma unroll
+	for (int i = 0; i < WM; i++)
+#pragma unroll
+		for (int j = 0; j < WN; j++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+	const int row_a = wm * (32 * WM), col_b = wn * (32 * WN);
+	uint2 ra[WM * 2], rb[WN * 2];
+	if (nk > 0) {
+		const int k0 = kmap(k_begin);
+		fa.template prep<true>(la, k0, klim);
+		fb.template prep<true>(lb, k0, klim);
+		fa.issue(la, ra);
+		fb.issue(lb, rb);
+		fa.store(lds[0], ra, t);
+		fb.store(lds[0] + A_HALVES, rb, t);
+	}
+	__syncthreads();
+	for (int kt = 0; kt < nk; kt++) {
+		const int cur = kt & 1;
+		const bool more = kt + 1 < nk;
+		if (more) { // next tile: addresses, then the loads go out ahead of this tile's MFMAs
+			const int k1 = kmap(k_begin + (kt + 1) * GEMM_BK);
+			fa.template prep<true>(la, k1, klim);
+			fb.template prep<true>(lb, k1, klim);
+			fa.issue(la, ra);
+			fb.issue(lb, rb);
+		}
+		const half_t* const sa = lds[cur];
+		const half_t* const sb = lds[cur] + A_HALVES;
+#pragma unroll
+		for (int s = 0; s < 2; s++) {
+			halfx8 fa8[WM], fb8[WN];
+#pragma unroll
+			for (int ti = 0; ti < WM; ti++) fa8[ti] = *(const halfx8*)(sa + (row_a + 32 * ti + li) * GEMM16_LDK + 16 * s + 8 * lh);
+#pragma unroll
+			for (int tj = 0; tj < WN; tj++) fb8[tj] = *(const halfx8*)(sb + (col_b + 32 * tj + li) * GEMM16_LDK + 16 * s + 8 * lh);
+#pragma unroll
+			for (int ti = 0; ti < WM; ti++)
+#pragma unroll
+				for (int tj = 0; tj < WN; tj++) acc[ti][tj] = nnc_mfma_f16(fa8[ti], fb8[tj], acc[ti][tj]);
+		}
+		if (more) {
+			fa.store(lds[cur ^ 1], ra, t);
+			fb.store(lds[cur ^ 1] + A_HALVES, rb, t);
+		}
+		__syncthreads();
+	}
+	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
+#pragma unroll
+	for (int ti = 0; ti < WM; ti++)
+#pragma unroll
+		for (int tj = 0; tj < WN; tj++) {
+			const int n = n0 + col_b + 32 * tj + li;
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const int m = m0 + row_a + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
+				epi(m, n, acc[ti][tj][r]);
+			}
+		}
+}
+
+// Finish a split-K contraction into a half-precision tensor (fixed summation order => deterministic).
+static __global__ void __launch_bounds__(256) splitk_reduce_half_kernel(const float* ws, const int splits, const long slab, half_t* c, const long ldm, const long ldn, const half_t* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff)
+{
+	ws += (long)blockIdx.y * splits * slab;
+	c += (long)blockIdx.y * c_zoff;
+	if (bias) bias += (long)blockIdx.y * bias_zoff;
+	for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < slab; idx += (long)gridDim.x * blockDim.x) {
+		const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
+		float v = 0.f;
+		for (int s = 0; s < splits; s++) v += ws[(long)s * slab + idx];
+		v *= alpha;
+		if (bias) v += (float)bias[(long)m * bias_ldm + n];
+		const long o = (long)m * ldm + (long)n * ldn;
+		if (accumulate) v += (float)c[o];
+		c[o] = (half_t)v;
+	}
+}
+
+} // namespace nnc

@@ -18,7 +18,7 @@ static int cur_tid = 0, nthreads = 0, ndone = 0;
 static unsigned block_gen = 0, block_arrived = 0;
 static unsigned wave_gen[16], wave_arrived[16], wave_live[16];
 static unsigned long progress = 0;
-static char xbufs[16][64][16];
+static char xbufs[16][64][32];
 static std::vector<char> dyn;
 static bool in_kernel = false;
 

@@ -60,7 +60,7 @@ void syncthreads();
 void wave_sync();
 int lane();
 int wave();
-void* xbuf(int lane); // 16 B per lane exchange slot of the calling fiber's wave
+void* xbuf(int lane); // 32 B per lane exchange slot of the calling fiber's wave
 void* dyn_smem();
 int wave_width();
 }
@@ -135,6 +135,31 @@ static inline emu_floatx4 emu_mfma_f32_16x16x4f32(float a, float b, emu_floatx4 
 			memcpy(&A, emu::xbuf(i + 16 * k), sizeof(A));
 			memcpy(&B, emu::xbuf(j + 16 * k), sizeof(B));
 			acc = fmaf(A.a, B.b, acc);
+		}
+		c[r] = acc;
+	}
+	emu::wave_sync();
+	return c;
+}
+// v_mfma_f32_32x32x16_f16 (gfx950): lane l = (row / column l & 31, k half l >> 5) supplies 8 halves per operand; D as the 32x32x2 form.
+// Products of two halves are exact in fp32; the sum runs in k order in fp32 (the hardware's internal order is not specified:
+// tests of the half-precision core compare within a tolerance).
+typedef _Float16 emu_halfx8 __attribute__((ext_vector_type(8)));
+static inline emu_floatx16 emu_mfma_f32_32x32x16_f16(emu_halfx8 a, emu_halfx8 b, emu_floatx16 c)
+{
+	struct ab { emu_halfx8 a, b; } mine = { a, b };
+	static_assert(sizeof(ab) == 32, "exchange slot");
+	memcpy(emu::xbuf(emu::lane()), &mine, sizeof(mine));
+	emu::wave_sync();
+	const int l = emu::lane(), j = l & 31, hi = l >> 5;
+	for (int r = 0; r < 16; r++) {
+		const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+		float acc = c[r];
+		for (int h = 0; h < 2; h++) {
+			ab A, B;
+			memcpy(&A, emu::xbuf(i + 32 * h), sizeof(A));
+			memcpy(&B, emu::xbuf(j + 32 * h), sizeof(B));
+			for (int e = 0; e < 8; e++) acc += (float)A.a[e] * (float)B.b[e];
 		}
 		c[r] = acc;
 	}

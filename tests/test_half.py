@@ -1,0 +1,182 @@
+"""CCV_16F datapath (BASELINE config 5): half-precision tensors through the command interface.
+
+  * contraction commands (GEMM forward / backward, convolution forward / backward) run on the half-precision MFMA core
+    (mfma_gemm_f16.h, v_mfma_f32_32x32x16_f16, fp32 accumulation) when every tensor is CCV_16F and readable in 4-element chunks;
+  * every other row, and the contraction rows for mixed types / odd strides, runs its fp32 kernels on fp32 images of the half
+    tensors (half_stage.cpp).
+Oracle: the reference's CPU backend in fp32 on the SAME half-rounded inputs; the result must agree with the oracle's, rounded
+to half, within the tolerance the reference's own half-precision GPU tests use (test/int/nnc/cudnn.tests.c:196 5e-3 on values of
+order 1, cublas.tests.c half cases 1e-3 .. 5e-3): |got - want| <= 5e-3 * max(1, |want|max) elementwise.
+"""
+import numpy as np
+import pytest
+from ccv_amd import nnc
+from harness import exec_on
+
+F, H = np.float32, np.float16
+
+
+def hrnd(rng, *shape, scale=1.0):
+    return ((rng.random(shape, dtype=F) - 0.5) * 2 * scale).astype(H)
+
+
+def _pair(L, ref, cmd, hint, flags, inputs, outputs):
+    """inputs / outputs in half (numpy float16) -> (backend result in half, oracle result in fp32 from the same values)"""
+    r1, got = exec_on(L, nnc.GPU_MEMORY, cmd, hint, flags, inputs, outputs)
+    up = lambda xs: [None if x is None else (x.astype(F) if x.dtype == H else x) for x in xs]
+    r2, want = exec_on(ref, nnc.CPU_MEMORY, cmd, hint, flags, up(inputs), up(outputs), backend=nnc.BACKEND_CPU_REF)
+    assert r2 == 0 and r1 == 0, (r1, r2)
+    return got, want
+
+
+def _close(got, want, tol=5e-3):
+    assert got.dtype == H
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    bound = tol * max(1.0, float(np.abs(w).max()))
+    err = float(np.abs(g - w).max())
+    assert err <= bound, "max |diff| %.4g > %.4g" % (err, bound)
+
+
+GEMM_H = [
+    # (a shape, w shape, transpose_a, transpose_b, bias, native)   native: every operand readable in 4-element chunks
+    ((8, 32), (12, 32), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, True),        # cnnp dense layer, k-contiguous x k-contiguous
+    ((64, 128), (128, 96), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, True, True),        # k-contiguous x row-contiguous (transposed into LDS)
+    ((40, 36), (40, 52), nnc.TRANSPOSE(0, 1), nnc.NO_TRANSPOSE, False, True),      # row-contiguous x row-contiguous
+    ((132, 200), (260, 200), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, True),   # several 128 x 128 tiles, ragged
+    ((8, 4096), (16, 4096), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, True),    # split-K
+    ((3, 8, 12), (3, 12, 16), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, False, True),    # batched
+    ((5, 3), (3, 7), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, True, False),             # odd sizes: fp32 core on fp32 images
+    ((6, 18), (9, 18), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, False),
+]
+
+
+def _t(t, nd):
+    return t if t[0] == t[1] or nd == 2 else (nd - 2, nd - 1)
+
+
+def _gemm_shapes(ashape, wshape, ta, tb):
+    ar, ac = ashape[-2:]
+    if ta[0] != ta[1]:
+        ar, ac = ac, ar
+    wr, wc = wshape[-2:]
+    if tb[0] != tb[1]:
+        wr, wc = wc, wr
+    assert ac == wr
+    batch = ashape[:-2] if len(ashape) > 2 else (wshape[:-2] if len(wshape) > 2 else ())
+    return batch + (ar, wc)
+
+
+def _kernel_records(L, fn):
+    L.profile_enable(1)
+    try:
+        fn()
+        L.stream_wait(None)
+        return [r[0] for r in L.profile_records()]
+    finally:
+        L.profile_enable(0)
+
+
+@pytest.mark.parametrize("case", GEMM_H, ids=[str(c[:2]) for c in GEMM_H])
+def test_gemm_forward_half(backend, ref_lib, case):
+    ashape, wshape, ta, tb, bias, native = case
+    rng = np.random.default_rng(0)
+    scale = 1.0 / np.sqrt(ashape[-1] if ta[0] == ta[1] else ashape[-2])
+    a, w = hrnd(rng, *ashape), hrnd(rng, *wshape, scale=4 * scale)
+    ta, tb = _t(ta, len(ashape)), _t(tb, len(wshape))
+    bshape = _gemm_shapes(ashape, wshape, ta, tb)
+    ins = [a, w] + ([hrnd(rng, bshape[-1])] if bias else [])
+    res = {}
+    names = _kernel_records(backend, lambda: res.update(r=_pair(backend, ref_lib, nnc.CMD_GEMM_FORWARD(ta, tb), nnc.NO_HINT, 0, ins, [np.zeros(bshape, H)])))
+    got, want = res["r"]
+    _close(got[0], want[0])
+    assert any("mfma_gemm_f16_kernel" in n for n in names) == native, names
+
+
+@pytest.mark.parametrize("case", GEMM_H, ids=[str(c[:2]) for c in GEMM_H])
+@pytest.mark.parametrize("flags", [0, nnc.ACCUMULATE_OUTPUT])
+def test_gemm_backward_half(backend, ref_lib, case, flags):
+    ashape, wshape, ta, tb, bias, native = case
+    rng = np.random.default_rng(1)
+    a, w = hrnd(rng, *ashape), hrnd(rng, *wshape)
+    ta, tb = _t(ta, len(ashape)), _t(tb, len(wshape))
+    bshape = _gemm_shapes(ashape, wshape, ta, tb)
+    g = hrnd(rng, *bshape, scale=1.0 / np.sqrt(max(bshape[-1], bshape[-2])))
+    outs = [hrnd(rng, *ashape), hrnd(rng, *wshape)] + ([hrnd(rng, bshape[-1])] if bias else [])
+    got, want = _pair(backend, ref_lib, nnc.CMD_GEMM_BACKWARD(ta, tb), nnc.NO_HINT, flags, [g, a, w], outs)
+    for x, y in zip(got, want):
+        _close(x, y)
+
+
+def test_relu_and_add_half_through_fp32_images(backend, ref_lib):
+    rng = np.random.default_rng(2)
+    a, b = hrnd(rng, 3, 5, 7, 6), hrnd(rng, 3, 5, 7, 6)
+    got, want = _pair(backend, ref_lib, nnc.CMD_RELU_FORWARD(), nnc.NO_HINT, 0, [a], [np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0].astype(H))  # exact: max(a, 0) of a half is a half
+    got, want = _pair(backend, ref_lib, nnc.CMD_ADD_FORWARD(0.5, 0.25), nnc.NO_HINT, 0, [a, b], [np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0].astype(H))  # one rounding, of the fp32 result
+
+
+def test_sgd_mixed_precision(backend, ref_lib):
+    """fp16 gradient, fp32 parameters and momentum (lib/nnc/cmd/sgd/gpu/ccv_nnc_sgd_gpu_ref.cu:13-100, the mixed variants)."""
+    rng = np.random.default_rng(3)
+    g = hrnd(rng, 1000)
+    a, m = (rng.random(1000, dtype=F) - 0.5).astype(F), (rng.random(1000, dtype=F) - 0.5).astype(F)
+    cmd = nnc.CMD_SGD_FORWARD(0, 0.01, 0.5, 0.0005, 0.9, 0.9)
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [g, a, m], [np.zeros_like(a), np.zeros_like(m)])
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, [g.astype(F), a, m], [np.zeros_like(a), np.zeros_like(m)], backend=nnc.BACKEND_CPU_REF)
+    assert r1 == 0 and r2 == 0
+    for x, y in zip(got, want):
+        assert x.dtype == F
+        np.testing.assert_allclose(x, y, rtol=1e-6, atol=1e-7)
+
+
+def test_half_view_output_keeps_what_it_does_not_write(backend, ref_lib):
+    """An output VIEW in half precision: elements outside the view must survive the round trip through the fp32 image."""
+    L = backend
+    rng = np.random.default_rng(4)
+    base = hrnd(rng, 6, 10)
+    a = hrnd(rng, 6, 4)
+    bt = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, nnc.CCV_16F, base.shape, 0), base)
+    at = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, nnc.CCV_16F, a.shape, 0), a)
+    view = bt.view((6, 4), (10, 1), 3)
+    assert L.cmd_exec(nnc.CMD_ADD_FORWARD(1, 1), nnc.NO_HINT, 0, [at, at], [view]) == 0
+    out = bt.numpy()
+    want = base.copy()
+    want[:, 3:7] = (a.astype(F) * 2).astype(H)
+    assert np.array_equal(out, want)
+
+
+CONV_H = [
+    # n, h, w, c, k, kh, kw, stride, border, groups, native
+    (2, 9, 10, 8, 16, 3, 3, (1, 1), (1, 1), 1, True),
+    (1, 12, 11, 32, 20, 3, 3, (1, 1), (1, 1), 1, True),     # chunk-major K order (C % 32 == 0)
+    (2, 11, 9, 12, 8, 5, 5, (2, 2), (2, 2), 1, True),       # stride 2: strided dgrad loader
+    (2, 7, 7, 16, 24, 1, 1, (1, 1), (0, 0), 2, True),       # 1x1, two groups
+    (3, 16, 16, 64, 64, 3, 3, (1, 1), (1, 1), 1, True),     # several K-steps, 64 x 64 tiles
+    (2, 9, 9, 3, 8, 3, 3, (1, 1), (1, 1), 1, False),        # 3 input channels: fp32 kernels on fp32 images
+]
+
+
+@pytest.mark.parametrize("case", CONV_H, ids=[str(c[:7]) for c in CONV_H])
+def test_conv_forward_backward_half(backend, ref_lib, case):
+    n, h, w_, c, k, kh, kw, stride, border, groups, native = case
+    rng = np.random.default_rng(7)
+    a = hrnd(rng, n, h, w_, c)
+    wt = hrnd(rng, k, kh, kw, c // groups, scale=2.0 / np.sqrt(kh * kw * c // groups))
+    bias = hrnd(rng, k)
+    hint = nnc.HINT(stride, border)
+    oh = (h + 2 * border[0] - kh) // stride[0] + 1
+    ow = (w_ + 2 * border[1] - kw) // stride[1] + 1
+    res = {}
+    names = _kernel_records(backend, lambda: res.update(r=_pair(backend, ref_lib, nnc.CMD_CONVOLUTION_FORWARD(groups, k, kh, kw, c // groups), hint, 0, [a, wt, bias], [np.zeros((n, oh, ow, k), H)])))
+    got, want = res["r"]
+    _close(got[0], want[0])
+    assert any("mfma_gemm_f16_kernel" in x for x in names) == native, names
+    g = hrnd(rng, n, oh, ow, k, scale=1.0 / np.sqrt(oh * ow))
+    for flags in (0, nnc.ACCUMULATE_OUTPUT):
+        outs = [hrnd(rng, n, h, w_, c), hrnd(rng, k, kh, kw, c // groups), hrnd(rng, k)]
+        got, want = _pair(backend, ref_lib, nnc.CMD_CONVOLUTION_BACKWARD(groups, k, kh, kw, c // groups), hint, flags, [g, a, wt], outs)
+        _close(got[0], want[0])
+        _close(got[1], want[1])
+        if not flags:  # (the CPU oracle overwrites dbias under ACCUMULATE_OUTPUT, conv_cpu_ref.c:262-263; the GPU backend being replaced accumulates)
+            _close(got[2], want[2])
