@@ -99,6 +99,38 @@ def via_host(args, losses, params):
             "equal": bool(loss_err <= 1e-4 and qerr <= 1e-4), "driver": h["driver"]}
 
 
+def resnet_config(args, half):
+    """BASELINE config 4 on one MI355X: ResNet-50 v1d (bin/nnc/imagenet.c:17-98), NCHW, batch 256, forward + backward + Nesterov SGD,
+    through the REFERENCE HOST's own model API (tools/host_resnet_bench.c -> oracle/_ref/host_resnet_bench.gpu: ccv_cnnp_model_fit on
+    this backend; cnnp, autodiff, compile and the scheduler are the reference's unmodified code).  The timing is the harness's
+    (wall clock around K fit calls bracketed by stream waits); `roofline` is the batch-norm command (HBM-bound, SURVEY 8(d):
+    2 |x| forward, 3 |x| backward algorithmic bytes) from the backend's HIP-event records of one more step."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_resnet_bench.gpu")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/host_resnet_bench.gpu not built (oracle/build_ref_host.sh)")
+    r = subprocess.run([exe, str(args.batch), "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"], capture_output=True, text=True, timeout=3000)
+    if r.returncode != 0:
+        raise SystemExit("host_resnet_bench failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
+    h = json.loads(r.stdout.strip().splitlines()[-1])
+    gflop = 25.97  # SURVEY.md section 8: ResNet-50 v1d forward + backward per image (1 MAC = 2 FLOP)
+    out = {"metric": "images/sec fwd+bwd ResNet-50 v1d 224x224 bs%d NCHW" % args.batch, "value": h["images_per_s"], "unit": "images/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16" if half else "f32", "data": "synthetic",
+           "config": {"workload": "ResNet-50 v1d (bin/nnc/imagenet.c) NCHW forward+backward+Nesterov SGD, batch %d, random-init weights, driven by the reference host's ccv_cnnp_model_fit" % args.batch,
+                      "global_batch": args.batch, "parallelism": "dp1", "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] * gflop / 1e3,
+                      "first_step_ms": h["first_step_ms"], "outputs_finite": h["outputs_finite"], "softmax_worst_row_sum_err": h["softmax_worst_row_sum_err"], "memory_gib": h["memory_gib"]}}
+    ks = h.get("kernels", [])
+    bn = [k for k in ks if k["bytes"] > 0 and k["ms"] > 0]
+    if bn:
+        byts, ms, n = sum(k["bytes"] for k in bn), sum(k["ms"] for k in bn), sum(k["launches"] for k in bn)
+        ach = byts / (ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                           "kernel": "batch norm forward + backward commands (%s)" % "; ".join(sorted(set(k["name"] for k in bn))), "launches": n, "avg_ms": ms / n,
+                           "ms_per_step": ms, "recorded_kernels": {k["name"][-100:]: {"ms": k["ms"], "launches": k["launches"], "tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0)} for k in ks}}
+    print(json.dumps(out))
+
+
 def pmc_traffic(symbol, batch):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/pmc_traffic_bs<batch>.json, written
     by tools/pmc_pass.sh + tools/pmc_traffic.py from `rocprofv3 --pmc` runs of this same command: counters cannot be
@@ -129,6 +161,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
+    ap.add_argument("--config", default="vggd-train-bs256", choices=["vggd-train-bs256", "vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16"],
+                    help="BASELINE.json configs: 3 (default, the metric), 2 (VGG-D forward only, batch 64), 4 (ResNet-50 v1d NCHW through the reference host; -f16 = the trainer's own precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-via-host", action="store_true", help="skip the second driver: the same step through the reference host's symbolic graph / autotune / static schedule (tools/host_vgg_bench.c)")
     ap.add_argument("--records", default=None, help="also write the per-launch contraction records (name, dims, ms, TFLOP/s) of the roofline leg to this file")
@@ -136,6 +170,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    fwd_only = args.config == "vggd-fwd-bs64"
+    if fwd_only and args.batch == 256:
+        args.batch = 64
+    if args.config.startswith("resnet50"):
+        if world > 1:
+            raise SystemExit("--config %s is a one-GPU line (the N-GPU form of this path is the reference host's single-process ccv_cnnp_model_set_data_parallel)" % args.config)
+        nnc.load()  # fail loudly without the HIP library / a GPU
+        return resnet_config(args, args.config.endswith("f16"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
 
@@ -172,6 +214,8 @@ def main():
 
     def step():
         net.forward(stream)
+        if fwd_only:
+            return
         if comm:
             net.backward(stream, after_node=lambda i: comm.after_backward_node(net, i, stream))
             comm.finish_overlap(stream)
@@ -194,7 +238,7 @@ def main():
             L.stream_wait(stream)
             step1_losses = net.loss.numpy()[:8].astype(np.float64)
             step1_loss = float(step1_losses[0])
-            if rank == 0 and world == 1 and not args.no_via_host:
+            if rank == 0 and world == 1 and not args.no_via_host and not fwd_only:
                 step1_params = [(float(p.numpy().astype(np.float64).sum()), float((p.numpy().astype(np.float64) ** 2).sum())) for p, _, _ in net.params]
     barrier()
     t0 = time.perf_counter()
@@ -240,16 +284,16 @@ def main():
     total_ms = sum(v[1] for v in by.values())
 
     if rank == 0:
-        _, fb = vgg_d_flops_per_image()
+        ff, fb = vgg_d_flops_per_image()
         value = world * args.batch * args.steps / dt
         out = {
-            "metric": "images/sec fwd+bwd VGG-D 224x224 bs256",
+            "metric": "images/sec fwd VGG-D 224x224 bs%d" % args.batch if fwd_only else "images/sec fwd+bwd VGG-D 224x224 bs256",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VGG-D (ccv vgg_d_params, 225x225x3 crop, NHWC) forward+backward+SGD, batch %d per GPU, random-init weights" % args.batch,
+            "config": {"workload": "VGG-D (ccv vgg_d_params, 225x225x3 crop, NHWC) %s, batch %d per GPU, random-init weights" % ("forward only" if fwd_only else "forward+backward+SGD", args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "gflop_per_image": fb / 1e9, "whole_step_tflops_per_gpu": value / world * fb / 1e12, "final_loss": loss},
+                       "gflop_per_image": (ff if fwd_only else fb) / 1e9, "whole_step_tflops_per_gpu": value / world * (ff if fwd_only else fb) / 1e12, "final_loss": loss},
         }
         if dom:
             name, (fl, ms, cnt) = dom
@@ -266,6 +310,9 @@ def main():
                 out["cpu_baseline"], oracle_loss = cpu_baseline(image0, label0)
             except Exception as e:  # the checker is optional for the bench line, never for the parity tests
                 out["cpu_baseline"], oracle_loss = {"value": None, "unit": "images/s", "cores": 0, "kind": "reference", "sample": "unavailable: %s" % e}, None
+            if fwd_only and out["cpu_baseline"].get("forward_only_cpu_ref_images_per_s"):
+                out["cpu_baseline"]["value"] = out["cpu_baseline"]["forward_only_cpu_ref_images_per_s"]
+                out["cpu_baseline"]["sample"] = "forward only: " + out["cpu_baseline"]["sample"]
             if oracle_loss is not None and step1_loss is not None:
                 # parity gate on the benchmarked configuration itself: image 0's loss after the first forward at batch 256 (the
                 # convolutions under the algorithms the timed steps use) vs the reference CPU backend on the same image and weights

@@ -179,6 +179,8 @@ static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 	const size_t n = tensor_count(x->info);
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
 	hipStream_t stream = stream_of(stream_context);
+	// (bench.py roofline leg, config 4: the whole command between two events; algorithmic bytes = x read once + y written once)
+	ProfScope prof(cmd.info.bnorm.is_test ? "bnorm_fwd_test|nnc::bn_apply_kernel" : "bnorm_fwd|nnc::chan_reduce + bn_apply_kernel", 0, 2.0 * sizeof(float) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream);
 	const float* scale = inputs[1]->data.f32;
 	const float* bias = inputs[2]->data.f32;
 	float* mean = inputs[3]->data.f32;
@@ -233,6 +235,7 @@ static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 	if ((int)tensor_count(saved_mean->info) != v.C || (int)tensor_count(saved_inv_std->info) != v.C || (int)tensor_count(dscale->info) != v.C || (int)tensor_count(dbias->info) != v.C) return CCV_NNC_EXEC_INVALID;
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
 	int ret;
+	ProfScope prof("bnorm_bwd|nnc::chan_reduce + bn_back_kernel", 0, 3.0 * sizeof(float) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream_of(stream_context)); // g, x read; h written
 	if ((ret = chan_reduce<RSum, false>(RSum(), g->data.f32, 0, v, dbias->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	RXhatG f; f.mean = saved_mean->data.f32; f.inv_std = saved_inv_std->data.f32;
 	if ((ret = chan_reduce<RXhatG, true>(f, x->data.f32, g->data.f32, v, dscale->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;

@@ -41,7 +41,9 @@ done
 # 3b. the VGG-D training step through the reference host (tools/host_vgg_bench.c: our client of the reference's public API;
 #     bench.py --via-host runs it on the MI355X, tests/test_via_host.py the emulator build at a small size)
 $CC $TFLAGS $ROOT/tools/host_vgg_bench.c -o $OUT/host_vgg_bench.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
+$CC $TFLAGS $ROOT/tools/host_resnet_bench.c -o $OUT/host_resnet_bench.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
 if [ -f $OUT/libccv_host_emu.so ]; then
+  $CC $TFLAGS $ROOT/tools/host_resnet_bench.c -o $OUT/host_resnet_bench.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
   $CC $TFLAGS $ROOT/tools/host_vgg_bench.c -o $OUT/host_vgg_bench.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
 fi
 wait
