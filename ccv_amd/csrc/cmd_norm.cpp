@@ -143,18 +143,33 @@ __global__ void __launch_bounds__(256) bn_back_kernel(const float* x, const floa
 	}
 }
 
-// Derive the [outer][C][inner] view: the statistics tensor (right-aligned against x) keeps exactly one axis.
+// Derive the [outer][C][inner] view of x from the statistics tensor.
+//   * statistics with x's rank (or right-aligned against it, lib/nnc/cmd/norm/ccv_nnc_batch_norm_cpu_ref.c:28-33): every axis of
+//     extent 1 is reduced, exactly one axis is kept;
+//   * a ONE-dimensional statistics tensor of C elements against an image tensor -- what ccv_cnnp_batch_norm creates
+//     (lib/nnc/ccv_cnnp_model_addons.c:951-957: dim[0] = ccv_nnc_tensor_get_c(params)) -- is per CHANNEL, and the channel axis is
+//     the one x's FORMAT names (NCHW: axis 1 of 4 / 0 of 3, NHWC: the last axis, CHWN: axis 0), as the backend being replaced reads
+//     it through its format-aware tensor descriptors (gpu/ccv_nnc_batch_norm_gpu_cudnn.cu:13-100).  Right-aligning such a tensor
+//     against NCHW data would pit C against W: found when the reference's ResNet trainer graph (NCHW) ran here -- most of its
+//     batch norms were refused (and the host does not look at a command's return code), the ones with W == C normalised over
+//     the wrong axis.
 static bool chan_view(const ccv_nnc_tensor_t* x, const ccv_nnc_tensor_t* stat, chan_view_t* v)
 {
 	const int nd = tensor_nd(x->info.dim), snd = tensor_nd(stat->info.dim);
 	if (nd < 1 || nd > 4 || snd > nd || !tensor_contiguous(x) || !tensor_contiguous(stat)) return false;
 	int kept = -1;
-	for (int k = 0; k < nd; k++) {
-		const int sd = k - (nd - snd) >= 0 ? stat->info.dim[k - (nd - snd)] : 1;
-		if (sd == 1) continue;
-		if (sd != x->info.dim[k] || kept >= 0) return false;
-		kept = k;
-	}
+	if (snd == 1 && nd >= 2 && stat->info.dim[0] > 1) {
+		if (x->info.format == CCV_TENSOR_FORMAT_NCHW) kept = nd == 4 ? 1 : (nd == 3 ? 0 : nd - 1);
+		else if (x->info.format == CCV_TENSOR_FORMAT_CHWN) kept = 0;
+		else kept = nd - 1;
+		if (stat->info.dim[0] != x->info.dim[kept]) return false;
+	} else
+		for (int k = 0; k < nd; k++) {
+			const int sd = k - (nd - snd) >= 0 ? stat->info.dim[k - (nd - snd)] : 1;
+			if (sd == 1) continue;
+			if (sd != x->info.dim[k] || kept >= 0) return false;
+			kept = k;
+		}
 	if (kept < 0) { // every axis reduced: one "channel"
 		v->outer = (long)tensor_count(x->info); v->C = 1; v->inner = 1;
 		return true;

@@ -147,9 +147,26 @@ constexpr int MAX_STAGED = 64;
 
 } // namespace
 
+// The reference host's graph runner does not look at what a command returns (lib/nnc/ccv_nnc_graph_run.c calls ccv_nnc_cmd_exec and
+// moves on): a refused command would leave its outputs unwritten in silence.  Say so on stderr, a few times per command id.
+void warn_refused(const uint32_t cmd, const int ret)
+{
+	static uint32_t seen[32];
+	static int counts[32], nseen = 0;
+	if (ret == CCV_NNC_EXEC_SUCCESS) return;
+	int i;
+	for (i = 0; i < nseen; i++) if (seen[i] == cmd) break;
+	if (i == nseen) { if (nseen == 32) return; seen[nseen] = cmd; counts[nseen++] = 0; }
+	if (counts[i]++ < 3) fprintf(stderr, "[nnc-mi355x] command 0x%08x refused with %d (INVALID -1 / NO_KERNEL -2 / OOM -3): its outputs were NOT written\n", cmd, ret);
+}
+
 int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
 {
-	if (!any_half_tensor(inputs, input_size, outputs, output_size)) return inner(cmd, hint, flags, inputs, input_size, outputs, output_size, ctx);
+	if (!any_half_tensor(inputs, input_size, outputs, output_size)) {
+		const int r = inner(cmd, hint, flags, inputs, input_size, outputs, output_size, ctx);
+		warn_refused(cmd.cmd, r);
+		return r;
+	}
 	if (input_size + output_size > MAX_STAGED) return CCV_NNC_EXEC_INVALID;
 	staged_t st[MAX_STAGED];
 	int nst = 0;
@@ -206,6 +223,7 @@ int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_
 	for (int i = 0; i < input_size; i++) in_s[i] = make_shadow(inputs[i], i);
 	for (int i = 0; i < output_size; i++) out_s[i] = make_shadow(outputs[i], input_size + i);
 	const int ret = inner(cmd, hint, flags, in_s, input_size, out_s, output_size, ctx);
+	warn_refused(cmd.cmd, ret);
 	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
 	for (int i = 0; i < nst; i++)
 		if (st[i].is_output) float_to_half(st[i].image, st[i].half, st[i].span, ctx);

@@ -4,7 +4,7 @@ Tolerances: fp32 conv/GEMM 1e-4 relative (north_star); pooling, relu, transfers 
 import numpy as np
 import pytest
 from ccv_amd import nnc
-from harness import exec_pair, exec_on, out_hw, tensor_eq
+from harness import exec_pair, exec_on, out_hw, tensor_eq, make_tensors
 
 F = np.float32
 
@@ -526,3 +526,43 @@ def test_conv_first_layer_direct(backend, ref_lib, case):
         np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5)
         # the CPU oracle overwrites dbias under ACCUMULATE (see test_conv_backward): the GPU backend being replaced accumulates
         np.testing.assert_allclose(got[2], (db0 + want[2]) if flags else want[2], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("fmt,shape", [("NCHW", (3, 6, 5, 7)), ("NCHW", (2, 8, 8, 8)), ("NHWC", (3, 5, 7, 6))])
+def test_batch_norm_with_one_dimensional_statistics(backend, ref_lib, fmt, shape):
+    """What ccv_cnnp_batch_norm issues (lib/nnc/ccv_cnnp_model_addons.c:951-986): scale / bias / mean / var / saved tensors of ONE
+    dimension (C) against an image tensor; the channel axis is the one the tensor FORMAT names.  The reference's CPU backend
+    right-aligns statistics against the data (batch_norm_cpu_ref.c:28-33), so the oracle is run with the same numbers shaped
+    (1, C, 1, 1) / (1, 1, 1, C).  (2, 8, 8, 8) NCHW is the trap: W == C, where a right-aligned reading normalises over W.)"""
+    rng = np.random.default_rng(11)
+    caxis = 1 if fmt == "NCHW" else 3
+    C = shape[caxis]
+    s4 = tuple(C if k == caxis else 1 for k in range(4))
+    axes = tuple(k for k in range(4) if k != caxis)
+    x = srnd(rng, *shape, scale=2.0)
+    scale, bias = srnd(rng, C) + F(1.5), srnd(rng, C)
+    mean, var = srnd(rng, C), rng.random(C, dtype=F) + F(0.5)
+    cmd = nnc.CMD_BATCH_NORM_FORWARD(1e-4, 0, 0.9, *axes)
+
+    def run(lib, mem, sshape, backend_id=None):
+        r = lambda a: a.reshape(sshape).copy()
+        tx, = make_tensors(lib, mem, [x], fmt)
+        ts = make_tensors(lib, mem, [r(scale), r(bias), r(mean), r(var)], fmt)
+        ty, tsm, tsi = make_tensors(lib, mem, [np.zeros_like(x), np.zeros(sshape, F), np.zeros(sshape, F)], fmt)
+        c = nnc.Cmd(); nnc.C.memmove(nnc.C.byref(c), nnc.C.byref(cmd), nnc.C.sizeof(c))
+        if backend_id is not None:
+            c.backend = backend_id
+        assert lib.cmd_exec(c, nnc.NO_HINT, 0, [tx] + ts, [ty, ts[2], ts[3], tsm, tsi]) == 0
+        g = srnd(np.random.default_rng(12), *shape)
+        tg, = make_tensors(lib, mem, [g], fmt)
+        th, tds, tdb = make_tensors(lib, mem, [np.zeros_like(x), np.zeros(sshape, F), np.zeros(sshape, F)], fmt)
+        cb = nnc.CMD_BATCH_NORM_BACKWARD(1e-4, 0, 0.9, *axes)
+        if backend_id is not None:
+            cb.backend = backend_id
+        assert lib.cmd_exec(cb, nnc.NO_HINT, 0, [tg] + [None] * 4 + [tx, ts[0]] + [None] * 6 + [tsm, tsi], [th, tds, tdb]) == 0
+        return [t.numpy().reshape(-1) if t.numpy().ndim != 4 or t.numpy().shape != x.shape else t.numpy() for t in (ty, ts[2], ts[3], tsm, tsi, th, tds, tdb)]
+
+    got = run(backend, nnc.GPU_MEMORY, (C,))
+    want = run(ref_lib, nnc.CPU_MEMORY, s4, nnc.BACKEND_CPU_REF)
+    for a, b, what in zip(got, want, ("y", "mean", "var", "saved_mean", "saved_inv_std", "h", "dscale", "dbias")):
+        np.testing.assert_allclose(a.reshape(-1), b.reshape(-1), rtol=2e-4, atol=2e-5, err_msg=what)

@@ -39,11 +39,12 @@ static double now_ms(void)
 	return tv.tv_sec * 1e3 + tv.tv_usec * 1e-3;
 }
 
-static ccv_cnnp_model_t* conv_bn(const int filters, const int k, const int stride, const int relu)
+/* no_bias as the trainer has it: the stem and the projection shortcuts without, the bottleneck convolutions with (imagenet.c:28-46, 75-82) */
+static ccv_cnnp_model_t* conv_bn(const int filters, const int k, const int stride, const int relu, const int no_bias)
 {
 	ccv_cnnp_model_t* m[3];
 	int n = 0;
-	m[n++] = ccv_cnnp_convolution(1, filters, DIM_ALLOC(k, k), DIM_ALLOC(), 1 /* no bias */, HINT((stride, stride), (k / 2, k / 2)), 0, 1, 0);
+	m[n++] = ccv_cnnp_convolution(1, filters, DIM_ALLOC(k, k), DIM_ALLOC(), no_bias, HINT((stride, stride), (k / 2, k / 2)), 0, 1, 0);
 	m[n++] = ccv_cnnp_batch_norm(0.9, 1e-4, 1, 0);
 	if (relu) m[n++] = ccv_cnnp_relu(0);
 	return ccv_cnnp_sequential_new(m, n, 1, 0);
@@ -58,9 +59,9 @@ static ccv_cnnp_model_t* bottleneck(const int filters, const int expansion, cons
 		if (stride > 1) shortcut = ccv_cnnp_model_apply(ccv_cnnp_average_pool(DIM_ALLOC(stride, stride), HINT((stride, stride), (0, 0)), 0), MODEL_IO_LIST(in));
 		shortcut = ccv_cnnp_model_apply(ccv_cnnp_convolution(1, filters * expansion, DIM_ALLOC(1, 1), DIM_ALLOC(), 1, HINT((1, 1), (0, 0)), 0, 1, 0), MODEL_IO_LIST(shortcut));
 	}
-	ccv_cnnp_model_io_t out = ccv_cnnp_model_apply(conv_bn(filters, 1, 1, 1), MODEL_IO_LIST(in));
-	out = ccv_cnnp_model_apply(conv_bn(filters, 3, stride, 1), MODEL_IO_LIST(out));
-	out = ccv_cnnp_model_apply(conv_bn(filters * expansion, 1, 1, 0), MODEL_IO_LIST(out));
+	ccv_cnnp_model_io_t out = ccv_cnnp_model_apply(conv_bn(filters, 1, 1, 1, 0), MODEL_IO_LIST(in));
+	out = ccv_cnnp_model_apply(conv_bn(filters, 3, stride, 1, 0), MODEL_IO_LIST(out));
+	out = ccv_cnnp_model_apply(conv_bn(filters * expansion, 1, 1, 0, 0), MODEL_IO_LIST(out));
 	out = ccv_cnnp_model_apply(ccv_cnnp_sum(0), MODEL_IO_LIST(out, shortcut));
 	out = ccv_cnnp_model_apply(ccv_cnnp_relu(0), MODEL_IO_LIST(out));
 	return ccv_cnnp_model_new(MODEL_IO_LIST(in), MODEL_IO_LIST(out), 1, 0);
@@ -69,9 +70,9 @@ static ccv_cnnp_model_t* bottleneck(const int filters, const int expansion, cons
 static ccv_cnnp_model_t* resnet(const int* const blocks, const int* const widths, const int stages, const int stem, const int classes)
 {
 	const ccv_cnnp_model_io_t in = ccv_cnnp_input();
-	ccv_cnnp_model_io_t out = ccv_cnnp_model_apply(conv_bn(stem / 2, 3, 2, 1), MODEL_IO_LIST(in));
-	out = ccv_cnnp_model_apply(conv_bn(stem / 2, 3, 1, 1), MODEL_IO_LIST(out));
-	out = ccv_cnnp_model_apply(conv_bn(stem, 3, 1, 1), MODEL_IO_LIST(out));
+	ccv_cnnp_model_io_t out = ccv_cnnp_model_apply(conv_bn(stem / 2, 3, 2, 1, 1), MODEL_IO_LIST(in));
+	out = ccv_cnnp_model_apply(conv_bn(stem / 2, 3, 1, 1, 1), MODEL_IO_LIST(out));
+	out = ccv_cnnp_model_apply(conv_bn(stem, 3, 1, 1, 1), MODEL_IO_LIST(out));
 	out = ccv_cnnp_model_apply(ccv_cnnp_max_pool(DIM_ALLOC(3, 3), HINT((2, 2), (1, 1)), 0), MODEL_IO_LIST(out));
 	int s, b;
 	for (s = 0; s < stages; s++)
