@@ -474,6 +474,91 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 #undef CONV_WGRAD
 }
 
+// ---- 1x1 convolutions on NCHW tensors: plain batched GEMMs over the tensors WHERE THEY LIE ------------------------------------
+// The reference's ResNet trainer keeps NCHW (bin/nnc/imagenet.c:354) and two thirds of its convolutions are 1x1, stride 1: with
+// P = H * W,   forward  b_n [K x P] = w [K x C] . a_n [C x P]          one GEMM per image (grid z = N), output rows contiguous
+//              dgrad    h_n [C x P] = w^T [C x K] . g_n [K x P]
+//              wgrad    dw [K x C]  = sum_n g_n [K x P] . a_n^T [P x C]  one GEMM with the reduction running over (n, p): PlaneKC
+//              dbias    [K]         = sum over planes of g              (chan_sum, cmd_norm.cpp)
+// -- no layout pass at all, where the general NCHW route transposes the input, the output and the weights around an NHWC
+// kernel (measured on the ResNet-50 step at batch 256: transposes were 80 of 167 ms).  Needs P % 4 == 0 and C % 4 == 0
+// (16-byte chunks; 8-byte for halves) and dense tensors; 7 x 7 maps (P = 49) take the general route.  T = float or half_t.
+template <class T> struct conv1x1_types;
+template <> struct conv1x1_types<float> { typedef GemmOut Out; };
+template <> struct conv1x1_types<half_t> { typedef GemmOutH Out; };
+template <class LA, class LB> static int conv1x1_run(const char* name, float*, LA la, LB lb, const GemmOut out, int M, int N, int K, int z, long a_z, long b_z, long c_z, int splits, int flags, ccv_nnc_stream_context_t* ctx) { return gemm_run(name, la, lb, out, M, N, K, z, a_z, b_z, c_z, 0L, splits, flags, ctx); }
+template <class LA, class LB> static int conv1x1_run(const char* name, half_t*, LA la, LB lb, const GemmOutH out, int M, int N, int K, int z, long a_z, long b_z, long c_z, int splits, int flags, ccv_nnc_stream_context_t* ctx) { return gemm_run_h(name, la, lb, out, M, N, K, z, a_z, b_z, c_z, 0L, splits, flags, ctx); }
+
+static bool nchw_dense(const ccv_nnc_tensor_t* t, int* N, int* C, int* P)
+{
+	if (t->info.format != CCV_TENSOR_FORMAT_NCHW || !tensor_contiguous(t)) return false;
+	const int nd = tensor_nd(t->info.dim);
+	if (nd != 3 && nd != 4) return false;
+	const int b = nd == 4;
+	*N = b ? t->info.dim[0] : 1; *C = t->info.dim[b]; *P = t->info.dim[b + 1] * t->info.dim[b + 2];
+	return true;
+}
+static bool conv1x1_cmd_ok(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint)
+{
+	if (cmd.info.size.dim[0] != 1 || cmd.info.size.dim[1] != 1 || cmd.info.convolution.groups > 1) return false;
+	for (int i = 0; i < 2; i++)
+		if ((hint.stride.dim[i] > 1) || hint.border.begin[i] != 0 || hint.border.end[i] != 0) return false;
+	return true;
+}
+template <class T> static bool chunk_aligned(const void* p) { return (((uintptr_t)p) & (4 * sizeof(T) - 1)) == 0; }
+
+// CCV_NNC_EXEC_NO_KERNEL = not this path
+template <class T>
+static int conv1x1_nchw_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, const ccv_nnc_tensor_t* a, const ccv_nnc_tensor_t* w, const ccv_nnc_tensor_t* bias, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* const ctx)
+{
+	typedef typename conv1x1_types<T>::Out Out;
+	int N, C, P, Nb, K, Pb;
+	if (!conv1x1_cmd_ok(cmd, hint) || !nchw_dense(a, &N, &C, &P) || !nchw_dense(b, &Nb, &K, &Pb) || N != Nb || P != Pb) return CCV_NNC_EXEC_NO_KERNEL;
+	if (K != cmd.info.convolution.count || !tensor_contiguous(w) || (long)tensor_count(w->info) != (long)K * C || (bias && (!tensor_contiguous(bias) || (int)tensor_count(bias->info) != K))) return CCV_NNC_EXEC_NO_KERNEL;
+	if (P % 4 || C % 4 || ((long)C * P) % 4 || !chunk_aligned<T>(a->data.u8) || !chunk_aligned<T>(w->data.u8) || N <= 0 || P <= 0) return CCV_NNC_EXEC_NO_KERNEL;
+	MatLoader<true, true> la;  // w [K][C]: reduction-contiguous rows
+	la.p = (const float*)w->data.u8; la.ldr = C; la.ldk = 1; la.R = K; la.K = C;
+	MatLoader<false, true> lb; // a_n [C][P]: output columns p contiguous, reduction index c strides by P
+	lb.p = (const float*)a->data.u8; lb.ldr = 1; lb.ldk = P; lb.R = P; lb.K = C;
+	Out out = { (T*)b->data.u8, (long)P, 1, bias ? (const T*)bias->data.u8 : 0, 1.f, 0, 1 };
+	out.bias_ldn = 0; // one bias per output ROW (= output channel)
+	return conv1x1_run("conv1x1_nchw_fwd", (T*)0, la, lb, out, K, P, C, N, 0L, (long)C * P, (long)K * P, 1, flags, ctx);
+}
+
+template <class T>
+static int conv1x1_nchw_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, const ccv_nnc_tensor_t* g, const ccv_nnc_tensor_t* a, const ccv_nnc_tensor_t* w, ccv_nnc_tensor_t* h, ccv_nnc_tensor_t* dw, ccv_nnc_tensor_t* dbias, ccv_nnc_stream_context_t* const ctx)
+{
+	typedef typename conv1x1_types<T>::Out Out;
+	int N, K, P;
+	if (!conv1x1_cmd_ok(cmd, hint) || !nchw_dense(g, &N, &K, &P) || K != cmd.info.convolution.count) return CCV_NNC_EXEC_NO_KERNEL;
+	const ccv_nnc_tensor_t* shape_src = a ? a : h;
+	int Na, C, Pa;
+	if (!shape_src || !nchw_dense(shape_src, &Na, &C, &Pa) || Na != N || Pa != P) return CCV_NNC_EXEC_NO_KERNEL;
+	if (h && (!nchw_dense(h, &Na, &C, &Pa) || Na != N || Pa != P || !w || !tensor_contiguous(w) || (long)tensor_count(w->info) != (long)K * C)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (dw && (!a || !tensor_contiguous(dw) || (long)tensor_count(dw->info) != (long)K * C)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (dbias && (!tensor_contiguous(dbias) || (int)tensor_count(dbias->info) != K)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (P % 4 || C % 4 || K % 4 || !chunk_aligned<T>(g->data.u8) || (a && !chunk_aligned<T>(a->data.u8)) || (w && !chunk_aligned<T>(w->data.u8)) || (long)N * P > 0x7fffffffL) return CCV_NNC_EXEC_NO_KERNEL;
+	const int acc = (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0;
+	int ret;
+	if (dw) { // dw [K][C] = sum over (n, p): both operands rows of planes
+		PlaneKC<true> la, lb;
+		la.p = (const float*)g->data.u8; la.ldr = P; la.s_n = (long)K * P; la.R = K; la.K = N * P; la.P = P;
+		lb.p = (const float*)a->data.u8; lb.ldr = P; lb.s_n = (long)C * P; lb.R = C; lb.K = N * P; lb.P = P;
+		Out out = { (T*)dw->data.u8, (long)C, 1, 0, 1.f, acc, 0 };
+		if ((ret = conv1x1_run("conv1x1_nchw_wgrad", (T*)0, la, lb, out, K, C, N * P, 1, 0L, 0L, 0L, 0, flags, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	}
+	if (dbias && (ret = (sizeof(T) == sizeof(float) ? chan_sum_planes(g->data.f32, N, K, P, dbias->data.f32, acc, ctx) : chan_sum_planes_f16(g->data.u8, N, K, P, dbias->data.u8, acc, ctx))) != CCV_NNC_EXEC_SUCCESS) return ret;
+	if (h) { // h_n [C][P] = w^T . g_n
+		MatLoader<false, true> la; // w viewed [C rows][K reduction]: rows contiguous (element (c, k) = w[k * C + c])
+		la.p = (const float*)w->data.u8; la.ldr = 1; la.ldk = C; la.R = C; la.K = K;
+		MatLoader<false, true> lb;
+		lb.p = (const float*)g->data.u8; lb.ldr = 1; lb.ldk = P; lb.R = P; lb.K = K;
+		Out out = { (T*)h->data.u8, (long)P, 1, 0, 1.f, 0, 0 };
+		if ((ret = conv1x1_run("conv1x1_nchw_dgrad", (T*)0, la, lb, out, C, P, K, N, 0L, (long)K * P, (long)C * P, 1, flags, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 // ---- layout staging ---------------------------------------------------------------------------------------------------
 // The kernels read NHWC activations and [K][kh][kw][Cg] weights.  NCHW activations (the reference's ResNet trainer) and
 // NCHW-format weights [K][Cg][kh][kw] (what the reference's GPU tests hand over, test/int/nnc/cudnn.tests.c:50,65) are
@@ -514,6 +599,10 @@ static int _conv_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	ccv_nnc_tensor_t* b = outputs[0];
 	if (CCV_GET_DATA_TYPE(a->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
 	if (a->info.format != b->info.format) return CCV_NNC_EXEC_INVALID;
+	if (a->info.format == CCV_TENSOR_FORMAT_NCHW && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM) {
+		const int r = conv1x1_nchw_forw<float>(cmd, hint, flags, a, w, bias, b, stream_context);
+		if (r != CCV_NNC_EXEC_NO_KERNEL) return r;
+	}
 	Image4 ai, bi;
 	if (!image4(a, &ai) || !image4(b, &bi)) return CCV_NNC_EXEC_INVALID;
 	int K, kh, kw, Cg;
@@ -559,6 +648,10 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	ccv_nnc_tensor_t* dw = output_size > 1 ? outputs[1] : 0;
 	ccv_nnc_tensor_t* dbias = output_size > 2 ? outputs[2] : 0;
 	if (CCV_GET_DATA_TYPE(gt->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
+	if (gt->info.format == CCV_TENSOR_FORMAT_NCHW && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM) {
+		const int r = conv1x1_nchw_back<float>(cmd, hint, flags, gt, a, w, h, dw, dbias, stream_context);
+		if (r != CCV_NNC_EXEC_NO_KERNEL) return r;
+	}
 	Image4 gi;
 	if (!image4(gt, &gi)) return CCV_NNC_EXEC_INVALID;
 	const ccv_nnc_tensor_t* shape_src = a ? a : h; // the forward input's shape
@@ -701,6 +794,7 @@ static int _conv_forw_half(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, c
 	const ccv_nnc_tensor_t* w = inputs[1];
 	const ccv_nnc_tensor_t* bias = input_size > 2 ? inputs[2] : 0;
 	ccv_nnc_tensor_t* b = outputs[0];
+	if (a->info.format == CCV_TENSOR_FORMAT_NCHW && b->info.format == CCV_TENSOR_FORMAT_NCHW) return conv1x1_nchw_forw<half_t>(cmd, hint, flags, a, w, bias, b, stream_context);
 	if (a->info.format != CCV_TENSOR_FORMAT_NHWC || b->info.format != CCV_TENSOR_FORMAT_NHWC || w->info.format != CCV_TENSOR_FORMAT_NHWC) return CCV_NNC_EXEC_NO_KERNEL;
 	Image4 ai, bi;
 	if (!image4(a, &ai) || !image4(b, &bi)) return CCV_NNC_EXEC_NO_KERNEL;
@@ -725,6 +819,7 @@ static int _conv_back_half(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, c
 	const ccv_nnc_tensor_t* shape_src = a ? a : h;
 	const ccv_nnc_tensor_t* wshape = dw ? dw : w;
 	if (!shape_src || !wshape) return CCV_NNC_EXEC_INVALID;
+	if (gt->info.format == CCV_TENSOR_FORMAT_NCHW) return conv1x1_nchw_back<half_t>(cmd, hint, flags, gt, a, w, h, dw, dbias, stream_context);
 	if (gt->info.format != CCV_TENSOR_FORMAT_NHWC || shape_src->info.format != CCV_TENSOR_FORMAT_NHWC || wshape->info.format != CCV_TENSOR_FORMAT_NHWC || (w && w->info.format != CCV_TENSOR_FORMAT_NHWC) || (h && h->info.format != CCV_TENSOR_FORMAT_NHWC)) return CCV_NNC_EXEC_NO_KERNEL;
 	Image4 gi, ai, hi;
 	if (!image4(gt, &gi) || !image4(shape_src, &ai)) return CCV_NNC_EXEC_NO_KERNEL;

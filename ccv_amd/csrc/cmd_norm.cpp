@@ -53,17 +53,27 @@ __global__ void __launch_bounds__(256) chan_reduce_planes_kernel(F f, const floa
 	__syncthreads();
 	if (threadIdx.x == 0) partial[(long)blockIdx.y * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ void __launch_bounds__(256) chan_fold_kernel(const float* partial, const long slices, const int C, float* out)
+// out[c] (+)= sum_i partial[i][c], fixed order.  One workgroup per 64 channels: thread (phase = t >> 6, lane) adds the slices
+// phase, phase + 4, ...; the four phases fold through LDS.  (One thread per channel walking every slice -- the first version --
+// was 66 us per call on the ResNet-50 step, 13 ms per step: as long as the reductions it finishes.)
+__global__ void __launch_bounds__(256) chan_fold_kernel(const float* partial, const long slices, const int C, float* out, const int accumulate)
 {
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= C) return;
+	__shared__ float red[4][64];
+	const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+	const int c = blockIdx.x * 64 + lane;
 	float s = 0.f;
-	for (long i = 0; i < slices; i++) s += partial[i * C + c];
-	out[c] = s;
+	if (c < C)
+		for (long i = phase; i < slices; i += 4) s += partial[i * C + c];
+	red[phase][lane] = s;
+	__syncthreads();
+	if (phase == 0 && c < C) {
+		const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+		out[c] = accumulate ? out[c] + v : v;
+	}
 }
 
 template <class F, bool USE_G>
-static int chan_reduce(F f, const float* x, const float* g, const chan_view_t& v, float* out, ccv_nnc_stream_context_t* ctx)
+static int chan_reduce(F f, const float* x, const float* g, const chan_view_t& v, float* out, ccv_nnc_stream_context_t* ctx, const int accumulate = 0)
 {
 	hipStream_t stream = stream_of(ctx);
 	long slices;
@@ -86,9 +96,110 @@ static int chan_reduce(F f, const float* x, const float* g, const chan_view_t& v
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_planes_kernel<F, USE_G>), dim3(v.C, (unsigned)v.outer), dim3(256), 0, stream, f, x, g, v.C, v.inner, partial);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 255) / 256), dim3(256), 0, stream, (const float*)partial, slices, v.C, out);
+	hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, stream, (const float*)partial, slices, v.C, out, accumulate);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
+}
+
+// ---- NCHW-style layouts (inner > 1): ONE WAVE PER PLANE -----------------------------------------------------------------------
+// The ResNet trainer's tensors (N x C x H x W): a channel's elements are N planes of H * W contiguous floats.  A wave walks
+// whole planes (16-byte lanes when the plane size allows), so planes of every size keep all 64 lanes busy -- a workgroup per
+// plane left 7 x 7 planes with 49 of 256 threads working and launched half a million workgroups per reduction.
+//   forward statistics: per plane, sum and -- in a second sweep over the SAME plane, which the first one has just pulled
+//     through the cache hierarchy (12 .. 50 KB) -- the centred sum of squares about the PLANE's mean; the per-channel
+//     fold combines the N planes exactly (Chan et al.: M2 = sum_o [M2_o + n (mean_o - mean)^2]).  x comes from HBM once
+//     where the two-reduction form read it twice; accuracy is that of the reference's mean -> centred-variance order.
+//   backward statistics: sum of g and sum of xhat * g in one sweep over (x, g).
+template <class OP>
+__device__ __forceinline__ void plane_sweep(const float* __restrict__ p, const long inner, const int lane, OP op)
+{
+	if ((inner & 3) == 0 && (((uintptr_t)p) & 15) == 0) {
+		const float4* const p4 = (const float4*)p;
+		const long n4 = inner >> 2;
+		for (long i = lane; i < n4; i += 64) { const float4 v = p4[i]; op(v.x, i * 4); op(v.y, i * 4 + 1); op(v.z, i * 4 + 2); op(v.w, i * 4 + 3); }
+	} else
+		for (long i = lane; i < inner; i += 64) op(p[i], i);
+}
+__device__ __forceinline__ float wave_sum(float s)
+{
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64); // butterfly: every lane ends with the same total
+	return s;
+}
+__global__ void __launch_bounds__(256) bn_plane_stats_kernel(const float* __restrict__ x, const long planes, const long inner, float* __restrict__ psum, float* __restrict__ pm2)
+{
+	const int lane = threadIdx.x & 63;
+	const long nw = (long)gridDim.x * 4;
+	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+		const float* const p = x + pl * inner;
+		float s = 0.f;
+		plane_sweep(p, inner, lane, [&](const float v, long) { s += v; });
+		s = wave_sum(s);
+		const float m = s / (float)inner;
+		float q = 0.f;
+		plane_sweep(p, inner, lane, [&](const float v, long) { const float d = v - m; q += d * d; });
+		q = wave_sum(q);
+		if (lane == 0) { psum[pl] = s; pm2[pl] = q; }
+	}
+}
+// per channel: fold the planes (fixed order), then everything bn_mean_kernel + bn_var_kernel do.  One workgroup per 64 channels.
+__global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restrict__ psum, const float* __restrict__ pm2, const long outer, const int C, const float inner, float* saved_mean, float* saved_inv_std, float* mean, float* var, const float* scale, const float* bias, float* nscale, float* nbias, const float inv_b, const float mom, const float eps)
+{
+	__shared__ float red[4][64];
+	__shared__ float mu_s[64];
+	const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+	const int c = blockIdx.x * 64 + lane;
+	float s = 0.f;
+	if (c < C) for (long o = phase; o < outer; o += 4) s += psum[o * C + c];
+	red[phase][lane] = s;
+	__syncthreads();
+	if (phase == 0) mu_s[lane] = inv_b * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+	__syncthreads();
+	const float mu = mu_s[lane];
+	float q = 0.f;
+	if (c < C) for (long o = phase; o < outer; o += 4) { const float d = psum[o * C + c] / inner - mu; q += pm2[o * C + c] + inner * d * d; }
+	__syncthreads();
+	red[phase][lane] = q;
+	__syncthreads();
+	if (phase != 0 || c >= C) return;
+	const float v = inv_b * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+	saved_mean[c] = mu;
+	mean[c] = mom * mean[c] + (1.f - mom) * mu;
+	var[c] = mom * var[c] + (1.f - mom) * v;
+	const float is = 1.f / sqrtf(v + eps);
+	saved_inv_std[c] = is;
+	const float w = is * scale[c];
+	nscale[c] = w;
+	nbias[c] = bias[c] - mu * w;
+}
+__global__ void __launch_bounds__(256) bn_plane_back_stats_kernel(const float* __restrict__ x, const float* __restrict__ g, const long planes, const int C, const long inner, const float* __restrict__ mean, const float* __restrict__ inv_std, float* __restrict__ pg, float* __restrict__ pxg)
+{
+	const int lane = threadIdx.x & 63;
+	const long nw = (long)gridDim.x * 4;
+	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+		const int c = (int)(pl % C);
+		const float mu = mean[c], is = inv_std[c];
+		const float* const gp = g + pl * inner;
+		const float* const xp = x + pl * inner;
+		float sg = 0.f, sx = 0.f;
+		if ((inner & 3) == 0 && ((((uintptr_t)gp) | ((uintptr_t)xp)) & 15) == 0) {
+			const long n4 = inner >> 2;
+			for (long i = lane; i < n4; i += 64) {
+				const float4 gv = ((const float4*)gp)[i], xv = ((const float4*)xp)[i];
+				sg += gv.x; sx += (xv.x - mu) * is * gv.x;
+				sg += gv.y; sx += (xv.y - mu) * is * gv.y;
+				sg += gv.z; sx += (xv.z - mu) * is * gv.z;
+				sg += gv.w; sx += (xv.w - mu) * is * gv.w;
+			}
+		} else
+			for (long i = lane; i < inner; i += 64) { const float gv = gp[i]; sg += gv; sx += (xp[i] - mu) * is * gv; }
+		sg = wave_sum(sg); sx = wave_sum(sx);
+		if (lane == 0) { pg[pl] = sg; pxg[pl] = sx; }
+	}
+}
+static unsigned plane_grid(const long planes)
+{
+	const long want = (planes + 3) / 4, cap = (long)device_cu_count() * 8;
+	return (unsigned)(want < cap ? (want > 0 ? want : 1) : cap);
 }
 
 // ---- per-channel finishing steps (C elements each) ---------------------------------------------------------------------
@@ -202,7 +313,7 @@ static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 	float* var = inputs[4]->data.f32;
 	const int cb = (v.C + 255) / 256;
 	// per-channel affine lives in front of the reduction partials in the workspace
-	WorkspaceScope ws(stream_context, sizeof(float) * 2 * (size_t)v.C, sizeof(float) * (size_t)v.C * (size_t)(v.inner == 1 ? (long)device_cu_count() * 4 + 64 : v.outer));
+	WorkspaceScope ws(stream_context, sizeof(float) * 2 * (size_t)v.C, sizeof(float) * (size_t)v.C * (size_t)(v.inner == 1 ? (long)device_cu_count() * 4 + 64 : 2 * v.outer));
 	float* nscale = (float*)ws.prefix();
 	if (!nscale) return CCV_NNC_EXEC_OOM;
 	float* nbias = nscale + v.C;
@@ -216,11 +327,21 @@ static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 		float* saved_inv_std = outputs[4]->data.f32;
 		if ((int)tensor_count(outputs[3]->info) != v.C || (int)tensor_count(outputs[4]->info) != v.C) return CCV_NNC_EXEC_INVALID;
 		const float inv_b = 1.f / (float)(n / v.C);
+		if (v.inner > 1) { // planes: one sweep from HBM for both statistics (see bn_plane_stats_kernel)
+			const long planes = v.outer * v.C;
+			float* const psum = (float*)workspace_of(stream_context, sizeof(float) * 2 * (size_t)planes);
+			if (!psum) return CCV_NNC_EXEC_OOM;
+			hipLaunchKernelGGL(bn_plane_stats_kernel, dim3(plane_grid(planes)), dim3(256), 0, stream, (const float*)x->data.f32, planes, v.inner, psum, psum + planes);
+			HIP_ENFORCE(hipGetLastError());
+			hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, stream, (const float*)psum, (const float*)(psum + planes), v.outer, v.C, (float)v.inner, saved_mean, saved_inv_std, mean, var, scale, bias, nscale, nbias, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon);
+			HIP_ENFORCE(hipGetLastError());
+		} else {
 		if ((ret = chan_reduce<RSum, false>(RSum(), x->data.f32, 0, v, saved_mean, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		hipLaunchKernelGGL(bn_mean_kernel, dim3(cb), dim3(256), 0, stream, saved_mean, mean, v.C, inv_b, cmd.info.bnorm.momentum);
 		RCenteredSq f; f.mean = saved_mean;
 		if ((ret = chan_reduce<RCenteredSq, false>(f, x->data.f32, 0, v, saved_inv_std, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		hipLaunchKernelGGL(bn_var_kernel, dim3(cb), dim3(256), 0, stream, saved_inv_std, var, (const float*)saved_mean, scale, bias, nscale, nbias, v.C, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon);
+		}
 	} else
 		hipLaunchKernelGGL(bn_test_affine_kernel, dim3(cb), dim3(256), 0, stream, (const float*)mean, (const float*)var, scale, bias, nscale, nbias, v.C, cmd.info.bnorm.epsilon);
 	HIP_ENFORCE(hipGetLastError());
@@ -251,15 +372,35 @@ static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
 	int ret;
 	ProfScope prof("bnorm_bwd|nnc::chan_reduce + bn_back_kernel", 0, 3.0 * sizeof(float) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream_of(stream_context)); // g, x read; h written
+	if (v.inner > 1) { // planes: both sums in one sweep over (x, g)
+		const long planes = v.outer * v.C;
+		float* const pg = (float*)workspace_of(stream_context, sizeof(float) * 2 * (size_t)planes);
+		if (!pg) return CCV_NNC_EXEC_OOM;
+		hipStream_t st = stream_of(stream_context);
+		hipLaunchKernelGGL(bn_plane_back_stats_kernel, dim3(plane_grid(planes)), dim3(256), 0, st, (const float*)x->data.f32, (const float*)g->data.f32, planes, v.C, v.inner, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, pg, pg + planes);
+		HIP_ENFORCE(hipGetLastError());
+		hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, st, (const float*)pg, v.outer, v.C, dbias->data.f32, 0);
+		hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, st, (const float*)(pg + planes), v.outer, v.C, dscale->data.f32, 0);
+		HIP_ENFORCE(hipGetLastError());
+	} else {
 	if ((ret = chan_reduce<RSum, false>(RSum(), g->data.f32, 0, v, dbias->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	RXhatG f; f.mean = saved_mean->data.f32; f.inv_std = saved_inv_std->data.f32;
 	if ((ret = chan_reduce<RXhatG, true>(f, x->data.f32, g->data.f32, v, dscale->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	}
 	hipLaunchKernelGGL(bn_back_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream_of(stream_context), (const float*)x->data.f32, (const float*)g->data.f32, h->data.f32, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, n, v.C, v.inner, (float)(n / v.C));
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
 } // namespace
+
+// out[c] (+)= sum over (o, i) of x[(o * C + c) * inner + i]: the bias gradient of a convolution on NCHW tensors (cmd_conv.cpp)
+int nnc::chan_sum_planes(const float* x, long outer, int C, long inner, float* out, int accumulate, ccv_nnc_stream_context_t* ctx)
+{
+	chan_view_t v;
+	v.outer = outer; v.C = C; v.inner = inner;
+	return chan_reduce<RSum, false>(RSum(), x, 0, v, out, ctx, accumulate);
+}
 
 #define NNC_REG(CMD, BACKEND, FORMATS, DATATYPES, MEMORY, EXEC) \
 	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \

@@ -141,6 +141,7 @@ int weights_nhwc_to_nchw(const float* w, float* out, int K, int C, int khw, ccv_
 // Shared device helpers (cmd_ew.cpp).
 int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int accumulate, ccv_nnc_stream_context_t* ctx); // out[c] (+)= sum_r x[r*ld + c]
 int fill_f32(float* p, size_t n, float v, ccv_nnc_stream_context_t* ctx);
+int chan_sum_planes(const float* x, long outer, int C, long inner, float* out, int accumulate, ccv_nnc_stream_context_t* ctx); // cmd_norm.cpp: out[c] (+)= sum_{o,i} x[(o * C + c) * inner + i]
 
 // Optional in-library kernel timing (bench.py roofline leg): when enabled, a ProfScope brackets ONE kernel launch with
 // HIP events on the stream the kernel is launched on and files (name, algorithmic flops/bytes, problem dims).
@@ -177,6 +178,7 @@ static int half_staged(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 bool any_half_tensor(ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size);
 int half_to_float(const void* in, float* out, size_t n, ccv_nnc_stream_context_t* ctx);
 int float_to_half(const float* in, void* out, size_t n, ccv_nnc_stream_context_t* ctx);
+int chan_sum_planes_f16(const void* x, long outer, int C, long inner, void* out, int accumulate, ccv_nnc_stream_context_t* ctx);
 int colsum_f16(const void* x, long rows, int cols, long ld, void* out, int accumulate, ccv_nnc_stream_context_t* ctx); // halves: out[c] (+)= sum_r x[r * ld + c], fp32 sums
 
 // Registration table (registry.cpp).

@@ -13,6 +13,7 @@ struct GemmOut {
 	float alpha;
 	int accumulate; // c += result (CCV_NNC_ACCUMULATE_OUTPUT)
 	long bias_ldm;  // row stride of bias (0 = a single row broadcast over the output rows)
+	long bias_ldn = 1; // column stride of bias (bias_ldm = 1, bias_ldn = 0: one value per output row)
 };
 
 // Split the reduction so that a contraction with few output tiles still fills 256 CUs (2 workgroups per CU fit by
@@ -90,7 +91,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
 	if (splits <= 1) {
 		EpiStore epi;
-		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm;
+		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
@@ -106,7 +107,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z);
+	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -137,6 +138,7 @@ struct GemmOutH {
 	float alpha;
 	int accumulate;
 	long bias_ldm;
+	long bias_ldn = 1;
 };
 
 template <class LA, class LB, int WM, int WN>
@@ -161,7 +163,7 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
 	if (splits <= 1) {
 		EpiStoreH epi;
-		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm;
+		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
@@ -177,7 +179,7 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiPartialH, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(splitk_reduce_half_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z);
+	hipLaunchKernelGGL(splitk_reduce_half_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

@@ -109,6 +109,32 @@ int colsum_f16(const void* xv, long rows, int cols, long ld, void* outv, int acc
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// out[c] (+)= sum over (o, i) of x[(o * C + c) * inner + i] for halves (bias gradient of an NCHW convolution): one workgroup per
+// plane, fp32 partials in the workspace, folded per channel in a fixed order.
+static __global__ void __launch_bounds__(256) plane_sum_h_kernel(const half_t* x, const int C, const long inner, float* partial)
+{
+	__shared__ float red[4];
+	const long base = ((long)blockIdx.y * C + blockIdx.x) * inner;
+	float s = 0.f;
+	for (long i = threadIdx.x; i < inner; i += 256) s += (float)x[base + i];
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) partial[(long)blockIdx.y * C + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+int chan_sum_planes_f16(const void* x, long outer, int C, long inner, void* out, int accumulate, ccv_nnc_stream_context_t* ctx)
+{
+	if (C <= 0 || outer <= 0) return CCV_NNC_EXEC_SUCCESS;
+	float* partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)outer * C);
+	if (!partial) return CCV_NNC_EXEC_OOM;
+	hipStream_t stream = stream_of(ctx);
+	hipLaunchKernelGGL(plane_sum_h_kernel, dim3(C, (unsigned)outer), dim3(256), 0, stream, (const half_t*)x, C, inner, partial);
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(colsum_h_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)partial, (int)outer, C, (half_t*)out, accumulate);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 bool any_half_tensor(ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size)
 {
 	for (int i = 0; i < input_size; i++)

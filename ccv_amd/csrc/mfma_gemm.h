@@ -150,6 +150,52 @@ struct MatLoader {
 	}
 };
 
+// Rows of P-element planes, the reduction index running over (image n, position p): element(r, k = n * P + p) = p[n * s_n + r * ldr + p].
+// Serves the filter gradient of a 1x1 convolution on NCHW tensors (both operands: channel rows of [N][C][P] tensors, reduced over
+// every position of every image) without re-laying the tensors out.  VEC needs P % 4 == 0 (a chunk stays inside one plane).
+template <bool VEC>
+struct PlaneKC {
+	static constexpr bool KCONTIG = true, VECTOR = VEC, INCR = false;
+	const float* p;
+	long zoff;
+	long ldr, s_n;
+	int R, K, P; // K = N * P
+	FastDiv d_p;
+	void finish() { d_p.init(P); }
+	struct Ctx { long off; int r; };
+	struct KCtx { long off; int k, klimit; };
+	__device__ __forceinline__ void advance(KCtx&, int) const {}
+	__device__ __forceinline__ Ctx make(int r) const { Ctx c; c.r = r; c.off = (long)r * ldr; return c; }
+	__device__ __forceinline__ KCtx kctx(int k, int klimit) const
+	{
+		KCtx x;
+		x.k = k; x.klimit = klimit;
+		const int kk = k < klimit ? k : 0;
+		const int n = d_p.div(kk);
+		x.off = (long)n * s_n + (kk - n * P);
+		return x;
+	}
+	__device__ __forceinline__ void pin(Ctx& c) const { NNC_PIN_V(c.r); }
+	__device__ __forceinline__ long offset(const Ctx& c, const KCtx& x) const
+	{
+		const bool ok = (c.r < R) & (x.k < x.klimit);
+		return ok ? c.off + x.off : zoff;
+	}
+	__device__ __forceinline__ float4 load(const Ctx& c, const KCtx& x) const
+	{
+		float v[4];
+#pragma unroll
+		for (int e = 0; e < 4; e++) { // the four k's may straddle a plane boundary when P % 4 != 0
+			const int k = x.k + e;
+			const bool ok = (c.r < R) & (k < x.klimit);
+			const int kk = ok ? k : 0;
+			const int n = d_p.div(kk);
+			v[e] = p[ok ? c.off + (long)n * s_n + (kk - n * P) : zoff];
+		}
+		return make_float4(v[0], v[1], v[2], v[3]);
+	}
+};
+
 // im2col gather with the reduction index running (tap_y, tap_x, channel), channel fastest: rows are output
 // pixels m = (n, oy, ox).  Serves conv forward (source = a) and conv dgrad (source = g, taps walked backwards).
 //   t_y = oy * my + oy_off + i * ty ;  source y = t_y / dv_y, valid iff t_y >= 0, t_y % dv_y == 0, y < H   (same for x)
@@ -411,17 +457,17 @@ struct Im2colNC {
 struct EpiStore {
 	float* c;
 	long ldm, ldn;
-	const float* bias; // bias[m * bias_ldm + n]; bias_ldm == 0: one row broadcast over m; may be null
+	const float* bias; // bias[m * bias_ldm + n * bias_ldn]; (0, 1): one row broadcast over m; (1, 0): one value per output ROW; may be null
 	float alpha;
 	int accumulate;
 	int M, N;
-	long bias_ldm;
+	long bias_ldm, bias_ldn;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) {
 			const long o = (long)m * ldm + (long)n * ldn;
 			v *= alpha;
-			if (bias) v += bias[(long)m * bias_ldm + n];
+			if (bias) v += bias[(long)m * bias_ldm + (long)n * bias_ldn];
 			if (accumulate) v += c[o];
 			c[o] = v;
 		}
@@ -757,7 +803,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 
 // Finish a split-K contraction: c = alpha * sum_s slab[s] (+ bias[n]) (+ old c). Fixed summation order => deterministic.
 // grid.y = batch entry z: its slab set starts at ws + z * splits * slab, its output at c + z * c_zoff.
-static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, const int splits, const long slab, float* c, const long ldm, const long ldn, const float* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff)
+static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, const int splits, const long slab, float* c, const long ldm, const long ldn, const float* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff, const long bias_ldn)
 {
 	ws += (long)blockIdx.y * splits * slab;
 	c += (long)blockIdx.y * c_zoff;
@@ -767,7 +813,7 @@ static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* 
 		float v = 0.f;
 		for (int s = 0; s < splits; s++) v += ws[(long)s * slab + idx];
 		v *= alpha;
-		if (bias) v += bias[(long)m * bias_ldm + n];
+		if (bias) v += bias[(long)m * bias_ldm + (long)n * bias_ldn];
 		const long o = (long)m * ldm + (long)n * ldn;
 		if (accumulate) v += c[o];
 		c[o] = v;

@@ -36,17 +36,17 @@ __device__ __forceinline__ floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b,
 struct EpiStoreH {
 	half_t* c;
 	long ldm, ldn;
-	const half_t* bias; // bias[m * bias_ldm + n]; may be null
+	const half_t* bias; // bias[m * bias_ldm + n * bias_ldn]; may be null
 	float alpha;
 	int accumulate;
 	int M, N;
-	long bias_ldm;
+	long bias_ldm, bias_ldn;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) {
 			const long o = (long)m * ldm + (long)n * ldn;
 			v *= alpha;
-			if (bias) v += (float)bias[(long)m * bias_ldm + n];
+			if (bias) v += (float)bias[(long)m * bias_ldm + (long)n * bias_ldn];
 			if (accumulate) v += (float)c[o];
 			c[o] = (half_t)v;
 		}
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 }
 
 // Finish a split-K contraction into a half-precision tensor (fixed summation order => deterministic).
-static __global__ void __launch_bounds__(256) splitk_reduce_half_kernel(const float* ws, const int splits, const long slab, half_t* c, const long ldm, const long ldn, const half_t* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff)
+static __global__ void __launch_bounds__(256) splitk_reduce_half_kernel(const float* ws, const int splits, const long slab, half_t* c, const long ldm, const long ldn, const half_t* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff, const long bias_ldn)
 {
 	ws += (long)blockIdx.y * splits * slab;
 	c += (long)blockIdx.y * c_zoff;
@@ -216,7 +216,7 @@ static __global__ void __launch_bounds__(256) splitk_reduce_half_kernel(const fl
 		float v = 0.f;
 		for (int s = 0; s < splits; s++) v += ws[(long)s * slab + idx];
 		v *= alpha;
-		if (bias) v += (float)bias[(long)m * bias_ldm + n];
+		if (bias) v += (float)bias[(long)m * bias_ldm + (long)n * bias_ldn];
 		const long o = (long)m * ldm + (long)n * ldn;
 		if (accumulate) v += (float)c[o];
 		c[o] = (half_t)v;

@@ -566,3 +566,49 @@ def test_batch_norm_with_one_dimensional_statistics(backend, ref_lib, fmt, shape
     want = run(ref_lib, nnc.CPU_MEMORY, s4, nnc.BACKEND_CPU_REF)
     for a, b, what in zip(got, want, ("y", "mean", "var", "saved_mean", "saved_inv_std", "h", "dscale", "dbias")):
         np.testing.assert_allclose(a.reshape(-1), b.reshape(-1), rtol=2e-4, atol=2e-5, err_msg=what)
+
+
+@pytest.mark.parametrize("case", [(3, 8, 6, 6, 12, True), (2, 16, 4, 8, 8, False), (2, 64, 14, 14, 128, True)], ids=["8to12", "16to8", "64to128"])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_conv_1x1_on_nchw_tensors_without_layout_passes(backend, ref_lib, case, dtype):
+    """ResNet's bottleneck convolutions as the reference's trainer issues them (NCHW, 1x1, stride 1: bin/nnc/imagenet.c): forward,
+    data gradient, filter gradient and bias gradient run as GEMMs over the NCHW tensors where they lie (conv1x1_nchw_*), no
+    transposes -- checked against the oracle (CPU_REF convolution forward on NCHW; its backward is NHWC-only, so the oracle's
+    backward runs on transposed copies) and by kernel name."""
+    n, c, h, w_, k, with_bias = case
+    rng = np.random.default_rng(21)
+    half = dtype == "f16"
+    T = np.float16 if half else F
+    a = srnd(rng, n, c, h, w_).astype(T)
+    wt = srnd(rng, k, c, 1, 1, scale=1.0 / np.sqrt(c)).astype(T)
+    bias = srnd(rng, k).astype(T)
+    g = srnd(rng, n, k, h, w_, scale=0.5).astype(T)
+    tol = dict(rtol=5e-3, atol=5e-3) if half else dict(rtol=1e-4, atol=1e-5)
+    names = []
+
+    def gpu(cmd, ins, outs):
+        backend.profile_enable(1)
+        r, res = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.HINT((1, 1), (0, 0)), 0, ins, outs, fmt="NCHW")
+        backend.stream_wait(None)
+        names.extend(x[0] for x in backend.profile_records())
+        backend.profile_enable(0)
+        assert r == 0
+        return res
+    b, = gpu(nnc.CMD_CONVOLUTION_FORWARD(1, k, 1, 1, c), [a, wt] + ([bias] if with_bias else []), [np.zeros((n, k, h, w_), T)])
+    hh, dw, db = gpu(nnc.CMD_CONVOLUTION_BACKWARD(1, k, 1, 1, c), [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, T)])
+    a32, w32, g32 = a.astype(F), wt.astype(F).reshape(k, c), g.astype(F)
+    want_b = np.einsum("kc,nchw->nkhw", w32, a32) + (bias.astype(F)[None, :, None, None] if with_bias else 0)
+    want_h = np.einsum("kc,nkhw->nchw", w32, g32)
+    want_dw = np.einsum("nkhw,nchw->kc", g32, a32).reshape(wt.shape)
+    want_db = g32.sum(axis=(0, 2, 3))
+    # the einsum is pinned against the reference's own forward on the same NCHW tensors
+    r, (ref_b,) = exec_on(ref_lib, nnc.CPU_MEMORY, nnc.CMD_CONVOLUTION_FORWARD(1, k, 1, 1, c), nnc.HINT((1, 1), (0, 0)), 0, [a32, wt.astype(F)] + ([bias.astype(F)] if with_bias else []), [np.zeros((n, k, h, w_), F)], fmt="NCHW", backend=nnc.BACKEND_CPU_REF)
+    assert r == 0
+    np.testing.assert_allclose(want_b, ref_b, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b.astype(F), want_b, **tol)
+    np.testing.assert_allclose(hh.astype(F), want_h, **tol)
+    np.testing.assert_allclose(dw.astype(F), want_dw, rtol=tol["rtol"], atol=tol["atol"] * max(1.0, float(np.abs(want_dw).max())))
+    np.testing.assert_allclose(db.astype(F), want_db, rtol=tol["rtol"], atol=tol["atol"] * max(1.0, float(np.abs(want_db).max())))
+    native = (h * w_) % 4 == 0 and c % 4 == 0 and k % 4 == 0
+    if native:
+        assert any(x.startswith("conv1x1_nchw_fwd") for x in names) and any(x.startswith("conv1x1_nchw_dgrad") for x in names) and any(x.startswith("conv1x1_nchw_wgrad") for x in names), names
