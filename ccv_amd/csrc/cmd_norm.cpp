@@ -39,19 +39,30 @@ __global__ void __launch_bounds__(256) chan_reduce_rows_kernel(F f, const float*
 	__syncthreads();
 	if (phase == 0 && c < C) partial[(long)blockIdx.y * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
-// inner > 1: planes of `inner` contiguous elements.  grid (C, outer): one block per plane, partial[o][c].
+// inner > 1: planes of `inner` contiguous elements, ONE WAVE PER PLANE (16-byte lanes when the plane allows), partial[o][c].
 template <class F, bool USE_G>
-__global__ void __launch_bounds__(256) chan_reduce_planes_kernel(F f, const float* x, const float* g, const int C, const long inner, float* partial)
+__global__ void __launch_bounds__(256) chan_reduce_planes_kernel(F f, const float* x, const float* g, const int C, const long inner, const long planes, float* partial)
 {
-	__shared__ float red[4];
-	const int c = blockIdx.x;
-	const long base = ((long)blockIdx.y * C + c) * inner;
-	float s = 0.f;
-	for (long i = threadIdx.x; i < inner; i += 256) s += f(x[base + i], USE_G ? g[base + i] : 0.f, c);
-	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-	__syncthreads();
-	if (threadIdx.x == 0) partial[(long)blockIdx.y * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+	const int lane = threadIdx.x & 63;
+	const long nw = (long)gridDim.x * 4;
+	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+		const int c = (int)(pl % C);
+		const float* const xp = x + pl * inner;
+		const float* const gp = USE_G ? g + pl * inner : x;
+		float s = 0.f;
+		if ((inner & 3) == 0 && ((((uintptr_t)xp) | ((uintptr_t)gp)) & 15) == 0) {
+			const long n4 = inner >> 2;
+			for (long i = lane; i < n4; i += 64) {
+				const float4 xv = ((const float4*)xp)[i];
+				float4 gv = xv;
+				if (USE_G) gv = ((const float4*)gp)[i];
+				s += f(xv.x, USE_G ? gv.x : 0.f, c); s += f(xv.y, USE_G ? gv.y : 0.f, c); s += f(xv.z, USE_G ? gv.z : 0.f, c); s += f(xv.w, USE_G ? gv.w : 0.f, c);
+			}
+		} else
+			for (long i = lane; i < inner; i += 64) s += f(xp[i], USE_G ? gp[i] : 0.f, c);
+		for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+		if (lane == 0) partial[pl] = s;
+	}
 }
 // out[c] (+)= sum_i partial[i][c], fixed order.  One workgroup per 64 channels: thread (phase = t >> 6, lane) adds the slices
 // phase, phase + 4, ...; the four phases fold through LDS.  (One thread per channel walking every slice -- the first version --
@@ -93,7 +104,8 @@ static int chan_reduce(F f, const float* x, const float* g, const chan_view_t& v
 		slices = v.outer;
 		partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * v.C);
 		if (!partial) return CCV_NNC_EXEC_OOM;
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_planes_kernel<F, USE_G>), dim3(v.C, (unsigned)v.outer), dim3(256), 0, stream, f, x, g, v.C, v.inner, partial);
+		const long planes = v.outer * v.C, want = (planes + 3) / 4, cap = (long)device_cu_count() * 8;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_planes_kernel<F, USE_G>), dim3((unsigned)(want < cap ? (want > 0 ? want : 1) : cap)), dim3(256), 0, stream, f, x, g, v.C, v.inner, planes, partial);
 	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, stream, (const float*)partial, slices, v.C, out, accumulate);
