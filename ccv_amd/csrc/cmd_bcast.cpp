@@ -472,6 +472,47 @@ static int argext(const ccv_nnc_cmd_t& cmd, ccv_nnc_tensor_t* const* const input
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
+// ---- MASKED_FILL (lib/nnc/cmd/util/ccv_nnc_util_cpu_ref.c:1280-1367 float mask, :1369- int32 mask; GPU file util/gpu/ccv_nnc_util_gpu_ref.cu)
+// c = (mask == p) ? q : a, a and mask broadcast against each other; backward: h = (mask == p) ? 0 : g (no gradient to the mask).
+struct FMaskFillF { float p, q; __device__ float operator()(float a, float b) const { return b == p ? q : a; } };
+struct FMaskFillI { int p; float q; __device__ float operator()(float a, float b) const { return __float_as_int(b) == p ? q : a; } }; // the mask's bits ARE an int32
+static int masked_fill(const float p, const float q, const ccv_nnc_tensor_t* a, const ccv_nnc_tensor_t* mask, ccv_nnc_tensor_t* c, ccv_nnc_stream_context_t* ctx)
+{
+	if (!a || !mask || !c || CCV_GET_DATA_TYPE(a->info.datatype) != CCV_32F || CCV_GET_DATA_TYPE(c->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
+	const int mdt = CCV_GET_DATA_TYPE(mask->info.datatype);
+	if (mdt == CCV_32S) { FMaskFillI f; f.p = (int)p; f.q = q; return bcast_map(f, a, mask, c, ctx); }
+	if (mdt != CCV_32F) return CCV_NNC_EXEC_INVALID;
+	FMaskFillF f; f.p = p; f.q = q;
+	return bcast_map(f, a, mask, c, ctx);
+}
+static int _masked_fill_forw(EXEC_ARGS)
+{
+	if (input_size < 2 || output_size < 1) return CCV_NNC_EXEC_INVALID;
+	return masked_fill(cmd.info.blas.a[0], cmd.info.blas.a[1], inputs[0], inputs[1], outputs[0], stream_context);
+}
+static int _masked_fill_back(EXEC_ARGS)
+{ // inputs (g, a, mask): util_gpu_ref.cu:211-218
+	if (input_size < 3 || output_size < 1) return CCV_NNC_EXEC_INVALID;
+	return masked_fill(cmd.info.blas.a[0], 0.f, inputs[0], inputs[2], outputs[0], stream_context);
+}
+
+// ---- REDUCE_ISNAN (lib/nnc/cmd/isnan/ccv_nnc_reduce_isnan_cpu_ref.c:16-80): int32 output, 1 where any element of the reduced
+// sub-space is NaN.  A max-reduction over the int32 flag carried in the float lanes (bit pattern 1 is a positive subnormal, 0 is
+// zero: ordered as the ints are; fp32 subnormals are not flushed on this target).
+struct FIsNan { __device__ float operator()(float x, float) const { return __int_as_float(x != x ? 1 : 0); } };
+static int _reduce_isnan_forw(EXEC_ARGS)
+{
+	if (input_size < 1 || output_size < 1 || !inputs[0] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	if (CCV_GET_DATA_TYPE(inputs[0]->info.datatype) != CCV_32F || CCV_GET_DATA_TYPE(outputs[0]->info.datatype) != CCV_32S) return CCV_NNC_EXEC_INVALID;
+	return bcast_reduce<FIsNan, RED_MAX>(FIsNan(), inputs[0], 0, outputs[0], stream_context);
+}
+
+// Backward rows the reference registers with an exec function that returns CCV_NNC_EXEC_INVALID (optimizers, argmax / argmin,
+// reduce-isnan and transposed convolution have no gradient command: lib/nnc/cmd/sgd/gpu/ccv_nnc_sgd_gpu_ref.cu:97-100,
+// adam/gpu/...:129-132, lamb, rmsprop, reduce/gpu/ccv_nnc_argmax_gpu_ref.cu:76-79, isnan/gpu/...:63-66,
+// convolution/gpu/ccv_nnc_conv_transpose_gpu_cudnn.cu:174-177): the same here, so that ccv_nnc_cmd_ok() answers as it does there.
+static int _no_gradient(EXEC_ARGS) { return CCV_NNC_EXEC_INVALID; }
+
 static int _argmax_forw(EXEC_ARGS) { return argext<true>(cmd, inputs, input_size, outputs, output_size, stream_context); }
 static int _argmin_forw(EXEC_ARGS) { return argext<false>(cmd, inputs, input_size, outputs, output_size, stream_context); }
 
@@ -511,3 +552,18 @@ NNC_REG(CCV_NNC_MAX_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_
 NNC_REG(CCV_NNC_MAX_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _max_back)
 NNC_REG(CCV_NNC_ARGMAX_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _argmax_forw)
 NNC_REG(CCV_NNC_ARGMIN_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _argmin_forw)
+NNC_REG(CCV_NNC_MASKED_FILL_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _masked_fill_forw)
+NNC_REG(CCV_NNC_MASKED_FILL_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _masked_fill_back)
+NNC_REG(CCV_NNC_REDUCE_ISNAN_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _reduce_isnan_forw)
+#define NNC_REG_NO_GRADIENT(CMD, BACKEND) \
+	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
+	{ registry->tensor_formats = ALL_FORMATS; registry->tensor_datatypes = CCV_32F | CCV_16F | CCV_32S; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = _no_gradient; }
+NNC_REG_NO_GRADIENT(CCV_NNC_REDUCE_ISNAN_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN)
+NNC_REG_NO_GRADIENT(CCV_NNC_SGD_BACKWARD, CCV_NNC_BACKEND_GPU_REF)
+NNC_REG_NO_GRADIENT(CCV_NNC_ADAM_BACKWARD, CCV_NNC_BACKEND_GPU_REF)
+NNC_REG_NO_GRADIENT(CCV_NNC_ADAMW_BACKWARD, CCV_NNC_BACKEND_GPU_REF)
+NNC_REG_NO_GRADIENT(CCV_NNC_LAMB_BACKWARD, CCV_NNC_BACKEND_GPU_REF)
+NNC_REG_NO_GRADIENT(CCV_NNC_RMSPROP_BACKWARD, CCV_NNC_BACKEND_GPU_REF)
+NNC_REG_NO_GRADIENT(CCV_NNC_ARGMAX_BACKWARD, CCV_NNC_BACKEND_GPU_REF)
+NNC_REG_NO_GRADIENT(CCV_NNC_ARGMIN_BACKWARD, CCV_NNC_BACKEND_GPU_REF)
+NNC_REG_NO_GRADIENT(CCV_NNC_CONVOLUTION_TRANSPOSE_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN)

@@ -729,6 +729,43 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// ---- CONVOLUTION_TRANSPOSE_FORWARD (lib/nnc/cmd/convolution/ccv_nnc_conv_transpose_cpu_ref.c:13-; replaces
+// convolution/gpu/ccv_nnc_conv_transpose_gpu_cudnn.cu:24-172): b = bias + sum over the kernel taps of a scattered through w, with
+// w [C_a][kh][kw][count / groups] -- exactly the DATA GRADIENT of the convolution whose output channels are a's channels and whose
+// input is b (stride / border of the hint relate b to a as a convolution's input to its output).  So: the dgrad path above with
+// (g := a, h := b), then the bias added per channel of b.
+static __global__ void __launch_bounds__(256) chan_bias_add_kernel(float* b, const float* bias, const size_t n, const int C, const long inner)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) b[i] += bias[(int)((inner == 1 ? i : i / inner) % C)];
+}
+static int _conv_transpose_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size < 2 || output_size < 1 || !inputs[0] || !inputs[1] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
+	ccv_nnc_tensor_t* a = inputs[0];
+	ccv_nnc_tensor_t* w = inputs[1];
+	ccv_nnc_tensor_t* bias = input_size > 2 ? inputs[2] : 0;
+	ccv_nnc_tensor_t* b = outputs[0];
+	Image4 ai, bi;
+	if (!image4(a, &ai) || !image4(b, &bi) || a->info.format != b->info.format || !tensor_contiguous(b)) return CCV_NNC_EXEC_INVALID;
+	if (bi.c != cmd.info.convolution.count) return CCV_NNC_EXEC_INVALID; // (count sits at the same offset in both parameter structs)
+	ccv_nnc_cmd_t conv = cmd;
+	conv.cmd = CCV_NNC_CONVOLUTION_BACKWARD;
+	conv.info.convolution.count = ai.c; // the convolution whose gradient this is has a's channels as its outputs
+	ccv_nnc_tensor_t* ins[3] = { a, 0, w };
+	ccv_nnc_tensor_t* outs[1] = { b };
+	const int ret = _conv_back(conv, hint, flags & ~CCV_NNC_ACCUMULATE_OUTPUT, ins, 3, outs, 1, stream_context);
+	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
+	if (bias) {
+		if (!tensor_contiguous(bias) || (int)tensor_count(bias->info) != bi.c) return CCV_NNC_EXEC_INVALID;
+		const size_t n = tensor_count(b->info);
+		const long inner = b->info.format == CCV_TENSOR_FORMAT_NCHW ? (long)bi.h * bi.w : 1;
+		hipLaunchKernelGGL(chan_bias_add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream_of(stream_context), b->data.f32, (const float*)bias->data.f32, n, bi.c, inner);
+		HIP_ENFORCE(hipGetLastError());
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 // ---- half precision: the three contractions as implicit GEMMs on the half-precision core (mfma_gemm_f16.h) ---------------------
 // CCV_16F activations (NHWC) and weights ([K][kh][kw][Cg]) with channel counts that are multiples of 4 (8-byte chunks); the same
 // loaders as the fp32 path -- they compute element offsets -- over half pointers.  Anything else in half precision (NCHW tensors,
@@ -854,6 +891,7 @@ static bool all_half(ccv_nnc_tensor_t* const* const inputs, const int input_size
 // half-precision core; any other command with a half tensor -> the fp32 paths on fp32 images.
 static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
+	MarkerScope marker(cmd.cmd);
 	if (!any_half_tensor(inputs, input_size, outputs, output_size)) return _conv_forw(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (all_half(inputs, input_size, outputs, output_size)) {
 		const int r = _conv_forw_half(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
@@ -863,6 +901,7 @@ static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 }
 static int _conv_back_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
+	MarkerScope marker(cmd.cmd);
 	if (!any_half_tensor(inputs, input_size, outputs, output_size)) return _conv_back(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (all_half(inputs, input_size, outputs, output_size)) {
 		const int r = _conv_back_half(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
@@ -928,4 +967,14 @@ extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_B
 	registry->algorithms = CONV_ALGO_COUNT; // one choice for both gradients
 	registry->exec = _conv_back_any;
 	registry->autotune = _conv_autotune;
+}
+
+extern "C" void _register_command_CCV_NNC_CONVOLUTION_TRANSPOSE_FORWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
+{
+	registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC;
+	registry->tensor_datatypes = CCV_32F;
+	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
+	registry->algorithms = 1;
+	registry->exec = _conv_transpose_forw;
+	NNC_HALF_STAGED(registry, _conv_transpose_forw);
 }

@@ -240,6 +240,7 @@ static int _gemm_back_f32(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 // (v_mfma_f32_32x32x16_f16); anything else with a half tensor (mixed types, odd strides) -> the fp32 core on fp32 images
 static int _gemm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
+	MarkerScope marker(cmd.cmd);
 	const int ut = uniform_float_type(inputs, input_size, outputs, output_size);
 	if (ut == 1) return _gemm_forw_f32(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (ut == 2 && gemm_forw_t<half_t>(cmd, flags, inputs, input_size, outputs, output_size, stream_context, true) == CCV_NNC_EXEC_SUCCESS)
@@ -249,6 +250,7 @@ static int _gemm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 }
 static int _gemm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
+	MarkerScope marker(cmd.cmd);
 	const int ut = uniform_float_type(inputs, input_size, outputs, output_size);
 	if (ut == 1) return _gemm_back_f32(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (ut == 2 && gemm_back_t<half_t>(cmd, flags, inputs, input_size, outputs, output_size, stream_context, true) == CCV_NNC_EXEC_SUCCESS)

@@ -152,6 +152,15 @@ struct ProfScope {
 	~ProfScope();
 };
 
+// Marker range around one command (device_rt.cpp; on after nnc_mi355x_set_profiler(1) / cusetprofiler(1) or NNC_MI355X_MARKERS=1).
+struct MarkerScope {
+	int active;
+	explicit MarkerScope(uint32_t cmd);
+	~MarkerScope();
+};
+void markers_enable(int on);
+const char* command_row_name(uint32_t cmd); // registry.cpp: "CMD/BACKEND" of the row that implements cmd
+
 // nnc_mi355x_debug_force_tile (device_rt.cpp): wm | wn << 8, 0 = built-in choice.
 extern int g_force_tile;
 

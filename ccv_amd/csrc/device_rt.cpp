@@ -3,6 +3,7 @@
 // here a stream context owns just a HIP stream and a grow-only workspace -- there are no vendor-library handles.
 #include "common.h"
 #include <pthread.h>
+#include <dlfcn.h>
 #include <vector>
 
 namespace {
@@ -177,6 +178,35 @@ int device_cu_count(void)
 
 void note_kernel(const char* name) { tl_last_kernel = name; }
 
+// ---- per-command marker ranges (roctx) ----
+static int (*g_roctx_push)(const char*) = 0;
+static int (*g_roctx_pop)(void) = 0;
+volatile int g_markers_on = -1; // -1 = environment not read yet
+void markers_enable(int on)
+{
+	if (on && !g_roctx_push) {
+		void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+		if (h) {
+			g_roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+			g_roctx_pop = (int (*)(void))dlsym(h, "roctxRangePop");
+		}
+	}
+	g_markers_on = (on && g_roctx_push && g_roctx_pop) ? 1 : 0;
+}
+static inline int markers_on(void)
+{
+	if (g_markers_on < 0) { const char* e = getenv("NNC_MI355X_MARKERS"); markers_enable(e && *e && *e != '0'); }
+	return g_markers_on;
+}
+MarkerScope::MarkerScope(const uint32_t cmd) : active(0)
+{
+	if (!markers_on()) return;
+	g_roctx_push(command_row_name(cmd));
+	active = 1;
+}
+MarkerScope::~MarkerScope() { if (active) g_roctx_pop(); }
+
 struct prof_rec_t { char name[192]; double flops, bytes; int dims[5]; hipEvent_t e0, e1; };
 static pthread_mutex_t g_prof_mutex = PTHREAD_MUTEX_INITIALIZER;
 static std::vector<prof_rec_t*> g_prof;
@@ -288,7 +318,12 @@ void nnc_mi355x_unregister_mem_pressure(const int id)
 	pthread_mutex_unlock(&g_mp_mutex);
 }
 
-void nnc_mi355x_set_profiler(int state) { (void)state; /* rocprofv3 attaches externally; nothing to toggle in-process */ }
+// cusetprofiler in the reference (lib/nnc/gpu/ccv_nnc_compat.cu: cudaProfilerStart / Stop): here it switches the per-command
+// marker ranges on.  Every command the backend executes is then bracketed by a roctx range named after its registry row
+// ("CCV_NNC_CONVOLUTION_FORWARD/CCV_NNC_BACKEND_GPU_CUDNN"), so a `rocprofv3 --marker-trace --kernel-trace` timeline attributes
+// kernels to graph nodes (tracing).  The roctx library is looked up at run time (librocprofiler-sdk-roctx,
+// then libroctx64); without it the switch does nothing.  NNC_MI355X_MARKERS=1 in the environment switches it on from the start.
+void nnc_mi355x_set_profiler(int state) { nnc::markers_enable(state); }
 
 int nnc_mi355x_device_count(void)
 {

@@ -188,6 +188,7 @@ void warn_refused(const uint32_t cmd, const int ret)
 
 int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
 {
+	MarkerScope marker(cmd.cmd); // every row registered through NNC_HALF_STAGED passes here: the per-command roctx range
 	if (!any_half_tensor(inputs, input_size, outputs, output_size)) {
 		const int r = inner(cmd, hint, flags, inputs, input_size, outputs, output_size, ctx);
 		warn_refused(cmd.cmd, r);

@@ -40,6 +40,15 @@ const row_t* find_row(uint32_t cmd, uint32_t backend, int memory, int formats, i
 }
 } // namespace
 
+namespace nnc {
+const char* command_row_name(const uint32_t cmd)
+{
+	for (int i = 0; i < g_row_count; i++)
+		if (g_rows[i].cmd == cmd) return g_rows[i].name;
+	return "CCV_NNC_(unregistered)";
+}
+}
+
 extern "C" {
 
 int nnc_mi355x_registry_count(void) { return g_row_count; }

@@ -121,6 +121,9 @@ enum {
 	CCV_NNC_REDUCE_MIN_FORWARD = 0x6785ef96, CCV_NNC_REDUCE_MIN_BACKWARD = 0x6785ef97,
 	CCV_NNC_REDUCE_NORM2_FORWARD = 0xb3034e16, CCV_NNC_REDUCE_NORM2_BACKWARD = 0xb3034e17,
 	CCV_NNC_RMSPROP_FORWARD = 0x9c886b1c, CCV_NNC_RMSPROP_BACKWARD = 0x9c886b1d,
+	CCV_NNC_MASKED_FILL_FORWARD = 0x7f992d84, CCV_NNC_MASKED_FILL_BACKWARD = 0x7f992d85,
+	CCV_NNC_REDUCE_ISNAN_FORWARD = 0xee0a4ade, CCV_NNC_REDUCE_ISNAN_BACKWARD = 0xee0a4adf,
+	CCV_NNC_CONVOLUTION_TRANSPOSE_FORWARD = 0xd691f78e, CCV_NNC_CONVOLUTION_TRANSPOSE_BACKWARD = 0xd691f78f,
 	CCV_NNC_SIGMOID_FORWARD = 0xf2f69650, CCV_NNC_SIGMOID_BACKWARD = 0xf2f69651,
 	CCV_NNC_SIGMOID_BINARY_CROSSENTROPY_FORWARD = 0xd9e0e4a, CCV_NNC_SIGMOID_BINARY_CROSSENTROPY_BACKWARD = 0xd9e0e4b,
 	CCV_NNC_SMOOTH_L1_FORWARD = 0x4e428e, CCV_NNC_SMOOTH_L1_BACKWARD = 0x4e428f,

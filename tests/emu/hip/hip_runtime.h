@@ -204,6 +204,8 @@ static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; ret
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }

@@ -201,3 +201,42 @@ def test_vgg_d_full_step_n2_vs_cpu_ref(gpu_lib, ref_lib):
         if not np.allclose(pg, pe, rtol=1e-5, atol=1e-7):
             bad.append("updated parameter %d %s: max |diff| %.3g" % (i, p.dims, float(np.abs(pg - pe).max())))
     assert not bad, "\n".join(bad)
+
+
+WINOGRAD_UNIT_CASES = [
+    # the reference's own Winograd-vs-direct unit tests, test/unit/nnc/winograd.tests.c:14-134: (name, h = w, C, K, bias)
+    ("56x56 non-uniform weights", 56, 128, 128, True),
+    ("55x55 non-uniform weights", 55, 128, 128, True),
+    ("224x224 RGB", 224, 3, 128, True),
+    ("56x56 no bias", 56, 128, 128, False),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WINOGRAD_UNIT_CASES, ids=[c[0] for c in WINOGRAD_UNIT_CASES])
+def test_reference_winograd_unit_shapes_on_the_hip_path(gpu_lib, ref_lib, case):
+    """the reference pins its CPU Winograd (CPU_OPT, algorithm 2) to its direct loops (CPU_REF) under
+    REQUIRE_TENSOR_EQ on these shapes -- 3-d H x W x C tensors, border 1, weights u / (9 C), bias i / K (winograd.tests.c:14-134).
+    Replayed here with the HIP path in the middle: every algorithm of this backend (implicit GEMM, Winograd via HBM, fused
+    Winograd, its own choice) against CPU_REF at the north star's 1e-4 relative and the reference conv tests' absolute 1e-4,
+    and CPU_OPT's Winograd against CPU_REF as the reference's own test has it (tensor_eq = REQUIRE_TENSOR_EQ semantics)."""
+    from harness import tensor_eq
+    name, h, c, k, with_bias = case
+    rng = np.random.default_rng(300 + h + c)
+    a = rng.random((h, h, c), dtype=F)
+    w = (rng.random((k, 3, 3, c), dtype=F) / F(9 * c)).astype(F)
+    bias = (np.arange(k, dtype=F) / F(k)).astype(F) if with_bias else np.zeros(k, F)
+    hint = nnc.HINT((1, 1), (1, 1))
+    fwd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
+    r, (want,) = exec_on(ref_lib, nnc.CPU_MEMORY, fwd, hint, 0, [a, w, bias], [np.zeros((h, h, k), F)], backend=nnc.BACKEND_CPU_REF)
+    assert r == 0
+    opt = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
+    opt.algorithm = 2  # CCV_NNC_CMD_OPT_CONV_ALGO_WINOGRAD
+    r, (cpu_wino,) = exec_on(ref_lib, nnc.CPU_MEMORY, opt, hint, 0, [a, w, bias], [np.zeros((h, h, k), F)], backend=nnc.BACKEND_CPU_OPT)
+    assert r == 0 and tensor_eq(cpu_wino, want), "the reference's own CPU Winograd vs its direct loops"
+    for algo in _algos(gpu_lib, True):
+        fwd.algorithm = algo
+        r, (got,) = exec_on(gpu_lib, nnc.GPU_MEMORY, fwd, hint, 0, [a, w, bias], [np.full((h, h, k), 7, F)])
+        assert r == 0, (name, algo, r)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=0, err_msg="%s algorithm %d" % (name, algo))
+        assert float(np.abs(got - want).max()) <= 1e-4
