@@ -11,8 +11,13 @@
 //   * area 8u -> 8u is integer-only on the device and BIT-EXACT (uint32 sums are order-independent);
 //   * float area / bicubic replay the reference's accumulation order per element (horizontal taps first, then rows);
 //   * the direct 8-bit filter is integer-only and bit-exact (replicated border, 2^14 fixed-point coefficients).
-// The float filter path of the reference goes through a tiled FFT whose border values are artefacts of its tiling; here it is
-// the same correlation computed directly with a replicated border -- identical in the interior (tests compare the interior).
+// The float filter path of the reference goes through a tiled FFT (_ccv_filter_kissfft, ccv_numeric.c:771-): the kernel is
+// flipped into the tile, the tile is zero-filled around the image data and the output is read back at an offset of size / 2,
+// which makes the result   d[y][x] = sum_{i,j} a[y + i - (kh - 1) / 2][x + j - (kw - 1) / 2] * b[i][j],   a = 0 outside the image
+// (centre tap (size - 1) / 2 for even AND odd windows: test/unit/numeric.tests.c:112-150) -- wherever the tile is large enough
+// for the circular convolution to be linear (image + kernel - 1 <= the tile: small images, and the interior of large ones; at
+// the borders of an image larger than one tile the reference's rows wrap around within the tile, an artefact of the tiling).
+// Here the same sum is computed directly, with the zero border everywhere.
 #include "common.h"
 #include <math.h>
 #include <vector>
@@ -155,7 +160,7 @@ __global__ void __launch_bounds__(256) filter_8u_kernel(const unsigned char* a, 
 		d[img * d_image + (long)y * d_step + x] = (unsigned char)(z < 0 ? 0 : z > 255 ? 255 : z);
 	}
 }
-// float correlation, replicated border, any channel count (the kernel b has the image's channel count or 1)
+// float correlation, zero border, centre tap (size - 1) / 2, any channel count (the kernel b has the image's channel count or 1)
 __global__ void __launch_bounds__(256) filter_f32_kernel(const float* a, float* d, const long a_step, const long a_image, const long d_step, const long d_image,
 	const int rows, const int cols, const int ch, const float* coeff, const int kh, const int kw, const int kch, const size_t total)
 {
@@ -169,12 +174,12 @@ __global__ void __launch_bounds__(256) filter_f32_kernel(const float* a, float* 
 		const float* ai = (const float*)((const char*)a + img * a_image);
 		float z = 0.f;
 		for (int i = 0; i < kh; i++) {
-			int sy = y + i - kh / 2;
-			sy = sy < 0 ? 0 : sy > rows - 1 ? rows - 1 : sy;
+			const int sy = y + i - (kh - 1) / 2;
+			if (sy < 0 || sy > rows - 1) continue;
 			const float* row = (const float*)((const char*)ai + (long)sy * a_step);
 			for (int j = 0; j < kw; j++) {
-				int sx = x + j - kw / 2;
-				sx = sx < 0 ? 0 : sx > cols - 1 ? cols - 1 : sx;
+				const int sx = x + j - (kw - 1) / 2;
+				if (sx < 0 || sx > cols - 1) continue;
 				z += row[sx * ch + c] * coeff[(i * kw + j) * kch + (kch > 1 ? c : 0)];
 			}
 		}

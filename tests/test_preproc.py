@@ -1,8 +1,9 @@
 """ccv_resample / ccv_filter batch kernels against
   * the reference's OWN implementation (oracle/_ref/libccv_classic.so, built from where the sources lie), and
   * the independent numpy restatement oracle/preproc_oracle.py (which is itself pinned against the reference here).
-8u area resample and the direct 8u filter are bit-exact; float paths within 1e-5; integer bicubic within 1 LSB (its
-coefficient rounding goes through float expressions the reference compiles with -ffast-math)."""
+8u area resample, the integer (8u -> 8u) bicubic and the direct 8u filter are bit-exact; float paths within 1e-5 (float -> 8u stores
+within one level: the truncating store of a float sum whose last bit depends on FMA contraction); the float filter equals the
+reference's FFT path wherever that is a linear convolution (whole image for one-tile images, interior otherwise)."""
 import ctypes as C
 import os
 import sys
@@ -157,7 +158,9 @@ def test_resample_cubic(backend, classic, shape, out, src, dst):
     rs, cs = _scales(shape, out)
     got = our_resample(backend, [a], out, dst, rs, cs, CUBIC)[0]
     want = ref_resample(classic, a, dst, rs, cs, CUBIC)
-    if dst == np.uint8:
+    if dst == np.uint8 and src == np.uint8:
+        np.testing.assert_array_equal(got, want)  # the integer-only bicubic (6-bit coefficients, ccv_resample.c:343-431): byte work, bit-exact
+    elif dst == np.uint8:
         assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
     else:
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-3)
@@ -208,6 +211,31 @@ def test_filter_f32_interior(backend, classic, shape, ksize):
     a = rng.random(shape + (1,), dtype=np.float32)
     k = rng.random(ksize, dtype=np.float32)
     got = our_filter(backend, [a], k)[0]
-    want = ref_filter(classic, a, k)  # tiled-FFT path: only the interior is well defined
+    want = ref_filter(classic, a, k)  # tiled-FFT path: at the borders of an image larger than one tile its rows wrap around
     kh, kw = ksize
     np.testing.assert_allclose(got[kh:-kh, kw:-kw], want[kh:-kh, kw:-kw], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape,ksize", [((12, 14), (7, 7)), ((10, 10), (10, 10)), ((11, 11), (11, 11)), ((9, 13), (6, 7)), ((16, 12), (9, 8))])
+def test_filter_f32_whole_image_where_the_reference_fft_is_linear(backend, classic, shape, ksize):
+    """Images that fit ONE tile of the reference's FFT path with room for the kernel (image + kernel - 1 <= tile:
+    ccv_numeric.c:775-776): the circular convolution is then the linear one and EVERY output element is defined -- zero border,
+    centre tap (size - 1) / 2 for even and odd windows.  The whole image is compared, borders included."""
+    rng = np.random.default_rng(10)
+    a = rng.random(shape + (1,), dtype=np.float32)
+    k = rng.random(ksize, dtype=np.float32)
+    got = our_filter(backend, [a], k)[0]
+    want = ref_filter(classic, a, k)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("n", [10, 11])
+def test_filter_centre_point_of_the_reference_unit_tests(backend, n):
+    """test/unit/numeric.tests.c:112-150 replayed: x = 0 .. n^2 - 1, y = x reversed, ccv_filter(x, y)[centre] = sum_i (n^2 - 1 - i) * i
+    at the centre (n - 1) / 2 -- for the even window too ("hint: (size - 1) / 2"), tolerance 0.1 as there."""
+    x = np.arange(n * n, dtype=np.float32).reshape(n, n, 1)
+    y = x[::-1, ::-1, 0].copy()
+    d = our_filter(backend, [x], y)[0]
+    want = float(sum((n * n - 1 - i) * i for i in range(n * n)))
+    c = (n - 1) // 2
+    assert abs(float(d[c, c, 0]) - want) <= 0.1 * max(1.0, want * 1e-6), (d[c, c, 0], want)
