@@ -232,8 +232,40 @@ def main():
     # (read back between warm-up steps, outside the timed region; with --warmup 0 there is no untimed step and no check).
     step1_loss = None
     step1_losses = step1_params = None
+    dp_check = None
+
+    def checked_first_step():
+        """N > 1, warm-up step 1, NOT overlapped: the exchange's sum identity on real gradients -- the all-reduced gradient of two
+        probe tensors (the last layer's bias, the first layer's filters) must equal the sum of the ranks' local gradients
+        (gathered over gloo), and after the update every rank must hold the same parameters (sum / sum of squares per tensor)."""
+        net.forward(stream)
+        net.backward(stream)
+        L.stream_wait(stream)
+        probes = [net.params[-1][1], net.params[0][1]]
+        local = [t.numpy().astype(np.float64) for t in probes]
+        comm.allreduce_grads(net, stream)
+        L.stream_wait(stream)
+        reduced = [t.numpy().astype(np.float64) for t in probes]
+        net.update(stream)
+        L.stream_wait(stream)
+        sums = [(float(p.numpy().astype(np.float64).sum()), float((p.numpy().astype(np.float64) ** 2).sum())) for p, _, _ in net.params]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (local, sums))
+        try:
+            err = 0.0
+            for k in range(len(probes)):
+                want = sum(g[0][k] for g in gathered)
+                err = max(err, float(np.abs(reduced[k] - want).max() / max(np.abs(want).max(), 1e-30)))
+            rep = max(abs(g[1][j][1] - gathered[0][1][j][1]) / max(gathered[0][1][j][1], 1e-30) for g in gathered for j in range(len(sums)))
+            return {"allreduce_vs_sum_of_local_gradients_max_rel_err": err, "replica_param_sumsq_max_rel_diff": rep, "ok": bool(err <= 1e-5 and rep <= 1e-6)}
+        except Exception as e:  # the check must never take the benchmark down
+            return {"ok": False, "error": str(e)}
+
     for i in range(args.warmup):
-        step()
+        if i == 0 and comm and not fwd_only:
+            dp_check = checked_first_step()
+        else:
+            step()
         if i == 0:
             L.stream_wait(stream)
             step1_losses = net.loss.numpy()[:8].astype(np.float64)
@@ -303,6 +335,10 @@ def main():
                                "traffic": traffic, "kernel": name, "launches": cnt, "avg_ms": ms / cnt,
                                "all_contractions": {"achieved": total_fl / (total_ms * 1e-3) / 1e12, "ms": total_ms,
                                                     "by_kernel": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
+        if dp_check is not None:
+            out["config"]["data_parallel_check"] = dp_check
+            if not dp_check.get("ok"):
+                print("bench.py: the data-parallel exchange FAILED its sum identity / replica equality check: %r" % (dp_check,), file=sys.stderr)
         if step1_params is not None:
             out["config"]["via_host"] = via_host(args, step1_losses, step1_params)
         if not args.no_cpu_baseline:
