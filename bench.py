@@ -185,7 +185,11 @@ def main():
     L.set_device(local_rank)
     dist = None
     comm = None
-    if world > 1:
+    force_comm = world == 1 and os.environ.get("NNC_BENCH_FORCE_COMM") == "1"  # exercise the N > 1 code path (RCCL communicator of ONE) on a 1-GPU box
+    if force_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+    if world > 1 or force_comm:
         # one node: RCCL's bootstrap sockets go over loopback, no InfiniBand probing (the boxes have no external network)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
@@ -196,7 +200,7 @@ def main():
 
     # parameters, images and labels from the counter hash tools/host_vgg_bench.c uses too: the command driver (this process),
     # the driver through the reference host (--via-host) and the CPU oracle all run on identical numbers
-    net = VGGD(L, args.batch, device=local_rank, init="hash", flat_grads=(world > 1),
+    net = VGGD(L, args.batch, device=local_rank, init="hash", flat_grads=(world > 1 or force_comm),
                sgd=(0, 0.001, 1.0 / (args.batch * world), 0.0005, 0.9, 0.9))
     imgs = hash_unit(args.batch * 225 * 225 * 3, 1000 + 2 * rank).reshape(args.batch, 225, 225, 3)
     labels = (hash_unit(args.batch, 1001 + 2 * rank) * np.float32(1000)).astype(np.int32)

@@ -315,6 +315,62 @@ static char* upload(upload_t& u, ccv_nnc_stream_context_t* ctx)
 	return dev;
 }
 
+// ------------------------------------------------------------------------------------------------ random-jitter batch
+// The pixel half of _ccv_cnnp_random_jitter (lib/nnc/ccv_cnnp_dataframe_addons.c:265-366) for a whole batch in ONE kernel: per
+// image the host has decided (the reference's own integer arithmetic on its generator's draws, :276-330) the source slice, the
+// size it is resampled to, the mirror flag and the crop window; the device resamples (area when shrinking, bicubic otherwise:
+// :335-344, as separable weighted taps built per image by the tables above), mirrors (ccv_flip, :347-348), normalises
+// ((v - mean) * inv_std, :351-354: BEFORE the late crop, so the window's overhang stays 0 as ccv_slice leaves it, :357-361)
+// and writes straight into the batch tensor the trainer feeds (NHWC or NCHW, CCV_32F or CCV_16F: dataframe combine + the
+// trainer's datatype conversion, bin/nnc/imagenet.c:390-397) -- no per-image intermediate ever exists.
+struct jitter_dev_t {
+	long src;                 // byte offset of the slice's first pixel in the source buffer
+	int step;                 // source row pitch, bytes
+	int xs, xt, ys, yt;       // offsets (elements) of this image's tap-start / tap arrays in the packed tables
+	int res_rows, res_cols;   // size after resampling
+	int crop_x, crop_y, flip; // window origin in the resampled image, mirror in x
+};
+template <typename TO>
+__global__ void __launch_bounds__(256) jitter_kernel(const unsigned char* src, const jitter_dev_t* imgs, const int* starts, const tap_f32_t* taps, TO* out,
+	const int out_rows, const int out_cols, const int ch, const int nchw, const float m0, const float m1, const float m2, const float s0, const float s1, const float s2, const size_t total)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+		// idx walks the OUTPUT tensor in its own memory order (coalesced stores)
+		size_t r = idx;
+		int c, ox, oy;
+		if (nchw) { ox = (int)(r % out_cols); r /= out_cols; oy = (int)(r % out_rows); r /= out_rows; c = (int)(r % ch); r /= ch; }
+		else { c = (int)(r % ch); r /= ch; ox = (int)(r % out_cols); r /= out_cols; oy = (int)(r % out_rows); r /= out_rows; }
+		const jitter_dev_t im = imgs[r];
+		const int ry = oy + im.crop_y;
+		int rx = ox + im.crop_x;
+		float v = 0.f;
+		if (ry >= 0 && ry < im.res_rows && rx >= 0 && rx < im.res_cols) {
+			if (im.flip) rx = im.res_cols - 1 - rx;
+			const int* xs = starts + im.xs;
+			const int* ys = starts + im.ys;
+			const tap_f32_t* xt = taps + im.xt;
+			const tap_f32_t* yt = taps + im.yt;
+			const unsigned char* base = src + im.src;
+			float acc = 0.f;
+			for (int ky = ys[ry]; ky < ys[ry + 1]; ky++) {
+				const unsigned char* row = base + (long)yt[ky].si * im.step + c;
+				float h = 0.f;
+				for (int kx = xs[rx]; kx < xs[rx + 1]; kx++) h += (float)row[xt[kx].si] * xt[kx].w;
+				acc += h * yt[ky].w;
+			}
+			v = (acc - (c == 0 ? m0 : c == 1 ? m1 : m2)) * (c == 0 ? s0 : c == 1 ? s1 : s2);
+		}
+		out[idx] = (TO)v;
+	}
+}
+template <typename TO>
+__global__ void __launch_bounds__(256) one_hot_kernel(const int* labels, TO* out, const int range, const float onval, const float offval, const size_t total)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) out[idx] = (TO)((int)(idx % range) == labels[idx / range] ? onval : offval);
+}
+
 } // namespace
 
 extern "C" {
@@ -391,6 +447,96 @@ int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, 
 		}
 	} else
 		return CCV_NNC_EXEC_INVALID; // the reference asserts: LINEAR / LANCZOS are not implemented there either (:470-476)
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+int nnc_mi355x_jitter_batch(const void* src, const nnc_mi355x_jitter_image_t* images, const int count, const nnc_mi355x_jitter_params_t params, void* out, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (!src || !images || !out || count < 0 || params.out_rows < 1 || params.out_cols < 1 || params.channels < 1 || params.channels > 3) return CCV_NNC_EXEC_INVALID;
+	const int odt = CCV_GET_DATA_TYPE(params.datatype);
+	if ((odt != CCV_32F && odt != CCV_16F) || (params.format != CCV_TENSOR_FORMAT_NHWC && params.format != CCV_TENSOR_FORMAT_NCHW)) return CCV_NNC_EXEC_INVALID;
+	if (count == 0) return CCV_NNC_EXEC_SUCCESS;
+	const int ch = params.channels;
+	std::vector<jitter_dev_t> descs(count);
+	std::vector<int> starts;
+	std::vector<tap_f32_t> taps;
+	for (int i = 0; i < count; i++) {
+		const nnc_mi355x_jitter_image_t& im = images[i];
+		if (im.slice_rows < 1 || im.slice_cols < 1 || im.resize_rows < 1 || im.resize_cols < 1 || im.slice_x < 0 || im.slice_y < 0 || im.slice_x + im.slice_cols > im.cols || im.slice_y + im.slice_rows > im.rows) return CCV_NNC_EXEC_INVALID;
+		jitter_dev_t& d = descs[i];
+		d.src = (long)im.offset + (long)im.slice_y * im.step + (long)im.slice_x * ch;
+		d.step = im.step; d.res_rows = im.resize_rows; d.res_cols = im.resize_cols; d.crop_x = im.crop_x; d.crop_y = im.crop_y; d.flip = im.flip ? 1 : 0;
+		std::vector<int> xs, ys;
+		std::vector<tap_f32_t> xt, yt;
+		const double scale_x = (double)im.slice_cols / im.resize_cols, scale_y = (double)im.slice_rows / im.resize_rows;
+		if (im.slice_rows >= im.resize_rows && im.slice_cols >= im.resize_cols && (im.slice_rows != im.resize_rows || im.slice_cols != im.resize_cols)) { // CCV_INTER_AREA (:335-338)
+			const double scale = 1.f / (scale_x * scale_y);
+			area_x_taps<tap_f32_t, float>(im.slice_cols, im.resize_cols, ch, scale_x, (float)scale, scale, xs, xt);
+			area_y_taps_f32(im.slice_rows, im.resize_rows, scale_y, ys, yt);
+		} else if (im.slice_rows != im.resize_rows || im.slice_cols != im.resize_cols) { // CCV_INTER_CUBIC (:339-340): four taps per output
+			xs.resize(im.resize_cols + 1); ys.resize(im.resize_rows + 1);
+			for (int j = 0; j < im.resize_cols; j++) {
+				const double sx = (j + 0.5) * scale_x - 0.5;
+				cubic_f_t c; cubic_f((int)sx, im.slice_cols, (float)sx, &c);
+				xs[j] = (int)xt.size();
+				for (int k = 0; k < 4; k++) { tap_f32_t t; t.si = c.si[k] * ch; t.w = c.w[k]; xt.push_back(t); }
+			}
+			xs[im.resize_cols] = (int)xt.size();
+			for (int j = 0; j < im.resize_rows; j++) {
+				const double sy = (j + 0.5) * scale_y - 0.5;
+				cubic_f_t c; cubic_f((int)sy, im.slice_rows, (float)sy, &c);
+				ys[j] = (int)yt.size();
+				for (int k = 0; k < 4; k++) { tap_f32_t t; t.si = c.si[k]; t.w = c.w[k]; yt.push_back(t); }
+			}
+			ys[im.resize_rows] = (int)yt.size();
+		} else { // same size: ccv_shift to 32F (:342): one tap of weight 1
+			xs.resize(im.resize_cols + 1); ys.resize(im.resize_rows + 1);
+			for (int j = 0; j <= im.resize_cols; j++) xs[j] = j;
+			for (int j = 0; j <= im.resize_rows; j++) ys[j] = j;
+			for (int j = 0; j < im.resize_cols; j++) { tap_f32_t t; t.si = j * ch; t.w = 1.f; xt.push_back(t); }
+			for (int j = 0; j < im.resize_rows; j++) { tap_f32_t t; t.si = j; t.w = 1.f; yt.push_back(t); }
+		}
+		// pack: starts are made absolute into the shared tap array
+		d.xs = (int)starts.size();
+		for (size_t j = 0; j < xs.size(); j++) starts.push_back(xs[j] + (int)taps.size());
+		d.xt = 0;
+		taps.insert(taps.end(), xt.begin(), xt.end());
+		d.ys = (int)starts.size();
+		for (size_t j = 0; j < ys.size(); j++) starts.push_back(ys[j] + (int)taps.size());
+		d.yt = 0;
+		taps.insert(taps.end(), yt.begin(), yt.end());
+	}
+	upload_t u;
+	const size_t od = u.add(descs.data(), descs.size() * sizeof(jitter_dev_t)), os = u.add(starts.data(), starts.size() * sizeof(int)), ot = u.add(taps.data(), taps.size() * sizeof(tap_f32_t));
+	char* dev = upload(u, stream_context);
+	if (!dev) return CCV_NNC_EXEC_OOM;
+	const size_t total = (size_t)count * params.out_rows * params.out_cols * ch;
+	hipStream_t stream = stream_of(stream_context);
+	const int nchw = params.format == CCV_TENSOR_FORMAT_NCHW;
+#define JITTER(TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(jitter_kernel<TO>), dim3(grid_for(total, 256)), dim3(256), 0, stream, (const unsigned char*)src, (const jitter_dev_t*)(dev + od), (const int*)(dev + os), (const tap_f32_t*)(dev + ot), (TO*)out, \
+		params.out_rows, params.out_cols, ch, nchw, params.mean[0], params.mean[1], params.mean[2], params.inv_std[0], params.inv_std[1], params.inv_std[2], total)
+	if (odt == CCV_32F) JITTER(float); else JITTER(_Float16);
+#undef JITTER
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+int nnc_mi355x_one_hot_batch(const int* labels_host, const int count, const int range, const float onval, const float offval, const int datatype, void* out, ccv_nnc_stream_context_t* const stream_context)
+{ // _ccv_cnnp_one_hot (lib/nnc/ccv_cnnp_dataframe_addons.c:378-): one row of `range` values per label, onval at the label, offval elsewhere
+	if (!labels_host || !out || count < 0 || range < 1) return CCV_NNC_EXEC_INVALID;
+	const int odt = CCV_GET_DATA_TYPE(datatype);
+	if (odt != CCV_32F && odt != CCV_16F) return CCV_NNC_EXEC_INVALID;
+	if (count == 0) return CCV_NNC_EXEC_SUCCESS;
+	for (int i = 0; i < count; i++) if (labels_host[i] < 0 || labels_host[i] >= range) return CCV_NNC_EXEC_INVALID;
+	upload_t u;
+	const size_t ol = u.add(labels_host, sizeof(int) * (size_t)count);
+	char* dev = upload(u, stream_context);
+	if (!dev) return CCV_NNC_EXEC_OOM;
+	const size_t total = (size_t)count * range;
+	hipStream_t stream = stream_of(stream_context);
+	if (odt == CCV_32F) hipLaunchKernelGGL(HIP_KERNEL_NAME(one_hot_kernel<float>), dim3(grid_for(total, 256)), dim3(256), 0, stream, (const int*)(dev + ol), (float*)out, range, onval, offval, total);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(one_hot_kernel<_Float16>), dim3(grid_for(total, 256)), dim3(256), 0, stream, (const int*)(dev + ol), (_Float16*)out, range, onval, offval, total);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

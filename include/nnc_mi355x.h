@@ -353,9 +353,34 @@ typedef struct {
  * bit-exact with the reference; the float paths replay its accumulation order.  Returns CCV_NNC_EXEC_*. */
 int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t a_desc, void* b, const nnc_mi355x_image_batch_t b_desc, const int count, const double rows_scale, const double cols_scale, const int type, ccv_nnc_stream_context_t* const stream_context);
 /* ccv_filter (lib/ccv.h, lib/ccv_numeric.c:1036-1061) over a batch: correlation of every image with a small HOST-side 32F
- * kernel (kernel_rows x kernel_cols x kernel_channels, channels = 1 or the image's), same-size output, replicated border.
- * 8u -> 8u follows the reference's direct fixed-point path bit for bit (ccv_numeric.c:960-1034). */
+ * kernel (kernel_rows x kernel_cols x kernel_channels, channels = 1 or the image's), same-size output.  8u -> 8u follows the
+ * reference's direct fixed-point path bit for bit (replicated border, ccv_numeric.c:960-1034); the float path is the linear
+ * correlation the reference's FFT path computes: zero border, centre tap (size - 1) / 2 (ccv_numeric.c:771-). */
 int nnc_mi355x_filter_batch(const void* a, const nnc_mi355x_image_batch_t a_desc, const void* kernel_host, const int kernel_rows, const int kernel_cols, const int kernel_channels, void* d, const nnc_mi355x_image_batch_t d_desc, const int count, ccv_nnc_stream_context_t* const stream_context);
+
+/* The pixel half of the data pipeline's random jitter (lib/nnc/ccv_cnnp_dataframe_addons.c:265-366, _ccv_cnnp_random_jitter) for a whole
+ * batch: the HOST keeps the decisions -- per image, from the reference's own generator and integer arithmetic (:276-330): the source
+ * slice, the size it is resampled to, the mirror flag, the crop window -- and hands them over; the DEVICE resamples (area when
+ * shrinking, bicubic otherwise, :335-344), mirrors (:347), normalises (:351-354; before the late crop, whose overhang stays 0) and
+ * writes the batch tensor the trainer consumes (NHWC / NCHW, CCV_32F / CCV_16F) in one kernel.  Source images: 8u, interleaved
+ * channels (what ccv_read produces), anywhere in ONE device buffer (e.g. a pinned staging ring copied with one H2D per batch).
+ * Not in this slice: contrast / saturation / lighting (_ccv_cnnp_image_manip, :165-253). */
+typedef struct {
+	size_t offset;                 /* byte offset of the image in the source buffer */
+	int rows, cols, step;          /* extent, row pitch in bytes */
+	int slice_x, slice_y, slice_rows, slice_cols; /* the region that is resampled (the whole image, or the crop-first slice :316-326) */
+	int resize_rows, resize_cols;  /* the size the slice is resampled to */
+	int crop_x, crop_y;            /* origin of the output window in the resampled image (0, 0 when cropped first); may overhang: zeros */
+	int flip;                      /* mirror in x */
+} nnc_mi355x_jitter_image_t;
+typedef struct {
+	int out_rows, out_cols, channels; /* random_jitter.size, 3 */
+	float mean[3], inv_std[3];        /* (v - mean) * inv_std; the reference stores 1 / std (:388-389) */
+	int format, datatype;             /* CCV_TENSOR_FORMAT_NHWC | NCHW; CCV_32F | CCV_16F */
+} nnc_mi355x_jitter_params_t;
+int nnc_mi355x_jitter_batch(const void* src, const nnc_mi355x_jitter_image_t* images_host, const int count, const nnc_mi355x_jitter_params_t params, void* out, ccv_nnc_stream_context_t* const stream_context);
+/* _ccv_cnnp_one_hot (:378-): out[i][k] = k == labels[i] ? onval : offval, `range` values per row, CCV_32F or CCV_16F. */
+int nnc_mi355x_one_hot_batch(const int* labels_host, const int count, const int range, const float onval, const float offval, const int datatype, void* out, ccv_nnc_stream_context_t* const stream_context);
 
 /* HIP-event timing on the stream a context launches on (bench.py roofline leg). */
 void* nnc_mi355x_event_new(void);
