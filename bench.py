@@ -99,7 +99,7 @@ def via_host(args, losses, params):
             "equal": bool(loss_err <= 1e-4 and qerr <= 1e-4), "driver": h["driver"]}
 
 
-def resnet_config(args, half):
+def resnet_config(args, half, dawn=False):
     """BASELINE config 4 on one MI355X: ResNet-50 v1d (bin/nnc/imagenet.c:17-98), NCHW, batch 256, forward + backward + Nesterov SGD,
     through the REFERENCE HOST's own model API (tools/host_resnet_bench.c -> oracle/_ref/host_resnet_bench.gpu: ccv_cnnp_model_fit on
     this backend; cnnp, autodiff, compile and the scheduler are the reference's unmodified code).  The timing is the harness's
@@ -109,15 +109,19 @@ def resnet_config(args, half):
     exe = os.path.join(ROOT, "oracle", "_ref", "host_resnet_bench.gpu")
     if not os.path.exists(exe):
         raise SystemExit("oracle/_ref/host_resnet_bench.gpu not built (oracle/build_ref_host.sh)")
-    r = subprocess.run([exe, str(args.batch), "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"], capture_output=True, text=True, timeout=3000)
+    r = subprocess.run([exe, str(args.batch), "32" if dawn else "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"] + (["dawn"] if dawn else []), capture_output=True, text=True, timeout=3000)
     if r.returncode != 0:
         raise SystemExit("host_resnet_bench failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
     h = json.loads(r.stdout.strip().splitlines()[-1])
     gflop = 25.97  # ResNet-50 v1d forward + backward per image (1 MAC = 2 FLOP)
-    out = {"metric": "images/sec fwd+bwd ResNet-50 v1d 224x224 bs%d NCHW" % args.batch, "value": h["images_per_s"], "unit": "images/s", "n_gpus": 1,
+    if dawn:  # DawnNet: 3x3 convolutions 3->64 @32^2, 64->128 @32^2, 2 x 128->128 @16^2, 128->256 @16^2, 256->512 @8^2, 2 x 512->512 @4^2, dense 512->10; x3 for fwd + bwd
+        macs = 9 * (3 * 64 * 1024 + 64 * 128 * 1024 + 2 * 128 * 128 * 256 + 128 * 256 * 256 + 256 * 512 * 64 + 2 * 512 * 512 * 16) + 5120
+        gflop = 3 * 2 * macs / 1e9
+    out = {"metric": ("images/sec fwd+bwd CIFAR-10 DawnNet 32x32 bs%d NCHW" if dawn else "images/sec fwd+bwd ResNet-50 v1d 224x224 bs%d NCHW") % args.batch, "value": h["images_per_s"], "unit": "images/s", "n_gpus": 1,
            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f16" if half else "f32", "data": "synthetic",
-           "config": {"workload": "ResNet-50 v1d (bin/nnc/imagenet.c) NCHW forward+backward+Nesterov SGD, batch %d, random-init weights, driven by the reference host's ccv_cnnp_model_fit" % args.batch,
+           "config": {"workload": ("CIFAR-10 DawnNet (bin/nnc/cifar-10.c:76-127) NCHW, the trainer's own step (evaluate, softmax cross-entropy, backward, apply gradients; Nesterov SGD), batch %d, random-init weights, driven by the reference host's model API" if dawn else
+                                   "ResNet-50 v1d (bin/nnc/imagenet.c) NCHW forward+backward+Nesterov SGD, batch %d, random-init weights, driven by the reference host's ccv_cnnp_model_fit") % args.batch,
                       "global_batch": args.batch, "parallelism": "dp1", "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] * gflop / 1e3,
                       "first_step_ms": h["first_step_ms"], "outputs_finite": h["outputs_finite"], "softmax_worst_row_sum_err": h["softmax_worst_row_sum_err"], "memory_gib": h["memory_gib"]}}
     ks = h.get("kernels", [])
@@ -161,8 +165,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
-    ap.add_argument("--config", default="vggd-train-bs256", choices=["vggd-train-bs256", "vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16"],
-                    help="BASELINE.json configs: 3 (default, the metric), 2 (VGG-D forward only, batch 64), 4 (ResNet-50 v1d NCHW through the reference host; -f16 = the trainer's own precision)")
+    ap.add_argument("--config", default="vggd-train-bs256", choices=["vggd-train-bs256", "vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512", "cifar10-dawn-f32-bs512"],
+                    help="BASELINE.json configs: 3 (default, the metric), 2 (VGG-D forward only, batch 64), 4 (ResNet-50 v1d NCHW through the reference host; -f16 = the trainer's own precision), 5 (CIFAR-10 DawnNet fp16, batch 512, through the reference host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-via-host", action="store_true", help="skip the second driver: the same step through the reference host's symbolic graph / autotune / static schedule (tools/host_vgg_bench.c)")
     ap.add_argument("--records", default=None, help="also write the per-launch contraction records (name, dims, ms, TFLOP/s) of the roofline leg to this file")
@@ -173,11 +177,13 @@ def main():
     fwd_only = args.config == "vggd-fwd-bs64"
     if fwd_only and args.batch == 256:
         args.batch = 64
-    if args.config.startswith("resnet50"):
+    if args.config.startswith("cifar10") and args.batch == 256:
+        args.batch = 512
+    if args.config.startswith("resnet50") or args.config.startswith("cifar10"):
         if world > 1:
             raise SystemExit("--config %s is a one-GPU line (the N-GPU form of this path is the reference host's single-process ccv_cnnp_model_set_data_parallel)" % args.config)
         nnc.load()  # fail loudly without the HIP library / a GPU
-        return resnet_config(args, args.config.endswith("f16"))
+        return resnet_config(args, "f16" in args.config, dawn=args.config.startswith("cifar10"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
 

@@ -7,8 +7,12 @@
  * symbolic graph, autodiff, simplify, compile, the multi-stream scheduler -- is the reference's unmodified code; this file is
  * the benchmark driver only.  Built by oracle/build_ref_host.sh against libccv_host_gpu.so (and the CPU-emulator build for the
  * small-size test of the CPU tier).
- *   host_resnet_bench.gpu <batch> <input hw> <steps> <warmup> <32|16> [mini]      -> one JSON line
- * 16 = CCV_16F tensors, what the trainer itself runs (imagenet.c:344); 32 = CCV_32F (BASELINE config 4). */
+ *   host_resnet_bench.gpu <batch> <input hw> <steps> <warmup> <32|16> [mini|dawn]      -> one JSON line
+ * 16 = CCV_16F tensors, what the trainer itself runs (imagenet.c:344); 32 = CCV_32F (BASELINE config 4).
+ * dawn = BASELINE config 5's network instead: the CIFAR-10 "DawnNet" of bin/nnc/cifar-10.c:76-127 (3x3 convolutions 64-128-256-512 with
+ * batch norm + ReLU, 2x2 max pools, two residual pairs, global max pool, dense 10), 32 x 32 inputs, and that trainer's own step
+ * (cifar-10.c:259-273): ccv_cnnp_model_evaluate(requires_grad) -> SOFTMAX_CROSSENTROPY forward / backward on the outputs ->
+ * ccv_cnnp_model_backward -> ccv_cnnp_model_apply_gradients, compiled with CMD_SGD_FORWARD(1, lr, 1 / batch, 0.01, 0.9, 0) and no loss. */
 #include <ccv.h>
 #include <nnc/ccv_nnc.h>
 #include <nnc/ccv_nnc_easy.h>
@@ -85,22 +89,53 @@ static ccv_cnnp_model_t* resnet(const int* const blocks, const int* const widths
 	return ccv_cnnp_model_new(MODEL_IO_LIST(in), MODEL_IO_LIST(out), 1, 0);
 }
 
+static ccv_cnnp_model_t* dawn_conv(const int filters)
+{
+	return ccv_cnnp_sequential_new(MODEL_LIST(
+		ccv_cnnp_convolution(1, filters, DIM_ALLOC(3, 3), DIM_ALLOC(), 0, HINT((1, 1), (1, 1)), 0, 1, 0),
+		ccv_cnnp_batch_norm(0.9, 1e-4, 1, 0),
+		ccv_cnnp_relu(0)), 1, 0);
+}
+static ccv_cnnp_model_t* dawn_layer(const int filters, const int residual)
+{
+	const ccv_cnnp_model_io_t in = ccv_cnnp_input();
+	ccv_cnnp_model_io_t out = ccv_cnnp_model_apply(dawn_conv(filters), MODEL_IO_LIST(in));
+	out = ccv_cnnp_model_apply(ccv_cnnp_max_pool(DIM_ALLOC(2, 2), HINT((2, 2), (0, 0)), 0), MODEL_IO_LIST(out));
+	if (residual) {
+		const ccv_cnnp_model_io_t shortcut = out;
+		out = ccv_cnnp_model_apply(dawn_conv(filters), MODEL_IO_LIST(out));
+		out = ccv_cnnp_model_apply(dawn_conv(filters), MODEL_IO_LIST(out));
+		out = ccv_cnnp_model_apply(ccv_cnnp_sum(0), MODEL_IO_LIST(out, shortcut));
+	}
+	return ccv_cnnp_model_new(MODEL_IO_LIST(in), MODEL_IO_LIST(out), 1, 0);
+}
+static ccv_cnnp_model_t* dawn(void)
+{
+	return ccv_cnnp_sequential_new(MODEL_LIST(
+		dawn_conv(64), dawn_layer(128, 1), dawn_layer(256, 0), dawn_layer(512, 1),
+		ccv_cnnp_max_pool(DIM_ALLOC(0, 0), ccv_nnc_no_hint, 0),
+		ccv_cnnp_flatten(0),
+		ccv_cnnp_dense(10, 0, 0, 1, 0)), 1, 0);
+}
+
 int main(int argc, char** argv)
 {
 	const int batch = argc > 1 ? atoi(argv[1]) : 256, hw = argc > 2 ? atoi(argv[2]) : 224;
 	const int steps = argc > 3 ? atoi(argv[3]) : 4, warmup = argc > 4 ? atoi(argv[4]) : 1;
 	const int half = argc > 5 && atoi(argv[5]) == 16;
 	const int mini = argc > 6 && strcmp(argv[6], "mini") == 0;
+	const int is_dawn = argc > 6 && strcmp(argv[6], "dawn") == 0;
 	const int dt = half ? CCV_16F : CCV_32F;
 	static const int blocks50[] = { 3, 4, 6, 3 }, widths50[] = { 64, 128, 256, 512 };
 	static const int blocks_m[] = { 1, 1 }, widths_m[] = { 8, 16 };
-	const int classes = mini ? 10 : 1000;
+	const int classes = (mini || is_dawn) ? 10 : 1000;
 	ccv_nnc_init();
-	ccv_cnnp_model_t* const model = mini ? resnet(blocks_m, widths_m, 2, 8, classes) : resnet(blocks50, widths50, 4, 64, classes);
+	ccv_cnnp_model_t* const model = is_dawn ? dawn() : mini ? resnet(blocks_m, widths_m, 2, 8, classes) : resnet(blocks50, widths50, 4, 64, classes);
 	ccv_nnc_tensor_param_t input = GPU_TENSOR_NCHW(000, 32F, batch, 3, hw, hw);
 	input.datatype = dt;
 	const float lr = 0.01f, wd = 0.0001f;
-	ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / batch, wd, 0.9, 0), CMD_CATEGORICAL_CROSSENTROPY_FORWARD());
+	if (is_dawn) ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / batch, 0.01, 0.9, 0), CMD_NOOP());
+	else ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / batch, wd, 0.9, 0), CMD_CATEGORICAL_CROSSENTROPY_FORWARD());
 	/* synthetic batch: images ~ U(-1, 1) (normalised pixels), labels as the trainer's smoothed one-hot rows (eta = 0.1) */
 	ccv_nnc_tensor_t* const hx = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, 3, hw, hw), 0);
 	ccv_nnc_tensor_t* const hfit = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, classes), 0);
@@ -129,20 +164,40 @@ int main(int argc, char** argv)
 	} else
 		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx, hfit), TENSOR_LIST(x, fit), 0);
 	ccv_nnc_stream_context_t* const stream = ccv_nnc_stream_context_new(CCV_STREAM_CONTEXT_GPU);
+	/* dawn: the CIFAR trainer's step (cifar-10.c:259-273); labels are class indices in fp32, the softmax / gradient tensors have the outputs' type */
+	ccv_nnc_tensor_t* const labels = ccv_nnc_tensor_new(0, GPU_TENSOR_NCHW(000, 32F, batch), 0);
+	ccv_nnc_tensor_t* const softmax = ccv_nnc_tensor_new(0, fp, 0);
+	ccv_nnc_tensor_t* const grad = ccv_nnc_tensor_new(0, fp, 0);
+	{
+		ccv_nnc_tensor_t* const hl = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch), 0);
+		for (i = 0; i < batch; i++) hl->data.f32[i] = (float)(int)(hash_unit(i, 2001) * classes);
+		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hl), TENSOR_LIST(labels), 0);
+		ccv_nnc_tensor_free(hl);
+	}
+#define TRAIN_STEP() do { \
+		if (is_dawn) { \
+			ccv_cnnp_model_evaluate(model, (ccv_cnnp_evaluate_param_t){ .requires_grad = 1, .disable_outgrad = CCV_CNNP_DISABLE_OUTGRAD_ALL }, TENSOR_LIST(x), TENSOR_LIST(out), 0, stream); \
+			ccv_nnc_cmd_exec(CMD_SOFTMAX_CROSSENTROPY_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(out, labels), TENSOR_LIST(0, softmax), stream); \
+			ccv_nnc_cmd_exec(CMD_SOFTMAX_CROSSENTROPY_BACKWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(0, 0, out, labels, 0, softmax), TENSOR_LIST(grad, 0), stream); \
+			ccv_cnnp_model_backward(model, TENSOR_LIST(grad), TENSOR_LIST(), 0, stream); \
+			ccv_cnnp_model_apply_gradients(model, stream); \
+		} else \
+			ccv_cnnp_model_fit(model, TENSOR_LIST(x), TENSOR_LIST(fit), TENSOR_LIST(out), 0, stream); \
+	} while (0)
 	/* step 1: compiles the graph (autodiff, simplify, arena, schedule) and initialises the parameters */
 	const double t_first0 = now_ms();
-	ccv_cnnp_model_fit(model, TENSOR_LIST(x), TENSOR_LIST(fit), TENSOR_LIST(out), 0, stream);
+	TRAIN_STEP();
 	ccv_nnc_stream_context_wait(stream);
 	const double t_first = now_ms() - t_first0;
 	/* the first step's softmax outputs: finite, rows summing to one (read back in fp32) */
 	ccv_nnc_tensor_t* const hout = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, classes), 0);
 	if (half) {
 		ccv_nnc_tensor_t* const hout16 = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(16F, batch, classes), 0);
-		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(out), TENSOR_LIST(hout16), 0);
+		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(is_dawn ? softmax : out), TENSOR_LIST(hout16), 0);
 		ccv_nnc_cmd_exec(CMD_DATATYPE_CONVERSION_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hout16), TENSOR_LIST(hout), 0);
 		ccv_nnc_tensor_free(hout16);
 	} else
-		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(out), TENSOR_LIST(hout), 0);
+		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(is_dawn ? softmax : out), TENSOR_LIST(hout), 0);
 	double row0 = 0, worst = 0;
 	int finite = 1;
 	for (i = 0; i < batch; i++) {
@@ -152,15 +207,15 @@ int main(int argc, char** argv)
 		if (i == 0) row0 = s;
 		if (fabs(s - 1) > worst) worst = fabs(s - 1);
 	}
-	for (i = 1; i < warmup; i++) ccv_cnnp_model_fit(model, TENSOR_LIST(x), TENSOR_LIST(fit), TENSOR_LIST(out), 0, stream);
+	for (i = 1; i < warmup; i++) TRAIN_STEP();
 	ccv_nnc_stream_context_wait(stream);
 	const double t0 = now_ms();
-	for (i = 0; i < steps; i++) ccv_cnnp_model_fit(model, TENSOR_LIST(x), TENSOR_LIST(fit), TENSOR_LIST(out), 0, stream);
+	for (i = 0; i < steps; i++) TRAIN_STEP();
 	ccv_nnc_stream_context_wait(stream);
 	const double ms = (now_ms() - t0) / (steps > 0 ? steps : 1);
 	/* roofline leg: one more step with the backend's per-launch HIP-event records on (contractions and batch norm) */
 	nnc_mi355x_profile_enable(1);
-	ccv_cnnp_model_fit(model, TENSOR_LIST(x), TENSOR_LIST(fit), TENSOR_LIST(out), 0, stream);
+	TRAIN_STEP();
 	ccv_nnc_stream_context_wait(stream);
 	struct { char name[192]; double ms, flops, bytes; int n; } agg[64];
 	int nagg = 0;
@@ -183,8 +238,11 @@ int main(int argc, char** argv)
 	printf("], ");
 	printf("\"driver\": \"reference host (ccv_cnnp_model_fit: cnnp, autodiff, compile, scheduler)\", \"model\": \"%s\", \"dtype\": \"%s\", \"format\": \"NCHW\", \"batch\": %d, \"input_hw\": %d, "
 		"\"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"first_step_ms\": %.1f, \"softmax_row0_sum\": %.6f, \"softmax_worst_row_sum_err\": %.3g, \"outputs_finite\": %s, \"memory_gib\": %.3f}\n",
-		mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, ms, batch / (ms * 1e-3), t_first, row0, worst, finite ? "true" : "false",
+		is_dawn ? "CIFAR-10 DawnNet (bin/nnc/cifar-10.c)" : mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, ms, batch / (ms * 1e-3), t_first, row0, worst, finite ? "true" : "false",
 		(double)ccv_cnnp_model_memory_size(model) / (1024.0 * 1024.0 * 1024.0));
+	ccv_nnc_tensor_free(labels);
+	ccv_nnc_tensor_free(softmax);
+	ccv_nnc_tensor_free(grad);
 	ccv_nnc_tensor_free(hout);
 	ccv_nnc_tensor_free(hx);
 	ccv_nnc_tensor_free(hfit);
