@@ -192,16 +192,15 @@ def main():
     dist = None
     comm = None
     force_comm = world == 1 and os.environ.get("NNC_BENCH_FORCE_COMM") == "1"  # exercise the N > 1 code path (RCCL communicator of ONE) on a 1-GPU box
-    if force_comm:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
     if world > 1 or force_comm:
         # one node: RCCL's bootstrap sockets go over loopback, no InfiniBand probing (the boxes have no external network)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
-        import torch.distributed as dist  # control plane only (rendezvous, barrier, max-reduce of the timing)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # control plane only (RCCL id hand-over, barriers, max over the ranks' clocks): ccv_amd/ctl.py, a Unix socket between the
+        # ranks torch.distributed.run started -- this process never imports torch (its wheel's second HIP runtime, see ctl.py)
+        from ccv_amd.ctl import LocalControl
         from ccv_amd.comm import ProcessComm
+        dist = LocalControl(rank, world)
         comm = ProcessComm(L, dist, rank, world)
 
     # parameters, images and labels from the counter hash tools/host_vgg_bench.c uses too: the command driver (this process),
@@ -247,7 +246,7 @@ def main():
     def checked_first_step():
         """N > 1, warm-up step 1, NOT overlapped: the exchange's sum identity on real gradients -- the all-reduced gradient of two
         probe tensors (the last layer's bias, the first layer's filters) must equal the sum of the ranks' local gradients
-        (gathered over gloo), and after the update every rank must hold the same parameters (sum / sum of squares per tensor)."""
+        (gathered over the control plane), and after the update every rank must hold the same parameters (sum / sum of squares per tensor)."""
         net.forward(stream)
         net.backward(stream)
         L.stream_wait(stream)
@@ -289,10 +288,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = dist.reduce_max(dt)
     loss = float(net.loss.numpy().mean())
 
     # roofline leg: three more steps with every contraction launch bracketed by HIP events on its stream; per launch position
@@ -369,6 +365,11 @@ def main():
                     raise SystemExit("bench.py: step-1 loss of image 0 differs from the oracle's: %r vs %r (rel %.3g > 1e-4)" % (step1_loss, oracle_loss, rel))
         print(json.dumps(out))
     if dist:
+        L.stream_wait(stream)
+        if comm_stream is not None:
+            L.stream_wait(comm_stream)
+        dist.barrier()  # every rank is past its last collective
+        L.dll.nnc_mi355x_comm_destroy()
         dist.barrier()
         dist.destroy_process_group()
 

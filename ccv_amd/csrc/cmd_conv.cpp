@@ -162,6 +162,13 @@ static bool wino_fused_plan(const conv_geom_t& g, const Image4& src, const Image
 	return true;
 }
 
+// Most scratch the fused kernel asks for (its U fragments), for the scopes that stage layouts in front of it.
+static size_t wino_fused_scratch_bound(const int Kout, const int Cred)
+{
+	if (Cred % WF_CC || Kout <= 0) return 0;
+	return ((sizeof(float) * (size_t)((Kout + WF_KT - 1) / WF_KT) * (Cred / WF_CC) * WF_U_FLOATS + 255) & ~(size_t)255);
+}
+
 template <bool FLIP>
 static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const wino_fused_plan_t& p, const Image4& src, const float* w, const float* bias, const Image4& dst, const int pad_y, const int pad_x, ccv_nnc_stream_context_t* const ctx)
 {
@@ -344,6 +351,7 @@ static int conv_c3_forw(const conv_geom_t& g, const Image4& a, const float* w, c
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
+static size_t conv_c3_wgrad_scratch_bound(const int K) { return sizeof(float) * (size_t)device_cu_count() * 4 * 4 * K * 32; } // per-wave partials at the grid cap
 // dw (+)= and dbias (+)= in one pass over the output gradient
 static int conv_c3_wgrad(const conv_geom_t& g, const Image4& gr, const Image4& a, float* dw, float* dbias, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
@@ -617,6 +625,7 @@ static int _conv_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	size_t inner = gemm_workspace_bound((long)g.N * g.OH * g.OW, g.Kg, (long)g.kh * g.kw * g.Cg);
 	wino_plan_t wpl;
 	if (cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.OH, g.OW, g.C, g.K, &wpl) && wpl.total() > inner) inner = wpl.total();
+	if (cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_fused_scratch_bound(g.K, g.C) > inner) inner = wino_fused_scratch_bound(g.K, g.C);
 	WorkspaceScope ws(stream_context, na + nb + nw, inner);
 	char* p = (char*)ws.prefix();
 	if (!p) return CCV_NNC_EXEC_OOM;
@@ -685,6 +694,8 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wpl) && wpl.total() > inner) inner = wpl.total();
 	wino_wgrad_plan_t wgp;
 	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wgp) && wgp.total() > inner) inner = wgp.total();
+	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_fused_scratch_bound(g.C, g.K) > inner) inner = wino_fused_scratch_bound(g.C, g.K);
+	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && g.C == 3 && conv_c3_wgrad_scratch_bound(g.K) > inner) inner = conv_c3_wgrad_scratch_bound(g.K);
 	WorkspaceScope ws(stream_context, ng + na + nh + nw + ndw, inner);
 	char* p = (char*)ws.prefix();
 	if ((ng + na + nh + nw + ndw) && !p) return CCV_NNC_EXEC_OOM;

@@ -126,7 +126,7 @@ static inline int grid_for(size_t n, int threads)
 // contraction launcher's split-K slabs) are handed the region behind the prefix.
 struct WorkspaceScope {
 	char* base;
-	size_t prev;
+	size_t prev, prev_limit;
 	WorkspaceScope(const ccv_nnc_stream_context_t* ctx, size_t prefix_bytes, size_t inner_bytes);
 	~WorkspaceScope();
 	void* prefix() const { return base; }

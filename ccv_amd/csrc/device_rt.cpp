@@ -125,9 +125,16 @@ hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
 }
 
 static thread_local size_t tl_ws_prefix = 0;
+static thread_local size_t tl_ws_limit = 0; // inside a WorkspaceScope: the bytes reserved up front (prefix + inner), 0 = no scope
 
 void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size)
 {
+	// Inside a scope the buffer must not move: the scope's owner holds pointers into its prefix (staged layouts).  A request
+	// beyond what the scope reserved is refused (the caller's CCV_NNC_EXEC_OOM path: the convolution falls back to an algorithm
+	// whose scratch the scope did account for) instead of growing -- growing frees and re-allocates the buffer, and the kernels
+	// launched afterwards would read the staged tensors out of freed memory (a GPU memory fault on the DawnNet's NCHW
+	// convolutions: the first-layer gradient's per-wave partials were not in the scope's bound).
+	if (tl_ws_limit && tl_ws_prefix + size > tl_ws_limit) return 0;
 	char* p = (char*)ccv_nnc_stream_compat_get_workspace(ctx, tl_ws_prefix + size, CCV_TENSOR_GPU_MEMORY);
 	return p ? p + tl_ws_prefix : 0;
 }
@@ -135,12 +142,15 @@ void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size)
 WorkspaceScope::WorkspaceScope(const ccv_nnc_stream_context_t* ctx, size_t prefix_bytes, size_t inner_bytes)
 {
 	prefix_bytes = (prefix_bytes + 255) & ~(size_t)255;
+	prev = tl_ws_prefix;
+	prev_limit = tl_ws_limit;
+	if (tl_ws_limit && tl_ws_prefix + prefix_bytes + inner_bytes > tl_ws_limit) { base = 0; return; } // nested scope beyond the outer reservation
 	char* p = (char*)ccv_nnc_stream_compat_get_workspace(ctx, tl_ws_prefix + prefix_bytes + inner_bytes, CCV_TENSOR_GPU_MEMORY);
 	base = p ? p + tl_ws_prefix : 0;
-	prev = tl_ws_prefix;
+	if (!tl_ws_limit) tl_ws_limit = tl_ws_prefix + prefix_bytes + inner_bytes;
 	tl_ws_prefix += prefix_bytes;
 }
-WorkspaceScope::~WorkspaceScope() { tl_ws_prefix = prev; }
+WorkspaceScope::~WorkspaceScope() { tl_ws_prefix = prev; tl_ws_limit = prev_limit; }
 
 const float* zero_page_of(const ccv_nnc_stream_context_t* ctx)
 {
@@ -199,13 +209,26 @@ static inline int markers_on(void)
 	if (g_markers_on < 0) { const char* e = getenv("NNC_MI355X_MARKERS"); markers_enable(e && *e && *e != '0'); }
 	return g_markers_on;
 }
+// NNC_MI355X_SYNC_TRACE=1 (debugging aid): every command prints its row on entry and waits for the device on exit, so a GPU
+// fault is reported right after the name of the command whose kernels raised it.
+static int g_sync_trace = -1;
+static inline int sync_trace_on(void)
+{
+	if (g_sync_trace < 0) { const char* e = getenv("NNC_MI355X_SYNC_TRACE"); g_sync_trace = (e && *e && *e != '0') ? 1 : 0; }
+	return g_sync_trace;
+}
 MarkerScope::MarkerScope(const uint32_t cmd) : active(0)
 {
+	if (sync_trace_on()) { fprintf(stderr, "[nnc_mi355x] > %s\n", command_row_name(cmd)); active |= 2; }
 	if (!markers_on()) return;
 	g_roctx_push(command_row_name(cmd));
-	active = 1;
+	active |= 1;
 }
-MarkerScope::~MarkerScope() { if (active) g_roctx_pop(); }
+MarkerScope::~MarkerScope()
+{
+	if (active & 1) g_roctx_pop();
+	if (active & 2) { const hipError_t e = hipDeviceSynchronize(); fprintf(stderr, "[nnc_mi355x] < %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
+}
 
 struct prof_rec_t { char name[192]; double flops, bytes; int dims[5]; hipEvent_t e0, e1; };
 static pthread_mutex_t g_prof_mutex = PTHREAD_MUTEX_INITIALIZER;

@@ -1,0 +1,60 @@
+"""The control plane bench.py's ranks use instead of torch.distributed (ccv_amd/ctl.py): real processes, world size 3, the
+calls ProcessComm and bench.py make -- id hand-over from rank 0, barriers, gather of per-rank objects, max over the clocks --
+and a stale socket name left behind by an earlier (crashed) job."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+from ccv_amd.ctl import LocalControl
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if rank == 0:
+    time.sleep(0.3)          # the others are already knocking (on the stale name) when rank 0 starts listening
+c = LocalControl(rank, world, timeout=60)
+ids = [b"\x01\x02" * 64] if rank == 0 else [None]
+c.broadcast_object_list(ids, src=0)
+assert ids[0] == b"\x01\x02" * 64
+got = [None] * world
+c.all_gather_object(got, {"rank": rank, "v": [rank * 1.5] * 3})
+assert [g["rank"] for g in got] == list(range(world)) and got[2]["v"] == [3.0] * 3
+for _ in range(20):
+    c.barrier()
+assert c.reduce_max(10.0 + rank) == 10.0 + world - 1
+assert "torch" not in sys.modules
+c.barrier(); c.destroy_process_group()
+print("rank %%d ok" %% rank)
+'''
+
+
+def test_local_control_world3(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_PORT="29643", TORCHELASTIC_RUN_ID="t1", TMPDIR=str(tmp_path))
+    sys.path.insert(0, ROOT)
+    from ccv_amd import ctl
+    old = dict(os.environ)
+    os.environ.update(MASTER_PORT="29643", TORCHELASTIC_RUN_ID="t1", TMPDIR=str(tmp_path))
+    try:
+        stale = ctl.default_path()
+    finally:
+        os.environ.clear(); os.environ.update(old)
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.bind(stale); s.close()   # a name nobody listens on
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE="3", LOCAL_RANK=str(r)), stdout=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0], outs
+    assert all("rank %d ok" % r in outs[r] for r in range(3))
+    assert not os.path.exists(stale)
+
+
+def test_local_control_world1_needs_no_socket(tmp_path):
+    from ccv_amd.ctl import LocalControl
+    c = LocalControl(0, 1, path=str(tmp_path / "never"))
+    ids = [b"x"]
+    c.broadcast_object_list(ids, src=0)
+    c.barrier()
+    assert ids == [b"x"] and c.reduce_max(2.5) == 2.5 and not os.path.exists(tmp_path / "never")
