@@ -835,6 +835,103 @@ static int conv_wgrad_h(const conv_geom_t& g, const Image4& gr, const Image4& a,
 }
 
 // CCV_NNC_EXEC_NO_KERNEL = "not this path": the caller runs the command on fp32 images instead.
+// ---- half-precision tensors in NCHW, kernels larger than 1 x 1 (the CIFAR-10 / ResNet trainers in their fp16 mode) ----------------
+// The fp32 Winograd kernels are the fastest 3 x 3 path this backend has (the half-precision implicit-GEMM filter gradient is slower
+// than fp32 Winograd's), and NCHW tensors are re-laid-out to NHWC for them anyway: here that one pass per tensor also carries the
+// half <-> float conversion (transpose_half_to_float / transpose_float_to_half), so an fp16 NCHW convolution moves
+// 6 bytes per activation element around the kernel where "convert, transpose, run, transpose, convert" moved 22.
+static void dense_nhwc_f32(const Image4& li, const bool batched, float* data, ccv_nnc_tensor_t* out, Image4* oi)
+{
+	memset(out, 0, sizeof(*out));
+	out->type = CCV_TENSOR_GPU_MEMORY;
+	out->info.type = CCV_TENSOR_GPU_MEMORY;
+	out->info.format = CCV_TENSOR_FORMAT_NHWC;
+	out->info.datatype = CCV_32F;
+	const int b = batched ? 1 : 0;
+	if (b) out->info.dim[0] = li.n;
+	out->info.dim[b] = li.h; out->info.dim[b + 1] = li.w; out->info.dim[b + 2] = li.c;
+	out->data.f32 = data;
+	image4(out, oi);
+}
+static int conv_nchw_half_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, const ccv_nnc_tensor_t* a, const ccv_nnc_tensor_t* w, const ccv_nnc_tensor_t* bias, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* const ctx)
+{
+	if ((flags & CCV_NNC_ACCUMULATE_OUTPUT) || w->info.format != CCV_TENSOR_FORMAT_NCHW || !tensor_contiguous(w)) return CCV_NNC_EXEC_NO_KERNEL;
+	int Na, Ca, Pa, Nb, Cb, Pb;
+	if (!nchw_dense(a, &Na, &Ca, &Pa) || !nchw_dense(b, &Nb, &Cb, &Pb)) return CCV_NNC_EXEC_NO_KERNEL;
+	Image4 ai, bi;
+	if (!image4(a, &ai) || !image4(b, &bi)) return CCV_NNC_EXEC_NO_KERNEL;
+	int K, kh, kw, Cg;
+	if (!weights_shape(w, &K, &kh, &kw, &Cg)) return CCV_NNC_EXEC_NO_KERNEL;
+	conv_geom_t g;
+	if (!conv_geometry(cmd, hint, ai, bi, 0, &g) || K != g.K || kh != g.kh || kw != g.kw || Cg != g.Cg) return CCV_NNC_EXEC_INVALID;
+	if (bias && (bias->info.dim[0] != g.K || !tensor_contiguous(bias))) return CCV_NNC_EXEC_INVALID;
+	const size_t na = align256(sizeof(float) * tensor_count(a->info)), nb = align256(sizeof(float) * tensor_count(b->info));
+	const size_t nw = align256(sizeof(float) * tensor_count(w->info)), nbias = bias ? align256(sizeof(float) * (size_t)g.K) : 0;
+	char* const p = (char*)nnc_staging_of(ctx, na + nb + nw + nbias);
+	if (!p) return CCV_NNC_EXEC_OOM;
+	float* const A = (float*)p; float* const B = (float*)(p + na); float* const W = (float*)(p + na + nb); float* const BI = bias ? (float*)(p + na + nb + nw) : 0;
+	int ret;
+	if ((ret = transpose_half_to_float(a->data.u8, A, Na, Ca, Pa, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	if ((ret = transpose_half_to_float(w->data.u8, W, g.K, g.Cg, g.kh * g.kw, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	if (bias && (ret = half_to_float(bias->data.u8, BI, (size_t)g.K, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	ccv_nnc_tensor_t at, bt;
+	Image4 as, bs;
+	dense_nhwc_f32(ai, tensor_nd(a->info.dim) == 4, A, &at, &as);
+	dense_nhwc_f32(bi, tensor_nd(b->info.dim) == 4, B, &bt, &bs);
+	if ((ret = conv_forw_nhwc(g, as, W, BI, bs, cmd.algorithm, flags, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	return transpose_float_to_half(B, b->data.u8, Nb, Pb, Cb, ctx);
+}
+static int conv_nchw_half_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, const ccv_nnc_tensor_t* gt, const ccv_nnc_tensor_t* a, const ccv_nnc_tensor_t* w, ccv_nnc_tensor_t* h, ccv_nnc_tensor_t* dw, ccv_nnc_tensor_t* dbias, ccv_nnc_stream_context_t* const ctx)
+{
+	if (flags & CCV_NNC_ACCUMULATE_OUTPUT) return CCV_NNC_EXEC_NO_KERNEL;
+	const ccv_nnc_tensor_t* shape_src = a ? a : h;
+	const ccv_nnc_tensor_t* wshape = dw ? dw : w;
+	if (wshape->info.format != CCV_TENSOR_FORMAT_NCHW || (w && (w->info.format != CCV_TENSOR_FORMAT_NCHW || !tensor_contiguous(w))) || (dw && !tensor_contiguous(dw))) return CCV_NNC_EXEC_NO_KERNEL;
+	int Ng, Cgr, Pg, Na, Ca, Pa;
+	if (!nchw_dense(gt, &Ng, &Cgr, &Pg) || !nchw_dense(shape_src, &Na, &Ca, &Pa) || (h && !nchw_dense(h, &Na, &Ca, &Pa))) return CCV_NNC_EXEC_NO_KERNEL;
+	Image4 gi, ai;
+	if (!image4(gt, &gi) || !image4(shape_src, &ai)) return CCV_NNC_EXEC_NO_KERNEL;
+	int K, kh, kw, Cg;
+	if (!weights_shape(wshape, &K, &kh, &kw, &Cg)) return CCV_NNC_EXEC_NO_KERNEL;
+	conv_geom_t g;
+	if (!conv_geometry(cmd, hint, ai, gi, 0, &g) || K != g.K || kh != g.kh || kw != g.kw || Cg != g.Cg) return CCV_NNC_EXEC_INVALID;
+	if ((dw && !a) || (h && !w)) return CCV_NNC_EXEC_INVALID;
+	Image4 hi;
+	if (h && (!image4(h, &hi) || hi.h != g.H || hi.w != g.W || hi.c != g.C || hi.n != g.N)) return CCV_NNC_EXEC_INVALID;
+	if (dbias && (!tensor_contiguous(dbias) || dbias->info.dim[0] != g.K)) return CCV_NNC_EXEC_INVALID;
+	const size_t wbytes = align256(sizeof(float) * (size_t)g.K * g.kh * g.kw * g.Cg);
+	const size_t ng = align256(sizeof(float) * tensor_count(gt->info));
+	const size_t na = dw ? align256(sizeof(float) * tensor_count(a->info)) : 0, nh = h ? align256(sizeof(float) * tensor_count(h->info)) : 0;
+	const size_t nw = h ? wbytes : 0, ndw = dw ? wbytes : 0, ndb = dbias ? align256(sizeof(float) * (size_t)g.K) : 0;
+	char* const p = (char*)nnc_staging_of(ctx, ng + na + nh + nw + ndw + ndb);
+	if (!p) return CCV_NNC_EXEC_OOM;
+	float* const G = (float*)p; float* const A = (float*)(p + ng); float* const Hh = (float*)(p + ng + na);
+	float* const W = (float*)(p + ng + na + nh); float* const DW = (float*)(p + ng + na + nh + nw); float* const DB = dbias ? (float*)(p + ng + na + nh + nw + ndw) : 0;
+	int ret;
+	if ((ret = transpose_half_to_float(gt->data.u8, G, Ng, Cgr, Pg, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	ccv_nnc_tensor_t gs, as, hs;
+	Image4 gim, aim, him;
+	dense_nhwc_f32(gi, tensor_nd(gt->info.dim) == 4, G, &gs, &gim);
+	bool bias_done = false;
+	if (dw) {
+		if ((ret = transpose_half_to_float(a->data.u8, A, Na, Ca, Pa, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		dense_nhwc_f32(ai, tensor_nd(a->info.dim) == 4, A, &as, &aim);
+		if ((ret = conv_wgrad_nhwc(g, gim, aim, DW, DB, &bias_done, cmd.algorithm, flags, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = transpose_float_to_half(DW, dw->data.u8, g.K, g.kh * g.kw, g.Cg, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret; // [K][khkw][C] -> [K][C][khkw]
+	}
+	if (dbias) {
+		if (!bias_done && (ret = colsum_f32(gim.p, (long)g.N * g.OH * g.OW, g.K, gim.sw, DB, 0, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = float_to_half(DB, dbias->data.u8, (size_t)g.K, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	}
+	if (h) {
+		if ((ret = transpose_half_to_float(w->data.u8, W, g.K, g.Cg, g.kh * g.kw, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		dense_nhwc_f32(hi, tensor_nd(h->info.dim) == 4, Hh, &hs, &him);
+		if ((ret = conv_dgrad_nhwc(g, gim, W, him, cmd.algorithm, flags, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = transpose_float_to_half(Hh, h->data.u8, Na, Pa, Ca, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 static int _conv_forw_half(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	if (input_size < 2 || output_size < 1 || !inputs[0] || !inputs[1] || !outputs[0]) return CCV_NNC_EXEC_INVALID;
@@ -842,7 +939,10 @@ static int _conv_forw_half(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, c
 	const ccv_nnc_tensor_t* w = inputs[1];
 	const ccv_nnc_tensor_t* bias = input_size > 2 ? inputs[2] : 0;
 	ccv_nnc_tensor_t* b = outputs[0];
-	if (a->info.format == CCV_TENSOR_FORMAT_NCHW && b->info.format == CCV_TENSOR_FORMAT_NCHW) return conv1x1_nchw_forw<half_t>(cmd, hint, flags, a, w, bias, b, stream_context);
+	if (a->info.format == CCV_TENSOR_FORMAT_NCHW && b->info.format == CCV_TENSOR_FORMAT_NCHW) {
+		const int r = conv1x1_nchw_forw<half_t>(cmd, hint, flags, a, w, bias, b, stream_context);
+		return r != CCV_NNC_EXEC_NO_KERNEL ? r : conv_nchw_half_forw(cmd, hint, flags, a, w, bias, b, stream_context);
+	}
 	if (a->info.format != CCV_TENSOR_FORMAT_NHWC || b->info.format != CCV_TENSOR_FORMAT_NHWC || w->info.format != CCV_TENSOR_FORMAT_NHWC) return CCV_NNC_EXEC_NO_KERNEL;
 	Image4 ai, bi;
 	if (!image4(a, &ai) || !image4(b, &bi)) return CCV_NNC_EXEC_NO_KERNEL;
@@ -867,7 +967,10 @@ static int _conv_back_half(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, c
 	const ccv_nnc_tensor_t* shape_src = a ? a : h;
 	const ccv_nnc_tensor_t* wshape = dw ? dw : w;
 	if (!shape_src || !wshape) return CCV_NNC_EXEC_INVALID;
-	if (gt->info.format == CCV_TENSOR_FORMAT_NCHW) return conv1x1_nchw_back<half_t>(cmd, hint, flags, gt, a, w, h, dw, dbias, stream_context);
+	if (gt->info.format == CCV_TENSOR_FORMAT_NCHW) {
+		const int r = conv1x1_nchw_back<half_t>(cmd, hint, flags, gt, a, w, h, dw, dbias, stream_context);
+		return r != CCV_NNC_EXEC_NO_KERNEL ? r : conv_nchw_half_back(cmd, hint, flags, gt, a, w, h, dw, dbias, stream_context);
+	}
 	if (gt->info.format != CCV_TENSOR_FORMAT_NHWC || shape_src->info.format != CCV_TENSOR_FORMAT_NHWC || wshape->info.format != CCV_TENSOR_FORMAT_NHWC || (w && w->info.format != CCV_TENSOR_FORMAT_NHWC) || (h && h->info.format != CCV_TENSOR_FORMAT_NHWC)) return CCV_NNC_EXEC_NO_KERNEL;
 	Image4 gi, ai, hi;
 	if (!image4(gt, &gi) || !image4(shape_src, &ai)) return CCV_NNC_EXEC_NO_KERNEL;

@@ -17,45 +17,72 @@ namespace {
 constexpr int EW_THREADS = 256;
 
 // ---- generic contiguous map: out[i] = f(in0[i], in1[i], in2[i]) ----------------------------------------------
-template <class F, int NIN>
-__global__ void __launch_bounds__(EW_THREADS) ew_map_kernel(F f, float* out, const float* in0, const float* in1, const float* in2, const size_t n4, const size_t n)
+// T = float or _Float16 (the CCV_16F tensors of the half-precision trainers: loaded and stored as halves, arithmetic in fp32 --
+// half the bytes of the fp32 form, a fifth of what running the fp32 kernel on converted images moves).  16 bytes per access.
+typedef _Float16 half_t;
+template <class T> struct pack16 { typedef T type __attribute__((ext_vector_type(16 / sizeof(T)))); };
+template <class F, int NIN, class T>
+__global__ void __launch_bounds__(EW_THREADS) ew_map_kernel(F f, T* out, const T* in0, const T* in1, const T* in2, const size_t nv, const size_t n)
 {
+	constexpr int W = 16 / sizeof(T);
+	typedef typename pack16<T>::type V;
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	// four independent 16-byte loads per input in flight per thread (one per trip left the chip at 4.9-5.1 TB/s on the ReLU
 	// passes of VGG-D: 2048 workgroups x 256 threads x 16 bytes = 8 MB in flight against ~13 MB of bandwidth-delay product)
 	size_t i = tid;
-	for (; i + 3 * stride < n4; i += 4 * stride) {
-		float4 a[4], b[4], c[4];
+	for (; i + 3 * stride < nv; i += 4 * stride) {
+		V a[4], b[4], c[4];
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
-			a[u] = NIN > 0 ? ((const float4*)in0)[i + u * stride] : make_float4(0, 0, 0, 0);
-			b[u] = NIN > 1 ? ((const float4*)in1)[i + u * stride] : make_float4(0, 0, 0, 0);
-			c[u] = NIN > 2 ? ((const float4*)in2)[i + u * stride] : make_float4(0, 0, 0, 0);
+			a[u] = NIN > 0 ? ((const V*)in0)[i + u * stride] : V{};
+			b[u] = NIN > 1 ? ((const V*)in1)[i + u * stride] : V{};
+			c[u] = NIN > 2 ? ((const V*)in2)[i + u * stride] : V{};
 		}
 #pragma unroll
-		for (int u = 0; u < 4; u++)
-			((float4*)out)[i + u * stride] = make_float4(f(a[u].x, b[u].x, c[u].x), f(a[u].y, b[u].y, c[u].y), f(a[u].z, b[u].z, c[u].z), f(a[u].w, b[u].w, c[u].w));
+		for (int u = 0; u < 4; u++) {
+			V r;
+#pragma unroll
+			for (int e = 0; e < W; e++) r[e] = (T)f((float)a[u][e], (float)b[u][e], (float)c[u][e]);
+			((V*)out)[i + u * stride] = r;
+		}
 	}
-	for (; i < n4; i += stride) {
-		const float4 a = NIN > 0 ? ((const float4*)in0)[i] : make_float4(0, 0, 0, 0);
-		const float4 b = NIN > 1 ? ((const float4*)in1)[i] : make_float4(0, 0, 0, 0);
-		const float4 c = NIN > 2 ? ((const float4*)in2)[i] : make_float4(0, 0, 0, 0);
-		((float4*)out)[i] = make_float4(f(a.x, b.x, c.x), f(a.y, b.y, c.y), f(a.z, b.z, c.z), f(a.w, b.w, c.w));
+	for (; i < nv; i += stride) {
+		const V a = NIN > 0 ? ((const V*)in0)[i] : V{};
+		const V b = NIN > 1 ? ((const V*)in1)[i] : V{};
+		const V c = NIN > 2 ? ((const V*)in2)[i] : V{};
+		V r;
+#pragma unroll
+		for (int e = 0; e < W; e++) r[e] = (T)f((float)a[e], (float)b[e], (float)c[e]);
+		((V*)out)[i] = r;
 	}
-	for (size_t j = n4 * 4 + tid; j < n; j += stride)
-		out[j] = f(NIN > 0 ? in0[j] : 0.f, NIN > 1 ? in1[j] : 0.f, NIN > 2 ? in2[j] : 0.f);
+	for (size_t j = nv * W + tid; j < n; j += stride)
+		out[j] = (T)f(NIN > 0 ? (float)in0[j] : 0.f, NIN > 1 ? (float)in1[j] : 0.f, NIN > 2 ? (float)in2[j] : 0.f);
 }
 
+template <class F, int NIN, class T>
+static int ew_map(F f, T* out, const T* in0, const T* in1, const T* in2, size_t n, ccv_nnc_stream_context_t* ctx)
+{
+	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	constexpr int W = 16 / sizeof(T);
+	const bool vec = aligned16(out) && (NIN < 1 || aligned16(in0)) && (NIN < 2 || aligned16(in1)) && (NIN < 3 || aligned16(in2));
+	const size_t nv = vec ? n / W : 0;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(ew_map_kernel<F, NIN, T>), dim3(grid_for(vec ? nv + 3 : n, EW_THREADS)), dim3(EW_THREADS), 0, stream_of(ctx), f, out, in0, in1, in2, nv, n);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
 template <class F, int NIN>
 static int ew_map(F f, float* out, const float* in0, const float* in1, const float* in2, size_t n, ccv_nnc_stream_context_t* ctx)
 {
-	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
-	const bool vec = aligned16(out) && (NIN < 1 || aligned16(in0)) && (NIN < 2 || aligned16(in1)) && (NIN < 3 || aligned16(in2));
-	const size_t n4 = vec ? n / 4 : 0;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(ew_map_kernel<F, NIN>), dim3(grid_for(vec ? n4 + 3 : n, EW_THREADS)), dim3(EW_THREADS), 0, stream_of(ctx), f, out, in0, in1, in2, n4, n);
-	HIP_ENFORCE(hipGetLastError());
-	return CCV_NNC_EXEC_SUCCESS;
+	return ew_map<F, NIN, float>(f, out, in0, in1, in2, n, ctx);
+}
+// the tensors' own element type: every tensor handed over is of a's type (half_stage.cpp keeps the big tensors of the rows
+// listed in its native table in half precision only when all of them are)
+template <class F, int NIN>
+static int ew_map_any(F f, const int datatype, void* out, const void* in0, const void* in1, const void* in2, size_t n, ccv_nnc_stream_context_t* ctx)
+{
+	if (CCV_GET_DATA_TYPE(datatype) == CCV_16F) return ew_map<F, NIN, half_t>(f, (half_t*)out, (const half_t*)in0, (const half_t*)in1, (const half_t*)in2, n, ctx);
+	return ew_map<F, NIN, float>(f, (float*)out, (const float*)in0, (const float*)in1, (const float*)in2, n, ctx);
 }
 
 struct OpRelu { __device__ float operator()(float a, float, float) const { return a > 0.f ? a : 0.f; } };                  // 2|x| bytes
@@ -68,21 +95,22 @@ struct OpAdd3 { __device__ float operator()(float a, float b, float c) const { r
 struct OpCopy { __device__ float operator()(float a, float, float) const { return a; } };
 
 // ---- SGD: n = mu*m + (1-damp)*(scale*g + decay*a); b = a - rate*n   (5|p| bytes: g, a, m in; b, n out) --------
-__global__ void __launch_bounds__(EW_THREADS) sgd_kernel(const float* g, const float* a, const float* m, float* b, float* nm, const size_t n, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening)
+template <class T> // float, or _Float16 when the trainer keeps gradient, parameter and momentum in CCV_16F (arithmetic in fp32)
+__global__ void __launch_bounds__(EW_THREADS) sgd_kernel(const T* g, const T* a, const T* m, T* b, T* nm, const size_t n, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening)
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-		const float av = a[i];
+		const float av = (float)a[i];
 		if (nesterov) {
-			float grad = scale * g[i];
-			const float mom = momentum * m[i] + grad + decay * av;
-			nm[i] = mom;
+			float grad = scale * (float)g[i];
+			const float mom = momentum * (float)m[i] + grad + decay * av;
+			nm[i] = (T)mom;
 			grad += momentum * mom;
-			b[i] = av - rate * grad;
+			b[i] = (T)(av - rate * grad);
 		} else {
-			const float mom = momentum * m[i] + inv_dampening * (scale * g[i] + decay * av);
-			nm[i] = mom;
-			b[i] = av - rate * mom;
+			const float mom = momentum * (float)m[i] + inv_dampening * (scale * (float)g[i] + decay * av);
+			nm[i] = (T)mom;
+			b[i] = (T)(av - rate * mom);
 		}
 	}
 }
@@ -169,7 +197,8 @@ static int _relu_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	const ccv_nnc_tensor_t* a = inputs[0];
 	ccv_nnc_tensor_t* b = outputs[0];
 	if (!tensor_contiguous(a) || !tensor_contiguous(b) || tensor_count(a->info) != tensor_count(b->info)) return CCV_NNC_EXEC_INVALID;
-	return ew_map<OpRelu, 1>(OpRelu(), b->data.f32, a->data.f32, 0, 0, tensor_count(a->info), stream_context);
+	if (a->info.datatype != b->info.datatype) return CCV_NNC_EXEC_INVALID;
+	return ew_map_any<OpRelu, 1>(OpRelu(), a->info.datatype, b->data.u8, a->data.u8, 0, 0, tensor_count(a->info), stream_context);
 }
 
 static int _relu_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
@@ -182,8 +211,9 @@ static int _relu_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	if ((g && !tensor_contiguous(g)) || !tensor_contiguous(b) || !tensor_contiguous(h)) return CCV_NNC_EXEC_INVALID;
 	const size_t n = tensor_count(b->info);
 	if (tensor_count(h->info) != n || (g && tensor_count(g->info) != n)) return CCV_NNC_EXEC_INVALID;
-	if (!g) return ew_map<OpReluBackOnes, 1>(OpReluBackOnes(), h->data.f32, b->data.f32, 0, 0, n, stream_context);
-	return ew_map<OpReluBack, 2>(OpReluBack(), h->data.f32, g->data.f32, b->data.f32, 0, n, stream_context);
+	if (b->info.datatype != h->info.datatype || (g && g->info.datatype != h->info.datatype)) return CCV_NNC_EXEC_INVALID;
+	if (!g) return ew_map_any<OpReluBackOnes, 1>(OpReluBackOnes(), h->info.datatype, h->data.u8, b->data.u8, 0, 0, n, stream_context);
+	return ew_map_any<OpReluBack, 2>(OpReluBack(), h->info.datatype, h->data.u8, g->data.u8, b->data.u8, 0, n, stream_context);
 }
 
 // int32 n-ary sum (the reference sums index tensors with it, ew_gpu_cudnn.cu:13-130): out = in0 + in1 + ...
@@ -215,22 +245,24 @@ static int _ewsum_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
-	if (CCV_GET_DATA_TYPE(c->info.datatype) != CCV_32F || !tensor_contiguous(c)) return CCV_NNC_EXEC_INVALID;
+	if ((CCV_GET_DATA_TYPE(c->info.datatype) != CCV_32F && CCV_GET_DATA_TYPE(c->info.datatype) != CCV_16F) || !tensor_contiguous(c)) return CCV_NNC_EXEC_INVALID;
 	const size_t n = tensor_count(c->info);
 	for (int i = 0; i < input_size; i++)
 		if (!inputs[i] || !tensor_contiguous(inputs[i]) || tensor_count(inputs[i]->info) != n) return CCV_NNC_EXEC_INVALID;
-	float* cp = c->data.f32;
+	void* cp = c->data.u8;
+	const int dt = c->info.datatype;
+	for (int i = 0; i < input_size; i++) if (inputs[i]->info.datatype != dt) return CCV_NNC_EXEC_INVALID;
 	// Fold left to right, exactly the association order of the reference: ((in0 + in1) + in2) + ...
 	if (input_size == 1) {
-		if (inputs[0]->data.f32 == cp) return CCV_NNC_EXEC_SUCCESS;
-		return ew_map<OpCopy, 1>(OpCopy(), cp, inputs[0]->data.f32, 0, 0, n, stream_context);
+		if (inputs[0]->data.u8 == cp) return CCV_NNC_EXEC_SUCCESS;
+		return ew_map_any<OpCopy, 1>(OpCopy(), dt, cp, inputs[0]->data.u8, 0, 0, n, stream_context);
 	}
 	int ret, i = 0;
-	if (input_size >= 3) { ret = ew_map<OpAdd3, 3>(OpAdd3(), cp, inputs[0]->data.f32, inputs[1]->data.f32, inputs[2]->data.f32, n, stream_context); i = 3; }
-	else { ret = ew_map<OpAdd2, 2>(OpAdd2(), cp, inputs[0]->data.f32, inputs[1]->data.f32, 0, n, stream_context); i = 2; }
+	if (input_size >= 3) { ret = ew_map_any<OpAdd3, 3>(OpAdd3(), dt, cp, inputs[0]->data.u8, inputs[1]->data.u8, inputs[2]->data.u8, n, stream_context); i = 3; }
+	else { ret = ew_map_any<OpAdd2, 2>(OpAdd2(), dt, cp, inputs[0]->data.u8, inputs[1]->data.u8, 0, n, stream_context); i = 2; }
 	for (; ret == CCV_NNC_EXEC_SUCCESS && i < input_size; ) {
-		if (i + 1 < input_size) { ret = ew_map<OpAdd3, 3>(OpAdd3(), cp, cp, inputs[i]->data.f32, inputs[i + 1]->data.f32, n, stream_context); i += 2; }
-		else { ret = ew_map<OpAdd2, 2>(OpAdd2(), cp, cp, inputs[i]->data.f32, 0, n, stream_context); i += 1; }
+		if (i + 1 < input_size) { ret = ew_map_any<OpAdd3, 3>(OpAdd3(), dt, cp, cp, inputs[i]->data.u8, inputs[i + 1]->data.u8, n, stream_context); i += 2; }
+		else { ret = ew_map_any<OpAdd2, 2>(OpAdd2(), dt, cp, cp, inputs[i]->data.u8, 0, n, stream_context); i += 1; }
 	}
 	return ret;
 }
@@ -245,10 +277,10 @@ static int _ewsum_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 		if (!o) continue;
 		if (!tensor_contiguous(o)) return CCV_NNC_EXEC_INVALID;
 		const size_t n = tensor_count(o->info);
-		if (!g) { OpFill f; f.v = 1.f; ret = ew_map<OpFill, 0>(f, o->data.f32, 0, 0, 0, n, stream_context); }
+		if (!g) { OpFill f; f.v = 1.f; ret = ew_map_any<OpFill, 0>(f, o->info.datatype, o->data.u8, 0, 0, 0, n, stream_context); }
 		else if (g->data.f32 != o->data.f32) {
-			if (!tensor_contiguous(g) || tensor_count(g->info) != n) return CCV_NNC_EXEC_INVALID;
-			ret = ew_map<OpCopy, 1>(OpCopy(), o->data.f32, g->data.f32, 0, 0, n, stream_context);
+			if (!tensor_contiguous(g) || tensor_count(g->info) != n || g->info.datatype != o->info.datatype) return CCV_NNC_EXEC_INVALID;
+			ret = ew_map_any<OpCopy, 1>(OpCopy(), o->info.datatype, o->data.u8, g->data.u8, 0, 0, n, stream_context);
 		}
 	}
 	return ret;
@@ -291,11 +323,18 @@ static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	if (cnt == 0) return CCV_NNC_EXEC_SUCCESS;
 	const float inv_dampening = 1 - cmd.info.sgd.dampening;
 	hipStream_t stream = stream_of(stream_context);
+	const int dt = CCV_GET_DATA_TYPE(a->info.datatype);
+	if (CCV_GET_DATA_TYPE(g->info.datatype) != dt || CCV_GET_DATA_TYPE(m->info.datatype) != dt || CCV_GET_DATA_TYPE(b->info.datatype) != dt || CCV_GET_DATA_TYPE(n->info.datatype) != dt) return CCV_NNC_EXEC_INVALID;
+	if (dt == CCV_16F) {
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(sgd_kernel<half_t>), dim3(grid_for(cnt, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const half_t*)g->data.f16, (const half_t*)a->data.f16, (const half_t*)m->data.f16, (half_t*)b->data.f16, (half_t*)n->data.f16, cnt, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
 	const bool vec = (cnt % 4 == 0) && aligned16(g->data.f32) && aligned16(a->data.f32) && aligned16(m->data.f32) && aligned16(b->data.f32) && aligned16(n->data.f32);
 	if (vec)
 		hipLaunchKernelGGL(sgd_kernel_v4, dim3(grid_for(cnt / 4, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float4*)g->data.f32, (const float4*)a->data.f32, (const float4*)m->data.f32, (float4*)b->data.f32, (float4*)n->data.f32, cnt / 4, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
 	else
-		hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(cnt, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)g->data.f32, (const float*)a->data.f32, (const float*)m->data.f32, b->data.f32, n->data.f32, cnt, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(sgd_kernel<float>), dim3(grid_for(cnt, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)g->data.f32, (const float*)a->data.f32, (const float*)m->data.f32, b->data.f32, n->data.f32, cnt, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

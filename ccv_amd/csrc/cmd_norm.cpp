@@ -23,8 +23,8 @@ struct RXhatG { const float* mean; const float* inv_std; __device__ float operat
 
 constexpr int RC_COLS = 64, RC_PHASES = 4;
 // inner == 1: rows of C contiguous channels.  grid (ceil(C/64), slices); lanes = 64 consecutive channels.
-template <class F, bool USE_G>
-__global__ void __launch_bounds__(256) chan_reduce_rows_kernel(F f, const float* x, const float* g, const long rows, const int C, const long rows_per_slice, float* partial)
+template <class F, bool USE_G, class T>
+__global__ void __launch_bounds__(256) chan_reduce_rows_kernel(F f, const T* x, const T* g, const long rows, const int C, const long rows_per_slice, float* partial)
 {
 	__shared__ float red[RC_PHASES][RC_COLS];
 	const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
@@ -34,57 +34,86 @@ __global__ void __launch_bounds__(256) chan_reduce_rows_kernel(F f, const float*
 	if (r1 > rows) r1 = rows;
 	float s = 0.f;
 	if (c < C)
-		for (long r = r0 + phase; r < r1; r += RC_PHASES) s += f(x[r * C + c], USE_G ? g[r * C + c] : 0.f, c);
+		for (long r = r0 + phase; r < r1; r += RC_PHASES) s += f((float)x[r * C + c], USE_G ? (float)g[r * C + c] : 0.f, c);
 	red[phase][lane] = s;
 	__syncthreads();
 	if (phase == 0 && c < C) partial[(long)blockIdx.y * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 // inner > 1: planes of `inner` contiguous elements, ONE WAVE PER PLANE (16-byte lanes when the plane allows), partial[o][c].
-template <class F, bool USE_G>
-__global__ void __launch_bounds__(256) chan_reduce_planes_kernel(F f, const float* x, const float* g, const int C, const long inner, const long planes, float* partial)
+typedef _Float16 half_t;
+template <class T> struct pack16 { typedef T type __attribute__((ext_vector_type(16 / sizeof(T)))); }; // one 16-byte access: 4 floats / 8 halves
+template <class F, bool USE_G, class T>
+__global__ void __launch_bounds__(256) chan_reduce_planes_kernel(F f, const T* x, const T* g, const int C, const long inner, const long planes, float* partial)
 {
+	constexpr int W = 16 / sizeof(T);
+	typedef typename pack16<T>::type V;
 	const int lane = threadIdx.x & 63;
 	const long nw = (long)gridDim.x * 4;
 	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
 		const int c = (int)(pl % C);
-		const float* const xp = x + pl * inner;
-		const float* const gp = USE_G ? g + pl * inner : x;
+		const T* const xp = x + pl * inner;
+		const T* const gp = USE_G ? g + pl * inner : x;
 		float s = 0.f;
-		if ((inner & 3) == 0 && ((((uintptr_t)xp) | ((uintptr_t)gp)) & 15) == 0) {
-			const long n4 = inner >> 2;
-			for (long i = lane; i < n4; i += 64) {
-				const float4 xv = ((const float4*)xp)[i];
-				float4 gv = xv;
-				if (USE_G) gv = ((const float4*)gp)[i];
-				s += f(xv.x, USE_G ? gv.x : 0.f, c); s += f(xv.y, USE_G ? gv.y : 0.f, c); s += f(xv.z, USE_G ? gv.z : 0.f, c); s += f(xv.w, USE_G ? gv.w : 0.f, c);
+		if ((inner % W) == 0 && ((((uintptr_t)xp) | ((uintptr_t)gp)) & 15) == 0) {
+			const long nv = inner / W;
+			for (long i = lane; i < nv; i += 64) {
+				const V xv = ((const V*)xp)[i];
+				V gv = xv;
+				if (USE_G) gv = ((const V*)gp)[i];
+#pragma unroll
+				for (int e = 0; e < W; e++) s += f((float)xv[e], USE_G ? (float)gv[e] : 0.f, c);
 			}
 		} else
-			for (long i = lane; i < inner; i += 64) s += f(xp[i], USE_G ? gp[i] : 0.f, c);
+			for (long i = lane; i < inner; i += 64) s += f((float)xp[i], USE_G ? (float)gp[i] : 0.f, c);
 		for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
 		if (lane == 0) partial[pl] = s;
 	}
 }
-// out[c] (+)= sum_i partial[i][c], fixed order.  One workgroup per 64 channels: thread (phase = t >> 6, lane) adds the slices
-// phase, phase + 4, ...; the four phases fold through LDS.  (One thread per channel walking every slice -- the first version --
-// was 66 us per call on the ResNet-50 step, 13 ms per step: as long as the reductions it finishes.)
-__global__ void __launch_bounds__(256) chan_fold_kernel(const float* partial, const long slices, const int C, float* out, const int accumulate)
+// Folding per-slice (per-plane) partials into per-channel sums, fixed order.  A workgroup is 16 channels x 16 phases: thread
+// (phase = t >> 4, channel = t & 15) adds the slices phase, phase + 16, ... with four independent running sums (four loads in
+// flight; one thread per channel walking every slice with one dependent add chain was 66 us per call, 64 channels x 4 phases
+// still 32 - 68 us on the DawnNet / ResNet-50 steps -- as long as the sweeps over the tensors these folds finish); the 16
+// phases meet in LDS.  FOLD_CH channels per workgroup also means 4x the workgroups of the 64-channel form.
+constexpr int FOLD_CH = 16, FOLD_PH = 16;
+__device__ __forceinline__ float fold_slices(const float* __restrict__ p, const long slices, const int C, const int c, const int phase)
 {
-	__shared__ float red[4][64];
-	const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
-	const int c = blockIdx.x * 64 + lane;
-	float s = 0.f;
-	if (c < C)
-		for (long i = phase; i < slices; i += 4) s += partial[i * C + c];
-	red[phase][lane] = s;
+	float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+	long i = phase;
+	for (; i + 3 * FOLD_PH < slices; i += 4 * FOLD_PH) {
+		s0 += p[i * C + c]; s1 += p[(i + FOLD_PH) * C + c]; s2 += p[(i + 2 * FOLD_PH) * C + c]; s3 += p[(i + 3 * FOLD_PH) * C + c];
+	}
+	for (; i < slices; i += FOLD_PH) s0 += p[i * C + c];
+	return (s0 + s1) + (s2 + s3);
+}
+__device__ __forceinline__ float fold_phases(float (*red)[FOLD_CH], const int ch)
+{ // after __syncthreads(): the 16 phase sums of channel ch, pairwise in a fixed order
+	float a[FOLD_PH];
+#pragma unroll
+	for (int k = 0; k < FOLD_PH; k++) a[k] = red[k][ch];
+#pragma unroll
+	for (int w = FOLD_PH / 2; w >= 1; w >>= 1)
+#pragma unroll
+		for (int k = 0; k < w; k++) a[k] = a[k] + a[k + w];
+	return a[0];
+}
+// out0[c] (+)= sum_i p0[i][c]  and, when p1 is given, out1[c] (+)= sum_i p1[i][c]  (blockIdx.y picks the array)
+__global__ void __launch_bounds__(256) chan_fold_kernel(const float* p0, const float* p1, const long slices, const int C, float* out0, float* out1, const int accumulate)
+{
+	__shared__ float red[FOLD_PH][FOLD_CH];
+	const int ch = threadIdx.x & (FOLD_CH - 1), phase = threadIdx.x / FOLD_CH;
+	const int c = blockIdx.x * FOLD_CH + ch;
+	const float* const p = blockIdx.y ? p1 : p0;
+	float* const out = blockIdx.y ? out1 : out0;
+	red[phase][ch] = c < C ? fold_slices(p, slices, C, c, phase) : 0.f;
 	__syncthreads();
 	if (phase == 0 && c < C) {
-		const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+		const float v = fold_phases(red, ch);
 		out[c] = accumulate ? out[c] + v : v;
 	}
 }
 
-template <class F, bool USE_G>
-static int chan_reduce(F f, const float* x, const float* g, const chan_view_t& v, float* out, ccv_nnc_stream_context_t* ctx, const int accumulate = 0)
+template <class F, bool USE_G, class T = float>
+static int chan_reduce(F f, const T* x, const T* g, const chan_view_t& v, float* out, ccv_nnc_stream_context_t* ctx, const int accumulate = 0)
 {
 	hipStream_t stream = stream_of(ctx);
 	long slices;
@@ -99,16 +128,16 @@ static int chan_reduce(F f, const float* x, const float* g, const chan_view_t& v
 		slices = v.outer > 0 ? (v.outer + rps - 1) / rps : 1;
 		partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * v.C);
 		if (!partial) return CCV_NNC_EXEC_OOM;
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_rows_kernel<F, USE_G>), dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, f, x, g, v.outer, v.C, rps > 0 ? rps : 1, partial);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_rows_kernel<F, USE_G, T>), dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, f, x, g, v.outer, v.C, rps > 0 ? rps : 1, partial);
 	} else {
 		slices = v.outer;
 		partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * v.C);
 		if (!partial) return CCV_NNC_EXEC_OOM;
 		const long planes = v.outer * v.C, want = (planes + 3) / 4, cap = (long)device_cu_count() * 8;
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_planes_kernel<F, USE_G>), dim3((unsigned)(want < cap ? (want > 0 ? want : 1) : cap)), dim3(256), 0, stream, f, x, g, v.C, v.inner, planes, partial);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_planes_kernel<F, USE_G, T>), dim3((unsigned)(want < cap ? (want > 0 ? want : 1) : cap)), dim3(256), 0, stream, f, x, g, v.C, v.inner, planes, partial);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, stream, (const float*)partial, slices, v.C, out, accumulate);
+	hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + FOLD_CH - 1) / FOLD_CH), dim3(256), 0, stream, (const float*)partial, (const float*)0, slices, v.C, out, (float*)0, accumulate);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -122,27 +151,34 @@ static int chan_reduce(F f, const float* x, const float* g, const chan_view_t& v
 //     fold combines the N planes exactly (Chan et al.: M2 = sum_o [M2_o + n (mean_o - mean)^2]).  x comes from HBM once
 //     where the two-reduction form read it twice; accuracy is that of the reference's mean -> centred-variance order.
 //   backward statistics: sum of g and sum of xhat * g in one sweep over (x, g).
-template <class OP>
-__device__ __forceinline__ void plane_sweep(const float* __restrict__ p, const long inner, const int lane, OP op)
+template <class T, class OP>
+__device__ __forceinline__ void plane_sweep(const T* __restrict__ p, const long inner, const int lane, OP op)
 {
-	if ((inner & 3) == 0 && (((uintptr_t)p) & 15) == 0) {
-		const float4* const p4 = (const float4*)p;
-		const long n4 = inner >> 2;
-		for (long i = lane; i < n4; i += 64) { const float4 v = p4[i]; op(v.x, i * 4); op(v.y, i * 4 + 1); op(v.z, i * 4 + 2); op(v.w, i * 4 + 3); }
+	constexpr int W = 16 / sizeof(T);
+	typedef typename pack16<T>::type V;
+	if ((inner % W) == 0 && (((uintptr_t)p) & 15) == 0) {
+		const V* const pv = (const V*)p;
+		const long nv = inner / W;
+		for (long i = lane; i < nv; i += 64) {
+			const V v = pv[i];
+#pragma unroll
+			for (int e = 0; e < W; e++) op((float)v[e], i * W + e);
+		}
 	} else
-		for (long i = lane; i < inner; i += 64) op(p[i], i);
+		for (long i = lane; i < inner; i += 64) op((float)p[i], i);
 }
 __device__ __forceinline__ float wave_sum(float s)
 {
 	for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64); // butterfly: every lane ends with the same total
 	return s;
 }
-__global__ void __launch_bounds__(256) bn_plane_stats_kernel(const float* __restrict__ x, const long planes, const long inner, float* __restrict__ psum, float* __restrict__ pm2)
+template <class T>
+__global__ void __launch_bounds__(256) bn_plane_stats_kernel(const T* __restrict__ x, const long planes, const long inner, float* __restrict__ psum, float* __restrict__ pm2)
 {
 	const int lane = threadIdx.x & 63;
 	const long nw = (long)gridDim.x * 4;
 	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
-		const float* const p = x + pl * inner;
+		const T* const p = x + pl * inner;
 		float s = 0.f;
 		plane_sweep(p, inner, lane, [&](const float v, long) { s += v; });
 		s = wave_sum(s);
@@ -153,27 +189,33 @@ __global__ void __launch_bounds__(256) bn_plane_stats_kernel(const float* __rest
 		if (lane == 0) { psum[pl] = s; pm2[pl] = q; }
 	}
 }
-// per channel: fold the planes (fixed order), then everything bn_mean_kernel + bn_var_kernel do.  One workgroup per 64 channels.
+// per channel: fold the planes (fixed order), then everything bn_mean_kernel + bn_var_kernel do.  16 channels x 16 phases per
+// workgroup like chan_fold_kernel.
 __global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restrict__ psum, const float* __restrict__ pm2, const long outer, const int C, const float inner, float* saved_mean, float* saved_inv_std, float* mean, float* var, const float* scale, const float* bias, float* nscale, float* nbias, const float inv_b, const float mom, const float eps)
 {
-	__shared__ float red[4][64];
-	__shared__ float mu_s[64];
-	const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
-	const int c = blockIdx.x * 64 + lane;
-	float s = 0.f;
-	if (c < C) for (long o = phase; o < outer; o += 4) s += psum[o * C + c];
-	red[phase][lane] = s;
+	__shared__ float red[FOLD_PH][FOLD_CH];
+	__shared__ float mu_s[FOLD_CH];
+	const int ch = threadIdx.x & (FOLD_CH - 1), phase = threadIdx.x / FOLD_CH;
+	const int c = blockIdx.x * FOLD_CH + ch;
+	red[phase][ch] = c < C ? fold_slices(psum, outer, C, c, phase) : 0.f;
 	__syncthreads();
-	if (phase == 0) mu_s[lane] = inv_b * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+	if (phase == 0) mu_s[ch] = inv_b * fold_phases(red, ch);
 	__syncthreads();
-	const float mu = mu_s[lane];
-	float q = 0.f;
-	if (c < C) for (long o = phase; o < outer; o += 4) { const float d = psum[o * C + c] / inner - mu; q += pm2[o * C + c] + inner * d * d; }
-	__syncthreads();
-	red[phase][lane] = q;
+	const float mu = mu_s[ch], inv_inner = 1.f / inner;
+	float q0 = 0.f, q1 = 0.f;
+	if (c < C) {
+		long o = phase;
+		for (; o + FOLD_PH < outer; o += 2 * FOLD_PH) {
+			const float d0 = psum[o * C + c] * inv_inner - mu, d1 = psum[(o + FOLD_PH) * C + c] * inv_inner - mu;
+			q0 += pm2[o * C + c] + inner * d0 * d0;
+			q1 += pm2[(o + FOLD_PH) * C + c] + inner * d1 * d1;
+		}
+		for (; o < outer; o += FOLD_PH) { const float d = psum[o * C + c] * inv_inner - mu; q0 += pm2[o * C + c] + inner * d * d; }
+	}
+	red[phase][ch] = q0 + q1;
 	__syncthreads();
 	if (phase != 0 || c >= C) return;
-	const float v = inv_b * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+	const float v = inv_b * fold_phases(red, ch);
 	saved_mean[c] = mu;
 	mean[c] = mom * mean[c] + (1.f - mom) * mu;
 	var[c] = mom * var[c] + (1.f - mom) * v;
@@ -183,27 +225,28 @@ __global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restr
 	nscale[c] = w;
 	nbias[c] = bias[c] - mu * w;
 }
-__global__ void __launch_bounds__(256) bn_plane_back_stats_kernel(const float* __restrict__ x, const float* __restrict__ g, const long planes, const int C, const long inner, const float* __restrict__ mean, const float* __restrict__ inv_std, float* __restrict__ pg, float* __restrict__ pxg)
+template <class T>
+__global__ void __launch_bounds__(256) bn_plane_back_stats_kernel(const T* __restrict__ x, const T* __restrict__ g, const long planes, const int C, const long inner, const float* __restrict__ mean, const float* __restrict__ inv_std, float* __restrict__ pg, float* __restrict__ pxg)
 {
+	constexpr int W = 16 / sizeof(T);
+	typedef typename pack16<T>::type V;
 	const int lane = threadIdx.x & 63;
 	const long nw = (long)gridDim.x * 4;
 	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
 		const int c = (int)(pl % C);
 		const float mu = mean[c], is = inv_std[c];
-		const float* const gp = g + pl * inner;
-		const float* const xp = x + pl * inner;
+		const T* const gp = g + pl * inner;
+		const T* const xp = x + pl * inner;
 		float sg = 0.f, sx = 0.f;
-		if ((inner & 3) == 0 && ((((uintptr_t)gp) | ((uintptr_t)xp)) & 15) == 0) {
-			const long n4 = inner >> 2;
-			for (long i = lane; i < n4; i += 64) {
-				const float4 gv = ((const float4*)gp)[i], xv = ((const float4*)xp)[i];
-				sg += gv.x; sx += (xv.x - mu) * is * gv.x;
-				sg += gv.y; sx += (xv.y - mu) * is * gv.y;
-				sg += gv.z; sx += (xv.z - mu) * is * gv.z;
-				sg += gv.w; sx += (xv.w - mu) * is * gv.w;
+		if ((inner % W) == 0 && ((((uintptr_t)gp) | ((uintptr_t)xp)) & 15) == 0) {
+			const long nv = inner / W;
+			for (long i = lane; i < nv; i += 64) {
+				const V gv = ((const V*)gp)[i], xv = ((const V*)xp)[i];
+#pragma unroll
+				for (int e = 0; e < W; e++) { sg += (float)gv[e]; sx += ((float)xv[e] - mu) * is * (float)gv[e]; }
 			}
 		} else
-			for (long i = lane; i < inner; i += 64) { const float gv = gp[i]; sg += gv; sx += (xp[i] - mu) * is * gv; }
+			for (long i = lane; i < inner; i += 64) { const float gv = (float)gp[i]; sg += gv; sx += ((float)xp[i] - mu) * is * gv; }
 		sg = wave_sum(sg); sx = wave_sum(sx);
 		if (lane == 0) { pg[pl] = sg; pxg[pl] = sx; }
 	}
@@ -245,24 +288,79 @@ __global__ void bn_test_affine_kernel(const float* mean, const float* var, const
 	nscale[c] = w;
 	nbias[c] = bias[c] - mean[c] * w;
 }
-// y = x * nscale[c] + nbias[c]
-__global__ void __launch_bounds__(256) bn_apply_kernel(const float* x, float* y, const float* nscale, const float* nbias, const size_t n, const int C, const long inner)
+// y = x * nscale[c] + nbias[c]   (any layout: one element per lane; the plane kernels below are the NCHW fast path)
+template <class T>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, T* y, const float* nscale, const float* nbias, const size_t n, const int C, const long inner)
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
 		const int c = (int)((inner == 1 ? i : i / inner) % C);
-		y[i] = x[i] * nscale[c] + nbias[c];
+		y[i] = (T)((float)x[i] * nscale[c] + nbias[c]);
 	}
 }
 // h = (scale * inv_std / B) * (B * g - dbias - xhat * dscale)      (:440-470)
-__global__ void __launch_bounds__(256) bn_back_kernel(const float* x, const float* g, float* h, const float* scale, const float* mean, const float* inv_std, const float* dscale, const float* dbias, const size_t n, const int C, const long inner, const float B)
+template <class T>
+__global__ void __launch_bounds__(256) bn_back_kernel(const T* x, const T* g, T* h, const float* scale, const float* mean, const float* inv_std, const float* dscale, const float* dbias, const size_t n, const int C, const long inner, const float B)
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
 		const int c = (int)((inner == 1 ? i : i / inner) % C);
 		const float is = inv_std[c];
-		const float xhat = (x[i] - mean[c]) * is;
-		h[i] = (1.f / B * scale[c] * is) * (B * g[i] - dbias[c] - xhat * dscale[c]);
+		const float xhat = ((float)x[i] - mean[c]) * is;
+		h[i] = (T)((1.f / B * scale[c] * is) * (B * (float)g[i] - dbias[c] - xhat * dscale[c]));
+	}
+}
+// The same two maps, a wave per plane (inner > 1): the channel is one modulo per plane instead of a 64-bit division per element,
+// 16-byte accesses when the plane allows.  h = a * g + b * x + k with per-channel a, b, k.
+template <class T>
+__global__ void __launch_bounds__(256) bn_apply_planes_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ nscale, const float* __restrict__ nbias, const long planes, const int C, const long inner)
+{
+	constexpr int W = 16 / sizeof(T);
+	typedef typename pack16<T>::type V;
+	const int lane = threadIdx.x & 63;
+	const long nw = (long)gridDim.x * 4;
+	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+		const int c = (int)(pl % C);
+		const float w = nscale[c], b = nbias[c];
+		const T* const xp = x + pl * inner;
+		T* const yp = y + pl * inner;
+		if ((inner % W) == 0 && ((((uintptr_t)xp) | ((uintptr_t)yp)) & 15) == 0) {
+			const long nv = inner / W;
+			for (long i = lane; i < nv; i += 64) {
+				const V v = ((const V*)xp)[i];
+				V r;
+#pragma unroll
+				for (int e = 0; e < W; e++) r[e] = (T)((float)v[e] * w + b);
+				((V*)yp)[i] = r;
+			}
+		} else
+			for (long i = lane; i < inner; i += 64) yp[i] = (T)((float)xp[i] * w + b);
+	}
+}
+template <class T>
+__global__ void __launch_bounds__(256) bn_back_planes_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ h, const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ dscale, const float* __restrict__ dbias, const long planes, const int C, const long inner, const float B)
+{
+	constexpr int W = 16 / sizeof(T);
+	typedef typename pack16<T>::type V;
+	const int lane = threadIdx.x & 63;
+	const long nw = (long)gridDim.x * 4;
+	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+		const int c = (int)(pl % C);
+		const float is = inv_std[c], mu = mean[c], k = 1.f / B * scale[c] * is, db = dbias[c], ds = dscale[c];
+		const T* const xp = x + pl * inner;
+		const T* const gp = g + pl * inner;
+		T* const hp = h + pl * inner;
+		if ((inner % W) == 0 && ((((uintptr_t)xp) | ((uintptr_t)gp) | ((uintptr_t)hp)) & 15) == 0) {
+			const long nv = inner / W;
+			for (long i = lane; i < nv; i += 64) {
+				const V xv = ((const V*)xp)[i], gv = ((const V*)gp)[i];
+				V r;
+#pragma unroll
+				for (int e = 0; e < W; e++) { const float xhat = ((float)xv[e] - mu) * is; r[e] = (T)(k * (B * (float)gv[e] - db - xhat * ds)); }
+				((V*)hp)[i] = r;
+			}
+		} else
+			for (long i = lane; i < inner; i += 64) { const float xhat = ((float)xp[i] - mu) * is; hp[i] = (T)(k * (B * (float)gp[i] - db - xhat * ds)); }
 	}
 }
 
@@ -304,13 +402,18 @@ static bool chan_view(const ccv_nnc_tensor_t* x, const ccv_nnc_tensor_t* stat, c
 	return true;
 }
 
-static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+// T: the element type of x and y (float, or _Float16 when half_stage.cpp hands the trainer's CCV_16F activations through as they
+// are); the statistics, scale and bias are fp32 here either way.
+template <class T>
+static int bnorm_forw_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	if (input_size != 5 || output_size < 1) return CCV_NNC_EXEC_INVALID;
-	for (int i = 0; i < 5; i++) if (!inputs[i] || CCV_GET_DATA_TYPE(inputs[i]->info.datatype) != CCV_32F || !tensor_contiguous(inputs[i])) return CCV_NNC_EXEC_INVALID;
+	for (int i = 0; i < 5; i++) if (!inputs[i] || (i > 0 && CCV_GET_DATA_TYPE(inputs[i]->info.datatype) != CCV_32F) || !tensor_contiguous(inputs[i])) return CCV_NNC_EXEC_INVALID;
 	const ccv_nnc_tensor_t* x = inputs[0];
 	ccv_nnc_tensor_t* y = outputs[0];
-	if (!y || !tensor_contiguous(y) || tensor_count(y->info) != tensor_count(x->info)) return CCV_NNC_EXEC_INVALID;
+	if (!y || !tensor_contiguous(y) || tensor_count(y->info) != tensor_count(x->info) || y->info.datatype != x->info.datatype) return CCV_NNC_EXEC_INVALID;
+	const T* const xp = (const T*)x->data.u8;
+	T* const yp = (T*)y->data.u8;
 	chan_view_t v;
 	if (!chan_view(x, inputs[1], &v)) return CCV_NNC_EXEC_INVALID;
 	for (int i = 1; i < 5; i++) if ((int)tensor_count(inputs[i]->info) != v.C) return CCV_NNC_EXEC_INVALID;
@@ -318,7 +421,7 @@ static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
 	hipStream_t stream = stream_of(stream_context);
 	// (bench.py roofline leg, config 4: the whole command between two events; algorithmic bytes = x read once + y written once)
-	ProfScope prof(cmd.info.bnorm.is_test ? "bnorm_fwd_test|nnc::bn_apply_kernel" : "bnorm_fwd|nnc::chan_reduce + bn_apply_kernel", 0, 2.0 * sizeof(float) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream);
+	ProfScope prof(cmd.info.bnorm.is_test ? "bnorm_fwd_test|nnc::bn_apply_kernel" : "bnorm_fwd|nnc::chan_reduce + bn_apply_kernel", 0, 2.0 * sizeof(T) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream);
 	const float* scale = inputs[1]->data.f32;
 	const float* bias = inputs[2]->data.f32;
 	float* mean = inputs[3]->data.f32;
@@ -343,26 +446,36 @@ static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 			const long planes = v.outer * v.C;
 			float* const psum = (float*)workspace_of(stream_context, sizeof(float) * 2 * (size_t)planes);
 			if (!psum) return CCV_NNC_EXEC_OOM;
-			hipLaunchKernelGGL(bn_plane_stats_kernel, dim3(plane_grid(planes)), dim3(256), 0, stream, (const float*)x->data.f32, planes, v.inner, psum, psum + planes);
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_plane_stats_kernel<T>), dim3(plane_grid(planes)), dim3(256), 0, stream, xp, planes, v.inner, psum, psum + planes);
 			HIP_ENFORCE(hipGetLastError());
-			hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, stream, (const float*)psum, (const float*)(psum + planes), v.outer, v.C, (float)v.inner, saved_mean, saved_inv_std, mean, var, scale, bias, nscale, nbias, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon);
+			hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((v.C + FOLD_CH - 1) / FOLD_CH), dim3(256), 0, stream, (const float*)psum, (const float*)(psum + planes), v.outer, v.C, (float)v.inner, saved_mean, saved_inv_std, mean, var, scale, bias, nscale, nbias, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon);
 			HIP_ENFORCE(hipGetLastError());
 		} else {
-		if ((ret = chan_reduce<RSum, false>(RSum(), x->data.f32, 0, v, saved_mean, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = chan_reduce<RSum, false, T>(RSum(), xp, (const T*)0, v, saved_mean, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		hipLaunchKernelGGL(bn_mean_kernel, dim3(cb), dim3(256), 0, stream, saved_mean, mean, v.C, inv_b, cmd.info.bnorm.momentum);
 		RCenteredSq f; f.mean = saved_mean;
-		if ((ret = chan_reduce<RCenteredSq, false>(f, x->data.f32, 0, v, saved_inv_std, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = chan_reduce<RCenteredSq, false, T>(f, xp, (const T*)0, v, saved_inv_std, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		hipLaunchKernelGGL(bn_var_kernel, dim3(cb), dim3(256), 0, stream, saved_inv_std, var, (const float*)saved_mean, scale, bias, nscale, nbias, v.C, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon);
 		}
 	} else
 		hipLaunchKernelGGL(bn_test_affine_kernel, dim3(cb), dim3(256), 0, stream, (const float*)mean, (const float*)var, scale, bias, nscale, nbias, v.C, cmd.info.bnorm.epsilon);
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, (const float*)x->data.f32, y->data.f32, (const float*)nscale, (const float*)nbias, n, v.C, v.inner);
+	if (v.inner > 1)
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_planes_kernel<T>), dim3(plane_grid(v.outer * v.C)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, v.outer * v.C, v.C, v.inner);
+	else
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, n, v.C, v.inner);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
-static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size >= 1 && inputs[0] && CCV_GET_DATA_TYPE(inputs[0]->info.datatype) == CCV_16F) return bnorm_forw_t<half_t>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	return bnorm_forw_t<float>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+}
+
+template <class T>
+static int bnorm_back_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	// inputs 0 (g), 5 (x), 6 (scale), 13 (saved_mean), 14 (saved_inv_std) of 15; outputs (h, dscale, dbias)   (ccv_nnc_norm.c:28-36)
 	if (input_size != 15 || output_size < 3) return CCV_NNC_EXEC_INVALID;
@@ -375,7 +488,11 @@ static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 	ccv_nnc_tensor_t* dscale = outputs[1];
 	ccv_nnc_tensor_t* dbias = outputs[2];
 	if (!g || !x || !scale || !saved_mean || !saved_inv_std || !h || !dscale || !dbias) return CCV_NNC_EXEC_INVALID;
-	if (CCV_GET_DATA_TYPE(x->info.datatype) != CCV_32F || !tensor_contiguous(g) || !tensor_contiguous(h)) return CCV_NNC_EXEC_INVALID;
+	if (!tensor_contiguous(g) || !tensor_contiguous(h) || g->info.datatype != x->info.datatype || h->info.datatype != x->info.datatype) return CCV_NNC_EXEC_INVALID;
+	if (CCV_GET_DATA_TYPE(scale->info.datatype) != CCV_32F || CCV_GET_DATA_TYPE(saved_mean->info.datatype) != CCV_32F || CCV_GET_DATA_TYPE(saved_inv_std->info.datatype) != CCV_32F || CCV_GET_DATA_TYPE(dscale->info.datatype) != CCV_32F || CCV_GET_DATA_TYPE(dbias->info.datatype) != CCV_32F) return CCV_NNC_EXEC_INVALID;
+	const T* const xp = (const T*)x->data.u8;
+	const T* const gp = (const T*)g->data.u8;
+	T* const hp = (T*)h->data.u8;
 	chan_view_t v;
 	if (!chan_view(x, scale, &v)) return CCV_NNC_EXEC_INVALID;
 	const size_t n = tensor_count(x->info);
@@ -383,25 +500,32 @@ static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 	if ((int)tensor_count(saved_mean->info) != v.C || (int)tensor_count(saved_inv_std->info) != v.C || (int)tensor_count(dscale->info) != v.C || (int)tensor_count(dbias->info) != v.C) return CCV_NNC_EXEC_INVALID;
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
 	int ret;
-	ProfScope prof("bnorm_bwd|nnc::chan_reduce + bn_back_kernel", 0, 3.0 * sizeof(float) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream_of(stream_context)); // g, x read; h written
+	ProfScope prof("bnorm_bwd|nnc::chan_reduce + bn_back_kernel", 0, 3.0 * sizeof(T) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream_of(stream_context)); // g, x read; h written
 	if (v.inner > 1) { // planes: both sums in one sweep over (x, g)
 		const long planes = v.outer * v.C;
 		float* const pg = (float*)workspace_of(stream_context, sizeof(float) * 2 * (size_t)planes);
 		if (!pg) return CCV_NNC_EXEC_OOM;
 		hipStream_t st = stream_of(stream_context);
-		hipLaunchKernelGGL(bn_plane_back_stats_kernel, dim3(plane_grid(planes)), dim3(256), 0, st, (const float*)x->data.f32, (const float*)g->data.f32, planes, v.C, v.inner, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, pg, pg + planes);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_plane_back_stats_kernel<T>), dim3(plane_grid(planes)), dim3(256), 0, st, xp, gp, planes, v.C, v.inner, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, pg, pg + planes);
 		HIP_ENFORCE(hipGetLastError());
-		hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, st, (const float*)pg, v.outer, v.C, dbias->data.f32, 0);
-		hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + 63) / 64), dim3(256), 0, st, (const float*)(pg + planes), v.outer, v.C, dscale->data.f32, 0);
+		hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + FOLD_CH - 1) / FOLD_CH, 2), dim3(256), 0, st, (const float*)pg, (const float*)(pg + planes), v.outer, v.C, dbias->data.f32, dscale->data.f32, 0);
 		HIP_ENFORCE(hipGetLastError());
 	} else {
-	if ((ret = chan_reduce<RSum, false>(RSum(), g->data.f32, 0, v, dbias->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	if ((ret = chan_reduce<RSum, false, T>(RSum(), gp, (const T*)0, v, dbias->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	RXhatG f; f.mean = saved_mean->data.f32; f.inv_std = saved_inv_std->data.f32;
-	if ((ret = chan_reduce<RXhatG, true>(f, x->data.f32, g->data.f32, v, dscale->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+	if ((ret = chan_reduce<RXhatG, true, T>(f, xp, gp, v, dscale->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
-	hipLaunchKernelGGL(bn_back_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream_of(stream_context), (const float*)x->data.f32, (const float*)g->data.f32, h->data.f32, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, n, v.C, v.inner, (float)(n / v.C));
+	if (v.inner > 1)
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_back_planes_kernel<T>), dim3(plane_grid(v.outer * v.C)), dim3(256), 0, stream_of(stream_context), xp, gp, hp, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, v.outer * v.C, v.C, v.inner, (float)(n / v.C));
+	else
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_back_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, stream_of(stream_context), xp, gp, hp, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, n, v.C, v.inner, (float)(n / v.C));
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
+}
+static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (input_size > 5 && inputs[5] && CCV_GET_DATA_TYPE(inputs[5]->info.datatype) == CCV_16F) return bnorm_back_t<half_t>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	return bnorm_back_t<float>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 }
 
 } // namespace
@@ -411,7 +535,7 @@ int nnc::chan_sum_planes(const float* x, long outer, int C, long inner, float* o
 {
 	chan_view_t v;
 	v.outer = outer; v.C = C; v.inner = inner;
-	return chan_reduce<RSum, false>(RSum(), x, 0, v, out, ctx, accumulate);
+	return chan_reduce<RSum, false, float>(RSum(), x, (const float*)0, v, out, ctx, accumulate);
 }
 
 #define NNC_REG(CMD, BACKEND, FORMATS, DATATYPES, MEMORY, EXEC) \

@@ -18,6 +18,7 @@ using namespace nnc;
 
 namespace {
 
+typedef _Float16 half_t;
 struct pool_geom_t {
 	int N, H, W, C, OH, OW;
 	int kh, kw, sy, sx, pby, pbx;
@@ -42,8 +43,9 @@ __device__ __forceinline__ void unflatten(int idx, const FastDiv& d1, const Fast
 	}
 }
 
-template <bool NHWC, bool IS_MAX>
-__global__ void __launch_bounds__(256) pool_forw_kernel(const pool_geom_t g, const float* a, float* b, const size_t total)
+// T = float, or _Float16 for the half-precision trainers' tensors (values compared / summed as fp32: exact for the maximum)
+template <bool NHWC, bool IS_MAX, class T>
+__global__ void __launch_bounds__(256) pool_forw_kernel(const pool_geom_t g, const T* a, T* b, const size_t total)
 {
 	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, oy, ox, c;
@@ -54,22 +56,22 @@ __global__ void __launch_bounds__(256) pool_forw_kernel(const pool_geom_t g, con
 		if (x0 < 0) x0 = 0;
 		if (y1 > g.H) y1 = g.H;
 		if (x1 > g.W) x1 = g.W;
-		const float* ap = a + n * g.a_sn + c * g.a_sc;
+		const T* ap = a + n * g.a_sn + c * g.a_sc;
 		float v;
 		if (IS_MAX) {
-			v = ap[y0 * g.a_sh + x0 * g.a_sw];
+			v = (float)ap[y0 * g.a_sh + x0 * g.a_sw];
 			for (int y = y0; y < y1; y++)
 				for (int x = x0; x < x1; x++) {
-					const float u = ap[y * g.a_sh + x * g.a_sw];
+					const float u = (float)ap[y * g.a_sh + x * g.a_sw];
 					if (u > v) v = u;
 				}
 		} else {
 			v = 0.f;
 			for (int y = y0; y < y1; y++)
-				for (int x = x0; x < x1; x++) v += ap[y * g.a_sh + x * g.a_sw];
+				for (int x = x0; x < x1; x++) v += (float)ap[y * g.a_sh + x * g.a_sw];
 			v = v / (float)((y1 - y0) * (x1 - x0));
 		}
-		b[n * g.b_sn + oy * g.b_sh + ox * g.b_sw + c * g.b_sc] = v;
+		b[n * g.b_sn + oy * g.b_sh + ox * g.b_sw + c * g.b_sc] = (T)v;
 	}
 }
 
@@ -77,8 +79,8 @@ __global__ void __launch_bounds__(256) pool_forw_kernel(const pool_geom_t g, con
 __device__ __forceinline__ int ceil_div(int a, int b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); }
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-template <bool NHWC, bool IS_MAX>
-__global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, const float* gr, const float* a, const float* b, float* h, const size_t total)
+template <bool NHWC, bool IS_MAX, class T>
+__global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, const T* gr, const T* a, const T* b, T* h, const size_t total)
 {
 	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, y, x, c;
@@ -92,12 +94,12 @@ __global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, con
 		const long ob = n * g.b_sn + c * g.b_sc;
 		float acc = 0.f;
 		float av = 0.f;
-		if (IS_MAX) av = a[n * g.a_sn + y * g.a_sh + x * g.a_sw + c * g.a_sc];
+		if (IS_MAX) av = (float)a[n * g.a_sn + y * g.a_sh + x * g.a_sw + c * g.a_sc];
 		for (int oy = oy0; oy <= oy1; oy++)
 			for (int ox = ox0; ox <= ox1; ox++) {
 				const long o = ob + oy * g.b_sh + ox * g.b_sw;
 				if (IS_MAX) {
-					if (av == b[o]) acc += gr[o];
+					if (av == (float)b[o]) acc += (float)gr[o];
 				} else {
 					int wy0 = oy * g.sy - g.pby, wx0 = ox * g.sx - g.pbx;
 					int wy1 = wy0 + g.kh, wx1 = wx0 + g.kw;
@@ -105,10 +107,10 @@ __global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, con
 					if (wx0 < 0) wx0 = 0;
 					if (wy1 > g.H) wy1 = g.H;
 					if (wx1 > g.W) wx1 = g.W;
-					acc += gr[o] / (float)((wy1 - wy0) * (wx1 - wx0));
+					acc += (float)gr[o] / (float)((wy1 - wy0) * (wx1 - wx0));
 				}
 			}
-		h[n * g.a_sn + y * g.a_sh + x * g.a_sw + c * g.a_sc] = acc;
+		h[n * g.a_sn + y * g.a_sh + x * g.a_sw + c * g.a_sc] = (T)acc;
 	}
 }
 
@@ -242,6 +244,8 @@ static int pool_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	pool_geom_t g;
 	bool nhwc;
 	if (!pool_geometry(cmd, hint, inputs[0], outputs[0], &g, &nhwc)) return CCV_NNC_EXEC_INVALID;
+	const bool half = CCV_GET_DATA_TYPE(inputs[0]->info.datatype) == CCV_16F;
+	if (inputs[0]->info.datatype != outputs[0]->info.datatype) return CCV_NNC_EXEC_INVALID;
 	const size_t per_image = (size_t)g.OH * g.OW * g.C;
 	if (per_image == 0 || g.N == 0) return CCV_NNC_EXEC_SUCCESS;
 	if (per_image >= 0x7fffffffUL) return CCV_NNC_EXEC_INVALID;
@@ -250,11 +254,19 @@ static int pool_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	for (int n0 = 0; n0 < g.N; n0 += nchunk) {
 		const int nn = g.N - n0 < nchunk ? g.N - n0 : nchunk;
 		const size_t total = per_image * nn;
+		if (half) {
+			const half_t* ap = (const half_t*)inputs[0]->data.f16 + (long)n0 * g.a_sn;
+			half_t* bp = (half_t*)outputs[0]->data.f16 + (long)n0 * g.b_sn;
+			if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<true, IS_MAX, half_t>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<false, IS_MAX, half_t>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
+			HIP_ENFORCE(hipGetLastError());
+			continue;
+		}
 		const float* ap = inputs[0]->data.f32 + (long)n0 * g.a_sn;
 		float* bp = outputs[0]->data.f32 + (long)n0 * g.b_sn;
 		if (pool_vec4_ok(g, nhwc, ap, bp, 0, 0)) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_v4_kernel<IS_MAX>), dim3(grid_for(total / 4, 256)), dim3(256), 0, stream, g, ap, bp, total / 4);
-		else if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
+		else if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<true, IS_MAX, float>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_forw_kernel<false, IS_MAX, float>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, ap, bp, total);
 		HIP_ENFORCE(hipGetLastError());
 	}
 	return CCV_NNC_EXEC_SUCCESS;
@@ -277,6 +289,8 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	pool_geom_t g;
 	bool nhwc;
 	if (!pool_geometry(cmd, hint, h, gt, &g, &nhwc)) return CCV_NNC_EXEC_INVALID;
+	const bool half = CCV_GET_DATA_TYPE(h->info.datatype) == CCV_16F;
+	if (gt->info.datatype != h->info.datatype || (a && a->info.datatype != h->info.datatype) || (b && b->info.datatype != h->info.datatype)) return CCV_NNC_EXEC_INVALID;
 	const size_t per_image = (size_t)g.H * g.W * g.C;
 	if (per_image == 0 || g.N == 0) return CCV_NNC_EXEC_SUCCESS;
 	if (per_image >= 0x7fffffffUL) return CCV_NNC_EXEC_INVALID;
@@ -285,13 +299,23 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	for (int n0 = 0; n0 < g.N; n0 += nchunk) {
 		const int nn = g.N - n0 < nchunk ? g.N - n0 : nchunk;
 		const size_t total = per_image * nn;
+		if (half) {
+			const half_t* gp = (const half_t*)gt->data.f16 + (long)n0 * g.b_sn;
+			const half_t* ap = a ? (const half_t*)a->data.f16 + (long)n0 * g.a_sn : 0;
+			const half_t* bp = b ? (const half_t*)b->data.f16 + (long)n0 * g.b_sn : 0;
+			half_t* hp = (half_t*)h->data.f16 + (long)n0 * g.a_sn;
+			if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX, half_t>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX, half_t>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
+			HIP_ENFORCE(hipGetLastError());
+			continue;
+		}
 		const float* gp = gt->data.f32 + (long)n0 * g.b_sn;
 		const float* ap = a ? a->data.f32 + (long)n0 * g.a_sn : 0;
 		const float* bp = b ? b->data.f32 + (long)n0 * g.b_sn : 0;
 		float* hp = h->data.f32 + (long)n0 * g.a_sn;
 		if (pool_vec4_ok(g, nhwc, gp, hp, ap, bp)) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_v4_kernel<IS_MAX>), dim3(grid_for(total / 4, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total / 4);
-		else if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
+		else if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX, float>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX, float>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
 		HIP_ENFORCE(hipGetLastError());
 	}
 	return CCV_NNC_EXEC_SUCCESS;

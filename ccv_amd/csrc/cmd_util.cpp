@@ -58,6 +58,27 @@ __global__ void __launch_bounds__(256) transpose_tile_kernel(const T* in, T* out
 	}
 }
 
+// The same tile transpose with a type change on the way through LDS: half-precision NCHW tensors become the fp32 NHWC images the
+// fp32 convolution kernels read (and back) in ONE pass each -- the layout change the NCHW path needs anyway carries the conversion,
+// where converting first and transposing second moved every element twice more.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) transpose_convert_kernel(const TI* in, TO* out, const int R, const int C)
+{
+	__shared__ float tile[TT][TT + 1];
+	const int c0 = blockIdx.x * TT, r0 = blockIdx.y * TT;
+	const size_t base = (size_t)blockIdx.z * R * C;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	for (int j = ty; j < TT; j += 4) {
+		const int r = r0 + j, c = c0 + tx;
+		if (r < R && c < C) tile[j][tx] = (float)in[base + (size_t)r * C + c];
+	}
+	__syncthreads();
+	for (int j = ty; j < TT; j += 4) {
+		const int c = c0 + j, r = r0 + tx;
+		if (r < R && c < C) out[base + (size_t)c * R + r] = (TO)tile[tx][j];
+	}
+}
+
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) convert_kernel(const TI* in, TO* out, const size_t n)
 {
@@ -166,6 +187,21 @@ int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_str
 }
 
 // Dense weight layout change [K][C][kh][kw] (NCHW-format weights) -> [K][kh][kw][C] (the layout the kernels read).
+// in[batch][R][C] -> out[batch][C][R], halves in / floats out and the reverse
+int transpose_half_to_float(const void* in, float* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
+{
+	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_convert_kernel<half_t, float>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, out, R, C);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+int transpose_float_to_half(const float* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
+{
+	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_convert_kernel<float, half_t>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), in, (half_t*)out, R, C);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
 int weights_nchw_to_nhwc(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx)
 {
 	return launch_transpose<uint32_t>(w, out, K, C, khw, ctx);

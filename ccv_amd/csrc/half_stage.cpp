@@ -186,6 +186,39 @@ void warn_refused(const uint32_t cmd, const int ret)
 	if (counts[i]++ < 3) fprintf(stderr, "[nnc-mi355x] command 0x%08x refused with %d (INVALID -1 / NO_KERNEL -2 / OOM -3): its outputs were NOT written\n", cmd, ret);
 }
 
+// Rows whose kernels read and write their LARGE tensors in half precision themselves (loads / stores of halves, fp32 arithmetic:
+// cmd_ew.cpp, cmd_norm.cpp, cmd_pool.cpp).  Bit i of `in` / `out` = that input / output stays in its own memory when every tensor
+// named by the masks is a dense CCV_16F tensor; the row's small tensors (batch-norm statistics, ...) still get fp32 images.
+static long g_half_staged = 0, g_half_native = 0; // nnc_mi355x_debug_half_counts (test hook; not synchronised: counts, not control)
+struct native_half_t { uint32_t cmd; unsigned in, out; };
+static const native_half_t g_native_half[] = {
+	{ CCV_NNC_RELU_FORWARD, 1u << 0, 1u << 0 },
+	{ CCV_NNC_RELU_BACKWARD, (1u << 0) | (1u << 2), 1u << 0 },            // g, (a unused), b -> h
+	{ CCV_NNC_EWSUM_FORWARD, ~0u, 1u << 0 },
+	{ CCV_NNC_EWSUM_BACKWARD, 1u << 0, ~0u },
+	{ CCV_NNC_BATCH_NORM_FORWARD, 1u << 0, 1u << 0 },                     // x -> y
+	{ CCV_NNC_BATCH_NORM_BACKWARD, (1u << 0) | (1u << 5), 1u << 0 },      // g, x -> h
+	{ CCV_NNC_MAX_POOL_FORWARD, 1u << 0, 1u << 0 },
+	{ CCV_NNC_MAX_POOL_BACKWARD, (1u << 0) | (1u << 1) | (1u << 2), 1u << 0 }, // g, x, y -> h
+	{ CCV_NNC_AVERAGE_POOL_FORWARD, 1u << 0, 1u << 0 },
+	{ CCV_NNC_AVERAGE_POOL_BACKWARD, 1u << 0, 1u << 0 },
+	{ CCV_NNC_SGD_FORWARD, (1u << 0) | (1u << 1) | (1u << 2), (1u << 0) | (1u << 1) }, // g, a, m -> b, n
+};
+static const native_half_t* native_half_row(const uint32_t cmd, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size)
+{
+	if (flags & CCV_NNC_ACCUMULATE_OUTPUT) return 0;
+	for (const native_half_t& r : g_native_half) {
+		if (r.cmd != cmd) continue;
+		int seen = 0;
+		for (int i = 0; i < input_size && i < 32; i++)
+			if (((r.in >> i) & 1) && inputs[i]) { if (CCV_GET_DATA_TYPE(inputs[i]->info.datatype) != CCV_16F || CCV_IS_TENSOR_VIEW(inputs[i])) return 0; seen++; }
+		for (int i = 0; i < output_size && i < 32; i++)
+			if (((r.out >> i) & 1) && outputs[i]) { if (CCV_GET_DATA_TYPE(outputs[i]->info.datatype) != CCV_16F || CCV_IS_TENSOR_VIEW(outputs[i])) return 0; seen++; }
+		return seen ? &r : 0;
+	}
+	return 0;
+}
+
 int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
 {
 	MarkerScope marker(cmd.cmd); // every row registered through NNC_HALF_STAGED passes here: the per-command roctx range
@@ -224,9 +257,17 @@ int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_
 	// opaque tensors keep their own memory: the dropout mask is a byte buffer the host merely SIZES through a tensor of the data's
 	// type (ccv_nnc_dropout.c:21-45) -- output 1 of the forward command, input 4 of the backward one
 	const int opaque_in = cmd.cmd == CCV_NNC_DROPOUT_BACKWARD ? 4 : -1, opaque_out = cmd.cmd == CCV_NNC_DROPOUT_FORWARD ? 1 : -1;
-	for (int i = 0; i < input_size; i++) { if (i == opaque_in) which[i] = -1; else visit(inputs[i], false, i); }
-	for (int i = 0; i < output_size; i++) { if (i == opaque_out) which[input_size + i] = -1; else visit(outputs[i], true, input_size + i); }
+	const native_half_t* const native = native_half_row(cmd.cmd, flags, inputs, input_size, outputs, output_size);
+	for (int i = 0; i < input_size; i++) { if (i == opaque_in || (native && i < 32 && ((native->in >> i) & 1))) which[i] = -1; else visit(inputs[i], false, i); }
+	for (int i = 0; i < output_size; i++) { if (i == opaque_out || (native && i < 32 && ((native->out >> i) & 1))) which[input_size + i] = -1; else visit(outputs[i], true, input_size + i); }
 	for (int i = 0; i < nst; i++) total += (st[i].span * sizeof(float) + 255) & ~(size_t)255;
+	g_half_staged += nst;
+	if (native)
+		for (int i = 0; i < input_size + output_size; i++) {
+			ccv_nnc_tensor_t* const t = i < input_size ? inputs[i] : outputs[i - input_size];
+			const int k = i < input_size ? i : i - input_size;
+			if (t && k < 32 && (((i < input_size ? native->in : native->out) >> k) & 1)) g_half_native++;
+		}
 	char* arena = (char*)nnc_staging_of(ctx, total);
 	if (total && !arena) return CCV_NNC_EXEC_OOM;
 	size_t off = 0;
@@ -258,3 +299,9 @@ int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_
 }
 
 } // namespace nnc
+
+extern "C" void nnc_mi355x_debug_half_counts(long* staged, long* native)
+{
+	if (staged) *staged = nnc::g_half_staged;
+	if (native) *native = nnc::g_half_native;
+}

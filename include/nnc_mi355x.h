@@ -397,6 +397,9 @@ int  nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, doub
  * ((2,2) (2,1) (1,2) (1,1) exist); (0,0) restores the built-in choice.  Used by the parity tests to cover every
  * tile shape on every loader at sizes the oracle finishes. */
 void nnc_mi355x_debug_force_tile(int wm, int wn);
+/* Test hook for the CCV_16F datapath (half_stage.cpp): how many half-precision tensors have been given an fp32 image so far
+ * (staged) and how many were handed to a kernel as halves (native) since the library was loaded. */
+void nnc_mi355x_debug_half_counts(long* staged, long* native);
 /* Performance tunables (policy only -- results do not depend on them beyond floating-point re-association): by name, e.g.
  * "WINO_SLICE_KB"; the environment variable NNC_MI355X_<NAME> sets the same value at first use.  Returns 0 / -1 (unknown). */
 int  nnc_mi355x_tune_set(const char* name, long value);

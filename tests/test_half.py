@@ -180,3 +180,148 @@ def test_conv_forward_backward_half(backend, ref_lib, case):
         _close(got[1], want[1])
         if not flags:  # (the CPU oracle overwrites dbias under ACCUMULATE_OUTPUT, conv_cpu_ref.c:262-263; the GPU backend being replaced accumulates)
             _close(got[2], want[2])
+
+
+@pytest.mark.parametrize("case", [(2, 10, 10, 16, 24, 3, 3, (1, 1), (1, 1)), (3, 8, 8, 3, 8, 3, 3, (1, 1), (1, 1)), (2, 9, 9, 8, 8, 5, 5, (2, 2), (2, 2))], ids=["3x3", "3x3-c3", "5x5-s2"])
+def test_conv_half_nchw_through_converting_transposes(backend, ref_lib, case):
+    """CCV_16F tensors and filters in NCHW, kernel larger than 1 x 1 -- the CIFAR-10 / ImageNet trainers' fp16 mode.  One
+    converting transpose per tensor feeds the fp32 NHWC kernels (no fp32 image of the NCHW tensor is made first); flags = 0."""
+    n, h, w_, c, k, kh, kw, stride, border = case
+    rng = np.random.default_rng(9)
+    a = hrnd(rng, n, h, w_, c)
+    wt = hrnd(rng, k, kh, kw, c, scale=2.0 / np.sqrt(kh * kw * c))
+    bias = hrnd(rng, k)
+    hint = nnc.HINT(stride, border)
+    oh = (h + 2 * border[0] - kh) // stride[0] + 1
+    ow = (w_ + 2 * border[1] - kw) // stride[1] + 1
+    nchw = lambda t: np.ascontiguousarray(t.transpose(0, 3, 1, 2))
+    s0, n0 = _half_counts(backend)
+    fcmd = nnc.CMD_CONVOLUTION_FORWARD(1, k, kh, kw, c)
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, fcmd, hint, 0, [nchw(a), nchw(wt), bias], [np.zeros((n, k, oh, ow), H)], "NCHW")
+    assert _half_counts(backend)[0] == s0  # nothing went through half_stage.cpp's fp32 images
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, fcmd, hint, 0, [a.astype(F), wt.astype(F), bias.astype(F)], [np.zeros((n, oh, ow, k), F)], backend=nnc.BACKEND_CPU_REF)
+    assert r1 == 0 and r2 == 0
+    _close(got[0], nchw(want[0]))
+    g = hrnd(rng, n, oh, ow, k, scale=1.0 / np.sqrt(oh * ow))
+    bcmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, kh, kw, c)
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, bcmd, hint, 0, [nchw(g), nchw(a), nchw(wt)], [np.zeros((n, c, h, w_), H), np.zeros((k, c, kh, kw), H), np.zeros(k, H)], "NCHW")
+    assert _half_counts(backend)[0] == s0
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, bcmd, hint, 0, [g.astype(F), a.astype(F), wt.astype(F)], [np.zeros((n, h, w_, c), F), np.zeros((k, kh, kw, c), F), np.zeros(k, F)], backend=nnc.BACKEND_CPU_REF)
+    assert r1 == 0 and r2 == 0
+    _close(got[0], nchw(want[0]))
+    _close(got[1], nchw(want[1]))
+    _close(got[2], want[2])
+
+
+# ---- rows with native half-precision kernels (half_stage.cpp's table): halves loaded / stored, fp32 arithmetic -----------------
+def _half_counts(L):
+    """(tensors staged through fp32 images, tensors handed to kernels as halves) so far -- nnc_mi355x_debug_half_counts"""
+    import ctypes
+    a, b = ctypes.c_long(0), ctypes.c_long(0)
+    L.dll.nnc_mi355x_debug_half_counts(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
+def test_native_half_relu_ewsum_exact(backend, ref_lib):
+    rng = np.random.default_rng(21)
+    shape = (3, 10, 9, 12)  # 3240 elements: 8-wide body + a tail
+    a, b, c = hrnd(rng, *shape), hrnd(rng, *shape), hrnd(rng, *shape)
+    s0, n0 = _half_counts(backend)
+    got, want = _pair(backend, ref_lib, nnc.CMD_RELU_FORWARD(), nnc.NO_HINT, 0, [a], [np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0].astype(H))
+    assert _half_counts(backend) == (s0, n0 + 2)  # both tensors went to the kernel as halves, no fp32 image was made
+    y = got[0]
+    g = hrnd(rng, *shape)
+    got, want = _pair(backend, ref_lib, nnc.CMD_RELU_BACKWARD(), nnc.NO_HINT, 0, [g, None, y], [np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0].astype(H))
+    got, want = _pair(backend, ref_lib, nnc.CMD_EWSUM_FORWARD(), nnc.NO_HINT, 0, [a, b], [np.zeros_like(a)])
+    assert np.array_equal(got[0], want[0].astype(H))  # one rounding of the fp32 sum
+    got, want = _pair(backend, ref_lib, nnc.CMD_EWSUM_FORWARD(), nnc.NO_HINT, 0, [a, b, c], [np.zeros_like(a)])
+    _close(got[0], want[0], tol=1e-3)
+    got, want = _pair(backend, ref_lib, nnc.CMD_EWSUM_BACKWARD(), nnc.NO_HINT, 0, [g, a, b, y], [np.zeros_like(a), np.zeros_like(a)])
+    assert np.array_equal(got[0], g) and np.array_equal(got[1], g)
+
+
+@pytest.mark.parametrize("fmt,shape", [("NCHW", (4, 6, 8, 8)), ("NCHW", (3, 5, 7, 7)), ("NHWC", (4, 6, 6, 16))], ids=["nchw-vec", "nchw-odd", "nhwc"])
+def test_native_half_batch_norm(backend, ref_lib, fmt, shape):
+    """x, y, g, h in CCV_16F and the statistics in fp32 -- what the half-precision trainers issue.  Oracle: the reference's CPU
+    batch norm in fp32 on the same half-rounded x / g."""
+    from harness import make_tensors
+    rng = np.random.default_rng(22)
+    caxis = 1 if fmt == "NCHW" else 3
+    C = shape[caxis]
+    s4 = tuple(C if k == caxis else 1 for k in range(4))
+    axes = tuple(k for k in range(4) if k != caxis)
+    x = hrnd(rng, *shape, scale=2.0)
+    g = hrnd(rng, *shape)
+    scale, bias = (rng.random(C, dtype=F) + F(1.0)), (rng.random(C, dtype=F) - F(0.5))
+    mean, var = (rng.random(C, dtype=F) - F(0.5)), rng.random(C, dtype=F) + F(0.5)
+    cmd = nnc.CMD_BATCH_NORM_FORWARD(1e-4, 0, 0.9, *axes)
+
+    def run(lib, mem, xx, gg, backend_id=None):
+        r = lambda a: a.reshape(s4).copy()
+        tx, tg = make_tensors(lib, mem, [xx, gg], fmt)
+        ts = make_tensors(lib, mem, [r(scale), r(bias), r(mean), r(var)], fmt)
+        ty, th = make_tensors(lib, mem, [np.zeros_like(xx), np.zeros_like(xx)], fmt)
+        tsm, tsi, tds, tdb = make_tensors(lib, mem, [np.zeros(s4, F) for _ in range(4)], fmt)
+        c = nnc.Cmd(); nnc.C.memmove(nnc.C.byref(c), nnc.C.byref(cmd), nnc.C.sizeof(c))
+        cb = nnc.CMD_BATCH_NORM_BACKWARD(1e-4, 0, 0.9, *axes)
+        if backend_id is not None:
+            c.backend = backend_id; cb.backend = backend_id
+        assert lib.cmd_exec(c, nnc.NO_HINT, 0, [tx] + ts, [ty, ts[2], ts[3], tsm, tsi]) == 0
+        assert lib.cmd_exec(cb, nnc.NO_HINT, 0, [tg] + [None] * 4 + [tx, ts[0]] + [None] * 6 + [tsm, tsi], [th, tds, tdb]) == 0
+        return [t.numpy() for t in (ty, th, ts[2], ts[3], tsm, tsi, tds, tdb)]
+
+    s0, n0 = _half_counts(backend)
+    got = run(backend, nnc.GPU_MEMORY, x, g)
+    assert _half_counts(backend) == (s0, n0 + 5)  # x, y; g, x, h -- the fp32 statistics need no image
+    want = run(ref_lib, nnc.CPU_MEMORY, x.astype(F), g.astype(F), nnc.BACKEND_CPU_REF)
+    assert got[0].dtype == H and got[1].dtype == H
+    _close(got[0], want[0], tol=2e-3)
+    _close(got[1], want[1], tol=2e-3)
+    for a, b, what in zip(got[2:], want[2:], ("mean", "var", "saved_mean", "saved_inv_std", "dscale", "dbias")):
+        np.testing.assert_allclose(a.reshape(-1), b.reshape(-1), rtol=2e-4, atol=2e-5, err_msg=what)
+
+
+@pytest.mark.parametrize("fmt", ["NCHW", "NHWC"])
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_native_half_pooling(backend, ref_lib, fmt, kind):
+    rng = np.random.default_rng(23)
+    n, h, w, c = 1, 9, 8, 6  # (the reference's CPU pooling walks one image; batches are covered by the fp32 tests of the same kernels)
+    a = hrnd(rng, n, h, w, c)
+    hint = nnc.HINT((2, 2), (1, 1))
+    oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    tr = (lambda t: np.ascontiguousarray(t.transpose(0, 3, 1, 2))) if fmt == "NCHW" else (lambda t: t)
+    fcmd = nnc.CMD_MAX_POOL_FORWARD(3, 3) if kind == "max" else nnc.CMD_AVERAGE_POOL_FORWARD(3, 3)
+    bcmd = nnc.CMD_MAX_POOL_BACKWARD(3, 3) if kind == "max" else nnc.CMD_AVERAGE_POOL_BACKWARD(3, 3)
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, fcmd, hint, 0, [tr(a)], [tr(np.zeros((n, oh, ow, c), H))], fmt)
+    # the oracle in NHWC (the reference's CPU pooling reads its tensors as NHWC), compared in the backend's layout
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, fcmd, hint, 0, [a.astype(F)], [np.zeros((n, oh, ow, c), F)], backend=nnc.BACKEND_CPU_REF)
+    want = [tr(want[0])]
+    assert r1 == 0 and r2 == 0 and got[0].dtype == H
+    if kind == "max":
+        assert np.array_equal(got[0], want[0].astype(H))
+    else:
+        _close(got[0], want[0], tol=1e-3)
+    y = got[0]
+    g = hrnd(rng, n, oh, ow, c)
+    ins = [tr(g), tr(a), y] if kind == "max" else [tr(g)]
+    untr = (lambda t: np.ascontiguousarray(t.transpose(0, 2, 3, 1))) if fmt == "NCHW" else (lambda t: t)
+    r1, gb = exec_on(backend, nnc.GPU_MEMORY, bcmd, hint, 0, ins, [tr(np.zeros_like(a))], fmt)
+    r2, wb = exec_on(ref_lib, nnc.CPU_MEMORY, bcmd, hint, 0, [untr(t).astype(F) for t in ins], [np.zeros(a.shape, F)], backend=nnc.BACKEND_CPU_REF)
+    assert r1 == 0 and r2 == 0 and gb[0].dtype == H
+    _close(gb[0], tr(wb[0]), tol=1e-3)
+
+
+@pytest.mark.parametrize("nesterov", [0, 1])
+def test_native_half_sgd(backend, ref_lib, nesterov):
+    """gradient, parameter and momentum all in CCV_16F (the cifar-10 trainer's half-precision mode): one kernel, fp32 arithmetic."""
+    rng = np.random.default_rng(24)
+    g, a, m = hrnd(rng, 1003), hrnd(rng, 1003), hrnd(rng, 1003, scale=0.1)
+    cmd = nnc.CMD_SGD_FORWARD(nesterov, 0.01, 0.5, 0.0005, 0.9, 0.0 if nesterov else 0.1)
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [g, a, m], [np.zeros_like(a), np.zeros_like(m)])
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, [g.astype(F), a.astype(F), m.astype(F)], [np.zeros(1003, F), np.zeros(1003, F)], backend=nnc.BACKEND_CPU_REF)
+    assert r1 == 0 and r2 == 0
+    for x, y in zip(got, want):
+        assert x.dtype == H
+        _close(x, y, tol=1e-3)
