@@ -202,6 +202,80 @@ __global__ void __launch_bounds__(256) pool_back_v4_kernel(const pool_geom_t g, 
 	}
 }
 
+// ---- windows that TILE the map (stride == window, no border, H = OH * kh, W = OW * kw: the 2 x 2 / 2 pools of VGG-D and the
+// CIFAR-10 nets): every input position belongs to exactly one window, so the gradient needs no window search.  A thread per
+// window x VEC contiguous channels (NHWC, 16-byte accesses) or per window (NCHW: lanes run along the row): y and g are read once,
+// x once, h written once; no divisions per element.  (The general kernels spent 155 us on the DawnNet's 134 MB pools in either
+// precision -- instruction-bound -- and ran VGG-D's at 3.4 TB/s.)
+template <class T, int VEC> struct packv { typedef T type __attribute__((ext_vector_type(VEC))); };
+template <class T> struct packv<T, 1> { typedef T type; };
+template <bool NHWC, bool IS_MAX, class T, int VEC>
+__global__ void __launch_bounds__(256) pool_back_tiled_kernel(const pool_geom_t g, const FastDiv d_cv, const T* __restrict__ gr, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ h, const size_t total)
+{
+	typedef typename packv<T, VEC>::type V;
+	const float cnt = (float)(g.kh * g.kw); // (divided by, like the general kernels: bit-identical averages)
+	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+		int n, oy, ox, c;
+		unflatten<NHWC>((int)idx64, g.d_oh, g.d_ow, d_cv, n, oy, ox, c);
+		c *= VEC;
+		const long o = n * g.b_sn + oy * g.b_sh + ox * g.b_sw + c * g.b_sc;
+		float gv[VEC], bv[VEC];
+		if constexpr (VEC > 1) {
+			const V t = *(const V*)(gr + o);
+			for (int e = 0; e < VEC; e++) gv[e] = (float)t[e];
+			if (IS_MAX) { const V u = *(const V*)(b + o); for (int e = 0; e < VEC; e++) bv[e] = (float)u[e]; }
+		} else {
+			gv[0] = (float)gr[o];
+			if (IS_MAX) bv[0] = (float)b[o];
+		}
+		const long i0 = n * g.a_sn + oy * g.kh * g.a_sh + ox * g.kw * g.a_sw + c * g.a_sc;
+		for (int dy = 0; dy < g.kh; dy++)
+			for (int dx = 0; dx < g.kw; dx++) {
+				const long i = i0 + dy * g.a_sh + dx * g.a_sw;
+				if constexpr (VEC > 1) {
+					V r;
+					if (IS_MAX) {
+						const V av = *(const V*)(a + i);
+						for (int e = 0; e < VEC; e++) r[e] = (T)((float)av[e] == bv[e] ? gv[e] : 0.f);
+					} else
+						for (int e = 0; e < VEC; e++) r[e] = (T)(gv[e] / cnt);
+					*(V*)(h + i) = r;
+				} else {
+					if (IS_MAX) h[i] = (T)((float)a[i] == bv[0] ? gv[0] : 0.f);
+					else h[i] = (T)(gv[0] / cnt);
+				}
+			}
+	}
+}
+static bool pool_tiles(const pool_geom_t& g)
+{
+	return g.kh == g.sy && g.kw == g.sx && g.pby == 0 && g.pbx == 0 && (long)g.OH * g.kh == g.H && (long)g.OW * g.kw == g.W;
+}
+template <bool IS_MAX, class T>
+static bool pool_back_tiled(const pool_geom_t& g, const bool nhwc, const T* gp, const T* ap, const T* bp, T* hp, const int nn, hipStream_t stream)
+{
+	if (!pool_tiles(g)) return false;
+	constexpr int W = 16 / sizeof(T);
+	FastDiv d_cv;
+	if (nhwc) {
+		const bool vec = g.C % W == 0 && g.a_sc == 1 && g.b_sc == 1 && ((g.a_sn | g.a_sh | g.a_sw | g.b_sn | g.b_sh | g.b_sw) % W) == 0 && aligned16(gp) && aligned16(hp) && (!ap || aligned16(ap)) && (!bp || aligned16(bp));
+		if (vec) {
+			d_cv.init(g.C / W);
+			const size_t total = (size_t)nn * g.OH * g.OW * (g.C / W);
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_tiled_kernel<true, IS_MAX, T, W>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, d_cv, gp, ap, bp, hp, total);
+		} else {
+			d_cv.init(g.C);
+			const size_t total = (size_t)nn * g.OH * g.OW * g.C;
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_tiled_kernel<true, IS_MAX, T, 1>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, d_cv, gp, ap, bp, hp, total);
+		}
+	} else {
+		d_cv.init(g.C);
+		const size_t total = (size_t)nn * g.OH * g.OW * g.C;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_tiled_kernel<false, IS_MAX, T, 1>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, d_cv, gp, ap, bp, hp, total);
+	}
+	return true;
+}
+
 static bool pool_vec4_ok(const pool_geom_t& g, bool nhwc, const void* p0, const void* p1, const void* p2, const void* p3)
 {
 	if (!nhwc || g.C % 4 || g.a_sc != 1 || g.b_sc != 1) return false;
@@ -304,6 +378,7 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 			const half_t* ap = a ? (const half_t*)a->data.f16 + (long)n0 * g.a_sn : 0;
 			const half_t* bp = b ? (const half_t*)b->data.f16 + (long)n0 * g.b_sn : 0;
 			half_t* hp = (half_t*)h->data.f16 + (long)n0 * g.a_sn;
+			if (pool_back_tiled<IS_MAX, half_t>(g, nhwc, gp, ap, bp, hp, nn, stream)) { HIP_ENFORCE(hipGetLastError()); continue; }
 			if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX, half_t>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
 			else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX, half_t>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
 			HIP_ENFORCE(hipGetLastError());
@@ -313,6 +388,7 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 		const float* ap = a ? a->data.f32 + (long)n0 * g.a_sn : 0;
 		const float* bp = b ? b->data.f32 + (long)n0 * g.b_sn : 0;
 		float* hp = h->data.f32 + (long)n0 * g.a_sn;
+		if (pool_back_tiled<IS_MAX, float>(g, nhwc, gp, ap, bp, hp, nn, stream)) { HIP_ENFORCE(hipGetLastError()); continue; }
 		if (pool_vec4_ok(g, nhwc, gp, hp, ap, bp)) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_v4_kernel<IS_MAX>), dim3(grid_for(total / 4, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total / 4);
 		else if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX, float>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX, float>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);

@@ -284,6 +284,9 @@ POOL_CASES = [
     (8, 8, 4, 2, 2, (2, 2), (0, 0)),
     (7, 7, 6, 7, 7, (1, 1), (0, 0)),     # global
     (6, 5, 3, 3, 3, (1, 1), (1, 1)),     # overlapping, stride 1
+    (8, 6, 5, 2, 2, (2, 2), (0, 0)),     # windows that tile the map (the gradient's window-per-thread kernel), channels not in 16-byte groups
+    (6, 9, 8, 2, 3, (2, 3), (0, 0)),     # tiling, 2 x 3 windows
+    (6, 6, 4, 3, 3, (3, 3), (0, 0)),     # tiling, averages divided by 9
 ]
 
 
@@ -304,13 +307,14 @@ def test_pool_forward_backward_bit_exact(backend, ref_lib, case, kind):
     assert np.array_equal(got[0].view(np.int32), want[0].view(np.int32))
 
 
+@pytest.mark.parametrize("geom", [(3, 9, 8, 5, 3, 3, (2, 2), (1, 1)), (3, 8, 10, 8, 2, 2, (2, 2), (0, 0))], ids=["overlapping", "tiling"])
 @pytest.mark.parametrize("kind", ["max", "avg"])
-def test_pool_batched_and_nchw(backend, ref_lib, kind):
+def test_pool_batched_and_nchw(backend, ref_lib, kind, geom):
     """The CPU oracle walks only image 0 of a batch and is NHWC-only: check a batch image by image, and NCHW against
     the transposed NHWC result."""
     rng = np.random.default_rng(3)
-    n, h, w, c, kh, kw = 3, 9, 8, 5, 3, 3
-    hint = nnc.HINT((2, 2), (1, 1))
+    n, h, w, c, kh, kw, stride, border = geom
+    hint = nnc.HINT(stride, border)
     oh, ow = out_hw(h, w, kh, kw, hint)
     a = np.round(srnd(rng, n, h, w, c) * 4) / 4
     g = srnd(rng, n, oh, ow, c)
