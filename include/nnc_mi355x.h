@@ -124,6 +124,10 @@ enum {
 	CCV_NNC_MASKED_FILL_FORWARD = 0x7f992d84, CCV_NNC_MASKED_FILL_BACKWARD = 0x7f992d85,
 	CCV_NNC_REDUCE_ISNAN_FORWARD = 0xee0a4ade, CCV_NNC_REDUCE_ISNAN_BACKWARD = 0xee0a4adf,
 	CCV_NNC_CONVOLUTION_TRANSPOSE_FORWARD = 0xd691f78e, CCV_NNC_CONVOLUTION_TRANSPOSE_BACKWARD = 0xd691f78f,
+	CCV_NNC_CMUL_FORWARD = 0xead486e6, CCV_NNC_CMUL_BACKWARD = 0xead486e7,
+	CCV_NNC_COMPRESSION_LSSC_FORWARD = 0x17ea8f72, CCV_NNC_COMPRESSION_LSSC_BACKWARD = 0x17ea8f73,
+	CCV_NNC_NMS_FORWARD = 0xdba26106, CCV_NNC_NMS_BACKWARD = 0xdba26107,
+	CCV_NNC_ROI_ALIGN_FORWARD = 0xfef55168, CCV_NNC_ROI_ALIGN_BACKWARD = 0xfef55169,
 	CCV_NNC_SIGMOID_FORWARD = 0xf2f69650, CCV_NNC_SIGMOID_BACKWARD = 0xf2f69651,
 	CCV_NNC_SIGMOID_BINARY_CROSSENTROPY_FORWARD = 0xd9e0e4a, CCV_NNC_SIGMOID_BINARY_CROSSENTROPY_BACKWARD = 0xd9e0e4b,
 	CCV_NNC_SMOOTH_L1_FORWARD = 0x4e428e, CCV_NNC_SMOOTH_L1_BACKWARD = 0x4e428f,
@@ -222,6 +226,7 @@ typedef struct { /* 120 bytes */
 		struct { int step; float rate; float scale; float beta1; float beta2; float decay; float epsilon; int amsgrad; } adam;
 		struct { float rate; float scale; float decay; float alpha; float momentum; float epsilon; } rmsprop;
 		struct { int step; float rate; float scale; float beta1; float beta2; float decay; float epsilon; } lamb;
+		struct { float iou_threshold; } nms;
 		char _widest[68]; /* gnorm is the widest member in the reference (68 B) */
 		void* userdata;
 	};
