@@ -313,7 +313,8 @@ static int _lamb_forw(EXEC_ARGS)
 	for (int i = 0; i < 4; i++) if (tensor_count(inputs[i]->info) != n) return CCV_NNC_EXEC_INVALID;
 	for (int i = 0; i < 3; i++) if (tensor_count(outputs[i]->info) != n) return CCV_NNC_EXEC_INVALID;
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
-	const int blocks = grid_for(n, EW_THREADS);
+	int blocks = grid_for(n, EW_THREADS); // one partial norm pair per workgroup, folded by one thread: keep them few
+	if (blocks > device_cu_count() * 8) blocks = device_cu_count() * 8;
 	const size_t head = (sizeof(double) * 2 * (size_t)blocks + sizeof(float) + 255) & ~(size_t)255;
 	char* ws = (char*)workspace_of(stream_context, head + sizeof(float) * n);
 	if (!ws) return CCV_NNC_EXEC_OOM;

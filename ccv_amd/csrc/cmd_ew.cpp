@@ -21,42 +21,48 @@ constexpr int EW_THREADS = 256;
 // half the bytes of the fp32 form, a fifth of what running the fp32 kernel on converted images moves).  16 bytes per access.
 typedef _Float16 half_t;
 template <class T> struct pack16 { typedef T type __attribute__((ext_vector_type(16 / sizeof(T)))); };
+// Work split: a workgroup takes ONE contiguous tile of 4 x 256 16-byte vectors (16 KB per tensor), four independent loads per
+// input in flight per thread, and the grid covers the tensor -- no grid-stride loop.  Measured on 3.29 GB tensors
+// (tools/ew_bw_bench.py, profiles/r02_v8_ew_bw_bench.txt): RELU forward 6.2 TB/s this way against 4.7 TB/s for a grid-stride
+// loop capped at 8 (or 16, 32, 64) workgroups per CU -- a few thousand workgroups striding the whole tensor scatter the DRAM
+// pages in flight, a front of workgroups walking it in order does not; non-temporal loads / stores made no difference.
+constexpr int EW_TILE = 4;
 template <class F, int NIN, class T>
 __global__ void __launch_bounds__(EW_THREADS) ew_map_kernel(F f, T* out, const T* in0, const T* in1, const T* in2, const size_t nv, const size_t n)
 {
 	constexpr int W = 16 / sizeof(T);
 	typedef typename pack16<T>::type V;
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	// four independent 16-byte loads per input in flight per thread (one per trip left the chip at 4.9-5.1 TB/s on the ReLU
-	// passes of VGG-D: 2048 workgroups x 256 threads x 16 bytes = 8 MB in flight against ~13 MB of bandwidth-delay product)
-	size_t i = tid;
-	for (; i + 3 * stride < nv; i += 4 * stride) {
-		V a[4], b[4], c[4];
+	const size_t base = (size_t)blockIdx.x * (EW_TILE * EW_THREADS) + threadIdx.x;
+	if (base + (EW_TILE - 1) * EW_THREADS < nv) {
+		V a[EW_TILE], b[EW_TILE], c[EW_TILE];
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
-			a[u] = NIN > 0 ? ((const V*)in0)[i + u * stride] : V{};
-			b[u] = NIN > 1 ? ((const V*)in1)[i + u * stride] : V{};
-			c[u] = NIN > 2 ? ((const V*)in2)[i + u * stride] : V{};
+		for (int u = 0; u < EW_TILE; u++) {
+			a[u] = NIN > 0 ? ((const V*)in0)[base + u * EW_THREADS] : V{};
+			b[u] = NIN > 1 ? ((const V*)in1)[base + u * EW_THREADS] : V{};
+			c[u] = NIN > 2 ? ((const V*)in2)[base + u * EW_THREADS] : V{};
 		}
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
+		for (int u = 0; u < EW_TILE; u++) {
 			V r;
 #pragma unroll
 			for (int e = 0; e < W; e++) r[e] = (T)f((float)a[u][e], (float)b[u][e], (float)c[u][e]);
-			((V*)out)[i + u * stride] = r;
+			((V*)out)[base + u * EW_THREADS] = r;
 		}
-	}
-	for (; i < nv; i += stride) {
-		const V a = NIN > 0 ? ((const V*)in0)[i] : V{};
-		const V b = NIN > 1 ? ((const V*)in1)[i] : V{};
-		const V c = NIN > 2 ? ((const V*)in2)[i] : V{};
-		V r;
+	} else
+		for (int u = 0; u < EW_TILE; u++) {
+			const size_t i = base + u * EW_THREADS;
+			if (i >= nv) break;
+			const V a = NIN > 0 ? ((const V*)in0)[i] : V{};
+			const V b = NIN > 1 ? ((const V*)in1)[i] : V{};
+			const V c = NIN > 2 ? ((const V*)in2)[i] : V{};
+			V r;
 #pragma unroll
-		for (int e = 0; e < W; e++) r[e] = (T)f((float)a[e], (float)b[e], (float)c[e]);
-		((V*)out)[i] = r;
-	}
-	for (size_t j = nv * W + tid; j < n; j += stride)
+			for (int e = 0; e < W; e++) r[e] = (T)f((float)a[e], (float)b[e], (float)c[e]);
+			((V*)out)[i] = r;
+		}
+	// what 16-byte vectors do not cover (or everything, when a pointer is not 16-byte aligned: nv == 0)
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t j = nv * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
 		out[j] = (T)f(NIN > 0 ? (float)in0[j] : 0.f, NIN > 1 ? (float)in1[j] : 0.f, NIN > 2 ? (float)in2[j] : 0.f);
 }
 
@@ -67,7 +73,10 @@ static int ew_map(F f, T* out, const T* in0, const T* in1, const T* in2, size_t 
 	constexpr int W = 16 / sizeof(T);
 	const bool vec = aligned16(out) && (NIN < 1 || aligned16(in0)) && (NIN < 2 || aligned16(in1)) && (NIN < 3 || aligned16(in2));
 	const size_t nv = vec ? n / W : 0;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(ew_map_kernel<F, NIN, T>), dim3(grid_for(vec ? nv + 3 : n, EW_THREADS)), dim3(EW_THREADS), 0, stream_of(ctx), f, out, in0, in1, in2, nv, n);
+	size_t blocks = vec ? (nv + EW_TILE * EW_THREADS - 1) / (EW_TILE * EW_THREADS) : (n + EW_THREADS - 1) / EW_THREADS;
+	if (blocks < 1) blocks = 1;
+	if (blocks > 0x7fffffffUL) blocks = 0x7fffffffUL; // (the scalar loop strides; a vector tensor this large does not exist on one GPU)
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(ew_map_kernel<F, NIN, T>), dim3((unsigned)blocks), dim3(EW_THREADS), 0, stream_of(ctx), f, out, in0, in1, in2, nv, n);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

@@ -112,10 +112,12 @@ const float* zero_page_of(const ccv_nnc_stream_context_t* ctx); // 256 zero byte
 int device_cu_count(void);
 void note_kernel(const char* name);
 
+long tune(int key);
 static inline int grid_for(size_t n, int threads)
-{ // memory-bound kernels: grid-stride, capped at 8 workgroups of 256 per CU (cdna guide, Guideline 11)
+{ // memory-bound grid-stride kernels.  The cap (TUNE_GRID_WG_PER_CU workgroups per CU) defaults to none: see device_rt.cpp.
 	size_t b = (n + threads - 1) / threads;
-	const size_t cap = (size_t)device_cu_count() * 8;
+	const long per_cu = tune(3 /* TUNE_GRID_WG_PER_CU, checked below the enum */);
+	const size_t cap = per_cu > 0 ? (size_t)device_cu_count() * (size_t)per_cu : (size_t)0x7fffffff;
 	if (b > cap) b = cap;
 	if (b < 1) b = 1;
 	return (int)b;
@@ -171,8 +173,10 @@ enum {
 	TUNE_WINO_SLICE_KB = 0, // Winograd via HBM: run the three stages per slice of images whose V + M scratch is at most this many KB (0 = whole batch)
 	TUNE_WINO_FUSED_MAX_C,  // algorithm -1 picks the fused Winograd kernel when the reduction channels are <= this (0 = never)
 	TUNE_WINO_FUSED_GRID,   // persistent workgroups of the fused Winograd kernel (0 = one per CU)
+	TUNE_GRID_WG_PER_CU,    // grid-stride kernels (grid_for): cap in workgroups per CU, 0 = no cap (one trip per thread)
 	TUNE_COUNT
 };
+static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");
 long tune(int key);
 
 // Half precision (half_stage.cpp): rows whose kernels compute in fp32 run CCV_16F tensors through fp32 images in the stream's
