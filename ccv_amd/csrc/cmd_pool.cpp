@@ -245,11 +245,30 @@ __global__ void __launch_bounds__(256) pool_back_tiled_kernel(const pool_geom_t 
 					else h[i] = (T)(gv[0] / cnt);
 				}
 			}
+		// rows / columns past the last window (VGG-D's 225 x 225 maps under 2 x 2 / 2: one of each) belong to no window: zero gradient.
+		// The threads of the last window column / row write them.
+		const int ex = g.OW * g.kw, ey = g.OH * g.kh;
+		const long z0 = n * g.a_sn + c * g.a_sc;
+		if (ox == g.OW - 1 && ex < g.W)
+			for (int dy = 0; dy < g.kh; dy++)
+				for (int x = ex; x < g.W; x++) {
+					const long i = z0 + (oy * g.kh + dy) * g.a_sh + x * g.a_sw;
+					if constexpr (VEC > 1) *(V*)(h + i) = V{}; else h[i] = (T)0.f;
+				}
+		if (oy == g.OH - 1 && ey < g.H)
+			for (int y = ey; y < g.H; y++) {
+				const int x1 = ox == g.OW - 1 ? g.W : (ox + 1) * g.kw;
+				for (int x = ox * g.kw; x < x1; x++) {
+					const long i = z0 + y * g.a_sh + x * g.a_sw;
+					if constexpr (VEC > 1) *(V*)(h + i) = V{}; else h[i] = (T)0.f;
+				}
+			}
 	}
 }
 static bool pool_tiles(const pool_geom_t& g)
 {
-	return g.kh == g.sy && g.kw == g.sx && g.pby == 0 && g.pbx == 0 && (long)g.OH * g.kh == g.H && (long)g.OW * g.kw == g.W;
+	// windows side by side from the origin; what is left over at the far edges (less than one window) is handled in the kernel
+	return g.kh == g.sy && g.kw == g.sx && g.pby == 0 && g.pbx == 0 && g.OH >= 1 && g.OW >= 1 && g.OH == g.H / g.kh && g.OW == g.W / g.kw;
 }
 template <bool IS_MAX, class T>
 static bool pool_back_tiled(const pool_geom_t& g, const bool nhwc, const T* gp, const T* ap, const T* bp, T* hp, const int nn, hipStream_t stream)

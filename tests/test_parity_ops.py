@@ -287,6 +287,8 @@ POOL_CASES = [
     (8, 6, 5, 2, 2, (2, 2), (0, 0)),     # windows that tile the map (the gradient's window-per-thread kernel), channels not in 16-byte groups
     (6, 9, 8, 2, 3, (2, 3), (0, 0)),     # tiling, 2 x 3 windows
     (6, 6, 4, 3, 3, (3, 3), (0, 0)),     # tiling, averages divided by 9
+    (9, 7, 8, 2, 2, (2, 2), (0, 0)),     # tiling with a left-over row and column (VGG-D's 225 x 225 maps): zero gradient there
+    (7, 8, 3, 3, 3, (3, 3), (0, 0)),     # left-over row of one, left-over columns of two
 ]
 
 
@@ -307,7 +309,7 @@ def test_pool_forward_backward_bit_exact(backend, ref_lib, case, kind):
     assert np.array_equal(got[0].view(np.int32), want[0].view(np.int32))
 
 
-@pytest.mark.parametrize("geom", [(3, 9, 8, 5, 3, 3, (2, 2), (1, 1)), (3, 8, 10, 8, 2, 2, (2, 2), (0, 0))], ids=["overlapping", "tiling"])
+@pytest.mark.parametrize("geom", [(3, 9, 8, 5, 3, 3, (2, 2), (1, 1)), (3, 8, 10, 8, 2, 2, (2, 2), (0, 0)), (2, 9, 11, 4, 2, 2, (2, 2), (0, 0))], ids=["overlapping", "tiling", "tiling-leftover"])
 @pytest.mark.parametrize("kind", ["max", "avg"])
 def test_pool_batched_and_nchw(backend, ref_lib, kind, geom):
     """The CPU oracle walks only image 0 of a batch and is NHWC-only: check a batch image by image, and NCHW against
