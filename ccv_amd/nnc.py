@@ -26,6 +26,9 @@ BACKEND_CPU_OPT, BACKEND_CPU_REF = 0x46deb194, 0x3d9883e5
 BACKEND_GPU_CUBLAS, BACKEND_GPU_CUDNN, BACKEND_GPU_NCCL, BACKEND_GPU_REF = 0x9b8cfed, 0x854b679a, 0x7afed9c7, 0x5f19790a
 
 CMD = dict(
+    SCALED_DOT_PRODUCT_ATTENTION_FORWARD=0x284ed926, SCALED_DOT_PRODUCT_ATTENTION_BACKWARD=0x284ed927,
+    CMUL_FORWARD=0xead486e6, CMUL_BACKWARD=0xead486e7, NMS_FORWARD=0xdba26106, NMS_BACKWARD=0xdba26107,
+    ROI_ALIGN_FORWARD=0xfef55168, ROI_ALIGN_BACKWARD=0xfef55169, COMPRESSION_LSSC_FORWARD=0x17ea8f72, COMPRESSION_LSSC_BACKWARD=0x17ea8f73,
     ADD_FORWARD=0x58fb3664, ADD_BACKWARD=0x58fb3665,
     AVERAGE_POOL_FORWARD=0x51267ab8, AVERAGE_POOL_BACKWARD=0x51267ab9,
     BATCH_NORM_FORWARD=0x5419819c, BATCH_NORM_BACKWARD=0x5419819d,

@@ -128,6 +128,7 @@ enum {
 	CCV_NNC_COMPRESSION_LSSC_FORWARD = 0x17ea8f72, CCV_NNC_COMPRESSION_LSSC_BACKWARD = 0x17ea8f73,
 	CCV_NNC_NMS_FORWARD = 0xdba26106, CCV_NNC_NMS_BACKWARD = 0xdba26107,
 	CCV_NNC_ROI_ALIGN_FORWARD = 0xfef55168, CCV_NNC_ROI_ALIGN_BACKWARD = 0xfef55169,
+	CCV_NNC_SCALED_DOT_PRODUCT_ATTENTION_FORWARD = 0x284ed926, CCV_NNC_SCALED_DOT_PRODUCT_ATTENTION_BACKWARD = 0x284ed927,
 	CCV_NNC_SIGMOID_FORWARD = 0xf2f69650, CCV_NNC_SIGMOID_BACKWARD = 0xf2f69651,
 	CCV_NNC_SIGMOID_BINARY_CROSSENTROPY_FORWARD = 0xd9e0e4a, CCV_NNC_SIGMOID_BINARY_CROSSENTROPY_BACKWARD = 0xd9e0e4b,
 	CCV_NNC_SMOOTH_L1_FORWARD = 0x4e428e, CCV_NNC_SMOOTH_L1_BACKWARD = 0x4e428f,
@@ -227,6 +228,7 @@ typedef struct { /* 120 bytes */
 		struct { float rate; float scale; float decay; float alpha; float momentum; float epsilon; } rmsprop;
 		struct { int step; float rate; float scale; float beta1; float beta2; float decay; float epsilon; } lamb;
 		struct { float iou_threshold; } nms;
+		struct { float scale; int is_causal; int flags; int deterministic; } scaled_dot_product_attention;
 		char _widest[68]; /* gnorm is the widest member in the reference (68 B) */
 		void* userdata;
 	};
