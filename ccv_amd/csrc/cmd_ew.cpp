@@ -192,12 +192,16 @@ __global__ void __launch_bounds__(256) colsum_partial_v4_kernel(const float* x, 
 	}
 }
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* partial, const int slices, const int cols, float* out, const int accumulate)
-{
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= cols) return;
-	float s = 0.f;
-	for (int i = 0; i < slices; i++) s += partial[(long)i * cols + c];
-	out[c] = accumulate ? out[c] + s : s;
+{ // 16 columns x 16 phases per workgroup (common.h: fold_slices / fold_phases)
+	__shared__ float red[FOLD_PH][FOLD_CH];
+	const int ch = threadIdx.x & (FOLD_CH - 1), phase = threadIdx.x / FOLD_CH;
+	const int c = blockIdx.x * FOLD_CH + ch;
+	red[phase][ch] = c < cols ? fold_slices(partial, slices, cols, c, phase) : 0.f;
+	__syncthreads();
+	if (phase == 0 && c < cols) {
+		const float s = fold_phases(red, ch);
+		out[c] = accumulate ? out[c] + s : s;
+	}
 }
 
 static int _relu_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
@@ -562,7 +566,7 @@ int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int acc
 	else
 		hipLaunchKernelGGL(colsum_partial_kernel, dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, x, rows, cols, ld, rows_per_slice > 0 ? rows_per_slice : 1, partial);
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, (const float*)partial, (int)slices, cols, out, accumulate);
+	hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + FOLD_CH - 1) / FOLD_CH), dim3(256), 0, stream, (const float*)partial, (int)slices, cols, out, accumulate);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

@@ -74,28 +74,6 @@ __global__ void __launch_bounds__(256) chan_reduce_planes_kernel(F f, const T* x
 // flight; one thread per channel walking every slice with one dependent add chain was 66 us per call, 64 channels x 4 phases
 // still 32 - 68 us on the DawnNet / ResNet-50 steps -- as long as the sweeps over the tensors these folds finish); the 16
 // phases meet in LDS.  FOLD_CH channels per workgroup also means 4x the workgroups of the 64-channel form.
-constexpr int FOLD_CH = 16, FOLD_PH = 16;
-__device__ __forceinline__ float fold_slices(const float* __restrict__ p, const long slices, const int C, const int c, const int phase)
-{
-	float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-	long i = phase;
-	for (; i + 3 * FOLD_PH < slices; i += 4 * FOLD_PH) {
-		s0 += p[i * C + c]; s1 += p[(i + FOLD_PH) * C + c]; s2 += p[(i + 2 * FOLD_PH) * C + c]; s3 += p[(i + 3 * FOLD_PH) * C + c];
-	}
-	for (; i < slices; i += FOLD_PH) s0 += p[i * C + c];
-	return (s0 + s1) + (s2 + s3);
-}
-__device__ __forceinline__ float fold_phases(float (*red)[FOLD_CH], const int ch)
-{ // after __syncthreads(): the 16 phase sums of channel ch, pairwise in a fixed order
-	float a[FOLD_PH];
-#pragma unroll
-	for (int k = 0; k < FOLD_PH; k++) a[k] = red[k][ch];
-#pragma unroll
-	for (int w = FOLD_PH / 2; w >= 1; w >>= 1)
-#pragma unroll
-		for (int k = 0; k < w; k++) a[k] = a[k] + a[k + w];
-	return a[0];
-}
 // out0[c] (+)= sum_i p0[i][c]  and, when p1 is given, out1[c] (+)= sum_i p1[i][c]  (blockIdx.y picks the array)
 __global__ void __launch_bounds__(256) chan_fold_kernel(const float* p0, const float* p1, const long slices, const int C, float* out0, float* out1, const int accumulate)
 {

@@ -85,8 +85,11 @@ __global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, con
 	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, y, x, c;
 		unflatten<NHWC>((int)idx64, g.d_h, g.d_w, g.d_c, n, y, x, c);
-		int oy0 = ceil_div(y + g.pby - g.kh + 1, g.sy), oy1 = floor_div(y + g.pby, g.sy);
-		int ox0 = ceil_div(x + g.pbx - g.kw + 1, g.sx), ox1 = floor_div(x + g.pbx, g.sx);
+		// windows that contain (y, x): ceil((t - k + 1) / s) .. floor(t / s) with t = y + pb >= 0; the ceiling as a floor of a
+		// non-negative dividend (+ k * s, - k afterwards), both by multiply-shift (FastDiv) instead of hardware division
+		const int ty = y + g.pby, tx = x + g.pbx;
+		int oy0 = g.d_sy.div(ty - g.kh + g.kh * g.sy + g.sy) - g.kh, oy1 = g.d_sy.div(ty);
+		int ox0 = g.d_sx.div(tx - g.kw + g.kw * g.sx + g.sx) - g.kw, ox1 = g.d_sx.div(tx);
 		if (oy0 < 0) oy0 = 0;
 		if (ox0 < 0) ox0 = 0;
 		if (oy1 > g.OH - 1) oy1 = g.OH - 1;

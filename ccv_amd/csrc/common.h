@@ -179,6 +179,33 @@ enum {
 static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");
 long tune(int key);
 
+// Folding per-slice partials [slices][C] into per-channel sums in a fixed order: a workgroup of 256 is 16 channels x 16 phases, thread
+// (phase = t >> 4, channel = t & 15) adds the slices phase, phase + 16, ... with four independent running sums (four loads in
+// flight), the 16 phases meet in LDS.  (One thread per channel walking every slice -- one dependent add chain -- was 42 - 68 us per
+// call on the VGG-D / ResNet-50 steps: as long as the reductions these folds finish.)
+constexpr int FOLD_CH = 16, FOLD_PH = 16;
+__device__ __forceinline__ float fold_slices(const float* __restrict__ p, const long slices, const int C, const int c, const int phase)
+{
+	float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+	long i = phase;
+	for (; i + 3 * FOLD_PH < slices; i += 4 * FOLD_PH) {
+		s0 += p[i * C + c]; s1 += p[(i + FOLD_PH) * C + c]; s2 += p[(i + 2 * FOLD_PH) * C + c]; s3 += p[(i + 3 * FOLD_PH) * C + c];
+	}
+	for (; i < slices; i += FOLD_PH) s0 += p[i * C + c];
+	return (s0 + s1) + (s2 + s3);
+}
+__device__ __forceinline__ float fold_phases(float (*red)[FOLD_CH], const int ch)
+{ // after __syncthreads(): the 16 phase sums of channel ch, pairwise in a fixed order
+	float a[FOLD_PH];
+#pragma unroll
+	for (int k = 0; k < FOLD_PH; k++) a[k] = red[k][ch];
+#pragma unroll
+	for (int w = FOLD_PH / 2; w >= 1; w >>= 1)
+#pragma unroll
+		for (int k = 0; k < w; k++) a[k] = a[k] + a[k + w];
+	return a[0];
+}
+
 // Half precision (half_stage.cpp): rows whose kernels compute in fp32 run CCV_16F tensors through fp32 images in the stream's
 // staging arena.  NNC_HALF_STAGED(registry, EXEC) -- used by every row's registration -- adds CCV_16F next to CCV_32F and routes
 // the row through the wrapper (which is a plain call of EXEC when no tensor is half precision).

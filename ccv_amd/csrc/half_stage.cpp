@@ -81,11 +81,15 @@ static __global__ void __launch_bounds__(256) colsum_h_partial_kernel(const half
 }
 static __global__ void __launch_bounds__(256) colsum_h_final_kernel(const float* partial, const int slices, const int cols, half_t* out, const int accumulate)
 {
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= cols) return;
-	float s = 0.f;
-	for (int i = 0; i < slices; i++) s += partial[(long)i * cols + c];
-	out[c] = (half_t)(accumulate ? (float)out[c] + s : s);
+	__shared__ float red[FOLD_PH][FOLD_CH]; // 16 columns x 16 phases per workgroup (common.h)
+	const int ch = threadIdx.x & (FOLD_CH - 1), phase = threadIdx.x / FOLD_CH;
+	const int c = blockIdx.x * FOLD_CH + ch;
+	red[phase][ch] = c < cols ? fold_slices(partial, slices, cols, c, phase) : 0.f;
+	__syncthreads();
+	if (phase == 0 && c < cols) {
+		const float s = fold_phases(red, ch);
+		out[c] = (half_t)(accumulate ? (float)out[c] + s : s);
+	}
 }
 int colsum_f16(const void* xv, long rows, int cols, long ld, void* outv, int accumulate, ccv_nnc_stream_context_t* ctx)
 {
@@ -104,23 +108,32 @@ int colsum_f16(const void* xv, long rows, int cols, long ld, void* outv, int acc
 	hipStream_t stream = stream_of(ctx);
 	hipLaunchKernelGGL(colsum_h_partial_kernel, dim3(col_tiles, (unsigned)slices), dim3(256), 0, stream, x, rows, cols, ld, rows_per_slice > 0 ? rows_per_slice : 1, partial);
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(colsum_h_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, (const float*)partial, (int)slices, cols, out, accumulate);
+	hipLaunchKernelGGL(colsum_h_final_kernel, dim3((cols + FOLD_CH - 1) / FOLD_CH), dim3(256), 0, stream, (const float*)partial, (int)slices, cols, out, accumulate);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
 // out[c] (+)= sum over (o, i) of x[(o * C + c) * inner + i] for halves (bias gradient of an NCHW convolution): one workgroup per
 // plane, fp32 partials in the workspace, folded per channel in a fixed order.
-static __global__ void __launch_bounds__(256) plane_sum_h_kernel(const half_t* x, const int C, const long inner, float* partial)
-{
-	__shared__ float red[4];
-	const long base = ((long)blockIdx.y * C + blockIdx.x) * inner;
-	float s = 0.f;
-	for (long i = threadIdx.x; i < inner; i += 256) s += (float)x[base + i];
-	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-	__syncthreads();
-	if (threadIdx.x == 0) partial[(long)blockIdx.y * C + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+static __global__ void __launch_bounds__(256) plane_sum_h_kernel(const half_t* __restrict__ x, const long planes, const long inner, float* __restrict__ partial)
+{ // a WAVE per plane (8 halves per 16-byte load when the plane allows): a workgroup per plane left 7 x 7 planes with 49 busy threads
+	typedef half_t h8 __attribute__((ext_vector_type(8)));
+	const int lane = threadIdx.x & 63;
+	const long nw = (long)gridDim.x * 4;
+	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+		const half_t* const p = x + pl * inner;
+		float s = 0.f;
+		if ((inner & 7) == 0 && (((uintptr_t)p) & 15) == 0) {
+			for (long i = lane; i < (inner >> 3); i += 64) {
+				const h8 v = ((const h8*)p)[i];
+#pragma unroll
+				for (int e = 0; e < 8; e++) s += (float)v[e];
+			}
+		} else
+			for (long i = lane; i < inner; i += 64) s += (float)p[i];
+		for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+		if (lane == 0) partial[pl] = s;
+	}
 }
 int chan_sum_planes_f16(const void* x, long outer, int C, long inner, void* out, int accumulate, ccv_nnc_stream_context_t* ctx)
 {
@@ -128,9 +141,10 @@ int chan_sum_planes_f16(const void* x, long outer, int C, long inner, void* out,
 	float* partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)outer * C);
 	if (!partial) return CCV_NNC_EXEC_OOM;
 	hipStream_t stream = stream_of(ctx);
-	hipLaunchKernelGGL(plane_sum_h_kernel, dim3(C, (unsigned)outer), dim3(256), 0, stream, (const half_t*)x, C, inner, partial);
+	const long planes = outer * C, want = (planes + 3) / 4;
+	hipLaunchKernelGGL(plane_sum_h_kernel, dim3((unsigned)(want < 0x7fffffffL ? want : 0x7fffffffL)), dim3(256), 0, stream, (const half_t*)x, planes, inner, partial);
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(colsum_h_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)partial, (int)outer, C, (half_t*)out, accumulate);
+	hipLaunchKernelGGL(colsum_h_final_kernel, dim3((C + FOLD_CH - 1) / FOLD_CH), dim3(256), 0, stream, (const float*)partial, (int)outer, C, (half_t*)out, accumulate);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
