@@ -109,7 +109,8 @@ def resnet_config(args, half, dawn=False):
     exe = os.path.join(ROOT, "oracle", "_ref", "host_resnet_bench.gpu")
     if not os.path.exists(exe):
         raise SystemExit("oracle/_ref/host_resnet_bench.gpu not built (oracle/build_ref_host.sh)")
-    r = subprocess.run([exe, str(args.batch), "32" if dawn else "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"] + (["dawn"] if dawn else []), capture_output=True, text=True, timeout=3000)
+    devices = 1 if dawn else max(1, args.gpus)  # the reference's single-process data parallelism (ccv_cnnp_model_set_data_parallel): `batch` per device
+    r = subprocess.run([exe, str(args.batch), "32" if dawn else "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"] + (["dawn"] if dawn else ["full", str(devices)]), capture_output=True, text=True, timeout=3000)
     if r.returncode != 0:
         raise SystemExit("host_resnet_bench failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
     h = json.loads(r.stdout.strip().splitlines()[-1])
@@ -117,12 +118,12 @@ def resnet_config(args, half, dawn=False):
     if dawn:  # DawnNet: 3x3 convolutions 3->64 @32^2, 64->128 @32^2, 2 x 128->128 @16^2, 128->256 @16^2, 256->512 @8^2, 2 x 512->512 @4^2, dense 512->10; x3 for fwd + bwd
         macs = 9 * (3 * 64 * 1024 + 64 * 128 * 1024 + 2 * 128 * 128 * 256 + 128 * 256 * 256 + 256 * 512 * 64 + 2 * 512 * 512 * 16) + 5120
         gflop = 3 * 2 * macs / 1e9
-    out = {"metric": ("images/sec fwd+bwd CIFAR-10 DawnNet 32x32 bs%d NCHW" if dawn else "images/sec fwd+bwd ResNet-50 v1d 224x224 bs%d NCHW") % args.batch, "value": h["images_per_s"], "unit": "images/s", "n_gpus": 1,
+    out = {"metric": ("images/sec fwd+bwd CIFAR-10 DawnNet 32x32 bs%d NCHW" if dawn else "images/sec fwd+bwd ResNet-50 v1d 224x224 bs%d NCHW") % args.batch, "value": h["images_per_s"], "unit": "images/s", "n_gpus": devices,
            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f16" if half else "f32", "data": "synthetic",
            "config": {"workload": ("CIFAR-10 DawnNet (bin/nnc/cifar-10.c:76-127) NCHW, the trainer's own step (evaluate, softmax cross-entropy, backward, apply gradients; Nesterov SGD), batch %d, random-init weights, driven by the reference host's model API" if dawn else
                                    "ResNet-50 v1d (bin/nnc/imagenet.c) NCHW forward+backward+Nesterov SGD, batch %d, random-init weights, driven by the reference host's ccv_cnnp_model_fit") % args.batch,
-                      "global_batch": args.batch, "parallelism": "dp1", "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] * gflop / 1e3,
+                      "global_batch": args.batch * devices, "parallelism": "dp%d%s" % (devices, " (one process, ccv_cnnp_model_set_data_parallel; gradients all-reduced by the COMM_ALLREDUCE rows over RCCL)" if devices > 1 else ""), "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] / devices * gflop / 1e3,
                       "first_step_ms": h["first_step_ms"], "outputs_finite": h["outputs_finite"], "softmax_worst_row_sum_err": h["softmax_worst_row_sum_err"], "memory_gib": h["memory_gib"]}}
     ks = h.get("kernels", [])
     bn = [k for k in ks if k["bytes"] > 0 and k["ms"] > 0]
@@ -180,8 +181,11 @@ def main():
     if args.config.startswith("cifar10") and args.batch == 256:
         args.batch = 512
     if args.config.startswith("resnet50") or args.config.startswith("cifar10"):
-        if world > 1:
-            raise SystemExit("--config %s is a one-GPU line (the N-GPU form of this path is the reference host's single-process ccv_cnnp_model_set_data_parallel)" % args.config)
+        if world > 1:  # started under torch.distributed.run: this path is ONE process driving all the GPUs (the reference host's own data parallelism)
+            if rank != 0:
+                return
+            if args.config.startswith("cifar10"):
+                raise SystemExit("--config %s is a one-GPU line" % args.config)
         nnc.load()  # fail loudly without the HIP library / a GPU
         return resnet_config(args, "f16" in args.config, dawn=args.config.startswith("cifar10"))
     if world != args.gpus and world > 1:

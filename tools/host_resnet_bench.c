@@ -125,6 +125,15 @@ int main(int argc, char** argv)
 	const int half = argc > 5 && atoi(argv[5]) == 16;
 	const int mini = argc > 6 && strcmp(argv[6], "mini") == 0;
 	const int is_dawn = argc > 6 && strcmp(argv[6], "dawn") == 0;
+	/* argv[7]: devices.  > 1 = the reference's single-process data parallelism (ccv_cnnp_model_set_data_parallel,
+	 * lib/nnc/ccv_cnnp_model.c; the graph is replicated per device by ccv_nnc_symbolic_graph_data_parallel and every parameter
+	 * gradient all-reduced with COMM_ALLREDUCE): `batch` images PER DEVICE, as bin/nnc/imagenet.c:314-317 drives it. */
+	const int devices = argc > 7 ? atoi(argv[7]) : 1;
+	/* argv[8]: rotation of the shards over the devices (device d gets shard (d + rot) % devices).  A test runs rot = 0 and rot = 1:
+	 * replicas whose gradients are really summed hold the same parameters either way, so a shard's outputs must not depend on
+	 * which device it ran on. */
+	const int rot = argc > 8 ? atoi(argv[8]) : 0;
+	if (devices < 1 || devices > 8 || (devices > 1 && is_dawn)) { fprintf(stderr, "devices must be 1..8 (fit path only)\n"); return 2; }
 	const int dt = half ? CCV_16F : CCV_32F;
 	static const int blocks50[] = { 3, 4, 6, 3 }, widths50[] = { 64, 128, 256, 512 };
 	static const int blocks_m[] = { 1, 1 }, widths_m[] = { 8, 16 };
@@ -135,17 +144,19 @@ int main(int argc, char** argv)
 	input.datatype = dt;
 	const float lr = 0.01f, wd = 0.0001f;
 	if (is_dawn) ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / batch, 0.01, 0.9, 0), CMD_NOOP());
-	else ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / batch, wd, 0.9, 0), CMD_CATEGORICAL_CROSSENTROPY_FORWARD());
+	else ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / (batch * devices), wd, 0.9, 0), CMD_CATEGORICAL_CROSSENTROPY_FORWARD());
+	if (devices > 1) ccv_cnnp_model_set_data_parallel(model, devices);
 	/* synthetic batch: images ~ U(-1, 1) (normalised pixels), labels as the trainer's smoothed one-hot rows (eta = 0.1) */
 	ccv_nnc_tensor_t* const hx = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, 3, hw, hw), 0);
 	ccv_nnc_tensor_t* const hfit = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, classes), 0);
 	size_t j;
 	const size_t nx = (size_t)batch * 3 * hw * hw;
-	for (j = 0; j < nx; j++) hx->data.f32[j] = hash_unit(j, 2000) * 2 - 1;
+	const int shard0 = rot % devices;
+	for (j = 0; j < nx; j++) hx->data.f32[j] = hash_unit(j, 2000 + 10 * shard0) * 2 - 1;
 	const float eta = 0.1f;
 	int i;
 	for (i = 0; i < batch; i++) {
-		const int c = (int)(hash_unit(i, 2001) * classes);
+		const int c = (int)(hash_unit(i, 2001 + 10 * shard0) * classes);
 		int k;
 		for (k = 0; k < classes; k++) hfit->data.f32[(size_t)i * classes + k] = (k == c ? 1 - eta : 0) + eta / classes;
 	}
@@ -163,7 +174,37 @@ int main(int argc, char** argv)
 		ccv_nnc_tensor_free(hfit16);
 	} else
 		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx, hfit), TENSOR_LIST(x, fit), 0);
+	/* devices 1 .. n-1: their own shards */
+	ccv_nnc_tensor_t* xs[8]; ccv_nnc_tensor_t* fits[8]; ccv_nnc_tensor_t* outs[8];
+	xs[0] = x; fits[0] = fit; outs[0] = out;
+	{
+		int d;
+		for (d = 1; d < devices; d++) {
+			ccv_nnc_tensor_param_t xd = xp, fd = fp;
+			CCV_TENSOR_SET_DEVICE_ID(xd.type, d); CCV_TENSOR_SET_DEVICE_ID(fd.type, d);
+			xs[d] = ccv_nnc_tensor_new(0, xd, 0); fits[d] = ccv_nnc_tensor_new(0, fd, 0); outs[d] = ccv_nnc_tensor_new(0, fd, 0);
+			const int shard = (d + rot) % devices;
+			for (j = 0; j < nx; j++) hx->data.f32[j] = hash_unit(j, 2000 + 10 * shard) * 2 - 1;
+			for (i = 0; i < batch; i++) {
+				const int c = (int)(hash_unit(i, 2001 + 10 * shard) * classes);
+				int k;
+				for (k = 0; k < classes; k++) hfit->data.f32[(size_t)i * classes + k] = (k == c ? 1 - eta : 0) + eta / classes;
+			}
+			if (half) {
+				ccv_nnc_tensor_t* const hx16 = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(16F, batch, 3, hw, hw), 0);
+				ccv_nnc_tensor_t* const hfit16 = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(16F, batch, classes), 0);
+				ccv_nnc_cmd_exec(CMD_DATATYPE_CONVERSION_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx, hfit), TENSOR_LIST(hx16, hfit16), 0);
+				ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx16, hfit16), TENSOR_LIST(xs[d], fits[d]), 0);
+				ccv_nnc_tensor_free(hx16);
+				ccv_nnc_tensor_free(hfit16);
+			} else
+				ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx, hfit), TENSOR_LIST(xs[d], fits[d]), 0);
+		}
+	}
 	ccv_nnc_stream_context_t* const stream = ccv_nnc_stream_context_new(CCV_STREAM_CONTEXT_GPU);
+	/* reproducible parameter initialisation: the host seeds its generators from a thread-local ADDRESS otherwise (ccv_nnc_stream.c:262-281) */
+	ccv_nnc_stream_context_set_seed(0, 20240923);
+	ccv_nnc_stream_context_set_seed(stream, 20240924);
 	/* dawn: the CIFAR trainer's step (cifar-10.c:259-273); labels are class indices in fp32, the softmax / gradient tensors have the outputs' type */
 	ccv_nnc_tensor_t* const labels = ccv_nnc_tensor_new(0, GPU_TENSOR_NCHW(000, 32F, batch), 0);
 	ccv_nnc_tensor_t* const softmax = ccv_nnc_tensor_new(0, fp, 0);
@@ -182,7 +223,7 @@ int main(int argc, char** argv)
 			ccv_cnnp_model_backward(model, TENSOR_LIST(grad), TENSOR_LIST(), 0, stream); \
 			ccv_cnnp_model_apply_gradients(model, stream); \
 		} else \
-			ccv_cnnp_model_fit(model, TENSOR_LIST(x), TENSOR_LIST(fit), TENSOR_LIST(out), 0, stream); \
+			ccv_cnnp_model_fit(model, xs, devices, fits, devices, outs, devices, 0, stream); \
 	} while (0)
 	/* step 1: compiles the graph (autodiff, simplify, arena, schedule) and initialises the parameters */
 	const double t_first0 = now_ms();
@@ -213,6 +254,22 @@ int main(int argc, char** argv)
 	for (i = 0; i < steps; i++) TRAIN_STEP();
 	ccv_nnc_stream_context_wait(stream);
 	const double ms = (now_ms() - t0) / (steps > 0 ? steps : 1);
+	/* per device: sum and sum of squares of the softmax outputs of the last timed step (replicas fed the same shard must agree
+	 * exactly, and -- the all-reduced gradient of identical shards being the single-device gradient -- with a one-device run) */
+	double dev_sum[8], dev_sumsq[8];
+	for (i = 0; i < devices; i++) {
+		ccv_nnc_tensor_t* const src = (is_dawn && i == 0) ? softmax : outs[i];
+		if (half) {
+			ccv_nnc_tensor_t* const h16 = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(16F, batch, classes), 0);
+			ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(src), TENSOR_LIST(h16), 0);
+			ccv_nnc_cmd_exec(CMD_DATATYPE_CONVERSION_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(h16), TENSOR_LIST(hout), 0);
+			ccv_nnc_tensor_free(h16);
+		} else
+			ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(src), TENSOR_LIST(hout), 0);
+		double a = 0, b = 0;
+		for (j = 0; j < (size_t)batch * classes; j++) { a += hout->data.f32[j]; b += (double)hout->data.f32[j] * hout->data.f32[j]; }
+		dev_sum[i] = a; dev_sumsq[i] = b;
+	}
 	/* roofline leg: one more step with the backend's per-launch HIP-event records on (contractions and batch norm) */
 	nnc_mi355x_profile_enable(1);
 	TRAIN_STEP();
@@ -236,9 +293,14 @@ int main(int argc, char** argv)
 	printf("{\"kernels\": [");
 	for (i = 0; i < nagg; i++) printf("%s{\"name\": \"%s\", \"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}", i ? ", " : "", agg[i].name, agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes);
 	printf("], ");
+	printf("\"device_out_sumsq\": [");
+	for (i = 0; i < devices; i++) printf("%s%.17g", i ? ", " : "", dev_sumsq[i]);
+	printf("], \"device_out_sum\": [");
+	for (i = 0; i < devices; i++) printf("%s%.17g", i ? ", " : "", dev_sum[i]);
+	printf("], ");
 	printf("\"driver\": \"reference host (ccv_cnnp_model_fit: cnnp, autodiff, compile, scheduler)\", \"model\": \"%s\", \"dtype\": \"%s\", \"format\": \"NCHW\", \"batch\": %d, \"input_hw\": %d, "
-		"\"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"first_step_ms\": %.1f, \"softmax_row0_sum\": %.6f, \"softmax_worst_row_sum_err\": %.3g, \"outputs_finite\": %s, \"memory_gib\": %.3f}\n",
-		is_dawn ? "CIFAR-10 DawnNet (bin/nnc/cifar-10.c)" : mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, ms, batch / (ms * 1e-3), t_first, row0, worst, finite ? "true" : "false",
+		"\"devices\": %d, \"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"first_step_ms\": %.1f, \"softmax_row0_sum\": %.6f, \"softmax_worst_row_sum_err\": %.3g, \"outputs_finite\": %s, \"memory_gib\": %.3f}\n",
+		is_dawn ? "CIFAR-10 DawnNet (bin/nnc/cifar-10.c)" : mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, devices, ms, (double)batch * devices / (ms * 1e-3), t_first, row0, worst, finite ? "true" : "false",
 		(double)ccv_cnnp_model_memory_size(model) / (1024.0 * 1024.0 * 1024.0));
 	ccv_nnc_tensor_free(labels);
 	ccv_nnc_tensor_free(softmax);
@@ -246,9 +308,7 @@ int main(int argc, char** argv)
 	ccv_nnc_tensor_free(hout);
 	ccv_nnc_tensor_free(hx);
 	ccv_nnc_tensor_free(hfit);
-	ccv_nnc_tensor_free(x);
-	ccv_nnc_tensor_free(fit);
-	ccv_nnc_tensor_free(out);
+	for (i = 0; i < devices; i++) { ccv_nnc_tensor_free(xs[i]); ccv_nnc_tensor_free(fits[i]); ccv_nnc_tensor_free(outs[i]); }
 	ccv_cnnp_model_free(model);
 	ccv_nnc_stream_context_free(stream);
 	return 0;
