@@ -335,6 +335,7 @@ static void conv_c3_args(const conv_geom_t& g, const Image4& a, const float* w, 
 	c->a_sn = a.sn; c->a_sh = a.sh; c->b_sn = b.sn; c->b_sh = b.sh; c->b_sw = b.sw;
 	c->N = g.N; c->H = g.H; c->W = g.W; c->OH = g.OH; c->OW = g.OW; c->K = g.K; c->pad_y = g.pby; c->pad_x = g.pbx;
 	c->groups_per_row = (g.OW + 15) / 16; c->groups = g.N * g.OH * c->groups_per_row;
+	c->d_gpr.init(c->groups_per_row); c->d_oh.init(g.OH);
 }
 static int conv_c3_forw(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, ccv_nnc_stream_context_t* const ctx)
 {

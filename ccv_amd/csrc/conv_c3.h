@@ -23,6 +23,7 @@ struct ConvC3Args {
 	int N, H, W, OH, OW, K;
 	int pad_y, pad_x;
 	int groups_per_row, groups; // 16-pixel groups per output row, total
+	FastDiv d_gpr, d_oh;        // group -> (row, position), row -> (image, oy) without hardware division (two per 28-MFMA group otherwise)
 };
 
 // element k (0..26; 27 = padding) of the patch of output pixel (oy, ox): row dy = k / 9, offset k % 9 into the 9-float run
@@ -52,8 +53,8 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const ConvC3
 	for (int j = 0; j < NT; j++) bv[j] = g.bias ? g.bias[NT * n + j] : 0.f;
 	const int waves = (gridDim.x * blockDim.x) >> 6;
 	for (int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; grp < g.groups; grp += waves) {
-		const int row = grp / g.groups_per_row, gx = grp - row * g.groups_per_row; // row = n * OH + oy
-		const int img = row / g.OH, oy = row - img * g.OH;
+		const int row = g.d_gpr.div(grp), gx = grp - row * g.groups_per_row; // row = n * OH + oy
+		const int img = g.d_oh.div(row), oy = row - img * g.OH;
 		const int ox0 = gx * 16;
 		const float* const ap = g.a + (long)img * g.a_sn;
 		float av[7];
@@ -95,8 +96,8 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_wgrad_kernel(const Conv
 	for (int i = 0; i < MT; i++) { acc[i][0] = floatx4{ 0.f, 0.f, 0.f, 0.f }; acc[i][1] = floatx4{ 0.f, 0.f, 0.f, 0.f }; }
 	const int waves = (gridDim.x * blockDim.x) >> 6, wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	for (int grp = wid; grp < g.groups; grp += waves) {
-		const int row = grp / g.groups_per_row, gx = grp - row * g.groups_per_row;
-		const int img = row / g.OH, oy = row - img * g.OH;
+		const int row = g.d_gpr.div(grp), gx = grp - row * g.groups_per_row;
+		const int img = g.d_oh.div(row), oy = row - img * g.OH;
 		const int ox0 = gx * 16;
 		const float* const ap = g.a + (long)img * g.a_sn;
 		const float* const gp = g.b + (long)img * g.b_sn + (long)oy * g.b_sh;

@@ -22,8 +22,9 @@ def _expected():
 
 
 EXPECTED = _expected()
-# convolutions at the reference tests' sizes (64 x 224 x 224 images) take minutes on the emulator
-QUICK = [(s, n) for s, n in EXPECTED if "convolution" not in n]
+# convolutions at the reference tests' sizes (64 x 224 x 224 images) take minutes on the emulator, and so do the twelve attention
+# trials of the flash_attn gradient case (B = 32, R = 160 ...; tests/test_attention.py covers the row on the emulator at small sizes)
+QUICK = [(s, n) for s, n in EXPECTED if "convolution" not in n and "scaled dot product attention" not in n]
 
 
 _VERDICTS = {}
