@@ -1,5 +1,5 @@
 // Bandwidth-bound element-wise commands on gfx950: RELU, EWSUM, SCALAR_MUL, SGD, SET, DATA_TRANSFER, plus the
-// column-sum used for bias gradients.  All kernels are grid-stride, 16 bytes per lane where the tensors allow it
+// column-sum used for bias gradients.  16 bytes per lane where the tensors allow it; the element-wise map is a tile per workgroup over a full grid, the others grid-stride
 // (coalesced dwordx4), otherwise 4 bytes per lane.  Roofline for every kernel here is HBM (8 TB/s spec);
 // algorithmic bytes are listed per kernel.
 // Oracle semantics:

@@ -329,39 +329,110 @@ struct jitter_dev_t {
 	int xs, xt, ys, yt;       // offsets (elements) of this image's tap-start / tap arrays in the packed tables
 	int res_rows, res_cols;   // size after resampling
 	int crop_x, crop_y, flip; // window origin in the resampled image, mirror in x
+	int nops, mean_slot;      // colour operations; index of this image's contrast mean in the means array (-1: no contrast)
+	int kind[4];
+	float v[4][3];
 };
-template <typename TO>
-__global__ void __launch_bounds__(256) jitter_kernel(const unsigned char* src, const jitter_dev_t* imgs, const int* starts, const tap_f32_t* taps, TO* out,
-	const int out_rows, const int out_cols, const int ch, const int nchw, const float m0, const float m1, const float m2, const float s0, const float s1, const float s2, const size_t total)
+// resampled value of channel c at (ry, rx) of the resampled image (before the mirror)
+__device__ __forceinline__ float jitter_sample(const unsigned char* __restrict__ src, const jitter_dev_t& im, const int* __restrict__ starts, const tap_f32_t* __restrict__ taps, const int ry, const int rx, const int c)
 {
+	const int* xs = starts + im.xs;
+	const int* ys = starts + im.ys;
+	const tap_f32_t* xt = taps + im.xt;
+	const tap_f32_t* yt = taps + im.yt;
+	const unsigned char* base = src + im.src;
+	float acc = 0.f;
+	for (int ky = ys[ry]; ky < ys[ry + 1]; ky++) {
+		const unsigned char* row = base + (long)yt[ky].si * im.step + c;
+		float h = 0.f;
+		for (int kx = xs[rx]; kx < xs[rx + 1]; kx++) h += (float)row[xt[kx].si] * xt[kx].w;
+		acc += h * yt[ky].w;
+	}
+	return acc;
+}
+// operations [0, upto) of the image's colour list on one pixel; every operation stores floats, like the reference's in-place ccv_* calls
+__device__ __forceinline__ void jitter_color(float p[3], const jitter_dev_t& im, const int upto, const double* __restrict__ mean)
+{
+	for (int o = 0; o < upto; o++) {
+		const double ds = (double)im.v[o][0];
+		switch (im.kind[o]) {
+			case NNC_MI355X_COLOR_BRIGHTNESS: // ccv_scale (ccv_algebra.c:272-): p * ds
+				for (int k = 0; k < 3; k++) p[k] = (float)((double)p[k] * ds);
+				break;
+			case NNC_MI355X_COLOR_SATURATION: { // ccv_saturation (ccv_image_processing.c:46-71)
+				const double gs = (double)p[0] * 0.299 + (double)p[1] * 0.587 + (double)p[2] * 0.114;
+				for (int k = 0; k < 3; k++) p[k] = (float)(((double)p[k] - gs) * ds + gs);
+				break;
+			}
+			case NNC_MI355X_COLOR_CONTRAST: // ccv_contrast (:73-125): about the image's per-channel mean
+				for (int k = 0; k < 3; k++) p[k] = (float)(((double)p[k] - mean[k]) * ds + mean[k]);
+				break;
+			case NNC_MI355X_COLOR_LIGHTING: // _ccv_cnnp_image_lighting (dataframe_addons.c:187-198): float add, clamp to [0, 255]
+				for (int k = 0; k < 3; k++) { const float q = p[k] + im.v[o][k]; p[k] = q < 0.f ? 0.f : (q > 255.f ? 255.f : q); }
+				break;
+		}
+	}
+}
+// Contrast needs the mean of the WHOLE resampled image as it stands when the operation is reached: the operations in front of it
+// applied to every resampled pixel, summed per channel in double.  grid (chunks, images with a contrast operation); partial sums
+// per chunk, folded by jitter_mean_fold_kernel in chunk order.
+constexpr int JM_CHUNKS = 32;
+__global__ void __launch_bounds__(256) jitter_mean_kernel(const unsigned char* __restrict__ src, const jitter_dev_t* __restrict__ imgs, const int* __restrict__ list, const int* __restrict__ starts, const tap_f32_t* __restrict__ taps, double* __restrict__ partial)
+{
+	__shared__ double red[4][3];
+	const jitter_dev_t im = imgs[list[blockIdx.y]];
+	int upto = 0;
+	while (upto < im.nops && im.kind[upto] != NNC_MI355X_COLOR_CONTRAST) upto++;
+	const long npix = (long)im.res_rows * im.res_cols;
+	const long per = (npix + JM_CHUNKS - 1) / JM_CHUNKS, p0 = blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+	double s[3] = { 0, 0, 0 };
+	for (long i = p0 + threadIdx.x; i < p1; i += 256) {
+		const int ry = (int)(i / im.res_cols), rx = (int)(i - (long)ry * im.res_cols);
+		float p[3];
+		for (int c = 0; c < 3; c++) p[c] = jitter_sample(src, im, starts, taps, ry, rx, c);
+		jitter_color(p, im, upto, 0);
+		for (int c = 0; c < 3; c++) s[c] += (double)p[c];
+	}
+	for (int c = 0; c < 3; c++) {
+		double v = s[c];
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) partial[((long)blockIdx.y * JM_CHUNKS + blockIdx.x) * 3 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void jitter_mean_fold_kernel(const double* __restrict__ partial, const jitter_dev_t* __restrict__ imgs, const int* __restrict__ list, double* __restrict__ means, const int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * 3) return;
+	const int slot = i / 3, c = i - slot * 3;
+	double s = 0;
+	for (int k = 0; k < JM_CHUNKS; k++) s += partial[((long)slot * JM_CHUNKS + k) * 3 + c];
+	const jitter_dev_t& im = imgs[list[slot]];
+	means[i] = s / ((double)im.res_rows * im.res_cols);
+}
+template <typename TO>
+__global__ void __launch_bounds__(256) jitter_kernel(const unsigned char* src, const jitter_dev_t* imgs, const int* starts, const tap_f32_t* taps, const double* means, TO* out,
+	const int out_rows, const int out_cols, const int ch, const int nchw, const float m0, const float m1, const float m2, const float s0, const float s1, const float s2, const size_t total)
+{ // one thread per output PIXEL (all its channels: saturation mixes them); lanes run along the row
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	const float mean_c[3] = { m0, m1, m2 }, inv_c[3] = { s0, s1, s2 };
 	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-		// idx walks the OUTPUT tensor in its own memory order (coalesced stores)
 		size_t r = idx;
-		int c, ox, oy;
-		if (nchw) { ox = (int)(r % out_cols); r /= out_cols; oy = (int)(r % out_rows); r /= out_rows; c = (int)(r % ch); r /= ch; }
-		else { c = (int)(r % ch); r /= ch; ox = (int)(r % out_cols); r /= out_cols; oy = (int)(r % out_rows); r /= out_rows; }
+		const int ox = (int)(r % out_cols); r /= out_cols;
+		const int oy = (int)(r % out_rows); r /= out_rows;
 		const jitter_dev_t im = imgs[r];
 		const int ry = oy + im.crop_y;
 		int rx = ox + im.crop_x;
-		float v = 0.f;
+		float p[3] = { 0.f, 0.f, 0.f };
 		if (ry >= 0 && ry < im.res_rows && rx >= 0 && rx < im.res_cols) {
 			if (im.flip) rx = im.res_cols - 1 - rx;
-			const int* xs = starts + im.xs;
-			const int* ys = starts + im.ys;
-			const tap_f32_t* xt = taps + im.xt;
-			const tap_f32_t* yt = taps + im.yt;
-			const unsigned char* base = src + im.src;
-			float acc = 0.f;
-			for (int ky = ys[ry]; ky < ys[ry + 1]; ky++) {
-				const unsigned char* row = base + (long)yt[ky].si * im.step + c;
-				float h = 0.f;
-				for (int kx = xs[rx]; kx < xs[rx + 1]; kx++) h += (float)row[xt[kx].si] * xt[kx].w;
-				acc += h * yt[ky].w;
-			}
-			v = (acc - (c == 0 ? m0 : c == 1 ? m1 : m2)) * (c == 0 ? s0 : c == 1 ? s1 : s2);
+			for (int c = 0; c < ch; c++) p[c] = jitter_sample(src, im, starts, taps, ry, rx, c);
+			if (im.nops) jitter_color(p, im, im.nops, im.mean_slot >= 0 ? means + 3 * im.mean_slot : 0);
+			for (int c = 0; c < ch; c++) p[c] = (p[c] - mean_c[c]) * inv_c[c];
 		}
-		out[idx] = (TO)v;
+		const size_t plane = (size_t)out_rows * out_cols, pix = (size_t)oy * out_cols + ox;
+		for (int c = 0; c < ch; c++) out[nchw ? (r * ch + c) * plane + pix : (r * plane + pix) * ch + c] = (TO)p[c];
 	}
 }
 template <typename TO>
@@ -459,6 +530,7 @@ int nnc_mi355x_jitter_batch(const void* src, const nnc_mi355x_jitter_image_t* im
 	if (count == 0) return CCV_NNC_EXEC_SUCCESS;
 	const int ch = params.channels;
 	std::vector<jitter_dev_t> descs(count);
+	std::vector<int> mean_list; // images with a contrast operation
 	std::vector<int> starts;
 	std::vector<tap_f32_t> taps;
 	for (int i = 0; i < count; i++) {
@@ -467,6 +539,17 @@ int nnc_mi355x_jitter_batch(const void* src, const nnc_mi355x_jitter_image_t* im
 		jitter_dev_t& d = descs[i];
 		d.src = (long)im.offset + (long)im.slice_y * im.step + (long)im.slice_x * ch;
 		d.step = im.step; d.res_rows = im.resize_rows; d.res_cols = im.resize_cols; d.crop_x = im.crop_x; d.crop_y = im.crop_y; d.flip = im.flip ? 1 : 0;
+		if (im.color_ops < 0 || im.color_ops > 4 || (im.color_ops && ch != 3)) return CCV_NNC_EXEC_INVALID;
+		d.nops = im.color_ops; d.mean_slot = -1;
+		int contrasts = 0;
+		for (int o = 0; o < 4; o++) {
+			d.kind[o] = o < im.color_ops ? im.color[o].kind : 0;
+			for (int k = 0; k < 3; k++) d.v[o][k] = o < im.color_ops ? im.color[o].v[k] : 0.f;
+			if (o < im.color_ops && (d.kind[o] < NNC_MI355X_COLOR_BRIGHTNESS || d.kind[o] > NNC_MI355X_COLOR_LIGHTING)) return CCV_NNC_EXEC_INVALID;
+			if (d.kind[o] == NNC_MI355X_COLOR_CONTRAST) contrasts++;
+		}
+		if (contrasts > 1) return CCV_NNC_EXEC_INVALID; // (the reference applies each operation at most once)
+		if (contrasts) { d.mean_slot = (int)mean_list.size(); mean_list.push_back(i); }
 		std::vector<int> xs, ys;
 		std::vector<tap_f32_t> xt, yt;
 		const double scale_x = (double)im.slice_cols / im.resize_cols, scale_y = (double)im.slice_rows / im.resize_rows;
@@ -509,12 +592,24 @@ int nnc_mi355x_jitter_batch(const void* src, const nnc_mi355x_jitter_image_t* im
 	}
 	upload_t u;
 	const size_t od = u.add(descs.data(), descs.size() * sizeof(jitter_dev_t)), os = u.add(starts.data(), starts.size() * sizeof(int)), ot = u.add(taps.data(), taps.size() * sizeof(tap_f32_t));
+	const size_t nm = mean_list.size();
+	const int zero = 0;
+	const size_t ol = u.add(nm ? (const void*)mean_list.data() : (const void*)&zero, sizeof(int) * (nm ? nm : 1));
+	// behind the tables: the contrast means and their per-chunk partial sums (device scratch, not uploaded)
+	const size_t tables = (u.host.size() + 15) & ~(size_t)15;
+	const size_t omean = tables, opart = omean + sizeof(double) * 3 * (nm ? nm : 1);
+	u.host.resize(opart + sizeof(double) * 3 * JM_CHUNKS * (nm ? nm : 1));
 	char* dev = upload(u, stream_context);
 	if (!dev) return CCV_NNC_EXEC_OOM;
-	const size_t total = (size_t)count * params.out_rows * params.out_cols * ch;
+	const size_t total = (size_t)count * params.out_rows * params.out_cols; // pixels
 	hipStream_t stream = stream_of(stream_context);
+	if (nm) {
+		hipLaunchKernelGGL(jitter_mean_kernel, dim3(JM_CHUNKS, (unsigned)nm), dim3(256), 0, stream, (const unsigned char*)src, (const jitter_dev_t*)(dev + od), (const int*)(dev + ol), (const int*)(dev + os), (const tap_f32_t*)(dev + ot), (double*)(dev + opart));
+		hipLaunchKernelGGL(jitter_mean_fold_kernel, dim3((unsigned)((nm * 3 + 63) / 64)), dim3(64), 0, stream, (const double*)(dev + opart), (const jitter_dev_t*)(dev + od), (const int*)(dev + ol), (double*)(dev + omean), (int)nm);
+		HIP_ENFORCE(hipGetLastError());
+	}
 	const int nchw = params.format == CCV_TENSOR_FORMAT_NCHW;
-#define JITTER(TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(jitter_kernel<TO>), dim3(grid_for(total, 256)), dim3(256), 0, stream, (const unsigned char*)src, (const jitter_dev_t*)(dev + od), (const int*)(dev + os), (const tap_f32_t*)(dev + ot), (TO*)out, \
+#define JITTER(TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(jitter_kernel<TO>), dim3(grid_for(total, 256)), dim3(256), 0, stream, (const unsigned char*)src, (const jitter_dev_t*)(dev + od), (const int*)(dev + os), (const tap_f32_t*)(dev + ot), (const double*)(dev + omean), (TO*)out, \
 		params.out_rows, params.out_cols, ch, nchw, params.mean[0], params.mean[1], params.mean[2], params.inv_std[0], params.inv_std[1], params.inv_std[2], total)
 	if (odt == CCV_32F) JITTER(float); else JITTER(_Float16);
 #undef JITTER

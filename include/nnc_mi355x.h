@@ -371,7 +371,11 @@ int nnc_mi355x_filter_batch(const void* a, const nnc_mi355x_image_batch_t a_desc
  * shrinking, bicubic otherwise, :335-344), mirrors (:347), normalises (:351-354; before the late crop, whose overhang stays 0) and
  * writes the batch tensor the trainer consumes (NHWC / NCHW, CCV_32F / CCV_16F) in one kernel.  Source images: 8u, interleaved
  * channels (what ccv_read produces), anywhere in ONE device buffer (e.g. a pinned staging ring copied with one H2D per batch).
- * Not in this slice: contrast / saturation / lighting (_ccv_cnnp_image_manip, :165-253). */
+ * Colour jitter (_ccv_cnnp_image_manip, :213-253): up to four per-image operations in the order the reference's shuffle produced,
+ * with the factors its generator drew -- brightness (ccv_scale), saturation (ccv_saturation), contrast (ccv_contrast: about the
+ * per-channel MEAN of the image as it stands at that point, which the device computes over the whole resampled image) and lighting
+ * (three PCA offsets, clamped to [0, 255], :187-198) -- applied per pixel between the resample and the normalisation, in double
+ * like the reference's ccv_* functions.  3-channel images only. */
 typedef struct {
 	size_t offset;                 /* byte offset of the image in the source buffer */
 	int rows, cols, step;          /* extent, row pitch in bytes */
@@ -379,7 +383,10 @@ typedef struct {
 	int resize_rows, resize_cols;  /* the size the slice is resampled to */
 	int crop_x, crop_y;            /* origin of the output window in the resampled image (0, 0 when cropped first); may overhang: zeros */
 	int flip;                      /* mirror in x */
+	int color_ops;                 /* 0 .. 4 colour operations, applied in this order */
+	struct { int kind; float v[3]; } color[4]; /* kind: NNC_MI355X_COLOR_*; v[0] = the factor (brightness / saturation / contrast), v = the three offsets (lighting) */
 } nnc_mi355x_jitter_image_t;
+enum { NNC_MI355X_COLOR_BRIGHTNESS = 1, NNC_MI355X_COLOR_SATURATION = 2, NNC_MI355X_COLOR_CONTRAST = 3, NNC_MI355X_COLOR_LIGHTING = 4 };
 typedef struct {
 	int out_rows, out_cols, channels; /* random_jitter.size, 3 */
 	float mean[3], inv_std[3];        /* (v - mean) * inv_std; the reference stores 1 / std (:388-389) */

@@ -16,10 +16,18 @@ F = np.float32
 AREA, CUBIC = 0x01, 0x04
 
 
+class ColorOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("v", C.c_float * 3)]
+
+
 class JitterImage(C.Structure):
     _fields_ = [("offset", C.c_size_t), ("rows", C.c_int), ("cols", C.c_int), ("step", C.c_int),
                 ("slice_x", C.c_int), ("slice_y", C.c_int), ("slice_rows", C.c_int), ("slice_cols", C.c_int),
-                ("resize_rows", C.c_int), ("resize_cols", C.c_int), ("crop_x", C.c_int), ("crop_y", C.c_int), ("flip", C.c_int)]
+                ("resize_rows", C.c_int), ("resize_cols", C.c_int), ("crop_x", C.c_int), ("crop_y", C.c_int), ("flip", C.c_int),
+                ("color_ops", C.c_int), ("color", ColorOp * 4)]
+
+
+BRIGHTNESS, SATURATION, CONTRAST, LIGHTING = 1, 2, 3, 4
 
 
 class JitterParams(C.Structure):
@@ -60,7 +68,25 @@ def plan(rng, rows, cols, rmin, rmax, size, aspect=0.0, symmetric=True, center_c
     return d
 
 
-def ref_pipeline(R, img, p, size, mean, inv_std):
+def ref_color(R, d, ops):
+    """_ccv_cnnp_image_manip (ccv_cnnp_dataframe_addons.c:213-253) on the float matrix handle d, in place, with the reference's own
+    ccv_scale / ccv_saturation / ccv_contrast; lighting restated from :187-198 (a static function there: float add, clamp to [0, 255])."""
+    for kind, v in ops:
+        if kind == BRIGHTNESS:
+            R.ccv_scale(d, C.byref(d), 0, C.c_double(float(F(v[0]))))
+        elif kind == SATURATION:
+            R.ccv_saturation(d, C.byref(d), 0, C.c_double(float(F(v[0]))))
+        elif kind == CONTRAST:
+            R.ccv_contrast(d, C.byref(d), 0, C.c_double(float(F(v[0]))))
+        else:
+            ts = C.cast(d, C.POINTER(nnc.TensorStruct)).contents   # ccv_dense_matrix_t shares the header layout (rows, cols, ..., step)
+            rows, cols, step = ts.info.dim[0], ts.info.dim[1], ts.info.dim[4]
+            raw = np.frombuffer((C.c_ubyte * (step * rows)).from_address(ts.data), dtype=np.uint8).reshape(rows, step)
+            a = raw[:, :cols * 12].view(F).reshape(rows, cols, 3)
+            a[:] = np.clip(a + np.asarray(v, F), F(0), F(255))
+
+
+def ref_pipeline(R, img, p, size, mean, inv_std, ops=()):
     x, y, sr, sc = p["slice"]
     m = _mat(R, img)
     cur = m
@@ -78,6 +104,8 @@ def ref_pipeline(R, img, p, size, mean, inv_std):
         R.ccv_shift(cur, C.byref(d), CCV_32F, 0, 0)
     if p["flip"]:
         R.ccv_flip(d, C.byref(d), 0, 0x01)
+    if ops:
+        ref_color(R, d, ops)
     out = _read(d, F, 3)
     for h in {m, getattr(cur, "value", None), d.value} - {None}:
         pass  # (matrices are leaked on purpose: the reference's cache owns some of them)
@@ -157,5 +185,67 @@ def test_jitter_batch_against_the_reference_functions(backend, classic, fmt, dty
     want_oh = np.full((n, 10), eta / 10, F)
     want_oh[np.arange(n), labels] = 1 - eta + eta / 10
     np.testing.assert_array_equal(oh.numpy(), want_oh.astype(T))
+    L.stream_free(st)
+    L.free(0, src)
+
+
+def test_jitter_colour_operations_against_the_reference_functions(backend, classic):
+    """brightness / saturation / contrast / lighting in shuffled orders (what _ccv_cnnp_image_manip's sfmt_genrand_shuffle produces),
+    with the factors a generator would have drawn, against ccv_scale / ccv_saturation / ccv_contrast run in that order on the
+    resampled float image; contrast uses the mean of the WHOLE resampled image at that point (after a clamping lighting step in one
+    of the cases)."""
+    L, R = backend, classic
+    R.ccv_slice.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    R.ccv_flip.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
+    R.ccv_shift.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+    for f in (R.ccv_scale, R.ccv_saturation, R.ccv_contrast):
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_double]
+    rng = np.random.default_rng(41)
+    size = (20, 20)
+    shapes = [(40, 52), (33, 33), (18, 30), (20, 20), (64, 48)]
+    ranges = [(22, 28), (20, 24), (24, 28), (20, 20), (24, 30)]
+    imgs = [rng.integers(0, 256, s + (3,), dtype=np.uint8) for s in shapes]
+    imgs[2][:6] = 255   # saturated rows: the lighting clamp bites
+    imgs[2][6:9] = 0
+    plans = [plan(rng, s[0], s[1], r[0], r[1], size) for s, r in zip(shapes, ranges)]
+    colour = [
+        [(CONTRAST, (1.3, 0, 0)), (BRIGHTNESS, (0.9, 0, 0)), (SATURATION, (1.2, 0, 0)), (LIGHTING, (3.1, -2.2, 1.4))],
+        [(SATURATION, (0.8, 0, 0)), (CONTRAST, (0.75, 0, 0))],
+        [(LIGHTING, (-6.0, 4.5, 7.0)), (CONTRAST, (1.25, 0, 0)), (BRIGHTNESS, (1.1, 0, 0))],   # contrast about the mean of the CLAMPED image
+        [],
+        [(BRIGHTNESS, (1.2, 0, 0))],
+    ]
+    mean, std = (123.68, 116.779, 103.939), (58.393, 57.12, 57.375)
+    inv_std = tuple(1.0 / s for s in std)
+    want = np.stack([ref_pipeline(R, a, p, size, mean, inv_std, ops) for a, p, ops in zip(imgs, plans, colour)])
+    descs = (JitterImage * len(imgs))()
+    blobs, off = [], 0
+    for i, (a, p, ops) in enumerate(zip(imgs, plans, colour)):
+        rows, cols = a.shape[:2]
+        step = (cols * 3 + 3) & ~3
+        buf = np.zeros((rows, step), np.uint8)
+        buf[:, :cols * 3] = a.reshape(rows, -1)
+        x, y, sr, sc = p["slice"]
+        d = JitterImage(off, rows, cols, step, x, y, sr, sc, p["resize"][0], p["resize"][1], p["crop"][0], p["crop"][1], int(p["flip"]))
+        d.color_ops = len(ops)
+        for k, (kind, v) in enumerate(ops):
+            d.color[k].kind = kind
+            for e in range(3):
+                d.color[k].v[e] = v[e]
+        descs[i] = d
+        blobs.append(buf.reshape(-1))
+        off += (buf.size + 15) & ~15
+        blobs.append(np.zeros(off - sum(b.size for b in blobs), np.uint8))
+    host = np.concatenate(blobs)
+    src = L.malloc(0, (host.nbytes + 127) & ~127)
+    L.memcpy(src, nnc.GPU_MEMORY, host.ctypes.data, nnc.CPU_MEMORY, host.nbytes)
+    n = len(imgs)
+    out = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, nnc.CCV_32F, (n, size[0], size[1], 3), 0), np.zeros((n, size[0], size[1], 3), F))
+    params = JitterParams(size[0], size[1], 3, (C.c_float * 3)(*mean), (C.c_float * 3)(*inv_std), nnc.NHWC, nnc.CCV_32F)
+    L.dll.nnc_mi355x_jitter_batch.argtypes = [C.c_void_p, C.POINTER(JitterImage), C.c_int, JitterParams, C.c_void_p, C.c_void_p]
+    st = L.stream_new(0)
+    assert L.dll.nnc_mi355x_jitter_batch(src, descs, n, params, out.ptr, st) == 0
+    L.stream_wait(st)
+    np.testing.assert_allclose(out.numpy(), want, rtol=1e-5, atol=3e-5)
     L.stream_free(st)
     L.free(0, src)

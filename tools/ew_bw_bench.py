@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""HBM rate of the element-wise / pooling rows on VGG-D-sized tensors (256 x 224 x 224 x 64 floats = 3.29 GB), per tunable setting:
-RELU forward (2|x| bytes), RELU backward (3|x|), 2x2/2 max pool forward / backward on the same tensor.
+"""HBM rate of the element-wise / pooling rows on VGG-D-sized tensors (256 x 224 x 224 x 64 floats = 3.29 GB):
+RELU forward (2|x| bytes), RELU backward (3|x|), EWSUM, 2x2/2 max pool forward / backward, with and without the grid cap of grid_for().
 usage: tools/ew_bw_bench.py > gpurun_out/ew_bw_bench.txt"""
 import ctypes as C
 import os, sys
@@ -44,7 +44,7 @@ def timed(label, nbytes, fn, reps=6):
 N, H, W, Cc = 256, 224, 224, 64
 x, y, g, h = tens(N, H, W, Cc, fill=True), tens(N, H, W, Cc), tens(N, H, W, Cc, fill=True), tens(N, H, W, Cc)
 nb = 4.0 * N * H * W * Cc
-# the clocks settle over the first seconds of load: the sweep is repeated, best round per setting reported
+# the clocks settle over the first seconds of load: every setting is measured in several rounds, best round reported
 def rate(nbytes, fn, reps=6):
     L.stream_wait(st)
     e0, e1 = L.dll.nnc_mi355x_event_new(), L.dll.nnc_mi355x_event_new()
@@ -55,22 +55,24 @@ def rate(nbytes, fn, reps=6):
     return nbytes / (L.dll.nnc_mi355x_event_elapsed_ms(e0, e1) / reps) / 1e9
 
 
-best = {}
-for rnd in range(4):
-    for nt in (0, 1):
-        for wg in (8, 16, 32, 64, 100000):
-            L.dll.nnc_mi355x_tune_set(b"EW_NONTEMPORAL", nt)
-            L.dll.nnc_mi355x_tune_set(b"EW_WG_PER_CU", wg)
-            f = rate(2 * nb, lambda: L.cmd_exec(nnc.CMD_RELU_FORWARD(), nnc.NO_HINT, 0, [x], [y], st))
-            bk = rate(3 * nb, lambda: L.cmd_exec(nnc.CMD_RELU_BACKWARD(), nnc.NO_HINT, 0, [g, None, y], [h], st))
-            k = (nt, wg)
-            best[k] = (max(best.get(k, (0, 0))[0], f), max(best.get(k, (0, 0))[1], bk))
-for (nt, wg), (f, bk) in sorted(best.items()):
-    print("nontemporal=%d wg/cu=%-6d relu forward %5.2f TB/s   relu backward %5.2f TB/s" % (nt, wg, f, bk))
-sys.stdout.flush()
-L.dll.nnc_mi355x_tune_set(b"EW_NONTEMPORAL", 0)
-L.dll.nnc_mi355x_tune_set(b"EW_WG_PER_CU", 8)
+# (The sweep that chose the current shape of ew_map_kernel -- grid-stride capped at 8 / 16 / 32 / 64 workgroups per CU, with and without
+# non-temporal accesses, against a full grid -- is profiles/r02_v8_ew_bw_bench.txt; the kernel now always takes the full-grid form.
+# GRID_WG_PER_CU still governs the grid-stride kernels behind grid_for(): the pooling kernels below.)
 p, gp = tens(N, H // 2, W // 2, Cc), tens(N, H // 2, W // 2, Cc, fill=True)
 hint = nnc.HINT((2, 2), (0, 0))
-timed("max pool 2x2/2 forward", 1.25 * nb, lambda: L.cmd_exec(nnc.CMD_MAX_POOL_FORWARD(2, 2), hint, 0, [x], [p], st))
-timed("max pool 2x2/2 backward (g, x, y -> h)", 2.5 * nb, lambda: L.cmd_exec(nnc.CMD_MAX_POOL_BACKWARD(2, 2), hint, 0, [gp, x, p], [h], st))
+cases = [
+    ("relu forward (2|x|)", 2 * nb, lambda: L.cmd_exec(nnc.CMD_RELU_FORWARD(), nnc.NO_HINT, 0, [x], [y], st)),
+    ("relu backward (3|x|)", 3 * nb, lambda: L.cmd_exec(nnc.CMD_RELU_BACKWARD(), nnc.NO_HINT, 0, [g, None, y], [h], st)),
+    ("ewsum of two (3|x|)", 3 * nb, lambda: L.cmd_exec(nnc.CMD_EWSUM_FORWARD(), nnc.NO_HINT, 0, [x, g], [h], st)),
+    ("max pool 2x2/2 forward (1.25|x|)", 1.25 * nb, lambda: L.cmd_exec(nnc.CMD_MAX_POOL_FORWARD(2, 2), hint, 0, [x], [p], st)),
+    ("max pool 2x2/2 backward (2.5|x|)", 2.5 * nb, lambda: L.cmd_exec(nnc.CMD_MAX_POOL_BACKWARD(2, 2), hint, 0, [gp, x, p], [h], st)),
+]
+best = {}
+for rnd in range(4):
+    for cap in (8, 0):
+        L.dll.nnc_mi355x_tune_set(b"GRID_WG_PER_CU", cap)
+        for label, nbytes, fn in cases:
+            fn()
+            best[(label, cap)] = max(best.get((label, cap), 0.0), rate(nbytes, fn))
+for label, _, _ in cases:
+    print("%-36s grid cap 8 per CU: %5.2f TB/s   no cap: %5.2f TB/s" % (label, best[(label, 8)], best[(label, 0)]))
