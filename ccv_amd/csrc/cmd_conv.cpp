@@ -15,6 +15,8 @@ using namespace nnc;
 
 namespace {
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 struct conv_geom_t {
 	int N, H, W, C;     // input
 	int OH, OW, K;      // output
@@ -416,6 +418,95 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 }
 
 // h = sum_{k,i,j} g[n, (y+p-i*d)/s, (x+p-j*d)/s, k] * w[k,i,j,c]
+// ---- data gradient of a stride-2 convolution by parity classes ------------------------------------------------------------------
+// h[y, x] = sum over the taps (ky, kx) with (y + pad - ky, x + pad - kx) BOTH even of g[(y + pad - ky) / 2, (x + pad - kx) / 2] . w[ky, kx]:
+// for a given parity (py, px) of (y, x) only the taps with ky = py + pad, kx = px + pad (mod 2) exist -- a quarter of them on
+// average, 1 + 2 + 2 + 4 = 9 of the 4 x 9 the strided im2col walk tests for a 3 x 3 filter (which ran the ResNet-50 stage
+// transitions at 112 TFLOP/s of mostly-zero work, 28 effective).  Per class the sum is a dense STRIDE-1 correlation of g with the
+// class's sub-filter (taps in descending ky: tap i reads g[u - pb + i], pb = (ky_max - py - pad) / 2), i.e. the forward implicit
+// GEMM with the roles of the channel axes swapped; its output -- the class's positions (2u + py, 2v + px) -- is computed into a dense
+// quarter-size image and interleaved into h.
+static __global__ void __launch_bounds__(256) parity_filter_kernel(const float* __restrict__ w, float* __restrict__ f, const int K, const int C, const int kh, const int kw, const int ny, const int nx, const int ky_max, const int kx_max, const size_t total)
+{ // f[c][i][j][k] = w[k][ky_max - 2 i][kx_max - 2 j][c]
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		size_t r = idx;
+		const int k = (int)(r % K); r /= K;
+		const int j = (int)(r % nx); r /= nx;
+		const int i = (int)(r % ny); r /= ny;
+		const int c = (int)r;
+		f[idx] = w[(((size_t)k * kh + (ky_max - 2 * i)) * kw + (kx_max - 2 * j)) * C + c];
+	}
+}
+static __global__ void __launch_bounds__(256) parity_scatter_kernel(const float* __restrict__ t, float* __restrict__ h, const int U, const int V, const int C4, const long h_sn, const long h_sh, const long h_sw, const int py, const int px, const size_t total)
+{ // t: dense [N][U][V][C]; h[n][2u + py][2v + px][:] = t[n][u][v][:]   (C4 = C / 4 float4 groups, or C scalars when C4 < 0)
+	const int cn = C4 < 0 ? -C4 : C4;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		size_t r = idx;
+		const int c = (int)(r % cn); r /= cn;
+		const int v = (int)(r % V); r /= V;
+		const int u = (int)(r % U); r /= U;
+		const long o = (long)r * h_sn + (long)(2 * u + py) * h_sh + (long)(2 * v + px) * h_sw;
+		if (C4 < 0) h[o + c] = t[idx];
+		else *(float4*)(h + o + 4 * c) = ((const float4*)t)[idx];
+	}
+}
+static bool conv_dgrad_parity_ok(const conv_geom_t& g)
+{
+	return g.sy == 2 && g.sx == 2 && g.dy == 1 && g.dx == 1 && g.groups == 1 && g.kh >= 1 && g.kw >= 1 && g.pby >= 0 && g.pbx >= 0 && g.pby < g.kh && g.pbx < g.kw && g.H >= 2 && g.W >= 2;
+}
+static size_t conv_dgrad_parity_prefix(const conv_geom_t& g)
+{ // the quarter image + the largest sub-filter
+	const size_t U = (g.H + 1) / 2, V = (g.W + 1) / 2;
+	return align256(sizeof(float) * (size_t)g.N * U * V * g.C) + align256(sizeof(float) * (size_t)((g.kh + 1) / 2) * ((g.kw + 1) / 2) * g.C * g.K);
+}
+static size_t conv_dgrad_parity_scratch(const conv_geom_t& g)
+{
+	if (!conv_dgrad_parity_ok(g)) return 0;
+	return conv_dgrad_parity_prefix(g) + gemm_workspace_bound((long)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2), g.C, (long)((g.kh + 1) / 2) * ((g.kw + 1) / 2) * g.K) + 256;
+}
+static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w, const float* bias, const Image4& b, const int algo, const int flags, ccv_nnc_stream_context_t* const ctx);
+static int conv_dgrad_parity(const conv_geom_t& g, const Image4& gr, const float* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	const int U0 = (g.H + 1) / 2, V0 = (g.W + 1) / 2;
+	const size_t tbytes = align256(sizeof(float) * (size_t)g.N * U0 * V0 * g.C);
+	WorkspaceScope ws(ctx, conv_dgrad_parity_prefix(g), gemm_workspace_bound((long)g.N * U0 * V0, g.C, (long)((g.kh + 1) / 2) * ((g.kw + 1) / 2) * g.K));
+	char* const p = (char*)ws.prefix();
+	if (!p) return CCV_NNC_EXEC_OOM;
+	float* const T = (float*)p;
+	float* const Fw = (float*)(p + tbytes);
+	hipStream_t stream = stream_of(ctx);
+	const bool vec = g.C % 4 == 0 && aligned16(h.p) && h.sn % 4 == 0 && h.sh % 4 == 0 && h.sw % 4 == 0;
+	for (int py = 0; py < 2; py++)
+		for (int px = 0; px < 2; px++) {
+			const int U = (g.H - py + 1) / 2, V = (g.W - px + 1) / 2; // positions y = 2u + py < H
+			if (U <= 0 || V <= 0) continue;
+			// taps of this class: ky = (py + pad) mod 2, + 2, ... < kh
+			const int ky0 = (py + g.pby) & 1, kx0 = (px + g.pbx) & 1;
+			const int ny = ky0 < g.kh ? (g.kh - ky0 + 1) / 2 : 0, nx = kx0 < g.kw ? (g.kw - kx0 + 1) / 2 : 0;
+			const size_t cells = (size_t)g.N * U * V * (vec ? g.C / 4 : g.C);
+			if (ny == 0 || nx == 0) { // no tap reaches these positions: zero gradient
+				HIP_ENFORCE(hipMemsetAsync(T, 0, sizeof(float) * (size_t)g.N * U * V * g.C, stream));
+			} else {
+				const int ky_max = ky0 + 2 * (ny - 1), kx_max = kx0 + 2 * (nx - 1);
+				const int pb_y = (ky_max - py - g.pby) / 2, pb_x = (kx_max - px - g.pbx) / 2;
+				if (ky_max - py - g.pby < 0 || kx_max - px - g.pbx < 0) return CCV_NNC_EXEC_NO_KERNEL;
+				const size_t fn = (size_t)g.C * ny * nx * g.K;
+				hipLaunchKernelGGL(parity_filter_kernel, dim3(grid_for(fn, 256)), dim3(256), 0, stream, w, Fw, g.K, g.C, g.kh, g.kw, ny, nx, ky_max, kx_max, fn);
+				HIP_ENFORCE(hipGetLastError());
+				conv_geom_t q;
+				q.N = g.N; q.H = g.OH; q.W = g.OW; q.C = g.K; q.OH = U; q.OW = V; q.K = g.C;
+				q.kh = ny; q.kw = nx; q.Cg = g.K; q.Kg = g.C; q.groups = 1; q.sy = 1; q.sx = 1; q.pby = pb_y; q.pbx = pb_x; q.dy = 1; q.dx = 1;
+				Image4 ti;
+				ti.p = T; ti.n = g.N; ti.h = U; ti.w = V; ti.c = g.C; ti.sc = 1; ti.sw = g.C; ti.sh = (long)V * g.C; ti.sn = (long)U * V * g.C;
+				const int r = conv_forw_nhwc(q, gr, Fw, 0, ti, CONV_ALGO_IMPLICIT_GEMM, flags & ~CCV_NNC_ACCUMULATE_OUTPUT, ctx);
+				if (r != CCV_NNC_EXEC_SUCCESS) return r;
+			}
+			hipLaunchKernelGGL(parity_scatter_kernel, dim3(grid_for(cells, 256)), dim3(256), 0, stream, (const float*)T, h.p, U, V, vec ? g.C / 4 : -g.C, h.sn, h.sh, h.sw, py, px, cells);
+			HIP_ENFORCE(hipGetLastError());
+		}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* w, const Image4& h, const int algo, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	if (gr.sc != 1 || !pixel_linear(h) || !image_fits_int(gr)) return CCV_NNC_EXEC_INVALID;
@@ -428,6 +519,10 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wp) && wino_images_ok(gr, h, w, 0) && (algo >= CONV_ALGO_WINOGRAD || wino_preferred(wp, g.K, g.C))) {
 		const int r = conv_wino_run<true>("conv_dgrad_wino", g, wp, gr, w, 0, h, 2 - g.pby, 2 - g.pbx, flags, ctx);
 		if (r != CCV_NNC_EXEC_OOM) return r;
+	}
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && !(flags & CCV_NNC_ACCUMULATE_OUTPUT) && conv_dgrad_parity_ok(g) && g.kh * g.kw > 1) {
+		const int r = conv_dgrad_parity(g, gr, w, h, flags, ctx);
+		if (r != CCV_NNC_EXEC_OOM && r != CCV_NNC_EXEC_NO_KERNEL) return r; // (no room under a staging scope / odd borders: the strided walk below)
 	}
 	const long M = (long)g.N * g.H * g.W;
 	const int Kred = g.kh * g.kw * g.Kg;
@@ -573,7 +668,6 @@ static int conv1x1_nchw_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint,
 // NCHW-format weights [K][Cg][kh][kw] (what the reference's GPU tests hand over, test/int/nnc/cudnn.tests.c:50,65) are
 // re-laid-out through the stream workspace by the tiled transpose of cmd_util.cpp: one extra read + write of the tensor,
 // HBM-bound, instead of a second family of gather kernels whose channel-strided loads could not be 16-byte vectors.
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static bool weights_shape(const ccv_nnc_tensor_t* w, int* K, int* kh, int* kw, int* Cg)
 {
@@ -696,6 +790,7 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	wino_wgrad_plan_t wgp;
 	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wgp) && wgp.total() > inner) inner = wgp.total();
 	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_fused_scratch_bound(g.C, g.K) > inner) inner = wino_fused_scratch_bound(g.C, g.K);
+	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && conv_dgrad_parity_scratch(g) > inner) inner = conv_dgrad_parity_scratch(g);
 	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && g.C == 3 && conv_c3_wgrad_scratch_bound(g.K) > inner) inner = conv_c3_wgrad_scratch_bound(g.K);
 	WorkspaceScope ws(stream_context, ng + na + nh + nw + ndw, inner);
 	char* p = (char*)ws.prefix();

@@ -618,3 +618,37 @@ def test_conv_1x1_on_nchw_tensors_without_layout_passes(backend, ref_lib, case, 
     native = (h * w_) % 4 == 0 and c % 4 == 0 and k % 4 == 0
     if native:
         assert any(x.startswith("conv1x1_nchw_fwd") for x in names) and any(x.startswith("conv1x1_nchw_dgrad") for x in names) and any(x.startswith("conv1x1_nchw_wgrad") for x in names), names
+
+
+STRIDE2_CASES = [
+    # n, h, w, c, k, kh, kw, border
+    (2, 12, 13, 8, 12, 3, 3, (1, 1)),    # ResNet stage transition shape class: odd and even extents
+    (2, 11, 10, 8, 8, 3, 3, (0, 0)),     # no border: the even positions get two taps per axis
+    (1, 14, 15, 4, 8, 7, 7, (3, 3)),     # 7 x 7 (stem): 3 + 4 taps per axis
+    (2, 9, 8, 5, 6, 2, 2, (0, 0)),       # 2 x 2: exactly one tap per class; scalar scatter (C % 4 != 0)
+    (1, 10, 10, 4, 4, 4, 4, (1, 1)),     # even filter
+    (1, 9, 9, 4, 4, 3, 5, (1, 2)),       # different extents per axis
+]
+
+
+@pytest.mark.parametrize("case", STRIDE2_CASES, ids=[str(c) for c in STRIDE2_CASES])
+def test_conv_stride2_data_gradient_by_parity_classes(backend, ref_lib, case):
+    """The data gradient of a stride-2 convolution as four dense stride-1 correlations (one per parity of the input position) +
+    an interleave (cmd_conv.cpp: conv_dgrad_parity) against the oracle; the launch records show forward-GEMM launches inside the
+    backward command, i.e. the parity path and not the strided im2col walk ran."""
+    n, h, w, c, k, kh, kw, border = case
+    rng = np.random.default_rng(15)
+    hint = nnc.HINT((2, 2), border)
+    oh, ow = out_hw(h, w, kh, kw, hint)
+    a, wt, g = srnd(rng, n, h, w, c), srnd(rng, k, kh, kw, c, scale=1.0 / (kh * kw * c)), srnd(rng, n, oh, ow, k)
+    cmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, kh, kw, c)
+    backend.profile_enable(1)
+    try:
+        got, want = exec_pair(backend, ref_lib, cmd, hint, 0, [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, F)])
+        backend.stream_wait(None)
+        names = [r[0] for r in backend.profile_records()]
+    finally:
+        backend.profile_enable(0)
+    assert any(x.startswith("conv_fwd") for x in names) and not any(x.startswith("conv_dgrad") for x in names), names
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5)
