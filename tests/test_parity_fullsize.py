@@ -240,3 +240,34 @@ def test_reference_winograd_unit_shapes_on_the_hip_path(gpu_lib, ref_lib, case):
         assert r == 0, (name, algo, r)
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=0, err_msg="%s algorithm %d" % (name, algo))
         assert float(np.abs(got - want).max()) <= 1e-4
+
+
+# ResNet-50 v1d's stride-2 convolutions (bin/nnc/imagenet.c:17-98: the 3 x 3 of the first block of stages 2-4, the stem) at their
+# full spatial sizes: the parity-class data gradient (cmd_conv.cpp: conv_dgrad_parity) against the reference's CPU backend.
+RESNET_STRIDE2 = [
+    ("stage2", 56, 128, 128, 3, 1),
+    ("stage3", 28, 256, 256, 3, 1),
+    ("stage4", 14, 512, 512, 3, 1),
+    ("stem-7x7-class", 112, 16, 32, 7, 3),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", RESNET_STRIDE2, ids=[c[0] for c in RESNET_STRIDE2])
+def test_resnet_stride2_data_gradient_full_size_vs_cpu_ref(gpu_lib, ref_lib, case):
+    _, hw, c, k, ks, pad = case
+    rng = np.random.default_rng(31)
+    n = 1
+    hint = nnc.HINT((2, 2), (pad, pad))
+    oh = (hw + 2 * pad - ks) // 2 + 1
+    a = rng.random((n, hw, hw, c), dtype=F)
+    w = ((rng.random((k, ks, ks, c), dtype=F) - F(0.5)) / F(c * ks * ks)).astype(F)
+    g = (rng.random((n, oh, oh, k), dtype=F) - F(0.5))
+    cmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, ks, ks, c)
+    outs = [np.zeros_like(a), np.zeros_like(w), np.zeros(k, F)]
+    r1, got = exec_on(gpu_lib, nnc.GPU_MEMORY, cmd, hint, 0, [g, a, w], outs)
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [g, a, w], outs, backend=nnc.BACKEND_CPU_REF)
+    assert r1 == 0 and r2 == 0
+    for x, y, what in zip(got, want, ("h", "dw", "dbias")):
+        bound = 1e-4 * float(np.abs(y).max())  # 1e-4 of the tensor's scale (signed sums: see the module docstring)
+        assert float(np.abs(x - y).max()) <= bound, what
