@@ -23,6 +23,7 @@ struct ConvC3Args {
 	int N, H, W, OH, OW, K;
 	int pad_y, pad_x;
 	int groups_per_row, groups; // 16-pixel groups per output row, total
+	unsigned b_image_bytes;     // forward: span of one output image in bytes (range of the per-image store descriptor; host-checked < 2^31)
 	FastDiv d_gpr, d_oh;        // group -> (row, position), row -> (image, oy) without hardware division (two per 28-MFMA group otherwise)
 };
 
@@ -52,14 +53,76 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const ConvC3
 #pragma unroll
 	for (int j = 0; j < NT; j++) bv[j] = g.bias ? g.bias[NT * n + j] : 0.f;
 	const int waves = (gridDim.x * blockDim.x) >> 6;
-	for (int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; grp < g.groups; grp += waves) {
-		const int row = g.d_gpr.div(grp), gx = grp - row * g.groups_per_row; // row = n * OH + oy
-		const int img = g.d_oh.div(row), oy = row - img * g.OH;
-		const int ox0 = gx * 16;
-		const float* const ap = g.a + (long)img * g.a_sn;
-		float av[7];
+	// MFMA row m of the group is pixel 4 (m & 3) + (m >> 2): D rows 4 kq + r are then pixels 4 r + kq, so ONE store instruction
+	// (fixed r, kq = 0..3, 16 lanes x 16 bytes each) writes four CONSECUTIVE pixels = 1 KB contiguous
+	const int pix = 4 * (n & 3) + (n >> 2);
+	// the lane's seven patch elements k = 4 s + kq: row dy = k / 9, column dx = (k % 9) / 3, offset dy * row pitch + k % 9 from the
+	// patch's first float -- fixed per lane, computed once
+	int koff[7], kdy[7], kdx[7];
 #pragma unroll
-		for (int s = 0; s < 7; s++) av[s] = convc3_patch(ap, g, oy, ox0 + n, 4 * s + kq);
+	for (int s = 0; s < 7; s++) {
+		const int k = 4 * s + kq, dy = k / 9, r9 = k - dy * 9;
+		kdy[s] = k < 27 ? dy : (1 << 28); // element 27 is padding: fails the row test
+		kdx[s] = r9 / 3;
+		koff[s] = dy * (int)g.a_sh + r9;
+	}
+	// The loop is bound by instruction ISSUE (knock-out on the MI355X: 0.39 of 0.94 ms with loads, MFMAs and stores all removed),
+	// so what is not per-lane work is kept off the vector unit and small: the group index is wave-uniform (SALU), a group's
+	// (image, row, position) advances incrementally by the wave stride instead of being divided out, the patch loads are
+	// unconditional (address 0 of the image when the element is padding; the value is masked) -- no branch per load.
+	int grp = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+	struct Pos { int img, oy, gx; };
+	Pos cur;
+	{
+		const int row = g.d_gpr.div(grp);
+		cur.gx = grp - row * g.groups_per_row; cur.img = g.d_oh.div(row); cur.oy = row - cur.img * g.OH;
+	}
+	// stride of one loop trip, decomposed the same way (wave-uniform constants)
+	const int st_row = g.d_gpr.div(waves), st_gx = waves - st_row * g.groups_per_row;
+	const int st_img = g.d_oh.div(st_row), st_oy = st_row - st_img * g.OH;
+	auto advance = [&](Pos p) {
+		p.gx += st_gx;
+		const int c1 = p.gx >= g.groups_per_row ? 1 : 0;
+		p.gx -= c1 * g.groups_per_row;
+		p.oy += st_oy + c1;
+		const int c2 = p.oy >= g.OH ? 1 : 0; // st_oy + c1 <= OH: one wrap at most
+		p.oy -= c2 * g.OH;
+		p.img += st_img + c2;
+		return p;
+	};
+	// raw loads + a bit mask of the elements that exist; the mask is applied where the values are first USED (a select right
+	// behind the load would make hipcc wait for the load on the spot)
+	auto fetch = [&](const Pos& p, float (&v)[7], unsigned& okmask) {
+		const float* const ap = g.a + (long)p.img * g.a_sn;
+		const int iy0 = p.oy - g.pad_y, ix0 = p.gx * 16 + pix - g.pad_x;
+		const int base = iy0 * (int)g.a_sh + ix0 * 3; // (one image spans < 2^31 floats: host-checked)
+		okmask = 0;
+#pragma unroll
+		for (int s = 0; s < 7; s++) {
+			const bool ok = ((unsigned)(iy0 + kdy[s]) < (unsigned)g.H) & ((unsigned)(ix0 + kdx[s]) < (unsigned)g.W);
+			okmask |= ok ? (1u << s) : 0u;
+			v[s] = ap[ok ? base + koff[s] : 0];
+		}
+	};
+	// Software pipeline: the NEXT group's patch loads are issued before this group's stores.  The memory counter retires in order,
+	// so a wave that loads after its stores waits for those stores' write acknowledgements before it can use the loads.
+	float av[7];
+	unsigned avm = 0;
+	if (grp < g.groups) fetch(cur, av, avm);
+#pragma unroll
+	for (int s = 0; s < 7; s++) av[s] = (avm >> s) & 1 ? av[s] : 0.f;
+#ifndef NNC_HIP_EMULATOR
+	// Everything loaded so far (the filter fragments above all) has landed before the loop starts: otherwise hipcc's wait-count
+	// pass carries "the filter loads may still be in flight" around the back edge and puts an s_waitcnt vmcnt(0) into EVERY
+	// iteration -- which waits for the stores and the prefetch as well, i.e. undoes the pipeline.
+	__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8)); // vmcnt(0), expcnt / lgkmcnt not waited for (gfx9 encoding)
+#endif
+	for (; grp < g.groups; grp += waves) {
+		const Pos nxt = advance(cur);
+		float nx[7];
+		unsigned nxm = 0;
+		const bool more = grp + waves < g.groups;
+		if (more) fetch(nxt, nx, nxm);
 		floatx4 acc[NT];
 #pragma unroll
 		for (int j = 0; j < NT; j++) acc[j] = floatx4{ 0.f, 0.f, 0.f, 0.f };
@@ -67,18 +130,28 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const ConvC3
 		for (int s = 0; s < 7; s++)
 #pragma unroll
 			for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wf[s][j], acc[j], 0, 0, 0);
-		// D: column n (channels NT n .. NT n + NT - 1 across the tiles), rows 4 kq + r = pixels
-		float* const bp = g.b + (long)img * g.b_sn + (long)oy * g.b_sh + NT * n;
+		// D: column n (channels NT n .. NT n + NT - 1 across the tiles), rows 4 kq + r = pixels 4 r + kq.  Stores go through a buffer
+		// descriptor over the image: a pixel past the row's end gets an out-of-range offset and the hardware drops the store --
+		// no branch, so exactly four stores sit between the prefetch above and its first use and hipcc can wait with vmcnt(4)
+		// (behind branches it cannot count them and waits for everything, stores included).
+		typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+		typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.b + (long)cur.img * g.b_sn), 0, g.b_image_bytes, 0x00020000);
+		const int ox0 = cur.gx * 16;
+		const unsigned row_off = (unsigned)(cur.oy * (int)g.b_sh + NT * n) * 4u;
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
-			const int ox = ox0 + 4 * kq + r;
-			if (ox < g.OW) {
-				float* const o = bp + (long)ox * g.b_sw;
-				if (NT == 4) *(float4*)o = make_float4(acc[0][r] + bv[0], acc[NT > 1 ? 1 : 0][r] + bv[NT > 1 ? 1 : 0], acc[NT > 2 ? 2 : 0][r] + bv[NT > 2 ? 2 : 0], acc[NT > 3 ? 3 : 0][r] + bv[NT > 3 ? 3 : 0]);
-				else if (NT == 2) *(float2*)o = make_float2(acc[0][r] + bv[0], acc[NT > 1 ? 1 : 0][r] + bv[NT > 1 ? 1 : 0]);
-				else o[0] = acc[0][r] + bv[0];
-			}
+			const int ox = ox0 + 4 * r + kq;
+			const unsigned voff = ox < g.OW ? row_off + (unsigned)(ox * (int)g.b_sw) * 4u : 0x7ffff000u;
+			if (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(u4{ __float_as_uint(acc[0][r] + bv[0]), __float_as_uint(acc[NT > 1 ? 1 : 0][r] + bv[NT > 1 ? 1 : 0]), __float_as_uint(acc[NT > 2 ? 2 : 0][r] + bv[NT > 2 ? 2 : 0]), __float_as_uint(acc[NT > 3 ? 3 : 0][r] + bv[NT > 3 ? 3 : 0]) }, rs, voff, 0, 0);
+			else if (NT == 2) __builtin_amdgcn_raw_buffer_store_b64(u2{ __float_as_uint(acc[0][r] + bv[0]), __float_as_uint(acc[NT > 1 ? 1 : 0][r] + bv[NT > 1 ? 1 : 0]) }, rs, voff, 0, 0);
+			else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][r] + bv[0]), rs, voff, 0, 0);
 		}
+		if (more) {
+#pragma unroll
+			for (int s = 0; s < 7; s++) av[s] = (nxm >> s) & 1 ? nx[s] : 0.f;
+		}
+		cur = nxt;
 	}
 }
 

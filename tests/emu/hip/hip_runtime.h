@@ -185,6 +185,17 @@ static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u4 v, emu_buffer_r
 	if ((unsigned long long)voffset + 16 > r.num_records || (unsigned long long)voffset + soffset + 16 > r.num_records) return;
 	memcpy((char*)r.base + voffset + soffset, &v, 16);
 }
+typedef unsigned int emu_u2 __attribute__((ext_vector_type(2)));
+static inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u2 v, emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
+{
+	if ((unsigned long long)voffset + 8 > r.num_records || (unsigned long long)voffset + soffset + 8 > r.num_records) return;
+	memcpy((char*)r.base + voffset + soffset, &v, 8);
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
+{
+	if ((unsigned long long)voffset + 4 > r.num_records || (unsigned long long)voffset + soffset + 4 > r.num_records) return;
+	memcpy((char*)r.base + voffset + soffset, &v, 4);
+}
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 // (the "memory" clobbers: a workgroup's LDS is a function-local static whose address never leaves the kernel, so without them
 // the x86 compiler may move a lane's LDS reads above the rendezvous -- other fibers' writes are invisible to its analysis)
