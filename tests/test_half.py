@@ -242,7 +242,7 @@ def test_native_half_relu_ewsum_exact(backend, ref_lib):
     assert np.array_equal(got[0], g) and np.array_equal(got[1], g)
 
 
-@pytest.mark.parametrize("fmt,shape", [("NCHW", (4, 6, 8, 8)), ("NCHW", (3, 5, 7, 7)), ("NHWC", (4, 6, 6, 16))], ids=["nchw-vec", "nchw-odd", "nhwc"])
+@pytest.mark.parametrize("fmt,shape", [("NCHW", (4, 6, 8, 8)), ("NCHW", (3, 5, 7, 7)), ("NHWC", (4, 6, 6, 16)), ("NCHW", (2, 3, 48, 56))], ids=["nchw-vec", "nchw-odd", "nhwc", "nchw-large-planes"])
 def test_native_half_batch_norm(backend, ref_lib, fmt, shape):
     """x, y, g, h in CCV_16F and the statistics in fp32 -- what the half-precision trainers issue.  Oracle: the reference's CPU
     batch norm in fp32 on the same half-rounded x / g."""
