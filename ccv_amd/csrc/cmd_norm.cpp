@@ -137,17 +137,7 @@ __device__ __forceinline__ void plane_sweep(const T* __restrict__ p, const long 
 	if ((inner % W) == 0 && (((uintptr_t)p) & 15) == 0) {
 		const V* const pv = (const V*)p;
 		const long nv = inner / W;
-		long i = lane;
-		for (; i + 192 < nv; i += 256) { // four independent 16-byte loads in flight per lane
-			V v[4];
-#pragma unroll
-			for (int u = 0; u < 4; u++) v[u] = pv[i + 64 * u];
-#pragma unroll
-			for (int u = 0; u < 4; u++)
-#pragma unroll
-				for (int e = 0; e < W; e++) op((float)v[u][e], (i + 64 * u) * W + e);
-		}
-		for (; i < nv; i += 64) {
+		for (long i = lane; i < nv; i += 64) {
 			const V v = pv[i];
 #pragma unroll
 			for (int e = 0; e < W; e++) op((float)v[e], i * W + e);
@@ -228,17 +218,7 @@ __global__ void __launch_bounds__(256) bn_plane_back_stats_kernel(const T* __res
 		float sg = 0.f, sx = 0.f;
 		if ((inner % W) == 0 && ((((uintptr_t)gp) | ((uintptr_t)xp)) & 15) == 0) {
 			const long nv = inner / W;
-			long i = lane;
-			for (; i + 192 < nv; i += 256) {
-				V gv[4], xv[4];
-#pragma unroll
-				for (int u = 0; u < 4; u++) { gv[u] = ((const V*)gp)[i + 64 * u]; xv[u] = ((const V*)xp)[i + 64 * u]; }
-#pragma unroll
-				for (int u = 0; u < 4; u++)
-#pragma unroll
-					for (int e = 0; e < W; e++) { sg += (float)gv[u][e]; sx += ((float)xv[u][e] - mu) * is * (float)gv[u][e]; }
-			}
-			for (; i < nv; i += 64) {
+			for (long i = lane; i < nv; i += 64) {
 				const V gv = ((const V*)gp)[i], xv = ((const V*)xp)[i];
 #pragma unroll
 				for (int e = 0; e < W; e++) { sg += (float)gv[e]; sx += ((float)xv[e] - mu) * is * (float)gv[e]; }
@@ -324,22 +304,7 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const T* __restric
 		T* const yp = y + pl * inner;
 		if ((inner % W) == 0 && ((((uintptr_t)xp) | ((uintptr_t)yp)) & 15) == 0) {
 			const long nv = inner / W;
-			// Four vectors per trip, all loads ahead of the stores: a load behind a store waits for that store's acknowledgement as
-			// well (the memory counter retires in order), so one-load-one-store trips keep a single KB per wave in flight.
-			long i = lane;
-			for (; i + 192 < nv; i += 256) {
-				V v[4];
-#pragma unroll
-				for (int u = 0; u < 4; u++) v[u] = ((const V*)xp)[i + 64 * u];
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					V r;
-#pragma unroll
-					for (int e = 0; e < W; e++) r[e] = (T)((float)v[u][e] * w + b);
-					((V*)yp)[i + 64 * u] = r;
-				}
-			}
-			for (; i < nv; i += 64) {
+			for (long i = lane; i < nv; i += 64) {
 				const V v = ((const V*)xp)[i];
 				V r;
 #pragma unroll
@@ -365,20 +330,7 @@ __global__ void __launch_bounds__(256) bn_back_planes_kernel(const T* __restrict
 		T* const hp = h + pl * inner;
 		if ((inner % W) == 0 && ((((uintptr_t)xp) | ((uintptr_t)gp) | ((uintptr_t)hp)) & 15) == 0) {
 			const long nv = inner / W;
-			long i = lane;
-			for (; i + 192 < nv; i += 256) { // four vectors of x and of g per trip, loads ahead of the stores (see bn_apply_planes_kernel)
-				V xv[4], gv[4];
-#pragma unroll
-				for (int u = 0; u < 4; u++) { xv[u] = ((const V*)xp)[i + 64 * u]; gv[u] = ((const V*)gp)[i + 64 * u]; }
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					V r;
-#pragma unroll
-					for (int e = 0; e < W; e++) { const float xhat = ((float)xv[u][e] - mu) * is; r[e] = (T)(k * (B * (float)gv[u][e] - db - xhat * ds)); }
-					((V*)hp)[i + 64 * u] = r;
-				}
-			}
-			for (; i < nv; i += 64) {
+			for (long i = lane; i < nv; i += 64) {
 				const V xv = ((const V*)xp)[i], gv = ((const V*)gp)[i];
 				V r;
 #pragma unroll
