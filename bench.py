@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--config", default="vggd-train-bs256", choices=["vggd-train-bs256", "vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512", "cifar10-dawn-f32-bs512"],
                     help="BASELINE.json configs: 3 (default, the metric), 2 (VGG-D forward only, batch 64), 4 (ResNet-50 v1d NCHW through the reference host; -f16 = the trainer's own precision), 5 (CIFAR-10 DawnNet fp16, batch 512, through the reference host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse-relu", action="store_true", help="issue RELU_FORWARD as its own command behind every convolution (the reference host's graph does) instead of letting the convolution's epilogue rectify (NNC_MI355X_CONV_ALGO_FUSE_RELU); the other setting is always timed beside the headline one")
     ap.add_argument("--no-via-host", action="store_true", help="skip the second driver: the same step through the reference host's symbolic graph / autotune / static schedule (tools/host_vgg_bench.c)")
     ap.add_argument("--records", default=None, help="also write the per-launch contraction records (name, dims, ms, TFLOP/s) of the roofline leg to this file")
     args = ap.parse_args()
@@ -209,7 +210,7 @@ def main():
 
     # parameters, images and labels from the counter hash tools/host_vgg_bench.c uses too: the command driver (this process),
     # the driver through the reference host (--via-host) and the CPU oracle all run on identical numbers
-    net = VGGD(L, args.batch, device=local_rank, init="hash", flat_grads=(world > 1 or force_comm),
+    net = VGGD(L, args.batch, device=local_rank, init="hash", flat_grads=(world > 1 or force_comm), fuse_relu=not args.no_fuse_relu,
                sgd=(0, 0.001, 1.0 / (args.batch * world), 0.0005, 0.9, 0.9))
     imgs = hash_unit(args.batch * 225 * 225 * 3, 1000 + 2 * rank).reshape(args.batch, 225, 225, 3)
     labels = (hash_unit(args.batch, 1001 + 2 * rank) * np.float32(1000)).astype(np.int32)
@@ -295,6 +296,19 @@ def main():
         dt = dist.reduce_max(dt)
     loss = float(net.loss.numpy().mean())
 
+    # the same K steps with the other ReLU setting (results are bit-identical: tests/test_vgg_step.py), reported beside the headline
+    net.fuse_relu = not net.fuse_relu
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt_alt = time.perf_counter() - t0
+    if dist:
+        dt_alt = dist.reduce_max(dt_alt)
+    net.fuse_relu = not net.fuse_relu
+
     # roofline leg: three more steps with every contraction launch bracketed by HIP events on its stream; per launch position
     # the MEDIAN of the three (one stalled launch -- an allocator call, a clock dip -- would otherwise skew a kernel's average)
     LEG = 3
@@ -335,7 +349,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "VGG-D (ccv vgg_d_params, 225x225x3 crop, NHWC) %s, batch %d per GPU, random-init weights" % ("forward only" if fwd_only else "forward+backward+SGD", args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "gflop_per_image": (ff if fwd_only else fb) / 1e9, "whole_step_tflops_per_gpu": value / world * (ff if fwd_only else fb) / 1e12, "final_loss": loss},
+                       "gflop_per_image": (ff if fwd_only else fb) / 1e9, "whole_step_tflops_per_gpu": value / world * (ff if fwd_only else fb) / 1e12, "final_loss": loss,
+                       "conv_relu": "convolution epilogue (NNC_MI355X_CONV_ALGO_FUSE_RELU)" if net.fuse_relu else "separate RELU_FORWARD commands"},
+            "relu_as_separate_commands" if net.fuse_relu else "relu_in_conv_epilogue": {"value": world * args.batch * args.steps / dt_alt, "unit": "images/s", "ms_per_step": 1e3 * dt_alt / args.steps},
         }
         if dom:
             name, (fl, ms, cnt) = dom

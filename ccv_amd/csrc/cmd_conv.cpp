@@ -17,6 +17,10 @@ namespace {
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// NNC_MI355X_CONV_ALGO_FUSE_RELU (include/nnc_mi355x.h): the forward command in progress on this thread was asked to write
+// max(0, .); a kernel that does so in its epilogue says so, otherwise _conv_forw_any rectifies the output afterwards.
+static thread_local int tl_relu_want = 0, tl_relu_done = 0;
+
 struct conv_geom_t {
 	int N, H, W, C;     // input
 	int OH, OW, K;      // output
@@ -117,6 +121,8 @@ static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan
 		WinoTiles ti;
 		ti.TH = p.TH; ti.TW = p.TW; ti.T = T;
 		ti.H = src.h; ti.W = src.w; ti.sn = src.sn; ti.sh = src.sh; ti.sw = src.sw; ti.oy = -pad_y; ti.ox = -pad_x; ti.C4 = Cs / 4;
+		ti.relu = (!FLIP && tl_relu_want) ? 1 : 0;
+		if (ti.relu) tl_relu_done = 1;
 		ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
 		hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_exact((size_t)T * ti.C4, 256)), dim3(256), 0, stream, (const float*)src.p + (long)n0 * src.sn, V, ti);
 		HIP_ENFORCE(hipGetLastError());
@@ -196,6 +202,8 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	if (wgs < 8 * team) wgs = 8 * team;
 	const unsigned grid = (unsigned)(wgs / (8 * team) * (8 * team));
 	a.team = team;
+	a.relu = (!FLIP && tl_relu_want) ? 1 : 0;
+	if (a.relu) tl_relu_done = 1;
 	note_kernel(name);
 	char prof_name[96];
 	snprintf(prof_name, sizeof(prof_name), "%s|nnc::wino_fused_kernel<%d, %d>", name, p.GH, p.GW);
@@ -346,6 +354,8 @@ static int conv_c3_forw(const conv_geom_t& g, const Image4& a, const float* w, c
 {
 	ConvC3Args c;
 	conv_c3_args(g, a, w, bias, b, &c);
+	c.relu = tl_relu_want ? 1 : 0;
+	if (c.relu) tl_relu_done = 1;
 	hipStream_t stream = stream_of(ctx);
 	const long want = ((long)c.groups + 3) / 4, cap = (long)device_cu_count() * 8;
 	const unsigned grid = (unsigned)(want < cap ? want : cap);
@@ -1102,15 +1112,30 @@ static bool all_half(ccv_nnc_tensor_t* const* const inputs, const int input_size
 
 // The registered exec functions: fp32 tensors -> the fp32 paths above; half precision throughout and chunk-readable -> the
 // half-precision core; any other command with a half tensor -> the fp32 paths on fp32 images.
-static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+static int conv_forw_dispatch(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
-	MarkerScope marker(cmd.cmd);
 	if (!any_half_tensor(inputs, input_size, outputs, output_size)) return _conv_forw(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (all_half(inputs, input_size, outputs, output_size)) {
 		const int r = _conv_forw_half(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 		if (r != CCV_NNC_EXEC_NO_KERNEL) return r;
 	}
 	return half_staged_exec(_conv_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+}
+static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	MarkerScope marker(cmd.cmd);
+	// Opt-in fusion (a caller that knows the convolution's only consumer is a RELU_FORWARD): algorithm = FUSE_RELU | (0..2, or 0xff
+	// for the backend's choice).  The host's autotuner never produces such a value (it walks 0 .. algorithms - 1).
+	if (cmd.algorithm < 0 || !(cmd.algorithm & NNC_MI355X_CONV_ALGO_FUSE_RELU)) return conv_forw_dispatch(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (flags & CCV_NNC_ACCUMULATE_OUTPUT) return CCV_NNC_EXEC_INVALID;
+	ccv_nnc_cmd_t plain = cmd;
+	plain.algorithm = (cmd.algorithm & 0xff) == 0xff ? -1 : (cmd.algorithm & 0xff);
+	tl_relu_want = 1; tl_relu_done = 0;
+	const int r = conv_forw_dispatch(plain, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	const int done = tl_relu_done;
+	tl_relu_want = 0; tl_relu_done = 0;
+	if (r != CCV_NNC_EXEC_SUCCESS || done) return r;
+	return relu_inplace(outputs[0], stream_context); // the path taken has no fused epilogue (implicit GEMM, half core, ...): one more pass
 }
 static int _conv_back_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {

@@ -548,6 +548,14 @@ int fill_f32(float* p, size_t n, float v, ccv_nnc_stream_context_t* ctx)
 	return ew_map<OpFill, 0>(f, p, 0, 0, 0, n, ctx);
 }
 
+int relu_inplace(ccv_nnc_tensor_t* t, ccv_nnc_stream_context_t* ctx)
+{
+	if (!t || !tensor_contiguous(t)) return CCV_NNC_EXEC_INVALID;
+	const int dt = CCV_GET_DATA_TYPE(t->info.datatype);
+	if (dt != CCV_32F && dt != CCV_16F) return CCV_NNC_EXEC_INVALID;
+	return ew_map_any<OpRelu, 1>(OpRelu(), t->info.datatype, t->data.u8, t->data.u8, 0, 0, tensor_count(t->info), ctx);
+}
+
 int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int accumulate, ccv_nnc_stream_context_t* ctx)
 {
 	if (cols <= 0) return CCV_NNC_EXEC_SUCCESS;

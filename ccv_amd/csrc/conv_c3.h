@@ -23,6 +23,7 @@ struct ConvC3Args {
 	int N, H, W, OH, OW, K;
 	int pad_y, pad_x;
 	int groups_per_row, groups; // 16-pixel groups per output row, total
+	int relu;                   // forward: write max(0, .) (NNC_MI355X_CONV_ALGO_FUSE_RELU)
 	unsigned b_image_bytes;     // forward: span of one output image in bytes (range of the per-image store descriptor; host-checked < 2^31)
 	FastDiv d_gpr, d_oh;        // group -> (row, position), row -> (image, oy) without hardware division (two per 28-MFMA group otherwise)
 };
@@ -139,13 +140,14 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const ConvC3
 		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.b + (long)cur.img * g.b_sn), 0, g.b_image_bytes, 0x00020000);
 		const int ox0 = cur.gx * 16;
 		const unsigned row_off = (unsigned)(cur.oy * (int)g.b_sh + NT * n) * 4u;
+		auto outv = [&](const int j, const int r) { const float o = acc[j][r] + bv[j]; return __float_as_uint(g.relu ? fmaxf(o, 0.f) : o); };
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const int ox = ox0 + 4 * r + kq;
 			const unsigned voff = ox < g.OW ? row_off + (unsigned)(ox * (int)g.b_sw) * 4u : 0x7ffff000u;
-			if (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(u4{ __float_as_uint(acc[0][r] + bv[0]), __float_as_uint(acc[NT > 1 ? 1 : 0][r] + bv[NT > 1 ? 1 : 0]), __float_as_uint(acc[NT > 2 ? 2 : 0][r] + bv[NT > 2 ? 2 : 0]), __float_as_uint(acc[NT > 3 ? 3 : 0][r] + bv[NT > 3 ? 3 : 0]) }, rs, voff, 0, 0);
-			else if (NT == 2) __builtin_amdgcn_raw_buffer_store_b64(u2{ __float_as_uint(acc[0][r] + bv[0]), __float_as_uint(acc[NT > 1 ? 1 : 0][r] + bv[NT > 1 ? 1 : 0]) }, rs, voff, 0, 0);
-			else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][r] + bv[0]), rs, voff, 0, 0);
+			if (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(u4{ outv(0, r), outv(NT > 1 ? 1 : 0, r), outv(NT > 2 ? 2 : 0, r), outv(NT > 3 ? 3 : 0, r) }, rs, voff, 0, 0);
+			else if (NT == 2) __builtin_amdgcn_raw_buffer_store_b64(u2{ outv(0, r), outv(NT > 1 ? 1 : 0, r) }, rs, voff, 0, 0);
+			else __builtin_amdgcn_raw_buffer_store_b32(outv(0, r), rs, voff, 0, 0);
 		}
 		if (more) {
 #pragma unroll

@@ -137,6 +137,7 @@ struct WinoFusedArgs {
 	int team;           // workgroups per team (divides KB; the grid is a multiple of 8 * team)
 	unsigned src_image_bytes; // range of the per-image buffer descriptor
 	unsigned uf_kb_bytes;     // bytes of one k block of U fragments (CCn * 36 KB)
+	int relu;                 // epilogue writes max(0, A^T M A + bias) (NNC_MI355X_CONV_ALGO_FUSE_RELU)
 };
 
 // s_waitcnt with only vmcnt counted (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
@@ -524,7 +525,8 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 				const int oy = (it.gy * GH + (tile >> GWL)) * 4 + (px >> 2), ox = (it.gx * GW + (tile & (GW - 1))) * 4 + (px & 3);
 				const float4 v = *(const float4*)(st + gp * TS + px * 32 + (lane & 7) * 4);
 				const unsigned voff = (kok & (oy < a.OH) & (ox < a.OW)) ? (unsigned)(oy * dh4 + ox * dw4 + kq * 4) : WF_OOB;
-				const float o0 = v.x + bv[0], o1 = v.y + bv[1], o2 = v.z + bv[2], o3 = v.w + bv[3];
+				float o0 = v.x + bv[0], o1 = v.y + bv[1], o2 = v.z + bv[2], o3 = v.w + bv[3];
+				if (a.relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
 				__builtin_amdgcn_raw_buffer_store_b128(u4{ __float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3) }, rs_dst, voff, 0, 0);
 			}
 			__builtin_amdgcn_wave_barrier(); // next round's writes after this round's reads

@@ -129,6 +129,7 @@ struct WinoTiles {
 	long sn, sh, sw; // its strides
 	int oy, ox;      // input transform: source row / column of tile (0, 0)'s first element = -padding
 	int C4;          // channels / 4
+	int relu;        // output transform: write max(0, .) (NNC_MI355X_CONV_ALGO_FUSE_RELU)
 	FastDiv d_c4, d_tw, d_th;
 };
 
@@ -200,7 +201,11 @@ static __global__ void __launch_bounds__(256) wino_output_kernel(const float* __
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int ox = tx * 4 + j;
-			if ((oy < g.H) & (ox < g.W)) *(float4*)(dst + (long)oy * g.sh + (long)ox * g.sw) = (float4)(y[j] + bv);
+			if ((oy < g.H) & (ox < g.W)) {
+				f4 o = y[j] + bv;
+				if (g.relu) o = f4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+				*(float4*)(dst + (long)oy * g.sh + (long)ox * g.sw) = (float4)o;
+			}
 		}
 	}
 }

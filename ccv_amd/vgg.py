@@ -57,8 +57,11 @@ def hash_unit(n, stream):
 
 class VGGD:
     def __init__(self, lib, batch, memory=nnc.GPU_MEMORY, device=0, input_hw=225, layers=VGG_D, classes=None, seed=0, backend=None,
-                 sgd=(0, 0.001, None, 0.0005, 0.9, 0.9), train=True, init="numpy", pool_per_image=False, flat_grads=False):
+                 sgd=(0, 0.001, None, 0.0005, 0.9, 0.9), train=True, init="numpy", pool_per_image=False, flat_grads=False, fuse_relu=False):
         self.lib, self.batch, self.memory, self.device, self.backend = lib, batch, memory, device, backend
+        # fuse_relu: the convolutions write max(0, .) themselves (NNC_MI355X_CONV_ALGO_FUSE_RELU, include/nnc_mi355x.h) and the in-place
+        # RELU_FORWARD behind each of them is not issued -- this driver knows the ReLU is the convolution's only consumer
+        self.fuse_relu = fuse_relu
         # The reference CPU pools only walk image 0 of a batch: when driving the oracle, issue them per image.
         self.pool_per_image = pool_per_image
         self.conv_fwd_backend = None  # bench.py's CPU leg: route CONVOLUTION_FORWARD to another backend of the same library (CPU_OPT)
@@ -216,8 +219,13 @@ class VGGD:
             if n["kind"] == "pool":
                 self._pool(n["cmd"], n["hint"], [n["a"]], [n["b"]], stream, "pool_fwd/%d" % i, hook)
             else:
-                self._exec(n["cmd"], n["hint"], 0, [n["a"], n["w"], n["bias"]], [n["b"]], stream, "%s_fwd/%d" % (n["kind"], i), hook)
-                if n["relu"]:
+                fused = self.fuse_relu and n["kind"] == "conv" and n["relu"]
+                cmd = n["cmd"]
+                if fused:
+                    cmd = nnc.Cmd(); nnc.C.memmove(nnc.C.byref(cmd), nnc.C.byref(n["cmd"]), nnc.C.sizeof(cmd))
+                    cmd.algorithm = nnc.CONV_ALGO_FUSE_RELU | (0xff if n["cmd"].algorithm < 0 else n["cmd"].algorithm)
+                self._exec(cmd, n["hint"], 0, [n["a"], n["w"], n["bias"]], [n["b"]], stream, "%s_fwd/%d" % (n["kind"], i), hook)
+                if n["relu"] and not fused:
                     self._exec(relu, nnc.NO_HINT, 0, [n["b"]], [n["b"]], stream, "relu_fwd/%d" % i, hook)
         self._exec(nnc.CMD_SOFTMAX_CROSSENTROPY_FORWARD(), nnc.NO_HINT, 0, [self.logits, self.label], [self.loss, self.softmax], stream, "softmax_ce_fwd", hook)
 

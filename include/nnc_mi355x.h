@@ -411,6 +411,13 @@ int  nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, doub
  * ((2,2) (2,1) (1,2) (1,1) exist); (0,0) restores the built-in choice.  Used by the parity tests to cover every
  * tile shape on every loader at sizes the oracle finishes. */
 void nnc_mi355x_debug_force_tile(int wm, int wn);
+/* Opt-in fusion for callers that know a CONVOLUTION_FORWARD's only consumer is the RELU_FORWARD behind it (the reference's graphs run
+ * that ReLU in place, test/int/nnc/graph.vgg.d.tests.c:80): cmd.algorithm = NNC_MI355X_CONV_ALGO_FUSE_RELU | a, a = 0 .. 2 or 0xff for the
+ * backend's choice, makes the command write max(0, conv + bias); the RELU_FORWARD may then be dropped.  Applied in the epilogue of the
+ * fused Winograd kernel, the Winograd output transform and the 3-channel kernel; as one more pass behind the other paths.
+ * ccv_nnc_cmd_autotune never produces such a value.  The symmetric change a maintainer would make in the host: a
+ * (CONVOLUTION_FORWARD, RELU_FORWARD) entry in ccv_nnc_ops_fusions[] (lib/nnc/ccv_nnc_symbolic_graph_simplify.c:595-). */
+#define NNC_MI355X_CONV_ALGO_FUSE_RELU 0x100
 /* Test hook for the CCV_16F datapath (half_stage.cpp): how many half-precision tensors have been given an fp32 image so far
  * (staged) and how many were handed to a kernel as halves (native) since the library was loaded. */
 void nnc_mi355x_debug_half_counts(long* staged, long* native);

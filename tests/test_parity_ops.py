@@ -652,3 +652,36 @@ def test_conv_stride2_data_gradient_by_parity_classes(backend, ref_lib, case):
     assert any(x.startswith("conv_fwd") for x in names) and not any(x.startswith("conv_dgrad") for x in names), names
     np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5)
+
+
+FUSE_RELU_CASES = [
+    # n, h, w, c, k, border, algorithm, fmt
+    (2, 13, 14, 16, 24, 1, 0xff, "NHWC"),   # the backend's choice
+    (2, 13, 14, 16, 24, 1, 0, "NHWC"),      # implicit GEMM: no fused epilogue, one more pass
+    (2, 13, 14, 16, 24, 1, 1, "NHWC"),      # Winograd via HBM: the output transform rectifies
+    (2, 13, 14, 16, 32, 1, 2, "NHWC"),      # fused Winograd: its epilogue does
+    (2, 12, 11, 3, 64, 0, 0xff, "NHWC"),    # 3-channel kernel
+    (2, 9, 9, 8, 8, 1, 0xff, "NCHW"),       # staged layouts
+]
+
+
+@pytest.mark.parametrize("case", FUSE_RELU_CASES, ids=[str(c) for c in FUSE_RELU_CASES])
+def test_conv_forward_with_fused_relu(backend, ref_lib, case):
+    """cmd.algorithm = NNC_MI355X_CONV_ALGO_FUSE_RELU | a: the command writes max(0, conv + bias) -- the oracle's convolution followed
+    by the oracle's ReLU, whichever kernel ran."""
+    n, h, w, c, k, border, algo, fmt = case
+    rng = np.random.default_rng(21)
+    a, wt, b = srnd(rng, n, h, w, c), srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c)), srnd(rng, k, scale=0.05)
+    hint = nnc.HINT((1, 1), (border, border))
+    oh, ow = out_hw(h, w, 3, 3, hint)
+    cmd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
+    _, (conv,) = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [a, wt, b], [np.zeros((n, oh, ow, k), F)], backend=nnc.BACKEND_CPU_REF)
+    want = np.maximum(conv, 0)
+    fused = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c)
+    fused.algorithm = nnc.CONV_ALGO_FUSE_RELU | algo
+    t = (lambda x: np.ascontiguousarray(x.transpose(0, 3, 1, 2))) if fmt == "NCHW" else (lambda x: x)
+    wt_l = np.ascontiguousarray(wt.transpose(0, 3, 1, 2)) if fmt == "NCHW" else wt
+    r, (got,) = exec_on(backend, nnc.GPU_MEMORY, fused, hint, 0, [t(a), wt_l, b], [t(np.full((n, oh, ow, k), -7, F))], fmt)
+    assert r == 0
+    assert (got >= 0).all() and (got == 0).any()
+    np.testing.assert_allclose(got, t(want), rtol=1e-4, atol=1e-5)

@@ -8,8 +8,8 @@ from ccv_amd.vgg import VGGD, VGG_D
 MINI = [("conv", 8), ("conv", 8), ("pool",), ("conv", 16), ("conv", 16), ("pool",), ("fc", 32), ("fc", 10)]
 
 
-def _run(lib, memory, backend, batch, hw, layers, pool_per_image, steps=2):
-    net = VGGD(lib, batch, memory=memory, input_hw=hw, layers=layers, seed=1, backend=backend, pool_per_image=pool_per_image)
+def _run(lib, memory, backend, batch, hw, layers, pool_per_image, steps=2, fuse_relu=False):
+    net = VGGD(lib, batch, memory=memory, input_hw=hw, layers=layers, seed=1, backend=backend, pool_per_image=pool_per_image, fuse_relu=fuse_relu)
     rng = np.random.default_rng(5)
     out = []
     for s in range(steps):
@@ -31,6 +31,17 @@ def test_vgg_mini_step_matches_reference(backend, ref_lib):
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5)
     for a, b in zip(got[1], want[1]):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_vgg_mini_step_with_fused_relu_is_the_same_step(backend):
+    """The convolutions rectifying in their own epilogue (NNC_MI355X_CONV_ALGO_FUSE_RELU) against conv followed by the in-place
+    RELU_FORWARD: max(0, .) is exact, so losses, gradients and updated parameters are bit-identical."""
+    a = _run(backend, nnc.GPU_MEMORY, None, 3, 23, MINI, False, fuse_relu=True)
+    b = _run(backend, nnc.GPU_MEMORY, None, 3, 23, MINI, False, fuse_relu=False)
+    for (l1, s1), (l2, s2) in zip(a[0], b[0]):
+        assert np.array_equal(l1, l2) and np.array_equal(s1, s2)
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        assert np.array_equal(x, y)
 
 
 def test_vgg_d_layer_table():

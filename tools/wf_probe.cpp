@@ -44,7 +44,7 @@ int main(int argc, char** argv)
 		CHECK(hipMemcpy(bias, h.data(), sizeof(float) * K, hipMemcpyHostToDevice));
 	}
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_weight_frag_kernel<false>), dim3((unsigned)(((size_t)KB * WF_KT * C + 255) / 256)), dim3(256), 0, 0, (const float*)w, uf, K, C, K, C);
-	WinoFusedArgs a;
+	WinoFusedArgs a = {};
 	a.src = src; a.dst = dst; a.uf = uf; a.bias = bias;
 	a.s_sn = (long)H * W * C; a.s_sh = (long)W * C; a.s_sw = C; a.d_sn = (long)H * W * K; a.d_sh = (long)W * K; a.d_sw = K;
 	a.H = H; a.W = W; a.OH = H; a.OW = W; a.pad_y = 1; a.pad_x = 1;
