@@ -20,6 +20,15 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // NNC_MI355X_CONV_ALGO_FUSE_RELU (include/nnc_mi355x.h): the forward command in progress on this thread was asked to write
 // max(0, .); a kernel that does so in its epilogue says so, otherwise _conv_forw_any rectifies the output afterwards.
 static thread_local int tl_relu_want = 0, tl_relu_done = 0;
+// ... and on the way back (the same bit on CONVOLUTION_BACKWARD): the data gradient is masked by a > 0, a being the command's forward
+// input -- a ReLU's output.  _conv_back publishes a's NHWC image while the data gradient runs; a kernel that masked as it wrote says so.
+static thread_local int tl_mask_want = 0, tl_mask_done = 0;
+static thread_local Image4 tl_mask = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+static bool mask_fits(const Image4& dst)
+{
+	const Image4& m = tl_mask;
+	return m.p && m.n == dst.n && m.h == dst.h && m.w == dst.w && m.c == dst.c && m.sc == 1 && aligned16(m.p) && m.sw % 4 == 0 && m.sh % 4 == 0 && (m.n == 1 || m.sn % 4 == 0);
+}
 
 struct conv_geom_t {
 	int N, H, W, C;     // input
@@ -123,6 +132,7 @@ static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan
 		ti.H = src.h; ti.W = src.w; ti.sn = src.sn; ti.sh = src.sh; ti.sw = src.sw; ti.oy = -pad_y; ti.ox = -pad_x; ti.C4 = Cs / 4;
 		ti.relu = (!FLIP && tl_relu_want) ? 1 : 0;
 		if (ti.relu) tl_relu_done = 1;
+		ti.mask = 0; ti.m_sn = ti.m_sh = ti.m_sw = 0;
 		ti.d_c4.init(ti.C4); ti.d_tw.init(ti.TW); ti.d_th.init(ti.TH);
 		hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_exact((size_t)T * ti.C4, 256)), dim3(256), 0, stream, (const float*)src.p + (long)n0 * src.sn, V, ti);
 		HIP_ENFORCE(hipGetLastError());
@@ -135,6 +145,10 @@ static int conv_wino_run(const char* name, const conv_geom_t& g, const wino_plan
 		if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
 		ti.H = dst.h; ti.W = dst.w; ti.sn = dst.sn; ti.sh = dst.sh; ti.sw = dst.sw; ti.C4 = Cd / 4;
 		ti.d_c4.init(ti.C4);
+		if (FLIP && mask_fits(dst)) { // data gradient under a ReLU backward: the output transform reads the map's 16 bytes next to each store
+			ti.mask = tl_mask.p + (long)n0 * tl_mask.sn; ti.m_sn = tl_mask.sn; ti.m_sh = tl_mask.sh; ti.m_sw = tl_mask.sw;
+			tl_mask_done = 1;
+		}
 		hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_exact((size_t)T * ti.C4, 256)), dim3(256), 0, stream, (const float*)M, bias, dst.p + (long)n0 * dst.sn, ti);
 		HIP_ENFORCE(hipGetLastError());
 	}
@@ -177,12 +191,39 @@ static size_t wino_fused_scratch_bound(const int Kout, const int Cred)
 	return ((sizeof(float) * (size_t)((Kout + WF_KT - 1) / WF_KT) * (Cred / WF_CC) * WF_U_FLOATS + 255) & ~(size_t)255);
 }
 
+// ... and its mask bits (data gradient under a ReLU backward): 1 KB per (tile group, 32-channel block) of the gradient written
+static size_t wino_fused_mask_bound(const conv_geom_t& g)
+{
+	if (!tl_mask_want) return 0;
+	const long TH = (g.H + 3) / 4, TW = (g.W + 3) / 4;
+	long most = 0;
+	static const int shapes[3][2] = { { 4, 4 }, { 2, 8 }, { 8, 2 } };
+	for (int i = 0; i < 3; i++) {
+		const long cover = ((TH + shapes[i][0] - 1) / shapes[i][0]) * ((TW + shapes[i][1] - 1) / shapes[i][1]);
+		if (cover > most) most = cover;
+	}
+	return (size_t)g.N * most * ((g.C + WF_KT - 1) / WF_KT) * 1024;
+}
+
 template <bool FLIP>
 static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const wino_fused_plan_t& p, const Image4& src, const float* w, const float* bias, const Image4& dst, const int pad_y, const int pad_x, ccv_nnc_stream_context_t* const ctx)
 {
-	float* const UF = (float*)workspace_of(ctx, p.uf_bytes);
+	// data gradient under a ReLU backward: the mask as bits in the epilogue's order, packed first (1 / 32 of the map; no room: unmasked, the caller's pass follows)
+	size_t bits_bytes = FLIP && mask_fits(dst) && (long)p.groups * p.KB <= 0x7fffffffL ? (size_t)p.groups * p.KB * 1024 : 0;
+	float* UF = (float*)workspace_of(ctx, p.uf_bytes + bits_bytes);
+	if (!UF && bits_bytes) { bits_bytes = 0; UF = (float*)workspace_of(ctx, p.uf_bytes); }
 	if (!UF) return CCV_NNC_EXEC_OOM;
 	hipStream_t stream = stream_of(ctx);
+	unsigned* const bits = bits_bytes ? (unsigned*)((char*)UF + p.uf_bytes) : 0;
+	if (bits) {
+		const dim3 grid((unsigned)((long)p.groups * p.KB));
+		const Image4& m = tl_mask;
+		if (p.GH == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_mask_pack_kernel<4, 4>), grid, dim3(256), 0, stream, (const float*)m.p, m.sn, m.sh, m.sw, bits, dst.h, dst.w, dst.c, p.GYn, p.GXn, p.KB);
+		else if (p.GH == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_mask_pack_kernel<2, 8>), grid, dim3(256), 0, stream, (const float*)m.p, m.sn, m.sh, m.sw, bits, dst.h, dst.w, dst.c, p.GYn, p.GXn, p.KB);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_mask_pack_kernel<8, 2>), grid, dim3(256), 0, stream, (const float*)m.p, m.sn, m.sh, m.sw, bits, dst.h, dst.w, dst.c, p.GYn, p.GXn, p.KB);
+		HIP_ENFORCE(hipGetLastError());
+		tl_mask_done = 1;
+	}
 	const int Kout = dst.c, Cred = src.c;
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_weight_frag_kernel<FLIP>), dim3(blocks_exact((size_t)p.KB * WF_KT * Cred, 256)), dim3(256), 0, stream, w, UF, Kout, Cred, g.K, g.C);
 	HIP_ENFORCE(hipGetLastError());
@@ -204,6 +245,7 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	a.team = team;
 	a.relu = (!FLIP && tl_relu_want) ? 1 : 0;
 	if (a.relu) tl_relu_done = 1;
+	a.mask_bits = bits;
 	note_kernel(name);
 	char prof_name[96];
 	snprintf(prof_name, sizeof(prof_name), "%s|nnc::wino_fused_kernel<%d, %d>", name, p.GH, p.GW);
@@ -802,7 +844,7 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wpl) && wpl.total() > inner) inner = wpl.total();
 	wino_wgrad_plan_t wgp;
 	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wgp) && wgp.total() > inner) inner = wgp.total();
-	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_fused_scratch_bound(g.C, g.K) > inner) inner = wino_fused_scratch_bound(g.C, g.K);
+	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_fused_scratch_bound(g.C, g.K) + wino_fused_mask_bound(g) > inner) inner = wino_fused_scratch_bound(g.C, g.K) + wino_fused_mask_bound(g);
 	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && conv_dgrad_parity_scratch(g) > inner) inner = conv_dgrad_parity_scratch(g);
 	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && g.C == 3 && conv_c3_wgrad_scratch_bound(g.K) > inner) inner = conv_c3_wgrad_scratch_bound(g.K);
 	WorkspaceScope ws(stream_context, ng + na + nh + nw + ndw, inner);
@@ -843,7 +885,10 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 			if ((ret = weights_nchw_to_nhwc(w->data.f32, (float*)(p + ng + na + nh), g.K, g.Cg, g.kh * g.kw, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 			wp = (const float*)(p + ng + na + nh);
 		}
-		if ((ret = conv_dgrad_nhwc(g, gim, wp, him, cmd.algorithm, flags, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if (tl_mask_want) tl_mask = aim;
+		ret = conv_dgrad_nhwc(g, gim, wp, him, cmd.algorithm, flags, stream_context);
+		tl_mask.p = 0;
+		if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
 		if (stage_io && (ret = format_transform(&hs, h, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
 	return CCV_NNC_EXEC_SUCCESS;
@@ -1137,9 +1182,28 @@ static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 	if (r != CCV_NNC_EXEC_SUCCESS || done) return r;
 	return relu_inplace(outputs[0], stream_context); // the path taken has no fused epilogue (implicit GEMM, half core, ...): one more pass
 }
+static int conv_back_dispatch(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
+// NNC_MI355X_CONV_ALGO_FUSE_RELU on the backward command: h = a > 0 ? (data gradient) : 0 -- the RELU_BACKWARD of the map a that would
+// run on h next.  Masked where the data gradient is written by the Winograd kernels; one in-place pass behind the others.
 static int _conv_back_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	MarkerScope marker(cmd.cmd);
+	if (cmd.algorithm < 0 || !(cmd.algorithm & NNC_MI355X_CONV_ALGO_FUSE_RELU)) return conv_back_dispatch(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	ccv_nnc_cmd_t plain = cmd;
+	plain.algorithm = (cmd.algorithm & 0xff) == 0xff ? -1 : (cmd.algorithm & 0xff);
+	ccv_nnc_tensor_t* const h = output_size > 0 ? outputs[0] : 0;
+	const ccv_nnc_tensor_t* const a = input_size > 1 ? inputs[1] : 0;
+	if (!h) return conv_back_dispatch(plain, hint, flags, inputs, input_size, outputs, output_size, stream_context); // no data gradient asked for: nothing to mask
+	if ((flags & CCV_NNC_ACCUMULATE_OUTPUT) || !a || !tensor_contiguous(h) || !tensor_contiguous(a) || h->info.datatype != a->info.datatype || h->info.format != a->info.format || tensor_count(h->info) != tensor_count(a->info)) return CCV_NNC_EXEC_INVALID;
+	tl_mask_want = 1; tl_mask_done = 0;
+	const int r = conv_back_dispatch(plain, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	const int done = tl_mask_done;
+	tl_mask_want = 0; tl_mask_done = 0; tl_mask.p = 0;
+	if (r != CCV_NNC_EXEC_SUCCESS || done) return r;
+	return relu_back_inplace(h, a, stream_context);
+}
+static int conv_back_dispatch(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
 	if (!any_half_tensor(inputs, input_size, outputs, output_size)) return _conv_back(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (all_half(inputs, input_size, outputs, output_size)) {
 		const int r = _conv_back_half(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);

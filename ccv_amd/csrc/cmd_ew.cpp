@@ -556,6 +556,14 @@ int relu_inplace(ccv_nnc_tensor_t* t, ccv_nnc_stream_context_t* ctx)
 	return ew_map_any<OpRelu, 1>(OpRelu(), t->info.datatype, t->data.u8, t->data.u8, 0, 0, tensor_count(t->info), ctx);
 }
 
+int relu_back_inplace(ccv_nnc_tensor_t* h, const ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx)
+{
+	if (!h || !b || !tensor_contiguous(h) || !tensor_contiguous(b) || h->info.datatype != b->info.datatype || tensor_count(h->info) != tensor_count(b->info)) return CCV_NNC_EXEC_INVALID;
+	const int dt = CCV_GET_DATA_TYPE(h->info.datatype);
+	if (dt != CCV_32F && dt != CCV_16F) return CCV_NNC_EXEC_INVALID;
+	return ew_map_any<OpReluBack, 2>(OpReluBack(), h->info.datatype, h->data.u8, h->data.u8, b->data.u8, 0, tensor_count(h->info), ctx);
+}
+
 int colsum_f32(const float* x, long rows, int cols, long ld, float* out, int accumulate, ccv_nnc_stream_context_t* ctx)
 {
 	if (cols <= 0) return CCV_NNC_EXEC_SUCCESS;

@@ -26,6 +26,7 @@ struct pool_geom_t {
 	long b_sn, b_sh, b_sw, b_sc; // output-shaped tensors (b, g)
 	FastDiv d_c, d_w, d_h, d_ow, d_oh; // index decomposition without hardware division
 	FastDiv d_c4, d_sy, d_sx;          // float4 kernels: C / 4 channel groups; strides for the window bounds
+	int relu_mask;                     // max backward: a is a ReLU's output, h is masked by a > 0 as well (NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD)
 };
 
 // idx -> (n, y, x, c) with the memory-contiguous index fastest; idx < 2^31 (the host splits larger tensors per image).
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, con
 					acc += (float)gr[o] / (float)((wy1 - wy0) * (wx1 - wx0));
 				}
 			}
+		if (IS_MAX && g.relu_mask && !(av > 0.f)) acc = 0.f;
 		h[n * g.a_sn + y * g.a_sh + x * g.a_sw + c * g.a_sc] = (T)acc;
 	}
 }
@@ -201,6 +203,12 @@ __global__ void __launch_bounds__(256) pool_back_v4_kernel(const pool_geom_t g, 
 					acc.x += gv.x / cnt; acc.y += gv.y / cnt; acc.z += gv.z / cnt; acc.w += gv.w / cnt;
 				}
 			}
+		if (IS_MAX && g.relu_mask) {
+			if (!(av.x > 0.f)) acc.x = 0.f;
+			if (!(av.y > 0.f)) acc.y = 0.f;
+			if (!(av.z > 0.f)) acc.z = 0.f;
+			if (!(av.w > 0.f)) acc.w = 0.f;
+		}
 		st4(h + n * g.a_sn + y * g.a_sh + x * g.a_sw + c4 * 4, acc);
 	}
 }
@@ -239,12 +247,12 @@ __global__ void __launch_bounds__(256) pool_back_tiled_kernel(const pool_geom_t 
 					V r;
 					if (IS_MAX) {
 						const V av = *(const V*)(a + i);
-						for (int e = 0; e < VEC; e++) r[e] = (T)((float)av[e] == bv[e] ? gv[e] : 0.f);
+						for (int e = 0; e < VEC; e++) r[e] = (T)(((float)av[e] == bv[e]) & (!g.relu_mask | ((float)av[e] > 0.f)) ? gv[e] : 0.f);
 					} else
 						for (int e = 0; e < VEC; e++) r[e] = (T)(gv[e] / cnt);
 					*(V*)(h + i) = r;
 				} else {
-					if (IS_MAX) h[i] = (T)((float)a[i] == bv[0] ? gv[0] : 0.f);
+					if (IS_MAX) { const float av = (float)a[i]; h[i] = (T)((av == bv[0]) & (!g.relu_mask | (av > 0.f)) ? gv[0] : 0.f); }
 					else h[i] = (T)(gv[0] / cnt);
 				}
 			}
@@ -323,6 +331,7 @@ static bool pool_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, 
 	g->b_sn = b.sn; g->b_sh = b.sh; g->b_sw = b.sw; g->b_sc = b.sc;
 	g->d_c.init(g->C); g->d_w.init(g->W); g->d_h.init(g->H); g->d_ow.init(g->OW); g->d_oh.init(g->OH);
 	g->d_c4.init(g->C / 4 > 0 ? g->C / 4 : 1); g->d_sy.init(g->sy); g->d_sx.init(g->sx);
+	g->relu_mask = 0;
 	return true;
 }
 
@@ -385,6 +394,10 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	pool_geom_t g;
 	bool nhwc;
 	if (!pool_geometry(cmd, hint, h, gt, &g, &nhwc)) return CCV_NNC_EXEC_INVALID;
+	// opt-in: the RELU_BACKWARD that would follow (h = a > 0 ? h : 0, a being that ReLU's output) folded into this command
+	const bool relu_mask = IS_MAX && cmd.algorithm > 0 && (cmd.algorithm & NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD);
+	if (relu_mask && (flags & CCV_NNC_ACCUMULATE_OUTPUT)) return CCV_NNC_EXEC_INVALID;
+	g.relu_mask = relu_mask ? 1 : 0; // every max kernel reads a anyway and masks as it writes: no extra traffic
 	const bool half = CCV_GET_DATA_TYPE(h->info.datatype) == CCV_16F;
 	if (gt->info.datatype != h->info.datatype || (a && a->info.datatype != h->info.datatype) || (b && b->info.datatype != h->info.datatype)) return CCV_NNC_EXEC_INVALID;
 	const size_t per_image = (size_t)g.H * g.W * g.C;

@@ -140,6 +140,7 @@ int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_str
 int transpose_half_to_float(const void* in, float* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx); // in[batch][R][C] halves -> out[batch][C][R] floats
 int transpose_float_to_half(const float* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx);
 int relu_inplace(ccv_nnc_tensor_t* t, ccv_nnc_stream_context_t* ctx); // t = max(t, 0), dense CCV_32F / CCV_16F (cmd_ew.cpp)
+int relu_back_inplace(ccv_nnc_tensor_t* h, const ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx); // h = b > 0 ? h : 0, dense, same type and count
 int weights_nchw_to_nhwc(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx);
 int weights_nhwc_to_nchw(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx);
 

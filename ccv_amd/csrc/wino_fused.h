@@ -138,6 +138,8 @@ struct WinoFusedArgs {
 	unsigned src_image_bytes; // range of the per-image buffer descriptor
 	unsigned uf_kb_bytes;     // bytes of one k block of U fragments (CCn * 36 KB)
 	int relu;                 // epilogue writes max(0, A^T M A + bias) (NNC_MI355X_CONV_ALGO_FUSE_RELU)
+	const unsigned* mask_bits; // or null.  Data gradient under a ReLU backward: one dword per (item, round, lane), bit 4 e + i set where the
+	                          // element store e of that round writes at channel i is kept (wino_mask_pack_kernel makes them in the epilogue's own order)
 };
 
 // s_waitcnt with only vmcnt counted (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
@@ -492,6 +494,14 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
 		for (int i = 0; i < 4; i++) bv[i] = (a.bias && kq < a.K) ? a.bias[kq + i] : 0.f;
 		const int dh4 = (int)a.d_sh * 4, dw4 = (int)a.d_sw * 4;
+		// mask bits of the item's four rounds: four 4-byte loads per lane, issued here (nothing stored yet: they come back during round 0's
+		// transforms; the wait before the first store covers them)
+		unsigned mb[4] = { ~0u, ~0u, ~0u, ~0u };
+		if (a.mask_bits) {
+			const unsigned* const mp = a.mask_bits + ((((long)it.n * a.GYn + it.gy) * a.GXn + it.gx) * a.KB + it.kb) * 256 + lane;
+#pragma unroll
+			for (int r = 0; r < 4; r++) mb[r] = it.live ? mp[r * 64] : 0u;
+		}
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -527,6 +537,10 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 				const unsigned voff = (kok & (oy < a.OH) & (ox < a.OW)) ? (unsigned)(oy * dh4 + ox * dw4 + kq * 4) : WF_OOB;
 				float o0 = v.x + bv[0], o1 = v.y + bv[1], o2 = v.z + bv[2], o3 = v.w + bv[3];
 				if (a.relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
+				if (a.mask_bits) {
+					const unsigned m = mb[r] >> (4 * e);
+					o0 = (m & 1) ? o0 : 0.f; o1 = (m & 2) ? o1 : 0.f; o2 = (m & 4) ? o2 : 0.f; o3 = (m & 8) ? o3 : 0.f;
+				}
 				__builtin_amdgcn_raw_buffer_store_b128(u4{ __float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3) }, rs_dst, voff, 0, 0);
 			}
 			__builtin_amdgcn_wave_barrier(); // next round's writes after this round's reads
@@ -561,6 +575,37 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		cur = nxt;
 	}
 #undef WF_XFORM
+}
+
+// The epilogue's mask bits (WinoFusedArgs::mask_bits) from the map a ReLU wrote: block = item in (n, gy, gx, kb) order, thread = (round,
+// lane), bit 4 e + i = mask > 0 at the element the epilogue's store e of that round writes at channel i -- the same index arithmetic as
+// the epilogue's read-back loop.  Reads the map once in 128-byte runs (eight lanes x 16 bytes per pixel), writes 1/32 of its size.
+template <int GH, int GW>
+__global__ void __launch_bounds__(256) wino_mask_pack_kernel(const float* __restrict__ mask, const long m_sn, const long m_sh, const long m_sw, unsigned* __restrict__ bits, const int OH, const int OW, const int K, const int GYn, const int GXn, const int KB)
+{
+	constexpr int GWL = GW == 4 ? 2 : (GW == 8 ? 3 : (GW == 2 ? 1 : (GW == 16 ? 4 : 0)));
+	static_assert(GH * GW == 16, "16 tiles per group");
+	int b = (int)blockIdx.x;
+	const int kb = b % KB; b /= KB;
+	const int gx = b % GXn; b /= GXn;
+	const int gy = b % GYn;
+	const int n = b / GYn;
+	const int r = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+	const int kq = kb * WF_KT + (lane & 7) * 4;
+	const float* const mp = mask + (long)n * m_sn + kq;
+	unsigned m = 0;
+#pragma unroll
+	for (int e = 0; e < 8; e++) {
+		const int pid = e * 8 + (lane >> 3);
+		const int gp = pid >> 4, px = pid & 15;
+		const int tile = 4 * gp + r;
+		const int oy = (gy * GH + (tile >> GWL)) * 4 + (px >> 2), ox = (gx * GW + (tile & (GW - 1))) * 4 + (px & 3);
+		if ((kq < K) & (oy < OH) & (ox < OW)) {
+			const float4 v = *(const float4*)(mp + (long)oy * m_sh + (long)ox * m_sw);
+			m |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * e);
+		}
+	}
+	bits[(size_t)blockIdx.x * 256 + threadIdx.x] = m;
 }
 
 } // namespace nnc

@@ -130,6 +130,7 @@ struct WinoTiles {
 	int oy, ox;      // input transform: source row / column of tile (0, 0)'s first element = -padding
 	int C4;          // channels / 4
 	int relu;        // output transform: write max(0, .) (NNC_MI355X_CONV_ALGO_FUSE_RELU)
+	const float* mask; long m_sn, m_sh, m_sw; // output transform of a data gradient: zero where mask <= 0 (the ReLU backward of the map the gradient belongs to), or null
 	FastDiv d_c4, d_tw, d_th;
 };
 
@@ -193,6 +194,7 @@ static __global__ void __launch_bounds__(256) wino_output_kernel(const float* __
 	}
 	const f4 bv = bias ? f4(*(const float4*)(bias + k4 * 4)) : f4(0.f, 0.f, 0.f, 0.f);
 	float* const dst = b + (long)n * g.sn + (long)k4 * 4;
+	const float* const msk = g.mask ? g.mask + (long)n * g.m_sn + (long)k4 * 4 : 0;
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
 		f4 y[4];
@@ -204,6 +206,10 @@ static __global__ void __launch_bounds__(256) wino_output_kernel(const float* __
 			if ((oy < g.H) & (ox < g.W)) {
 				f4 o = y[j] + bv;
 				if (g.relu) o = f4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+				if (msk) {
+					const float4 mv = *(const float4*)(msk + (long)oy * g.m_sh + (long)ox * g.m_sw);
+					o = f4(mv.x > 0.f ? o.x : 0.f, mv.y > 0.f ? o.y : 0.f, mv.z > 0.f ? o.z : 0.f, mv.w > 0.f ? o.w : 0.f);
+				}
 				*(float4*)(dst + (long)oy * g.sh + (long)ox * g.sw) = (float4)o;
 			}
 		}

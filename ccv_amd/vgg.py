@@ -60,7 +60,9 @@ class VGGD:
                  sgd=(0, 0.001, None, 0.0005, 0.9, 0.9), train=True, init="numpy", pool_per_image=False, flat_grads=False, fuse_relu=False):
         self.lib, self.batch, self.memory, self.device, self.backend = lib, batch, memory, device, backend
         # fuse_relu: the convolutions write max(0, .) themselves (NNC_MI355X_CONV_ALGO_FUSE_RELU, include/nnc_mi355x.h) and the in-place
-        # RELU_FORWARD behind each of them is not issued -- this driver knows the ReLU is the convolution's only consumer
+        # RELU_FORWARD behind each of them is not issued -- this driver knows the ReLU is the convolution's only consumer; on the way back
+        # the command that writes the gradient of a rectified map (convolution or max-pool backward, both read that map) masks it, and the
+        # RELU_BACKWARD is not issued either.  Same numbers either way (tests/test_vgg_step.py).
         self.fuse_relu = fuse_relu
         # The reference CPU pools only walk image 0 of a batch: when driving the oracle, issue them per image.
         self.pool_per_image = pool_per_image
@@ -235,16 +237,31 @@ class VGGD:
         relub = nnc.CMD_RELU_BACKWARD()
         g_logits = self.grads[id(self.logits)]
         self._exec(nnc.CMD_SOFTMAX_CROSSENTROPY_BACKWARD(), nnc.NO_HINT, 0, [None, None, None, self.label, None, self.softmax], [g_logits], stream, "softmax_ce_bwd", hook)
+        masked = set()  # fuse_relu: gradients whose producer already applied the ReLU backward of the map they belong to
         for i in range(len(self.nodes) - 1, -1, -1):
             n = self.nodes[i]
             gb = self.grads[id(n["b"])]
             if n["kind"] == "pool":
-                self._pool(n["bcmd"], n["hint"], [gb, n["a"], n["b"]], [self.grads[id(n["a"])]], stream, "pool_bwd/%d" % i, hook)
+                cmd = n["bcmd"]
+                prev = self.nodes[i - 1] if i > 0 else None
+                if self.fuse_relu and prev is not None and prev["kind"] == "conv" and prev["relu"] and prev["b"] is n["a"]:
+                    # the pooled map IS the ReLU's output: max-pool backward masks by it as it writes (NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD)
+                    cmd = nnc.Cmd(); nnc.C.memmove(nnc.C.byref(cmd), nnc.C.byref(n["bcmd"]), nnc.C.sizeof(cmd))
+                    cmd.algorithm = nnc.POOL_ALGO_FUSE_RELU_BACKWARD
+                    masked.add(id(n["a"]))
+                self._pool(cmd, n["hint"], [gb, n["a"], n["b"]], [self.grads[id(n["a"])]], stream, "pool_bwd/%d" % i, hook)
                 continue
-            if n["relu"]:
+            if n["relu"] and id(n["b"]) not in masked:
                 self._exec(relub, nnc.NO_HINT, 0, [gb, None, n["b"]], [gb], stream, "relu_bwd/%d" % i, hook)
             h = None if n["first"] else self.grads[id(n["a"])]
-            self._exec(n["bcmd"], n["hint"], 0, [gb, n["a"], n["w"]], [h, n["dw"], n["dbias"]], stream, "%s_bwd/%d" % (n["kind"], i), hook)
+            cmd = n["bcmd"]
+            prev = self.nodes[i - 1] if i > 0 else None
+            if self.fuse_relu and h is not None and n["kind"] == "conv" and prev["kind"] == "conv" and prev["relu"] and prev["b"] is n["a"]:
+                # the convolution's input IS the previous ReLU's output: the data gradient is masked by it as it is written
+                cmd = nnc.Cmd(); nnc.C.memmove(nnc.C.byref(cmd), nnc.C.byref(n["bcmd"]), nnc.C.sizeof(cmd))
+                cmd.algorithm = nnc.CONV_ALGO_FUSE_RELU | (0xff if n["bcmd"].algorithm < 0 else n["bcmd"].algorithm)
+                masked.add(id(n["a"]))
+            self._exec(cmd, n["hint"], 0, [gb, n["a"], n["w"]], [h, n["dw"], n["dbias"]], stream, "%s_bwd/%d" % (n["kind"], i), hook)
             if after_node is not None:
                 after_node(i)
 

@@ -418,6 +418,12 @@ void nnc_mi355x_debug_force_tile(int wm, int wn);
  * ccv_nnc_cmd_autotune never produces such a value.  The symmetric change a maintainer would make in the host: a
  * (CONVOLUTION_FORWARD, RELU_FORWARD) entry in ccv_nnc_ops_fusions[] (lib/nnc/ccv_nnc_symbolic_graph_simplify.c:595-). */
 #define NNC_MI355X_CONV_ALGO_FUSE_RELU 0x100
+/* The same on the way back, for callers that know the gradient a command writes goes through a RELU_BACKWARD (in place) next and that
+ * the command's input a IS that ReLU's output (the reference's VGG-D graph: every convolution and pooling reads a rectified map):
+ *   MAX_POOL_BACKWARD (g, a, b) -> h with cmd.algorithm = NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD: h = (a == b's window max && a > 0) ? g : 0,
+ *   i.e. MAX_POOL_BACKWARD followed by RELU_BACKWARD (h, -, a) -> h; the RELU_BACKWARD may then be dropped.  The kernels read a anyway
+ *   and mask as they write: no extra traffic, one pass over the map less. */
+#define NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD 0x100
 /* Test hook for the CCV_16F datapath (half_stage.cpp): how many half-precision tensors have been given an fp32 image so far
  * (staged) and how many were handed to a kernel as halves (native) since the library was loaded. */
 void nnc_mi355x_debug_half_counts(long* staged, long* native);

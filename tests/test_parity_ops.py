@@ -685,3 +685,80 @@ def test_conv_forward_with_fused_relu(backend, ref_lib, case):
     assert r == 0
     assert (got >= 0).all() and (got == 0).any()
     np.testing.assert_allclose(got, t(want), rtol=1e-4, atol=1e-5)
+
+
+POOL_RELU_BACK_CASES = [
+    # h, w, c, window, stride, fmt
+    (13, 13, 8, 3, 2, "NHWC"),   # VGG-D's overlapping windows, 16-byte lanes
+    (13, 12, 5, 3, 2, "NHWC"),   # scalar lanes
+    (12, 12, 8, 2, 2, "NHWC"),   # windows that tile the map
+    (9, 9, 4, 2, 2, "NCHW"),     # tiling, one row / column left over
+    (11, 10, 3, 3, 2, "NCHW"),
+]
+
+
+@pytest.mark.parametrize("case", POOL_RELU_BACK_CASES, ids=[str(c) for c in POOL_RELU_BACK_CASES])
+def test_max_pool_backward_with_relu_backward_folded_in(backend, ref_lib, case):
+    """cmd.algorithm = NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD: the command's result is the oracle's MAX_POOL_BACKWARD followed by the
+    oracle's RELU_BACKWARD on the pooled map (a rectified map: about half of it zeros, ties included)."""
+    h, w, c, k, s, fmt = case
+    rng = np.random.default_rng(33)
+    a = np.maximum(srnd(rng, 1, h, w, c), 0)
+    a[rng.random(a.shape) < 0.6] = 0  # sparse enough for whole windows of zeros
+    hint = nnc.HINT((s, s), (0, 0))
+    oh, ow = out_hw(h, w, k, k, hint)
+    g = srnd(rng, 1, oh, ow, c)
+    _, (b,) = exec_on(ref_lib, nnc.CPU_MEMORY, nnc.CMD_MAX_POOL_FORWARD(k, k), hint, 0, [a], [np.zeros((1, oh, ow, c), F)], backend=nnc.BACKEND_CPU_REF)
+    _, (hp,) = exec_on(ref_lib, nnc.CPU_MEMORY, nnc.CMD_MAX_POOL_BACKWARD(k, k), hint, 0, [g, a, b], [np.zeros_like(a)], backend=nnc.BACKEND_CPU_REF)
+    _, (want,) = exec_on(ref_lib, nnc.CPU_MEMORY, nnc.CMD_RELU_BACKWARD(), nnc.NO_HINT, 0, [hp, None, a], [np.zeros_like(a)], backend=nnc.BACKEND_CPU_REF)
+    assert (want != hp).any()  # the mask matters: windows whose maximum is 0 route gradient to zeros
+    cmd = nnc.CMD_MAX_POOL_BACKWARD(k, k)
+    cmd.algorithm = nnc.POOL_ALGO_FUSE_RELU_BACKWARD
+    t = (lambda x: np.ascontiguousarray(x.transpose(0, 3, 1, 2))) if fmt == "NCHW" else (lambda x: x)
+    r, (got,) = exec_on(backend, nnc.GPU_MEMORY, cmd, hint, 0, [t(g), t(a), t(b)], [t(np.full_like(a, 5))], fmt)
+    assert r == 0
+    assert np.array_equal(got, t(want))
+
+
+CONV_RELU_BACK_CASES = [
+    # n, h, w, c, k, border, algorithm, fmt
+    (2, 13, 14, 32, 16, 1, 2, "NHWC"),     # fused Winograd data gradient: mask bits packed in the epilogue's order, 2 k-blocks... of c
+    (3, 18, 21, 64, 16, 1, 2, "NHWC"),     # several tile groups per image, ragged edges, 2 channel blocks of the gradient
+    (2, 13, 14, 16, 24, 1, 1, "NHWC"),     # Winograd via HBM: the output transform reads the map
+    (2, 13, 14, 16, 24, 1, 0, "NHWC"),     # implicit GEMM: one more pass
+    (2, 13, 14, 16, 24, 1, 0xff, "NHWC"),
+    (2, 12, 12, 8, 8, 0, 0xff, "NHWC"),
+    (2, 9, 9, 8, 8, 1, 0xff, "NCHW"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_RELU_BACK_CASES, ids=[str(c) for c in CONV_RELU_BACK_CASES])
+def test_conv_backward_with_relu_backward_folded_in(backend, ref_lib, case):
+    """NNC_MI355X_CONV_ALGO_FUSE_RELU on CONVOLUTION_BACKWARD: h is the oracle's data gradient followed by the oracle's RELU_BACKWARD
+    on the forward input a (a rectified map); dw and dbias are the plain ones."""
+    n, h, w, c, k, border, algo, fmt = case
+    rng = np.random.default_rng(41)
+    a = np.maximum(srnd(rng, n, h, w, c), 0)
+    wt, hint = srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c)), nnc.HINT((1, 1), (border, border))
+    oh, ow = out_hw(h, w, 3, 3, hint)
+    g = srnd(rng, n, oh, ow, k)
+    cmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+    _, plain = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, F)], backend=nnc.BACKEND_CPU_REF)
+    _, (want_h,) = exec_on(ref_lib, nnc.CPU_MEMORY, nnc.CMD_RELU_BACKWARD(), nnc.NO_HINT, 0, [plain[0], None, a], [np.zeros_like(a)], backend=nnc.BACKEND_CPU_REF)
+    assert (want_h != plain[0]).any()
+    fused = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+    fused.algorithm = nnc.CONV_ALGO_FUSE_RELU | algo
+    t = (lambda x: np.ascontiguousarray(x.transpose(0, 3, 1, 2))) if fmt == "NCHW" else (lambda x: x)
+    r, got = exec_on(backend, nnc.GPU_MEMORY, fused, hint, 0, [t(g), t(a), t(wt)], [t(np.full_like(a, 3)), t(np.zeros_like(wt)), np.zeros(k, F)], fmt)
+    assert r == 0
+    if algo in (1, 2) and hasattr(backend.dll, "nnc_mi355x_last_kernel_name"):
+        assert backend.dll.nnc_mi355x_last_kernel_name().decode() == ("conv_dgrad_wino_fused" if algo == 2 else "conv_dgrad_wino")
+    tol = lambda ref: dict(rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+    np.testing.assert_allclose(got[0], t(want_h), **tol(want_h))
+    assert np.array_equal(got[0] == 0, t(want_h) == 0) or np.abs(got[0][(got[0] == 0) != (t(want_h) == 0)]).max() < 1e-6
+    np.testing.assert_allclose(got[1], t(plain[1]), **tol(plain[1]))
+    np.testing.assert_allclose(got[2], plain[2], **tol(plain[2]))
+    # without a data gradient asked for the bit means nothing
+    r, got = exec_on(backend, nnc.GPU_MEMORY, fused, hint, 0, [t(g), t(a), t(wt)], [None, t(np.zeros_like(wt)), np.zeros(k, F)], fmt)
+    assert r == 0
+    np.testing.assert_allclose(got[1], t(plain[1]), **tol(plain[1]))
