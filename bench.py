@@ -329,9 +329,11 @@ def main():
             for name, fl, _by, ms, dims in recs:
                 f.write("%-12s M=%-8d N=%-6d K=%-8d Z=%d S=%-3d %9.3f ms %7.2f TFLOP/s  %s\n" % (name.split("|")[0], dims[0], dims[1], dims[2], dims[3], dims[4], ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, name.split("|")[-1][-60:]))
     # per KERNEL (the symbol behind '|'): the fused Winograd kernel serves forward and the data gradient under two command names
+    # (and, with ReLU folded in, two instantiations of one source: the data gradient's epilogue-mask variant <.., 0, true> is filed with
+    # its plain sibling -- same kernel, one more epilogue option, like the forward's max(0, .))
     by = {}
     for name, fl, _by, ms, dims in recs:
-        k = by.setdefault(name.split("|", 1)[-1], [0.0, 0.0, 0])
+        k = by.setdefault(name.split("|", 1)[-1].replace(", 0, true>", ">"), [0.0, 0.0, 0])
         k[0] += fl
         k[1] += ms
         k[2] += 1

@@ -248,10 +248,14 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	a.mask_bits = bits;
 	note_kernel(name);
 	char prof_name[96];
-	snprintf(prof_name, sizeof(prof_name), "%s|nnc::wino_fused_kernel<%d, %d>", name, p.GH, p.GW);
+	snprintf(prof_name, sizeof(prof_name), bits ? "%s|nnc::wino_fused_kernel<%d, %d, 0, true>" : "%s|nnc::wino_fused_kernel<%d, %d>", name, p.GH, p.GW);
 	const long T = (long)src.n * ((dst.h + 3) / 4) * ((dst.w + 3) / 4);
 	ProfScope prof(prof_name, 2.0 * 36.0 * (double)T * Kout * Cred, 0, (int)T, Kout, Cred, 36, 1, stream);
-	if (p.GH == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4>), dim3(grid), dim3(256), 0, stream, a);
+	if (bits) {
+		if (p.GH == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4, 0, true>), dim3(grid), dim3(256), 0, stream, a);
+		else if (p.GH == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<2, 8, 0, true>), dim3(grid), dim3(256), 0, stream, a);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<8, 2, 0, true>), dim3(grid), dim3(256), 0, stream, a);
+	} else if (p.GH == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4>), dim3(grid), dim3(256), 0, stream, a);
 	else if (p.GH == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<2, 8>), dim3(grid), dim3(256), 0, stream, a);
 	else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<8, 2>), dim3(grid), dim3(256), 0, stream, a);
 	HIP_ENFORCE(hipGetLastError());

@@ -253,7 +253,9 @@ __device__ __forceinline__ void wf_bt_op(const f2& x0, const f2& x1, const f2& x
 // item already fetch and transform the first chunks of the next one, so only the very first item of a workgroup pays the DMA
 // latency, the launch and the initial transform (measured before: 8-16 us per workgroup against 15 us of MFMAs for a
 // 64-channel item).  Between two items sits the epilogue alone.
-template <int GH, int GW, int DBG = 0>
+// MASK: the variant whose epilogue applies WinoFusedArgs::mask_bits (its own instantiation: the five registers it holds across the
+// epilogue would otherwise spill in the plain kernel too).
+template <int GH, int GW, int DBG = 0, bool MASK = false>
 __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs a)
 {
 	typedef WfGeom<GH, GW> G;
@@ -497,7 +499,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		// mask bits of the item's four rounds: four 4-byte loads per lane, issued here (nothing stored yet: they come back during round 0's
 		// transforms; the wait before the first store covers them)
 		unsigned mb[4] = { ~0u, ~0u, ~0u, ~0u };
-		if (a.mask_bits) {
+		if constexpr (MASK) {
 			const unsigned* const mp = a.mask_bits + ((((long)it.n * a.GYn + it.gy) * a.GXn + it.gx) * a.KB + it.kb) * 256 + lane;
 #pragma unroll
 			for (int r = 0; r < 4; r++) mb[r] = it.live ? mp[r * 64] : 0u;
@@ -537,7 +539,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 				const unsigned voff = (kok & (oy < a.OH) & (ox < a.OW)) ? (unsigned)(oy * dh4 + ox * dw4 + kq * 4) : WF_OOB;
 				float o0 = v.x + bv[0], o1 = v.y + bv[1], o2 = v.z + bv[2], o3 = v.w + bv[3];
 				if (a.relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
-				if (a.mask_bits) {
+				if constexpr (MASK) {
 					const unsigned m = mb[r] >> (4 * e);
 					o0 = (m & 1) ? o0 : 0.f; o1 = (m & 2) ? o1 : 0.f; o2 = (m & 4) ? o2 : 0.f; o3 = (m & 8) ? o3 : 0.f;
 				}
