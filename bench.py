@@ -84,7 +84,7 @@ def via_host(args, losses, params):
     if not os.path.exists(exe):
         return {"status": "oracle/_ref/host_vgg_bench.gpu not built"}
     try:
-        r = subprocess.run([exe, str(args.batch), "225", str(min(args.steps, 6)), "2"], capture_output=True, text=True, timeout=900)
+        r = subprocess.run([exe, str(args.batch), "225", str(min(args.steps, 6)), "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, NNC_MI355X_PEEPHOLE_STATS="1"))
         if r.returncode != 0:
             return {"status": "failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
         h = json.loads(r.stdout.strip().splitlines()[-1])
@@ -94,7 +94,10 @@ def via_host(args, losses, params):
     loss_err = float(np.max(np.abs(hl - losses[:len(hl)]) / np.maximum(np.abs(losses[:len(hl)]), 1e-30)))
     perr = max(abs(a - b[0]) / max(abs(b[0]), 1e-3 * b[1] ** 0.5, 1e-30) for a, b in zip(h["updated_param_sum"], params))
     qerr = max(abs(a - b[1]) / max(b[1], 1e-30) for a, b in zip(h["updated_param_sumsq"], params))
+    import re
+    m = re.search(r"look-ahead: (\d+) commands recorded, (\d+) completed by their ReLU, (\d+) launched as they were", r.stderr)
     return {"images_per_s": h["images_per_s"], "ms_per_step": h["ms_per_step"], "autotune_ms": h["autotune_ms"],
+            "relu_look_ahead": {"recorded": int(m.group(1)), "folded": int(m.group(2)), "launched_plain": int(m.group(3))} if m else None,
             "step1_max_rel_err_vs_command_driver": {"loss": loss_err, "updated_param_sum": perr, "updated_param_sumsq": qerr},
             "equal": bool(loss_err <= 1e-4 and qerr <= 1e-4), "driver": h["driver"]}
 
@@ -169,6 +172,7 @@ def main():
     ap.add_argument("--config", default="vggd-train-bs256", choices=["vggd-train-bs256", "vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512", "cifar10-dawn-f32-bs512"],
                     help="BASELINE.json configs: 3 (default, the metric), 2 (VGG-D forward only, batch 64), 4 (ResNet-50 v1d NCHW through the reference host; -f16 = the trainer's own precision), 5 (CIFAR-10 DawnNet fp16, batch 512, through the reference host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-leg", action="store_true", help="skip the second timed leg with the other ReLU setting (profiling runs: one kind of step in the trace)")
     ap.add_argument("--no-fuse-relu", action="store_true", help="issue RELU_FORWARD as its own command behind every convolution (the reference host's graph does) instead of letting the convolution's epilogue rectify (NNC_MI355X_CONV_ALGO_FUSE_RELU); the other setting is always timed beside the headline one")
     ap.add_argument("--no-via-host", action="store_true", help="skip the second driver: the same step through the reference host's symbolic graph / autotune / static schedule (tools/host_vgg_bench.c)")
     ap.add_argument("--records", default=None, help="also write the per-launch contraction records (name, dims, ms, TFLOP/s) of the roofline leg to this file")
@@ -297,17 +301,19 @@ def main():
     loss = float(net.loss.numpy().mean())
 
     # the same K steps with the other ReLU setting (results are bit-identical: tests/test_vgg_step.py), reported beside the headline
-    net.fuse_relu = not net.fuse_relu
-    step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    dt_alt = None
+    if not args.no_alt_leg:
+        net.fuse_relu = not net.fuse_relu
         step()
-    barrier()
-    dt_alt = time.perf_counter() - t0
-    if dist:
-        dt_alt = dist.reduce_max(dt_alt)
-    net.fuse_relu = not net.fuse_relu
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_alt = time.perf_counter() - t0
+        if dist:
+            dt_alt = dist.reduce_max(dt_alt)
+        net.fuse_relu = not net.fuse_relu
 
     # roofline leg: three more steps with every contraction launch bracketed by HIP events on its stream; per launch position
     # the MEDIAN of the three (one stalled launch -- an allocator call, a clock dip -- would otherwise skew a kernel's average)
@@ -353,8 +359,9 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "gflop_per_image": (ff if fwd_only else fb) / 1e9, "whole_step_tflops_per_gpu": value / world * (ff if fwd_only else fb) / 1e12, "final_loss": loss,
                        "conv_relu": "convolution epilogue (NNC_MI355X_CONV_ALGO_FUSE_RELU)" if net.fuse_relu else "separate RELU_FORWARD commands"},
-            "relu_as_separate_commands" if net.fuse_relu else "relu_in_conv_epilogue": {"value": world * args.batch * args.steps / dt_alt, "unit": "images/s", "ms_per_step": 1e3 * dt_alt / args.steps},
         }
+        if dt_alt:
+            out["relu_as_separate_commands" if net.fuse_relu else "relu_folded_in"] = {"value": world * args.batch * args.steps / dt_alt, "unit": "images/s", "ms_per_step": 1e3 * dt_alt / args.steps}
         if dom:
             name, (fl, ms, cnt) = dom
             traffic = pmc_traffic(name, args.batch)

@@ -1170,7 +1170,18 @@ static int conv_forw_dispatch(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint
 	}
 	return half_staged_exec(_conv_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 }
+static int conv_forw_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
+// The registered entry: a convolution whose like has run before is recorded, not launched -- the in-place RELU_FORWARD the reference's
+// graphs issue next folds into it (peephole.cpp); anything else on the stream launches it as it is.
 static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	uint64_t sig;
+	if (deferred_try(_conv_forw_any, DEFER_CONV_FORWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;
+	const int r = conv_forw_entry(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);
+	return r;
+}
+static int conv_forw_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	MarkerScope marker(cmd.cmd);
 	// Opt-in fusion (a caller that knows the convolution's only consumer is a RELU_FORWARD): algorithm = FUSE_RELU | (0..2, or 0xff
@@ -1189,7 +1200,16 @@ static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 static int conv_back_dispatch(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
 // NNC_MI355X_CONV_ALGO_FUSE_RELU on the backward command: h = a > 0 ? (data gradient) : 0 -- the RELU_BACKWARD of the map a that would
 // run on h next.  Masked where the data gradient is written by the Winograd kernels; one in-place pass behind the others.
+static int conv_back_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
 static int _conv_back_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	uint64_t sig; // (recorded like the forward: the RELU_BACKWARD of the map this command read may follow on the gradient it writes)
+	if (deferred_try(_conv_back_any, DEFER_CONV_BACKWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;
+	const int r = conv_back_entry(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);
+	return r;
+}
+static int conv_back_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	MarkerScope marker(cmd.cmd);
 	if (cmd.algorithm < 0 || !(cmd.algorithm & NNC_MI355X_CONV_ALGO_FUSE_RELU)) return conv_back_dispatch(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);

@@ -211,6 +211,8 @@ static int _relu_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	ccv_nnc_tensor_t* b = outputs[0];
 	if (!tensor_contiguous(a) || !tensor_contiguous(b) || tensor_count(a->info) != tensor_count(b->info)) return CCV_NNC_EXEC_INVALID;
 	if (a->info.datatype != b->info.datatype) return CCV_NNC_EXEC_INVALID;
+	const int folded = deferred_fuse_relu_forw(a, b, stream_context); // in place behind a recorded convolution: that one rectifies as it stores (peephole.cpp)
+	if (folded >= 0) return folded;
 	return ew_map_any<OpRelu, 1>(OpRelu(), a->info.datatype, b->data.u8, a->data.u8, 0, 0, tensor_count(a->info), stream_context);
 }
 
@@ -225,6 +227,8 @@ static int _relu_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	const size_t n = tensor_count(b->info);
 	if (tensor_count(h->info) != n || (g && tensor_count(g->info) != n)) return CCV_NNC_EXEC_INVALID;
 	if (b->info.datatype != h->info.datatype || (g && g->info.datatype != h->info.datatype)) return CCV_NNC_EXEC_INVALID;
+	const int folded = deferred_fuse_relu_back(g, b, h, stream_context); // in place on the gradient a recorded command is about to write, masked by the map it read
+	if (folded >= 0) return folded;
 	if (!g) return ew_map_any<OpReluBackOnes, 1>(OpReluBackOnes(), h->info.datatype, h->data.u8, b->data.u8, 0, 0, n, stream_context);
 	return ew_map_any<OpReluBack, 2>(OpReluBack(), h->info.datatype, h->data.u8, g->data.u8, b->data.u8, 0, n, stream_context);
 }

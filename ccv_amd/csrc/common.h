@@ -103,7 +103,16 @@ static inline bool image4(const ccv_nnc_tensor_t* t, Image4* o)
 extern volatile int g_comm_pending;
 void comm_flush(void);
 void comm_release_context(const void* ctx);
-static inline void comm_flush_if_pending(void) { if (g_comm_pending) comm_flush(); }
+// Recorded-but-not-yet-launched commands waiting for the ReLU that may follow them (peephole.cpp): the same points flush them.
+typedef int (*exec_fn_t)(const ccv_nnc_cmd_t, const ccv_nnc_hint_t, const int, ccv_nnc_tensor_t* const*, const int, ccv_nnc_tensor_t* const*, const int, ccv_nnc_stream_context_t*);
+enum { DEFER_CONV_FORWARD = 1, DEFER_CONV_BACKWARD = 2, DEFER_POOL_BACKWARD = 3 };
+extern volatile int g_deferred_live;
+bool deferred_try(exec_fn_t fn, int kind, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, int flags, ccv_nnc_tensor_t* const* inputs, int input_size, ccv_nnc_tensor_t* const* outputs, int output_size, ccv_nnc_stream_context_t* ctx, uint64_t* sig); // true: recorded, report success
+void deferred_mark_good(uint64_t sig); // this signature ran successfully on the spot: the next one like it may be recorded
+int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx); // -1: no recorded command this ReLU completes
+int deferred_fuse_relu_back(const ccv_nnc_tensor_t* g, const ccv_nnc_tensor_t* b, ccv_nnc_tensor_t* h, ccv_nnc_stream_context_t* ctx);
+void deferred_flush(const ccv_nnc_stream_context_t* ctx); // 0: every stream's
+static inline void comm_flush_if_pending(void) { if (g_comm_pending) comm_flush(); if (g_deferred_live) deferred_flush(0); }
 
 // The HIP stream a command must enqueue on, and that stream's scratch memory.
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx);

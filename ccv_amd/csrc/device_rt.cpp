@@ -120,7 +120,8 @@ namespace nnc {
 
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
 {
-	comm_flush_if_pending(); // a launch is about to be ordered on a stream: recorded collectives go first (cmd_comm.cpp)
+	if (g_comm_pending) comm_flush(); // a launch is about to be ordered on a stream: recorded collectives go first (cmd_comm.cpp)
+	if (g_deferred_live) deferred_flush(ctx); // ... and so does this stream's recorded command (peephole.cpp)
 	if (!ctx) return (hipStream_t)0;
 	if (CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU) return (hipStream_t)0;
 	return bind(ctx)->stream;
@@ -378,6 +379,7 @@ ccv_nnc_stream_context_t* ccv_nnc_init_stream_context(ccv_nnc_stream_context_t* 
 static void local_release(device_local_t* l)
 {
 	if (!l->stream && !l->workspace && !l->staging) return;
+	nnc::comm_flush_if_pending();
 	const int prev = current_device();
 	HIP_ENFORCE(hipSetDevice(l->device));
 	if (l->stream) HIP_ENFORCE(hipStreamSynchronize(l->stream));

@@ -1,0 +1,235 @@
+// ReLU folded into its neighbour WITHOUT the caller's help: a one-command look-ahead per stream.
+//
+// The reference's graphs issue CONVOLUTION_FORWARD followed by an in-place RELU_FORWARD on its output
+// (test/int/nnc/graph.vgg.d.tests.c:14-90, bin/nnc/cifar-10.c:76-127 through ccv_cnnp's convolution + relu blocks), and on the way
+// back MAX_POOL_BACKWARD / CONVOLUTION_BACKWARD followed by an in-place RELU_BACKWARD on the gradient they wrote, masked by the map
+// they read.  The host has no fusion for these pairs (ccv_nnc_ops_fusions[] in lib/nnc/ccv_nnc_symbolic_graph_simplify.c:595- holds
+// softmax + crossentropy only), so each pair costs one more pass over the largest tensors of the step: 12.8 of VGG-D's 98.9 ms.
+//
+// What this does: such a command is not launched when it arrives but recorded (one slot per stream context).  If the NEXT command on
+// that stream is the matching ReLU, the recorded command runs with the opt-in bit (NNC_MI355X_CONV_ALGO_FUSE_RELU /
+// NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD, include/nnc_mi355x.h) and the ReLU is done; anything else -- another command on the
+// stream, a signal, a wait, a copy, a free, a callback: every point that could observe the stream's order, the same hooks the
+// recorded collectives use (cmd_comm.cpp) -- launches it as it was first.  Results are the same either way: max(0, .) and the
+// a > 0 mask are exact.
+//
+// Only commands whose exact signature (parameters, hint, flags, every tensor's type / format / shape / strides) has already run
+// successfully on the spot are recorded, so a recorded command cannot fail on a parameter check later; if it fails at launch all the
+// same (out of memory) the process stops with a message rather than having reported success for work that did not happen.
+// NNC_MI355X_PEEPHOLE=0 in the environment (or nnc_mi355x_set_peephole(0)) turns the look-ahead off.
+#include "common.h"
+#include <mutex>
+#include <unordered_set>
+#include <cstdlib>
+#include <cstring>
+
+namespace nnc {
+
+volatile int g_deferred_live = 0;
+
+namespace {
+
+struct Slot {
+	int live;
+	exec_fn_t fn;
+	int kind;
+	ccv_nnc_cmd_t cmd;
+	ccv_nnc_hint_t hint;
+	int flags;
+	ccv_nnc_tensor_view_t in[3], out[3];
+	int has_in[3], has_out[3];
+	int nin, nout;
+	ccv_nnc_stream_context_t* ctx;
+	int device;
+};
+constexpr int SLOTS = 16;
+Slot g_slots[SLOTS];
+std::recursive_mutex g_mu;
+std::unordered_set<uint64_t> g_good;
+int g_enabled = -1;
+long g_recorded = 0, g_folded = 0, g_plain = 0; // nnc_mi355x_debug_peephole_counts
+thread_local int tl_running = 0; // inside a recorded command's launch: its own stream_of / nested commands must not touch the slots
+
+struct StatsAtExit { // NNC_MI355X_PEEPHOLE_STATS=1: one line at unload -- how many pairs of a run actually folded
+	~StatsAtExit()
+	{
+		const char* v = getenv("NNC_MI355X_PEEPHOLE_STATS");
+		if (v && *v == '1') fprintf(stderr, "[nnc_mi355x] look-ahead: %ld commands recorded, %ld completed by their ReLU, %ld launched as they were\n", g_recorded, g_folded, g_plain);
+	}
+} g_stats_at_exit;
+
+bool enabled()
+{
+	if (g_enabled < 0) {
+		const char* v = getenv("NNC_MI355X_PEEPHOLE");
+		g_enabled = (v && *v == '0') ? 0 : 1;
+	}
+	return g_enabled == 1;
+}
+
+void mix(uint64_t& h, const void* p, size_t n)
+{
+	const unsigned char* b = (const unsigned char*)p;
+	for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
+}
+void mix_tensor(uint64_t& h, const ccv_nnc_tensor_t* t)
+{
+	const int none = -1;
+	if (!t) { mix(h, &none, sizeof(none)); return; }
+	mix(h, &t->type, sizeof(t->type));
+	mix(h, &t->info, sizeof(t->info));
+	if (CCV_IS_TENSOR_VIEW(t)) {
+		const ccv_nnc_tensor_view_t* v = (const ccv_nnc_tensor_view_t*)t;
+		mix(h, &v->contiguous, sizeof(v->contiguous));
+		mix(h, v->stride, sizeof(v->stride));
+	}
+	const uintptr_t align = (uintptr_t)t->data.u8 & 15; // kernels choose 16-byte paths by alignment
+	mix(h, &align, sizeof(align));
+}
+uint64_t signature(const int kind, const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_t& hint, const int flags, ccv_nnc_tensor_t* const* inputs, const int nin, ccv_nnc_tensor_t* const* outputs, const int nout)
+{
+	uint64_t h = 0xcbf29ce484222325ULL;
+	mix(h, &kind, sizeof(kind));
+	mix(h, &cmd.cmd, sizeof(cmd.cmd));
+	mix(h, &cmd.backend, sizeof(cmd.backend));
+	mix(h, &cmd.algorithm, sizeof(cmd.algorithm));
+	mix(h, &cmd.info, sizeof(cmd.info));
+	mix(h, &hint, sizeof(hint));
+	mix(h, &flags, sizeof(flags));
+	mix(h, &nin, sizeof(nin));
+	mix(h, &nout, sizeof(nout));
+	for (int i = 0; i < nin; i++) mix_tensor(h, inputs[i]);
+	for (int i = 0; i < nout; i++) mix_tensor(h, outputs[i]);
+	return h;
+}
+
+void keep(ccv_nnc_tensor_view_t* dst, int* has, const ccv_nnc_tensor_t* t)
+{
+	*has = t ? 1 : 0;
+	if (!t) return;
+	memset(dst, 0, sizeof(*dst));
+	memcpy(dst, t, CCV_IS_TENSOR_VIEW(t) ? sizeof(ccv_nnc_tensor_view_t) : sizeof(ccv_nnc_tensor_t));
+}
+
+// launch a recorded command (relu_bit: with the ReLU folded in); the slot is released first: the launch's own hooks find nothing
+int run(Slot& s, const int relu_bit)
+{
+	Slot c = s;
+	s.live = 0;
+	--g_deferred_live;
+	ccv_nnc_tensor_t* in[3];
+	ccv_nnc_tensor_t* out[3];
+	for (int i = 0; i < c.nin; i++) in[i] = c.has_in[i] ? (ccv_nnc_tensor_t*)&c.in[i] : 0;
+	for (int i = 0; i < c.nout; i++) out[i] = c.has_out[i] ? (ccv_nnc_tensor_t*)&c.out[i] : 0;
+	if (relu_bit) ++g_folded; else ++g_plain;
+	if (relu_bit) c.cmd.algorithm = relu_bit | (c.cmd.algorithm < 0 ? 0xff : (c.cmd.algorithm & 0xff));
+	int prev = 0;
+	HIP_ENFORCE(hipGetDevice(&prev));
+	if (prev != c.device) HIP_ENFORCE(hipSetDevice(c.device));
+	++tl_running;
+	const int r = c.fn(c.cmd, c.hint, c.flags, in, c.nin, out, c.nout, c.ctx);
+	--tl_running;
+	if (prev != c.device) HIP_ENFORCE(hipSetDevice(prev));
+	if (r != CCV_NNC_EXEC_SUCCESS) {
+		fprintf(stderr, "[nnc_mi355x] a recorded command (0x%x) failed at launch with %d after its caller was told it had been enqueued\n", c.cmd.cmd, r);
+		abort();
+	}
+	return r;
+}
+
+Slot* slot_of(const ccv_nnc_stream_context_t* ctx, const int device)
+{
+	for (int i = 0; i < SLOTS; i++)
+		if (g_slots[i].live && g_slots[i].ctx == ctx && g_slots[i].device == device) return &g_slots[i];
+	return 0;
+}
+
+bool same_buffer(const ccv_nnc_tensor_view_t& kept, const ccv_nnc_tensor_t* t)
+{
+	// the ReLU runs over dense tensors (cmd_ew.cpp) in place: same memory, same element count and type as what the recorded command wrote / read
+	return t && t->data.u8 == kept.data.u8 && t->info.datatype == kept.info.datatype && tensor_count(t->info) == tensor_count(kept.info) && tensor_contiguous(t) && tensor_contiguous((const ccv_nnc_tensor_t*)&kept);
+}
+
+} // namespace
+
+bool deferred_try(exec_fn_t fn, const int kind, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx, uint64_t* const sig)
+{
+	*sig = 0;
+	if (tl_running || !enabled() || input_size > 3 || output_size > 3 || output_size < 1 || !outputs[0] || (flags & CCV_NNC_ACCUMULATE_OUTPUT)) return false;
+	if (cmd.algorithm > 0 && (cmd.algorithm & ~0xff)) return false; // the caller set the bit itself
+	if (CCV_TENSOR_GET_MEMORY(outputs[0]->info.type) != CCV_TENSOR_GPU_MEMORY) return false;
+	const uint64_t h = signature(kind, cmd, hint, flags, inputs, input_size, outputs, output_size);
+	*sig = h;
+	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	if (!g_good.count(h)) return false; // first time: run on the spot, deferred_mark_good() files it when it succeeds
+	int device = 0;
+	HIP_ENFORCE(hipGetDevice(&device));
+	if (Slot* const old = slot_of(ctx, device)) run(*old, 0); // two recordable commands in a row: the first goes as it is
+	Slot* s = 0;
+	for (int i = 0; i < SLOTS && !s; i++)
+		if (!g_slots[i].live) s = &g_slots[i];
+	if (!s) return false;
+	s->fn = fn; s->kind = kind; s->cmd = cmd; s->hint = hint; s->flags = flags; s->ctx = ctx; s->device = device;
+	s->nin = input_size; s->nout = output_size;
+	for (int i = 0; i < input_size; i++) keep(&s->in[i], &s->has_in[i], inputs[i]);
+	for (int i = 0; i < output_size; i++) keep(&s->out[i], &s->has_out[i], outputs[i]);
+	s->live = 1;
+	++g_deferred_live;
+	++g_recorded;
+	return true;
+}
+
+void deferred_mark_good(const uint64_t sig)
+{
+	if (!sig) return;
+	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	if (g_good.size() < 65536) g_good.insert(sig);
+}
+
+int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* const a, ccv_nnc_tensor_t* const b, ccv_nnc_stream_context_t* const ctx)
+{
+	if (!g_deferred_live || tl_running) return -1;
+	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	int device = 0;
+	HIP_ENFORCE(hipGetDevice(&device));
+	Slot* const s = slot_of(ctx, device);
+	if (!s || s->kind != DEFER_CONV_FORWARD || !s->has_out[0] || a->data.u8 != b->data.u8 || !same_buffer(s->out[0], b) || !same_buffer(s->out[0], a)) return -1;
+	return run(*s, NNC_MI355X_CONV_ALGO_FUSE_RELU);
+}
+
+int deferred_fuse_relu_back(const ccv_nnc_tensor_t* const g, const ccv_nnc_tensor_t* const b, ccv_nnc_tensor_t* const h, ccv_nnc_stream_context_t* const ctx)
+{
+	if (!g_deferred_live || tl_running || !g) return -1;
+	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	int device = 0;
+	HIP_ENFORCE(hipGetDevice(&device));
+	Slot* const s = slot_of(ctx, device);
+	if (!s || (s->kind != DEFER_CONV_BACKWARD && s->kind != DEFER_POOL_BACKWARD) || !s->has_out[0] || s->nin < 2 || !s->has_in[1]) return -1;
+	// RELU_BACKWARD (g, -, b) -> h in place on the gradient the recorded command writes, b the map the recorded command read as its input a
+	if (g->data.u8 != h->data.u8 || !same_buffer(s->out[0], h) || !same_buffer(s->in[1], b) || s->in[1].info.format != s->out[0].info.format) return -1;
+	return run(*s, s->kind == DEFER_CONV_BACKWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD);
+}
+
+void deferred_flush(const ccv_nnc_stream_context_t* const ctx)
+{
+	if (tl_running) return;
+	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	for (int i = 0; i < SLOTS; i++)
+		if (g_slots[i].live && (!ctx || !g_slots[i].ctx || g_slots[i].ctx == ctx)) run(g_slots[i], 0); // (the default stream orders against every other: no context = all)
+}
+
+} // namespace nnc
+
+extern "C" void nnc_mi355x_set_peephole(const int on)
+{
+	nnc::deferred_flush(0);
+	nnc::g_enabled = on ? 1 : 0;
+}
+
+extern "C" void nnc_mi355x_debug_peephole_counts(long* const recorded, long* const folded, long* const plain)
+{
+	std::lock_guard<std::recursive_mutex> lock(nnc::g_mu);
+	if (recorded) *recorded = nnc::g_recorded;
+	if (folded) *folded = nnc::g_folded;
+	if (plain) *plain = nnc::g_plain;
+}

