@@ -29,6 +29,7 @@ volatile int g_deferred_live = 0;
 
 namespace {
 
+constexpr int MAX_IO = 6;
 struct Slot {
 	int live;
 	exec_fn_t fn;
@@ -36,8 +37,8 @@ struct Slot {
 	ccv_nnc_cmd_t cmd;
 	ccv_nnc_hint_t hint;
 	int flags;
-	ccv_nnc_tensor_view_t in[3], out[3];
-	int has_in[3], has_out[3];
+	ccv_nnc_tensor_view_t in[MAX_IO], out[MAX_IO]; // (the host hands a backward command the forward's inputs and outputs too: up to 5 + 3)
+	int has_in[MAX_IO], has_out[MAX_IO];
 	int nin, nout;
 	ccv_nnc_stream_context_t* ctx;
 	int device;
@@ -117,8 +118,8 @@ int run(Slot& s, const int relu_bit)
 	Slot c = s;
 	s.live = 0;
 	--g_deferred_live;
-	ccv_nnc_tensor_t* in[3];
-	ccv_nnc_tensor_t* out[3];
+	ccv_nnc_tensor_t* in[MAX_IO];
+	ccv_nnc_tensor_t* out[MAX_IO];
 	for (int i = 0; i < c.nin; i++) in[i] = c.has_in[i] ? (ccv_nnc_tensor_t*)&c.in[i] : 0;
 	for (int i = 0; i < c.nout; i++) out[i] = c.has_out[i] ? (ccv_nnc_tensor_t*)&c.out[i] : 0;
 	if (relu_bit) ++g_folded; else ++g_plain;
@@ -155,7 +156,7 @@ bool same_buffer(const ccv_nnc_tensor_view_t& kept, const ccv_nnc_tensor_t* t)
 bool deferred_try(exec_fn_t fn, const int kind, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx, uint64_t* const sig)
 {
 	*sig = 0;
-	if (tl_running || !enabled() || input_size > 3 || output_size > 3 || output_size < 1 || !outputs[0] || (flags & CCV_NNC_ACCUMULATE_OUTPUT)) return false;
+	if (tl_running || !enabled() || input_size > MAX_IO || output_size > MAX_IO || output_size < 1 || !outputs[0] || (flags & CCV_NNC_ACCUMULATE_OUTPUT)) return false;
 	if (cmd.algorithm > 0 && (cmd.algorithm & ~0xff)) return false; // the caller set the bit itself
 	if (CCV_TENSOR_GET_MEMORY(outputs[0]->info.type) != CCV_TENSOR_GPU_MEMORY) return false;
 	const uint64_t h = signature(kind, cmd, hint, flags, inputs, input_size, outputs, output_size);

@@ -9,7 +9,7 @@ timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/p
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
 timeout 900 python bench.py --steps $STEPS --warmup 1 --records gpurun_out/records.txt > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench exit $?" >> gpurun_out/bench.err
 if [ -z "$NO_PROF" ]; then
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o vgg -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1; echo "prof exit $?" >> "$OLDPWD/gpurun_out/prof_bench.log")
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o vgg -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-via-host --no-alt-leg > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1; echo "prof exit $?" >> "$OLDPWD/gpurun_out/prof_bench.log")
   find gpurun_out/prof -name "*_results.db" | head -1 | while read f; do python tools/prof_summary.py "$f" > gpurun_out/kernel_stats.md; done
   find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
 fi
