@@ -300,10 +300,13 @@ def main():
         dt = dist.reduce_max(dt)
     loss = float(net.loss.numpy().mean())
 
-    # the same K steps with the other ReLU setting (results are bit-identical: tests/test_vgg_step.py), reported beside the headline
+    # the same K steps with the other ReLU setting (results are bit-identical: tests/test_vgg_step.py), reported beside the headline.
+    # The library's look-ahead (peephole.cpp) would fold the separately issued ReLUs as well -- it is what gives the reference host the
+    # same saving (via_host) -- so it is switched off for this leg: what is timed is the step with every ReLU as its own pass.
     dt_alt = None
     if not args.no_alt_leg:
         net.fuse_relu = not net.fuse_relu
+        L.dll.nnc_mi355x_set_peephole(0)
         step()
         barrier()
         t0 = time.perf_counter()
@@ -314,6 +317,7 @@ def main():
         if dist:
             dt_alt = dist.reduce_max(dt_alt)
         net.fuse_relu = not net.fuse_relu
+        L.dll.nnc_mi355x_set_peephole(1)
 
     # roofline leg: three more steps with every contraction launch bracketed by HIP events on its stream; per launch position
     # the MEDIAN of the three (one stalled launch -- an allocator call, a clock dip -- would otherwise skew a kernel's average)
@@ -361,7 +365,7 @@ def main():
                        "conv_relu": "convolution epilogue (NNC_MI355X_CONV_ALGO_FUSE_RELU)" if net.fuse_relu else "separate RELU_FORWARD commands"},
         }
         if dt_alt:
-            out["relu_as_separate_commands" if net.fuse_relu else "relu_folded_in"] = {"value": world * args.batch * args.steps / dt_alt, "unit": "images/s", "ms_per_step": 1e3 * dt_alt / args.steps}
+            out["relu_as_separate_passes" if net.fuse_relu else "relu_folded_in"] = {"value": world * args.batch * args.steps / dt_alt, "unit": "images/s", "ms_per_step": 1e3 * dt_alt / args.steps}
         if dom:
             name, (fl, ms, cnt) = dom
             traffic = pmc_traffic(name, args.batch)
