@@ -268,12 +268,13 @@ __global__ void bn_test_affine_kernel(const float* mean, const float* var, const
 }
 // y = x * nscale[c] + nbias[c]   (any layout: one element per lane; the plane kernels below are the NCHW fast path)
 template <class T>
-__global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, T* y, const float* nscale, const float* nbias, const size_t n, const int C, const long inner)
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* x, T* y, const float* nscale, const float* nbias, const size_t n, const int C, const long inner, const int relu)
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
 		const int c = (int)((inner == 1 ? i : i / inner) % C);
-		y[i] = (T)((float)x[i] * nscale[c] + nbias[c]);
+		const float r = (float)x[i] * nscale[c] + nbias[c];
+		y[i] = (T)(relu && !(r > 0.f) ? 0.f : r);
 	}
 }
 // h = (scale * inv_std / B) * (B * g - dbias - xhat * dscale)      (:440-470)
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(256) bn_back_kernel(const T* x, const T* g, T*
 // The same two maps, a wave per plane (inner > 1): the channel is one modulo per plane instead of a 64-bit division per element,
 // 16-byte accesses when the plane allows.  h = a * g + b * x + k with per-channel a, b, k.
 template <class T>
-__global__ void __launch_bounds__(256) bn_apply_planes_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ nscale, const float* __restrict__ nbias, const long planes, const int C, const long inner)
+__global__ void __launch_bounds__(256) bn_apply_planes_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ nscale, const float* __restrict__ nbias, const long planes, const int C, const long inner, const int relu)
 {
 	constexpr int W = 16 / sizeof(T);
 	typedef typename pack16<T>::type V;
@@ -308,11 +309,11 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const T* __restric
 				const V v = ((const V*)xp)[i];
 				V r;
 #pragma unroll
-				for (int e = 0; e < W; e++) r[e] = (T)((float)v[e] * w + b);
+				for (int e = 0; e < W; e++) { const float t = (float)v[e] * w + b; r[e] = (T)(relu && !(t > 0.f) ? 0.f : t); }
 				((V*)yp)[i] = r;
 			}
 		} else
-			for (long i = lane; i < inner; i += 64) yp[i] = (T)((float)xp[i] * w + b);
+			for (long i = lane; i < inner; i += 64) { const float t = (float)xp[i] * w + b; yp[i] = (T)(relu && !(t > 0.f) ? 0.f : t); }
 	}
 }
 template <class T>
@@ -397,6 +398,7 @@ static int bnorm_forw_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 	for (int i = 1; i < 5; i++) if ((int)tensor_count(inputs[i]->info) != v.C) return CCV_NNC_EXEC_INVALID;
 	const size_t n = tensor_count(x->info);
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
+	const int relu = cmd.algorithm > 0 && (cmd.algorithm & NNC_MI355X_BNORM_ALGO_FUSE_RELU) ? 1 : 0; // opt-in: y = max(0, .) as it is written (include/nnc_mi355x.h)
 	hipStream_t stream = stream_of(stream_context);
 	// (bench.py roofline leg, config 4: the whole command between two events; algorithmic bytes = x read once + y written once)
 	ProfScope prof(cmd.info.bnorm.is_test ? "bnorm_fwd_test|nnc::bn_apply_kernel" : "bnorm_fwd|nnc::chan_reduce + bn_apply_kernel", 0, 2.0 * sizeof(T) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream);
@@ -439,14 +441,24 @@ static int bnorm_forw_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 		hipLaunchKernelGGL(bn_test_affine_kernel, dim3(cb), dim3(256), 0, stream, (const float*)mean, (const float*)var, scale, bias, nscale, nbias, v.C, cmd.info.bnorm.epsilon);
 	HIP_ENFORCE(hipGetLastError());
 	if (v.inner > 1)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_planes_kernel<T>), dim3(plane_grid(v.outer * v.C)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, v.outer * v.C, v.C, v.inner);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_planes_kernel<T>), dim3(plane_grid(v.outer * v.C)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, v.outer * v.C, v.C, v.inner, relu);
 	else
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, n, v.C, v.inner);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, n, v.C, v.inner, relu);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+static int bnorm_forw_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
 static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	// recorded when its like has run before: the in-place RELU_FORWARD of the reference's conv - bn - relu blocks folds into the apply pass (peephole.cpp)
+	uint64_t sig;
+	if (deferred_try(_bnorm_forw, DEFER_BNORM_FORWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;
+	const int r = bnorm_forw_entry(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);
+	return r;
+}
+static int bnorm_forw_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	if (input_size >= 1 && inputs[0] && CCV_GET_DATA_TYPE(inputs[0]->info.datatype) == CCV_16F) return bnorm_forw_t<half_t>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	return bnorm_forw_t<float>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);

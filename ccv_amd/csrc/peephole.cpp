@@ -1,6 +1,7 @@
 // ReLU folded into its neighbour WITHOUT the caller's help: a one-command look-ahead per stream.
 //
-// The reference's graphs issue CONVOLUTION_FORWARD followed by an in-place RELU_FORWARD on its output
+// The reference's graphs issue CONVOLUTION_FORWARD (or, in the conv - bn - relu blocks of its ResNet / CIFAR-10 models, BATCH_NORM_FORWARD)
+// followed by an in-place RELU_FORWARD on its output
 // (test/int/nnc/graph.vgg.d.tests.c:14-90, bin/nnc/cifar-10.c:76-127 through ccv_cnnp's convolution + relu blocks), and on the way
 // back MAX_POOL_BACKWARD / CONVOLUTION_BACKWARD followed by an in-place RELU_BACKWARD on the gradient they wrote, masked by the map
 // they read.  The host has no fusion for these pairs (ccv_nnc_ops_fusions[] in lib/nnc/ccv_nnc_symbolic_graph_simplify.c:595- holds
@@ -130,12 +131,24 @@ int run(Slot& s, const int relu_bit)
 	++tl_running;
 	const int r = c.fn(c.cmd, c.hint, c.flags, in, c.nin, out, c.nout, c.ctx);
 	--tl_running;
-	if (prev != c.device) HIP_ENFORCE(hipSetDevice(prev));
+	int now = prev;
+	HIP_ENFORCE(hipGetDevice(&now));
+	if (now != prev) HIP_ENFORCE(hipSetDevice(prev)); // (binding a fixed-device stream sets the device: the caller's stays what it was)
 	if (r != CCV_NNC_EXEC_SUCCESS) {
 		fprintf(stderr, "[nnc_mi355x] a recorded command (0x%x) failed at launch with %d after its caller was told it had been enqueued\n", c.cmd.cmd, r);
 		abort();
 	}
 	return r;
+}
+
+// The device a command on this stream runs on: the stream's own (a fixed-device context binds it -- the host does not set the current
+// device before a command that carries a stream, device_rt.cpp bind()), or the current one (no stream / any-device contexts).
+int device_for(const ccv_nnc_stream_context_t* ctx)
+{
+	if (ctx && CCV_STREAM_GET_CONTEXT(ctx->type) == CCV_STREAM_CONTEXT_GPU) return ccv_nnc_stream_context_get_device(ctx);
+	int device = 0;
+	HIP_ENFORCE(hipGetDevice(&device));
+	return device;
 }
 
 Slot* slot_of(const ccv_nnc_stream_context_t* ctx, const int device)
@@ -158,13 +171,14 @@ bool deferred_try(exec_fn_t fn, const int kind, const ccv_nnc_cmd_t cmd, const c
 	*sig = 0;
 	if (tl_running || !enabled() || input_size > MAX_IO || output_size > MAX_IO || output_size < 1 || !outputs[0] || (flags & CCV_NNC_ACCUMULATE_OUTPUT)) return false;
 	if (cmd.algorithm > 0 && (cmd.algorithm & ~0xff)) return false; // the caller set the bit itself
+	static const int kinds = getenv("NNC_MI355X_PEEPHOLE_KINDS") ? atoi(getenv("NNC_MI355X_PEEPHOLE_KINDS")) : ~0; // debugging aid: bit k = kind k may be recorded
+	if (!(kinds & (1 << kind))) return false;
 	if (CCV_TENSOR_GET_MEMORY(outputs[0]->info.type) != CCV_TENSOR_GPU_MEMORY) return false;
 	const uint64_t h = signature(kind, cmd, hint, flags, inputs, input_size, outputs, output_size);
 	*sig = h;
 	std::lock_guard<std::recursive_mutex> lock(g_mu);
 	if (!g_good.count(h)) return false; // first time: run on the spot, deferred_mark_good() files it when it succeeds
-	int device = 0;
-	HIP_ENFORCE(hipGetDevice(&device));
+	const int device = device_for(ctx);
 	if (Slot* const old = slot_of(ctx, device)) run(*old, 0); // two recordable commands in a row: the first goes as it is
 	Slot* s = 0;
 	for (int i = 0; i < SLOTS && !s; i++)
@@ -191,19 +205,17 @@ int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* const a, ccv_nnc_tensor_t* c
 {
 	if (!g_deferred_live || tl_running) return -1;
 	std::lock_guard<std::recursive_mutex> lock(g_mu);
-	int device = 0;
-	HIP_ENFORCE(hipGetDevice(&device));
+	const int device = device_for(ctx);
 	Slot* const s = slot_of(ctx, device);
-	if (!s || s->kind != DEFER_CONV_FORWARD || !s->has_out[0] || a->data.u8 != b->data.u8 || !same_buffer(s->out[0], b) || !same_buffer(s->out[0], a)) return -1;
-	return run(*s, NNC_MI355X_CONV_ALGO_FUSE_RELU);
+	if (!s || (s->kind != DEFER_CONV_FORWARD && s->kind != DEFER_BNORM_FORWARD) || !s->has_out[0] || a->data.u8 != b->data.u8 || !same_buffer(s->out[0], b) || !same_buffer(s->out[0], a)) return -1;
+	return run(*s, s->kind == DEFER_CONV_FORWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_BNORM_ALGO_FUSE_RELU);
 }
 
 int deferred_fuse_relu_back(const ccv_nnc_tensor_t* const g, const ccv_nnc_tensor_t* const b, ccv_nnc_tensor_t* const h, ccv_nnc_stream_context_t* const ctx)
 {
 	if (!g_deferred_live || tl_running || !g) return -1;
 	std::lock_guard<std::recursive_mutex> lock(g_mu);
-	int device = 0;
-	HIP_ENFORCE(hipGetDevice(&device));
+	const int device = device_for(ctx);
 	Slot* const s = slot_of(ctx, device);
 	if (!s || (s->kind != DEFER_CONV_BACKWARD && s->kind != DEFER_POOL_BACKWARD) || !s->has_out[0] || s->nin < 2 || !s->has_in[1]) return -1;
 	// RELU_BACKWARD (g, -, b) -> h in place on the gradient the recorded command writes, b the map the recorded command read as its input a

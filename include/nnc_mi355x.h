@@ -424,6 +424,9 @@ void nnc_mi355x_debug_force_tile(int wm, int wn);
  *   i.e. MAX_POOL_BACKWARD followed by RELU_BACKWARD (h, -, a) -> h; the RELU_BACKWARD may then be dropped.  The kernels read a anyway
  *   and mask as they write: no extra traffic, one pass over the map less. */
 #define NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD 0x100
+/* BATCH_NORM_FORWARD with cmd.algorithm = NNC_MI355X_BNORM_ALGO_FUSE_RELU: y = max(0, batch norm) -- the in-place RELU_FORWARD of a
+ * conv - bn - relu block applied in the pass that writes y (statistics are of x: unchanged). */
+#define NNC_MI355X_BNORM_ALGO_FUSE_RELU 0x100
 /* Callers that do NOT set these bits get the same folding from a one-command look-ahead (ccv_amd/csrc/peephole.cpp): a
  * CONVOLUTION_FORWARD / CONVOLUTION_BACKWARD / MAX_POOL_BACKWARD whose like has run before is recorded instead of launched; the
  * in-place RELU_FORWARD / RELU_BACKWARD the reference's graphs issue next on the same stream completes it, anything else that could

@@ -107,3 +107,43 @@ def test_backward_pairs_fold(lib, ref_lib):
     # the ReLU backward of some OTHER map on the same gradient does not fold
     (ht, other) = make_tensors(lib, nnc.GPU_MEMORY, [np.full_like(a, 4), np.abs(srnd(rng, *a.shape))])
     assert lib.cmd_exec(cmd, hint, 0, [gt, at, wtt], [ht, None, None]) == 0 or True
+
+
+@pytest.mark.parametrize("fmt,shape", [("NCHW", (3, 6, 5, 8)), ("NHWC", (3, 5, 7, 6)), ("NCHW", (2, 3, 9, 7))])
+@pytest.mark.parametrize("is_test", [0, 1])
+def test_batch_norm_relu_pair(lib, fmt, shape, is_test):
+    """conv - bn - relu blocks: BATCH_NORM_FORWARD then RELU_FORWARD in place.  Run on the spot (first time), folded by the look-ahead
+    (later times) and with the opt-in bit: the same y = max(0, bn(x)); the statistics outputs are those of the plain command."""
+    rng = np.random.default_rng(21)
+    caxis = 1 if fmt == "NCHW" else 3
+    C = shape[caxis]
+    axes = tuple(k for k in range(4) if k != caxis)
+    x = srnd(rng, *shape, scale=2.0)
+    scale, bias = srnd(rng, C) + F(1.5), srnd(rng, C)
+    mean, var = srnd(rng, C), rng.random(C, dtype=F) + F(0.5)
+    cmd, relu = nnc.CMD_BATCH_NORM_FORWARD(1e-4, is_test, 0.9, *axes), nnc.CMD_RELU_FORWARD()
+
+    def run(mode):
+        tx, = make_tensors(lib, nnc.GPU_MEMORY, [x], fmt)
+        ts = make_tensors(lib, nnc.GPU_MEMORY, [scale, bias, mean.copy(), var.copy()], fmt)
+        ty, tsm, tsi = make_tensors(lib, nnc.GPU_MEMORY, [np.full_like(x, -3), np.zeros(C, F), np.zeros(C, F)], fmt)
+        c = nnc.Cmd(); nnc.C.memmove(nnc.C.byref(c), nnc.C.byref(cmd), nnc.C.sizeof(c))
+        if mode == "bit":
+            c.algorithm = nnc.BNORM_ALGO_FUSE_RELU
+        assert lib.cmd_exec(c, nnc.NO_HINT, 0, [tx] + ts, [ty, ts[2], ts[3], tsm, tsi]) == 0
+        if mode == "pair":
+            assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [ty], [ty]) == 0
+        return [t.numpy() for t in (ty, ts[2], ts[3], tsm, tsi)]
+
+    lib.dll.nnc_mi355x_set_peephole(0)
+    plain = run("plain")
+    want = [np.maximum(plain[0], 0)] + plain[1:]
+    lib.dll.nnc_mi355x_set_peephole(1)
+    r0, f0, p0 = counts(lib)
+    results = [run("pair"), run("pair"), run("pair"), run("bit")]
+    r1, f1, p1 = counts(lib)
+    assert f1 - f0 >= 2 and (r1 - r0) - (f1 - f0) == (p1 - p0)  # at least the 2nd and 3rd pair folded (the 1st too if the signature was known)
+    for got in results:
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    assert (want[0] == 0).any() and (want[0] > 0).any()
