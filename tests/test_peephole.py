@@ -147,3 +147,64 @@ def test_batch_norm_relu_pair(lib, fmt, shape, is_test):
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
     assert (want[0] == 0).any() and (want[0] > 0).any()
+
+
+TWO_DEVICE_SCRIPT = """
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r)
+from ccv_amd import nnc
+L = nnc.load(%r)
+assert L.device_count() == 4
+rng = np.random.default_rng(5)
+F = nnc.CCV_32F
+def on(dev, arr):
+    return L.tensor(nnc.GPU_TENSOR_NHWC(dev, F, *arr.shape), arr)
+def counts():
+    r, f, p = C.c_long(), C.c_long(), C.c_long()
+    L.dll.nnc_mi355x_debug_peephole_counts(C.byref(r), C.byref(f), C.byref(p))
+    return r.value, f.value, p.value
+n, h, w, c, k = 2, 9, 10, 16, 16
+a = [((rng.random((n, h, w, c), dtype=np.float32) - 0.5) * 2).astype(np.float32) for _ in range(2)]
+wt = ((rng.random((k, 3, 3, c), dtype=np.float32) - 0.5) / (4.5 * c)).astype(np.float32)
+b = ((rng.random(k, dtype=np.float32) - 0.5) * 0.1).astype(np.float32)
+hint = nnc.HINT((1, 1), (1, 1))
+cmd, relu = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c), nnc.CMD_RELU_FORWARD()
+streams = [L.stream_new(1), L.stream_new(2)]           # fixed-device contexts: the commands below never set the current device themselves
+ins = [[on(d, a[i]), on(d, wt), on(d, b)] for i, d in enumerate((1, 2))]
+L.dll.nnc_mi355x_set_peephole(0)
+want = []
+for i, d in enumerate((1, 2)):
+    out = on(d, np.zeros((n, h, w, k), np.float32))
+    assert L.cmd_exec(cmd, hint, 0, ins[i], [out], streams[i]) == 0
+    assert L.cmd_exec(relu, nnc.NO_HINT, 0, [out], [out], streams[i]) == 0
+    L.stream_wait(streams[i])
+    want.append(out.numpy())
+L.dll.nnc_mi355x_set_peephole(1)
+r0, f0, p0 = counts()
+for trip in range(3):
+    # the data-parallel order of the reference host: both replicas' convolutions, then both replicas' ReLUs -- one thread, and the
+    # current device is whatever the previous command left behind
+    outs = [on(d, np.full((n, h, w, k), -5, np.float32)) for d in (1, 2)]
+    for i in range(2):
+        assert L.cmd_exec(cmd, hint, 0, ins[i], [outs[i]], streams[i]) == 0
+    for i in range(2):
+        assert L.cmd_exec(relu, nnc.NO_HINT, 0, [outs[i]], [outs[i]], streams[i]) == 0
+    for i in range(2):
+        L.stream_wait(streams[i])
+        assert np.array_equal(outs[i].numpy(), want[i]), (trip, i)
+r1, f1, p1 = counts()
+assert (r1 - r0, f1 - f0, p1 - p0) == (4, 4, 0), (r1 - r0, f1 - f0, p1 - p0)   # trip 0 ran on the spot; trips 1 and 2: both devices' pairs folded
+print("OK")
+"""
+
+
+def test_two_devices_fold_independently(emu_lib):
+    """One thread driving two devices the way ccv_nnc_graph's data-parallel schedule does: slots are keyed by the stream's own device
+    (the current device is stale when a command arrives), so each replica's pair folds -- and the results are those of the plain pairs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    r = subprocess.run([sys.executable, "-c", TWO_DEVICE_SCRIPT % (root, so)], env=dict(os.environ, NNC_EMU_DEVICE_COUNT="4"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
