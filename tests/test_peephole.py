@@ -208,3 +208,34 @@ def test_two_devices_fold_independently(emu_lib):
     so = os.path.join(root, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
     r = subprocess.run([sys.executable, "-c", TWO_DEVICE_SCRIPT % (root, so)], env=dict(os.environ, NNC_EMU_DEVICE_COUNT="4"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("fmt", ["NHWC", "NCHW"])
+def test_half_precision_pairs_fold_to_the_same_halves(lib, fmt):
+    """CCV_16F tensors: convolution + ReLU and batch norm + ReLU pairs, folded vs issued with the look-ahead off -- identical halves
+    (rounding to half and max(0, .) commute)."""
+    H = np.float16
+    rng = np.random.default_rng(8)
+    n, h, w, c, k = 2, 10, 9, 16, 16
+    t = (lambda x: np.ascontiguousarray(x.transpose(0, 3, 1, 2))) if fmt == "NCHW" else (lambda x: x)
+    a, wt, b = t(srnd(rng, n, h, w, c).astype(H)), t(srnd(rng, k, 3, 3, c, scale=1.0 / (3 * c)).astype(H)), srnd(rng, k, scale=0.05).astype(H)
+    hint = nnc.HINT((1, 1), (1, 1))
+    cmd, relu = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c), nnc.CMD_RELU_FORWARD()
+    ins = make_tensors(lib, nnc.GPU_MEMORY, [a, wt, b], fmt)
+
+    def pair():
+        (out,) = make_tensors(lib, nnc.GPU_MEMORY, [t(np.full((n, h, w, k), -2, H))], fmt)
+        assert lib.cmd_exec(cmd, hint, 0, ins, [out]) == 0
+        assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [out], [out]) == 0
+        return out.numpy()
+
+    lib.dll.nnc_mi355x_set_peephole(0)
+    want = pair()
+    lib.dll.nnc_mi355x_set_peephole(1)
+    r0, f0, p0 = counts(lib)
+    got = [pair() for _ in range(3)]
+    r1, f1, p1 = counts(lib)
+    assert f1 - f0 >= 2
+    assert want.dtype == H and (want == 0).any() and (want > 0).any()
+    for g in got:
+        assert np.array_equal(g, want)
