@@ -136,7 +136,7 @@ def resnet_config(args, half, dawn=False):
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                            "kernel": "batch norm forward + backward commands (%s)" % "; ".join(sorted(set(k["name"] for k in bn))), "launches": n, "avg_ms": ms / n,
                            "ms_per_step": ms, "recorded_kernels": {k["name"][-100:]: {"ms": k["ms"], "launches": k["launches"], "tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0)} for k in ks}}
-    print(json.dumps(out))
+    emit(out)
 
 
 def pmc_traffic(symbol, batch):
@@ -163,7 +163,28 @@ def pmc_traffic(symbol, batch):
     return tot / n if n else None
 
 
+_RESULT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to C stdout when a communicator is created (and child
+    processes or libraries may print too): file descriptor 1 is pointed at stderr for the life of the process and the JSON line goes
+    to a private duplicate of the real stdout."""
+    global _RESULT
+    if _RESULT is None:
+        sys.stdout.flush()
+        _RESULT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(out):
+    claim_stdout()
+    _RESULT.write(json.dumps(out) + "\n")
+    _RESULT.flush()
+
+
 def main():
+    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -394,9 +415,9 @@ def main():
                 rel = abs(step1_loss - oracle_loss) / max(abs(oracle_loss), 1e-30)
                 out["config"]["step1_loss_image0"] = {"gpu": step1_loss, "oracle": oracle_loss, "rel_err": rel, "bound": 1e-4}
                 if not rel <= 1e-4:
-                    print(json.dumps(out))
+                    emit(out)
                     raise SystemExit("bench.py: step-1 loss of image 0 differs from the oracle's: %r vs %r (rel %.3g > 1e-4)" % (step1_loss, oracle_loss, rel))
-        print(json.dumps(out))
+        emit(out)
     if dist:
         L.stream_wait(stream)
         if comm_stream is not None:
