@@ -114,7 +114,10 @@ void keep(ccv_nnc_tensor_view_t* dst, int* has, const ccv_nnc_tensor_t* t)
 }
 
 // launch a recorded command (relu_bit: with the ReLU folded in); the slot is released first: the launch's own hooks find nothing
-int run(Slot& s, const int relu_bit)
+typedef std::unique_lock<std::recursive_mutex> Lock;
+// (the launch itself runs WITHOUT the slots' mutex: it takes the collectives' mutex through stream_of, and a thread recording a
+// collective takes this one through the same hook -- never both at once in opposite orders)
+int run(Slot& s, const int relu_bit, Lock& lk)
 {
 	Slot c = s;
 	s.live = 0;
@@ -129,7 +132,9 @@ int run(Slot& s, const int relu_bit)
 	HIP_ENFORCE(hipGetDevice(&prev));
 	if (prev != c.device) HIP_ENFORCE(hipSetDevice(c.device));
 	++tl_running;
+	lk.unlock();
 	const int r = c.fn(c.cmd, c.hint, c.flags, in, c.nin, out, c.nout, c.ctx);
+	lk.lock();
 	--tl_running;
 	int now = prev;
 	HIP_ENFORCE(hipGetDevice(&now));
@@ -176,10 +181,10 @@ bool deferred_try(exec_fn_t fn, const int kind, const ccv_nnc_cmd_t cmd, const c
 	if (CCV_TENSOR_GET_MEMORY(outputs[0]->info.type) != CCV_TENSOR_GPU_MEMORY) return false;
 	const uint64_t h = signature(kind, cmd, hint, flags, inputs, input_size, outputs, output_size);
 	*sig = h;
-	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	Lock lock(g_mu);
 	if (!g_good.count(h)) return false; // first time: run on the spot, deferred_mark_good() files it when it succeeds
 	const int device = device_for(ctx);
-	if (Slot* const old = slot_of(ctx, device)) run(*old, 0); // two recordable commands in a row: the first goes as it is
+	if (Slot* const old = slot_of(ctx, device)) run(*old, 0, lock); // two recordable commands in a row: the first goes as it is
 	Slot* s = 0;
 	for (int i = 0; i < SLOTS && !s; i++)
 		if (!g_slots[i].live) s = &g_slots[i];
@@ -204,31 +209,31 @@ void deferred_mark_good(const uint64_t sig)
 int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* const a, ccv_nnc_tensor_t* const b, ccv_nnc_stream_context_t* const ctx)
 {
 	if (!g_deferred_live || tl_running) return -1;
-	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	Lock lock(g_mu);
 	const int device = device_for(ctx);
 	Slot* const s = slot_of(ctx, device);
 	if (!s || (s->kind != DEFER_CONV_FORWARD && s->kind != DEFER_BNORM_FORWARD) || !s->has_out[0] || a->data.u8 != b->data.u8 || !same_buffer(s->out[0], b) || !same_buffer(s->out[0], a)) return -1;
-	return run(*s, s->kind == DEFER_CONV_FORWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_BNORM_ALGO_FUSE_RELU);
+	return run(*s, s->kind == DEFER_CONV_FORWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_BNORM_ALGO_FUSE_RELU, lock);
 }
 
 int deferred_fuse_relu_back(const ccv_nnc_tensor_t* const g, const ccv_nnc_tensor_t* const b, ccv_nnc_tensor_t* const h, ccv_nnc_stream_context_t* const ctx)
 {
 	if (!g_deferred_live || tl_running || !g) return -1;
-	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	Lock lock(g_mu);
 	const int device = device_for(ctx);
 	Slot* const s = slot_of(ctx, device);
 	if (!s || (s->kind != DEFER_CONV_BACKWARD && s->kind != DEFER_POOL_BACKWARD) || !s->has_out[0] || s->nin < 2 || !s->has_in[1]) return -1;
 	// RELU_BACKWARD (g, -, b) -> h in place on the gradient the recorded command writes, b the map the recorded command read as its input a
 	if (g->data.u8 != h->data.u8 || !same_buffer(s->out[0], h) || !same_buffer(s->in[1], b) || s->in[1].info.format != s->out[0].info.format) return -1;
-	return run(*s, s->kind == DEFER_CONV_BACKWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD);
+	return run(*s, s->kind == DEFER_CONV_BACKWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD, lock);
 }
 
 void deferred_flush(const ccv_nnc_stream_context_t* const ctx)
 {
 	if (tl_running) return;
-	std::lock_guard<std::recursive_mutex> lock(g_mu);
+	Lock lock(g_mu);
 	for (int i = 0; i < SLOTS; i++)
-		if (g_slots[i].live && (!ctx || !g_slots[i].ctx || g_slots[i].ctx == ctx)) run(g_slots[i], 0); // (the default stream orders against every other: no context = all)
+		if (g_slots[i].live && (!ctx || !g_slots[i].ctx || g_slots[i].ctx == ctx)) run(g_slots[i], 0, lock); // (the default stream orders against every other: no context = all)
 }
 
 } // namespace nnc
