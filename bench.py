@@ -113,7 +113,7 @@ def resnet_config(args, half, dawn=False):
     if not os.path.exists(exe):
         raise SystemExit("oracle/_ref/host_resnet_bench.gpu not built (oracle/build_ref_host.sh)")
     devices = 1 if dawn else max(1, args.gpus)  # the reference's single-process data parallelism (ccv_cnnp_model_set_data_parallel): `batch` per device
-    r = subprocess.run([exe, str(args.batch), "32" if dawn else "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"] + (["dawn"] if dawn else ["full", str(devices)]), capture_output=True, text=True, timeout=3000)
+    r = subprocess.run([exe, str(args.batch), "32" if dawn else "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"] + (["dawn"] if dawn else ["full", str(devices)]), capture_output=True, text=True, timeout=3000, env=dict(os.environ, NNC_MI355X_PEEPHOLE_STATS="1"))
     if r.returncode != 0:
         raise SystemExit("host_resnet_bench failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
     h = json.loads(r.stdout.strip().splitlines()[-1])
@@ -130,6 +130,10 @@ def resnet_config(args, half, dawn=False):
                       "first_step_ms": h["first_step_ms"], "outputs_finite": h["outputs_finite"], "softmax_worst_row_sum_err": h["softmax_worst_row_sum_err"], "memory_gib": h["memory_gib"]}}
     ks = h.get("kernels", [])
     bn = [k for k in ks if k["bytes"] > 0 and k["ms"] > 0]
+    import re
+    m = re.search(r"look-ahead: (\d+) commands recorded, (\d+) completed by their ReLU, (\d+) launched as they were", r.stderr)
+    if m:  # the library's ReLU look-ahead (peephole.cpp): the host's graph is unchanged, batch norm + ReLU and pool-gradient + ReLU-backward pairs fold
+        out["config"]["relu_look_ahead"] = {"recorded": int(m.group(1)), "folded": int(m.group(2)), "launched_plain": int(m.group(3))}
     if bn:
         byts, ms, n = sum(k["bytes"] for k in bn), sum(k["ms"] for k in bn), sum(k["launches"] for k in bn)
         ach = byts / (ms * 1e-3) / 1e9
