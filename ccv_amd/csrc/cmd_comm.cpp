@@ -77,7 +77,7 @@ hipStream_t neighbor_stream(ccv_nnc_stream_context_t* ctx, int device)
 // the order: the next non-COMM launch of this library on any stream (stream_of), a synchronise, a signal, a host callback,
 // or MAX_PENDING records.  Back-to-back COMM nodes of a schedule (a layer's weight and bias, the tail of backward) thus
 // travel together; results and stream order are exactly those of immediate issue.
-struct pending_t { int op; const float* in; float* out; size_t count; int root; ncclComm_t comm; hipStream_t stream; int device; };
+struct pending_t { int op; const void* in; void* out; size_t count; ncclDataType_t dt; int root; ncclComm_t comm; hipStream_t stream; int device; };
 constexpr int MAX_PENDING = 256;
 pending_t g_pending[MAX_PENDING];
 int g_pending_n = 0;
@@ -93,9 +93,9 @@ void flush_locked()
 	RCCL_ENFORCE(ncclGroupStart());
 	for (int i = 0; i < g_pending_n; i++) {
 		const pending_t& p = g_pending[i];
-		if (p.op == 0) RCCL_ENFORCE(ncclAllReduce(p.in, p.out, p.count, ncclFloat, ncclSum, p.comm, p.stream));
-		else if (p.op == 1) RCCL_ENFORCE(ncclBroadcast(p.in, p.out, p.count, ncclFloat, p.root, p.comm, p.stream));
-		else RCCL_ENFORCE(ncclReduce(p.in, p.out, p.count, ncclFloat, ncclSum, p.root, p.comm, p.stream));
+		if (p.op == 0) RCCL_ENFORCE(ncclAllReduce(p.in, p.out, p.count, p.dt, ncclSum, p.comm, p.stream));
+		else if (p.op == 1) RCCL_ENFORCE(ncclBroadcast(p.in, p.out, p.count, p.dt, p.root, p.comm, p.stream));
+		else RCCL_ENFORCE(ncclReduce(p.in, p.out, p.count, p.dt, ncclSum, p.root, p.comm, p.stream));
 	}
 	RCCL_ENFORCE(ncclGroupEnd());
 	HIP_ENFORCE(hipSetDevice(cur));
@@ -105,17 +105,20 @@ void flush_locked()
 	tl_in_comm--;
 }
 
-void record(const int op, const float* in, float* out, size_t count, int root, ncclComm_t comm, hipStream_t stream, int device)
+void record(const int op, const void* in, void* out, size_t count, ncclDataType_t dt, int root, ncclComm_t comm, hipStream_t stream, int device)
 { // g_comm_mutex held
 	if (g_pending_n == MAX_PENDING) flush_locked();
 	pending_t& p = g_pending[g_pending_n++];
-	p.op = op; p.in = in; p.out = out; p.count = count; p.root = root; p.comm = comm; p.stream = stream; p.device = device;
+	p.op = op; p.in = in; p.out = out; p.count = count; p.dt = dt; p.root = root; p.comm = comm; p.stream = stream; p.device = device;
 	nnc::g_comm_pending = 1;
 }
 
-bool comm_tensor_ok(const ccv_nnc_tensor_t* t, size_t count)
+// The element types the reference's rows register (comm_gpu_nccl.cu:65,76,173-206: CCV_32F | CCV_16F, mapped by
+// ccv_nnc_nccl_datatype, lib/nnc/gpu/ccv_nnc_compat.cu:1447-1460).  Every tensor of one command has the first one's type: RCCL sums
+// halves in half precision exactly as NCCL does for the reference, no widening behind the caller's back.
+bool comm_tensor_ok(const ccv_nnc_tensor_t* t, size_t count, int datatype)
 {
-	return t && tensor_contiguous(t) && tensor_count(t->info) == count && CCV_GET_DATA_TYPE(t->info.datatype) == CCV_32F;
+	return t && tensor_contiguous(t) && tensor_count(t->info) == count && CCV_GET_DATA_TYPE(t->info.datatype) == datatype;
 }
 
 enum { OP_ALLREDUCE, OP_BROADCAST, OP_REDUCE };
@@ -127,18 +130,21 @@ int comm_exec(const int op, ccv_nnc_tensor_t* const* const inputs, const int inp
 	const ccv_nnc_tensor_t* first = op == OP_REDUCE ? outputs[0] : inputs[0];
 	if (!first) return CCV_NNC_EXEC_INVALID;
 	const size_t count = tensor_count(first->info);
+	const int datatype = CCV_GET_DATA_TYPE(first->info.datatype);
+	if (datatype != CCV_32F && datatype != CCV_16F) return CCV_NNC_EXEC_INVALID;
+	const ncclDataType_t dt = datatype == CCV_16F ? ncclHalf : ncclFloat;
 	tl_in_comm++;
 	pthread_mutex_lock(&g_comm_mutex);
 	int ret = CCV_NNC_EXEC_SUCCESS;
 	if (g_rank_comm) { // (b): one tensor per process
-		if (n != 1 || !comm_tensor_ok(inputs[0], count) || !comm_tensor_ok(outputs[0], count)) ret = CCV_NNC_EXEC_INVALID;
-		else record(op == OP_ALLREDUCE ? 0 : op == OP_BROADCAST ? 1 : 2, inputs[0]->data.f32, outputs[0]->data.f32, count, 0, g_rank_comm, stream_of(ctx), -1);
+		if (n != 1 || !comm_tensor_ok(inputs[0], count, datatype) || !comm_tensor_ok(outputs[0], count, datatype)) ret = CCV_NNC_EXEC_INVALID;
+		else record(op == OP_ALLREDUCE ? 0 : op == OP_BROADCAST ? 1 : 2, inputs[0]->data.u8, outputs[0]->data.u8, count, dt, 0, g_rank_comm, stream_of(ctx), -1);
 	} else {
 		int device_count = 0;
 		for (int i = 0; i < n && ret == CCV_NNC_EXEC_SUCCESS; i++) {
 			const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
-			if (!comm_tensor_ok(t, count)) ret = CCV_NNC_EXEC_INVALID;
-			else if (op == OP_ALLREDUCE && !comm_tensor_ok(inputs[i], count)) ret = CCV_NNC_EXEC_INVALID;
+			if (!comm_tensor_ok(t, count, datatype)) ret = CCV_NNC_EXEC_INVALID;
+			else if (op == OP_ALLREDUCE && !comm_tensor_ok(inputs[i], count, datatype)) ret = CCV_NNC_EXEC_INVALID;
 			else {
 				const int d = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
 				if (d + 1 > device_count) device_count = d + 1;
@@ -152,9 +158,9 @@ int comm_exec(const int op, ccv_nnc_tensor_t* const* const inputs, const int inp
 				const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
 				const int d = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
 				hipStream_t st = neighbor_stream(ctx, d);
-				if (op == OP_ALLREDUCE) record(0, inputs[i]->data.f32, outputs[i]->data.f32, count, 0, cl->comm[d], st, d);
-				else if (op == OP_BROADCAST) record(1, inputs[0]->data.f32, outputs[i]->data.f32, count, root, cl->comm[d], st, d);
-				else record(2, inputs[i]->data.f32, outputs[0]->data.f32, count, root, cl->comm[d], st, d);
+				if (op == OP_ALLREDUCE) record(0, inputs[i]->data.u8, outputs[i]->data.u8, count, dt, 0, cl->comm[d], st, d);
+				else if (op == OP_BROADCAST) record(1, inputs[0]->data.u8, outputs[i]->data.u8, count, dt, root, cl->comm[d], st, d);
+				else record(2, inputs[i]->data.u8, outputs[0]->data.u8, count, dt, root, cl->comm[d], st, d);
 			}
 		}
 	}
@@ -254,7 +260,7 @@ void comm_release_context(const void* ctx)
 
 #define NNC_REG(CMD, EXEC) \
 	extern "C" void _register_command_##CMD##_backend_CCV_NNC_BACKEND_GPU_NCCL(ccv_nnc_cmd_backend_registry_t* const registry) \
-	{ registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN; registry->tensor_datatypes = CCV_32F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = EXEC; }
+	{ registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC | CCV_TENSOR_FORMAT_CHWN; registry->tensor_datatypes = CCV_32F | CCV_16F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = EXEC; }
 NNC_REG(CCV_NNC_COMM_ALLREDUCE_FORWARD, _allreduce)
 NNC_REG(CCV_NNC_COMM_ALLREDUCE_BACKWARD, _allreduce)
 NNC_REG(CCV_NNC_COMM_BROADCAST_FORWARD, _broadcast_forw)

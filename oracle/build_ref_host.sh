@@ -42,6 +42,8 @@ done
 #     bench.py --via-host runs it on the MI355X, tests/test_via_host.py the emulator build at a small size)
 $CC $TFLAGS $ROOT/tools/host_vgg_bench.c -o $OUT/host_vgg_bench.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
 $CC $TFLAGS $ROOT/tools/host_resnet_bench.c -o $OUT/host_resnet_bench.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
+# the same harness on the reference's OWN CPU backends (libccv_ref.so, no GPU backend linked): the other side of the whole-network parity tests
+[ -f $OUT/libccv_ref.so ] && $CC -O2 -fopenmp -I$REF/lib -DHAVE_SSE2 -DHAVE_PTHREAD -DUSE_OPENMP -Wno-everything -DHOST_BENCH_CPU $ROOT/tools/host_resnet_bench.c -o $OUT/host_resnet_bench.cpu -L$OUT -lccv_ref $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
 if [ -f $OUT/libccv_host_emu.so ]; then
   $CC $TFLAGS $ROOT/tools/host_resnet_bench.c -o $OUT/host_resnet_bench.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
   $CC $TFLAGS $ROOT/tools/host_vgg_bench.c -o $OUT/host_vgg_bench.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &

@@ -11,7 +11,7 @@ typedef struct { char internal[128]; } ncclUniqueId;
 struct emu_nccl_clique;
 struct emu_nccl_comm { emu_nccl_clique* clique; int rank; };
 typedef emu_nccl_comm* ncclComm_t;
-struct emu_nccl_op { int kind; const void* send; void* recv; size_t count; int root; };
+struct emu_nccl_op { int kind; const void* send; void* recv; size_t count; int root; int dt; };
 struct emu_nccl_clique { int n; std::vector<emu_nccl_op> pending; std::vector<int> posted; };
 static inline void emu_nccl_try_run(emu_nccl_clique* q)
 {
@@ -19,15 +19,22 @@ static inline void emu_nccl_try_run(emu_nccl_clique* q)
 	const size_t count = q->pending[0].count;
 	const int kind = q->pending[0].kind, root = q->pending[0].root;
 	std::vector<float> acc(count, 0.f);
+	if (q->pending[0].dt == ncclHalf) { // half elements: each partial sum rounded to half, as a ring of half adders leaves it
+		if (kind == 1) { const _Float16* s = (const _Float16*)q->pending[root].send; for (size_t i = 0; i < count; i++) acc[i] = (float)s[i]; }
+		else for (int r = 0; r < q->n; r++) { const _Float16* s = (const _Float16*)q->pending[r].send; for (size_t i = 0; i < count; i++) acc[i] = (float)(_Float16)(acc[i] + (float)s[i]); }
+		for (int r = 0; r < q->n; r++) { if (kind == 2 && r != root) continue; _Float16* d = (_Float16*)q->pending[r].recv; for (size_t i = 0; i < count; i++) d[i] = (_Float16)acc[i]; }
+		for (int r = 0; r < q->n; r++) q->posted[r] = 0;
+		return;
+	}
 	if (kind == 1) { const float* s = (const float*)q->pending[root].send; for (size_t i = 0; i < count; i++) acc[i] = s[i]; }
 	else for (int r = 0; r < q->n; r++) { const float* s = (const float*)q->pending[r].send; for (size_t i = 0; i < count; i++) acc[i] += s[i]; }
 	for (int r = 0; r < q->n; r++) { if (kind == 2 && r != root) continue; float* d = (float*)q->pending[r].recv; for (size_t i = 0; i < count; i++) d[i] = acc[i]; }
 	for (int r = 0; r < q->n; r++) q->posted[r] = 0;
 }
-static inline ncclResult_t emu_nccl_post(ncclComm_t c, int kind, const void* s, void* r, size_t count, int root)
+static inline ncclResult_t emu_nccl_post(ncclComm_t c, int kind, const void* s, void* r, size_t count, int root, int dt)
 {
 	emu_nccl_clique* q = c->clique;
-	q->pending[c->rank] = emu_nccl_op{kind, s, r, count, root};
+	q->pending[c->rank] = emu_nccl_op{kind, s, r, count, root, dt};
 	q->posted[c->rank] = 1;
 	emu_nccl_try_run(q);
 	return ncclSuccess;
@@ -38,7 +45,7 @@ static inline ncclResult_t ncclCommInitRank(ncclComm_t* comm, int n, ncclUniqueI
 static inline ncclResult_t ncclCommDestroy(ncclComm_t c) { delete c; return ncclSuccess; }
 static inline ncclResult_t ncclGroupStart() { return ncclSuccess; }
 static inline ncclResult_t ncclGroupEnd() { return ncclSuccess; }
-static inline ncclResult_t ncclAllReduce(const void* s, void* r, size_t count, ncclDataType_t, ncclRedOp_t, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 0, s, r, count, 0); }
-static inline ncclResult_t ncclBroadcast(const void* s, void* r, size_t count, ncclDataType_t, int root, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 1, s, r, count, root); }
-static inline ncclResult_t ncclReduce(const void* s, void* r, size_t count, ncclDataType_t, ncclRedOp_t, int root, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 2, s, r, count, root); }
+static inline ncclResult_t ncclAllReduce(const void* s, void* r, size_t count, ncclDataType_t dt, ncclRedOp_t, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 0, s, r, count, 0, dt); }
+static inline ncclResult_t ncclBroadcast(const void* s, void* r, size_t count, ncclDataType_t dt, int root, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 1, s, r, count, root, dt); }
+static inline ncclResult_t ncclReduce(const void* s, void* r, size_t count, ncclDataType_t dt, ncclRedOp_t, int root, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 2, s, r, count, root, dt); }
 static inline const char* ncclGetErrorString(ncclResult_t) { return "emu-nccl error"; }

@@ -57,3 +57,59 @@ def test_comm_two_stream_contexts_coalesced(emu_lib):
     so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
     r = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, so)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# CCV_16F rows: the reference registers CCV_32F | CCV_16F (lib/nnc/cmd/comm/gpu/ccv_nnc_comm_gpu_nccl.cu:65,76,173-206) and maps the element
+# type with ccv_nnc_nccl_datatype (lib/nnc/gpu/ccv_nnc_compat.cu:1447-1460); the f16 trainers (bin/nnc/imagenet.c:344) all-reduce half gradients.
+SCRIPT_HALF = textwrap.dedent("""
+    import ctypes as C, sys, numpy as np
+    sys.path.insert(0, %r)
+    from ccv_amd import nnc
+    L = nnc.load(%r)
+    assert L.device_count() == 4
+    rng = np.random.default_rng(5)
+    H = nnc.CCV_16F
+    def on(dev, arr, dt=H):
+        return L.tensor(nnc.GPU_TENSOR_NHWC(dev, dt, *arr.shape), arr)
+    s = L.stream_new(0)
+    # small integers: every partial sum is exact in half precision, so the result is order-independent and must be exact
+    xs = [rng.integers(-64, 64, 4096).astype(np.float16) for _ in range(4)]
+    ts = [on(d, xs[d]) for d in range(4)]
+    ar = nnc.generic_cmd("COMM_ALLREDUCE_FORWARD")
+    assert L.cmd_exec(ar, nnc.NO_HINT, 0, ts, ts, s) == 0
+    L.stream_wait(s)
+    want = sum(x.astype(np.float32) for x in xs).astype(np.float16)
+    for d in range(4):
+        got = ts[d].numpy()
+        assert got.dtype == np.float16
+        np.testing.assert_array_equal(got, want)
+    # general values, two devices: one rounding of an exact two-term sum
+    ya = [rng.standard_normal(1000).astype(np.float16) for _ in range(2)]
+    ty = [on(d, ya[d]) for d in range(2)]
+    assert L.cmd_exec(ar, nnc.NO_HINT, 0, ty, ty, s) == 0
+    L.stream_wait(s)
+    want2 = (ya[0].astype(np.float32) + ya[1].astype(np.float32)).astype(np.float16)
+    for d in range(2):
+        np.testing.assert_array_equal(ty[d].numpy(), want2)
+    # broadcast / reduce in half
+    src = on(3, xs[0]); outs = [on(d, np.zeros(4096, np.float16)) for d in range(4)]
+    assert L.cmd_exec(nnc.generic_cmd("COMM_BROADCAST_FORWARD"), nnc.NO_HINT, 0, [src], outs, s) == 0
+    red = on(1, np.zeros(4096, np.float16))
+    assert L.cmd_exec(nnc.generic_cmd("COMM_REDUCE_FORWARD"), nnc.NO_HINT, 0, [on(d, xs[d]) for d in range(4)], [red], s) == 0
+    L.stream_wait(s)
+    for d in range(4):
+        np.testing.assert_array_equal(outs[d].numpy(), xs[0])
+    np.testing.assert_array_equal(red.numpy(), want)
+    # a command mixing element types is refused, not reinterpreted
+    mixed = [on(0, xs[0]), on(1, xs[1].astype(np.float32), nnc.CCV_32F)]
+    assert L.cmd_exec(ar, nnc.NO_HINT, 0, mixed, mixed, s) != 0
+    L.stream_free(s)
+    print("OK")
+""")
+
+
+def test_comm_half_precision_rows(emu_lib):
+    env = dict(os.environ, NNC_EMU_DEVICE_COUNT="4")
+    so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    r = subprocess.run([sys.executable, "-c", SCRIPT_HALF % (ROOT, so)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

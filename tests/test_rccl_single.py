@@ -34,6 +34,22 @@ def test_rccl_world_of_one_allreduce_and_broadcast(gpu_lib, solo_comm):
 
 
 @pytest.mark.gpu
+def test_rccl_world_of_one_half_precision(gpu_lib, solo_comm):
+    """The CCV_16F COMM rows (comm_gpu_nccl.cu:65-206 registers CCV_32F | CCV_16F) through real RCCL: ncclHalf over a communicator of one
+    returns the halves bit for bit; the row is found by the dispatcher for half tensors."""
+    L = gpu_lib
+    s = L.stream_new(0)
+    x = np.random.default_rng(1).standard_normal(1 << 18).astype(np.float16)
+    t = L.tensor(nnc.GPU_TENSOR_NHWC(0, nnc.CCV_16F, x.size), x)
+    ar = nnc.generic_cmd("COMM_ALLREDUCE_FORWARD")
+    assert L.cmd_exec(ar, nnc.NO_HINT, 0, [t], [t], s) == 0
+    assert L.cmd_exec(nnc.generic_cmd("COMM_BROADCAST_FORWARD"), nnc.NO_HINT, 0, [t], [t], s) == 0
+    L.stream_wait(s)
+    assert np.array_equal(t.numpy(), x)
+    L.stream_free(s)
+
+
+@pytest.mark.gpu
 def test_overlapped_bucketed_exchange_world_of_one(gpu_lib, solo_comm):
     """bench.py's N > 1 step -- buckets all-reduced on a second HIP stream behind signals while backward runs -- with a
     communicator of one: two steps must leave exactly the parameters of the plain single-GPU step."""

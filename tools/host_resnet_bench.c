@@ -12,7 +12,16 @@
  * dawn = BASELINE config 5's network instead: the CIFAR-10 "DawnNet" of bin/nnc/cifar-10.c:76-127 (3x3 convolutions 64-128-256-512 with
  * batch norm + ReLU, 2x2 max pools, two residual pairs, global max pool, dense 10), 32 x 32 inputs, and that trainer's own step
  * (cifar-10.c:259-273): ccv_cnnp_model_evaluate(requires_grad) -> SOFTMAX_CROSSENTROPY forward / backward on the outputs ->
- * ccv_cnnp_model_backward -> ccv_cnnp_model_apply_gradients, compiled with CMD_SGD_FORWARD(1, lr, 1 / batch, 0.01, 0.9, 0) and no loss. */
+ * ccv_cnnp_model_backward -> ccv_cnnp_model_apply_gradients, compiled with CMD_SGD_FORWARD(1, lr, 1 / batch, 0.01, 0.9, 0) and no loss.
+ *
+ * Whole-network parity (tests/test_via_host.py): built a second time with -DHOST_BENCH_CPU against oracle/_ref/libccv_ref.so -- the SAME
+ * host on the reference's own CPU backends, every tensor in CPU memory (host_resnet_bench.cpu).  With HOST_BENCH_CHECK=1 both builds set every
+ * parameter from the counter hash before the first step (the two backends' random generators differ, ccv_cnnp_model_set_parameter makes the
+ * start identical) and print, after step 1: the per-image loss, the outputs' sum / sum of squares, and sum / sum of squares of every updated
+ * parameter.  The test compares the two lines. */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* RTLD_NEXT (CPU build) */
+#endif
 #include <ccv.h>
 #include <nnc/ccv_nnc.h>
 #include <nnc/ccv_nnc_easy.h>
@@ -22,10 +31,87 @@
 #include <math.h>
 #include <sys/time.h>
 
+/* Tensor layout.  The trainer keeps NCHW (imagenet.c:354) and so does the GPU build; the reference's CPU backends have no NCHW pooling and no
+ * NCHW convolution gradient (pool/ccv_nnc_max_pool_cpu_ref.c:145, convolution/ccv_nnc_conv_cpu_ref.c:358 register NHWC only), so the CPU build --
+ * and any build under HOST_BENCH_FORMAT=nhwc -- runs the same network on NHWC tensors holding the SAME numbers: images and 4-d filters are filled
+ * through the NCHW linear index of each element (g_nhwc), sums over a tensor do not depend on its layout, and both networks reduce the map to 1 x 1
+ * before the dense layer, so every compared quantity is the same function of the same parameters. */
+static int g_nhwc = 0;
+static ccv_nnc_tensor_param_t tensor4(ccv_nnc_tensor_param_t p, const int n, const int c, const int h, const int w)
+{
+	if (g_nhwc) { p.format = CCV_TENSOR_FORMAT_NHWC; p.dim[0] = n; p.dim[1] = h; p.dim[2] = w; p.dim[3] = c; }
+	return p;
+}
+/* position in the tensor's own layout of the element whose NCHW linear index is j (dims n, c, h, w) */
+static size_t layout_index(const size_t j, const int c, const int h, const int w)
+{
+	if (!g_nhwc) return j;
+	const size_t x = j % w, y = (j / w) % h, ch = (j / ((size_t)w * h)) % c, n = j / ((size_t)w * h * c);
+	return ((n * h + y) * w + x) * c + ch;
+}
+#ifdef HOST_BENCH_CPU
+/* the reference's CPU backends: tensors in CPU memory, no stream, no launch records */
+#define DEV_TENSOR_NCHW(...) CPU_TENSOR_NCHW(32F, __VA_ARGS__)
+/* The oracle of this repository is the reference's CPU_REF backend (north star: "outputs match the reference CPU backend").  Left alone, the host
+ * would pick CPU_OPT for the convolutions: its 1 x 1 path needs a BLAS library the image does not have (convolution/cpu_opt/_ccv_nnc_conv_cpu_gemm.c:35
+ * -> lib/ccv_algebra.c:340 asserts) and its direct path disagrees with CPU_REF, numpy and this backend on strided, padded layers
+ * (tests/test_oracle_pin.py::test_cpu_opt_direct_convolution_differs_on_strided_padded_layers).  The executable therefore answers the two CPU_OPT
+ * registrations itself with empty rows -- the dynamic linker resolves the host's call to these -- and ccv_nnc_cmd_find_backend falls through to CPU_REF. */
+void _register_command_CCV_NNC_CONVOLUTION_FORWARD_backend_CCV_NNC_BACKEND_CPU_OPT(void* const registry) {}
+void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_BACKEND_CPU_OPT(void* const registry) {}
+/* The reference's CPU pooling loops walk ONE image: no batch loop in pool/ccv_nnc_max_pool_cpu_ref.c:37-63 / ccv_nnc_avg_pool_cpu_ref.c (the GPU
+ * backend being replaced pools the whole batch, as cuDNN does; SURVEY.md section 7 and ccv_amd/vgg.py's pool_per_image are the same finding).
+ * The four CPU_REF pooling rows are therefore wrapped the same way: the reference's own registration runs, then its exec function is called once
+ * per image on 3-d tensors carved out of the 4-d ones -- the reference's loops do all the arithmetic. */
+#include <dlfcn.h>
+#include <nnc/ccv_nnc_internal.h>
+#define POOL_PER_IMAGE(CMD, slot) \
+static ccv_nnc_cmd_exec_f pool_exec_##slot; \
+static int pool_per_image_##slot(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context) \
+{ \
+	int i, n, batch = 1; \
+	for (i = 0; i < input_size; i++) if (inputs[i] && ccv_nnc_tensor_nd(inputs[i]->info.dim) == 4) batch = inputs[i]->info.dim[0]; \
+	if (batch == 1) return pool_exec_##slot(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context); \
+	ccv_nnc_tensor_t ti[8], to[8]; \
+	ccv_nnc_tensor_t* pi[8]; ccv_nnc_tensor_t* po[8]; \
+	for (n = 0; n < batch; n++) { \
+		for (i = 0; i < input_size + output_size; i++) { \
+			ccv_nnc_tensor_t* const src = i < input_size ? inputs[i] : outputs[i - input_size]; \
+			ccv_nnc_tensor_t* const dst = i < input_size ? &ti[i] : &to[i - input_size]; \
+			if (i < input_size) pi[i] = src ? dst : 0; else po[i - input_size] = src ? dst : 0; \
+			if (!src) continue; \
+			if (CCV_IS_TENSOR_VIEW(src) || ccv_nnc_tensor_nd(src->info.dim) != 4 || src->info.dim[0] != batch) { fprintf(stderr, "host_resnet_bench: pooling tensor is not a dense 4-d batch\n"); abort(); } \
+			*dst = *src; \
+			dst->info.dim[0] = src->info.dim[1]; dst->info.dim[1] = src->info.dim[2]; dst->info.dim[2] = src->info.dim[3]; dst->info.dim[3] = 0; \
+			dst->data.f32 = src->data.f32 + (size_t)n * src->info.dim[1] * src->info.dim[2] * src->info.dim[3]; \
+		} \
+		const int r = pool_exec_##slot(cmd, hint, flags, pi, input_size, po, output_size, stream_context); \
+		if (r != CCV_NNC_EXEC_SUCCESS) return r; \
+	} \
+	return CCV_NNC_EXEC_SUCCESS; \
+} \
+void _register_command_##CMD##_backend_CCV_NNC_BACKEND_CPU_REF(ccv_nnc_cmd_backend_registry_t* const registry) \
+{ \
+	void (*real)(ccv_nnc_cmd_backend_registry_t* const) = (void (*)(ccv_nnc_cmd_backend_registry_t* const))dlsym(RTLD_NEXT, "_register_command_" #CMD "_backend_CCV_NNC_BACKEND_CPU_REF"); \
+	if (!real) { fprintf(stderr, "host_resnet_bench: the reference's " #CMD " CPU_REF registration is missing\n"); abort(); } \
+	real(registry); \
+	pool_exec_##slot = registry->exec; \
+	registry->exec = pool_per_image_##slot; \
+}
+POOL_PER_IMAGE(CCV_NNC_MAX_POOL_FORWARD, 0)
+POOL_PER_IMAGE(CCV_NNC_MAX_POOL_BACKWARD, 1)
+POOL_PER_IMAGE(CCV_NNC_AVERAGE_POOL_FORWARD, 2)
+POOL_PER_IMAGE(CCV_NNC_AVERAGE_POOL_BACKWARD, 3)
+static void nnc_mi355x_profile_enable(int on) {}
+static int nnc_mi355x_profile_count(void) { return 0; }
+static int nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5]) { return -1; }
+#else
+#define DEV_TENSOR_NCHW(...) GPU_TENSOR_NCHW(000, 32F, __VA_ARGS__)
 /* the backend's in-library launch records (include/nnc_mi355x.h) */
 void nnc_mi355x_profile_enable(int on);
 int nnc_mi355x_profile_count(void);
 int nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5]);
+#endif
 
 static float hash_unit(const uint64_t i, const uint64_t seed)
 {
@@ -34,6 +120,14 @@ static float hash_unit(const uint64_t i, const uint64_t seed)
 	h ^= h >> 27; h *= 0x94D049BB133111EBull;
 	h ^= h >> 31;
 	return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+
+/* HOST_BENCH_CHECK's parameter j of tensor i (j = the element's NCHW linear index): filters He-uniform, the dense matrix a tenth of that (moderate
+ * logits: a saturated softmax would compare denormal probabilities), vectors (batch-norm scale / bias, biases) in 0.75 .. 1.25 */
+static float check_init(const int i, const size_t j, const int nd, const size_t fan)
+{
+	const float bound = sqrtf(6.f / (float)fan) * (nd == 2 ? 0.1f : 1.f);
+	return nd >= 2 ? (hash_unit(j, 5000 + i) * 2 - 1) * bound : 0.75f + 0.5f * hash_unit(j, 5000 + i);
 }
 
 static double now_ms(void)
@@ -134,25 +228,30 @@ int main(int argc, char** argv)
 	 * which device it ran on. */
 	const int rot = argc > 8 ? atoi(argv[8]) : 0;
 	if (devices < 1 || devices > 8 || (devices > 1 && is_dawn)) { fprintf(stderr, "devices must be 1..8 (fit path only)\n"); return 2; }
+#ifdef HOST_BENCH_CPU
+	g_nhwc = 1;
+#else
+	g_nhwc = getenv("HOST_BENCH_FORMAT") && strcmp(getenv("HOST_BENCH_FORMAT"), "nhwc") == 0;
+#endif
 	const int dt = half ? CCV_16F : CCV_32F;
 	static const int blocks50[] = { 3, 4, 6, 3 }, widths50[] = { 64, 128, 256, 512 };
 	static const int blocks_m[] = { 1, 1 }, widths_m[] = { 8, 16 };
 	const int classes = (mini || is_dawn) ? 10 : 1000;
 	ccv_nnc_init();
 	ccv_cnnp_model_t* const model = is_dawn ? dawn() : mini ? resnet(blocks_m, widths_m, 2, 8, classes) : resnet(blocks50, widths50, 4, 64, classes);
-	ccv_nnc_tensor_param_t input = GPU_TENSOR_NCHW(000, 32F, batch, 3, hw, hw);
+	ccv_nnc_tensor_param_t input = tensor4(DEV_TENSOR_NCHW(batch, 3, hw, hw), batch, 3, hw, hw);
 	input.datatype = dt;
 	const float lr = 0.01f, wd = 0.0001f;
 	if (is_dawn) ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / batch, 0.01, 0.9, 0), CMD_NOOP());
 	else ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / (batch * devices), wd, 0.9, 0), CMD_CATEGORICAL_CROSSENTROPY_FORWARD());
 	if (devices > 1) ccv_cnnp_model_set_data_parallel(model, devices);
 	/* synthetic batch: images ~ U(-1, 1) (normalised pixels), labels as the trainer's smoothed one-hot rows (eta = 0.1) */
-	ccv_nnc_tensor_t* const hx = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, 3, hw, hw), 0);
+	ccv_nnc_tensor_t* const hx = ccv_nnc_tensor_new(0, tensor4(CPU_TENSOR_NCHW(32F, batch, 3, hw, hw), batch, 3, hw, hw), 0);
 	ccv_nnc_tensor_t* const hfit = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, classes), 0);
 	size_t j;
 	const size_t nx = (size_t)batch * 3 * hw * hw;
 	const int shard0 = rot % devices;
-	for (j = 0; j < nx; j++) hx->data.f32[j] = hash_unit(j, 2000 + 10 * shard0) * 2 - 1;
+	for (j = 0; j < nx; j++) hx->data.f32[layout_index(j, 3, hw, hw)] = hash_unit(j, 2000 + 10 * shard0) * 2 - 1;
 	const float eta = 0.1f;
 	int i;
 	for (i = 0; i < batch; i++) {
@@ -160,13 +259,14 @@ int main(int argc, char** argv)
 		int k;
 		for (k = 0; k < classes; k++) hfit->data.f32[(size_t)i * classes + k] = (k == c ? 1 - eta : 0) + eta / classes;
 	}
-	ccv_nnc_tensor_param_t xp = GPU_TENSOR_NCHW(000, 32F, batch, 3, hw, hw), fp = GPU_TENSOR_NCHW(000, 32F, batch, classes);
+	ccv_nnc_tensor_param_t xp = tensor4(DEV_TENSOR_NCHW(batch, 3, hw, hw), batch, 3, hw, hw), fp = DEV_TENSOR_NCHW(batch, classes);
 	xp.datatype = dt; fp.datatype = dt;
+	if (g_nhwc) fp.format = CCV_TENSOR_FORMAT_NHWC;
 	ccv_nnc_tensor_t* const x = ccv_nnc_tensor_new(0, xp, 0);
 	ccv_nnc_tensor_t* const fit = ccv_nnc_tensor_new(0, fp, 0);
 	ccv_nnc_tensor_t* const out = ccv_nnc_tensor_new(0, fp, 0);
 	if (half) {
-		ccv_nnc_tensor_t* const hx16 = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(16F, batch, 3, hw, hw), 0);
+		ccv_nnc_tensor_t* const hx16 = ccv_nnc_tensor_new(0, tensor4(CPU_TENSOR_NCHW(16F, batch, 3, hw, hw), batch, 3, hw, hw), 0);
 		ccv_nnc_tensor_t* const hfit16 = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(16F, batch, classes), 0);
 		ccv_nnc_cmd_exec(CMD_DATATYPE_CONVERSION_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx, hfit), TENSOR_LIST(hx16, hfit16), 0);
 		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx16, hfit16), TENSOR_LIST(x, fit), 0);
@@ -184,14 +284,14 @@ int main(int argc, char** argv)
 			CCV_TENSOR_SET_DEVICE_ID(xd.type, d); CCV_TENSOR_SET_DEVICE_ID(fd.type, d);
 			xs[d] = ccv_nnc_tensor_new(0, xd, 0); fits[d] = ccv_nnc_tensor_new(0, fd, 0); outs[d] = ccv_nnc_tensor_new(0, fd, 0);
 			const int shard = (d + rot) % devices;
-			for (j = 0; j < nx; j++) hx->data.f32[j] = hash_unit(j, 2000 + 10 * shard) * 2 - 1;
+			for (j = 0; j < nx; j++) hx->data.f32[layout_index(j, 3, hw, hw)] = hash_unit(j, 2000 + 10 * shard) * 2 - 1;
 			for (i = 0; i < batch; i++) {
 				const int c = (int)(hash_unit(i, 2001 + 10 * shard) * classes);
 				int k;
 				for (k = 0; k < classes; k++) hfit->data.f32[(size_t)i * classes + k] = (k == c ? 1 - eta : 0) + eta / classes;
 			}
 			if (half) {
-				ccv_nnc_tensor_t* const hx16 = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(16F, batch, 3, hw, hw), 0);
+				ccv_nnc_tensor_t* const hx16 = ccv_nnc_tensor_new(0, tensor4(CPU_TENSOR_NCHW(16F, batch, 3, hw, hw), batch, 3, hw, hw), 0);
 				ccv_nnc_tensor_t* const hfit16 = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(16F, batch, classes), 0);
 				ccv_nnc_cmd_exec(CMD_DATATYPE_CONVERSION_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx, hfit), TENSOR_LIST(hx16, hfit16), 0);
 				ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx16, hfit16), TENSOR_LIST(xs[d], fits[d]), 0);
@@ -201,12 +301,55 @@ int main(int argc, char** argv)
 				ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hx, hfit), TENSOR_LIST(xs[d], fits[d]), 0);
 		}
 	}
+#ifdef HOST_BENCH_CPU
+	ccv_nnc_stream_context_t* const stream = 0;
+#else
 	ccv_nnc_stream_context_t* const stream = ccv_nnc_stream_context_new(CCV_STREAM_CONTEXT_GPU);
+#endif
 	/* reproducible parameter initialisation: the host seeds its generators from a thread-local ADDRESS otherwise (ccv_nnc_stream.c:262-281) */
 	ccv_nnc_stream_context_set_seed(0, 20240923);
-	ccv_nnc_stream_context_set_seed(stream, 20240924);
+	if (stream) ccv_nnc_stream_context_set_seed(stream, 20240924);
+	/* HOST_BENCH_CHECK=1: identical parameters on every backend.  Filters / matrices: uniform in +-sqrt(6 / fan-in) (He); vectors (batch-norm
+	 * scales and biases, convolution / dense biases): 0.75 .. 1.25 -- the backends' own initialisers differ in their generators. */
+	const int check = getenv("HOST_BENCH_CHECK") && atoi(getenv("HOST_BENCH_CHECK"));
+	int param_count = 0;
+	if (check) {
+		/* the parameter tensors exist only after a first run (ccv_cnnp_model_parameter_tensor_params asserts it): one test-mode forward pass
+		 * allocates and randomly initialises them (batch-norm running statistics are not touched in test mode), then every one is overwritten;
+		 * the training step that follows re-compiles the graph in its own mode with zeroed momentum */
+		ccv_cnnp_model_evaluate(model, (ccv_cnnp_evaluate_param_t){ .is_test = 1 }, xs, devices, outs, devices, 0, stream);
+		ccv_nnc_stream_context_wait(stream);
+		param_count = ccv_cnnp_model_parameter_count(model);
+		for (i = 0; i < param_count; i++) {
+			const ccv_cnnp_model_io_t pio = ccv_cnnp_model_parameters(model, -1, i);
+			ccv_nnc_tensor_param_t pp = ccv_cnnp_model_parameter_tensor_params(model, pio);
+			const int pdt = pp.datatype;
+			pp.type = CCV_TENSOR_CPU_MEMORY; pp.datatype = CCV_32F;
+			ccv_nnc_tensor_t* const hp = ccv_nnc_tensor_new(0, pp, 0);
+			const size_t cnt = ccv_nnc_tensor_count(pp);
+			const int nd = ccv_nnc_tensor_nd(pp.dim);
+			size_t fan = 1;
+			int a;
+			for (a = 1; a < nd; a++) fan *= pp.dim[a];
+			/* a 4-d filter is [K][C][kh][kw] on NCHW tensors and [K][kh][kw][C] on NHWC ones (the fan-in is the product of the last three either way) */
+			const int permute = nd == 4 && pp.format == CCV_TENSOR_FORMAT_NHWC;
+			for (j = 0; j < cnt; j++) {
+				const float v = check_init(i, j, nd, fan);
+				hp->data.f32[permute ? layout_index(j, pp.dim[3], pp.dim[1], pp.dim[2]) : j] = v;
+			}
+			if (pdt == CCV_16F) {
+				pp.datatype = CCV_16F;
+				ccv_nnc_tensor_t* const hp16 = ccv_nnc_tensor_new(0, pp, 0);
+				ccv_nnc_cmd_exec(CMD_DATATYPE_CONVERSION_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hp), TENSOR_LIST(hp16), 0);
+				ccv_cnnp_model_set_parameter(model, pio, hp16);
+				ccv_nnc_tensor_free(hp16);
+			} else
+				ccv_cnnp_model_set_parameter(model, pio, hp);
+			ccv_nnc_tensor_free(hp);
+		}
+	}
 	/* dawn: the CIFAR trainer's step (cifar-10.c:259-273); labels are class indices in fp32, the softmax / gradient tensors have the outputs' type */
-	ccv_nnc_tensor_t* const labels = ccv_nnc_tensor_new(0, GPU_TENSOR_NCHW(000, 32F, batch), 0);
+	ccv_nnc_tensor_t* const labels = ccv_nnc_tensor_new(0, DEV_TENSOR_NCHW(batch), 0);
 	ccv_nnc_tensor_t* const softmax = ccv_nnc_tensor_new(0, fp, 0);
 	ccv_nnc_tensor_t* const grad = ccv_nnc_tensor_new(0, fp, 0);
 	{
@@ -247,6 +390,69 @@ int main(int argc, char** argv)
 		for (k = 0; k < classes; k++) { const float v = hout->data.f32[(size_t)i * classes + k]; if (!(v == v) || v < 0 || v > 1.001f) finite = 0; s += v; }
 		if (i == 0) row0 = s;
 		if (fabs(s - 1) > worst) worst = fabs(s - 1);
+	}
+	if (check) { /* after step 1: per-image loss -sum_k fit[k] log(out[k]) (dawn: -log softmax[label]), outputs, every updated parameter */
+		printf("{\"check\": {\"loss\": [");
+		for (i = 0; i < batch && i < 8; i++) {
+			double l = 0;
+			int k;
+			if (is_dawn) { const int c = (int)(hash_unit(i, 2001) * classes); l = -log((double)hout->data.f32[(size_t)i * classes + c]); }
+			else for (k = 0; k < classes; k++) l -= (double)hfit->data.f32[(size_t)i * classes + k] * log((double)hout->data.f32[(size_t)i * classes + k] + 1e-30);
+			printf("%s%.9g", i ? ", " : "", l);
+		}
+		double osum = 0, osumsq = 0;
+		for (j = 0; j < (size_t)batch * classes; j++) { osum += hout->data.f32[j]; osumsq += (double)hout->data.f32[j] * hout->data.f32[j]; }
+		printf("], \"out_sum\": %.12g, \"out_sumsq\": %.12g, \"out_first\": [", osum, osumsq);
+		for (i = 0; i < classes && i < 10; i++) printf("%s%.9g", i ? ", " : "", hout->data.f32[i]);
+		printf("], \"param_count\": %d, \"param_sum\": [", param_count);
+		double* const psq = (double*)malloc(sizeof(double) * (param_count + 1));
+		double* const pmax = (double*)malloc(sizeof(double) * (param_count + 1));
+		double* const dsum = (double*)malloc(sizeof(double) * (param_count + 1));
+		double* const dsq = (double*)malloc(sizeof(double) * (param_count + 1));
+		for (i = 0; i < param_count; i++) {
+			const ccv_cnnp_model_io_t pio = ccv_cnnp_model_parameters(model, -1, i);
+			ccv_nnc_tensor_param_t pp = ccv_cnnp_model_parameter_tensor_params(model, pio);
+			const int pdt = pp.datatype;
+			pp.type = CCV_TENSOR_CPU_MEMORY; pp.datatype = CCV_32F;
+			ccv_nnc_tensor_t* const hp = ccv_nnc_tensor_new(0, pp, 0);
+			if (pdt == CCV_16F) {
+				pp.datatype = CCV_16F;
+				ccv_nnc_tensor_t* const hp16 = ccv_nnc_tensor_new(0, pp, 0);
+				ccv_cnnp_model_parameter_copy(model, pio, hp16);
+				ccv_nnc_cmd_exec(CMD_DATATYPE_CONVERSION_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hp16), TENSOR_LIST(hp), 0);
+				ccv_nnc_tensor_free(hp16);
+			} else
+				ccv_cnnp_model_parameter_copy(model, pio, hp);
+			const size_t cnt = ccv_nnc_tensor_count(pp);
+			/* the step itself: updated - initial (the sums above are dominated by the initial values; these are the gradient's) */
+			const int nd = ccv_nnc_tensor_nd(pp.dim);
+			size_t fan = 1;
+			int ax;
+			for (ax = 1; ax < nd; ax++) fan *= pp.dim[ax];
+			const int permute = nd == 4 && pp.format == CCV_TENSOR_FORMAT_NHWC;
+			double a = 0, b = 0, m = 0, da = 0, db = 0;
+			for (j = 0; j < cnt; j++) {
+				const double v = hp->data.f32[permute ? layout_index(j, pp.dim[3], pp.dim[1], pp.dim[2]) : j];
+				float v0 = check_init(i, j, nd, fan);
+				if (pdt == CCV_16F) { uint16_t h16; ccv_float_to_half_precision(&v0, &h16, 1); ccv_half_precision_to_float(&h16, &v0, 1); }
+				a += v; b += v * v; if (fabs(v) > m) m = fabs(v);
+				da += v - v0; db += (v - v0) * (v - v0);
+			}
+			psq[i] = b; pmax[i] = m; dsum[i] = da; dsq[i] = db;
+			printf("%s%.12g", i ? ", " : "", a);
+			ccv_nnc_tensor_free(hp);
+		}
+		printf("], \"param_sumsq\": [");
+		for (i = 0; i < param_count; i++) printf("%s%.12g", i ? ", " : "", psq[i]);
+		printf("], \"param_absmax\": [");
+		for (i = 0; i < param_count; i++) printf("%s%.9g", i ? ", " : "", pmax[i]);
+		printf("], \"step_sum\": [");
+		for (i = 0; i < param_count; i++) printf("%s%.9g", i ? ", " : "", dsum[i]);
+		printf("], \"step_sumsq\": [");
+		for (i = 0; i < param_count; i++) printf("%s%.9g", i ? ", " : "", dsq[i]);
+		printf("]}, \"devices\": %d, \"dtype\": \"%s\", \"format\": \"%s\"}\n", devices, half ? "f16" : "f32", g_nhwc ? "NHWC" : "NCHW");
+		free(psq); free(pmax); free(dsum); free(dsq);
+		return 0; /* the check line is the whole output: nothing is timed in this mode */
 	}
 	for (i = 1; i < warmup; i++) TRAIN_STEP();
 	ccv_nnc_stream_context_wait(stream);
@@ -310,6 +516,6 @@ int main(int argc, char** argv)
 	ccv_nnc_tensor_free(hfit);
 	for (i = 0; i < devices; i++) { ccv_nnc_tensor_free(xs[i]); ccv_nnc_tensor_free(fits[i]); ccv_nnc_tensor_free(outs[i]); }
 	ccv_cnnp_model_free(model);
-	ccv_nnc_stream_context_free(stream);
+	if (stream) ccv_nnc_stream_context_free(stream);
 	return 0;
 }
