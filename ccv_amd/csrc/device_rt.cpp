@@ -425,6 +425,9 @@ void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const 
 		return *ws;
 	}
 	if (mem != CCV_TENSOR_GPU_MEMORY) return 0;
+	// A command recorded by the look-ahead (peephole.cpp) asks for its scratch when it is LAUNCHED, and may grow (= move) this buffer then.
+	// Launch it before anybody is handed a pointer: no caller can hold scratch memory across a recorded command's launch.
+	if (nnc::g_deferred_live) nnc::deferred_flush(stream_context);
 	device_local_t* l;
 	hipStream_t st = 0;
 	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = l->stream; }
@@ -459,6 +462,7 @@ static void local_drain(device_local_t* l, hipStream_t st)
 void* nnc_staging_of(const ccv_nnc_stream_context_t* const stream_context, const size_t size)
 {
 	if (size == 0) return 0;
+	if (nnc::g_deferred_live) nnc::deferred_flush(stream_context); // as for the workspace: a recorded command may stage (and grow the arena) at its launch
 	device_local_t* l;
 	hipStream_t st = 0;
 	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = l->stream; }

@@ -7,9 +7,10 @@
 // takes this route, so that a half-precision graph never meets a row that cannot run it:
 //   1. every distinct CCV_16F tensor of the command gets an fp32 image in the stream's staging arena (device_rt.cpp; separate
 //      from the workspace, which the command underneath may grow and thereby move);
-//   2. inputs are converted up (exact); outputs that are views, accumulated into, or alias an input are converted up too;
+//   2. inputs are converted up (exact); outputs that are accumulated into or alias an input are converted up too;
 //   3. the fp32 exec function runs on shadow tensor structs (same shape / strides / view flags, datatype CCV_32F);
-//   4. outputs are converted down (round to nearest even, as the reference's ccv_float_to_half_precision does).
+//   4. outputs are converted down (round to nearest even, as the reference's ccv_float_to_half_precision does) -- a dense tensor as one
+//      run, a VIEW element by element through its strides: what lies between a view's rows is not this command's to write.
 // Storage is half precision, arithmetic fp32: at least the accuracy the reference's own half-precision kernels have (they
 // accumulate in fp32 as well), so its GPU-vs-CPU tolerances hold.  Cost: one extra read + write of each half tensor -- this is
 // the coverage path, not the fast one.
@@ -47,6 +48,32 @@ static __global__ void __launch_bounds__(256) half_down_kernel(const float* __re
 		for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (half_t)in[i];
 	} else
 		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (half_t)in[i];
+}
+
+// A VIEW's elements only, from the fp32 image of its span back to the half tensor: the gaps between a view's rows belong to somebody else (sibling
+// views of one parent -- channel-concatenated branches the host may run on other streams) and are never written.  One thread per element.
+struct view_geom_t { int nd; int dim[CCV_NNC_MAX_DIM_ALLOC]; int stride[CCV_NNC_MAX_DIM_ALLOC]; };
+static __global__ void __launch_bounds__(256) half_down_view_kernel(const float* __restrict__ in, half_t* __restrict__ out, const size_t n, const view_geom_t g)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		size_t r = i, off = 0;
+		for (int d = g.nd - 1; d >= 0; d--) { off += (r % (size_t)g.dim[d]) * (size_t)g.stride[d]; r /= (size_t)g.dim[d]; }
+		out[off] = (half_t)in[off];
+	}
+}
+static int float_to_half_view(const float* image, void* half, const ccv_nnc_tensor_t* t, ccv_nnc_stream_context_t* ctx)
+{
+	view_geom_t g;
+	int st[CCV_NNC_MAX_DIM_ALLOC];
+	tensor_strides(t, st);
+	g.nd = tensor_nd(t->info.dim);
+	size_t n = 1;
+	for (int i = 0; i < g.nd; i++) { g.dim[i] = t->info.dim[i]; g.stride[i] = st[i]; n *= (size_t)t->info.dim[i]; }
+	if (!n || !g.nd) return CCV_NNC_EXEC_SUCCESS;
+	hipLaunchKernelGGL(half_down_view_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream_of(ctx), image, (half_t*)half, n, g);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
 }
 
 int half_to_float(const void* in, float* out, size_t n, ccv_nnc_stream_context_t* ctx)
@@ -263,8 +290,8 @@ int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_
 		} else if (span > st[e].span) st[e].span = span;
 		if (is_output) {
 			st[e].is_output = true;
-			// what the command does not write must survive the round trip: the gaps of a view, the old value under accumulation
-			if (CCV_IS_TENSOR_VIEW(t) || (flags & CCV_NNC_ACCUMULATE_OUTPUT)) st[e].load = true;
+			// the old value under accumulation must be in the image (a view's gaps need not: they are never written back)
+			if (flags & CCV_NNC_ACCUMULATE_OUTPUT) st[e].load = true;
 		} else { st[e].is_input = true; st[e].load = true; }
 		which[slot] = e;
 	};
@@ -306,9 +333,20 @@ int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_
 	for (int i = 0; i < output_size; i++) out_s[i] = make_shadow(outputs[i], input_size + i);
 	const int ret = inner(cmd, hint, flags, in_s, input_size, out_s, output_size, ctx);
 	warn_refused(cmd.cmd, ret);
+	// `inner` may have been RECORDED by the look-ahead instead of launched (batch norm forward, peephole.cpp) with shadow tensors that point into
+	// the arena: it is launched now, before the images are converted back (or, with nothing to convert back, before the arena can be reused)
+	if (nst && g_deferred_live) deferred_flush(ctx);
 	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
-	for (int i = 0; i < nst; i++)
-		if (st[i].is_output) float_to_half(st[i].image, st[i].half, st[i].span, ctx);
+	// per OUTPUT tensor, not per image: two views of one parent share an image and each writes its own elements
+	for (int i = 0; i < output_size; i++) {
+		const int e = which[input_size + i];
+		if (e < 0 || !outputs[i]) continue;
+		bool done = false;
+		for (int j = 0; j < i && !done; j++) done = which[input_size + j] == e && outputs[j] && outputs[j]->data.u8 == outputs[i]->data.u8 && !CCV_IS_TENSOR_VIEW(outputs[j]) && !CCV_IS_TENSOR_VIEW(outputs[i]);
+		if (done) continue;
+		if (CCV_IS_TENSOR_VIEW(outputs[i]) && !tensor_contiguous(outputs[i])) float_to_half_view(st[e].image, st[e].half, outputs[i], ctx);
+		else float_to_half(st[e].image, st[e].half, tensor_count(outputs[i]->info), ctx);
+	}
 	return CCV_NNC_EXEC_SUCCESS;
 }
 

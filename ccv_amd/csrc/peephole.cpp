@@ -14,15 +14,23 @@
 // recorded collectives use (cmd_comm.cpp) -- launches it as it was first.  Results are the same either way: max(0, .) and the
 // a > 0 mask are exact.
 //
-// Only commands whose exact signature (parameters, hint, flags, every tensor's type / format / shape / strides) has already run
-// successfully on the spot are recorded, so a recorded command cannot fail on a parameter check later; if it fails at launch all the
-// same (out of memory) the process stops with a message rather than having reported success for work that did not happen.
+// Only commands whose exact signature (parameters, hint, flags, every tensor's type / format / shape / strides, and which of its tensors
+// share memory) has already run successfully on the spot are recorded, so a recorded command cannot fail on a parameter check later.  If it
+// fails at launch all the same (out of memory): completed by its ReLU, the ReLU command returns the failure; launched by a flush, the failure
+// is printed and kept, and the next recordable command of the process returns it (deferred_take_error) -- never a silent success.
 // NNC_MI355X_PEEPHOLE=0 in the environment (or nnc_mi355x_set_peephole(0)) turns the look-ahead off.
+//
+// Threads.  Every order-observing hook flushes (stream_of, copies, frees, signals, callbacks), and some of them flush EVERY stream's slot from
+// whatever thread called (a loader thread's host-to-device copy).  A slot being launched stays visible in state LAUNCHING -- still counted in
+// g_deferred_live -- until its kernels have been enqueued; anything that would order itself against that stream (the matching ReLU, another
+// command's stream_of, a flush of that context) waits for it on a condition variable instead of finding no slot and running ahead of it.
 #include "common.h"
 #include <mutex>
+#include <condition_variable>
 #include <unordered_set>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 
 namespace nnc {
 
@@ -31,8 +39,9 @@ volatile int g_deferred_live = 0;
 namespace {
 
 constexpr int MAX_IO = 6;
+enum { FREE = 0, RECORDED = 1, LAUNCHING = 2 };
 struct Slot {
-	int live;
+	int live; // FREE / RECORDED / LAUNCHING
 	exec_fn_t fn;
 	int kind;
 	ccv_nnc_cmd_t cmd;
@@ -47,9 +56,12 @@ struct Slot {
 constexpr int SLOTS = 16;
 Slot g_slots[SLOTS];
 std::recursive_mutex g_mu;
+std::condition_variable_any g_launched; // a LAUNCHING slot became FREE
+volatile int g_sticky_error = 0;        // a flushed command failed at launch: the next recordable command reports it
 std::unordered_set<uint64_t> g_good;
 int g_enabled = -1;
 long g_recorded = 0, g_folded = 0, g_plain = 0; // nnc_mi355x_debug_peephole_counts
+int g_debug_launch_delay_us = 0; // nnc_mi355x_debug_peephole_launch_delay_us: tests widen the window between a slot's release and its launch
 thread_local int tl_running = 0; // inside a recorded command's launch: its own stream_of / nested commands must not touch the slots
 
 struct StatsAtExit { // NNC_MI355X_PEEPHOLE_STATS=1: one line at unload -- how many pairs of a run actually folded
@@ -102,6 +114,16 @@ uint64_t signature(const int kind, const ccv_nnc_cmd_t& cmd, const ccv_nnc_hint_
 	mix(h, &nout, sizeof(nout));
 	for (int i = 0; i < nin; i++) mix_tensor(h, inputs[i]);
 	for (int i = 0; i < nout; i++) mix_tensor(h, outputs[i]);
+	// which tensors share memory: the exec functions validate aliasing (batch norm's running statistics in = out, cmd_norm.cpp; in-place
+	// outputs), so a call with the same shapes but another aliasing pattern is a different call
+	const int n = nin + nout;
+	for (int i = 0; i < n; i++)
+		for (int j = i + 1; j < n; j++) {
+			const ccv_nnc_tensor_t* const a = i < nin ? inputs[i] : outputs[i - nin];
+			const ccv_nnc_tensor_t* const b = j < nin ? inputs[j] : outputs[j - nin];
+			const unsigned char same = a && b && a->data.u8 == b->data.u8;
+			mix(h, &same, 1);
+		}
 	return h;
 }
 
@@ -113,15 +135,15 @@ void keep(ccv_nnc_tensor_view_t* dst, int* has, const ccv_nnc_tensor_t* t)
 	memcpy(dst, t, CCV_IS_TENSOR_VIEW(t) ? sizeof(ccv_nnc_tensor_view_t) : sizeof(ccv_nnc_tensor_t));
 }
 
-// launch a recorded command (relu_bit: with the ReLU folded in); the slot is released first: the launch's own hooks find nothing
+// launch a recorded command (relu_bit: with the ReLU folded in).  The slot is LAUNCHING until the launch has been enqueued: the launch's own
+// hooks skip the slots (tl_running), every other thread that needs this stream's order waits (wait_launching).
 typedef std::unique_lock<std::recursive_mutex> Lock;
 // (the launch itself runs WITHOUT the slots' mutex: it takes the collectives' mutex through stream_of, and a thread recording a
 // collective takes this one through the same hook -- never both at once in opposite orders)
-int run(Slot& s, const int relu_bit, Lock& lk)
+int run(Slot& s, const int relu_bit, Lock& lk, const bool report)
 {
 	Slot c = s;
-	s.live = 0;
-	--g_deferred_live;
+	s.live = LAUNCHING;
 	ccv_nnc_tensor_t* in[MAX_IO];
 	ccv_nnc_tensor_t* out[MAX_IO];
 	for (int i = 0; i < c.nin; i++) in[i] = c.has_in[i] ? (ccv_nnc_tensor_t*)&c.in[i] : 0;
@@ -133,17 +155,38 @@ int run(Slot& s, const int relu_bit, Lock& lk)
 	if (prev != c.device) HIP_ENFORCE(hipSetDevice(c.device));
 	++tl_running;
 	lk.unlock();
+	if (g_debug_launch_delay_us > 0) usleep(g_debug_launch_delay_us);
 	const int r = c.fn(c.cmd, c.hint, c.flags, in, c.nin, out, c.nout, c.ctx);
 	lk.lock();
 	--tl_running;
+	s.live = FREE;
+	--g_deferred_live;
+	g_launched.notify_all();
 	int now = prev;
 	HIP_ENFORCE(hipGetDevice(&now));
 	if (now != prev) HIP_ENFORCE(hipSetDevice(prev)); // (binding a fixed-device stream sets the device: the caller's stays what it was)
 	if (r != CCV_NNC_EXEC_SUCCESS) {
 		fprintf(stderr, "[nnc_mi355x] a recorded command (0x%x) failed at launch with %d after its caller was told it had been enqueued\n", c.cmd.cmd, r);
-		abort();
+		if (!report) g_sticky_error = r; // no caller to hand it to: the next recordable command returns it (deferred_take_error)
 	}
 	return r;
+}
+
+bool orders_against(const Slot& s, const ccv_nnc_stream_context_t* const ctx)
+{ // the default stream orders against every other: no context = all
+	return !ctx || !s.ctx || s.ctx == ctx;
+}
+
+// another thread is enqueueing a recorded command whose stream `ctx` orders against: wait until it is in the stream
+void wait_launching(const ccv_nnc_stream_context_t* const ctx, Lock& lk)
+{
+	for (;;) {
+		bool busy = false;
+		for (int i = 0; i < SLOTS && !busy; i++)
+			busy = g_slots[i].live == LAUNCHING && orders_against(g_slots[i], ctx);
+		if (!busy) return;
+		g_launched.wait(lk);
+	}
 }
 
 // The device a command on this stream runs on: the stream's own (a fixed-device context binds it -- the host does not set the current
@@ -159,7 +202,7 @@ int device_for(const ccv_nnc_stream_context_t* ctx)
 Slot* slot_of(const ccv_nnc_stream_context_t* ctx, const int device)
 {
 	for (int i = 0; i < SLOTS; i++)
-		if (g_slots[i].live && g_slots[i].ctx == ctx && g_slots[i].device == device) return &g_slots[i];
+		if (g_slots[i].live == RECORDED && g_slots[i].ctx == ctx && g_slots[i].device == device) return &g_slots[i];
 	return 0;
 }
 
@@ -184,16 +227,17 @@ bool deferred_try(exec_fn_t fn, const int kind, const ccv_nnc_cmd_t cmd, const c
 	Lock lock(g_mu);
 	if (!g_good.count(h)) return false; // first time: run on the spot, deferred_mark_good() files it when it succeeds
 	const int device = device_for(ctx);
-	if (Slot* const old = slot_of(ctx, device)) run(*old, 0, lock); // two recordable commands in a row: the first goes as it is
+	wait_launching(ctx, lock);
+	if (Slot* const old = slot_of(ctx, device)) run(*old, 0, lock, false); // two recordable commands in a row: the first goes as it is
 	Slot* s = 0;
 	for (int i = 0; i < SLOTS && !s; i++)
-		if (!g_slots[i].live) s = &g_slots[i];
+		if (g_slots[i].live == FREE) s = &g_slots[i];
 	if (!s) return false;
 	s->fn = fn; s->kind = kind; s->cmd = cmd; s->hint = hint; s->flags = flags; s->ctx = ctx; s->device = device;
 	s->nin = input_size; s->nout = output_size;
 	for (int i = 0; i < input_size; i++) keep(&s->in[i], &s->has_in[i], inputs[i]);
 	for (int i = 0; i < output_size; i++) keep(&s->out[i], &s->has_out[i], outputs[i]);
-	s->live = 1;
+	s->live = RECORDED;
 	++g_deferred_live;
 	++g_recorded;
 	return true;
@@ -211,9 +255,10 @@ int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* const a, ccv_nnc_tensor_t* c
 	if (!g_deferred_live || tl_running) return -1;
 	Lock lock(g_mu);
 	const int device = device_for(ctx);
+	wait_launching(ctx, lock); // (a foreign thread's flush is enqueueing this stream's recorded command: the ReLU goes behind it, unfolded)
 	Slot* const s = slot_of(ctx, device);
 	if (!s || (s->kind != DEFER_CONV_FORWARD && s->kind != DEFER_BNORM_FORWARD) || !s->has_out[0] || a->data.u8 != b->data.u8 || !same_buffer(s->out[0], b) || !same_buffer(s->out[0], a)) return -1;
-	return run(*s, s->kind == DEFER_CONV_FORWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_BNORM_ALGO_FUSE_RELU, lock);
+	return run(*s, s->kind == DEFER_CONV_FORWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_BNORM_ALGO_FUSE_RELU, lock, true);
 }
 
 int deferred_fuse_relu_back(const ccv_nnc_tensor_t* const g, const ccv_nnc_tensor_t* const b, ccv_nnc_tensor_t* const h, ccv_nnc_stream_context_t* const ctx)
@@ -221,11 +266,13 @@ int deferred_fuse_relu_back(const ccv_nnc_tensor_t* const g, const ccv_nnc_tenso
 	if (!g_deferred_live || tl_running || !g) return -1;
 	Lock lock(g_mu);
 	const int device = device_for(ctx);
+	wait_launching(ctx, lock);
 	Slot* const s = slot_of(ctx, device);
 	if (!s || (s->kind != DEFER_CONV_BACKWARD && s->kind != DEFER_POOL_BACKWARD) || !s->has_out[0] || s->nin < 2 || !s->has_in[1]) return -1;
+	if (s->out[0].info.datatype != s->in[1].info.datatype) return -1; // the folded epilogue masks h by a in one element type (conv_back_entry refuses a mix)
 	// RELU_BACKWARD (g, -, b) -> h in place on the gradient the recorded command writes, b the map the recorded command read as its input a
 	if (g->data.u8 != h->data.u8 || !same_buffer(s->out[0], h) || !same_buffer(s->in[1], b) || s->in[1].info.format != s->out[0].info.format) return -1;
-	return run(*s, s->kind == DEFER_CONV_BACKWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD, lock);
+	return run(*s, s->kind == DEFER_CONV_BACKWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD, lock, true);
 }
 
 void deferred_flush(const ccv_nnc_stream_context_t* const ctx)
@@ -233,7 +280,17 @@ void deferred_flush(const ccv_nnc_stream_context_t* const ctx)
 	if (tl_running) return;
 	Lock lock(g_mu);
 	for (int i = 0; i < SLOTS; i++)
-		if (g_slots[i].live && (!ctx || !g_slots[i].ctx || g_slots[i].ctx == ctx)) run(g_slots[i], 0, lock); // (the default stream orders against every other: no context = all)
+		if (g_slots[i].live == RECORDED && orders_against(g_slots[i], ctx)) run(g_slots[i], 0, lock, false);
+	wait_launching(ctx, lock); // what another thread is enqueueing right now is part of the order this caller is about to observe
+}
+
+int deferred_take_error(void)
+{
+	if (!g_sticky_error || tl_running) return 0;
+	Lock lock(g_mu);
+	const int e = g_sticky_error;
+	g_sticky_error = 0;
+	return e;
 }
 
 } // namespace nnc
@@ -243,6 +300,8 @@ extern "C" void nnc_mi355x_set_peephole(const int on)
 	nnc::deferred_flush(0);
 	nnc::g_enabled = on ? 1 : 0;
 }
+
+extern "C" void nnc_mi355x_debug_peephole_launch_delay_us(const int us) { nnc::g_debug_launch_delay_us = us; }
 
 extern "C" void nnc_mi355x_debug_peephole_counts(long* const recorded, long* const folded, long* const plain)
 {

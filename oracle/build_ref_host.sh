@@ -4,7 +4,7 @@
 # GPU integration tests (test/int/nnc/*.tests.c, compiled from where they lie) linked against that host.
 #   oracle/_ref/libccv_host_gpu.so   host + product library          (runs on the MI355X box)
 #   oracle/_ref/libccv_host_emu.so   host + CPU-emulator build       (runs in this container: CPU test tier)
-#   oracle/_ref/int/<name>.gpu|.emu  the reference's int tests; argv[1] = substring filter on the test-case name
+#   oracle/_ref/int/<name>.gpu|.emu  the reference's int tests; argv[1] = filter on the test-case name (a substring; the exact name under NNC_CASE_EXACT, oracle/case_exact.c)
 # The macro names (-DHAVE_CUDA ...) are the reference host's spelling of "a GPU backend is linked in"; no vendor library
 # or header is involved: the host's GPU half is pure C (lib/nnc/gpu/ccv_nnc_compat.h:17-62) and every symbol it needs
 # comes from ccv_amd/csrc (INTEGRATION.md lists them).  Nothing from $REF is copied into the repo.
@@ -30,12 +30,15 @@ fi
 mkdir -p $OUT/int
 TESTS=${TESTS:-"cudnn cublas sgd tensor schedule datatype transform loss reduce adam rmsprop gelu leaky_relu swish smooth_l1 compare index pad upsample lamb random concat cnnp.core dynamic.graph parallel nccl nms roi_align compression"}  # graph.vgg.d / symbolic.graph.vgg.d have no test case without libpng (their bodies are #ifdef HAVE_LIBPNG): nothing to link
 TFLAGS="-O2 -fopenmp -I$REF/lib -I$REF/test -DHAVE_SSE2 -DHAVE_PTHREAD -DUSE_OPENMP -DHAVE_CUDA -DHAVE_CUDNN -DHAVE_NCCL -Wno-everything"
+# exact-name case selection for the reference's runner (oracle/case_exact.c)
+$CC -O2 -fPIC -c $HERE/case_exact.c -o $OUT/int/case_exact.o
+EXACT="-Dstrstr=nnc_case_strstr $OUT/int/case_exact.o"
 for t in $TESTS; do
   src=$REF/test/int/nnc/$t.tests.c
   [ -f $src ] || continue
-  $CC $TFLAGS $src -o $OUT/int/$t.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
+  $CC $TFLAGS $EXACT $src -o $OUT/int/$t.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
   if [ -f $OUT/libccv_host_emu.so ]; then
-    $CC $TFLAGS $src -o $OUT/int/$t.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
+    $CC $TFLAGS $EXACT $src -o $OUT/int/$t.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
   fi
 done
 # 3b. the VGG-D training step through the reference host (tools/host_vgg_bench.c: our client of the reference's public API;

@@ -146,6 +146,28 @@ def test_half_view_output_keeps_what_it_does_not_write(backend, ref_lib):
     assert np.array_equal(out, want)
 
 
+def test_half_sibling_view_outputs_do_not_clobber_each_other(backend):
+    """two output VIEWS of one half-precision parent (channel-concatenated branches): each is written back element by element
+    through its own strides.  Writing a view back as its whole span rewrote the sibling's elements with what had been loaded before the
+    command ran -- here the second write-back would have undone the first."""
+    L = backend
+    rng = np.random.default_rng(14)
+    g = hrnd(rng, 5, 6)
+    parent = hrnd(rng, 5, 12)
+    gt = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, nnc.CCV_16F, g.shape, 0), g)
+    pt = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, nnc.CCV_16F, parent.shape, 0), parent)
+    left, right = pt.view((5, 6), (12, 1), 0), pt.view((5, 6), (12, 1), 6)
+    assert L.cmd_exec(nnc.CMD_ADD_BACKWARD(0.5, 2.0), nnc.NO_HINT, 0, [gt], [left, right]) == 0
+    out = pt.numpy()
+    want = np.concatenate([(g.astype(F) * F(0.5)).astype(H), (g.astype(F) * F(2.0)).astype(H)], axis=1)
+    assert np.array_equal(out, want)
+    # one view at a time, the other half untouched
+    pt2 = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, nnc.CCV_16F, parent.shape, 0), parent)
+    assert L.cmd_exec(nnc.CMD_ADD_FORWARD(1, 2), nnc.NO_HINT, 0, [gt, gt], [pt2.view((5, 6), (12, 1), 6)]) == 0
+    out2 = pt2.numpy()
+    assert np.array_equal(out2[:, :6], parent[:, :6]) and np.array_equal(out2[:, 6:], (g.astype(F) * F(3.0)).astype(H))
+
+
 CONV_H = [
     # n, h, w, c, k, kh, kw, stride, border, groups, native
     (2, 9, 10, 8, 16, 3, 3, (1, 1), (1, 1), 1, True),

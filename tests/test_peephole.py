@@ -239,3 +239,42 @@ def test_half_precision_pairs_fold_to_the_same_halves(lib, fmt):
     assert want.dtype == H and (want == 0).any() and (want > 0).any()
     for g in got:
         assert np.array_equal(g, want)
+
+
+def test_foreign_thread_flush_does_not_let_the_relu_overtake(lib, ref_lib):
+    """every copy / free / signal hook flushes ALL streams' recorded commands from whatever thread called it.  While a loader
+    thread is still enqueueing this stream's recorded convolution (the window is widened with the debug delay), the training thread's in-place
+    ReLU must wait for it instead of finding no slot and running ahead -- the result is the rectified convolution, folded or not."""
+    import threading
+    import time
+    rng = np.random.default_rng(11)
+    n, h, w, c, k = 2, 9, 10, 16, 32
+    a, wt, b = srnd(rng, n, h, w, c), srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c)), srnd(rng, k, scale=0.05)
+    hint = nnc.HINT((1, 1), (1, 1))
+    cmd, relu = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c), nnc.CMD_RELU_FORWARD()
+    _, (conv,) = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [a, wt, b], [np.zeros((n, h, w, k), F)], backend=nnc.BACKEND_CPU_REF)
+    assert (conv < 0).any()
+    ins = make_tensors(lib, nnc.GPU_MEMORY, [a, wt, b])
+    stream = lib.stream_new(0)
+    try:
+        (out,) = make_tensors(lib, nnc.GPU_MEMORY, [np.full((n, h, w, k), -9, F)])
+        assert lib.cmd_exec(cmd, hint, 0, ins, [out], stream) == 0      # first occurrence: on the spot
+        assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [out], [out], stream) == 0
+        lib.stream_wait(stream)
+        for trip in range(3):
+            (out,) = make_tensors(lib, nnc.GPU_MEMORY, [np.full((n, h, w, k), -9, F)])
+            r0, f0, p0 = counts(lib)
+            assert lib.cmd_exec(cmd, hint, 0, ins, [out], stream) == 0  # recorded
+            assert counts(lib)[0] == r0 + 1
+            lib.dll.nnc_mi355x_debug_peephole_launch_delay_us(300000)
+            loader = threading.Thread(target=lambda: make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(16, F)]))  # a host-to-device copy: flushes every stream's slot
+            loader.start()
+            time.sleep(0.1)                                              # the loader is inside the launch window now
+            assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [out], [out], stream) == 0
+            loader.join()
+            lib.dll.nnc_mi355x_debug_peephole_launch_delay_us(0)
+            lib.stream_wait(stream)
+            np.testing.assert_allclose(out.numpy(), np.maximum(conv, 0), rtol=1e-4, atol=1e-5)
+    finally:
+        lib.dll.nnc_mi355x_debug_peephole_launch_delay_us(0)
+        lib.stream_free(stream)
