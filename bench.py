@@ -187,6 +187,43 @@ def emit(out):
     _RESULT.flush()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): this process becomes the launcher -- one rank per GPU, each a
+    fresh `python bench.py <same arguments>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set the way torch.distributed.run sets them (the ranks
+    rendezvous over ccv_amd/ctl.py's Unix socket, named after MASTER_PORT and the run id; RCCL is bootstrapped from rank 0's id).  Fails loudly when
+    fewer devices are visible than ranks were asked for.  Rank 0's JSON line is the run's; any rank failing takes the run down with its code.
+    The driver's contract launches N ranks itself; this covers the other spelling so that a SCALE record can never silently be a 1-GPU number."""
+    import socket
+    import subprocess
+    L = nnc.load()
+    have = L.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, have))
+    with socket.socket() as s:  # a free port: names the control socket (and is what a launcher would have passed)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    run_id = "self%d_%d" % (os.getpid(), int(time.time()))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TORCHELASTIC_RUN_ID=run_id, NNC_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=_RESULT.fileno() if r == 0 else 2))
+    rc = 0
+    for r, p in enumerate(procs):
+        try:
+            code = p.wait(timeout=3000)
+        except subprocess.TimeoutExpired:
+            code = -9
+        if code != 0 and rc == 0:
+            rc = code
+            print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()  # (exactly the processes started above)
+    if rc != 0:
+        raise SystemExit(rc if rc > 0 else 1)
+
+
 def main():
     claim_stdout()
     ap = argparse.ArgumentParser()
@@ -211,15 +248,16 @@ def main():
     if args.config.startswith("cifar10") and args.batch == 256:
         args.batch = 512
     if args.config.startswith("resnet50") or args.config.startswith("cifar10"):
-        if world > 1:  # started under torch.distributed.run: this path is ONE process driving all the GPUs (the reference host's own data parallelism)
-            if rank != 0:
-                return
-            if args.config.startswith("cifar10"):
-                raise SystemExit("--config %s is a one-GPU line" % args.config)
-        nnc.load()  # fail loudly without the HIP library / a GPU
+        if world > 1 and rank != 0:  # started under torch.distributed.run: this path is ONE process driving all the GPUs (the reference host's own data parallelism)
+            return
+        have = nnc.load().device_count()  # fail loudly without the HIP library / a GPU
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, have))
         return resnet_config(args, "f16" in args.config, dawn=args.config.startswith("cifar10"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if (args.gpus > 1 or os.environ.get("NNC_BENCH_FORCE_SELF_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # (FORCE_SELF_LAUNCH: the launcher path at N = 1, for the one-GPU test box)
 
     L = nnc.load()  # raises without the HIP library / a GPU: there is no fallback path
     L.set_device(local_rank)
@@ -399,6 +437,9 @@ def main():
                                "traffic": traffic, "kernel": name, "launches": cnt, "avg_ms": ms / cnt,
                                "all_contractions": {"achieved": total_fl / (total_ms * 1e-3) / 1e12, "ms": total_ms,
                                                     "by_kernel": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
+        if comm is not None:
+            out["config"]["rccl_ranks"] = int(L.dll.nnc_mi355x_comm_count())  # ncclCommCount of the communicator the gradients went through
+            out["config"]["launcher"] = "self (bench.py started the ranks)" if os.environ.get("NNC_BENCH_SELF_LAUNCHED") == "1" else "external (torch.distributed.run)"
         if dp_check is not None:
             out["config"]["data_parallel_check"] = dp_check
             if not dp_check.get("ok"):

@@ -218,6 +218,14 @@ int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size
 	pthread_mutex_unlock(&g_comm_mutex);
 	return ret;
 }
+int nnc_mi355x_comm_count(void)
+{ // ranks of the process communicator (deployment (b)), as RCCL itself counts them; 0 = none
+	pthread_mutex_lock(&g_comm_mutex);
+	int n = 0;
+	if (g_rank_comm && ncclCommCount(g_rank_comm, &n) != ncclSuccess) n = -1;
+	pthread_mutex_unlock(&g_comm_mutex);
+	return n;
+}
 void nnc_mi355x_comm_stats(long* collectives, long* groups)
 {
 	pthread_mutex_lock(&g_comm_mutex);

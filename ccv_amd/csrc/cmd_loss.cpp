@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(256) softmax_ce_forw_kernel(const float* a, co
 			p = wave_sum_f(p);
 		} else {
 			const int lb = label_kind == LABEL_F32_INDEX ? (int)(((const float*)label)[row] + 0.5f) : ((const int*)label)[row];
-			if (trim0 == 0.f && trim1 == 1.f) p = m - ap[lb];
+			// a label outside [0, count) is an assert in the reference (softmax_crossentropy_cpu_ref.c); here it must not become a read outside
+			// the row: the loss of that row is NaN, which no caller can mistake for a result
+			if (trim0 == 0.f && trim1 == 1.f) p = (unsigned)lb < (unsigned)count ? m - ap[lb] : __builtin_nanf("");
 			else {
 				for (int j = lane; j < count; j += 64) p += (j == lb ? trim1 : trim0) * (m - ap[j]);
 				p = wave_sum_f(p);

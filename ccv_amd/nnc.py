@@ -34,7 +34,7 @@ CMD = dict(
     BATCH_NORM_FORWARD=0x5419819c, BATCH_NORM_BACKWARD=0x5419819d,
     CLAMP_FORWARD=0x2640d854, CLAMP_BACKWARD=0x2640d855,
     COMM_ALLREDUCE_FORWARD=0x75c8d340, COMM_BROADCAST_FORWARD=0x830eee, COMM_REDUCE_FORWARD=0x3434ead8,
-    CONVOLUTION_FORWARD=0x254d05f4, CONVOLUTION_BACKWARD=0x254d05f5,
+    CONVOLUTION_FORWARD=0x254d05f4, CONVOLUTION_BACKWARD=0x254d05f5, CONVOLUTION_TRANSPOSE_FORWARD=0xd691f78e,
     DATATYPE_CONVERSION_FORWARD=0xd873e38c, DATA_TRANSFER_FORWARD=0x12d21e1a, DATA_TRANSFER_BACKWARD=0x12d21e1b,
     EWDIV_FORWARD=0x1cd2fa18, EWDIV_BACKWARD=0x1cd2fa19, EWEXP_FORWARD=0xd784b170, EWEXP_BACKWARD=0xd784b171,
     EWLOG_FORWARD=0xf4191bf2, EWLOG_BACKWARD=0xf4191bf3, EWPROD_FORWARD=0xee07e8fe, EWPROD_BACKWARD=0xee07e8ff,
@@ -96,6 +96,10 @@ class _Size(C.Structure):
 
 class _Conv(C.Structure):
     _fields_ = [("count", C.c_int), ("groups", C.c_int), ("dilation", C.c_int * MAX_DIM_ALLOC)]
+
+
+class _ConvTranspose(C.Structure):  # ccv_nnc.h:121-126: the convolution block + output_padding
+    _fields_ = [("count", C.c_int), ("groups", C.c_int), ("dilation", C.c_int * MAX_DIM_ALLOC), ("output_padding", C.c_int)]
 
 
 class _Bnorm(C.Structure):
@@ -167,7 +171,7 @@ class _I1(C.Structure):   # mse.reduce_op
 
 
 class _CmdUnion(C.Union):
-    _fields_ = [("convolution", _Conv), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
+    _fields_ = [("convolution", _Conv), ("convolution_transpose", _ConvTranspose), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
                 ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
                 ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("upsample", _Upsample), ("lnorm", _Lnorm), ("gnorm", _Gnorm), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
@@ -220,6 +224,16 @@ def CMD_CONVOLUTION_FORWARD(groups, count, *size, dilation=None):
     c.info.convolution.count, c.info.convolution.groups = count, groups
     if dilation:
         c.info.convolution.dilation[0], c.info.convolution.dilation[1] = dilation
+    return c
+
+
+def CMD_CONVOLUTION_TRANSPOSE_FORWARD(groups, count, output_padding, *size, dilation=None):
+    """CMD_CONVOLUTION_TRANSPOSE_FORWARD(_groups, _count, _output_padding, kh, kw, c) (lib/nnc/cmd/ccv_nnc_cmd_easy.h:58)."""
+    c = _cmd("CONVOLUTION_TRANSPOSE_FORWARD", size)
+    t = c.info.convolution_transpose
+    t.count, t.groups, t.output_padding = count, groups, output_padding
+    if dilation:
+        t.dilation[0], t.dilation[1] = dilation
     return c
 
 

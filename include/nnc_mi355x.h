@@ -341,6 +341,8 @@ int nnc_mi355x_cmd_ok(const uint32_t cmd, const uint32_t backend); /* ccv_nnc_cm
 int nnc_mi355x_comm_unique_id(void* id_out_128_bytes);
 int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size);
 void nnc_mi355x_comm_destroy(void);
+/* Ranks of the process communicator as RCCL counts them (ncclCommCount); 0 before nnc_mi355x_comm_init_rank.  bench.py prints it as `rccl_ranks`. */
+int nnc_mi355x_comm_count(void);
 /* Counters of the COMM commands' coalescing (cmd_comm.cpp): per-device collectives issued so far, and the RCCL groups they
  * travelled in (consecutive COMM commands share one group). */
 void nnc_mi355x_comm_stats(long* collectives, long* groups);

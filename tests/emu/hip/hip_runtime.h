@@ -87,6 +87,10 @@ template <typename T> static inline T emu_shfl_from(T v, int src)
 	return r;
 }
 template <typename T> static inline T __shfl(T v, int src, int width = 64) { const int l = emu::lane(); return emu_shfl_from(v, (l / width) * width + (src % width)); }
+// separately rounded fp32 operations (no contraction into fma)
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) { return emu_shfl_from(v, emu::lane() ^ mask); }
 template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) { const int l = emu::lane(); const int s = l + (int)d; return emu_shfl_from(v, ((s / width) == (l / width)) ? s : l); }
 template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) { const int l = emu::lane(); const int s = l - (int)d; return emu_shfl_from(v, (s >= 0 && (s / width) == (l / width)) ? s : l); }

@@ -42,6 +42,7 @@ static inline ncclResult_t emu_nccl_post(ncclComm_t c, int kind, const void* s, 
 static inline ncclResult_t ncclCommInitAll(ncclComm_t* comms, int n, const int*) { emu_nccl_clique* q = new emu_nccl_clique; q->n = n; q->pending.resize(n); q->posted.assign(n, 0); for (int i = 0; i < n; i++) comms[i] = new emu_nccl_comm{q, i}; return ncclSuccess; }
 static inline ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { memset(id, 0x5a, sizeof(*id)); return ncclSuccess; }
 static inline ncclResult_t ncclCommInitRank(ncclComm_t* comm, int n, ncclUniqueId, int rank) { if (n != 1 || rank != 0) return ncclInvalidUsage; return ncclCommInitAll(comm, 1, 0); }
+static inline ncclResult_t ncclCommCount(const ncclComm_t c, int* n) { *n = c->clique->n; return ncclSuccess; }
 static inline ncclResult_t ncclCommDestroy(ncclComm_t c) { delete c; return ncclSuccess; }
 static inline ncclResult_t ncclGroupStart() { return ncclSuccess; }
 static inline ncclResult_t ncclGroupEnd() { return ncclSuccess; }

@@ -25,3 +25,36 @@ def test_stdout_carries_exactly_the_json_line():
     lines = r.stdout.splitlines()
     assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "m", "value": 1.5}, r.stdout
     assert "banner from a C library" in r.stderr and "raw write" in r.stderr and "python print" in r.stderr
+
+
+def test_gpus_n_without_devices_fails_loudly():
+    """`python bench.py --gpus 2` on a box without (enough) GPUs must not print a line for fewer GPUs than asked: non-zero exit, nothing on stdout."""
+    if os.path.exists("/dev/kfd"):
+        import pytest
+        pytest.skip("a GPU box: covered by the gpu-tier self-launch test")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "", (r.returncode, r.stdout)
+    assert "HIP device" in r.stderr or "not built" in r.stderr, r.stderr[-1000:]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_self_launched_ranks_on_this_box():
+    """`python bench.py --gpus N` with no launcher starts its own N ranks (one per GPU, RCCL communicator of N, rendezvous over
+    ccv_amd/ctl.py).  N = the devices this box has (1 on the test box: the launcher path is forced, the rank goes through the whole N > 1 code -- RCCL
+    id hand-over, parameter broadcast, bucketed overlapped all-reduce, the exchange check); asking for one GPU more than there are is refused."""
+    from ccv_amd import nnc
+    n = nnc.load().device_count()
+    env = dict(os.environ, NNC_BENCH_FORCE_SELF_LAUNCH="1", NNC_BENCH_FORCE_COMM="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-via-host", "--no-alt-leg"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["config"]["rccl_ranks"] == n and out["config"]["launcher"].startswith("self")
+    assert out["config"]["data_parallel_check"]["ok"], out["config"]["data_parallel_check"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--batch", "16"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "visible" in r.stderr

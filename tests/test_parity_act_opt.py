@@ -166,6 +166,20 @@ def _reduce_cmd(name, *axis):
     return c
 
 
+@pytest.mark.parametrize("name", ["REDUCE_SUM_FORWARD", "REDUCE_MEAN_FORWARD", "REDUCE_NORM2_FORWARD"])  # (REDUCE_MAX / MIN have no GPU row in the host's table, cmd_bcast.cpp)
+@pytest.mark.parametrize("shape,axis", [((3, 5000), (1,)), ((70, 90, 2), (0, 1)), ((9000,), (0,))])
+def test_large_reductions_take_the_two_stage_path(backend, ref_lib, name, shape, axis):
+    """>= 4096 reduced elements per output: workgroups fold slices of the reduced sub-space, a second kernel folds the slices (cmd_bcast.cpp;
+    the serial one-lane-per-output kernel keeps the small cases in the reference's order).  Sums to 1e-5 of the sum of magnitudes."""
+    a = _x(shape, 23, 2.0)
+    oshape = tuple(1 if i in axis else d for i, d in enumerate(shape))
+    got, want = exec_pair(backend, ref_lib, _reduce_cmd(name, *axis), nnc.NO_HINT, 0, [a], [np.zeros(oshape, F)])
+    scale = float(np.abs(a).sum(axis=axis).max()) if "NORM2" not in name else float(np.sqrt((a.astype(np.float64) ** 2).sum(axis=axis)).max())
+    if "MEAN" in name:
+        scale /= np.prod([shape[i] for i in axis])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-5 * scale)
+
+
 @pytest.mark.parametrize("shape,axis", [((4, 5, 6), (1,)), ((3, 7), (0,)), ((2, 3, 4, 5), (0, 2)), ((6, 9), (0, 1))])
 def test_reduce_norm2(backend, ref_lib, shape, axis):
     a = _x(shape, 21, 2.0)

@@ -196,6 +196,46 @@ def test_conv_winograd_matches_implicit_gemm_at_vgg_sizes(gpu_lib, shape):
         assert float(np.abs(res[0][i] - res[1][i]).max()) <= 1e-4 * scale, (i, scale)
 
 
+# CONVOLUTION_TRANSPOSE_FORWARD (a registered row without a test).  a [n][oh][ow][Ca] is scattered through w [Ca][kh][kw][count / groups]
+# into b [n][H][W][count], where (H, W) -> (oh, ow) is the convolution the hint describes (convolution/ccv_nnc_conv_transpose_cpu_ref.c:13-; the
+# reference's GPU cases: test/int/nnc/cudnn.tests.c:5338-5500, 7 x 7 stride 2 on 224 x 224, tolerance 2e-4 there).
+#               n, H,  W,  count, Ca, k, stride, border, groups, dilation, bias, fmt
+CONVT_CASES = [(2, 9,  9,  16,    8,  3, 1,      1,      1,      1,        True,  "NHWC"),
+               (2, 13, 13, 3,     6,  7, 2,      3,      1,      1,        True,  "NHWC"),   # the reference case's geometry, small
+               (3, 8,  10, 8,     16, 2, 2,      0,      2,      1,        False, "NHWC"),   # the up-sampling deconvolution, two groups
+               (2, 9,  11, 12,    8,  3, 2,      1,      1,      1,        True,  "NCHW"),
+               (1, 12, 12, 8,     4,  3, 1,      2,      1,      2,        True,  "NHWC")]   # dilated taps
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=[str(c) for c in CONVT_CASES])
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
+def test_conv_transpose_forward(backend, ref_lib, case, half):
+    n, H, W, count, ca, k, stride, border, groups, dil, with_bias, fmt = case
+    rng = np.random.default_rng(7)
+    ke = (k - 1) * dil + 1
+    oh, ow = (H + 2 * border - ke) // stride + 1, (W + 2 * border - ke) // stride + 1
+    cg = count // groups
+    a = srnd(rng, n, oh, ow, ca)
+    w = srnd(rng, ca, k, k, cg, scale=1.0 / (k * k * ca))
+    bias = srnd(rng, count, scale=0.5) if with_bias else None
+    out = np.zeros((n, H, W, count), F)
+    if fmt == "NCHW":
+        a, w, out = a.transpose(0, 3, 1, 2).copy(), w.transpose(0, 3, 1, 2).copy(), out.transpose(0, 3, 1, 2).copy()
+    cmd = nnc.CMD_CONVOLUTION_TRANSPOSE_FORWARD(groups, count, 0, k, k, ca, dilation=(dil, dil) if dil > 1 else None)
+    hint = nnc.HINT((stride, stride), (border, border))
+    if half:  # the oracle runs in fp32 on the half-rounded inputs (tests/test_half.py's rule); bound 5e-3 as the reference's half case (cudnn.tests.c:5500)
+        a, w = a.astype(np.float16), w.astype(np.float16)
+        bias = bias.astype(np.float16) if bias is not None else None
+        r1, (got,) = exec_on(backend, nnc.GPU_MEMORY, cmd, hint, 0, [a, w, bias], [out.astype(np.float16)], fmt)
+        r2, (want,) = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, hint, 0, [a.astype(F), w.astype(F), None if bias is None else bias.astype(F)], [out], fmt, backend=nnc.BACKEND_CPU_REF)
+        assert r1 == 0 and r2 == 0 and got.dtype == np.float16
+        np.testing.assert_allclose(got.astype(F), want, rtol=0, atol=5e-3 * max(1.0, float(np.abs(want).max())))
+        return
+    got, want = exec_pair(backend, ref_lib, cmd, hint, 0, [a, w, bias], [out], fmt)
+    assert np.abs(want).max() > 0.01
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
 def test_conv_backward_partial_outputs(backend, ref_lib):
     case = CONV_CASES[0]
     n, h, w, c, k, kh, kw, stride, border, groups, dil, bias = case

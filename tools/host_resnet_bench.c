@@ -227,7 +227,7 @@ int main(int argc, char** argv)
 	 * replicas whose gradients are really summed hold the same parameters either way, so a shard's outputs must not depend on
 	 * which device it ran on. */
 	const int rot = argc > 8 ? atoi(argv[8]) : 0;
-	if (devices < 1 || devices > 8 || (devices > 1 && is_dawn)) { fprintf(stderr, "devices must be 1..8 (fit path only)\n"); return 2; }
+	if (devices < 1 || devices > 8) { fprintf(stderr, "devices must be 1..8\n"); return 2; }
 #ifdef HOST_BENCH_CPU
 	g_nhwc = 1;
 #else
@@ -242,7 +242,7 @@ int main(int argc, char** argv)
 	ccv_nnc_tensor_param_t input = tensor4(DEV_TENSOR_NCHW(batch, 3, hw, hw), batch, 3, hw, hw);
 	input.datatype = dt;
 	const float lr = 0.01f, wd = 0.0001f;
-	if (is_dawn) ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / batch, 0.01, 0.9, 0), CMD_NOOP());
+	if (is_dawn) ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / (batch * devices), 0.01, 0.9, 0), CMD_NOOP());
 	else ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / (batch * devices), wd, 0.9, 0), CMD_CATEGORICAL_CROSSENTROPY_FORWARD());
 	if (devices > 1) ccv_cnnp_model_set_data_parallel(model, devices);
 	/* synthetic batch: images ~ U(-1, 1) (normalised pixels), labels as the trainer's smoothed one-hot rows (eta = 0.1) */
@@ -349,29 +349,50 @@ int main(int argc, char** argv)
 		}
 	}
 	/* dawn: the CIFAR trainer's step (cifar-10.c:259-273); labels are class indices in fp32, the softmax / gradient tensors have the outputs' type */
-	ccv_nnc_tensor_t* const labels = ccv_nnc_tensor_new(0, DEV_TENSOR_NCHW(batch), 0);
-	ccv_nnc_tensor_t* const softmax = ccv_nnc_tensor_new(0, fp, 0);
-	ccv_nnc_tensor_t* const grad = ccv_nnc_tensor_new(0, fp, 0);
+	ccv_nnc_tensor_t* labels_d[8]; ccv_nnc_tensor_t* softmax_d[8]; ccv_nnc_tensor_t* grad_d[8];
 	{
 		ccv_nnc_tensor_t* const hl = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch), 0);
-		for (i = 0; i < batch; i++) hl->data.f32[i] = (float)(int)(hash_unit(i, 2001) * classes);
-		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hl), TENSOR_LIST(labels), 0);
+		int d;
+		for (d = 0; d < devices; d++) {
+			ccv_nnc_tensor_param_t lp = DEV_TENSOR_NCHW(batch), sp = fp;
+			CCV_TENSOR_SET_DEVICE_ID(lp.type, d); CCV_TENSOR_SET_DEVICE_ID(sp.type, d);
+			labels_d[d] = ccv_nnc_tensor_new(0, lp, 0); softmax_d[d] = ccv_nnc_tensor_new(0, sp, 0); grad_d[d] = ccv_nnc_tensor_new(0, sp, 0);
+			const int shard = (d + rot) % devices;
+			for (i = 0; i < batch; i++) hl->data.f32[i] = (float)(int)(hash_unit(i, 2001 + 10 * shard) * classes);
+			ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hl), TENSOR_LIST(labels_d[d]), 0);
+		}
 		ccv_nnc_tensor_free(hl);
 	}
+	ccv_nnc_tensor_t* const labels = labels_d[0];
+	ccv_nnc_tensor_t* const softmax = softmax_d[0];
+	ccv_nnc_tensor_t* const grad = grad_d[0];
+	/* N devices: the CIFAR trainer's own spelling (cifar-10.c:259-273) -- every call without a stream, the loss commands once per device on that
+	 * device's tensors, ccv_cnnp_model_backward over the N gradients; the host all-reduces the parameter gradients (COMM_ALLREDUCE rows) */
+	ccv_nnc_stream_context_t* const step_stream = (is_dawn && devices > 1) ? 0 : stream;
+	/* end of a timed region: the stream, and -- the N-device DawnNet step runs without one -- every device's legacy stream (a blocking device-to-host
+	 * copy of a few bytes per device orders behind everything queued there) */
+	ccv_nnc_tensor_t* const sync_host = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch), 0);
+#define SYNC_ALL() do { \
+		ccv_nnc_stream_context_wait(stream); \
+		if (!step_stream) { int d_; for (d_ = 0; d_ < devices; d_++) ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(labels_d[d_]), TENSOR_LIST(sync_host), 0); } \
+	} while (0)
 #define TRAIN_STEP() do { \
 		if (is_dawn) { \
-			ccv_cnnp_model_evaluate(model, (ccv_cnnp_evaluate_param_t){ .requires_grad = 1, .disable_outgrad = CCV_CNNP_DISABLE_OUTGRAD_ALL }, TENSOR_LIST(x), TENSOR_LIST(out), 0, stream); \
-			ccv_nnc_cmd_exec(CMD_SOFTMAX_CROSSENTROPY_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(out, labels), TENSOR_LIST(0, softmax), stream); \
-			ccv_nnc_cmd_exec(CMD_SOFTMAX_CROSSENTROPY_BACKWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(0, 0, out, labels, 0, softmax), TENSOR_LIST(grad, 0), stream); \
-			ccv_cnnp_model_backward(model, TENSOR_LIST(grad), TENSOR_LIST(), 0, stream); \
-			ccv_cnnp_model_apply_gradients(model, stream); \
+			int d_; \
+			ccv_cnnp_model_evaluate(model, (ccv_cnnp_evaluate_param_t){ .requires_grad = 1, .disable_outgrad = CCV_CNNP_DISABLE_OUTGRAD_ALL }, xs, devices, outs, devices, 0, step_stream); \
+			for (d_ = 0; d_ < devices; d_++) { \
+				ccv_nnc_cmd_exec(CMD_SOFTMAX_CROSSENTROPY_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(outs[d_], labels_d[d_]), TENSOR_LIST(0, softmax_d[d_]), step_stream); \
+				ccv_nnc_cmd_exec(CMD_SOFTMAX_CROSSENTROPY_BACKWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(0, 0, outs[d_], labels_d[d_], 0, softmax_d[d_]), TENSOR_LIST(grad_d[d_], 0), step_stream); \
+			} \
+			ccv_cnnp_model_backward(model, grad_d, devices, TENSOR_LIST(), 0, step_stream); \
+			ccv_cnnp_model_apply_gradients(model, step_stream); \
 		} else \
 			ccv_cnnp_model_fit(model, xs, devices, fits, devices, outs, devices, 0, stream); \
 	} while (0)
 	/* step 1: compiles the graph (autodiff, simplify, arena, schedule) and initialises the parameters */
 	const double t_first0 = now_ms();
 	TRAIN_STEP();
-	ccv_nnc_stream_context_wait(stream);
+	SYNC_ALL();
 	const double t_first = now_ms() - t_first0;
 	/* the first step's softmax outputs: finite, rows summing to one (read back in fp32) */
 	ccv_nnc_tensor_t* const hout = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, classes), 0);
@@ -455,10 +476,10 @@ int main(int argc, char** argv)
 		return 0; /* the check line is the whole output: nothing is timed in this mode */
 	}
 	for (i = 1; i < warmup; i++) TRAIN_STEP();
-	ccv_nnc_stream_context_wait(stream);
+	SYNC_ALL();
 	const double t0 = now_ms();
 	for (i = 0; i < steps; i++) TRAIN_STEP();
-	ccv_nnc_stream_context_wait(stream);
+	SYNC_ALL();
 	const double ms = (now_ms() - t0) / (steps > 0 ? steps : 1);
 	/* per device: sum and sum of squares of the softmax outputs of the last timed step (replicas fed the same shard must agree
 	 * exactly, and -- the all-reduced gradient of identical shards being the single-device gradient -- with a one-device run) */
@@ -479,7 +500,7 @@ int main(int argc, char** argv)
 	/* roofline leg: one more step with the backend's per-launch HIP-event records on (contractions and batch norm) */
 	nnc_mi355x_profile_enable(1);
 	TRAIN_STEP();
-	ccv_nnc_stream_context_wait(stream);
+	SYNC_ALL();
 	struct { char name[192]; double ms, flops, bytes; int n; } agg[64];
 	int nagg = 0;
 	const int nrec = nnc_mi355x_profile_count();
@@ -508,10 +529,9 @@ int main(int argc, char** argv)
 		"\"devices\": %d, \"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"first_step_ms\": %.1f, \"softmax_row0_sum\": %.6f, \"softmax_worst_row_sum_err\": %.3g, \"outputs_finite\": %s, \"memory_gib\": %.3f}\n",
 		is_dawn ? "CIFAR-10 DawnNet (bin/nnc/cifar-10.c)" : mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, devices, ms, (double)batch * devices / (ms * 1e-3), t_first, row0, worst, finite ? "true" : "false",
 		(double)ccv_cnnp_model_memory_size(model) / (1024.0 * 1024.0 * 1024.0));
-	ccv_nnc_tensor_free(labels);
-	ccv_nnc_tensor_free(softmax);
-	ccv_nnc_tensor_free(grad);
+	for (i = 0; i < devices; i++) { ccv_nnc_tensor_free(labels_d[i]); ccv_nnc_tensor_free(softmax_d[i]); ccv_nnc_tensor_free(grad_d[i]); }
 	ccv_nnc_tensor_free(hout);
+	ccv_nnc_tensor_free(sync_host);
 	ccv_nnc_tensor_free(hx);
 	ccv_nnc_tensor_free(hfit);
 	for (i = 0; i < devices; i++) { ccv_nnc_tensor_free(xs[i]); ccv_nnc_tensor_free(fits[i]); ccv_nnc_tensor_free(outs[i]); }
