@@ -38,7 +38,7 @@ for step in "$@"; do
     prof:*) n=${step#prof:}; prof_cmd $n python "$PWD/bench.py" --config $n --steps 2 --warmup 1 ${PROF_ARGS}; head -40 gpurun_out/kernel_stats_$n.md;;
     profhost) NNC_MI355X_PEEPHOLE_STATS=1 prof_cmd host "$PWD/oracle/_ref/host_vgg_bench.gpu" 256 225 4 1; cp gpurun_out/kernel_stats_host.md gpurun_out/via_host_kernel_stats.md 2>/dev/null; grep -i "look-ahead" gpurun_out/prof_host.log;;
     pmc) timeout 2400 tools/pmc_pass.sh;;
-    int:*) s=${step#int:}; timeout 1800 python tools/ref_int_tests.py run gpu $s --timeout 180 ${INT_MATCH:+--match "$INT_MATCH"} --out gpurun_out/ref_int_$s.txt | tail -25;;
+    int:*) s=${step#int:}; timeout 1800 python tools/ref_int_tests.py run gpu $s --timeout 180 ${INT_MATCH:+--match "$INT_MATCH"} --out "gpurun_out/ref_int_${s}${INT_MATCH:+_$(echo "$INT_MATCH" | tr -c "a-zA-Z0-9" _)}.txt" | tail -25;;
     run:*) f=${step#run:}; b=$(basename $f .py); timeout ${RUN_TIMEOUT:-900} python $f ${RUN_ARGS} > gpurun_out/$b.log 2>&1; echo "exit $?" >> gpurun_out/$b.log; tail -40 gpurun_out/$b.log;;
     *) echo "unknown step $step";;
   esac
