@@ -216,6 +216,54 @@ constexpr __host__ __device__ int wf_piece_at(int it)
 	return -1;
 }
 
+// ---- the PAIRED patch schedule (round 3; a NEGATIVE result, kept for tools/wf_probe.cpp -- the library does not instantiate it) -------------
+// Hypothesis (round 2's reading of the knock-out probe): the loop is bound by L2 -> L1 line fills -- a chunk is 8 channels = a 32-byte run of a
+// 128-byte line, and the next chunk's run of the same line is fetched a whole trip (~200 KB of other fills) later, so every patch line enters L1
+// four times.  Measured on the MI355X (profiles/r03_v2_wf_probe_paired_schedule.txt): conv1_2 4.15 ms paired vs 3.37 classic, conv2_2 3.52 vs 2.85.
+// Fetching the two halves of a 64-byte run back to back means 22 patch pieces in 11 consecutive iterations on all four waves at once, and what the
+// loop is really bound by is the CU's vector-memory ISSUE rate: one 1 KB wave-instruction (DMA piece or 16-byte store alike) per ~60-80 cycles per
+// CU whatever it touches; a queue of them blocks the in-order wave, MFMAs included.  The classic schedule's even pacing (one piece per 1.8
+// iterations per wave) is what that limit wants; 80 pieces per 4608-cycle trip plus 128 stores per item leave this decomposition ~15 % above its
+// vector-memory floor.  The schedule itself:  The 160 KB of LDS do not hold 16-channel chunks double-buffered,
+// but they do not have to: the two 11 KB patch buffers of a wave become sub-chunk 0 / sub-chunk 1 of ONE 16-channel chunk, fetched TOGETHER --
+// piece q of sub-chunk 0 (A_q) and piece q of sub-chunk 1 (B_q: the same pixels, soffset + 32 bytes) back to back, so the second finds the
+// line the first brought in.  Single-buffered, which the dependences allow: a trip only reads the NEXT sub-chunk's buffer, late (iterations
+// 23..32), so over a pair of trips (time t = 36 * half + iteration)
+//   t = 34 .. 44          A_0 .. A_10 -> buffer 0 (free since the previous trip's transform), slot k = 1
+//   t = 34 + SKEW ..      B_0 .. B_10 -> buffer 1 (free once the even trip has read it: last read t = 32), slot k = 3
+//   t = 0, 3 .. 24        the even trip's nine U pieces (for the odd trip), slot k = 2;  t = 46, 48 .. 62 the odd trip's (for the next even trip)
+// and the odd trip's transform (t = 59 on) waits for the A pieces with a counted wait.  Same pieces, same count, same LDS: only WHEN they fly.
+// Piece code: -1 none, q patch A_q, 16 + q patch B_q, 32 + n U piece n.
+template <int SKEW>
+struct WfPair {
+	static constexpr __host__ __device__ int at(int half, int it, int k)
+	{
+		const int t = half * 36 + it;
+		if (k == 1) return (t >= 34 && t <= 44) ? t - 34 : -1;
+		if (k == 3) return (t - SKEW >= 34 && t - SKEW <= 44) ? 16 + (t - SKEW - 34) : -1;
+		if (k == 2) {
+			if (half == 0) return (t % 3 == 0 && t / 3 < 9) ? 32 + t / 3 : -1;
+			return (t >= 46 && (t - 46) % 2 == 0 && (t - 46) / 2 < 9) ? 32 + (t - 46) / 2 : -1;
+		}
+		return -1;
+	}
+	// pieces issued strictly after (t0, k0) and strictly before (t1, k1)
+	static constexpr __host__ __device__ int issued_between(int t0, int k0, int t1, int k1)
+	{
+		int n = 0;
+		for (int t = t0; t <= t1 && t < 72; t++)
+			for (int k = 0; k < 4; k++) {
+				if (t == t0 && k <= k0) continue;
+				if (t == t1 && k >= k1) continue;
+				if (at(t / 36, t % 36, k) >= 0) n++;
+			}
+		return n;
+	}
+	static constexpr int W_ODD_START = issued_between(24, 2, 36, 0);  // behind the even trip's last U piece: the patch pieces that may stay in flight
+	static constexpr int W_XFORM = issued_between(44, 1, 59, 1);      // behind A_10, before the odd trip's first read of buffer 0 (iteration 23, slot 1)
+	static_assert(SKEW >= 0 && 44 + SKEW < 59, "every B piece is issued before the odd trip's transform starts (and long before t = 72)");
+};
+
 // One third (PART) of the six-point transform y = B^T x on two channels at once, one f2 operation (K) at a time -- the kernel
 // slots exactly one such operation (2 VALU) behind every MFMA.  T: a, b, c, t, m, n of
 //   a = x4 - 4 x2, b = x3 - 4 x1, c = x4 - x2, t = x3 - x1, m = x4 - 5 x2, n = x5 - 5 x3
@@ -246,7 +294,8 @@ __device__ __forceinline__ void wf_bt_op(const f2& x0, const f2& x1, const f2& x
 
 // DBG (tools/wf_probe.cpp only; the library instantiates DBG = 0): knock parts of the loop out to attribute its time.
 //   1 no DMA in the loop, 2 no patch reads, 4 no U fragment reads, 8 no transform VALU, 16 no MFMAs, 32 no barrier, 64 no epilogue,
-//   256 no wait for the DMA (racy: timing only), 512 no patch DMA, 1024 no U DMA
+//   256 no wait for the DMA (racy: timing only), 512 no patch DMA, 1024 no U DMA, 128 no stores in the epilogue (its arithmetic and staging stay),
+//   2048 no output transform in the epilogue (the accumulators' z = 0 values are staged and stored instead)
 //
 // PERSISTENT: one workgroup per CU walks a contiguous range of work items (tile-group quad x k block, the k blocks of a quad
 // consecutive: its patch lines stay in L1 / L2), and the chunk stream simply continues across items: the last two trips of an
@@ -255,9 +304,13 @@ __device__ __forceinline__ void wf_bt_op(const f2& x0, const f2& x1, const f2& x
 // 64-channel item).  Between two items sits the epilogue alone.
 // MASK: the variant whose epilogue applies WinoFusedArgs::mask_bits (its own instantiation: the five registers it holds across the
 // epilogue would otherwise spill in the plain kernel too).
-template <int GH, int GW, int DBG = 0, bool MASK = false>
+// SCHED: 0 = the classic schedule (one chunk per trip, double-buffered patches); 1 + SKEW = the PAIRED schedule (WfPair<SKEW>; needs an even
+// number of chunks, i.e. C % 16 == 0 -- the host picks).
+template <int GH, int GW, int DBG = 0, bool MASK = false, int SCHED = 0>
 __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs a)
 {
+	constexpr bool PAIR = SCHED > 0;
+	typedef WfPair<(SCHED > 0 ? SCHED - 1 : 0)> PS;
 	typedef WfGeom<GH, GW> G;
 	constexpr int GWL = GW == 4 ? 2 : (GW == 8 ? 3 : (GW == 2 ? 1 : (GW == 16 ? 4 : 0)));
 	__shared__ __attribute__((aligned(16))) float lds[2 * WF_U_FLOATS + 8 * WF_P_FLOATS]; // 160 KB: [U ring x2][patch x2 per wave]
@@ -361,7 +414,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 	asm volatile("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them (5 wait states)
 #endif
 	wf_static_for<WF_P_PIECES + 9>([&](auto qc) { dma_piece(qc, p_lds, 0, u_lds, (unsigned)wave * 9216u); });
-	wf_static_for<WF_P_PIECES>([&](auto qc) { dma_piece(qc, p_lds + WF_P_FLOATS * 4, WF_CC * 4, 0, 0); });
+	wf_static_for<WF_P_PIECES>([&](auto qc) { dma_piece(qc, p_lds + WF_P_FLOATS * 4, WF_CC * 4, 0, 0); }); // (PAIR: sub-chunk 1 of the first 16-channel chunk)
 	WF_WAIT_VMCNT(WF_P_PIECES); // chunk 0's patch and this wave's share of U(0) have landed; chunk 1's patch may still fly
 	// the transform an item's FIRST trip starts from, out of patch buffer pb (S, and column 0 of V): at the start of the workgroup,
 	// and after every epilogue -- S is not carried across the epilogue (72 registers next to the epilogue's own temporaries); the
@@ -402,8 +455,9 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 	// hipcc's register allocation falls apart (every accumulator tile spilled to scratch around the merges: 1.1 KB per lane, the
 	// kernel 2x slower), so the accumulators are zeroed after each epilogue and the last trip of an item transforms the NEXT
 	// item's first chunk -- its S and column 0 of V then live across the epilogue.
-	auto trip = [&](auto modec, const int par, const unsigned sp, const unsigned su) {
+	auto trip = [&](auto modec, auto halfc, const int par, const unsigned sp, const unsigned su) {
 		constexpr bool FIRST = (decltype(modec)::value & 1) != 0, LAST = (decltype(modec)::value & 2) != 0;
+		constexpr int HALF = decltype(halfc)::value; // PAIR: 0 = the even trip of a pair, 1 = the odd one (= par); classic: unused
 		const float* const ub = ubuf + par * WF_U_FLOATS + lane * 4;
 		const float* const pbn = pbuf + (par ^ 1) * WF_P_FLOATS;
 		const unsigned p_dst = p_lds + par * (WF_P_FLOATS * 4), u_dst = u_lds + (par ^ 1) * (WF_U_FLOATS * 4);
@@ -445,7 +499,10 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 					constexpr int itn = it + 1, zn = (itn % 6) * 6 + itn / 6;
 					u[itn & 1] = *(const float4*)(ub + zn * 256);
 				}
-				if constexpr (k == 1 && it == 23 && !(DBG & 256)) WF_WAIT_VMCNT(13); // the next chunk's patch (previous trip's pieces): this trip has issued 13 pieces so far
+				if constexpr (!PAIR && k == 1 && it == 23 && !(DBG & 256)) WF_WAIT_VMCNT(13); // the next chunk's patch (previous trip's pieces): this trip has issued 13 pieces so far
+				// PAIR, odd trip: sub-chunk 0 of the next 16 channels (A_0 .. A_10, the last one issued at iteration 8 of this trip); the even trip's
+				// reads are of sub-chunk 1, confirmed by the wait of the odd trip before it and the count-zero wait at this trip's start
+				if constexpr (PAIR && HALF == 1 && k == 1 && it == 23 && !(DBG & 256)) WF_WAIT_VMCNT(PS::W_XFORM);
 				if constexpr ((k == 1 || k == 2) && !(DBG & 2) && !LAST) {
 					constexpr int s = it * 2 + (k - 1); // read slot; rows start at slots 46, 49, 54, 57, 60, 63
 					constexpr int r = s >= 63 ? 5 : s >= 60 ? 4 : s >= 57 ? 3 : s >= 54 ? 2 : s >= 49 ? 1 : s >= 46 ? 0 : -1;
@@ -460,10 +517,17 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 				// pieces alternating).  A patch piece gathers 32-byte runs out of 32 different cache lines and keeps the CU's address
 				// path busy for ~110 cycles; issued back to back by four waves they queue and the ISSUE blocks (measured: 450 cycles
 				// per piece, 1 ms of conv1_2's 4.2).
-				if constexpr (k == 3 && !(DBG & 1) && wf_piece_at(it) >= 0) {
+				if constexpr (!PAIR && k == 3 && !(DBG & 1) && wf_piece_at(it) >= 0) {
 					constexpr int n = wf_piece_at(it) < 0 ? 0 : wf_piece_at(it); // (the clamp only matters in the discarded instantiation)
 					constexpr int q = (n & 1) ? (n >> 1) : (n <= 16 ? WF_P_PIECES + (n >> 1) : WF_P_PIECES - 1); // even n <= 16: U piece n / 2; odd n: patch piece n / 2; n = 18: the eleventh patch piece
 					if constexpr (q < WF_P_PIECES ? !(DBG & 512) : !(DBG & 1024)) dma_piece(GroupId<q>(), p_dst, sp, u_dst, su);
+				}
+				// (c') PAIR: the pieces of WfPair -- A_q into buffer 0 at soffset sp, B_q into buffer 1 at sp + 32 bytes, U pieces as above
+				if constexpr (PAIR && !(DBG & 1) && PS::at(HALF, it, k) >= 0) {
+					constexpr int code = PS::at(HALF, it, k) < 0 ? 0 : PS::at(HALF, it, k);
+					if constexpr (code < 16) { if constexpr (!(DBG & 512)) dma_piece(GroupId<code>(), p_lds, sp, 0u, 0u); }
+					else if constexpr (code < 32) { if constexpr (!(DBG & 512)) dma_piece(GroupId<code - 16>(), p_lds + WF_P_FLOATS * 4, sp + WF_CC * 4, 0u, 0u); }
+					else { if constexpr (!(DBG & 1024)) dma_piece(GroupId<WF_P_PIECES + (code - 32)>(), 0u, 0u, u_dst, su); }
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			});
@@ -509,6 +573,13 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
 			for (int j = 0; j < 2; j++) {
 				float s[4][6]; // columns transformed vertically
+				if constexpr (DBG & 2048) {
+#pragma unroll
+					for (int i = 0; i < 4; i++)
+#pragma unroll
+						for (int jj = 0; jj < 4; jj++) st[g * TS + (i * 4 + jj) * 32 + j * 16 + ti] = acc[i * 4 + jj][j][r];
+					continue;
+				}
 #pragma unroll
 				for (int zx = 0; zx < 6; zx++) {
 					const float col[6] = { acc[0 * 6 + zx][j][r], acc[1 * 6 + zx][j][r], acc[2 * 6 + zx][j][r], acc[3 * 6 + zx][j][r], acc[4 * 6 + zx][j][r], acc[5 * 6 + zx][j][r] };
@@ -543,7 +614,8 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 					const unsigned m = mb[r] >> (4 * e);
 					o0 = (m & 1) ? o0 : 0.f; o1 = (m & 2) ? o1 : 0.f; o2 = (m & 4) ? o2 : 0.f; o3 = (m & 8) ? o3 : 0.f;
 				}
-				__builtin_amdgcn_raw_buffer_store_b128(u4{ __float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3) }, rs_dst, voff, 0, 0);
+				if constexpr (DBG & 128) { NNC_PIN_V(o0); NNC_PIN_V(o1); NNC_PIN_V(o2); NNC_PIN_V(o3); }
+				else __builtin_amdgcn_raw_buffer_store_b128(u4{ __float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3) }, rs_dst, voff, 0, 0);
 			}
 			__builtin_amdgcn_wave_barrier(); // next round's writes after this round's reads
 		}
@@ -553,7 +625,33 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 			for (int j = 0; j < 2; j++) acc[z][j] = floatx4{ 0.f, 0.f, 0.f, 0.f }; // the next item starts from zero (one trip variant: see trip)
 	};
 
-	// ---- the stream
+	// ---- the stream, PAIRED schedule: an item is CCn / 2 pairs of trips; pair m multiplies sub-chunks 2m, 2m + 1 and fetches the 16 channels
+	// of pair m + 1 (the last pair of an item: the next item's first 16) -- see WfPair
+	if constexpr (PAIR) {
+		const int M = a.CCn >> 1; // (host: CCn even)
+		for (int ii = 0; ii < count; ii++) {
+			const Item nxt = item_of(ii + 1 < count ? first + ii + 1 : first + ii);
+			for (int m = 0; m < M; m++) {
+				const bool last = m == M - 1;
+				// even trip.  Every DMA piece of the previous pair has to have landed (its U pieces for this trip, its B pieces for this trip's
+				// transform); right after an epilogue there is nothing to wait for -- the epilogue confirmed every piece, and a count-zero wait
+				// there would wait for its stores' acknowledgements
+				if constexpr (!(DBG & 256)) { if (m != 0 || ii == 0) WF_WAIT_VMCNT(0); }
+				if constexpr (!(DBG & 32)) __builtin_amdgcn_s_barrier();
+				if (last) set_patch(nxt); // this pair's patch pieces (from t = 34 on) are the next item's first 16 channels
+				const unsigned sp = last ? 0u : (unsigned)(m + 1) * (2 * WF_CC * 4);
+				trip(GroupId<0>(), GroupId<0>(), 0, sp, (unsigned)(2 * m + 1) * (WF_U_FLOATS * 4) + (unsigned)wave * 9216u);
+				// odd trip: the even trip's U pieces have landed, its last patch pieces may fly
+				if constexpr (!(DBG & 256)) WF_WAIT_VMCNT(PS::W_ODD_START);
+				if constexpr (!(DBG & 32)) __builtin_amdgcn_s_barrier();
+				if (last) set_u(nxt);
+				trip(GroupId<0>(), GroupId<1>(), 1, sp, (last ? 0u : (unsigned)(2 * m + 2) * (WF_U_FLOATS * 4)) + (unsigned)wave * 9216u);
+			}
+			epilogue(cur, 1);
+			cur = nxt;
+		}
+	} else {
+	// ---- the stream, classic schedule
 	int gtrip = 0;
 	for (int ii = 0; ii < count; ii++) {
 		const Item nxt = item_of(ii + 1 < count ? first + ii + 1 : first + ii); // (the last item fetches its own first chunks again: harmless)
@@ -571,10 +669,11 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 			if (cc == a.CCn - 1) set_u(nxt);     // and so does the U chunk
 			const int c2 = cc + 2 >= a.CCn ? cc + 2 - a.CCn : cc + 2, c1 = cc + 1 >= a.CCn ? 0 : cc + 1;
 			const unsigned sp = (unsigned)c2 * (WF_CC * 4), su = (unsigned)c1 * (WF_U_FLOATS * 4) + (unsigned)wave * 9216u;
-			trip(GroupId<0>(), par, sp, su);
+			trip(GroupId<0>(), GroupId<0>(), par, sp, su);
 		}
 		epilogue(cur, (gtrip - 1) & 1); // (S and column 0 of V of the next item's first chunk, made by the last trip, stay in registers across it)
 		cur = nxt;
+	}
 	}
 #undef WF_XFORM
 }

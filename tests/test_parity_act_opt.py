@@ -299,8 +299,8 @@ def test_random_uniform_and_normal(backend):
     r, out = exec_on(backend, nnc.GPU_MEMORY, nnc._blas_a("RANDOM_UNIFORM_FORWARD", -8.0, 4.0), nnc.NO_HINT, 0, [], [np.zeros(n, F)])
     assert r == 0
     u = out[0]
-    assert u.min() >= -8 and u.max() <= 4 and  # (the reference draws r in (0, 1) and rounds r u + (1 - r) l in fp32 as well: the ends can be met, not passed)
-    assert abs(u.mean() + 2.0) < 0.05 and abs(u.std() - 12 / np.sqrt(12)) < 0.05
+    # (the reference draws r in (0, 1) and rounds r u + (1 - r) l in fp32 as well: the ends can be met, not passed)
+    assert u.min() >= -8 and u.max() <= 4 and abs(u.mean() + 2.0) < 0.05 and abs(u.std() - 12 / np.sqrt(12)) < 0.05
     assert len(np.unique(u)) > n * 0.95
     r, out2 = exec_on(backend, nnc.GPU_MEMORY, nnc._blas_a("RANDOM_UNIFORM_FORWARD", -8.0, 4.0), nnc.NO_HINT, 0, [], [np.zeros(n, F)])
     assert not np.array_equal(out2[0], u)   # a new seed per call

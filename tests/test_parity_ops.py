@@ -504,6 +504,7 @@ FUSED_CASES = [
     (1, 33, 9, 16, 40, (1, 0)),     # tall image: the 8x2 group shape; asymmetric padding
     (5, 20, 20, 16, 64, (1, 1)),    # more groups than one workgroup's four waves, two k blocks
     (9, 30, 30, 24, 96, (1, 1)),    # many work items (9 x 4 groups / 4 x 3 k blocks = 27): every persistent workgroup of the emulator's device walks several
+    (2, 12, 17, 64, 64, (1, 1)),    # four pairs of chunks per item (the paired schedule's steady state), two k blocks
 ]
 
 

@@ -8,20 +8,20 @@
 #define CHECK(e) do { hipError_t s_ = (e); if (s_ != hipSuccess) { printf("HIP error %d at %d\n", (int)s_, __LINE__); return 1; } } while (0)
 using namespace nnc;
 
-template <int DBG>
+template <int DBG, int SCHED = 0>
 static void run(const WinoFusedArgs& a, unsigned grid, double flops, const char* what)
 {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
 	const int reps = 5;
-	for (int i = 0; i < 2; i++) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4, DBG>), dim3(grid), dim3(256), 0, 0, a);
+	for (int i = 0; i < 2; i++) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4, DBG, false, SCHED>), dim3(grid), dim3(256), 0, 0, a);
 	hipEventRecord(e0, 0);
-	for (int i = 0; i < reps; i++) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4, DBG>), dim3(grid), dim3(256), 0, 0, a);
+	for (int i = 0; i < reps; i++) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4, DBG, false, SCHED>), dim3(grid), dim3(256), 0, 0, a);
 	hipEventRecord(e1, 0);
 	hipEventSynchronize(e1);
 	float ms = 0;
 	hipEventElapsedTime(&ms, e0, e1);
-	printf("DBG=%3d  %8.3f ms  %6.1f MFMA-TFLOP/s-equivalent  %s%s\n", DBG, ms / reps, flops * reps / (ms * 1e-3) / 1e12, what, hipGetLastError() == hipSuccess ? "" : "  (launch error)");
+	printf("SCHED=%d DBG=%4d  %8.3f ms  %6.1f MFMA-TFLOP/s-equivalent  %s%s\n", SCHED, DBG, ms / reps, flops * reps / (ms * 1e-3) / 1e12, what, hipGetLastError() == hipSuccess ? "" : "  (launch error)");
 }
 
 int main(int argc, char** argv)
@@ -59,6 +59,17 @@ int main(int argc, char** argv)
 	const unsigned grid = 256;
 	const double flops = 2.0 * 36.0 * (double)a.groups * 16 * K * C; // issued MFMA work (padded tile groups included)
 	printf("fused Winograd 3x3: N=%d %dx%dx%d -> %d; %d work items of %d trips on %d persistent workgroups in teams of %d; MFMA floor %.3f ms\n", NB, H, W, C, K, items, CCn, grid, team, flops / 157.3e12 * 1e3);
+	run<0, 1>(a, grid, flops, "PAIRED schedule: everything");
+	run<0, 3>(a, grid, flops, "PAIRED schedule, B pieces 2 iterations behind: everything");
+	run<64, 1>(a, grid, flops, "PAIRED: no epilogue");
+	run<1, 1>(a, grid, flops, "PAIRED: no DMA in the loop");
+	run<512, 1>(a, grid, flops, "PAIRED: no patch DMA");
+	run<1024, 1>(a, grid, flops, "PAIRED: no U DMA");
+	run<16, 1>(a, grid, flops, "PAIRED: no MFMAs");
+	run<16 + 64, 1>(a, grid, flops, "PAIRED: no MFMAs, no epilogue");
+	run<128, 1>(a, grid, flops, "PAIRED: epilogue without its stores");
+	run<2048, 1>(a, grid, flops, "PAIRED: epilogue without its output transform");
+	run<128 + 2048, 1>(a, grid, flops, "PAIRED: epilogue without stores and transform (staging + waits left)");
 	run<0>(a, grid, flops, "everything");
 	run<1>(a, grid, flops, "no DMA in the loop");
 	run<8>(a, grid, flops, "no transform VALU");
