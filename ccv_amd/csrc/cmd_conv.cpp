@@ -9,6 +9,7 @@
 #include "gemm_launch.h"
 #include "winograd.h"
 #include "wino_fused.h"
+#include "wino_wgrad_fused.h"
 #include "conv_c3.h"
 
 using namespace nnc;
@@ -365,6 +366,72 @@ static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, con
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// ---- fused Winograd filter gradient (wino_wgrad_fused.h): dw (+)= , dbias (+)= with neither V nor W in HBM ------------------------------------
+struct wino_wgrad_fused_plan_t {
+	int TH, TW, GYn, GXn, groups, kblocks, cblocks, slices, per_slice;
+	size_t partial_bytes, bias_bytes;
+	size_t total() const { return partial_bytes + bias_bytes; }
+};
+static bool wino_wgrad_fused_plan(const conv_geom_t& g, wino_wgrad_fused_plan_t* p)
+{
+	if (g.kh != 3 || g.kw != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.groups != 1) return false;
+	if (g.C % WG_CB || g.K % WG_KB || g.pby < 0 || g.pby > 2 || g.pbx < 0 || g.pbx > 2) return false;
+	p->TH = (g.OH + 3) / 4; p->TW = (g.OW + 3) / 4;
+	p->GYn = (p->TH + WG_GH - 1) / WG_GH; p->GXn = (p->TW + WG_GW - 1) / WG_GW;
+	const long groups = (long)g.N * p->GYn * p->GXn;
+	if (groups <= 0 || groups > 0x7fffffffL) return false;
+	p->groups = (int)groups;
+	p->kblocks = g.K / WG_KB; p->cblocks = g.C / WG_CB;
+	// one workgroup per CU: slices x blocks ~ the CU count, slices a multiple of 8 (one eighth per XCD), never more slices than tile groups / 8
+	const long nb = (long)p->kblocks * p->cblocks;
+	long s = (device_cu_count() / nb) & ~7L;
+	if (s < 8) s = 8;
+	while (s > 8 && (groups + s - 1) / s < 8) s -= 8;
+	p->slices = (int)s;
+	p->per_slice = (int)((groups + s - 1) / s);
+	p->partial_bytes = (sizeof(float) * 36 * (size_t)s * g.K * g.C + 255) & ~(size_t)255;
+	p->bias_bytes = (sizeof(float) * 4 * (size_t)s * g.K + 255) & ~(size_t)255;
+	return true;
+}
+static bool wino_wgrad_fused_images_ok(const Image4& a, const Image4& gr, const float* dw)
+{
+	const auto ok = [](const Image4& t) { return t.sc == 1 && aligned16(t.p) && t.sw % 4 == 0 && t.sh % 4 == 0 && (t.n == 1 || t.sn % 4 == 0) && ((long)(t.h - 1) * t.sh + (long)(t.w - 1) * t.sw + t.c) * 4 < 0x7ffff000L; };
+	return ok(a) && ok(gr) && dw != 0;
+}
+// algorithm -1: where both channel counts are at most TUNE_WINO_WGRAD_FUSED_MAX (measured on the MI355X, DESIGN.md section 5.6: the blocks of a
+// (K / 32) x (C / 64) grid each read and transform every tile, so the redundancy grows with the channel counts while the via-HBM GEMMs get better)
+static bool wino_wgrad_fused_preferred(const conv_geom_t& g)
+{
+	const long m = tune(TUNE_WINO_WGRAD_FUSED_MAX);
+	return m > 0 && g.C <= m && g.K <= m;
+}
+static int conv_wino_wgrad_fused(const conv_geom_t& g, const wino_wgrad_fused_plan_t& p, const Image4& gr, const Image4& a, float* dw, float* dbias, bool* bias_done, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	char* const ws = (char*)workspace_of(ctx, p.total());
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	hipStream_t stream = stream_of(ctx);
+	WinoWgradFusedArgs k;
+	k.a = a.p; k.g = gr.p; k.partial = (float*)ws; k.bias_partial = dbias ? (float*)(ws + p.partial_bytes) : 0;
+	k.a_sn = a.sn; k.a_sh = a.sh; k.a_sw = a.sw; k.g_sn = gr.sn; k.g_sh = gr.sh; k.g_sw = gr.sw;
+	k.H = a.h; k.W = a.w; k.OH = gr.h; k.OW = gr.w; k.pad_y = g.pby; k.pad_x = g.pbx;
+	k.GYn = p.GYn; k.GXn = p.GXn; k.groups = p.groups; k.C = g.C; k.K = g.K; k.kblocks = p.kblocks; k.cblocks = p.cblocks;
+	k.slices = p.slices; k.per_slice = p.per_slice;
+	k.a_image_bytes = (unsigned)(((long)(a.h - 1) * a.sh + (long)(a.w - 1) * a.sw + a.c) * 4);
+	k.g_image_bytes = (unsigned)(((long)(gr.h - 1) * gr.sh + (long)(gr.w - 1) * gr.sw + gr.c) * 4);
+	note_kernel("conv_wgrad_wino_fused");
+	{
+		const long T = (long)g.N * p.TH * p.TW;
+		ProfScope prof("conv_wgrad_wino_fused|nnc::wino_wgrad_fused_kernel", 2.0 * 36.0 * (double)T * g.K * g.C, 0, g.K, g.C, (int)T, 36, p.slices, stream);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_wgrad_fused_kernel<0>), dim3((unsigned)(p.slices * p.kblocks * p.cblocks)), dim3(256), 0, stream, k);
+		HIP_ENFORCE(hipGetLastError());
+	}
+	const long most = (long)g.K * g.C;
+	hipLaunchKernelGGL(wino_wgrad_fused_final_kernel, dim3(blocks_exact((size_t)most, 256)), dim3(256), 0, stream, (const float*)k.partial, (const float*)k.bias_partial, dw, dbias, g.K, g.C, p.slices, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
+	HIP_ENFORCE(hipGetLastError());
+	if (bias_done) *bias_done = dbias != 0;
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 static bool wino_images_ok(const Image4& src, const Image4& dst, const float* w, const float* bias)
 {
 	return src.sc == 1 && dst.sc == 1 && aligned16(src.p) && aligned16(dst.p) && aligned16(w) && (!bias || aligned16(bias)) &&
@@ -616,6 +683,11 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 		if (r == CCV_NNC_EXEC_SUCCESS && bias_done) *bias_done = dbias != 0;
 		if (r != CCV_NNC_EXEC_OOM) return r;
 	}
+	wino_wgrad_fused_plan_t wfp;
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && algo != CONV_ALGO_WINOGRAD && wino_wgrad_fused_plan(g, &wfp) && wino_wgrad_fused_images_ok(a, gr, dw) && (algo == CONV_ALGO_WINOGRAD_FUSED || wino_wgrad_fused_preferred(g))) {
+		const int r = conv_wino_wgrad_fused(g, wfp, gr, a, dw, dbias, bias_done, flags, ctx);
+		if (r != CCV_NNC_EXEC_OOM) return r;
+	}
 	wino_wgrad_plan_t wp;
 	if (algo != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wp) && wino_images_ok(a, gr, dw, 0) && (algo >= CONV_ALGO_WINOGRAD || wino_preferred(wp.t, g.C, g.K))) {
 		const int r = conv_wino_wgrad(g, wp, gr, a, dw, dbias, bias_done, flags, ctx);
@@ -850,6 +922,8 @@ static int _conv_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const 
 	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_plan(g, g.H, g.W, g.K, g.C, &wpl) && wpl.total() > inner) inner = wpl.total();
 	wino_wgrad_plan_t wgp;
 	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_plan(g, &wgp) && wgp.total() > inner) inner = wgp.total();
+	wino_wgrad_fused_plan_t wfgp;
+	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_wgrad_fused_plan(g, &wfgp) && wfgp.total() > inner) inner = wfgp.total();
 	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && wino_fused_scratch_bound(g.C, g.K) + wino_fused_mask_bound(g) > inner) inner = wino_fused_scratch_bound(g.C, g.K) + wino_fused_mask_bound(g);
 	if (h && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && conv_dgrad_parity_scratch(g) > inner) inner = conv_dgrad_parity_scratch(g);
 	if (dw && cmd.algorithm != CONV_ALGO_IMPLICIT_GEMM && g.C == 3 && conv_c3_wgrad_scratch_bound(g.K) > inner) inner = conv_c3_wgrad_scratch_bound(g.K);

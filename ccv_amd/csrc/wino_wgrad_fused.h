@@ -1,0 +1,275 @@
+// Fused Winograd F(3x3, 4x4) FILTER GRADIENT for gfx950, fp32 (round 3): dw = A'^T ( sum over tiles W[z] (x) V[z] ) A' with
+//   V = B^T d B   (d: the 6x6 input patch of a 4x4 output-gradient tile)      -- what wino_input_kernel wrote to HBM
+//   W = G' e G'^T (e: the 4x4 output-gradient tile)                             -- what wino_outgrad_kernel wrote to HBM
+// computed in registers by the lanes that feed them to the MFMAs: neither V (2.25x the activations) nor W (2.25x the gradient) exists in
+// HBM.  On VGG-D at batch 256 the via-HBM form spent 14.6 ms of the 88 ms step writing and re-reading them, plus the
+// 64 / 128-channel contractions at 91 - 110 TFLOP/s because they are HBM-bound.  Spec of the arithmetic: the via-HBM path (winograd.h
+// wino_input_kernel / wino_outgrad_kernel / wino_wgrad_final_kernel), itself pinned against the reference's direct loops
+// (lib/nnc/cmd/convolution/ccv_nnc_conv_cpu_ref.c:134-262) by tests/test_parity_ops.py and tests/test_parity_fullsize.py.
+//
+// Shape.  The reduction index of dU[z][k][c] = sum_t W[z][t][k] V[z][t][c] is the TILE, so on v_mfma_f32_16x16x4_f32 one instruction takes
+// four tiles: A[m = k][kk = tile] = W, B[kk = tile][n = c] = V, D[k][c] += .  A lane (ch = l & 15, slot = l >> 4) therefore owns ONE tile and one
+// channel index on each side: it reads the 16 gradient values of its (tile, k) and the 36 input values of its (tile, c) and transforms them
+// itself -- no staging of transformed data, no cross-lane traffic.  Accumulators: 36 positions x 16 k x 32 c per wave = 72 MFMA tiles = 288
+// registers (the same budget as the fused forward kernel: 60 tiles pinned to AGPRs through asm operand classes); a workgroup of four waves
+// covers a 32 k x 64 c block, and the grid is (K / 32) x (C / 64) blocks x `slices` ranges of tile groups; every workgroup writes its
+// partial dU once at the end, wino_wgrad_fused_final_kernel folds the slices in a fixed order and applies A'^T . A'.
+//
+// Data path.  A trip = one 2 x 4 group of tiles (two MFMA k-steps): the 10 x 18 pixel input region x 64 channels (45 KB: whole 128-byte
+// lines) and the 8 x 16 pixel gradient region x 32 channels (16 KB) arrive by LDS-DMA (buffer_load ... lds: no VGPR round trip, out-of-image
+// pixels are out-of-range offsets and land as zeros -- a clipped tile's gradient is zero, so it adds nothing), double-buffered, the 61 pieces
+// of the NEXT trip spread between the MFMAs of the current one (wino_fused.h: a queue of vector-memory instructions blocks the in-order wave,
+// MFMAs included; the CU retires one 1 KB piece per ~65 cycles).  One barrier per trip.  Per trip and wave: 144 MFMAs (4608 cycles), ~820
+// transform VALU, 176 LDS reads, <= 16 DMA pieces.
+#pragma once
+#include "wino_fused.h"
+
+namespace nnc {
+
+constexpr int WG_KB = 32, WG_CB = 64;                  // output / input channels per workgroup
+constexpr int WG_GH = 2, WG_GW = 4;                    // tiles per trip (rows x columns): row = one MFMA k-step of four tiles
+constexpr int WG_RH = 4 * WG_GH + 2, WG_RW = 4 * WG_GW + 2; // input region, pixels
+constexpr int WG_A_BYTES = WG_RH * WG_RW * WG_CB * 4;  // 46080
+constexpr int WG_G_BYTES = (4 * WG_GH) * (4 * WG_GW) * WG_KB * 4; // 16384
+constexpr int WG_A_PIECES = WG_A_BYTES / 1024, WG_G_PIECES = WG_G_BYTES / 1024; // 45, 16
+constexpr int WG_STAGE_BYTES = WG_A_BYTES + WG_G_BYTES;
+static_assert(WG_A_BYTES % 1024 == 0 && WG_G_BYTES % 1024 == 0 && 2 * WG_STAGE_BYTES <= 160 * 1024, "two stages of whole DMA pieces in LDS");
+constexpr int WG_A_PER_WAVE = (WG_A_PIECES + 3) / 4, WG_G_PER_WAVE = WG_G_PIECES / 4; // 12 (the last wave-slot of some waves is empty), 4
+constexpr int WG_PIECES_PER_WAVE = WG_A_PER_WAVE + WG_G_PER_WAVE;                    // 16 issue slots per wave and trip
+
+struct WinoWgradFusedArgs {
+	const float* a;      // input activations, NHWC, channels dense
+	const float* g;      // output gradient, NHWC, channels dense
+	float* partial;      // [slices][36][K][C]
+	float* bias_partial; // [slices][4 tile slots][K], or null
+	long a_sn, a_sh, a_sw, g_sn, g_sh, g_sw; // element strides
+	int H, W, OH, OW;    // input / gradient extents
+	int pad_y, pad_x;
+	int GYn, GXn;        // tile groups per image column / row
+	int groups;          // N * GYn * GXn
+	int C, K;
+	int kblocks, cblocks; // K / 32, C / 64
+	int slices;           // a multiple of 8 (one eighth per XCD)
+	int per_slice;        // tile groups per slice
+	unsigned a_image_bytes, g_image_bytes; // ranges of the per-image buffer descriptors
+};
+
+template <int DBG = 0>
+__global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgradFusedArgs p)
+{
+	__shared__ __attribute__((aligned(16))) float lds[2 * WG_STAGE_BYTES / 4 + 256]; // two stages + 1 KB where the empty issue slots (waves 1 - 3 have 11 input pieces, not 12) drop their zeros
+	const int t = threadIdx.x, lane = t & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	const int wk = wave >> 1, wc = wave & 1;
+	const int ch = lane & 15, slot = lane >> 4;
+	// workgroup -> (slice, k block, c block): the blocks of one slice read the same regions, so they sit on ONE XCD (workgroup b runs on XCD b % 8)
+	const int nb = p.kblocks * p.cblocks;
+	const int xcd = (int)blockIdx.x & 7, r = (int)blockIdx.x >> 3;
+	const int slice = xcd * (p.slices >> 3) + r / nb, blk = r % nb;
+	const int kb = blk / p.cblocks, cb = blk - kb * p.cblocks;
+	int g_first = slice * p.per_slice, g_end = g_first + p.per_slice;
+	if (g_end > p.groups) g_end = p.groups;
+	const int gpi = p.GYn * p.GXn;
+
+	floatx4 acc[36][2];
+#pragma unroll
+	for (int z = 0; z < 36; z++)
+#pragma unroll
+		for (int j = 0; j < 2; j++) acc[z][j] = floatx4{ 0.f, 0.f, 0.f, 0.f };
+	float bsum = 0.f;
+
+	// ---- DMA: this wave's pieces.  a piece q = wave + 4 i: region pixel 4 q + (lane >> 4), channels 4 (lane & 15) .. + 3 of the c block;
+	// g piece q = wave + 4 i: gradient pixel 8 q + (lane >> 3), channels 4 (lane & 7) .. + 3 of the k block.  Item-independent halves kept in registers.
+	int ayx[WG_A_PER_WAVE], gyx[WG_G_PER_WAVE];
+#pragma unroll
+	for (int i = 0; i < WG_A_PER_WAVE; i++) {
+		const int q = wave + 4 * i, pi = q * 4 + (lane >> 4);
+		ayx[i] = q < WG_A_PIECES ? ((pi / WG_RW) << 8 | (pi % WG_RW)) : -1;
+	}
+#pragma unroll
+	for (int i = 0; i < WG_G_PER_WAVE; i++) {
+		const int pj = (wave + 4 * i) * 8 + (lane >> 3);
+		gyx[i] = (pj / (4 * WG_GW)) << 8 | (pj % (4 * WG_GW));
+	}
+	const int a_coff = (cb * WG_CB + (lane & 15) * 4) * 4, g_coff = (kb * WG_KB + (lane & 7) * 4) * 4; // bytes
+	const int a_sh4 = (int)p.a_sh * 4, a_sw4 = (int)p.a_sw * 4, g_sh4 = (int)p.g_sh * 4, g_sw4 = (int)p.g_sw * 4;
+	const unsigned lds0 = __builtin_amdgcn_readfirstlane(wf_lds_addr(lds));
+	wf_rsrc_t rs_a, rs_g;
+	int nY0 = 0, nX0 = 0, ny0 = 0, nx0 = 0; // origin of the group being FETCHED: input region / gradient region
+	auto set_group = [&](const int group) {
+		const int n = group / gpi, gr = group - n * gpi;
+		const int gy = gr / p.GXn, gx = gr - gy * p.GXn;
+		rs_a = wf_make_rsrc(p.a + (long)n * p.a_sn, p.a_image_bytes);
+		rs_g = wf_make_rsrc(p.g + (long)n * p.g_sn, p.g_image_bytes);
+		ny0 = gy * 4 * WG_GH; nx0 = gx * 4 * WG_GW;
+		nY0 = ny0 - p.pad_y; nX0 = nx0 - p.pad_x;
+	};
+	// piece i (0 .. 11: input, 12 .. 15: gradient) of the group set by set_group, into stage `st`
+	auto dma_piece = [&](auto ic, const int st, const bool live) {
+		constexpr int i = decltype(ic)::value;
+		if constexpr (i < WG_A_PER_WAVE) {
+			const int Y = nY0 + (ayx[i] >> 8), X = nX0 + (ayx[i] & 255);
+			const bool ok = live & (ayx[i] >= 0) & (Y >= 0) & (Y < p.H) & (X >= 0) & (X < p.W);
+			const unsigned voff = ok ? (unsigned)(Y * a_sh4 + X * a_sw4 + a_coff) : WF_OOB;
+			const unsigned dst = wave + 4 * i < WG_A_PIECES ? lds0 + st * WG_STAGE_BYTES + (wave + 4 * i) * 1024 : lds0 + 2 * WG_STAGE_BYTES; // (scalar select: no branch in the MFMA stream)
+			wf_dma16(rs_a, lds, dst, voff, 0u);
+		} else {
+			constexpr int j = i - WG_A_PER_WAVE;
+			const int y = ny0 + (gyx[j] >> 8), x = nx0 + (gyx[j] & 255);
+			const bool ok = live & (y < p.OH) & (x < p.OW);
+			const unsigned voff = ok ? (unsigned)(y * g_sh4 + x * g_sw4 + g_coff) : WF_OOB;
+			wf_dma16(rs_g, lds, lds0 + st * WG_STAGE_BYTES + WG_A_BYTES + (wave + 4 * j) * 1024, voff, 0u);
+		}
+	};
+
+	if (g_first < g_end) { // (an empty slice still writes its zeros below: the fold reads every slice)
+	set_group(g_first);
+#ifndef NNC_HIP_EMULATOR
+	asm volatile("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them
+#endif
+	wf_static_for<WG_PIECES_PER_WAVE>([&](auto ic) { dma_piece(ic, 0, true); });
+
+	for (int grp = g_first; grp < g_end; grp++) {
+		const int st = (grp - g_first) & 1;
+		WF_WAIT_VMCNT(0);                 // this wave's pieces of the trip have landed ...
+		__builtin_amdgcn_s_barrier();     // ... and so have everybody's; every wave is done reading the other stage
+		const bool has_next = grp + 1 < g_end;
+		if (has_next) set_group(grp + 1);
+		const float* const ab = lds + st * (WG_STAGE_BYTES / 4) + (4 * slot) * WG_CB + wc * 32 + ch;                   // + (Y * 18 + X) * 64 + 16 jf
+		const float* const gb = lds + st * (WG_STAGE_BYTES / 4) + WG_A_BYTES / 4 + (4 * slot) * WG_KB + wk * 16 + ch;  // + (y * 16 + x) * 32
+		wf_static_for<2>([&](auto ksc) {
+			constexpr int ks = decltype(ksc)::value; // tiles (ty = ks, tx = slot)
+			// W = G' e G'^T of this lane's (tile, k)
+			float W[36];
+			{
+				float e[4][4];
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+#pragma unroll
+					for (int j = 0; j < 4; j++) e[i][j] = gb[((4 * ks + i) * (4 * WG_GW) + j) * WG_KB];
+				if (wc == 0 && cb == 0) {
+#pragma unroll
+					for (int i = 0; i < 4; i++) bsum += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
+				}
+				float t1[6][4];
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					const float col[4] = { e[0][j], e[1][j], e[2][j], e[3][j] };
+					float y[6];
+					wino_g4(col, y);
+#pragma unroll
+					for (int rr = 0; rr < 6; rr++) t1[rr][j] = y[rr];
+				}
+#pragma unroll
+				for (int rr = 0; rr < 6; rr++) {
+					float y[6];
+					wino_g4(t1[rr], y);
+#pragma unroll
+					for (int q = 0; q < 6; q++) W[rr * 6 + q] = y[q];
+				}
+			}
+			wf_static_for<2>([&](auto jfc) {
+				constexpr int jf = decltype(jfc)::value;
+				// V = B^T d B of this lane's (tile, c = 16 jf + ch)
+				float V[36];
+				{
+					float s[6][6];
+#pragma unroll
+					for (int c6 = 0; c6 < 6; c6++) {
+						float col[6], y[6];
+#pragma unroll
+						for (int r6 = 0; r6 < 6; r6++) col[r6] = ab[((4 * ks + r6) * WG_RW + c6) * WG_CB + 16 * jf];
+						wino_bt(col, y);
+#pragma unroll
+						for (int r6 = 0; r6 < 6; r6++) s[r6][c6] = y[r6];
+					}
+#pragma unroll
+					for (int r6 = 0; r6 < 6; r6++) {
+						float y[6];
+						wino_bt(s[r6], y);
+#pragma unroll
+						for (int q = 0; q < 6; q++) V[r6 * 6 + q] = y[q];
+					}
+				}
+#pragma unroll
+				for (int z = 0; z < 36; z++) { NNC_PIN_V(V[z]); }
+				if constexpr (jf == 0) {
+#pragma unroll
+					for (int z = 0; z < 36; z++) { NNC_PIN_V(W[z]); }
+				}
+#ifndef NNC_HIP_EMULATOR
+				asm volatile("s_nop 1"); // the last transform VALU -> an MFMA reading its result (asm MFMAs are outside hipcc's hazard handling)
+#endif
+				wf_static_for<36>([&](auto zc) {
+					constexpr int z = decltype(zc)::value;
+					if constexpr (!(DBG & 16)) WF_MFMA(acc[z][jf], W[z], V[z], z < WF_Z_AGPR);
+					// the next trip's pieces, one per six MFMAs over the first 96 of the trip's 144: the last block gives them time to land
+					constexpr int m = (ks * 2 + jf) * 36 + z;
+					// (the last trip of a slice issues them too, every lane out of range: zeros into a stage nobody reads -- no branch in the MFMA stream)
+					if constexpr (m % 6 == 0 && m / 6 < WG_PIECES_PER_WAVE && !(DBG & 1)) dma_piece(GroupId<m / 6>(), st ^ 1, has_next);
+				});
+			});
+		});
+	}
+	}
+
+#ifndef NNC_HIP_EMULATOR
+	asm volatile("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
+#endif
+	{
+		// D layout of 16x16x4: lane holds rows 4 (lane >> 4) + i (k), column lane & 15 (c)
+		float* const out = p.partial + (long)slice * 36 * p.K * p.C + (long)(kb * WG_KB + wk * 16 + 4 * slot) * p.C + cb * WG_CB + wc * 32 + ch;
+		const long plane = (long)p.K * p.C;
+#pragma unroll
+		for (int z = 0; z < 36; z++)
+#pragma unroll
+			for (int j = 0; j < 2; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) out[z * plane + (long)i * p.C + 16 * j] = acc[z][j][i];
+		if (p.bias_partial && wc == 0 && cb == 0) p.bias_partial[((long)slice * 4 + slot) * p.K + kb * WG_KB + wk * 16 + ch] = bsum;
+	}
+}
+
+// dw[k][i][j][c] (+)= (A'^T (sum over slices partial[s][.][k][c]) A')[i][j]; dbias[k] (+)= sum over slices and tile slots.  One thread per (k, c), slices in order.
+static __global__ void __launch_bounds__(256) wino_wgrad_fused_final_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial, float* __restrict__ dw, float* __restrict__ dbias, const int K, const int C, const int slices, const int accumulate)
+{
+	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const long plane = (long)K * C;
+	if (idx < plane) {
+		const int k = (int)(idx / C), c = (int)(idx - (long)k * C);
+		float du[36];
+#pragma unroll
+		for (int z = 0; z < 36; z++) du[z] = 0.f;
+		for (int s = 0; s < slices; s++) {
+			const float* const ps = partial + (long)s * 36 * plane + idx;
+#pragma unroll
+			for (int z = 0; z < 36; z++) du[z] += ps[z * plane];
+		}
+		float sm[3][6];
+#pragma unroll
+		for (int q = 0; q < 6; q++) {
+			const float col[6] = { du[0 * 6 + q], du[1 * 6 + q], du[2 * 6 + q], du[3 * 6 + q], du[4 * 6 + q], du[5 * 6 + q] };
+			float y[3];
+			wino_at3(col, y);
+#pragma unroll
+			for (int i = 0; i < 3; i++) sm[i][q] = y[i];
+		}
+#pragma unroll
+		for (int i = 0; i < 3; i++) {
+			float y[3];
+			wino_at3(sm[i], y);
+#pragma unroll
+			for (int j = 0; j < 3; j++) {
+				float* const o = dw + ((long)k * 9 + i * 3 + j) * C + c;
+				*o = accumulate ? *o + y[j] : y[j];
+			}
+		}
+	}
+	if (dbias && bias_partial && idx < K) {
+		float s = 0.f;
+		for (int i = 0; i < slices * 4; i++) s += bias_partial[(long)i * K + idx];
+		dbias[idx] = accumulate ? dbias[idx] + s : s;
+	}
+}
+
+} // namespace nnc

@@ -542,6 +542,39 @@ def _fused_check(backend, ref_lib, case, a, wt, b, hint, oh, ow):
         np.testing.assert_allclose(got[i], want[i], rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(want[i]).max())))
 
 
+WGRAD_FUSED_CASES = [
+    # n, h, w, c, k, border: the fused Winograd filter gradient (wino_wgrad_fused.h): C % 64 == 0, K % 32 == 0
+    (2, 12, 17, 64, 64, (1, 1)),    # ragged 2 x 4 tile groups (3 x 5 tiles), two k blocks
+    (1, 9, 9, 64, 32, (1, 1)),      # fewer tile groups than slices: most slices are empty and write zeros
+    (3, 23, 30, 128, 96, (0, 0)),   # no padding; 2 c blocks x 3 k blocks
+    (2, 8, 16, 64, 64, (2, 2)),     # full padding: the gradient is larger than the input
+    (5, 30, 30, 64, 64, (1, 1)),    # 5 x 4 x 2 = 40 tile groups over 8+ slices: several trips per workgroup, double-buffered stages
+    (1, 33, 7, 64, 32, (1, 0)),     # tall, narrow, asymmetric padding
+]
+
+
+@pytest.mark.parametrize("flags", [0, nnc.ACCUMULATE_OUTPUT], ids=["store", "accumulate"])
+@pytest.mark.parametrize("case", WGRAD_FUSED_CASES)
+def test_conv_wgrad_winograd_fused(backend, ref_lib, case, flags):
+    """cmd.algorithm = 2 on the backward row with C % 64 == 0 and K % 32 == 0: the filter gradient with BOTH Winograd transforms in registers (neither
+    B^T a B nor G' g G'^T in HBM), tiles as the MFMA reduction dimension, split over tile ranges, slices folded in a fixed order; bias gradient from
+    the same pass.  Against the reference's direct loops; under ACCUMULATE the CPU oracle overwrites dbias (conv_cpu_ref.c:262-263) -- see DESIGN.md."""
+    n, h, w, c, k, border = case
+    a, wt, b, hint, oh, ow = _wino_inputs(case)
+    g = srnd(np.random.default_rng(6), n, oh, ow, k)
+    dw0, db0 = srnd(np.random.default_rng(7), k, 3, 3, c, scale=0.1), srnd(np.random.default_rng(8), k, scale=0.1)
+    bw = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, bw, hint, flags, [g, a, wt], [np.zeros_like(a), dw0.copy(), db0.copy()], backend=nnc.BACKEND_CPU_REF)
+    bw.algorithm = 2
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, bw, hint, flags, [g, a, wt], [None, dw0.copy(), db0.copy()])
+    assert r1 == 0 and r2 == 0
+    assert backend.dll.nnc_mi355x_last_kernel_name().decode() == "conv_wgrad_wino_fused"
+    scale = max(1.0, float(np.abs(want[1]).max()))
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5 * scale)
+    want_db = g.sum(axis=(0, 1, 2), dtype=np.float64) + (db0 if flags else 0)
+    np.testing.assert_allclose(got[2], want_db, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(want_db).max())))
+
+
 C3_CASES = [
     # n, h, w, k, border: 3x3 stride 1 on THREE input channels -> conv_c3.h (K = 16 / 32 / 64), under the backend's own choice
     (2, 9, 21, 64, (0, 0)),     # VGG-D conv1_1 class: no padding, ragged 16-pixel groups (19 wide)
