@@ -26,6 +26,8 @@
 
 namespace nnc {
 
+typedef float f2v __attribute__((ext_vector_type(2))); // two fp32 in an aligned register pair: hipcc selects v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 for its arithmetic
+
 constexpr int WG_KB = 32, WG_CB = 64;                  // output / input channels per workgroup
 constexpr int WG_GH = 2, WG_GW = 4;                    // tiles per trip (rows x columns): row = one MFMA k-step of four tiles
 constexpr int WG_RH = 4 * WG_GH + 2, WG_RW = 4 * WG_GW + 2; // input region, pixels
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 #pragma unroll
 	for (int i = 0; i < WG_A_PER_WAVE; i++) {
 		const int q = wave + 4 * i, pi = q * 4 + (lane >> 4);
-		ayx[i] = q < WG_A_PIECES ? ((pi / WG_RW) << 8 | (pi % WG_RW)) : -1;
+		ayx[i] = q < WG_A_PIECES ? ((pi / WG_RW) << 8 | (pi % WG_RW)) : 0xff00;
 	}
 #pragma unroll
 	for (int i = 0; i < WG_G_PER_WAVE; i++) {
@@ -95,28 +97,34 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 	const int a_sh4 = (int)p.a_sh * 4, a_sw4 = (int)p.a_sw * 4, g_sh4 = (int)p.g_sh * 4, g_sw4 = (int)p.g_sw * 4;
 	const unsigned lds0 = __builtin_amdgcn_readfirstlane(wf_lds_addr(lds));
 	wf_rsrc_t rs_a, rs_g;
-	int nY0 = 0, nX0 = 0, ny0 = 0, nx0 = 0; // origin of the group being FETCHED: input region / gradient region
+	// the group being FETCHED: the descriptors start at the region's origin (which may lie before the image: only in-image lanes get an in-range
+	// offset), the in-image part of the region as uniform ranges in region coordinates -- a piece's address work is two extracts, two multiply-adds,
+	// four compares against scalars and a select (the first version recomputed image coordinates per lane: 27 instructions per piece, 430 per trip)
+	int aY0 = 0, aY1 = 0, aX0 = 0, aX1 = 0, gY1 = 0, gX1 = 0;
 	auto set_group = [&](const int group) {
 		const int n = group / gpi, gr = group - n * gpi;
 		const int gy = gr / p.GXn, gx = gr - gy * p.GXn;
-		rs_a = wf_make_rsrc(p.a + (long)n * p.a_sn, p.a_image_bytes);
-		rs_g = wf_make_rsrc(p.g + (long)n * p.g_sn, p.g_image_bytes);
-		ny0 = gy * 4 * WG_GH; nx0 = gx * 4 * WG_GW;
-		nY0 = ny0 - p.pad_y; nX0 = nx0 - p.pad_x;
+		const int ny0 = gy * 4 * WG_GH, nx0 = gx * 4 * WG_GW, nY0 = ny0 - p.pad_y, nX0 = nx0 - p.pad_x;
+		rs_a = wf_make_rsrc(p.a + (long)n * p.a_sn + (long)nY0 * p.a_sh + (long)nX0 * p.a_sw, 0x7fff0000u);
+		rs_g = wf_make_rsrc(p.g + (long)n * p.g_sn + (long)ny0 * p.g_sh + (long)nx0 * p.g_sw, 0x7fff0000u);
+		aY0 = nY0 < 0 ? -nY0 : 0; aY1 = p.H - nY0 < WG_RH ? p.H - nY0 : WG_RH;
+		aX0 = nX0 < 0 ? -nX0 : 0; aX1 = p.W - nX0 < WG_RW ? p.W - nX0 : WG_RW;
+		gY1 = p.OH - ny0 < 4 * WG_GH ? p.OH - ny0 : 4 * WG_GH;
+		gX1 = p.OW - nx0 < 4 * WG_GW ? p.OW - nx0 : 4 * WG_GW;
 	};
 	// piece i (0 .. 11: input, 12 .. 15: gradient) of the group set by set_group, into stage `st`
 	auto dma_piece = [&](auto ic, const int st, const bool live) {
 		constexpr int i = decltype(ic)::value;
 		if constexpr (i < WG_A_PER_WAVE) {
-			const int Y = nY0 + (ayx[i] >> 8), X = nX0 + (ayx[i] & 255);
-			const bool ok = live & (ayx[i] >= 0) & (Y >= 0) & (Y < p.H) & (X >= 0) & (X < p.W);
+			const int Y = ayx[i] >> 8, X = ayx[i] & 255; // (an empty slot holds Y = 255: never in range)
+			const bool ok = live & (Y >= aY0) & (Y < aY1) & (X >= aX0) & (X < aX1);
 			const unsigned voff = ok ? (unsigned)(Y * a_sh4 + X * a_sw4 + a_coff) : WF_OOB;
 			const unsigned dst = wave + 4 * i < WG_A_PIECES ? lds0 + st * WG_STAGE_BYTES + (wave + 4 * i) * 1024 : lds0 + 2 * WG_STAGE_BYTES; // (scalar select: no branch in the MFMA stream)
 			wf_dma16(rs_a, lds, dst, voff, 0u);
 		} else {
 			constexpr int j = i - WG_A_PER_WAVE;
-			const int y = ny0 + (gyx[j] >> 8), x = nx0 + (gyx[j] & 255);
-			const bool ok = live & (y < p.OH) & (x < p.OW);
+			const int y = gyx[j] >> 8, x = gyx[j] & 255;
+			const bool ok = live & (y < gY1) & (x < gX1);
 			const unsigned voff = ok ? (unsigned)(y * g_sh4 + x * g_sw4 + g_coff) : WF_OOB;
 			wf_dma16(rs_g, lds, lds0 + st * WG_STAGE_BYTES + WG_A_BYTES + (wave + 4 * j) * 1024, voff, 0u);
 		}
@@ -135,79 +143,81 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 		__builtin_amdgcn_s_barrier();     // ... and so have everybody's; every wave is done reading the other stage
 		const bool has_next = grp + 1 < g_end;
 		if (has_next) set_group(grp + 1);
-		const float* const ab = lds + st * (WG_STAGE_BYTES / 4) + (4 * slot) * WG_CB + wc * 32 + ch;                   // + (Y * 18 + X) * 64 + 16 jf
+		// lane (ch, slot): input channels 2 ch, 2 ch + 1 of the wave's 32 (the two MFMA column fragments: one 8-byte LDS read serves both, and the
+		// transform runs on the pair -- packed fp32 where hipcc finds it), output channel ch of the wave's 16, tile (row = k-step, column = slot)
+		const float* const ab = lds + st * (WG_STAGE_BYTES / 4) + (4 * slot) * WG_CB + wc * 32 + 2 * ch;               // + (Y * 18 + X) * 64
 		const float* const gb = lds + st * (WG_STAGE_BYTES / 4) + WG_A_BYTES / 4 + (4 * slot) * WG_KB + wk * 16 + ch;  // + (y * 16 + x) * 32
+		// W = G' e G'^T of this lane's (tile, k), BOTH k-steps at once (x: tile row 0, y: tile row 1)
+		f2v W[36];
+		{
+			f2v e[4][4];
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+#pragma unroll
+				for (int j = 0; j < 4; j++) e[i][j] = f2v{ gb[(i * (4 * WG_GW) + j) * WG_KB], gb[((4 + i) * (4 * WG_GW) + j) * WG_KB] };
+			if (wc == 0 && cb == 0) {
+#pragma unroll
+				for (int i = 0; i < 4; i++) { const f2v r4 = (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]); bsum += r4.x + r4.y; }
+			}
+			f2v t1[6][4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const f2v col[4] = { e[0][j], e[1][j], e[2][j], e[3][j] };
+				f2v y[6];
+				wino_g4(col, y);
+#pragma unroll
+				for (int rr = 0; rr < 6; rr++) t1[rr][j] = y[rr];
+			}
+#pragma unroll
+			for (int rr = 0; rr < 6; rr++) {
+				f2v y[6];
+				wino_g4(t1[rr], y);
+#pragma unroll
+				for (int q = 0; q < 6; q++) W[rr * 6 + q] = y[q];
+			}
+		}
+#pragma unroll
+		for (int z = 0; z < 36; z++) { NNC_PIN_V(W[z].x); NNC_PIN_V(W[z].y); }
 		wf_static_for<2>([&](auto ksc) {
 			constexpr int ks = decltype(ksc)::value; // tiles (ty = ks, tx = slot)
-			// W = G' e G'^T of this lane's (tile, k)
-			float W[36];
+			// V = B^T d B of this lane's (tile, c = 2 ch, 2 ch + 1)
+			f2v V[36];
 			{
-				float e[4][4];
+				f2v sm[6][6];
 #pragma unroll
-				for (int i = 0; i < 4; i++)
+				for (int c6 = 0; c6 < 6; c6++) {
+					f2v col[6], y[6];
 #pragma unroll
-					for (int j = 0; j < 4; j++) e[i][j] = gb[((4 * ks + i) * (4 * WG_GW) + j) * WG_KB];
-				if (wc == 0 && cb == 0) {
+					for (int r6 = 0; r6 < 6; r6++) col[r6] = *(const f2v*)(ab + ((4 * ks + r6) * WG_RW + c6) * WG_CB);
+					wino_bt(col, y);
 #pragma unroll
-					for (int i = 0; i < 4; i++) bsum += (e[i][0] + e[i][1]) + (e[i][2] + e[i][3]);
-				}
-				float t1[6][4];
-#pragma unroll
-				for (int j = 0; j < 4; j++) {
-					const float col[4] = { e[0][j], e[1][j], e[2][j], e[3][j] };
-					float y[6];
-					wino_g4(col, y);
-#pragma unroll
-					for (int rr = 0; rr < 6; rr++) t1[rr][j] = y[rr];
+					for (int r6 = 0; r6 < 6; r6++) sm[r6][c6] = y[r6];
 				}
 #pragma unroll
-				for (int rr = 0; rr < 6; rr++) {
-					float y[6];
-					wino_g4(t1[rr], y);
+				for (int r6 = 0; r6 < 6; r6++) {
+					f2v y[6];
+					wino_bt(sm[r6], y);
 #pragma unroll
-					for (int q = 0; q < 6; q++) W[rr * 6 + q] = y[q];
+					for (int q = 0; q < 6; q++) V[r6 * 6 + q] = y[q];
 				}
 			}
-			wf_static_for<2>([&](auto jfc) {
-				constexpr int jf = decltype(jfc)::value;
-				// V = B^T d B of this lane's (tile, c = 16 jf + ch)
-				float V[36];
-				{
-					float s[6][6];
 #pragma unroll
-					for (int c6 = 0; c6 < 6; c6++) {
-						float col[6], y[6];
-#pragma unroll
-						for (int r6 = 0; r6 < 6; r6++) col[r6] = ab[((4 * ks + r6) * WG_RW + c6) * WG_CB + 16 * jf];
-						wino_bt(col, y);
-#pragma unroll
-						for (int r6 = 0; r6 < 6; r6++) s[r6][c6] = y[r6];
-					}
-#pragma unroll
-					for (int r6 = 0; r6 < 6; r6++) {
-						float y[6];
-						wino_bt(s[r6], y);
-#pragma unroll
-						for (int q = 0; q < 6; q++) V[r6 * 6 + q] = y[q];
-					}
-				}
-#pragma unroll
-				for (int z = 0; z < 36; z++) { NNC_PIN_V(V[z]); }
-				if constexpr (jf == 0) {
-#pragma unroll
-					for (int z = 0; z < 36; z++) { NNC_PIN_V(W[z]); }
-				}
+			for (int z = 0; z < 36; z++) { NNC_PIN_V(V[z].x); NNC_PIN_V(V[z].y); }
 #ifndef NNC_HIP_EMULATOR
-				asm volatile("s_nop 1"); // the last transform VALU -> an MFMA reading its result (asm MFMAs are outside hipcc's hazard handling)
+			asm volatile("s_nop 1"); // the last transform VALU -> an MFMA reading its result (asm MFMAs are outside hipcc's hazard handling)
 #endif
-				wf_static_for<36>([&](auto zc) {
-					constexpr int z = decltype(zc)::value;
-					if constexpr (!(DBG & 16)) WF_MFMA(acc[z][jf], W[z], V[z], z < WF_Z_AGPR);
-					// the next trip's pieces, one per six MFMAs over the first 96 of the trip's 144: the last block gives them time to land
-					constexpr int m = (ks * 2 + jf) * 36 + z;
-					// (the last trip of a slice issues them too, every lane out of range: zeros into a stage nobody reads -- no branch in the MFMA stream)
-					if constexpr (m % 6 == 0 && m / 6 < WG_PIECES_PER_WAVE && !(DBG & 1)) dma_piece(GroupId<m / 6>(), st ^ 1, has_next);
-				});
+			wf_static_for<72>([&](auto mc) {
+				constexpr int mm = decltype(mc)::value, z = mm >> 1, jf = mm & 1; // an accumulator recurs every 72 MFMAs; W[z] feeds two in a row
+				if constexpr (!(DBG & 16)) {
+					if constexpr (ks == 0 && jf == 0) WF_MFMA(acc[z][0], W[z].x, V[z].x, z < WF_Z_AGPR);
+					else if constexpr (ks == 0) WF_MFMA(acc[z][1], W[z].x, V[z].y, z < WF_Z_AGPR);
+					else if constexpr (jf == 0) WF_MFMA(acc[z][0], W[z].y, V[z].x, z < WF_Z_AGPR);
+					else WF_MFMA(acc[z][1], W[z].y, V[z].y, z < WF_Z_AGPR);
+				}
+				// the next trip's pieces, one per six MFMAs over the first 96 of the trip's 144: the last 48 give them time to land
+				// (the last trip of a slice issues them too, every lane out of range: zeros into a stage nobody reads -- no branch in the MFMA stream)
+				constexpr int m = ks * 72 + mm;
+				if constexpr (m % 6 == 0 && m / 6 < WG_PIECES_PER_WAVE && !(DBG & 1)) dma_piece(GroupId<m / 6>(), st ^ 1, has_next);
 			});
 		});
 	}
@@ -218,14 +228,14 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 #endif
 	{
 		// D layout of 16x16x4: lane holds rows 4 (lane >> 4) + i (k), column lane & 15 (c)
-		float* const out = p.partial + (long)slice * 36 * p.K * p.C + (long)(kb * WG_KB + wk * 16 + 4 * slot) * p.C + cb * WG_CB + wc * 32 + ch;
+		float* const out = p.partial + (long)slice * 36 * p.K * p.C + (long)(kb * WG_KB + wk * 16 + 4 * slot) * p.C + cb * WG_CB + wc * 32 + 2 * ch; // column fragment j = input channel 2 ch + j
 		const long plane = (long)p.K * p.C;
 #pragma unroll
 		for (int z = 0; z < 36; z++)
 #pragma unroll
 			for (int j = 0; j < 2; j++)
 #pragma unroll
-				for (int i = 0; i < 4; i++) out[z * plane + (long)i * p.C + 16 * j] = acc[z][j][i];
+				for (int i = 0; i < 4; i++) out[z * plane + (long)i * p.C + j] = acc[z][j][i];
 		if (p.bias_partial && wc == 0 && cb == 0) p.bias_partial[((long)slice * 4 + slot) * p.K + kb * WG_KB + wk * 16 + ch] = bsum;
 	}
 }
