@@ -369,8 +369,8 @@ static int conv_wino_wgrad(const conv_geom_t& g, const wino_wgrad_plan_t& p, con
 // ---- fused Winograd filter gradient (wino_wgrad_fused.h): dw (+)= , dbias (+)= with neither V nor W in HBM ------------------------------------
 struct wino_wgrad_fused_plan_t {
 	int TH, TW, GYn, GXn, groups, kblocks, cblocks, slices, per_slice;
-	size_t partial_bytes, bias_bytes;
-	size_t total() const { return partial_bytes + bias_bytes; }
+	size_t partial_bytes, bias_bytes, du_bytes;
+	size_t total() const { return partial_bytes + bias_bytes + du_bytes; }
 };
 static bool wino_wgrad_fused_plan(const conv_geom_t& g, wino_wgrad_fused_plan_t* p)
 {
@@ -391,6 +391,7 @@ static bool wino_wgrad_fused_plan(const conv_geom_t& g, wino_wgrad_fused_plan_t*
 	p->per_slice = (int)((groups + s - 1) / s);
 	p->partial_bytes = (sizeof(float) * 36 * (size_t)s * g.K * g.C + 255) & ~(size_t)255;
 	p->bias_bytes = (sizeof(float) * 4 * (size_t)s * g.K + 255) & ~(size_t)255;
+	p->du_bytes = (sizeof(float) * 36 * (size_t)g.K * g.C + 255) & ~(size_t)255;
 	return true;
 }
 static bool wino_wgrad_fused_images_ok(const Image4& a, const Image4& gr, const float* dw)
@@ -425,8 +426,12 @@ static int conv_wino_wgrad_fused(const conv_geom_t& g, const wino_wgrad_fused_pl
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_wgrad_fused_kernel<0>), dim3((unsigned)(p.slices * p.kblocks * p.cblocks)), dim3(256), 0, stream, k);
 		HIP_ENFORCE(hipGetLastError());
 	}
-	const long most = (long)g.K * g.C;
-	hipLaunchKernelGGL(wino_wgrad_fused_final_kernel, dim3(blocks_exact((size_t)most, 256)), dim3(256), 0, stream, (const float*)k.partial, (const float*)k.bias_partial, dw, dbias, g.K, g.C, p.slices, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
+	const long n = 36L * g.K * g.C;
+	const int acc = (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0;
+	float* const dU = (float*)(ws + p.partial_bytes + p.bias_bytes);
+	hipLaunchKernelGGL(wino_wgrad_fused_fold_kernel, dim3(blocks_exact((size_t)n, 256)), dim3(256), 0, stream, (const float*)k.partial, (const float*)k.bias_partial, dU, dbias, n, g.K, p.slices, acc);
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3(blocks_exact((size_t)g.K * g.C, 256)), dim3(256), 0, stream, (const float*)dU, dw, g.K, g.C, acc);
 	HIP_ENFORCE(hipGetLastError());
 	if (bias_done) *bias_done = dbias != 0;
 	return CCV_NNC_EXEC_SUCCESS;

@@ -13,7 +13,7 @@
 // itself -- no staging of transformed data, no cross-lane traffic.  Accumulators: 36 positions x 16 k x 32 c per wave = 72 MFMA tiles = 288
 // registers (the same budget as the fused forward kernel: 60 tiles pinned to AGPRs through asm operand classes); a workgroup of four waves
 // covers a 32 k x 64 c block, and the grid is (K / 32) x (C / 64) blocks x `slices` ranges of tile groups; every workgroup writes its
-// partial dU once at the end, wino_wgrad_fused_final_kernel folds the slices in a fixed order and applies A'^T . A'.
+// partial dU once at the end, wino_wgrad_fused_fold_kernel folds the slices in a fixed order and winograd.h's wino_wgrad_final_kernel applies A'^T . A'.
 //
 // Data path.  A trip = one 2 x 4 group of tiles (two MFMA k-steps): the 10 x 18 pixel input region x 64 channels (45 KB: whole 128-byte
 // lines) and the 8 x 16 pixel gradient region x 32 channels (16 KB) arrive by LDS-DMA (buffer_load ... lds: no VGPR round trip, out-of-image
@@ -139,8 +139,11 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 
 	for (int grp = g_first; grp < g_end; grp++) {
 		const int st = (grp - g_first) & 1;
-		WF_WAIT_VMCNT(0);                 // this wave's pieces of the trip have landed ...
-		__builtin_amdgcn_s_barrier();     // ... and so have everybody's; every wave is done reading the other stage
+		// (DBG, tools/wgrad_probe.cpp only: 1 no DMA in the loop, 2 no LDS reads / transforms, 16 no MFMAs, 32 no wait + barrier -- timing only)
+		if constexpr (!(DBG & 32)) {
+			WF_WAIT_VMCNT(0);                 // this wave's pieces of the trip have landed ...
+			__builtin_amdgcn_s_barrier();     // ... and so have everybody's; every wave is done reading the other stage
+		}
 		const bool has_next = grp + 1 < g_end;
 		if (has_next) set_group(grp + 1);
 		// lane (ch, slot): input channels 2 ch, 2 ch + 1 of the wave's 32 (the two MFMA column fragments: one 8-byte LDS read serves both, and the
@@ -149,7 +152,10 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 		const float* const gb = lds + st * (WG_STAGE_BYTES / 4) + WG_A_BYTES / 4 + (4 * slot) * WG_KB + wk * 16 + ch;  // + (y * 16 + x) * 32
 		// W = G' e G'^T of this lane's (tile, k), BOTH k-steps at once (x: tile row 0, y: tile row 1)
 		f2v W[36];
-		{
+		if constexpr (DBG & 2) {
+#pragma unroll
+			for (int z = 0; z < 36; z++) W[z] = f2v{ 1.f + z, 2.f };
+		} else {
 			f2v e[4][4];
 #pragma unroll
 			for (int i = 0; i < 4; i++)
@@ -182,7 +188,10 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 			constexpr int ks = decltype(ksc)::value; // tiles (ty = ks, tx = slot)
 			// V = B^T d B of this lane's (tile, c = 2 ch, 2 ch + 1)
 			f2v V[36];
-			{
+			if constexpr (DBG & 2) {
+#pragma unroll
+				for (int z = 0; z < 36; z++) V[z] = f2v{ 3.f, 1.f + z };
+			} else {
 				f2v sm[6][6];
 #pragma unroll
 				for (int c6 = 0; c6 < 6; c6++) {
@@ -240,40 +249,21 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 	}
 }
 
-// dw[k][i][j][c] (+)= (A'^T (sum over slices partial[s][.][k][c]) A')[i][j]; dbias[k] (+)= sum over slices and tile slots.  One thread per (k, c), slices in order.
-static __global__ void __launch_bounds__(256) wino_wgrad_fused_final_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial, float* __restrict__ dw, float* __restrict__ dbias, const int K, const int C, const int slices, const int accumulate)
+// dU[z][k][c] = sum over slices of partial[s][z][k][c], slices in order (deterministic): one thread per (z, k, c) element -- 36 K C threads walking
+// `slices` coalesced rows.  (The first version folded inside the final transform, one thread per (k, c): 16 workgroups walking 128 slices x 36
+// strided loads took 1.3 ms on conv1_2, a third of the contraction itself.)  dbias[k] (+)= the same fold of the bias partials, by the first K threads.
+static __global__ void __launch_bounds__(256) wino_wgrad_fused_fold_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial, float* __restrict__ du, float* __restrict__ dbias, const long n, const int K, const int slices, const int accumulate)
 {
 	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const long plane = (long)K * C;
-	if (idx < plane) {
-		const int k = (int)(idx / C), c = (int)(idx - (long)k * C);
-		float du[36];
-#pragma unroll
-		for (int z = 0; z < 36; z++) du[z] = 0.f;
-		for (int s = 0; s < slices; s++) {
-			const float* const ps = partial + (long)s * 36 * plane + idx;
-#pragma unroll
-			for (int z = 0; z < 36; z++) du[z] += ps[z * plane];
+	if (idx < n) {
+		float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f; // four loads in flight; the order of the additions is fixed
+		int s = 0;
+		for (; s + 4 <= slices; s += 4) {
+			s0 += partial[(long)s * n + idx]; s1 += partial[(long)(s + 1) * n + idx];
+			s2 += partial[(long)(s + 2) * n + idx]; s3 += partial[(long)(s + 3) * n + idx];
 		}
-		float sm[3][6];
-#pragma unroll
-		for (int q = 0; q < 6; q++) {
-			const float col[6] = { du[0 * 6 + q], du[1 * 6 + q], du[2 * 6 + q], du[3 * 6 + q], du[4 * 6 + q], du[5 * 6 + q] };
-			float y[3];
-			wino_at3(col, y);
-#pragma unroll
-			for (int i = 0; i < 3; i++) sm[i][q] = y[i];
-		}
-#pragma unroll
-		for (int i = 0; i < 3; i++) {
-			float y[3];
-			wino_at3(sm[i], y);
-#pragma unroll
-			for (int j = 0; j < 3; j++) {
-				float* const o = dw + ((long)k * 9 + i * 3 + j) * C + c;
-				*o = accumulate ? *o + y[j] : y[j];
-			}
-		}
+		for (; s < slices; s++) s0 += partial[(long)s * n + idx];
+		du[idx] = (s0 + s1) + (s2 + s3);
 	}
 	if (dbias && bias_partial && idx < K) {
 		float s = 0.f;
