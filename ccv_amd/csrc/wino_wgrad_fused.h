@@ -135,13 +135,20 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 #ifndef NNC_HIP_EMULATOR
 	asm volatile("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them
 #endif
-	wf_static_for<WG_PIECES_PER_WAVE>([&](auto ic) { dma_piece(ic, 0, true); });
+	wf_static_for<WG_PIECES_PER_WAVE>([&](auto nc) {
+		constexpr int n = decltype(nc)::value, piece = n < 7 ? n : (n < 11 ? WG_A_PER_WAVE + (n - 7) : n - 4); // the trips' issue order
+		dma_piece(GroupId<piece>(), 0, true);
+	});
 
 	for (int grp = g_first; grp < g_end; grp++) {
 		const int st = (grp - g_first) & 1;
 		// (DBG, tools/wgrad_probe.cpp only: 1 no DMA in the loop, 2 no LDS reads / transforms, 16 no MFMAs, 32 no wait + barrier -- timing only)
+		// Issue order of a trip's 16 pieces per wave (during the PREVIOUS trip, one behind every ninth MFMA -- the CU retires a piece per ~65 cycles,
+		// a denser stream queues and blocks the in-order wave): first what k-step 0 needs -- input pieces 0 .. 6 (region rows 0 .. 5; + row 6 for wave 3)
+		// and the four gradient pieces (both k-steps' W are made at the top) -- then input pieces 7 .. 11 (rows 6 .. 9, k-step 1 only).  So the wait at
+		// the top leaves the last five in flight, and a second wait + barrier sits in front of k-step 1 (behind the eight pieces issued meanwhile).
 		if constexpr (!(DBG & 32)) {
-			WF_WAIT_VMCNT(0);                 // this wave's pieces of the trip have landed ...
+			WF_WAIT_VMCNT(5);                 // this wave's early pieces of the trip have landed ...
 			__builtin_amdgcn_s_barrier();     // ... and so have everybody's; every wave is done reading the other stage
 		}
 		const bool has_next = grp + 1 < g_end;
@@ -186,6 +193,10 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 		for (int z = 0; z < 36; z++) { NNC_PIN_V(W[z].x); NNC_PIN_V(W[z].y); }
 		wf_static_for<2>([&](auto ksc) {
 			constexpr int ks = decltype(ksc)::value; // tiles (ty = ks, tx = slot)
+			if constexpr (ks == 1 && !(DBG & 32)) {
+				WF_WAIT_VMCNT(8);             // the late five of THIS trip's pieces (rows 6 .. 9), behind the eight issued for the next trip so far
+				__builtin_amdgcn_s_barrier();
+			}
 			// V = B^T d B of this lane's (tile, c = 2 ch, 2 ch + 1)
 			f2v V[36];
 			if constexpr (DBG & 2) {
@@ -223,10 +234,14 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 					else if constexpr (jf == 0) WF_MFMA(acc[z][0], W[z].y, V[z].x, z < WF_Z_AGPR);
 					else WF_MFMA(acc[z][1], W[z].y, V[z].y, z < WF_Z_AGPR);
 				}
-				// the next trip's pieces, one per six MFMAs over the first 96 of the trip's 144: the last 48 give them time to land
+				// the next trip's pieces, one behind every ninth MFMA, early ones first (see the top of the trip)
 				// (the last trip of a slice issues them too, every lane out of range: zeros into a stage nobody reads -- no branch in the MFMA stream)
 				constexpr int m = ks * 72 + mm;
-				if constexpr (m % 6 == 0 && m / 6 < WG_PIECES_PER_WAVE && !(DBG & 1)) dma_piece(GroupId<m / 6>(), st ^ 1, has_next);
+				if constexpr (m % 9 == 0 && !(DBG & 1)) {
+					constexpr int n = m / 9; // 0 .. 15
+					constexpr int piece = n < 7 ? n : (n < 11 ? WG_A_PER_WAVE + (n - 7) : n - 4);
+					dma_piece(GroupId<piece>(), st ^ 1, has_next);
+				}
 			});
 		});
 	}
