@@ -58,6 +58,37 @@ __global__ void __launch_bounds__(256) transpose_tile_kernel(const T* in, T* out
 	}
 }
 
+// The same for 4-byte elements with 16-BYTE global accesses both ways (R % 4 == 0, C % 4 == 0, 16-byte aligned bases): a thread loads four consecutive c
+// of a row as one dwordx4, writes them to the tile as four dwords, and after the barrier gathers four consecutive r of a column into one dwordx4 store.
+// The one-dword-per-lane kernel above ran the ResNet-50 / DawnNet re-layouts at ~4 TB/s (profiles/r02_v10_transpose_bench.txt; 15 % of config 4's step);
+// pitch 65 keeps both LDS phases at 2-way conflicts at most (bank = (4 r4 + e + lane row) mod 32).
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_tile_vec4_kernel(const T* __restrict__ in, T* __restrict__ out, const int R, const int C)
+{
+	typedef T T4 __attribute__((ext_vector_type(4)));
+	__shared__ T tile[TT][TT + 1];
+	const int c0 = blockIdx.x * TT, r0 = blockIdx.y * TT;
+	const size_t base = (size_t)blockIdx.z * R * C;
+	const int q = threadIdx.x & 15, l = threadIdx.x >> 4;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const int r = r0 + l + 16 * i, c = c0 + 4 * q;
+		if (r < R && c < C) {
+			const T4 v = *(const T4*)(in + base + (size_t)r * C + c);
+			tile[l + 16 * i][4 * q] = v[0]; tile[l + 16 * i][4 * q + 1] = v[1]; tile[l + 16 * i][4 * q + 2] = v[2]; tile[l + 16 * i][4 * q + 3] = v[3];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const int c = c0 + l + 16 * i, r = r0 + 4 * q;
+		if (c < C && r < R) {
+			const T4 v = { tile[4 * q][l + 16 * i], tile[4 * q + 1][l + 16 * i], tile[4 * q + 2][l + 16 * i], tile[4 * q + 3][l + 16 * i] };
+			*(T4*)(out + base + (size_t)c * R + r) = v;
+		}
+	}
+}
+
 // The same tile transpose with a type change on the way through LDS: half-precision NCHW tensors become the fp32 NHWC images the
 // fp32 convolution kernels read (and back) in ONE pass each -- the layout change the NCHW path needs anyway carries the conversion,
 // where converting first and transposing second moved every element twice more.
@@ -76,6 +107,35 @@ __global__ void __launch_bounds__(256) transpose_convert_kernel(const TI* in, TO
 	for (int j = ty; j < TT; j += 4) {
 		const int c = c0 + j, r = r0 + tx;
 		if (r < R && c < C) out[base + (size_t)c * R + r] = (TO)tile[tx][j];
+	}
+}
+
+// ... and its four-elements-per-access form (8-byte accesses on the half side, 16-byte on the float side; same conditions as transpose_tile_vec4_kernel)
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) transpose_convert_vec4_kernel(const TI* __restrict__ in, TO* __restrict__ out, const int R, const int C)
+{
+	typedef TI TI4 __attribute__((ext_vector_type(4)));
+	typedef TO TO4 __attribute__((ext_vector_type(4)));
+	__shared__ float tile[TT][TT + 1];
+	const int c0 = blockIdx.x * TT, r0 = blockIdx.y * TT;
+	const size_t base = (size_t)blockIdx.z * R * C;
+	const int q = threadIdx.x & 15, l = threadIdx.x >> 4;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const int r = r0 + l + 16 * i, c = c0 + 4 * q;
+		if (r < R && c < C) {
+			const TI4 v = *(const TI4*)(in + base + (size_t)r * C + c);
+			tile[l + 16 * i][4 * q] = (float)v[0]; tile[l + 16 * i][4 * q + 1] = (float)v[1]; tile[l + 16 * i][4 * q + 2] = (float)v[2]; tile[l + 16 * i][4 * q + 3] = (float)v[3];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const int c = c0 + l + 16 * i, r = r0 + 4 * q;
+		if (c < C && r < R) {
+			const TO4 v = { (TO)tile[4 * q][l + 16 * i], (TO)tile[4 * q + 1][l + 16 * i], (TO)tile[4 * q + 2][l + 16 * i], (TO)tile[4 * q + 3][l + 16 * i] };
+			*(TO4*)(out + base + (size_t)c * R + r) = v;
+		}
 	}
 }
 
@@ -126,6 +186,13 @@ template <typename T>
 static int launch_transpose(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
 {
 	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;
+	if constexpr (sizeof(T) == 4) {
+		if (R % 4 == 0 && C % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_tile_vec4_kernel<T>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const T*)in, (T*)out, R, C);
+			HIP_ENFORCE(hipGetLastError());
+			return CCV_NNC_EXEC_SUCCESS;
+		}
+	}
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_tile_kernel<T>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const T*)in, (T*)out, R, C);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
@@ -191,6 +258,11 @@ int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_str
 int transpose_half_to_float(const void* in, float* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
 {
 	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;
+	if (R % 4 == 0 && C % 4 == 0 && ((uintptr_t)in & 7) == 0 && ((uintptr_t)out & 15) == 0) {
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_convert_vec4_kernel<half_t, float>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, out, R, C);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_convert_kernel<half_t, float>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, out, R, C);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
@@ -198,6 +270,11 @@ int transpose_half_to_float(const void* in, float* out, int batch, int R, int C,
 int transpose_float_to_half(const float* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
 {
 	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;
+	if (R % 4 == 0 && C % 4 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0) {
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_convert_vec4_kernel<float, half_t>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), in, (half_t*)out, R, C);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_convert_kernel<float, half_t>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), in, (half_t*)out, R, C);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
