@@ -197,6 +197,17 @@ static int launch_transpose(const void* in, void* out, int batch, int R, int C, 
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
+// 2-byte elements that are halves (the only 2-byte tensor type the rows register): four per access through the float tile of the converting
+// transpose -- half -> float -> half is exact
+static int launch_transpose_half(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
+{
+	if (batch > 0 && R > 0 && C > 0 && R % 4 == 0 && C % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 7) == 0) {
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_convert_vec4_kernel<half_t, half_t>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, (half_t*)out, R, C);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
+	return launch_transpose<uint16_t>(in, out, batch, R, C, ctx);
+}
 
 static int by_size_permute(size_t es, const void* in, void* out, const perm4_t& p, ccv_nnc_stream_context_t* ctx)
 {
@@ -211,7 +222,7 @@ static int by_size_permute(size_t es, const void* in, void* out, const perm4_t& 
 static int by_size_transpose(size_t es, const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
 {
 	switch (es) {
-		case 2: return launch_transpose<uint16_t>(in, out, batch, R, C, ctx);
+		case 2: return launch_transpose_half(in, out, batch, R, C, ctx);
 		case 4: return launch_transpose<uint32_t>(in, out, batch, R, C, ctx);
 		case 8: return launch_transpose<uint64_t>(in, out, batch, R, C, ctx);
 	}
