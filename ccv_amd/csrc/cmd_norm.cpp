@@ -23,6 +23,7 @@ struct RXhatG { const float* mean; const float* inv_std; __device__ float operat
 
 constexpr int RC_COLS = 64, RC_PHASES = 4;
 // inner == 1: rows of C contiguous channels.  grid (ceil(C/64), slices); lanes = 64 consecutive channels.
+static unsigned plane_grid(const long planes);
 template <class F, bool USE_G, class T>
 __global__ void __launch_bounds__(256) chan_reduce_rows_kernel(F f, const T* x, const T* g, const long rows, const int C, const long rows_per_slice, float* partial)
 {
@@ -111,8 +112,8 @@ static int chan_reduce(F f, const T* x, const T* g, const chan_view_t& v, float*
 		slices = v.outer;
 		partial = (float*)workspace_of(ctx, sizeof(float) * (size_t)slices * v.C);
 		if (!partial) return CCV_NNC_EXEC_OOM;
-		const long planes = v.outer * v.C, want = (planes + 3) / 4, cap = (long)device_cu_count() * 8;
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_planes_kernel<F, USE_G, T>), dim3((unsigned)(want < cap ? (want > 0 ? want : 1) : cap)), dim3(256), 0, stream, f, x, g, v.C, v.inner, planes, partial);
+		const long planes = v.outer * v.C;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(chan_reduce_planes_kernel<F, USE_G, T>), dim3(plane_grid(planes)), dim3(256), 0, stream, f, x, g, v.C, v.inner, planes, partial);
 	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + FOLD_CH - 1) / FOLD_CH), dim3(256), 0, stream, (const float*)partial, (const float*)0, slices, v.C, out, (float*)0, accumulate);
@@ -231,7 +232,11 @@ __global__ void __launch_bounds__(256) bn_plane_back_stats_kernel(const T* __res
 }
 static unsigned plane_grid(const long planes)
 {
-	const long want = (planes + 3) / 4, cap = (long)device_cu_count() * 8;
+	// one plane per wave over the WHOLE tensor, no grid-stride cap (round 3): the same lesson as the element-wise maps (section 3.2 of DESIGN.md -- a few
+	// thousand workgroups striding a multi-GB tensor keep DRAM pages from all over it in flight, a front of workgroups walking it in order does not; the
+	// capped form ran the batch-norm passes at ~3.4 TB/s).  TUNE_GRID_WG_PER_CU > 0 restores a cap.
+	const long want = (planes + 3) / 4, per_cu = tune(TUNE_GRID_WG_PER_CU);
+	const long cap = per_cu > 0 ? (long)device_cu_count() * per_cu : 0x7fffffffL;
 	return (unsigned)(want < cap ? (want > 0 ? want : 1) : cap);
 }
 
