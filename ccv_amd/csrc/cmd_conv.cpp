@@ -689,7 +689,9 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 		if (r != CCV_NNC_EXEC_OOM) return r;
 	}
 	wino_wgrad_fused_plan_t wfp;
-	if (algo != CONV_ALGO_IMPLICIT_GEMM && algo != CONV_ALGO_WINOGRAD && wino_wgrad_fused_plan(g, &wfp) && wino_wgrad_fused_images_ok(a, gr, dw) && (algo == CONV_ALGO_WINOGRAD_FUSED || wino_wgrad_fused_preferred(g))) {
+	// (algorithm 2 = "the fused kernels" takes the fused filter gradient under the same rule as algorithm -1: the host's autotuner times the WHOLE backward
+	// command per algorithm, and a 256-channel layer wants the fused data gradient next to the via-HBM filter gradient)
+	if (algo != CONV_ALGO_IMPLICIT_GEMM && algo != CONV_ALGO_WINOGRAD && wino_wgrad_fused_plan(g, &wfp) && wino_wgrad_fused_images_ok(a, gr, dw) && wino_wgrad_fused_preferred(g)) {
 		const int r = conv_wino_wgrad_fused(g, wfp, gr, a, dw, dbias, bias_done, flags, ctx);
 		if (r != CCV_NNC_EXEC_OOM) return r;
 	}

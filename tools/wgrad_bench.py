@@ -12,6 +12,7 @@ LAYERS = [(223, 64, 64), (111, 64, 128), (111, 128, 128), (55, 128, 256), (55, 2
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     L = nnc.load()
+    L.tune_set("WINO_WGRAD_FUSED_MAX", 1 << 20)  # measure the fused form on every eligible shape (the library's rule takes it up to 128 channels)
     s = L.stream_new(0)
     F = nnc.CCV_32F
     mk = lambda *d: L.tensor(nnc.GPU_TENSOR_NHWC(0, F, *d))
