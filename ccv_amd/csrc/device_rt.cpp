@@ -597,6 +597,92 @@ void nnc_mi355x_stream_signal_free(ccv_nnc_stream_signal_t* const signal)
 	free(signal);
 }
 
+// ---- pinned staging ring (include/nnc_mi355x.h: the host side of the GPU data pipeline) ------------------------------------------------
+namespace {
+struct staging_ring_t {
+	int device, slots;
+	size_t slot_bytes;
+	hipStream_t copy_stream;
+	void** host;
+	void** dev;
+	hipEvent_t* copied;   // recorded on the copy stream behind a slot's host-to-device copy
+	hipEvent_t* consumed; // recorded on the consumer's stream behind its last kernel reading the slot's device buffer
+	char* copy_pending;   // a copy out of host[s] has been submitted and not yet waited for
+	char* consumed_set;
+};
+}
+void* nnc_mi355x_staging_ring_new(int device, int slots, size_t slot_bytes)
+{
+	if (slots < 1 || slots > 64 || slot_bytes == 0) return 0;
+	const int prev = current_device();
+	HIP_ENFORCE(hipSetDevice(device));
+	staging_ring_t* r = (staging_ring_t*)calloc(1, sizeof(staging_ring_t));
+	r->device = device; r->slots = slots; r->slot_bytes = slot_bytes;
+	r->host = (void**)calloc(slots, sizeof(void*)); r->dev = (void**)calloc(slots, sizeof(void*));
+	r->copied = (hipEvent_t*)calloc(slots, sizeof(hipEvent_t)); r->consumed = (hipEvent_t*)calloc(slots, sizeof(hipEvent_t));
+	r->copy_pending = (char*)calloc(slots, 1); r->consumed_set = (char*)calloc(slots, 1);
+	bool ok = hipStreamCreate(&r->copy_stream) == hipSuccess; // a blocking stream like every stream of this library: orders against the legacy NULL stream
+	for (int i = 0; ok && i < slots; i++) {
+		ok = hipHostMalloc(&r->host[i], slot_bytes, hipHostMallocDefault) == hipSuccess && (r->dev[i] = nnc_mi355x_malloc(device, slot_bytes)) != 0
+			&& hipEventCreateWithFlags(&r->copied[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r->consumed[i], hipEventDisableTiming) == hipSuccess;
+	}
+	HIP_ENFORCE(hipSetDevice(prev));
+	if (!ok) { (void)hipGetLastError(); nnc_mi355x_staging_ring_free(r); return 0; }
+	return r;
+}
+void* nnc_mi355x_staging_ring_host(void* ring, int slot)
+{
+	staging_ring_t* r = (staging_ring_t*)ring;
+	if (!r || slot < 0 || slot >= r->slots) return 0;
+	if (r->copy_pending[slot]) { HIP_ENFORCE(hipEventSynchronize(r->copied[slot])); r->copy_pending[slot] = 0; } // the pinned buffer is still being read by the copy
+	return r->host[slot];
+}
+void* nnc_mi355x_staging_ring_device(void* ring, int slot)
+{
+	staging_ring_t* r = (staging_ring_t*)ring;
+	return (!r || slot < 0 || slot >= r->slots) ? 0 : r->dev[slot];
+}
+int nnc_mi355x_staging_ring_submit(void* ring, int slot, size_t bytes)
+{
+	staging_ring_t* r = (staging_ring_t*)ring;
+	if (!r || slot < 0 || slot >= r->slots || bytes > r->slot_bytes) return 0;
+	nnc::comm_flush_if_pending(); // (a copy is an order-observing point for recorded commands, like nnc_mi355x_memcpy)
+	if (r->consumed_set[slot]) HIP_ENFORCE(hipStreamWaitEvent(r->copy_stream, r->consumed[slot], 0)); // the device buffer's last reader, on the device
+	HIP_ENFORCE(hipMemcpyAsync(r->dev[slot], r->host[slot], bytes, hipMemcpyHostToDevice, r->copy_stream));
+	HIP_ENFORCE(hipEventRecord(r->copied[slot], r->copy_stream));
+	r->copy_pending[slot] = 1;
+	return 1;
+}
+int nnc_mi355x_staging_ring_acquire(void* ring, int slot, ccv_nnc_stream_context_t* const consumer)
+{
+	staging_ring_t* r = (staging_ring_t*)ring;
+	if (!r || slot < 0 || slot >= r->slots) return 0;
+	HIP_ENFORCE(hipStreamWaitEvent(nnc::stream_of(consumer), r->copied[slot], 0));
+	return 1;
+}
+int nnc_mi355x_staging_ring_release(void* ring, int slot, ccv_nnc_stream_context_t* const consumer)
+{
+	staging_ring_t* r = (staging_ring_t*)ring;
+	if (!r || slot < 0 || slot >= r->slots) return 0;
+	HIP_ENFORCE(hipEventRecord(r->consumed[slot], nnc::stream_of(consumer)));
+	r->consumed_set[slot] = 1;
+	return 1;
+}
+void nnc_mi355x_staging_ring_free(void* ring)
+{
+	staging_ring_t* r = (staging_ring_t*)ring;
+	if (!r) return;
+	if (r->copy_stream) { (void)hipStreamSynchronize(r->copy_stream); (void)hipStreamDestroy(r->copy_stream); }
+	for (int i = 0; i < r->slots; i++) {
+		if (r->host && r->host[i]) (void)hipHostFree(r->host[i]);
+		if (r->dev && r->dev[i]) nnc_mi355x_free(r->device, r->dev[i]);
+		if (r->copied && r->copied[i]) (void)hipEventDestroy(r->copied[i]);
+		if (r->consumed && r->consumed[i]) (void)hipEventDestroy(r->consumed[i]);
+	}
+	free(r->host); free(r->dev); free(r->copied); free(r->consumed); free(r->copy_pending); free(r->consumed_set);
+	free(r);
+}
+
 void* nnc_mi355x_event_new(void)
 {
 	hipEvent_t e;

@@ -398,6 +398,22 @@ int nnc_mi355x_jitter_batch(const void* src, const nnc_mi355x_jitter_image_t* im
 /* _ccv_cnnp_one_hot (:378-): out[i][k] = k == labels[i] ? onval : offval, `range` values per row, CCV_32F or CCV_16F. */
 int nnc_mi355x_one_hot_batch(const int* labels_host, const int count, const int range, const float onval, const float offval, const int datatype, void* out, ccv_nnc_stream_context_t* const stream_context);
 
+/* Pinned staging ring: the host side of the GPU data pipeline (replaces the per-batch pageable copies behind
+ * ccv_cnnp_dataframe_copy_to_gpu, lib/nnc/ccv_cnnp_dataframe_addons.c:21-120).  `slots` pinned host buffers and as many device buffers of
+ * `slot_bytes`, one copy stream of its own.  A loader thread fills slot s on the host (..._host), hands it over (..._submit: asynchronous
+ * host-to-device copy; the copy first waits -- on the device -- for the consumer that last read the slot's device buffer); the training stream
+ * takes it (..._acquire: the consumer stream waits for the copy, the host does not), runs its kernels on ..._device(s) (nnc_mi355x_jitter_batch),
+ * and gives it back (..._release: marks the point on the consumer stream behind which the device buffer may be overwritten).  ..._host blocks
+ * until the previous copy OUT of that pinned buffer has finished, so a slot is refilled while other slots' copies and kernels run.
+ * Returns 0 / a null pointer on a bad slot or an allocation failure. */
+void* nnc_mi355x_staging_ring_new(int device, int slots, size_t slot_bytes);
+void* nnc_mi355x_staging_ring_host(void* ring, int slot);
+void* nnc_mi355x_staging_ring_device(void* ring, int slot);
+int   nnc_mi355x_staging_ring_submit(void* ring, int slot, size_t bytes);
+int   nnc_mi355x_staging_ring_acquire(void* ring, int slot, ccv_nnc_stream_context_t* const consumer);
+int   nnc_mi355x_staging_ring_release(void* ring, int slot, ccv_nnc_stream_context_t* const consumer);
+void  nnc_mi355x_staging_ring_free(void* ring);
+
 /* HIP-event timing on the stream a context launches on (bench.py roofline leg). */
 void* nnc_mi355x_event_new(void);
 void  nnc_mi355x_event_record(void* event, const ccv_nnc_stream_context_t* const stream_context);
