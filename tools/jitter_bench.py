@@ -16,6 +16,7 @@ import test_jitter as J  # noqa: E402
 
 
 def main():
+    sys.stdout.reconfigure(line_buffering=True)
     L = nnc.load()
     n, size = 256, (224, 224)
     rng = np.random.default_rng(0)
@@ -73,6 +74,7 @@ def main():
     d.nnc_mi355x_staging_ring_submit.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     d.nnc_mi355x_staging_ring_acquire.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     d.nnc_mi355x_staging_ring_release.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    d.nnc_mi355x_staging_ring_free.argtypes = [C.c_void_p]
     slots = 3
     ring = d.nnc_mi355x_staging_ring_new(0, slots, (host.nbytes + 127) & ~127)
     for fill in (False, True):
