@@ -31,8 +31,8 @@ namespace nnc {
 constexpr int WF_KT = 32;                       // output channels per workgroup (2 MFMA column tiles per wave)
 constexpr int WF_CC = 8;                        // reduction channels per chunk
 constexpr int WF_U_FLOATS = 36 * 64 * 2 * 2;    // one chunk of U fragments: [z][lane][j][e], 36 KB
-constexpr int WF_HP = 352;                      // pixel slots per channel-half plane of a patch buffer (11 DMA pieces x 64 granules / 2)
-constexpr int WF_P_FLOATS = 2 * WF_HP * 4;      // one patch buffer: [h][slot][4 channels], 11 KB
+constexpr int WF_HP = 352;                      // pixel slots of a patch buffer (11 DMA pieces x 64 granules / 2)
+constexpr int WF_P_FLOATS = 2 * WF_HP * 4;      // one patch buffer: [slot][8 channels], 11 KB -- a pixel's 32 bytes adjacent: lanes 2 i, 2 i + 1 of a piece fetch the two halves of ONE pixel
 constexpr int WF_P_PIECES = 11;
 constexpr int WF_Z_AGPR = 30;                     // positions whose two accumulator tiles live in AGPRs (60 tiles = 240 of the 256: hipcc needs slack there), the rest in VGPRs
 constexpr unsigned WF_OOB = 0x7ffff000u;        // a buffer offset beyond every image: the DMA writes zeros
@@ -313,6 +313,8 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 	typedef WfPair<(SCHED > 0 ? SCHED - 1 : 0)> PS;
 	typedef WfGeom<GH, GW> G;
 	constexpr int GWL = GW == 4 ? 2 : (GW == 8 ? 3 : (GW == 2 ? 1 : (GW == 16 ? 4 : 0)));
+	static_assert(GWL >= 1 && GWL <= 3, "tile groups 8 x 2, 4 x 4, 2 x 8");
+	constexpr int FSH = 3 - GWL; // see the patch reads
 	__shared__ __attribute__((aligned(16))) float lds[2 * WF_U_FLOATS + 8 * WF_P_FLOATS]; // 160 KB: [U ring x2][patch x2 per wave]
 	const int t = threadIdx.x;
 	const int lane = t & 63;
@@ -363,8 +365,9 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
 	for (int q = 0; q < WF_P_PIECES; q++) {
 		const int s = q * 64 + lane;
-		const int hh = s >= WF_HP ? 1 : 0, slot = s - hh * WF_HP;
+		const int slot = s >> 1; // granule s of the buffer belongs to pixel slot s / 2: the two lanes of a pixel fetch 32 contiguous bytes (one line, one sector)
 		const unsigned yx = wf_slot_tab<GH, GW>.yx[slot];
+		const int hh = (s & 1) ^ (int)((yx >> (10 + FSH)) & 1); // ... its channel halves swapped in every other band of plane rows (f below): bank spreading for the reads
 		pyx[q] = yx == 0xffffu ? -1 : (int)(yx | (unsigned)hh << 16);
 	}
 	const int sh4 = (int)a.s_sh * 4, sw4 = (int)a.s_sw * 4; // an image spans < 2^31 bytes (host-checked): 32-bit offsets
@@ -396,10 +399,12 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 
 	// per-lane read offsets (floats) into a patch buffer: slot(4 ty + r, 4 tx + c) = const(r, c) + ty * cx(c & 3) + tx
 	const int h = g >> 1;
-	const int pbase = h * WF_HP * 4 + 2 * (g & 1);
-	const int b5 = (ty * (GW + 1) + tx) * 4 + pbase, b4 = (ty * GW + tx) * 4 + pbase;
+	// (a pixel is 32 bytes, so tiles L and L + 8 of a plane would share their banks: the halves of a pixel are stored swapped where f(py) = bit FSH of the
+	// pixel's plane row py = Y >> 2 is set -- tiles ty and ty + 8 / GW then read different halves of the 64 banks; py = ty + (r >> 2), hence two bases per lane)
+	const int pb0 = (h ^ ((ty >> FSH) & 1)) * 4 + 2 * (g & 1), pb1 = (h ^ (((ty + 1) >> FSH) & 1)) * 4 + 2 * (g & 1);
+	const int b5[2] = { (ty * (GW + 1) + tx) * 8 + pb0, (ty * (GW + 1) + tx) * 8 + pb1 }, b4[2] = { (ty * GW + tx) * 8 + pb0, (ty * GW + tx) * 8 + pb1 };
 	auto patch_read = [&](const float* const pb, const int r, const int c) -> f2 {
-		const int off = (G::plane_off(r & 3, c & 3) + (r >> 2) * G::cx(c & 3) + (c >> 2)) * 4 + ((c & 3) < 2 ? b5 : b4);
+		const int off = (G::plane_off(r & 3, c & 3) + (r >> 2) * G::cx(c & 3) + (c >> 2)) * 8 + ((c & 3) < 2 ? b5[r >> 2] : b4[r >> 2]);
 		const float2 v = *(const float2*)(pb + off);
 		return f2(v.x, v.y);
 	};
@@ -685,6 +690,8 @@ template <int GH, int GW>
 __global__ void __launch_bounds__(256) wino_mask_pack_kernel(const float* __restrict__ mask, const long m_sn, const long m_sh, const long m_sw, unsigned* __restrict__ bits, const int OH, const int OW, const int K, const int GYn, const int GXn, const int KB)
 {
 	constexpr int GWL = GW == 4 ? 2 : (GW == 8 ? 3 : (GW == 2 ? 1 : (GW == 16 ? 4 : 0)));
+	static_assert(GWL >= 1 && GWL <= 3, "tile groups 8 x 2, 4 x 4, 2 x 8");
+	constexpr int FSH = 3 - GWL; // see the patch reads
 	static_assert(GH * GW == 16, "16 tiles per group");
 	int b = (int)blockIdx.x;
 	const int kb = b % KB; b /= KB;
