@@ -41,15 +41,10 @@ constexpr unsigned WF_OOB = 0x7ffff000u;        // a buffer offset beyond every 
 template <class F, int... I> __device__ __forceinline__ void wf_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(GroupId<I>()), ...); }
 template <int N, class F> __device__ __forceinline__ void wf_static_for(F&& f) { wf_static_for_impl(f, std::make_integer_sequence<int, N>()); }
 
-struct f2 {
-	float x, y;
-	__device__ __forceinline__ f2() {}
-	__device__ __forceinline__ f2(float a, float b) : x(a), y(b) {}
-};
-__device__ __forceinline__ f2 operator+(const f2 a, const f2 b) { return f2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ f2 operator-(const f2 a, const f2 b) { return f2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ f2 operator*(const float s, const f2 a) { return f2(s * a.x, s * a.y); }
-__device__ __forceinline__ f2 operator*(const f2 a, const float s) { return f2(s * a.x, s * a.y); }
+// A channel pair in an aligned register pair: hipcc selects v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 for its arithmetic.  Next to the MFMAs a packed
+// operation costs what a scalar one does (tools/coissue2_probe.cpp on the MI355X: one wave, MFMA + n independent VALU = 41.7 + 4.1 n clocks per MFMA for
+// v_fma_f32 and v_pk_fma_f32 alike; the first VALU behind an MFMA costs ~14 clocks, hence the transforms in batches), so the transforms are half the VALU.
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Space-to-depth slot of region pixel (Y, X) for a GH x GW tile group: planes by (Y & 3, X & 3), plane (yy, xx) holds
 // (GH + (yy < 2)) x (GW + (xx < 2)) pixels row-major.  The 16 tiles of a wave read pixel (4 ty + r, 4 tx + c): same plane,
@@ -270,7 +265,11 @@ struct WfPair {
 //   y0 = 4 x0 + m, y1 = a + b, y2 = a - b, y3 = c + 2 t, y4 = c - 2 t, y5 = 4 x1 + n          (= wino_bt)
 // (each result is pinned where it is computed: hipcc otherwise sinks every transform to the end of the loop body, behind
 // the last MFMA, whatever the sched_barrier fences say -- they bind the machine scheduler, not the IR passes before it)
-#define WF_PIN2(v) do { NNC_PIN_V((v).x); NNC_PIN_V((v).y); } while (0)
+#ifdef NNC_HIP_EMULATOR
+#define WF_PIN2(v) ((void)0)
+#else
+#define WF_PIN2(v) asm volatile("" : "+v"(v))
+#endif
 template <int PART, int K>
 __device__ __forceinline__ void wf_bt_op(const f2& x0, const f2& x1, const f2& x2, const f2& x3, const f2& x4, const f2& x5, f2& y0, f2& y1, f2& y2, f2& y3, f2& y4, f2& y5, f2 (&T)[6])
 {
@@ -406,7 +405,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 	auto patch_read = [&](const float* const pb, const int r, const int c) -> f2 {
 		const int off = (G::plane_off(r & 3, c & 3) + (r >> 2) * G::cx(c & 3) + (c >> 2)) * 8 + ((c & 3) < 2 ? b5[r >> 2] : b4[r >> 2]);
 		const float2 v = *(const float2*)(pb + off);
-		return f2(v.x, v.y);
+		return f2{ v.x, v.y };
 	};
 
 	// ---- prologue (once per workgroup): the first item's chunk 0 transformed completely (S, then V columns 0..4; column 5 is
@@ -468,7 +467,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		const unsigned p_dst = p_lds + par * (WF_P_FLOATS * 4), u_dst = u_lds + (par ^ 1) * (WF_U_FLOATS * 4);
 		f2 d[2][6];
 		float4 u[2];
-		if constexpr (DBG & 2) for (int i = 0; i < 12; i++) d[i / 6][i % 6] = f2(1.f, 2.f);
+		if constexpr (DBG & 2) for (int i = 0; i < 12; i++) d[i / 6][i % 6] = f2{ 1.f, 2.f };
 		if constexpr (DBG & 4) u[1] = make_float4(1.f, 2.f, 3.f, 4.f);
 		u[0] = *(const float4*)(ub);
 		wf_static_for<36>([&](auto itc) {
