@@ -276,10 +276,10 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
-// algorithm -1: the fused kernel where it measures faster on the MI355X (tools/conv_algo_sweep.py at batch 256):
-// few reduction channels -- the via-HBM form is bandwidth-bound there (conv1_2: 3.6 vs 7.8 ms, 128 -> 128 at 111^2: 3.1 vs 4.5) --
-// up to TUNE_WINO_FUSED_MAX_C (default 128), and up to twice that when the 16-tile groups pad the tile grid by less than a
-// fifth (256 -> 256 at 55^2: 2.9 vs 3.1 ms; at 27^2, 7 -> 8 tiles per side, the via-HBM form wins).
+// algorithm -1: the fused kernel where it measures faster on the MI355X (tools/conv_algo_sweep.py at batch 256, profiles/r03_v8_conv_algo_sweep.txt):
+// up to TUNE_WINO_FUSED_MAX_C reduction channels (default 256 since round 3's pixel-major patches + packed transforms: 256 -> 256 at 55^2 2.53 vs 3.13 ms
+// forward, 64 -> 64 at 223^2 3.04 vs 7.7), and up to twice that when the 16-tile groups pad the tile grid by less than a fifth (512 -> 512 at 13^2: 0.74 vs
+// 0.80 ms; at 27^2, 7 -> 8 tiles per side, the via-HBM form wins: 2.41 vs 2.78).
 static bool wino_fused_preferred(const int C_red, const wino_fused_plan_t& p, const Image4& dst)
 {
 	const long maxc = tune(TUNE_WINO_FUSED_MAX_C);

@@ -63,6 +63,17 @@ static inline void gemm_pick_tile(const int M, const int N, int* wm, int* wn)
 	}
 }
 
+// The buffer-load form of a plain-matrix operand (BufMatLoader, mfma_gemm.h): which loaders qualify, and whether one's offsets fit.
+template <class L> struct is_vec_mat_loader { static constexpr bool value = false; };
+template <bool KC> struct is_vec_mat_loader<MatLoader<KC, true>> { static constexpr bool value = true; };
+template <bool KC>
+static inline bool buf_loader_ok(const MatLoader<KC, true>& l)
+{
+	if (l.R <= 0 || l.K <= 0) return false;
+	if (KC) return l.ldk == 1 && l.ldr > 0 && l.ldr * 128 * 4 + (long)l.K * 4 < 0x7fffffffL;
+	return l.ldr == 1 && l.ldk > 0 && l.R % 4 == 0 && (long)l.K * l.ldk * 4 + (long)l.R * 4 < 0x7fffffffL;
+}
+
 // zcount > 1 (batched GEMM / grouped conv): every z applies the given element offsets to A, B, C and bias.
 template <class LA, class LB, int WM, int WN>
 static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko)
@@ -124,6 +135,19 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	lb.zoff = zp - lb.p;
 	int wm = 2, wn = 2;
 	gemm_pick_tile(M, N, &wm, &wn);
+	// two plain matrices in 16-byte chunks, whole K-steps: the buffer-load form (no address VALU in the K loop, mfma_gemm.h)
+	if constexpr (is_vec_mat_loader<LA>::value && is_vec_mat_loader<LB>::value) {
+		if (tune(TUNE_GEMM_BUFFER_LOADS) && K > 0 && K % GEMM_BK == 0 && buf_loader_ok(la) && buf_loader_ok(lb)) {
+			BufMatLoader<LA::KCONTIG> ba; BufMatLoader<LB::KCONTIG> bb;
+			ba.p = la.p; ba.zoff = 0; ba.ldr = la.ldr; ba.ldk = la.ldk; ba.R = la.R; ba.K = la.K;
+			bb.p = lb.p; bb.zoff = 0; bb.ldr = lb.ldr; bb.ldk = lb.ldk; bb.R = lb.R; bb.K = lb.K;
+			typedef BufMatLoader<LA::KCONTIG> BA; typedef BufMatLoader<LB::KCONTIG> BB;
+			if (wm == 2 && wn == 2) return gemm_run_tile<BA, BB, 2, 2>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+			if (wm == 2) return gemm_run_tile<BA, BB, 2, 1>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+			if (wn == 1) return gemm_run_tile<BA, BB, 1, 1>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+			return gemm_run_tile<BA, BB, 1, 2>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+		}
+	}
 	if (wm == 2 && wn == 2) return gemm_run_tile<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	if (wm == 2) return gemm_run_tile<LA, LB, 2, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	if (wn == 1) return gemm_run_tile<LA, LB, 1, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);

@@ -567,6 +567,80 @@ struct TileFetch {
 	}
 };
 
+// ---- plain matrices through BUFFER loads --------------------------------------------------------------------------------------------------
+// Next to fp32 MFMAs every VALU instruction of the wave costs matrix-pipe time (tools/coissue2_probe.cpp on the MI355X: the first VALU behind an MFMA
+// ~14 clocks, each further one ~4; integer or float, scalar or packed alike), and the pointer path above spends ~5 VALU per 16-byte chunk per K-step on
+// 64-bit address arithmetic and the zero-page select (85-190 VALU per 128 MFMAs in the Winograd GEMMs).  A plain matrix needs none of it:
+// element(r, k) = p[r * ldr + k] (KC) or p[k * ldk + r] (!KC) is a per-lane byte offset that never changes (row part) plus a wave-uniform one
+// (the K-step's k: an SGPR, the instruction's soffset), and rows beyond R are an out-of-range offset the buffer's range check turns into zeros.
+// Conditions (gemm_run checks them): 16-byte chunks (the VEC conditions), K and the K-slices whole K-steps (no k tail to mask), R % 4 == 0 for !KC,
+// offsets inside 31 bits.  The descriptor's base is the block tile's first row; its range ends with the matrix.
+template <bool KC>
+struct BufMatLoader {
+	static constexpr bool KCONTIG = KC, VECTOR = true, INCR = false;
+	const float* p;
+	long zoff; // (unused: gemm_run sets it on every loader)
+	long ldr, ldk;
+	int R, K;
+	void finish() {}
+};
+template <class L> struct is_buffer_loader { static constexpr bool value = false; };
+template <bool KC> struct is_buffer_loader<BufMatLoader<KC>> { static constexpr bool value = true; };
+
+template <class L, int NCH>
+struct TileFetchBuf {
+	static constexpr int ROWS = NCH * 32;
+	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+	__amdgpu_buffer_rsrc_t rs;
+	unsigned voff[NCH];
+	unsigned kscale; // bytes per unit of k
+	__device__ __forceinline__ void init(const L& l, int row0, int t)
+	{
+		const long extent = L::KCONTIG ? (long)(l.R - 1) * l.ldr + l.K : (long)(l.K - 1) * l.ldk + l.R; // floats from l.p to the end of the matrix
+		const long base = L::KCONTIG ? (long)row0 * l.ldr : (long)row0;
+		const long left = (extent - base) * 4;
+		rs = __builtin_amdgcn_make_buffer_rsrc((void*)(l.p + base), 0, (unsigned)(left > 0x7fffffffL ? 0x7fffffffL : (left < 0 ? 0 : left)), 0x00020000);
+		kscale = L::KCONTIG ? 4u : (unsigned)l.ldk * 4u;
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) {
+			const int id = t + GEMM_THREADS * jj;
+			if (L::KCONTIG) {
+				const int r = id >> 3;
+				voff[jj] = row0 + r < l.R ? (unsigned)r * (unsigned)l.ldr * 4u + (unsigned)((id & 7) << 4) : 0x80000000u;
+			} else {
+				const int r = (id % (ROWS / 4)) << 2, k = id / (ROWS / 4);
+				voff[jj] = row0 + r < l.R ? (unsigned)k * (unsigned)l.ldk * 4u + (unsigned)r * 4u : 0x80000000u;
+			}
+		}
+	}
+	template <bool FIRST> __device__ __forceinline__ void prep_k(const L&, int, int) {}
+	template <bool FIRST> __device__ __forceinline__ void prep_chunk(const L&, const int) {}
+	template <bool FIRST> __device__ __forceinline__ void prep(const L&, int, int) {}
+	__device__ __forceinline__ void issue_chunk(const L&, float4 (&r)[NCH], const int jj, const int kbase, const int) const
+	{
+		const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[jj], (unsigned)kbase * kscale, 0);
+		r[jj] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+	}
+	__device__ __forceinline__ void issue(const L& l, float4 (&r)[NCH], const int kbase, const int klimit) const
+	{
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) issue_chunk(l, r, jj, kbase, klimit);
+	}
+	__device__ __forceinline__ void store_chunk(float* lds, const float4 (&r)[NCH], int t, const int jj) const
+	{
+		const int id = t + GEMM_THREADS * jj;
+		if (L::KCONTIG) *(float4*)(lds + (id >> 3) * GEMM_LDK + ((id & 7) << 2)) = r[jj];
+		else *(float4*)(lds + (id / (ROWS / 4)) * ROWS + ((id % (ROWS / 4)) << 2)) = r[jj];
+	}
+	__device__ __forceinline__ void store(float* lds, const float4 (&r)[NCH], int t) const
+	{
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) store_chunk(lds, r, t, jj);
+	}
+};
+template <class L, int NCH, bool BUF = is_buffer_loader<L>::value> struct FetchOf { typedef TileFetch<L, NCH> type; };
+template <class L, int NCH> struct FetchOf<L, NCH, true> { typedef TileFetchBuf<L, NCH> type; };
+
 // Fragment reads of quarter q (k = 8q .. 8q+7) of a K-step for the W 32-row MFMA tiles of a wave whose rows start at `base`.
 // Which row of the wave's span an MFMA tile's lane stands for is free as long as the epilogue agrees (frag_row below):
 //   KC  ([row][k] image): tile ti, lane li = row 32 * ti + li; its four k values are ONE ds_read_b128
@@ -696,8 +770,8 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 		return (s - cc * ko.taps) * ko.C + cc * GEMM_BK;
 	};
 	const int klim = ko.taps ? ko.K : k_end;
-	TileFetch<LA, WM * 2> fa;
-	TileFetch<LB, WN * 2> fb;
+	typename FetchOf<LA, WM * 2>::type fa;
+	typename FetchOf<LB, WN * 2>::type fb;
 	fa.init(la, m0, t);
 	fb.init(lb, n0, t);
 	floatx16 acc[WM][WN];

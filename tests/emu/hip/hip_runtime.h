@@ -189,6 +189,13 @@ static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u4 v, emu_buffer_r
 	if ((unsigned long long)voffset + 16 > r.num_records || (unsigned long long)voffset + soffset + 16 > r.num_records) return;
 	memcpy((char*)r.base + voffset + soffset, &v, 16);
 }
+static inline emu_u4 __builtin_amdgcn_raw_buffer_load_b128(emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
+{ // out-of-range lanes read zeros
+	emu_u4 v = { 0u, 0u, 0u, 0u };
+	if ((unsigned long long)voffset + 16 > r.num_records || (unsigned long long)voffset + soffset + 16 > r.num_records) return v;
+	memcpy(&v, r.base + voffset + soffset, 16);
+	return v;
+}
 typedef unsigned int emu_u2 __attribute__((ext_vector_type(2)));
 static inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u2 v, emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
 {
@@ -221,6 +228,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
