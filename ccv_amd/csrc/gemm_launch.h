@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 #include "mfma_gemm.h"
-#include "mfma_gemm_f16.h"
+#include "mfma_gemm_f16_buf.h"
 
 namespace nnc {
 
@@ -208,6 +208,57 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// The buffer-load form of a half-precision plain-matrix operand (mfma_gemm_f16_buf.h): dword-aligned chunk addresses, offsets inside 31 bits.
+template <bool KC>
+static inline bool buf_loader_h_ok(const MatLoader<KC, true>& l, const long z_off, const int zcount)
+{
+	if (l.R <= 0 || l.K <= 0 || (((uintptr_t)l.p) & 15)) return false;
+	if (zcount > 1 && (z_off & 7)) return false;
+	if (KC) return l.ldk == 1 && l.ldr > 0 && l.ldr % 8 == 0 && l.ldr * 128 * 2 + (long)l.K * 2 < 0x7fffffffL;
+	return l.ldr == 1 && l.ldk > 0 && l.ldk % 2 == 0 && ((long)l.K * l.ldk + l.R) * 2 < 0x7fffffffL;
+}
+
+template <bool AKC, bool BKC>
+static int gemm_run_buf_h(const char* name, const BufMatLoader<AKC>& la, const BufMatLoader<BKC>& lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	hipStream_t stream = stream_of(ctx);
+	const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+	const long tiles = (long)tiles_m * tiles_n;
+	if (tiles > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
+	int k_per_split = K;
+	if (splits > 1) {
+		if (splits < 8) splits = 8;
+		splits = (splits + 7) & ~7;
+		k_per_split = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+	}
+	note_kernel(name);
+	char prof_name[192];
+	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_buf_kernel<%d, %d> EPI = %s", name, (int)AKC, (int)BKC, splits <= 1 ? "EpiStoreH" : "EpiPartialH");
+	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
+	if (splits <= 1) {
+		EpiStoreH epi;
+		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
+		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiStoreH>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, 1, a_z, b_z, c_z, bias_z);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
+	const long slab = (long)M * N;
+	float* ws = (float*)workspace_of(ctx, sizeof(float) * (size_t)slab * splits * zcount);
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	EpiPartialH epi;
+	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
+	{
+		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiPartialH>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L);
+	}
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(splitk_reduce_half_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 // la.p / lb.p point at HALVES (cast to the loaders' float* type); every offset / stride / z offset is in elements.
 template <class LA, class LB>
 static int gemm_run_h(const char* name, LA la, LB lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko = KOrder())
@@ -220,6 +271,15 @@ static int gemm_run_h(const char* name, LA la, LB lb, const GemmOutH out, const 
 	lb.zoff = zp - (const half_t*)lb.p;
 	// two tile shapes: 128 x 128, and 64 x 64 when an output dimension is <= 64 (channels) or the tile grid would not fill the chip
 	const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+	// two plain matrices, whole K-steps, the 128 x 128 tile: the buffer-load kernel (mfma_gemm_f16_buf.h: no VALU in the K loop, transpose reads for a row-contiguous operand)
+	if constexpr (is_vec_mat_loader<LA>::value && is_vec_mat_loader<LB>::value) {
+		if (tune(TUNE_GEMM_BUFFER_LOADS) && M > 64 && N > 64 && (big_tiles * zcount >= device_cu_count() || K >= 4096) && K > 0 && K % GEMM_BK == 0 && buf_loader_h_ok(la, a_z, zcount) && buf_loader_h_ok(lb, b_z, zcount)) {
+			BufMatLoader<LA::KCONTIG> ba; BufMatLoader<LB::KCONTIG> bb;
+			ba.p = la.p; ba.zoff = 0; ba.ldr = la.ldr; ba.ldk = la.ldk; ba.R = la.R; ba.K = la.K;
+			bb.p = lb.p; bb.zoff = 0; bb.ldr = lb.ldr; bb.ldk = lb.ldk; bb.R = lb.R; bb.K = lb.K;
+			return gemm_run_buf_h<LA::KCONTIG, LB::KCONTIG>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+		}
+	}
 	if (M > 64 && N > 64 && (big_tiles * zcount >= device_cu_count() || K >= 4096)) return gemm_run_tile_h<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	return gemm_run_tile_h<LA, LB, 1, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 }

@@ -190,10 +190,13 @@ static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u4 v, emu_buffer_r
 	memcpy((char*)r.base + voffset + soffset, &v, 16);
 }
 static inline emu_u4 __builtin_amdgcn_raw_buffer_load_b128(emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
-{ // out-of-range lanes read zeros
+{ // raw buffer (stride 0): the range check is per DWORD -- an out-of-range dword reads zero, the others are delivered
 	emu_u4 v = { 0u, 0u, 0u, 0u };
-	if ((unsigned long long)voffset + 16 > r.num_records || (unsigned long long)voffset + soffset + 16 > r.num_records) return v;
-	memcpy(&v, r.base + voffset + soffset, 16);
+	for (int d = 0; d < 4; d++) {
+		const unsigned long long off = (unsigned long long)voffset + soffset + 4ull * d;
+		if ((unsigned long long)voffset + 4ull * d + 4 > r.num_records || off + 4 > r.num_records) continue;
+		unsigned w; memcpy(&w, r.base + off, 4); v[d] = w;
+	}
 	return v;
 }
 typedef unsigned int emu_u2 __attribute__((ext_vector_type(2)));
