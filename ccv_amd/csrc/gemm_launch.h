@@ -214,15 +214,16 @@ static inline bool buf_loader_h_ok(const MatLoader<KC, true>& l, const long z_of
 {
 	if (l.R <= 0 || l.K <= 0 || (((uintptr_t)l.p) & 15)) return false;
 	if (zcount > 1 && (z_off & 7)) return false;
-	if (KC) return l.ldk == 1 && l.ldr > 0 && l.ldr % 8 == 0 && l.ldr * 128 * 2 + (long)l.K * 2 < 0x7fffffffL;
+	if (KC) return l.ldk == 1 && l.ldr > 0 && l.ldr % 8 == 0 && l.ldr * 256 * 2 + (long)l.K * 2 < 0x7fffffffL;
 	return l.ldr == 1 && l.ldk > 0 && l.ldk % 2 == 0 && ((long)l.K * l.ldk + l.R) * 2 < 0x7fffffffL;
 }
 
-template <bool AKC, bool BKC>
-static int gemm_run_buf_h(const char* name, const BufMatLoader<AKC>& la, const BufMatLoader<BKC>& lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+template <bool AKC, bool BKC, int TM, int TN, int WM, int WN, int BK>
+static int gemm_run_buf_tile_h(const char* name, const BufMatLoader<AKC>& la, const BufMatLoader<BKC>& lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
 	hipStream_t stream = stream_of(ctx);
-	const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+	constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+	const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
 	const long tiles = (long)tiles_m * tiles_n;
 	if (tiles > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
@@ -230,17 +231,17 @@ static int gemm_run_buf_h(const char* name, const BufMatLoader<AKC>& la, const B
 	if (splits > 1) {
 		if (splits < 8) splits = 8;
 		splits = (splits + 7) & ~7;
-		k_per_split = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+		k_per_split = ((K + splits - 1) / splits + BK - 1) / BK * BK;
 	}
 	note_kernel(name);
 	char prof_name[192];
-	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_buf_kernel<%d, %d> EPI = %s", name, (int)AKC, (int)BKC, splits <= 1 ? "EpiStoreH" : "EpiPartialH");
+	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_buf_kernel<%d, %d, %d x %d x %d> EPI = %s", name, (int)AKC, (int)BKC, BM, BN, BK, splits <= 1 ? "EpiStoreH" : "EpiPartialH");
 	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
 	if (splits <= 1) {
 		EpiStoreH epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiStoreH>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, 1, a_z, b_z, c_z, bias_z);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiStoreH, TM, TN, WM, WN, BK>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(64 * WM * WN), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, 1, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -251,12 +252,29 @@ static int gemm_run_buf_h(const char* name, const BufMatLoader<AKC>& la, const B
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiPartialH>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiPartialH, TM, TN, WM, WN, BK>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(64 * WM * WN), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L);
 	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(splitk_reduce_half_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
+}
+
+template <bool AKC, bool BKC>
+static int gemm_run_buf_h(const char* name, const BufMatLoader<AKC>& la, const BufMatLoader<BKC>& lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	// 256 x 256 (eight waves of 128 x 64) for the very large products only: measured on the MI355X 8192^3 715 vs 620 TFLOP/s, but 4096^3 545 vs 655 and
+	// ResNet-50's 1x1 layers slower (one workgroup per CU: nothing hides its barrier) -- profiles/r03_v9_half_bench.txt
+	const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+	const long mode = tune(TUNE_GEMM_BUFFER_LOADS); // 1 = the rules below; 2 = never the 256 x 256 tile; 3 = 256 x 256 wherever it fits; 4 = BK 32 only (tests, tools/half_modes.sh)
+	const bool k64 = K % 64 == 0 && mode != 4;
+	if (mode != 2 && ((M >= 2048 && N >= 2048 && t256 * zcount >= 2 * device_cu_count()) || (mode == 3 && M >= 192 && N >= 192))) {
+		if (k64) return gemm_run_buf_tile_h<AKC, BKC, 4, 2, 2, 4, 64>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+		return gemm_run_buf_tile_h<AKC, BKC, 4, 2, 2, 4, 32>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+	}
+	// K-steps of 64 where K allows: half the barriers per MFMA (4096^3: 806 vs 655 TFLOP/s)
+	if (k64) return gemm_run_buf_tile_h<AKC, BKC, 2, 2, 2, 2, 64>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+	return gemm_run_buf_tile_h<AKC, BKC, 2, 2, 2, 2, 32>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 }
 
 // la.p / lb.p point at HALVES (cast to the loaders' float* type); every offset / stride / z offset is in elements.

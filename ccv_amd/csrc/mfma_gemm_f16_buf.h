@@ -8,14 +8,17 @@
 //     halves = 320 bytes: the four k rows of a block land 16 banks apart (80 dwords mod 64), conflict-free;
 //   * rows / columns beyond the matrix: an out-of-range chunk reads zeros (buffer range check); a chunk that straddles the end of a row-contiguous
 //     operand's rows reads its neighbours -- garbage that only ever meets output columns >= N, which the epilogue does not store.
-// 128 x 128 block tile, BK = 32 (two MFMA sub-steps of v_mfma_f32_32x32x16_f16 per tile), 256 threads; 40 KB of LDS: three workgroups per CU.
+// Block tile (32 TM WM) x (32 TN WN): WM x WN waves of TM x TN MFMA tiles each, BK = 32 (two sub-steps of v_mfma_f32_32x32x16_f16 per tile).  Two shapes are
+// instantiated: 128 x 128 (2 x 2 waves of 2 x 2 tiles: 40 KB of LDS, three workgroups per CU) and 256 x 256 (2 x 4 waves of 4 x 2 tiles, 80 KB) -- with 64 x 64
+// per wave the four waves' fragment reads alone (1 KB per MFMA) keep the LDS busy every cycle the MFMAs run; 128 x 64 per wave needs 3/4 of that.
 // Both operands use the k map of mfma_gemm_f16.h: lane (row = l & 31, half = l >> 5) supplies k = 16 s + 8 half + 0..7 of sub-step s.
 #pragma once
 #include "mfma_gemm_f16.h"
 
 namespace nnc {
 
-constexpr int GEMM16_NPITCH = 160; // halves per k row of a row-contiguous operand's LDS image (128 + 32: see above)
+// halves per k row of a row-contiguous operand's LDS image: the tile's rows + 32 (160 / 288 halves = 80 / 144 dwords: 16 banks past a multiple of 64)
+constexpr int gemm16_npitch(const int rows) { return rows + 32; }
 
 // Column `i` (= lane & 15) of the [4][16] block of halves whose rows start at blk, blk + pitch, ...: out[j] = blk[j * pitch + i].
 #ifdef NNC_HIP_EMULATOR
@@ -30,12 +33,16 @@ __device__ __forceinline__ halfx4 tr_read4(const half_t* const blk, const int pi
 }
 #endif
 
-template <bool KC>
+template <bool KC, int ROWS, int NT, int BK>
 struct FetchH16 {
+	static constexpr int KPITCH = BK + 8; // halves per row of a k-contiguous operand's image (80 / 144 bytes: 16-byte aligned rows, 20 / 36-dword stride: ds_read_b128 conflict-free)
+	static constexpr int NPITCH = gemm16_npitch(ROWS);
+	static constexpr int NCH = ROWS * (BK / 8) / NT; // 16-byte chunks per thread and K-step
+	static_assert(ROWS * (BK / 8) % NT == 0 && NCH >= 1, "whole chunks per thread");
 	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-	static constexpr int LDS_HALVES = KC ? 128 * GEMM16_LDK : GEMM_BK * GEMM16_NPITCH;
+	static constexpr int LDS_HALVES = KC ? ROWS * KPITCH : BK * NPITCH;
 	__amdgpu_buffer_rsrc_t rs;
-	unsigned voff[2];
+	unsigned voff[NCH];
 	unsigned kscale;
 	__device__ __forceinline__ void init(const BufMatLoader<KC>& l, const int row0, const int t)
 	{
@@ -46,45 +53,48 @@ struct FetchH16 {
 		rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p + base), 0, (unsigned)(left > 0x7fffffffL ? 0x7fffffffL : (left < 0 ? 0 : left)), 0x00020000);
 		kscale = KC ? 2u : (unsigned)l.ldk * 2u;
 #pragma unroll
-		for (int jj = 0; jj < 2; jj++) {
-			const int id = t + GEMM_THREADS * jj;
-			if (KC) { const int r = id >> 2; voff[jj] = row0 + r < l.R ? (unsigned)r * (unsigned)l.ldr * 2u + (unsigned)(id & 3) * 16u : 0x80000000u; }
-			else { const int k = id >> 4, r = (id & 15) << 3; voff[jj] = row0 + r < l.R ? (unsigned)k * (unsigned)l.ldk * 2u + (unsigned)r * 2u : 0x80000000u; }
+		for (int jj = 0; jj < NCH; jj++) {
+			const int id = t + NT * jj;
+			if (KC) { const int r = id / (BK / 8); voff[jj] = row0 + r < l.R ? (unsigned)r * (unsigned)l.ldr * 2u + (unsigned)(id % (BK / 8)) * 16u : 0x80000000u; }
+			else { const int k = id / (ROWS / 8), r = (id % (ROWS / 8)) << 3; voff[jj] = row0 + r < l.R ? (unsigned)k * (unsigned)l.ldk * 2u + (unsigned)r * 2u : 0x80000000u; }
 		}
 	}
-	__device__ __forceinline__ void issue(u4 (&r)[2], const int kbase) const
+	__device__ __forceinline__ void issue(u4 (&r)[NCH], const int kbase) const
 	{
 #pragma unroll
-		for (int jj = 0; jj < 2; jj++) r[jj] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[jj], (unsigned)kbase * kscale, 0);
+		for (int jj = 0; jj < NCH; jj++) r[jj] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[jj], (unsigned)kbase * kscale, 0);
 	}
-	__device__ __forceinline__ void store(half_t* const lds, const u4 (&r)[2], const int t) const
+	__device__ __forceinline__ void store(half_t* const lds, const u4 (&r)[NCH], const int t) const
 	{
 #pragma unroll
-		for (int jj = 0; jj < 2; jj++) {
-			const int id = t + GEMM_THREADS * jj;
-			if (KC) *(u4*)(lds + (id >> 2) * GEMM16_LDK + ((id & 3) << 3)) = r[jj];
-			else *(u4*)(lds + (id >> 4) * GEMM16_NPITCH + ((id & 15) << 3)) = r[jj];
+		for (int jj = 0; jj < NCH; jj++) {
+			const int id = t + NT * jj;
+			if (KC) *(u4*)(lds + (id / (BK / 8)) * KPITCH + ((id % (BK / 8)) << 3)) = r[jj];
+			else *(u4*)(lds + (id / (ROWS / 8)) * NPITCH + ((id % (ROWS / 8)) << 3)) = r[jj];
 		}
 	}
 	// the fragment of sub-step s for the 32 rows starting at `base`: k = 16 s + 8 lh + 0..7 of row base + li
 	__device__ __forceinline__ static halfx8 frag(const half_t* const s_, const int base, const int li, const int lh, const int s)
 	{
-		if (KC) return *(const halfx8*)(s_ + (base + li) * GEMM16_LDK + 16 * s + 8 * lh);
-		const half_t* const blk = s_ + (16 * s + 8 * lh) * GEMM16_NPITCH + base + 16 * (li >> 4);
-		const halfx4 lo = tr_read4(blk, GEMM16_NPITCH, li & 15), hi = tr_read4(blk + 4 * GEMM16_NPITCH, GEMM16_NPITCH, li & 15);
+		if (KC) return *(const halfx8*)(s_ + (base + li) * KPITCH + 16 * s + 8 * lh);
+		const half_t* const blk = s_ + (16 * s + 8 * lh) * NPITCH + base + 16 * (li >> 4);
+		const halfx4 lo = tr_read4(blk, NPITCH, li & 15), hi = tr_read4(blk + 4 * NPITCH, NPITCH, li & 15);
 		return halfx8{ lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
 	}
 };
 
 // grid: x = tiles (* split-K slices), XCD-swizzled exactly as mfma_gemm_f16_kernel; z = batch.  K and the K-slices are whole K-steps (the host checks).
-template <bool AKC, bool BKC, class EPI>
-__global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_buf_kernel(BufMatLoader<AKC> la, BufMatLoader<BKC> lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff)
+template <bool AKC, bool BKC, class EPI, int TM = 2, int TN = 2, int WM = 2, int WN = 2, int BK = 32>
+__global__ void __launch_bounds__(64 * WM * WN) mfma_gemm_f16_buf_kernel(BufMatLoader<AKC> la, BufMatLoader<BKC> lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff)
 {
-	constexpr int A_HALVES = FetchH16<AKC>::LDS_HALVES, B_HALVES = FetchH16<BKC>::LDS_HALVES;
+	constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+	typedef FetchH16<AKC, BM, NT, BK> FA;
+	typedef FetchH16<BKC, BN, NT, BK> FB;
+	constexpr int A_HALVES = FA::LDS_HALVES, B_HALVES = FB::LDS_HALVES;
 	__shared__ __attribute__((aligned(16))) half_t lds[2][A_HALVES + B_HALVES];
 	const int t = threadIdx.x;
 	const int lane = t & 63, wave = t >> 6;
-	const int wm = wave >> 1, wn = wave & 1;
+	const int wm = wave / WN, wn = wave % WN;
 	const int li = lane & 31, lh = lane >> 5;
 	const int nwg = gridDim.x;
 	const int bid = blockIdx.x;
@@ -103,27 +113,27 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_buf_kernel(BufMatL
 	}
 	const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 	(void)tiles_m;
-	const int m0 = tile_m * 128, n0 = tile_n * 128;
+	const int m0 = tile_m * BM, n0 = tile_n * BN;
 	la.p = (const float*)((const half_t*)la.p + (long)blockIdx.z * a_zoff);
 	lb.p = (const float*)((const half_t*)lb.p + (long)blockIdx.z * b_zoff);
 	epi.c += (long)blockIdx.z * c_zoff;
 	if (splits > 1) epi.c += (long)slice * M_N_slab(epi);
 	const int k_begin = slice * k_per_split;
 	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
-	const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
-	FetchH16<AKC> fa;
-	FetchH16<BKC> fb;
+	const int nk = (k_end - k_begin + BK - 1) / BK;
+	FA fa;
+	FB fb;
 	fa.init(la, m0, t);
 	fb.init(lb, n0, t);
-	floatx16 acc[2][2];
+	floatx16 acc[TM][TN];
 #pragma unroll
-	for (int i = 0; i < 2; i++)
+	for (int i = 0; i < TM; i++)
 #pragma unroll
-		for (int j = 0; j < 2; j++)
+		for (int j = 0; j < TN; j++)
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-	const int row_a = wm * 64, col_b = wn * 64;
-	typename FetchH16<AKC>::u4 ra[2], rb[2];
+	const int row_a = wm * (32 * TM), col_b = wn * (32 * TN);
+	typename FA::u4 ra[FA::NCH], rb[FB::NCH];
 	if (nk > 0) {
 		fa.issue(ra, k_begin);
 		fb.issue(rb, k_begin);
@@ -135,26 +145,32 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_buf_kernel(BufMatL
 		const int cur = kt & 1;
 		const bool more = kt + 1 < nk;
 		if (more) { // the next tile's loads go out ahead of this tile's MFMAs
-			fa.issue(ra, k_begin + (kt + 1) * GEMM_BK);
-			fb.issue(rb, k_begin + (kt + 1) * GEMM_BK);
+			fa.issue(ra, k_begin + (kt + 1) * BK);
+			fb.issue(rb, k_begin + (kt + 1) * BK);
 		}
 		const half_t* const sa = lds[cur];
 		const half_t* const sb = lds[cur] + A_HALVES;
 #pragma unroll
-		for (int s = 0; s < 2; s++) {
-			halfx8 fa8[2], fb8[2];
+		for (int s = 0; s < BK / 16; s++) {
+			halfx8 fa8[TM], fb8[TN];
 #pragma unroll
-			for (int ti = 0; ti < 2; ti++) fa8[ti] = FetchH16<AKC>::frag(sa, row_a + 32 * ti, li, lh, s);
+			for (int ti = 0; ti < TM; ti++) fa8[ti] = FA::frag(sa, row_a + 32 * ti, li, lh, s);
 #pragma unroll
-			for (int tj = 0; tj < 2; tj++) fb8[tj] = FetchH16<BKC>::frag(sb, col_b + 32 * tj, li, lh, s);
+			for (int tj = 0; tj < TN; tj++) fb8[tj] = FB::frag(sb, col_b + 32 * tj, li, lh, s);
 #ifndef NNC_HIP_EMULATOR
 			// the transpose reads are asm: hipcc does not count them (the operands tie the MFMAs below behind the wait)
-			if (!AKC || !BKC) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa8[0]), "+v"(fa8[1]), "+v"(fb8[0]), "+v"(fb8[1]) :: "memory");
+			if (!AKC || !BKC) {
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+				for (int ti = 0; ti < TM; ti++) asm volatile("" : "+v"(fa8[ti]));
+#pragma unroll
+				for (int tj = 0; tj < TN; tj++) asm volatile("" : "+v"(fb8[tj]));
+			}
 #endif
 #pragma unroll
-			for (int ti = 0; ti < 2; ti++)
+			for (int ti = 0; ti < TM; ti++)
 #pragma unroll
-				for (int tj = 0; tj < 2; tj++) acc[ti][tj] = nnc_mfma_f16(fa8[ti], fb8[tj], acc[ti][tj]);
+				for (int tj = 0; tj < TN; tj++) acc[ti][tj] = nnc_mfma_f16(fa8[ti], fb8[tj], acc[ti][tj]);
 		}
 		if (more) {
 			fa.store(lds[cur ^ 1], ra, t);
@@ -165,9 +181,9 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_buf_kernel(BufMatL
 	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
 #pragma unroll
-	for (int ti = 0; ti < 2; ti++)
+	for (int ti = 0; ti < TM; ti++)
 #pragma unroll
-		for (int tj = 0; tj < 2; tj++) {
+		for (int tj = 0; tj < TN; tj++) {
 			const int n = n0 + col_b + 32 * tj + li;
 #pragma unroll
 			for (int r = 0; r < 16; r++) {

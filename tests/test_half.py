@@ -99,7 +99,31 @@ def test_gemm_forward_half(backend, ref_lib, case):
         assert any("mfma_gemm_f16_buf_kernel" in n for n in names), names
 
 
-@pytest.mark.parametrize("case", GEMM_H, ids=[str(c[:2]) for c in GEMM_H])
+@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("layout", ["kc x kc", "nc x nc"])
+def test_gemm_half_buffer_kernel_shapes(backend, ref_lib, mode, layout):
+    """The other shapes of the buffer-load kernel (mfma_gemm_f16_buf.h), forced through the tuning key: the 256 x 256 x 64 tile (mode 3) and K-steps of 32 (mode 4)."""
+    rng = np.random.default_rng(5)
+    M, N, K = 264, 324, 4096
+    if layout == "kc x kc":
+        a, w, ta, tb = hrnd(rng, M, K), hrnd(rng, N, K, scale=4.0 / np.sqrt(K)), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1)
+    else:
+        a, w, ta, tb = hrnd(rng, K, M), hrnd(rng, K, N, scale=4.0 / np.sqrt(K)), nnc.TRANSPOSE(0, 1), nnc.NO_TRANSPOSE
+    backend.tune_set("GEMM_BUFFER_LOADS", mode)
+    try:
+        res = {}
+        names = _kernel_records(backend, lambda: res.update(r=_pair(backend, ref_lib, nnc.CMD_GEMM_FORWARD(ta, tb), nnc.NO_HINT, 0, [a, w, hrnd(rng, N)], [np.zeros((M, N), H)])))
+    finally:
+        backend.tune_set("GEMM_BUFFER_LOADS", 1)
+    got, want = res["r"]
+    _close(got[0], want[0])
+    assert any(("256 x 256 x 64" if mode == 3 else "128 x 128 x 32") in n for n in names), names
+
+
+GEMM_H_BACK = [c for c in GEMM_H if c[5] != "buf"] + [c for c in GEMM_H if c[5] == "buf"][:2]  # (the reference's K = 4096 products are what takes the time here)
+
+
+@pytest.mark.parametrize("case", GEMM_H_BACK, ids=[str(c[:2]) for c in GEMM_H_BACK])
 @pytest.mark.parametrize("flags", [0, nnc.ACCUMULATE_OUTPUT])
 def test_gemm_backward_half(backend, ref_lib, case, flags):
     ashape, wshape, ta, tb, bias, native = case
