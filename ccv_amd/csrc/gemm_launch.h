@@ -269,7 +269,8 @@ static int gemm_run_buf_h(const char* name, const BufMatLoader<AKC>& la, const B
 	const long mode = tune(TUNE_GEMM_BUFFER_LOADS); // 1 = the rules below; 2 = never the 256 x 256 tile; 3 = 256 x 256 wherever it fits; 4 = BK 32 only (tests, tools/half_modes.sh)
 	const bool k64 = K % 64 == 0 && mode != 4;
 	if (mode != 2 && ((M >= 2048 && N >= 2048 && t256 * zcount >= 2 * device_cu_count()) || (mode == 3 && M >= 192 && N >= 192))) {
-		if (k64) return gemm_run_buf_tile_h<AKC, BKC, 4, 2, 2, 4, 64>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+		if (k64 && AKC && BKC) return gemm_run_buf_tile_h<AKC, BKC, 4, 2, 2, 4, 64>( // (a transpose-read operand needs the registers of the second load set: K-steps of 32 there)
+			name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 		return gemm_run_buf_tile_h<AKC, BKC, 4, 2, 2, 4, 32>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 	}
 	// K-steps of 64 where K allows: half the barriers per MFMA (4096^3: 806 vs 655 TFLOP/s)

@@ -133,23 +133,25 @@ __global__ void __launch_bounds__(64 * WM * WN) mfma_gemm_f16_buf_kernel(BufMatL
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 	const int row_a = wm * (32 * TM), col_b = wn * (32 * TN);
-	typename FA::u4 ra[FA::NCH], rb[FB::NCH];
+	// Two register sets: the loads of tile kt + 2 go out at the top of K-step kt (into the set tile kt came through), tile kt + 1 -- loaded a whole K-step
+	// ago -- is written to the other LDS buffer behind the MFMAs.  Pairs of K-steps with the set index a compile-time constant.
+	typename FA::u4 ra[2][FA::NCH], rb[2][FB::NCH];
 	if (nk > 0) {
-		fa.issue(ra, k_begin);
-		fb.issue(rb, k_begin);
-		fa.store(lds[0], ra, t);
-		fb.store(lds[0] + A_HALVES, rb, t);
+		fa.issue(ra[0], k_begin);
+		fb.issue(rb[0], k_begin);
+		if (nk > 1) { fa.issue(ra[1], k_begin + BK); fb.issue(rb[1], k_begin + BK); }
+		fa.store(lds[0], ra[0], t);
+		fb.store(lds[0] + A_HALVES, rb[0], t);
 	}
 	__syncthreads();
-	for (int kt = 0; kt < nk; kt++) {
-		const int cur = kt & 1;
-		const bool more = kt + 1 < nk;
-		if (more) { // the next tile's loads go out ahead of this tile's MFMAs
-			fa.issue(ra, k_begin + (kt + 1) * BK);
-			fb.issue(rb, k_begin + (kt + 1) * BK);
+	auto kstep = [&](auto sid, const int kt) {
+		constexpr int S = decltype(sid)::value;
+		if (kt + 2 < nk) {
+			fa.issue(ra[S], k_begin + (kt + 2) * BK);
+			fb.issue(rb[S], k_begin + (kt + 2) * BK);
 		}
-		const half_t* const sa = lds[cur];
-		const half_t* const sb = lds[cur] + A_HALVES;
+		const half_t* const sa = lds[S];
+		const half_t* const sb = lds[S] + A_HALVES;
 #pragma unroll
 		for (int s = 0; s < BK / 16; s++) {
 			halfx8 fa8[TM], fb8[TN];
@@ -172,11 +174,19 @@ __global__ void __launch_bounds__(64 * WM * WN) mfma_gemm_f16_buf_kernel(BufMatL
 #pragma unroll
 				for (int tj = 0; tj < TN; tj++) acc[ti][tj] = nnc_mfma_f16(fa8[ti], fb8[tj], acc[ti][tj]);
 		}
-		if (more) {
-			fa.store(lds[cur ^ 1], ra, t);
-			fb.store(lds[cur ^ 1] + A_HALVES, rb, t);
+		if (kt + 1 < nk) {
+			fa.store(lds[S ^ 1], ra[S ^ 1], t);
+			fb.store(lds[S ^ 1] + A_HALVES, rb[S ^ 1], t);
 		}
 		__syncthreads();
+	};
+	{
+		int kt = 0;
+		for (; kt + 1 < nk; kt += 2) {
+			kstep(GroupId<0>(), kt);
+			kstep(GroupId<1>(), kt + 1);
+		}
+		if (kt < nk) kstep(GroupId<0>(), kt);
 	}
 	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
