@@ -9,7 +9,6 @@
 #include "gemm_launch.h"
 #include "winograd.h"
 #include "wino_fused.h"
-#include "wino_fused2.h"
 #include "wino_wgrad_fused.h"
 #include "conv_c3.h"
 
@@ -254,18 +253,10 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	const long T = (long)src.n * ((dst.h + 3) / 4) * ((dst.w + 3) / 4);
 	// (the PAIRED patch schedule of wino_fused.h -- SCHED = 1 + SKEW -- is not instantiated here: measured slower on the MI355X, tools/wf_probe.cpp,
 	// profiles/r03_v2_wf_probe_paired_schedule.txt)
-	const bool two = tune(TUNE_WINO_FUSED_WAVES) >= 8 && p.CCn >= 2; // two waves per SIMD (wino_fused2.h): same arguments, same grid, 512 threads
-	if (two) snprintf(prof_name, sizeof(prof_name), bits ? "%s|nnc::wino_fused2_kernel<%d, %d, 0, true>" : "%s|nnc::wino_fused2_kernel<%d, %d>", name, p.GH, p.GW);
 	ProfScope prof(prof_name, 2.0 * 36.0 * (double)T * Kout * Cred, 0, (int)T, Kout, Cred, 36, 1, stream);
-	if (two) {
-		if (bits) {
-			if (p.GH == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused2_kernel<4, 4, 0, true>), dim3(grid), dim3(512), 0, stream, a);
-			else if (p.GH == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused2_kernel<2, 8, 0, true>), dim3(grid), dim3(512), 0, stream, a);
-			else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused2_kernel<8, 2, 0, true>), dim3(grid), dim3(512), 0, stream, a);
-		} else if (p.GH == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused2_kernel<4, 4>), dim3(grid), dim3(512), 0, stream, a);
-		else if (p.GH == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused2_kernel<2, 8>), dim3(grid), dim3(512), 0, stream, a);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused2_kernel<8, 2>), dim3(grid), dim3(512), 0, stream, a);
-	} else if (bits) {
+	// (tools/wino_fused2.h: the same decomposition on two waves per SIMD, each wave half of the transform-domain columns -- measured on the MI355X, not
+	// faster: VALU costs matrix-pipe time whichever wave issues it, profiles/r03_v7_issue_probes.txt -- is an experiment, not part of the library)
+	if (bits) {
 		if (p.GH == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<4, 4, 0, true>), dim3(grid), dim3(256), 0, stream, a);
 		else if (p.GH == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<2, 8, 0, true>), dim3(grid), dim3(256), 0, stream, a);
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(wino_fused_kernel<8, 2, 0, true>), dim3(grid), dim3(256), 0, stream, a);

@@ -189,7 +189,6 @@ enum {
 	TUNE_WINO_WGRAD_FUSED_MAX, // algorithm -1 takes the fused Winograd filter gradient when both channel counts are <= this (0 = never)
 	TUNE_GEMM_BUFFER_LOADS, // plain-matrix contractions fetch their operands with buffer loads (no address VALU in the K loop); 0 = the pointer path;
 	                        // half precision: 2 = never the 256 x 256 tile, 3 = that tile wherever it fits, 4 = K-steps of 32 only (gemm_launch.h)
-	TUNE_WINO_FUSED_WAVES,  // fused Winograd forward / data gradient: 8 = two waves per SIMD (wino_fused2.h), 4 = one (wino_fused.h)
 	TUNE_COUNT
 };
 static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");

@@ -689,8 +689,6 @@ template <int GH, int GW>
 __global__ void __launch_bounds__(256) wino_mask_pack_kernel(const float* __restrict__ mask, const long m_sn, const long m_sh, const long m_sw, unsigned* __restrict__ bits, const int OH, const int OW, const int K, const int GYn, const int GXn, const int KB)
 {
 	constexpr int GWL = GW == 4 ? 2 : (GW == 8 ? 3 : (GW == 2 ? 1 : (GW == 16 ? 4 : 0)));
-	static_assert(GWL >= 1 && GWL <= 3, "tile groups 8 x 2, 4 x 4, 2 x 8");
-	constexpr int FSH = 3 - GWL; // see the patch reads
 	static_assert(GH * GW == 16, "16 tiles per group");
 	int b = (int)blockIdx.x;
 	const int kb = b % KB; b /= KB;

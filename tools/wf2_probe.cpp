@@ -1,6 +1,6 @@
 // Perf probe (not part of the library): times the two-waves-per-SIMD fused Winograd kernel (ccv_amd/csrc/wino_fused2.h) next to the one-wave kernel
 // (wino_fused.h) on one layer shape, with parts of its loop knocked out (DBG template bits).  Built HERE (hipcc cross-compiles) into tools/bin/:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ccv_amd/csrc tools/wf2_probe.cpp -o tools/bin/wf2_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ccv_amd/csrc -I tools tools/wf2_probe.cpp -o tools/bin/wf2_probe
 //   tools/bin/wf2_probe [batch] [hw] [C] [K]
 #include "wino_fused2.h"
 #include <cstdio>

@@ -1,3 +1,8 @@
+// EXPERIMENT (round 3; tools/wf2_probe.cpp -- not part of the library).  Measured on the MI355X (profiles/r03_v7_issue_probes.txt): NOT faster than the one-wave
+// kernel (conv1_2 3.59 vs 3.24 ms, conv2_2 2.88 vs 2.81) -- a VALU instruction costs matrix-pipe time whichever wave of the SIMD issues it (two waves, MFMA + one
+// packed VALU each: 45 clocks per MFMA, as on one wave), so only the DMA issue and the LDS waits hide behind the sibling, and the pair's epilogue (12 workgroup
+// barriers, partial sums through LDS) costs more than it saves.  One GPU parity case of the emulator-green kernel still differs (a hazard the synchronous
+// emulator cannot show); it was not chased once the timing was known.
 // Fused Winograd F(4x4, 3x3), two waves per SIMD: the same decomposition, LDS layout, U fragments and work distribution as wino_fused.h, with each
 // 16-tile x 32-channel block split between a PAIR of waves by transform-domain column -- wave `role` of the pair owns the 18 positions
 // z = zy * 6 + (3 role + zxl) (144 accumulator registers, all in AGPRs), so eight waves of <= 256 registers fit a CU and the SIMD always has a
