@@ -111,6 +111,125 @@ __global__ void __launch_bounds__(256) sdpa_forw_kernel(const sdpa_geom_t g, con
 	}
 }
 
+// ---- forward on the matrix cores (round 3) -----------------------------------------------------------------------------------------
+// fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32 (the exact fmaf chain of mfma_gemm.h), the running-maximum softmax kept.  A wave owns 32 query rows, a
+// workgroup (4 waves) 128; key blocks of 32 stream through LDS, shared by the four waves.  Both products are computed TRANSPOSED so that the softmax never
+// crosses lanes except for one half-wave swap:
+//   S^T [32 keys x 32 rows] = K Q^T      A = K tile out of LDS (lane: key l & 31, its half's D / 2 values as 16-byte reads), B = Q^T held in registers for the
+//                                        whole kernel (lane: row l & 31, D / 2 values); MFMA i contracts d = i (lanes 0-31) and d = D / 2 + i (lanes 32-63)
+//   D layout: lane (row = l & 31, half = l >> 5) holds the keys ky(r) = (r & 3) + 8 (r >> 2) + 4 half of ITS row: maximum and sum are 16 registers + one swap
+//   O^T [Dv x 32 rows] += V^T P^T        MFMA j contracts the keys ky(j) (lanes 0-31) and ky(j) + 4 (lanes 32-63): its B operand IS register j of P^T -- the
+//                                        probabilities never leave the registers they were computed in; A = V[key][dv = l & 31] out of LDS
+// Conditions (sdpa_forward_launch): D % 8 == 0, Dv % 32 == 0, both <= 128, 16-byte aligned rows; everything else takes the kernel above.
+template <int DH, int TV> // DH = D / 2 rounded up to the instantiation (32 or 64), TV = Dv / 32 (1 .. 4)
+__global__ void __launch_bounds__(256) sdpa_forw_mfma_kernel(const sdpa_geom_t g, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ mask, float* __restrict__ o, float* __restrict__ lse)
+{
+	constexpr int DP = 2 * DH, KP = DP + 4, VP = 32 * TV + 4; // LDS row pitches (floats)
+	__shared__ __attribute__((aligned(16))) float Ks[32 * KP];
+	__shared__ __attribute__((aligned(16))) float Vs[32 * VP];
+	typedef float floatx16 __attribute__((ext_vector_type(16)));
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int li = lane & 31, lh = lane >> 5;
+	const int h = blockIdx.y, b = blockIdx.z, hk = h / g.ratio;
+	const int xw = blockIdx.x * 128 + wave * 32; // the wave's first query row
+	const int x = xw + li;
+	const int dh = g.D >> 1; // this half's share of d: [lh * dh, lh * dh + dh)
+	float qreg[DH];
+#pragma unroll
+	for (int i = 0; i < DH; i += 4) {
+		float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (x < g.R && i < dh) qv = *(const float4*)(q + b * g.q_sb + (long)x * g.q_sr + h * g.q_sh + lh * dh + i);
+		qreg[i] = qv.x; qreg[i + 1] = qv.y; qreg[i + 2] = qv.z; qreg[i + 3] = qv.w;
+	}
+	floatx16 acc[TV];
+#pragma unroll
+	for (int tv = 0; tv < TV; tv++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) acc[tv][r] = 0.f;
+	float m_run = -INFINITY, l_run = 0.f;
+	const int vis = x < g.R ? visible_keys(g, x) : 0;
+	int vis_max = 0; // the furthest key any row of this WORKGROUP sees (the key loop is shared: barriers inside)
+	{
+		const int x_last = blockIdx.x * 128 + 127 < g.R ? blockIdx.x * 128 + 127 : g.R - 1;
+		vis_max = visible_keys(g, x_last); // visible_keys is monotone in x
+	}
+	const float* const mrow = mask ? mask + b * g.m_sb + h * g.m_sh + (long)(x < g.R ? x : 0) * g.m_sr : 0;
+	for (int y0 = 0; y0 < vis_max; y0 += 32) {
+		__syncthreads();
+		// the K and V tiles: 16-byte chunks, rows beyond C read as zeros
+		for (int c = t; c < 32 * (g.D >> 2); c += 256) {
+			const int j = c / (g.D >> 2), d = (c - j * (g.D >> 2)) << 2;
+			*(float4*)(Ks + j * KP + d) = y0 + j < g.C ? *(const float4*)(k + b * g.k_sb + (long)(y0 + j) * g.k_sc + hk * g.k_sh + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		for (int c = t; c < 32 * (g.Dv >> 2); c += 256) {
+			const int j = c / (g.Dv >> 2), d = (c - j * (g.Dv >> 2)) << 2;
+			*(float4*)(Vs + j * VP + d) = y0 + j < g.C ? *(const float4*)(v + b * g.v_sb + (long)(y0 + j) * g.v_sc + hk * g.v_sh + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		__syncthreads();
+		floatx16 s;
+#pragma unroll
+		for (int r = 0; r < 16; r++) s[r] = 0.f;
+		const float* const krow = Ks + li * KP + lh * dh;
+#pragma unroll
+		for (int i = 0; i < DH; i += 4) {
+			if (i < dh) {
+				const float4 kv = *(const float4*)(krow + i);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qreg[i], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qreg[i + 1], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qreg[i + 2], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qreg[i + 3], s, 0, 0, 0);
+			}
+		}
+		// scores of this lane's row: register r <-> key y0 + (r & 3) + 8 (r >> 2) + 4 lh
+		float bm = -INFINITY;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+			if (y < vis) {
+				s[r] = g.scale * s[r] + (mrow ? mrow[y] : 0.f);
+				bm = fmaxf(bm, s[r]);
+			} else s[r] = -INFINITY;
+		}
+		bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+		const float m_new = fmaxf(m_run, bm);
+		float ps = 0.f;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			s[r] = s[r] == -INFINITY ? 0.f : expf(s[r] - m_new);
+			ps += s[r];
+		}
+		ps += __shfl_xor(ps, 32, 64);
+		const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+		l_run = l_run * alpha + ps;
+		m_run = m_new;
+#pragma unroll
+		for (int tv = 0; tv < TV; tv++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[tv][r] *= alpha;
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const float* const vrow = Vs + ((j & 3) + 8 * (j >> 2) + 4 * lh) * VP + li;
+#pragma unroll
+			for (int tv = 0; tv < TV; tv++)
+				if (tv * 32 < g.Dv) acc[tv] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * tv], s[j], acc[tv], 0, 0, 0);
+		}
+	}
+	if (x < g.R) {
+		const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+		float* const orow = o + b * g.o_sb + (long)x * g.o_sr + h * g.o_sh;
+#pragma unroll
+		for (int tv = 0; tv < TV; tv++)
+			if (tv * 32 < g.Dv) {
+#pragma unroll
+				for (int r4 = 0; r4 < 4; r4++) { // registers 4 r4 .. 4 r4 + 3 are dv = 32 tv + 8 r4 + 4 lh + 0..3
+					const int d = 32 * tv + 8 * r4 + 4 * lh;
+					orow[d] = acc[tv][4 * r4] * inv; orow[d + 1] = acc[tv][4 * r4 + 1] * inv; orow[d + 2] = acc[tv][4 * r4 + 2] * inv; orow[d + 3] = acc[tv][4 * r4 + 3] * inv;
+				}
+			}
+		if (lse && lh == 0) lse[((long)b * g.Hq + h) * g.R + x] = l_run > 0.f ? m_run + logf(l_run) : -INFINITY;
+	}
+}
+
 // delta[b][h][x] = sum_d g[b, x, h, d] * o[b, x, h, d]   (o: the scratch copy, dense [B][R][Hq][Dv])
 __global__ void __launch_bounds__(256) sdpa_delta_kernel(const sdpa_geom_t g, const float* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ o, float* __restrict__ delta)
 {
@@ -290,8 +409,22 @@ static bool sdpa_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_tensor_t* q, c
 }
 static int sdpa_forward_launch(const sdpa_geom_t& g, const float* q, const float* k, const float* v, const float* mask, float* o, float* lse, hipStream_t stream)
 {
-	const dim3 grid((g.R + BR - 1) / BR, g.Hq, g.B);
 	if (!g.R || !g.Hq || !g.B) return CCV_NNC_EXEC_SUCCESS;
+	// the matrix-core kernel: whole 16-byte chunks of q / k / v rows, the output tile a whole number of MFMA tiles
+	const bool rows16 = !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) && !((g.q_sb | g.q_sr | g.q_sh | g.k_sb | g.k_sc | g.k_sh | g.v_sb | g.v_sc | g.v_sh) & 3);
+	if (tune(TUNE_SDPA_MFMA) && rows16 && g.D % 8 == 0 && g.Dv % 32 == 0 && g.D <= 128 && g.Dv <= 128) {
+		const dim3 grid((g.R + 127) / 128, g.Hq, g.B);
+		const int tv = g.Dv / 32;
+		// (both products of every (row, key) pair; causal masks skip key blocks, so this is an upper bound there)
+		ProfScope prof("sdpa_fwd|nnc::sdpa_forw_mfma_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (g.D + g.Dv), 0, g.R, g.C, g.D, g.B * g.Hq, 1, stream);
+#define SDPA_MFMA(DH, TV) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_mfma_kernel<DH, TV>), grid, dim3(256), 0, stream, g, q, k, v, mask, o, lse)
+		if (g.D <= 64) { if (tv == 1) SDPA_MFMA(32, 1); else if (tv == 2) SDPA_MFMA(32, 2); else if (tv == 3) SDPA_MFMA(32, 3); else SDPA_MFMA(32, 4); }
+		else { if (tv == 1) SDPA_MFMA(64, 1); else if (tv == 2) SDPA_MFMA(64, 2); else if (tv == 3) SDPA_MFMA(64, 3); else SDPA_MFMA(64, 4); }
+#undef SDPA_MFMA
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
+	const dim3 grid((g.R + BR - 1) / BR, g.Hq, g.B);
 	const int dm = g.D > g.Dv ? g.D : g.Dv;
 	if (dm <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_kernel<64, 64>), grid, dim3(256), 0, stream, g, q, k, v, mask, o, lse);
 	else if (dm <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_kernel<128, 32>), grid, dim3(256), 0, stream, g, q, k, v, mask, o, lse);

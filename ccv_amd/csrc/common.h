@@ -189,6 +189,7 @@ enum {
 	TUNE_WINO_WGRAD_FUSED_MAX, // algorithm -1 takes the fused Winograd filter gradient when both channel counts are <= this (0 = never)
 	TUNE_GEMM_BUFFER_LOADS, // plain-matrix contractions fetch their operands with buffer loads (no address VALU in the K loop); 0 = the pointer path;
 	                        // half precision: 2 = never the 256 x 256 tile, 3 = that tile wherever it fits, 4 = K-steps of 32 only (gemm_launch.h)
+	TUNE_SDPA_MFMA,         // scaled-dot-product attention forward on the matrix cores where the shapes allow (1), or the VALU kernel always (0)
 	TUNE_COUNT
 };
 static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");

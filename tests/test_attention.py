@@ -32,6 +32,10 @@ CASES = [
     (1, 18, 50, 2, 1, 136, 136, False, None),    # D > 128
     (2, 19, 21, 4, 4, 32, 32, False, (1, 1)),    # one mask for every batch item and head
     (2, 19, 21, 4, 2, 32, 32, True, (2, 4)),     # a mask per batch item and head, and causal
+    # the matrix-core forward kernel (D % 8 == 0, Dv % 32 == 0, both <= 128): several waves and workgroups, ragged row / key blocks
+    (2, 150, 70, 4, 2, 64, 64, True, None),
+    (1, 131, 97, 2, 2, 128, 96, False, (1, 2)),
+    (2, 40, 200, 3, 1, 40, 32, True, (2, 1)),
 ]
 
 
@@ -107,3 +111,29 @@ def test_attention_single_head_3d_and_head_projection(backend, ref_lib):
     assert r1 == 0 and r2 == 0
     close(got[2], want[2])
     close(got[0], want[0])
+
+
+def test_attention_forward_on_the_matrix_cores_agrees_with_the_valu_kernel(backend, ref_lib):
+    """The same forward through both kernels of cmd_attention.cpp (tuning key SDPA_MFMA): both within tolerance of the oracle, the matrix-core one recorded as such."""
+    B, R, Cn, Hq, Hk, D, Dv = 2, 150, 70, 4, 2, 64, 64
+    rng = np.random.default_rng(11)
+    q = rng.random((B, R, Hq, D), dtype=F) - F(0.5)
+    k = rng.random((B, Cn, Hk, D), dtype=F) - F(0.5)
+    v = rng.random((B, Cn, Hk, Dv), dtype=F) - F(0.5)
+    cmd = sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_FORWARD", float(1.0 / np.sqrt(D)), True)
+    r0, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, [q, k, v], [np.zeros((B, R, Hq, Dv), F)], backend=nnc.BACKEND_CPU_REF)
+    assert r0 == 0
+    seen = {}
+    for mode in (1, 0):
+        backend.tune_set("SDPA_MFMA", mode)
+        backend.profile_enable(1)
+        try:
+            r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [q, k, v], [np.zeros((B, R, Hq, Dv), F)])
+            backend.stream_wait(None)
+            seen[mode] = [r[0] for r in backend.profile_records()]
+        finally:
+            backend.profile_enable(0)
+            backend.tune_set("SDPA_MFMA", 1)
+        assert r1 == 0
+        close(got[0], want[0])
+    assert any("sdpa_forw_mfma_kernel" in n for n in seen[1]) and not any("sdpa_forw_mfma_kernel" in n for n in seen[0]), seen

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Scaled-dot-product attention forward on the MI355X: the matrix-core kernel (sdpa_forw_mfma_kernel, fp32 MFMA) against the VALU kernel of cmd_attention.cpp
+on the same tensors (tuning key SDPA_MFMA), HIP-event timed.  usage: python tools/attention_bench.py > gpurun_out/attention_bench.txt"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from ccv_amd import nnc
+import test_attention as T
+
+L = nnc.load()
+s = L.stream_new(0)
+e0, e1 = L.dll.nnc_mi355x_event_new(), L.dll.nnc_mi355x_event_new()
+F = nnc.CCV_32F
+
+
+def tens(*dims, fill=0.5):
+    t = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, F, dims, 0))
+    rng = np.random.default_rng(0)
+    block = (rng.random(1 << 20, dtype=np.float32) - 0.5) * fill
+    t.upload(np.resize(block, int(np.prod(dims))).reshape(dims))
+    return t
+
+
+for (B, R, C, H, Hk, D, causal) in [(8, 2048, 2048, 16, 16, 64, False), (8, 2048, 2048, 16, 16, 64, True), (4, 4096, 4096, 16, 4, 128, True), (32, 512, 512, 12, 12, 64, False)]:
+    q, k, v, o = tens(B, R, H, D), tens(B, C, Hk, D), tens(B, C, Hk, D), tens(B, R, H, D)
+    cmd = T.sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_FORWARD", float(1.0 / np.sqrt(D)), causal)
+    flops = 2.0 * B * H * R * C * 2 * D * (0.5 if causal else 1.0)
+    line = "B %d R %d C %d heads %d/%d D %d %s:" % (B, R, C, H, Hk, D, "causal" if causal else "full  ")
+    for mode in (1, 0):
+        L.tune_set("SDPA_MFMA", mode)
+        reps = 3 if mode else 1
+        assert L.cmd_exec(cmd, nnc.NO_HINT, 0, [q, k, v], [o], s) == 0
+        L.dll.nnc_mi355x_event_record(e0, s)
+        for _ in range(reps):
+            assert L.cmd_exec(cmd, nnc.NO_HINT, 0, [q, k, v], [o], s) == 0
+        L.dll.nnc_mi355x_event_record(e1, s)
+        ms = L.dll.nnc_mi355x_event_elapsed_ms(e0, e1) / reps
+        line += "   %s %8.3f ms %6.1f TFLOP/s" % ("matrix cores" if mode else "VALU kernel ", ms, flops / ms / 1e9)
+    L.tune_set("SDPA_MFMA", 1)
+    print(line, flush=True)
