@@ -267,10 +267,11 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
-// algorithm -1: the fused kernel where it measures faster on the MI355X (tools/conv_algo_sweep.py at batch 256, profiles/r03_v8_conv_algo_sweep.txt):
-// up to TUNE_WINO_FUSED_MAX_C reduction channels (default 256 since round 3's pixel-major patches + packed transforms: 256 -> 256 at 55^2 2.53 vs 3.13 ms
-// forward, 64 -> 64 at 223^2 3.04 vs 7.7), and up to twice that when the 16-tile groups pad the tile grid by less than a fifth (512 -> 512 at 13^2: 0.74 vs
-// 0.80 ms; at 27^2, 7 -> 8 tiles per side, the via-HBM form wins: 2.41 vs 2.78).
+// algorithm -1: the fused kernel where it measures faster on the MI355X (tools/conv_algo_sweep.py, profiles/r03_v8_conv_algo_sweep.txt): up to
+// TUNE_WINO_FUSED_MAX_C reduction channels (default 128), and up to twice that when the 16-tile groups pad the tile grid by less than a fifth (256 -> 256 at
+// 55^2: 2.53 vs 3.13 ms via HBM).  Round 3 tried 256 as the default -- at batch 256 it is 0.2 ms of the VGG-D step (512 -> 512 at 13^2: 0.74 vs 0.80 ms; 256 -> 512
+// at 27^2 even), but at batch 64 the same layers have 4 items per persistent workgroup and run 51 TFLOP/s (forward 8513 -> 7033 images/s), and DawnNet's 256-channel
+// layers at 8^2 pad four-fold: the rule stays where few items or heavy padding cannot hurt it.
 static bool wino_fused_preferred(const int C_red, const wino_fused_plan_t& p, const Image4& dst)
 {
 	const long maxc = tune(TUNE_WINO_FUSED_MAX_C);
