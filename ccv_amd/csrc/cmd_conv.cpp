@@ -1097,6 +1097,12 @@ static void dense_nhwc_f32(const Image4& li, const bool batched, float* data, cc
 	out->data.f32 = data;
 	image4(out, oi);
 }
+// Which half NCHW convolutions take the f16 implicit-GEMM core (TUNE_CONV_NCHW_HALF_F16 = the least reduction channels; the loaders' chunk conditions)
+static bool conv_nchw_half_f16_ok(const conv_geom_t& g)
+{
+	const long least = tune(TUNE_CONV_NCHW_HALF_F16);
+	return least > 0 && g.groups == 1 && g.Cg >= least && g.Cg % 8 == 0 && g.K % 8 == 0 && (long)g.N * g.OH * g.OW <= 0x7fffffffL && (long)g.N * g.H * g.W <= 0x7fffffffL;
+}
 static int conv_nchw_half_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, const ccv_nnc_tensor_t* a, const ccv_nnc_tensor_t* w, const ccv_nnc_tensor_t* bias, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* const ctx)
 {
 	if ((flags & CCV_NNC_ACCUMULATE_OUTPUT) || w->info.format != CCV_TENSOR_FORMAT_NCHW || !tensor_contiguous(w)) return CCV_NNC_EXEC_NO_KERNEL;
@@ -1109,12 +1115,28 @@ static int conv_nchw_half_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hin
 	conv_geom_t g;
 	if (!conv_geometry(cmd, hint, ai, bi, 0, &g) || K != g.K || kh != g.kh || kw != g.kw || Cg != g.Cg) return CCV_NNC_EXEC_INVALID;
 	if (bias && (bias->info.dim[0] != g.K || !tensor_contiguous(bias))) return CCV_NNC_EXEC_INVALID;
+	int ret;
+	// Enough reduction channels: the f16 implicit GEMM on the matrix cores between HALF transposes (2 + 2 bytes per activation element around the kernel instead
+	// of 6 + 6, and 456-539 TFLOP/s of direct arithmetic against the fp32 Winograd kernels' ~190 direct-equivalent; tools/half_bench.py).  The ReLU a look-ahead
+	// may have asked for is left to its own pass there (tl_relu_done stays clear).
+	if (conv_nchw_half_f16_ok(g)) {
+		const size_t ha = align256(sizeof(half_t) * tensor_count(a->info)), hb = align256(sizeof(half_t) * tensor_count(b->info)), hw = align256(sizeof(half_t) * tensor_count(w->info));
+		char* const q = (char*)nnc_staging_of(ctx, ha + hb + hw);
+		if (!q) return CCV_NNC_EXEC_OOM;
+		if ((ret = transpose_half(a->data.u8, q, Na, Ca, Pa, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if ((ret = transpose_half(w->data.u8, q + ha + hb, g.K, g.Cg, g.kh * g.kw, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		ccv_nnc_tensor_t at, bt;
+		Image4 as, bs;
+		dense_nhwc_f32(ai, tensor_nd(a->info.dim) == 4, (float*)q, &at, &as);            // (geometry only: element strides are the same for halves)
+		dense_nhwc_f32(bi, tensor_nd(b->info.dim) == 4, (float*)(q + ha), &bt, &bs);
+		if ((ret = conv_forw_h(g, as, q + ha + hb, bias ? bias->data.u8 : 0, bs, flags, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		return transpose_half(q + ha, b->data.u8, Nb, Pb, Cb, ctx);
+	}
 	const size_t na = align256(sizeof(float) * tensor_count(a->info)), nb = align256(sizeof(float) * tensor_count(b->info));
 	const size_t nw = align256(sizeof(float) * tensor_count(w->info)), nbias = bias ? align256(sizeof(float) * (size_t)g.K) : 0;
 	char* const p = (char*)nnc_staging_of(ctx, na + nb + nw + nbias);
 	if (!p) return CCV_NNC_EXEC_OOM;
 	float* const A = (float*)p; float* const B = (float*)(p + na); float* const W = (float*)(p + na + nb); float* const BI = bias ? (float*)(p + na + nb + nw) : 0;
-	int ret;
 	if ((ret = transpose_half_to_float(a->data.u8, A, Na, Ca, Pa, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	if ((ret = transpose_half_to_float(w->data.u8, W, g.K, g.Cg, g.kh * g.kw, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	if (bias && (ret = half_to_float(bias->data.u8, BI, (size_t)g.K, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
@@ -1167,6 +1189,8 @@ static int conv_nchw_half_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hin
 		if (!bias_done && (ret = colsum_f32(gim.p, (long)g.N * g.OH * g.OW, g.K, gim.sw, DB, 0, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		if ((ret = float_to_half(DB, dbias->data.u8, (size_t)g.K, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
+	// (the data gradient stays on the fp32 Winograd kernels: conv_dgrad_h between half transposes was measured -- DawnNet f16 63.7 k -> 59.1 k images/s, ResNet-50 f16
+	// 3708 -> 3624 -- its 247 TFLOP/s against ~190 direct-equivalent does not pay for the extra transpose of g and the ReLU-backward mask it cannot fold)
 	if (h) {
 		if ((ret = transpose_half_to_float(w->data.u8, W, g.K, g.Cg, g.kh * g.kw, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		dense_nhwc_f32(hi, tensor_nd(h->info.dim) == 4, Hh, &hs, &him);

@@ -266,6 +266,7 @@ int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_str
 
 // Dense weight layout change [K][C][kh][kw] (NCHW-format weights) -> [K][kh][kw][C] (the layout the kernels read).
 // in[batch][R][C] -> out[batch][C][R], halves in / floats out and the reverse
+int transpose_half(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx) { return launch_transpose_half(in, out, batch, R, C, ctx); }
 int transpose_half_to_float(const void* in, float* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
 {
 	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;

@@ -149,6 +149,7 @@ size_t gemm_workspace_bound(long M, long N, long K); // most bytes gemm_run() ca
 int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx);
 int transpose_half_to_float(const void* in, float* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx); // in[batch][R][C] halves -> out[batch][C][R] floats
 int transpose_float_to_half(const float* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx);
+int transpose_half(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx); // in[batch][R][C] halves -> out[batch][C][R] halves
 int relu_inplace(ccv_nnc_tensor_t* t, ccv_nnc_stream_context_t* ctx); // t = max(t, 0), dense CCV_32F / CCV_16F (cmd_ew.cpp)
 int relu_back_inplace(ccv_nnc_tensor_t* h, const ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx); // h = b > 0 ? h : 0, dense, same type and count
 int weights_nchw_to_nhwc(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx);
@@ -189,6 +190,8 @@ enum {
 	TUNE_WINO_WGRAD_FUSED_MAX, // algorithm -1 takes the fused Winograd filter gradient when both channel counts are <= this (0 = never)
 	TUNE_GEMM_BUFFER_LOADS, // plain-matrix contractions fetch their operands with buffer loads (no address VALU in the K loop); 0 = the pointer path;
 	                        // half precision: 2 = never the 256 x 256 tile, 3 = that tile wherever it fits, 4 = K-steps of 32 only (gemm_launch.h)
+	TUNE_CONV_NCHW_HALF_F16, // half NCHW convolutions larger than 1 x 1: forward / data gradient on the f16 implicit-GEMM core between half transposes when the
+	                        // reduction has at least this many channels (0 = never: the fp32 Winograd kernels between converting transposes)
 	TUNE_SDPA_MFMA,         // scaled-dot-product attention forward on the matrix cores where the shapes allow (1), or the VALU kernel always (0)
 	TUNE_COUNT
 };

@@ -235,10 +235,12 @@ def test_conv_forward_backward_half(backend, ref_lib, case):
             _close(got[2], want[2])
 
 
-@pytest.mark.parametrize("case", [(2, 10, 10, 16, 24, 3, 3, (1, 1), (1, 1)), (3, 8, 8, 3, 8, 3, 3, (1, 1), (1, 1)), (2, 9, 9, 8, 8, 5, 5, (2, 2), (2, 2))], ids=["3x3", "3x3-c3", "5x5-s2"])
+@pytest.mark.parametrize("case", [(2, 10, 10, 16, 24, 3, 3, (1, 1), (1, 1)), (3, 8, 8, 3, 8, 3, 3, (1, 1), (1, 1)), (2, 9, 9, 8, 8, 5, 5, (2, 2), (2, 2)),
+                                  (2, 10, 10, 64, 72, 3, 3, (1, 1), (1, 1)), (2, 9, 9, 64, 64, 5, 5, (2, 2), (2, 2))], ids=["3x3", "3x3-c3", "5x5-s2", "3x3-c64-f16", "5x5-s2-c64-f16"])
 def test_conv_half_nchw_through_converting_transposes(backend, ref_lib, case):
     """CCV_16F tensors and filters in NCHW, kernel larger than 1 x 1 -- the CIFAR-10 / ImageNet trainers' fp16 mode.  One
-    converting transpose per tensor feeds the fp32 NHWC kernels (no fp32 image of the NCHW tensor is made first); flags = 0."""
+    converting transpose per tensor feeds the fp32 NHWC kernels (no fp32 image of the NCHW tensor is made first); flags = 0.
+    From 64 reduction channels on the forward pass runs the f16 implicit GEMM between half transposes instead (CONV_NCHW_HALF_F16)."""
     n, h, w_, c, k, kh, kw, stride, border = case
     rng = np.random.default_rng(9)
     a = hrnd(rng, n, h, w_, c)
@@ -250,7 +252,10 @@ def test_conv_half_nchw_through_converting_transposes(backend, ref_lib, case):
     nchw = lambda t: np.ascontiguousarray(t.transpose(0, 3, 1, 2))
     s0, n0 = _half_counts(backend)
     fcmd = nnc.CMD_CONVOLUTION_FORWARD(1, k, kh, kw, c)
-    r1, got = exec_on(backend, nnc.GPU_MEMORY, fcmd, hint, 0, [nchw(a), nchw(wt), bias], [np.zeros((n, k, oh, ow), H)], "NCHW")
+    res = {}
+    names = _kernel_records(backend, lambda: res.update(r=exec_on(backend, nnc.GPU_MEMORY, fcmd, hint, 0, [nchw(a), nchw(wt), bias], [np.zeros((n, k, oh, ow), H)], "NCHW")))
+    r1, got = res["r"]
+    assert any("mfma_gemm_f16" in x for x in names) == (c >= 64), names
     assert _half_counts(backend)[0] == s0  # nothing went through half_stage.cpp's fp32 images
     r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, fcmd, hint, 0, [a.astype(F), wt.astype(F), bias.astype(F)], [np.zeros((n, oh, ow, k), F)], backend=nnc.BACKEND_CPU_REF)
     assert r1 == 0 and r2 == 0
