@@ -130,7 +130,7 @@ static int chan_reduce(F f, const T* x, const T* g, const chan_view_t& v, float*
 //     fold combines the N planes exactly (Chan et al.: M2 = sum_o [M2_o + n (mean_o - mean)^2]).  x comes from HBM once
 //     where the two-reduction form read it twice; accuracy is that of the reference's mean -> centred-variance order.
 //   backward statistics: sum of g and sum of xhat * g in one sweep over (x, g).
-template <class T, class OP>
+template <int G, class T, class OP>
 __device__ __forceinline__ void plane_sweep(const T* __restrict__ p, const long inner, const int lane, OP op)
 {
 	constexpr int W = 16 / sizeof(T);
@@ -138,33 +138,42 @@ __device__ __forceinline__ void plane_sweep(const T* __restrict__ p, const long 
 	if ((inner % W) == 0 && (((uintptr_t)p) & 15) == 0) {
 		const V* const pv = (const V*)p;
 		const long nv = inner / W;
-		for (long i = lane; i < nv; i += 64) {
+		for (long i = lane; i < nv; i += G) {
 			const V v = pv[i];
 #pragma unroll
 			for (int e = 0; e < W; e++) op((float)v[e], i * W + e);
 		}
 	} else
-		for (long i = lane; i < inner; i += 64) op((float)p[i], i);
+		for (long i = lane; i < inner; i += G) op((float)p[i], i);
 }
 __device__ __forceinline__ float wave_sum(float s)
 {
 	for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64); // butterfly: every lane ends with the same total
 	return s;
 }
-template <class T>
+// G lanes per plane: 64 (a wave per plane) or 16 (four planes per wave: the 14 x 14 and 7 x 7 planes of a ResNet are 784 / 196 bytes -- a whole wave per plane
+// spends its time on the loop overhead and the reduction, not on its 1 - 4 loads; by layer size the one-wave form ran 5 TB/s at 56 x 56 and ~0.5 at 7 x 7)
+template <int G> __device__ __forceinline__ float group_sum(float s)
+{
+	for (int off = G / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64); // butterfly inside the G-lane group
+	return s;
+}
+#define PLANE_LOOP(G) \
+	const int lane = threadIdx.x & (G - 1); \
+	const long nw = (long)gridDim.x * 4 * (64 / G); \
+	for (long pl = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + ((threadIdx.x & 63) / G); pl < planes; pl += nw)
+template <class T, int G>
 __global__ void __launch_bounds__(256) bn_plane_stats_kernel(const T* __restrict__ x, const long planes, const long inner, float* __restrict__ psum, float* __restrict__ pm2)
 {
-	const int lane = threadIdx.x & 63;
-	const long nw = (long)gridDim.x * 4;
-	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+	PLANE_LOOP(G) {
 		const T* const p = x + pl * inner;
 		float s = 0.f;
-		plane_sweep(p, inner, lane, [&](const float v, long) { s += v; });
-		s = wave_sum(s);
+		plane_sweep<G>(p, inner, lane, [&](const float v, long) { s += v; });
+		s = group_sum<G>(s);
 		const float m = s / (float)inner;
 		float q = 0.f;
-		plane_sweep(p, inner, lane, [&](const float v, long) { const float d = v - m; q += d * d; });
-		q = wave_sum(q);
+		plane_sweep<G>(p, inner, lane, [&](const float v, long) { const float d = v - m; q += d * d; });
+		q = group_sum<G>(q);
 		if (lane == 0) { psum[pl] = s; pm2[pl] = q; }
 	}
 }
@@ -204,14 +213,12 @@ __global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restr
 	nscale[c] = w;
 	nbias[c] = bias[c] - mu * w;
 }
-template <class T>
+template <class T, int G>
 __global__ void __launch_bounds__(256) bn_plane_back_stats_kernel(const T* __restrict__ x, const T* __restrict__ g, const long planes, const int C, const long inner, const float* __restrict__ mean, const float* __restrict__ inv_std, float* __restrict__ pg, float* __restrict__ pxg)
 {
 	constexpr int W = 16 / sizeof(T);
 	typedef typename pack16<T>::type V;
-	const int lane = threadIdx.x & 63;
-	const long nw = (long)gridDim.x * 4;
-	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+	PLANE_LOOP(G) {
 		const int c = (int)(pl % C);
 		const float mu = mean[c], is = inv_std[c];
 		const T* const gp = g + pl * inner;
@@ -219,17 +226,19 @@ __global__ void __launch_bounds__(256) bn_plane_back_stats_kernel(const T* __res
 		float sg = 0.f, sx = 0.f;
 		if ((inner % W) == 0 && ((((uintptr_t)gp) | ((uintptr_t)xp)) & 15) == 0) {
 			const long nv = inner / W;
-			for (long i = lane; i < nv; i += 64) {
+			for (long i = lane; i < nv; i += G) {
 				const V gv = ((const V*)gp)[i], xv = ((const V*)xp)[i];
 #pragma unroll
 				for (int e = 0; e < W; e++) { sg += (float)gv[e]; sx += ((float)xv[e] - mu) * is * (float)gv[e]; }
 			}
 		} else
-			for (long i = lane; i < inner; i += 64) { const float gv = (float)gp[i]; sg += gv; sx += ((float)xp[i] - mu) * is * gv; }
-		sg = wave_sum(sg); sx = wave_sum(sx);
+			for (long i = lane; i < inner; i += G) { const float gv = (float)gp[i]; sg += gv; sx += ((float)xp[i] - mu) * is * gv; }
+		sg = group_sum<G>(sg); sx = group_sum<G>(sx);
 		if (lane == 0) { pg[pl] = sg; pxg[pl] = sx; }
 	}
 }
+// lanes per plane of the batch-norm plane kernels: 16 (four planes per wave) for planes of at most 1 KB
+template <class T> static int plane_lanes(const long inner) { return tune(TUNE_BN_SMALL_PLANES) && inner * (long)sizeof(T) <= 1024 ? 16 : 64; }
 static unsigned plane_grid(const long planes)
 {
 	// one plane per wave over the WHOLE tensor, no grid-stride cap (round 3): the same lesson as the element-wise maps (section 3.2 of DESIGN.md -- a few
@@ -296,21 +305,19 @@ __global__ void __launch_bounds__(256) bn_back_kernel(const T* x, const T* g, T*
 }
 // The same two maps, a wave per plane (inner > 1): the channel is one modulo per plane instead of a 64-bit division per element,
 // 16-byte accesses when the plane allows.  h = a * g + b * x + k with per-channel a, b, k.
-template <class T>
+template <class T, int G>
 __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ nscale, const float* __restrict__ nbias, const long planes, const int C, const long inner, const int relu)
 {
 	constexpr int W = 16 / sizeof(T);
 	typedef typename pack16<T>::type V;
-	const int lane = threadIdx.x & 63;
-	const long nw = (long)gridDim.x * 4;
-	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+	PLANE_LOOP(G) {
 		const int c = (int)(pl % C);
 		const float w = nscale[c], b = nbias[c];
 		const T* const xp = x + pl * inner;
 		T* const yp = y + pl * inner;
 		if ((inner % W) == 0 && ((((uintptr_t)xp) | ((uintptr_t)yp)) & 15) == 0) {
 			const long nv = inner / W;
-			for (long i = lane; i < nv; i += 64) {
+			for (long i = lane; i < nv; i += G) {
 				const V v = ((const V*)xp)[i];
 				V r;
 #pragma unroll
@@ -318,17 +325,15 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const T* __restric
 				((V*)yp)[i] = r;
 			}
 		} else
-			for (long i = lane; i < inner; i += 64) { const float t = (float)xp[i] * w + b; yp[i] = (T)(relu && !(t > 0.f) ? 0.f : t); }
+			for (long i = lane; i < inner; i += G) { const float t = (float)xp[i] * w + b; yp[i] = (T)(relu && !(t > 0.f) ? 0.f : t); }
 	}
 }
-template <class T>
+template <class T, int G>
 __global__ void __launch_bounds__(256) bn_back_planes_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ h, const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ inv_std, const float* __restrict__ dscale, const float* __restrict__ dbias, const long planes, const int C, const long inner, const float B)
 {
 	constexpr int W = 16 / sizeof(T);
 	typedef typename pack16<T>::type V;
-	const int lane = threadIdx.x & 63;
-	const long nw = (long)gridDim.x * 4;
-	for (long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += nw) {
+	PLANE_LOOP(G) {
 		const int c = (int)(pl % C);
 		const float is = inv_std[c], mu = mean[c], k = 1.f / B * scale[c] * is, db = dbias[c], ds = dscale[c];
 		const T* const xp = x + pl * inner;
@@ -336,7 +341,7 @@ __global__ void __launch_bounds__(256) bn_back_planes_kernel(const T* __restrict
 		T* const hp = h + pl * inner;
 		if ((inner % W) == 0 && ((((uintptr_t)xp) | ((uintptr_t)gp) | ((uintptr_t)hp)) & 15) == 0) {
 			const long nv = inner / W;
-			for (long i = lane; i < nv; i += 64) {
+			for (long i = lane; i < nv; i += G) {
 				const V xv = ((const V*)xp)[i], gv = ((const V*)gp)[i];
 				V r;
 #pragma unroll
@@ -344,7 +349,7 @@ __global__ void __launch_bounds__(256) bn_back_planes_kernel(const T* __restrict
 				((V*)hp)[i] = r;
 			}
 		} else
-			for (long i = lane; i < inner; i += 64) { const float xhat = ((float)xp[i] - mu) * is; hp[i] = (T)(k * (B * (float)gp[i] - db - xhat * ds)); }
+			for (long i = lane; i < inner; i += G) { const float xhat = ((float)xp[i] - mu) * is; hp[i] = (T)(k * (B * (float)gp[i] - db - xhat * ds)); }
 	}
 }
 
@@ -431,7 +436,8 @@ static int bnorm_forw_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 			const long planes = v.outer * v.C;
 			float* const psum = (float*)workspace_of(stream_context, sizeof(float) * 2 * (size_t)planes);
 			if (!psum) return CCV_NNC_EXEC_OOM;
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_plane_stats_kernel<T>), dim3(plane_grid(planes)), dim3(256), 0, stream, xp, planes, v.inner, psum, psum + planes);
+			if (plane_lanes<T>(v.inner) == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_plane_stats_kernel<T, 16>), dim3(plane_grid((planes + 3) / 4)), dim3(256), 0, stream, xp, planes, v.inner, psum, psum + planes);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_plane_stats_kernel<T, 64>), dim3(plane_grid(planes)), dim3(256), 0, stream, xp, planes, v.inner, psum, psum + planes);
 			HIP_ENFORCE(hipGetLastError());
 			hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((v.C + FOLD_CH - 1) / FOLD_CH), dim3(256), 0, stream, (const float*)psum, (const float*)(psum + planes), v.outer, v.C, (float)v.inner, saved_mean, saved_inv_std, mean, var, scale, bias, nscale, nbias, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon);
 			HIP_ENFORCE(hipGetLastError());
@@ -446,7 +452,7 @@ static int bnorm_forw_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 		hipLaunchKernelGGL(bn_test_affine_kernel, dim3(cb), dim3(256), 0, stream, (const float*)mean, (const float*)var, scale, bias, nscale, nbias, v.C, cmd.info.bnorm.epsilon);
 	HIP_ENFORCE(hipGetLastError());
 	if (v.inner > 1)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_planes_kernel<T>), dim3(plane_grid(v.outer * v.C)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, v.outer * v.C, v.C, v.inner, relu);
+		{ if (plane_lanes<T>(v.inner) == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_planes_kernel<T, 16>), dim3(plane_grid((v.outer * v.C + 3) / 4)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, v.outer * v.C, v.C, v.inner, relu); else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_planes_kernel<T, 64>), dim3(plane_grid(v.outer * v.C)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, v.outer * v.C, v.C, v.inner, relu); }
 	else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, stream, xp, yp, (const float*)nscale, (const float*)nbias, n, v.C, v.inner, relu);
 	HIP_ENFORCE(hipGetLastError());
@@ -502,7 +508,8 @@ static int bnorm_back_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 		float* const pg = (float*)workspace_of(stream_context, sizeof(float) * 2 * (size_t)planes);
 		if (!pg) return CCV_NNC_EXEC_OOM;
 		hipStream_t st = stream_of(stream_context);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_plane_back_stats_kernel<T>), dim3(plane_grid(planes)), dim3(256), 0, st, xp, gp, planes, v.C, v.inner, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, pg, pg + planes);
+		if (plane_lanes<T>(v.inner) == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_plane_back_stats_kernel<T, 16>), dim3(plane_grid((planes + 3) / 4)), dim3(256), 0, st, xp, gp, planes, v.C, v.inner, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, pg, pg + planes);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_plane_back_stats_kernel<T, 64>), dim3(plane_grid(planes)), dim3(256), 0, st, xp, gp, planes, v.C, v.inner, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, pg, pg + planes);
 		HIP_ENFORCE(hipGetLastError());
 		hipLaunchKernelGGL(chan_fold_kernel, dim3((v.C + FOLD_CH - 1) / FOLD_CH, 2), dim3(256), 0, st, (const float*)pg, (const float*)(pg + planes), v.outer, v.C, dbias->data.f32, dscale->data.f32, 0);
 		HIP_ENFORCE(hipGetLastError());
@@ -512,7 +519,7 @@ static int bnorm_back_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 	if ((ret = chan_reduce<RXhatG, true, T>(f, xp, gp, v, dscale->data.f32, stream_context)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
 	if (v.inner > 1)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_back_planes_kernel<T>), dim3(plane_grid(v.outer * v.C)), dim3(256), 0, stream_of(stream_context), xp, gp, hp, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, v.outer * v.C, v.C, v.inner, (float)(n / v.C));
+		{ if (plane_lanes<T>(v.inner) == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_back_planes_kernel<T, 16>), dim3(plane_grid((v.outer * v.C + 3) / 4)), dim3(256), 0, stream_of(stream_context), xp, gp, hp, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, v.outer * v.C, v.C, v.inner, (float)(n / v.C)); else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_back_planes_kernel<T, 64>), dim3(plane_grid(v.outer * v.C)), dim3(256), 0, stream_of(stream_context), xp, gp, hp, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, v.outer * v.C, v.C, v.inner, (float)(n / v.C)); }
 	else
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_back_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, stream_of(stream_context), xp, gp, hp, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, (const float*)dscale->data.f32, (const float*)dbias->data.f32, n, v.C, v.inner, (float)(n / v.C));
 	HIP_ENFORCE(hipGetLastError());

@@ -192,6 +192,7 @@ enum {
 	                        // half precision: 2 = never the 256 x 256 tile, 3 = that tile wherever it fits, 4 = K-steps of 32 only (gemm_launch.h)
 	TUNE_CONV_NCHW_HALF_F16, // half NCHW convolutions larger than 1 x 1: forward / data gradient on the f16 implicit-GEMM core between half transposes when the
 	                        // reduction has at least this many channels (0 = never: the fp32 Winograd kernels between converting transposes)
+	TUNE_BN_SMALL_PLANES,   // batch norm on [N][C][planes]: four planes per wave when a plane is at most 1 KB (1), or a wave per plane always (0)
 	TUNE_SDPA_MFMA,         // scaled-dot-product attention forward on the matrix cores where the shapes allow (1), or the VALU kernel always (0)
 	TUNE_COUNT
 };

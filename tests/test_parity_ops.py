@@ -608,7 +608,8 @@ def test_conv_first_layer_direct(backend, ref_lib, case):
         np.testing.assert_allclose(got[2], (db0 + want[2]) if flags else want[2], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("fmt,shape", [("NCHW", (3, 6, 5, 7)), ("NCHW", (2, 8, 8, 8)), ("NHWC", (3, 5, 7, 6)), ("NCHW", (2, 3, 40, 44))])  # (the last: planes of 1760 floats, several trips per lane)
+@pytest.mark.parametrize("fmt,shape", [("NCHW", (3, 6, 5, 7)), ("NCHW", (2, 8, 8, 8)), ("NHWC", (3, 5, 7, 6)), ("NCHW", (2, 3, 40, 44)),  # (2, 3, 40, 44): planes of 1760 floats, several trips per lane
+                                       ("NCHW", (5, 6, 7, 7)), ("NCHW", (3, 5, 14, 14))])  # ResNet's small planes: four planes per wave, 30 / 15 planes (ragged last waves)
 def test_batch_norm_with_one_dimensional_statistics(backend, ref_lib, fmt, shape):
     """What ccv_cnnp_batch_norm issues (lib/nnc/ccv_cnnp_model_addons.c:951-986): scale / bias / mean / var / saved tensors of ONE
     dimension (C) against an image tensor; the channel axis is the one the tensor FORMAT names.  The reference's CPU backend
