@@ -1165,6 +1165,35 @@ static int conv_nchw_half_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hin
 	Image4 hi;
 	if (h && (!image4(h, &hi) || hi.h != g.H || hi.w != g.W || hi.c != g.C || hi.n != g.N)) return CCV_NNC_EXEC_INVALID;
 	if (dbias && (!tensor_contiguous(dbias) || dbias->info.dim[0] != g.K)) return CCV_NNC_EXEC_INVALID;
+	int ret;
+	// Enough channels on both sides: the whole backward pass on the f16 implicit-GEMM core between HALF transposes (see conv_nchw_half_forw): since the row-contiguous
+	// operands of mfma_gemm_f16.h go through the LDS transpose read the filter gradient runs 430 and the data gradient 550 TFLOP/s of direct arithmetic there
+	// (round 2: 118 / 250, which lost to the fp32 Winograd kernels' ~150 - 250 direct-equivalent).  A ReLU-backward mask the look-ahead offers is left to its own pass.
+	if (conv_nchw_half_f16_ok(g) && g.Kg >= tune(TUNE_CONV_NCHW_HALF_F16) && tune(TUNE_CONV_NCHW_HALF_F16) > 0) {
+		const size_t hg = align256(sizeof(half_t) * tensor_count(gt->info)), ha = dw ? align256(sizeof(half_t) * tensor_count(a->info)) : 0, hh = h ? align256(sizeof(half_t) * tensor_count(h->info)) : 0;
+		const size_t hw = align256(sizeof(half_t) * (size_t)g.K * g.kh * g.kw * g.Cg);
+		char* const q = (char*)nnc_staging_of(ctx, hg + ha + hh + (h ? hw : 0) + (dw ? hw : 0));
+		if (!q) return CCV_NNC_EXEC_OOM;
+		char* const G16 = q; char* const A16 = q + hg; char* const H16 = q + hg + ha; char* const W16 = q + hg + ha + hh; char* const DW16 = W16 + (h ? hw : 0);
+		if ((ret = transpose_half(gt->data.u8, G16, Ng, Cgr, Pg, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		ccv_nnc_tensor_t g16, a16, h16;
+		Image4 g16i, a16i, h16i;
+		dense_nhwc_f32(gi, tensor_nd(gt->info.dim) == 4, (float*)G16, &g16, &g16i); // (geometry only: element strides are the same for halves)
+		if (dw) {
+			if ((ret = transpose_half(a->data.u8, A16, Na, Ca, Pa, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			dense_nhwc_f32(ai, tensor_nd(a->info.dim) == 4, (float*)A16, &a16, &a16i);
+			if ((ret = conv_wgrad_h(g, g16i, a16i, DW16, 0, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			if ((ret = transpose_half(DW16, dw->data.u8, g.K, g.kh * g.kw, g.Cg, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret; // [K][khkw][C] -> [K][C][khkw]
+		}
+		if (dbias && (ret = colsum_f16(g16i.p, (long)g.N * g.OH * g.OW, g.K, g16i.sw, dbias->data.u8, 0, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		if (h) {
+			if ((ret = transpose_half(w->data.u8, W16, g.K, g.Cg, g.kh * g.kw, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			dense_nhwc_f32(hi, tensor_nd(h->info.dim) == 4, (float*)H16, &h16, &h16i);
+			if ((ret = conv_dgrad_h(g, g16i, W16, h16i, 0, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			if ((ret = transpose_half(H16, h->data.u8, Na, Pa, Ca, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+		}
+		return CCV_NNC_EXEC_SUCCESS;
+	}
 	const size_t wbytes = align256(sizeof(float) * (size_t)g.K * g.kh * g.kw * g.Cg);
 	const size_t ng = align256(sizeof(float) * tensor_count(gt->info));
 	const size_t na = dw ? align256(sizeof(float) * tensor_count(a->info)) : 0, nh = h ? align256(sizeof(float) * tensor_count(h->info)) : 0;
@@ -1173,7 +1202,6 @@ static int conv_nchw_half_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hin
 	if (!p) return CCV_NNC_EXEC_OOM;
 	float* const G = (float*)p; float* const A = (float*)(p + ng); float* const Hh = (float*)(p + ng + na);
 	float* const W = (float*)(p + ng + na + nh); float* const DW = (float*)(p + ng + na + nh + nw); float* const DB = dbias ? (float*)(p + ng + na + nh + nw + ndw) : 0;
-	int ret;
 	if ((ret = transpose_half_to_float(gt->data.u8, G, Ng, Cgr, Pg, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	ccv_nnc_tensor_t gs, as, hs;
 	Image4 gim, aim, him;
@@ -1189,8 +1217,6 @@ static int conv_nchw_half_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hin
 		if (!bias_done && (ret = colsum_f32(gim.p, (long)g.N * g.OH * g.OW, g.K, gim.sw, DB, 0, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		if ((ret = float_to_half(DB, dbias->data.u8, (size_t)g.K, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 	}
-	// (the data gradient stays on the fp32 Winograd kernels: conv_dgrad_h between half transposes was measured -- DawnNet f16 63.7 k -> 59.1 k images/s, ResNet-50 f16
-	// 3708 -> 3624 -- its 247 TFLOP/s against ~190 direct-equivalent does not pay for the extra transpose of g and the ReLU-backward mask it cannot fold)
 	if (h) {
 		if ((ret = transpose_half_to_float(w->data.u8, W, g.K, g.Cg, g.kh * g.kw, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		dense_nhwc_f32(hi, tensor_nd(h->info.dim) == 4, Hh, &hs, &him);

@@ -9,7 +9,9 @@
 // chunk, BK = 32) carries over -- a chunk of halves is an 8-byte load.  What differs is everything after the load:
 //   * both operands are staged in ONE LDS image shape, [rows][40 halves] (k contiguous, row stride 80 bytes): a lane's
 //     fragment -- 8 consecutive k of its row -- is one 16-byte ds_read_b128, conflict-free across 16-lane groups (20-word row
-//     stride).  A row-contiguous operand (4 rows x 1 k per chunk) is transposed on its way in: four ds_write_b16.
+//     stride).  A row-contiguous operand (4 rows x 1 k per chunk) is staged as it comes, [32 k][rows + 32 halves] (one ds_write_b64 per chunk; round 2
+//     transposed it on the way in with four ds_write_b16), and its fragments are gathered by the LDS transpose read ds_read_b64_tr_b16 (tr_read4 below;
+//     the layout and the bank arithmetic are mfma_gemm_f16_buf.h's).
 //   * one K-step (32 deep) is two MFMAs per 32x32 tile instead of sixteen; with 14x the MFMA rate the kernel is bound by
 //     operand traffic (HBM / L2 -> LDS), not by MFMA issue, so the steady state is left to hipcc's scheduler: global loads
 //     of tile kt+1 are issued before the MFMAs of tile kt and written to the other LDS buffer after them.
@@ -66,6 +68,23 @@ struct EpiPartialH {
 __device__ __forceinline__ long M_N_slab(const EpiStoreH&) { return 0; }
 __device__ __forceinline__ long M_N_slab(const EpiPartialH& e) { return e.slab; }
 
+// halves per k row of a row-contiguous operand's LDS image: the tile's rows + 32 (160 / 96 halves = 80 / 48 dwords: the four k rows of a transpose-read
+// block land 16 banks apart)
+constexpr int gemm16_npitch(const int rows) { return rows + 32; }
+// Column `i` (= lane & 15) of the [4][16] block of halves whose rows start at blk, blk + pitch, ...: out[j] = blk[j * pitch + i].  On the device this is
+// ONE ds_read_b64_tr_b16: each 16-lane group reads the block, lane i supplying the address of four consecutive halves of row i >> 2 and receiving column i.
+#ifdef NNC_HIP_EMULATOR
+static inline halfx4 tr_read4(const half_t* const blk, const int pitch, const int i) { return halfx4{ blk[i], blk[pitch + i], blk[2 * pitch + i], blk[3 * pitch + i] }; }
+#else
+__device__ __forceinline__ halfx4 tr_read4(const half_t* const blk, const int pitch, const int i)
+{
+	halfx4 v;
+	const unsigned addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)(blk + (i >> 2) * pitch + (i & 3) * 4);
+	asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+	return v;
+}
+#endif
+
 // The chunks one thread stages for an operand tile, on top of TileFetch's address schedule.
 template <class L, int NCH>
 struct TileFetchH : TileFetch<L, NCH> {
@@ -82,22 +101,28 @@ struct TileFetchH : TileFetch<L, NCH> {
 		for (int jj = 0; jj < NCH; jj++) {
 			const int id = t + GEMM_THREADS * jj;
 			if (L::KCONTIG) *(uint2*)(lds + (id >> 3) * GEMM16_LDK + ((id & 7) << 2)) = r[jj]; // row id >> 3, k (id & 7) * 4 .. + 3
-			else { // k = id / (ROWS / 4), rows (id % (ROWS / 4)) * 4 .. + 3: transposed into the [rows][k] image
-				const int k = id / (Base::ROWS / 4), r0 = (id % (Base::ROWS / 4)) << 2;
-				const unsigned short h0 = (unsigned short)(r[jj].x & 0xffff), h1 = (unsigned short)(r[jj].x >> 16), h2 = (unsigned short)(r[jj].y & 0xffff), h3 = (unsigned short)(r[jj].y >> 16);
-				unsigned short* const d = (unsigned short*)lds + r0 * GEMM16_LDK + k;
-				d[0] = h0; d[GEMM16_LDK] = h1; d[2 * GEMM16_LDK] = h2; d[3 * GEMM16_LDK] = h3;
-			}
+			else *(uint2*)(lds + (id / (Base::ROWS / 4)) * gemm16_npitch(Base::ROWS) + ((id % (Base::ROWS / 4)) << 2)) = r[jj]; // k = id / (ROWS / 4), rows (id % (ROWS / 4)) * 4 .. + 3, as they come
 		}
 	}
 };
+
+// The fragment of sub-step s for the 32 rows starting at `base`: k = 16 s + 8 lh + 0..7 of row base + li, out of either image
+template <bool KC, int ROWS>
+__device__ __forceinline__ halfx8 frag16(const half_t* const s_, const int base, const int li, const int lh, const int s)
+{
+	if (KC) return *(const halfx8*)(s_ + (base + li) * GEMM16_LDK + 16 * s + 8 * lh);
+	constexpr int NP = gemm16_npitch(ROWS);
+	const half_t* const blk = s_ + (16 * s + 8 * lh) * NP + base + 16 * (li >> 4);
+	const halfx4 lo = tr_read4(blk, NP, li & 15), hi = tr_read4(blk + 4 * NP, NP, li & 15);
+	return halfx8{ lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+}
 
 // grid: x = tiles (* split-K slices), XCD-swizzled exactly as the fp32 core; z = batch / conv group.
 template <class LA, class LB, class EPI, int WM, int WN>
 __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff, const KOrder ko)
 {
 	constexpr int BM = 64 * WM, BN = 64 * WN;
-	constexpr int A_HALVES = BM * GEMM16_LDK, B_HALVES = BN * GEMM16_LDK;
+	constexpr int A_HALVES = LA::KCONTIG ? BM * GEMM16_LDK : GEMM_BK * gemm16_npitch(BM), B_HALVES = LB::KCONTIG ? BN * GEMM16_LDK : GEMM_BK * gemm16_npitch(BN);
 	__shared__ __attribute__((aligned(16))) half_t lds[2][A_HALVES + B_HALVES];
 	const int t = threadIdx.x;
 	const int lane = t & 63, wave = t >> 6;
@@ -176,9 +201,18 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 		for (int s = 0; s < 2; s++) {
 			halfx8 fa8[WM], fb8[WN];
 #pragma unroll
-			for (int ti = 0; ti < WM; ti++) fa8[ti] = *(const halfx8*)(sa + (row_a + 32 * ti + li) * GEMM16_LDK + 16 * s + 8 * lh);
+			for (int ti = 0; ti < WM; ti++) fa8[ti] = frag16<LA::KCONTIG, BM>(sa, row_a + 32 * ti, li, lh, s);
 #pragma unroll
-			for (int tj = 0; tj < WN; tj++) fb8[tj] = *(const halfx8*)(sb + (col_b + 32 * tj + li) * GEMM16_LDK + 16 * s + 8 * lh);
+			for (int tj = 0; tj < WN; tj++) fb8[tj] = frag16<LB::KCONTIG, BN>(sb, col_b + 32 * tj, li, lh, s);
+#ifndef NNC_HIP_EMULATOR
+			if (!LA::KCONTIG || !LB::KCONTIG) { // the transpose reads are asm: hipcc does not count them (the operands tie the MFMAs below behind the wait)
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+				for (int ti = 0; ti < WM; ti++) asm volatile("" : "+v"(fa8[ti]));
+#pragma unroll
+				for (int tj = 0; tj < WN; tj++) asm volatile("" : "+v"(fb8[tj]));
+			}
+#endif
 #pragma unroll
 			for (int ti = 0; ti < WM; ti++)
 #pragma unroll

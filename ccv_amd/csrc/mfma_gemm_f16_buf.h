@@ -17,22 +17,6 @@
 
 namespace nnc {
 
-// halves per k row of a row-contiguous operand's LDS image: the tile's rows + 32 (160 / 288 halves = 80 / 144 dwords: 16 banks past a multiple of 64)
-constexpr int gemm16_npitch(const int rows) { return rows + 32; }
-
-// Column `i` (= lane & 15) of the [4][16] block of halves whose rows start at blk, blk + pitch, ...: out[j] = blk[j * pitch + i].
-#ifdef NNC_HIP_EMULATOR
-static inline halfx4 tr_read4(const half_t* const blk, const int pitch, const int i) { return halfx4{ blk[i], blk[pitch + i], blk[2 * pitch + i], blk[3 * pitch + i] }; }
-#else
-__device__ __forceinline__ halfx4 tr_read4(const half_t* const blk, const int pitch, const int i)
-{
-	halfx4 v;
-	const unsigned addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)(blk + (i >> 2) * pitch + (i & 3) * 4);
-	asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-	return v;
-}
-#endif
-
 template <bool KC, int ROWS, int NT, int BK>
 struct FetchH16 {
 	static constexpr int KPITCH = BK + 8; // halves per row of a k-contiguous operand's image (80 / 144 bytes: 16-byte aligned rows, 20 / 36-dword stride: ds_read_b128 conflict-free)
