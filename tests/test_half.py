@@ -45,13 +45,11 @@ GEMM_H = [
     ((132, 200), (260, 200), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, True),   # several 128 x 128 tiles, ragged
     ((8, 4096), (16, 4096), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, True),    # split-K
     ((3, 8, 12), (3, 12, 16), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, False, True),    # batched
-    # whole K-steps, 128 x 128 tiles, a tile grid that fills the chip (here: batched): the buffer-load kernel (mfma_gemm_f16_buf.h); a row-contiguous operand goes
-    # through the LDS transpose read.  Small K keeps the CPU oracle's share of the test short; K = 64 is ONE K-step of 64, 160 five of 32, 192 three of 64.
-    ((72, 136, 64), (72, 264, 64), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), False, "buf"),    # k-contiguous x k-contiguous, ragged tiles
-    ((72, 136, 192), (72, 192, 196), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, False, "buf"),     # k-contiguous x row-contiguous; 196 columns: the last 8-row chunk straddles the end of a row
-    ((72, 160, 136), (72, 160, 200), nnc.TRANSPOSE(0, 1), nnc.NO_TRANSPOSE, False, "buf"),  # row-contiguous x row-contiguous
-    ((72, 64, 264), (72, 136, 64), nnc.TRANSPOSE(0, 1), nnc.TRANSPOSE(0, 1), False, "buf"), # row-contiguous x k-contiguous
-    ((136, 4096), (264, 4096), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, "buf"),         # one long reduction: split-K slices of whole K-steps, bias
+    # whole K-steps, 128 x 128 tiles, K >= 4096: the buffer-load kernel (mfma_gemm_f16_buf.h); a row-contiguous operand goes through the LDS transpose read
+    ((136, 4096), (264, 4096), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, "buf"),   # k-contiguous x k-contiguous, ragged tiles
+    ((136, 4096), (4096, 196), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, True, "buf"),      # k-contiguous x row-contiguous; 196 columns: the last 8-row chunk straddles the end of a row
+    ((4096, 136), (4096, 200), nnc.TRANSPOSE(0, 1), nnc.NO_TRANSPOSE, False, "buf"),  # row-contiguous x row-contiguous
+    ((4096, 264), (136, 4096), nnc.TRANSPOSE(0, 1), nnc.TRANSPOSE(0, 1), False, "buf"),  # row-contiguous x k-contiguous
     ((5, 3), (3, 7), nnc.NO_TRANSPOSE, nnc.NO_TRANSPOSE, True, False),             # odd sizes: fp32 core on fp32 images
     ((6, 18), (9, 18), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1), True, False),
 ]
@@ -106,16 +104,15 @@ def test_gemm_forward_half(backend, ref_lib, case):
 def test_gemm_half_buffer_kernel_shapes(backend, ref_lib, mode, layout):
     """The other shapes of the buffer-load kernel (mfma_gemm_f16_buf.h), forced through the tuning key: the 256 x 256 x 64 tile (mode 3) and K-steps of 32 (mode 4)."""
     rng = np.random.default_rng(5)
-    Z, M, N, K = 40, 264, 324, 128
+    M, N, K = 264, 324, 4096
     if layout == "kc x kc":
-        a, w, ta, tb = hrnd(rng, Z, M, K), hrnd(rng, Z, N, K, scale=4.0 / np.sqrt(K)), (1, 2), (1, 2)
-        ta = nnc.NO_TRANSPOSE
+        a, w, ta, tb = hrnd(rng, M, K), hrnd(rng, N, K, scale=4.0 / np.sqrt(K)), nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1)
     else:
-        a, w, ta, tb = hrnd(rng, Z, K, M), hrnd(rng, Z, K, N, scale=4.0 / np.sqrt(K)), (1, 2), nnc.NO_TRANSPOSE
+        a, w, ta, tb = hrnd(rng, K, M), hrnd(rng, K, N, scale=4.0 / np.sqrt(K)), nnc.TRANSPOSE(0, 1), nnc.NO_TRANSPOSE
     backend.tune_set("GEMM_BUFFER_LOADS", mode)
     try:
         res = {}
-        names = _kernel_records(backend, lambda: res.update(r=_pair(backend, ref_lib, nnc.CMD_GEMM_FORWARD(ta, tb), nnc.NO_HINT, 0, [a, w], [np.zeros((Z, M, N), H)])))
+        names = _kernel_records(backend, lambda: res.update(r=_pair(backend, ref_lib, nnc.CMD_GEMM_FORWARD(ta, tb), nnc.NO_HINT, 0, [a, w, hrnd(rng, N)], [np.zeros((M, N), H)])))
     finally:
         backend.tune_set("GEMM_BUFFER_LOADS", 1)
     got, want = res["r"]
