@@ -112,12 +112,10 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const ConvC3
 	if (grp < g.groups) fetch(cur, av, avm);
 #pragma unroll
 	for (int s = 0; s < 7; s++) av[s] = (avm >> s) & 1 ? av[s] : 0.f;
-#ifndef NNC_HIP_EMULATOR
 	// Everything loaded so far (the filter fragments above all) has landed before the loop starts: otherwise hipcc's wait-count
 	// pass carries "the filter loads may still be in flight" around the back edge and puts an s_waitcnt vmcnt(0) into EVERY
 	// iteration -- which waits for the stores and the prefetch as well, i.e. undoes the pipeline.
-	__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8)); // vmcnt(0), expcnt / lgkmcnt not waited for (gfx9 encoding)
-#endif
+	NNC_WAIT_VM0_ONLY();
 	for (; grp < g.groups; grp += waves) {
 		const Pos nxt = advance(cur);
 		float nx[7];

@@ -1,0 +1,106 @@
+// The gfx950 instructions the kernels of this library issue BY HAND -- inline asm or builtins hipcc must not schedule, count or allocate its own way -- each
+// next to the portable statement the CPU test build (tests/emu: lanes as fibers, LDS-DMA synchronous) compiles in its place.  This file holds the ONE
+// NNC_HIP_EMULATOR switch of the kernel sources; the kernels use the names below and carry no conditional of their own.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nnc {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half_t;
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+typedef int wf_rsrc_t __attribute__((ext_vector_type(4)));
+
+// Pin a value to its position in the instruction stream: an empty volatile asm that "rewrites" x is ordered against the
+// sched_barrier fences, so arithmetic that consumes x cannot be hoisted above the fence in front of it (pure address
+// arithmetic otherwise floats to the top of the loop body, in front of the first MFMA).  No instruction is emitted.
+// s_waitcnt with only vmcnt counted (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+// One MFMA, accumulating in place.  hipcc's builtin cannot be used here: the wave owns 72 accumulator tiles (288 registers)
+// while the accumulator file holds 256, and with the builtin hipcc keeps EVERY tile in VGPRs and copies it through a[0:7]
+// around each MFMA (measured: 554 v_accvgpr_write + 308 v_accvgpr_read per chunk).  As an asm statement the register
+// class is part of the operand: 64 tiles live in AGPRs ("+a"), the last 8 in VGPRs ("+v"), all in place.  What hipcc does not
+// do for an asm MFMA (cdna guide 5.7) is handled by construction: its A operand was computed at least a whole slot earlier
+// (VALU -> MFMA operand needs 2 wait states), its B operand comes from a ds_read hipcc waits for, and the epilogue's first
+// read of an accumulator sits behind explicit s_nops.
+// WF_MFMA0: the same with C = 0 -- a work item's first MFMA into each accumulator, so that the 288 registers are not zeroed per
+// item.  (Declared read-write all the same: as a pure output it would be a NEW value per item, and hipcc then spills every
+// accumulator to scratch around the loop to merge the two -- measured, 1.1 KB of scratch per lane.)
+// One LDS-DMA piece: every lane copies 16 bytes from (descriptor base + VOFF + SOFF) to LDS byte address LDS_ADDR + 16 * lane; a
+// lane whose offset is out of the descriptor's range writes zeros.  As an asm statement for a different reason than the MFMA:
+// hipcc counts a builtin LDS-DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY part
+// of the array (measured: one per iteration) -- the pipeline would be synchronous.  Invisible to hipcc, the pieces are
+// waited for by the kernel's own counted WF_WAIT_VMCNT.  M0 (the LDS destination base) is written in the statement that
+// uses it and restored (cdna guide 5.7).
+// Column `i` (= lane & 15) of the [4][16] block of halves whose rows start at blk, blk + pitch, ...: out[j] = blk[j * pitch + i].  On the device this is
+// ONE ds_read_b64_tr_b16: each 16-lane group reads the block, lane i supplying the address of four consecutive halves of row i >> 2 and receiving column i.
+// NNC_ASM_NOPS("s_nop 4"): wait states hipcc's hazard pass cannot know about (operands of asm MFMAs, descriptor words fresh from v_readfirstlane).
+// NNC_WAIT_LGKM0(): the asm LDS reads (tr_read4) are not counted by hipcc either.  NNC_WAIT_VM0_ONLY(): every vector-memory operation so far, nothing else.
+#ifdef NNC_HIP_EMULATOR
+
+#define NNC_PIN_V(x) ((void)0)
+#define NNC_PIN_S(x) ((void)0)
+#define WF_WAIT_VMCNT(n) __builtin_amdgcn_wave_barrier()
+#define WF_MFMA(ACC, A, B, IN_AGPR) (ACC) = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (ACC), 0, 0, 0)
+#define WF_MFMA0(ACC, A, B, IN_AGPR) (ACC) = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (floatx4{ 0.f, 0.f, 0.f, 0.f }), 0, 0, 0)
+__device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned bytes)
+{
+	const unsigned long long b = (unsigned long long)base;
+	return wf_rsrc_t{ (int)(unsigned)b, (int)(unsigned)(b >> 32), (int)bytes, 0 };
+}
+__device__ __forceinline__ unsigned wf_lds_addr(float* p) { return (unsigned)(unsigned long long)p; } // emulator: low half of the host pointer; wf_dma16 gets the base again
+__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_base, unsigned lds_addr, unsigned voff, unsigned soff)
+{
+	const unsigned long long b = (unsigned long long)(unsigned)r[0] | (unsigned long long)(unsigned)r[1] << 32;
+	float* const dst = (float*)((char*)lds_base + (lds_addr - wf_lds_addr(lds_base)));
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (unsigned)r[2], 0), (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+}
+static inline halfx4 tr_read4(const half_t* const blk, const int pitch, const int i) { return halfx4{ blk[i], blk[pitch + i], blk[2 * pitch + i], blk[3 * pitch + i] }; }
+static inline floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return emu_mfma_f32_32x32x16_f16(a, b, c); }
+#define NNC_PIN_VEC(v) ((void)0)
+#define NNC_ASM_NOPS(text) ((void)0)
+#define NNC_WAIT_LGKM0() ((void)0)
+#define NNC_WAIT_VM0_ONLY() ((void)0)
+
+#else
+
+#define NNC_PIN_V(x) asm volatile("" : "+v"(x))
+#define NNC_PIN_S(x) asm volatile("" : "+s"(x))
+#define WF_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+#define WF_MFMA0(ACC, A, B, IN_AGPR) do { \
+		if (IN_AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "+a"(ACC) : "v"(A), "v"(B)); \
+		else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "+v"(ACC) : "v"(A), "v"(B)); \
+	} while (0)
+#define WF_MFMA(ACC, A, B, IN_AGPR) do { \
+		if (IN_AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B)); \
+		else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B)); \
+	} while (0)
+__device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned bytes)
+{ // raw buffer descriptor (stride 0), word 3 = the gfx90a / gfx94x / gfx950 raw-buffer format word; all four words wave-uniform
+	const unsigned long long b = (unsigned long long)base;
+	return wf_rsrc_t{ __builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32) & 0xffff), __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000 };
+}
+__device__ __forceinline__ unsigned wf_lds_addr(float* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)p; } // LDS byte address
+__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float*, unsigned lds_addr, unsigned voff, unsigned soff)
+{ // lds_addr / soff: wave-uniform integers the caller keeps in SGPRs (plain integer arithmetic on the array's base address -- a
+  // pointer cast per piece costs hipcc's null check, four SALU).  M0 is not restored: nothing else in this kernel uses it
+  // (checked in the ISA: hipcc's LDS instructions do not read M0 on gfx950, the kernel has no other LDS-DMA and no s_movrel).
+	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ halfx4 tr_read4(const half_t* const blk, const int pitch, const int i)
+{
+	halfx4 v;
+	const unsigned addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)(blk + (i >> 2) * pitch + (i & 3) * 4);
+	asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+	return v;
+}
+__device__ __forceinline__ floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+#define NNC_PIN_VEC(v) asm volatile("" : "+v"(v))
+#define NNC_ASM_NOPS(text) asm volatile(text)
+#define NNC_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define NNC_WAIT_VM0_ONLY() __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8)) // vmcnt(0), expcnt / lgkmcnt not waited for (gfx9 encoding)
+
+#endif
+
+} // namespace nnc

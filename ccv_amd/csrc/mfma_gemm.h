@@ -28,11 +28,10 @@
 // are dispatched to the same XCD so its private 4 MiB L2 serves the re-reads.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "isa.h"
 
 namespace nnc {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEMM_BK = 32, GEMM_THREADS = 256;
 constexpr int GEMM_LDK = 36; // row stride of a k-contiguous LDS image
@@ -42,16 +41,6 @@ constexpr int GEMM_LDK = 36; // row stride of a k-contiguous LDS image
 // masked lane only swaps the OFFSET and the access stays a plain global_load off `p`.
 __device__ __forceinline__ float4 ld16(const float* q) { return *(const float4*)q; }
 
-// Pin a value to its position in the instruction stream: an empty volatile asm that "rewrites" x is ordered against the
-// sched_barrier fences, so arithmetic that consumes x cannot be hoisted above the fence in front of it (pure address
-// arithmetic otherwise floats to the top of the loop body, in front of the first MFMA).  No instruction is emitted.
-#ifdef NNC_HIP_EMULATOR
-#define NNC_PIN_V(x) ((void)0)
-#define NNC_PIN_S(x) ((void)0)
-#else
-#define NNC_PIN_V(x) asm volatile("" : "+v"(x))
-#define NNC_PIN_S(x) asm volatile("" : "+s"(x))
-#endif
 
 // Exact n / d for 0 <= n < 2^31, d >= 1 as multiply + shift (Granlund-Montgomery): m = ceil(2^(31+s) / d), s = ceil(log2 d).
 struct FastDiv {

@@ -22,17 +22,9 @@
 
 namespace nnc {
 
-typedef _Float16 half_t;
-typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
-typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEMM16_LDK = 40; // halves per LDS row: 32 of a K-step + 8 of padding (80 bytes: 16-byte aligned rows, 20-word stride)
 
-#ifdef NNC_HIP_EMULATOR
-static inline floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return emu_mfma_f32_32x32x16_f16(a, b, c); }
-#else
-__device__ __forceinline__ floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-#endif
 
 // Epilogues.  Direct store: c[m * ldm + n * ldn] = alpha * acc (+ bias[n]) (+ old c when accumulating), rounded to half.
 struct EpiStoreH {
@@ -71,19 +63,6 @@ __device__ __forceinline__ long M_N_slab(const EpiPartialH& e) { return e.slab; 
 // halves per k row of a row-contiguous operand's LDS image: the tile's rows + 32 (160 / 96 halves = 80 / 48 dwords: the four k rows of a transpose-read
 // block land 16 banks apart)
 constexpr int gemm16_npitch(const int rows) { return rows + 32; }
-// Column `i` (= lane & 15) of the [4][16] block of halves whose rows start at blk, blk + pitch, ...: out[j] = blk[j * pitch + i].  On the device this is
-// ONE ds_read_b64_tr_b16: each 16-lane group reads the block, lane i supplying the address of four consecutive halves of row i >> 2 and receiving column i.
-#ifdef NNC_HIP_EMULATOR
-static inline halfx4 tr_read4(const half_t* const blk, const int pitch, const int i) { return halfx4{ blk[i], blk[pitch + i], blk[2 * pitch + i], blk[3 * pitch + i] }; }
-#else
-__device__ __forceinline__ halfx4 tr_read4(const half_t* const blk, const int pitch, const int i)
-{
-	halfx4 v;
-	const unsigned addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)(blk + (i >> 2) * pitch + (i & 3) * 4);
-	asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-	return v;
-}
-#endif
 
 // The chunks one thread stages for an operand tile, on top of TileFetch's address schedule.
 template <class L, int NCH>
@@ -204,15 +183,13 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 			for (int ti = 0; ti < WM; ti++) fa8[ti] = frag16<LA::KCONTIG, BM>(sa, row_a + 32 * ti, li, lh, s);
 #pragma unroll
 			for (int tj = 0; tj < WN; tj++) fb8[tj] = frag16<LB::KCONTIG, BN>(sb, col_b + 32 * tj, li, lh, s);
-#ifndef NNC_HIP_EMULATOR
 			if (!LA::KCONTIG || !LB::KCONTIG) { // the transpose reads are asm: hipcc does not count them (the operands tie the MFMAs below behind the wait)
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				NNC_WAIT_LGKM0();
 #pragma unroll
-				for (int ti = 0; ti < WM; ti++) asm volatile("" : "+v"(fa8[ti]));
+				for (int ti = 0; ti < WM; ti++) NNC_PIN_VEC(fa8[ti]);
 #pragma unroll
-				for (int tj = 0; tj < WN; tj++) asm volatile("" : "+v"(fb8[tj]));
+				for (int tj = 0; tj < WN; tj++) NNC_PIN_VEC(fb8[tj]);
 			}
-#endif
 #pragma unroll
 			for (int ti = 0; ti < WM; ti++)
 #pragma unroll

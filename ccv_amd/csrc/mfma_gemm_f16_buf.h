@@ -143,16 +143,14 @@ __global__ void __launch_bounds__(64 * WM * WN) mfma_gemm_f16_buf_kernel(BufMatL
 			for (int ti = 0; ti < TM; ti++) fa8[ti] = FA::frag(sa, row_a + 32 * ti, li, lh, s);
 #pragma unroll
 			for (int tj = 0; tj < TN; tj++) fb8[tj] = FB::frag(sb, col_b + 32 * tj, li, lh, s);
-#ifndef NNC_HIP_EMULATOR
 			// the transpose reads are asm: hipcc does not count them (the operands tie the MFMAs below behind the wait)
 			if (!AKC || !BKC) {
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				NNC_WAIT_LGKM0();
 #pragma unroll
-				for (int ti = 0; ti < TM; ti++) asm volatile("" : "+v"(fa8[ti]));
+				for (int ti = 0; ti < TM; ti++) NNC_PIN_VEC(fa8[ti]);
 #pragma unroll
-				for (int tj = 0; tj < TN; tj++) asm volatile("" : "+v"(fb8[tj]));
+				for (int tj = 0; tj < TN; tj++) NNC_PIN_VEC(fb8[tj]);
 			}
-#endif
 #pragma unroll
 			for (int ti = 0; ti < TM; ti++)
 #pragma unroll

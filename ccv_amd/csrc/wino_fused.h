@@ -137,72 +137,6 @@ struct WinoFusedArgs {
 	                          // element store e of that round writes at channel i is kept (wino_mask_pack_kernel makes them in the epilogue's own order)
 };
 
-// s_waitcnt with only vmcnt counted (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
-#ifdef NNC_HIP_EMULATOR // a wave's wait covers the DMA pieces of ALL its lanes: on the emulator (lanes are fibers, DMA is synchronous) that is a wave rendezvous
-#define WF_WAIT_VMCNT(n) __builtin_amdgcn_wave_barrier()
-#else
-#define WF_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
-#endif
-
-// One MFMA, accumulating in place.  hipcc's builtin cannot be used here: the wave owns 72 accumulator tiles (288 registers)
-// while the accumulator file holds 256, and with the builtin hipcc keeps EVERY tile in VGPRs and copies it through a[0:7]
-// around each MFMA (measured: 554 v_accvgpr_write + 308 v_accvgpr_read per chunk).  As an asm statement the register
-// class is part of the operand: 64 tiles live in AGPRs ("+a"), the last 8 in VGPRs ("+v"), all in place.  What hipcc does not
-// do for an asm MFMA (cdna guide 5.7) is handled by construction: its A operand was computed at least a whole slot earlier
-// (VALU -> MFMA operand needs 2 wait states), its B operand comes from a ds_read hipcc waits for, and the epilogue's first
-// read of an accumulator sits behind explicit s_nops.
-// WF_MFMA0: the same with C = 0 -- a work item's first MFMA into each accumulator, so that the 288 registers are not zeroed per
-// item.  (Declared read-write all the same: as a pure output it would be a NEW value per item, and hipcc then spills every
-// accumulator to scratch around the loop to merge the two -- measured, 1.1 KB of scratch per lane.)
-#ifdef NNC_HIP_EMULATOR
-#define WF_MFMA(ACC, A, B, IN_AGPR) (ACC) = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (ACC), 0, 0, 0)
-#define WF_MFMA0(ACC, A, B, IN_AGPR) (ACC) = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (floatx4{ 0.f, 0.f, 0.f, 0.f }), 0, 0, 0)
-#else
-#define WF_MFMA0(ACC, A, B, IN_AGPR) do { \
-		if (IN_AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "+a"(ACC) : "v"(A), "v"(B)); \
-		else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "+v"(ACC) : "v"(A), "v"(B)); \
-	} while (0)
-#define WF_MFMA(ACC, A, B, IN_AGPR) do { \
-		if (IN_AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B)); \
-		else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B)); \
-	} while (0)
-#endif
-
-// One LDS-DMA piece: every lane copies 16 bytes from (descriptor base + VOFF + SOFF) to LDS byte address LDS_ADDR + 16 * lane; a
-// lane whose offset is out of the descriptor's range writes zeros.  As an asm statement for a different reason than the MFMA:
-// hipcc counts a builtin LDS-DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY part
-// of the array (measured: one per iteration) -- the pipeline would be synchronous.  Invisible to hipcc, the pieces are
-// waited for by the kernel's own counted WF_WAIT_VMCNT.  M0 (the LDS destination base) is written in the statement that
-// uses it and restored (cdna guide 5.7).
-typedef int wf_rsrc_t __attribute__((ext_vector_type(4)));
-#ifdef NNC_HIP_EMULATOR
-__device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned bytes)
-{
-	const unsigned long long b = (unsigned long long)base;
-	return wf_rsrc_t{ (int)(unsigned)b, (int)(unsigned)(b >> 32), (int)bytes, 0 };
-}
-__device__ __forceinline__ unsigned wf_lds_addr(float* p) { return (unsigned)(unsigned long long)p; } // emulator: low half of the host pointer; wf_dma16 gets the base again
-__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_base, unsigned lds_addr, unsigned voff, unsigned soff)
-{
-	const unsigned long long b = (unsigned long long)(unsigned)r[0] | (unsigned long long)(unsigned)r[1] << 32;
-	float* const dst = (float*)((char*)lds_base + (lds_addr - wf_lds_addr(lds_base)));
-	__builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (unsigned)r[2], 0), (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
-}
-#else
-__device__ __forceinline__ wf_rsrc_t wf_make_rsrc(const void* base, unsigned bytes)
-{ // raw buffer descriptor (stride 0), word 3 = the gfx90a / gfx94x / gfx950 raw-buffer format word; all four words wave-uniform
-	const unsigned long long b = (unsigned long long)base;
-	return wf_rsrc_t{ __builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32) & 0xffff), __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000 };
-}
-__device__ __forceinline__ unsigned wf_lds_addr(float* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)p; } // LDS byte address
-__device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float*, unsigned lds_addr, unsigned voff, unsigned soff)
-{ // lds_addr / soff: wave-uniform integers the caller keeps in SGPRs (plain integer arithmetic on the array's base address -- a
-  // pointer cast per piece costs hipcc's null check, four SALU).  M0 is not restored: nothing else in this kernel uses it
-  // (checked in the ISA: hipcc's LDS instructions do not read M0 on gfx950, the kernel has no other LDS-DMA and no s_movrel).
-	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
-}
-#endif
-
 // DMA piece n = 0..19 of a trip is issued behind iteration 9 n / 5 (0, 1, 3, 5, 7, 9, 10, ...): -1 = none behind iteration `it`
 constexpr __host__ __device__ int wf_piece_at(int it)
 {
@@ -265,11 +199,7 @@ struct WfPair {
 //   y0 = 4 x0 + m, y1 = a + b, y2 = a - b, y3 = c + 2 t, y4 = c - 2 t, y5 = 4 x1 + n          (= wino_bt)
 // (each result is pinned where it is computed: hipcc otherwise sinks every transform to the end of the loop body, behind
 // the last MFMA, whatever the sched_barrier fences say -- they bind the machine scheduler, not the IR passes before it)
-#ifdef NNC_HIP_EMULATOR
-#define WF_PIN2(v) ((void)0)
-#else
-#define WF_PIN2(v) asm volatile("" : "+v"(v))
-#endif
+#define WF_PIN2(v) NNC_PIN_VEC(v)
 template <int PART, int K>
 __device__ __forceinline__ void wf_bt_op(const f2& x0, const f2& x1, const f2& x2, const f2& x3, const f2& x4, const f2& x5, f2& y0, f2& y1, f2& y2, f2& y3, f2& y4, f2& y5, f2 (&T)[6])
 {
@@ -414,9 +344,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 	set_patch(cur);
 	set_u(cur);
 	f2 S[6][6], Vc[2][6], T[6]; // S[row][column] = d B of the chunk being multiplied; Vc[zx & 1][zy] = column zx of V = B^T S, two columns at a time
-#ifndef NNC_HIP_EMULATOR
-	asm volatile("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them (5 wait states)
-#endif
+	NNC_ASM_NOPS("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them (5 wait states)
 	wf_static_for<WF_P_PIECES + 9>([&](auto qc) { dma_piece(qc, p_lds, 0, u_lds, (unsigned)wave * 9216u); });
 	wf_static_for<WF_P_PIECES>([&](auto qc) { dma_piece(qc, p_lds + WF_P_FLOATS * 4, WF_CC * 4, 0, 0); }); // (PAIR: sub-chunk 1 of the first 16-channel chunk)
 	WF_WAIT_VMCNT(WF_P_PIECES); // chunk 0's patch and this wave's share of U(0) have landed; chunk 1's patch may still fly
@@ -545,9 +473,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 	// has just read (the DMA in flight targets the other one), one round per r (the 4 tiles 4 g' + r, g' = 0..3: 4 tiles x 16
 	// pixels x 32 channels + padding < 9 KB per wave, private: no barrier between rounds).
 	auto epilogue = [&](const Item& it, const int par) {
-#ifndef NNC_HIP_EMULATOR
-		asm volatile("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
-#endif
+		NNC_ASM_NOPS("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
 		if constexpr (DBG & 64) { if (a.bias == (const float*)1) a.dst[t] = acc[0][0][0] + acc[35][1][3] + acc[17][0][1]; return; }
 		if constexpr (!(DBG & 32)) __builtin_amdgcn_s_barrier(); // every wave is done reading the U buffer the staging overwrites (the DMA in flight targets the other one)
 		constexpr int TS = 16 * 32 + 16; // floats per tile in the staging area: the 4 tiles of a ds_write land on 2 x 16 banks

@@ -132,9 +132,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 
 	if (g_first < g_end) { // (an empty slice still writes its zeros below: the fold reads every slice)
 	set_group(g_first);
-#ifndef NNC_HIP_EMULATOR
-	asm volatile("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them
-#endif
+	NNC_ASM_NOPS("s_nop 4"); // descriptor words fresh from v_readfirstlane -> the first buffer_load reading them
 	wf_static_for<WG_PIECES_PER_WAVE>([&](auto nc) {
 		constexpr int n = decltype(nc)::value, piece = n < 7 ? n : (n < 11 ? WG_A_PER_WAVE + (n - 7) : n - 4); // the trips' issue order
 		dma_piece(GroupId<piece>(), 0, true);
@@ -223,9 +221,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 			}
 #pragma unroll
 			for (int z = 0; z < 36; z++) { NNC_PIN_V(V[z].x); NNC_PIN_V(V[z].y); }
-#ifndef NNC_HIP_EMULATOR
-			asm volatile("s_nop 1"); // the last transform VALU -> an MFMA reading its result (asm MFMAs are outside hipcc's hazard handling)
-#endif
+			NNC_ASM_NOPS("s_nop 1"); // the last transform VALU -> an MFMA reading its result (asm MFMAs are outside hipcc's hazard handling)
 			wf_static_for<72>([&](auto mc) {
 				constexpr int mm = decltype(mc)::value, z = mm >> 1, jf = mm & 1; // an accumulator recurs every 72 MFMAs; W[z] feeds two in a row
 				if constexpr (!(DBG & 16)) {
@@ -247,9 +243,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgra
 	}
 	}
 
-#ifndef NNC_HIP_EMULATOR
-	asm volatile("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
-#endif
+	NNC_ASM_NOPS("s_nop 15\n\ts_nop 15"); // the last MFMAs' results -> the compiler-visible reads below
 	{
 		// D layout of 16x16x4: lane holds rows 4 (lane >> 4) + i (k), column lane & 15 (c)
 		float* const out = p.partial + (long)slice * 36 * p.K * p.C + (long)(kb * WG_KB + wk * 16 + 4 * slot) * p.C + cb * WG_CB + wc * 32 + 2 * ch; // column fragment j = input channel 2 ch + j
