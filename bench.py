@@ -140,6 +140,14 @@ def resnet_config(args, half, dawn=False):
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                            "kernel": "batch norm forward + backward commands (%s)" % "; ".join(sorted(set(k["name"] for k in bn))), "launches": n, "avg_ms": ms / n,
                            "ms_per_step": ms, "recorded_kernels": {k["name"][-100:]: {"ms": k["ms"], "launches": k["launches"], "tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0)} for k in ks}}
+    # half precision: the f16 contraction kernel with the most time in that recorded step, against the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
+    f16k = [k for k in ks if "mfma_gemm_f16" in k["name"] and k["ms"] > 0 and k["flops"] > 0]
+    if half and f16k:
+        top = max(f16k, key=lambda k: k["ms"])
+        ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+        allf = sum(k["flops"] for k in f16k) / (sum(k["ms"] for k in f16k) * 1e-3) / 1e12
+        out["roofline_f16_contractions"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "kernel": top["name"][-100:],
+                                            "launches": top["launches"], "avg_ms": top["ms"] / top["launches"], "all_f16_contractions": {"achieved": allf, "ms": sum(k["ms"] for k in f16k)}}
     emit(out)
 
 
