@@ -101,6 +101,8 @@ struct OpFill { float v; __device__ float operator()(float, float, float) const 
 struct OpScale { float s; __device__ float operator()(float a, float, float) const { return s * a; } };                    // 2|x|
 struct OpAdd2 { __device__ float operator()(float a, float b, float) const { return a + b; } };                            // 3|x|
 struct OpAdd3 { __device__ float operator()(float a, float b, float c) const { return a + b + c; } };
+struct OpAdd2Relu { __device__ float operator()(float a, float b, float) const { const float t = a + b; return t > 0.f ? t : 0.f; } };       // EWSUM + the ReLU behind it
+struct OpAdd3Relu { __device__ float operator()(float a, float b, float c) const { const float t = a + b + c; return t > 0.f ? t : 0.f; } };
 struct OpCopy { __device__ float operator()(float a, float, float) const { return a; } };
 
 // ---- SGD: n = mu*m + (1-damp)*(scale*g + decay*a); b = a - rate*n   (5|p| bytes: g, a, m in; b, n out) --------
@@ -245,12 +247,26 @@ __global__ void __launch_bounds__(EW_THREADS) ewsum_i32_kernel8(int* out, const 
 	}
 }
 
+static int ewsum_forw_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context);
 static int _ewsum_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
+	// recorded when its like has run before: the in-place RELU_FORWARD behind a residual sum folds into the pass that writes the sum (peephole.cpp)
+	uint64_t sig;
+	if (const int e = deferred_take_error()) return e;
+	const bool floats = output_size >= 1 && outputs[0] && (CCV_GET_DATA_TYPE(outputs[0]->info.datatype) == CCV_32F || CCV_GET_DATA_TYPE(outputs[0]->info.datatype) == CCV_16F); // (no ReLU row for CCV_32S: nothing to wait for)
+	sig = 0;
+	if (floats && deferred_try(_ewsum_forw, DEFER_EWSUM_FORWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;
+	const int r = ewsum_forw_entry(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);
+	return r;
+}
+static int ewsum_forw_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	const bool relu = cmd.algorithm > 0 && (cmd.algorithm & NNC_MI355X_EWSUM_ALGO_FUSE_RELU); // opt-in, or the look-ahead completing this sum with its ReLU: c = max(0, sum)
 	if (input_size < 1 || output_size < 1 || !outputs[0]) return CCV_NNC_EXEC_INVALID;
 	ccv_nnc_tensor_t* c = outputs[0];
 	if (CCV_GET_DATA_TYPE(c->info.datatype) == CCV_32S) {
-		if (!tensor_contiguous(c) || input_size > 8) return CCV_NNC_EXEC_INVALID;
+		if (!tensor_contiguous(c) || input_size > 8 || relu) return CCV_NNC_EXEC_INVALID;
 		const size_t n = tensor_count(c->info);
 		i32_ptrs_t ptrs;
 		for (int i = 0; i < input_size; i++) {
@@ -271,15 +287,31 @@ static int _ewsum_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 	for (int i = 0; i < input_size; i++) if (inputs[i]->info.datatype != dt) return CCV_NNC_EXEC_INVALID;
 	// Fold left to right, exactly the association order of the reference: ((in0 + in1) + in2) + ...
 	if (input_size == 1) {
+		if (relu) return ew_map_any<OpRelu, 1>(OpRelu(), dt, cp, inputs[0]->data.u8, 0, 0, n, stream_context);
 		if (inputs[0]->data.u8 == cp) return CCV_NNC_EXEC_SUCCESS;
 		return ew_map_any<OpCopy, 1>(OpCopy(), dt, cp, inputs[0]->data.u8, 0, 0, n, stream_context);
 	}
+	// (the LAST pass of the fold rectifies when asked to: relu && i reaches input_size there)
 	int ret, i = 0;
-	if (input_size >= 3) { ret = ew_map_any<OpAdd3, 3>(OpAdd3(), dt, cp, inputs[0]->data.u8, inputs[1]->data.u8, inputs[2]->data.u8, n, stream_context); i = 3; }
-	else { ret = ew_map_any<OpAdd2, 2>(OpAdd2(), dt, cp, inputs[0]->data.u8, inputs[1]->data.u8, 0, n, stream_context); i = 2; }
+	if (input_size >= 3) {
+		if (relu && input_size == 3) ret = ew_map_any<OpAdd3Relu, 3>(OpAdd3Relu(), dt, cp, inputs[0]->data.u8, inputs[1]->data.u8, inputs[2]->data.u8, n, stream_context);
+		else ret = ew_map_any<OpAdd3, 3>(OpAdd3(), dt, cp, inputs[0]->data.u8, inputs[1]->data.u8, inputs[2]->data.u8, n, stream_context);
+		i = 3;
+	} else {
+		if (relu) ret = ew_map_any<OpAdd2Relu, 2>(OpAdd2Relu(), dt, cp, inputs[0]->data.u8, inputs[1]->data.u8, 0, n, stream_context);
+		else ret = ew_map_any<OpAdd2, 2>(OpAdd2(), dt, cp, inputs[0]->data.u8, inputs[1]->data.u8, 0, n, stream_context);
+		i = 2;
+	}
 	for (; ret == CCV_NNC_EXEC_SUCCESS && i < input_size; ) {
-		if (i + 1 < input_size) { ret = ew_map_any<OpAdd3, 3>(OpAdd3(), dt, cp, cp, inputs[i]->data.u8, inputs[i + 1]->data.u8, n, stream_context); i += 2; }
-		else { ret = ew_map_any<OpAdd2, 2>(OpAdd2(), dt, cp, cp, inputs[i]->data.u8, 0, n, stream_context); i += 1; }
+		if (i + 1 < input_size) {
+			if (relu && i + 2 == input_size) ret = ew_map_any<OpAdd3Relu, 3>(OpAdd3Relu(), dt, cp, cp, inputs[i]->data.u8, inputs[i + 1]->data.u8, n, stream_context);
+			else ret = ew_map_any<OpAdd3, 3>(OpAdd3(), dt, cp, cp, inputs[i]->data.u8, inputs[i + 1]->data.u8, n, stream_context);
+			i += 2;
+		} else {
+			if (relu) ret = ew_map_any<OpAdd2Relu, 2>(OpAdd2Relu(), dt, cp, cp, inputs[i]->data.u8, 0, n, stream_context);
+			else ret = ew_map_any<OpAdd2, 2>(OpAdd2(), dt, cp, cp, inputs[i]->data.u8, 0, n, stream_context);
+			i += 1;
+		}
 	}
 	return ret;
 }

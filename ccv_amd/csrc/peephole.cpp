@@ -1,7 +1,7 @@
 // ReLU folded into its neighbour WITHOUT the caller's help: a one-command look-ahead per stream.
 //
-// The reference's graphs issue CONVOLUTION_FORWARD (or, in the conv - bn - relu blocks of its ResNet / CIFAR-10 models, BATCH_NORM_FORWARD)
-// followed by an in-place RELU_FORWARD on its output
+// The reference's graphs issue CONVOLUTION_FORWARD (or, in the conv - bn - relu blocks of its ResNet / CIFAR-10 models, BATCH_NORM_FORWARD; or, at the
+// end of a residual block, EWSUM_FORWARD) followed by an in-place RELU_FORWARD on its output
 // (test/int/nnc/graph.vgg.d.tests.c:14-90, bin/nnc/cifar-10.c:76-127 through ccv_cnnp's convolution + relu blocks), and on the way
 // back MAX_POOL_BACKWARD / CONVOLUTION_BACKWARD followed by an in-place RELU_BACKWARD on the gradient they wrote, masked by the map
 // they read.  The host has no fusion for these pairs (ccv_nnc_ops_fusions[] in lib/nnc/ccv_nnc_symbolic_graph_simplify.c:595- holds
@@ -257,8 +257,8 @@ int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* const a, ccv_nnc_tensor_t* c
 	const int device = device_for(ctx);
 	wait_launching(ctx, lock); // (a foreign thread's flush is enqueueing this stream's recorded command: the ReLU goes behind it, unfolded)
 	Slot* const s = slot_of(ctx, device);
-	if (!s || (s->kind != DEFER_CONV_FORWARD && s->kind != DEFER_BNORM_FORWARD) || !s->has_out[0] || a->data.u8 != b->data.u8 || !same_buffer(s->out[0], b) || !same_buffer(s->out[0], a)) return -1;
-	return run(*s, s->kind == DEFER_CONV_FORWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_BNORM_ALGO_FUSE_RELU, lock, true);
+	if (!s || (s->kind != DEFER_CONV_FORWARD && s->kind != DEFER_BNORM_FORWARD && s->kind != DEFER_EWSUM_FORWARD) || !s->has_out[0] || a->data.u8 != b->data.u8 || !same_buffer(s->out[0], b) || !same_buffer(s->out[0], a)) return -1;
+	return run(*s, s->kind == DEFER_CONV_FORWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : (s->kind == DEFER_BNORM_FORWARD ? NNC_MI355X_BNORM_ALGO_FUSE_RELU : NNC_MI355X_EWSUM_ALGO_FUSE_RELU), lock, true);
 }
 
 int deferred_fuse_relu_back(const ccv_nnc_tensor_t* const g, const ccv_nnc_tensor_t* const b, ccv_nnc_tensor_t* const h, ccv_nnc_stream_context_t* const ctx)

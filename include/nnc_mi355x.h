@@ -445,6 +445,9 @@ void nnc_mi355x_debug_force_tile(int wm, int wn);
 /* BATCH_NORM_FORWARD with cmd.algorithm = NNC_MI355X_BNORM_ALGO_FUSE_RELU: y = max(0, batch norm) -- the in-place RELU_FORWARD of a
  * conv - bn - relu block applied in the pass that writes y (statistics are of x: unchanged). */
 #define NNC_MI355X_BNORM_ALGO_FUSE_RELU 0x100
+/* EWSUM_FORWARD with cmd.algorithm = NNC_MI355X_EWSUM_ALGO_FUSE_RELU: c = max(0, a + b + ...) -- the in-place RELU_FORWARD behind the residual sum of a
+ * ResNet block (bin/nnc/imagenet.c: ccv_cnnp_sum then ccv_cnnp_relu) applied in the pass that writes the sum. */
+#define NNC_MI355X_EWSUM_ALGO_FUSE_RELU 0x100
 /* Callers that do NOT set these bits get the same folding from a one-command look-ahead (ccv_amd/csrc/peephole.cpp): a
  * CONVOLUTION_FORWARD / CONVOLUTION_BACKWARD / MAX_POOL_BACKWARD whose like has run before is recorded instead of launched; the
  * in-place RELU_FORWARD / RELU_BACKWARD the reference's graphs issue next on the same stream completes it, anything else that could

@@ -23,7 +23,8 @@ LIBS="/usr/lib/x86_64-linux-gnu/libsqlite3.so.0 -lm -lrt -lpthread"
 # 2. the two host libraries
 $CC -shared -fopenmp -o $OUT/libccv_host_gpu.so $OBJS -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib
 if [ -f $ROOT/tests/emu/_build/libnnc_mi355x_emu.so ]; then
-  cp $ROOT/tests/emu/_build/libnnc_mi355x_emu.so $OUT/libnnc_mi355x_emu.so
+  # (a link, not a copy: the host binaries of the CPU tier must run the emulator library as it is NOW -- a copy went stale whenever only `make emu` was rerun)
+  ln -sf ../../tests/emu/_build/libnnc_mi355x_emu.so $OUT/libnnc_mi355x_emu.so
   $CC -shared -fopenmp -o $OUT/libccv_host_emu.so $OBJS -L$OUT -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib
 fi
 # 3. the reference's int tests

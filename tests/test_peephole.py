@@ -149,6 +149,45 @@ def test_batch_norm_relu_pair(lib, fmt, shape, is_test):
     assert (want[0] == 0).any() and (want[0] > 0).any()
 
 
+@pytest.mark.parametrize("ninputs", [2, 3, 4])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_ewsum_relu_pair(lib, ninputs, dtype):
+    """The end of a residual block: EWSUM_FORWARD then RELU_FORWARD in place on the sum.  Run on the spot (first time), folded by the look-ahead (later times)
+    and with the opt-in bit: the same c = max(0, a + b + ...), bit for bit (the sum's association order is the plain command's)."""
+    rng = np.random.default_rng(33)
+    T = np.float16 if dtype == "f16" else F
+    xs = [srnd(rng, 3, 6, 5, 8, scale=2.0).astype(T) for _ in range(ninputs)]
+    cmd, relu = nnc.CMD_EWSUM_FORWARD(), nnc.CMD_RELU_FORWARD()
+
+    def run(mode):
+        ts = make_tensors(lib, nnc.GPU_MEMORY, xs)
+        tc, = make_tensors(lib, nnc.GPU_MEMORY, [np.full_like(xs[0], -3)])
+        c = nnc.Cmd(); nnc.C.memmove(nnc.C.byref(c), nnc.C.byref(cmd), nnc.C.sizeof(c))
+        if mode == "bit":
+            c.algorithm = nnc.EWSUM_ALGO_FUSE_RELU
+        assert lib.cmd_exec(c, nnc.NO_HINT, 0, ts, [tc]) == 0
+        if mode == "pair":
+            assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [tc], [tc]) == 0
+        return tc.numpy()
+
+    lib.dll.nnc_mi355x_set_peephole(0)
+    want = np.maximum(run("plain"), 0)
+    lib.dll.nnc_mi355x_set_peephole(1)
+    r0, f0, p0 = counts(lib)
+    results = [run("pair"), run("pair"), run("pair"), run("bit")]
+    r1, f1, p1 = counts(lib)
+    assert f1 - f0 >= 2 and (r1 - r0) - (f1 - f0) == (p1 - p0)
+    for got in results:
+        assert np.array_equal(got, want)
+    assert (want == 0).any() and (want > 0).any()
+    # a sum that is NOT followed by its ReLU is launched as it was by the next command on the stream
+    ts = make_tensors(lib, nnc.GPU_MEMORY, xs)
+    tc, td = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros_like(xs[0]), np.zeros_like(xs[0])])
+    assert lib.cmd_exec(cmd, nnc.NO_HINT, 0, ts, [tc]) == 0
+    assert lib.cmd_exec(relu, nnc.NO_HINT, 0, [tc], [td]) == 0  # out of place: no fold, tc keeps the plain sum
+    assert np.array_equal(td.numpy(), np.maximum(tc.numpy(), 0)) and (tc.numpy() < 0).any()
+
+
 TWO_DEVICE_SCRIPT = """
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, %r)
