@@ -47,7 +47,8 @@ def cpu_baseline(image, label):
     from oracle_bind import oracle_lib
     O, backend, per_image = oracle_lib()
     kind = "reference" if O.kind == "reference" else "port"
-    net = VGGD(O, 1, memory=nnc.CPU_MEMORY, backend=backend, pool_per_image=per_image, init="hash")
+    from oracle_vgg import make_vggd
+    net = make_vggd(O, 1, memory=nnc.CPU_MEMORY, backend=backend, pool_per_image=per_image, init="hash")
     net.set_input(image[None], [label])
     REPS = 3
 

@@ -7,8 +7,9 @@ in ONE flat arena (VGGD(flat_grads=True)), and the exchange is a single COMM_ALL
 few hundred bytes -- are latency-bound.  The gradient scale 1/(batch * world) is folded into the SGD command
 (bin/nnc/imagenet.c:314-317), so the sum needs no extra pass.
 
-transport="rccl": the COMM_* commands of libnnc_mi355x.so on an RCCL communicator spanning the processes.
-transport="gloo": CPU tensors + torch.distributed (gloo) -- used by the world_size-2 CPU tests of this logic.
+The transport is the COMM_* commands of libnnc_mi355x.so on an RCCL communicator spanning the processes; the three hooks at the top of the
+class (_init_transport, _collective, _order) are what the world_size-2 CPU tests of this bucketing logic replace with gloo on CPU tensors
+(tests/gloo_comm.py) -- the product package itself imports neither torch nor anything of the checker.
 """
 import ctypes as C
 import numpy as np
@@ -16,37 +17,38 @@ from . import nnc
 
 
 class ProcessComm:
-    def __init__(self, lib, dist, rank, world, transport="rccl"):
-        self.lib, self.dist, self.rank, self.world, self.transport = lib, dist, rank, world, transport
-        if transport == "rccl":
-            ids = [None]
-            if rank == 0:
-                buf = C.create_string_buffer(128)
-                if lib.dll.nnc_mi355x_comm_unique_id(buf) != 0:
-                    raise RuntimeError("ncclGetUniqueId failed")
-                ids = [buf.raw]
-            dist.broadcast_object_list(ids, src=0)
-            r = lib.dll.nnc_mi355x_comm_init_rank(C.c_char_p(ids[0]), rank, world)
-            if r != 0:
-                raise RuntimeError("nnc_mi355x_comm_init_rank failed: %d" % r)
+    def __init__(self, lib, dist, rank, world):
+        """dist: anything with broadcast_object_list(list, src) -- only rank 0's RCCL id travels through it."""
+        self.lib, self.dist, self.rank, self.world = lib, dist, rank, world
+        self._init_transport()
         self._allreduce = nnc.generic_cmd("COMM_ALLREDUCE_FORWARD")
         self._broadcast = nnc.generic_cmd("COMM_BROADCAST_FORWARD")
 
+    # ---- transport hooks -----------------------------------------------------------------------------------------------------
+    def _init_transport(self):
+        ids = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            if self.lib.dll.nnc_mi355x_comm_unique_id(buf) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+            ids = [buf.raw]
+        self.dist.broadcast_object_list(ids, src=0)
+        r = self.lib.dll.nnc_mi355x_comm_init_rank(C.c_char_p(ids[0]), self.rank, self.world)
+        if r != 0:
+            raise RuntimeError("nnc_mi355x_comm_init_rank failed: %d" % r)
+
     def _collective(self, cmd, t, stream, op):
-        if self.transport == "rccl":
-            r = self.lib.cmd_exec(cmd, nnc.NO_HINT, 0, [t], [t], stream)
-            if r != 0:
-                raise RuntimeError("collective failed: %d" % r)
-        else:
-            import torch
-            base = t.owner if t.owner is not None else t
-            flat = base.array.reshape(-1)
-            first = (t.ptr - base.ptr) // flat.itemsize   # a dense alias covers [first, first + count) of its owner
-            x = torch.from_numpy(flat[first:first + int(np.prod(t.dims))])
-            if op == "sum":
-                self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
-            else:
-                self.dist.broadcast(x, src=0)
+        r = self.lib.cmd_exec(cmd, nnc.NO_HINT, 0, [t], [t], stream)
+        if r != 0:
+            raise RuntimeError("collective failed: %d" % r)
+
+    def _signals(self, net, count):
+        return [self.lib.signal_new(net.device) for _ in range(count)]
+
+    def _order(self, first, then, signal):
+        """what is enqueued on `then` from here on runs behind what `first` holds now"""
+        self.lib.signal_emit(first, signal)
+        self.lib.signal_wait(then, signal)
 
     def broadcast_params(self, net, stream=None):
         """Replicas start from rank 0's weights (_ccv_cnnp_model_copy_tensors, ccv_cnnp_model.c:1451-1452)."""
@@ -70,9 +72,8 @@ class ProcessComm:
                 self._buckets.append((i, net.grad_arena.alias((hi - lo_off,), lo_off)))
                 hi = None
         self._comm_stream = comm_stream
-        if self.transport == "rccl":
-            self._sig_ready = [self.lib.signal_new(net.device) for _ in self._buckets]
-            self._sig_done = self.lib.signal_new(net.device)
+        sigs = self._signals(net, len(self._buckets) + 1)
+        self._sig_ready, self._sig_done = sigs[:-1], sigs[-1]
         self._next = 0
 
     def after_backward_node(self, net, i, stream):
@@ -81,20 +82,14 @@ class ProcessComm:
             trigger, t = self._buckets[self._next]
             if trigger != i:
                 break
-            if self.transport == "rccl":
-                self.lib.signal_emit(stream, self._sig_ready[self._next])
-                self.lib.signal_wait(self._comm_stream, self._sig_ready[self._next])
-                self._collective(self._allreduce, t, self._comm_stream, "sum")
-            else:
-                self._collective(self._allreduce, t, None, "sum")
+            self._order(stream, self._comm_stream, self._sig_ready[self._next])
+            self._collective(self._allreduce, t, self._comm_stream, "sum")
             self._next += 1
 
     def finish_overlap(self, stream):
         """every bucket issued; the compute stream (SGD) continues once the comm stream has drained them"""
         assert self._next == len(self._buckets), "backward did not reach every bucket"
-        if self.transport == "rccl":
-            self.lib.signal_emit(self._comm_stream, self._sig_done)
-            self.lib.signal_wait(stream, self._sig_done)
+        self._order(self._comm_stream, stream, self._sig_done)
         self._next = 0
 
     def allreduce_grads(self, net, stream=None):

@@ -78,7 +78,9 @@ hipStream_t neighbor_stream(ccv_nnc_stream_context_t* ctx, int device)
 // or MAX_PENDING records.  Back-to-back COMM nodes of a schedule (a layer's weight and bias, the tail of backward) thus
 // travel together; results and stream order are exactly those of immediate issue.
 struct pending_t { int op; const void* in; void* out; size_t count; ncclDataType_t dt; int root; ncclComm_t comm; hipStream_t stream; int device; };
-constexpr int MAX_PENDING = 256;
+// (round 4: 4 096 records -- ResNet-50's ~200 gradient tensors x 8 devices are 1 600 records when the host issues them back to back; with 256 the
+// queue forced seven mid-stream group launches per step, each under the process-wide mutex)
+constexpr int MAX_PENDING = 4096;
 pending_t g_pending[MAX_PENDING];
 int g_pending_n = 0;
 long g_stat_collectives = 0, g_stat_groups = 0;
@@ -133,35 +135,46 @@ int comm_exec(const int op, ccv_nnc_tensor_t* const* const inputs, const int inp
 	const int datatype = CCV_GET_DATA_TYPE(first->info.datatype);
 	if (datatype != CCV_32F && datatype != CCV_16F) return CCV_NNC_EXEC_INVALID;
 	const ncclDataType_t dt = datatype == CCV_16F ? ncclHalf : ncclFloat;
+	// Lock order: every stream this command needs is resolved BEFORE g_comm_mutex is taken.  stream_of() runs the
+	// look-ahead's hooks (peephole.cpp): it launches this stream's recorded command and WAITS for one another thread is still enqueueing
+	// (wait_launching).  That other thread -- a loader whose host-to-device copy flushed every slot -- is inside the recorded command's exec
+	// function, whose own stream_of() takes g_comm_mutex as soon as a collective is pending (comm_flush).  Waiting for it with the mutex held
+	// and one device's collective already recorded deadlocked the two.  tl_in_comm keeps these stream_of() calls from flushing the pending
+	// collectives (which would undo the coalescing); nothing below the lock calls back into the stream hooks.
 	tl_in_comm++;
-	pthread_mutex_lock(&g_comm_mutex);
 	int ret = CCV_NNC_EXEC_SUCCESS;
+	int device_count = 0;
+	hipStream_t streams[MAX_CLIQUE];
+	int devices[MAX_CLIQUE];
 	if (g_rank_comm) { // (b): one tensor per process
 		if (n != 1 || !comm_tensor_ok(inputs[0], count, datatype) || !comm_tensor_ok(outputs[0], count, datatype)) ret = CCV_NNC_EXEC_INVALID;
-		else record(op == OP_ALLREDUCE ? 0 : op == OP_BROADCAST ? 1 : 2, inputs[0]->data.u8, outputs[0]->data.u8, count, dt, 0, g_rank_comm, stream_of(ctx), -1);
+		else streams[0] = stream_of(ctx);
 	} else {
-		int device_count = 0;
+		if (n > MAX_CLIQUE) ret = CCV_NNC_EXEC_INVALID;
 		for (int i = 0; i < n && ret == CCV_NNC_EXEC_SUCCESS; i++) {
 			const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
 			if (!comm_tensor_ok(t, count, datatype)) ret = CCV_NNC_EXEC_INVALID;
 			else if (op == OP_ALLREDUCE && !comm_tensor_ok(inputs[i], count, datatype)) ret = CCV_NNC_EXEC_INVALID;
 			else {
-				const int d = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
-				if (d + 1 > device_count) device_count = d + 1;
+				devices[i] = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
+				if (devices[i] + 1 > device_count) device_count = devices[i] + 1;
 			}
 		}
 		if (device_count > MAX_CLIQUE) ret = CCV_NNC_EXEC_INVALID;
-		if (ret == CCV_NNC_EXEC_SUCCESS) {
-			const int root = op == OP_BROADCAST ? CCV_TENSOR_GET_DEVICE_ID(inputs[0]->info.type) : op == OP_REDUCE ? CCV_TENSOR_GET_DEVICE_ID(outputs[0]->info.type) : 0;
-			clique_t* const cl = clique_of(ctx, device_count);
-			for (int i = 0; i < n; i++) {
-				const ccv_nnc_tensor_t* t = op == OP_REDUCE ? inputs[i] : outputs[i];
-				const int d = CCV_TENSOR_GET_DEVICE_ID(t->info.type);
-				hipStream_t st = neighbor_stream(ctx, d);
-				if (op == OP_ALLREDUCE) record(0, inputs[i]->data.u8, outputs[i]->data.u8, count, dt, 0, cl->comm[d], st, d);
-				else if (op == OP_BROADCAST) record(1, inputs[0]->data.u8, outputs[i]->data.u8, count, dt, root, cl->comm[d], st, d);
-				else record(2, inputs[i]->data.u8, outputs[0]->data.u8, count, dt, root, cl->comm[d], st, d);
-			}
+		for (int i = 0; i < n && ret == CCV_NNC_EXEC_SUCCESS; i++) streams[i] = neighbor_stream(ctx, devices[i]);
+	}
+	if (ret != CCV_NNC_EXEC_SUCCESS) { tl_in_comm--; return ret; }
+	pthread_mutex_lock(&g_comm_mutex);
+	if (g_rank_comm)
+		record(op == OP_ALLREDUCE ? 0 : op == OP_BROADCAST ? 1 : 2, inputs[0]->data.u8, outputs[0]->data.u8, count, dt, 0, g_rank_comm, streams[0], -1);
+	else {
+		const int root = op == OP_BROADCAST ? CCV_TENSOR_GET_DEVICE_ID(inputs[0]->info.type) : op == OP_REDUCE ? CCV_TENSOR_GET_DEVICE_ID(outputs[0]->info.type) : 0;
+		clique_t* const cl = clique_of(ctx, device_count);
+		for (int i = 0; i < n; i++) {
+			const int d = devices[i];
+			if (op == OP_ALLREDUCE) record(0, inputs[i]->data.u8, outputs[i]->data.u8, count, dt, 0, cl->comm[d], streams[i], d);
+			else if (op == OP_BROADCAST) record(1, inputs[0]->data.u8, outputs[i]->data.u8, count, dt, root, cl->comm[d], streams[i], d);
+			else record(2, inputs[i]->data.u8, outputs[0]->data.u8, count, dt, root, cl->comm[d], streams[i], d);
 		}
 	}
 	pthread_mutex_unlock(&g_comm_mutex);

@@ -1312,7 +1312,7 @@ static int conv_forw_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, c
 static int _conv_forw_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	uint64_t sig;
-	if (const int e = deferred_take_error()) return e; // a recorded command failed when a flush launched it (peephole.cpp)
+	if (const int e = deferred_take_error(stream_context)) return e; // a recorded command failed when a flush launched it (peephole.cpp)
 	if (deferred_try(_conv_forw_any, DEFER_CONV_FORWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;
 	const int r = conv_forw_entry(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);
@@ -1341,7 +1341,7 @@ static int conv_back_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, c
 static int _conv_back_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	uint64_t sig; // (recorded like the forward: the RELU_BACKWARD of the map this command read may follow on the gradient it writes)
-	if (const int e = deferred_take_error()) return e; // a recorded command failed when a flush launched it (peephole.cpp)
+	if (const int e = deferred_take_error(stream_context)) return e; // a recorded command failed when a flush launched it (peephole.cpp)
 	if (deferred_try(_conv_back_any, DEFER_CONV_BACKWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;
 	const int r = conv_back_entry(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);

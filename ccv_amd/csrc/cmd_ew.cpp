@@ -252,7 +252,7 @@ static int _ewsum_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 {
 	// recorded when its like has run before: the in-place RELU_FORWARD behind a residual sum folds into the pass that writes the sum (peephole.cpp)
 	uint64_t sig;
-	if (const int e = deferred_take_error()) return e;
+	if (const int e = deferred_take_error(stream_context)) return e;
 	const bool floats = output_size >= 1 && outputs[0] && (CCV_GET_DATA_TYPE(outputs[0]->info.datatype) == CCV_32F || CCV_GET_DATA_TYPE(outputs[0]->info.datatype) == CCV_16F); // (no ReLU row for CCV_32S: nothing to wait for)
 	sig = 0;
 	if (floats && deferred_try(_ewsum_forw, DEFER_EWSUM_FORWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;

@@ -508,7 +508,7 @@ static int _bnorm_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 {
 	// recorded when its like has run before: the in-place RELU_FORWARD of the reference's conv - bn - relu blocks folds into the apply pass (peephole.cpp)
 	uint64_t sig;
-	if (const int e = deferred_take_error()) return e; // a recorded command failed when a flush launched it (peephole.cpp)
+	if (const int e = deferred_take_error(stream_context)) return e; // a recorded command failed when a flush launched it (peephole.cpp)
 	if (deferred_try(_bnorm_forw, DEFER_BNORM_FORWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;
 	const int r = bnorm_forw_entry(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);

@@ -437,7 +437,7 @@ static int _max_pool_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 static int _max_pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	uint64_t sig; // recorded: the RELU_BACKWARD of the pooled map may follow on the gradient this writes (peephole.cpp)
-	if (const int e = deferred_take_error()) return e; // a recorded command failed when a flush launched it (peephole.cpp)
+	if (const int e = deferred_take_error(stream_context)) return e; // a recorded command failed when a flush launched it (peephole.cpp)
 	if (deferred_try(_max_pool_back, DEFER_POOL_BACKWARD, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context, &sig)) return CCV_NNC_EXEC_SUCCESS;
 	const int r = pool_back<true>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);

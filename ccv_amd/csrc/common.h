@@ -112,7 +112,8 @@ void deferred_mark_good(uint64_t sig); // this signature ran successfully on the
 int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx); // -1: no recorded command this ReLU completes
 int deferred_fuse_relu_back(const ccv_nnc_tensor_t* g, const ccv_nnc_tensor_t* b, ccv_nnc_tensor_t* h, ccv_nnc_stream_context_t* ctx);
 void deferred_flush(const ccv_nnc_stream_context_t* ctx); // 0: every stream's
-int deferred_take_error(void); // a recorded command failed when a flush launched it: returned (once) by the next recordable command
+int deferred_take_error(const ccv_nnc_stream_context_t* ctx); // a recorded command of this stream failed when a flush launched it: returned (once) by the stream's next recordable command
+void deferred_suppress(int delta); // +1 / -1 around commands that must run on the spot (half_stage.cpp)
 static inline void comm_flush_if_pending(void) { if (g_comm_pending) comm_flush(); if (g_deferred_live) deferred_flush(0); }
 
 // The HIP stream a command must enqueue on, and that stream's scratch memory.

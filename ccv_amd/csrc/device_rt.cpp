@@ -2,6 +2,7 @@
 // Replaces lib/nnc/gpu/ccv_nnc_compat.cu:101-655 of the reference (CUDA runtime + cuBLAS/cuDNN handle pools);
 // here a stream context owns just a HIP stream and a grow-only workspace -- there are no vendor-library handles.
 #include "common.h"
+#include <atomic>
 #include <pthread.h>
 #include <dlfcn.h>
 #include <vector>
@@ -598,7 +599,12 @@ void nnc_mi355x_stream_signal_free(ccv_nnc_stream_signal_t* const signal)
 }
 
 // ---- pinned staging ring (include/nnc_mi355x.h: the host side of the GPU data pipeline) ------------------------------------------------
+// A slot goes FREE -> (host fills it) -> SUBMITTED -> ACQUIRED -> FREE.  The loader thread calls host / submit, the consumer thread acquire / release;
+// the slot's state is the ONE word they share (an atomic), and a call out of that order is refused (returns 0) instead of waiting on an event
+// nobody has recorded (acquire before submit) or overwriting a device buffer a kernel still reads (submit before release).  Every HIP call is made
+// with the ring's device current, whatever the calling thread's device was.
 namespace {
+enum { RING_FREE = 0, RING_SUBMITTED = 1, RING_ACQUIRED = 2 };
 struct staging_ring_t {
 	int device, slots;
 	size_t slot_bytes;
@@ -607,26 +613,31 @@ struct staging_ring_t {
 	void** dev;
 	hipEvent_t* copied;   // recorded on the copy stream behind a slot's host-to-device copy
 	hipEvent_t* consumed; // recorded on the consumer's stream behind its last kernel reading the slot's device buffer
-	char* copy_pending;   // a copy out of host[s] has been submitted and not yet waited for
-	char* consumed_set;
+	std::atomic<int>* state;        // RING_*
+	std::atomic<int>* copy_pending; // a copy out of host[s] has been submitted and not yet waited for (loader side)
+	std::atomic<int>* consumed_set; // consumed[s] has been recorded at least once
+};
+struct DeviceGuard { // the ring's device for the calls below, the caller's afterwards
+	int prev;
+	explicit DeviceGuard(const int device) : prev(current_device()) { if (prev != device) HIP_ENFORCE(hipSetDevice(device)); else prev = -1; }
+	~DeviceGuard() { if (prev >= 0) HIP_ENFORCE(hipSetDevice(prev)); }
 };
 }
 void* nnc_mi355x_staging_ring_new(int device, int slots, size_t slot_bytes)
 {
 	if (slots < 1 || slots > 64 || slot_bytes == 0) return 0;
-	const int prev = current_device();
-	HIP_ENFORCE(hipSetDevice(device));
+	DeviceGuard guard(device);
 	staging_ring_t* r = (staging_ring_t*)calloc(1, sizeof(staging_ring_t));
 	r->device = device; r->slots = slots; r->slot_bytes = slot_bytes;
 	r->host = (void**)calloc(slots, sizeof(void*)); r->dev = (void**)calloc(slots, sizeof(void*));
 	r->copied = (hipEvent_t*)calloc(slots, sizeof(hipEvent_t)); r->consumed = (hipEvent_t*)calloc(slots, sizeof(hipEvent_t));
-	r->copy_pending = (char*)calloc(slots, 1); r->consumed_set = (char*)calloc(slots, 1);
+	r->state = new std::atomic<int>[slots]; r->copy_pending = new std::atomic<int>[slots]; r->consumed_set = new std::atomic<int>[slots];
+	for (int i = 0; i < slots; i++) { r->state[i] = RING_FREE; r->copy_pending[i] = 0; r->consumed_set[i] = 0; }
 	bool ok = hipStreamCreate(&r->copy_stream) == hipSuccess; // a blocking stream like every stream of this library: orders against the legacy NULL stream
 	for (int i = 0; ok && i < slots; i++) {
 		ok = hipHostMalloc(&r->host[i], slot_bytes, hipHostMallocDefault) == hipSuccess && (r->dev[i] = nnc_mi355x_malloc(device, slot_bytes)) != 0
 			&& hipEventCreateWithFlags(&r->copied[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r->consumed[i], hipEventDisableTiming) == hipSuccess;
 	}
-	HIP_ENFORCE(hipSetDevice(prev));
 	if (!ok) { (void)hipGetLastError(); nnc_mi355x_staging_ring_free(r); return 0; }
 	return r;
 }
@@ -634,7 +645,11 @@ void* nnc_mi355x_staging_ring_host(void* ring, int slot)
 {
 	staging_ring_t* r = (staging_ring_t*)ring;
 	if (!r || slot < 0 || slot >= r->slots) return 0;
-	if (r->copy_pending[slot]) { HIP_ENFORCE(hipEventSynchronize(r->copied[slot])); r->copy_pending[slot] = 0; } // the pinned buffer is still being read by the copy
+	if (r->copy_pending[slot].load(std::memory_order_acquire)) { // the pinned buffer is still being read by the copy
+		DeviceGuard guard(r->device);
+		HIP_ENFORCE(hipEventSynchronize(r->copied[slot]));
+		r->copy_pending[slot].store(0, std::memory_order_release);
+	}
 	return r->host[slot];
 }
 void* nnc_mi355x_staging_ring_device(void* ring, int slot)
@@ -646,32 +661,45 @@ int nnc_mi355x_staging_ring_submit(void* ring, int slot, size_t bytes)
 {
 	staging_ring_t* r = (staging_ring_t*)ring;
 	if (!r || slot < 0 || slot >= r->slots || bytes > r->slot_bytes) return 0;
+	if (r->state[slot].load(std::memory_order_acquire) != RING_FREE) return 0; // the previous round of this slot has not been released: its device buffer may still be read
 	nnc::comm_flush_if_pending(); // (a copy is an order-observing point for recorded commands, like nnc_mi355x_memcpy)
-	if (r->consumed_set[slot]) HIP_ENFORCE(hipStreamWaitEvent(r->copy_stream, r->consumed[slot], 0)); // the device buffer's last reader, on the device
+	DeviceGuard guard(r->device);
+	if (r->consumed_set[slot].load(std::memory_order_acquire)) HIP_ENFORCE(hipStreamWaitEvent(r->copy_stream, r->consumed[slot], 0)); // the device buffer's last reader, on the device
 	HIP_ENFORCE(hipMemcpyAsync(r->dev[slot], r->host[slot], bytes, hipMemcpyHostToDevice, r->copy_stream));
 	HIP_ENFORCE(hipEventRecord(r->copied[slot], r->copy_stream));
-	r->copy_pending[slot] = 1;
+	r->copy_pending[slot].store(1, std::memory_order_release);
+	r->state[slot].store(RING_SUBMITTED, std::memory_order_release); // copied[slot] is recorded: an acquire may wait on it now
 	return 1;
 }
 int nnc_mi355x_staging_ring_acquire(void* ring, int slot, ccv_nnc_stream_context_t* const consumer)
 {
 	staging_ring_t* r = (staging_ring_t*)ring;
 	if (!r || slot < 0 || slot >= r->slots) return 0;
-	HIP_ENFORCE(hipStreamWaitEvent(nnc::stream_of(consumer), r->copied[slot], 0));
+	int expect = RING_SUBMITTED;
+	if (!r->state[slot].compare_exchange_strong(expect, RING_ACQUIRED, std::memory_order_acq_rel)) return 0; // nothing submitted: there is no copy to wait for
+	hipStream_t st = nnc::stream_of(consumer); // (binds the consumer's own device; the wait may name an event of another device)
+	HIP_ENFORCE(hipStreamWaitEvent(st, r->copied[slot], 0));
 	return 1;
 }
 int nnc_mi355x_staging_ring_release(void* ring, int slot, ccv_nnc_stream_context_t* const consumer)
 {
 	staging_ring_t* r = (staging_ring_t*)ring;
 	if (!r || slot < 0 || slot >= r->slots) return 0;
-	HIP_ENFORCE(hipEventRecord(r->consumed[slot], nnc::stream_of(consumer)));
-	r->consumed_set[slot] = 1;
+	if (r->state[slot].load(std::memory_order_acquire) != RING_ACQUIRED) return 0;
+	hipStream_t st = nnc::stream_of(consumer);
+	{
+		DeviceGuard guard(r->device); // consumed[slot] belongs to the ring's device, and so must the stream recording it
+		HIP_ENFORCE(hipEventRecord(r->consumed[slot], st));
+	}
+	r->consumed_set[slot].store(1, std::memory_order_release);
+	r->state[slot].store(RING_FREE, std::memory_order_release);
 	return 1;
 }
 void nnc_mi355x_staging_ring_free(void* ring)
 {
 	staging_ring_t* r = (staging_ring_t*)ring;
 	if (!r) return;
+	DeviceGuard guard(r->device);
 	if (r->copy_stream) { (void)hipStreamSynchronize(r->copy_stream); (void)hipStreamDestroy(r->copy_stream); }
 	for (int i = 0; i < r->slots; i++) {
 		if (r->host && r->host[i]) (void)hipHostFree(r->host[i]);
@@ -679,7 +707,8 @@ void nnc_mi355x_staging_ring_free(void* ring)
 		if (r->copied && r->copied[i]) (void)hipEventDestroy(r->copied[i]);
 		if (r->consumed && r->consumed[i]) (void)hipEventDestroy(r->consumed[i]);
 	}
-	free(r->host); free(r->dev); free(r->copied); free(r->consumed); free(r->copy_pending); free(r->consumed_set);
+	free(r->host); free(r->dev); free(r->copied); free(r->consumed);
+	delete[] r->state; delete[] r->copy_pending; delete[] r->consumed_set;
 	free(r);
 }
 

@@ -215,7 +215,9 @@ static inline bool buf_loader_h_ok(const MatLoader<KC, true>& l, const long z_of
 	if (l.R <= 0 || l.K <= 0 || (((uintptr_t)l.p) & 15)) return false;
 	if (zcount > 1 && (z_off & 7)) return false;
 	if (KC) return l.ldk == 1 && l.ldr > 0 && l.ldr % 8 == 0 && l.ldr * 256 * 2 + (long)l.K * 2 < 0x7fffffffL;
-	return l.ldr == 1 && l.ldk > 0 && l.ldk % 2 == 0 && ((long)l.K * l.ldk + l.R) * 2 < 0x7fffffffL;
+	// row-contiguous: the descriptor's range ends with element (R - 1, K - 1), and the raw buffer's range check is per DWORD -- with an odd R (a padded view,
+	// ldk > R) the dword holding that last element would straddle the range and read as zeros: the last k term of row R - 1 lost
+	return l.ldr == 1 && l.R % 2 == 0 && l.ldk > 0 && l.ldk % 2 == 0 && ((long)l.K * l.ldk + l.R) * 2 < 0x7fffffffL;
 }
 
 template <bool AKC, bool BKC, int TM, int TN, int WM, int WN, int BK>

@@ -331,11 +331,13 @@ int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_
 	};
 	for (int i = 0; i < input_size; i++) in_s[i] = make_shadow(inputs[i], i);
 	for (int i = 0; i < output_size; i++) out_s[i] = make_shadow(outputs[i], input_size + i);
+	// With staged tensors `inner` must run on the spot: its shadow tensors point into the arena and its outputs are converted back right below.  The look-ahead
+	// (peephole.cpp) would record a batch norm / convolution here; a recorded command launched by a flush has no caller to report a failure to, and this
+	// function went on to convert the never-written image down to half and return SUCCESS.  So: no recording underneath.
+	if (nst) deferred_suppress(1);
 	const int ret = inner(cmd, hint, flags, in_s, input_size, out_s, output_size, ctx);
+	if (nst) deferred_suppress(-1);
 	warn_refused(cmd.cmd, ret);
-	// `inner` may have been RECORDED by the look-ahead instead of launched (batch norm forward, peephole.cpp) with shadow tensors that point into
-	// the arena: it is launched now, before the images are converted back (or, with nothing to convert back, before the arena can be reused)
-	if (nst && g_deferred_live) deferred_flush(ctx);
 	if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
 	// per OUTPUT tensor, not per image: two views of one parent share an image and each writes its own elements
 	for (int i = 0; i < output_size; i++) {

@@ -57,7 +57,12 @@ constexpr int SLOTS = 16;
 Slot g_slots[SLOTS];
 std::recursive_mutex g_mu;
 std::condition_variable_any g_launched; // a LAUNCHING slot became FREE
-volatile int g_sticky_error = 0;        // a flushed command failed at launch: the next recordable command reports it
+// a flushed command failed at launch: the next recordable command ON THAT STREAM (context, device) reports it -- not whichever command of the process
+// comes next (a valid command on another stream or device used to be refused with somebody else's out-of-memory)
+struct StickyError { const ccv_nnc_stream_context_t* ctx; int device; int err; };
+constexpr int MAX_STICKY = 16;
+StickyError g_sticky[MAX_STICKY];
+volatile int g_sticky_live = 0;
 std::unordered_set<uint64_t> g_good;
 int g_enabled = -1;
 long g_recorded = 0, g_folded = 0, g_plain = 0; // nnc_mi355x_debug_peephole_counts
@@ -167,7 +172,14 @@ int run(Slot& s, const int relu_bit, Lock& lk, const bool report)
 	if (now != prev) HIP_ENFORCE(hipSetDevice(prev)); // (binding a fixed-device stream sets the device: the caller's stays what it was)
 	if (r != CCV_NNC_EXEC_SUCCESS) {
 		fprintf(stderr, "[nnc_mi355x] a recorded command (0x%x) failed at launch with %d after its caller was told it had been enqueued\n", c.cmd.cmd, r);
-		if (!report) g_sticky_error = r; // no caller to hand it to: the next recordable command returns it (deferred_take_error)
+		if (!report) { // no caller to hand it to: the next recordable command of this stream returns it (deferred_take_error)
+			int at = -1;
+			for (int i = 0; i < MAX_STICKY && at < 0; i++) if (g_sticky[i].err && g_sticky[i].ctx == c.ctx && g_sticky[i].device == c.device) at = i;
+			for (int i = 0; i < MAX_STICKY && at < 0; i++) if (!g_sticky[i].err) at = i;
+			if (at < 0) at = 0; // table full of unreported failures: the oldest gives way
+			if (!g_sticky[at].err) ++g_sticky_live;
+			g_sticky[at].ctx = c.ctx; g_sticky[at].device = c.device; g_sticky[at].err = r;
+		}
 	}
 	return r;
 }
@@ -284,14 +296,25 @@ void deferred_flush(const ccv_nnc_stream_context_t* const ctx)
 	wait_launching(ctx, lock); // what another thread is enqueueing right now is part of the order this caller is about to observe
 }
 
-int deferred_take_error(void)
+int deferred_take_error(const ccv_nnc_stream_context_t* const ctx)
 {
-	if (!g_sticky_error || tl_running) return 0;
+	if (!g_sticky_live || tl_running) return 0;
 	Lock lock(g_mu);
-	const int e = g_sticky_error;
-	g_sticky_error = 0;
-	return e;
+	const int device = device_for(ctx);
+	for (int i = 0; i < MAX_STICKY; i++)
+		if (g_sticky[i].err && g_sticky[i].ctx == ctx && g_sticky[i].device == device) {
+			const int e = g_sticky[i].err;
+			g_sticky[i].err = 0;
+			--g_sticky_live;
+			return e;
+		}
+	return 0;
 }
+
+// Commands run underneath while this is raised are never recorded (and their stream hooks leave the slots alone): half_stage.cpp runs a command on fp32
+// images that live in a staging arena and converts them back right behind it -- a recorded command there would have to be launched at once anyway, and a
+// failure of that launch had no caller to go to.
+void deferred_suppress(const int delta) { tl_running += delta; }
 
 } // namespace nnc
 

@@ -8,8 +8,8 @@ MAX_POOL_FORWARD, GEMM_FORWARD with TRANSPOSE(0,1) weights, in-place RELU_FORWAR
 what ccv_nnc_symbolic_graph_minimize derives for it: SOFTMAX_CROSSENTROPY, *_BACKWARD per node in reverse order, one
 SGD_FORWARD per parameter tensor (32 tensors, 111.09 M parameters).
 
-The driver is memory-agnostic: it runs on the MI355X backend (GPU tensors) for bench/smoke, and on the reference's own
-CPU backend (oracle/_ref, CPU tensors) for the end-to-end parity test and the cpu_baseline leg of bench.py.
+The driver only issues commands through the library object it is given; the checker's side of the parity tests (the same sequence
+on CPU tensors, with the per-image pooling the reference's CPU loops need) is a subclass under tests/ (tests/oracle_vgg.py).
 """
 import numpy as np
 from . import nnc
@@ -57,15 +57,13 @@ def hash_unit(n, stream):
 
 class VGGD:
     def __init__(self, lib, batch, memory=nnc.GPU_MEMORY, device=0, input_hw=225, layers=VGG_D, classes=None, seed=0, backend=None,
-                 sgd=(0, 0.001, None, 0.0005, 0.9, 0.9), train=True, init="numpy", pool_per_image=False, flat_grads=False, fuse_relu=False):
+                 sgd=(0, 0.001, None, 0.0005, 0.9, 0.9), train=True, init="numpy", flat_grads=False, fuse_relu=False):
         self.lib, self.batch, self.memory, self.device, self.backend = lib, batch, memory, device, backend
         # fuse_relu: the convolutions write max(0, .) themselves (NNC_MI355X_CONV_ALGO_FUSE_RELU, include/nnc_mi355x.h) and the in-place
         # RELU_FORWARD behind each of them is not issued -- this driver knows the ReLU is the convolution's only consumer; on the way back
         # the command that writes the gradient of a rectified map (convolution or max-pool backward, both read that map) masks it, and the
         # RELU_BACKWARD is not issued either.  Same numbers either way (tests/test_vgg_step.py).
         self.fuse_relu = fuse_relu
-        # The reference CPU pools only walk image 0 of a batch: when driving the oracle, issue them per image.
-        self.pool_per_image = pool_per_image
         self.conv_fwd_backend = None  # bench.py's CPU leg: route CONVOLUTION_FORWARD to another backend of the same library (CPU_OPT)
         self.layers = list(layers)
         self.train = train
@@ -208,12 +206,7 @@ class VGGD:
         return t.alias(d, i * int(np.prod(d)))
 
     def _pool(self, cmd, hint, ins, outs, stream, tag, hook):
-        if not self.pool_per_image:
-            return self._exec(cmd, hint, 0, ins, outs, stream, tag, hook)
-        for i in range(self.batch):
-            vi = [self._img(t, i) for t in ins]
-            vo = [self._img(t, i) for t in outs]
-            self._exec(cmd, hint, 0, vi, vo, stream, tag, hook)
+        return self._exec(cmd, hint, 0, ins, outs, stream, tag, hook)
 
     def forward(self, stream=None, hook=None):
         relu = nnc.CMD_RELU_FORWARD()

@@ -11,95 +11,170 @@ dim3 blockDim, gridDim;
 namespace emu {
 static const size_t kStack = 256 * 1024;
 struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = false; };
-static std::vector<Fiber> fibers;
+// Everything one resident workgroup owns.  The ordinary launch runs the grid's workgroups one after the other through ONE of these; launch_concurrent
+// (kernels whose workgroups talk to each other inside a launch: spin-waits on flags other workgroups of the grid publish) keeps a WINDOW of them
+// resident and interleaves their fibers.
+struct Block {
+	std::vector<Fiber> fibers;
+	int ndone = 0;
+	unsigned block_gen = 0, block_arrived = 0;
+	unsigned wave_gen[16] = {}, wave_arrived[16] = {}, wave_live[16] = {};
+	char xbufs[16][64][32];
+	std::vector<char> dyn;
+	uint3_emu bidx{0, 0, 0};
+	bool active = false;
+};
+static Block seq_block;
+static Block* cur = &seq_block;
 static ucontext_t main_ctx;
 static const std::function<void()>* cur_body = nullptr;
-static int cur_tid = 0, nthreads = 0, ndone = 0;
-static unsigned block_gen = 0, block_arrived = 0;
-static unsigned wave_gen[16], wave_arrived[16], wave_live[16];
+static int cur_tid = 0, nthreads = 0;
 static unsigned long progress = 0;
-static char xbufs[16][64][32];
-static std::vector<char> dyn;
 static bool in_kernel = false;
 
-static inline int live() { return nthreads - ndone; }
-static void check_block() { if (block_arrived > 0 && (int)block_arrived == live()) { block_arrived = 0; block_gen++; progress++; } }
-static void check_wave(int w) { if (wave_arrived[w] > 0 && wave_arrived[w] == wave_live[w]) { wave_arrived[w] = 0; wave_gen[w]++; progress++; } }
-static void yield() { const int t = cur_tid; swapcontext(&fibers[t].ctx, &main_ctx); }
+static inline int live() { return nthreads - cur->ndone; }
+static void check_block() { if (cur->block_arrived > 0 && (int)cur->block_arrived == live()) { cur->block_arrived = 0; cur->block_gen++; progress++; } }
+static void check_wave(int w) { if (cur->wave_arrived[w] > 0 && cur->wave_arrived[w] == cur->wave_live[w]) { cur->wave_arrived[w] = 0; cur->wave_gen[w]++; progress++; } }
+static void yield() { Block* const b = cur; const int t = cur_tid; swapcontext(&b->fibers[t].ctx, &main_ctx); }
 static void entry()
 {
 	(*cur_body)();
+	Block* const b = cur;
 	const int t = cur_tid;
-	fibers[t].done = true;
-	ndone++;
-	wave_live[t / 64]--;
+	b->fibers[t].done = true;
+	b->ndone++;
+	b->wave_live[t / 64]--;
 	progress++;
 	check_block();
 	check_wave(t / 64);
-	swapcontext(&fibers[t].ctx, &main_ctx);
+	swapcontext(&b->fibers[t].ctx, &main_ctx);
 }
 void syncthreads()
 {
-	const unsigned g = block_gen;
-	block_arrived++;
+	Block* const b = cur; // (a fiber stays in its block: `cur` is that block again whenever this fiber runs)
+	const unsigned g = b->block_gen;
+	b->block_arrived++;
 	check_block();
-	while (block_gen == g) yield();
+	while (b->block_gen == g) yield();
 }
 void wave_sync()
 {
+	Block* const b = cur;
 	const int w = cur_tid / 64;
-	const unsigned g = wave_gen[w];
-	wave_arrived[w]++;
+	const unsigned g = b->wave_gen[w];
+	b->wave_arrived[w]++;
 	check_wave(w);
-	while (wave_gen[w] == g) yield();
+	while (b->wave_gen[w] == g) yield();
 }
+void spin_yield() { yield(); } // a polling loop's s_sleep: let the other resident workgroups run (no progress of its own)
 int lane() { return cur_tid % 64; }
 int wave() { return cur_tid / 64; }
 int wave_width() { const int w = cur_tid / 64; return std::min(64, nthreads - w * 64); }
-void* xbuf(int l) { return xbufs[cur_tid / 64][l]; }
-void* dyn_smem() { return dyn.data(); }
+void* xbuf(int l) { return cur->xbufs[cur_tid / 64][l]; }
+void* dyn_smem() { return cur->dyn.data(); }
 
-void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body)
+static void block_prepare(Block& b, const int n, const size_t shmem, const uint3_emu bidx)
+{
+	if ((int)b.fibers.size() < n) b.fibers.resize(n);
+	for (int t = 0; t < n; t++)
+		if (!b.fibers[t].stack) {
+			b.fibers[t].stack = (char*)mmap(0, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+			if (b.fibers[t].stack == (char*)MAP_FAILED) { perror("mmap"); abort(); }
+		}
+	b.dyn.assign(shmem + 64, 0);
+	b.bidx = bidx;
+	b.ndone = 0; b.block_arrived = 0;
+	for (int w = 0; w < 16; w++) { b.wave_arrived[w] = 0; b.wave_live[w] = (unsigned)std::max(0, std::min(64, n - w * 64)); }
+	for (int t = 0; t < n; t++) {
+		b.fibers[t].done = false;
+		getcontext(&b.fibers[t].ctx);
+		b.fibers[t].ctx.uc_stack.ss_sp = b.fibers[t].stack;
+		b.fibers[t].ctx.uc_stack.ss_size = kStack;
+		b.fibers[t].ctx.uc_link = &main_ctx;
+		makecontext(&b.fibers[t].ctx, (void (*)())entry, 0);
+	}
+	b.active = true;
+}
+// one sweep: every unfinished fiber of the block runs until its next rendezvous
+static void block_sweep(Block& b, const int n, const dim3 block)
+{
+	cur = &b;
+	blockIdx = b.bidx;
+	for (int t = 0; t < n; t++) {
+		if (b.fibers[t].done) continue;
+		cur_tid = t;
+		threadIdx = uint3_emu{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
+		swapcontext(&main_ctx, &b.fibers[t].ctx);
+	}
+}
+static int launch_begin(dim3 grid, dim3 block, const std::function<void()>& body)
 {
 	if (in_kernel) { fprintf(stderr, "emu: nested launch\n"); abort(); }
 	const int n = (int)(block.x * block.y * block.z);
 	if (n <= 0 || n > 1024) { fprintf(stderr, "emu: bad block size %d\n", n); abort(); }
-	if ((size_t)grid.x * grid.y * grid.z == 0) return;
-	if ((int)fibers.size() < n) fibers.resize(n);
-	for (int t = 0; t < n; t++)
-		if (!fibers[t].stack) {
-			fibers[t].stack = (char*)mmap(0, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-			if (fibers[t].stack == (char*)MAP_FAILED) { perror("mmap"); abort(); }
-		}
-	dyn.assign(shmem + 64, 0);
 	in_kernel = true;
 	cur_body = &body;
 	blockDim = block; gridDim = grid; nthreads = n;
+	return n;
+}
+
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body)
+{
+	if ((size_t)grid.x * grid.y * grid.z == 0) return;
+	const int n = launch_begin(grid, block, body);
 	for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
-		blockIdx = uint3_emu{bx, by, bz};
-		ndone = 0; block_arrived = 0;
-		for (int w = 0; w < 16; w++) { wave_arrived[w] = 0; wave_live[w] = (unsigned)std::max(0, std::min(64, n - w * 64)); }
-		for (int t = 0; t < n; t++) {
-			fibers[t].done = false;
-			getcontext(&fibers[t].ctx);
-			fibers[t].ctx.uc_stack.ss_sp = fibers[t].stack;
-			fibers[t].ctx.uc_stack.ss_size = kStack;
-			fibers[t].ctx.uc_link = &main_ctx;
-			makecontext(&fibers[t].ctx, (void (*)())entry, 0);
-		}
+		block_prepare(seq_block, n, shmem, uint3_emu{bx, by, bz});
 		int stale = 0;
-		while (ndone < n) {
+		while (seq_block.ndone < n) {
 			const unsigned long before = progress;
-			for (int t = 0; t < n; t++) {
-				if (fibers[t].done) continue;
-				cur_tid = t;
-				threadIdx = uint3_emu{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
-				swapcontext(&main_ctx, &fibers[t].ctx);
-			}
-			if (progress == before) { if (++stale > 2) { fprintf(stderr, "emu: deadlock in block (%u,%u,%u): divergent barrier or wave op (%d/%d threads done)\n", bx, by, bz, ndone, n); abort(); } }
+			block_sweep(seq_block, n, block);
+			if (progress == before) { if (++stale > 2) { fprintf(stderr, "emu: deadlock in block (%u,%u,%u): divergent barrier or wave op (%d/%d threads done)\n", bx, by, bz, seq_block.ndone, n); abort(); } }
 			else stale = 0;
 		}
 	}
+	cur = &seq_block;
+	in_kernel = false;
+}
+
+// Workgroups that wait for each other inside a launch.  A window of workgroups is resident at a time (NNC_EMU_RESIDENT_BLOCKS, default 8); a finished
+// one is replaced by the next of the dispatch order -- forward by default, NNC_EMU_DISPATCH_ORDER=reverse / shuffle to show that a kernel's protocol does not
+// depend on it (HIP promises no dispatch order).  Such kernels keep their LDS in the dynamic region: `__shared__` statics are ONE object in this emulator.
+void launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body)
+{
+	const size_t total = (size_t)grid.x * grid.y * grid.z;
+	if (total == 0) return;
+	const int n = launch_begin(grid, block, body);
+	static std::vector<Block*> window;
+	const char* const we = getenv("NNC_EMU_RESIDENT_BLOCKS");
+	size_t resident = we ? (size_t)atol(we) : 8;
+	if (resident < 1) resident = 1;
+	if (resident > total) resident = total;
+	while (window.size() < resident) window.push_back(new Block);
+	std::vector<size_t> order(total);
+	for (size_t i = 0; i < total; i++) order[i] = i;
+	const char* const oe = getenv("NNC_EMU_DISPATCH_ORDER");
+	if (oe && !strcmp(oe, "reverse")) std::reverse(order.begin(), order.end());
+	else if (oe && !strcmp(oe, "shuffle")) { unsigned long long st = 0x9e3779b97f4a7c15ULL; for (size_t i = total; i > 1; i--) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; std::swap(order[i - 1], order[(st >> 33) % i]); } }
+	size_t next = 0, finished = 0;
+	for (size_t i = 0; i < resident; i++) window[i]->active = false;
+	int stale = 0;
+	while (finished < total) {
+		const unsigned long before = progress;
+		for (size_t i = 0; i < resident; i++) {
+			Block& b = *window[i];
+			if (!b.active) {
+				if (next >= total) continue;
+				const size_t id = order[next++];
+				block_prepare(b, n, shmem, uint3_emu{(unsigned)(id % grid.x), (unsigned)((id / grid.x) % grid.y), (unsigned)(id / ((size_t)grid.x * grid.y))});
+				progress++;
+			}
+			block_sweep(b, n, block);
+			if (b.ndone == n) { b.active = false; finished++; }
+		}
+		if (progress == before) { if (++stale > 64) { fprintf(stderr, "emu: deadlock in a concurrent launch: %zu of %zu workgroups finished, %zu resident, none makes progress\n", finished, total, resident); abort(); } }
+		else stale = 0;
+	}
+	cur = &seq_block;
 	in_kernel = false;
 }
 } // namespace emu

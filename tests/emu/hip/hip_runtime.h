@@ -56,6 +56,8 @@ struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcess
 
 namespace emu {
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body); // workgroups that wait for each other: a window of them resident
+void spin_yield(); // inside a polling loop
 void syncthreads();
 void wave_sync();
 int lane();
@@ -69,6 +71,12 @@ template <typename K, typename... Args>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args)
 {
 	emu::launch(grid, block, shmem, [&]() { kernel(args...); });
+}
+
+template <typename K, typename... Args>
+static inline void emuLaunchConcurrentKernel(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args)
+{
+	emu::launch_concurrent(grid, block, shmem, [&]() { kernel(args...); });
 }
 
 static inline void __syncthreads() { asm volatile("" ::: "memory"); emu::syncthreads(); asm volatile("" ::: "memory"); }

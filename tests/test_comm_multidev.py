@@ -113,3 +113,56 @@ def test_comm_half_precision_rows(emu_lib):
     so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
     r = subprocess.run([sys.executable, "-c", SCRIPT_HALF % (ROOT, so)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+LOCK_ORDER_SCRIPT = textwrap.dedent("""
+    import ctypes as C, sys, threading, time, numpy as np
+    sys.path.insert(0, %r)
+    from ccv_amd import nnc
+    L = nnc.load(%r)
+    assert L.device_count() >= 2
+    rng = np.random.default_rng(5)
+    F = nnc.CCV_32F
+    def on(dev, arr):
+        return L.tensor(nnc.GPU_TENSOR_NHWC(dev, F, *arr.shape), arr)
+    n, h, w, c, k = 2, 9, 10, 16, 32
+    a = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((k, 3, 3, c)) / (9 * c)).astype(np.float32)
+    b = (0.05 * rng.standard_normal(k)).astype(np.float32)
+    s1 = L.stream_new(1)                         # the stream of device 1
+    ins = [on(1, a), on(1, wt), on(1, b)]
+    out = on(1, np.zeros((n, h, w, k), np.float32))
+    cmd, hint = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c), nnc.HINT((1, 1), (1, 1))
+    assert L.cmd_exec(cmd, hint, 0, ins, [out], s1) == 0     # first occurrence: on the spot
+    L.stream_wait(s1)
+    want = out.numpy().copy()
+    x = [rng.standard_normal(1000).astype(np.float32) for _ in range(2)]
+    for trip in range(3):
+        out2 = on(1, np.full((n, h, w, k), -9, np.float32))
+        t = [on(d, x[d]) for d in range(2)]
+        assert L.cmd_exec(cmd, hint, 0, ins, [out2], s1) == 0   # recorded on s1 (look-ahead)
+        L.dll.nnc_mi355x_debug_peephole_launch_delay_us(300000)
+        loader = threading.Thread(target=lambda: on(0, np.zeros(16, np.float32)))   # a host-to-device copy: launches every recorded command
+        loader.start()
+        time.sleep(0.1)                                          # the loader sits inside the launch window of s1's convolution
+        # device 0's collective is recorded first (its stream is not s1), then device 1's stream has to be resolved: that waits for the
+        # loader's launch, whose own stream_of() wants the collectives' mutex as soon as one is pending
+        assert L.cmd_exec(nnc.generic_cmd("COMM_ALLREDUCE_FORWARD"), nnc.NO_HINT, 0, t, t, s1) == 0
+        loader.join()
+        L.dll.nnc_mi355x_debug_peephole_launch_delay_us(0)
+        L.stream_wait(s1); L.stream_wait(None)
+        np.testing.assert_array_equal(out2.numpy(), want)
+        for d in range(2):
+            np.testing.assert_allclose(t[d].numpy(), x[0].astype(np.float64) + x[1], rtol=1e-6, atol=1e-6)
+    L.stream_free(s1)
+    print("OK")
+""")
+
+
+def test_comm_command_while_a_foreign_thread_launches_this_streams_recorded_command(emu_lib):
+    # ADVICE round 3: comm_exec resolved its streams with g_comm_mutex held -- stream_of() waits for a recorded command another thread is enqueueing
+    # (peephole.cpp wait_launching) while that thread's launch waits for the mutex to flush the collective already recorded: a deadlock.
+    env = dict(os.environ, NNC_EMU_DEVICE_COUNT="4")
+    so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    r = subprocess.run([sys.executable, "-c", LOCK_ORDER_SCRIPT % (ROOT, so)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

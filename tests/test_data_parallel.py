@@ -1,7 +1,8 @@
 """N > 1 path on CPU: world_size-2 gloo processes, each running its shard of the minibatch through the command
 interface, exchanging the flat gradient arena, applying SGD -- must equal the single-process run on the whole minibatch
 (the reference's own criterion: DP(2 x 16) == single(32), test/int/nnc/parallel.tests.c:192-369).
-Compute here is the oracle (CPU tensors); the GPU form of the same logic is ccv_amd/comm.py transport="rccl"."""
+Compute here is the oracle (CPU tensors) and the transport gloo (tests/gloo_comm.py: ccv_amd/comm.py with its transport hooks replaced);
+the product form of the same logic is ccv_amd/comm.py on RCCL."""
 import os
 import subprocess
 import sys
@@ -17,16 +18,16 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests")
 import numpy as np
 import torch.distributed as dist
 from ccv_amd import nnc
-from ccv_amd.vgg import VGGD
-from ccv_amd.comm import ProcessComm
+from oracle_vgg import make_vggd
+from gloo_comm import GlooProcessComm
 from oracle_bind import oracle_lib
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 O, backend, per_image = oracle_lib()
 B = 4
-net = VGGD(O, B // world, memory=nnc.CPU_MEMORY, input_hw=19, layers=%(layers)r, seed=3 + rank, backend=backend, pool_per_image=per_image,
+net = make_vggd(O, B // world, memory=nnc.CPU_MEMORY, input_hw=19, layers=%(layers)r, seed=3 + rank, backend=backend, pool_per_image=per_image,
            flat_grads=True, sgd=(0, 0.01, 1.0 / B, 0.0005, 0.9, 0.9))
-comm = ProcessComm(O, dist, rank, world, transport="gloo")
+comm = GlooProcessComm(O, dist, rank, world)
 comm.broadcast_params(net)   # rank 1 was seeded differently on purpose
 comm.plan_overlap(net, None, bucket_bytes=2048)   # several buckets even on this tiny net
 assert len(comm._buckets) >= 2
@@ -48,7 +49,7 @@ dist.barrier(); dist.destroy_process_group()
 
 
 def test_dp2_equals_single(ref_lib, tmp_path):
-    from ccv_amd.vgg import VGGD
+    from oracle_vgg import make_vggd
     from oracle_bind import oracle_lib
     script = tmp_path / "worker.py"
     script.write_text(WORKER % dict(root=ROOT, layers=MINI))
@@ -60,7 +61,7 @@ def test_dp2_equals_single(ref_lib, tmp_path):
     dp = np.load(out)
     O, backend, per_image = oracle_lib()
     B = 4
-    net = VGGD(O, B, memory=nnc.CPU_MEMORY, input_hw=19, layers=MINI, seed=3, backend=backend, pool_per_image=per_image, sgd=(0, 0.01, 1.0 / B, 0.0005, 0.9, 0.9))
+    net = make_vggd(O, B, memory=nnc.CPU_MEMORY, input_hw=19, layers=MINI, seed=3, backend=backend, pool_per_image=per_image, sgd=(0, 0.01, 1.0 / B, 0.0005, 0.9, 0.9))
     rng = np.random.default_rng(11)
     for step in range(2):
         x, y = rng.random((B, 19, 19, 3), dtype=np.float32), rng.integers(0, 10, B)

@@ -170,7 +170,8 @@ def test_vgg_d_full_step_n2_vs_cpu_ref(gpu_lib, ref_lib):
     gpu_lib.stream_wait(None)
     net.forward()
     gpu_lib.stream_wait(None)
-    ref = VGGD(ref_lib, 2, memory=nnc.CPU_MEMORY, seed=0, backend=nnc.BACKEND_CPU_REF, pool_per_image=True)
+    from oracle_vgg import OracleVGGD
+    ref = OracleVGGD(ref_lib, 2, memory=nnc.CPU_MEMORY, seed=0, backend=nnc.BACKEND_CPU_REF)
     ref.set_input(x, y)
     ref.forward()
     np.testing.assert_allclose(net.loss.numpy(), ref.loss.numpy(), rtol=1e-4, atol=0)

@@ -16,7 +16,7 @@ class _SoloDist:
 @pytest.fixture(scope="module")
 def solo_comm(gpu_lib):
     # one process communicator per process (nnc_mi355x_comm_init_rank refuses a second one), as in a real rank
-    return ProcessComm(gpu_lib, _SoloDist(), 0, 1, transport="rccl")
+    return ProcessComm(gpu_lib, _SoloDist(), 0, 1)
 
 
 @pytest.mark.gpu

@@ -9,7 +9,8 @@ MINI = [("conv", 8), ("conv", 8), ("pool",), ("conv", 16), ("conv", 16), ("pool"
 
 
 def _run(lib, memory, backend, batch, hw, layers, pool_per_image, steps=2, fuse_relu=False):
-    net = VGGD(lib, batch, memory=memory, input_hw=hw, layers=layers, seed=1, backend=backend, pool_per_image=pool_per_image, fuse_relu=fuse_relu)
+    from oracle_vgg import make_vggd
+    net = make_vggd(lib, batch, memory=memory, input_hw=hw, layers=layers, seed=1, backend=backend, pool_per_image=pool_per_image, fuse_relu=fuse_relu)
     rng = np.random.default_rng(5)
     out = []
     for s in range(steps):

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from ccv_amd import nnc
-from ccv_amd.vgg import VGGD
+from oracle_vgg import make_vggd
 from oracle_bind import oracle_lib
 
 L = nnc.load()
@@ -15,7 +15,7 @@ for trial in range(2):
     x, y = rng.random((4, 33, 33, 3), dtype=np.float32), rng.integers(0, 10, 4)
     snaps = {}
     def run(lib, mem, be, ppi, key):
-        net = VGGD(lib, 4, memory=mem, input_hw=33, layers=mini, seed=2 + trial, backend=be, pool_per_image=ppi)
+        net = make_vggd(lib, 4, memory=mem, input_hw=33, layers=mini, seed=2 + trial, backend=be, pool_per_image=ppi)
         net.set_input(x, y)
         if mem == nnc.GPU_MEMORY: lib.stream_wait(None)
         n3, n4 = net.nodes[3], net.nodes[4]

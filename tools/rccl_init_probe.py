@@ -5,4 +5,4 @@ from ccv_amd.comm import ProcessComm
 class Solo:
     def broadcast_object_list(self, objs, src=0): return None
 L = nnc.load()
-t0 = time.time(); comm = ProcessComm(L, Solo(), 0, 1, transport="rccl"); print("comm init %.2f s  env=%s" % (time.time() - t0, {k: v for k, v in os.environ.items() if k.startswith("NCCL") or k.startswith("RCCL")}), flush=True)
+t0 = time.time(); comm = ProcessComm(L, Solo(), 0, 1); print("comm init %.2f s  env=%s" % (time.time() - t0, {k: v for k, v in os.environ.items() if k.startswith("NCCL") or k.startswith("RCCL")}), flush=True)

@@ -14,7 +14,7 @@ class Solo:
 
 
 L = nnc.load()
-t0 = time.time(); comm = ProcessComm(L, Solo(), 0, 1, transport="rccl"); print("comm init %.2f s" % (time.time() - t0), flush=True)
+t0 = time.time(); comm = ProcessComm(L, Solo(), 0, 1); print("comm init %.2f s" % (time.time() - t0), flush=True)
 s, cs = L.stream_new(0), L.stream_new(0)
 for n in (1 << 10, 1 << 20, 100 << 20):
     t = L.tensor(nnc.GPU_TENSOR_NHWC(0, nnc.CCV_32F, n))
