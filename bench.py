@@ -149,7 +149,53 @@ def resnet_config(args, half, dawn=False):
         allf = sum(k["flops"] for k in f16k) / (sum(k["ms"] for k in f16k) * 1e-3) / 1e12
         out["roofline_f16_contractions"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "kernel": top["name"][-100:],
                                             "launches": top["launches"], "avg_ms": top["ms"] / top["launches"], "all_f16_contractions": {"achieved": allf, "ms": sum(k["ms"] for k in f16k)}}
+    # one host thread enqueues for every device of the reference's single-process data parallelism (lib/nnc/ccv_nnc_graph_run.c:581-675): N x the
+    # enqueue time of a step must stay under the GPU time of a step for the N-device form to scale
+    he = h.get("host_enqueue")
+    if he and he.get("commands_per_step"):
+        out["config"]["host_enqueue"] = dict(he, devices_one_thread_can_feed=h["ms_per_step"] / he["ms_per_step_median"] if he["ms_per_step_median"] > 0 else None,
+                                             note="wall time of the step call on drained streams, one host thread, one device; the step's GPU time / this = how many devices that thread keeps busy")
+    if not args.no_cpu_baseline and devices == 1:
+        out["cpu_baseline"], out["config"]["oracle_gate"] = host_cpu_baseline(args, half, dawn)
     emit(out)
+
+
+def host_cpu_baseline(args, half, dawn):
+    """configs 4 / 5 next to the reference's own CPU path on this box's host cores: the SAME harness built against the reference's
+    CPU backend (oracle/_ref/host_resnet_bench.cpu: the reference's unmodified host, its CPU_REF rows, every tensor in CPU memory, fp32) -- timed on a
+    bounded sample (2 images of ResNet-50 / 16 of the DawnNet per step, one warm-up + two timed steps), and, with HOST_BENCH_CHECK=1, both builds run ONE
+    step from identical parameters: the per-image losses of this backend against the CPU's are the line's oracle gate (tests/test_via_host.py holds the
+    parameters and steps too)."""
+    import subprocess
+    cpu = os.path.join(ROOT, "oracle", "_ref", "host_resnet_bench.cpu")
+    gpu = os.path.join(ROOT, "oracle", "_ref", "host_resnet_bench.gpu")
+    if not os.path.exists(cpu):
+        return None, None
+    n = 16 if dawn else 2
+    tail = ["dawn"] if dawn else ["full"]
+    hw = "32" if dawn else "224"
+    base = gate = None
+    try:
+        r = subprocess.run([cpu, str(n), hw, "2", "1", "32"] + tail, capture_output=True, text=True, timeout=900)
+        if r.returncode == 0:
+            c = json.loads(r.stdout.strip().splitlines()[-1])
+            base = {"value": c["images_per_s"], "unit": "images/s", "cores": os.cpu_count(), "kind": "reference",
+                    "sample": "%s forward + backward + SGD on %d images per step (fp32, the reference host on its CPU_REF rows, OpenMP over the host's hardware threads, no BLAS in the image), one warm-up + two timed steps: %.1f ms per step" % ("DawnNet" if dawn else "ResNet-50 v1d 224 x 224", n, c["ms_per_step"])}
+        env = dict(os.environ, HOST_BENCH_CHECK="1")
+        rc = subprocess.run([cpu, str(n), hw, "0", "1", "32"] + tail, capture_output=True, text=True, timeout=900, env=env)
+        rg = subprocess.run([gpu, str(n), hw, "0", "1", "16" if half else "32"] + tail, capture_output=True, text=True, timeout=900, env=env)
+        if rc.returncode == 0 and rg.returncode == 0:
+            want = json.loads(rc.stdout.strip().splitlines()[-1])["check"]
+            got = json.loads(rg.stdout.strip().splitlines()[-1])["check"]
+            rel = max(abs(a - b) / max(abs(b), 1e-30) for a, b in zip(got["loss"], want["loss"]))
+            tol = 5e-3 if half else 1e-4
+            gate = {"step1_loss_per_image_max_rel_err": rel, "tolerance": tol, "ok": bool(rel <= tol), "images": n, "loss_image0": {"gpu": got["loss"][0], "cpu_ref": want["loss"][0]},
+                    "out_sumsq_rel_err": abs(got["out_sumsq"] - want["out_sumsq"]) / want["out_sumsq"]}
+            if not gate["ok"]:
+                raise SystemExit("bench.py: step-1 losses differ from the reference host's CPU step by %.3g (> %.1g)" % (rel, tol))
+    except subprocess.TimeoutExpired:
+        pass
+    return base, gate
 
 
 def pmc_traffic(symbol, batch):

@@ -9,6 +9,7 @@
 // outer = N, inner = H*W).  Per-channel reductions run in two deterministic stages (slice partials in the stream
 // workspace, fixed-order fold), wavefront-coalesced in whichever of C / inner is contiguous.
 #include "common.h"
+#include "isa.h"
 
 using namespace nnc;
 
@@ -387,6 +388,276 @@ __global__ void __launch_bounds__(256) bn_back_planes_kernel(const T* __restrict
 	}
 }
 
+// ---- cluster kernels (round 4): x read ONCE -------------------------------------------------------------------------------------------------------
+// Training-mode batch norm needs every element of a channel twice -- for the statistics, then to be normalised -- and the plane kernels above read x from
+// HBM both times (forward 3 |x| of traffic for 2 |x| of algorithm, backward 5 for 3): at batch 256 a ResNet channel is 0.2 - 13 MB, the tensor 0.1 - 0.8 GB,
+// nothing the caches hold between two kernels.  Here a CLUSTER of G workgroups owns one channel and keeps it ON CHIP between the two uses: every workgroup
+// loads its contiguous share of the channel's 16-byte chunks into registers (NV per thread, all loads issued before the first use), reduces it, publishes its
+// partial sums, picks up its siblings', folds them in a fixed order -- every workgroup of the cluster arrives at bit-identical statistics -- and normalises
+// out of the registers.  The register files of 256 CUs hold ~100 MB: the tensor passes through in a few waves of clusters.
+//   * Statistics: per workgroup the sum, then the centred second moment about the WORKGROUP's mean (from registers: exact two-pass form), combined over
+//     the cluster with Chan et al.'s fold -- the plane kernels' scheme with "workgroup share" in place of "plane".
+//   * The hand-over is placement- and order-independent (MI355X guide, inter-workgroup visibility): a workgroup's place in the grid is a TICKET it draws
+//     from an agent-scope counter when it starts, so the workgroups holding tickets below any resident one are resident or finished -- a cluster can only
+//     be waiting for siblings that are running or about to be dispatched, whatever order the dispatcher chose; the only requirement is that G workgroups
+//     fit on the chip at once next to whatever else runs (G <= BN_CLUSTER_MAX_G of >= 1024 slots).  Partials travel as 8-byte {epoch, value} granules,
+//     one agent-scope store each, polled by one wave with agent-scope loads + s_sleep; no fences (the data is the flag).  Polls are bounded
+//     (CLUSTER_SPIN_LIMIT): a workgroup that gives up raises the timeout word and the next synchronise stops the process.
+//   * The last workgroup to finish puts the ticket and done counters back to zero for the stream's next launch.
+constexpr int BN_CLUSTER_NV = 24;      // 16-byte chunks a thread holds (forward; backward holds half as many of x and of g): 80 VGPRs of data + 20 of offsets, 4 workgroups per CU
+constexpr int BN_CLUSTER_MAX_G = 320;  // workgroups per cluster the host will ask for
+static long g_bn_cluster_launches = 0; // nnc_mi355x_debug_bn_cluster_launches(): tests assert which kernels ran
+constexpr int BN_CLUSTER_LDS = (8 + 2 * BN_CLUSTER_MAX_G + 8) * (int)sizeof(float);
+struct bn_cluster_geom_t {
+	int C;
+	long inner;       // elements per plane
+	unsigned nv;      // 16-byte chunks per plane
+	unsigned magic;   // floor(2^32 / nv) + 1: q / nv == __umulhi(q, magic) for every chunk index q of a channel (host checks Q * nv < 2^32)
+	unsigned Q;       // chunks per channel = outer * nv
+	unsigned per;     // chunks per workgroup
+	unsigned G;       // workgroups per channel
+	unsigned grid;    // C * G
+	unsigned bytes;   // of the whole tensor (< 4 GB: every chunk is a 32-bit byte offset against a raw-buffer descriptor based at the channel's first plane)
+	unsigned image_bytes; // C * inner * sizeof(T)
+};
+typedef unsigned int bn_u4 __attribute__((ext_vector_type(4)));
+// sum over the workgroup's 256 threads, the same value in every thread (fixed order: butterfly inside a wave, then the four waves)
+__device__ __forceinline__ float cluster_block_sum(float v, float* const red)
+{
+	v = wave_sum(v);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+	__syncthreads();
+	const float r = (red[0] + red[1]) + (red[2] + red[3]);
+	__syncthreads();
+	return r;
+}
+// wave 0 collects the cluster's NP partials per workgroup into part[w * NP + k]; false = gave up
+template <int NP>
+__device__ __forceinline__ void cluster_collect(const unsigned long long* const slots, const unsigned G, const unsigned epoch, float* const part, unsigned* const timeout_word)
+{
+	const int lane = threadIdx.x & 63;
+	const unsigned total = G * NP;
+	for (unsigned base = 0; base < total; base += 64) { // (wave-uniform trip count)
+		const unsigned idx = base + lane;
+		unsigned spins = 0;
+		for (;;) {
+			unsigned long long gr = ((unsigned long long)epoch << 32);
+			if (idx < total) gr = nnc_load_granule(slots + idx);
+			const int ok = (unsigned)(gr >> 32) == epoch;
+			if (ok && idx < total) part[idx] = __uint_as_float((unsigned)gr);
+			int pending = ok ? 0 : 1;
+			for (int off = 32; off > 0; off >>= 1) pending += __shfl_xor(pending, off, 64);
+			if (!pending) break;
+			if (++spins > CLUSTER_SPIN_LIMIT) { if (lane == 0) nnc_store_agent(timeout_word, 0xb0000000u | NP); break; }
+			NNC_SPIN_SLEEP();
+		}
+	}
+}
+// chunk q of a channel -> byte offset from the channel's first plane (image n = q / nv, chunk i = q % nv of its plane); q >= q1 -> out of the descriptor's
+// range: the load returns zeros, the store is dropped (no branch around either)
+__device__ __forceinline__ unsigned cluster_chunk_voff(const bn_cluster_geom_t& g, const unsigned q, const unsigned q1)
+{
+	const unsigned n = __umulhi(q, g.magic);
+	const unsigned i = q - n * g.nv;
+	return (n * g.image_bytes + i * 16u) | (q < q1 ? 0u : 0xffffffffu); // (an OR with a select: hipcc turned the plain select into a branch per chunk)
+}
+template <class T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cluster_rsrc(const T* const p, const bn_cluster_geom_t& g, const unsigned c)
+{
+	const unsigned first = c * (unsigned)g.inner * (unsigned)sizeof(T);
+	return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p + first), 0, g.bytes - first, 0x00020000);
+}
+__device__ __forceinline__ void cluster_finish(cluster_sync_t* const sync, const unsigned grid)
+{
+	if (threadIdx.x == 0 && nnc_fetch_add_agent(&sync->done, 1) == grid - 1) { nnc_store_agent(&sync->ticket, 0); nnc_store_agent(&sync->done, 0); }
+}
+
+template <class T, int NV>
+__global__ void __launch_bounds__(256, 4) bn_cluster_forw_kernel(const T* __restrict__ x, T* __restrict__ y, const bn_cluster_geom_t g, cluster_sync_t* const sync, const unsigned epoch, unsigned* const timeout_word, const float* __restrict__ scale, const float* __restrict__ bias, float* mean, float* var, float* __restrict__ saved_mean, float* __restrict__ saved_inv_std, const float inv_b, const float mom, const float eps, const int relu)
+{
+	constexpr int W = 16 / sizeof(T);
+	typedef typename pack16<T>::type V;
+	HIP_DYNAMIC_SHARED(float, lds)
+	float* const red = lds;                 // [4] + ticket
+	float* const part = lds + 8;            // [G][2]
+	float* const stat = lds + 8 + 2 * BN_CLUSTER_MAX_G;
+	const int t = threadIdx.x;
+	if (t == 0) ((unsigned*)red)[4] = nnc_fetch_add_agent(&sync->ticket, 1);
+	__syncthreads();
+	const unsigned ticket = ((const unsigned*)red)[4];
+	const unsigned c = ticket / g.G, w = ticket - c * g.G;
+	const unsigned q0 = w * g.per, q1 = q0 + g.per < g.Q ? q0 + g.per : g.Q;
+	const __amdgpu_buffer_rsrc_t rx = cluster_rsrc(x, g, c), ry = cluster_rsrc(y, g, c);
+	bn_u4 raw[NV]; // (kept as the four dwords that arrived: as a vector of eight halves hipcc unpacks every chunk into eight registers on arrival)
+#pragma unroll
+	for (int j = 0; j < NV; j++) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, cluster_chunk_voff(g, q0 + t + 256 * j, q1), 0, 0);
+	// (chunks past the share's end were loaded as zeros: they add nothing to the sum, and the second moment skips them by a select, not a branch --
+	// per-chunk lane masks would cost 2 SGPRs each; the sched_barriers keep hipcc from converting / centring every chunk at once, which spills)
+	const int nj = q1 > q0 + t ? (int)((q1 - q0 - t + 255) >> 8) : 0; // chunks this thread holds
+	float s = 0.f;
+#pragma unroll
+	for (int j = 0; j < NV; j++) {
+		const V vj = __builtin_bit_cast(V, raw[j]);
+#pragma unroll
+		for (int e = 0; e < W; e++) s += (float)vj[e];
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	const float cnt = (float)(q1 - q0) * (float)W;
+	const float s_w = cluster_block_sum(s, red);
+	const float m_w = s_w / cnt;
+	float m2 = 0.f;
+#pragma unroll
+	for (int j = 0; j < NV; j++) {
+		const bool on = j < nj;
+		NNC_PIN_VEC(raw[j]); // (an opaque "new" value: otherwise the halves converted for the first sum stay converted -- eight registers per chunk -- for this pass)
+		const V vj = __builtin_bit_cast(V, raw[j]);
+#pragma unroll
+		for (int e = 0; e < W; e++) { const float d = (float)vj[e] - m_w; m2 += on ? d * d : 0.f; }
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	const float m2_w = cluster_block_sum(m2, red);
+	float mu = s_w * inv_b, M2 = m2_w;
+	if (g.G > 1) {
+		unsigned long long* const slots = (unsigned long long*)(sync + 1) + (size_t)c * g.G * 2;
+		if (t == 0) { nnc_store_granule(slots + w * 2, epoch, s_w); nnc_store_granule(slots + w * 2 + 1, epoch, m2_w); }
+		if (t < 64) {
+			cluster_collect<2>(slots, g.G, epoch, part, timeout_word);
+			// the cluster's mean, then Chan's fold of the shares' second moments about it -- lane-strided partial sums, then the butterfly: every workgroup of
+			// the cluster runs the same instructions on the same numbers
+			float a = 0.f;
+			for (unsigned k = t; k < g.G; k += 64) a += part[2 * k];
+			a = wave_sum(a);
+			const float mean_all = a * inv_b;
+			float b2 = 0.f;
+			for (unsigned k = t; k < g.G; k += 64) {
+				const unsigned k0 = k * g.per, k1 = k0 + g.per < g.Q ? k0 + g.per : g.Q;
+				const float n_k = (float)(k1 - k0) * (float)W;
+				const float d = part[2 * k] / n_k - mean_all;
+				b2 += part[2 * k + 1] + n_k * d * d;
+			}
+			b2 = wave_sum(b2);
+			if (t == 0) { stat[0] = mean_all; stat[1] = b2; }
+		}
+		__syncthreads();
+		mu = stat[0]; M2 = stat[1];
+	}
+	const float vb = M2 * inv_b;
+	const float is = 1.f / sqrtf(vb + eps);
+	const float ws = is * scale[c], bs = bias[c] - mu * ws;
+	if (w == 0 && t == 0) { // batch_norm_cpu_ref.c:67-72, :107-118
+		saved_mean[c] = mu;
+		saved_inv_std[c] = is;
+		mean[c] = mom * mean[c] + (1.f - mom) * mu;
+		var[c] = mom * var[c] + (1.f - mom) * vb;
+	}
+	unsigned ts = t; // the stores' offsets are computed again (a few integer operations per chunk) instead of living in 20 registers since the loads
+	NNC_PIN_V(ts);
+#pragma unroll
+	for (int j = 0; j < NV; j++) {
+		V r;
+		NNC_PIN_VEC(raw[j]);
+		const V vj = __builtin_bit_cast(V, raw[j]);
+#pragma unroll
+		for (int e = 0; e < W; e++) { const float o = (float)vj[e] * ws + bs; r[e] = (T)(relu && !(o > 0.f) ? 0.f : o); }
+		__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bn_u4, r), ry, cluster_chunk_voff(g, q0 + ts + 256 * j, q1), 0, 0);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	cluster_finish(sync, g.grid);
+}
+
+// backward: sum of g and of xhat * g over the channel (fused, one pass over the registers), then h = (scale * inv_std / B) * (B * g - dbias - xhat * dscale)
+template <class T, int NV>
+__global__ void __launch_bounds__(256, 4) bn_cluster_back_kernel(const T* __restrict__ x, const T* __restrict__ gr, T* __restrict__ h, const bn_cluster_geom_t g, cluster_sync_t* const sync, const unsigned epoch, unsigned* const timeout_word, const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ inv_std, float* __restrict__ dscale, float* __restrict__ dbias, const float B)
+{
+	constexpr int W = 16 / sizeof(T);
+	typedef typename pack16<T>::type V;
+	HIP_DYNAMIC_SHARED(float, lds)
+	float* const red = lds;
+	float* const part = lds + 8;
+	float* const stat = lds + 8 + 2 * BN_CLUSTER_MAX_G;
+	const int t = threadIdx.x;
+	if (t == 0) ((unsigned*)red)[4] = nnc_fetch_add_agent(&sync->ticket, 1);
+	__syncthreads();
+	const unsigned ticket = ((const unsigned*)red)[4];
+	const unsigned c = ticket / g.G, w = ticket - c * g.G;
+	const unsigned q0 = w * g.per, q1 = q0 + g.per < g.Q ? q0 + g.per : g.Q;
+	const __amdgpu_buffer_rsrc_t rx = cluster_rsrc(x, g, c), rg = cluster_rsrc(gr, g, c), rh = cluster_rsrc(h, g, c);
+	bn_u4 xraw[NV], graw[NV];
+#pragma unroll
+	for (int j = 0; j < NV; j++) {
+		const unsigned voff = cluster_chunk_voff(g, q0 + t + 256 * j, q1);
+		xraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
+		graw[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, voff, 0, 0);
+	}
+	const float mu = mean[c], is = inv_std[c];
+	float sg = 0.f, sx = 0.f; // (chunks past the share's end are zeros in g: they add nothing to either sum)
+#pragma unroll
+	for (int j = 0; j < NV; j++) {
+		NNC_PIN_VEC(xraw[j]); NNC_PIN_VEC(graw[j]);
+		const V xj = __builtin_bit_cast(V, xraw[j]), gj = __builtin_bit_cast(V, graw[j]);
+#pragma unroll
+		for (int e = 0; e < W; e++) { const float gg = (float)gj[e]; sg += gg; sx += ((float)xj[e] - mu) * is * gg; }
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	const float sg_w = cluster_block_sum(sg, red);
+	const float sx_w = cluster_block_sum(sx, red);
+	float db = sg_w, ds = sx_w;
+	if (g.G > 1) {
+		unsigned long long* const slots = (unsigned long long*)(sync + 1) + (size_t)c * g.G * 2;
+		if (t == 0) { nnc_store_granule(slots + w * 2, epoch, sg_w); nnc_store_granule(slots + w * 2 + 1, epoch, sx_w); }
+		if (t < 64) {
+			cluster_collect<2>(slots, g.G, epoch, part, timeout_word);
+			float a = 0.f, b2 = 0.f;
+			for (unsigned k = t; k < g.G; k += 64) { a += part[2 * k]; b2 += part[2 * k + 1]; }
+			a = wave_sum(a); b2 = wave_sum(b2);
+			if (t == 0) { stat[0] = a; stat[1] = b2; }
+		}
+		__syncthreads();
+		db = stat[0]; ds = stat[1];
+	}
+	if (w == 0 && t == 0) { dbias[c] = db; dscale[c] = ds; }
+	const float k = 1.f / B * scale[c] * is;
+	unsigned ts = t;
+	NNC_PIN_V(ts);
+#pragma unroll
+	for (int j = 0; j < NV; j++) {
+		V r;
+		NNC_PIN_VEC(xraw[j]); NNC_PIN_VEC(graw[j]);
+		const V xj = __builtin_bit_cast(V, xraw[j]), gj = __builtin_bit_cast(V, graw[j]);
+#pragma unroll
+		for (int e = 0; e < W; e++) { const float xhat = ((float)xj[e] - mu) * is; r[e] = (T)(k * (B * (float)gj[e] - db - xhat * ds)); }
+		__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bn_u4, r), rh, cluster_chunk_voff(g, q0 + ts + 256 * j, q1), 0, 0);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	cluster_finish(sync, g.grid);
+}
+
+// Can the cluster kernels take this tensor, and with which geometry?  nv_per_thread: chunks a thread may hold.
+template <class T>
+static bool bn_cluster_plan(const chan_view_t& v, const int nv_per_thread, const void* p0, const void* p1, const void* p2, bn_cluster_geom_t* g)
+{
+	constexpr int W = 16 / (int)sizeof(T);
+	const long mode = tune(TUNE_BN_CLUSTER);
+	if (mode <= 0 || v.inner <= 1 || v.inner % W != 0 || v.C < 1 || v.outer < 1) return false;
+	if ((((uintptr_t)p0) | ((uintptr_t)p1) | ((uintptr_t)p2)) & 15) return false;
+	const long nv = v.inner / W, Q = v.outer * nv;
+	const unsigned long long bytes = (unsigned long long)v.outer * v.C * v.inner * sizeof(T);
+	if (bytes > 0xfffffff0ull) return false; // 32-bit byte offsets
+	if (nv > 0xfffff || Q > 0x7fffffffL || (unsigned long long)Q * (unsigned long long)nv >= (1ull << 32)) return false;
+	long cap = 256L * nv_per_thread; // chunks one workgroup holds
+	if (mode > 1 && mode < cap) cap = mode; // (tests: several workgroups per channel on small tensors)
+	long G = (Q + cap - 1) / cap;
+	if (G > BN_CLUSTER_MAX_G) return false;
+	const long per = (Q + G - 1) / G;
+	G = (Q + per - 1) / per; // no empty workgroup
+	const long grid = (long)v.C * G;
+	if (grid > 0x7fffffffL || (size_t)grid * 16 > CLUSTER_SYNC_BYTES - 256) return false;
+	g->C = v.C; g->inner = v.inner; g->nv = (unsigned)nv; g->magic = (unsigned)((1ull << 32) / (unsigned long long)nv) + 1u;
+	g->Q = (unsigned)Q; g->per = (unsigned)per; g->G = (unsigned)G; g->grid = (unsigned)grid;
+	g->bytes = (unsigned)bytes; g->image_bytes = (unsigned)((unsigned long long)v.C * v.inner * sizeof(T));
+	return true;
+}
+
 // Derive the [outer][C][inner] view of x from the statistics tensor.
 //   * statistics with x's rank (or right-aligned against it, lib/nnc/cmd/norm/ccv_nnc_batch_norm_cpu_ref.c:28-33): every axis of
 //     extent 1 is reduced, exactly one axis is kept;
@@ -466,6 +737,19 @@ static int bnorm_forw_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 		float* saved_inv_std = outputs[4]->data.f32;
 		if ((int)tensor_count(outputs[3]->info) != v.C || (int)tensor_count(outputs[4]->info) != v.C) return CCV_NNC_EXEC_INVALID;
 		const float inv_b = 1.f / (float)(n / v.C);
+		bn_cluster_geom_t cg;
+		if (bn_cluster_plan<T>(v, BN_CLUSTER_NV, xp, yp, 0, &cg)) { // a cluster of workgroups per channel: x read once (round 4)
+			unsigned epoch = 0;
+			unsigned* timeout_word = 0;
+			cluster_sync_t* const sync = (cluster_sync_t*)cluster_sync_of(stream_context, (size_t)cg.grid * 16, &epoch, &timeout_word);
+			if (sync) {
+				const auto kernel = bn_cluster_forw_kernel<T, BN_CLUSTER_NV>; // (a name without commas for the launch macros)
+				NNC_LAUNCH_CONCURRENT(kernel, dim3(cg.grid), dim3(256), BN_CLUSTER_LDS, stream, xp, yp, cg, sync, epoch, timeout_word, scale, bias, mean, var, saved_mean, saved_inv_std, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon, relu);
+				HIP_ENFORCE(hipGetLastError());
+				++g_bn_cluster_launches;
+				return CCV_NNC_EXEC_SUCCESS;
+			}
+		}
 		if (v.inner > 1) { // planes: one sweep from HBM for both statistics (see bn_plane_stats_kernel)
 			const long planes = v.outer * v.C;
 			float* const psum = (float*)workspace_of(stream_context, sizeof(float) * 2 * (size_t)planes);
@@ -547,6 +831,19 @@ static int bnorm_back_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
 	int ret;
 	ProfScope prof("bnorm_bwd|nnc::chan_reduce + bn_back_kernel", 0, 3.0 * sizeof(T) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream_of(stream_context)); // g, x read; h written
+	bn_cluster_geom_t cg;
+	if (bn_cluster_plan<T>(v, BN_CLUSTER_NV / 2, xp, gp, hp, &cg)) { // a cluster of workgroups per channel: x and g read once (round 4)
+		unsigned epoch = 0;
+		unsigned* timeout_word = 0;
+		cluster_sync_t* const sync = (cluster_sync_t*)cluster_sync_of(stream_context, (size_t)cg.grid * 16, &epoch, &timeout_word);
+		if (sync) {
+			const auto kernel = bn_cluster_back_kernel<T, BN_CLUSTER_NV / 2>;
+			NNC_LAUNCH_CONCURRENT(kernel, dim3(cg.grid), dim3(256), BN_CLUSTER_LDS, stream_of(stream_context), xp, gp, hp, cg, sync, epoch, timeout_word, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, dscale->data.f32, dbias->data.f32, (float)(n / v.C));
+			HIP_ENFORCE(hipGetLastError());
+			++g_bn_cluster_launches;
+			return CCV_NNC_EXEC_SUCCESS;
+		}
+	}
 	if (v.inner > 1) { // planes: both sums in one sweep over (x, g)
 		const long planes = v.outer * v.C;
 		float* const pg = (float*)workspace_of(stream_context, sizeof(float) * 2 * (size_t)planes);
@@ -576,6 +873,8 @@ static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 }
 
 } // namespace
+
+extern "C" long nnc_mi355x_debug_bn_cluster_launches(void) { return g_bn_cluster_launches; }
 
 // out[c] (+)= sum over (o, i) of x[(o * C + c) * inner + i]: the bias gradient of a convolution on NCHW tensors (cmd_conv.cpp)
 int nnc::chan_sum_planes(const float* x, long outer, int C, long inner, float* out, int accumulate, ccv_nnc_stream_context_t* ctx)

@@ -121,6 +121,11 @@ hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx);
 void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size);
 const float* zero_page_of(const ccv_nnc_stream_context_t* ctx); // 256 zero bytes in the HBM of the device `ctx` launches on
 int device_cu_count(void);
+// kernels whose workgroups wait for each other inside one launch: the stream's hand-over area (device_rt.cpp), this launch's epoch, the timeout word
+struct cluster_sync_t { unsigned ticket, done; unsigned pad[62]; }; // 256 bytes, the granules follow
+constexpr size_t CLUSTER_SYNC_BYTES = 2u << 20;
+constexpr unsigned CLUSTER_SPIN_LIMIT = 1u << 21; // polls (each ~ a microsecond) before a waiting workgroup gives up: seconds, not a hung GPU
+void* cluster_sync_of(const ccv_nnc_stream_context_t* ctx, size_t granule_bytes, unsigned* epoch, unsigned** timeout_word);
 void note_kernel(const char* name);
 
 long tune(int key);
@@ -195,6 +200,7 @@ enum {
 	                        // reduction has at least this many channels (0 = never: the fp32 Winograd kernels between converting transposes)
 	TUNE_BN_SMALL_PLANES,   // batch norm on [N][C][planes]: four planes per wave when a plane is at most 1 KB (1), or a wave per plane always (0)
 	TUNE_SDPA_MFMA,         // scaled-dot-product attention forward on the matrix cores where the shapes allow (1), or the VALU kernel always (0)
+	TUNE_BN_CLUSTER,        // batch norm (training) on [N][C][planes]: a cluster of workgroups per channel holds the channel in registers between the statistics and the apply pass -- x read ONCE (1), or the plane kernels (0); > 1: chunks per workgroup (tests force several workgroups per channel on small tensors)
 	TUNE_COUNT
 };
 static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");

@@ -17,6 +17,8 @@ struct device_local_t {
 	int device;
 	void* staging;        // second grow-only arena: the fp32 images of half-precision tensors (half_stage.cpp) -- they must survive
 	size_t staging_size;  // whatever the command underneath asks of the workspace (a growing workspace is freed and re-allocated)
+	void* cluster_sync;   // the words the workgroups of ONE launch on this stream hand each other (nnc::cluster_sync_of): never scratch, never moved
+	unsigned cluster_epoch;
 };
 // Layout contract with the reference host (lib/nnc/ccv_nnc_stream.c:15-20, lib/nnc/gpu/ccv_nnc_compat.cu:286-299):
 // the host allocates `super` + a {size_t, void*} CPU-workspace tail for EVERY context (CPU contexts included) and, under
@@ -98,10 +100,10 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 
 namespace nnc {
 int g_force_tile = 0;
-static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C", "WINO_FUSED_GRID", "GRID_WG_PER_CU", "WINO_WGRAD_FUSED_MAX", "GEMM_BUFFER_LOADS", "CONV_NCHW_HALF_F16", "BN_SMALL_PLANES", "SDPA_MFMA" };
+static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C", "WINO_FUSED_GRID", "GRID_WG_PER_CU", "WINO_WGRAD_FUSED_MAX", "GEMM_BUFFER_LOADS", "CONV_NCHW_HALF_F16", "BN_SMALL_PLANES", "SDPA_MFMA", "BN_CLUSTER" };
 // GRID_WG_PER_CU = 0: grid-stride kernels get one trip per thread.  tools/ew_bw_bench.py: a grid capped at 8 .. 64 workgroups per CU
 // striding a 3.3 GB tensor runs at 4.7 - 5.2 TB/s, the same kernel with the whole tensor as its grid at 6.2 TB/s.
-static long g_tune_values[TUNE_COUNT] = { 0, 128, 0, 0, 128, 1, 64, 1, 1 }; // defaults: the measured best on the MI355X
+static long g_tune_values[TUNE_COUNT] = { 0, 128, 0, 0, 128, 1, 64, 1, 1, 1 }; // defaults: the measured best on the MI355X
 static int g_tune_env_read = 0;
 long tune(int key)
 {
@@ -155,6 +157,57 @@ WorkspaceScope::WorkspaceScope(const ccv_nnc_stream_context_t* ctx, size_t prefi
 	tl_ws_prefix += prefix_bytes;
 }
 WorkspaceScope::~WorkspaceScope() { tl_ws_prefix = prev; tl_ws_limit = prev_limit; }
+
+// ---- the hand-over words of kernels whose workgroups wait for each other inside ONE launch (cmd_norm.cpp's cluster kernels) -----------------------
+// One area per stream (per device for ANY-device contexts, per thread and device for the NULL stream): launches on one stream run one after the other, so
+// the area has ONE user at a time.  Layout: cluster_sync_t (a ticket counter and a done counter, both zero between launches -- the last workgroup of a
+// launch puts them back) followed by 8-byte {tag, value} granules.  A launch's tags are its EPOCH, a per-area launch count that never repeats a value still
+// in the area (32 bits, zero skipped), so the granules are never cleared: nothing but these kernels writes here, and what an older launch left cannot match.
+// A polling loop that gives up (CLUSTER_SPIN_LIMIT polls: the workgroups it waits for never became resident) raises g_cluster_timeout in pinned host memory;
+// the next synchronise of any stream stops the process with a message -- wrong numbers never travel on in silence.
+static unsigned* g_cluster_timeout = 0;
+static pthread_mutex_t g_cluster_mutex = PTHREAD_MUTEX_INITIALIZER;
+static void cluster_check_timeout()
+{
+	if (g_cluster_timeout && *(volatile unsigned*)g_cluster_timeout) {
+		fprintf(stderr, "[nnc_mi355x] a cluster kernel gave up waiting for its sibling workgroups (code %u): its results are invalid\n", *(volatile unsigned*)g_cluster_timeout);
+		abort();
+	}
+}
+void* cluster_sync_of(const ccv_nnc_stream_context_t* ctx, size_t granule_bytes, unsigned* epoch, unsigned** timeout_word)
+{
+	if (granule_bytes > CLUSTER_SYNC_BYTES - 256) return 0;
+	if (g_deferred_live) deferred_flush(ctx);
+	device_local_t* l;
+	if (ctx && CCV_STREAM_GET_CONTEXT(ctx->type) == CCV_STREAM_CONTEXT_GPU) l = bind(ctx);
+	else {
+		const int device = current_device();
+		if (device >= MAX_DEVICES) return 0;
+		l = &tl_default[device];
+		l->device = device;
+	}
+	if (!g_cluster_timeout) {
+		pthread_mutex_lock(&g_cluster_mutex);
+		if (!g_cluster_timeout) {
+			unsigned* w = 0;
+			HIP_ENFORCE(hipHostMalloc((void**)&w, 256, hipHostMallocDefault));
+			memset(w, 0, 256);
+			g_cluster_timeout = w;
+		}
+		pthread_mutex_unlock(&g_cluster_mutex);
+	}
+	if (!l->cluster_sync) {
+		void* p = nnc_mi355x_malloc(l->device, CLUSTER_SYNC_BYTES);
+		if (!p) return 0;
+		HIP_ENFORCE(hipMemset(p, 0, CLUSTER_SYNC_BYTES)); // (synchronous, once per stream and device)
+		l->cluster_sync = p;
+		l->cluster_epoch = 0;
+	}
+	if (++l->cluster_epoch == 0) l->cluster_epoch = 1;
+	*epoch = l->cluster_epoch;
+	*timeout_word = g_cluster_timeout;
+	return l->cluster_sync;
+}
 
 const float* zero_page_of(const ccv_nnc_stream_context_t* ctx)
 {
@@ -221,8 +274,10 @@ static inline int sync_trace_on(void)
 	if (g_sync_trace < 0) { const char* e = getenv("NNC_MI355X_SYNC_TRACE"); g_sync_trace = (e && *e && *e != '0') ? 1 : 0; }
 	return g_sync_trace;
 }
+static std::atomic<long> g_exec_commands(0); // nnc_mi355x_debug_exec_count(): commands that reached an exec function of this library (the host-enqueue measurement)
 MarkerScope::MarkerScope(const uint32_t cmd) : active(0)
 {
+	g_exec_commands.fetch_add(1, std::memory_order_relaxed);
 	if (sync_trace_on()) { fprintf(stderr, "[nnc_mi355x] > %s\n", command_row_name(cmd)); active |= 2; }
 	if (!markers_on()) return;
 	g_roctx_push(command_row_name(cmd));
@@ -379,15 +434,16 @@ ccv_nnc_stream_context_t* ccv_nnc_init_stream_context(ccv_nnc_stream_context_t* 
 
 static void local_release(device_local_t* l)
 {
-	if (!l->stream && !l->workspace && !l->staging) return;
+	if (!l->stream && !l->workspace && !l->staging && !l->cluster_sync) return;
 	nnc::comm_flush_if_pending();
 	const int prev = current_device();
 	HIP_ENFORCE(hipSetDevice(l->device));
 	if (l->stream) HIP_ENFORCE(hipStreamSynchronize(l->stream));
 	if (l->workspace) HIP_ENFORCE(hipFree(l->workspace));
 	if (l->staging) HIP_ENFORCE(hipFree(l->staging));
+	if (l->cluster_sync) HIP_ENFORCE(hipFree(l->cluster_sync));
 	if (l->stream) HIP_ENFORCE(hipStreamDestroy(l->stream));
-	l->workspace = 0; l->workspace_size = 0; l->staging = 0; l->staging_size = 0; l->stream = 0;
+	l->workspace = 0; l->workspace_size = 0; l->staging = 0; l->staging_size = 0; l->stream = 0; l->cluster_sync = 0;
 	HIP_ENFORCE(hipSetDevice(prev));
 }
 
@@ -406,8 +462,9 @@ void ccv_nnc_deinit_stream_context(ccv_nnc_stream_context_t* const stream_contex
 void ccv_nnc_synchronize_stream_context(const ccv_nnc_stream_context_t* const stream_context)
 {
 	nnc::comm_flush_if_pending();
-	if (!stream_context) { HIP_ENFORCE(hipStreamSynchronize((hipStream_t)0)); return; }
+	if (!stream_context) { HIP_ENFORCE(hipStreamSynchronize((hipStream_t)0)); nnc::cluster_check_timeout(); return; }
 	HIP_ENFORCE(hipStreamSynchronize(bind(stream_context)->stream));
+	nnc::cluster_check_timeout();
 }
 
 void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const stream_context, const size_t workspace_size, const int mem)
@@ -731,6 +788,7 @@ float nnc_mi355x_event_elapsed_ms(void* start, void* stop)
 }
 void nnc_mi355x_event_free(void* event) { HIP_ENFORCE(hipEventDestroy((hipEvent_t)event)); }
 const char* nnc_mi355x_last_kernel_name(void) { return tl_last_kernel; }
+long nnc_mi355x_debug_exec_count(void) { return nnc::g_exec_commands.load(std::memory_order_relaxed); }
 void nnc_mi355x_debug_force_tile(int wm, int wn)
 {
 	const bool known = (wm == 2 && wn == 2) || (wm == 2 && wn == 1) || (wm == 1 && wn == 2) || (wm == 1 && wn == 1);

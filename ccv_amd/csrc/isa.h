@@ -62,6 +62,15 @@ static inline floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx
 #define NNC_ASM_NOPS(text) ((void)0)
 #define NNC_WAIT_LGKM0() ((void)0)
 #define NNC_WAIT_VM0_ONLY() ((void)0)
+// -- workgroups of ONE launch that hand each other a few words (cmd_norm.cpp's cluster kernels): agent-scope accesses of the words themselves, no fences.
+//    A granule is one naturally aligned 8-byte {tag, value} written by ONE store: the data is the flag.  The emulator keeps a window of workgroups resident
+//    and runs them interleaved (tests/emu: launch_concurrent); a polling loop yields to them.
+#define NNC_LAUNCH_CONCURRENT(kernel, grid, block, shmem, stream, ...) emuLaunchConcurrentKernel(kernel, grid, block, shmem, stream, __VA_ARGS__)
+static inline unsigned nnc_fetch_add_agent(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+static inline void nnc_store_agent(unsigned* p, unsigned v) { *p = v; }
+static inline void nnc_store_granule(unsigned long long* p, unsigned tag, float value) { unsigned u; memcpy(&u, &value, 4); *p = ((unsigned long long)tag << 32) | u; }
+static inline unsigned long long nnc_load_granule(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
+#define NNC_SPIN_SLEEP() emu::spin_yield()
 
 #else
 
@@ -96,6 +105,13 @@ __device__ __forceinline__ halfx4 tr_read4(const half_t* const blk, const int pi
 	return v;
 }
 __device__ __forceinline__ floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+#define NNC_LAUNCH_CONCURRENT(kernel, grid, block, shmem, stream, ...) hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+// (global_atomic / global_load / global_store with sc1: served by the memory side of the L2s, never by a CU's L1 -- MI355X guide, inter-workgroup visibility)
+__device__ __forceinline__ unsigned nnc_fetch_add_agent(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void nnc_store_agent(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void nnc_store_granule(unsigned long long* p, unsigned tag, float value) { __hip_atomic_store(p, ((unsigned long long)tag << 32) | __float_as_uint(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long nnc_load_granule(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define NNC_SPIN_SLEEP() __builtin_amdgcn_s_sleep(4)
 #define NNC_PIN_VEC(v) asm volatile("" : "+v"(v))
 #define NNC_ASM_NOPS(text) asm volatile(text)
 #define NNC_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")

@@ -456,6 +456,11 @@ void nnc_mi355x_debug_force_tile(int wm, int wn);
 void nnc_mi355x_set_peephole(int on);
 /* Test hook: commands recorded so far, how many of them a ReLU completed (folded), how many were launched as they were (plain). */
 void nnc_mi355x_debug_peephole_counts(long* recorded, long* folded, long* plain);
+/* batch-norm commands that ran on the cluster kernels (cmd_norm.cpp: a cluster of workgroups per channel keeps the channel in registers between the
+ * statistics and the apply pass; NNC_MI355X_BN_CLUSTER=0 / nnc_mi355x_tune_set("BN_CLUSTER", 0) selects the plane kernels). */
+long nnc_mi355x_debug_bn_cluster_launches(void);
+/* commands that have reached an exec function of this library since it was loaded (tools/host_resnet_bench.c divides the host's enqueue time by it) */
+long nnc_mi355x_debug_exec_count(void);
 /* Test hook for the CCV_16F datapath (half_stage.cpp): how many half-precision tensors have been given an fp32 image so far
  * (staged) and how many were handed to a kernel as halves (native) since the library was loaded. */
 void nnc_mi355x_debug_half_counts(long* staged, long* native);

@@ -29,7 +29,7 @@ static Block* cur = &seq_block;
 static ucontext_t main_ctx;
 static const std::function<void()>* cur_body = nullptr;
 static int cur_tid = 0, nthreads = 0;
-static unsigned long progress = 0;
+static unsigned long progress = 0, threads_finished = 0;
 static bool in_kernel = false;
 
 static inline int live() { return nthreads - cur->ndone; }
@@ -45,6 +45,7 @@ static void entry()
 	b->ndone++;
 	b->wave_live[t / 64]--;
 	progress++;
+	threads_finished++;
 	check_block();
 	check_wave(t / 64);
 	swapcontext(&b->fibers[t].ctx, &main_ctx);
@@ -136,7 +137,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 	in_kernel = false;
 }
 
-// Workgroups that wait for each other inside a launch.  A window of workgroups is resident at a time (NNC_EMU_RESIDENT_BLOCKS, default 8); a finished
+// Workgroups that wait for each other inside a launch.  A window of workgroups is resident at a time (NNC_EMU_RESIDENT_BLOCKS, default 32); a finished
 // one is replaced by the next of the dispatch order -- forward by default, NNC_EMU_DISPATCH_ORDER=reverse / shuffle to show that a kernel's protocol does not
 // depend on it (HIP promises no dispatch order).  Such kernels keep their LDS in the dynamic region: `__shared__` statics are ONE object in this emulator.
 void launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body)
@@ -146,7 +147,7 @@ void launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<
 	const int n = launch_begin(grid, block, body);
 	static std::vector<Block*> window;
 	const char* const we = getenv("NNC_EMU_RESIDENT_BLOCKS");
-	size_t resident = we ? (size_t)atol(we) : 8;
+	size_t resident = we ? (size_t)atol(we) : 32;
 	if (resident < 1) resident = 1;
 	if (resident > total) resident = total;
 	while (window.size() < resident) window.push_back(new Block);
@@ -157,21 +158,21 @@ void launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<
 	else if (oe && !strcmp(oe, "shuffle")) { unsigned long long st = 0x9e3779b97f4a7c15ULL; for (size_t i = total; i > 1; i--) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; std::swap(order[i - 1], order[(st >> 33) % i]); } }
 	size_t next = 0, finished = 0;
 	for (size_t i = 0; i < resident; i++) window[i]->active = false;
+	// (a polling loop's wave votes count as `progress`: the deadlock test here is "no THREAD has finished and no workgroup was admitted for 20 000 sweeps")
 	int stale = 0;
 	while (finished < total) {
-		const unsigned long before = progress;
+		const unsigned long before = threads_finished + next;
 		for (size_t i = 0; i < resident; i++) {
 			Block& b = *window[i];
 			if (!b.active) {
 				if (next >= total) continue;
 				const size_t id = order[next++];
 				block_prepare(b, n, shmem, uint3_emu{(unsigned)(id % grid.x), (unsigned)((id / grid.x) % grid.y), (unsigned)(id / ((size_t)grid.x * grid.y))});
-				progress++;
 			}
 			block_sweep(b, n, block);
 			if (b.ndone == n) { b.active = false; finished++; }
 		}
-		if (progress == before) { if (++stale > 64) { fprintf(stderr, "emu: deadlock in a concurrent launch: %zu of %zu workgroups finished, %zu resident, none makes progress\n", finished, total, resident); abort(); } }
+		if (threads_finished + next == before) { if (++stale > 20000) { fprintf(stderr, "emu: deadlock in a concurrent launch: %zu of %zu workgroups finished, %zu resident, none makes progress\n", finished, total, resident); abort(); } }
 		else stale = 0;
 	}
 	cur = &seq_block;

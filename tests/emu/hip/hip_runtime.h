@@ -236,6 +236,7 @@ static inline void emu_wave_barrier() { asm volatile("" ::: "memory"); emu::wave
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }

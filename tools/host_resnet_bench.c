@@ -105,12 +105,14 @@ POOL_PER_IMAGE(CCV_NNC_AVERAGE_POOL_BACKWARD, 3)
 static void nnc_mi355x_profile_enable(int on) {}
 static int nnc_mi355x_profile_count(void) { return 0; }
 static int nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5]) { return -1; }
+static long nnc_mi355x_debug_exec_count(void) { return 0; }
 #else
 #define DEV_TENSOR_NCHW(...) GPU_TENSOR_NCHW(000, 32F, __VA_ARGS__)
 /* the backend's in-library launch records (include/nnc_mi355x.h) */
 void nnc_mi355x_profile_enable(int on);
 int nnc_mi355x_profile_count(void);
 int nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5]);
+long nnc_mi355x_debug_exec_count(void);
 #endif
 
 static float hash_unit(const uint64_t i, const uint64_t seed)
@@ -497,6 +499,25 @@ int main(int argc, char** argv)
 		for (j = 0; j < (size_t)batch * classes; j++) { a += hout->data.f32[j]; b += (double)hout->data.f32[j] * hout->data.f32[j]; }
 		dev_sum[i] = a; dev_sumsq[i] = b;
 	}
+	/* host-enqueue leg (round 4): how long ONE host thread needs to put a step into the streams.  Each step starts on drained streams, so nothing the GPU
+	 * does can hold the host back; the step call returning = everything enqueued (the host's scheduler runs the graph asynchronously on the stream).
+	 * With the reference's single-process data parallelism one thread enqueues for all N devices: N x this number has to stay below the GPU time of a step. */
+	double enq_ms[5], enq_step_ms[5];
+	long enq_cmds = 0;
+	for (i = 0; i < 5; i++) { enq_ms[i] = enq_step_ms[i] = 0; }
+#ifndef HOST_BENCH_CPU /* (the CPU build runs its commands inside the call: nothing to separate, and each step takes seconds) */
+	for (i = 0; i < 5; i++) {
+		SYNC_ALL();
+		const long c0 = nnc_mi355x_debug_exec_count();
+		const double e0 = now_ms();
+		TRAIN_STEP();
+		const double e1 = now_ms();
+		SYNC_ALL();
+		enq_ms[i] = e1 - e0; enq_step_ms[i] = now_ms() - e0;
+		enq_cmds = nnc_mi355x_debug_exec_count() - c0;
+	}
+#endif
+	{ int a_, b_; for (a_ = 0; a_ < 5; a_++) for (b_ = a_ + 1; b_ < 5; b_++) if (enq_ms[b_] < enq_ms[a_]) { double t_ = enq_ms[a_]; enq_ms[a_] = enq_ms[b_]; enq_ms[b_] = t_; t_ = enq_step_ms[a_]; enq_step_ms[a_] = enq_step_ms[b_]; enq_step_ms[b_] = t_; } }
 	/* roofline leg: one more step with the backend's per-launch HIP-event records on (contractions and batch norm) */
 	nnc_mi355x_profile_enable(1);
 	TRAIN_STEP();
@@ -526,8 +547,8 @@ int main(int argc, char** argv)
 	for (i = 0; i < devices; i++) printf("%s%.17g", i ? ", " : "", dev_sum[i]);
 	printf("], ");
 	printf("\"driver\": \"reference host (ccv_cnnp_model_fit: cnnp, autodiff, compile, scheduler)\", \"model\": \"%s\", \"dtype\": \"%s\", \"format\": \"NCHW\", \"batch\": %d, \"input_hw\": %d, "
-		"\"devices\": %d, \"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"first_step_ms\": %.1f, \"softmax_row0_sum\": %.6f, \"softmax_worst_row_sum_err\": %.3g, \"outputs_finite\": %s, \"memory_gib\": %.3f}\n",
-		is_dawn ? "CIFAR-10 DawnNet (bin/nnc/cifar-10.c)" : mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, devices, ms, (double)batch * devices / (ms * 1e-3), t_first, row0, worst, finite ? "true" : "false",
+		"\"devices\": %d, \"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"host_enqueue\": {\"ms_per_step_median\": %.4f, \"ms_per_step_min\": %.4f, \"drained_step_ms\": %.4f, \"commands_per_step\": %ld, \"us_per_command\": %.3f}, \"first_step_ms\": %.1f, \"softmax_row0_sum\": %.6f, \"softmax_worst_row_sum_err\": %.3g, \"outputs_finite\": %s, \"memory_gib\": %.3f}\n",
+		is_dawn ? "CIFAR-10 DawnNet (bin/nnc/cifar-10.c)" : mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, devices, ms, (double)batch * devices / (ms * 1e-3), enq_ms[2], enq_ms[0], enq_step_ms[2], enq_cmds, enq_cmds > 0 ? enq_ms[2] * 1e3 / enq_cmds : 0.0, t_first, row0, worst, finite ? "true" : "false",
 		(double)ccv_cnnp_model_memory_size(model) / (1024.0 * 1024.0 * 1024.0));
 	for (i = 0; i < devices; i++) { ccv_nnc_tensor_free(labels_d[i]); ccv_nnc_tensor_free(softmax_d[i]); ccv_nnc_tensor_free(grad_d[i]); }
 	ccv_nnc_tensor_free(hout);
