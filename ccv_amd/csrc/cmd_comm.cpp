@@ -107,9 +107,20 @@ void flush_locked()
 	tl_in_comm--;
 }
 
+int max_pending()
+{ // NNC_MI355X_COMM_MAX_PENDING: a smaller queue (tests force the mid-stream group launches a full queue causes)
+	static int cap = 0;
+	if (!cap) {
+		const char* const e = getenv("NNC_MI355X_COMM_MAX_PENDING");
+		const int v = e ? atoi(e) : MAX_PENDING;
+		cap = v >= 1 && v <= MAX_PENDING ? v : MAX_PENDING;
+	}
+	return cap;
+}
+
 void record(const int op, const void* in, void* out, size_t count, ncclDataType_t dt, int root, ncclComm_t comm, hipStream_t stream, int device)
 { // g_comm_mutex held
-	if (g_pending_n == MAX_PENDING) flush_locked();
+	if (g_pending_n >= max_pending()) flush_locked();
 	pending_t& p = g_pending[g_pending_n++];
 	p.op = op; p.in = in; p.out = out; p.count = count; p.dt = dt; p.root = root; p.comm = comm; p.stream = stream; p.device = device;
 	nnc::g_comm_pending = 1;
@@ -256,7 +267,7 @@ void nnc_mi355x_comm_destroy(void)
 }
 
 namespace nnc {
-volatile int g_comm_pending = 0;
+std::atomic<int> g_comm_pending(0);
 void comm_flush(void)
 { // called (through the g_comm_pending check) by stream_of, synchronise, signals, callbacks: see "Coalescing" above
 	if (tl_in_comm) return;

@@ -1,6 +1,7 @@
 // Host-side helpers shared by the command implementations (C-style C++, compiled by hipcc).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -100,13 +101,13 @@ static inline bool image4(const ccv_nnc_tensor_t* t, Image4* o)
 }
 
 // Recorded-but-not-yet-issued collectives (cmd_comm.cpp "Coalescing"): anything that could observe stream order flushes them first.
-extern volatile int g_comm_pending;
+extern std::atomic<int> g_comm_pending; // (atomics, not volatile ints: these are read outside their mutexes by every order-observing hook on any thread -- ThreadSanitizer run, round 4)
 void comm_flush(void);
 void comm_release_context(const void* ctx);
 // Recorded-but-not-yet-launched commands waiting for the ReLU that may follow them (peephole.cpp): the same points flush them.
 typedef int (*exec_fn_t)(const ccv_nnc_cmd_t, const ccv_nnc_hint_t, const int, ccv_nnc_tensor_t* const*, const int, ccv_nnc_tensor_t* const*, const int, ccv_nnc_stream_context_t*);
 enum { DEFER_CONV_FORWARD = 1, DEFER_CONV_BACKWARD = 2, DEFER_POOL_BACKWARD = 3, DEFER_BNORM_FORWARD = 4, DEFER_EWSUM_FORWARD = 5 };
-extern volatile int g_deferred_live;
+extern std::atomic<int> g_deferred_live;
 bool deferred_try(exec_fn_t fn, int kind, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, int flags, ccv_nnc_tensor_t* const* inputs, int input_size, ccv_nnc_tensor_t* const* outputs, int output_size, ccv_nnc_stream_context_t* ctx, uint64_t* sig); // true: recorded, report success
 void deferred_mark_good(uint64_t sig); // this signature ran successfully on the spot: the next one like it may be recorded
 int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx); // -1: no recorded command this ReLU completes

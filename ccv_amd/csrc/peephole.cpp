@@ -34,7 +34,7 @@
 
 namespace nnc {
 
-volatile int g_deferred_live = 0;
+std::atomic<int> g_deferred_live(0);
 
 namespace {
 
@@ -62,7 +62,7 @@ std::condition_variable_any g_launched; // a LAUNCHING slot became FREE
 struct StickyError { const ccv_nnc_stream_context_t* ctx; int device; int err; };
 constexpr int MAX_STICKY = 16;
 StickyError g_sticky[MAX_STICKY];
-volatile int g_sticky_live = 0;
+std::atomic<int> g_sticky_live(0);
 std::unordered_set<uint64_t> g_good;
 int g_enabled = -1;
 long g_recorded = 0, g_folded = 0, g_plain = 0; // nnc_mi355x_debug_peephole_counts

@@ -22,13 +22,25 @@ def _has_gpu():
     return os.path.exists("/dev/kfd") and os.path.exists(os.path.join(ROOT, "ccv_amd", "lib", "libnnc_mi355x.so"))
 
 
+def emu_build():
+    """(make target, directory) of the emulator build under test: the plain one, or -- tests/test_sanitizers.py re-runs parts of this suite with
+    NNC_EMU_BUILD=tsan / asan and the sanitizer's runtime preloaded -- the ThreadSanitizer / AddressSanitizer + UBSan build of the same sources."""
+    kind = os.environ.get("NNC_EMU_BUILD", "")
+    return ("emu-" + kind, "_build_" + kind) if kind else ("emu", "_build")
+
+
+def emu_so():
+    return os.path.join(ROOT, "tests", "emu", emu_build()[1], "libnnc_mi355x_emu.so")
+
+
 @pytest.fixture(scope="session")
 def emu_lib():
     """The product sources compiled against the CPU HIP emulator (test infrastructure only)."""
     from ccv_amd import nnc
-    r = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "ccv_amd", "csrc"), "emu"], capture_output=True, text=True)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}  # (the compiler is not run under the sanitizer's runtime)
+    r = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "ccv_amd", "csrc"), emu_build()[0]], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    return nnc.load(os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so"))
+    return nnc.load(emu_so())
 
 
 @pytest.fixture(scope="session")

@@ -4,13 +4,27 @@
 #include <sys/mman.h>
 #include <time.h>
 #include <vector>
+#include <mutex>
+
+// ThreadSanitizer build (make emu-tsan): every lane is a TSAN fiber and every switch a synchronisation -- the lanes of a kernel run one after the other
+// on the launching thread, so they are never in a race with each other; what TSAN then sees is the HOST side of the library (peephole.cpp, cmd_comm.cpp,
+// device_rt.cpp) called from the tests' threads.
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define EMU_TSAN 1
+extern "C" { void* __tsan_get_current_fiber(void); void* __tsan_create_fiber(unsigned flags); void __tsan_destroy_fiber(void* fiber); void __tsan_switch_to_fiber(void* fiber, unsigned flags); }
+#endif
+#endif
 
 uint3_emu threadIdx, blockIdx;
 dim3 blockDim, gridDim;
 
 namespace emu {
 static const size_t kStack = 256 * 1024;
-struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = false; };
+struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = false; void* tsan = nullptr; };
+static void* main_tsan = nullptr;
+// ONE kernel at a time, whatever thread launches it (a loader thread's conversion kernel next to the training thread's): the device is one device
+static std::recursive_mutex launch_mutex;
 // Everything one resident workgroup owns.  The ordinary launch runs the grid's workgroups one after the other through ONE of these; launch_concurrent
 // (kernels whose workgroups talk to each other inside a launch: spin-waits on flags other workgroups of the grid publish) keeps a WINDOW of them
 // resident and interleaves their fibers.
@@ -35,7 +49,13 @@ static bool in_kernel = false;
 static inline int live() { return nthreads - cur->ndone; }
 static void check_block() { if (cur->block_arrived > 0 && (int)cur->block_arrived == live()) { cur->block_arrived = 0; cur->block_gen++; progress++; } }
 static void check_wave(int w) { if (cur->wave_arrived[w] > 0 && cur->wave_arrived[w] == cur->wave_live[w]) { cur->wave_arrived[w] = 0; cur->wave_gen[w]++; progress++; } }
-static void yield() { Block* const b = cur; const int t = cur_tid; swapcontext(&b->fibers[t].ctx, &main_ctx); }
+static inline void to_main_tsan()
+{
+#ifdef EMU_TSAN
+	__tsan_switch_to_fiber(main_tsan, 0);
+#endif
+}
+static void yield() { Block* const b = cur; const int t = cur_tid; to_main_tsan(); swapcontext(&b->fibers[t].ctx, &main_ctx); }
 static void entry()
 {
 	(*cur_body)();
@@ -48,6 +68,7 @@ static void entry()
 	threads_finished++;
 	check_block();
 	check_wave(t / 64);
+	to_main_tsan();
 	swapcontext(&b->fibers[t].ctx, &main_ctx);
 }
 void syncthreads()
@@ -93,6 +114,10 @@ static void block_prepare(Block& b, const int n, const size_t shmem, const uint3
 		b.fibers[t].ctx.uc_stack.ss_size = kStack;
 		b.fibers[t].ctx.uc_link = &main_ctx;
 		makecontext(&b.fibers[t].ctx, (void (*)())entry, 0);
+#ifdef EMU_TSAN
+		if (b.fibers[t].tsan) __tsan_destroy_fiber(b.fibers[t].tsan); // (a fresh shadow stack per use: a lane leaves its function by a context switch, never by returning)
+		b.fibers[t].tsan = __tsan_create_fiber(0);
+#endif
 	}
 	b.active = true;
 }
@@ -105,6 +130,10 @@ static void block_sweep(Block& b, const int n, const dim3 block)
 		if (b.fibers[t].done) continue;
 		cur_tid = t;
 		threadIdx = uint3_emu{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
+#ifdef EMU_TSAN
+		main_tsan = __tsan_get_current_fiber();
+		__tsan_switch_to_fiber(b.fibers[t].tsan, 0);
+#endif
 		swapcontext(&main_ctx, &b.fibers[t].ctx);
 	}
 }
@@ -122,6 +151,7 @@ static int launch_begin(dim3 grid, dim3 block, const std::function<void()>& body
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body)
 {
 	if ((size_t)grid.x * grid.y * grid.z == 0) return;
+	std::lock_guard<std::recursive_mutex> lock(launch_mutex);
 	const int n = launch_begin(grid, block, body);
 	for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
 		block_prepare(seq_block, n, shmem, uint3_emu{bx, by, bz});
@@ -144,6 +174,7 @@ void launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<
 {
 	const size_t total = (size_t)grid.x * grid.y * grid.z;
 	if (total == 0) return;
+	std::lock_guard<std::recursive_mutex> lock(launch_mutex);
 	const int n = launch_begin(grid, block, body);
 	static std::vector<Block*> window;
 	const char* const we = getenv("NNC_EMU_RESIDENT_BLOCKS");
@@ -182,7 +213,7 @@ void launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<
 
 struct emu_stream_s { int device; };
 struct emu_event_s { double t_ms; };
-static int g_device = 0;
+static thread_local int g_device = 0; // (HIP: the current device is per host thread -- found by the ThreadSanitizer run of the two-thread tests)
 static int device_count() { const char* e = getenv("NNC_EMU_DEVICE_COUNT"); return e ? atoi(e) : 1; }
 static double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 

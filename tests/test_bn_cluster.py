@@ -114,7 +114,8 @@ np.savez(sys.argv[1], *out)
 def test_hand_over_does_not_depend_on_dispatch_order_or_residency(emu_lib, tmp_path):
     """The emulator dispatches the workgroups forward / in reverse / shuffled, 3 to 16 of them resident: every run gives the same bits (the tickets make a
     workgroup's place in its cluster independent of where the dispatcher started it; the folds run in a fixed order)."""
-    so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    from conftest import emu_so
+    so = emu_so()
     outs = []
     for order, resident in (("forward", 16), ("reverse", 15), ("shuffle", 14), ("shuffle", 30)):
         f = tmp_path / ("%s_%d.npz" % (order, resident))

@@ -54,7 +54,8 @@ SCRIPT = textwrap.dedent("""
 
 def test_comm_two_stream_contexts_coalesced(emu_lib):
     env = dict(os.environ, NNC_EMU_DEVICE_COUNT="4")
-    so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    from conftest import emu_so
+    so = emu_so()
     r = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, so)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
@@ -110,7 +111,8 @@ SCRIPT_HALF = textwrap.dedent("""
 
 def test_comm_half_precision_rows(emu_lib):
     env = dict(os.environ, NNC_EMU_DEVICE_COUNT="4")
-    so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    from conftest import emu_so
+    so = emu_so()
     r = subprocess.run([sys.executable, "-c", SCRIPT_HALF % (ROOT, so)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
@@ -163,6 +165,56 @@ def test_comm_command_while_a_foreign_thread_launches_this_streams_recorded_comm
     # comm_exec resolved its streams with g_comm_mutex held -- stream_of() waits for a recorded command another thread is enqueueing
     # (peephole.cpp wait_launching) while that thread's launch waits for the mutex to flush the collective already recorded: a deadlock.
     env = dict(os.environ, NNC_EMU_DEVICE_COUNT="4")
-    so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    from conftest import emu_so
+    so = emu_so()
     r = subprocess.run([sys.executable, "-c", LOCK_ORDER_SCRIPT % (ROOT, so)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+STRESS_SCRIPT = textwrap.dedent("""
+    import ctypes as C, sys, threading, time, numpy as np
+    sys.path.insert(0, %r)
+    from ccv_amd import nnc
+    L = nnc.load(%r)
+    D = L.device_count()
+    assert D == 8
+    rng = np.random.default_rng(9)
+    def on(dev, arr):
+        return L.tensor(nnc.GPU_TENSOR_NHWC(dev, nnc.CCV_32F, *arr.shape), arr)
+    streams = [L.stream_new(0), L.stream_new(1), L.stream_new(2)]      # three stream contexts, on three devices
+    ar = nnc.generic_cmd("COMM_ALLREDUCE_FORWARD")
+    stop = [False]
+    def loader():                                                       # a data-loader thread: copies and frees, each an order-observing point
+        k = 0
+        while not stop[0]:
+            t = on(k %% D, np.zeros(64, np.float32)); t.free(); k += 1
+    th = threading.Thread(target=loader); th.start()
+    c0, g0 = C.c_long(), C.c_long(); L.dll.nnc_mi355x_comm_stats(C.byref(c0), C.byref(g0))
+    for step in range(2):
+        xs = [[rng.standard_normal(17 + 3 * m).astype(np.float32) for _ in range(D)] for m in range(42)]   # 42 gradient tensors x 8 devices = 336 records
+        ts = [[on(d, xs[m][d]) for d in range(D)] for m in range(42)]
+        for m in range(42):
+            assert L.cmd_exec(ar, nnc.NO_HINT, 0, ts[m], ts[m], streams[m %% 3]) == 0
+        for s in streams:
+            L.stream_wait(s)
+        for m in range(42):
+            want = sum(x.astype(np.float64) for x in xs[m])
+            for d in range(D):
+                np.testing.assert_allclose(ts[m][d].numpy(), want, rtol=1e-6, atol=1e-6)
+    stop[0] = True; th.join()
+    c1, g1 = C.c_long(), C.c_long(); L.dll.nnc_mi355x_comm_stats(C.byref(c1), C.byref(g1))
+    assert c1.value - c0.value == 2 * 336, c1.value - c0.value
+    assert g1.value - g0.value >= 2 * 3, g1.value - g0.value          # a queue of 100: at least three forced group launches per step
+    for s in streams:
+        L.stream_free(s)
+    print("OK", g1.value - g0.value)
+""")
+
+
+def test_comm_queue_overflow_on_eight_devices_three_streams_with_a_loader_thread(emu_lib):
+    """>= 300 COMM records per step on 8 emulated devices from 3 stream contexts while a second thread copies and frees (every
+    copy / free flushes the queue from that thread); the queue is cut to 100 records so that it overflows mid-step.  Every sum exact."""
+    from conftest import emu_so
+    env = dict(os.environ, NNC_EMU_DEVICE_COUNT="8", NNC_MI355X_COMM_MAX_PENDING="100")
+    r = subprocess.run([sys.executable, "-c", STRESS_SCRIPT % (ROOT, emu_so())], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -244,7 +244,8 @@ def test_two_devices_fold_independently(emu_lib):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    so = os.path.join(root, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    from conftest import emu_so
+    so = emu_so()
     r = subprocess.run([sys.executable, "-c", TWO_DEVICE_SCRIPT % (root, so)], env=dict(os.environ, NNC_EMU_DEVICE_COUNT="4"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 

@@ -35,7 +35,7 @@ for step in "$@"; do
     bench) timeout 900 python bench.py --steps $STEPS --warmup 2 --records gpurun_out/records.txt ${BENCH_ARGS} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?" >> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err;;
     config:*) n=${step#config:}; timeout 1500 python bench.py --config $n --steps $STEPS --warmup 2 ${BENCH_ARGS} > gpurun_out/bench_$n.json 2> gpurun_out/bench_$n.err; echo "exit $?" >> gpurun_out/bench_$n.err; cut -c1-1500 gpurun_out/bench_$n.json; tail -3 gpurun_out/bench_$n.err;;
     prof) prof_cmd vgg python "$PWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-via-host --no-alt-leg ${PROF_ARGS}; cp gpurun_out/kernel_stats_vgg.md gpurun_out/kernel_stats.md 2>/dev/null; head -40 gpurun_out/kernel_stats.md;;
-    prof:*) n=${step#prof:}; prof_cmd $n python "$PWD/bench.py" --config $n --steps 2 --warmup 1 ${PROF_ARGS}; head -40 gpurun_out/kernel_stats_$n.md;;
+    prof:*) n=${step#prof:}; prof_cmd $n python "$PWD/bench.py" --config $n --steps 2 --warmup 1 --no-cpu-baseline ${PROF_ARGS}; head -40 gpurun_out/kernel_stats_$n.md;;
     profhost) NNC_MI355X_PEEPHOLE_STATS=1 prof_cmd host "$PWD/oracle/_ref/host_vgg_bench.gpu" 256 225 4 1; cp gpurun_out/kernel_stats_host.md gpurun_out/via_host_kernel_stats.md 2>/dev/null; grep -i "look-ahead" gpurun_out/prof_host.log;;
     pmc) timeout 2400 tools/pmc_pass.sh;;
     int:*) s=${step#int:}; timeout 1800 python tools/ref_int_tests.py run gpu $s --timeout 180 ${INT_MATCH:+--match "$INT_MATCH"} --out "gpurun_out/ref_int_${s}${INT_MATCH:+_$(echo "$INT_MATCH" | tr -c "a-zA-Z0-9" _)}.txt" | tail -25;;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC counter passes (rocprofv3 --pmc, one small counter group per pass; never combined with sys/runtime tracing) over a
-# reduced VGG-D step.  Output: gpurun_out/pmc/<group>/... csv + gpurun_out/pmc_summary.md (per-kernel sums).
+# reduced VGG-D step (PMC_BENCH_ARGS: another bench.py command line, e.g. "--config resnet50-nchw-bs256 --steps 1 --warmup 1 --no-cpu-baseline").  Output: gpurun_out/pmc/<group>/... csv + gpurun_out/pmc_summary.md (per-kernel sums).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc
@@ -11,7 +11,7 @@ GROUPS_WANTED=${PMC_GROUPS:-mfma wait inst lds fetch write l2}
 run_pass() {
   name=$1; shift
   case " $GROUPS_WANTED " in *" $name "*) ;; *) return;; esac
-  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $OLDPWD/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-via-host --no-alt-leg > $OUT/$name.log 2>&1; echo "exit $?" >> $OUT/$name.log)
+  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $OLDPWD/bench.py ${PMC_BENCH_ARGS:---steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-via-host --no-alt-leg} > $OUT/$name.log 2>&1; echo "exit $?" >> $OUT/$name.log)
 }
 run_pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE
 run_pass wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES
