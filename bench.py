@@ -113,11 +113,37 @@ def resnet_config(args, half, dawn=False):
     exe = os.path.join(ROOT, "oracle", "_ref", "host_resnet_bench.gpu")
     if not os.path.exists(exe):
         raise SystemExit("oracle/_ref/host_resnet_bench.gpu not built (oracle/build_ref_host.sh)")
-    devices = 1 if dawn else max(1, args.gpus)  # the reference's single-process data parallelism (ccv_cnnp_model_set_data_parallel): `batch` per device
-    r = subprocess.run([exe, str(args.batch), "32" if dawn else "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"] + (["dawn"] if dawn else ["full", str(devices)]), capture_output=True, text=True, timeout=3000, env=dict(os.environ, NNC_MI355X_PEEPHOLE_STATS="1"))
-    if r.returncode != 0:
-        raise SystemExit("host_resnet_bench failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
+    gpus = max(1, args.gpus)
+    cmd = [exe, str(args.batch), "32" if dawn else "224", str(args.steps), str(max(args.warmup, 1)), "16" if half else "32"]
+    env = dict(os.environ, NNC_MI355X_PEEPHOLE_STATS="1")
+    rank_lines = None
+    if (gpus > 1 and args.dp == "process") or os.environ.get("NNC_BENCH_FORCE_COMM") == "1":  # (FORCE_COMM: the same code on a communicator of one, for a 1-GPU box)
+        # ONE PROCESS PER GPU (the default for N > 1 since round 4): N harness processes, rank r on device r, RCCL bootstrapped from an id made here; the
+        # ranks meet in the reference's multi-stage training API with one in-place all-reduce per parameter gradient (tools/host_resnet_bench.c).  One
+        # host thread feeds ~10 devices on config 4 fp32 but only ~6 on config 4-f16 and ~4 on config 5: this form does not care.
+        import ctypes as C
+        buf = C.create_string_buffer(128)
+        if nnc.load().dll.nnc_mi355x_comm_unique_id(buf) != 0:
+            raise SystemExit("ncclGetUniqueId failed")
+        devices = 1
+        procs = [subprocess.Popen(cmd + (["dawn"] if dawn else ["full"]), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  env=dict(env, HOST_BENCH_WORLD=str(gpus), HOST_BENCH_RANK=str(k), HOST_BENCH_DEVICE=str(k), HOST_BENCH_COMM_ID=buf.raw.hex())) for k in range(gpus)]
+        outs = [p.communicate(timeout=3000) for p in procs]
+        for k, (p, (so, se)) in enumerate(zip(procs, outs)):
+            if p.returncode != 0:
+                raise SystemExit("host_resnet_bench rank %d failed (%d): %s" % (k, p.returncode, (so + se)[-600:]))
+        rank_lines = [json.loads(so.strip().splitlines()[-1]) for so, _ in outs]
+        r = type("R", (), {"stdout": outs[0][0], "stderr": outs[0][1], "returncode": 0})()
+    else:
+        devices = gpus  # the reference's single-process data parallelism (ccv_cnnp_model_set_data_parallel): `batch` per device, one host thread for all of them
+        r = subprocess.run(cmd + (["dawn", str(devices)] if dawn else ["full", str(devices)]), capture_output=True, text=True, timeout=3000, env=env)
+        if r.returncode != 0:
+            raise SystemExit("host_resnet_bench failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
     h = json.loads(r.stdout.strip().splitlines()[-1])
+    if rank_lines:  # the slowest rank's clock (every rank brackets its timed steps with a cross-rank barrier + stream wait)
+        h = dict(rank_lines[0], ms_per_step=max(l["ms_per_step"] for l in rank_lines))
+        h["images_per_s"] = gpus * args.batch / (h["ms_per_step"] * 1e-3)
+        devices = gpus
     gflop = 25.97  # ResNet-50 v1d forward + backward per image (1 MAC = 2 FLOP)
     if dawn:  # DawnNet: 3x3 convolutions 3->64 @32^2, 64->128 @32^2, 2 x 128->128 @16^2, 128->256 @16^2, 256->512 @8^2, 2 x 512->512 @4^2, dense 512->10; x3 for fwd + bwd
         macs = 9 * (3 * 64 * 1024 + 64 * 128 * 1024 + 2 * 128 * 128 * 256 + 128 * 256 * 256 + 256 * 512 * 64 + 2 * 512 * 512 * 16) + 5120
@@ -127,7 +153,7 @@ def resnet_config(args, half, dawn=False):
            "dtype": "f16" if half else "f32", "data": "synthetic",
            "config": {"workload": ("CIFAR-10 DawnNet (bin/nnc/cifar-10.c:76-127) NCHW, the trainer's own step (evaluate, softmax cross-entropy, backward, apply gradients; Nesterov SGD), batch %d, random-init weights, driven by the reference host's model API" if dawn else
                                    "ResNet-50 v1d (bin/nnc/imagenet.c) NCHW forward+backward+Nesterov SGD, batch %d, random-init weights, driven by the reference host's ccv_cnnp_model_fit") % args.batch,
-                      "global_batch": args.batch * devices, "parallelism": "dp%d%s" % (devices, " (one process, ccv_cnnp_model_set_data_parallel; gradients all-reduced by the COMM_ALLREDUCE rows over RCCL)" if devices > 1 else ""), "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] / devices * gflop / 1e3,
+                      "global_batch": args.batch * devices, "parallelism": "dp%d%s" % (devices, "" if devices == 1 else " (one process per GPU; the reference's evaluate / backward / parameter_gradients_map(COMM_ALLREDUCE) / apply_gradients; RCCL ranks %s)" % [l["process_per_gpu"]["rccl_ranks"] for l in rank_lines] if rank_lines else " (one process, ccv_cnnp_model_set_data_parallel; gradients all-reduced by the COMM_ALLREDUCE rows over RCCL)"), "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] / devices * gflop / 1e3,
                       "first_step_ms": h["first_step_ms"], "outputs_finite": h["outputs_finite"], "softmax_worst_row_sum_err": h["softmax_worst_row_sum_err"], "memory_gib": h["memory_gib"]}}
     ks = h.get("kernels", [])
     bn = [k for k in ks if k["bytes"] > 0 and k["ms"] > 0]
@@ -288,6 +314,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
     ap.add_argument("--config", default="vggd-train-bs256", choices=["vggd-train-bs256", "vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512", "cifar10-dawn-f32-bs512"],
                     help="BASELINE.json configs: 3 (default, the metric), 2 (VGG-D forward only, batch 64), 4 (ResNet-50 v1d NCHW through the reference host; -f16 = the trainer's own precision), 5 (CIFAR-10 DawnNet fp16, batch 512, through the reference host)")
+    ap.add_argument("--dp", default="process", choices=["process", "host"], help="configs 4 / 5 at --gpus N > 1: one harness process per GPU (default), or the reference host's own single-process data parallelism (one host thread enqueues for all N devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-leg", action="store_true", help="skip the second timed leg with the other ReLU setting (profiling runs: one kind of step in the trace)")
     ap.add_argument("--no-fuse-relu", action="store_true", help="issue RELU_FORWARD as its own command behind every convolution (the reference host's graph does) instead of letting the convolution's epilogue rectify (NNC_MI355X_CONV_ALGO_FUSE_RELU); the other setting is always timed beside the headline one")

@@ -58,3 +58,22 @@ def test_self_launched_ranks_on_this_box():
     assert out["config"]["data_parallel_check"]["ok"], out["config"]["data_parallel_check"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--batch", "16"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and r.stdout.strip() == "" and "visible" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["resnet50-nchw-bs256", "cifar10-dawn-f16-bs512"])
+def test_process_per_gpu_form_of_configs_4_and_5_on_this_box(config):
+    """Round 4: configs 4 / 5 at --gpus N run one harness process per GPU (tools/host_resnet_bench.c with HOST_BENCH_WORLD / RANK / DEVICE / COMM_ID).  N = the
+    devices this box has; on the one-GPU box NNC_BENCH_FORCE_COMM=1 sends the single rank through the same code (RCCL communicator of one, the reference's
+    evaluate / backward / parameter_gradients_map(COMM_ALLREDUCE) / apply_gradients step, the cross-rank barrier around the timed steps)."""
+    from ccv_amd import nnc
+    n = nnc.load().device_count()
+    env = dict(os.environ, NNC_BENCH_FORCE_COMM="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and "one process per GPU" in out["config"]["parallelism"] and ("RCCL ranks %s" % ([n] * n)) in out["config"]["parallelism"], out["config"]["parallelism"]
+    assert out["config"]["outputs_finite"] and out["value"] > 0

@@ -106,13 +106,22 @@ static void nnc_mi355x_profile_enable(int on) {}
 static int nnc_mi355x_profile_count(void) { return 0; }
 static int nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5]) { return -1; }
 static long nnc_mi355x_debug_exec_count(void) { return 0; }
+static int nnc_mi355x_comm_init_rank(const void* id, int rank, int world) { return -1; }
+static int nnc_mi355x_comm_count(void) { return 0; }
+static void nnc_mi355x_comm_destroy(void) {}
 #else
-#define DEV_TENSOR_NCHW(...) GPU_TENSOR_NCHW(000, 32F, __VA_ARGS__)
+/* HOST_BENCH_DEVICE: the device this process trains on (the process-per-GPU form with every GPU visible: rank r takes device r) */
+static int g_device = 0;
+static ccv_nnc_tensor_param_t on_device(ccv_nnc_tensor_param_t p) { CCV_TENSOR_SET_DEVICE_ID(p.type, g_device); return p; }
+#define DEV_TENSOR_NCHW(...) on_device(GPU_TENSOR_NCHW(000, 32F, __VA_ARGS__))
 /* the backend's in-library launch records (include/nnc_mi355x.h) */
 void nnc_mi355x_profile_enable(int on);
 int nnc_mi355x_profile_count(void);
 int nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, double* bytes, float* ms, int dims[5]);
 long nnc_mi355x_debug_exec_count(void);
+int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size);
+int nnc_mi355x_comm_count(void);
+void nnc_mi355x_comm_destroy(void);
 #endif
 
 static float hash_unit(const uint64_t i, const uint64_t seed)
@@ -230,6 +239,29 @@ int main(int argc, char** argv)
 	 * which device it ran on. */
 	const int rot = argc > 8 ? atoi(argv[8]) : 0;
 	if (devices < 1 || devices > 8) { fprintf(stderr, "devices must be 1..8\n"); return 2; }
+	/* ONE PROCESS PER GPU (round 4): HOST_BENCH_WORLD = P processes, this one HOST_BENCH_RANK, RCCL bootstrapped from the 128-byte id in HOST_BENCH_COMM_ID
+	 * (hex; bench.py's launcher makes it with nnc_mi355x_comm_unique_id and hands it to every rank).  Each process drives ONE device with its own host thread
+	 * -- the reference's single-process form has one thread enqueue for all N devices, which is what bounds configs 4-f16 / 5 at 8 GPUs --
+	 * and the replicas meet in the reference's own multi-stage training API: evaluate, the loss commands, ccv_cnnp_model_backward, then
+	 * ccv_cnnp_model_parameter_gradients_map(COMM_ALLREDUCE_FORWARD) -- one in-place all-reduce per parameter gradient through this backend's COMM row
+	 * (cmd_comm.cpp deployment (b): the communicator spans the processes; the back-to-back commands leave as ONE RCCL group) -- and
+	 * ccv_cnnp_model_apply_gradients with the minimizer's scale 1 / (batch x P).  HOST_BENCH_WORLD=1 with HOST_BENCH_COMM_ID set runs the same code on a
+	 * communicator of one (what a one-GPU box and the emulator can check). */
+	const int world = getenv("HOST_BENCH_WORLD") ? atoi(getenv("HOST_BENCH_WORLD")) : 1, rank = getenv("HOST_BENCH_RANK") ? atoi(getenv("HOST_BENCH_RANK")) : 0;
+	const char* const comm_id = getenv("HOST_BENCH_COMM_ID");
+	const int ranks = comm_id && *comm_id ? 1 : 0; /* the process-per-GPU form */
+#ifndef HOST_BENCH_CPU
+	g_device = getenv("HOST_BENCH_DEVICE") ? atoi(getenv("HOST_BENCH_DEVICE")) : 0;
+	if (g_device != 0 && devices != 1) { fprintf(stderr, "HOST_BENCH_DEVICE with the single-process N-device form\n"); return 2; }
+#endif
+	if (ranks) {
+		unsigned char id[128];
+		int k;
+		if (devices != 1 || world < 1 || rank < 0 || rank >= world || strlen(comm_id) != 256) { fprintf(stderr, "host_resnet_bench: process-per-GPU mode wants devices = 1, 0 <= rank < world and a 256-digit id\n"); return 2; }
+		for (k = 0; k < 128; k++) { unsigned v = 0; sscanf(comm_id + 2 * k, "%2x", &v); id[k] = (unsigned char)v; }
+		const int r = nnc_mi355x_comm_init_rank(id, rank, world);
+		if (r != 0) { fprintf(stderr, "host_resnet_bench: nnc_mi355x_comm_init_rank failed (%d)\n", r); return 3; }
+	}
 #ifdef HOST_BENCH_CPU
 	g_nhwc = 1;
 #else
@@ -244,15 +276,15 @@ int main(int argc, char** argv)
 	ccv_nnc_tensor_param_t input = tensor4(DEV_TENSOR_NCHW(batch, 3, hw, hw), batch, 3, hw, hw);
 	input.datatype = dt;
 	const float lr = 0.01f, wd = 0.0001f;
-	if (is_dawn) ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / (batch * devices), 0.01, 0.9, 0), CMD_NOOP());
-	else ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / (batch * devices), wd, 0.9, 0), CMD_CATEGORICAL_CROSSENTROPY_FORWARD());
+	if (is_dawn) ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / (batch * devices * world), 0.01, 0.9, 0), CMD_NOOP());
+	else ccv_cnnp_model_compile(model, &input, 1, CMD_SGD_FORWARD(1, lr, 1. / (batch * devices * world), wd, 0.9, 0), ranks ? CMD_NOOP() : CMD_CATEGORICAL_CROSSENTROPY_FORWARD());
 	if (devices > 1) ccv_cnnp_model_set_data_parallel(model, devices);
 	/* synthetic batch: images ~ U(-1, 1) (normalised pixels), labels as the trainer's smoothed one-hot rows (eta = 0.1) */
 	ccv_nnc_tensor_t* const hx = ccv_nnc_tensor_new(0, tensor4(CPU_TENSOR_NCHW(32F, batch, 3, hw, hw), batch, 3, hw, hw), 0);
 	ccv_nnc_tensor_t* const hfit = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch, classes), 0);
 	size_t j;
 	const size_t nx = (size_t)batch * 3 * hw * hw;
-	const int shard0 = rot % devices;
+	const int shard0 = ranks ? rank : rot % devices; /* (process-per-GPU: every rank its own shard) */
 	for (j = 0; j < nx; j++) hx->data.f32[layout_index(j, 3, hw, hw)] = hash_unit(j, 2000 + 10 * shard0) * 2 - 1;
 	const float eta = 0.1f;
 	int i;
@@ -306,7 +338,9 @@ int main(int argc, char** argv)
 #ifdef HOST_BENCH_CPU
 	ccv_nnc_stream_context_t* const stream = 0;
 #else
-	ccv_nnc_stream_context_t* const stream = ccv_nnc_stream_context_new(CCV_STREAM_CONTEXT_GPU);
+	int stream_type = CCV_STREAM_CONTEXT_GPU;
+	CCV_STREAM_SET_DEVICE_ID(stream_type, g_device);
+	ccv_nnc_stream_context_t* const stream = ccv_nnc_stream_context_new(stream_type);
 #endif
 	/* reproducible parameter initialisation: the host seeds its generators from a thread-local ADDRESS otherwise (ccv_nnc_stream.c:262-281) */
 	ccv_nnc_stream_context_set_seed(0, 20240923);
@@ -359,7 +393,7 @@ int main(int argc, char** argv)
 			ccv_nnc_tensor_param_t lp = DEV_TENSOR_NCHW(batch), sp = fp;
 			CCV_TENSOR_SET_DEVICE_ID(lp.type, d); CCV_TENSOR_SET_DEVICE_ID(sp.type, d);
 			labels_d[d] = ccv_nnc_tensor_new(0, lp, 0); softmax_d[d] = ccv_nnc_tensor_new(0, sp, 0); grad_d[d] = ccv_nnc_tensor_new(0, sp, 0);
-			const int shard = (d + rot) % devices;
+			const int shard = ranks ? rank : (d + rot) % devices;
 			for (i = 0; i < batch; i++) hl->data.f32[i] = (float)(int)(hash_unit(i, 2001 + 10 * shard) * classes);
 			ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(hl), TENSOR_LIST(labels_d[d]), 0);
 		}
@@ -374,9 +408,15 @@ int main(int argc, char** argv)
 	/* end of a timed region: the stream, and -- the N-device DawnNet step runs without one -- every device's legacy stream (a blocking device-to-host
 	 * copy of a few bytes per device orders behind everything queued there) */
 	ccv_nnc_tensor_t* const sync_host = ccv_nnc_tensor_new(0, CPU_TENSOR_NCHW(32F, batch), 0);
+	ccv_nnc_tensor_t* const barrier_t = ccv_nnc_tensor_new(0, DEV_TENSOR_NCHW(16), 0);
+	ccv_nnc_cmd_exec(CMD_SET_FORWARD(0), ccv_nnc_no_hint, 0, TENSOR_LIST(), TENSOR_LIST(barrier_t), 0);
 #define SYNC_ALL() do { \
+		if (ranks) ccv_nnc_cmd_exec(CMD_COMM_ALLREDUCE_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(barrier_t), TENSOR_LIST(barrier_t), stream); /* every rank's queue has reached this point */ \
 		ccv_nnc_stream_context_wait(stream); \
 		if (!step_stream) { int d_; for (d_ = 0; d_ < devices; d_++) ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(labels_d[d_]), TENSOR_LIST(sync_host), 0); } \
+	} while (0)
+#define ALLREDUCE_GRADIENTS() do { \
+		if (ranks) ccv_cnnp_model_parameter_gradients_map(model, ccv_cnnp_model_parameters(model, ALL_PARAMETERS, ALL_PARAMETERS), CMD_COMM_ALLREDUCE_FORWARD(), ccv_nnc_no_hint, 0, 0, 0, 0, 0, step_stream); \
 	} while (0)
 #define TRAIN_STEP() do { \
 		if (is_dawn) { \
@@ -387,6 +427,13 @@ int main(int argc, char** argv)
 				ccv_nnc_cmd_exec(CMD_SOFTMAX_CROSSENTROPY_BACKWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(0, 0, outs[d_], labels_d[d_], 0, softmax_d[d_]), TENSOR_LIST(grad_d[d_], 0), step_stream); \
 			} \
 			ccv_cnnp_model_backward(model, grad_d, devices, TENSOR_LIST(), 0, step_stream); \
+			ALLREDUCE_GRADIENTS(); \
+			ccv_cnnp_model_apply_gradients(model, step_stream); \
+		} else if (ranks) { /* the ResNet trainer's step in the multi-stage form: the loss the fit call compiles in, issued by hand on the softmax outputs */ \
+			ccv_cnnp_model_evaluate(model, (ccv_cnnp_evaluate_param_t){ .requires_grad = 1, .disable_outgrad = CCV_CNNP_DISABLE_OUTGRAD_ALL }, xs, 1, outs, 1, 0, step_stream); \
+			ccv_nnc_cmd_exec(CMD_CATEGORICAL_CROSSENTROPY_BACKWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(0, outs[0], fits[0]), TENSOR_LIST(grad_d[0]), step_stream); \
+			ccv_cnnp_model_backward(model, grad_d, 1, TENSOR_LIST(), 0, step_stream); \
+			ALLREDUCE_GRADIENTS(); \
 			ccv_cnnp_model_apply_gradients(model, step_stream); \
 		} else \
 			ccv_cnnp_model_fit(model, xs, devices, fits, devices, outs, devices, 0, stream); \
@@ -547,8 +594,8 @@ int main(int argc, char** argv)
 	for (i = 0; i < devices; i++) printf("%s%.17g", i ? ", " : "", dev_sum[i]);
 	printf("], ");
 	printf("\"driver\": \"reference host (ccv_cnnp_model_fit: cnnp, autodiff, compile, scheduler)\", \"model\": \"%s\", \"dtype\": \"%s\", \"format\": \"NCHW\", \"batch\": %d, \"input_hw\": %d, "
-		"\"devices\": %d, \"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"host_enqueue\": {\"ms_per_step_median\": %.4f, \"ms_per_step_min\": %.4f, \"drained_step_ms\": %.4f, \"commands_per_step\": %ld, \"us_per_command\": %.3f}, \"first_step_ms\": %.1f, \"softmax_row0_sum\": %.6f, \"softmax_worst_row_sum_err\": %.3g, \"outputs_finite\": %s, \"memory_gib\": %.3f}\n",
-		is_dawn ? "CIFAR-10 DawnNet (bin/nnc/cifar-10.c)" : mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, devices, ms, (double)batch * devices / (ms * 1e-3), enq_ms[2], enq_ms[0], enq_step_ms[2], enq_cmds, enq_cmds > 0 ? enq_ms[2] * 1e3 / enq_cmds : 0.0, t_first, row0, worst, finite ? "true" : "false",
+		"\"devices\": %d, \"process_per_gpu\": {\"world\": %d, \"rank\": %d, \"rccl_ranks\": %d}, \"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"host_enqueue\": {\"ms_per_step_median\": %.4f, \"ms_per_step_min\": %.4f, \"drained_step_ms\": %.4f, \"commands_per_step\": %ld, \"us_per_command\": %.3f}, \"first_step_ms\": %.1f, \"softmax_row0_sum\": %.6f, \"softmax_worst_row_sum_err\": %.3g, \"outputs_finite\": %s, \"memory_gib\": %.3f}\n",
+		is_dawn ? "CIFAR-10 DawnNet (bin/nnc/cifar-10.c)" : mini ? "resnet-mini (2 bottlenecks)" : "ResNet-50 v1d", half ? "f16" : "f32", batch, hw, devices, ranks ? world : 0, rank, ranks ? nnc_mi355x_comm_count() : 0, ms, (double)batch * devices / (ms * 1e-3), enq_ms[2], enq_ms[0], enq_step_ms[2], enq_cmds, enq_cmds > 0 ? enq_ms[2] * 1e3 / enq_cmds : 0.0, t_first, row0, worst, finite ? "true" : "false",
 		(double)ccv_cnnp_model_memory_size(model) / (1024.0 * 1024.0 * 1024.0));
 	for (i = 0; i < devices; i++) { ccv_nnc_tensor_free(labels_d[i]); ccv_nnc_tensor_free(softmax_d[i]); ccv_nnc_tensor_free(grad_d[i]); }
 	ccv_nnc_tensor_free(hout);
