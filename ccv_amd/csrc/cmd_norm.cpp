@@ -455,11 +455,12 @@ __device__ __forceinline__ void cluster_collect(const unsigned long long* const 
 }
 // chunk q of a channel -> byte offset from the channel's first plane (image n = q / nv, chunk i = q % nv of its plane); q >= q1 -> out of the descriptor's
 // range: the load returns zeros, the store is dropped (no branch around either)
+template <int CB>
 __device__ __forceinline__ unsigned cluster_chunk_voff(const bn_cluster_geom_t& g, const unsigned q, const unsigned q1)
 {
 	const unsigned n = __umulhi(q, g.magic);
 	const unsigned i = q - n * g.nv;
-	return (n * g.image_bytes + i * 16u) | (q < q1 ? 0u : 0xffffffffu); // (an OR with a select: hipcc turned the plain select into a branch per chunk)
+	return (n * g.image_bytes + i * (unsigned)CB) | (q < q1 ? 0u : 0xffffffffu); // (an OR with a select: hipcc turned the plain select into a branch per chunk)
 }
 template <class T>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t cluster_rsrc(const T* const p, const bn_cluster_geom_t& g, const unsigned c)
@@ -471,12 +472,52 @@ __device__ __forceinline__ void cluster_finish(cluster_sync_t* const sync, const
 {
 	if (threadIdx.x == 0 && nnc_fetch_add_agent(&sync->done, 1) == grid - 1) { nnc_store_agent(&sync->ticket, 0); nnc_store_agent(&sync->done, 0); }
 }
+// One chunk: CB = 16, 8 or 4 bytes as they arrived (kept as dwords: as a vector of halves hipcc unpacks every chunk into one register per element on
+// arrival).  CB is the largest power of two that divides a plane's byte size and the tensors' alignment: 16 for ResNet's 56 x 56 .. 14 x 14 fp32 planes, 8 for
+// its 14 x 14 half planes (392 bytes), 4 for the 7 x 7 fp32 planes (196 bytes).
+typedef unsigned int bn_u2 __attribute__((ext_vector_type(2)));
+template <class T, int CB>
+struct bn_chunk_t {
+	static constexpr int E = CB / (int)sizeof(T); // elements
+	unsigned d[CB / 4];
+	__device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t rs, const unsigned voff)
+	{
+		if constexpr (CB == 16) { const bn_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+		else if constexpr (CB == 8) { const bn_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0); d[0] = v[0]; d[1] = v[1]; }
+		else d[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0);
+	}
+	__device__ __forceinline__ void store(const __amdgpu_buffer_rsrc_t rs, const unsigned voff) const
+	{
+		if constexpr (CB == 16) __builtin_amdgcn_raw_buffer_store_b128(bn_u4{ d[0], d[1], d[2], d[3] }, rs, voff, 0, 0);
+		else if constexpr (CB == 8) __builtin_amdgcn_raw_buffer_store_b64(bn_u2{ d[0], d[1] }, rs, voff, 0, 0);
+		else __builtin_amdgcn_raw_buffer_store_b32(d[0], rs, voff, 0, 0);
+	}
+	// an opaque "new" value: otherwise the halves converted for one pass stay converted -- a register per element -- for the next
+	__device__ __forceinline__ void pin()
+	{
+#pragma unroll
+		for (int k = 0; k < CB / 4; k++) NNC_PIN_V(d[k]);
+	}
+	__device__ __forceinline__ float get(const int e) const
+	{
+		if constexpr (sizeof(T) == 4) return __uint_as_float(d[e]);
+		else return (float)__builtin_bit_cast(half_t, (unsigned short)(d[e >> 1] >> (16 * (e & 1))));
+	}
+	__device__ __forceinline__ void set(const int e, const float v)
+	{
+		if constexpr (sizeof(T) == 4) d[e] = __float_as_uint(v);
+		else {
+			const unsigned h = (unsigned)__builtin_bit_cast(unsigned short, (half_t)v);
+			d[e >> 1] = (e & 1) ? (d[e >> 1] & 0xffffu) | (h << 16) : (d[e >> 1] & 0xffff0000u) | h;
+		}
+	}
+};
 
-template <class T, int NV>
+template <class T, int CB, int NV>
 __global__ void __launch_bounds__(256, 4) bn_cluster_forw_kernel(const T* __restrict__ x, T* __restrict__ y, const bn_cluster_geom_t g, cluster_sync_t* const sync, const unsigned epoch, unsigned* const timeout_word, const float* __restrict__ scale, const float* __restrict__ bias, float* mean, float* var, float* __restrict__ saved_mean, float* __restrict__ saved_inv_std, const float inv_b, const float mom, const float eps, const int relu)
 {
-	constexpr int W = 16 / sizeof(T);
-	typedef typename pack16<T>::type V;
+	typedef bn_chunk_t<T, CB> chunk_t;
+	constexpr int W = chunk_t::E;
 	HIP_DYNAMIC_SHARED(float, lds)
 	float* const red = lds;                 // [4] + ticket
 	float* const part = lds + 8;            // [G][2]
@@ -488,18 +529,17 @@ __global__ void __launch_bounds__(256, 4) bn_cluster_forw_kernel(const T* __rest
 	const unsigned c = ticket / g.G, w = ticket - c * g.G;
 	const unsigned q0 = w * g.per, q1 = q0 + g.per < g.Q ? q0 + g.per : g.Q;
 	const __amdgpu_buffer_rsrc_t rx = cluster_rsrc(x, g, c), ry = cluster_rsrc(y, g, c);
-	bn_u4 raw[NV]; // (kept as the four dwords that arrived: as a vector of eight halves hipcc unpacks every chunk into eight registers on arrival)
+	chunk_t raw[NV];
 #pragma unroll
-	for (int j = 0; j < NV; j++) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, cluster_chunk_voff(g, q0 + t + 256 * j, q1), 0, 0);
+	for (int j = 0; j < NV; j++) raw[j].load(rx, cluster_chunk_voff<CB>(g, q0 + t + 256 * j, q1));
 	// (chunks past the share's end were loaded as zeros: they add nothing to the sum, and the second moment skips them by a select, not a branch --
 	// per-chunk lane masks would cost 2 SGPRs each; the sched_barriers keep hipcc from converting / centring every chunk at once, which spills)
 	const int nj = q1 > q0 + t ? (int)((q1 - q0 - t + 255) >> 8) : 0; // chunks this thread holds
 	float s = 0.f;
 #pragma unroll
 	for (int j = 0; j < NV; j++) {
-		const V vj = __builtin_bit_cast(V, raw[j]);
 #pragma unroll
-		for (int e = 0; e < W; e++) s += (float)vj[e];
+		for (int e = 0; e < W; e++) s += raw[j].get(e);
 		__builtin_amdgcn_sched_barrier(0);
 	}
 	const float cnt = (float)(q1 - q0) * (float)W;
@@ -509,10 +549,9 @@ __global__ void __launch_bounds__(256, 4) bn_cluster_forw_kernel(const T* __rest
 #pragma unroll
 	for (int j = 0; j < NV; j++) {
 		const bool on = j < nj;
-		NNC_PIN_VEC(raw[j]); // (an opaque "new" value: otherwise the halves converted for the first sum stay converted -- eight registers per chunk -- for this pass)
-		const V vj = __builtin_bit_cast(V, raw[j]);
+		raw[j].pin();
 #pragma unroll
-		for (int e = 0; e < W; e++) { const float d = (float)vj[e] - m_w; m2 += on ? d * d : 0.f; }
+		for (int e = 0; e < W; e++) { const float d = raw[j].get(e) - m_w; m2 += on ? d * d : 0.f; }
 		__builtin_amdgcn_sched_barrier(0);
 	}
 	const float m2_w = cluster_block_sum(m2, red);
@@ -550,27 +589,28 @@ __global__ void __launch_bounds__(256, 4) bn_cluster_forw_kernel(const T* __rest
 		mean[c] = mom * mean[c] + (1.f - mom) * mu;
 		var[c] = mom * var[c] + (1.f - mom) * vb;
 	}
-	unsigned ts = t; // the stores' offsets are computed again (a few integer operations per chunk) instead of living in 20 registers since the loads
+	unsigned ts = t; // the stores' offsets are computed again (a few integer operations per chunk) instead of living in registers since the loads
 	NNC_PIN_V(ts);
 #pragma unroll
 	for (int j = 0; j < NV; j++) {
-		V r;
-		NNC_PIN_VEC(raw[j]);
-		const V vj = __builtin_bit_cast(V, raw[j]);
+		chunk_t r;
+		raw[j].pin();
 #pragma unroll
-		for (int e = 0; e < W; e++) { const float o = (float)vj[e] * ws + bs; r[e] = (T)(relu && !(o > 0.f) ? 0.f : o); }
-		__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bn_u4, r), ry, cluster_chunk_voff(g, q0 + ts + 256 * j, q1), 0, 0);
+		for (int k = 0; k < CB / 4; k++) r.d[k] = 0;
+#pragma unroll
+		for (int e = 0; e < W; e++) { const float o = raw[j].get(e) * ws + bs; r.set(e, relu && !(o > 0.f) ? 0.f : o); }
+		r.store(ry, cluster_chunk_voff<CB>(g, q0 + ts + 256 * j, q1));
 		__builtin_amdgcn_sched_barrier(0);
 	}
 	cluster_finish(sync, g.grid);
 }
 
 // backward: sum of g and of xhat * g over the channel (fused, one pass over the registers), then h = (scale * inv_std / B) * (B * g - dbias - xhat * dscale)
-template <class T, int NV>
+template <class T, int CB, int NV>
 __global__ void __launch_bounds__(256, 4) bn_cluster_back_kernel(const T* __restrict__ x, const T* __restrict__ gr, T* __restrict__ h, const bn_cluster_geom_t g, cluster_sync_t* const sync, const unsigned epoch, unsigned* const timeout_word, const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ inv_std, float* __restrict__ dscale, float* __restrict__ dbias, const float B)
 {
-	constexpr int W = 16 / sizeof(T);
-	typedef typename pack16<T>::type V;
+	typedef bn_chunk_t<T, CB> chunk_t;
+	constexpr int W = chunk_t::E;
 	HIP_DYNAMIC_SHARED(float, lds)
 	float* const red = lds;
 	float* const part = lds + 8;
@@ -582,21 +622,20 @@ __global__ void __launch_bounds__(256, 4) bn_cluster_back_kernel(const T* __rest
 	const unsigned c = ticket / g.G, w = ticket - c * g.G;
 	const unsigned q0 = w * g.per, q1 = q0 + g.per < g.Q ? q0 + g.per : g.Q;
 	const __amdgpu_buffer_rsrc_t rx = cluster_rsrc(x, g, c), rg = cluster_rsrc(gr, g, c), rh = cluster_rsrc(h, g, c);
-	bn_u4 xraw[NV], graw[NV];
+	chunk_t xraw[NV], graw[NV];
 #pragma unroll
 	for (int j = 0; j < NV; j++) {
-		const unsigned voff = cluster_chunk_voff(g, q0 + t + 256 * j, q1);
-		xraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
-		graw[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, voff, 0, 0);
+		const unsigned voff = cluster_chunk_voff<CB>(g, q0 + t + 256 * j, q1);
+		xraw[j].load(rx, voff);
+		graw[j].load(rg, voff);
 	}
 	const float mu = mean[c], is = inv_std[c];
 	float sg = 0.f, sx = 0.f; // (chunks past the share's end are zeros in g: they add nothing to either sum)
 #pragma unroll
 	for (int j = 0; j < NV; j++) {
-		NNC_PIN_VEC(xraw[j]); NNC_PIN_VEC(graw[j]);
-		const V xj = __builtin_bit_cast(V, xraw[j]), gj = __builtin_bit_cast(V, graw[j]);
+		xraw[j].pin(); graw[j].pin();
 #pragma unroll
-		for (int e = 0; e < W; e++) { const float gg = (float)gj[e]; sg += gg; sx += ((float)xj[e] - mu) * is * gg; }
+		for (int e = 0; e < W; e++) { const float gg = graw[j].get(e); sg += gg; sx += (xraw[j].get(e) - mu) * is * gg; }
 		__builtin_amdgcn_sched_barrier(0);
 	}
 	const float sg_w = cluster_block_sum(sg, red);
@@ -621,41 +660,44 @@ __global__ void __launch_bounds__(256, 4) bn_cluster_back_kernel(const T* __rest
 	NNC_PIN_V(ts);
 #pragma unroll
 	for (int j = 0; j < NV; j++) {
-		V r;
-		NNC_PIN_VEC(xraw[j]); NNC_PIN_VEC(graw[j]);
-		const V xj = __builtin_bit_cast(V, xraw[j]), gj = __builtin_bit_cast(V, graw[j]);
+		chunk_t r;
+		xraw[j].pin(); graw[j].pin();
 #pragma unroll
-		for (int e = 0; e < W; e++) { const float xhat = ((float)xj[e] - mu) * is; r[e] = (T)(k * (B * (float)gj[e] - db - xhat * ds)); }
-		__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bn_u4, r), rh, cluster_chunk_voff(g, q0 + ts + 256 * j, q1), 0, 0);
+		for (int kk = 0; kk < CB / 4; kk++) r.d[kk] = 0;
+#pragma unroll
+		for (int e = 0; e < W; e++) { const float xhat = (xraw[j].get(e) - mu) * is; r.set(e, k * (B * graw[j].get(e) - db - xhat * ds)); }
+		r.store(rh, cluster_chunk_voff<CB>(g, q0 + ts + 256 * j, q1));
 		__builtin_amdgcn_sched_barrier(0);
 	}
 	cluster_finish(sync, g.grid);
 }
 
-// Can the cluster kernels take this tensor, and with which geometry?  nv_per_thread: chunks a thread may hold.
+// Can the cluster kernels take this tensor, and with which geometry?  CB: bytes per chunk (16 / 8 / 4: the largest that divides the plane's bytes and the
+// pointers); chunks_per_thread: what a thread may hold at CB = 16 (twice / four times as many at 8 / 4: the same registers).
 template <class T>
-static bool bn_cluster_plan(const chan_view_t& v, const int nv_per_thread, const void* p0, const void* p1, const void* p2, bn_cluster_geom_t* g)
+static int bn_cluster_plan(const chan_view_t& v, const int chunks_per_thread, const void* p0, const void* p1, const void* p2, bn_cluster_geom_t* g)
 {
-	constexpr int W = 16 / (int)sizeof(T);
 	const long mode = tune(TUNE_BN_CLUSTER);
-	if (mode <= 0 || v.inner <= 1 || v.inner % W != 0 || v.C < 1 || v.outer < 1) return false;
-	if ((((uintptr_t)p0) | ((uintptr_t)p1) | ((uintptr_t)p2)) & 15) return false;
-	const long nv = v.inner / W, Q = v.outer * nv;
+	if (mode <= 0 || v.inner <= 1 || v.C < 1 || v.outer < 1) return 0;
+	const uintptr_t bits = ((uintptr_t)p0) | ((uintptr_t)p1) | ((uintptr_t)p2) | (uintptr_t)(v.inner * (long)sizeof(T));
+	const int CB = (bits & 15) == 0 ? 16 : (bits & 7) == 0 ? 8 : (bits & 3) == 0 ? 4 : 0;
+	if (!CB) return 0;
+	const long nv = v.inner * (long)sizeof(T) / CB, Q = v.outer * nv;
 	const unsigned long long bytes = (unsigned long long)v.outer * v.C * v.inner * sizeof(T);
-	if (bytes > 0xfffffff0ull) return false; // 32-bit byte offsets
-	if (nv > 0xfffff || Q > 0x7fffffffL || (unsigned long long)Q * (unsigned long long)nv >= (1ull << 32)) return false;
-	long cap = 256L * nv_per_thread; // chunks one workgroup holds
+	if (bytes > 0xfffffff0ull) return 0; // 32-bit byte offsets
+	if (nv > 0xfffff || Q > 0x7fffffffL || (unsigned long long)Q * (unsigned long long)nv >= (1ull << 32)) return 0;
+	long cap = 256L * chunks_per_thread * (16 / CB); // chunks one workgroup holds
 	if (mode > 1 && mode < cap) cap = mode; // (tests: several workgroups per channel on small tensors)
 	long G = (Q + cap - 1) / cap;
-	if (G > BN_CLUSTER_MAX_G) return false;
+	if (G > BN_CLUSTER_MAX_G) return 0;
 	const long per = (Q + G - 1) / G;
 	G = (Q + per - 1) / per; // no empty workgroup
 	const long grid = (long)v.C * G;
-	if (grid > 0x7fffffffL || (size_t)grid * 16 > CLUSTER_SYNC_BYTES - 256) return false;
+	if (grid > 0x7fffffffL || (size_t)grid * 16 > CLUSTER_SYNC_BYTES - 256) return 0;
 	g->C = v.C; g->inner = v.inner; g->nv = (unsigned)nv; g->magic = (unsigned)((1ull << 32) / (unsigned long long)nv) + 1u;
 	g->Q = (unsigned)Q; g->per = (unsigned)per; g->G = (unsigned)G; g->grid = (unsigned)grid;
 	g->bytes = (unsigned)bytes; g->image_bytes = (unsigned)((unsigned long long)v.C * v.inner * sizeof(T));
-	return true;
+	return CB;
 }
 
 // Derive the [outer][C][inner] view of x from the statistics tensor.
@@ -738,13 +780,15 @@ static int bnorm_forw_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 		if ((int)tensor_count(outputs[3]->info) != v.C || (int)tensor_count(outputs[4]->info) != v.C) return CCV_NNC_EXEC_INVALID;
 		const float inv_b = 1.f / (float)(n / v.C);
 		bn_cluster_geom_t cg;
-		if (bn_cluster_plan<T>(v, BN_CLUSTER_NV, xp, yp, 0, &cg)) { // a cluster of workgroups per channel: x read once (round 4)
+		if (const int CB = bn_cluster_plan<T>(v, BN_CLUSTER_NV, xp, yp, 0, &cg)) { // a cluster of workgroups per channel: x read once (round 4)
 			unsigned epoch = 0;
 			unsigned* timeout_word = 0;
 			cluster_sync_t* const sync = (cluster_sync_t*)cluster_sync_of(stream_context, (size_t)cg.grid * 16, &epoch, &timeout_word);
 			if (sync) {
-				const auto kernel = bn_cluster_forw_kernel<T, BN_CLUSTER_NV>; // (a name without commas for the launch macros)
-				NNC_LAUNCH_CONCURRENT(kernel, dim3(cg.grid), dim3(256), BN_CLUSTER_LDS, stream, xp, yp, cg, sync, epoch, timeout_word, scale, bias, mean, var, saved_mean, saved_inv_std, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon, relu);
+#define BN_CL_FWD(CBV) do { const auto kernel = bn_cluster_forw_kernel<T, CBV, BN_CLUSTER_NV * (16 / CBV)>; /* (a name without commas for the launch macros) */ \
+					NNC_LAUNCH_CONCURRENT(kernel, dim3(cg.grid), dim3(256), BN_CLUSTER_LDS, stream, xp, yp, cg, sync, epoch, timeout_word, scale, bias, mean, var, saved_mean, saved_inv_std, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon, relu); } while (0)
+				if (CB == 16) BN_CL_FWD(16); else if (CB == 8) BN_CL_FWD(8); else BN_CL_FWD(4);
+#undef BN_CL_FWD
 				HIP_ENFORCE(hipGetLastError());
 				++g_bn_cluster_launches;
 				return CCV_NNC_EXEC_SUCCESS;
@@ -832,13 +876,15 @@ static int bnorm_back_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 	int ret;
 	ProfScope prof("bnorm_bwd|nnc::chan_reduce + bn_back_kernel", 0, 3.0 * sizeof(T) * (double)n, (int)(n / v.C), v.C, 1, 1, 1, stream_of(stream_context)); // g, x read; h written
 	bn_cluster_geom_t cg;
-	if (bn_cluster_plan<T>(v, BN_CLUSTER_NV / 2, xp, gp, hp, &cg)) { // a cluster of workgroups per channel: x and g read once (round 4)
+	if (const int CB = bn_cluster_plan<T>(v, BN_CLUSTER_NV / 2, xp, gp, hp, &cg)) { // a cluster of workgroups per channel: x and g read once (round 4)
 		unsigned epoch = 0;
 		unsigned* timeout_word = 0;
 		cluster_sync_t* const sync = (cluster_sync_t*)cluster_sync_of(stream_context, (size_t)cg.grid * 16, &epoch, &timeout_word);
 		if (sync) {
-			const auto kernel = bn_cluster_back_kernel<T, BN_CLUSTER_NV / 2>;
-			NNC_LAUNCH_CONCURRENT(kernel, dim3(cg.grid), dim3(256), BN_CLUSTER_LDS, stream_of(stream_context), xp, gp, hp, cg, sync, epoch, timeout_word, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, dscale->data.f32, dbias->data.f32, (float)(n / v.C));
+#define BN_CL_BWD(CBV) do { const auto kernel = bn_cluster_back_kernel<T, CBV, (BN_CLUSTER_NV / 2) * (16 / CBV)>; \
+				NNC_LAUNCH_CONCURRENT(kernel, dim3(cg.grid), dim3(256), BN_CLUSTER_LDS, stream_of(stream_context), xp, gp, hp, cg, sync, epoch, timeout_word, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, dscale->data.f32, dbias->data.f32, (float)(n / v.C)); } while (0)
+			if (CB == 16) BN_CL_BWD(16); else if (CB == 8) BN_CL_BWD(8); else BN_CL_BWD(4);
+#undef BN_CL_BWD
 			HIP_ENFORCE(hipGetLastError());
 			++g_bn_cluster_launches;
 			return CCV_NNC_EXEC_SUCCESS;

@@ -182,10 +182,39 @@ static int launch_permute(const void* in, void* out, const perm4_t& p, ccv_nnc_s
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
+// Filters between [K][C][kh * kw] (the NCHW tensors' filter layout) and [K][kh * kw][C]: per output channel a [R][S] -> [S][R] transpose of a few KB whose one
+// side is 9 (or 49) long.  Through the 64 x 64 tile kernel above that is a grid of K x ceil(C / 64) workgroups with 9 of every 64 lanes working: ~28 us per
+// call on ResNet-50's filters, three calls per convolution per step (forward, data gradient, filter gradient back) -- 1.5 ms of config 4's step for 100 MB.
+// Here: one workgroup per filter; the R * S contiguous words come in as they lie (coalesced), cross through LDS, and leave as they will lie (coalesced).
+constexpr int WT_BYTES = 65536; // one matrix in LDS: 512 x 9 or 1024 x 9 floats, 128 x 49 floats, 512 x 49 halves ...
+template <typename T>
+__global__ void __launch_bounds__(256) filter_transpose_kernel(const T* __restrict__ in, T* __restrict__ out, const int R, const int S)
+{
+	__shared__ T buf[WT_BYTES / sizeof(T)];
+	const int n = R * S;
+	const size_t base = (size_t)blockIdx.x * n;
+	for (int i = threadIdx.x; i < n; i += 256) buf[i] = in[base + i];
+	__syncthreads();
+	for (int o = threadIdx.x; o < n; o += 256) { // o = s * R + r  <-  r * S + s
+		const int s_ = o / R, r = o - s_ * R;
+		out[base + o] = buf[r * S + s_];
+	}
+}
+template <typename T>
+static bool filter_transpose_fits(const int R, const int S) { return (R < 64 || S < 64) && (long)R * S * (long)sizeof(T) <= WT_BYTES; }
+template <typename T>
+static int filter_transpose(const void* in, void* out, int K, int R, int S, ccv_nnc_stream_context_t* ctx)
+{
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_transpose_kernel<T>), dim3(K), dim3(256), 0, stream_of(ctx), (const T*)in, (T*)out, R, S);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 template <typename T>
 static int launch_transpose(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
 {
 	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;
+	if (filter_transpose_fits<T>(R, C)) return filter_transpose<T>(in, out, batch, R, C, ctx); // (thin matrices: one workgroup each, see above)
 	if constexpr (sizeof(T) == 4) {
 		if (R % 4 == 0 && C % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_tile_vec4_kernel<T>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const T*)in, (T*)out, R, C);
@@ -291,38 +320,13 @@ int transpose_float_to_half(const float* in, void* out, int batch, int R, int C,
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
-// Filters between [K][C][kh * kw] (the NCHW tensors' filter layout) and [K][kh * kw][C]: per output channel a [R][S] -> [S][R] transpose of a few KB whose one
-// side is 9 (or 49) long.  Through the 64 x 64 tile kernel above that is a grid of K x ceil(C / 64) workgroups with 9 of every 64 lanes working: ~28 us per
-// call on ResNet-50's filters, three calls per convolution per step (forward, data gradient, filter gradient back) -- 1.5 ms of config 4's step for 100 MB.
-// Here: one workgroup per filter; the R * S contiguous words come in as they lie (coalesced), cross through LDS, and leave as they will lie (coalesced).
-constexpr int WT_MAX = 12288; // words of one filter in LDS (48 KB): 512 x 9, 1024 x 9, 128 x 49 ...
-__global__ void __launch_bounds__(256) filter_transpose_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const int R, const int S)
-{
-	__shared__ uint32_t buf[WT_MAX];
-	const int n = R * S;
-	const size_t base = (size_t)blockIdx.x * n;
-	for (int i = threadIdx.x; i < n; i += 256) buf[i] = in[base + i];
-	__syncthreads();
-	for (int o = threadIdx.x; o < n; o += 256) { // o = s * R + r  <-  r * S + s
-		const int s_ = o / R, r = o - s_ * R;
-		out[base + o] = buf[r * S + s_];
-	}
-}
-static int filter_transpose(const float* w, float* out, int K, int R, int S, ccv_nnc_stream_context_t* ctx)
-{
-	if (K <= 0 || R <= 0 || S <= 0) return CCV_NNC_EXEC_SUCCESS;
-	if ((long)R * S > WT_MAX || (R >= 64 && S >= 64)) return launch_transpose<uint32_t>(w, out, K, R, S, ctx);
-	hipLaunchKernelGGL(filter_transpose_kernel, dim3(K), dim3(256), 0, stream_of(ctx), (const uint32_t*)w, (uint32_t*)out, R, S);
-	HIP_ENFORCE(hipGetLastError());
-	return CCV_NNC_EXEC_SUCCESS;
-}
 int weights_nchw_to_nhwc(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx)
 {
-	return filter_transpose(w, out, K, C, khw, ctx);
+	return launch_transpose<uint32_t>(w, out, K, C, khw, ctx);
 }
 int weights_nhwc_to_nchw(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx)
 {
-	return filter_transpose(w, out, K, khw, C, ctx);
+	return launch_transpose<uint32_t>(w, out, K, khw, C, ctx);
 }
 
 } // namespace nnc

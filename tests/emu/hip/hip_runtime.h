@@ -208,6 +208,22 @@ static inline emu_u4 __builtin_amdgcn_raw_buffer_load_b128(emu_buffer_rsrc r, un
 	return v;
 }
 typedef unsigned int emu_u2 __attribute__((ext_vector_type(2)));
+static inline emu_u2 __builtin_amdgcn_raw_buffer_load_b64(emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
+{ // (range check per dword, as for the 16-byte load)
+	emu_u2 v = { 0u, 0u };
+	for (int d = 0; d < 2; d++) {
+		const unsigned long long off = (unsigned long long)voffset + soffset + 4ull * d;
+		if ((unsigned long long)voffset + 4ull * d + 4 > r.num_records || off + 4 > r.num_records) continue;
+		unsigned w; memcpy(&w, r.base + off, 4); v[d] = w;
+	}
+	return v;
+}
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
+{
+	unsigned w = 0;
+	if ((unsigned long long)voffset + 4 <= r.num_records && (unsigned long long)voffset + soffset + 4 <= r.num_records) memcpy(&w, r.base + voffset + soffset, 4);
+	return w;
+}
 static inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u2 v, emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int)
 {
 	if ((unsigned long long)voffset + 8 > r.num_records || (unsigned long long)voffset + soffset + 8 > r.num_records) return;

@@ -37,6 +37,7 @@ def _run(lib, mem, x, g, scale, bias, mean, var, sshape, backend_id=None, relu=F
 
 CASES = [  # (N, C, H, W), chunks per workgroup (0 = the kernels' own capacity: one workgroup per channel at these sizes)
     ((4, 6, 8, 8), 0), ((4, 6, 8, 8), 16), ((3, 5, 6, 10), 7), ((5, 3, 12, 12), 33), ((2, 4, 40, 44), 100), ((7, 2, 4, 4), 2), ((6, 5, 14, 14), 64),
+    ((5, 6, 7, 7), 0), ((5, 6, 7, 7), 60), ((3, 4, 5, 6), 11),  # planes that are not whole 16-byte chunks: 8-byte / 4-byte chunks (7 x 7 fp32: 196 bytes, 14 x 14 halves: 392)
 ]
 
 
@@ -51,8 +52,8 @@ def test_batch_norm_cluster_kernels(backend, ref_lib, shape, cap, dtype, relu):
     g = rng.standard_normal(shape).astype(T)
     scale, bias = (rng.random(C, dtype=F) + F(1.0)), (rng.random(C, dtype=F) - F(0.5))
     mean, var = (rng.random(C, dtype=F) - F(0.5)), rng.random(C, dtype=F) + F(0.5)
-    if shape[2] * shape[3] % (4 if T is F else 8) != 0:
-        pytest.skip("planes of whole 16-byte chunks only")
+    if shape[2] * shape[3] * np.dtype(T).itemsize % 4 != 0:
+        pytest.skip("planes of whole dwords only (7 x 7 halves: the plane kernels)")
     old = backend.tune_get("BN_CLUSTER")
     n0 = backend.dll.nnc_mi355x_debug_bn_cluster_launches()
     try:
