@@ -153,7 +153,7 @@ def resnet_config(args, half, dawn=False):
            "dtype": "f16" if half else "f32", "data": "synthetic",
            "config": {"workload": ("CIFAR-10 DawnNet (bin/nnc/cifar-10.c:76-127) NCHW, the trainer's own step (evaluate, softmax cross-entropy, backward, apply gradients; Nesterov SGD), batch %d, random-init weights, driven by the reference host's model API" if dawn else
                                    "ResNet-50 v1d (bin/nnc/imagenet.c) NCHW forward+backward+Nesterov SGD, batch %d, random-init weights, driven by the reference host's ccv_cnnp_model_fit") % args.batch,
-                      "global_batch": args.batch * devices, "parallelism": "dp%d%s" % (devices, "" if devices == 1 else " (one process per GPU; the reference's evaluate / backward / parameter_gradients_map(COMM_ALLREDUCE) / apply_gradients; RCCL ranks %s)" % [l["process_per_gpu"]["rccl_ranks"] for l in rank_lines] if rank_lines else " (one process, ccv_cnnp_model_set_data_parallel; gradients all-reduced by the COMM_ALLREDUCE rows over RCCL)"), "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] / devices * gflop / 1e3,
+                      "global_batch": args.batch * devices, "parallelism": "dp%d%s" % (devices, (" (one process per GPU; the reference's evaluate / backward / parameter_gradients_map(COMM_ALLREDUCE) / apply_gradients; RCCL ranks %s)" % [l["process_per_gpu"]["rccl_ranks"] for l in rank_lines]) if rank_lines else (" (one process, ccv_cnnp_model_set_data_parallel; gradients all-reduced by the COMM_ALLREDUCE rows over RCCL)" if devices > 1 else "")), "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] / devices * gflop / 1e3,
                       "first_step_ms": h["first_step_ms"], "outputs_finite": h["outputs_finite"], "softmax_worst_row_sum_err": h["softmax_worst_row_sum_err"], "memory_gib": h["memory_gib"]}}
     ks = h.get("kernels", [])
     bn = [k for k in ks if k["bytes"] > 0 and k["ms"] > 0]
