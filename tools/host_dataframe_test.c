@@ -3,6 +3,7 @@
  *   (1) the reference's own pipeline on the CPU: ccv_cnnp_dataframe_image_random_jitter, row by row (+ ccv_cnnp_dataframe_one_hot);
  *   (2) the GPU stage of integration/nnc_mi355x_dataframe.c: whole batches, decisions from the same SFMT stream, pixels on the device --
  * and the images / one-hot rows compared element by element.  Prints one JSON line.
+ * host_dataframe_test <images> <batch> <mode> <32|16> bench: the GPU stage alone over <images> rows (64 distinct decoded images, repeated), no read-back: images/s.
  * usage: host_dataframe_test <images> <batch> <mode>   mode: "imagenet" (resize 256..480 -> 224 crop, aspect, colour jitter, flip) | "cifar" (32 x 32, offsets, flip) | "pad" (late crop with zero overhang) */
 #include "ccv.h"
 #include "nnc/ccv_nnc.h"
@@ -28,12 +29,14 @@ int main(int argc, char** argv)
 	const int count = argc > 1 ? atoi(argv[1]) : 12, batch = argc > 2 ? atoi(argv[2]) : 4;
 	const char* const mode = argc > 3 ? argv[3] : "imagenet";
 	const int half = argc > 4 && atoi(argv[4]) == 16;
+	const int bench = argc > 5 && strcmp(argv[5], "bench") == 0;
 	ccv_nnc_init();
 	const int cifar = strcmp(mode, "cifar") == 0, pad = strcmp(mode, "pad") == 0;
 	const int range = cifar ? 10 : 1000;
 	ccv_array_t* const set = ccv_array_new(sizeof(ccv_categorized_t), count, 0);
 	int i, j;
 	for (i = 0; i < count; i++) { /* smooth-ish synthetic photographs of assorted sizes (what ccv_read would decode) */
+		if (bench && i >= 64) { ccv_categorized_t cat = *(ccv_categorized_t*)ccv_array_get(set, i % 64); ccv_array_push(set, &cat); continue; }
 		const int rows = cifar ? 32 : 180 + (int)(hash32(i, 1) % 260), cols = cifar ? 32 : 200 + (int)(hash32(i, 2) % 300);
 		ccv_dense_matrix_t* const m = ccv_dense_matrix_new(rows, cols, CCV_8U | CCV_C3, 0, 0);
 		int y, x, c;
@@ -60,6 +63,25 @@ int main(int argc, char** argv)
 	}
 	const int rows = jitter.size.rows, cols = jitter.size.cols;
 	const float eta = 0.1f, onval = 1 - eta + eta / range, offval = eta / range;
+	if (bench) { /* throughput of the GPU stage from ONE host thread, raw images resident in host memory */
+		ccv_cnnp_dataframe_t* const df = ccv_cnnp_dataframe_from_array_new(set);
+		const int images = ccv_cnnp_dataframe_extract_value(df, 0, offsetof(ccv_categorized_t, matrix), 0);
+		ccv_cnnp_dataframe_t* const bdf = nnc_mi355x_dataframe_jitter_batch_new(df, images, 0, offsetof(ccv_categorized_t, c), batch, jitter, range, onval, offval, half ? CCV_16F : CCV_32F, CCV_TENSOR_FORMAT_NCHW, 0, 3);
+		ccv_nnc_stream_context_t* const stream = ccv_nnc_stream_context_new(CCV_STREAM_CONTEXT_GPU);
+		int epoch, done = 0;
+		double t0 = 0;
+		for (epoch = 0; epoch < 3; epoch++) { /* epoch 0 warms up (ring allocation, first launches) */
+			ccv_cnnp_dataframe_iter_t* const iter = ccv_cnnp_dataframe_iter_new(bdf, COLUMN_ID_LIST(0));
+			void* data[1];
+			if (epoch == 1) { ccv_nnc_stream_context_wait(stream); t0 = now_ms(); done = 0; }
+			while (ccv_cnnp_dataframe_iter_next(iter, data, 1, stream) == 0) done += ((const nnc_mi355x_batch_t*)data[0])->count;
+			ccv_cnnp_dataframe_iter_free(iter);
+		}
+		ccv_nnc_stream_context_wait(stream);
+		const double ms = now_ms() - t0;
+		printf("{\"mode\": \"%s\", \"bench\": true, \"images\": %d, \"batch\": %d, \"dtype\": \"%s\", \"ms\": %.1f, \"images_per_s\": %.1f}\n", mode, done, batch, half ? "f16" : "f32", ms, done / (ms * 1e-3));
+		return 0;
+	}
 	/* (1) the reference's stages, CPU, one row at a time */
 	float* const want = (float*)malloc(sizeof(float) * (size_t)count * rows * cols * 3);
 	float* const want_hot = (float*)malloc(sizeof(float) * (size_t)count * range);
