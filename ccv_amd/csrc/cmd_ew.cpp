@@ -103,6 +103,7 @@ struct OpAdd2 { __device__ float operator()(float a, float b, float) const { ret
 struct OpAdd3 { __device__ float operator()(float a, float b, float c) const { return a + b + c; } };
 struct OpAdd2Relu { __device__ float operator()(float a, float b, float) const { const float t = a + b; return t > 0.f ? t : 0.f; } };       // EWSUM + the ReLU behind it
 struct OpAdd3Relu { __device__ float operator()(float a, float b, float c) const { const float t = a + b + c; return t > 0.f ? t : 0.f; } };
+struct OpAdd2ReluBack { __device__ float operator()(float a, float b, float m) const { return m > 0.f ? a + b : 0.f; } };                         // EWSUM + the RELU_BACKWARD behind it (4|x| instead of 6|x|)
 struct OpCopy { __device__ float operator()(float a, float, float) const { return a; } };
 
 // ---- SGD: n = mu*m + (1-damp)*(scale*g + decay*a); b = a - rate*n   (5|p| bytes: g, a, m in; b, n out) --------
@@ -265,6 +266,16 @@ static int ewsum_forw_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, 
 	const bool relu = cmd.algorithm > 0 && (cmd.algorithm & NNC_MI355X_EWSUM_ALGO_FUSE_RELU); // opt-in, or the look-ahead completing this sum with its ReLU: c = max(0, sum)
 	if (input_size < 1 || output_size < 1 || !outputs[0]) return CCV_NNC_EXEC_INVALID;
 	ccv_nnc_tensor_t* c = outputs[0];
+	if (cmd.algorithm > 0 && (cmd.algorithm & NNC_MI355X_EWSUM_ALGO_FUSE_RELU_BACKWARD)) {
+		// (a0, a1, mask) -> c = mask > 0 ? a0 + a1 : 0: the sum rounded to the tensors' type exactly as the plain command rounds it, then masked as RELU_BACKWARD masks
+		if (relu || input_size != 3 || !inputs[0] || !inputs[1] || !inputs[2]) return CCV_NNC_EXEC_INVALID;
+		const int dt = c->info.datatype;
+		if ((CCV_GET_DATA_TYPE(dt) != CCV_32F && CCV_GET_DATA_TYPE(dt) != CCV_16F) || !tensor_contiguous(c)) return CCV_NNC_EXEC_INVALID;
+		const size_t n = tensor_count(c->info);
+		for (int i = 0; i < 3; i++)
+			if (!tensor_contiguous(inputs[i]) || tensor_count(inputs[i]->info) != n || inputs[i]->info.datatype != dt) return CCV_NNC_EXEC_INVALID;
+		return ew_map_any<OpAdd2ReluBack, 3>(OpAdd2ReluBack(), dt, c->data.u8, inputs[0]->data.u8, inputs[1]->data.u8, inputs[2]->data.u8, n, stream_context);
+	}
 	if (CCV_GET_DATA_TYPE(c->info.datatype) == CCV_32S) {
 		if (!tensor_contiguous(c) || input_size > 8 || relu) return CCV_NNC_EXEC_INVALID;
 		const size_t n = tensor_count(c->info);

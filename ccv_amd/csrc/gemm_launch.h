@@ -16,6 +16,13 @@ struct GemmOut {
 	long bias_ldn = 1; // column stride of bias (bias_ldm = 1, bias_ldn = 0: one value per output row)
 };
 
+// May the epilogue write four consecutive output columns of a row in one access (mfma_gemm.h "epilogues": the block tile is read back row-major out of LDS)?
+// n-contiguous output, row stride / column count / batch offset multiples of 4 elements, the base aligned to 4 elements.  TUNE_GEMM_VEC_EPILOGUE = 0 turns it off.
+static inline int epi_vec_ok(const void* const c, const size_t es, const long ldm, const long ldn, const int N, const int zcount, const long c_z)
+{
+	return tune(TUNE_GEMM_VEC_EPILOGUE) && ldn == 1 && ldm % 4 == 0 && N % 4 == 0 && ((uintptr_t)c & (4 * es - 1)) == 0 && (zcount <= 1 || c_z % 4 == 0);
+}
+
 // Split the reduction so that a contraction with few output tiles still fills 256 CUs (2 workgroups per CU fit by
 // LDS).  Every slice keeps >= 8 K-steps; slices are multiples of BK so only the last one is ragged.
 static inline int gemm_auto_splits(long tiles, int K)
@@ -46,11 +53,17 @@ inline size_t gemm_workspace_bound(long M, long N, long K)
 
 // Pick the block tile: 128x128 unless an output dimension would be mostly padding (64-channel layers), where the
 // narrower tile keeps the MFMA pipe on useful work.  Score = useful / issued work x a mild preference for big tiles.
-static inline void gemm_pick_tile(const int M, const int N, int* wm, int* wn)
+static inline void gemm_pick_tile(const int M, const int N, const int K, const int zcount, int* wm, int* wn)
 {
 	static const int shapes[4][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 }, { 1, 1 } };
 	static const double eff[4] = { 1.0, 0.93, 0.93, 0.8 }; // 64 x 64: both outputs 64 channels (the Winograd filter gradient of conv1_2)
 	if (g_force_tile) { *wm = g_force_tile & 0xff; *wn = g_force_tile >> 8; return; }
+	// The per-image products of a 1 x 1 convolution on NCHW tensors (a batch of >= 64 small matrices): with at most 8 K-steps a workgroup is mostly its
+	// prologue and its epilogue, and what hides those is MORE workgroups per CU -- four 64 x 64 tiles fit by LDS where two 128 x 128 do.  Likewise a filter
+	// gradient whose whole output is a few tiles (it splits K either way).  Measured on ResNet-50's layers at batch 256 (tools/conv1x1_bench.py,
+	// profiles/r04_v4_conv1x1_bench_f32.txt): 64 -> 256 at 56^2 forward 0.413 -> 0.375 ms, its filter gradient 0.485 -> 0.419, 256 -> 128 forward 0.472 -> 0.430;
+	// with K >= 512 the big tile is as good or better.
+	if ((zcount >= 64 && K <= 256 && (long)M * N <= 1L << 20) || (zcount == 1 && (long)M * N <= 32768 && K >= 65536)) { *wm = 1; *wn = 1; return; }
 	// 256 x 128 / 128 x 256 tiles (WM, WN = 4, 2 / 2, 4: one workgroup per CU) were measured on the whole VGG-D step: 4x2
 	// 108 vs 127 TFLOP/s and 2x4 121 vs 127 for the 128 x 128 tile on the same layers (profiles/r01_v6_bigtile_bench.json),
 	// although an isolated probe of one layer had them 4 % ahead; the kernel template still supports them (tools/kprobe.cpp).
@@ -103,6 +116,7 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	if (splits <= 1) {
 		EpiStore epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
+		epi.vec = epi_vec_ok(out.c, sizeof(float), out.ldm, out.ldn, N, zcount, c_z);
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
@@ -113,12 +127,13 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	if (!ws) return CCV_NNC_EXEC_OOM;
 	EpiPartial epi;
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
+	epi.vec = tune(TUNE_GEMM_VEC_EPILOGUE) && N % 4 == 0; // (the slabs start at the 256-byte aligned workspace and are M * N floats each)
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiPartial, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(splitk_reduce_kernel<float>), dim3(grid_for((size_t)slab * 4, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -134,7 +149,7 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 	la.zoff = zp - la.p;
 	lb.zoff = zp - lb.p;
 	int wm = 2, wn = 2;
-	gemm_pick_tile(M, N, &wm, &wn);
+	gemm_pick_tile(M, N, K, zcount, &wm, &wn);
 	// two plain matrices in 16-byte chunks, whole K-steps: the buffer-load form (no address VALU in the K loop, mfma_gemm.h)
 	if constexpr (is_vec_mat_loader<LA>::value && is_vec_mat_loader<LB>::value) {
 		if (tune(TUNE_GEMM_BUFFER_LOADS) && K > 0 && K % GEMM_BK == 0 && buf_loader_ok(la) && buf_loader_ok(lb)) {
@@ -188,6 +203,7 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	if (splits <= 1) {
 		EpiStoreH epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
+		epi.vec = epi_vec_ok(out.c, sizeof(half_t), out.ldm, out.ldn, N, zcount, c_z);
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
@@ -198,12 +214,13 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	if (!ws) return CCV_NNC_EXEC_OOM;
 	EpiPartialH epi;
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
+	epi.vec = tune(TUNE_GEMM_VEC_EPILOGUE) && N % 4 == 0;
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiPartialH, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(splitk_reduce_half_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(splitk_reduce_kernel<half_t>), dim3(grid_for((size_t)slab * 4, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -242,6 +259,7 @@ static int gemm_run_buf_tile_h(const char* name, const BufMatLoader<AKC>& la, co
 	if (splits <= 1) {
 		EpiStoreH epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
+		epi.vec = epi_vec_ok(out.c, sizeof(half_t), out.ldm, out.ldn, N, zcount, c_z);
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiStoreH, TM, TN, WM, WN, BK>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(64 * WM * WN), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, 1, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
@@ -252,12 +270,13 @@ static int gemm_run_buf_tile_h(const char* name, const BufMatLoader<AKC>& la, co
 	if (!ws) return CCV_NNC_EXEC_OOM;
 	EpiPartialH epi;
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
+	epi.vec = tune(TUNE_GEMM_VEC_EPILOGUE) && N % 4 == 0;
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiPartialH, TM, TN, WM, WN, BK>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(64 * WM * WN), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(splitk_reduce_half_kernel, dim3(grid_for((size_t)slab, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(splitk_reduce_kernel<half_t>), dim3(grid_for((size_t)slab * 4, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

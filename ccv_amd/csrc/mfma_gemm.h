@@ -442,6 +442,16 @@ struct Im2colNC {
 };
 
 // ---------------------------------------------------------------------------------------------- epilogues
+// Two ways out of the accumulators:
+//   * operator()(m, n, v): one element -- any output strides; a lane of the 32x32 MFMA holds a COLUMN of its tile (16 rows of one n), so a wave's store
+//     instruction covers 2 rows x 32 consecutive n: 128-byte segments of fp32, 64-byte segments of halves, 16 store instructions per tile;
+//   * store4(m, n, v): four consecutive n of row m in one 16-byte (8-byte for halves) access -- the kernels stage the block tile through LDS (free by
+//     then) and read it back ROW-major (epi_flush_rows below), so a wave instruction writes 1 KB / 512 B contiguous.  `vec` (set by the launcher)
+//     says the output allows it: n-contiguous (ldn == 1), N, ldm and every base offset multiples of 4 elements, 16-byte (8-byte) aligned.
+//     Measured on the MI355X (tools/conv1x1_bench.py, profiles/r04_v4_conv1x1_bench_*.txt): the 1x1 convolutions of ResNet-50 that WRITE the wide tensor
+//     (64 -> 256 at 56^2: 1.0 GB written per launch) ran 1.25 TB/s (f16) / 1.7 TB/s (fp32) with the scalar stores while the same shape's data
+//     gradient, which READS the wide tensor, ran 4.5 / 3.9 TB/s.
+// Both forms apply alpha, bias and the accumulate flag in the same order, so their results are bit-identical.
 // Direct store: c[m*ldm + n*ldn] = alpha * acc (+ bias[n]) (+ old c when accumulating).
 struct EpiStore {
 	float* c;
@@ -451,6 +461,8 @@ struct EpiStore {
 	int accumulate;
 	int M, N;
 	long bias_ldm, bias_ldn;
+	int vec = 0;
+	static constexpr int FLUSH_UNROLL = 2;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) {
@@ -461,6 +473,19 @@ struct EpiStore {
 			c[o] = v;
 		}
 	}
+	__device__ __forceinline__ void store4(int m, int n, float4 v) const
+	{
+		if (m < M && n < N) {
+			const long o = (long)m * ldm + (long)n;
+			v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+			if (bias) {
+				const float* const b = bias + (long)m * bias_ldm + (long)n * bias_ldn;
+				v.x += b[0]; v.y += b[bias_ldn]; v.z += b[2 * bias_ldn]; v.w += b[3 * bias_ldn];
+			}
+			if (accumulate) { const float4 u = *(const float4*)(c + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+			*(float4*)(c + o) = v;
+		}
+	}
 };
 // Split-K partial: slab[blockIdx.y][m][n] = acc; splitk_reduce_kernel finishes (deterministic order).
 struct EpiPartial {
@@ -468,11 +493,36 @@ struct EpiPartial {
 	const float* bias; // unused (applied by splitk_reduce_kernel); keeps the epilogue concept uniform
 	long slab; // M*N
 	int M, N;
+	int vec = 0;
+	static constexpr int FLUSH_UNROLL = 1;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) c[(long)m * N + n] = v;
 	}
+	__device__ __forceinline__ void store4(int m, int n, const float4 v) const
+	{
+		if (m < M && n < N) *(float4*)(c + (long)m * N + n) = v;
+	}
 };
+
+// The row-major read-back of a staged block-tile slice: `cs` holds ROWS x BN accumulators (row pitch BN + 8 floats: the two half-waves of a staging write --
+// four rows apart -- land 32 banks apart, and rows stay 16-byte aligned); thread t takes 16-byte vectors t, t + NT, ... and hands each to the epilogue's
+// store4 with the output row the staged row stands for (row_of) -- consecutive lanes = consecutive 16 bytes of one output row.
+template <int NT, int ROWS, int BN, class EPI, class ROWOF>
+__device__ __forceinline__ void epi_flush_rows(const float* const cs, const EPI& epi, const int m0, const int n0, const int t, const ROWOF& row_of)
+{
+	constexpr int PITCH = BN + 8, V = BN / 4, TOTAL = ROWS * V;
+	static_assert(TOTAL % NT == 0, "whole vectors per thread");
+	// (EPI::FLUSH_UNROLL vectors in flight per thread -- two where the epilogue loads a bias / the old value, one for the plain slab stores: fully unrolled, the eight read-backs of a 128-column slice and their bias / old-value loads cost ~20 more
+	// VGPRs than the K loop needs and the half-precision kernels drop from three waves per SIMD to two -- measured slower on the 3 x 3 layers)
+#pragma unroll EPI::FLUSH_UNROLL
+	for (int j = 0; j < TOTAL / NT; j++) {
+		const int id = t + NT * j;
+		const int sr = id / V, c4 = id - sr * V;
+		const float4 v = *(const float4*)(cs + sr * PITCH + 4 * c4);
+		epi.store4(m0 + row_of(sr), n0 + 4 * c4, v);
+	}
+}
 
 // ---------------------------------------------------------------------------------------------- kernel
 // The NCH chunks (of 4 floats) one thread stages for an operand tile of ROWS = 32 * NCH rows at K offset kbase.
@@ -851,6 +901,25 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	// D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), both in fragment-lane terms
 	// (frag_row maps a tile's lane to the row / column of the wave's span it stands for).
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
+	if (epi.vec) {
+		// through LDS, one tile row of every wave per pass: 64 staged rows (wave row wm, fragment row q) x BN columns, read back row-major (epi_flush_rows)
+		constexpr int PITCH = BN + 8;
+		static_assert(64 * PITCH <= 2 * (A_FLOATS + B_FLOATS), "the staged slice fits the operand buffers");
+		float* const cs = &lds[0][0];
+#pragma unroll
+		for (int ti = 0; ti < WM; ti++) {
+			__syncthreads(); // every wave is done with the operand images (first pass) / with reading the previous slice
+#pragma unroll
+			for (int tj = 0; tj < WN; tj++) {
+				const int col = col_b + frag_row<LB::KCONTIG, WN>(tj, li);
+#pragma unroll
+				for (int r = 0; r < 16; r++) cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + col] = acc[ti][tj][r];
+			}
+			__syncthreads();
+			epi_flush_rows<GEMM_THREADS, 64, BN>(cs, epi, m0, n0, t, [&](const int sr) { return (sr >> 5) * (32 * WM) + frag_row<LA::KCONTIG, WM>(ti, sr & 31); });
+		}
+		return;
+	}
 #pragma unroll
 	for (int ti = 0; ti < WM; ti++)
 #pragma unroll
@@ -864,22 +933,43 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 		}
 }
 
-// Finish a split-K contraction: c = alpha * sum_s slab[s] (+ bias[n]) (+ old c). Fixed summation order => deterministic.
-// grid.y = batch entry z: its slab set starts at ws + z * splits * slab, its output at c + z * c_zoff.
-static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, const int splits, const long slab, float* c, const long ldm, const long ldn, const float* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff, const long bias_ldn)
+// Finish a split-K contraction: c = alpha * sum_s slab[s] (+ bias[n]) (+ old c).  Fixed summation order => deterministic.
+// grid.y = batch entry z: its slab set starts at ws + z * splits * slab, its output at c + z * c_zoff.  T = float, or _Float16 for a half-precision result.
+// A workgroup takes 64 consecutive outputs x 4 phases: wave `ph` sums the slabs ph, ph + 4, ... (four independent loads in flight), the phases meet in LDS
+// as (p0 + p1) + (p2 + p3).  Round 3's form -- one thread per output walking all `splits` slabs, one dependent load-add chain of up to 512 -- took 56 us per
+// call on ResNet-50's filter gradients (86 calls per step: small outputs, hundreds of slices), as long as some of the contractions it finishes.
+template <class T>
+static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, const int splits, const long slab, T* c, const long ldm, const long ldn, const T* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff, const long bias_ldn)
 {
+	__shared__ float red[4][64];
 	ws += (long)blockIdx.y * splits * slab;
 	c += (long)blockIdx.y * c_zoff;
 	if (bias) bias += (long)blockIdx.y * bias_zoff;
-	for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < slab; idx += (long)gridDim.x * blockDim.x) {
-		const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
+	const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+	for (long base = (long)blockIdx.x * 64; base < slab; base += (long)gridDim.x * 64) {
+		const long idx = base + lane;
 		float v = 0.f;
-		for (int s = 0; s < splits; s++) v += ws[(long)s * slab + idx];
-		v *= alpha;
-		if (bias) v += bias[(long)m * bias_ldm + (long)n * bias_ldn];
-		const long o = (long)m * ldm + (long)n * ldn;
-		if (accumulate) v += c[o];
-		c[o] = v;
+		if (idx < slab) {
+			const float* const p = ws + idx;
+			int s = ph;
+			for (; s + 12 < splits; s += 16) {
+				const float a0 = p[(long)s * slab], a1 = p[(long)(s + 4) * slab], a2 = p[(long)(s + 8) * slab], a3 = p[(long)(s + 12) * slab];
+				v += a0; v += a1; v += a2; v += a3;
+			}
+			for (; s < splits; s += 4) v += p[(long)s * slab];
+		}
+		red[ph][lane] = v;
+		__syncthreads();
+		if (ph == 0 && idx < slab) {
+			v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+			const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
+			v *= alpha;
+			if (bias) v += (float)bias[(long)m * bias_ldm + (long)n * bias_ldn];
+			const long o = (long)m * ldm + (long)n * ldn;
+			if (accumulate) v += (float)c[o];
+			c[o] = (T)v;
+		}
+		__syncthreads();
 	}
 }
 

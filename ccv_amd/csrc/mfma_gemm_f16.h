@@ -35,6 +35,8 @@ struct EpiStoreH {
 	int accumulate;
 	int M, N;
 	long bias_ldm, bias_ldn;
+	int vec = 0; // store4 allowed (mfma_gemm.h, "epilogues"): four halves of a row in one 8-byte store
+	static constexpr int FLUSH_UNROLL = 2;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) {
@@ -45,6 +47,19 @@ struct EpiStoreH {
 			c[o] = (half_t)v;
 		}
 	}
+	__device__ __forceinline__ void store4(int m, int n, float4 v) const
+	{
+		if (m < M && n < N) {
+			const long o = (long)m * ldm + (long)n;
+			v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+			if (bias) {
+				const half_t* const b = bias + (long)m * bias_ldm + (long)n * bias_ldn;
+				v.x += (float)b[0]; v.y += (float)b[bias_ldn]; v.z += (float)b[2 * bias_ldn]; v.w += (float)b[3 * bias_ldn];
+			}
+			if (accumulate) { const halfx4 u = *(const halfx4*)(c + o); v.x += (float)u[0]; v.y += (float)u[1]; v.z += (float)u[2]; v.w += (float)u[3]; }
+			*(halfx4*)(c + o) = halfx4{ (half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w };
+		}
+	}
 };
 // Split-K partial (fp32 slabs, exactly as the fp32 core's): splitk_reduce_half_kernel finishes.
 struct EpiPartialH {
@@ -52,9 +67,15 @@ struct EpiPartialH {
 	const half_t* bias; // unused
 	long slab;
 	int M, N;
+	int vec = 0;
+	static constexpr int FLUSH_UNROLL = 1;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) c[(long)m * N + n] = v;
+	}
+	__device__ __forceinline__ void store4(int m, int n, const float4 v) const
+	{
+		if (m < M && n < N) *(float4*)(c + (long)m * N + n) = v;
 	}
 };
 __device__ __forceinline__ long M_N_slab(const EpiStoreH&) { return 0; }
@@ -203,6 +224,22 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 	}
 	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
+	if (epi.vec) { // through LDS, one tile row of every wave per pass (mfma_gemm.h: "epilogues", epi_flush_rows)
+		constexpr int PITCH = BN + 8;
+		static_assert(64 * PITCH * 2 <= 2 * (A_HALVES + B_HALVES), "the staged slice (fp32) fits the operand buffers");
+		float* const cs = (float*)&lds[0][0];
+#pragma unroll
+		for (int ti = 0; ti < WM; ti++) {
+			__syncthreads();
+#pragma unroll
+			for (int tj = 0; tj < WN; tj++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + col_b + 32 * tj + li] = acc[ti][tj][r];
+			__syncthreads();
+			epi_flush_rows<GEMM_THREADS, 64, BN>(cs, epi, m0, n0, t, [&](const int sr) { return (sr >> 5) * (32 * WM) + 32 * ti + (sr & 31); });
+		}
+		return;
+	}
 #pragma unroll
 	for (int ti = 0; ti < WM; ti++)
 #pragma unroll
@@ -216,22 +253,6 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 		}
 }
 
-// Finish a split-K contraction into a half-precision tensor (fixed summation order => deterministic).
-static __global__ void __launch_bounds__(256) splitk_reduce_half_kernel(const float* ws, const int splits, const long slab, half_t* c, const long ldm, const long ldn, const half_t* bias, const long bias_ldm, const float alpha, const int accumulate, const int M, const int N, const long c_zoff, const long bias_zoff, const long bias_ldn)
-{
-	ws += (long)blockIdx.y * splits * slab;
-	c += (long)blockIdx.y * c_zoff;
-	if (bias) bias += (long)blockIdx.y * bias_zoff;
-	for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < slab; idx += (long)gridDim.x * blockDim.x) {
-		const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
-		float v = 0.f;
-		for (int s = 0; s < splits; s++) v += ws[(long)s * slab + idx];
-		v *= alpha;
-		if (bias) v += (float)bias[(long)m * bias_ldm + (long)n * bias_ldn];
-		const long o = (long)m * ldm + (long)n * ldn;
-		if (accumulate) v += (float)c[o];
-		c[o] = (half_t)v;
-	}
-}
+// (a split-K contraction into a half-precision tensor is finished by splitk_reduce_kernel<half_t>, mfma_gemm.h)
 
 } // namespace nnc

@@ -172,6 +172,22 @@ __global__ void __launch_bounds__(64 * WM * WN) mfma_gemm_f16_buf_kernel(BufMatL
 	}
 	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
+	if (epi.vec) { // through LDS, one tile row of every wave per pass (mfma_gemm.h: "epilogues", epi_flush_rows)
+		constexpr int PITCH = BN + 8;
+		static_assert(32 * WM * PITCH * 2 <= 2 * (A_HALVES + B_HALVES), "the staged slice (fp32) fits the operand buffers");
+		float* const cs = (float*)&lds[0][0];
+#pragma unroll
+		for (int ti = 0; ti < TM; ti++) {
+			__syncthreads();
+#pragma unroll
+			for (int tj = 0; tj < TN; tj++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + col_b + 32 * tj + li] = acc[ti][tj][r];
+			__syncthreads();
+			epi_flush_rows<NT, 32 * WM, BN>(cs, epi, m0, n0, t, [&](const int sr) { return (sr >> 5) * (32 * TM) + 32 * ti + (sr & 31); });
+		}
+		return;
+	}
 #pragma unroll
 	for (int ti = 0; ti < TM; ti++)
 #pragma unroll

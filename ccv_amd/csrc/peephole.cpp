@@ -280,6 +280,15 @@ int deferred_fuse_relu_back(const ccv_nnc_tensor_t* const g, const ccv_nnc_tenso
 	const int device = device_for(ctx);
 	wait_launching(ctx, lock);
 	Slot* const s = slot_of(ctx, device);
+	if (s && s->kind == DEFER_EWSUM_FORWARD) {
+		// the gradient sum at the head of a residual block, then RELU_BACKWARD (g, -, b) -> h in place on that sum: the sum masks as it stores.  The mask map b
+		// joins the recorded command as its last input (NNC_MI355X_EWSUM_ALGO_FUSE_RELU_BACKWARD, cmd_ew.cpp); two summands, none of them the mask or the output's alias of it
+		if (s->nin != 2 || !s->has_in[0] || !s->has_in[1] || !s->has_out[0] || g->data.u8 != h->data.u8 || !same_buffer(s->out[0], h)) return -1;
+		if (!b || !tensor_contiguous(b) || b->info.datatype != h->info.datatype || tensor_count(b->info) != tensor_count(h->info) || b->data.u8 == h->data.u8 || CCV_TENSOR_GET_MEMORY(b->info.type) != CCV_TENSOR_GPU_MEMORY) return -1;
+		keep(&s->in[2], &s->has_in[2], b);
+		s->nin = 3;
+		return run(*s, NNC_MI355X_EWSUM_ALGO_FUSE_RELU_BACKWARD, lock, true);
+	}
 	if (!s || (s->kind != DEFER_CONV_BACKWARD && s->kind != DEFER_POOL_BACKWARD) || !s->has_out[0] || s->nin < 2 || !s->has_in[1]) return -1;
 	if (s->out[0].info.datatype != s->in[1].info.datatype) return -1; // the folded epilogue masks h by a in one element type (conv_back_entry refuses a mix)
 	// RELU_BACKWARD (g, -, b) -> h in place on the gradient the recorded command writes, b the map the recorded command read as its input a

@@ -385,6 +385,10 @@ void nnc_mi355x_debug_force_tile(int wm, int wn);
 /* EWSUM_FORWARD with cmd.algorithm = NNC_MI355X_EWSUM_ALGO_FUSE_RELU: c = max(0, a + b + ...) -- the in-place RELU_FORWARD behind the residual sum of a
  * ResNet block (bin/nnc/imagenet.c: ccv_cnnp_sum then ccv_cnnp_relu) applied in the pass that writes the sum. */
 #define NNC_MI355X_EWSUM_ALGO_FUSE_RELU 0x100
+/* EWSUM_FORWARD with cmd.algorithm = NNC_MI355X_EWSUM_ALGO_FUSE_RELU_BACKWARD: the LAST input is a mask map b (a ReLU's forward output), the others are summed:
+ * c = b > 0 ? a0 + a1 : 0 -- the gradient sum at the head of a residual block followed by the in-place RELU_BACKWARD of the block before it (the backward pass
+ * of bin/nnc/imagenet.c's bottlenecks issues exactly that pair), in one pass.  Two summands only.  The look-ahead (peephole.cpp) sets it for the unmodified host. */
+#define NNC_MI355X_EWSUM_ALGO_FUSE_RELU_BACKWARD 0x200
 /* Callers that do NOT set these bits get the same folding from a one-command look-ahead (ccv_amd/csrc/peephole.cpp): a
  * CONVOLUTION_FORWARD / CONVOLUTION_BACKWARD / MAX_POOL_BACKWARD whose like has run before is recorded instead of launched; the
  * in-place RELU_FORWARD / RELU_BACKWARD the reference's graphs issue next on the same stream completes it, anything else that could

@@ -188,6 +188,50 @@ def test_ewsum_relu_pair(lib, ninputs, dtype):
     assert np.array_equal(td.numpy(), np.maximum(tc.numpy(), 0)) and (tc.numpy() < 0).any()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_ewsum_relu_backward_pair(lib, dtype):
+    """The head of a residual block on the way back: EWSUM_FORWARD of the two gradients, then RELU_BACKWARD in place on the sum, masked by the forward output of the
+    block before (bin/nnc/imagenet.c's bottlenecks through the reference's autodiff).  On the spot, folded by the look-ahead, and with the opt-in bit (the mask as the
+    last input): the same halves / floats, bit for bit."""
+    rng = np.random.default_rng(35)
+    T = np.float16 if dtype == "f16" else F
+    ga, gb = (srnd(rng, 3, 6, 5, 8, scale=2.0).astype(T) for _ in range(2))
+    y = np.maximum(srnd(rng, 3, 6, 5, 8), 0).astype(T)  # a ReLU's output: zeros and positives
+    cmd, rb = nnc.CMD_EWSUM_FORWARD(), nnc.CMD_RELU_BACKWARD()
+
+    def run(mode):
+        ta, tb, ty = make_tensors(lib, nnc.GPU_MEMORY, [ga, gb, y])
+        tc, = make_tensors(lib, nnc.GPU_MEMORY, [np.full_like(ga, -3)])
+        c = nnc.Cmd(); nnc.C.memmove(nnc.C.byref(c), nnc.C.byref(cmd), nnc.C.sizeof(c))
+        if mode == "bit":
+            c.algorithm = nnc.EWSUM_ALGO_FUSE_RELU_BACKWARD
+            assert lib.cmd_exec(c, nnc.NO_HINT, 0, [ta, tb, ty], [tc]) == 0
+            return tc.numpy()
+        assert lib.cmd_exec(c, nnc.NO_HINT, 0, [ta, tb], [tc]) == 0
+        if mode == "pair":
+            assert lib.cmd_exec(rb, nnc.NO_HINT, 0, [tc, None, ty], [tc]) == 0
+        return tc.numpy()
+
+    lib.dll.nnc_mi355x_set_peephole(0)
+    plain = run("plain")
+    want = np.where(y > 0, plain, 0).astype(T)
+    assert np.array_equal(run("pair"), want)  # (the unfolded pair)
+    lib.dll.nnc_mi355x_set_peephole(1)
+    r0, f0, p0 = counts(lib)
+    results = [run("pair"), run("pair"), run("pair"), run("bit")]
+    r1, f1, p1 = counts(lib)
+    assert f1 - f0 >= 2 and (r1 - r0) - (f1 - f0) == (p1 - p0)
+    for got in results:
+        assert np.array_equal(got, want)
+    assert (want == 0).any() and (want != 0).any()
+    # a mask that IS the sum's output (RELU_BACKWARD masked by its own gradient buffer) or an out-of-place RELU_BACKWARD does not fold: the plain pair's result
+    ta, tb, ty = make_tensors(lib, nnc.GPU_MEMORY, [ga, gb, y])
+    tc, td = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros_like(ga), np.zeros_like(ga)])
+    assert lib.cmd_exec(cmd, nnc.NO_HINT, 0, [ta, tb], [tc]) == 0
+    assert lib.cmd_exec(rb, nnc.NO_HINT, 0, [tc, None, ty], [td]) == 0
+    assert np.array_equal(tc.numpy(), plain) and np.array_equal(td.numpy(), want)
+
+
 TWO_DEVICE_SCRIPT = """
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, %r)

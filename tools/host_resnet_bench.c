@@ -572,12 +572,14 @@ int main(int argc, char** argv)
 	struct { char name[192]; double ms, flops, bytes; int n; } agg[64];
 	int nagg = 0;
 	const int nrec = nnc_mi355x_profile_count();
+	FILE* const recf = getenv("HOST_BENCH_RECORDS") ? fopen(getenv("HOST_BENCH_RECORDS"), "w") : 0; /* every launch of that step: name, dims, ms, TFLOP/s, GB/s */
 	for (i = 0; i < nrec; i++) {
 		char name[256];
 		double fl, by;
 		float rms;
 		int dims[5], k;
 		nnc_mi355x_profile_get(i, name, 256, &fl, &by, &rms, dims);
+		if (recf) fprintf(recf, "%4d %-150s dims %d %d %d %d %d  %8.4f ms  %7.1f TFLOP/s  %7.1f GB/s\n", i, name, dims[0], dims[1], dims[2], dims[3], dims[4], rms, rms > 0 ? fl / (rms * 1e-3) / 1e12 : 0.0, rms > 0 ? by / (rms * 1e-3) / 1e9 : 0.0);
 		char* bar = strchr(name, '|'); /* aggregate per KERNEL symbol (behind '|') */
 		const char* key = bar ? bar + 1 : name;
 		for (k = 0; k < nagg; k++) if (strncmp(agg[k].name, key, 191) == 0) break;
@@ -585,6 +587,7 @@ int main(int argc, char** argv)
 		agg[k].ms += rms; agg[k].flops += fl; agg[k].bytes += by; agg[k].n++;
 	}
 	nnc_mi355x_profile_enable(0);
+	if (recf) fclose(recf);
 	printf("{\"kernels\": [");
 	for (i = 0; i < nagg; i++) printf("%s{\"name\": \"%s\", \"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}", i ? ", " : "", agg[i].name, agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes);
 	printf("], ");
