@@ -1028,7 +1028,27 @@ static int _conv_transpose_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hi
 static bool aligned8(const void* p) { return (((uintptr_t)p) & 7) == 0; }
 static bool half_image_ok(const Image4& t) { return t.sc == 1 && aligned8(t.p) && t.sw % 4 == 0 && t.sh % 4 == 0 && (t.n == 1 || t.sn % 4 == 0) && image_fits_int(t); }
 
-static int conv_forw_h(const conv_geom_t& g, const Image4& a, const void* w, const void* bias, const Image4& b, const int flags, ccv_nnc_stream_context_t* const ctx)
+// K-slices of the half-precision forward / data-gradient contraction: 1, except where the launcher is told otherwise (nnc_mi355x_debug_force_splits: measurements)
+static int conv_h_splits(const conv_geom_t& g, const long M, const int N, const int Kred)
+{
+	if (g.groups != 1) return 1;
+	if (g_force_splits > 1) return g_force_splits;
+	// Few output tiles and a long reduction (the 4 x 4 and 7 x 7 maps of the trainers: 256 - 392 tiles of 128 x 128 for 256 CUs, 144 K-steps each): eight K-slices
+	// put eight times the workgroups on the chip -- measured (tools/conv_half_bench.py, profiles/r04_v5_conv_half_bench.txt) 512 -> 512 at 4 x 4, batch 512:
+	// forward 0.127 -> 0.072 ms, data gradient 0.135 -> 0.078; at 7 x 7, batch 256: 0.128 -> 0.107 / 0.147 -> 0.118; from ~800 tiles on it only costs
+	// (256 -> 256 at 14 x 14 even, 128 -> 128 at 16 x 16: 0.085 -> 0.139).
+	const long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+	return tiles <= 2L * device_cu_count() && Kred >= 2304 ? 8 : 1;
+}
+
+// Can the forward / data-gradient contraction write an NCHW result itself (EpiStoreHT: groups of four pixels of a plane in one store, one K-slice)?
+static bool conv_h_planar_ok(const conv_geom_t& g, const long M, const int N, const int Kred, const long P, const void* dst)
+{
+	return tune(TUNE_GEMM_VEC_EPILOGUE) && g.groups == 1 && P % 4 == 0 && M % 4 == 0 && aligned8(dst) && conv_h_splits(g, M, N, Kred) == 1 && M * (long)N < 0x7fffffff0L && M <= 0x7fffffffL;
+}
+
+// planar != 0: the result goes to that NCHW tensor [N][K][OH * OW] (b is not written)
+static int conv_forw_h(const conv_geom_t& g, const Image4& a, const void* w, const void* bias, const Image4& b, const int flags, ccv_nnc_stream_context_t* const ctx, void* const planar = 0)
 {
 	const long M = (long)g.N * g.OH * g.OW;
 	const int Kred = g.kh * g.kw * g.Cg;
@@ -1041,10 +1061,15 @@ static int conv_forw_h(const conv_geom_t& g, const Image4& a, const void* w, con
 	la.my = g.sy; la.mx = g.sx; la.oy_off = -g.pby; la.ox_off = -g.pbx; la.ty = g.dy; la.tx = g.dx; la.dv_y = 1; la.dv_x = 1;
 	MatLoader<true, true> lb;
 	lb.p = (const float*)w; lb.ldr = Kred; lb.ldk = 1; lb.R = g.Kg; lb.K = Kred;
-	return gemm_run_h("conv_fwd_h", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, 1, flags, ctx, ko);
+	if (planar) {
+		EpiStoreHT epi;
+		epi.c = (half_t*)planar; epi.bias = (const half_t*)bias; epi.M = (int)M; epi.N = g.Kg; epi.P = g.OH * g.OW;
+		return gemm_run_h_planar("conv_fwd_h", la, lb, epi, Kred, ctx, ko);
+	}
+	return gemm_run_h("conv_fwd_h", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, conv_h_splits(g, M, g.Kg, Kred), flags, ctx, ko);
 }
 
-static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx)
+static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx, void* const planar = 0)
 {
 	const long M = (long)g.N * g.H * g.W;
 	const int Kred = g.kh * g.kw * g.Kg;
@@ -1058,7 +1083,12 @@ static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, c
 		la.my = 1; la.mx = 1; la.oy_off = g.pby; la.ox_off = g.pbx; la.ty = -g.dy; la.tx = -g.dx; la.dv_y = g.sy; la.dv_x = g.sx; \
 		WgtDgradNC<true, false> lb; \
 		lb.p = (const float*)w; lb.ko_stride = (long)g.kh * g.kw * g.Cg; lb.C = g.Cg; lb.Ko = g.Kg; lb.K = Kred; \
-		return gemm_run_h("conv_dgrad_h", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, 1, flags, ctx, ko); \
+		if (planar) { \
+			EpiStoreHT epi; \
+			epi.c = (half_t*)planar; epi.bias = 0; epi.M = (int)M; epi.N = g.Cg; epi.P = g.H * g.W; \
+			return gemm_run_h_planar("conv_dgrad_h", la, lb, epi, Kred, ctx, ko); \
+		} \
+		return gemm_run_h("conv_dgrad_h", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, conv_h_splits(g, M, g.Cg, Kred), flags, ctx, ko); \
 	} while (0)
 	if (g.sy != 1 || g.sx != 1) CONV_DGRAD_H(true);
 	else CONV_DGRAD_H(false);
@@ -1129,6 +1159,8 @@ static int conv_nchw_half_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hin
 		Image4 as, bs;
 		dense_nhwc_f32(ai, tensor_nd(a->info.dim) == 4, (float*)q, &at, &as);            // (geometry only: element strides are the same for halves)
 		dense_nhwc_f32(bi, tensor_nd(b->info.dim) == 4, (float*)(q + ha), &bt, &bs);
+		// the contraction writes the NCHW result itself where it can (groups of four pixels of a plane per store: no NHWC image of b, no pass to re-lay it)
+		if (conv_h_planar_ok(g, (long)g.N * g.OH * g.OW, g.Kg, g.kh * g.kw * g.Cg, Pb, b->data.u8)) return conv_forw_h(g, as, q + ha + hb, bias ? bias->data.u8 : 0, bs, flags, ctx, b->data.u8);
 		if ((ret = conv_forw_h(g, as, q + ha + hb, bias ? bias->data.u8 : 0, bs, flags, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 		return transpose_half(q + ha, b->data.u8, Nb, Pb, Cb, ctx);
 	}
@@ -1189,8 +1221,12 @@ static int conv_nchw_half_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hin
 		if (h) {
 			if ((ret = transpose_half(w->data.u8, W16, g.K, g.Cg, g.kh * g.kw, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
 			dense_nhwc_f32(hi, tensor_nd(h->info.dim) == 4, (float*)H16, &h16, &h16i);
-			if ((ret = conv_dgrad_h(g, g16i, W16, h16i, 0, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
-			if ((ret = transpose_half(H16, h->data.u8, Na, Pa, Ca, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			if (conv_h_planar_ok(g, (long)g.N * g.H * g.W, g.Cg, g.kh * g.kw * g.Kg, Pa, h->data.u8)) {
+				if ((ret = conv_dgrad_h(g, g16i, W16, h16i, 0, ctx, h->data.u8)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			} else {
+				if ((ret = conv_dgrad_h(g, g16i, W16, h16i, 0, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+				if ((ret = transpose_half(H16, h->data.u8, Na, Pa, Ca, ctx)) != CCV_NNC_EXEC_SUCCESS) return ret;
+			}
 		}
 		return CCV_NNC_EXEC_SUCCESS;
 	}

@@ -187,6 +187,7 @@ const char* command_row_name(uint32_t cmd); // registry.cpp: "CMD/BACKEND" of th
 
 // nnc_mi355x_debug_force_tile (device_rt.cpp): wm | wn << 8, 0 = built-in choice.
 extern int g_force_tile;
+extern int g_force_splits; // nnc_mi355x_debug_force_splits: 0 = built-in choice
 
 // Tunables (nnc_mi355x_tune_set / environment NNC_MI355X_<NAME>, device_rt.cpp): performance policy only, never semantics.
 enum {

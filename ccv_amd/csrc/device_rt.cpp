@@ -100,6 +100,7 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 
 namespace nnc {
 int g_force_tile = 0;
+int g_force_splits = 0;
 static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C", "WINO_FUSED_GRID", "GRID_WG_PER_CU", "WINO_WGRAD_FUSED_MAX", "GEMM_BUFFER_LOADS", "CONV_NCHW_HALF_F16", "BN_SMALL_PLANES", "SDPA_MFMA", "BN_CLUSTER", "GEMM_VEC_EPILOGUE" };
 // GRID_WG_PER_CU = 0: grid-stride kernels get one trip per thread.  tools/ew_bw_bench.py: a grid capped at 8 .. 64 workgroups per CU
 // striding a 3.3 GB tensor runs at 4.7 - 5.2 TB/s, the same kernel with the whole tensor as its grid at 6.2 TB/s.
@@ -794,6 +795,7 @@ void nnc_mi355x_debug_force_tile(int wm, int wn)
 	const bool known = (wm == 2 && wn == 2) || (wm == 2 && wn == 1) || (wm == 1 && wn == 2) || (wm == 1 && wn == 1);
 	nnc::g_force_tile = known ? (wm | wn << 8) : 0;
 }
+void nnc_mi355x_debug_force_splits(int splits) { nnc::g_force_splits = splits > 0 ? splits : 0; } /* measurement aid (tools/conv_half_bench.py): the K-slices of contractions that leave the choice to the launcher */
 
 int nnc_mi355x_tune_set(const char* name, long value)
 {

@@ -188,7 +188,7 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
 	const long tiles = (long)tiles_m * tiles_n;
 	if (tiles > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
-	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
+	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? (g_force_splits ? g_force_splits : gemm_auto_splits(tiles, K)) : 1;
 	int k_per_split = K;
 	if (splits > 1) {
 		if (splits < 8) splits = 8;
@@ -221,6 +221,31 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(splitk_reduce_kernel<half_t>), dim3(grid_for((size_t)slab * 4, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
+// A half-precision contraction whose rows are the pixels of an NHWC view, written straight into an NCHW tensor (EpiStoreHT, mfma_gemm_f16.h): one slab, no batch.
+template <class LA, class LB>
+static int gemm_run_h_planar(const char* name, LA la, LB lb, EpiStoreHT epi, const int K, ccv_nnc_stream_context_t* const ctx, const KOrder ko)
+{
+	const int M = epi.M, N = epi.N;
+	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
+	la.finish();
+	lb.finish();
+	epi.d_p.init(epi.P);
+	const half_t* zp = (const half_t*)zero_page_of(ctx);
+	la.zoff = zp - (const half_t*)la.p;
+	lb.zoff = zp - (const half_t*)lb.p;
+	hipStream_t stream = stream_of(ctx);
+	note_kernel(name);
+	const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+	const bool big = g_force_tile ? !((g_force_tile & 0xff) == 1 && (g_force_tile >> 8) == 1) : (M > 64 && N > 64 && (big_tiles >= device_cu_count() || K >= 4096));
+	char prof_name[192];
+	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_kernel<%d, %d> EPI = EpiStoreHT", name, big ? 2 : 1, big ? 2 : 1);
+	ProfScope prof(prof_name, 2.0 * (double)M * (double)N * (double)K, 0, M, N, K, 1, 1, stream);
+	if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 2, 2>), dim3((unsigned)big_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 127) / 128, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 1, 1>), dim3((unsigned)(((M + 63) / 64) * ((N + 63) / 64)), 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 63) / 64, (N + 63) / 64, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -319,6 +344,10 @@ static int gemm_run_h(const char* name, LA la, LB lb, const GemmOutH out, const 
 			bb.p = lb.p; bb.zoff = 0; bb.ldr = lb.ldr; bb.ldk = lb.ldk; bb.R = lb.R; bb.K = lb.K;
 			return gemm_run_buf_h<LA::KCONTIG, LB::KCONTIG>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 		}
+	}
+	if (g_force_tile) { // measurement aid: (1, 1) = the 64 x 64 tile, anything else the 128 x 128 one
+		if ((g_force_tile & 0xff) == 1 && (g_force_tile >> 8) == 1) return gemm_run_tile_h<LA, LB, 1, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+		return gemm_run_tile_h<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	}
 	if (M > 64 && N > 64 && (big_tiles * zcount >= device_cu_count() || K >= 4096)) return gemm_run_tile_h<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	return gemm_run_tile_h<LA, LB, 1, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);

@@ -37,6 +37,7 @@ struct EpiStoreH {
 	long bias_ldm, bias_ldn;
 	int vec = 0; // store4 allowed (mfma_gemm.h, "epilogues"): four halves of a row in one 8-byte store
 	static constexpr int FLUSH_UNROLL = 2;
+	static constexpr bool PLANAR = false;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) {
@@ -69,6 +70,7 @@ struct EpiPartialH {
 	int M, N;
 	int vec = 0;
 	static constexpr int FLUSH_UNROLL = 1;
+	static constexpr bool PLANAR = false;
 	__device__ __forceinline__ void operator()(int m, int n, float v) const
 	{
 		if (m < M && n < N) c[(long)m * N + n] = v;
@@ -78,6 +80,31 @@ struct EpiPartialH {
 		if (m < M && n < N) *(float4*)(c + (long)m * N + n) = v;
 	}
 };
+// Planar store: the contraction's rows are the pixels m = (image, p) of an NHWC view, its columns the channels n, and the result goes to an NCHW tensor
+// c[image][n][p] -- the convolutions of the half-precision trainers (NCHW tensors) write their output where it belongs instead of into an NHWC scratch image that a
+// transpose pass then re-lays (one read + one write of the output less per forward / data-gradient command).  The kernel stages each 64-row slice of the block tile
+// TRANSPOSED in LDS ([n][m], pitch 65: conflict-free both ways) and a lane writes four consecutive p of one channel plane in one 8-byte store; P % 4 == 0 keeps such a
+// group inside one image.  Bias per channel n; no alpha / accumulate (the callers have none).
+struct EpiStoreHT {
+	half_t* c;
+	const half_t* bias; // bias[n]; may be null
+	int M, N, P;        // N = channels of the output tensor, P = pixels per image
+	FastDiv d_p;
+	static constexpr bool PLANAR = true;
+	static constexpr int FLUSH_UNROLL = 2;
+	int vec = 1;
+	__device__ __forceinline__ void operator()(int, int, float) const {}          // (the kernel's other two ways out are never taken for a planar epilogue:
+	__device__ __forceinline__ void store4(int, int, const float4) const {}       //  they only have to compile)
+	__device__ __forceinline__ void store4p(const int m, const int n, const float4 v) const
+	{
+		if (m < M && n < N) { // M % 4 == 0 (whole images of P % 4 == 0 pixels)
+			const int img = d_p.div(m);
+			const float b = bias ? (float)bias[n] : 0.f;
+			*(halfx4*)(c + ((long)img * N + n) * P + (m - img * P)) = halfx4{ (half_t)(v.x + b), (half_t)(v.y + b), (half_t)(v.z + b), (half_t)(v.w + b) };
+		}
+	}
+};
+__device__ __forceinline__ long M_N_slab(const EpiStoreHT&) { return 0; }
 __device__ __forceinline__ long M_N_slab(const EpiStoreH&) { return 0; }
 __device__ __forceinline__ long M_N_slab(const EpiPartialH& e) { return e.slab; }
 
@@ -224,6 +251,28 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 	}
 	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
+	if constexpr (EPI::PLANAR) { // NCHW output: each 64-row slice staged transposed ([n][m], pitch 65), read back along m (EpiStoreHT above)
+		constexpr int PM = 65;
+		static_assert(BN * PM * 2 <= 2 * (A_HALVES + B_HALVES), "the transposed slice (fp32) fits the operand buffers");
+		float* const cs = (float*)&lds[0][0];
+#pragma unroll
+		for (int ti = 0; ti < WM; ti++) {
+			__syncthreads();
+#pragma unroll
+			for (int tj = 0; tj < WN; tj++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) cs[(col_b + 32 * tj + li) * PM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[ti][tj][r];
+			__syncthreads();
+#pragma unroll 2
+			for (int j = 0; j < BN * 16 / GEMM_THREADS; j++) {
+				const int id = t + GEMM_THREADS * j;
+				const int nl = id >> 4, ml = (id & 15) << 2; // 16 groups of four staged rows per channel
+				const float* const q = cs + nl * PM + ml;
+				epi.store4p(m0 + (ml >> 5) * (32 * WM) + 32 * ti + (ml & 31), n0 + nl, make_float4(q[0], q[1], q[2], q[3]));
+			}
+		}
+		return;
+	}
 	if (epi.vec) { // through LDS, one tile row of every wave per pass (mfma_gemm.h: "epilogues", epi_flush_rows)
 		constexpr int PITCH = BN + 8;
 		static_assert(64 * PITCH * 2 <= 2 * (A_HALVES + B_HALVES), "the staged slice (fp32) fits the operand buffers");

@@ -645,6 +645,7 @@ class Lib:
 
     def profile_enable(self, on): self.dll.nnc_mi355x_profile_enable(int(on))
     def force_tile(self, wm, wn): self.dll.nnc_mi355x_debug_force_tile(int(wm), int(wn))
+    def force_splits(self, n): self.dll.nnc_mi355x_debug_force_splits(int(n))
 
     def tune_set(self, name, value):
         self.dll.nnc_mi355x_tune_set.argtypes = [C.c_char_p, C.c_long]

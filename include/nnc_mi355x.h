@@ -366,6 +366,7 @@ int  nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, doub
  * ((2,2) (2,1) (1,2) (1,1) exist); (0,0) restores the built-in choice.  Used by the parity tests to cover every
  * tile shape on every loader at sizes the oracle finishes. */
 void nnc_mi355x_debug_force_tile(int wm, int wn);
+void nnc_mi355x_debug_force_splits(int splits);
 /* Opt-in fusion for callers that know a CONVOLUTION_FORWARD's only consumer is the RELU_FORWARD behind it (the reference's graphs run
  * that ReLU in place, test/int/nnc/graph.vgg.d.tests.c:80): cmd.algorithm = NNC_MI355X_CONV_ALGO_FUSE_RELU | a, a = 0 .. 2 or 0xff for the
  * backend's choice, makes the command write max(0, conv + bias); the RELU_FORWARD may then be dropped.  Applied in the epilogue of the

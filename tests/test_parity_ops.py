@@ -852,6 +852,8 @@ VEC_EPI_CASES = [
     ("conv 3x3 nhwc", lambda: nnc.CMD_CONVOLUTION_FORWARD(1, 24, 3, 3, 8), ((1, 1), (1, 1)), 0, [(2, 9, 9, 8), (24, 3, 3, 8), (24,)], [(2, 9, 9, 24)], "NHWC"),
     ("conv 1x1 nchw", lambda: nnc.CMD_CONVOLUTION_FORWARD(1, 72, 1, 1, 32), ((1, 1), (0, 0)), 0, [(3, 32, 6, 6), (72, 32, 1, 1), (72,)], [(3, 72, 6, 6)], "NCHW"),
     ("conv 1x1 nchw backward", lambda: nnc.CMD_CONVOLUTION_BACKWARD(1, 72, 1, 1, 32), ((1, 1), (0, 0)), 0, [(3, 72, 6, 6), (3, 32, 6, 6), (72, 32, 1, 1)], [(3, 32, 6, 6), (72, 32, 1, 1), (72,)], "NCHW"),
+    ("conv 3x3 nchw (half: the planar epilogue)", lambda: nnc.CMD_CONVOLUTION_FORWARD(1, 72, 3, 3, 64), ((1, 1), (1, 1)), 0, [(3, 64, 10, 10), (72, 64, 3, 3), (72,)], [(3, 72, 10, 10)], "NCHW"),
+    ("conv 3x3 nchw backward (half: the planar epilogue)", lambda: nnc.CMD_CONVOLUTION_BACKWARD(1, 72, 3, 3, 64), ((1, 1), (1, 1)), 0, [(3, 72, 10, 10), (3, 64, 10, 10), (72, 64, 3, 3)], [(3, 64, 10, 10), (72, 64, 3, 3), (72,)], "NCHW"),
     ("conv 1x1 nchw backward accumulate", lambda: nnc.CMD_CONVOLUTION_BACKWARD(1, 72, 1, 1, 32), ((1, 1), (0, 0)), nnc.ACCUMULATE_OUTPUT, [(3, 72, 6, 6), (3, 32, 6, 6), (72, 32, 1, 1)], [(3, 32, 6, 6), (72, 32, 1, 1), (72,)], "NCHW"),
 ]
 
@@ -861,7 +863,7 @@ VEC_EPI_CASES = [
 def test_vector_epilogue_is_bit_identical_to_the_scalar_one(backend, ref_lib, case, dtype):
     name, mk, hint, flags, in_shapes, out_shapes, fmt = case
     rng = np.random.default_rng(11)
-    ins = [srnd(rng, *s, scale=0.05 if "4096" in name else 1.0).astype(dtype) for s in in_shapes]
+    ins = [srnd(rng, *s, scale=0.05 if ("4096" in name or "planar" in name) else 1.0).astype(dtype) for s in in_shapes]
     outs = [srnd(rng, *s).astype(dtype) for s in out_shapes]
     h = nnc.HINT(*hint) if hint else nnc.NO_HINT
     res = {}
@@ -877,7 +879,7 @@ def test_vector_epilogue_is_bit_identical_to_the_scalar_one(backend, ref_lib, ca
         assert np.array_equal(a.view(np.uint32 if dtype == np.float32 else np.uint16), b.view(np.uint32 if dtype == np.float32 else np.uint16)), name
     # and both are right: the oracle on the same values in fp32 (the reference's CPU backward pass takes NHWC-format filters only: the NCHW backward cases are
     # held to the oracle by test_conv1x1_nchw_* / test_resnet_block.py)
-    if "nchw backward" in name:
+    if "nchw backward" in name or "planar" in name:  # (... nor NCHW-format 3 x 3 filters: tests/test_half.py holds those to the oracle)
         return
     r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, mk(), h, flags, [x.astype(F) for x in ins], [x.astype(F) for x in outs], fmt, backend=nnc.BACKEND_CPU_REF)
     assert r2 == 0
