@@ -164,7 +164,19 @@ def resnet_config(args, half, dawn=False):
     if bn:
         byts, ms, n = sum(k["bytes"] for k in bn), sum(k["ms"] for k in bn), sum(k["launches"] for k in bn)
         ach = byts / (ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+        # HBM bytes per batch-norm command from the committed PMC pass of this configuration (tools/pmc_pass.sh with PMC_BENCH_ARGS="--config ..." ->
+        # profiles/pmc_traffic_<config>.json; counters cannot be collected inside the timed run): every batch-norm kernel (cluster kernels, plane
+        # kernels), read + written, over the forward + backward commands of the recorded step
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)
+        if os.path.exists(tpath):
+            pk = json.load(open(tpath))["kernels"]
+            bnk = [v for k, v in pk.items() if k.startswith("bn_")]
+            fw_cmds_per_step = sum(k["launches"] for k in bn if "apply" in k["name"])  # the forward commands of the recorded step
+            fw_in_pass = sum(v["launches"] for k, v in pk.items() if k.startswith("bn_cluster_forw") or k.startswith("bn_apply_planes"))  # one of these per forward command
+            if bnk and fw_cmds_per_step and fw_in_pass:
+                traffic = sum((v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in bnk) / (fw_in_pass / fw_cmds_per_step) / n
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                            "kernel": "batch norm forward + backward commands (%s)" % "; ".join(sorted(set(k["name"] for k in bn))), "launches": n, "avg_ms": ms / n,
                            "ms_per_step": ms, "recorded_kernels": {k["name"][-100:]: {"ms": k["ms"], "launches": k["launches"], "tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0)} for k in ks}}
     # half precision: the f16 contraction kernel with the most time in that recorded step, against the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s)

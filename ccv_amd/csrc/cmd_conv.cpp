@@ -1044,7 +1044,7 @@ static int conv_h_splits(const conv_geom_t& g, const long M, const int N, const 
 // Can the forward / data-gradient contraction write an NCHW result itself (EpiStoreHT: groups of four pixels of a plane in one store, one K-slice)?
 static bool conv_h_planar_ok(const conv_geom_t& g, const long M, const int N, const int Kred, const long P, const void* dst)
 {
-	return tune(TUNE_GEMM_VEC_EPILOGUE) && g.groups == 1 && P % 4 == 0 && M % 4 == 0 && aligned8(dst) && conv_h_splits(g, M, N, Kred) == 1 && M * (long)N < 0x7fffffff0L && M <= 0x7fffffffL;
+	return tune(TUNE_GEMM_VEC_EPILOGUE) == 1 && g.groups == 1 && P % 4 == 0 && M % 4 == 0 && aligned8(dst) && conv_h_splits(g, M, N, Kred) == 1 && M * (long)N < 0x7fffffff0L && M <= 0x7fffffffL;
 }
 
 // planar != 0: the result goes to that NCHW tensor [N][K][OH * OW] (b is not written)

@@ -4,7 +4,7 @@ fp32: a few ulp (1e-6 relative) is the tolerance, exact for the piecewise-linear
 import numpy as np
 import pytest
 from ccv_amd import nnc
-from harness import exec_pair
+from harness import exec_pair, exec_on
 
 F = np.float32
 SHAPES = [(7,), (4, 5, 6, 3), (3, 1027)]
@@ -364,3 +364,33 @@ def test_upsample(backend, ref_lib, fmt, up_type, align, src, dst):
     assert np.array_equal(got[0], want[0])
     got, want = exec_pair(backend, ref_lib, nnc.CMD_UPSAMPLE("UPSAMPLE_BACKWARD", up_type, ws, hs, align), nnc.NO_HINT, 0, [g], [np.full(ashape, 5, F)], fmt=fmt)
     assert np.array_equal(got[0], want[0])
+
+
+# The reference's four float bilinear int cases and the two half-precision ones (test/int/nnc/upsample.tests.c:15-172) read samples/chessbox.png and compare with a
+# recorded file; the build has no libpng, so they are replayed here on a synthetic chessboard of the same kind -- hard edges, three channels, the reference's own scale
+# factors (2 x up, 1/2 down) and both layouts -- against the reference's CPU backend instead of its recorded output (missing item 7).
+def _chessboard(rows, cols):
+    y, x = np.mgrid[0:rows, 0:cols]
+    board = (((y // 12) + (x // 12)) % 2).astype(F)
+    return np.stack([board * 255, 255 - board * 200, 40 + 100 * board + (x % 7)], axis=-1).astype(F)
+
+
+@pytest.mark.parametrize("fmt", ["NHWC", "NCHW"])
+@pytest.mark.parametrize("what", ["upsample", "downsample"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16], ids=["float", "half"])
+def test_bilinear_resample_of_a_chessboard_like_the_reference_int_cases(backend, ref_lib, fmt, what, dtype):
+    """"upsample bilinear" = UPSAMPLE_FORWARD(BILINEAR, 2, 2, 0) of the image; "downsample bilinear" = UPSAMPLE_BACKWARD(BILINEAR, 2, 2, 0) with the image in the
+    gradient's place (upsample.tests.c:63-172: the transposed operator is the reference's downsampler)."""
+    rows, cols = 96, 128
+    img = _chessboard(rows, cols)
+    a = (img if fmt == "NHWC" else np.ascontiguousarray(img.transpose(2, 0, 1))).astype(dtype)
+    orows, ocols = (rows * 2, cols * 2) if what == "upsample" else (rows // 2, cols // 2)
+    bshape = (orows, ocols, 3) if fmt == "NHWC" else (3, orows, ocols)
+    cmd = nnc.CMD_UPSAMPLE("UPSAMPLE_FORWARD" if what == "upsample" else "UPSAMPLE_BACKWARD", 1, 2, 2, 0)
+    r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [a], [np.zeros(bshape, dtype)], fmt)
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, [a.astype(F)], [np.zeros(bshape, F)], fmt, backend=nnc.BACKEND_CPU_REF)
+    assert r1 == 0 and r2 == 0
+    if dtype == np.float32:
+        assert np.array_equal(got[0], want[0])  # the taps and their order are the reference's
+    else:
+        np.testing.assert_allclose(got[0].astype(F), want[0], rtol=2e-3, atol=0.26)  # halves of values up to 4 x 255: one rounding of the fp32 result
