@@ -5,9 +5,9 @@
 //   o[b, x, h, :] = sum_y softmax_y(scale * q[b, x, h, :] . k[b, y, h / (Hq / Hk), :] + mask[b, h, x, y]) v[b, y, ., :]
 //   causal: row x sees the keys y < x - R + C + 1 (the bottom-right aligned triangle, cpu_ref.c:143); a row that sees none gives 0;
 //   optional "unify heads" projection: d = o (as [B * R, Hq * Dv]) w^T + bias (forward only, like the backend being replaced).
-// This is a FIRST kernel set, fp32 arithmetic on the VALU (half tensors through half_stage.cpp's fp32 images), written for
+// The VALU kernel set (the fallback for shapes the matrix-core kernels further down do not take; half tensors go through half_stage.cpp's fp32 images), written for
 // correctness and determinism, streaming K / V blocks through LDS with the running-maximum softmax so no [R, C] score matrix
-// exists in memory; it is not yet an MFMA kernel.  Work split:
+// exists in memory.  Work split:
 //   forward   a workgroup per (16 query rows, head, batch): thread (row = t / 16, lane = t % 16) owns the scores of keys
 //             lane, lane + 16, ... of a key block, then the output columns lane, lane + 16, ... of its row
 //   backward  the forward pass again into scratch (output + log-sum-exp per row), delta[x] = g[x] . o[x];
@@ -369,6 +369,235 @@ __global__ void __launch_bounds__(256) sdpa_dkv_kernel(const sdpa_geom_t g, cons
 	}
 }
 
+// ---- backward on the matrix cores (round 4) --------------------------------------------------------------------------------------
+// The forward kernel's decomposition, twice more.  dq: a wave owns 32 query rows (their q and g rows in registers for the whole kernel), key blocks of 32 stream
+// through LDS; per block  S^T = K Q^T  and  dP^T = V G^T  (A = the K / V tile, lane: key l & 31, its half's values as 16-byte reads; B = the row's registers), so
+// lane (row, half) holds p and dp of the keys ky(r) of ITS row:  ds = p (dp - delta)  stays in the registers it was computed in and is the B operand of
+// dQ^T [D x 32 rows] += K^T dS^T  (A = K[key ky(j)][d = l & 31] out of the same LDS tile).  p = exp(scale s + mask - lse) from the forward pass's log-sum-exp: no
+// running maximum here.  Conditions: D % 32 == 0 (whole output tiles), Dv % 8 == 0, both <= 128, 16-byte rows.
+template <int DH, int GH, int TD> // DH / GH = D / 2, Dv / 2 rounded up to 32 or 64; TD = D / 32
+__global__ void __launch_bounds__(256) sdpa_dq_mfma_kernel(const sdpa_geom_t g, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ mask, const float* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dq, const long dq_sb, const long dq_sr, const long dq_sh)
+{
+	constexpr int KP = 2 * DH + 4, VP = 2 * GH + 4;
+	__shared__ __attribute__((aligned(16))) float Ks[32 * KP];
+	__shared__ __attribute__((aligned(16))) float Vs[32 * VP];
+	typedef float floatx16 __attribute__((ext_vector_type(16)));
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int li = lane & 31, lh = lane >> 5;
+	const int h = blockIdx.y, b = blockIdx.z, hk = h / g.ratio;
+	const int x = blockIdx.x * 128 + wave * 32 + li;
+	const int dh = g.D >> 1, gh = g.Dv >> 1;
+	float qreg[DH], greg[GH];
+#pragma unroll
+	for (int i = 0; i < DH; i += 4) {
+		float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (x < g.R && i < dh) u = *(const float4*)(q + b * g.q_sb + (long)x * g.q_sr + h * g.q_sh + lh * dh + i);
+		qreg[i] = u.x; qreg[i + 1] = u.y; qreg[i + 2] = u.z; qreg[i + 3] = u.w;
+	}
+#pragma unroll
+	for (int i = 0; i < GH; i += 4) {
+		float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (x < g.R && i < gh) u = *(const float4*)(gr + b * g_sb + (long)x * g_sr + h * g_sh + lh * gh + i);
+		greg[i] = u.x; greg[i + 1] = u.y; greg[i + 2] = u.z; greg[i + 3] = u.w;
+	}
+	floatx16 acc[TD];
+#pragma unroll
+	for (int td = 0; td < TD; td++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) acc[td][r] = 0.f;
+	const int vis = x < g.R ? visible_keys(g, x) : 0;
+	const float my_lse = x < g.R ? lse[((long)b * g.Hq + h) * g.R + x] : 0.f, my_delta = x < g.R ? delta[((long)b * g.Hq + h) * g.R + x] : 0.f;
+	int vis_max = 0;
+	{
+		const int x_last = blockIdx.x * 128 + 127 < g.R ? blockIdx.x * 128 + 127 : g.R - 1;
+		vis_max = visible_keys(g, x_last);
+	}
+	const float* const mrow = mask ? mask + b * g.m_sb + h * g.m_sh + (long)(x < g.R ? x : 0) * g.m_sr : 0;
+	for (int y0 = 0; y0 < vis_max; y0 += 32) {
+		__syncthreads();
+		for (int c = t; c < 32 * (g.D >> 2); c += 256) {
+			const int j = c / (g.D >> 2), d = (c - j * (g.D >> 2)) << 2;
+			*(float4*)(Ks + j * KP + d) = y0 + j < g.C ? *(const float4*)(k + b * g.k_sb + (long)(y0 + j) * g.k_sc + hk * g.k_sh + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		for (int c = t; c < 32 * (g.Dv >> 2); c += 256) {
+			const int j = c / (g.Dv >> 2), d = (c - j * (g.Dv >> 2)) << 2;
+			*(float4*)(Vs + j * VP + d) = y0 + j < g.C ? *(const float4*)(v + b * g.v_sb + (long)(y0 + j) * g.v_sc + hk * g.v_sh + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		__syncthreads();
+		floatx16 s, dp;
+#pragma unroll
+		for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+		const float* const krow = Ks + li * KP + lh * dh;
+#pragma unroll
+		for (int i = 0; i < DH; i += 4)
+			if (i < dh) {
+				const float4 u = *(const float4*)(krow + i);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, qreg[i], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, qreg[i + 1], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, qreg[i + 2], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, qreg[i + 3], s, 0, 0, 0);
+			}
+		const float* const vrow = Vs + li * VP + lh * gh;
+#pragma unroll
+		for (int i = 0; i < GH; i += 4)
+			if (i < gh) {
+				const float4 u = *(const float4*)(vrow + i);
+				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, greg[i], dp, 0, 0, 0);
+				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, greg[i + 1], dp, 0, 0, 0);
+				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, greg[i + 2], dp, 0, 0, 0);
+				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, greg[i + 3], dp, 0, 0, 0);
+			}
+		// this lane's row: register r <-> key y0 + (r & 3) + 8 (r >> 2) + 4 lh;  ds = p (dp - delta)
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+			float ds = 0.f;
+			if (y < vis) {
+				const float sc = g.scale * s[r] + (mrow ? mrow[y] : 0.f);
+				ds = expf(sc - my_lse) * (dp[r] - my_delta);
+			}
+			s[r] = ds;
+		}
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const float* const kcol = Ks + ((j & 3) + 8 * (j >> 2) + 4 * lh) * KP + li;
+#pragma unroll
+			for (int td = 0; td < TD; td++)
+				if (td * 32 < g.D) acc[td] = __builtin_amdgcn_mfma_f32_32x32x2f32(kcol[32 * td], s[j], acc[td], 0, 0, 0);
+		}
+	}
+	if (x < g.R) {
+		float* const orow = dq + b * dq_sb + (long)x * dq_sr + h * dq_sh;
+#pragma unroll
+		for (int td = 0; td < TD; td++)
+			if (td * 32 < g.D) {
+#pragma unroll
+				for (int r4 = 0; r4 < 4; r4++) { // registers 4 r4 .. 4 r4 + 3 are d = 32 td + 8 r4 + 4 lh + 0..3
+					const int d = 32 * td + 8 * r4 + 4 * lh;
+					orow[d] = g.scale * acc[td][4 * r4]; orow[d + 1] = g.scale * acc[td][4 * r4 + 1]; orow[d + 2] = g.scale * acc[td][4 * r4 + 2]; orow[d + 3] = g.scale * acc[td][4 * r4 + 3];
+				}
+			}
+	}
+}
+
+// dk, dv: a wave owns 32 KEYS (their k and v rows in registers), a workgroup 128; the query blocks of 32 of every query head that shares the key head stream
+// through LDS (q, g, lse, delta).  S = Q K^T and dP = G V^T with A = the Q / G tile (lane: query l & 31, its half's values), B = the key's registers: lane
+// (key, half) holds p and ds of the queries qx(r) of ITS key, and they are the B operands of  dV^T [Dv x 32 keys] += G^T P  and  dK^T [D x 32 keys] += Q^T dS
+// (A = G / Q [query qx(j)][column l & 31] out of the same tiles).  One fixed summation order, no atomics.  Conditions: D % 32 == 0, Dv % 32 == 0, both <= 64
+// (four accumulator tiles + both key rows + the two score tiles in 160 registers; beyond that the VALU kernel below).
+template <int TD, int TV> // D / 32, Dv / 32 (1 or 2)
+__global__ void __launch_bounds__(256) sdpa_dkv_mfma_kernel(const sdpa_geom_t g, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ mask, const float* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dk, const long dk_sb, const long dk_sc, const long dk_sh, float* __restrict__ dv, const long dv_sb, const long dv_sc, const long dv_sh)
+{
+	constexpr int DH = 16 * TD, GH = 16 * TV, QP = 2 * DH + 4, GP = 2 * GH + 4;
+	__shared__ __attribute__((aligned(16))) float Qs[32 * QP];
+	__shared__ __attribute__((aligned(16))) float Gs[32 * GP];
+	__shared__ float Ls[32], Ds[32];
+	typedef float floatx16 __attribute__((ext_vector_type(16)));
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int li = lane & 31, lh = lane >> 5;
+	const int hk = blockIdx.y, b = blockIdx.z;
+	const int y0wg = blockIdx.x * 128, y = y0wg + wave * 32 + li;
+	float kreg[DH], vreg[GH];
+#pragma unroll
+	for (int i = 0; i < DH; i += 4) {
+		const float4 u = y < g.C ? *(const float4*)(k + b * g.k_sb + (long)y * g.k_sc + hk * g.k_sh + lh * DH + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+		kreg[i] = u.x; kreg[i + 1] = u.y; kreg[i + 2] = u.z; kreg[i + 3] = u.w;
+	}
+#pragma unroll
+	for (int i = 0; i < GH; i += 4) {
+		const float4 u = y < g.C ? *(const float4*)(v + b * g.v_sb + (long)y * g.v_sc + hk * g.v_sh + lh * GH + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+		vreg[i] = u.x; vreg[i + 1] = u.y; vreg[i + 2] = u.z; vreg[i + 3] = u.w;
+	}
+	floatx16 ak[TD], av[TV];
+#pragma unroll
+	for (int i = 0; i < TD; i++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) ak[i][r] = 0.f;
+#pragma unroll
+	for (int i = 0; i < TV; i++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) av[i][r] = 0.f;
+	// first query row that can see the workgroup's first key (causal): x > y0wg + R - C - 1
+	int xs = 0;
+	if (g.causal) { xs = y0wg + g.R - g.C; if (xs < 0) xs = 0; xs = xs / 32 * 32; }
+	for (int h = hk * g.ratio; h < (hk + 1) * g.ratio; h++)
+		for (int x0 = xs; x0 < g.R; x0 += 32) {
+			__syncthreads();
+			for (int c = t; c < 32 * (g.D >> 2); c += 256) {
+				const int j = c / (g.D >> 2), d = (c - j * (g.D >> 2)) << 2;
+				*(float4*)(Qs + j * QP + d) = x0 + j < g.R ? *(const float4*)(q + b * g.q_sb + (long)(x0 + j) * g.q_sr + h * g.q_sh + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+			for (int c = t; c < 32 * (g.Dv >> 2); c += 256) {
+				const int j = c / (g.Dv >> 2), d = (c - j * (g.Dv >> 2)) << 2;
+				*(float4*)(Gs + j * GP + d) = x0 + j < g.R ? *(const float4*)(gr + b * g_sb + (long)(x0 + j) * g_sr + h * g_sh + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+			if (t < 32) { const int x = x0 + t; Ls[t] = x < g.R ? lse[((long)b * g.Hq + h) * g.R + x] : 0.f; Ds[t] = x < g.R ? delta[((long)b * g.Hq + h) * g.R + x] : 0.f; }
+			__syncthreads();
+			floatx16 s, dp;
+#pragma unroll
+			for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+			const float* const qrow = Qs + li * QP + lh * DH;
+#pragma unroll
+			for (int i = 0; i < DH; i += 4) {
+				const float4 u = *(const float4*)(qrow + i);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, kreg[i], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, kreg[i + 1], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, kreg[i + 2], s, 0, 0, 0);
+				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, kreg[i + 3], s, 0, 0, 0);
+			}
+			const float* const grow = Gs + li * GP + lh * GH;
+#pragma unroll
+			for (int i = 0; i < GH; i += 4) {
+				const float4 u = *(const float4*)(grow + i);
+				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, vreg[i], dp, 0, 0, 0);
+				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, vreg[i + 1], dp, 0, 0, 0);
+				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, vreg[i + 2], dp, 0, 0, 0);
+				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, vreg[i + 3], dp, 0, 0, 0);
+			}
+			// this lane's key: register r <-> query x0 + qx, qx = (r & 3) + 8 (r >> 2) + 4 lh
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const int qx = (r & 3) + 8 * (r >> 2) + 4 * lh, x = x0 + qx;
+				float p = 0.f, ds = 0.f;
+				if (x < g.R && y < g.C && y < visible_keys(g, x)) {
+					const float sc = g.scale * s[r] + (mask ? mask[b * g.m_sb + h * g.m_sh + (long)x * g.m_sr + y] : 0.f);
+					p = expf(sc - Ls[qx]);
+					ds = p * (dp[r] - Ds[qx]);
+				}
+				s[r] = p; dp[r] = ds;
+			}
+#pragma unroll
+			for (int j = 0; j < 16; j++) {
+				const int qx = (j & 3) + 8 * (j >> 2) + 4 * lh;
+				const float* const gcol = Gs + qx * GP + li;
+				const float* const qcol = Qs + qx * QP + li;
+#pragma unroll
+				for (int i = 0; i < TV; i++) av[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(gcol[32 * i], s[j], av[i], 0, 0, 0);
+#pragma unroll
+				for (int i = 0; i < TD; i++) ak[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qcol[32 * i], dp[j], ak[i], 0, 0, 0);
+			}
+		}
+	if (y < g.C) {
+#pragma unroll
+		for (int r4 = 0; r4 < 4; r4++) { // registers 4 r4 .. 4 r4 + 3 of tile i are column 32 i + 8 r4 + 4 lh + 0..3 of this lane's key
+			if (dk) {
+				float* const o = dk + b * dk_sb + (long)y * dk_sc + hk * dk_sh;
+#pragma unroll
+				for (int i = 0; i < TD; i++)
+#pragma unroll
+					for (int e = 0; e < 4; e++) o[32 * i + 8 * r4 + 4 * lh + e] = g.scale * ak[i][4 * r4 + e];
+			}
+			if (dv) {
+				float* const o = dv + b * dv_sb + (long)y * dv_sc + hk * dv_sh;
+#pragma unroll
+				for (int i = 0; i < TV; i++)
+#pragma unroll
+					for (int e = 0; e < 4; e++) o[32 * i + 8 * r4 + 4 * lh + e] = av[i][4 * r4 + e];
+			}
+		}
+	}
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------------------------
 struct bhd_t { int b, n, h, d; long sb, sn, sh; };
 static bool bhd(const ccv_nnc_tensor_t* t, bhd_t* o)
@@ -507,14 +736,39 @@ static int _sdpa_back(EXEC_ARGS)
 	hipLaunchKernelGGL(sdpa_delta_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, stream, g, gp, gi.sb, gi.sn, gi.sh, (const float*)o, delta);
 	HIP_ENFORCE(hipGetLastError());
 	const int dm = g.D > g.Dv ? g.D : g.Dv;
-	if (dq) {
+	// the matrix-core kernels: whole 16-byte chunks of every row, whole 32-column output tiles
+	const bool rows16 = !(((uintptr_t)qp | (uintptr_t)kp | (uintptr_t)vp | (uintptr_t)gp) & 15) && !((g.q_sb | g.q_sr | g.q_sh | g.k_sb | g.k_sc | g.k_sh | g.v_sb | g.v_sc | g.v_sh | gi.sb | gi.sn | gi.sh) & 3);
+	const bool mfma_dq = tune(TUNE_SDPA_MFMA) && rows16 && g.D % 32 == 0 && g.Dv % 8 == 0 && g.D <= 128 && g.Dv <= 128;
+	const bool mfma_dkv = tune(TUNE_SDPA_MFMA) && rows16 && g.D % 32 == 0 && g.Dv % 32 == 0 && g.D <= 64 && g.Dv <= 64;
+	if (dq && mfma_dq) {
+		const dim3 grid((g.R + 127) / 128, g.Hq, g.B);
+		const int td = g.D / 32;
+		note_kernel("sdpa_dq_mfma");
+		ProfScope prof("sdpa_dq|nnc::sdpa_dq_mfma_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (2 * g.D + g.Dv), 0, g.R, g.C, g.D, g.B * g.Hq, 1, stream);
+#define SDPA_DQ(DH, GH, TD) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_dq_mfma_kernel<DH, GH, TD>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dq->data.f32, dqi.sb, dqi.sn, dqi.sh)
+		if (g.Dv <= 64) { if (td == 1) SDPA_DQ(32, 32, 1); else if (td == 2) SDPA_DQ(32, 32, 2); else if (td == 3) SDPA_DQ(64, 32, 3); else SDPA_DQ(64, 32, 4); }
+		else { if (td == 1) SDPA_DQ(32, 64, 1); else if (td == 2) SDPA_DQ(32, 64, 2); else if (td == 3) SDPA_DQ(64, 64, 3); else SDPA_DQ(64, 64, 4); }
+#undef SDPA_DQ
+		HIP_ENFORCE(hipGetLastError());
+	} else if (dq) {
 		const dim3 grid((g.R + BR - 1) / BR, g.Hq, g.B);
 		if (dm <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_dq_kernel<64, 64>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dq->data.f32, dqi.sb, dqi.sn, dqi.sh);
 		else if (dm <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_dq_kernel<128, 32>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dq->data.f32, dqi.sb, dqi.sn, dqi.sh);
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_dq_kernel<256, 16>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dq->data.f32, dqi.sb, dqi.sn, dqi.sh);
 		HIP_ENFORCE(hipGetLastError());
 	}
-	if (dk || dv) {
+	if ((dk || dv) && mfma_dkv) {
+		const dim3 grid((g.C + 127) / 128, g.Hk, g.B);
+		float* const dkp = dk ? dk->data.f32 : 0; float* const dvp = dv ? dv->data.f32 : 0;
+		const long ksb = dk ? dki.sb : 0, ksn = dk ? dki.sn : 0, ksh = dk ? dki.sh : 0, vsb = dv ? dvi.sb : 0, vsn = dv ? dvi.sn : 0, vsh = dv ? dvi.sh : 0;
+		note_kernel("sdpa_dkv_mfma");
+		ProfScope prof("sdpa_dkv|nnc::sdpa_dkv_mfma_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (2 * g.D + 2 * g.Dv), 0, g.C, g.R, g.D, g.B * g.Hk, 1, stream);
+#define SDPA_DKV(TD, TV) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_dkv_mfma_kernel<TD, TV>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dkp, ksb, ksn, ksh, dvp, vsb, vsn, vsh)
+		if (g.D == 32) { if (g.Dv == 32) SDPA_DKV(1, 1); else SDPA_DKV(1, 2); }
+		else { if (g.Dv == 32) SDPA_DKV(2, 1); else SDPA_DKV(2, 2); }
+#undef SDPA_DKV
+		HIP_ENFORCE(hipGetLastError());
+	} else if (dk || dv) {
 		const dim3 grid((g.C + BR - 1) / BR, g.Hk, g.B);
 		float* const dkp = dk ? dk->data.f32 : 0; float* const dvp = dv ? dv->data.f32 : 0;
 		const long ksb = dk ? dki.sb : 0, ksn = dk ? dki.sn : 0, ksh = dk ? dki.sh : 0, vsb = dv ? dvi.sb : 0, vsn = dv ? dvi.sn : 0, vsh = dv ? dvi.sh : 0;

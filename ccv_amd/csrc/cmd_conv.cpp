@@ -510,7 +510,7 @@ static int conv_c3_wgrad(const conv_geom_t& g, const Image4& gr, const Image4& a
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_wgrad_kernel<1>), dim3(grid), dim3(256), 0, stream, c, part);
 	}
 	HIP_ENFORCE(hipGetLastError());
-	hipLaunchKernelGGL(convc3_wgrad_fold, dim3((unsigned)g.K), dim3(256), 0, stream, (const float*)part, waves, g.K, dw, dbias, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
+	hipLaunchKernelGGL(convc3_wgrad_fold, dim3((unsigned)g.K), dim3(256), 0, stream, (const float*)part, (int)grid /* one partial per workgroup */, g.K, dw, dbias, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -1035,10 +1035,10 @@ static int conv_h_splits(const conv_geom_t& g, const long M, const int N, const 
 	if (g_force_splits > 1) return g_force_splits;
 	// Few output tiles and a long reduction (the 4 x 4 and 7 x 7 maps of the trainers: 256 - 392 tiles of 128 x 128 for 256 CUs, 144 K-steps each): eight K-slices
 	// put eight times the workgroups on the chip -- measured (tools/conv_half_bench.py, profiles/r04_v5_conv_half_bench.txt) 512 -> 512 at 4 x 4, batch 512:
-	// forward 0.127 -> 0.072 ms, data gradient 0.135 -> 0.078; at 7 x 7, batch 256: 0.128 -> 0.107 / 0.147 -> 0.118; from ~800 tiles on it only costs
-	// (256 -> 256 at 14 x 14 even, 128 -> 128 at 16 x 16: 0.085 -> 0.139).
+	// forward 0.127 -> 0.072 ms, data gradient 0.135 -> 0.078, plus 0.035 ms for the pass that folds the eight slabs (134 MB of partials); at 7 x 7, batch 256
+	// (392 tiles) the kernel gains 0.021 - 0.029 ms and the fold costs 0.05: one tile per CU at most is where it pays.
 	const long tiles = ((M + 127) / 128) * ((N + 127) / 128);
-	return tiles <= 2L * device_cu_count() && Kred >= 2304 ? 8 : 1;
+	return tiles <= (long)device_cu_count() && Kred >= 2304 ? 8 : 1;
 }
 
 // Can the forward / data-gradient contraction write an NCHW result itself (EpiStoreHT: groups of four pixels of a plane in one store, one K-slice)?

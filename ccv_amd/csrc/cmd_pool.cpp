@@ -306,6 +306,88 @@ static bool pool_back_tiled(const pool_geom_t& g, const bool nhwc, const T* gp, 
 	return true;
 }
 
+// ---- NCHW rows (round 4): the trainers' tensors are NCHW, where the lanes of the kernels above run along x one element each -- 4 (2) bytes loaded per
+// load instruction and lane, the index arithmetic of a whole element (three multiply-shift divisions) per 4 bytes.  Measured in ResNet-50's step at batch 256:
+// the stem's 3 x 3 / 2 max-pool gradient took 1.5 ms for 2.05 GB in fp32 AND 1.3 ms for half of that in f16 (instruction-bound).
+// In the GRADIENT kernel below a lane owns 4 consecutive x of a row: one 16-byte (8-byte) load of a and store of h, and every output (b, g) that any of the
+// four needs is loaded ONCE and offered to all four.  Per element the operations and their order are exactly the kernels' above (each element still sees the
+// windows that concern it in raster order), so the results stay bit-identical with the reference.  Measured in the steps (profiles/r04_v6_pool_rows.txt): the stem's
+// max-pool gradient 1526 -> 509 us (fp32), 1304 -> 426 us (f16); the DawnNet's 2 x 2 max-pool gradients 60 -> 42 us.  It is NOT taken for average pools whose
+// windows tile the map (the window-per-thread kernel above is faster there: 281 vs 636 us), and a forward twin -- four outputs per lane over the union of
+// their windows' columns -- was written and removed: slower than a lane per output on three of four shapes (the DawnNet's 2 x 2: 87 vs 35 us).
+constexpr int PR = 4; // elements per lane along x
+template <class T> struct row4 { typedef T type __attribute__((ext_vector_type(PR))); };
+
+// backward: a lane computes h (n, c, y, x0 .. x0 + 3); W % 4 == 0, a / h rows 4-element aligned.  Every output (oy, ox) whose window covers any of the four is
+// visited once, in raster order, and added to the elements it covers.
+template <bool IS_MAX, class T>
+__global__ void __launch_bounds__(256) pool_back_rows_kernel(const pool_geom_t g, const FastDiv d_w4, const T* __restrict__ gr, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ h, const size_t total)
+{
+	typedef typename row4<T>::type V;
+	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+		int n, y, xq, c;
+		unflatten<false>((int)idx64, g.d_h, d_w4, g.d_c, n, y, xq, c);
+		const int x0 = xq * PR;
+		const int ty = y + g.pby;
+		int oy0 = g.d_sy.div(ty - g.kh + g.kh * g.sy + g.sy) - g.kh, oy1 = g.d_sy.div(ty);
+		// columns: the union over x0 .. x0 + 3
+		int ox0 = g.d_sx.div(x0 + g.pbx - g.kw + g.kw * g.sx + g.sx) - g.kw, ox1 = g.d_sx.div(x0 + PR - 1 + g.pbx);
+		if (oy0 < 0) oy0 = 0;
+		if (ox0 < 0) ox0 = 0;
+		if (oy1 > g.OH - 1) oy1 = g.OH - 1;
+		if (ox1 > g.OW - 1) ox1 = g.OW - 1;
+		const long ib = n * g.a_sn + c * g.a_sc + y * g.a_sh + x0;
+		float av[PR], acc[PR];
+		if (IS_MAX) {
+			const V t = *(const V*)(a + ib);
+#pragma unroll
+			for (int e = 0; e < PR; e++) av[e] = (float)t[e];
+		}
+#pragma unroll
+		for (int e = 0; e < PR; e++) acc[e] = 0.f;
+		const long ob = n * g.b_sn + c * g.b_sc;
+		for (int oy = oy0; oy <= oy1; oy++) {
+			float cy = 0.f;
+			if (!IS_MAX) { // rows of the clipped window (the divisor of this output's average)
+				int wy0 = oy * g.sy - g.pby, wy1 = wy0 + g.kh;
+				if (wy0 < 0) wy0 = 0;
+				if (wy1 > g.H) wy1 = g.H;
+				cy = (float)(wy1 - wy0);
+			}
+			for (int ox = ox0; ox <= ox1; ox++) {
+				const long o = ob + oy * g.b_sh + ox;
+				const float gv = (float)gr[o];
+				const int wx0 = ox * g.sx - g.pbx, wx1 = wx0 + g.kw; // unclipped: coverage test against in-range x
+				float term = gv, bv = 0.f;
+				if (IS_MAX) bv = (float)b[o];
+				else {
+					const int cx0 = wx0 < 0 ? 0 : wx0, cx1 = wx1 > g.W ? g.W : wx1;
+					term = gv / (cy * (float)(cx1 - cx0)); // (float)((wy1 - wy0) * (wx1 - wx0)) of the kernels above: a product of two small integers, exact either way
+				}
+#pragma unroll
+				for (int e = 0; e < PR; e++) {
+					const bool in = (x0 + e >= wx0) & (x0 + e < wx1);
+					if (IS_MAX) acc[e] = (in & (av[e] == bv)) ? acc[e] + gv : acc[e];
+					else acc[e] = in ? acc[e] + term : acc[e];
+				}
+			}
+		}
+		V r;
+#pragma unroll
+		for (int e = 0; e < PR; e++) {
+			if (IS_MAX && g.relu_mask && !(av[e] > 0.f)) acc[e] = 0.f;
+			r[e] = (T)acc[e];
+		}
+		*(V*)(h + ib) = r;
+	}
+}
+// dense NCHW planes whose rows are whole groups of four (of the walked tensor), 8- / 16-byte aligned
+template <class T>
+static bool pool_rows_ok(const pool_geom_t& g, const bool nhwc, const int walked_w, const long s_h, const long s_c, const long s_n, const void* vp, const long o_sw, const long i_sw)
+{
+	return tune(TUNE_POOL_ROWS) && !nhwc && o_sw == 1 && i_sw == 1 && walked_w % PR == 0 && s_h % PR == 0 && s_c % PR == 0 && s_n % PR == 0 && (((uintptr_t)vp) & (PR * sizeof(T) - 1)) == 0;
+}
+
 static bool pool_vec4_ok(const pool_geom_t& g, bool nhwc, const void* p0, const void* p1, const void* p2, const void* p3)
 {
 	if (!nhwc || g.C % 4 || g.a_sc != 1 || g.b_sc != 1) return false;
@@ -413,6 +495,12 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 			const half_t* ap = a ? (const half_t*)a->data.f16 + (long)n0 * g.a_sn : 0;
 			const half_t* bp = b ? (const half_t*)b->data.f16 + (long)n0 * g.b_sn : 0;
 			half_t* hp = (half_t*)h->data.f16 + (long)n0 * g.a_sn;
+			if ((IS_MAX || !pool_tiles(g)) && pool_rows_ok<half_t>(g, nhwc, g.W, g.a_sh, g.a_sc, g.a_sn, hp, g.a_sw, g.b_sw) && (!ap || (((uintptr_t)ap) & (PR * sizeof(half_t) - 1)) == 0)) {
+				FastDiv d4; d4.init(g.W / PR);
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_rows_kernel<IS_MAX, half_t>), dim3(grid_for(total / PR, 256)), dim3(256), 0, stream, g, d4, gp, ap, bp, hp, total / PR);
+				HIP_ENFORCE(hipGetLastError());
+				continue;
+			}
 			if (pool_back_tiled<IS_MAX, half_t>(g, nhwc, gp, ap, bp, hp, nn, stream)) { HIP_ENFORCE(hipGetLastError()); continue; }
 			if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX, half_t>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
 			else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<false, IS_MAX, half_t>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);
@@ -423,6 +511,12 @@ static int pool_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 		const float* ap = a ? a->data.f32 + (long)n0 * g.a_sn : 0;
 		const float* bp = b ? b->data.f32 + (long)n0 * g.b_sn : 0;
 		float* hp = h->data.f32 + (long)n0 * g.a_sn;
+		if ((IS_MAX || !pool_tiles(g)) && pool_rows_ok<float>(g, nhwc, g.W, g.a_sh, g.a_sc, g.a_sn, hp, g.a_sw, g.b_sw) && (!ap || aligned16(ap))) {
+			FastDiv d4; d4.init(g.W / PR);
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_rows_kernel<IS_MAX, float>), dim3(grid_for(total / PR, 256)), dim3(256), 0, stream, g, d4, gp, ap, bp, hp, total / PR);
+			HIP_ENFORCE(hipGetLastError());
+			continue;
+		}
 		if (pool_back_tiled<IS_MAX, float>(g, nhwc, gp, ap, bp, hp, nn, stream)) { HIP_ENFORCE(hipGetLastError()); continue; }
 		if (pool_vec4_ok(g, nhwc, gp, hp, ap, bp)) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_v4_kernel<IS_MAX>), dim3(grid_for(total / 4, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total / 4);
 		else if (nhwc) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool_back_kernel<true, IS_MAX, float>), dim3(grid_for(total, 256)), dim3(256), 0, stream, g, gp, ap, bp, hp, total);

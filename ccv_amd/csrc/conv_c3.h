@@ -159,7 +159,7 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const ConvC3
 // constant 1 -- the bias gradient sum over pixels g[pixel][k] in the same contraction.  A = g (k x pixel): lane (m, kq) loads
 // g[pixel 4 step + kq][MT m .. MT m + MT - 1] (16 bytes for MT = 4: output channel MT m + i in row m of channel tile i);
 // B = patch (pixel x 32): two tiles.  Every wave accumulates MT x 2 tiles over its share of the pixels and writes them to
-// part[wave][K][32]; convc3_wgrad_fold adds the waves up in a fixed order (deterministic) and applies accumulate.
+// part[workgroup][K][32] (its four waves summed through LDS); convc3_wgrad_fold adds the workgroups up in a fixed order (deterministic) and applies accumulate.
 template <int MT>
 static __global__ void __launch_bounds__(256) conv3x3_c3_wgrad_kernel(const ConvC3Args g, float* const part)
 {
@@ -196,14 +196,20 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_wgrad_kernel(const Conv
 			}
 		}
 	}
-	// D of tile (i, t): row 4 kq + r = output channel MT (4 kq + r) + i, column n = patch element 16 t + n
-	float* const out = part + (long)wid * g.K * 32;
+	// D of tile (i, t): row 4 kq + r = output channel MT (4 kq + r) + i, column n = patch element 16 t + n.  The workgroup's four waves meet in LDS first
+	// ((w0 + w1) + (w2 + w3), a fixed order): one [K][32] partial per WORKGROUP -- a quarter of what the fold pass has to read (it was 148 us of the DawnNet's
+	// 5.6 ms step for a 45 us kernel: 4096 per-wave partials of 8 KB through 64 workgroups)
+	__shared__ float red[4][MT * 16 * 32];
+	float* const mine = red[threadIdx.x >> 6];
 #pragma unroll
 	for (int i = 0; i < MT; i++)
 #pragma unroll
 		for (int t = 0; t < 2; t++)
 #pragma unroll
-			for (int r = 0; r < 4; r++) out[(long)(MT * (4 * kq + r) + i) * 32 + 16 * t + n] = acc[i][t][r];
+			for (int r = 0; r < 4; r++) mine[(MT * (4 * kq + r) + i) * 32 + 16 * t + n] = acc[i][t][r];
+	__syncthreads();
+	float* const out = part + (long)blockIdx.x * g.K * 32;
+	for (int i = threadIdx.x; i < MT * 16 * 32; i += 256) out[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
 // dw[k][0..26] (+)= sum_w part[w][k][0..26], dbias[k] (+)= sum_w part[w][k][27].  One workgroup per output channel k: thread

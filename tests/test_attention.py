@@ -137,3 +137,38 @@ def test_attention_forward_on_the_matrix_cores_agrees_with_the_valu_kernel(backe
         assert r1 == 0
         close(got[0], want[0])
     assert any("sdpa_forw_mfma_kernel" in n for n in seen[1]) and not any("sdpa_forw_mfma_kernel" in n for n in seen[0]), seen
+
+
+def test_attention_backward_on_the_matrix_cores_agrees_with_the_valu_kernels(backend, ref_lib):
+    """dq and dk / dv through both kernel sets of cmd_attention.cpp (tuning key SDPA_MFMA): the same gradients within tolerance of each other and of the reference's
+    CPU backward pass, the matrix-core kernels recorded as such (round 4: sdpa_dq_mfma_kernel, sdpa_dkv_mfma_kernel)."""
+    B, R, Cn, Hq, Hk, D, Dv = 2, 150, 170, 4, 2, 64, 64
+    rng = np.random.default_rng(12)
+    q = rng.random((B, R, Hq, D), dtype=F) - F(0.5)
+    k = rng.random((B, Cn, Hk, D), dtype=F) - F(0.5)
+    v = rng.random((B, Cn, Hk, Dv), dtype=F) - F(0.5)
+    g = rng.random((B, R, Hq, Dv), dtype=F) - F(0.5)
+    cmd = sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_BACKWARD", float(1.0 / np.sqrt(D)), True)
+    ins = [g, None, None, q, k, v]
+    outs = [np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)]
+    r0, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, ins, outs, backend=nnc.BACKEND_CPU_REF)
+    assert r0 == 0
+    seen, res = {}, {}
+    for mode in (1, 0):
+        backend.tune_set("SDPA_MFMA", mode)
+        backend.profile_enable(1)
+        try:
+            r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, ins, outs)
+            backend.stream_wait(None)
+            seen[mode] = [r[0] for r in backend.profile_records()]
+        finally:
+            backend.profile_enable(0)
+            backend.tune_set("SDPA_MFMA", 1)
+        assert r1 == 0
+        res[mode] = got
+        for a, b in zip(got, want):
+            close(a, b)
+    for a, b in zip(res[1], res[0]):
+        close(a, b, tol=2e-5)
+    assert any("sdpa_dq_mfma_kernel" in n for n in seen[1]) and any("sdpa_dkv_mfma_kernel" in n for n in seen[1]), seen
+    assert not any("_mfma_kernel" in n for n in seen[0]), seen

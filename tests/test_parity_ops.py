@@ -349,7 +349,9 @@ def test_pool_forward_backward_bit_exact(backend, ref_lib, case, kind):
     assert np.array_equal(got[0].view(np.int32), want[0].view(np.int32))
 
 
-@pytest.mark.parametrize("geom", [(3, 9, 8, 5, 3, 3, (2, 2), (1, 1)), (3, 8, 10, 8, 2, 2, (2, 2), (0, 0)), (2, 9, 11, 4, 2, 2, (2, 2), (0, 0))], ids=["overlapping", "tiling", "tiling-leftover"])
+@pytest.mark.parametrize("geom", [(3, 9, 8, 5, 3, 3, (2, 2), (1, 1)), (3, 8, 10, 8, 2, 2, (2, 2), (0, 0)), (2, 9, 11, 4, 2, 2, (2, 2), (0, 0)),
+                                  (2, 16, 16, 3, 3, 3, (2, 2), (1, 1)), (2, 8, 16, 5, 2, 2, (2, 2), (0, 0)), (2, 6, 12, 4, 2, 2, (2, 2), (0, 0)), (2, 7, 8, 3, 3, 3, (1, 1), (1, 1)), (2, 8, 8, 2, 8, 8, (1, 1), (0, 0))],
+                         ids=["overlapping", "tiling", "tiling-leftover", "stem-3x3-s2-rows", "tiling-rows", "tiling-rows-odd-ow", "3x3-s1-rows", "global-rows"])
 @pytest.mark.parametrize("kind", ["max", "avg"])
 def test_pool_batched_and_nchw(backend, ref_lib, kind, geom):
     """The CPU oracle walks only image 0 of a batch and is NHWC-only: check a batch image by image, and NCHW against
@@ -376,6 +378,18 @@ def test_pool_batched_and_nchw(backend, ref_lib, kind, geom):
     assert r == 0 and np.array_equal(bc.transpose(0, 2, 3, 1), b)
     r, (hc,) = exec_on(backend, nnc.GPU_MEMORY, bcmd, hint, 0, [gc, ac, bc], [np.zeros_like(ac)], fmt="NCHW")
     assert r == 0 and np.array_equal(hc.transpose(0, 2, 3, 1), hg)
+    # the trainers' half-precision tensors: NCHW (rows of four per lane where the map allows) == NHWC (one lane per element), bit for bit
+    H = np.float16
+    a16, g16 = a.astype(H), g.astype(H)
+    r, (b16,) = exec_on(backend, nnc.GPU_MEMORY, fcmd, hint, 0, [a16], [np.zeros((n, oh, ow, c), H)])
+    assert r == 0
+    r, (h16,) = exec_on(backend, nnc.GPU_MEMORY, bcmd, hint, 0, [g16, a16, b16], [np.zeros_like(a16)])
+    assert r == 0
+    ac16, gc16 = np.ascontiguousarray(a16.transpose(0, 3, 1, 2)), np.ascontiguousarray(g16.transpose(0, 3, 1, 2))
+    r, (bc16,) = exec_on(backend, nnc.GPU_MEMORY, fcmd, hint, 0, [ac16], [np.zeros((n, c, oh, ow), H)], fmt="NCHW")
+    assert r == 0 and np.array_equal(bc16.transpose(0, 2, 3, 1), b16)
+    r, (hc16,) = exec_on(backend, nnc.GPU_MEMORY, bcmd, hint, 0, [gc16, ac16, bc16], [np.zeros_like(ac16)], fmt="NCHW")
+    assert r == 0 and np.array_equal(hc16.transpose(0, 2, 3, 1), h16)
 
 
 @pytest.mark.parametrize("shape", [(1,), (7,), (4, 5, 6, 3), (2, 1027)])
