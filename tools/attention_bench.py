@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Scaled-dot-product attention forward on the MI355X: the matrix-core kernel (sdpa_forw_mfma_kernel, fp32 MFMA) against the VALU kernel of cmd_attention.cpp
-on the same tensors (tuning key SDPA_MFMA), HIP-event timed.  usage: python tools/attention_bench.py > gpurun_out/attention_bench.txt"""
+"""Scaled-dot-product attention forward AND backward on the MI355X: the matrix-core kernels (sdpa_forw_mfma_kernel, sdpa_dq_mfma_kernel, sdpa_dkv_mfma_kernel: fp32 MFMA)
+against the VALU kernels of cmd_attention.cpp on the same tensors (tuning key SDPA_MFMA), HIP-event timed.  The backward command includes its own forward
+re-run (output + log-sum-exp into scratch) and the delta pass: 3.5 x the forward's products in all.  usage: python tools/attention_bench.py > gpurun_out/attention_bench.txt"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -39,3 +40,21 @@ for (B, R, C, H, Hk, D, causal) in [(8, 2048, 2048, 16, 16, 64, False), (8, 2048
         line += "   %s %8.3f ms %6.1f TFLOP/s" % ("matrix cores" if mode else "VALU kernel ", ms, flops / ms / 1e9)
     L.tune_set("SDPA_MFMA", 1)
     print(line, flush=True)
+    g, dq, dk, dv = tens(B, R, H, D), tens(B, R, H, D), tens(B, C, Hk, D), tens(B, C, Hk, D)
+    bcmd = T.sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_BACKWARD", float(1.0 / np.sqrt(D)), causal)
+    line = "   backward (forward re-run + dq + dk / dv: 7 products)        "
+    for mode in (1, 0):
+        L.tune_set("SDPA_MFMA", mode)
+        reps = 3 if mode else 1
+        assert L.cmd_exec(bcmd, nnc.NO_HINT, 0, [g, None, None, q, k, v], [dq, dk, dv], s) == 0
+        L.dll.nnc_mi355x_event_record(e0, s)
+        for _ in range(reps):
+            assert L.cmd_exec(bcmd, nnc.NO_HINT, 0, [g, None, None, q, k, v], [dq, dk, dv], s) == 0
+        L.dll.nnc_mi355x_event_record(e1, s)
+        L.stream_wait(s)
+        ms = L.dll.nnc_mi355x_event_elapsed_ms(e0, e1) / reps
+        line += "   %s %8.3f ms %6.1f TFLOP/s" % ("matrix cores" if mode else "VALU kernels", ms, 3.5 * flops / ms / 1e9)
+    L.tune_set("SDPA_MFMA", 1)
+    print(line, flush=True)
+    for t in (q, k, v, o, g, dq, dk, dv):
+        t.free()
