@@ -15,6 +15,7 @@
 //             dk, dv: a workgroup per (16 keys, KEY head, batch) walks every query block of every query head that shares the
 //             key head and accumulates its 16 rows of dk / dv in registers -- no atomics, one fixed summation order.
 #include "common.h"
+#include "isa.h" // half_t, halfx8, nnc_mfma_f16
 #include <math.h>
 
 using namespace nnc;
@@ -226,6 +227,110 @@ __global__ void __launch_bounds__(256) sdpa_forw_mfma_kernel(const sdpa_geom_t g
 					orow[d] = acc[tv][4 * r4] * inv; orow[d + 1] = acc[tv][4 * r4 + 1] * inv; orow[d + 2] = acc[tv][4 * r4 + 2] * inv; orow[d + 3] = acc[tv][4 * r4 + 3] * inv;
 				}
 			}
+		if (lse && lh == 0) lse[((long)b * g.Hq + h) * g.R + x] = l_run > 0.f ? m_run + logf(l_run) : -INFINITY;
+	}
+}
+
+// ---- forward in half precision on the f16 matrix cores (round 4) ---------------------------------------------------------------------
+// CCV_16F q / k / v / o (the reference's flash_attn rows, scaled_dot_product_attention/gpu/..._flash_attn.cu): the fp32 kernel's decomposition on
+// v_mfma_f32_32x32x16_f16 -- 16 reduction terms per instruction instead of 2, fp32 accumulation, the running-maximum softmax in fp32:
+//   S^T [32 keys x 32 rows] = K Q^T      A = 8 halves of the lane's key row out of LDS (one ds_read_b128 per 16 of d), B = 8 halves of the lane's query row, held in
+//                                        registers for the whole kernel; lane (l & 31, half l >> 5) stands for d = 16 s + 8 half + 0..7 in both operands
+//   O^T [Dv x 32 rows] += V^T P^T        two sub-steps of 16 keys; the lane holds the probabilities of the keys ky(r) = (r & 3) + 8 (r >> 2) + 4 half of its row, so
+//                                        sub-step t takes registers 8 t .. 8 t + 7 -- rounded to half, still in place -- as B, and A = the same eight keys of column
+//                                        dv = l & 31 out of a TRANSPOSED V tile in LDS ([dv][key]: two 8-byte reads: keys 16 t + 4 half + 0..3 and + 8)
+// Conditions: D % 16 == 0, Dv % 32 == 0, both <= 128, 16-byte aligned rows, no additive mask (with one, or for other shapes, the half tensors go through fp32
+// images and the fp32 kernels).  The log-sum-exp output, if asked for, is fp32.
+template <int DS, int TV> // DS = D / 16 (1 .. 8), TV = Dv / 32 (1 .. 4)
+__global__ void __launch_bounds__(256) sdpa_forw_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, half_t* __restrict__ o, float* __restrict__ lse)
+{
+	constexpr int KP = 16 * DS + 8, VTP = 40; // halves per row: K tile [32 keys][D + 8], V^T tile [Dv][32 keys + 8]
+	__shared__ __attribute__((aligned(16))) half_t Ks[32 * KP];
+	__shared__ __attribute__((aligned(16))) half_t Vt[32 * TV * VTP];
+	typedef float floatx16 __attribute__((ext_vector_type(16)));
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int li = lane & 31, lh = lane >> 5;
+	const int h = blockIdx.y, b = blockIdx.z, hk = h / g.ratio;
+	const int x = blockIdx.x * 128 + wave * 32 + li;
+	halfx8 qf[DS];
+#pragma unroll
+	for (int s = 0; s < DS; s++) {
+		qf[s] = halfx8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+		if (x < g.R) qf[s] = *(const halfx8*)(q + b * g.q_sb + (long)x * g.q_sr + h * g.q_sh + 16 * s + 8 * lh);
+	}
+	floatx16 acc[TV];
+#pragma unroll
+	for (int tv = 0; tv < TV; tv++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) acc[tv][r] = 0.f;
+	float m_run = -INFINITY, l_run = 0.f;
+	const int vis = x < g.R ? visible_keys(g, x) : 0;
+	int vis_max = 0;
+	{
+		const int x_last = blockIdx.x * 128 + 127 < g.R ? blockIdx.x * 128 + 127 : g.R - 1;
+		vis_max = visible_keys(g, x_last);
+	}
+	for (int y0 = 0; y0 < vis_max; y0 += 32) {
+		__syncthreads();
+		for (int c = t; c < 32 * 2 * DS; c += 256) { // K: 16-byte chunks as they lie
+			const int j = c / (2 * DS), d = (c - j * (2 * DS)) << 3;
+			*(halfx8*)(Ks + j * KP + d) = y0 + j < g.C ? *(const halfx8*)(k + b * g.k_sb + (long)(y0 + j) * g.k_sc + hk * g.k_sh + d) : halfx8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+		}
+		for (int c = t; c < 32 * 4 * TV; c += 256) { // V: a 16-byte chunk of key j lands transposed, one half per dv row
+			const int j = c & 31, d = (c >> 5) << 3;
+			const halfx8 u = y0 + j < g.C ? *(const halfx8*)(v + b * g.v_sb + (long)(y0 + j) * g.v_sc + hk * g.v_sh + d) : halfx8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+			for (int e = 0; e < 8; e++) Vt[(d + e) * VTP + j] = u[e];
+		}
+		__syncthreads();
+		floatx16 s;
+#pragma unroll
+		for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+		for (int i = 0; i < DS; i++) s = nnc_mfma_f16(*(const halfx8*)(Ks + li * KP + 16 * i + 8 * lh), qf[i], s);
+		// scores of this lane's row: register r <-> key y0 + (r & 3) + 8 (r >> 2) + 4 lh
+		float bm = -INFINITY;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+			if (y < vis) { s[r] = g.scale * s[r]; bm = fmaxf(bm, s[r]); }
+			else s[r] = -INFINITY;
+		}
+		bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+		const float m_new = fmaxf(m_run, bm);
+		float ps = 0.f;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			s[r] = s[r] == -INFINITY ? 0.f : expf(s[r] - m_new);
+			ps += s[r];
+		}
+		ps += __shfl_xor(ps, 32, 64);
+		const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+		l_run = l_run * alpha + ps;
+		m_run = m_new;
+#pragma unroll
+		for (int tv = 0; tv < TV; tv++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[tv][r] *= alpha;
+#pragma unroll
+		for (int tt = 0; tt < 2; tt++) {
+			const halfx8 pf = halfx8{ (half_t)s[8 * tt], (half_t)s[8 * tt + 1], (half_t)s[8 * tt + 2], (half_t)s[8 * tt + 3], (half_t)s[8 * tt + 4], (half_t)s[8 * tt + 5], (half_t)s[8 * tt + 6], (half_t)s[8 * tt + 7] };
+#pragma unroll
+			for (int tv = 0; tv < TV; tv++) {
+				const half_t* const vrow = Vt + (32 * tv + li) * VTP + 16 * tt + 4 * lh;
+				const halfx4 lo = *(const halfx4*)vrow, hi = *(const halfx4*)(vrow + 8);
+				acc[tv] = nnc_mfma_f16(halfx8{ lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] }, pf, acc[tv]);
+			}
+		}
+	}
+	if (x < g.R) {
+		const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+		half_t* const orow = o + b * g.o_sb + (long)x * g.o_sr + h * g.o_sh;
+#pragma unroll
+		for (int tv = 0; tv < TV; tv++)
+#pragma unroll
+			for (int r4 = 0; r4 < 4; r4++) // registers 4 r4 .. 4 r4 + 3 are dv = 32 tv + 8 r4 + 4 lh + 0..3
+				*(halfx4*)(orow + 32 * tv + 8 * r4 + 4 * lh) = halfx4{ (half_t)(acc[tv][4 * r4] * inv), (half_t)(acc[tv][4 * r4 + 1] * inv), (half_t)(acc[tv][4 * r4 + 2] * inv), (half_t)(acc[tv][4 * r4 + 3] * inv) };
 		if (lse && lh == 0) lse[((long)b * g.Hq + h) * g.R + x] = l_run > 0.f ? m_run + logf(l_run) : -INFINITY;
 	}
 }
@@ -600,10 +705,10 @@ __global__ void __launch_bounds__(256) sdpa_dkv_mfma_kernel(const sdpa_geom_t g,
 
 // ---- host -----------------------------------------------------------------------------------------------------------------------
 struct bhd_t { int b, n, h, d; long sb, sn, sh; };
-static bool bhd(const ccv_nnc_tensor_t* t, bhd_t* o)
+static bool bhd(const ccv_nnc_tensor_t* t, bhd_t* o, const int datatype = CCV_32F)
 { // [B, N, H, D] or [B, N, D]; D contiguous
 	const int nd = tensor_nd(t->info.dim);
-	if ((nd != 3 && nd != 4) || CCV_GET_DATA_TYPE(t->info.datatype) != CCV_32F) return false;
+	if ((nd != 3 && nd != 4) || CCV_GET_DATA_TYPE(t->info.datatype) != datatype) return false;
 	int st[CCV_NNC_MAX_DIM_ALLOC];
 	tensor_strides(t, st);
 	if (st[nd - 1] != 1) return false;
@@ -705,6 +810,71 @@ static int _sdpa_forw(EXEC_ARGS)
 	return nnc_mi355x_cmd_exec(gemm, no_hint, 0, gin, bias ? 3 : 2, gout, 1, stream_context);
 }
 
+// CCV_16F tensors: the f16 kernel where its conditions hold (CCV_NNC_EXEC_NO_KERNEL = not this path: the caller goes through fp32 images)
+static int sdpa_forw_half(EXEC_ARGS)
+{
+	if (input_size < 3 || output_size < 1 || !inputs[0] || !inputs[1] || !inputs[2] || !outputs[0]) return CCV_NNC_EXEC_NO_KERNEL;
+	for (int i = 3; i < input_size; i++) if (inputs[i]) return CCV_NNC_EXEC_NO_KERNEL; // mask / head projection: the fp32 route
+	for (int i = 2; i < output_size; i++) if (outputs[i]) return CCV_NNC_EXEC_NO_KERNEL;
+	if (!tune(TUNE_SDPA_MFMA)) return CCV_NNC_EXEC_NO_KERNEL;
+	const ccv_nnc_tensor_t* const q = inputs[0]; const ccv_nnc_tensor_t* const k = inputs[1]; const ccv_nnc_tensor_t* const v = inputs[2];
+	ccv_nnc_tensor_t* const c = outputs[0];
+	ccv_nnc_tensor_t* const lse_t = output_size > 1 ? outputs[1] : 0;
+	bhd_t qi, ki, vi, ci;
+	if (!bhd(q, &qi, CCV_16F) || !bhd(k, &ki, CCV_16F) || !bhd(v, &vi, CCV_16F) || !bhd(c, &ci, CCV_16F)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (tensor_nd(q->info.dim) != tensor_nd(k->info.dim) || tensor_nd(k->info.dim) != tensor_nd(v->info.dim)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (qi.b != ki.b || ki.b != vi.b || qi.d != ki.d || ki.n != vi.n || ki.h != vi.h || qi.h < ki.h || qi.h % ki.h) return CCV_NNC_EXEC_NO_KERNEL;
+	sdpa_geom_t g;
+	memset(&g, 0, sizeof(g));
+	g.B = qi.b; g.R = qi.n; g.C = ki.n; g.Hq = qi.h; g.Hk = ki.h; g.D = qi.d; g.Dv = vi.d; g.ratio = qi.h / ki.h;
+	g.q_sb = qi.sb; g.q_sr = qi.sn; g.q_sh = qi.sh; g.k_sb = ki.sb; g.k_sc = ki.sn; g.k_sh = ki.sh; g.v_sb = vi.sb; g.v_sc = vi.sn; g.v_sh = vi.sh;
+	g.scale = cmd.info.scaled_dot_product_attention.scale;
+	g.causal = cmd.info.scaled_dot_product_attention.is_causal;
+	if (ci.b != g.B || ci.n != g.R || ci.h != g.Hq || ci.d != g.Dv) return CCV_NNC_EXEC_INVALID;
+	g.o_sb = ci.sb; g.o_sr = ci.sn; g.o_sh = ci.sh;
+	if (g.D % 16 || g.Dv % 32 || g.D > 128 || g.Dv > 128 || g.D < 16) return CCV_NNC_EXEC_NO_KERNEL;
+	if ((((uintptr_t)q->data.u8 | (uintptr_t)k->data.u8 | (uintptr_t)v->data.u8) & 15) || ((uintptr_t)c->data.u8 & 7)) return CCV_NNC_EXEC_NO_KERNEL;
+	if ((g.q_sb | g.q_sr | g.q_sh | g.k_sb | g.k_sc | g.k_sh | g.v_sb | g.v_sc | g.v_sh) & 7) return CCV_NNC_EXEC_NO_KERNEL;
+	if ((g.o_sb | g.o_sr | g.o_sh) & 3) return CCV_NNC_EXEC_NO_KERNEL;
+	float* lse = 0;
+	if (lse_t) {
+		if (CCV_GET_DATA_TYPE(lse_t->info.datatype) != CCV_32F || !tensor_contiguous(lse_t) || tensor_count(lse_t->info) != (size_t)g.B * g.Hq * g.R) return CCV_NNC_EXEC_NO_KERNEL;
+		lse = lse_t->data.f32;
+	}
+	MarkerScope marker(cmd.cmd);
+	if (!g.R || !g.Hq || !g.B) return CCV_NNC_EXEC_SUCCESS;
+	hipStream_t stream = stream_of(stream_context);
+	const dim3 grid((g.R + 127) / 128, g.Hq, g.B);
+	const half_t* const qp = (const half_t*)q->data.u8; const half_t* const kp = (const half_t*)k->data.u8; const half_t* const vp = (const half_t*)v->data.u8;
+	half_t* const op = (half_t*)c->data.u8;
+	note_kernel("sdpa_fwd_f16");
+	ProfScope prof("sdpa_fwd_h|nnc::sdpa_forw_f16_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (g.D + g.Dv), 0, g.R, g.C, g.D, g.B * g.Hq, 1, stream);
+#define SDPA_F16_TV(DS) do { switch (g.Dv / 32) { \
+		case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 1>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
+		case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 2>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
+		case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 3>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
+		default: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 4>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; } } while (0)
+	switch (g.D / 16) {
+		case 1: SDPA_F16_TV(1); break; case 2: SDPA_F16_TV(2); break; case 3: SDPA_F16_TV(3); break; case 4: SDPA_F16_TV(4); break;
+		case 5: SDPA_F16_TV(5); break; case 6: SDPA_F16_TV(6); break; case 7: SDPA_F16_TV(7); break; default: SDPA_F16_TV(8); break;
+	}
+#undef SDPA_F16_TV
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+// the registered forward entry: fp32 tensors -> the fp32 kernels; half q / k / v / o -> the f16 kernel where it applies; anything else with a half tensor -> the fp32
+// kernels on fp32 images (half_stage.cpp)
+static int _sdpa_forw_any(EXEC_ARGS)
+{
+	if (!any_half_tensor(inputs, input_size, outputs, output_size)) {
+		MarkerScope marker(cmd.cmd);
+		return _sdpa_forw(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	}
+	const int r = sdpa_forw_half(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context); // (opens its own marker range once it knows it runs)
+	if (r != CCV_NNC_EXEC_NO_KERNEL) return r;
+	return half_staged_exec(_sdpa_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+}
+
 static int _sdpa_back(EXEC_ARGS)
 { // inputs (g, ., ., q, k, v, [mask], [w], [bias], [y], [lse], [qkv]); outputs (dq, dk, dv, ...)
 	if (input_size < 6 || output_size < 3 || !inputs[0] || !inputs[3] || !inputs[4] || !inputs[5]) return CCV_NNC_EXEC_INVALID;
@@ -786,5 +956,6 @@ static int _sdpa_back(EXEC_ARGS)
 	extern "C" void _register_command_##CMD##_backend_##BACKEND(ccv_nnc_cmd_backend_registry_t* const registry) \
 	{ registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC; registry->tensor_datatypes = CCV_32F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = EXEC; NNC_HALF_STAGED(registry, EXEC); }
 
-NNC_REG(CCV_NNC_SCALED_DOT_PRODUCT_ATTENTION_FORWARD, CCV_NNC_BACKEND_GPU_REF, _sdpa_forw)
+extern "C" void _register_command_CCV_NNC_SCALED_DOT_PRODUCT_ATTENTION_FORWARD_backend_CCV_NNC_BACKEND_GPU_REF(ccv_nnc_cmd_backend_registry_t* const registry)
+{ registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC; registry->tensor_datatypes = CCV_32F | CCV_16F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = _sdpa_forw_any; }
 NNC_REG(CCV_NNC_SCALED_DOT_PRODUCT_ATTENTION_BACKWARD, CCV_NNC_BACKEND_GPU_REF, _sdpa_back)

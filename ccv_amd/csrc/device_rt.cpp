@@ -607,11 +607,13 @@ void ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal)
 }
 void ccv_nnc_stream_compat_emit_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
+	if (nnc::sync_trace_on()) fprintf(stderr, "[nnc_mi355x] > EMIT signal %p on stream %p\n", (const void*)signal, (const void*)stream);
 	nnc::comm_flush_if_pending();
 	HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, bind(stream)->stream));
 }
 void ccv_nnc_stream_compat_wait_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
+	if (nnc::sync_trace_on()) fprintf(stderr, "[nnc_mi355x] > WAIT signal %p on stream %p\n", (const void*)signal, (const void*)stream);
 	nnc::comm_flush_if_pending();
 	HIP_ENFORCE(hipStreamWaitEvent(bind(stream)->stream, ((const signal_gpu_t*)signal)->event, 0));
 }

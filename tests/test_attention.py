@@ -172,3 +172,48 @@ def test_attention_backward_on_the_matrix_cores_agrees_with_the_valu_kernels(bac
         close(a, b, tol=2e-5)
     assert any("sdpa_dq_mfma_kernel" in n for n in seen[1]) and any("sdpa_dkv_mfma_kernel" in n for n in seen[1]), seen
     assert not any("_mfma_kernel" in n for n in seen[0]), seen
+
+
+HALF_CASES = [
+    # B, R, C, Hq, Hk, D, Dv, causal
+    (2, 150, 70, 4, 2, 64, 64, True),      # the reference's flash_attn rows' kind of shape: ragged row / key blocks, grouped-query heads
+    (1, 131, 97, 2, 2, 128, 96, False),
+    (2, 40, 200, 3, 1, 48, 32, True),
+    (1, 33, 37, 2, 2, 16, 128, False),
+    (2, 20, 37, 4, 4, 24, 24, False),      # D not in 16s: the half tensors go through fp32 images and the fp32 kernels
+]
+
+
+@pytest.mark.parametrize("case", HALF_CASES, ids=[str(c) for c in HALF_CASES])
+def test_attention_forward_in_half_precision(backend, ref_lib, case):
+    """CCV_16F q / k / v / o (what the reference's flash_attn backend takes, cublas.tests.c:2752-2833, tolerance 3e-3 there): the f16 matrix-core kernel where its
+    conditions hold (recorded as sdpa_forw_f16_kernel), fp32 images otherwise; against the oracle on the same half values in fp32."""
+    B, R, Cn, Hq, Hk, D, Dv, causal = case
+    H = np.float16
+    rng = np.random.default_rng(21)
+    q = (rng.random((B, R, Hq, D), dtype=F) - F(0.5)).astype(H)
+    k = (rng.random((B, Cn, Hk, D), dtype=F) - F(0.5)).astype(H)
+    v = (rng.random((B, Cn, Hk, Dv), dtype=F) - F(0.5)).astype(H)
+    cmd = sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_FORWARD", float(1.0 / np.sqrt(D)), causal)
+    r0, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, [q.astype(F), k.astype(F), v.astype(F)], [np.zeros((B, R, Hq, Dv), F)], backend=nnc.BACKEND_CPU_REF)
+    assert r0 == 0
+    backend.profile_enable(1)
+    try:
+        r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [q, k, v], [np.zeros((B, R, Hq, Dv), H), np.zeros((B, Hq, R), F)])
+        backend.stream_wait(None)
+        names = [r[0] for r in backend.profile_records()]
+    finally:
+        backend.profile_enable(0)
+    assert r1 == 0
+    native = D % 16 == 0 and Dv % 32 == 0
+    assert any("sdpa_forw_f16_kernel" in n for n in names) == native, names
+    np.testing.assert_allclose(got[0].astype(F), want[0], rtol=0, atol=3e-3)
+    if native:  # the log-sum-exp rows (fp32) of the rows that see a key
+        s = np.einsum("brhd,bchd->bhrc", q.astype(np.float64), np.repeat(k, Hq // Hk, axis=2).astype(np.float64)) / np.sqrt(D)
+        if causal:
+            vis = np.arange(R)[:, None] - R + Cn + 1
+            s = np.where(np.arange(Cn)[None, :] < vis, s, -np.inf)
+        seen = np.isfinite(s).any(-1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lse = np.log(np.exp(s - s.max(-1, keepdims=True).clip(-1e30)).sum(-1)) + s.max(-1).clip(-1e30)
+        np.testing.assert_allclose(got[1][seen], lse[seen], rtol=2e-3, atol=2e-3)

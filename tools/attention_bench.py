@@ -15,11 +15,11 @@ e0, e1 = L.dll.nnc_mi355x_event_new(), L.dll.nnc_mi355x_event_new()
 F = nnc.CCV_32F
 
 
-def tens(*dims, fill=0.5):
-    t = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, F, dims, 0))
+def tens(*dims, fill=0.5, dtype=F):
+    t = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, dtype, dims, 0))
     rng = np.random.default_rng(0)
     block = (rng.random(1 << 20, dtype=np.float32) - 0.5) * fill
-    t.upload(np.resize(block, int(np.prod(dims))).reshape(dims))
+    t.upload(np.resize(block, int(np.prod(dims))).reshape(dims).astype(np.float16 if dtype == nnc.CCV_16F else np.float32))
     return t
 
 
@@ -40,6 +40,18 @@ for (B, R, C, H, Hk, D, causal) in [(8, 2048, 2048, 16, 16, 64, False), (8, 2048
         line += "   %s %8.3f ms %6.1f TFLOP/s" % ("matrix cores" if mode else "VALU kernel ", ms, flops / ms / 1e9)
     L.tune_set("SDPA_MFMA", 1)
     print(line, flush=True)
+    # the same forward on CCV_16F tensors: the f16 matrix-core kernel (sdpa_forw_f16_kernel)
+    qh, kh, vh, oh = (tens(*d, dtype=nnc.CCV_16F) for d in ((B, R, H, D), (B, C, Hk, D), (B, C, Hk, D), (B, R, H, D)))
+    assert L.cmd_exec(cmd, nnc.NO_HINT, 0, [qh, kh, vh], [oh], s) == 0
+    L.dll.nnc_mi355x_event_record(e0, s)
+    for _ in range(5):
+        assert L.cmd_exec(cmd, nnc.NO_HINT, 0, [qh, kh, vh], [oh], s) == 0
+    L.dll.nnc_mi355x_event_record(e1, s)
+    L.stream_wait(s)
+    ms = L.dll.nnc_mi355x_event_elapsed_ms(e0, e1) / 5
+    print("   forward in half precision (f16 matrix cores)                 %8.3f ms %6.1f TFLOP/s" % (ms, flops / ms / 1e9), flush=True)
+    for t in (qh, kh, vh, oh):
+        t.free()
     g, dq, dk, dv = tens(B, R, H, D), tens(B, R, H, D), tens(B, C, Hk, D), tens(B, C, Hk, D)
     bcmd = T.sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_BACKWARD", float(1.0 / np.sqrt(D)), causal)
     line = "   backward (forward re-run + dq + dk / dv: 7 products)        "
