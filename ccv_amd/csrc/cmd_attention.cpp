@@ -703,6 +703,190 @@ __global__ void __launch_bounds__(256) sdpa_dkv_mfma_kernel(const sdpa_geom_t g,
 	}
 }
 
+// ---- backward in half precision on the f16 matrix cores (round 4) --------------------------------------------------------------------
+// The fp32 matrix-core kernels' decomposition on v_mfma_f32_32x32x16_f16.  Every product whose reduction runs over the streamed tile's ROWS wants that tile
+// transposed in LDS (eight consecutive rows of one column as two 8-byte reads), so the streamed K (dq) / Q and G (dk, dv) tiles are staged both ways; p and ds are
+// rounded to half in the registers they were computed in and are the B operands of the second products (registers 8 t .. 8 t + 7 <-> the eight rows of sub-step t).
+// delta = sum_d g o from the half-precision forward pass's scratch output.
+__global__ void __launch_bounds__(256) sdpa_delta_h_kernel(const sdpa_geom_t g, const half_t* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const half_t* __restrict__ o, float* __restrict__ delta)
+{
+	const long n = (long)g.B * g.Hq * g.R;
+	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+		const int x = (int)(i % g.R), h = (int)((i / g.R) % g.Hq), b = (int)(i / ((long)g.R * g.Hq));
+		const half_t* const gp = gr + b * g_sb + (long)x * g_sr + h * g_sh;
+		const half_t* const op = o + (((long)b * g.R + x) * g.Hq + h) * g.Dv;
+		float s = 0.f;
+		for (int d = 0; d < g.Dv; d++) s += (float)gp[d] * (float)op[d];
+		delta[i] = s;
+	}
+}
+// eight rows of column `col` of a transposed tile ([column][40 halves]): rows 16 t + 4 lh + 0..3 and + 8 -- the rows registers 8 t .. 8 t + 7 of a 32 x 32 result stand for
+__device__ __forceinline__ halfx8 sdpa_tfrag(const half_t* const tt, const int col, const int t16, const int lh)
+{
+	const half_t* const p = tt + col * 40 + 16 * t16 + 4 * lh;
+	const halfx4 lo = *(const halfx4*)p, hi = *(const halfx4*)(p + 8);
+	return halfx8{ lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+}
+__device__ __forceinline__ halfx8 sdpa_half8(const float (&v)[16], const int t16)
+{
+	return halfx8{ (half_t)v[8 * t16], (half_t)v[8 * t16 + 1], (half_t)v[8 * t16 + 2], (half_t)v[8 * t16 + 3], (half_t)v[8 * t16 + 4], (half_t)v[8 * t16 + 5], (half_t)v[8 * t16 + 6], (half_t)v[8 * t16 + 7] };
+}
+// 32 rows x COLS halves of a [rows][stride] tensor into a row-major tile (pitch COLS + 8) and, when tt != 0, its transpose ([column][40]); rows >= limit read as zeros
+template <int COLS>
+__device__ __forceinline__ void sdpa_stage_h(const half_t* const src, const long row_stride, const int first, const int limit, half_t* const rm, half_t* const tt, const int t)
+{
+	for (int c = t; c < 32 * (COLS / 8); c += 256) {
+		const int j = c & 31, d = (c >> 5) << 3;
+		const halfx8 u = first + j < limit ? *(const halfx8*)(src + (long)(first + j) * row_stride + d) : halfx8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+		*(halfx8*)(rm + j * (COLS + 8) + d) = u;
+		if (tt) {
+#pragma unroll
+			for (int e = 0; e < 8; e++) tt[(d + e) * 40 + j] = u[e];
+		}
+	}
+}
+template <int DS, int GS> // D / 16 (even: D % 32 == 0), Dv / 16
+__global__ void __launch_bounds__(256) sdpa_dq_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, const half_t* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, half_t* __restrict__ dq, const long dq_sb, const long dq_sr, const long dq_sh)
+{
+	constexpr int D = 16 * DS, DV = 16 * GS, TD = DS / 2;
+	__shared__ __attribute__((aligned(16))) half_t Ks[32 * (D + 8)];
+	__shared__ __attribute__((aligned(16))) half_t Kt[D * 40];
+	__shared__ __attribute__((aligned(16))) half_t Vs[32 * (DV + 8)];
+	typedef float floatx16 __attribute__((ext_vector_type(16)));
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int li = lane & 31, lh = lane >> 5;
+	const int h = blockIdx.y, b = blockIdx.z, hk = h / g.ratio;
+	const int x = blockIdx.x * 128 + wave * 32 + li;
+	halfx8 qf[DS], gf[GS];
+#pragma unroll
+	for (int i = 0; i < DS; i++) qf[i] = x < g.R ? *(const halfx8*)(q + b * g.q_sb + (long)x * g.q_sr + h * g.q_sh + 16 * i + 8 * lh) : halfx8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+	for (int i = 0; i < GS; i++) gf[i] = x < g.R ? *(const halfx8*)(gr + b * g_sb + (long)x * g_sr + h * g_sh + 16 * i + 8 * lh) : halfx8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+	floatx16 acc[TD];
+#pragma unroll
+	for (int td = 0; td < TD; td++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) acc[td][r] = 0.f;
+	const int vis = x < g.R ? visible_keys(g, x) : 0;
+	const float my_lse = x < g.R ? lse[((long)b * g.Hq + h) * g.R + x] : 0.f, my_delta = x < g.R ? delta[((long)b * g.Hq + h) * g.R + x] : 0.f;
+	int vis_max = 0;
+	{
+		const int x_last = blockIdx.x * 128 + 127 < g.R ? blockIdx.x * 128 + 127 : g.R - 1;
+		vis_max = visible_keys(g, x_last);
+	}
+	for (int y0 = 0; y0 < vis_max; y0 += 32) {
+		__syncthreads();
+		sdpa_stage_h<D>(k + b * g.k_sb + hk * g.k_sh, g.k_sc, y0, g.C, Ks, Kt, t);
+		sdpa_stage_h<DV>(v + b * g.v_sb + hk * g.v_sh, g.v_sc, y0, g.C, Vs, (half_t*)0, t);
+		__syncthreads();
+		floatx16 s, dp;
+#pragma unroll
+		for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+		for (int i = 0; i < DS; i++) s = nnc_mfma_f16(*(const halfx8*)(Ks + li * (D + 8) + 16 * i + 8 * lh), qf[i], s);
+#pragma unroll
+		for (int i = 0; i < GS; i++) dp = nnc_mfma_f16(*(const halfx8*)(Vs + li * (DV + 8) + 16 * i + 8 * lh), gf[i], dp);
+		float ds[16];
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+			ds[r] = y < vis ? expf(g.scale * s[r] - my_lse) * (dp[r] - my_delta) : 0.f;
+		}
+#pragma unroll
+		for (int tt = 0; tt < 2; tt++) {
+			const halfx8 dsf = sdpa_half8(ds, tt);
+#pragma unroll
+			for (int td = 0; td < TD; td++) acc[td] = nnc_mfma_f16(sdpa_tfrag(Kt, 32 * td + li, tt, lh), dsf, acc[td]);
+		}
+	}
+	if (x < g.R) {
+		half_t* const orow = dq + b * dq_sb + (long)x * dq_sr + h * dq_sh;
+#pragma unroll
+		for (int td = 0; td < TD; td++)
+#pragma unroll
+			for (int r4 = 0; r4 < 4; r4++)
+				*(halfx4*)(orow + 32 * td + 8 * r4 + 4 * lh) = halfx4{ (half_t)(g.scale * acc[td][4 * r4]), (half_t)(g.scale * acc[td][4 * r4 + 1]), (half_t)(g.scale * acc[td][4 * r4 + 2]), (half_t)(g.scale * acc[td][4 * r4 + 3]) };
+	}
+}
+template <int DS, int GS> // D / 16, Dv / 16 (both even)
+__global__ void __launch_bounds__(256) sdpa_dkv_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, const half_t* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, half_t* __restrict__ dk, const long dk_sb, const long dk_sc, const long dk_sh, half_t* __restrict__ dv, const long dv_sb, const long dv_sc, const long dv_sh)
+{
+	constexpr int D = 16 * DS, DV = 16 * GS, TD = DS / 2, TV = GS / 2;
+	__shared__ __attribute__((aligned(16))) half_t Qs[32 * (D + 8)];
+	__shared__ __attribute__((aligned(16))) half_t Qt[D * 40];
+	__shared__ __attribute__((aligned(16))) half_t Gs[32 * (DV + 8)];
+	__shared__ __attribute__((aligned(16))) half_t Gt[DV * 40];
+	__shared__ float Ls[32], Ds[32];
+	typedef float floatx16 __attribute__((ext_vector_type(16)));
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int li = lane & 31, lh = lane >> 5;
+	const int hk = blockIdx.y, b = blockIdx.z;
+	const int y0wg = blockIdx.x * 128, y = y0wg + wave * 32 + li;
+	halfx8 kf[DS], vf[GS];
+#pragma unroll
+	for (int i = 0; i < DS; i++) kf[i] = y < g.C ? *(const halfx8*)(k + b * g.k_sb + (long)y * g.k_sc + hk * g.k_sh + 16 * i + 8 * lh) : halfx8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+	for (int i = 0; i < GS; i++) vf[i] = y < g.C ? *(const halfx8*)(v + b * g.v_sb + (long)y * g.v_sc + hk * g.v_sh + 16 * i + 8 * lh) : halfx8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+	floatx16 ak[TD], av[TV];
+#pragma unroll
+	for (int i = 0; i < TD; i++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) ak[i][r] = 0.f;
+#pragma unroll
+	for (int i = 0; i < TV; i++)
+#pragma unroll
+		for (int r = 0; r < 16; r++) av[i][r] = 0.f;
+	int xs = 0;
+	if (g.causal) { xs = y0wg + g.R - g.C; if (xs < 0) xs = 0; xs = xs / 32 * 32; }
+	for (int h = hk * g.ratio; h < (hk + 1) * g.ratio; h++)
+		for (int x0 = xs; x0 < g.R; x0 += 32) {
+			__syncthreads();
+			sdpa_stage_h<D>(q + b * g.q_sb + h * g.q_sh, g.q_sr, x0, g.R, Qs, Qt, t);
+			sdpa_stage_h<DV>(gr + b * g_sb + h * g_sh, g_sr, x0, g.R, Gs, Gt, t);
+			if (t < 32) { const int x = x0 + t; Ls[t] = x < g.R ? lse[((long)b * g.Hq + h) * g.R + x] : 0.f; Ds[t] = x < g.R ? delta[((long)b * g.Hq + h) * g.R + x] : 0.f; }
+			__syncthreads();
+			floatx16 s, dp;
+#pragma unroll
+			for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+			for (int i = 0; i < DS; i++) s = nnc_mfma_f16(*(const halfx8*)(Qs + li * (D + 8) + 16 * i + 8 * lh), kf[i], s);
+#pragma unroll
+			for (int i = 0; i < GS; i++) dp = nnc_mfma_f16(*(const halfx8*)(Gs + li * (DV + 8) + 16 * i + 8 * lh), vf[i], dp);
+			float pv[16], ds[16];
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const int qx = (r & 3) + 8 * (r >> 2) + 4 * lh, x = x0 + qx;
+				float p = 0.f;
+				if (x < g.R && y < g.C && y < visible_keys(g, x)) p = expf(g.scale * s[r] - Ls[qx]);
+				pv[r] = p;
+				ds[r] = p * (dp[r] - Ds[qx]);
+			}
+#pragma unroll
+			for (int tt = 0; tt < 2; tt++) {
+				const halfx8 pf = sdpa_half8(pv, tt), dsf = sdpa_half8(ds, tt);
+#pragma unroll
+				for (int i = 0; i < TV; i++) av[i] = nnc_mfma_f16(sdpa_tfrag(Gt, 32 * i + li, tt, lh), pf, av[i]);
+#pragma unroll
+				for (int i = 0; i < TD; i++) ak[i] = nnc_mfma_f16(sdpa_tfrag(Qt, 32 * i + li, tt, lh), dsf, ak[i]);
+			}
+		}
+	if (y < g.C) {
+#pragma unroll
+		for (int r4 = 0; r4 < 4; r4++) {
+			if (dk) {
+				half_t* const o = dk + b * dk_sb + (long)y * dk_sc + hk * dk_sh;
+#pragma unroll
+				for (int i = 0; i < TD; i++) *(halfx4*)(o + 32 * i + 8 * r4 + 4 * lh) = halfx4{ (half_t)(g.scale * ak[i][4 * r4]), (half_t)(g.scale * ak[i][4 * r4 + 1]), (half_t)(g.scale * ak[i][4 * r4 + 2]), (half_t)(g.scale * ak[i][4 * r4 + 3]) };
+			}
+			if (dv) {
+				half_t* const o = dv + b * dv_sb + (long)y * dv_sc + hk * dv_sh;
+#pragma unroll
+				for (int i = 0; i < TV; i++) *(halfx4*)(o + 32 * i + 8 * r4 + 4 * lh) = halfx4{ (half_t)av[i][4 * r4], (half_t)av[i][4 * r4 + 1], (half_t)av[i][4 * r4 + 2], (half_t)av[i][4 * r4 + 3] };
+			}
+		}
+	}
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------------------------
 struct bhd_t { int b, n, h, d; long sb, sn, sh; };
 static bool bhd(const ccv_nnc_tensor_t* t, bhd_t* o, const int datatype = CCV_32F)
@@ -810,6 +994,23 @@ static int _sdpa_forw(EXEC_ARGS)
 	return nnc_mi355x_cmd_exec(gemm, no_hint, 0, gin, bias ? 3 : 2, gout, 1, stream_context);
 }
 
+static void sdpa_forw_f16_launch(const sdpa_geom_t& g, const half_t* const qp, const half_t* const kp, const half_t* const vp, half_t* const op, float* const lse, hipStream_t stream)
+{
+	const dim3 grid((g.R + 127) / 128, g.Hq, g.B);
+	note_kernel("sdpa_fwd_f16");
+	ProfScope prof("sdpa_fwd_h|nnc::sdpa_forw_f16_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (g.D + g.Dv), 0, g.R, g.C, g.D, g.B * g.Hq, 1, stream);
+#define SDPA_F16_TV(DS) do { switch (g.Dv / 32) { \
+		case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 1>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
+		case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 2>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
+		case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 3>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
+		default: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 4>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; } } while (0)
+	switch (g.D / 16) {
+		case 1: SDPA_F16_TV(1); break; case 2: SDPA_F16_TV(2); break; case 3: SDPA_F16_TV(3); break; case 4: SDPA_F16_TV(4); break;
+		case 5: SDPA_F16_TV(5); break; case 6: SDPA_F16_TV(6); break; case 7: SDPA_F16_TV(7); break; default: SDPA_F16_TV(8); break;
+	}
+#undef SDPA_F16_TV
+	HIP_ENFORCE(hipGetLastError());
+}
 // CCV_16F tensors: the f16 kernel where its conditions hold (CCV_NNC_EXEC_NO_KERNEL = not this path: the caller goes through fp32 images)
 static int sdpa_forw_half(EXEC_ARGS)
 {
@@ -843,23 +1044,7 @@ static int sdpa_forw_half(EXEC_ARGS)
 	}
 	MarkerScope marker(cmd.cmd);
 	if (!g.R || !g.Hq || !g.B) return CCV_NNC_EXEC_SUCCESS;
-	hipStream_t stream = stream_of(stream_context);
-	const dim3 grid((g.R + 127) / 128, g.Hq, g.B);
-	const half_t* const qp = (const half_t*)q->data.u8; const half_t* const kp = (const half_t*)k->data.u8; const half_t* const vp = (const half_t*)v->data.u8;
-	half_t* const op = (half_t*)c->data.u8;
-	note_kernel("sdpa_fwd_f16");
-	ProfScope prof("sdpa_fwd_h|nnc::sdpa_forw_f16_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (g.D + g.Dv), 0, g.R, g.C, g.D, g.B * g.Hq, 1, stream);
-#define SDPA_F16_TV(DS) do { switch (g.Dv / 32) { \
-		case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 1>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
-		case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 2>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
-		case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 3>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
-		default: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 4>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; } } while (0)
-	switch (g.D / 16) {
-		case 1: SDPA_F16_TV(1); break; case 2: SDPA_F16_TV(2); break; case 3: SDPA_F16_TV(3); break; case 4: SDPA_F16_TV(4); break;
-		case 5: SDPA_F16_TV(5); break; case 6: SDPA_F16_TV(6); break; case 7: SDPA_F16_TV(7); break; default: SDPA_F16_TV(8); break;
-	}
-#undef SDPA_F16_TV
-	HIP_ENFORCE(hipGetLastError());
+	sdpa_forw_f16_launch(g, (const half_t*)q->data.u8, (const half_t*)k->data.u8, (const half_t*)v->data.u8, (half_t*)c->data.u8, lse, stream_of(stream_context));
 	return CCV_NNC_EXEC_SUCCESS;
 }
 // the registered forward entry: fp32 tensors -> the fp32 kernels; half q / k / v / o -> the f16 kernel where it applies; anything else with a half tensor -> the fp32
@@ -950,6 +1135,83 @@ static int _sdpa_back(EXEC_ARGS)
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// CCV_16F g / q / k / v -> dq / dk / dv: the f16 kernels where their conditions hold (CCV_NNC_EXEC_NO_KERNEL = not this path)
+static int sdpa_back_half(EXEC_ARGS)
+{
+	if (input_size < 6 || output_size < 3 || !inputs[0] || !inputs[3] || !inputs[4] || !inputs[5]) return CCV_NNC_EXEC_NO_KERNEL;
+	for (int i = 6; i < input_size && i < 9; i++) if (inputs[i]) return CCV_NNC_EXEC_NO_KERNEL; // mask / head projection: the fp32 route
+	if (!tune(TUNE_SDPA_MFMA)) return CCV_NNC_EXEC_NO_KERNEL;
+	ccv_nnc_tensor_t* const dq = outputs[0]; ccv_nnc_tensor_t* const dk = outputs[1]; ccv_nnc_tensor_t* const dv = outputs[2];
+	const ccv_nnc_tensor_t* const q = inputs[3]; const ccv_nnc_tensor_t* const k = inputs[4]; const ccv_nnc_tensor_t* const v = inputs[5];
+	bhd_t qi, ki, vi, gi, dqi, dki, dvi;
+	if (!bhd(q, &qi, CCV_16F) || !bhd(k, &ki, CCV_16F) || !bhd(v, &vi, CCV_16F) || !bhd(inputs[0], &gi, CCV_16F)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (tensor_nd(q->info.dim) != tensor_nd(k->info.dim) || tensor_nd(k->info.dim) != tensor_nd(v->info.dim)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (qi.b != ki.b || ki.b != vi.b || qi.d != ki.d || ki.n != vi.n || ki.h != vi.h || qi.h < ki.h || qi.h % ki.h) return CCV_NNC_EXEC_NO_KERNEL;
+	sdpa_geom_t g;
+	memset(&g, 0, sizeof(g));
+	g.B = qi.b; g.R = qi.n; g.C = ki.n; g.Hq = qi.h; g.Hk = ki.h; g.D = qi.d; g.Dv = vi.d; g.ratio = qi.h / ki.h;
+	g.q_sb = qi.sb; g.q_sr = qi.sn; g.q_sh = qi.sh; g.k_sb = ki.sb; g.k_sc = ki.sn; g.k_sh = ki.sh; g.v_sb = vi.sb; g.v_sc = vi.sn; g.v_sh = vi.sh;
+	g.scale = cmd.info.scaled_dot_product_attention.scale;
+	g.causal = cmd.info.scaled_dot_product_attention.is_causal;
+	if (gi.b != g.B || gi.n != g.R || gi.h != g.Hq || gi.d != g.Dv) return CCV_NNC_EXEC_INVALID;
+	if (dq && (!bhd(dq, &dqi, CCV_16F) || dqi.b != g.B || dqi.n != g.R || dqi.h != g.Hq || dqi.d != g.D)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (dk && (!bhd(dk, &dki, CCV_16F) || dki.b != g.B || dki.n != g.C || dki.h != g.Hk || dki.d != g.D)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (dv && (!bhd(dv, &dvi, CCV_16F) || dvi.b != g.B || dvi.n != g.C || dvi.h != g.Hk || dvi.d != g.Dv)) return CCV_NNC_EXEC_NO_KERNEL;
+	if (g.D % 32 || g.Dv % 32 || g.D > 128 || g.Dv > 128) return CCV_NNC_EXEC_NO_KERNEL;
+	if (((uintptr_t)q->data.u8 | (uintptr_t)k->data.u8 | (uintptr_t)v->data.u8 | (uintptr_t)inputs[0]->data.u8) & 15) return CCV_NNC_EXEC_NO_KERNEL;
+	if ((g.q_sb | g.q_sr | g.q_sh | g.k_sb | g.k_sc | g.k_sh | g.v_sb | g.v_sc | g.v_sh | gi.sb | gi.sn | gi.sh) & 7) return CCV_NNC_EXEC_NO_KERNEL;
+	if (dq && ((((uintptr_t)dq->data.u8) & 7) || ((dqi.sb | dqi.sn | dqi.sh) & 3))) return CCV_NNC_EXEC_NO_KERNEL;
+	if (dk && ((((uintptr_t)dk->data.u8) & 7) || ((dki.sb | dki.sn | dki.sh) & 3))) return CCV_NNC_EXEC_NO_KERNEL;
+	if (dv && ((((uintptr_t)dv->data.u8) & 7) || ((dvi.sb | dvi.sn | dvi.sh) & 3))) return CCV_NNC_EXEC_NO_KERNEL;
+	MarkerScope marker(cmd.cmd);
+	if (!g.B || !g.R || !g.C) return CCV_NNC_EXEC_SUCCESS;
+	const size_t rows = (size_t)g.B * g.Hq * g.R;
+	const size_t o_bytes = (sizeof(half_t) * rows * g.Dv + 255) & ~(size_t)255, r_bytes = (sizeof(float) * rows + 255) & ~(size_t)255;
+	char* const ws = (char*)workspace_of(stream_context, o_bytes + 2 * r_bytes);
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	half_t* const o = (half_t*)ws; float* const lse = (float*)(ws + o_bytes); float* const delta = (float*)(ws + o_bytes + r_bytes);
+	hipStream_t stream = stream_of(stream_context);
+	sdpa_geom_t gf = g;
+	gf.o_sb = (long)g.R * g.Hq * g.Dv; gf.o_sr = (long)g.Hq * g.Dv; gf.o_sh = g.Dv;
+	const half_t* const qp = (const half_t*)q->data.u8; const half_t* const kp = (const half_t*)k->data.u8; const half_t* const vp = (const half_t*)v->data.u8; const half_t* const gp = (const half_t*)inputs[0]->data.u8;
+	sdpa_forw_f16_launch(gf, qp, kp, vp, o, lse, stream);
+	hipLaunchKernelGGL(sdpa_delta_h_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, stream, g, gp, gi.sb, gi.sn, gi.sh, (const half_t*)o, delta);
+	HIP_ENFORCE(hipGetLastError());
+#define SDPA_BY_GS(KERNEL, DS, ...) do { switch (g.Dv / 32) { \
+		case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<DS, 2>), __VA_ARGS__); break; case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<DS, 4>), __VA_ARGS__); break; \
+		case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<DS, 6>), __VA_ARGS__); break; default: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<DS, 8>), __VA_ARGS__); break; } } while (0)
+#define SDPA_BY_DS(KERNEL, ...) do { switch (g.D / 32) { \
+		case 1: SDPA_BY_GS(KERNEL, 2, __VA_ARGS__); break; case 2: SDPA_BY_GS(KERNEL, 4, __VA_ARGS__); break; \
+		case 3: SDPA_BY_GS(KERNEL, 6, __VA_ARGS__); break; default: SDPA_BY_GS(KERNEL, 8, __VA_ARGS__); break; } } while (0)
+	if (dq) {
+		note_kernel("sdpa_dq_f16");
+		ProfScope prof("sdpa_dq_h|nnc::sdpa_dq_f16_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (2 * g.D + g.Dv), 0, g.R, g.C, g.D, g.B * g.Hq, 1, stream);
+		SDPA_BY_DS(sdpa_dq_f16_kernel, dim3((g.R + 127) / 128, g.Hq, g.B), dim3(256), 0, stream, g, qp, kp, vp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, (half_t*)dq->data.u8, dqi.sb, dqi.sn, dqi.sh);
+		HIP_ENFORCE(hipGetLastError());
+	}
+	if (dk || dv) {
+		half_t* const dkp = dk ? (half_t*)dk->data.u8 : 0; half_t* const dvp = dv ? (half_t*)dv->data.u8 : 0;
+		const long ksb = dk ? dki.sb : 0, ksn = dk ? dki.sn : 0, ksh = dk ? dki.sh : 0, vsb = dv ? dvi.sb : 0, vsn = dv ? dvi.sn : 0, vsh = dv ? dvi.sh : 0;
+		note_kernel("sdpa_dkv_f16");
+		ProfScope prof("sdpa_dkv_h|nnc::sdpa_dkv_f16_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (2 * g.D + 2 * g.Dv), 0, g.C, g.R, g.D, g.B * g.Hk, 1, stream);
+		SDPA_BY_DS(sdpa_dkv_f16_kernel, dim3((g.C + 127) / 128, g.Hk, g.B), dim3(256), 0, stream, g, qp, kp, vp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dkp, ksb, ksn, ksh, dvp, vsb, vsn, vsh);
+		HIP_ENFORCE(hipGetLastError());
+	}
+#undef SDPA_BY_DS
+#undef SDPA_BY_GS
+	return CCV_NNC_EXEC_SUCCESS;
+}
+static int _sdpa_back_any(EXEC_ARGS)
+{
+	if (!any_half_tensor(inputs, input_size, outputs, output_size)) {
+		MarkerScope marker(cmd.cmd);
+		return _sdpa_back(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	}
+	const int r = sdpa_back_half(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (r != CCV_NNC_EXEC_NO_KERNEL) return r;
+	return half_staged_exec(_sdpa_back, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+}
+
 } // namespace
 
 #define NNC_REG(CMD, BACKEND, EXEC) \
@@ -958,4 +1220,5 @@ static int _sdpa_back(EXEC_ARGS)
 
 extern "C" void _register_command_CCV_NNC_SCALED_DOT_PRODUCT_ATTENTION_FORWARD_backend_CCV_NNC_BACKEND_GPU_REF(ccv_nnc_cmd_backend_registry_t* const registry)
 { registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC; registry->tensor_datatypes = CCV_32F | CCV_16F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = _sdpa_forw_any; }
-NNC_REG(CCV_NNC_SCALED_DOT_PRODUCT_ATTENTION_BACKWARD, CCV_NNC_BACKEND_GPU_REF, _sdpa_back)
+extern "C" void _register_command_CCV_NNC_SCALED_DOT_PRODUCT_ATTENTION_BACKWARD_backend_CCV_NNC_BACKEND_GPU_REF(ccv_nnc_cmd_backend_registry_t* const registry)
+{ registry->tensor_formats = CCV_TENSOR_FORMAT_NCHW | CCV_TENSOR_FORMAT_NHWC; registry->tensor_datatypes = CCV_32F | CCV_16F; registry->tensor_memory = CCV_TENSOR_GPU_MEMORY; registry->algorithms = 1; registry->exec = _sdpa_back_any; }

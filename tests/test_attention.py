@@ -217,3 +217,57 @@ def test_attention_forward_in_half_precision(backend, ref_lib, case):
         with np.errstate(divide="ignore", invalid="ignore"):
             lse = np.log(np.exp(s - s.max(-1, keepdims=True).clip(-1e30)).sum(-1)) + s.max(-1).clip(-1e30)
         np.testing.assert_allclose(got[1][seen], lse[seen], rtol=2e-3, atol=2e-3)
+
+
+HALF_BACK_CASES = [
+    # B, R, C, Hq, Hk, D, Dv, causal
+    (2, 150, 170, 4, 2, 64, 64, True),
+    (1, 131, 97, 2, 2, 128, 96, False),
+    (2, 70, 40, 3, 1, 32, 32, True),
+    (1, 33, 37, 2, 2, 48, 32, False),      # D not in 32s: fp32 images and the fp32 kernels
+]
+
+
+@pytest.mark.parametrize("case", HALF_BACK_CASES, ids=[str(c) for c in HALF_BACK_CASES])
+def test_attention_backward_in_half_precision(backend, ref_lib, case):
+    """CCV_16F g / q / k / v -> dq / dk / dv (the reference's flash_attn backward, cublas.tests.c:2835-): the f16 matrix-core kernels where their conditions hold
+    (sdpa_dq_f16_kernel, sdpa_dkv_f16_kernel, behind the half-precision forward re-run), fp32 images otherwise; against the closed-form float64 gradients of the
+    same half values."""
+    B, R, Cn, Hq, Hk, D, Dv, causal = case
+    H = np.float16
+    rng = np.random.default_rng(31)
+    q = (rng.random((B, R, Hq, D), dtype=F) - F(0.5)).astype(H)
+    k = (rng.random((B, Cn, Hk, D), dtype=F) - F(0.5)).astype(H)
+    v = (rng.random((B, Cn, Hk, Dv), dtype=F) - F(0.5)).astype(H)
+    g = (rng.random((B, R, Hq, Dv), dtype=F) - F(0.5)).astype(H)
+    scale = float(1.0 / np.sqrt(D))
+    cmd = sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_BACKWARD", scale, causal)
+    backend.profile_enable(1)
+    try:
+        r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [g, None, None, q, k, v], [np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)])
+        backend.stream_wait(None)
+        names = [r[0] for r in backend.profile_records()]
+    finally:
+        backend.profile_enable(0)
+    assert r1 == 0
+    native = D % 32 == 0 and Dv % 32 == 0
+    assert (any("sdpa_dq_f16_kernel" in n for n in names) and any("sdpa_dkv_f16_kernel" in n for n in names)) == native, names
+    ratio = Hq // Hk
+    q64, g64 = q.astype(np.float64), g.astype(np.float64)
+    kr, vr = np.repeat(k, ratio, axis=2).astype(np.float64), np.repeat(v, ratio, axis=2).astype(np.float64)
+    s = np.einsum("brhd,bchd->bhrc", q64, kr) * scale
+    if causal:
+        vis = np.arange(R)[:, None] - R + Cn + 1
+        s = np.where(np.arange(Cn)[None, :] < vis, s, -np.inf)
+    seen = np.isfinite(s).any(-1)
+    with np.errstate(invalid="ignore"):
+        p = np.exp(s - np.where(seen, s.max(-1), 0.0)[..., None])
+    p = np.where(np.isfinite(s), p, 0.0)
+    p = p / np.where(seen, p.sum(-1), 1.0)[..., None]
+    dp = np.einsum("brhd,bchd->bhrc", g64, vr)
+    ds = p * (dp - (p * dp).sum(-1, keepdims=True))
+    dq = scale * np.einsum("bhrc,bchd->brhd", ds, kr)
+    dk = scale * np.einsum("bhrc,brhd->bchd", ds, q64).reshape(B, Cn, Hk, ratio, D).sum(3)
+    dv = np.einsum("bhrc,brhd->bchd", p, g64).reshape(B, Cn, Hk, ratio, Dv).sum(3)
+    for a, w in zip(got, (dq, dk, dv)):
+        close(a.astype(F), w, tol=5e-3)

@@ -50,7 +50,17 @@ for (B, R, C, H, Hk, D, causal) in [(8, 2048, 2048, 16, 16, 64, False), (8, 2048
     L.stream_wait(s)
     ms = L.dll.nnc_mi355x_event_elapsed_ms(e0, e1) / 5
     print("   forward in half precision (f16 matrix cores)                 %8.3f ms %6.1f TFLOP/s" % (ms, flops / ms / 1e9), flush=True)
-    for t in (qh, kh, vh, oh):
+    gh, dqh, dkh, dvh = (tens(*d, dtype=nnc.CCV_16F) for d in ((B, R, H, D), (B, R, H, D), (B, C, Hk, D), (B, C, Hk, D)))
+    bcmd_h = T.sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_BACKWARD", float(1.0 / np.sqrt(D)), causal)
+    assert L.cmd_exec(bcmd_h, nnc.NO_HINT, 0, [gh, None, None, qh, kh, vh], [dqh, dkh, dvh], s) == 0
+    L.dll.nnc_mi355x_event_record(e0, s)
+    for _ in range(3):
+        assert L.cmd_exec(bcmd_h, nnc.NO_HINT, 0, [gh, None, None, qh, kh, vh], [dqh, dkh, dvh], s) == 0
+    L.dll.nnc_mi355x_event_record(e1, s)
+    L.stream_wait(s)
+    ms = L.dll.nnc_mi355x_event_elapsed_ms(e0, e1) / 3
+    print("   backward in half precision (f16 matrix cores, 7 products)    %8.3f ms %6.1f TFLOP/s" % (ms, 3.5 * flops / ms / 1e9), flush=True)
+    for t in (qh, kh, vh, oh, gh, dqh, dkh, dvh):
         t.free()
     g, dq, dk, dv = tens(B, R, H, D), tens(B, R, H, D), tens(B, C, Hk, D), tens(B, C, Hk, D)
     bcmd = T.sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_BACKWARD", float(1.0 / np.sqrt(D)), causal)
