@@ -171,9 +171,9 @@ def resnet_config(args, half, dawn=False):
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)
         if os.path.exists(tpath):
             pk = json.load(open(tpath))["kernels"]
-            bnk = [v for k, v in pk.items() if k.startswith("bn_")]
+            bnk = [v for k, v in pk.items() if "bn_" in k]  # (half-precision kernels appear under their mangled names)
             fw_cmds_per_step = sum(k["launches"] for k in bn if "apply" in k["name"])  # the forward commands of the recorded step
-            fw_in_pass = sum(v["launches"] for k, v in pk.items() if k.startswith("bn_cluster_forw") or k.startswith("bn_apply_planes"))  # one of these per forward command
+            fw_in_pass = sum(v["launches"] for k, v in pk.items() if "bn_cluster_forw" in k or "bn_apply_planes" in k)  # one of these per forward command
             if bnk and fw_cmds_per_step and fw_in_pass:
                 traffic = sum((v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in bnk) / (fw_in_pass / fw_cmds_per_step) / n
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
