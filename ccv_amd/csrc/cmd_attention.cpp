@@ -239,10 +239,10 @@ __global__ void __launch_bounds__(256) sdpa_forw_mfma_kernel(const sdpa_geom_t g
 //   O^T [Dv x 32 rows] += V^T P^T        two sub-steps of 16 keys; the lane holds the probabilities of the keys ky(r) = (r & 3) + 8 (r >> 2) + 4 half of its row, so
 //                                        sub-step t takes registers 8 t .. 8 t + 7 -- rounded to half, still in place -- as B, and A = the same eight keys of column
 //                                        dv = l & 31 out of a TRANSPOSED V tile in LDS ([dv][key]: two 8-byte reads: keys 16 t + 4 half + 0..3 and + 8)
-// Conditions: D % 16 == 0, Dv % 32 == 0, both <= 128, 16-byte aligned rows, no additive mask (with one, or for other shapes, the half tensors go through fp32
-// images and the fp32 kernels).  The log-sum-exp output, if asked for, is fp32.
+// Conditions: D % 16 == 0, Dv % 32 == 0, both <= 128, 16-byte aligned rows; an additive mask is a CCV_16F tensor too (other shapes, and the head projection, go through
+// fp32 images and the fp32 kernels).  The log-sum-exp output, if asked for, is fp32.
 template <int DS, int TV> // DS = D / 16 (1 .. 8), TV = Dv / 32 (1 .. 4)
-__global__ void __launch_bounds__(256) sdpa_forw_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, half_t* __restrict__ o, float* __restrict__ lse)
+__global__ void __launch_bounds__(256) sdpa_forw_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, const half_t* __restrict__ mask, half_t* __restrict__ o, float* __restrict__ lse)
 {
 	constexpr int KP = 16 * DS + 8, VTP = 40; // halves per row: K tile [32 keys][D + 8], V^T tile [Dv][32 keys + 8]
 	__shared__ __attribute__((aligned(16))) half_t Ks[32 * KP];
@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(256) sdpa_forw_f16_kernel(const sdpa_geom_t g,
 		const int x_last = blockIdx.x * 128 + 127 < g.R ? blockIdx.x * 128 + 127 : g.R - 1;
 		vis_max = visible_keys(g, x_last);
 	}
+	const half_t* const mrow = mask ? mask + b * g.m_sb + h * g.m_sh + (long)(x < g.R ? x : 0) * g.m_sr : 0;
 	for (int y0 = 0; y0 < vis_max; y0 += 32) {
 		__syncthreads();
 		for (int c = t; c < 32 * 2 * DS; c += 256) { // K: 16-byte chunks as they lie
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(256) sdpa_forw_f16_kernel(const sdpa_geom_t g,
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-			if (y < vis) { s[r] = g.scale * s[r]; bm = fmaxf(bm, s[r]); }
+			if (y < vis) { s[r] = g.scale * s[r] + (mrow ? (float)mrow[y] : 0.f); bm = fmaxf(bm, s[r]); }
 			else s[r] = -INFINITY;
 		}
 		bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
@@ -746,7 +747,7 @@ __device__ __forceinline__ void sdpa_stage_h(const half_t* const src, const long
 	}
 }
 template <int DS, int GS> // D / 16 (even: D % 32 == 0), Dv / 16
-__global__ void __launch_bounds__(256) sdpa_dq_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, const half_t* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, half_t* __restrict__ dq, const long dq_sb, const long dq_sr, const long dq_sh)
+__global__ void __launch_bounds__(256) sdpa_dq_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, const half_t* __restrict__ mask, const half_t* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, half_t* __restrict__ dq, const long dq_sb, const long dq_sr, const long dq_sh)
 {
 	constexpr int D = 16 * DS, DV = 16 * GS, TD = DS / 2;
 	__shared__ __attribute__((aligned(16))) half_t Ks[32 * (D + 8)];
@@ -774,6 +775,7 @@ __global__ void __launch_bounds__(256) sdpa_dq_f16_kernel(const sdpa_geom_t g, c
 		const int x_last = blockIdx.x * 128 + 127 < g.R ? blockIdx.x * 128 + 127 : g.R - 1;
 		vis_max = visible_keys(g, x_last);
 	}
+	const half_t* const mrow = mask ? mask + b * g.m_sb + h * g.m_sh + (long)(x < g.R ? x : 0) * g.m_sr : 0;
 	for (int y0 = 0; y0 < vis_max; y0 += 32) {
 		__syncthreads();
 		sdpa_stage_h<D>(k + b * g.k_sb + hk * g.k_sh, g.k_sc, y0, g.C, Ks, Kt, t);
@@ -790,7 +792,7 @@ __global__ void __launch_bounds__(256) sdpa_dq_f16_kernel(const sdpa_geom_t g, c
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-			ds[r] = y < vis ? expf(g.scale * s[r] - my_lse) * (dp[r] - my_delta) : 0.f;
+			ds[r] = y < vis ? expf(g.scale * s[r] + (mrow ? (float)mrow[y] : 0.f) - my_lse) * (dp[r] - my_delta) : 0.f;
 		}
 #pragma unroll
 		for (int tt = 0; tt < 2; tt++) {
@@ -809,7 +811,7 @@ __global__ void __launch_bounds__(256) sdpa_dq_f16_kernel(const sdpa_geom_t g, c
 	}
 }
 template <int DS, int GS> // D / 16, Dv / 16 (both even)
-__global__ void __launch_bounds__(256) sdpa_dkv_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, const half_t* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, half_t* __restrict__ dk, const long dk_sb, const long dk_sc, const long dk_sh, half_t* __restrict__ dv, const long dv_sb, const long dv_sc, const long dv_sh)
+__global__ void __launch_bounds__(256) sdpa_dkv_f16_kernel(const sdpa_geom_t g, const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, const half_t* __restrict__ mask, const half_t* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, half_t* __restrict__ dk, const long dk_sb, const long dk_sc, const long dk_sh, half_t* __restrict__ dv, const long dv_sb, const long dv_sc, const long dv_sh)
 {
 	constexpr int D = 16 * DS, DV = 16 * GS, TD = DS / 2, TV = GS / 2;
 	__shared__ __attribute__((aligned(16))) half_t Qs[32 * (D + 8)];
@@ -857,7 +859,7 @@ __global__ void __launch_bounds__(256) sdpa_dkv_f16_kernel(const sdpa_geom_t g, 
 			for (int r = 0; r < 16; r++) {
 				const int qx = (r & 3) + 8 * (r >> 2) + 4 * lh, x = x0 + qx;
 				float p = 0.f;
-				if (x < g.R && y < g.C && y < visible_keys(g, x)) p = expf(g.scale * s[r] - Ls[qx]);
+				if (x < g.R && y < g.C && y < visible_keys(g, x)) p = expf(g.scale * s[r] + (mask ? (float)mask[b * g.m_sb + h * g.m_sh + (long)x * g.m_sr + y] : 0.f) - Ls[qx]);
 				pv[r] = p;
 				ds[r] = p * (dp[r] - Ds[qx]);
 			}
@@ -901,6 +903,7 @@ static bool bhd(const ccv_nnc_tensor_t* t, bhd_t* o, const int datatype = CCV_32
 	else { o->h = 1; o->d = t->info.dim[2]; o->sh = 0; }
 	return true;
 }
+static bool sdpa_mask_geometry(const ccv_nnc_tensor_t* mask, sdpa_geom_t* g, int datatype);
 static bool sdpa_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_tensor_t* q, const ccv_nnc_tensor_t* k, const ccv_nnc_tensor_t* v, const ccv_nnc_tensor_t* mask, sdpa_geom_t* g, bhd_t* qi, bhd_t* ki, bhd_t* vi)
 {
 	if (!bhd(q, qi) || !bhd(k, ki) || !bhd(v, vi)) return false;
@@ -909,9 +912,16 @@ static bool sdpa_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_tensor_t* q, c
 	g->B = qi->b; g->R = qi->n; g->C = ki->n; g->Hq = qi->h; g->Hk = ki->h; g->D = qi->d; g->Dv = vi->d; g->ratio = qi->h / ki->h;
 	g->q_sb = qi->sb; g->q_sr = qi->sn; g->q_sh = qi->sh; g->k_sb = ki->sb; g->k_sc = ki->sn; g->k_sh = ki->sh; g->v_sb = vi->sb; g->v_sc = vi->sn; g->v_sh = vi->sh;
 	g->m_sb = g->m_sh = g->m_sr = 0;
-	if (mask) { // [B or 1][Hq or 1][R][C], or 3-d [B or 1][R][C]
+	if (mask && !sdpa_mask_geometry(mask, g, CCV_32F)) return false;
+	g->scale = cmd.info.scaled_dot_product_attention.scale;
+	g->causal = cmd.info.scaled_dot_product_attention.is_causal;
+	return g->D >= 1 && g->Dv >= 1 && g->D <= 256 && g->Dv <= 256;
+}
+static bool sdpa_mask_geometry(const ccv_nnc_tensor_t* const mask, sdpa_geom_t* const g, const int datatype)
+{
+	{ // [B or 1][Hq or 1][R][C], or 3-d [B or 1][R][C]
 		const int nd = tensor_nd(mask->info.dim);
-		if ((nd != 3 && nd != 4) || CCV_GET_DATA_TYPE(mask->info.datatype) != CCV_32F) return false;
+		if ((nd != 3 && nd != 4) || CCV_GET_DATA_TYPE(mask->info.datatype) != datatype) return false;
 		int st[CCV_NNC_MAX_DIM_ALLOC];
 		tensor_strides(mask, st);
 		if (st[nd - 1] != 1 || mask->info.dim[nd - 1] != g->C || mask->info.dim[nd - 2] != g->R) return false;
@@ -921,9 +931,7 @@ static bool sdpa_geometry(const ccv_nnc_cmd_t& cmd, const ccv_nnc_tensor_t* q, c
 		g->m_sb = mb == 1 ? 0 : st[0];
 		g->m_sh = (nd == 4 && mh != 1) ? st[1] : 0;
 	}
-	g->scale = cmd.info.scaled_dot_product_attention.scale;
-	g->causal = cmd.info.scaled_dot_product_attention.is_causal;
-	return g->D >= 1 && g->Dv >= 1 && g->D <= 256 && g->Dv <= 256;
+	return true;
 }
 static int sdpa_forward_launch(const sdpa_geom_t& g, const float* q, const float* k, const float* v, const float* mask, float* o, float* lse, hipStream_t stream)
 {
@@ -994,16 +1002,16 @@ static int _sdpa_forw(EXEC_ARGS)
 	return nnc_mi355x_cmd_exec(gemm, no_hint, 0, gin, bias ? 3 : 2, gout, 1, stream_context);
 }
 
-static void sdpa_forw_f16_launch(const sdpa_geom_t& g, const half_t* const qp, const half_t* const kp, const half_t* const vp, half_t* const op, float* const lse, hipStream_t stream)
+static void sdpa_forw_f16_launch(const sdpa_geom_t& g, const half_t* const qp, const half_t* const kp, const half_t* const vp, const half_t* const mp, half_t* const op, float* const lse, hipStream_t stream)
 {
 	const dim3 grid((g.R + 127) / 128, g.Hq, g.B);
 	note_kernel("sdpa_fwd_f16");
 	ProfScope prof("sdpa_fwd_h|nnc::sdpa_forw_f16_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (g.D + g.Dv), 0, g.R, g.C, g.D, g.B * g.Hq, 1, stream);
 #define SDPA_F16_TV(DS) do { switch (g.Dv / 32) { \
-		case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 1>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
-		case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 2>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
-		case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 3>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; \
-		default: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 4>), grid, dim3(256), 0, stream, g, qp, kp, vp, op, lse); break; } } while (0)
+		case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 1>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, op, lse); break; \
+		case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 2>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, op, lse); break; \
+		case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 3>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, op, lse); break; \
+		default: hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_forw_f16_kernel<DS, 4>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, op, lse); break; } } while (0)
 	switch (g.D / 16) {
 		case 1: SDPA_F16_TV(1); break; case 2: SDPA_F16_TV(2); break; case 3: SDPA_F16_TV(3); break; case 4: SDPA_F16_TV(4); break;
 		case 5: SDPA_F16_TV(5); break; case 6: SDPA_F16_TV(6); break; case 7: SDPA_F16_TV(7); break; default: SDPA_F16_TV(8); break;
@@ -1015,8 +1023,9 @@ static void sdpa_forw_f16_launch(const sdpa_geom_t& g, const half_t* const qp, c
 static int sdpa_forw_half(EXEC_ARGS)
 {
 	if (input_size < 3 || output_size < 1 || !inputs[0] || !inputs[1] || !inputs[2] || !outputs[0]) return CCV_NNC_EXEC_NO_KERNEL;
-	for (int i = 3; i < input_size; i++) if (inputs[i]) return CCV_NNC_EXEC_NO_KERNEL; // mask / head projection: the fp32 route
+	for (int i = 4; i < input_size; i++) if (inputs[i]) return CCV_NNC_EXEC_NO_KERNEL; // the head projection: the fp32 route
 	for (int i = 2; i < output_size; i++) if (outputs[i]) return CCV_NNC_EXEC_NO_KERNEL;
+	const ccv_nnc_tensor_t* const mask = input_size > 3 ? inputs[3] : 0;
 	if (!tune(TUNE_SDPA_MFMA)) return CCV_NNC_EXEC_NO_KERNEL;
 	const ccv_nnc_tensor_t* const q = inputs[0]; const ccv_nnc_tensor_t* const k = inputs[1]; const ccv_nnc_tensor_t* const v = inputs[2];
 	ccv_nnc_tensor_t* const c = outputs[0];
@@ -1033,6 +1042,7 @@ static int sdpa_forw_half(EXEC_ARGS)
 	g.causal = cmd.info.scaled_dot_product_attention.is_causal;
 	if (ci.b != g.B || ci.n != g.R || ci.h != g.Hq || ci.d != g.Dv) return CCV_NNC_EXEC_INVALID;
 	g.o_sb = ci.sb; g.o_sr = ci.sn; g.o_sh = ci.sh;
+	if (mask && !sdpa_mask_geometry(mask, &g, CCV_16F)) return CCV_NNC_EXEC_NO_KERNEL;
 	if (g.D % 16 || g.Dv % 32 || g.D > 128 || g.Dv > 128 || g.D < 16) return CCV_NNC_EXEC_NO_KERNEL;
 	if ((((uintptr_t)q->data.u8 | (uintptr_t)k->data.u8 | (uintptr_t)v->data.u8) & 15) || ((uintptr_t)c->data.u8 & 7)) return CCV_NNC_EXEC_NO_KERNEL;
 	if ((g.q_sb | g.q_sr | g.q_sh | g.k_sb | g.k_sc | g.k_sh | g.v_sb | g.v_sc | g.v_sh) & 7) return CCV_NNC_EXEC_NO_KERNEL;
@@ -1044,7 +1054,7 @@ static int sdpa_forw_half(EXEC_ARGS)
 	}
 	MarkerScope marker(cmd.cmd);
 	if (!g.R || !g.Hq || !g.B) return CCV_NNC_EXEC_SUCCESS;
-	sdpa_forw_f16_launch(g, (const half_t*)q->data.u8, (const half_t*)k->data.u8, (const half_t*)v->data.u8, (half_t*)c->data.u8, lse, stream_of(stream_context));
+	sdpa_forw_f16_launch(g, (const half_t*)q->data.u8, (const half_t*)k->data.u8, (const half_t*)v->data.u8, mask ? (const half_t*)mask->data.u8 : 0, (half_t*)c->data.u8, lse, stream_of(stream_context));
 	return CCV_NNC_EXEC_SUCCESS;
 }
 // the registered forward entry: fp32 tensors -> the fp32 kernels; half q / k / v / o -> the f16 kernel where it applies; anything else with a half tensor -> the fp32
@@ -1139,7 +1149,8 @@ static int _sdpa_back(EXEC_ARGS)
 static int sdpa_back_half(EXEC_ARGS)
 {
 	if (input_size < 6 || output_size < 3 || !inputs[0] || !inputs[3] || !inputs[4] || !inputs[5]) return CCV_NNC_EXEC_NO_KERNEL;
-	for (int i = 6; i < input_size && i < 9; i++) if (inputs[i]) return CCV_NNC_EXEC_NO_KERNEL; // mask / head projection: the fp32 route
+	for (int i = 7; i < input_size && i < 9; i++) if (inputs[i]) return CCV_NNC_EXEC_NO_KERNEL; // the head projection: the fp32 route
+	const ccv_nnc_tensor_t* const mask = input_size > 6 ? inputs[6] : 0;
 	if (!tune(TUNE_SDPA_MFMA)) return CCV_NNC_EXEC_NO_KERNEL;
 	ccv_nnc_tensor_t* const dq = outputs[0]; ccv_nnc_tensor_t* const dk = outputs[1]; ccv_nnc_tensor_t* const dv = outputs[2];
 	const ccv_nnc_tensor_t* const q = inputs[3]; const ccv_nnc_tensor_t* const k = inputs[4]; const ccv_nnc_tensor_t* const v = inputs[5];
@@ -1158,6 +1169,8 @@ static int sdpa_back_half(EXEC_ARGS)
 	if (dk && (!bhd(dk, &dki, CCV_16F) || dki.b != g.B || dki.n != g.C || dki.h != g.Hk || dki.d != g.D)) return CCV_NNC_EXEC_NO_KERNEL;
 	if (dv && (!bhd(dv, &dvi, CCV_16F) || dvi.b != g.B || dvi.n != g.C || dvi.h != g.Hk || dvi.d != g.Dv)) return CCV_NNC_EXEC_NO_KERNEL;
 	if (g.D % 32 || g.Dv % 32 || g.D > 128 || g.Dv > 128) return CCV_NNC_EXEC_NO_KERNEL;
+	if (mask && !sdpa_mask_geometry(mask, &g, CCV_16F)) return CCV_NNC_EXEC_NO_KERNEL;
+	const half_t* const mp = mask ? (const half_t*)mask->data.u8 : 0;
 	if (((uintptr_t)q->data.u8 | (uintptr_t)k->data.u8 | (uintptr_t)v->data.u8 | (uintptr_t)inputs[0]->data.u8) & 15) return CCV_NNC_EXEC_NO_KERNEL;
 	if ((g.q_sb | g.q_sr | g.q_sh | g.k_sb | g.k_sc | g.k_sh | g.v_sb | g.v_sc | g.v_sh | gi.sb | gi.sn | gi.sh) & 7) return CCV_NNC_EXEC_NO_KERNEL;
 	if (dq && ((((uintptr_t)dq->data.u8) & 7) || ((dqi.sb | dqi.sn | dqi.sh) & 3))) return CCV_NNC_EXEC_NO_KERNEL;
@@ -1174,7 +1187,7 @@ static int sdpa_back_half(EXEC_ARGS)
 	sdpa_geom_t gf = g;
 	gf.o_sb = (long)g.R * g.Hq * g.Dv; gf.o_sr = (long)g.Hq * g.Dv; gf.o_sh = g.Dv;
 	const half_t* const qp = (const half_t*)q->data.u8; const half_t* const kp = (const half_t*)k->data.u8; const half_t* const vp = (const half_t*)v->data.u8; const half_t* const gp = (const half_t*)inputs[0]->data.u8;
-	sdpa_forw_f16_launch(gf, qp, kp, vp, o, lse, stream);
+	sdpa_forw_f16_launch(gf, qp, kp, vp, mp, o, lse, stream);
 	hipLaunchKernelGGL(sdpa_delta_h_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, stream, g, gp, gi.sb, gi.sn, gi.sh, (const half_t*)o, delta);
 	HIP_ENFORCE(hipGetLastError());
 #define SDPA_BY_GS(KERNEL, DS, ...) do { switch (g.Dv / 32) { \
@@ -1186,7 +1199,7 @@ static int sdpa_back_half(EXEC_ARGS)
 	if (dq) {
 		note_kernel("sdpa_dq_f16");
 		ProfScope prof("sdpa_dq_h|nnc::sdpa_dq_f16_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (2 * g.D + g.Dv), 0, g.R, g.C, g.D, g.B * g.Hq, 1, stream);
-		SDPA_BY_DS(sdpa_dq_f16_kernel, dim3((g.R + 127) / 128, g.Hq, g.B), dim3(256), 0, stream, g, qp, kp, vp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, (half_t*)dq->data.u8, dqi.sb, dqi.sn, dqi.sh);
+		SDPA_BY_DS(sdpa_dq_f16_kernel, dim3((g.R + 127) / 128, g.Hq, g.B), dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, (half_t*)dq->data.u8, dqi.sb, dqi.sn, dqi.sh);
 		HIP_ENFORCE(hipGetLastError());
 	}
 	if (dk || dv) {
@@ -1194,7 +1207,7 @@ static int sdpa_back_half(EXEC_ARGS)
 		const long ksb = dk ? dki.sb : 0, ksn = dk ? dki.sn : 0, ksh = dk ? dki.sh : 0, vsb = dv ? dvi.sb : 0, vsn = dv ? dvi.sn : 0, vsh = dv ? dvi.sh : 0;
 		note_kernel("sdpa_dkv_f16");
 		ProfScope prof("sdpa_dkv_h|nnc::sdpa_dkv_f16_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (2 * g.D + 2 * g.Dv), 0, g.C, g.R, g.D, g.B * g.Hk, 1, stream);
-		SDPA_BY_DS(sdpa_dkv_f16_kernel, dim3((g.C + 127) / 128, g.Hk, g.B), dim3(256), 0, stream, g, qp, kp, vp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dkp, ksb, ksn, ksh, dvp, vsb, vsn, vsh);
+		SDPA_BY_DS(sdpa_dkv_f16_kernel, dim3((g.C + 127) / 128, g.Hk, g.B), dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dkp, ksb, ksn, ksh, dvp, vsb, vsn, vsh);
 		HIP_ENFORCE(hipGetLastError());
 	}
 #undef SDPA_BY_DS

@@ -175,12 +175,12 @@ def test_attention_backward_on_the_matrix_cores_agrees_with_the_valu_kernels(bac
 
 
 HALF_CASES = [
-    # B, R, C, Hq, Hk, D, Dv, causal
-    (2, 150, 70, 4, 2, 64, 64, True),      # the reference's flash_attn rows' kind of shape: ragged row / key blocks, grouped-query heads
-    (1, 131, 97, 2, 2, 128, 96, False),
-    (2, 40, 200, 3, 1, 48, 32, True),
-    (1, 33, 37, 2, 2, 16, 128, False),
-    (2, 20, 37, 4, 4, 24, 24, False),      # D not in 16s: the half tensors go through fp32 images and the fp32 kernels
+    # B, R, C, Hq, Hk, D, Dv, causal, mask
+    (2, 150, 70, 4, 2, 64, 64, True, None),      # the reference's flash_attn rows' kind of shape: ragged row / key blocks, grouped-query heads
+    (1, 131, 97, 2, 2, 128, 96, False, None),
+    (2, 40, 200, 3, 1, 48, 32, True, (2, 1)),    # an additive mask per batch item (CCV_16F like the rest), and causal
+    (1, 33, 37, 2, 2, 16, 128, False, (1, 2)),
+    (2, 20, 37, 4, 4, 24, 24, False, None),      # D not in 16s: the half tensors go through fp32 images and the fp32 kernels
 ]
 
 
@@ -188,18 +188,20 @@ HALF_CASES = [
 def test_attention_forward_in_half_precision(backend, ref_lib, case):
     """CCV_16F q / k / v / o (what the reference's flash_attn backend takes, cublas.tests.c:2752-2833, tolerance 3e-3 there): the f16 matrix-core kernel where its
     conditions hold (recorded as sdpa_forw_f16_kernel), fp32 images otherwise; against the oracle on the same half values in fp32."""
-    B, R, Cn, Hq, Hk, D, Dv, causal = case
+    B, R, Cn, Hq, Hk, D, Dv, causal, mask_shape = case
     H = np.float16
     rng = np.random.default_rng(21)
     q = (rng.random((B, R, Hq, D), dtype=F) - F(0.5)).astype(H)
     k = (rng.random((B, Cn, Hk, D), dtype=F) - F(0.5)).astype(H)
     v = (rng.random((B, Cn, Hk, Dv), dtype=F) - F(0.5)).astype(H)
+    mask = None if mask_shape is None else ((rng.random(mask_shape + (R, Cn), dtype=F) - F(0.5)) * F(2)).astype(H)
     cmd = sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_FORWARD", float(1.0 / np.sqrt(D)), causal)
-    r0, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, [q.astype(F), k.astype(F), v.astype(F)], [np.zeros((B, R, Hq, Dv), F)], backend=nnc.BACKEND_CPU_REF)
+    extra, extra32 = ([mask], [mask.astype(F)]) if mask is not None else ([], [])
+    r0, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, [q.astype(F), k.astype(F), v.astype(F)] + extra32, [np.zeros((B, R, Hq, Dv), F)], backend=nnc.BACKEND_CPU_REF)
     assert r0 == 0
     backend.profile_enable(1)
     try:
-        r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [q, k, v], [np.zeros((B, R, Hq, Dv), H), np.zeros((B, Hq, R), F)])
+        r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [q, k, v] + extra, [np.zeros((B, R, Hq, Dv), H), np.zeros((B, Hq, R), F)])
         backend.stream_wait(None)
         names = [r[0] for r in backend.profile_records()]
     finally:
@@ -210,6 +212,8 @@ def test_attention_forward_in_half_precision(backend, ref_lib, case):
     np.testing.assert_allclose(got[0].astype(F), want[0], rtol=0, atol=3e-3)
     if native:  # the log-sum-exp rows (fp32) of the rows that see a key
         s = np.einsum("brhd,bchd->bhrc", q.astype(np.float64), np.repeat(k, Hq // Hk, axis=2).astype(np.float64)) / np.sqrt(D)
+        if mask is not None:
+            s = s + mask.astype(np.float64)
         if causal:
             vis = np.arange(R)[:, None] - R + Cn + 1
             s = np.where(np.arange(Cn)[None, :] < vis, s, -np.inf)
@@ -220,11 +224,11 @@ def test_attention_forward_in_half_precision(backend, ref_lib, case):
 
 
 HALF_BACK_CASES = [
-    # B, R, C, Hq, Hk, D, Dv, causal
-    (2, 150, 170, 4, 2, 64, 64, True),
-    (1, 131, 97, 2, 2, 128, 96, False),
-    (2, 70, 40, 3, 1, 32, 32, True),
-    (1, 33, 37, 2, 2, 48, 32, False),      # D not in 32s: fp32 images and the fp32 kernels
+    # B, R, C, Hq, Hk, D, Dv, causal, mask
+    (2, 150, 170, 4, 2, 64, 64, True, None),
+    (1, 131, 97, 2, 2, 128, 96, False, (1, 2)),
+    (2, 70, 40, 3, 1, 32, 32, True, (2, 3)),
+    (1, 33, 37, 2, 2, 48, 32, False, None),      # D not in 32s: fp32 images and the fp32 kernels
 ]
 
 
@@ -233,18 +237,19 @@ def test_attention_backward_in_half_precision(backend, ref_lib, case):
     """CCV_16F g / q / k / v -> dq / dk / dv (the reference's flash_attn backward, cublas.tests.c:2835-): the f16 matrix-core kernels where their conditions hold
     (sdpa_dq_f16_kernel, sdpa_dkv_f16_kernel, behind the half-precision forward re-run), fp32 images otherwise; against the closed-form float64 gradients of the
     same half values."""
-    B, R, Cn, Hq, Hk, D, Dv, causal = case
+    B, R, Cn, Hq, Hk, D, Dv, causal, mask_shape = case
     H = np.float16
     rng = np.random.default_rng(31)
     q = (rng.random((B, R, Hq, D), dtype=F) - F(0.5)).astype(H)
     k = (rng.random((B, Cn, Hk, D), dtype=F) - F(0.5)).astype(H)
     v = (rng.random((B, Cn, Hk, Dv), dtype=F) - F(0.5)).astype(H)
     g = (rng.random((B, R, Hq, Dv), dtype=F) - F(0.5)).astype(H)
+    mask = None if mask_shape is None else ((rng.random(mask_shape + (R, Cn), dtype=F) - F(0.5)) * F(2)).astype(H)
     scale = float(1.0 / np.sqrt(D))
     cmd = sdpa_cmd("SCALED_DOT_PRODUCT_ATTENTION_BACKWARD", scale, causal)
     backend.profile_enable(1)
     try:
-        r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [g, None, None, q, k, v], [np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)])
+        r1, got = exec_on(backend, nnc.GPU_MEMORY, cmd, nnc.NO_HINT, 0, [g, None, None, q, k, v] + ([mask] if mask is not None else []), [np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)])
         backend.stream_wait(None)
         names = [r[0] for r in backend.profile_records()]
     finally:
@@ -256,6 +261,8 @@ def test_attention_backward_in_half_precision(backend, ref_lib, case):
     q64, g64 = q.astype(np.float64), g.astype(np.float64)
     kr, vr = np.repeat(k, ratio, axis=2).astype(np.float64), np.repeat(v, ratio, axis=2).astype(np.float64)
     s = np.einsum("brhd,bchd->bhrc", q64, kr) * scale
+    if mask is not None:
+        s = s + mask.astype(np.float64)
     if causal:
         vis = np.arange(R)[:, None] - R + Cn + 1
         s = np.where(np.arange(Cn)[None, :] < vis, s, -np.inf)
