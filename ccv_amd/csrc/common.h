@@ -205,6 +205,7 @@ enum {
 	TUNE_BN_CLUSTER,        // batch norm (training) on [N][C][planes]: a cluster of workgroups per channel holds the channel in registers between the statistics and the apply pass -- x read ONCE (1), or the plane kernels (0); > 1: chunks per workgroup (tests force several workgroups per channel on small tensors)
 	TUNE_GEMM_VEC_EPILOGUE, // contraction epilogues stage the block tile through LDS and store 16-byte (8-byte for halves) row segments where the output allows, half NCHW convolutions write their planar result themselves (1); 2 = the row segments only; 0 = one element per lane always
 	TUNE_POOL_ROWS,         // pooling on NCHW tensors: a lane per four consecutive x of a row where the maps allow (1), or a lane per element always (0)
+	TUNE_GEMM_HALF_CHUNK8,  // the half-precision contraction kernel stages its operands in 16-byte chunks of eight halves where strides and channel counts allow (1), or always in 8-byte chunks of four (0)
 	TUNE_COUNT
 };
 static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");

@@ -200,12 +200,14 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	char prof_name[192];
 	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_kernel<%d, %d> EPI = %s", name, WM, WN, splits <= 1 ? "EpiStoreH" : "EpiPartialH");
 	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
+	const bool v8 = tune(TUNE_GEMM_HALF_CHUNK8) && loader_vec8_ok(la) && loader_vec8_ok(lb) && (zcount <= 1 || (a_z % 8 == 0 && b_z % 8 == 0));
 	if (splits <= 1) {
 		EpiStoreH epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
 		epi.vec = epi_vec_ok(out.c, sizeof(half_t), out.ldm, out.ldn, N, zcount, c_z);
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
+		if (v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN, 8>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -217,13 +219,25 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	epi.vec = tune(TUNE_GEMM_VEC_EPILOGUE) && N % 4 == 0;
 	{
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiPartialH, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
+		if (v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiPartialH, WM, WN, 8>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiPartialH, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
 	}
 	HIP_ENFORCE(hipGetLastError());
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(splitk_reduce_kernel<half_t>), dim3(grid_for((size_t)slab * 4, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
+
+// Can this loader's operand be staged in 16-byte chunks of eight halves (TileFetchH8, mfma_gemm_f16.h)?  Eight consecutive k / rows adjacent in memory and 16-byte
+// aligned: channel counts and every stride a multiple of eight, an aligned base, no ragged k tail inside a chunk.
+template <class L> static inline bool loader_vec8_ok(const L&) { return false; }
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+template <bool S, bool I> static inline bool loader_vec8_ok(const Im2colKC<true, S, I>& l) { return al16(l.p) && l.C % 8 == 0 && l.s_w % 8 == 0 && l.s_h % 8 == 0 && l.s_n % 8 == 0; }
+static inline bool loader_vec8_ok(const MatLoader<true, true>& l) { return al16(l.p) && l.ldk == 1 && l.ldr % 8 == 0 && l.K % 8 == 0; }
+static inline bool loader_vec8_ok(const MatLoader<false, true>& l) { return al16(l.p) && l.ldr == 1 && l.ldk % 8 == 0 && l.R % 8 == 0; }
+template <bool I> static inline bool loader_vec8_ok(const WgtDgradNC<true, I>& l) { return al16(l.p) && l.C % 8 == 0 && l.ko_stride % 8 == 0; }
+template <bool I> static inline bool loader_vec8_ok(const Im2colNC<true, I>& l) { return al16(l.p) && l.C % 8 == 0 && l.s_w % 8 == 0 && l.s_h % 8 == 0 && l.s_n % 8 == 0; }
+static inline bool loader_vec8_ok(const PlaneKC<true>& l) { return al16(l.p) && l.P % 8 == 0 && l.ldr % 8 == 0 && l.s_n % 8 == 0; }
 
 // A half-precision contraction whose rows are the pixels of an NHWC view, written straight into an NCHW tensor (EpiStoreHT, mfma_gemm_f16.h): one slab, no batch.
 template <class LA, class LB>
@@ -244,7 +258,10 @@ static int gemm_run_h_planar(const char* name, LA la, LB lb, EpiStoreHT epi, con
 	char prof_name[192];
 	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_kernel<%d, %d> EPI = EpiStoreHT", name, big ? 2 : 1, big ? 2 : 1);
 	ProfScope prof(prof_name, 2.0 * (double)M * (double)N * (double)K, 0, M, N, K, 1, 1, stream);
-	if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 2, 2>), dim3((unsigned)big_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 127) / 128, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
+	const bool v8 = tune(TUNE_GEMM_HALF_CHUNK8) && loader_vec8_ok(la) && loader_vec8_ok(lb);
+	if (big && v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 2, 2, 8>), dim3((unsigned)big_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 127) / 128, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
+	else if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 2, 2>), dim3((unsigned)big_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 127) / 128, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
+	else if (v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 1, 1, 8>), dim3((unsigned)(((M + 63) / 64) * ((N + 63) / 64)), 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 63) / 64, (N + 63) / 64, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
 	else hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 1, 1>), dim3((unsigned)(((M + 63) / 64) * ((N + 63) / 64)), 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 63) / 64, (N + 63) / 64, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;

@@ -133,6 +133,59 @@ struct TileFetchH : TileFetch<L, NCH> {
 	}
 };
 
+// The same with EIGHT elements per chunk (round 4): one 16-byte load, one ds_write_b128 and one offset per chunk -- half the loads, LDS writes and address
+// arithmetic per K-step of the form above.  The loaders do not care how wide a chunk is (they resolve the offset of its first element); what has to hold is that
+// eight consecutive k (k-contiguous operand) or rows (row-contiguous operand) lie next to each other, 16-byte aligned -- channel counts and strides in
+// multiples of eight: the launcher checks (loader_vec8_ok, gemm_launch.h).  The LDS images are the ones above, so the fragment reads do not change.
+template <class L, int NCH> // NCH = ROWS / 64
+struct TileFetchH8 {
+	static constexpr int ROWS = NCH * 64;
+	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+	typedef u4 reg_t;
+	static_assert(L::VECTOR, "vector loaders only");
+	typename L::Ctx ctx[L::KCONTIG ? NCH : 1];
+	int koff[NCH];
+	long off[NCH];
+	__device__ __forceinline__ void init(const L& l, const int row0, const int t)
+	{
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) {
+			const int id = t + GEMM_THREADS * jj;
+			if (L::KCONTIG) { ctx[L::KCONTIG ? jj : 0] = l.make(row0 + (id >> 2)); koff[jj] = (id & 3) << 3; } // row id >> 2, k (id & 3) * 8 .. + 7
+			else { if (jj == 0) ctx[0] = l.make(row0 + ((id % (ROWS / 8)) << 3)); koff[jj] = id / (ROWS / 8); } // k = id / (ROWS / 8), rows (id % (ROWS / 8)) * 8 .. + 7
+		}
+	}
+	template <bool FIRST>
+	__device__ __forceinline__ void prep(const L& l, const int kbase, const int klimit)
+	{
+		if (L::KCONTIG) {
+			const typename L::KCtx kc = l.kctx(kbase + koff[0], klimit);
+#pragma unroll
+			for (int jj = 0; jj < NCH; jj++) off[jj] = l.offset(ctx[L::KCONTIG ? jj : 0], kc);
+		} else {
+#pragma unroll
+			for (int jj = 0; jj < NCH; jj++) off[jj] = l.offset(ctx[0], l.kctx(kbase + koff[jj], klimit));
+		}
+	}
+	__device__ __forceinline__ void issue(const L& l, u4 (&r)[NCH]) const
+	{
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) r[jj] = *(const u4*)((const half_t*)l.p + off[jj]);
+	}
+	__device__ __forceinline__ void store(half_t* lds, const u4 (&r)[NCH], const int t) const
+	{
+#pragma unroll
+		for (int jj = 0; jj < NCH; jj++) {
+			const int id = t + GEMM_THREADS * jj;
+			if (L::KCONTIG) *(u4*)(lds + (id >> 2) * GEMM16_LDK + ((id & 3) << 3)) = r[jj];
+			else *(u4*)(lds + (id / (ROWS / 8)) * gemm16_npitch(ROWS) + ((id % (ROWS / 8)) << 3)) = r[jj];
+		}
+	}
+};
+// the fetcher and its register type by chunk width: W 32-row tiles per wave -> 64 W rows per operand tile
+template <class L, int W, int CW> struct FetchHOf { typedef TileFetchH<L, W * 2> type; typedef uint2 reg_t; static constexpr int NCH = W * 2; };
+template <class L, int W> struct FetchHOf<L, W, 8> { typedef TileFetchH8<L, W> type; typedef typename TileFetchH8<L, W>::u4 reg_t; static constexpr int NCH = W; };
+
 // The fragment of sub-step s for the 32 rows starting at `base`: k = 16 s + 8 lh + 0..7 of row base + li, out of either image
 template <bool KC, int ROWS>
 __device__ __forceinline__ halfx8 frag16(const half_t* const s_, const int base, const int li, const int lh, const int s)
@@ -145,7 +198,7 @@ __device__ __forceinline__ halfx8 frag16(const half_t* const s_, const int base,
 }
 
 // grid: x = tiles (* split-K slices), XCD-swizzled exactly as the fp32 core; z = batch / conv group.
-template <class LA, class LB, class EPI, int WM, int WN>
+template <class LA, class LB, class EPI, int WM, int WN, int CW = 4> // CW: elements per staged chunk (4: 8-byte loads; 8: 16-byte loads, TileFetchH8)
 __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff, const KOrder ko)
 {
 	constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -189,8 +242,8 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 		return (s - cc * ko.taps) * ko.C + cc * GEMM_BK;
 	};
 	const int klim = ko.taps ? ko.K : k_end;
-	TileFetchH<LA, WM * 2> fa;
-	TileFetchH<LB, WN * 2> fb;
+	typename FetchHOf<LA, WM, CW>::type fa;
+	typename FetchHOf<LB, WN, CW>::type fb;
 	fa.init(la, m0, t);
 	fb.init(lb, n0, t);
 	floatx16 acc[WM][WN];
@@ -201,7 +254,8 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 	const int row_a = wm * (32 * WM), col_b = wn * (32 * WN);
-	uint2 ra[WM * 2], rb[WN * 2];
+	typename FetchHOf<LA, WM, CW>::reg_t ra[FetchHOf<LA, WM, CW>::NCH];
+	typename FetchHOf<LB, WN, CW>::reg_t rb[FetchHOf<LB, WN, CW>::NCH];
 	if (nk > 0) {
 		const int k0 = kmap(k_begin);
 		fa.template prep<true>(la, k0, klim);

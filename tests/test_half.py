@@ -383,3 +383,35 @@ def test_native_half_sgd(backend, ref_lib, nesterov):
     for x, y in zip(got, want):
         assert x.dtype == H
         _close(x, y, tol=1e-3)
+
+
+# ---- the half-precision contraction kernel's two staging widths (mfma_gemm_f16.h: TileFetchH, 8-byte chunks of four halves; TileFetchH8, 16-byte chunks of eight where
+# channel counts and strides are multiples of eight): the same LDS images, the same fragments -- bit-identical results
+@pytest.mark.parametrize("what", ["conv-nhwc", "conv-nchw", "conv-nchw-s2", "gemm"])
+def test_half_contraction_chunks_of_eight_equal_chunks_of_four(backend, what):
+    rng = np.random.default_rng(17)
+    if what == "gemm":
+        runs = [(nnc.CMD_GEMM_FORWARD(nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1)), nnc.NO_HINT, [hrnd(rng, 72, 136), hrnd(rng, 80, 136), hrnd(rng, 80)], [np.zeros((72, 80), H)], "NHWC"),
+                (nnc.CMD_GEMM_BACKWARD(nnc.NO_TRANSPOSE, nnc.TRANSPOSE(0, 1)), nnc.NO_HINT, [hrnd(rng, 72, 80), hrnd(rng, 72, 136), hrnd(rng, 80, 136)], [np.zeros((72, 136), H), np.zeros((80, 136), H), np.zeros(80, H)], "NHWC")]
+    else:
+        fmt = "NHWC" if what == "conv-nhwc" else "NCHW"
+        n, h, w, c, k = 3, 10, 12, 64, 72
+        stride = (2, 2) if what.endswith("s2") else (1, 1)
+        hint = nnc.HINT(stride, (1, 1))
+        oh, ow = (h + 2 - 3) // stride[0] + 1, (w + 2 - 3) // stride[1] + 1
+        sh = (lambda *d: d) if fmt == "NHWC" else (lambda nn, hh, ww, cc: (nn, cc, hh, ww))
+        a, wt, g = hrnd(rng, *sh(n, h, w, c)), hrnd(rng, *sh(k, 3, 3, c), scale=0.05), hrnd(rng, *sh(n, oh, ow, k), scale=0.1)
+        runs = [(nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, c), hint, [a, wt, hrnd(rng, k)], [np.zeros(sh(n, oh, ow, k), H)], fmt),
+                (nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c), hint, [g, a, wt], [np.zeros(sh(n, h, w, c), H), np.zeros(sh(k, 3, 3, c), H), np.zeros(k, H)], fmt)]
+    for cmd, hint, ins, outs, fmt in runs:
+        res = {}
+        try:
+            for mode in (1, 0):
+                backend.tune_set("GEMM_HALF_CHUNK8", mode)
+                r, got = exec_on(backend, nnc.GPU_MEMORY, cmd, hint, 0, ins, outs, fmt)
+                assert r == 0
+                res[mode] = got
+        finally:
+            backend.tune_set("GEMM_HALF_CHUNK8", 1)
+        for x, y in zip(res[1], res[0]):
+            assert np.array_equal(x.view(np.uint16), y.view(np.uint16))
