@@ -1028,17 +1028,20 @@ static int _conv_transpose_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hi
 static bool aligned8(const void* p) { return (((uintptr_t)p) & 7) == 0; }
 static bool half_image_ok(const Image4& t) { return t.sc == 1 && aligned8(t.p) && t.sw % 4 == 0 && t.sh % 4 == 0 && (t.n == 1 || t.sn % 4 == 0) && image_fits_int(t); }
 
-// K-slices of the half-precision forward / data-gradient contraction: 1, except where the launcher is told otherwise (nnc_mi355x_debug_force_splits: measurements)
+// The half-precision forward / data-gradient contraction with at most one 128 x 128 output tile per CU and a long reduction (the 4 x 4 maps of the CIFAR trainer:
+// 256 tiles for 256 CUs, 144 K-steps each): 64 x 64 tiles put four workgroups on every CU.  Measured (tools/conv_half_bench.py, profiles/r04_v8_conv_half_bench_chunk8.txt)
+// 512 -> 512 at 4 x 4, batch 512: forward 0.079 ms against 0.058 + 0.035 for eight K-slices of the big tile and the pass that folds their slabs (round 4's first
+// answer, from before the 16-byte chunks: 0.127 unsplit, 0.072 + 0.035 in slices); at 7 x 7, batch 256 (392 tiles) the big tile unsplit stays best (0.108 vs 0.130).
+static bool conv_h_small_tiles(const conv_geom_t& g, const long M, const int N, const int Kred)
+{
+	if (g.groups != 1 || g_force_tile || g_force_splits) return false;
+	const long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+	return tiles <= (long)device_cu_count() && Kred >= 2304;
+}
+// K-slices of those contractions: 1, except where the launcher is told otherwise (nnc_mi355x_debug_force_splits: measurements)
 static int conv_h_splits(const conv_geom_t& g, const long M, const int N, const int Kred)
 {
-	if (g.groups != 1) return 1;
-	if (g_force_splits > 1) return g_force_splits;
-	// Few output tiles and a long reduction (the 4 x 4 and 7 x 7 maps of the trainers: 256 - 392 tiles of 128 x 128 for 256 CUs, 144 K-steps each): eight K-slices
-	// put eight times the workgroups on the chip -- measured (tools/conv_half_bench.py, profiles/r04_v5_conv_half_bench.txt) 512 -> 512 at 4 x 4, batch 512:
-	// forward 0.127 -> 0.072 ms, data gradient 0.135 -> 0.078, plus 0.035 ms for the pass that folds the eight slabs (134 MB of partials); at 7 x 7, batch 256
-	// (392 tiles) the kernel gains 0.021 - 0.029 ms and the fold costs 0.05: one tile per CU at most is where it pays.
-	const long tiles = ((M + 127) / 128) * ((N + 127) / 128);
-	return tiles <= (long)device_cu_count() && Kred >= 2304 ? 8 : 1;
+	return g.groups == 1 && g_force_splits > 1 ? g_force_splits : 1;
 }
 
 // Can the forward / data-gradient contraction write an NCHW result itself (EpiStoreHT: groups of four pixels of a plane in one store, one K-slice)?
@@ -1064,9 +1067,9 @@ static int conv_forw_h(const conv_geom_t& g, const Image4& a, const void* w, con
 	if (planar) {
 		EpiStoreHT epi;
 		epi.c = (half_t*)planar; epi.bias = (const half_t*)bias; epi.M = (int)M; epi.N = g.Kg; epi.P = g.OH * g.OW;
-		return gemm_run_h_planar("conv_fwd_h", la, lb, epi, Kred, ctx, ko);
+		return gemm_run_h_planar("conv_fwd_h", la, lb, epi, Kred, ctx, ko, conv_h_small_tiles(g, M, g.Kg, Kred));
 	}
-	return gemm_run_h("conv_fwd_h", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, conv_h_splits(g, M, g.Kg, Kred), flags, ctx, ko);
+	return gemm_run_h("conv_fwd_h", la, lb, out, (int)M, g.Kg, Kred, g.groups, (long)g.Cg, (long)g.Kg * Kred, (long)g.Kg, (long)g.Kg, conv_h_splits(g, M, g.Kg, Kred), flags, ctx, ko, conv_h_small_tiles(g, M, g.Kg, Kred));
 }
 
 static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx, void* const planar = 0)
@@ -1086,9 +1089,9 @@ static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, c
 		if (planar) { \
 			EpiStoreHT epi; \
 			epi.c = (half_t*)planar; epi.bias = 0; epi.M = (int)M; epi.N = g.Cg; epi.P = g.H * g.W; \
-			return gemm_run_h_planar("conv_dgrad_h", la, lb, epi, Kred, ctx, ko); \
+			return gemm_run_h_planar("conv_dgrad_h", la, lb, epi, Kred, ctx, ko, conv_h_small_tiles(g, M, g.Cg, Kred)); \
 		} \
-		return gemm_run_h("conv_dgrad_h", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, conv_h_splits(g, M, g.Cg, Kred), flags, ctx, ko); \
+		return gemm_run_h("conv_dgrad_h", la, lb, out, (int)M, g.Cg, Kred, g.groups, (long)g.Kg, (long)g.Kg * g.kh * g.kw * g.Cg, (long)g.Cg, 0L, conv_h_splits(g, M, g.Cg, Kred), flags, ctx, ko, conv_h_small_tiles(g, M, g.Cg, Kred)); \
 	} while (0)
 	if (g.sy != 1 || g.sx != 1) CONV_DGRAD_H(true);
 	else CONV_DGRAD_H(false);

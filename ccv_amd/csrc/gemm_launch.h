@@ -241,7 +241,7 @@ static inline bool loader_vec8_ok(const PlaneKC<true>& l) { return al16(l.p) && 
 
 // A half-precision contraction whose rows are the pixels of an NHWC view, written straight into an NCHW tensor (EpiStoreHT, mfma_gemm_f16.h): one slab, no batch.
 template <class LA, class LB>
-static int gemm_run_h_planar(const char* name, LA la, LB lb, EpiStoreHT epi, const int K, ccv_nnc_stream_context_t* const ctx, const KOrder ko)
+static int gemm_run_h_planar(const char* name, LA la, LB lb, EpiStoreHT epi, const int K, ccv_nnc_stream_context_t* const ctx, const KOrder ko, const bool small_tiles = false)
 {
 	const int M = epi.M, N = epi.N;
 	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
@@ -254,7 +254,7 @@ static int gemm_run_h_planar(const char* name, LA la, LB lb, EpiStoreHT epi, con
 	hipStream_t stream = stream_of(ctx);
 	note_kernel(name);
 	const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-	const bool big = g_force_tile ? !((g_force_tile & 0xff) == 1 && (g_force_tile >> 8) == 1) : (M > 64 && N > 64 && (big_tiles >= device_cu_count() || K >= 4096));
+	const bool big = g_force_tile ? !((g_force_tile & 0xff) == 1 && (g_force_tile >> 8) == 1) : (!small_tiles && M > 64 && N > 64 && (big_tiles >= device_cu_count() || K >= 4096));
 	char prof_name[192];
 	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_kernel<%d, %d> EPI = EpiStoreHT", name, big ? 2 : 1, big ? 2 : 1);
 	ProfScope prof(prof_name, 2.0 * (double)M * (double)N * (double)K, 0, M, N, K, 1, 1, stream);
@@ -343,7 +343,7 @@ static int gemm_run_buf_h(const char* name, const BufMatLoader<AKC>& la, const B
 
 // la.p / lb.p point at HALVES (cast to the loaders' float* type); every offset / stride / z offset is in elements.
 template <class LA, class LB>
-static int gemm_run_h(const char* name, LA la, LB lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko = KOrder())
+static int gemm_run_h(const char* name, LA la, LB lb, const GemmOutH out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko = KOrder(), const bool small_tiles = false)
 {
 	if (M <= 0 || N <= 0) return CCV_NNC_EXEC_SUCCESS;
 	la.finish();
@@ -366,7 +366,7 @@ static int gemm_run_h(const char* name, LA la, LB lb, const GemmOutH out, const 
 		if ((g_force_tile & 0xff) == 1 && (g_force_tile >> 8) == 1) return gemm_run_tile_h<LA, LB, 1, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 		return gemm_run_tile_h<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	}
-	if (M > 64 && N > 64 && (big_tiles * zcount >= device_cu_count() || K >= 4096)) return gemm_run_tile_h<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
+	if (!small_tiles && M > 64 && N > 64 && (big_tiles * zcount >= device_cu_count() || K >= 4096)) return gemm_run_tile_h<LA, LB, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 	return gemm_run_tile_h<LA, LB, 1, 1>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 }
 
