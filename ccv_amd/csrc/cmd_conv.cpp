@@ -457,7 +457,7 @@ static bool wino_preferred(const wino_plan_t& p, const int C_src, const int C_ds
 // ---- first-layer convolution (3 input channels): conv_c3.h ----------------------------------------------------------------
 static bool conv_c3_ok(const conv_geom_t& g, const Image4& a, const Image4& b)
 {
-	if (g.C != 3 || g.kh != 3 || g.kw != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.groups != 1) return false;
+	if (g.C != 3 || g.kh != 3 || g.kw != 3 || g.sy < 1 || g.sx < 1 || g.sy > 4 || g.sx > 4 || g.dy != 1 || g.dx != 1 || g.groups != 1) return false;
 	if (g.K != 16 && g.K != 32 && g.K != 64) return false;
 	if (a.sc != 1 || a.sw != 3 || b.sc != 1 || !aligned16(b.p) || b.sw % 4 || b.sh % 4 || (b.n > 1 && b.sn % 4)) return false;
 	if ((long)a.h * a.sh >= 0x7fffffffL) return false; // 32-bit offsets within an image
@@ -468,7 +468,7 @@ static void conv_c3_args(const conv_geom_t& g, const Image4& a, const float* w, 
 {
 	c->a = a.p; c->w = w; c->bias = bias; c->b = b.p;
 	c->a_sn = a.sn; c->a_sh = a.sh; c->b_sn = b.sn; c->b_sh = b.sh; c->b_sw = b.sw;
-	c->N = g.N; c->H = g.H; c->W = g.W; c->OH = g.OH; c->OW = g.OW; c->K = g.K; c->pad_y = g.pby; c->pad_x = g.pbx;
+	c->N = g.N; c->H = g.H; c->W = g.W; c->OH = g.OH; c->OW = g.OW; c->K = g.K; c->pad_y = g.pby; c->pad_x = g.pbx; c->sy = g.sy; c->sx = g.sx;
 	c->groups_per_row = (g.OW + 15) / 16; c->groups = g.N * g.OH * c->groups_per_row;
 	c->d_gpr.init(c->groups_per_row); c->d_oh.init(g.OH);
 	c->b_image_bytes = (unsigned)((((long)b.h - 1) * b.sh + ((long)b.w - 1) * b.sw + b.c) * 4);

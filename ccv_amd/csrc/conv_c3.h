@@ -1,4 +1,4 @@
-// First-layer convolution: 3x3, stride 1, THREE input channels (VGG-D conv1_1, BASELINE config 1), forward and filter gradient.
+// First-layer convolution: 3x3, THREE input channels (VGG-D conv1_1, BASELINE config 1; round 4: any stride -- ResNet-50's stride-2 stem layer), forward and filter gradient.
 // On the general contraction kernel its 27-deep reduction is padded to a 32-deep K-step on 32x32x2 MFMAs and the wide
 // output tile is written behind a long epilogue: 19 TFLOP/s, 2.3 ms for a 3.26 GB store at batch 256 (1.4 TB/s).  These kernels
 // are shaped by the tensor instead:
@@ -22,6 +22,7 @@ struct ConvC3Args {
 	long a_sn, a_sh, b_sn, b_sh, b_sw; // element strides (a: pixel stride 3)
 	int N, H, W, OH, OW, K;
 	int pad_y, pad_x;
+	int sy, sx;                 // stride (1 or more): the patch of output pixel (oy, ox) starts at input (oy * sy - pad_y, ox * sx - pad_x)
 	int groups_per_row, groups; // 16-pixel groups per output row, total
 	int relu;                   // forward: write max(0, .) (NNC_MI355X_CONV_ALGO_FUSE_RELU)
 	unsigned b_image_bytes;     // forward: span of one output image in bytes (range of the per-image store descriptor; host-checked < 2^31)
@@ -32,9 +33,9 @@ struct ConvC3Args {
 __device__ __forceinline__ float convc3_patch(const float* const img, const ConvC3Args& g, const int oy, const int ox, const int k)
 {
 	const int dy = k / 9, r9 = k - dy * 9, dx = r9 / 3;
-	const int iy = oy - g.pad_y + dy, ix = ox - g.pad_x + dx;
+	const int iy = oy * g.sy - g.pad_y + dy, ix = ox * g.sx - g.pad_x + dx;
 	const bool ok = (k < 27) & (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.W);
-	return ok ? img[(long)iy * g.a_sh + (ox - g.pad_x) * 3 + r9] : 0.f;
+	return ok ? img[(long)iy * g.a_sh + (ox * g.sx - g.pad_x) * 3 + r9] : 0.f;
 }
 
 // NT = K / 16 (1, 2 or 4 channel tiles).  grid: as many workgroups as fit the chip; waves stride over the pixel groups.
@@ -95,7 +96,7 @@ static __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const ConvC3
 	// behind the load would make hipcc wait for the load on the spot)
 	auto fetch = [&](const Pos& p, float (&v)[7], unsigned& okmask) {
 		const float* const ap = g.a + (long)p.img * g.a_sn;
-		const int iy0 = p.oy - g.pad_y, ix0 = p.gx * 16 + pix - g.pad_x;
+		const int iy0 = p.oy * g.sy - g.pad_y, ix0 = (p.gx * 16 + pix) * g.sx - g.pad_x;
 		const int base = iy0 * (int)g.a_sh + ix0 * 3; // (one image spans < 2^31 floats: host-checked)
 		okmask = 0;
 #pragma unroll

@@ -590,21 +590,25 @@ def test_conv_wgrad_winograd_fused(backend, ref_lib, case, flags):
 
 
 C3_CASES = [
-    # n, h, w, k, border: 3x3 stride 1 on THREE input channels -> conv_c3.h (K = 16 / 32 / 64), under the backend's own choice
+    # n, h, w, k, border[, stride]: 3x3 on THREE input channels -> conv_c3.h (K = 16 / 32 / 64), under the backend's own choice
     (2, 9, 21, 64, (0, 0)),     # VGG-D conv1_1 class: no padding, ragged 16-pixel groups (19 wide)
     (1, 16, 16, 64, (1, 1)),    # BASELINE config 1 class: padding 1
     (3, 7, 40, 32, (1, 1)),
     (2, 5, 6, 16, (2, 2)),      # full padding, rows shorter than one group
     (1, 18, 33, 64, (1, 0)),    # asymmetric padding
+    (2, 20, 38, 32, (1, 1), (2, 2)),   # ResNet-50 v1d's stem: stride 2, 32 filters
+    (1, 17, 33, 64, (1, 1), (2, 2)),   # odd sizes under stride 2
+    (2, 9, 23, 16, (0, 0), (2, 3)),    # different strides per axis, no padding
 ]
 
 
 @pytest.mark.parametrize("case", C3_CASES)
 def test_conv_first_layer_direct(backend, ref_lib, case):
-    n, h, w, k, border = case
+    n, h, w, k, border = case[:5]
+    stride = case[5] if len(case) > 5 else (1, 1)
     rng = np.random.default_rng(9)
     a, wt, b = srnd(rng, n, h, w, 3), srnd(rng, k, 3, 3, 3, scale=1.0 / 27), srnd(rng, k)
-    hint = nnc.HINT((1, 1), border)
+    hint = nnc.HINT(stride, border)
     oh, ow = out_hw(h, w, 3, 3, hint)
     fwd = nnc.CMD_CONVOLUTION_FORWARD(1, k, 3, 3, 3)
     got, want = exec_pair(backend, ref_lib, fwd, hint, 0, [a, wt, b], [np.full((n, oh, ow, k), 7, F)])
@@ -615,7 +619,8 @@ def test_conv_first_layer_direct(backend, ref_lib, case):
     dw0, db0 = srnd(rng, *wt.shape), srnd(rng, k)
     for flags in (0, nnc.ACCUMULATE_OUTPUT):
         got, want = exec_pair(backend, ref_lib, bwd, hint, flags, [g, a, wt], [np.zeros_like(a), dw0.copy(), db0.copy()])
-        assert backend.dll.nnc_mi355x_last_kernel_name().decode() in ("conv_wgrad_c3", "conv_dgrad", "conv_dgrad_wino", "conv_dgrad_wino_fused")
+        # (the data gradient runs last; under a stride it is the parity-class form, whose launches are forward contractions)
+        assert backend.dll.nnc_mi355x_last_kernel_name().decode() in ("conv_wgrad_c3", "conv_dgrad", "conv_dgrad_wino", "conv_dgrad_wino_fused") + (("conv_fwd",) if stride != (1, 1) else ())
         np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=2e-5)
         # the CPU oracle overwrites dbias under ACCUMULATE (see test_conv_backward): the GPU backend being replaced accumulates
