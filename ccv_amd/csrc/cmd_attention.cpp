@@ -589,9 +589,10 @@ __global__ void __launch_bounds__(256) sdpa_dq_mfma_kernel(const sdpa_geom_t g, 
 // dk, dv: a wave owns 32 KEYS (their k and v rows in registers), a workgroup 128; the query blocks of 32 of every query head that shares the key head stream
 // through LDS (q, g, lse, delta).  S = Q K^T and dP = G V^T with A = the Q / G tile (lane: query l & 31, its half's values), B = the key's registers: lane
 // (key, half) holds p and ds of the queries qx(r) of ITS key, and they are the B operands of  dV^T [Dv x 32 keys] += G^T P  and  dK^T [D x 32 keys] += Q^T dS
-// (A = G / Q [query qx(j)][column l & 31] out of the same tiles).  One fixed summation order, no atomics.  Conditions: D % 32 == 0, Dv % 32 == 0, both <= 64
-// (four accumulator tiles + both key rows + the two score tiles in 160 registers; beyond that the VALU kernel below).
-template <int TD, int TV> // D / 32, Dv / 32 (1 or 2)
+// (A = G / Q [query qx(j)][column l & 31] out of the same tiles).  One fixed summation order, no atomics.  Conditions: D % 32 == 0, Dv % 32 == 0, both <= 128;
+// up to 64 columns each both gradients come out of one pass (four accumulator tiles + both key rows + the two score tiles in 160 registers), beyond that the
+// kernel runs twice -- once for dv (no dP product), once for dk -- with half the accumulators each.
+template <int TD, int TV, bool DO_K = true, bool DO_V = true> // D / 32, Dv / 32; both gradients in one pass up to 64 columns each, one per pass beyond (the caller launches twice)
 __global__ void __launch_bounds__(256) sdpa_dkv_mfma_kernel(const sdpa_geom_t g, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ mask, const float* __restrict__ gr, const long g_sb, const long g_sr, const long g_sh, const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dk, const long dk_sb, const long dk_sc, const long dk_sh, float* __restrict__ dv, const long dv_sb, const long dv_sc, const long dv_sh)
 {
 	constexpr int DH = 16 * TD, GH = 16 * TV, QP = 2 * DH + 4, GP = 2 * GH + 4;
@@ -609,10 +610,12 @@ __global__ void __launch_bounds__(256) sdpa_dkv_mfma_kernel(const sdpa_geom_t g,
 		const float4 u = y < g.C ? *(const float4*)(k + b * g.k_sb + (long)y * g.k_sc + hk * g.k_sh + lh * DH + i) : make_float4(0.f, 0.f, 0.f, 0.f);
 		kreg[i] = u.x; kreg[i + 1] = u.y; kreg[i + 2] = u.z; kreg[i + 3] = u.w;
 	}
+	if constexpr (DO_K) {
 #pragma unroll
-	for (int i = 0; i < GH; i += 4) {
-		const float4 u = y < g.C ? *(const float4*)(v + b * g.v_sb + (long)y * g.v_sc + hk * g.v_sh + lh * GH + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-		vreg[i] = u.x; vreg[i + 1] = u.y; vreg[i + 2] = u.z; vreg[i + 3] = u.w;
+		for (int i = 0; i < GH; i += 4) {
+			const float4 u = y < g.C ? *(const float4*)(v + b * g.v_sb + (long)y * g.v_sc + hk * g.v_sh + lh * GH + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+			vreg[i] = u.x; vreg[i + 1] = u.y; vreg[i + 2] = u.z; vreg[i + 3] = u.w;
+		}
 	}
 	floatx16 ak[TD], av[TV];
 #pragma unroll
@@ -651,14 +654,16 @@ __global__ void __launch_bounds__(256) sdpa_dkv_mfma_kernel(const sdpa_geom_t g,
 				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, kreg[i + 2], s, 0, 0, 0);
 				s = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, kreg[i + 3], s, 0, 0, 0);
 			}
-			const float* const grow = Gs + li * GP + lh * GH;
+			if constexpr (DO_K) {
+				const float* const grow = Gs + li * GP + lh * GH;
 #pragma unroll
-			for (int i = 0; i < GH; i += 4) {
-				const float4 u = *(const float4*)(grow + i);
-				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, vreg[i], dp, 0, 0, 0);
-				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, vreg[i + 1], dp, 0, 0, 0);
-				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, vreg[i + 2], dp, 0, 0, 0);
-				dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, vreg[i + 3], dp, 0, 0, 0);
+				for (int i = 0; i < GH; i += 4) {
+					const float4 u = *(const float4*)(grow + i);
+					dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, vreg[i], dp, 0, 0, 0);
+					dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, vreg[i + 1], dp, 0, 0, 0);
+					dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, vreg[i + 2], dp, 0, 0, 0);
+					dp = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, vreg[i + 3], dp, 0, 0, 0);
+				}
 			}
 			// this lane's key: register r <-> query x0 + qx, qx = (r & 3) + 8 (r >> 2) + 4 lh
 #pragma unroll
@@ -677,23 +682,27 @@ __global__ void __launch_bounds__(256) sdpa_dkv_mfma_kernel(const sdpa_geom_t g,
 				const int qx = (j & 3) + 8 * (j >> 2) + 4 * lh;
 				const float* const gcol = Gs + qx * GP + li;
 				const float* const qcol = Qs + qx * QP + li;
+				if constexpr (DO_V) {
 #pragma unroll
-				for (int i = 0; i < TV; i++) av[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(gcol[32 * i], s[j], av[i], 0, 0, 0);
+					for (int i = 0; i < TV; i++) av[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(gcol[32 * i], s[j], av[i], 0, 0, 0);
+				}
+				if constexpr (DO_K) {
 #pragma unroll
-				for (int i = 0; i < TD; i++) ak[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qcol[32 * i], dp[j], ak[i], 0, 0, 0);
+					for (int i = 0; i < TD; i++) ak[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qcol[32 * i], dp[j], ak[i], 0, 0, 0);
+				}
 			}
 		}
 	if (y < g.C) {
 #pragma unroll
 		for (int r4 = 0; r4 < 4; r4++) { // registers 4 r4 .. 4 r4 + 3 of tile i are column 32 i + 8 r4 + 4 lh + 0..3 of this lane's key
-			if (dk) {
+			if (DO_K && dk) {
 				float* const o = dk + b * dk_sb + (long)y * dk_sc + hk * dk_sh;
 #pragma unroll
 				for (int i = 0; i < TD; i++)
 #pragma unroll
 					for (int e = 0; e < 4; e++) o[32 * i + 8 * r4 + 4 * lh + e] = g.scale * ak[i][4 * r4 + e];
 			}
-			if (dv) {
+			if (DO_V && dv) {
 				float* const o = dv + b * dv_sb + (long)y * dv_sc + hk * dv_sh;
 #pragma unroll
 				for (int i = 0; i < TV; i++)
@@ -1104,7 +1113,7 @@ static int _sdpa_back(EXEC_ARGS)
 	// the matrix-core kernels: whole 16-byte chunks of every row, whole 32-column output tiles
 	const bool rows16 = !(((uintptr_t)qp | (uintptr_t)kp | (uintptr_t)vp | (uintptr_t)gp) & 15) && !((g.q_sb | g.q_sr | g.q_sh | g.k_sb | g.k_sc | g.k_sh | g.v_sb | g.v_sc | g.v_sh | gi.sb | gi.sn | gi.sh) & 3);
 	const bool mfma_dq = tune(TUNE_SDPA_MFMA) && rows16 && g.D % 32 == 0 && g.Dv % 8 == 0 && g.D <= 128 && g.Dv <= 128;
-	const bool mfma_dkv = tune(TUNE_SDPA_MFMA) && rows16 && g.D % 32 == 0 && g.Dv % 32 == 0 && g.D <= 64 && g.Dv <= 64;
+	const bool mfma_dkv = tune(TUNE_SDPA_MFMA) && rows16 && g.D % 32 == 0 && g.Dv % 32 == 0 && g.D <= 128 && g.Dv <= 128;
 	if (dq && mfma_dq) {
 		const dim3 grid((g.R + 127) / 128, g.Hq, g.B);
 		const int td = g.D / 32;
@@ -1129,8 +1138,18 @@ static int _sdpa_back(EXEC_ARGS)
 		note_kernel("sdpa_dkv_mfma");
 		ProfScope prof("sdpa_dkv|nnc::sdpa_dkv_mfma_kernel", 2.0 * g.B * g.Hq * (double)g.R * g.C * (2 * g.D + 2 * g.Dv), 0, g.C, g.R, g.D, g.B * g.Hk, 1, stream);
 #define SDPA_DKV(TD, TV) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_dkv_mfma_kernel<TD, TV>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dkp, ksb, ksn, ksh, dvp, vsb, vsn, vsh)
-		if (g.D == 32) { if (g.Dv == 32) SDPA_DKV(1, 1); else SDPA_DKV(1, 2); }
-		else { if (g.Dv == 32) SDPA_DKV(2, 1); else SDPA_DKV(2, 2); }
+		if (g.D <= 64 && g.Dv <= 64) {
+			if (g.D == 32) { if (g.Dv == 32) SDPA_DKV(1, 1); else SDPA_DKV(1, 2); }
+			else { if (g.Dv == 32) SDPA_DKV(2, 1); else SDPA_DKV(2, 2); }
+		} else {
+			// one gradient per pass (registers): dv first, then dk
+#define SDPA_DKV2(TD, TV) do { if (dvp) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_dkv_mfma_kernel<TD, TV, false, true>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dkp, ksb, ksn, ksh, dvp, vsb, vsn, vsh); \
+			if (dkp) hipLaunchKernelGGL(HIP_KERNEL_NAME(sdpa_dkv_mfma_kernel<TD, TV, true, false>), grid, dim3(256), 0, stream, g, qp, kp, vp, mp, gp, gi.sb, gi.sn, gi.sh, (const float*)lse, (const float*)delta, dkp, ksb, ksn, ksh, dvp, vsb, vsn, vsh); } while (0)
+#define SDPA_DKV2_TV(TD) do { switch (g.Dv / 32) { case 1: SDPA_DKV2(TD, 1); break; case 2: SDPA_DKV2(TD, 2); break; case 3: SDPA_DKV2(TD, 3); break; default: SDPA_DKV2(TD, 4); break; } } while (0)
+			switch (g.D / 32) { case 1: SDPA_DKV2_TV(1); break; case 2: SDPA_DKV2_TV(2); break; case 3: SDPA_DKV2_TV(3); break; default: SDPA_DKV2_TV(4); break; }
+#undef SDPA_DKV2_TV
+#undef SDPA_DKV2
+		}
 #undef SDPA_DKV
 		HIP_ENFORCE(hipGetLastError());
 	} else if (dk || dv) {
