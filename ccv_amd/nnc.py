@@ -26,7 +26,7 @@ BACKEND_CPU_OPT, BACKEND_CPU_REF = 0x46deb194, 0x3d9883e5
 BACKEND_GPU_CUBLAS, BACKEND_GPU_CUDNN, BACKEND_GPU_NCCL, BACKEND_GPU_REF = 0x9b8cfed, 0x854b679a, 0x7afed9c7, 0x5f19790a
 
 CMD = dict(
-    SCALED_DOT_PRODUCT_ATTENTION_FORWARD=0x284ed926, SCALED_DOT_PRODUCT_ATTENTION_BACKWARD=0x284ed927,
+    SCALED_DOT_PRODUCT_ATTENTION_FORWARD=0x284ed926, SCALED_DOT_PRODUCT_ATTENTION_BACKWARD=0x284ed927, LSTM_FORWARD=0xc5cb998c, LSTM_BACKWARD=0xc5cb998d,
     CMUL_FORWARD=0xead486e6, CMUL_BACKWARD=0xead486e7, NMS_FORWARD=0xdba26106, NMS_BACKWARD=0xdba26107,
     ROI_ALIGN_FORWARD=0xfef55168, ROI_ALIGN_BACKWARD=0xfef55169, COMPRESSION_LSSC_FORWARD=0x17ea8f72, COMPRESSION_LSSC_BACKWARD=0x17ea8f73,
     ADD_FORWARD=0x58fb3664, ADD_BACKWARD=0x58fb3665,
@@ -170,10 +170,14 @@ class _I1(C.Structure):   # mse.reduce_op
     _fields_ = [("v", C.c_int)]
 
 
+class _Rnn(C.Structure):  # ccv_nnc.h:127-136
+    _fields_ = [("hidden_size", C.c_int), ("proj_size", C.c_int), ("num_layers", C.c_int), ("bias", C.c_int), ("batch_first", C.c_int), ("bidirectional", C.c_int), ("dropout", C.c_float), ("is_test", C.c_int)]
+
+
 class _CmdUnion(C.Union):
     _fields_ = [("convolution", _Conv), ("convolution_transpose", _ConvTranspose), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
                 ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
-                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("upsample", _Upsample), ("lnorm", _Lnorm), ("gnorm", _Gnorm), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("upsample", _Upsample), ("lnorm", _Lnorm), ("gnorm", _Gnorm), ("rnn", _Rnn), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
 
 class CmdParam(C.Structure):
@@ -426,6 +430,17 @@ EWSUM_ALGO_FUSE_RELU = 0x100  # NNC_MI355X_EWSUM_ALGO_FUSE_RELU
 EWSUM_ALGO_FUSE_RELU_BACKWARD = 0x200  # NNC_MI355X_EWSUM_ALGO_FUSE_RELU_BACKWARD: the last input is the mask map
 
 
+def _lstm(name, hidden_size, proj_size, num_layers, bias, batch_first, bidirectional, dropout, is_test):
+    c = _cmd(name, (0, 0, 0))
+    c.info.rnn.hidden_size, c.info.rnn.proj_size, c.info.rnn.num_layers, c.info.rnn.bias = hidden_size, proj_size, num_layers, bias
+    c.info.rnn.batch_first, c.info.rnn.bidirectional, c.info.rnn.dropout, c.info.rnn.is_test = batch_first, bidirectional, dropout, is_test
+    return c
+
+
+def CMD_LSTM_FORWARD(*a): return _lstm("LSTM_FORWARD", *a)    # lib/nnc/cmd/rnn/ccv_nnc_lstm.c:84
+def CMD_LSTM_BACKWARD(*a): return _lstm("LSTM_BACKWARD", *a)  # :86
+
+
 def generic_cmd(name, size=(0, 0, 0)):
     return _cmd(name, size)
 
@@ -623,6 +638,8 @@ class Lib:
             d.nnc_mi355x_registry_get.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(BackendRegistry)]
             d.nnc_mi355x_cmd_ok.argtypes = [C.c_uint32, C.c_uint32]
             d.nnc_mi355x_version.restype = C.c_char_p
+            d.nnc_mi355x_lstm_reserve_space_size.restype = C.c_size_t
+            d.nnc_mi355x_lstm_reserve_space_size.argtypes = [Cmd, C.c_int, C.c_int, C.c_int, C.c_int]
             d.nnc_mi355x_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         self._exec.restype = C.c_int
         self._exec.argtypes = self._EXEC_ARGS

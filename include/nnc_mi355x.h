@@ -136,6 +136,7 @@ enum {
 	CCV_NNC_SWISH_FORWARD = 0x583d90c2, CCV_NNC_SWISH_BACKWARD = 0x583d90c3,
 	CCV_NNC_TANH_FORWARD = 0x6a62be30, CCV_NNC_TANH_BACKWARD = 0x6a62be31,
 	CCV_NNC_UPSAMPLE_FORWARD = 0x73875556, CCV_NNC_UPSAMPLE_BACKWARD = 0x73875557,
+	CCV_NNC_LSTM_FORWARD = 0xc5cb998c, CCV_NNC_LSTM_BACKWARD = 0xc5cb998d,
 };
 
 /* Backend slot ids (lib/nnc/cmd/ccv_nnc_backend.h). */
@@ -229,6 +230,7 @@ typedef struct { /* 120 bytes */
 		struct { int step; float rate; float scale; float beta1; float beta2; float decay; float epsilon; } lamb;
 		struct { float iou_threshold; } nms;
 		struct { float scale; int is_causal; int flags; int deterministic; } scaled_dot_product_attention;
+		struct { int hidden_size; int proj_size; int num_layers; int bias; int batch_first; int bidirectional; float dropout; int is_test; } rnn; /* ccv_nnc.h:127-136 */
 		char _widest[68]; /* gnorm is the widest member in the reference (68 B) */
 		void* userdata;
 	};
@@ -367,6 +369,10 @@ int  nnc_mi355x_profile_get(int i, char* name, int name_len, double* flops, doub
  * tile shape on every loader at sizes the oracle finishes. */
 void nnc_mi355x_debug_force_tile(int wm, int wn);
 void nnc_mi355x_debug_force_splits(int splits);
+/* Bytes of reserved space LSTM_FORWARD writes (output 3) and LSTM_BACKWARD reads (input 12) -- the function both LSTM rows carry in registry->aux,
+ * which the host's shape inference calls through ccv_nnc_cmd_aux (lib/nnc/cmd/rnn/ccv_nnc_lstm.c:35,64-71); replaces
+ * _ccv_nnc_lstm_reserve_space_size / cudnnGetRNNTempSpaceSizes (lib/nnc/cmd/rnn/gpu/ccv_nnc_lstm_gpu_cudnn.cu:17-48).  0 when cmd.info.rnn.is_test. */
+size_t nnc_mi355x_lstm_reserve_space_size(const ccv_nnc_cmd_t cmd, int datatype, int feature_size, int batch_count, int max_seq_count);
 /* Opt-in fusion for callers that know a CONVOLUTION_FORWARD's only consumer is the RELU_FORWARD behind it (the reference's graphs run
  * that ReLU in place, test/int/nnc/graph.vgg.d.tests.c:80): cmd.algorithm = NNC_MI355X_CONV_ALGO_FUSE_RELU | a, a = 0 .. 2 or 0xff for the
  * backend's choice, makes the command write max(0, conv + bias); the RELU_FORWARD may then be dropped.  Applied in the epilogue of the
