@@ -18,6 +18,7 @@
 // Reserved space (floats, H wide; fits the reference tests' sizing, lstm.tests.c:23-34): per pseudo-layer and step S = 5 (+1 projection, +1 dropout)
 // planes of B x H -- i, f, g, o, tanh(c), [projected h], [dropout scale] --, then the cell state after each of the first T - 1 steps.
 #include "gemm_launch.h"
+#include "isa.h"
 
 using namespace nnc;
 
@@ -100,6 +101,233 @@ __device__ __forceinline__ void lstm_rows_times(const float* const a, const int 
 			}
 		}
 	}
+}
+
+// ---- the whole sequence of one pseudo-layer in ONE launch (TUNE_LSTM_PERSISTENT; no projection, hidden size <= 512, the grid within the CU count) ----
+// A workgroup owns 16 hidden units (their 64 gate columns) of a 16-row batch tile for all T steps.  Its slice of R -- 64 columns x P -- never leaves the
+// register file: lane c of wave q holds column c's P / 4 coefficients of reduction quarter q.  Per step: the tile's state h' [16][P] arrives in LDS, every
+// thread forms its 16 partial sums, the four quarters meet in LDS, thread (row, unit) adds the input half, does the gate arithmetic, keeps c in a register and
+// PUBLISHES h: one 8-byte {step tag, value} word per element written with one agent-scope store -- the data is the flag (isa.h) --, which the tile's other
+// workgroups poll while they fill their LDS image for the next step.  Two tag-parity planes suffice: a workgroup can only publish step s + 2 after it has read
+// every word of step s + 1, whose writers had all finished reading step s.  The words are zeroed before the launch (tags start at 1).  A poll that gives up
+// (CLUSTER_SPIN_LIMIT: the workgroups were not resident together) raises the stream's timeout word like cmd_norm.cpp's cluster kernels; the next synchronise stops the process.
+struct lstm_seq_t {
+	const float* gx; const float* r; const float* bw; const float* hx; const float* cx;
+	float* y; float* hy; float* cy; float* rsv; unsigned long long* xch; const int* lens; unsigned* timeout_word;
+	int T, B, H, dir, ldy, S;
+	size_t slot0, cslot0; // of this pseudo-layer in the reserved space (floats)
+};
+#define LSTM_SEQ_LDS(KPT) (sizeof(float) * (16 * (4 * (KPT) + 4) + 4 * 16 * 65 + 4))
+template <int KPT>
+__global__ void __launch_bounds__(256) lstm_seq_forw_kernel(const lstm_seq_t a)
+{
+	constexpr int KT = 4 * KPT, PITCH = KT + 4;
+	HIP_DYNAMIC_SHARED(float, lds) // (dynamic: the emulator keeps several of these workgroups resident, and only this form is per workgroup there)
+	float* const htile = lds;                                        // [16][PITCH]
+	float (*const part)[16][65] = (float (*)[16][65])(lds + 16 * PITCH); // [4][16][65]
+	int& dead = *(int*)(lds + 16 * PITCH + 4 * 16 * 65);
+	const int tid = threadIdx.x, c = tid & 63, kq = tid >> 6;
+	const int H = a.H, B = a.B, j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
+	const size_t BH = (size_t)B * H;
+	float rreg[KPT];
+	{
+		const int n = (c >> 4) * H + j0 + (c & 15);
+		const bool on = j0 + (c & 15) < H;
+#pragma unroll
+		for (int i = 0; i < KPT; i++) { const int k = kq * KPT + i; rreg[i] = on && k < H ? a.r[(size_t)n * H + k] : 0.f; }
+	}
+	const int rr = tid >> 4, u = tid & 15, b = row0 + rr, j = j0 + u;
+	const bool mine = b < B && j < H;
+	const size_t e = (size_t)b * H + j;
+	float cst = mine && a.cx ? a.cx[e] : 0.f, hst = mine && a.hx ? a.hx[e] : 0.f;
+	const int len = mine && a.lens ? a.lens[b] : a.T;
+	float bias[4] = { 0.f, 0.f, 0.f, 0.f };
+	if (mine && a.bw)
+#pragma unroll
+		for (int g = 0; g < 4; g++) bias[g] = a.bw[g * H + j] + a.bw[4 * H + g * H + j];
+	if (tid == 0) dead = 0;
+	__syncthreads();
+	for (int s = 0; s < a.T; s++) {
+		const int t = a.dir ? a.T - 1 - s : s;
+		float gin[4] = { 0.f, 0.f, 0.f, 0.f };
+		if (mine) { // (issued before the wait: the input half does not depend on the other workgroups)
+			const float* const gr = a.gx + ((size_t)t * B + b) * 4 * H + j;
+#pragma unroll
+			for (int g = 0; g < 4; g++) gin[g] = gr[g * H];
+		}
+		// the tile's state before this step: hx at the first step, the words the tile's workgroups published at the step before otherwise
+		for (int q0 = tid; q0 < 16 * H; q0 += 256 * 8) { // eight words in flight per thread, then the ones that had not arrived yet again
+			unsigned long long gr[8];
+			const unsigned long long* w[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const int q = q0 + 256 * i, r2 = q / H, k = q - r2 * H, b2 = row0 + r2;
+				const bool on = q < 16 * H && b2 < B;
+				w[i] = a.xch + ((size_t)((s + 1) & 1) * B + (on ? b2 : 0)) * H + (on ? k : 0);
+				gr[i] = (unsigned long long)(unsigned)s << 32; // (rows past the batch: "arrived", zero)
+				if (on) gr[i] = s == 0 ? (unsigned long long)__float_as_uint(a.hx ? a.hx[(size_t)b2 * H + k] : 0.f) : nnc_load_granule(w[i]);
+			}
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				unsigned spins = 0;
+				while ((unsigned)(gr[i] >> 32) != (unsigned)s) {
+					if (*(volatile int*)&dead) break;
+					if (++spins > CLUSTER_SPIN_LIMIT) { dead = 1; nnc_store_agent(a.timeout_word, 0xc0000000u | (unsigned)s); break; }
+					NNC_SPIN_SLEEP();
+					gr[i] = nnc_load_granule(w[i]);
+				}
+				const int q = q0 + 256 * i, r2 = q / H, k = q - r2 * H;
+				if (q < 16 * H) htile[r2 * PITCH + k] = __uint_as_float((unsigned)gr[i]);
+			}
+		}
+		if (KT > H) for (int q = tid; q < 16 * (KT - H); q += 256) { const int r2 = q / (KT - H), k = H + q - r2 * (KT - H); htile[r2 * PITCH + k] = 0.f; }
+		__syncthreads();
+		float acc[16];
+#pragma unroll
+		for (int r2 = 0; r2 < 16; r2++) acc[r2] = 0.f;
+#pragma unroll
+		for (int i = 0; i < KPT; i += 4) {
+#pragma unroll
+			for (int r2 = 0; r2 < 16; r2++) {
+				const float4 hv = *(const float4*)&htile[r2 * PITCH + kq * KPT + i];
+				acc[r2] += rreg[i] * hv.x + rreg[i + 1] * hv.y + rreg[i + 2] * hv.z + rreg[i + 3] * hv.w;
+			}
+		}
+#pragma unroll
+		for (int r2 = 0; r2 < 16; r2++) part[kq][r2][c] = acc[r2];
+		__syncthreads();
+		if (mine) {
+			float* const gates = a.rsv ? a.rsv + a.slot0 + (size_t)s * a.S * BH : 0;
+			float hnew = hst;
+			if (t < len) {
+				float pre[4];
+#pragma unroll
+				for (int g = 0; g < 4; g++) pre[g] = ((part[0][rr][g * 16 + u] + part[1][rr][g * 16 + u]) + (part[2][rr][g * 16 + u] + part[3][rr][g * 16 + u])) + gin[g] + bias[g];
+				const float i = lstm_sigmoid(pre[0]), f = lstm_sigmoid(pre[1]), g = tanhf(pre[2]), o = lstm_sigmoid(pre[3]);
+				cst = f * cst + i * g;
+				const float tc = tanhf(cst);
+				hnew = o * tc;
+				a.y[((size_t)t * B + b) * a.ldy + j] = hnew;
+				if (gates) { gates[e] = i; gates[BH + e] = f; gates[2 * BH + e] = g; gates[3 * BH + e] = o; gates[4 * BH + e] = tc; }
+			} else {
+				a.y[((size_t)t * B + b) * a.ldy + j] = 0.f;
+				if (gates) for (int k = 0; k < 5; k++) gates[k * BH + e] = 0.f;
+			}
+			hst = hnew;
+			if (s < a.T - 1) {
+				nnc_store_granule(a.xch + ((size_t)(s & 1) * B + b) * H + j, (unsigned)(s + 1), hnew);
+				if (a.rsv) a.rsv[a.cslot0 + (size_t)s * BH + e] = cst;
+			}
+		}
+		__syncthreads();
+	}
+	if (mine) { if (a.hy) a.hy[e] = hst; if (a.cy) a.cy[e] = cst; }
+}
+
+// The backward pass of one pseudo-layer's whole sequence in ONE launch (hidden size <= 128): the same ownership as lstm_seq_forw_kernel.  Per step, thread (row, unit)
+// turns its state gradients (dh, dc: registers for the whole sequence) into the four gate gradients, writes them to dG (the contractions after the loop read them)
+// and publishes them as tagged words; the tile's workgroups gather the tile's dG [16][4H] into LDS, and every workgroup forms dh' = dG R for ITS 16 units -- lane
+// (unit, slice) holds the H / 4 coefficients R[n][unit] of its slice of n in registers, the 16 slices meet in LDS.
+struct lstm_seq_back_t {
+	const float* r; const float* rsv; const float* cx; const float* dy; const float* dhy; const float* dcy;
+	float* dg; float* dhx; float* dcx; unsigned long long* xch; const int* lens; unsigned* timeout_word;
+	int T, B, H, dir, ldy, S;
+	size_t slot0, cslot0;
+};
+constexpr int LSTM_SEQ_BACK_KPT = 32; // H <= 128: 4H / 16 slices
+#define LSTM_SEQ_BACK_LDS (sizeof(float) * (16 * (16 * LSTM_SEQ_BACK_KPT + 4) + 16 * 16 * 17 + 4))
+__global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_t a)
+{
+	constexpr int KPT = LSTM_SEQ_BACK_KPT, NT = 16 * KPT, PITCH = NT + 4;
+	HIP_DYNAMIC_SHARED(float, lds)
+	float* const dgtile = lds;                                            // [16][PITCH]
+	float (*const part)[16][17] = (float (*)[16][17])(lds + 16 * PITCH);  // [16 slices][16 rows][16 units]
+	int& dead = *(int*)(lds + 16 * PITCH + 16 * 16 * 17);
+	const int tid = threadIdx.x, u = tid & 15, nq = tid >> 4;
+	const int H = a.H, B = a.B, N4 = 4 * H, j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
+	const size_t BH = (size_t)B * H;
+	float rreg[KPT];
+#pragma unroll
+	for (int i = 0; i < KPT; i++) { const int n = nq * KPT + i; rreg[i] = n < N4 && j0 + u < H ? a.r[(size_t)n * H + j0 + u] : 0.f; }
+	const int rr = nq, b = row0 + rr, j = j0 + u; // (the same 16 x 16 split of the threads serves as (slice, unit) and as (row, unit))
+	const bool mine = b < B && j < H;
+	const size_t e = (size_t)b * H + j;
+	float dh = mine && a.dhy ? a.dhy[e] : 0.f, dc = mine && a.dcy ? a.dcy[e] : 0.f;
+	const int len = mine && a.lens ? a.lens[b] : a.T;
+	if (tid == 0) dead = 0;
+	__syncthreads();
+	for (int it = 0; it < a.T; it++) {
+		const int s = a.T - 1 - it, t = a.dir ? a.T - 1 - s : s;
+		if (mine) {
+			float d4[4] = { 0.f, 0.f, 0.f, 0.f };
+			if (t < len) {
+				const float* const gates = a.rsv + a.slot0 + (size_t)s * a.S * BH;
+				const float i = gates[e], f = gates[BH + e], g = gates[2 * BH + e], o = gates[3 * BH + e], tc = gates[4 * BH + e];
+				const float cprev = s == 0 ? (a.cx ? a.cx[e] : 0.f) : a.rsv[a.cslot0 + (size_t)(s - 1) * BH + e];
+				const float dht = dh + a.dy[((size_t)t * B + b) * a.ldy + j];
+				const float dct = dc + dht * o * (1.f - tc * tc);
+				d4[0] = dct * g * i * (1.f - i);
+				d4[1] = dct * cprev * f * (1.f - f);
+				d4[2] = dct * i * (1.f - g * g);
+				d4[3] = dht * tc * o * (1.f - o);
+				dc = dct * f;
+			}
+			float* const dgt = a.dg + ((size_t)t * B + b) * N4 + j;
+#pragma unroll
+			for (int g = 0; g < 4; g++) {
+				dgt[g * H] = d4[g];
+				nnc_store_granule(a.xch + ((size_t)(it & 1) * B + b) * N4 + g * H + j, (unsigned)(it + 1), d4[g]);
+			}
+		}
+		for (int q0 = tid; q0 < 16 * N4; q0 += 256 * 8) {
+			unsigned long long gr[8];
+			const unsigned long long* w[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const int q = q0 + 256 * i, r2 = q / N4, n = q - r2 * N4, b2 = row0 + r2;
+				const bool on = q < 16 * N4 && b2 < B;
+				w[i] = a.xch + ((size_t)(it & 1) * B + (on ? b2 : 0)) * N4 + (on ? n : 0);
+				gr[i] = (unsigned long long)(unsigned)(it + 1) << 32;
+				if (on) gr[i] = nnc_load_granule(w[i]);
+			}
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				unsigned spins = 0;
+				while ((unsigned)(gr[i] >> 32) != (unsigned)(it + 1)) {
+					if (*(volatile int*)&dead) break;
+					if (++spins > CLUSTER_SPIN_LIMIT) { dead = 1; nnc_store_agent(a.timeout_word, 0xd0000000u | (unsigned)it); break; }
+					NNC_SPIN_SLEEP();
+					gr[i] = nnc_load_granule(w[i]);
+				}
+				const int q = q0 + 256 * i, r2 = q / N4, n = q - r2 * N4;
+				if (q < 16 * N4) dgtile[r2 * PITCH + n] = __uint_as_float((unsigned)gr[i]);
+			}
+		}
+		if (NT > N4) for (int q = tid; q < 16 * (NT - N4); q += 256) { const int r2 = q / (NT - N4), n = N4 + q - r2 * (NT - N4); dgtile[r2 * PITCH + n] = 0.f; }
+		__syncthreads();
+		float acc[16];
+#pragma unroll
+		for (int r2 = 0; r2 < 16; r2++) acc[r2] = 0.f;
+#pragma unroll
+		for (int i = 0; i < KPT; i += 4) {
+#pragma unroll
+			for (int r2 = 0; r2 < 16; r2++) {
+				const float4 gv = *(const float4*)&dgtile[r2 * PITCH + nq * KPT + i];
+				acc[r2] += rreg[i] * gv.x + rreg[i + 1] * gv.y + rreg[i + 2] * gv.z + rreg[i + 3] * gv.w;
+			}
+		}
+#pragma unroll
+		for (int r2 = 0; r2 < 16; r2++) part[nq][r2][u] = acc[r2];
+		__syncthreads();
+		if (mine) {
+			float v = 0.f;
+#pragma unroll
+			for (int q = 0; q < 16; q++) v += part[q][rr][u];
+			dh = t < len ? v : dh + v; // (past the end the gate gradients were zero: v == 0, the state gradient goes on unchanged)
+		}
+		__syncthreads();
+	}
+	if (mine) { if (a.dhx) a.dhx[e] = dh; if (a.dcx) a.dcx[e] = dc; }
 }
 
 // One step of one pseudo-layer: the four gates' recurrent products + the gate arithmetic.  direct = no projection (hout is the next state, P == H).
@@ -336,10 +564,13 @@ static int _lstm_forw(EXEC_ARGS_L)
 	MarkerScope marker(cmd.cmd);
 	hipStream_t stream = stream_of(stream_context);
 	const int DP = g.D * g.P;
-	// scratch: [ lengths | x, y in sequence-major order (batch-first tensors) | two layer outputs | the input half of the gates | R k-major | W_p k-major | state x 2 x 2 | o tanh(c) ]
+	// scratch: [ lengths | x, y in sequence-major order (batch-first tensors) | two layer outputs | the input half of the gates | R k-major | W_p k-major | state x 2 x 2 | o tanh(c) | the persistent kernel's state words ]
 	const size_t n_len = (sizeof(int) * g.B + 255) & ~(size_t)255, n_xs = g.batch_first ? al(TB * g.I) : 0, n_ys = g.batch_first ? al(TB * DP) : 0, n_lay = g.L > 1 ? al(TB * DP) : 0;
 	const size_t n_gx = al(TB * 4 * g.H), n_rt = al((size_t)4 * g.H * g.P), n_wpt = g.proj ? al((size_t)g.P * g.H) : 0, n_h = al((size_t)g.B * g.P), n_c = al(g.BH()), n_raw = g.proj ? al(g.BH()) : 0;
-	WorkspaceScope ws(stream_context, n_len + n_xs + n_ys + 2 * n_lay + n_gx + n_rt + n_wpt + 2 * n_h + 2 * n_c + n_raw, lstm_inner_bytes(g));
+	// the whole sequence in one launch: every workgroup must be resident at once (they wait for each other) -- the grid stays within the CU count
+	const bool persistent = tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 512 && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
+	const size_t n_xch = persistent ? (sizeof(unsigned long long) * 2 * g.B * g.H + 255) & ~(size_t)255 : 0;
+	WorkspaceScope ws(stream_context, n_len + n_xs + n_ys + 2 * n_lay + n_gx + n_rt + n_wpt + 2 * n_h + 2 * n_c + n_raw + n_xch, lstm_inner_bytes(g));
 	char* at = (char*)ws.prefix();
 	if (!at) return CCV_NNC_EXEC_OOM;
 	int* const lens = xs ? (int*)at : 0; at += n_len;
@@ -351,7 +582,10 @@ static int _lstm_forw(EXEC_ARGS_L)
 	float* const wpt = (float*)at; at += n_wpt;
 	float* const hs[2] = { (float*)at, (float*)(at + n_h) }; at += 2 * n_h;
 	float* const cs[2] = { (float*)at, (float*)(at + n_c) }; at += 2 * n_c;
-	float* const hraw = (float*)at;
+	float* const hraw = (float*)at; at += n_raw;
+	unsigned long long* const xch = (unsigned long long*)at;
+	unsigned* timeout_word = 0;
+	if (persistent) { unsigned epoch; if (!cluster_sync_of(stream_context, 0, &epoch, &timeout_word)) return CCV_NNC_EXEC_OOM; }
 	if (xs) { const int ret = lstm_lens(xs, g, lens, stream); if (ret != CCV_NNC_EXEC_SUCCESS) return ret; }
 	const float* xin = x->data.f32;
 	if (g.batch_first) { hipLaunchKernelGGL(lstm_swap01_kernel, dim3(blocks_of(TB * g.I)), dim3(256), 0, stream, x->data.f32, xseq, g.B, g.T, g.I); xin = xseq; }
@@ -359,7 +593,6 @@ static int _lstm_forw(EXEC_ARGS_L)
 	const lstm_view_t view = lstm_view(g, rsv);
 	const float* const W = w->data.f32;
 	const dim3 step_grid((g.H + 63) / 64, (g.B + LS_ROWS - 1) / LS_ROWS), proj_grid((g.P + 63) / 64, (g.B + LS_ROWS - 1) / LS_ROWS);
-	note_kernel("lstm_forw");
 	for (int l = 0; l < g.L; l++) {
 		const int in = g.in_of(l);
 		float* const yl = l == g.L - 1 ? (g.batch_first ? yseq : y->data.f32) : lay[l & 1];
@@ -375,12 +608,25 @@ static int _lstm_forw(EXEC_ARGS_L)
 			const GemmOut out = { gx, 4L * g.H, 1, 0, 1.f, 0, 0 };
 			const int ret = gemm_strided<float>("lstm_gx", A, Bm, out, 1, 0, 0, 0, 0, 0, stream_context);
 			if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
-			hipLaunchKernelGGL(lstm_transpose_kernel, dim3(blocks_of((size_t)4 * g.H * g.P)), dim3(256), 0, stream, Rc, rt, 4 * g.H, g.P);
+			if (!persistent) hipLaunchKernelGGL(lstm_transpose_kernel, dim3(blocks_of((size_t)4 * g.H * g.P)), dim3(256), 0, stream, Rc, rt, 4 * g.H, g.P);
 			if (g.proj) hipLaunchKernelGGL(lstm_transpose_kernel, dim3(blocks_of((size_t)g.P * g.H)), dim3(256), 0, stream, Wp, wpt, g.P, g.H);
 			if (hx) HIP_ENFORCE(hipMemcpyAsync(hs[0], hx->data.f32 + (size_t)p * g.B * g.P, sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
 			else HIP_ENFORCE(hipMemsetAsync(hs[0], 0, sizeof(float) * g.B * g.P, stream));
 			if (cx) HIP_ENFORCE(hipMemcpyAsync(cs[0], cx->data.f32 + (size_t)p * g.BH(), sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
 			else HIP_ENFORCE(hipMemsetAsync(cs[0], 0, sizeof(float) * g.BH(), stream));
+			if (persistent) { // one launch for the whole sequence (lstm_seq_forw_kernel)
+				HIP_ENFORCE(hipMemsetAsync(xch, 0, n_xch, stream));
+				const lstm_seq_t a = { gx, Rc, bw, hx ? hx->data.f32 + (size_t)p * g.BH() : 0, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, yl + (size_t)d * g.P, hy ? hy->data.f32 + (size_t)p * g.BH() : 0, cy ? cy->data.f32 + (size_t)p * g.BH() : 0,
+					rsv, xch, lens, timeout_word, g.T, g.B, g.H, d, DP, g.S, rsv ? g.slot(p, 0, 0) : 0, rsv && g.T > 1 ? g.cslot(p, 0) : 0 };
+				const dim3 seq_grid((g.H + 15) / 16, (g.B + 15) / 16);
+				if (g.H <= 128) NNC_LAUNCH_CONCURRENT(lstm_seq_forw_kernel<32>, seq_grid, dim3(256), LSTM_SEQ_LDS(32), stream, a);
+				else if (g.H <= 256) NNC_LAUNCH_CONCURRENT(lstm_seq_forw_kernel<64>, seq_grid, dim3(256), LSTM_SEQ_LDS(64), stream, a);
+				else NNC_LAUNCH_CONCURRENT(lstm_seq_forw_kernel<128>, seq_grid, dim3(256), LSTM_SEQ_LDS(128), stream, a);
+				HIP_ENFORCE(hipGetLastError());
+				note_kernel("lstm_seq_forw");
+				continue;
+			}
+			note_kernel("lstm_step_forw");
 			for (int s = 0; s < g.T; s++) {
 				const int t = d ? g.T - 1 - s : s;
 				float* const yt = yl + (size_t)t * g.B * DP + (size_t)d * g.P;
@@ -435,7 +681,9 @@ static int _lstm_back(EXEC_ARGS_L)
 	const size_t n_len = (sizeof(int) * g.B + 255) & ~(size_t)255, n_xs = g.batch_first ? al(TB * g.I) : 0, n_dys = g.batch_first ? al(TB * DP) : 0, n_lay = g.L > 1 ? al(TB * DP) : 0;
 	const size_t n_dg = al(TB * 4 * g.H), n_in = g.L > 1 ? al(TB * in_max) : 0, n_hp = al(TB * g.P), n_h = al((size_t)g.B * g.P), n_c = al(g.BH());
 	const size_t n_dhp = g.proj ? al(TB * g.P) : 0, n_draw = g.proj ? al(g.BH()) : 0, n_raw = g.proj ? al(TB * g.H) : 0;
-	WorkspaceScope ws(stream_context, n_len + 2 * n_xs + n_dys + 2 * n_lay + n_dg + n_in + n_hp + 2 * n_h + 2 * n_c + n_dhp + n_draw + n_raw, lstm_inner_bytes(g));
+	const bool persistent = tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 4 * LSTM_SEQ_BACK_KPT && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
+	const size_t n_xch = persistent ? (sizeof(unsigned long long) * 2 * g.B * 4 * g.H + 255) & ~(size_t)255 : 0;
+	WorkspaceScope ws(stream_context, n_len + 2 * n_xs + n_dys + 2 * n_lay + n_dg + n_in + n_hp + 2 * n_h + 2 * n_c + n_dhp + n_draw + n_raw + n_xch, lstm_inner_bytes(g));
 	char* at = (char*)ws.prefix();
 	if (!at) return CCV_NNC_EXEC_OOM;
 	int* const lens = xs ? (int*)at : 0; at += n_len;
@@ -451,7 +699,10 @@ static int _lstm_back(EXEC_ARGS_L)
 	float* const czero = (float*)at; at += n_c; // the cell state a sequence starts from when the host passes none
 	float* const dhp = (float*)at; at += n_dhp;
 	float* const draw = (float*)at; at += n_draw;
-	float* const raw = (float*)at;
+	float* const raw = (float*)at; at += n_raw;
+	unsigned long long* const xch = (unsigned long long*)at;
+	unsigned* timeout_word = 0;
+	if (persistent) { unsigned epoch; if (!cluster_sync_of(stream_context, 0, &epoch, &timeout_word)) return CCV_NNC_EXEC_OOM; }
 	if (xs) { const int ret = lstm_lens(xs, g, lens, stream); if (ret != CCV_NNC_EXEC_SUCCESS) return ret; }
 	if (!cx) HIP_ENFORCE(hipMemsetAsync(czero, 0, sizeof(float) * g.BH(), stream));
 	const float* x0 = x ? x->data.f32 : 0;
@@ -467,7 +718,6 @@ static int _lstm_back(EXEC_ARGS_L)
 	const float* const W = w->data.f32;
 	float* const DW = dw ? dw->data.f32 : 0;
 	const dim3 rec_grid((g.P + 63) / 64, (g.B + LS_ROWS - 1) / LS_ROWS), raw_grid((g.H + 63) / 64, (g.B + LS_ROWS - 1) / LS_ROWS);
-	note_kernel("lstm_back");
 	for (int l = g.L - 1; l >= 0; l--) {
 		const int in = g.in_of(l);
 		const float* const dyl = l == g.L - 1 ? dytop : lay[l & 1];
@@ -484,6 +734,13 @@ static int _lstm_back(EXEC_ARGS_L)
 			else HIP_ENFORCE(hipMemsetAsync(dh[g.T & 1], 0, sizeof(float) * g.B * g.P, stream));
 			if (dcy) HIP_ENFORCE(hipMemcpyAsync(dc, dcy->data.f32 + (size_t)p * g.BH(), sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
 			else HIP_ENFORCE(hipMemsetAsync(dc, 0, sizeof(float) * g.BH(), stream));
+			if (persistent) { // one launch for the whole sequence (lstm_seq_back_kernel)
+				HIP_ENFORCE(hipMemsetAsync(xch, 0, n_xch, stream));
+				const lstm_seq_back_t a = { Rc, rsv, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, dyl + (size_t)d * g.P, dhy ? dhy->data.f32 + (size_t)p * g.BH() : 0, dcy ? dcy->data.f32 + (size_t)p * g.BH() : 0,
+					dG, dhx ? dhx->data.f32 + (size_t)p * g.BH() : 0, dcx ? dcx->data.f32 + (size_t)p * g.BH() : 0, xch, lens, timeout_word, g.T, g.B, g.H, d, DP, g.S, g.slot(p, 0, 0), g.T > 1 ? g.cslot(p, 0) : 0 };
+				NNC_LAUNCH_CONCURRENT(lstm_seq_back_kernel, dim3((g.H + 15) / 16, (g.B + 15) / 16), dim3(256), LSTM_SEQ_BACK_LDS, stream, a);
+				HIP_ENFORCE(hipGetLastError());
+			} else
 			for (int s = g.T - 1; s >= 0; s--) {
 				const int t = d ? g.T - 1 - s : s;
 				const float* const dyt = dyl + (size_t)t * g.B * DP + (size_t)d * g.P;
@@ -501,8 +758,8 @@ static int _lstm_back(EXEC_ARGS_L)
 				hipLaunchKernelGGL(lstm_rowmat_kernel<2>, rec_grid, dim3(256), 0, stream, (const float*)dgt, 4 * g.H, Rc, g.P, 4 * g.H, g.P, g.B, dh[s & 1], g.P, dh_in, (float*)0, 0, (float*)0, 0, (const int*)lens, t);
 			}
 			HIP_ENFORCE(hipGetLastError());
-			if (dhx) HIP_ENFORCE(hipMemcpyAsync(dhx->data.f32 + (size_t)p * g.B * g.P, dh[0], sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
-			if (dcx) HIP_ENFORCE(hipMemcpyAsync(dcx->data.f32 + (size_t)p * g.BH(), dc, sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
+			if (!persistent && dhx) HIP_ENFORCE(hipMemcpyAsync(dhx->data.f32 + (size_t)p * g.B * g.P, dh[0], sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
+			if (!persistent && dcx) HIP_ENFORCE(hipMemcpyAsync(dcx->data.f32 + (size_t)p * g.BH(), dc, sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
 			int ret;
 			{ // dX (+)= dG W: [T B][4H] x [4H][in]; the second direction adds to the first
 				const MatOperand A = { dG, 4L * g.H, 1, (int)TB, 4 * g.H };
@@ -542,6 +799,7 @@ static int _lstm_back(EXEC_ARGS_L)
 	}
 	if (g.batch_first) hipLaunchKernelGGL(lstm_swap01_kernel, dim3(blocks_of(TB * g.I)), dim3(256), 0, stream, (const float*)dxseq, dx->data.f32, g.T, g.B, g.I);
 	HIP_ENFORCE(hipGetLastError());
+	note_kernel(persistent ? "lstm_seq_back" : "lstm_step_back");
 	return CCV_NNC_EXEC_SUCCESS;
 }
 

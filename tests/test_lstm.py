@@ -71,7 +71,15 @@ CASES = [
 ]
 
 
-def _run(lib, case, dtype=F, tol=1e-4):
+def _run(lib, case, dtype=F, tol=1e-4, persistent=1):
+    lib.tune_set("LSTM_PERSISTENT", persistent)
+    try:
+        _run_inner(lib, case, dtype, tol, persistent)
+    finally:
+        lib.tune_set("LSTM_PERSISTENT", 1)
+
+
+def _run_inner(lib, case, dtype, tol, persistent):
     T, B, I, H, P, L, bias, batch_first, bidir, lens, dropout, states, two_d = case
     D = 2 if bidir else 1
     Pe = P or H
@@ -108,6 +116,8 @@ def _run(lib, case, dtype=F, tol=1e-4):
     cy_t = gpu(np.zeros((L * D, B, H), dtype)) if states else None
     r_t = gpu(np.full((rrows, H), np.nan, dtype))
     assert lib.cmd_exec(fcmd, nnc.NO_HINT, 0, [x_t, xs_t, hx_t, cx_t, w_t], [y_t, hy_t, cy_t, r_t]) == 0
+    if dtype == F:  # which forward ran: the whole sequence in one launch, or a launch per step (projection: always per step)
+        assert lib.dll.nnc_mi355x_last_kernel_name().decode() == ("lstm_seq_forw" if persistent and not (P and P != H) else "lstm_step_forw")
     r = r_t.numpy().astype(np.float64).reshape(-1)
     masks = None
     if dropout > 0:  # the scales the command drew: plane S - 1 of every (pseudo-layer, step) of the reserved space (cmd_lstm.cpp's header)
@@ -147,6 +157,8 @@ def _run(lib, case, dtype=F, tol=1e-4):
     dcx_t = gpu(np.zeros((L * D, B, H), dtype)) if states else None
     ins = [gpu(lay(gy)), gpu(ghy), gpu(gcy), None, x_t, xs_t, hx_t, cx_t, w_t, y_t, hy_t, cy_t, r_t]
     assert lib.cmd_exec(bcmd, nnc.NO_HINT, 0, ins, [dx_t, None, dhx_t, dcx_t, dw_t]) == 0
+    if dtype == F:
+        assert lib.dll.nnc_mi355x_last_kernel_name().decode() == ("lstm_seq_back" if persistent and not (P and P != H) and H <= 128 else "lstm_step_back")
     dx, dhx, dcx, dw = oracle.backward(gy.astype(np.float64), tape, ghy, gcy)
     close(unlay(dx_t.numpy()), dx, tol)
     close(dw_t.numpy().reshape(-1), dw, tol)
@@ -155,9 +167,14 @@ def _run(lib, case, dtype=F, tol=1e-4):
         close(dcx_t.numpy(), dcx, tol)
 
 
+@pytest.mark.parametrize("persistent", [1, 0], ids=["one-launch", "per-step"])
 @pytest.mark.parametrize("case", CASES, ids=[str(c[:9]) + ("+lens" if c[9] else "") + ("+drop" if c[10] else "") for c in CASES])
-def test_lstm_forward_backward(backend, case):
-    _run(backend, case)
+def test_lstm_forward_backward(backend, case, persistent):
+    """Both forms of the forward pass (tuning key LSTM_PERSISTENT): the whole sequence of a pseudo-layer in one launch -- its slice of R in registers, the state handed
+    between workgroups through tagged words -- and a launch per step; the backward command reads the reserved space either of them wrote."""
+    if persistent and case[4] and case[4] != case[3]:
+        pytest.skip("a projection always takes the per-step form")
+    _run(backend, case, persistent=persistent)
 
 
 def test_lstm_in_half_precision(backend):
