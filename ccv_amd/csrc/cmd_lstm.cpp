@@ -224,21 +224,22 @@ __global__ void __launch_bounds__(256) lstm_seq_forw_kernel(const lstm_seq_t a)
 	if (mine) { if (a.hy) a.hy[e] = hst; if (a.cy) a.cy[e] = cst; }
 }
 
-// The backward pass of one pseudo-layer's whole sequence in ONE launch (hidden size <= 128): the same ownership as lstm_seq_forw_kernel.  Per step, thread (row, unit)
+// The backward pass of one pseudo-layer's whole sequence in ONE launch (hidden size <= 128 today: NCH = 1): the same ownership as lstm_seq_forw_kernel.  Per step, thread (row, unit)
 // turns its state gradients (dh, dc: registers for the whole sequence) into the four gate gradients, writes them to dG (the contractions after the loop read them)
 // and publishes them as tagged words; the tile's workgroups gather the tile's dG [16][4H] into LDS, and every workgroup forms dh' = dG R for ITS 16 units -- lane
-// (unit, slice) holds the H / 4 coefficients R[n][unit] of its slice of n in registers, the 16 slices meet in LDS.
+// (unit, slice) holds the H / 4 coefficients R[n][unit] of its slices of n in registers (32 columns of every 512-column chunk of dG that passes through LDS), the 16 slices meet in LDS.
 struct lstm_seq_back_t {
 	const float* r; const float* rsv; const float* cx; const float* dy; const float* dhy; const float* dcy;
 	float* dg; float* dhx; float* dcx; unsigned long long* xch; const int* lens; unsigned* timeout_word;
 	int T, B, H, dir, ldy, S;
 	size_t slot0, cslot0;
 };
-constexpr int LSTM_SEQ_BACK_KPT = 32; // H <= 128: 4H / 16 slices
-#define LSTM_SEQ_BACK_LDS (sizeof(float) * (16 * (16 * LSTM_SEQ_BACK_KPT + 4) + 16 * 16 * 17 + 4))
+constexpr int LSTM_SEQ_BACK_NC = 512; // gate-gradient columns staged in LDS at a time: 4H in NCH = ceil(H / 128) chunks
+#define LSTM_SEQ_BACK_LDS (sizeof(float) * (16 * (LSTM_SEQ_BACK_NC + 4) + 16 * 16 * 17 + 4))
+template <int NCH>
 __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_t a)
 {
-	constexpr int KPT = LSTM_SEQ_BACK_KPT, NT = 16 * KPT, PITCH = NT + 4;
+	constexpr int NC = LSTM_SEQ_BACK_NC, PITCH = NC + 4; // lane (unit, slice) takes 32 columns of every chunk: slice nq of chunk c = columns c * 512 + nq * 32 ..
 	HIP_DYNAMIC_SHARED(float, lds)
 	float* const dgtile = lds;                                            // [16][PITCH]
 	float (*const part)[16][17] = (float (*)[16][17])(lds + 16 * PITCH);  // [16 slices][16 rows][16 units]
@@ -246,9 +247,17 @@ __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_
 	const int tid = threadIdx.x, u = tid & 15, nq = tid >> 4;
 	const int H = a.H, B = a.B, N4 = 4 * H, j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
 	const size_t BH = (size_t)B * H;
-	float rreg[KPT];
+	float rreg[4][32]; // (chunk ch's 32 coefficients; only the first NCH rows are ever touched)
 #pragma unroll
-	for (int i = 0; i < KPT; i++) { const int n = nq * KPT + i; rreg[i] = n < N4 && j0 + u < H ? a.r[(size_t)n * H + j0 + u] : 0.f; }
+	for (int ch = 0; ch < NCH; ch++) {
+		const int ju = j0 + u < H ? j0 + u : H - 1;
+#pragma unroll
+		for (int i = 0; i < 32; i++) { // (clamped, unconditional loads off 32-bit offsets: a branch and a 64-bit address per coefficient spill)
+			const int n = ch * NC + nq * 32 + i;
+			const float v = a.r[(unsigned)((n < N4 ? n : N4 - 1) * H + ju)];
+			rreg[ch][i] = n < N4 && j0 + u < H ? v : 0.f;
+		}
+	}
 	const int rr = nq, b = row0 + rr, j = j0 + u; // (the same 16 x 16 split of the threads serves as (slice, unit) and as (row, unit))
 	const bool mine = b < B && j < H;
 	const size_t e = (size_t)b * H + j;
@@ -279,43 +288,53 @@ __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_
 				nnc_store_granule(a.xch + ((size_t)(it & 1) * B + b) * N4 + g * H + j, (unsigned)(it + 1), d4[g]);
 			}
 		}
-		for (int q0 = tid; q0 < 16 * N4; q0 += 256 * 8) {
-			unsigned long long gr[8];
-			const unsigned long long* w[8];
-#pragma unroll
-			for (int i = 0; i < 8; i++) {
-				const int q = q0 + 256 * i, r2 = q / N4, n = q - r2 * N4, b2 = row0 + r2;
-				const bool on = q < 16 * N4 && b2 < B;
-				w[i] = a.xch + ((size_t)(it & 1) * B + (on ? b2 : 0)) * N4 + (on ? n : 0);
-				gr[i] = (unsigned long long)(unsigned)(it + 1) << 32;
-				if (on) gr[i] = nnc_load_granule(w[i]);
-			}
-#pragma unroll
-			for (int i = 0; i < 8; i++) {
-				unsigned spins = 0;
-				while ((unsigned)(gr[i] >> 32) != (unsigned)(it + 1)) {
-					if (*(volatile int*)&dead) break;
-					if (++spins > CLUSTER_SPIN_LIMIT) { dead = 1; nnc_store_agent(a.timeout_word, 0xd0000000u | (unsigned)it); break; }
-					NNC_SPIN_SLEEP();
-					gr[i] = nnc_load_granule(w[i]);
-				}
-				const int q = q0 + 256 * i, r2 = q / N4, n = q - r2 * N4;
-				if (q < 16 * N4) dgtile[r2 * PITCH + n] = __uint_as_float((unsigned)gr[i]);
-			}
-		}
-		if (NT > N4) for (int q = tid; q < 16 * (NT - N4); q += 256) { const int r2 = q / (NT - N4), n = N4 + q - r2 * (NT - N4); dgtile[r2 * PITCH + n] = 0.f; }
-		__syncthreads();
 		float acc[16];
 #pragma unroll
 		for (int r2 = 0; r2 < 16; r2++) acc[r2] = 0.f;
+		auto chunk = [&](const int ch, const float (&rc)[32]) __attribute__((always_inline)) {
+			const int n0 = ch * NC, nn = N4 - n0 < NC ? N4 - n0 : NC; // this chunk's columns
+			if (ch > 0) __syncthreads();
+			__builtin_amdgcn_sched_barrier(0); // (one chunk's words at a time: hoisting the next chunk's loads over this one's arithmetic spills)
+#pragma unroll 1
+			for (int q0 = tid; q0 < 16 * NC; q0 += 256 * 8) { // (row = q / 512: shifts; eight words in flight per thread, not all 32 of the chunk: registers)
+				unsigned long long gr[8];
+				const unsigned long long* w[8];
 #pragma unroll
-		for (int i = 0; i < KPT; i += 4) {
+				for (int i = 0; i < 8; i++) {
+					const int q = q0 + 256 * i, r2 = q / NC, n = q - r2 * NC, b2 = row0 + r2;
+					const bool on = n < nn && b2 < B;
+					w[i] = a.xch + ((size_t)(it & 1) * B + (on ? b2 : 0)) * N4 + (on ? n0 + n : 0);
+					gr[i] = (unsigned long long)(unsigned)(it + 1) << 32; // (columns / rows past the end: "arrived", zero)
+					if (on) gr[i] = nnc_load_granule(w[i]);
+				}
 #pragma unroll
-			for (int r2 = 0; r2 < 16; r2++) {
-				const float4 gv = *(const float4*)&dgtile[r2 * PITCH + nq * KPT + i];
-				acc[r2] += rreg[i] * gv.x + rreg[i + 1] * gv.y + rreg[i + 2] * gv.z + rreg[i + 3] * gv.w;
+				for (int i = 0; i < 8; i++) {
+					unsigned spins = 0;
+					while ((unsigned)(gr[i] >> 32) != (unsigned)(it + 1)) {
+						if (*(volatile int*)&dead) break;
+						if (++spins > CLUSTER_SPIN_LIMIT) { dead = 1; nnc_store_agent(a.timeout_word, 0xd0000000u | (unsigned)it); break; }
+						NNC_SPIN_SLEEP();
+						gr[i] = nnc_load_granule(w[i]);
+					}
+					const int q = q0 + 256 * i, r2 = q / NC, n = q - r2 * NC;
+					dgtile[r2 * PITCH + n] = __uint_as_float((unsigned)gr[i]);
+				}
 			}
-		}
+			__syncthreads();
+#pragma unroll
+			for (int i = 0; i < 32; i += 4) {
+#pragma unroll
+				for (int r2 = 0; r2 < 16; r2++) {
+					const float4 gv = *(const float4*)&dgtile[r2 * PITCH + nq * 32 + i];
+					acc[r2] += rc[i] * gv.x + rc[i + 1] * gv.y + rc[i + 2] * gv.z + rc[i + 3] * gv.w;
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		};
+		chunk(0, rreg[0]);
+		if (NCH > 1) chunk(1, rreg[1]);
+		if (NCH > 2) chunk(2, rreg[2]);
+		if (NCH > 3) chunk(3, rreg[3]);
 #pragma unroll
 		for (int r2 = 0; r2 < 16; r2++) part[nq][r2][u] = acc[r2];
 		__syncthreads();
@@ -681,7 +700,7 @@ static int _lstm_back(EXEC_ARGS_L)
 	const size_t n_len = (sizeof(int) * g.B + 255) & ~(size_t)255, n_xs = g.batch_first ? al(TB * g.I) : 0, n_dys = g.batch_first ? al(TB * DP) : 0, n_lay = g.L > 1 ? al(TB * DP) : 0;
 	const size_t n_dg = al(TB * 4 * g.H), n_in = g.L > 1 ? al(TB * in_max) : 0, n_hp = al(TB * g.P), n_h = al((size_t)g.B * g.P), n_c = al(g.BH());
 	const size_t n_dhp = g.proj ? al(TB * g.P) : 0, n_draw = g.proj ? al(g.BH()) : 0, n_raw = g.proj ? al(TB * g.H) : 0;
-	const bool persistent = tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 4 * LSTM_SEQ_BACK_KPT && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
+	const bool persistent = tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 128 /* (the kernel takes 4H in chunks of 512 columns, but hipcc spills its registers from the second chunk on: wider layers go step by step) */ && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
 	const size_t n_xch = persistent ? (sizeof(unsigned long long) * 2 * g.B * 4 * g.H + 255) & ~(size_t)255 : 0;
 	WorkspaceScope ws(stream_context, n_len + 2 * n_xs + n_dys + 2 * n_lay + n_dg + n_in + n_hp + 2 * n_h + 2 * n_c + n_dhp + n_draw + n_raw + n_xch, lstm_inner_bytes(g));
 	char* at = (char*)ws.prefix();
@@ -738,7 +757,8 @@ static int _lstm_back(EXEC_ARGS_L)
 				HIP_ENFORCE(hipMemsetAsync(xch, 0, n_xch, stream));
 				const lstm_seq_back_t a = { Rc, rsv, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, dyl + (size_t)d * g.P, dhy ? dhy->data.f32 + (size_t)p * g.BH() : 0, dcy ? dcy->data.f32 + (size_t)p * g.BH() : 0,
 					dG, dhx ? dhx->data.f32 + (size_t)p * g.BH() : 0, dcx ? dcx->data.f32 + (size_t)p * g.BH() : 0, xch, lens, timeout_word, g.T, g.B, g.H, d, DP, g.S, g.slot(p, 0, 0), g.T > 1 ? g.cslot(p, 0) : 0 };
-				NNC_LAUNCH_CONCURRENT(lstm_seq_back_kernel, dim3((g.H + 15) / 16, (g.B + 15) / 16), dim3(256), LSTM_SEQ_BACK_LDS, stream, a);
+				const dim3 seq_grid((g.H + 15) / 16, (g.B + 15) / 16);
+				NNC_LAUNCH_CONCURRENT(lstm_seq_back_kernel<1>, seq_grid, dim3(256), LSTM_SEQ_BACK_LDS, stream, a);
 				HIP_ENFORCE(hipGetLastError());
 			} else
 			for (int s = g.T - 1; s >= 0; s--) {
@@ -755,6 +775,13 @@ static int _lstm_back(EXEC_ARGS_L)
 				} else
 					hipLaunchKernelGGL(lstm_step_back_kernel, dim3(blocks_of(g.BH())), dim3(256), 0, stream, rsv + g.slot(p, s, 0), cprev, dh_in, dyt, DP, dc, dgt, (const int*)lens, t, g.B, g.H);
 				// the state gradient the step before receives: dG R (+ this one's own where the step was past the end)
+				if (!lens && g.H >= 256) { // wide layers, every sequence full length: a [B][4H] x [4H][P] contraction worth the matrix cores (the lane-per-column kernel walks 4H terms one after the other)
+					const MatOperand A = { dgt, 4L * g.H, 1, g.B, 4 * g.H };
+					const MatOperand Bm = { Rc, 1, g.P, g.P, 4 * g.H };
+					const GemmOut out = { dh[s & 1], g.P, 1, 0, 1.f, 0, 0 };
+					const int ret = gemm_strided<float>("lstm_dh", A, Bm, out, 1, 0, 0, 0, 0, 0, stream_context);
+					if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
+				} else
 				hipLaunchKernelGGL(lstm_rowmat_kernel<2>, rec_grid, dim3(256), 0, stream, (const float*)dgt, 4 * g.H, Rc, g.P, 4 * g.H, g.P, g.B, dh[s & 1], g.P, dh_in, (float*)0, 0, (float*)0, 0, (const int*)lens, t);
 			}
 			HIP_ENFORCE(hipGetLastError());

@@ -68,6 +68,8 @@ CASES = [
     (5,  3,  6, 12,  8, 2, 1, 1, 1, [2, 5, 4],             0.3, True,  False),   # everything at once
     (3,  2,  5,  8,  0, 1, 0, 0, 0, None,                  0.0, True,  False),   # no bias
     (3, 20, 70, 80,  0, 1, 1, 0, 0, [3, 1, 2] * 6 + [3, 2], 0.0, True, False),   # two tiles of hidden units, of batch rows and of the recurrent reduction
+    (3,  3, 10, 144, 0, 1, 1, 0, 1, [3, 2, 1],             0.0, True,  False),   # hidden size > 128: two register chunks per lane in the one-launch kernels
+    (2,  2,  5, 272, 0, 1, 1, 0, 0, None,                  0.0, True,  False),   # > 256: the widest forward kernel, three chunks backward
 ]
 
 
