@@ -46,6 +46,7 @@ done
 #     bench.py --via-host runs it on the MI355X, tests/test_via_host.py the emulator build at a small size)
 $CC $TFLAGS $ROOT/tools/host_vgg_bench.c -o $OUT/host_vgg_bench.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
 $CC $TFLAGS $ROOT/tools/host_resnet_bench.c -o $OUT/host_resnet_bench.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
+$CC $TFLAGS $ROOT/tools/host_lstm_check.c -o $OUT/host_lstm_check.gpu -L$OUT -lccv_host_gpu -L$ROOT/ccv_amd/lib -lnnc_mi355x $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../ccv_amd/lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib &
 # the same harness on the reference's OWN CPU backends (libccv_ref.so, no GPU backend linked): the other side of the whole-network parity tests
 [ -f $OUT/libccv_ref.so ] && $CC -O2 -fopenmp -I$REF/lib -DHAVE_SSE2 -DHAVE_PTHREAD -DUSE_OPENMP -Wno-everything -DHOST_BENCH_CPU $ROOT/tools/host_resnet_bench.c -o $OUT/host_resnet_bench.cpu -L$OUT -lccv_ref $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
 # the GPU data pipeline bound into the reference's dataframe (integration/nnc_mi355x_dataframe.c: host-side glue a maintainer compiles into the host) + its test client
@@ -54,6 +55,7 @@ $CC $DFLAGS $ROOT/tools/host_dataframe_test.c $ROOT/integration/nnc_mi355x_dataf
 if [ -f $OUT/libccv_host_emu.so ]; then
   $CC $DFLAGS $ROOT/tools/host_dataframe_test.c $ROOT/integration/nnc_mi355x_dataframe.c -o $OUT/host_dataframe_test.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
   $CC $TFLAGS $ROOT/tools/host_resnet_bench.c -o $OUT/host_resnet_bench.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
+  $CC $TFLAGS $ROOT/tools/host_lstm_check.c -o $OUT/host_lstm_check.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
   $CC $TFLAGS $ROOT/tools/host_vgg_bench.c -o $OUT/host_vgg_bench.emu -L$OUT -lccv_host_emu -lnnc_mi355x_emu $LIBS -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib/llvm/lib &
 fi
 wait
