@@ -105,8 +105,8 @@ __device__ __forceinline__ void lstm_rows_times(const float* const a, const int 
 
 // ---- the whole sequence of one pseudo-layer in ONE launch (TUNE_LSTM_PERSISTENT; no projection, hidden size <= 512, the grid within the CU count) ----
 // A workgroup owns 16 hidden units (their 64 gate columns) of a 16-row batch tile for all T steps.  Its slice of R -- 64 columns x P -- never leaves the
-// register file: lane c of wave q holds column c's P / 4 coefficients of reduction quarter q.  Per step: the tile's state h' [16][P] arrives in LDS, every
-// thread forms its 16 partial sums, the four quarters meet in LDS, thread (row, unit) adds the input half, does the gate arithmetic, keeps c in a register and
+// register file, as the B fragments of v_mfma_f32_16x16x4_f32: wave q holds gate q's 16 columns, P / 4 registers per lane.  Per step: the tile's state h' [16][P] arrives in LDS, every
+// wave forms its gate's 16 x 16 block with P / 4 matrix instructions (the A fragment one LDS word per lane and instruction), the four gates meet in LDS, thread (row, unit) adds the input half, does the gate arithmetic, keeps c in a register and
 // PUBLISHES h: one 8-byte {step tag, value} word per element written with one agent-scope store -- the data is the flag (isa.h) --, which the tile's other
 // workgroups poll while they fill their LDS image for the next step.  Two tag-parity planes suffice: a workgroup can only publish step s + 2 after it has read
 // every word of step s + 1, whose writers had all finished reading step s.  The words are zeroed before the launch (tags start at 1).  A poll that gives up
@@ -129,12 +129,12 @@ __global__ void __launch_bounds__(256) lstm_seq_forw_kernel(const lstm_seq_t a)
 	const int tid = threadIdx.x, c = tid & 63, kq = tid >> 6;
 	const int H = a.H, B = a.B, j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
 	const size_t BH = (size_t)B * H;
-	float rreg[KPT];
+	float rreg[KPT]; // wave kq = gate kq: the B fragments of v_mfma_f32_16x16x4_f32 -- lane (unit = l & 15, k = 4 kk + (l >> 4)) -- of R_gate[j0 .. j0 + 15][0 .. P)
 	{
-		const int n = (c >> 4) * H + j0 + (c & 15);
+		const int n = kq * H + j0 + (c & 15);
 		const bool on = j0 + (c & 15) < H;
 #pragma unroll
-		for (int i = 0; i < KPT; i++) { const int k = kq * KPT + i; rreg[i] = on && k < H ? a.r[(size_t)n * H + k] : 0.f; }
+		for (int i = 0; i < KPT; i++) { const int k = 4 * i + (c >> 4); rreg[i] = on && k < H ? a.r[(size_t)n * H + k] : 0.f; }
 	}
 	const int rr = tid >> 4, u = tid & 15, b = row0 + rr, j = j0 + u;
 	const bool mine = b < B && j < H;
@@ -182,19 +182,12 @@ __global__ void __launch_bounds__(256) lstm_seq_forw_kernel(const lstm_seq_t a)
 		}
 		if (KT > H) for (int q = tid; q < 16 * (KT - H); q += 256) { const int r2 = q / (KT - H), k = H + q - r2 * (KT - H); htile[r2 * PITCH + k] = 0.f; }
 		__syncthreads();
-		float acc[16];
+		// this wave's gate for the tile's 16 rows x the workgroup's 16 units on the matrix cores: the A fragment -- lane (row = l & 15, k = 4 kk + (l >> 4)) -- out of LDS
+		floatx4 acc = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-		for (int r2 = 0; r2 < 16; r2++) acc[r2] = 0.f;
+		for (int i = 0; i < KPT; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(htile[(c & 15) * PITCH + 4 * i + (c >> 4)], rreg[i], acc, 0, 0, 0);
 #pragma unroll
-		for (int i = 0; i < KPT; i += 4) {
-#pragma unroll
-			for (int r2 = 0; r2 < 16; r2++) {
-				const float4 hv = *(const float4*)&htile[r2 * PITCH + kq * KPT + i];
-				acc[r2] += rreg[i] * hv.x + rreg[i + 1] * hv.y + rreg[i + 2] * hv.z + rreg[i + 3] * hv.w;
-			}
-		}
-#pragma unroll
-		for (int r2 = 0; r2 < 16; r2++) part[kq][r2][c] = acc[r2];
+		for (int i = 0; i < 4; i++) part[kq][4 * (c >> 4) + i][c & 15] = acc[i]; // (D: rows 4 (l >> 4) + i, column l & 15)
 		__syncthreads();
 		if (mine) {
 			float* const gates = a.rsv ? a.rsv + a.slot0 + (size_t)s * a.S * BH : 0;
@@ -202,7 +195,7 @@ __global__ void __launch_bounds__(256) lstm_seq_forw_kernel(const lstm_seq_t a)
 			if (t < len) {
 				float pre[4];
 #pragma unroll
-				for (int g = 0; g < 4; g++) pre[g] = ((part[0][rr][g * 16 + u] + part[1][rr][g * 16 + u]) + (part[2][rr][g * 16 + u] + part[3][rr][g * 16 + u])) + gin[g] + bias[g];
+				for (int g = 0; g < 4; g++) pre[g] = part[g][rr][u] + gin[g] + bias[g];
 				const float i = lstm_sigmoid(pre[0]), f = lstm_sigmoid(pre[1]), g = tanhf(pre[2]), o = lstm_sigmoid(pre[3]);
 				cst = f * cst + i * g;
 				const float tc = tanhf(cst);
@@ -224,10 +217,10 @@ __global__ void __launch_bounds__(256) lstm_seq_forw_kernel(const lstm_seq_t a)
 	if (mine) { if (a.hy) a.hy[e] = hst; if (a.cy) a.cy[e] = cst; }
 }
 
-// The backward pass of one pseudo-layer's whole sequence in ONE launch (hidden size <= 128 today: NCH = 1): the same ownership as lstm_seq_forw_kernel.  Per step, thread (row, unit)
+// The backward pass of one pseudo-layer's whole sequence in ONE launch (hidden size <= 512: NCH = ceil(H / 128) chunks of dG through LDS per step): the same ownership as lstm_seq_forw_kernel.  Per step, thread (row, unit)
 // turns its state gradients (dh, dc: registers for the whole sequence) into the four gate gradients, writes them to dG (the contractions after the loop read them)
-// and publishes them as tagged words; the tile's workgroups gather the tile's dG [16][4H] into LDS, and every workgroup forms dh' = dG R for ITS 16 units -- lane
-// (unit, slice) holds the H / 4 coefficients R[n][unit] of its slices of n in registers (32 columns of every 512-column chunk of dG that passes through LDS), the 16 slices meet in LDS.
+// and publishes them as tagged words; the tile's workgroups gather the tile's dG [16][4H] into LDS, and every workgroup forms dh' = dG R for ITS 16 units on the matrix cores --
+// wave w reduces columns w * 128 .. + 127 of every 512-column chunk of dG that passes through LDS, its R coefficients (the B fragments of v_mfma_f32_16x16x4_f32: H / 4 registers per lane) resident, the four partial blocks meet in LDS.
 struct lstm_seq_back_t {
 	const float* r; const float* rsv; const float* cx; const float* dy; const float* dhy; const float* dcy;
 	float* dg; float* dhx; float* dcx; unsigned long long* xch; const int* lens; unsigned* timeout_word;
@@ -247,15 +240,16 @@ __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_
 	const int tid = threadIdx.x, u = tid & 15, nq = tid >> 4;
 	const int H = a.H, B = a.B, N4 = 4 * H, j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
 	const size_t BH = (size_t)B * H;
-	float rreg[4][32]; // (chunk ch's 32 coefficients; only the first NCH rows are ever touched)
+	const int wq = tid >> 6, l = tid & 63; // wave wq reduces columns wq * 128 .. + 127 of every 512-column chunk on the matrix cores
+	float rreg[NCH][32]; // the B fragments: lane (unit = l & 15, n = 4 kk + (l >> 4)) of R[chunk's columns of this wave][j0 .. j0 + 15]
 #pragma unroll
 	for (int ch = 0; ch < NCH; ch++) {
-		const int ju = j0 + u < H ? j0 + u : H - 1;
+		const int ju = j0 + (l & 15) < H ? j0 + (l & 15) : H - 1;
 #pragma unroll
-		for (int i = 0; i < 32; i++) { // (clamped, unconditional loads off 32-bit offsets: a branch and a 64-bit address per coefficient spill)
-			const int n = ch * NC + nq * 32 + i;
+		for (int i = 0; i < 32; i++) {
+			const int n = ch * NC + wq * 128 + 4 * i + (l >> 4);
 			const float v = a.r[(unsigned)((n < N4 ? n : N4 - 1) * H + ju)];
-			rreg[ch][i] = n < N4 && j0 + u < H ? v : 0.f;
+			rreg[ch][i] = n < N4 && j0 + (l & 15) < H ? v : 0.f;
 		}
 	}
 	const int rr = nq, b = row0 + rr, j = j0 + u; // (the same 16 x 16 split of the threads serves as (slice, unit) and as (row, unit))
@@ -288,9 +282,7 @@ __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_
 				nnc_store_granule(a.xch + ((size_t)(it & 1) * B + b) * N4 + g * H + j, (unsigned)(it + 1), d4[g]);
 			}
 		}
-		float acc[16];
-#pragma unroll
-		for (int r2 = 0; r2 < 16; r2++) acc[r2] = 0.f;
+		floatx4 acc = { 0.f, 0.f, 0.f, 0.f };
 		auto chunk = [&](const int ch, const float (&rc)[32]) __attribute__((always_inline)) {
 			const int n0 = ch * NC, nn = N4 - n0 < NC ? N4 - n0 : NC; // this chunk's columns
 			if (ch > 0) __syncthreads();
@@ -322,26 +314,17 @@ __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_
 			}
 			__syncthreads();
 #pragma unroll
-			for (int i = 0; i < 32; i += 4) {
-#pragma unroll
-				for (int r2 = 0; r2 < 16; r2++) {
-					const float4 gv = *(const float4*)&dgtile[r2 * PITCH + nq * 32 + i];
-					acc[r2] += rc[i] * gv.x + rc[i + 1] * gv.y + rc[i + 2] * gv.z + rc[i + 3] * gv.w;
-				}
-				__builtin_amdgcn_sched_barrier(0);
-			}
+			for (int i = 0; i < 32; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dgtile[(l & 15) * PITCH + wq * 128 + 4 * i + (l >> 4)], rc[i], acc, 0, 0, 0);
 		};
 		chunk(0, rreg[0]);
-		if (NCH > 1) chunk(1, rreg[1]);
-		if (NCH > 2) chunk(2, rreg[2]);
-		if (NCH > 3) chunk(3, rreg[3]);
+		if constexpr (NCH > 1) chunk(1, rreg[1]);
+		if constexpr (NCH > 2) chunk(2, rreg[2]);
+		if constexpr (NCH > 3) chunk(3, rreg[3]);
 #pragma unroll
-		for (int r2 = 0; r2 < 16; r2++) part[nq][r2][u] = acc[r2];
+		for (int i = 0; i < 4; i++) part[wq][4 * (l >> 4) + i][l & 15] = acc[i]; // (D: rows 4 (l >> 4) + i, column l & 15; one partial block per wave)
 		__syncthreads();
 		if (mine) {
-			float v = 0.f;
-#pragma unroll
-			for (int q = 0; q < 16; q++) v += part[q][rr][u];
+			const float v = (part[0][rr][u] + part[1][rr][u]) + (part[2][rr][u] + part[3][rr][u]);
 			dh = t < len ? v : dh + v; // (past the end the gate gradients were zero: v == 0, the state gradient goes on unchanged)
 		}
 		__syncthreads();
@@ -700,7 +683,7 @@ static int _lstm_back(EXEC_ARGS_L)
 	const size_t n_len = (sizeof(int) * g.B + 255) & ~(size_t)255, n_xs = g.batch_first ? al(TB * g.I) : 0, n_dys = g.batch_first ? al(TB * DP) : 0, n_lay = g.L > 1 ? al(TB * DP) : 0;
 	const size_t n_dg = al(TB * 4 * g.H), n_in = g.L > 1 ? al(TB * in_max) : 0, n_hp = al(TB * g.P), n_h = al((size_t)g.B * g.P), n_c = al(g.BH());
 	const size_t n_dhp = g.proj ? al(TB * g.P) : 0, n_draw = g.proj ? al(g.BH()) : 0, n_raw = g.proj ? al(TB * g.H) : 0;
-	const bool persistent = tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 128 /* (the kernel takes 4H in chunks of 512 columns, but hipcc spills its registers from the second chunk on: wider layers go step by step) */ && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
+	const bool persistent = tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 512 && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
 	const size_t n_xch = persistent ? (sizeof(unsigned long long) * 2 * g.B * 4 * g.H + 255) & ~(size_t)255 : 0;
 	WorkspaceScope ws(stream_context, n_len + 2 * n_xs + n_dys + 2 * n_lay + n_dg + n_in + n_hp + 2 * n_h + 2 * n_c + n_dhp + n_draw + n_raw + n_xch, lstm_inner_bytes(g));
 	char* at = (char*)ws.prefix();
@@ -758,7 +741,10 @@ static int _lstm_back(EXEC_ARGS_L)
 				const lstm_seq_back_t a = { Rc, rsv, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, dyl + (size_t)d * g.P, dhy ? dhy->data.f32 + (size_t)p * g.BH() : 0, dcy ? dcy->data.f32 + (size_t)p * g.BH() : 0,
 					dG, dhx ? dhx->data.f32 + (size_t)p * g.BH() : 0, dcx ? dcx->data.f32 + (size_t)p * g.BH() : 0, xch, lens, timeout_word, g.T, g.B, g.H, d, DP, g.S, g.slot(p, 0, 0), g.T > 1 ? g.cslot(p, 0) : 0 };
 				const dim3 seq_grid((g.H + 15) / 16, (g.B + 15) / 16);
-				NNC_LAUNCH_CONCURRENT(lstm_seq_back_kernel<1>, seq_grid, dim3(256), LSTM_SEQ_BACK_LDS, stream, a);
+				if (g.H <= 128) NNC_LAUNCH_CONCURRENT(lstm_seq_back_kernel<1>, seq_grid, dim3(256), LSTM_SEQ_BACK_LDS, stream, a);
+				else if (g.H <= 256) NNC_LAUNCH_CONCURRENT(lstm_seq_back_kernel<2>, seq_grid, dim3(256), LSTM_SEQ_BACK_LDS, stream, a);
+				else if (g.H <= 384) NNC_LAUNCH_CONCURRENT(lstm_seq_back_kernel<3>, seq_grid, dim3(256), LSTM_SEQ_BACK_LDS, stream, a);
+				else NNC_LAUNCH_CONCURRENT(lstm_seq_back_kernel<4>, seq_grid, dim3(256), LSTM_SEQ_BACK_LDS, stream, a);
 				HIP_ENFORCE(hipGetLastError());
 			} else
 			for (int s = g.T - 1; s >= 0; s--) {

@@ -160,7 +160,7 @@ def _run_inner(lib, case, dtype, tol, persistent):
     ins = [gpu(lay(gy)), gpu(ghy), gpu(gcy), None, x_t, xs_t, hx_t, cx_t, w_t, y_t, hy_t, cy_t, r_t]
     assert lib.cmd_exec(bcmd, nnc.NO_HINT, 0, ins, [dx_t, None, dhx_t, dcx_t, dw_t]) == 0
     if dtype == F:
-        assert lib.dll.nnc_mi355x_last_kernel_name().decode() == ("lstm_seq_back" if persistent and not (P and P != H) and H <= 128 else "lstm_step_back")
+        assert lib.dll.nnc_mi355x_last_kernel_name().decode() == ("lstm_seq_back" if persistent and not (P and P != H) else "lstm_step_back")
     dx, dhx, dcx, dw = oracle.backward(gy.astype(np.float64), tape, ghy, gcy)
     close(unlay(dx_t.numpy()), dx, tol)
     close(dw_t.numpy().reshape(-1), dw, tol)
