@@ -228,16 +228,16 @@ struct lstm_seq_back_t {
 	size_t slot0, cslot0;
 };
 constexpr int LSTM_SEQ_BACK_NC = 512; // gate-gradient columns staged in LDS at a time: 4H in NCH = ceil(H / 128) chunks
-#define LSTM_SEQ_BACK_LDS (sizeof(float) * (16 * (LSTM_SEQ_BACK_NC + 4) + 16 * 16 * 17 + 4))
+#define LSTM_SEQ_BACK_LDS (sizeof(float) * (16 * (LSTM_SEQ_BACK_NC + 4) + 4 * 16 * 17 + 4))
 template <int NCH>
 __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_t a)
 {
-	constexpr int NC = LSTM_SEQ_BACK_NC, PITCH = NC + 4; // lane (unit, slice) takes 32 columns of every chunk: slice nq of chunk c = columns c * 512 + nq * 32 ..
+	constexpr int NC = LSTM_SEQ_BACK_NC, PITCH = NC + 4;
 	HIP_DYNAMIC_SHARED(float, lds)
 	float* const dgtile = lds;                                            // [16][PITCH]
-	float (*const part)[16][17] = (float (*)[16][17])(lds + 16 * PITCH);  // [16 slices][16 rows][16 units]
-	int& dead = *(int*)(lds + 16 * PITCH + 16 * 16 * 17);
-	const int tid = threadIdx.x, u = tid & 15, nq = tid >> 4;
+	float (*const part)[16][17] = (float (*)[16][17])(lds + 16 * PITCH);  // [4 waves][16 rows][16 units]
+	int& dead = *(int*)(lds + 16 * PITCH + 4 * 16 * 17);
+	const int tid = threadIdx.x, u = tid & 15, rr = tid >> 4; // (row, unit): the element of dh / dc a thread keeps for the whole sequence
 	const int H = a.H, B = a.B, N4 = 4 * H, j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
 	const size_t BH = (size_t)B * H;
 	const int wq = tid >> 6, l = tid & 63; // wave wq reduces columns wq * 128 .. + 127 of every 512-column chunk on the matrix cores
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_
 			rreg[ch][i] = n < N4 && j0 + (l & 15) < H ? v : 0.f;
 		}
 	}
-	const int rr = nq, b = row0 + rr, j = j0 + u; // (the same 16 x 16 split of the threads serves as (slice, unit) and as (row, unit))
+	const int b = row0 + rr, j = j0 + u;
 	const bool mine = b < B && j < H;
 	const size_t e = (size_t)b * H + j;
 	float dh = mine && a.dhy ? a.dhy[e] : 0.f, dc = mine && a.dcy ? a.dcy[e] : 0.f;
