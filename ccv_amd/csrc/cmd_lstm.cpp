@@ -612,10 +612,6 @@ static int _lstm_forw(EXEC_ARGS_L)
 			if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
 			if (!persistent) hipLaunchKernelGGL(lstm_transpose_kernel, dim3(blocks_of((size_t)4 * g.H * g.P)), dim3(256), 0, stream, Rc, rt, 4 * g.H, g.P);
 			if (g.proj) hipLaunchKernelGGL(lstm_transpose_kernel, dim3(blocks_of((size_t)g.P * g.H)), dim3(256), 0, stream, Wp, wpt, g.P, g.H);
-			if (hx) HIP_ENFORCE(hipMemcpyAsync(hs[0], hx->data.f32 + (size_t)p * g.B * g.P, sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
-			else HIP_ENFORCE(hipMemsetAsync(hs[0], 0, sizeof(float) * g.B * g.P, stream));
-			if (cx) HIP_ENFORCE(hipMemcpyAsync(cs[0], cx->data.f32 + (size_t)p * g.BH(), sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
-			else HIP_ENFORCE(hipMemsetAsync(cs[0], 0, sizeof(float) * g.BH(), stream));
 			if (persistent) { // one launch for the whole sequence (lstm_seq_forw_kernel)
 				HIP_ENFORCE(hipMemsetAsync(xch, 0, n_xch, stream));
 				const lstm_seq_t a = { gx, Rc, bw, hx ? hx->data.f32 + (size_t)p * g.BH() : 0, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, yl + (size_t)d * g.P, hy ? hy->data.f32 + (size_t)p * g.BH() : 0, cy ? cy->data.f32 + (size_t)p * g.BH() : 0,
@@ -629,6 +625,10 @@ static int _lstm_forw(EXEC_ARGS_L)
 				continue;
 			}
 			note_kernel("lstm_step_forw");
+			if (hx) HIP_ENFORCE(hipMemcpyAsync(hs[0], hx->data.f32 + (size_t)p * g.B * g.P, sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
+			else HIP_ENFORCE(hipMemsetAsync(hs[0], 0, sizeof(float) * g.B * g.P, stream));
+			if (cx) HIP_ENFORCE(hipMemcpyAsync(cs[0], cx->data.f32 + (size_t)p * g.BH(), sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
+			else HIP_ENFORCE(hipMemsetAsync(cs[0], 0, sizeof(float) * g.BH(), stream));
 			for (int s = 0; s < g.T; s++) {
 				const int t = d ? g.T - 1 - s : s;
 				float* const yt = yl + (size_t)t * g.B * DP + (size_t)d * g.P;
@@ -732,10 +732,12 @@ static int _lstm_back(EXEC_ARGS_L)
 			const float* const Wc = W + wo;
 			const float* const Rc = Wc + (size_t)4 * g.H * in;
 			const float* const Wp = Rc + (size_t)4 * g.H * g.P;
-			if (dhy) HIP_ENFORCE(hipMemcpyAsync(dh[g.T & 1], dhy->data.f32 + (size_t)p * g.B * g.P, sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
-			else HIP_ENFORCE(hipMemsetAsync(dh[g.T & 1], 0, sizeof(float) * g.B * g.P, stream));
-			if (dcy) HIP_ENFORCE(hipMemcpyAsync(dc, dcy->data.f32 + (size_t)p * g.BH(), sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
-			else HIP_ENFORCE(hipMemsetAsync(dc, 0, sizeof(float) * g.BH(), stream));
+			if (!persistent) {
+				if (dhy) HIP_ENFORCE(hipMemcpyAsync(dh[g.T & 1], dhy->data.f32 + (size_t)p * g.B * g.P, sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
+				else HIP_ENFORCE(hipMemsetAsync(dh[g.T & 1], 0, sizeof(float) * g.B * g.P, stream));
+				if (dcy) HIP_ENFORCE(hipMemcpyAsync(dc, dcy->data.f32 + (size_t)p * g.BH(), sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
+				else HIP_ENFORCE(hipMemsetAsync(dc, 0, sizeof(float) * g.BH(), stream));
+			}
 			if (persistent) { // one launch for the whole sequence (lstm_seq_back_kernel)
 				HIP_ENFORCE(hipMemsetAsync(xch, 0, n_xch, stream));
 				const lstm_seq_back_t a = { Rc, rsv, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, dyl + (size_t)d * g.P, dhy ? dhy->data.f32 + (size_t)p * g.BH() : 0, dcy ? dcy->data.f32 + (size_t)p * g.BH() : 0,
