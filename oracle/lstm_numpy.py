@@ -14,8 +14,11 @@ cuDNN's published LSTM in float64:
 (linear-layer ids 0..3 = input matrices of i, f, g, o; 4..7 = recurrent ones; 8 = projection), the weight space packed as every pseudo-layer's
 matrices (layer-major, forward direction then backward) followed by every pseudo-layer's two bias sets -- the sizes the reference's own test helper
 computes (lstm.tests.c:14-21) --, a layer's input = the previous layer's outputs of both directions side by side, dropout between layers, padded
-sequences (zeros in y past an item's end, final states taken at each item's own last step).  What anchors it instead of golden vectors: the
-gradients returned by `backward` are checked against central differences of `forward` (tests/test_lstm.py), so the pair is at least self-consistent."""
+sequences (zeros in y past an item's end, final states taken at each item's own last step).  What anchors it instead of the reference's golden vectors
+(there are none): (1) the gradients returned by `backward` equal central differences of `forward`; (2) outputs, final states and every gradient equal
+torch.nn.LSTM's on the CPU in float64 to 1e-10 -- an independent implementation that takes cuDNN's own parameters (weight_ih / weight_hh / weight_hr / bias_ih /
+bias_hh per layer and direction, gates i f g o; its CUDA path hands exactly these to cudnnRNNForward) -- with layers, both directions, the projection and
+packed sequences (tests/test_lstm.py::test_oracle_matches_an_independent_lstm).  Still "unpinned" in the strict sense: neither is the reference itself."""
 import numpy as np
 
 
