@@ -18,7 +18,7 @@ sequences (zeros in y past an item's end, final states taken at each item's own 
 (there are none): (1) the gradients returned by `backward` equal central differences of `forward`; (2) outputs, final states and every gradient equal
 torch.nn.LSTM's on the CPU in float64 to 1e-10 -- an independent implementation that takes cuDNN's own parameters (weight_ih / weight_hh / weight_hr / bias_ih /
 bias_hh per layer and direction, gates i f g o; its CUDA path hands exactly these to cudnnRNNForward) -- with layers, both directions, the projection and
-packed sequences (tests/test_lstm.py::test_oracle_matches_an_independent_lstm).  Still "unpinned" in the strict sense: neither is the reference itself."""
+packed sequences (tests/lstm_torch_check.py, run by tests/test_lstm.py::test_oracle_matches_an_independent_lstm).  Still "unpinned" in the strict sense: neither is the reference itself."""
 import numpy as np
 
 
