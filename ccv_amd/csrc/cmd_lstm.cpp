@@ -517,15 +517,19 @@ static int lstm_lens(const ccv_nnc_tensor_t* const xs, const lstm_geom_t& g, int
 }
 
 static size_t lstm_inner_bytes(const lstm_geom_t& g)
-{
-	const long TB = (long)g.T * g.B;
-	const int in_max = g.I > g.D * g.P ? g.I : g.D * g.P;
-	size_t inner = gemm_workspace_bound(TB, 4L * g.H, in_max);
-	size_t v;
-	if ((v = gemm_workspace_bound(TB, in_max, 4L * g.H)) > inner) inner = v;
-	if ((v = gemm_workspace_bound(4L * g.H, in_max, TB)) > inner) inner = v;
-	if ((v = gemm_workspace_bound(g.P, g.H, TB)) > inner) inner = v;
-	if ((v = sizeof(float) * ((size_t)device_cu_count() * 4 + 64) * 4 * g.H) > inner) inner = v; // colsum_f32's partials
+{ // what the contractions and the column sum made underneath may ask of the workspace (split-K slabs: the bound is not monotonic in the shape, so every shape is listed)
+	const long TB = (long)g.T * g.B, G4 = 4L * g.H;
+	const int ins[2] = { g.I, g.D * g.P };
+	size_t inner = sizeof(float) * ((size_t)device_cu_count() * 4 + 64) * 4 * g.H; // colsum_f32's partials
+	auto take = [&](const long M, const long N, const long K) { const size_t v = gemm_workspace_bound(M, N, K); if (v > inner) inner = v; };
+	for (int i = 0; i < 2; i++) {
+		take(TB, G4, ins[i]); // gx = X W^T
+		take(TB, ins[i], G4); // dX = dG W
+		take(G4, ins[i], TB); // dW = dG^T X
+	}
+	take(G4, g.P, TB);  // dR = dG^T H'
+	take(g.P, g.H, TB); // dW_p
+	take(g.B, g.P, G4); // a wide layer's state gradient, one step
 	return inner + 4096;
 }
 
