@@ -37,7 +37,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(image, label):
+def cpu_baseline(image, label, fwd_only=False):
     """The reference's own CPU path on this host: VGG-D at batch 1 on `image` (the GPU run's image 0,
     same seed-0 weights), all host cores (OpenMP), one warm-up + three repetitions each of
       * the whole step (forward + backward + SGD) through CPU_REF -- the reported `value` (median);
@@ -56,14 +56,14 @@ def cpu_baseline(image, label):
         t0 = time.time()
         fn()
         return time.time() - t0
-    net.step()  # warm-up (pages, OpenMP pool) on the initial weights
+    (net.forward if fwd_only else net.step)()  # warm-up (pages, OpenMP pool) on the initial weights
     loss0 = float(net.loss.numpy()[0])
-    steps = sorted(timed(net.step) for _ in range(REPS))
     fwd_ref = sorted(timed(net.forward) for _ in range(REPS))
+    steps = fwd_ref if fwd_only else sorted(timed(net.step) for _ in range(REPS))  # (config 2 is forward only: no training step is timed for it)
     out = {"value": 1.0 / steps[REPS // 2], "unit": "images/s", "cores": os.cpu_count() if kind == "reference" else 1, "kind": kind,
            "cpu": cpu_model(), "forward_only_cpu_ref_images_per_s": 1.0 / fwd_ref[REPS // 2],
-           "sample": "1 image, full VGG-D fwd+bwd+SGD through lib/nnc CPU_REF (oracle/_ref, clang -O3 -fopenmp, no BLAS: the fc layers run "
-                     "the reference's own loops), warm-up + %d repetitions, median %.2f s (min %.2f, max %.2f)" % (REPS, steps[REPS // 2], steps[0], steps[-1])}
+           "sample": "1 image, VGG-D %s through lib/nnc CPU_REF (oracle/_ref, clang -O3 -fopenmp, no BLAS: the fc layers run "
+                     "the reference's own loops), warm-up + %d repetitions, median %.2f s (min %.2f, max %.2f)" % ("forward" if fwd_only else "fwd+bwd+SGD", REPS, steps[REPS // 2], steps[0], steps[-1])}
     if kind == "reference":
         net.conv_fwd_backend = nnc.BACKEND_CPU_OPT
         try:
@@ -76,16 +76,17 @@ def cpu_baseline(image, label):
     return out, loss0
 
 
-def via_host(args, losses, params):
+def via_host(args, losses, params, fwd_only=False):
     """The same training step through the REFERENCE HOST (oracle/_ref/host_vgg_bench.gpu = tools/host_vgg_bench.c against the
     unmodified reference host + this backend): symbolic graph, ccv_nnc_symbolic_graph_minimize, compile (tensor arena),
-    ccv_nnc_graph_autotune, static schedule -- timed there, and its first step compared with this process's."""
+    ccv_nnc_graph_autotune, static schedule -- timed there, and its first step compared with this process's.  fwd_only (config 2):
+    the forward graph alone -- the node sequence of test/int/nnc/graph.vgg.d.tests.c:14-90 on synthetic images."""
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "host_vgg_bench.gpu")
     if not os.path.exists(exe):
         return {"status": "oracle/_ref/host_vgg_bench.gpu not built"}
     try:
-        r = subprocess.run([exe, str(args.batch), "225", str(min(args.steps, 6)), "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, NNC_MI355X_PEEPHOLE_STATS="1"))
+        r = subprocess.run([exe, str(args.batch), "225", str(min(args.steps, 6)), "2", "full"] + (["fwd"] if fwd_only else []), capture_output=True, text=True, timeout=900, env=dict(os.environ, NNC_MI355X_PEEPHOLE_STATS="1"))
         if r.returncode != 0:
             return {"status": "failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
         h = json.loads(r.stdout.strip().splitlines()[-1])
@@ -93,13 +94,15 @@ def via_host(args, losses, params):
         return {"status": "failed: %s" % e}
     hl = np.array(h["loss"], dtype=np.float64)
     loss_err = float(np.max(np.abs(hl - losses[:len(hl)]) / np.maximum(np.abs(losses[:len(hl)]), 1e-30)))
-    perr = max(abs(a - b[0]) / max(abs(b[0]), 1e-3 * b[1] ** 0.5, 1e-30) for a, b in zip(h["updated_param_sum"], params))
-    qerr = max(abs(a - b[1]) / max(b[1], 1e-30) for a, b in zip(h["updated_param_sumsq"], params))
+    perr = qerr = 0.0
+    if not fwd_only:
+        perr = max(abs(a - b[0]) / max(abs(b[0]), 1e-3 * b[1] ** 0.5, 1e-30) for a, b in zip(h["updated_param_sum"], params))
+        qerr = max(abs(a - b[1]) / max(b[1], 1e-30) for a, b in zip(h["updated_param_sumsq"], params))
     import re
     m = re.search(r"look-ahead: (\d+) commands recorded, (\d+) completed by their ReLU, (\d+) launched as they were", r.stderr)
     return {"images_per_s": h["images_per_s"], "ms_per_step": h["ms_per_step"], "autotune_ms": h["autotune_ms"],
             "relu_look_ahead": {"recorded": int(m.group(1)), "folded": int(m.group(2)), "launched_plain": int(m.group(3))} if m else None,
-            "step1_max_rel_err_vs_command_driver": {"loss": loss_err, "updated_param_sum": perr, "updated_param_sumsq": qerr},
+            "step1_max_rel_err_vs_command_driver": {"loss": loss_err} if fwd_only else {"loss": loss_err, "updated_param_sum": perr, "updated_param_sumsq": qerr},
             "equal": bool(loss_err <= 1e-4 and qerr <= 1e-4), "driver": h["driver"]}
 
 
@@ -213,17 +216,28 @@ def host_cpu_baseline(args, half, dawn):
     tail = ["dawn"] if dawn else ["full"]
     hw = "32" if dawn else "224"
     base = gate = None
+    # the CPU sample does not depend on the GPU side's precision: within ONE default run (extra_configs) the fp32 and f16 lines of a network share it
+    cache = os.environ.get("NNC_BENCH_CPU_CACHE")
+    cpath = os.path.join(cache, "cpu_%s_%d.json" % ("dawn" if dawn else "resnet50", n)) if cache else None
+    want = None
+    if cpath and os.path.exists(cpath):
+        c = json.load(open(cpath))
+        base, want = c["base"], c["want"]
     try:
-        r = subprocess.run([cpu, str(n), hw, "2", "1", "32"] + tail, capture_output=True, text=True, timeout=900)
-        if r.returncode == 0:
-            c = json.loads(r.stdout.strip().splitlines()[-1])
-            base = {"value": c["images_per_s"], "unit": "images/s", "cores": os.cpu_count(), "kind": "reference",
-                    "sample": "%s forward + backward + SGD on %d images per step (fp32, the reference host on its CPU_REF rows, OpenMP over the host's hardware threads, no BLAS in the image), one warm-up + two timed steps: %.1f ms per step" % ("DawnNet" if dawn else "ResNet-50 v1d 224 x 224", n, c["ms_per_step"])}
         env = dict(os.environ, HOST_BENCH_CHECK="1")
-        rc = subprocess.run([cpu, str(n), hw, "0", "1", "32"] + tail, capture_output=True, text=True, timeout=900, env=env)
+        if base is None:
+            r = subprocess.run([cpu, str(n), hw, "2", "1", "32"] + tail, capture_output=True, text=True, timeout=900)
+            if r.returncode == 0:
+                c = json.loads(r.stdout.strip().splitlines()[-1])
+                base = {"value": c["images_per_s"], "unit": "images/s", "cores": os.cpu_count(), "kind": "reference",
+                        "sample": "%s forward + backward + SGD on %d images per step (fp32, the reference host on its CPU_REF rows, OpenMP over the host's hardware threads, no BLAS in the image), one warm-up + two timed steps: %.1f ms per step" % ("DawnNet" if dawn else "ResNet-50 v1d 224 x 224", n, c["ms_per_step"])}
+            rc = subprocess.run([cpu, str(n), hw, "0", "1", "32"] + tail, capture_output=True, text=True, timeout=900, env=env)
+            if rc.returncode == 0:
+                want = json.loads(rc.stdout.strip().splitlines()[-1])["check"]
+            if cpath and base is not None and want is not None:
+                json.dump({"base": base, "want": want}, open(cpath, "w"))
         rg = subprocess.run([gpu, str(n), hw, "0", "1", "16" if half else "32"] + tail, capture_output=True, text=True, timeout=900, env=env)
-        if rc.returncode == 0 and rg.returncode == 0:
-            want = json.loads(rc.stdout.strip().splitlines()[-1])["check"]
+        if want is not None and rg.returncode == 0:
             got = json.loads(rg.stdout.strip().splitlines()[-1])["check"]
             rel = max(abs(a - b) / max(abs(b), 1e-30) for a, b in zip(got["loss"], want["loss"]))
             tol = 5e-3 if half else 1e-4
@@ -258,6 +272,54 @@ def pmc_traffic(symbol, batch):
             tot += (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
             n += v["launches"]
     return tot / n if n else None
+
+
+EXTRA_CONFIGS = ["vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512"]
+
+
+def extra_configs(args):
+    """BASELINE configs 2, 4, 4 at the trainer's own precision, and 5 under the SAME clock as the headline: the default run (N = 1) ends with one short run of
+    each -- a fresh `bench.py --config <name> --steps 5 --warmup 2` process after the headline's timed region and legs are over (its autotune and warm-up
+    are untimed there as here) -- and carries their lines, reduced to value / ms_per_step / roofline / cpu_baseline / oracle gate, in `extra_configs`.  A
+    config that fails or times out is reported as such; it never takes the headline down."""
+    import subprocess
+    import tempfile
+    res = {}
+    cache = tempfile.mkdtemp(prefix="nnc_bench_cpu_")
+    for name in EXTRA_CONFIGS:
+        t0 = time.time()
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "5", "--warmup", "2", "--no-extra-configs", "--no-alt-leg"]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, NNC_BENCH_CPU_CACHE=cache))
+            lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                res[name] = {"status": "failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:]), "wall_s": time.time() - t0}
+                continue
+            d = json.loads(lines[-1])
+        except Exception as e:  # noqa: BLE001
+            res[name] = {"status": "failed: %s" % e, "wall_s": time.time() - t0}
+            continue
+        cfg = d.get("config", {})
+        e = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "via_host_images_per_s") if d.get(k) is not None}
+        e["workload"] = cfg.get("workload")
+        for rk in ("roofline", "roofline_f16_contractions"):
+            if rk in d:
+                e[rk] = {k: d[rk].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_ms") if k in d[rk]}
+                if isinstance(e[rk].get("kernel"), str):
+                    e[rk]["kernel"] = e[rk]["kernel"][:120]
+        if "cpu_baseline" in d and d["cpu_baseline"]:
+            e["cpu_baseline"] = {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+        gate = cfg.get("oracle_gate") or cfg.get("step1_loss_image0")
+        if gate:
+            e["oracle_gate"] = gate
+        for k in ("relu_look_ahead", "host_enqueue", "whole_step_tflops_per_gpu", "memory_gib"):
+            if k in cfg:
+                e[k] = cfg[k]
+        e["wall_s"] = time.time() - t0
+        res[name] = e
+    return res
 
 
 _RESULT = None
@@ -330,6 +392,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-leg", action="store_true", help="skip the second timed leg with the other ReLU setting (profiling runs: one kind of step in the trace)")
     ap.add_argument("--no-fuse-relu", action="store_true", help="issue RELU_FORWARD as its own command behind every convolution (the reference host's graph does) instead of letting the convolution's epilogue rectify (NNC_MI355X_CONV_ALGO_FUSE_RELU); the other setting is always timed beside the headline one")
+    ap.add_argument("--no-extra-configs", action="store_true", help="the default run (config 3, one GPU) ends with a short run of configs 2, 4, 4-f16 and 5 whose lines it carries in `extra_configs`; this skips them")
     ap.add_argument("--no-via-host", action="store_true", help="skip the second driver: the same step through the reference host's symbolic graph / autotune / static schedule (tools/host_vgg_bench.c)")
     ap.add_argument("--records", default=None, help="also write the per-launch contraction records (name, dims, ms, TFLOP/s) of the roofline leg to this file")
     args = ap.parse_args()
@@ -445,7 +508,9 @@ def main():
             L.stream_wait(stream)
             step1_losses = net.loss.numpy()[:8].astype(np.float64)
             step1_loss = float(step1_losses[0])
-            if rank == 0 and world == 1 and not args.no_via_host and not fwd_only:
+            if rank == 0 and world == 1 and not args.no_via_host and fwd_only:
+                step1_params = []
+            elif rank == 0 and world == 1 and not args.no_via_host:
                 step1_params = [(float(p.numpy().astype(np.float64).sum()), float((p.numpy().astype(np.float64) ** 2).sum())) for p, _, _ in net.params]
     barrier()
     t0 = time.perf_counter()
@@ -539,15 +604,14 @@ def main():
             if not dp_check.get("ok"):
                 print("bench.py: the data-parallel exchange FAILED its sum identity / replica equality check: %r" % (dp_check,), file=sys.stderr)
         if step1_params is not None:
-            out["config"]["via_host"] = via_host(args, step1_losses, step1_params)
+            out["config"]["via_host"] = via_host(args, step1_losses, step1_params, fwd_only)
+            # the drop-in number (the unmodified reference host driving this backend), next to `value` (ccv_amd/vgg.py, the command driver)
+            out["via_host_images_per_s"] = out["config"]["via_host"].get("images_per_s")
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"], oracle_loss = cpu_baseline(image0, label0)
+                out["cpu_baseline"], oracle_loss = cpu_baseline(image0, label0, fwd_only)
             except Exception as e:  # the checker is optional for the bench line, never for the parity tests
                 out["cpu_baseline"], oracle_loss = {"value": None, "unit": "images/s", "cores": 0, "kind": "reference", "sample": "unavailable: %s" % e}, None
-            if fwd_only and out["cpu_baseline"].get("forward_only_cpu_ref_images_per_s"):
-                out["cpu_baseline"]["value"] = out["cpu_baseline"]["forward_only_cpu_ref_images_per_s"]
-                out["cpu_baseline"]["sample"] = "forward only: " + out["cpu_baseline"]["sample"]
             if oracle_loss is not None and step1_loss is not None:
                 # parity gate on the benchmarked configuration itself: image 0's loss after the first forward at batch 256 (the
                 # convolutions under the algorithms the timed steps use) vs the reference CPU backend on the same image and weights
@@ -556,6 +620,9 @@ def main():
                 if not rel <= 1e-4:
                     emit(out)
                     raise SystemExit("bench.py: step-1 loss of image 0 differs from the oracle's: %r vs %r (rel %.3g > 1e-4)" % (step1_loss, oracle_loss, rel))
+        if args.config == "vggd-train-bs256" and world == 1 and not args.no_extra_configs and not force_comm:
+            L.stream_wait(stream)
+            out["extra_configs"] = extra_configs(args)
         emit(out)
     if dist:
         L.stream_wait(stream)

@@ -382,9 +382,11 @@ static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	if (cmd.info.sgd.nesterov && cmd.info.sgd.dampening != 0) return CCV_NNC_EXEC_INVALID;
 	if (cnt == 0) return CCV_NNC_EXEC_SUCCESS;
 	const float inv_dampening = 1 - cmd.info.sgd.dampening;
-	hipStream_t stream = stream_of(stream_context);
 	const int dt = CCV_GET_DATA_TYPE(a->info.datatype);
 	if (CCV_GET_DATA_TYPE(g->info.datatype) != dt || CCV_GET_DATA_TYPE(m->info.datatype) != dt || CCV_GET_DATA_TYPE(b->info.datatype) != dt || CCV_GET_DATA_TYPE(n->info.datatype) != dt) return CCV_NNC_EXEC_INVALID;
+	// every parameter has been checked: behind a recorded CONVOLUTION_BACKWARD whose signal this stream waits for, the update waits with it (peephole.cpp, the trail)
+	if (g_deferred_live && deferred_trail_cmd(_sgd_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context)) return CCV_NNC_EXEC_SUCCESS;
+	hipStream_t stream = stream_of(stream_context);
 	if (dt == CCV_16F) {
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(sgd_kernel<half_t>), dim3(grid_for(cnt, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const half_t*)g->data.f16, (const half_t*)a->data.f16, (const half_t*)m->data.f16, (half_t*)b->data.f16, (half_t*)n->data.f16, cnt, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
 		HIP_ENFORCE(hipGetLastError());

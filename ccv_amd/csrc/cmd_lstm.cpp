@@ -17,6 +17,7 @@
 // gradient and the same small product against R, then three contractions per pseudo-layer (dX = dG W, dW = dG^T X, dR = dG^T H') and a column sum.
 // Reserved space (floats, H wide; fits the reference tests' sizing, lstm.tests.c:23-34): per pseudo-layer and step S = 5 (+1 projection, +1 dropout)
 // planes of B x H -- i, f, g, o, tanh(c), [projected h], [dropout scale] --, then the cell state after each of the first T - 1 steps.
+#include <optional>
 #include "gemm_launch.h"
 #include "isa.h"
 
@@ -592,6 +593,10 @@ static int _lstm_forw(EXEC_ARGS_L)
 	unsigned long long* const xch = (unsigned long long*)at;
 	unsigned* timeout_word = 0;
 	if (persistent) { unsigned epoch; if (!cluster_sync_of(stream_context, 0, &epoch, &timeout_word)) return CCV_NNC_EXEC_OOM; }
+	// the one-launch kernels' workgroups wait for each other: this command's launches are one TURN of the device's spinning launches (common.h) -- another
+	// stream's persistent or cluster kernel can no longer hold part of the CUs while this one waits for the rest
+	std::optional<ClusterTurn> turn;
+	if (persistent) turn.emplace(stream_context);
 	if (xs) { const int ret = lstm_lens(xs, g, lens, stream); if (ret != CCV_NNC_EXEC_SUCCESS) return ret; }
 	const float* xin = x->data.f32;
 	if (g.batch_first) { hipLaunchKernelGGL(lstm_swap01_kernel, dim3(blocks_of(TB * g.I)), dim3(256), 0, stream, x->data.f32, xseq, g.B, g.T, g.I); xin = xseq; }
@@ -709,6 +714,10 @@ static int _lstm_back(EXEC_ARGS_L)
 	unsigned long long* const xch = (unsigned long long*)at;
 	unsigned* timeout_word = 0;
 	if (persistent) { unsigned epoch; if (!cluster_sync_of(stream_context, 0, &epoch, &timeout_word)) return CCV_NNC_EXEC_OOM; }
+	// the one-launch kernels' workgroups wait for each other: this command's launches are one TURN of the device's spinning launches (common.h) -- another
+	// stream's persistent or cluster kernel can no longer hold part of the CUs while this one waits for the rest
+	std::optional<ClusterTurn> turn;
+	if (persistent) turn.emplace(stream_context);
 	if (xs) { const int ret = lstm_lens(xs, g, lens, stream); if (ret != CCV_NNC_EXEC_SUCCESS) return ret; }
 	if (!cx) HIP_ENFORCE(hipMemsetAsync(czero, 0, sizeof(float) * g.BH(), stream));
 	const float* x0 = x ? x->data.f32 : 0;

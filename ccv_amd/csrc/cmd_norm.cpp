@@ -785,6 +785,7 @@ static int bnorm_forw_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 			unsigned* timeout_word = 0;
 			cluster_sync_t* const sync = (cluster_sync_t*)cluster_sync_of(stream_context, (size_t)cg.grid * 16, &epoch, &timeout_word);
 			if (sync) {
+				ClusterTurn turn(stream_context); // spinning launches are one after the other per device, whatever streams they come from (common.h)
 #define BN_CL_FWD(CBV) do { const auto kernel = bn_cluster_forw_kernel<T, CBV, BN_CLUSTER_NV * (16 / CBV)>; /* (a name without commas for the launch macros) */ \
 					NNC_LAUNCH_CONCURRENT(kernel, dim3(cg.grid), dim3(256), BN_CLUSTER_LDS, stream, xp, yp, cg, sync, epoch, timeout_word, scale, bias, mean, var, saved_mean, saved_inv_std, inv_b, cmd.info.bnorm.momentum, cmd.info.bnorm.epsilon, relu); } while (0)
 				if (CB == 16) BN_CL_FWD(16); else if (CB == 8) BN_CL_FWD(8); else BN_CL_FWD(4);
@@ -881,6 +882,7 @@ static int bnorm_back_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 		unsigned* timeout_word = 0;
 		cluster_sync_t* const sync = (cluster_sync_t*)cluster_sync_of(stream_context, (size_t)cg.grid * 16, &epoch, &timeout_word);
 		if (sync) {
+			ClusterTurn turn(stream_context);
 #define BN_CL_BWD(CBV) do { const auto kernel = bn_cluster_back_kernel<T, CBV, (BN_CLUSTER_NV / 2) * (16 / CBV)>; \
 				NNC_LAUNCH_CONCURRENT(kernel, dim3(cg.grid), dim3(256), BN_CLUSTER_LDS, stream_of(stream_context), xp, gp, hp, cg, sync, epoch, timeout_word, (const float*)scale->data.f32, (const float*)saved_mean->data.f32, (const float*)saved_inv_std->data.f32, dscale->data.f32, dbias->data.f32, (float)(n / v.C)); } while (0)
 			if (CB == 16) BN_CL_BWD(16); else if (CB == 8) BN_CL_BWD(8); else BN_CL_BWD(4);

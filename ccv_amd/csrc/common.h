@@ -112,6 +112,10 @@ bool deferred_try(exec_fn_t fn, int kind, const ccv_nnc_cmd_t cmd, const ccv_nnc
 void deferred_mark_good(uint64_t sig); // this signature ran successfully on the spot: the next one like it may be recorded
 int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx); // -1: no recorded command this ReLU completes
 int deferred_fuse_relu_back(const ccv_nnc_tensor_t* g, const ccv_nnc_tensor_t* b, ccv_nnc_tensor_t* h, ccv_nnc_stream_context_t* ctx);
+bool deferred_signal_op(int emit, const ccv_nnc_stream_context_t* ctx, const ccv_nnc_stream_signal_t* signal); // true: kept in a recorded command's trail (peephole.cpp), not to be performed now
+bool deferred_trail_cmd(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, int flags, ccv_nnc_tensor_t* const* inputs, int input_size, ccv_nnc_tensor_t* const* outputs, int output_size, ccv_nnc_stream_context_t* ctx); // true: kept behind the trail operations of its stream
+void signal_emit_now(const ccv_nnc_stream_context_t* ctx, const ccv_nnc_stream_signal_t* signal); // device_rt.cpp: the event record / stream wait themselves
+void signal_wait_now(const ccv_nnc_stream_context_t* ctx, const ccv_nnc_stream_signal_t* signal);
 void deferred_flush(const ccv_nnc_stream_context_t* ctx); // 0: every stream's
 int deferred_take_error(const ccv_nnc_stream_context_t* ctx); // a recorded command of this stream failed when a flush launched it: returned (once) by the stream's next recordable command
 void deferred_suppress(int delta); // +1 / -1 around commands that must run on the spot (half_stage.cpp)
@@ -127,6 +131,19 @@ struct cluster_sync_t { unsigned ticket, done; unsigned pad[62]; }; // 256 bytes
 constexpr size_t CLUSTER_SYNC_BYTES = 2u << 20;
 constexpr unsigned CLUSTER_SPIN_LIMIT = 1u << 21; // polls (each ~ a microsecond) before a waiting workgroup gives up: seconds, not a hung GPU
 void* cluster_sync_of(const ccv_nnc_stream_context_t* ctx, size_t granule_bytes, unsigned* epoch, unsigned** timeout_word);
+// Kernels whose workgroups wait for each other need their waiting sets RESIDENT; two such launches from two streams of one device can each hold part of
+// the CUs and starve one another until CLUSTER_SPIN_LIMIT (ordinary kernels cannot: they finish and free their CUs).  A ClusterTurn brackets the
+// launches of one command: the stream first waits for the event behind the previous turn taken on ANOTHER stream of the device, and leaves an event
+// behind its own launches -- spinning launches of one process are one after the other per device, whatever streams the host's scheduler picked.
+struct ClusterTurn {
+	hipStream_t stream;
+	int device;
+	explicit ClusterTurn(const ccv_nnc_stream_context_t* ctx);
+	~ClusterTurn();
+	ClusterTurn(const ClusterTurn&) = delete;
+	ClusterTurn& operator=(const ClusterTurn&) = delete;
+};
+long cluster_turns_chained(void); // (tests) turns that had to wait for a turn on another stream
 void note_kernel(const char* name);
 
 long tune(int key);

@@ -175,6 +175,34 @@ static void cluster_check_timeout()
 		abort();
 	}
 }
+// ---- one spinning launch at a time per device (ClusterTurn, common.h)
+static struct { pthread_mutex_t mutex; hipEvent_t event; hipStream_t last; int have; } g_cluster_turn[MAX_DEVICES];
+static pthread_once_t g_cluster_turn_once = PTHREAD_ONCE_INIT;
+static long g_cluster_turns_chained = 0;
+static void cluster_turn_init() { for (int i = 0; i < MAX_DEVICES; i++) pthread_mutex_init(&g_cluster_turn[i].mutex, 0); }
+long cluster_turns_chained(void) { return __atomic_load_n(&g_cluster_turns_chained, __ATOMIC_RELAXED); }
+ClusterTurn::ClusterTurn(const ccv_nnc_stream_context_t* ctx) : stream(stream_of(ctx)), device(current_device())
+{
+	pthread_once(&g_cluster_turn_once, cluster_turn_init);
+	if (device < 0 || device >= MAX_DEVICES) { device = -1; return; }
+	auto& t = g_cluster_turn[device];
+	pthread_mutex_lock(&t.mutex); // held across the command's launches: the order of the turns is the order of their events
+	if (t.have && t.last != stream) {
+		HIP_ENFORCE(hipStreamWaitEvent(stream, t.event, 0));
+		__atomic_add_fetch(&g_cluster_turns_chained, 1, __ATOMIC_RELAXED);
+	}
+}
+ClusterTurn::~ClusterTurn()
+{
+	if (device < 0) return;
+	auto& t = g_cluster_turn[device];
+	if (!t.event) HIP_ENFORCE(hipEventCreateWithFlags(&t.event, hipEventDisableTiming));
+	HIP_ENFORCE(hipEventRecord(t.event, stream)); // (a wait already queued on another stream refers to the record it saw, not to this one)
+	t.last = stream;
+	t.have = 1;
+	pthread_mutex_unlock(&t.mutex);
+}
+
 void* cluster_sync_of(const ccv_nnc_stream_context_t* ctx, size_t granule_bytes, unsigned* epoch, unsigned** timeout_word)
 {
 	if (granule_bytes > CLUSTER_SYNC_BYTES - 256) return 0;
@@ -365,6 +393,9 @@ void nnc_mi355x_memcpy(void* dest, const int dest_type, const void* src, const i
 		if (da == db) HIP_ENFORCE(hipMemcpy(dest, src, n, hipMemcpyDeviceToDevice));
 		else HIP_ENFORCE(hipMemcpyPeer(dest, db, src, da, n)); // xGMI peer copy
 	}
+	// a blocking copy is a point where the host OBSERVES device results (read-backs, checkpoints): a cluster kernel that gave up must stop the process
+	// here, not at some later stream wait
+	if (sm == CCV_TENSOR_GPU_MEMORY || dm == CCV_TENSOR_GPU_MEMORY) nnc::cluster_check_timeout();
 }
 
 void* nnc_mi355x_host_alloc(size_t size)
@@ -499,6 +530,7 @@ void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const 
 	if (l->workspace_size >= workspace_size && l->workspace) return l->workspace;
 	if (l->workspace) {
 		HIP_ENFORCE(hipStreamSynchronize(st)); // queued kernels may still read the old buffer
+		nnc::cluster_check_timeout();
 		HIP_ENFORCE(hipFree(l->workspace));
 	}
 	l->workspace = nnc_mi355x_malloc(st ? l->device : current_device(), workspace_size);
@@ -510,6 +542,7 @@ static void local_drain(device_local_t* l, hipStream_t st)
 {
 	if (!l->workspace && !l->staging) return;
 	HIP_ENFORCE(hipStreamSynchronize(st));
+	nnc::cluster_check_timeout();
 	if (l->workspace) HIP_ENFORCE(hipFree(l->workspace));
 	if (l->staging) HIP_ENFORCE(hipFree(l->staging));
 	l->workspace = 0; l->workspace_size = 0;
@@ -534,6 +567,7 @@ void* nnc_staging_of(const ccv_nnc_stream_context_t* const stream_context, const
 	if (l->staging_size >= size && l->staging) return l->staging;
 	if (l->staging) {
 		HIP_ENFORCE(hipStreamSynchronize(st)); // queued conversions may still read the old arena
+		nnc::cluster_check_timeout();
 		HIP_ENFORCE(hipFree(l->staging));
 	}
 	l->staging = nnc_mi355x_malloc(st ? l->device : current_device(), size);
@@ -602,20 +636,31 @@ ccv_nnc_stream_signal_t* ccv_nnc_init_stream_signal(ccv_nnc_stream_signal_t* con
 }
 void ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal)
 {
+	nnc::comm_flush_if_pending(); // (a recorded command's trail may still name this signal)
 	signal_gpu_t* g = (signal_gpu_t*)signal;
 	HIP_ENFORCE(hipEventDestroy(g->event));
 }
+} // extern "C"
+namespace nnc {
+void signal_emit_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal) { HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, bind(stream)->stream)); }
+void signal_wait_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal) { HIP_ENFORCE(hipStreamWaitEvent(bind(stream)->stream, ((const signal_gpu_t*)signal)->event, 0)); }
+}
+extern "C" {
+// A signal is a point where stream order becomes visible to other streams.  Recorded collectives go first; a recorded command's look-ahead decides whether the
+// operation must launch it now or can wait in its trail (peephole.cpp: the emit behind a CONVOLUTION_BACKWARD, the SGD streams' waits for it).
 void ccv_nnc_stream_compat_emit_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
 	if (nnc::sync_trace_on()) fprintf(stderr, "[nnc_mi355x] > EMIT signal %p on stream %p\n", (const void*)signal, (const void*)stream);
-	nnc::comm_flush_if_pending();
-	HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, bind(stream)->stream));
+	if (nnc::g_comm_pending) nnc::comm_flush();
+	if (nnc::g_deferred_live && nnc::deferred_signal_op(1, stream, signal)) return;
+	nnc::signal_emit_now(stream, signal);
 }
 void ccv_nnc_stream_compat_wait_signal(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
 	if (nnc::sync_trace_on()) fprintf(stderr, "[nnc_mi355x] > WAIT signal %p on stream %p\n", (const void*)signal, (const void*)stream);
-	nnc::comm_flush_if_pending();
-	HIP_ENFORCE(hipStreamWaitEvent(bind(stream)->stream, ((const signal_gpu_t*)signal)->event, 0));
+	if (nnc::g_comm_pending) nnc::comm_flush();
+	if (nnc::g_deferred_live && nnc::deferred_signal_op(0, stream, signal)) return;
+	nnc::signal_wait_now(stream, signal);
 }
 int ccv_nnc_stream_context_get_device(const ccv_nnc_stream_context_t* const stream_context)
 {
@@ -786,6 +831,7 @@ float nnc_mi355x_event_elapsed_ms(void* start, void* stop)
 {
 	float ms = 0;
 	HIP_ENFORCE(hipEventSynchronize((hipEvent_t)stop));
+	nnc::cluster_check_timeout();
 	HIP_ENFORCE(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
 	return ms;
 }

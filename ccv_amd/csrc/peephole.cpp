@@ -20,6 +20,18 @@
 // is printed and kept, and the next recordable command of the process returns it (deferred_take_error) -- never a silent success.
 // NNC_MI355X_PEEPHOLE=0 in the environment (or nnc_mi355x_set_peephole(0)) turns the look-ahead off.
 //
+// The TRAIL (round 5).  The reference's static schedule puts work BETWEEN a CONVOLUTION_BACKWARD and the RELU_BACKWARD that would complete it: behind the
+// convolution it emits the signal the layer's two SGD_FORWARD commands (one stream each) wait for, issues those waits, the SGD commands and their own
+// signals, and only then the ReLU (lib/nnc/ccv_nnc_graph_run.c:581-675 walks the schedule in topological order).  A flush at the first of those hooks lost
+// every such pair: 95 of VGG-D's 218 recorded commands went out as they were, 4.4 ms of the step through the host.  So a recorded command now carries a
+// trail: operations that arrived behind it and cannot be observed by anyone until something else is -- an EMIT on the recorded command's own stream (or on
+// a stream already in the trail), a WAIT for a signal whose emit is in the trail (the waiting stream joins the trail), an SGD_FORWARD on a stream in the
+// trail -- are kept, in arrival order, and replayed in that order right behind the recorded command when it finally launches, folded or not.  Everything
+// the trail does not hold is decided as before: an operation on a stream outside the trail that names no signal of the trail cannot depend on it and runs
+// at once; any other operation that orders against a stream of the trail launches the recorded command and replays the trail first.  Stream order and
+// signal order are what the host's schedule is made of, and both are kept; the kernels, their streams and their events are the same, only the ReLU's pass
+// over the gradient is gone.
+//
 // Threads.  Every order-observing hook flushes (stream_of, copies, frees, signals, callbacks), and some of them flush EVERY stream's slot from
 // whatever thread called (a loader thread's host-to-device copy).  A slot being launched stays visible in state LAUNCHING -- still counted in
 // g_deferred_live -- until its kernels have been enqueued; anything that would order itself against that stream (the matching ReLU, another
@@ -40,6 +52,21 @@ namespace {
 
 constexpr int MAX_IO = 6;
 enum { FREE = 0, RECORDED = 1, LAUNCHING = 2 };
+enum { OP_EMIT = 1, OP_WAIT = 2, OP_CMD = 3 };
+constexpr int TRAIL_IO = 4;   // tensors per side of a trail command (SGD_FORWARD: 3 in, 2 out)
+constexpr int TRAIL_MAX = 24; // operations behind one recorded command (VGG-D through the reference host: 7)
+struct TrailOp {
+	int op;
+	ccv_nnc_stream_context_t* ctx;
+	int device;
+	const ccv_nnc_stream_signal_t* signal; // OP_EMIT / OP_WAIT
+	exec_fn_t fn;                           // OP_CMD ...
+	ccv_nnc_cmd_t cmd;
+	ccv_nnc_hint_t hint;
+	int flags, nin, nout;
+	ccv_nnc_tensor_view_t in[TRAIL_IO], out[TRAIL_IO];
+	int has_in[TRAIL_IO], has_out[TRAIL_IO];
+};
 struct Slot {
 	int live; // FREE / RECORDED / LAUNCHING
 	exec_fn_t fn;
@@ -52,6 +79,8 @@ struct Slot {
 	int nin, nout;
 	ccv_nnc_stream_context_t* ctx;
 	int device;
+	int ntrail;
+	TrailOp trail[TRAIL_MAX];
 };
 constexpr int SLOTS = 16;
 Slot g_slots[SLOTS];
@@ -66,6 +95,7 @@ std::atomic<int> g_sticky_live(0);
 std::unordered_set<uint64_t> g_good;
 int g_enabled = -1;
 long g_recorded = 0, g_folded = 0, g_plain = 0; // nnc_mi355x_debug_peephole_counts
+long g_trailed = 0;                             // operations that waited in a trail (nnc_mi355x_debug_peephole_trailed)
 int g_debug_launch_delay_us = 0; // nnc_mi355x_debug_peephole_launch_delay_us: tests widen the window between a slot's release and its launch
 thread_local int tl_running = 0; // inside a recorded command's launch: its own stream_of / nested commands must not touch the slots
 
@@ -145,10 +175,22 @@ void keep(ccv_nnc_tensor_view_t* dst, int* has, const ccv_nnc_tensor_t* t)
 typedef std::unique_lock<std::recursive_mutex> Lock;
 // (the launch itself runs WITHOUT the slots' mutex: it takes the collectives' mutex through stream_of, and a thread recording a
 // collective takes this one through the same hook -- never both at once in opposite orders)
+struct Head { exec_fn_t fn; int kind; ccv_nnc_cmd_t cmd; ccv_nnc_hint_t hint; int flags; ccv_nnc_tensor_view_t in[MAX_IO], out[MAX_IO]; int has_in[MAX_IO], has_out[MAX_IO]; int nin, nout; ccv_nnc_stream_context_t* ctx; int device; };
+void sticky(const ccv_nnc_stream_context_t* const ctx, const int device, const int r)
+{ // no caller to hand a failed launch to: the next recordable command of that stream returns it (deferred_take_error)
+	int at = -1;
+	for (int i = 0; i < MAX_STICKY && at < 0; i++) if (g_sticky[i].err && g_sticky[i].ctx == ctx && g_sticky[i].device == device) at = i;
+	for (int i = 0; i < MAX_STICKY && at < 0; i++) if (!g_sticky[i].err) at = i;
+	if (at < 0) at = 0; // table full of unreported failures: the oldest gives way
+	if (!g_sticky[at].err) ++g_sticky_live;
+	g_sticky[at].ctx = ctx; g_sticky[at].device = device; g_sticky[at].err = r;
+}
 int run(Slot& s, const int relu_bit, Lock& lk, const bool report)
 {
-	Slot c = s;
-	s.live = LAUNCHING;
+	Head c;
+	c.fn = s.fn; c.kind = s.kind; c.cmd = s.cmd; c.hint = s.hint; c.flags = s.flags; c.nin = s.nin; c.nout = s.nout; c.ctx = s.ctx; c.device = s.device;
+	memcpy(c.in, s.in, sizeof(c.in)); memcpy(c.out, s.out, sizeof(c.out)); memcpy(c.has_in, s.has_in, sizeof(c.has_in)); memcpy(c.has_out, s.has_out, sizeof(c.has_out));
+	s.live = LAUNCHING; // (the trail stays in the slot: nobody appends to or reads a LAUNCHING slot but this thread)
 	ccv_nnc_tensor_t* in[MAX_IO];
 	ccv_nnc_tensor_t* out[MAX_IO];
 	for (int i = 0; i < c.nin; i++) in[i] = c.has_in[i] ? (ccv_nnc_tensor_t*)&c.in[i] : 0;
@@ -162,8 +204,31 @@ int run(Slot& s, const int relu_bit, Lock& lk, const bool report)
 	lk.unlock();
 	if (g_debug_launch_delay_us > 0) usleep(g_debug_launch_delay_us);
 	const int r = c.fn(c.cmd, c.hint, c.flags, in, c.nin, out, c.nout, c.ctx);
+	// the trail, in arrival order, right behind the command: its emits, the waits for them, the commands behind those waits
+	for (int k = 0; k < s.ntrail; k++) {
+		TrailOp& t = s.trail[k];
+		int dev = 0;
+		HIP_ENFORCE(hipGetDevice(&dev));
+		if (dev != t.device) HIP_ENFORCE(hipSetDevice(t.device));
+		if (t.op == OP_EMIT) signal_emit_now(t.ctx, t.signal);
+		else if (t.op == OP_WAIT) signal_wait_now(t.ctx, t.signal);
+		else {
+			ccv_nnc_tensor_t* tin[TRAIL_IO];
+			ccv_nnc_tensor_t* tout[TRAIL_IO];
+			for (int i = 0; i < t.nin; i++) tin[i] = t.has_in[i] ? (ccv_nnc_tensor_t*)&t.in[i] : 0;
+			for (int i = 0; i < t.nout; i++) tout[i] = t.has_out[i] ? (ccv_nnc_tensor_t*)&t.out[i] : 0;
+			const int tr = t.fn(t.cmd, t.hint, t.flags, tin, t.nin, tout, t.nout, t.ctx);
+			if (tr != CCV_NNC_EXEC_SUCCESS) {
+				fprintf(stderr, "[nnc_mi355x] a command (0x%x) kept behind a recorded one failed at launch with %d after its caller was told it had been enqueued\n", t.cmd.cmd, tr);
+				lk.lock();
+				sticky(t.ctx, t.device, tr);
+				lk.unlock();
+			}
+		}
+	}
 	lk.lock();
 	--tl_running;
+	s.ntrail = 0;
 	s.live = FREE;
 	--g_deferred_live;
 	g_launched.notify_all();
@@ -172,21 +237,19 @@ int run(Slot& s, const int relu_bit, Lock& lk, const bool report)
 	if (now != prev) HIP_ENFORCE(hipSetDevice(prev)); // (binding a fixed-device stream sets the device: the caller's stays what it was)
 	if (r != CCV_NNC_EXEC_SUCCESS) {
 		fprintf(stderr, "[nnc_mi355x] a recorded command (0x%x) failed at launch with %d after its caller was told it had been enqueued\n", c.cmd.cmd, r);
-		if (!report) { // no caller to hand it to: the next recordable command of this stream returns it (deferred_take_error)
-			int at = -1;
-			for (int i = 0; i < MAX_STICKY && at < 0; i++) if (g_sticky[i].err && g_sticky[i].ctx == c.ctx && g_sticky[i].device == c.device) at = i;
-			for (int i = 0; i < MAX_STICKY && at < 0; i++) if (!g_sticky[i].err) at = i;
-			if (at < 0) at = 0; // table full of unreported failures: the oldest gives way
-			if (!g_sticky[at].err) ++g_sticky_live;
-			g_sticky[at].ctx = c.ctx; g_sticky[at].device = c.device; g_sticky[at].err = r;
-		}
+		if (!report) sticky(c.ctx, c.device, r);
 	}
 	return r;
 }
 
+bool in_trail(const Slot& s, const ccv_nnc_stream_context_t* const ctx)
+{
+	for (int k = 0; k < s.ntrail; k++) if (s.trail[k].ctx == ctx) return true;
+	return false;
+}
 bool orders_against(const Slot& s, const ccv_nnc_stream_context_t* const ctx)
-{ // the default stream orders against every other: no context = all
-	return !ctx || !s.ctx || s.ctx == ctx;
+{ // the default stream orders against every other: no context = all; a stream with operations in the slot's trail orders against the slot
+	return !ctx || !s.ctx || s.ctx == ctx || in_trail(s, ctx);
 }
 
 // another thread is enqueueing a recorded command whose stream `ctx` orders against: wait until it is in the stream
@@ -241,12 +304,14 @@ bool deferred_try(exec_fn_t fn, const int kind, const ccv_nnc_cmd_t cmd, const c
 	const int device = device_for(ctx);
 	wait_launching(ctx, lock);
 	if (Slot* const old = slot_of(ctx, device)) run(*old, 0, lock, false); // two recordable commands in a row: the first goes as it is
+	for (int i = 0; i < SLOTS; i++) // this stream has operations in another recorded command's trail: they go first
+		if (g_slots[i].live == RECORDED && in_trail(g_slots[i], ctx)) run(g_slots[i], 0, lock, false);
 	Slot* s = 0;
 	for (int i = 0; i < SLOTS && !s; i++)
 		if (g_slots[i].live == FREE) s = &g_slots[i];
 	if (!s) return false;
 	s->fn = fn; s->kind = kind; s->cmd = cmd; s->hint = hint; s->flags = flags; s->ctx = ctx; s->device = device;
-	s->nin = input_size; s->nout = output_size;
+	s->nin = input_size; s->nout = output_size; s->ntrail = 0;
 	for (int i = 0; i < input_size; i++) keep(&s->in[i], &s->has_in[i], inputs[i]);
 	for (int i = 0; i < output_size; i++) keep(&s->out[i], &s->has_out[i], outputs[i]);
 	s->live = RECORDED;
@@ -296,6 +361,81 @@ int deferred_fuse_relu_back(const ccv_nnc_tensor_t* const g, const ccv_nnc_tenso
 	return run(*s, s->kind == DEFER_CONV_BACKWARD ? NNC_MI355X_CONV_ALGO_FUSE_RELU : NNC_MI355X_POOL_ALGO_FUSE_RELU_BACKWARD, lock, true);
 }
 
+// ---- the trail (see the head of this file)
+namespace {
+Slot* slot_with_stream(const ccv_nnc_stream_context_t* const ctx, const int device)
+{ // the RECORDED slot whose own stream this is, or whose trail holds operations of it
+	if (!ctx) return 0;
+	for (int i = 0; i < SLOTS; i++) {
+		Slot& s = g_slots[i];
+		if (s.live != RECORDED) continue;
+		if (s.ctx == ctx && s.device == device) return &s;
+		for (int k = 0; k < s.ntrail; k++) if (s.trail[k].ctx == ctx && s.trail[k].device == device) return &s;
+	}
+	return 0;
+}
+Slot* slot_with_signal(const ccv_nnc_stream_signal_t* const signal)
+{
+	for (int i = 0; i < SLOTS; i++) {
+		Slot& s = g_slots[i];
+		if (s.live != RECORDED) continue;
+		for (int k = 0; k < s.ntrail; k++) if (s.trail[k].op != OP_CMD && s.trail[k].signal == signal) return &s;
+	}
+	return 0;
+}
+bool trailing_on() { static const int on = !(getenv("NNC_MI355X_PEEPHOLE_TRAIL") && *getenv("NNC_MI355X_PEEPHOLE_TRAIL") == '0'); return on; }
+}
+
+// ccv_nnc_stream_compat_emit_signal / _wait_signal (device_rt.cpp) ask here first.  true: the operation waits in a trail (it will run behind the recorded
+// command it follows); false: the caller performs it now -- whatever had to go first has been launched.
+bool deferred_signal_op(const int emit, const ccv_nnc_stream_context_t* const ctx, const ccv_nnc_stream_signal_t* const signal)
+{
+	if (!g_deferred_live || tl_running) return false;
+	Lock lock(g_mu);
+	if (!ctx || !trailing_on()) { lock.unlock(); deferred_flush(0); return false; }
+	const int device = device_for(ctx);
+	wait_launching(ctx, lock);
+	Slot* const by_stream = slot_with_stream(ctx, device);
+	Slot* const by_signal = slot_with_signal(signal);
+	if (!by_stream && !by_signal) return false; // neither the stream nor the signal has anything to do with a recorded command
+	Slot* const s = by_stream ? by_stream : by_signal;
+	// an emit on a stream outside every trail that re-records a signal of a trail, an operation that would tie two recorded commands together, a full
+	// trail: decided the old way -- launch what is involved, then do it now
+	// (a WAIT on the recorded command's OWN stream is decided the old way too: the ReLU that would complete the command comes behind that wait and may need it)
+	const bool own_wait = !emit && by_stream && by_stream->ctx == ctx && by_stream->device == device;
+	if ((emit && !by_stream) || own_wait || (by_stream && by_signal && by_stream != by_signal) || s->ntrail >= TRAIL_MAX) {
+		if (by_stream) run(*by_stream, 0, lock, false);
+		if (by_signal && by_signal != by_stream && by_signal->live == RECORDED) run(*by_signal, 0, lock, false);
+		return false;
+	}
+	TrailOp& t = s->trail[s->ntrail++];
+	t.op = emit ? OP_EMIT : OP_WAIT;
+	t.ctx = (ccv_nnc_stream_context_t*)ctx; t.device = device; t.signal = signal;
+	++g_trailed;
+	return true;
+}
+
+// A command that may wait in a trail (SGD_FORWARD: its parameters have been checked by the caller, it allocates nothing) on a stream that already has
+// operations in one: kept behind them.  false: the caller launches it now (its stream_of flushes whatever orders against the stream).
+bool deferred_trail_cmd(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
+{
+	if (!g_deferred_live || tl_running || !ctx || input_size > TRAIL_IO || output_size > TRAIL_IO || !trailing_on()) return false;
+	Lock lock(g_mu);
+	const int device = device_for(ctx);
+	wait_launching(ctx, lock);
+	Slot* const s = slot_with_stream(ctx, device);
+	if (!s || (s->ctx == ctx && s->device == device) || s->ntrail >= TRAIL_MAX) return false; // (on the recorded command's own stream only its ReLU may follow)
+	for (int i = 0; i < SLOTS; i++) // ... and in no other trail
+		if (&g_slots[i] != s && g_slots[i].live == RECORDED && in_trail(g_slots[i], ctx)) return false;
+	TrailOp& t = s->trail[s->ntrail++];
+	t.op = OP_CMD; t.ctx = ctx; t.device = device; t.signal = 0;
+	t.fn = fn; t.cmd = cmd; t.hint = hint; t.flags = flags; t.nin = input_size; t.nout = output_size;
+	for (int i = 0; i < input_size; i++) keep(&t.in[i], &t.has_in[i], inputs[i]);
+	for (int i = 0; i < output_size; i++) keep(&t.out[i], &t.has_out[i], outputs[i]);
+	++g_trailed;
+	return true;
+}
+
 void deferred_flush(const ccv_nnc_stream_context_t* const ctx)
 {
 	if (tl_running) return;
@@ -331,6 +471,12 @@ extern "C" void nnc_mi355x_set_peephole(const int on)
 {
 	nnc::deferred_flush(0);
 	nnc::g_enabled = on ? 1 : 0;
+}
+
+extern "C" long nnc_mi355x_debug_peephole_trailed(void)
+{
+	std::lock_guard<std::recursive_mutex> lock(nnc::g_mu);
+	return nnc::g_trailed;
 }
 
 extern "C" void nnc_mi355x_debug_peephole_launch_delay_us(const int us) { nnc::g_debug_launch_delay_us = us; }

@@ -604,16 +604,20 @@ class Lib:
     """A loaded implementation of the command interface."""
     _EXEC_ARGS = [Cmd, Hint, C.c_int, C.POINTER(C.POINTER(TensorStruct)), C.c_int, C.POINTER(C.POINTER(TensorStruct)), C.c_int, C.c_void_p]
 
-    def __init__(self, path, kind):
+    def __init__(self, path, kind="mi355x"):
+        # This package loads the MI355X backend (or the CPU emulator build of the same sources in the test tier) and nothing else: the checker
+        # libraries -- the reference's CPU backend, the C restatement -- are loaded by tests/oracle_bind.py (CheckerLib), outside the product.
+        if kind != "mi355x":
+            raise ValueError("ccv_amd.nnc.Lib loads libnnc_mi355x.so only; checker libraries: tests/oracle_bind.py")
         self.path, self.kind = path, kind
-        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL if kind != "oracle" else C.RTLD_LOCAL)
+        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self._bind()
+        self._exec.restype = C.c_int
+        self._exec.argtypes = self._EXEC_ARGS
+
+    def _bind(self):
         d = self.dll
-        if kind == "reference":
-            d.ccv_nnc_init()
-            self._exec = d.ccv_nnc_cmd_exec
-        elif kind == "oracle":  # oracle/libnnc_oracle.so: CPU tensors only, no device runtime
-            self._exec = d.nnc_oracle_cmd_exec
-        else:
+        if True:
             self._exec = d.nnc_mi355x_cmd_exec
             d.nnc_mi355x_malloc.restype = C.c_void_p
             d.nnc_mi355x_malloc.argtypes = [C.c_int, C.c_size_t]
@@ -641,8 +645,6 @@ class Lib:
             d.nnc_mi355x_lstm_reserve_space_size.restype = C.c_size_t
             d.nnc_mi355x_lstm_reserve_space_size.argtypes = [Cmd, C.c_int, C.c_int, C.c_int, C.c_int]
             d.nnc_mi355x_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)]
-        self._exec.restype = C.c_int
-        self._exec.argtypes = self._EXEC_ARGS
 
     # device runtime (product / emulator only)
     def malloc(self, device, size): return self.dll.nnc_mi355x_malloc(device, size)

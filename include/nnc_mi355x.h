@@ -6,7 +6,7 @@
  *
  *   1. ABI mirrors of the reference's plugin-surface structs.  They are re-stated here
  *      (field order / sizes identical, only the members this path touches are named) so the
- *      library builds without the reference tree.  tests/test_abi_layout.py compiles a
+ *      library builds without the reference tree.  tests/test_abi.py compiles a
  *      sizeof/offsetof probe against the real headers whenever /root/reference is present.
  *        ccv_nnc_tensor_param_t / ccv_nnc_tensor_t / ccv_nnc_tensor_view_t
  *                                         <- lib/nnc/ccv_nnc_tfb.h:79-111
@@ -26,7 +26,7 @@
  *   3. The device "compat" ABI the unmodified host .c files call for memory, streams,
  *      events and workspace (lib/nnc/gpu/ccv_nnc_compat.h:23-59).  Native names are
  *      nnc_mi355x_*; the reference-spelled aliases (cumalloc, ...) live in
- *      ccv_amd/csrc/ref_abi_aliases.cpp and simply forward.
+ *      ccv_amd/csrc/ref_host_abi.cpp and simply forward.
  *
  *   4. A standalone dispatch (nnc_mi355x_cmd_exec) mirroring ccv_nnc_cmd_exec
  *      (lib/nnc/ccv_nnc_cmd.c:651-693) for callers that do not link the reference host

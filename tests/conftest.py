@@ -59,7 +59,8 @@ def ref_lib():
             subprocess.check_call([os.path.join(ROOT, "oracle", "build_ref.sh")])
         else:
             pytest.skip("oracle/_ref/libccv_ref.so not built and /root/reference absent")
-    return nnc.Lib(p, "reference")
+    from oracle_bind import CheckerLib
+    return CheckerLib(p, "reference")
 
 
 def pytest_generate_tests(metafunc):

@@ -17,7 +17,8 @@ from golden_cases import CASES, build_case, run_case  # noqa: E402
 
 
 def main():
-    R = nnc.Lib(os.path.join(ROOT, "oracle", "_ref", "libccv_ref.so"), "reference")
+    from oracle_bind import CheckerLib
+    R = CheckerLib(os.path.join(ROOT, "oracle", "_ref", "libccv_ref.so"), "reference")
     out = {}
     for name in CASES:
         case = build_case(name)

@@ -362,3 +362,79 @@ def test_foreign_thread_flush_does_not_let_the_relu_overtake(lib, ref_lib):
     finally:
         lib.dll.nnc_mi355x_debug_peephole_launch_delay_us(0)
         lib.stream_free(stream)
+
+
+def _host_schedule_step(lib, tensors, streams, sigs, k, c, hint, interloper=None):
+    """One CONVOLUTION_BACKWARD node the way the reference's static schedule issues it (lib/nnc/ccv_nnc_graph_run.c:581-675; the order NNC_MI355X_SYNC_TRACE=1
+    shows for tools/host_vgg_bench.c): the command on stream A, the emit of the signal its two SGD_FORWARD commands wait for, those waits / updates / emits on
+    streams X and Y, then the in-place RELU_BACKWARD on A, then A waits for both updates."""
+    gt, at, wtt, ht, dwt, dbt, mw, mb, bt = tensors
+    A, X, Y = streams
+    S, Sx, Sy = sigs
+    cmd, relub = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c), nnc.CMD_RELU_BACKWARD()
+    sgd = nnc.CMD_SGD_FORWARD(0, 0.01, 0.5, 0.0005, 0.9, 0.9)
+    assert lib.cmd_exec(cmd, hint, 0, [gt, at, wtt], [ht, dwt, dbt], A) == 0
+    lib.signal_emit(A, S)
+    lib.signal_wait(X, S)
+    assert lib.cmd_exec(sgd, nnc.NO_HINT, 0, [dwt, wtt, mw], [wtt, mw], X) == 0
+    lib.signal_emit(X, Sx)
+    if interloper:
+        interloper()
+    lib.signal_wait(Y, S)
+    assert lib.cmd_exec(sgd, nnc.NO_HINT, 0, [dbt, bt, mb], [bt, mb], Y) == 0
+    lib.signal_emit(Y, Sy)
+    assert lib.cmd_exec(relub, nnc.NO_HINT, 0, [ht, None, at], [ht], A) == 0
+    lib.signal_wait(A, Sx)
+    lib.signal_wait(A, Sy)
+
+
+@pytest.mark.parametrize("interlope", ["none", "copy", "command_on_update_stream"])
+def test_relu_backward_folds_across_the_schedules_signal_and_update_operations(lib, interlope):
+    """Round 5: the emit / waits / SGD commands / emits the host issues between a CONVOLUTION_BACKWARD and its RELU_BACKWARD wait in
+    the recorded command's trail and are replayed behind it in arrival order -- the pair folds, and gradient, updated parameters and momenta are bit-identical to
+    the same sequence with the look-ahead switched off.  A read-back in the middle, or another command on an update stream, launches everything first (no fold,
+    same numbers)."""
+    rng = np.random.default_rng(21)
+    n, h, w, c, k = 2, 11, 12, 16, 32
+    hint = nnc.HINT((1, 1), (1, 1))
+    a = np.maximum(srnd(rng, n, h, w, c), 0)
+    a[rng.random(a.shape) < 0.4] = 0
+    g, wt, b = srnd(rng, n, h, w, k), srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c)), srnd(rng, k, scale=0.05)
+    trailed = getattr(lib.dll, "nnc_mi355x_debug_peephole_trailed")
+    trailed.restype = C.c_long
+    streams = [lib.stream_new(0) for _ in range(3)]
+    sigs = [lib.signal_new(0) for _ in range(3)]
+    results = {}
+    try:
+        for mode in ("off", "on"):
+            lib.dll.nnc_mi355x_set_peephole(1 if mode == "on" else 0)
+            tensors = make_tensors(lib, nnc.GPU_MEMORY, [g, a, wt, np.full_like(a, 7), np.zeros_like(wt), np.zeros(k, F), np.zeros_like(wt), np.zeros(k, F), b])
+            (scratch,) = make_tensors(lib, nnc.GPU_MEMORY, [np.ones(64, F)])
+            interloper = None
+            if interlope == "copy":
+                interloper = lambda: scratch.numpy()                                                                    # noqa: E731 (a device-to-host copy observes every stream)
+            elif interlope == "command_on_update_stream":
+                interloper = lambda: lib.cmd_exec(nnc.CMD_SET_FORWARD(3), nnc.NO_HINT, 0, [], [scratch], streams[1])  # noqa: E731 (stream X has operations in the trail)
+            for trip in range(3):  # trip 0: the signatures' first occurrence runs on the spot
+                r0, f0, p0 = counts(lib)
+                t0 = trailed()
+                _host_schedule_step(lib, tensors, streams, sigs, k, c, hint, interloper)
+                for s in streams:
+                    lib.stream_wait(s)
+                if mode == "on" and trip > 0:
+                    dr, df, dp = (x - y for x, y in zip(counts(lib), (r0, f0, p0)))
+                    assert dr == 1
+                    if interlope == "none":
+                        assert (df, dp) == (1, 0) and trailed() - t0 == 7, (df, dp, trailed() - t0)
+                    else:
+                        assert (df, dp) == (0, 1)
+            results[mode] = [t.numpy().copy() for t in tensors[3:]]
+        for x, y in zip(results["off"], results["on"]):
+            assert np.array_equal(x, y)
+        assert (results["on"][0] == 0).any() and (results["on"][0] != 0).any()
+    finally:
+        lib.dll.nnc_mi355x_set_peephole(1)
+        for s in streams:
+            lib.stream_free(s)
+        for s in sigs:
+            lib.signal_free(s)

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 (rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|Power|fclk|mclk") > gpurun_out/clock_idle.txt
-python bench.py --steps 30 --warmup 2 --no-cpu-baseline > gpurun_out/clock_bench.log 2>&1 &
+python bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-extra-configs > gpurun_out/clock_bench.log 2>&1 &
 BPID=$!
 : > gpurun_out/clock_samples.txt
 for i in $(seq 1 60); do

@@ -32,9 +32,9 @@ for step in "$@"; do
     box) (rocminfo | grep -E "Marketing Name|gfx" | head -4; nproc; free -g | head -2) > gpurun_out/box.txt 2>&1; cat gpurun_out/box.txt;;
     tests) timeout ${TESTS_TIMEOUT:-1800} python -m pytest tests -m gpu -q -p no:cacheprovider ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; tail -6 gpurun_out/pytest_gpu.log;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log; tail -3 gpurun_out/smoke.log;;
-    bench) timeout 900 python bench.py --steps $STEPS --warmup 2 --records gpurun_out/records.txt ${BENCH_ARGS} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?" >> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err;;
+    bench) timeout 1800 python bench.py --steps $STEPS --warmup 2 --records gpurun_out/records.txt ${BENCH_ARGS} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?" >> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err;;
     config:*) n=${step#config:}; timeout 1500 python bench.py --config $n --steps $STEPS --warmup 2 ${BENCH_ARGS} > gpurun_out/bench_$n.json 2> gpurun_out/bench_$n.err; echo "exit $?" >> gpurun_out/bench_$n.err; cut -c1-1500 gpurun_out/bench_$n.json; tail -3 gpurun_out/bench_$n.err;;
-    prof) prof_cmd vgg python "$PWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-via-host --no-alt-leg ${PROF_ARGS}; cp gpurun_out/kernel_stats_vgg.md gpurun_out/kernel_stats.md 2>/dev/null; head -40 gpurun_out/kernel_stats.md;;
+    prof) prof_cmd vgg python "$PWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-via-host --no-alt-leg --no-extra-configs ${PROF_ARGS}; cp gpurun_out/kernel_stats_vgg.md gpurun_out/kernel_stats.md 2>/dev/null; head -40 gpurun_out/kernel_stats.md;;
     prof:*) n=${step#prof:}; prof_cmd $n python "$PWD/bench.py" --config $n --steps 2 --warmup 1 --no-cpu-baseline ${PROF_ARGS}; head -40 gpurun_out/kernel_stats_$n.md;;
     profhost) NNC_MI355X_PEEPHOLE_STATS=1 prof_cmd host "$PWD/oracle/_ref/host_vgg_bench.gpu" 256 225 4 1; cp gpurun_out/kernel_stats_host.md gpurun_out/via_host_kernel_stats.md 2>/dev/null; grep -i "look-ahead" gpurun_out/prof_host.log;;
     pmc) timeout 2400 tools/pmc_pass.sh;;

@@ -7,7 +7,9 @@
  * scheduler) and runs it on the MI355X backend.  Everything above ccv_nnc_cmd_exec is the reference's unmodified code;
  * this file is the benchmark driver only.  Built by oracle/build_ref_host.sh against libccv_host_gpu.so (and against the CPU
  * emulator build for the small-size test of the CPU tier).
- *   host_vgg_bench.gpu <batch> <input hw> <steps> <warmup> [mini]     -> one JSON line
+ *   host_vgg_bench.gpu <batch> <input hw> <steps> <warmup> [mini|full] [fwd]     -> one JSON line
+ * "fwd": the forward graph alone (BASELINE config 2; the node sequence of test/int/nnc/symbolic.graph.vgg.d.tests.c:14-90 /
+ * graph.vgg.d.tests.c:14-90 on a synthetic image instead of the PNG): no minimize, the loss tensor kept, autotune, static schedule.
  * Weights / images / labels come from the counter hash below, which ccv_amd/vgg.py reproduces (init="hash"): bench.py runs
  * both drivers on the same numbers and compares losses and updated parameters. */
 #include <ccv.h>
@@ -46,6 +48,7 @@ int main(int argc, char** argv)
 	const int batch = argc > 1 ? atoi(argv[1]) : 256, hw0 = argc > 2 ? atoi(argv[2]) : 225;
 	const int steps = argc > 3 ? atoi(argv[3]) : 4, warmup = argc > 4 ? atoi(argv[4]) : 1;
 	const int use_mini = argc > 5 && strcmp(argv[5], "mini") == 0;
+	const int fwd_only = (argc > 5 && strcmp(argv[5], "fwd") == 0) || (argc > 6 && strcmp(argv[6], "fwd") == 0);
 	const int* const layers = use_mini ? mini : vgg_d;
 	const int nlayers = use_mini ? (int)(sizeof(mini) / sizeof(int)) : (int)(sizeof(vgg_d) / sizeof(int));
 	ccv_nnc_init();
@@ -105,19 +108,24 @@ int main(int argc, char** argv)
 	const int aux_size = ccv_nnc_minimizer_saved_aux_size(sgd);
 	ccv_nnc_tensor_symbol_map_t* const saved_aux = (ccv_nnc_tensor_symbol_map_t*)malloc(sizeof(ccv_nnc_tensor_symbol_map_t) * aux_size * nparams);
 	ccv_nnc_graph_exec_symbol_t update_execs[MAXP];
-	ccv_nnc_symbolic_graph_minimize(sg, sgd, TENSOR_SYMBOL_LIST(loss), params, nparams, 0, 0, SYMBOLIC_GRAPH_SOURCES(sg), SYMBOLIC_GRAPH_DESTINATIONS(sg), gradients, updated, saved_aux, update_execs);
-	const ccv_nnc_tensor_symbol_t dloss = ccv_nnc_tensor_symbol_for_backward(sg, loss);
-	ccv_nnc_graph_exec_symbol_new(sg, CMD_SET_FORWARD(1), TENSOR_SYMBOL_LIST(), TENSOR_SYMBOL_LIST(dloss), "set 1");
-	ccv_nnc_graph_exec_symbol_autogen(sg, 0, 0, CCV_NNC_AUTOGEN_ALL_EXECS | CCV_NNC_AUTOGEN_SOURCES_AND_DESTINATIONS);
+	if (!fwd_only) {
+		ccv_nnc_symbolic_graph_minimize(sg, sgd, TENSOR_SYMBOL_LIST(loss), params, nparams, 0, 0, SYMBOLIC_GRAPH_SOURCES(sg), SYMBOLIC_GRAPH_DESTINATIONS(sg), gradients, updated, saved_aux, update_execs);
+		const ccv_nnc_tensor_symbol_t dloss = ccv_nnc_tensor_symbol_for_backward(sg, loss);
+		ccv_nnc_graph_exec_symbol_new(sg, CMD_SET_FORWARD(1), TENSOR_SYMBOL_LIST(), TENSOR_SYMBOL_LIST(dloss), "set 1");
+		ccv_nnc_graph_exec_symbol_autogen(sg, 0, 0, CCV_NNC_AUTOGEN_ALL_EXECS | CCV_NNC_AUTOGEN_SOURCES_AND_DESTINATIONS);
+	}
 	ccv_nnc_graph_t* graph;
 	ccv_nnc_tensor_arena_t* arena;
 	ccv_nnc_graph_exec_arena_t* exec_arena;
 	/* outputs kept alive: the updated parameters, the loss and every momentum source / destination */
-	ccv_nnc_tensor_symbol_t keep[MAXP * 3 + 2];
+	ccv_nnc_tensor_symbol_t keep[MAXP * 3 + 3];
 	int nkeep = 0;
-	for (i = 0; i < nparams; i++) keep[nkeep++] = updated[i];
-	for (i = 0; i < aux_size * nparams; i++) keep[nkeep++] = saved_aux[i].destination;
+	if (!fwd_only) {
+		for (i = 0; i < nparams; i++) keep[nkeep++] = updated[i];
+		for (i = 0; i < aux_size * nparams; i++) keep[nkeep++] = saved_aux[i].destination;
+	}
 	keep[nkeep++] = loss;
+	keep[nkeep++] = softmax;
 	ccv_nnc_symbolic_graph_compile(sg, ccv_nnc_default_compile_params, 0, 0, keep, nkeep, SYMBOLIC_GRAPH_SOURCES(sg), SYMBOLIC_GRAPH_DESTINATIONS(sg), &graph, &arena, &exec_arena);
 	/* data: parameters, momenta, images, labels */
 	uint64_t stream_id = 0;
@@ -136,7 +144,7 @@ int main(int argc, char** argv)
 		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(host), TENSOR_LIST(dev), 0);
 		ccv_nnc_tensor_free(host);
 	}
-	for (i = 0; i < aux_size * nparams; i++)
+	for (i = 0; !fwd_only && i < aux_size * nparams; i++)
 		ccv_nnc_cmd_exec(CMD_SET_FORWARD(0), ccv_nnc_no_hint, 0, TENSOR_LIST(), TENSOR_LIST(ccv_nnc_tensor_from_symbol(arena, saved_aux[i].source)), 0);
 	{
 		ccv_nnc_tensor_t* const host = ccv_nnc_tensor_new(0, CPU_TENSOR_NHWC(32F, batch, hw0, hw0, 3), 0);
@@ -161,7 +169,7 @@ int main(int argc, char** argv)
 	ccv_nnc_tensor_t* const hloss = ccv_nnc_tensor_new(0, CPU_TENSOR_NHWC(32F, batch), 0);
 	ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(ccv_nnc_tensor_from_symbol(arena, loss)), TENSOR_LIST(hloss), 0);
 	double psum[MAXP], psq[MAXP];
-	for (i = 0; i < nparams; i++) {
+	for (i = 0; !fwd_only && i < nparams; i++) {
 		ccv_nnc_tensor_t* const dev = ccv_nnc_tensor_from_symbol(arena, updated[i]);
 		ccv_nnc_tensor_param_t info = dev->info;
 		info.type = CCV_TENSOR_CPU_MEMORY;
@@ -180,12 +188,27 @@ int main(int argc, char** argv)
 	for (i = 0; i < steps; i++) ccv_nnc_graph_run_with_schedule(graph, 0, 0, 0, stream);
 	ccv_nnc_stream_context_wait(stream);
 	const double ms = (now_ms() - t0) / (steps > 0 ? steps : 1);
-	printf("{\"driver\": \"reference host (symbolic graph, minimize, compile, autotune, static schedule)\", \"batch\": %d, \"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"autotune_ms\": %.1f, \"loss\": [", batch, ms, batch / (ms * 1e-3), t_tune);
+	/* forward only: the softmax rows of the first images, for the parity check against the command driver / the CPU reference */
+	double softmax_row_sum_err = 0;
+	float top_prob = 0;
+	if (fwd_only) {
+		ccv_nnc_tensor_t* const hs = ccv_nnc_tensor_new(0, CPU_TENSOR_NHWC(32F, batch, classes), 0);
+		ccv_nnc_cmd_exec(CMD_DATA_TRANSFER_FORWARD(), ccv_nnc_no_hint, 0, TENSOR_LIST(ccv_nnc_tensor_from_symbol(arena, softmax)), TENSOR_LIST(hs), 0);
+		int b, k;
+		for (b = 0; b < batch; b++) {
+			double s = 0;
+			for (k = 0; k < classes; k++) { s += hs->data.f32[b * classes + k]; if (b == 0 && hs->data.f32[k] > top_prob) top_prob = hs->data.f32[k]; }
+			if (fabs(s - 1) > softmax_row_sum_err) softmax_row_sum_err = fabs(s - 1);
+		}
+		ccv_nnc_tensor_free(hs);
+	}
+	printf("{\"driver\": \"reference host (symbolic graph, %scompile, autotune, static schedule)\", \"forward_only\": %d, \"softmax_worst_row_sum_err\": %.3g, \"image0_top_prob\": %.9g, \"batch\": %d,", fwd_only ? "" : "minimize, ", fwd_only, softmax_row_sum_err, top_prob, batch);
+	printf(" \"ms_per_step\": %.4f, \"images_per_s\": %.2f, \"autotune_ms\": %.1f, \"loss\": [", ms, batch / (ms * 1e-3), t_tune);
 	for (i = 0; i < batch && i < 8; i++) printf("%s%.9g", i ? ", " : "", hloss->data.f32[i]);
 	printf("], \"updated_param_sum\": [");
-	for (i = 0; i < nparams; i++) printf("%s%.12g", i ? ", " : "", psum[i]);
+	for (i = 0; !fwd_only && i < nparams; i++) printf("%s%.12g", i ? ", " : "", psum[i]);
 	printf("], \"updated_param_sumsq\": [");
-	for (i = 0; i < nparams; i++) printf("%s%.12g", i ? ", " : "", psq[i]);
+	for (i = 0; !fwd_only && i < nparams; i++) printf("%s%.12g", i ? ", " : "", psq[i]);
 	printf("]}\n");
 	ccv_nnc_tensor_free(hloss);
 	ccv_nnc_graph_free(graph);

@@ -11,7 +11,7 @@ GROUPS_WANTED=${PMC_GROUPS:-mfma wait inst lds fetch write l2}
 run_pass() {
   name=$1; shift
   case " $GROUPS_WANTED " in *" $name "*) ;; *) return;; esac
-  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $OLDPWD/bench.py ${PMC_BENCH_ARGS:---steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-via-host --no-alt-leg} > $OUT/$name.log 2>&1; echo "exit $?" >> $OUT/$name.log)
+  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $OLDPWD/bench.py ${PMC_BENCH_ARGS:---steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-via-host --no-alt-leg --no-extra-configs} > $OUT/$name.log 2>&1; echo "exit $?" >> $OUT/$name.log)
 }
 run_pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE
 run_pass wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES
