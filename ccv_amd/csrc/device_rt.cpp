@@ -374,6 +374,9 @@ void nnc_mi355x_set_device(int device)
 	if (device >= 0) HIP_ENFORCE(hipSetDevice(device));
 }
 
+// (Round 5 measured a chunked, pinned, overlapped path for large PAGEABLE copies here -- what ccv_nnc_tensor_write / _read, lib/nnc/ccv_nnc_tensor_io.c:28-133,
+// and DATA_TRANSFER of CPU tensors go through -- against the runtime's blocking copy: the runtime moves pageable memory at 52 - 57 GB/s either way on this box
+// (PCIe Gen5 x16's practical rate), the hand-made ring reached 34 - 51.  profiles/r05_v1_memcpy_pageable.txt; tools/memcpy_bench.py.  Nothing to build.)
 void nnc_mi355x_memcpy(void* dest, const int dest_type, const void* src, const int src_type, size_t n)
 {
 	nnc::comm_flush_if_pending();

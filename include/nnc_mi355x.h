@@ -404,6 +404,11 @@ size_t nnc_mi355x_lstm_reserve_space_size(const ccv_nnc_cmd_t cmd, int datatype,
 void nnc_mi355x_set_peephole(int on);
 /* Test hook: commands recorded so far, how many of them a ReLU completed (folded), how many were launched as they were (plain). */
 void nnc_mi355x_debug_peephole_counts(long* recorded, long* folded, long* plain);
+/* The look-ahead's TRAIL (round 5): the reference's static schedule issues the signal emit behind a CONVOLUTION_BACKWARD, the waits of the layer's two
+ * SGD_FORWARD streams, those commands and their emits BEFORE the RELU_BACKWARD that completes the convolution (lib/nnc/ccv_nnc_graph_run.c:581-675).  Such
+ * operations are kept behind the recorded command, in arrival order, and replayed right behind it when it launches; nothing else can observe the difference
+ * (peephole.cpp).  NNC_MI355X_PEEPHOLE_TRAIL=0 restores the flush at the first of them.  Test hook: operations that have waited in a trail so far. */
+long nnc_mi355x_debug_peephole_trailed(void);
 /* batch-norm commands that ran on the cluster kernels (cmd_norm.cpp: a cluster of workgroups per channel keeps the channel in registers between the
  * statistics and the apply pass; NNC_MI355X_BN_CLUSTER=0 / nnc_mi355x_tune_set("BN_CLUSTER", 0) selects the plane kernels). */
 long nnc_mi355x_debug_bn_cluster_launches(void);
