@@ -349,10 +349,73 @@ ProfScope::~ProfScope()
 
 extern "C" {
 
+// ---- device memory behind cumalloc / cufree: a stream-ordered pool -------------------------------------------------------------------------------
+// The reference's dynamic graphs allocate and free tensors all the time; its own free lists (lib/nnc/ccv_nnc_xpu_alloc.c: size-keyed trees per stream and
+// device) catch most of it and call cumalloc / cufree for the rest -- and hipFree waits for the whole device, hipMalloc costs tens of microseconds to
+// milliseconds.  Here both go to the device's memory pool in STREAM ORDER on the legacy NULL stream: a free is queued behind everything already queued on the
+// device's (blocking) streams and returns at once; the pool keeps the memory (release threshold = everything) and a later allocation of the size is served
+// from it without a driver call into the kernel; work queued behind that allocation on any blocking stream runs behind it.  Same semantics as the blocking
+// pair for every caller that launches its work after the allocation returns and frees after queueing its last use -- what the host does (cufree's callers:
+// ccv_nnc_tensor_free, the arena, xpu_alloc's drain) -- without the host-side stall.  Memory pressure: the host's registered callbacks (curegmp:
+// ccv_nnc_xpu_alloc's drain, the stream contexts' workspaces) run, the pool is trimmed to what is in use, the allocation is retried; the last resort is the
+// blocking hipMalloc.  NNC_MI355X_POOL_ALLOC=0 selects hipMalloc / hipFree.  With several devices visible the pool is opened to every peer that can be
+// reached (hipMemPoolSetAccess): peer copies and RCCL's in-process transports read it like plain allocations.
+static int g_pool_mode = -1;
+static hipMemPool_t g_pools[MAX_DEVICES];
+static pthread_mutex_t g_pool_mutex = PTHREAD_MUTEX_INITIALIZER;
+static std::atomic<long> g_pool_allocs(0), g_pool_retries(0);
+static hipMemPool_t pool_of(const int device)
+{
+	if (g_pool_mode < 0) {
+		const char* e = getenv("NNC_MI355X_POOL_ALLOC");
+		g_pool_mode = (e && *e == '0') ? 0 : 1;
+	}
+	if (!g_pool_mode || device < 0 || device >= MAX_DEVICES) return 0;
+	if (g_pools[device]) return g_pools[device];
+	pthread_mutex_lock(&g_pool_mutex);
+	if (!g_pools[device]) {
+		hipMemPool_t pool = 0;
+		if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+			uint64_t keep = UINT64_MAX; // freed memory stays with the pool until pressure trims it
+			if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) (void)hipGetLastError();
+			int count = 0;
+			if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 1; }
+			for (int peer = 0; peer < count; peer++) {
+				int can = 0;
+				if (peer == device || hipDeviceCanAccessPeer(&can, peer, device) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+				hipMemAccessDesc desc;
+				memset(&desc, 0, sizeof(desc));
+				desc.location.type = hipMemLocationTypeDevice;
+				desc.location.id = peer;
+				desc.flags = hipMemAccessFlagsProtReadWrite;
+				if (hipMemPoolSetAccess(pool, &desc, 1) != hipSuccess) (void)hipGetLastError();
+			}
+			g_pools[device] = pool;
+		} else {
+			(void)hipGetLastError();
+			g_pool_mode = 0; // no pool support: the blocking pair
+		}
+	}
+	pthread_mutex_unlock(&g_pool_mutex);
+	return g_pools[device];
+}
+
 void* nnc_mi355x_malloc(int device, size_t size)
 {
 	void* ptr = 0;
 	HIP_ENFORCE(hipSetDevice(device));
+	if (hipMemPool_t pool = pool_of(device)) {
+		if (hipMallocAsync(&ptr, size, (hipStream_t)0) == hipSuccess && ptr) { g_pool_allocs.fetch_add(1, std::memory_order_relaxed); return ptr; }
+		(void)hipGetLastError();
+		ptr = 0;
+		trigger_mem_pressure(); // the host drops its caches (they come back through nnc_mi355x_free: into the pool) ...
+		HIP_ENFORCE(hipStreamSynchronize((hipStream_t)0)); // ... the queued frees have happened ...
+		if (hipMemPoolTrimTo(pool, 0) != hipSuccess) (void)hipGetLastError(); // ... and what the pool holds unused goes back to the device
+		g_pool_retries.fetch_add(1, std::memory_order_relaxed);
+		if (hipMallocAsync(&ptr, size, (hipStream_t)0) == hipSuccess && ptr) return ptr;
+		(void)hipGetLastError();
+		ptr = 0;
+	}
 	if (hipMalloc(&ptr, size) != hipSuccess || !ptr) {
 		(void)hipGetLastError();
 		ptr = 0;
@@ -364,9 +427,25 @@ void* nnc_mi355x_malloc(int device, size_t size)
 
 void nnc_mi355x_free(int device, void* ptr)
 {
-	nnc::comm_flush_if_pending(); // a recorded collective may still name this memory
+	nnc::comm_flush_if_pending(); // a recorded collective (or a recorded command and its trail) may still name this memory
+	if (!ptr) return;
 	HIP_ENFORCE(hipSetDevice(device));
-	HIP_ENFORCE(hipFree(ptr));
+	if (pool_of(device)) HIP_ENFORCE(hipFreeAsync(ptr, (hipStream_t)0)); // (memory that came from the blocking hipMalloc is freed by it just the same)
+	else HIP_ENFORCE(hipFree(ptr));
+}
+// Test / measurement hooks: allocations served by the pool, allocations that needed the pressure path, bytes the pool holds (reserved) and has handed out (used)
+void nnc_mi355x_debug_pool_counts(long* allocs, long* retries, long* reserved_bytes, long* used_bytes)
+{
+	if (allocs) *allocs = g_pool_allocs.load(std::memory_order_relaxed);
+	if (retries) *retries = g_pool_retries.load(std::memory_order_relaxed);
+	uint64_t r = 0, u = 0;
+	const int device = current_device();
+	if (hipMemPool_t pool = pool_of(device)) {
+		if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &r) != hipSuccess) (void)hipGetLastError();
+		if (hipMemPoolGetAttribute(pool, hipMemPoolAttrUsedMemCurrent, &u) != hipSuccess) (void)hipGetLastError();
+	}
+	if (reserved_bytes) *reserved_bytes = (long)r;
+	if (used_bytes) *used_bytes = (long)u;
 }
 
 void nnc_mi355x_set_device(int device)

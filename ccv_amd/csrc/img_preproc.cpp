@@ -20,6 +20,7 @@
 // Here the same sum is computed directly, with the zero border everywhere.
 #include "common.h"
 #include <math.h>
+#include <pthread.h>
 #include <vector>
 
 using namespace nnc;
@@ -51,6 +52,66 @@ __global__ void __launch_bounds__(256) area_8u_kernel(const unsigned char* a, un
 		}
 		const unsigned v = acc / inv_scale_256;
 		b[img * b_image + (long)dy * b_step + e] = (unsigned char)(v > 255 ? 255 : v);
+	}
+}
+
+// The same arithmetic, ONE WORKGROUP PER OUTPUT ROW (round 5; VERDICT round 4 item 8: the kernel above is one lane per output byte with scalar byte gathers,
+// 0.45 TB/s on 256 x 480^2 -> 224^2).  uint32 sums are a ring: sum_y wy (sum_x wx a) = sum_x wx (sum_y wy a) bit for bit, overflow included, so the rows are
+// reduced FIRST -- every lane loads VEC bytes (16 when base and pitches allow, else 4) of each of the output row's source rows, coalesced, and leaves VEC
+// column sums in LDS -- and the horizontal taps then read LDS instead of gathering bytes through L2; four output bytes leave a lane as one dword.  A source row
+// is fetched once per output row that taps it (neighbouring rows' workgroups find it in L2).  The quotient acc / inv_scale_256 is at most a few hundred: a float
+// estimate corrected by one exact multiply-compare replaces the 32-bit division.  Needs: 4-byte aligned source rows and destination rows, channels 1 / 3 / 4.
+template <int CH, int VEC>
+__global__ void __launch_bounds__(128) area_8u_rows_kernel(const unsigned char* __restrict__ a, unsigned char* __restrict__ b, const long a_step, const long a_image, const long b_step, const long b_image,
+	const int b_rows, const int b_cols_ch, const int a_cols_ch, const int* __restrict__ xstart, const tap_u32_t* __restrict__ xtaps, const int* __restrict__ ystart, const tap_u32_t* __restrict__ ytaps, const unsigned inv_scale_256, const float inv_scale_rcp)
+{
+	HIP_DYNAMIC_SHARED(unsigned, area_v) // column sums of this output row: a_cols_ch of them (rounded up to whole lanes' worth)
+	const int dy = (int)(blockIdx.x % (unsigned)b_rows);
+	const size_t img = blockIdx.x / (unsigned)b_rows;
+	const unsigned char* const ai = a + img * a_image;
+	const int ky0 = ystart[dy], ky1 = ystart[dy + 1];
+	const int units = (a_cols_ch + VEC - 1) / VEC;
+	for (int u = (int)threadIdx.x; u < units; u += 128) {
+		unsigned acc[VEC];
+#pragma unroll
+		for (int j = 0; j < VEC; j++) acc[j] = 0;
+		for (int ky = ky0; ky < ky1; ky++) {
+			const unsigned char* const row = ai + (long)ytaps[ky].si * a_step + (long)u * VEC;
+			const unsigned w = ytaps[ky].w;
+			if (VEC == 16) {
+				const uint4 q = *(const uint4*)row; // (a row's last unit may reach up to 15 bytes into the next row -- or past a 16-byte multiple of the buffer never: pitches are multiples of 16)
+				const unsigned d[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+				for (int j = 0; j < 16; j++) acc[j] += ((d[j >> 2] >> (8 * (j & 3))) & 0xffu) * w;
+			} else {
+				const unsigned q = *(const unsigned*)row;
+#pragma unroll
+				for (int j = 0; j < 4; j++) acc[j] += ((q >> (8 * j)) & 0xffu) * w;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < VEC; j += 4) *(uint4*)(area_v + u * VEC + j) = uint4{ acc[j], acc[j + 1], acc[j + 2], acc[j + 3] };
+	}
+	__syncthreads();
+	unsigned char* const brow = b + img * b_image + (long)dy * b_step;
+	for (int t4 = (int)threadIdx.x * 4; t4 < b_cols_ch; t4 += 128 * 4) {
+		unsigned packed = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int e = t4 + j;
+			if (e < b_cols_ch) {
+				const int dx = e / CH, c = e - dx * CH;
+				unsigned h = 0;
+				for (int kx = xstart[dx]; kx < xstart[dx + 1]; kx++) h += area_v[xtaps[kx].si + c] * xtaps[kx].w;
+				unsigned q = (unsigned)((float)h * inv_scale_rcp); // within one of h / inv_scale_256 (the quotient is < 2^16, the estimate's error < 2^-7)
+				const unsigned long long qd = (unsigned long long)q * inv_scale_256;
+				if (qd > h) q--;
+				else if (h - qd >= inv_scale_256) q++;
+				packed |= (q > 255 ? 255u : q) << (8 * j);
+			}
+		}
+		if (t4 + 4 <= b_cols_ch) *(unsigned*)(brow + t4) = packed;
+		else for (int j = 0; t4 + j < b_cols_ch; j++) brow[t4 + j] = (unsigned char)(packed >> (8 * j));
 	}
 }
 
@@ -444,6 +505,52 @@ __global__ void __launch_bounds__(256) one_hot_kernel(const int* labels, TO* out
 
 } // namespace
 
+// ---- the 8-bit area path's tap tables, per geometry, resident on the device (a few KB each; the least recently used of 16 gives way)
+namespace {
+struct area_tables_t { int a_rows, a_cols, b_rows, b_cols, ch, device, live; double sx, sy; char* dev; size_t oxs, oxt, oys, oyt; unsigned inv; unsigned long stamp; };
+area_tables_t g_area_tables[16];
+unsigned long g_area_stamp = 0;
+pthread_mutex_t g_area_mutex = PTHREAD_MUTEX_INITIALIZER;
+char* area_8u_tables(const int a_rows, const int a_cols, const int b_rows, const int b_cols, const int ch, const double sx, const double sy, size_t* oxs, size_t* oxt, size_t* oys, size_t* oyt, unsigned* inv)
+{
+	int device = 0;
+	HIP_ENFORCE(hipGetDevice(&device));
+	pthread_mutex_lock(&g_area_mutex);
+	area_tables_t* hit = 0;
+	area_tables_t* lru = &g_area_tables[0];
+	for (area_tables_t& e : g_area_tables) {
+		if (e.live && e.a_rows == a_rows && e.a_cols == a_cols && e.b_rows == b_rows && e.b_cols == b_cols && e.ch == ch && e.device == device && e.sx == sx && e.sy == sy) { hit = &e; break; }
+		if (!e.live || (lru->live && e.stamp < lru->stamp)) lru = &e;
+	}
+	if (!hit) {
+		std::vector<int> xs, ys;
+		std::vector<tap_u32_t> xt, yt;
+		area_x_taps<tap_u32_t, unsigned>(a_cols, b_cols, ch, sx, 256u, 256.0, xs, xt); // NB the reference's left tap uses 0x100 and the right one 256: the same number
+		area_y_taps_8u(a_rows, b_rows, sy, ys, yt);
+		*inv = (unsigned)(int)(sx * sy * 0x10000);
+		if (*inv == 0) { pthread_mutex_unlock(&g_area_mutex); return 0; }
+		upload_t u;
+		area_tables_t e;
+		e.oxs = u.add(xs.data(), xs.size() * sizeof(int)); e.oxt = u.add(xt.data(), xt.size() * sizeof(tap_u32_t)); e.oys = u.add(ys.data(), ys.size() * sizeof(int)); e.oyt = u.add(yt.data(), yt.size() * sizeof(tap_u32_t));
+		e.dev = (char*)nnc_mi355x_malloc(device, u.host.size());
+		if (!e.dev) { *inv = 1; pthread_mutex_unlock(&g_area_mutex); return 0; }
+		HIP_ENFORCE(hipMemcpy(e.dev, u.host.data(), u.host.size(), hipMemcpyHostToDevice)); // (once per geometry)
+		if (lru->live) { // queued kernels may still read it: the free is stream-ordered behind them (or waits for the device)
+			nnc_mi355x_free(lru->device, lru->dev);
+			HIP_ENFORCE(hipSetDevice(device));
+		}
+		e.a_rows = a_rows; e.a_cols = a_cols; e.b_rows = b_rows; e.b_cols = b_cols; e.ch = ch; e.device = device; e.live = 1; e.sx = sx; e.sy = sy; e.inv = *inv;
+		*lru = e;
+		hit = lru;
+	}
+	hit->stamp = ++g_area_stamp;
+	*oxs = hit->oxs; *oxt = hit->oxt; *oys = hit->oys; *oyt = hit->oyt; *inv = hit->inv;
+	char* const dev = hit->dev;
+	pthread_mutex_unlock(&g_area_mutex);
+	return dev;
+}
+}
+
 extern "C" {
 
 int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, void* b, const nnc_mi355x_image_batch_t bd, const int count, const double rows_scale, const double cols_scale, const int type, ccv_nnc_stream_context_t* const stream_context)
@@ -467,16 +574,27 @@ int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, 
 	if ((type & 0x01 /* CCV_INTER_AREA */) && ad.rows >= bd.rows && ad.cols >= bd.cols) {
 		if (adt == CCV_8U && bdt == CCV_8U && (long)ad.rows * ad.cols / ((long)bd.rows * bd.cols) < 0x100) {
 			if (ch > 4) return CCV_NNC_EXEC_INVALID; // the reference clamps the channel count to 4 on this path (:14)
-			std::vector<int> xs, ys;
-			std::vector<tap_u32_t> xt, yt;
-			area_x_taps<tap_u32_t, unsigned>(ad.cols, bd.cols, ch, scale_x, 256u, 256.0, xs, xt);
-			// NB the reference's left tap uses 0x100 and the right one 256: the same number
-			area_y_taps_8u(ad.rows, bd.rows, scale_y, ys, yt);
-			const unsigned inv_scale_256 = (unsigned)(int)(scale_x * scale_y * 0x10000);
-			if (inv_scale_256 == 0) return CCV_NNC_EXEC_INVALID;
-			const size_t oxs = u.add(xs.data(), xs.size() * sizeof(int)), oxt = u.add(xt.data(), xt.size() * sizeof(tap_u32_t)), oys = u.add(ys.data(), ys.size() * sizeof(int)), oyt = u.add(yt.data(), yt.size() * sizeof(tap_u32_t));
-			char* dev = upload(u, stream_context);
-			if (!dev) return CCV_NNC_EXEC_OOM;
+			// the tap tables depend on the geometry alone: built once per (sizes, channels, scales, device) and kept on the device -- a loader resamples
+			// thousands of batches to the same size, and the host-side building + upload used to be part of every call
+			size_t oxs, oxt, oys, oyt;
+			unsigned inv_scale_256;
+			char* const dev = area_8u_tables(ad.rows, ad.cols, bd.rows, bd.cols, ch, scale_x, scale_y, &oxs, &oxt, &oys, &oyt, &inv_scale_256);
+			if (!dev) return inv_scale_256 == 0 ? CCV_NNC_EXEC_INVALID : CCV_NNC_EXEC_OOM;
+			// one workgroup per output row (area_8u_rows_kernel) when rows are dword-aligned on both sides and the row's column sums fit the LDS
+			const long a_cols_ch = (long)ad.cols * ch;
+			const bool al4 = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)ad.step | (uintptr_t)ad.image_stride | (uintptr_t)bd.step | (uintptr_t)bd.image_stride) & 3) == 0;
+			const bool al16 = (((uintptr_t)a | (uintptr_t)ad.step | (uintptr_t)ad.image_stride) & 15) == 0;
+			const size_t lds = (size_t)((a_cols_ch + 15) / 16 * 16) * sizeof(unsigned);
+			static const int rows_kernel = getenv("NNC_MI355X_RESAMPLE_ROWS") ? atoi(getenv("NNC_MI355X_RESAMPLE_ROWS")) : 1;
+			if (rows_kernel && al4 && (ch == 1 || ch == 3 || ch == 4) && lds <= 48 * 1024 && (long)count * bd.rows < 0x7fffffffL && ad.step >= a_cols_ch) {
+				const float rcp = (float)(1.0 / (double)inv_scale_256);
+				const dim3 g((unsigned)((long)count * bd.rows));
+#define AREA_ROWS(CH, VEC) hipLaunchKernelGGL(HIP_KERNEL_NAME(area_8u_rows_kernel<CH, VEC>), g, dim3(128), lds, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, (int)a_cols_ch, \
+					(const int*)(dev + oxs), (const tap_u32_t*)(dev + oxt), (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), inv_scale_256, rcp)
+				if (al16) { if (ch == 1) AREA_ROWS(1, 16); else if (ch == 3) AREA_ROWS(3, 16); else AREA_ROWS(4, 16); }
+				else { if (ch == 1) AREA_ROWS(1, 4); else if (ch == 3) AREA_ROWS(3, 4); else AREA_ROWS(4, 4); }
+#undef AREA_ROWS
+			} else
 			hipLaunchKernelGGL(area_8u_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, ch,
 				(const int*)(dev + oxs), (const tap_u32_t*)(dev + oxt), (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), inv_scale_256, total);
 		} else {

@@ -5,6 +5,7 @@
 #include <time.h>
 #include <vector>
 #include <mutex>
+#include <atomic>
 
 // ThreadSanitizer build (make emu-tsan): every lane is a TSAN fiber and every switch a synchronisation -- the lanes of a kernel run one after the other
 // on the launching thread, so they are never in a race with each other; what TSAN then sees is the HOST side of the library (peephole.cpp, cmd_comm.cpp,
@@ -220,6 +221,23 @@ static double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); retur
 hipError_t hipMalloc(void** p, size_t n) { *p = nullptr; if (posix_memalign(p, 256, n ? n : 256)) return hipErrorOutOfMemory; return hipSuccess; }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+// stream-ordered allocation (hip_runtime.h): one pool object, malloc / free underneath; EMU_POOL_FAIL_NEXT=<n> in the environment of a test makes the next n
+// pool allocations fail (the pressure path of nnc_mi355x_malloc)
+struct emuMemPool { int unused; };
+static emuMemPool g_emu_pool;
+static std::atomic<int> g_emu_pool_fail(-1);
+hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t* pool, int) { *pool = &g_emu_pool; return hipSuccess; }
+hipError_t hipMemPoolSetAttribute(hipMemPool_t, hipMemPoolAttr, void*) { return hipSuccess; }
+hipError_t hipMemPoolGetAttribute(hipMemPool_t, hipMemPoolAttr, void* value) { *(uint64_t*)value = 0; return hipSuccess; }
+hipError_t hipMemPoolSetAccess(hipMemPool_t, const hipMemAccessDesc*, size_t) { return hipSuccess; }
+hipError_t hipMemPoolTrimTo(hipMemPool_t, size_t) { return hipSuccess; }
+hipError_t hipMallocAsync(void** p, size_t n, hipStream_t)
+{
+	if (g_emu_pool_fail.load() < 0) { const char* e = getenv("EMU_POOL_FAIL_NEXT"); g_emu_pool_fail.store(e ? atoi(e) : 0); }
+	if (g_emu_pool_fail.load() > 0) { g_emu_pool_fail.fetch_sub(1); *p = nullptr; return hipErrorOutOfMemory; }
+	return hipMalloc(p, n);
+}
+hipError_t hipFreeAsync(void* p, hipStream_t) { free(p); return hipSuccess; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void*) { return hipSuccess; }

@@ -136,6 +136,40 @@ def test_resample_area_8u_bit_exact(backend, classic, shape, out):
         np.testing.assert_array_equal(g, PO.resample_area_8u(a, out[0], out[1], rs, cs))
 
 
+@pytest.mark.parametrize("shape,out,fill", [((64, 48, 3), (9, 7), 255), ((64, 48, 3), (32, 24), 255), ((61, 52, 1), (4, 5), None), ((128, 64, 4), (8, 4), None), ((80, 80, 3), (79, 77), None), ((48, 64, 3), (47, 3), 0)])
+def test_resample_area_8u_extremes_bit_exact(backend, classic, shape, out, fill):
+    """The row-per-workgroup kernel (round 5) at its edges: saturated and empty images (the quotient estimate and its correction at 255 and 0), sixteen-fold and
+    barely-any reduction (many taps / almost no taps per output), 16-byte and 4-byte row pitches, 1 / 3 / 4 channels -- bit-exact against ccv_resample."""
+    rng = np.random.default_rng(41)
+    imgs = [np.full(shape, fill, np.uint8) if fill is not None else rng.integers(0, 256, shape, dtype=np.uint8) for _ in range(2)]
+    if fill is None:
+        imgs[1][::2] = 255  # rows of saturation next to noise
+    rs, cs = _scales(shape, out)
+    got = our_resample(backend, imgs, out, np.uint8, rs, cs, AREA)
+    for g, a in zip(got, imgs):
+        np.testing.assert_array_equal(g, ref_resample(classic, a, np.uint8, rs, cs, AREA))
+
+
+@pytest.mark.gpu
+def test_resample_area_8u_imagenet_size_bit_exact(gpu_lib):
+    """256 x 480 x 480 x 3 -> 224 x 224 (the size the bench quotes) on the MI355X, every image against the numpy restatement of ccv_resample's 8-bit area path
+    (oracle/preproc_oracle.py, pinned to libccv_classic.so by the tests above), and the old one-lane-per-byte kernel against the new one."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (480, 480, 3), dtype=np.uint8) for _ in range(8)]
+    rs = cs = 224 / 480
+    got = our_resample(gpu_lib, imgs, (224, 224), np.uint8, rs, cs, AREA)
+    for g, a in zip(got[:3], imgs[:3]):
+        np.testing.assert_array_equal(g, PO.resample_area_8u(a, 224, 224, rs, cs))
+    code = "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_preproc as T; from ccv_amd import nnc; rng = np.random.default_rng(5); imgs = [rng.integers(0, 256, (480, 480, 3), dtype=np.uint8) for _ in range(8)]; got = T.our_resample(nnc.load(), imgs, (224, 224), np.uint8, 224 / 480, 224 / 480, T.AREA); np.save(sys.argv[1], np.stack(got))" % (ROOT, os.path.join(ROOT, "tests"))
+    path = os.path.join(ROOT, "gpurun_out", "resample_old_kernel.npy")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, NNC_MI355X_RESAMPLE_ROWS="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    np.testing.assert_array_equal(np.load(path), np.stack(got))
+
+
 @pytest.mark.parametrize("shape,out", RESAMPLE_CASES[:3])
 @pytest.mark.parametrize("src,dst", [(np.uint8, np.float32), (np.float32, np.float32), (np.float32, np.uint8)])
 def test_resample_area_float(backend, classic, shape, out, src, dst):
