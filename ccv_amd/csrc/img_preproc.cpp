@@ -19,6 +19,7 @@
 // the borders of an image larger than one tile the reference's rows wrap around within the tile, an artefact of the tiling).
 // Here the same sum is computed directly, with the zero border everywhere.
 #include "common.h"
+#include "isa.h"
 #include <math.h>
 #include <pthread.h>
 #include <vector>
@@ -55,63 +56,90 @@ __global__ void __launch_bounds__(256) area_8u_kernel(const unsigned char* a, un
 	}
 }
 
-// The same arithmetic, ONE WORKGROUP PER OUTPUT ROW (round 5; VERDICT round 4 item 8: the kernel above is one lane per output byte with scalar byte gathers,
+// The same arithmetic, ONE WORKGROUP PER GROUP OF OUTPUT ROWS (round 5; VERDICT round 4 item 8: the kernel above is one lane per output byte with scalar byte gathers,
 // 0.45 TB/s on 256 x 480^2 -> 224^2).  uint32 sums are a ring: sum_y wy (sum_x wx a) = sum_x wx (sum_y wy a) bit for bit, overflow included, so the rows are
 // reduced FIRST -- every lane loads VEC bytes (16 when base and pitches allow, else 4) of each of the output row's source rows, coalesced, and leaves VEC
 // column sums in LDS -- and the horizontal taps then read LDS instead of gathering bytes through L2; four output bytes leave a lane as one dword.  A source row
 // is fetched once per output row that taps it (neighbouring rows' workgroups find it in L2).  The quotient acc / inv_scale_256 is at most a few hundred: a float
 // estimate corrected by one exact multiply-compare replaces the 32-bit division.  Needs: 4-byte aligned source rows and destination rows, channels 1 / 3 / 4.
-template <int CH, int VEC>
+// where column sum x of a row lives in LDS: a lane's sixteen sums are four 16-byte pieces; piece k of lane u sits at piece slot k ^ ((u >> 1) & 3)
+template <int VEC> __device__ __forceinline__ int area_col(const int x) { return VEC == 16 ? (x & ~12) | ((((x >> 2) ^ (x >> 5)) & 3) << 2) : x; }
+// R consecutive output rows per workgroup: the kernel is bound by the LATENCY of its dependent loads (tap tables -> source rows -> LDS -> taps again), not by
+// bytes or arithmetic -- one row per workgroup ran at 1.3 TB/s with every pipe idle most of the time -- so a workgroup issues the source loads of R rows back
+// to back and applies a lane's horizontal taps (loaded once) to all R rows' column sums.
+template <int CH, int VEC, int R>
 __global__ void __launch_bounds__(128) area_8u_rows_kernel(const unsigned char* __restrict__ a, unsigned char* __restrict__ b, const long a_step, const long a_image, const long b_step, const long b_image,
-	const int b_rows, const int b_cols_ch, const int a_cols_ch, const int* __restrict__ xstart, const tap_u32_t* __restrict__ xtaps, const int* __restrict__ ystart, const tap_u32_t* __restrict__ ytaps, const unsigned inv_scale_256, const float inv_scale_rcp)
+	const int b_rows, const int b_cols_ch, const int a_cols_ch, const int row_groups, const int* __restrict__ xstart, const tap_u32_t* __restrict__ xtaps, const int* __restrict__ ystart, const tap_u32_t* __restrict__ ytaps, const unsigned inv_scale_256, const float inv_scale_rcp)
 {
-	HIP_DYNAMIC_SHARED(unsigned, area_v) // column sums of this output row: a_cols_ch of them (rounded up to whole lanes' worth)
-	const int dy = (int)(blockIdx.x % (unsigned)b_rows);
-	const size_t img = blockIdx.x / (unsigned)b_rows;
+	HIP_DYNAMIC_SHARED(unsigned, area_v) // column sums of the R output rows: R x pitch (pitch = a_cols_ch rounded up to whole lanes' worth)
+	const int dy0 = (int)(blockIdx.x % (unsigned)row_groups) * R;
+	const size_t img = blockIdx.x / (unsigned)row_groups;
 	const unsigned char* const ai = a + img * a_image;
-	const int ky0 = ystart[dy], ky1 = ystart[dy + 1];
-	const int units = (a_cols_ch + VEC - 1) / VEC;
+	const int units = (a_cols_ch + VEC - 1) / VEC, pitch = units * VEC;
+	int ky0[R], ky1[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) { const int dy = dy0 + r < b_rows ? dy0 + r : b_rows - 1; ky0[r] = ystart[dy]; ky1[r] = ystart[dy + 1]; }
 	for (int u = (int)threadIdx.x; u < units; u += 128) {
-		unsigned acc[VEC];
 #pragma unroll
-		for (int j = 0; j < VEC; j++) acc[j] = 0;
-		for (int ky = ky0; ky < ky1; ky++) {
-			const unsigned char* const row = ai + (long)ytaps[ky].si * a_step + (long)u * VEC;
-			const unsigned w = ytaps[ky].w;
-			if (VEC == 16) {
-				const uint4 q = *(const uint4*)row; // (a row's last unit may reach up to 15 bytes into the next row -- or past a 16-byte multiple of the buffer never: pitches are multiples of 16)
-				const unsigned d[4] = { q.x, q.y, q.z, q.w };
+		for (int r = 0; r < R; r++) {
+			unsigned acc[VEC];
 #pragma unroll
-				for (int j = 0; j < 16; j++) acc[j] += ((d[j >> 2] >> (8 * (j & 3))) & 0xffu) * w;
-			} else {
-				const unsigned q = *(const unsigned*)row;
+			for (int j = 0; j < VEC; j++) acc[j] = 0;
+			for (int ky = ky0[r]; ky < ky1[r]; ky++) {
+				const unsigned char* const row = ai + (long)ytaps[ky].si * a_step + (long)u * VEC;
+				const unsigned w = ytaps[ky].w;
+				if (VEC == 16) {
+					const uint4 q = *(const uint4*)row; // (a row's last unit stays inside the row pitch: pitches are multiples of 16 here)
+					const unsigned d[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
-				for (int j = 0; j < 4; j++) acc[j] += ((q >> (8 * j)) & 0xffu) * w;
+					for (int j = 0; j < 16; j++) acc[j] += nnc_mul24((d[j >> 2] >> (8 * (j & 3))) & 0xffu, w); // (weights are at most 256: the 24-bit multiply-add, not the quarter-rate 32-bit one)
+				} else {
+					const unsigned q = *(const unsigned*)row;
+#pragma unroll
+					for (int j = 0; j < 4; j++) acc[j] += nnc_mul24((q >> (8 * j)) & 0xffu, w);
+				}
 			}
-		}
+			// (16 sums per lane are four 16-byte pieces 64 bytes apart from the neighbouring lane's: unswizzled, the eight lanes of a ds_write_b128 group land on two
+			// bank quads -- the counters showed 85 % of the LDS cycles of this kernel were conflicts; area_col() spreads the pieces over all eight quads)
 #pragma unroll
-		for (int j = 0; j < VEC; j += 4) *(uint4*)(area_v + u * VEC + j) = uint4{ acc[j], acc[j + 1], acc[j + 2], acc[j + 3] };
+			for (int j = 0; j < VEC; j += 4) *(uint4*)(area_v + r * pitch + area_col<VEC>(u * VEC + j)) = uint4{ acc[j], acc[j + 1], acc[j + 2], acc[j + 3] };
+		}
 	}
 	__syncthreads();
-	unsigned char* const brow = b + img * b_image + (long)dy * b_step;
 	for (int t4 = (int)threadIdx.x * 4; t4 < b_cols_ch; t4 += 128 * 4) {
-		unsigned packed = 0;
+		unsigned packed[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) packed[r] = 0;
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int e = t4 + j;
 			if (e < b_cols_ch) {
 				const int dx = e / CH, c = e - dx * CH;
-				unsigned h = 0;
-				for (int kx = xstart[dx]; kx < xstart[dx + 1]; kx++) h += area_v[xtaps[kx].si + c] * xtaps[kx].w;
-				unsigned q = (unsigned)((float)h * inv_scale_rcp); // within one of h / inv_scale_256 (the quotient is < 2^16, the estimate's error < 2^-7)
-				const unsigned long long qd = (unsigned long long)q * inv_scale_256;
-				if (qd > h) q--;
-				else if (h - qd >= inv_scale_256) q++;
-				packed |= (q > 255 ? 255u : q) << (8 * j);
+				unsigned h[R];
+#pragma unroll
+				for (int r = 0; r < R; r++) h[r] = 0;
+				for (int kx = xstart[dx]; kx < xstart[dx + 1]; kx++) {
+					const tap_u32_t t = xtaps[kx];
+#pragma unroll
+					for (int r = 0; r < R; r++) h[r] += nnc_mul24(area_v[r * pitch + area_col<VEC>(t.si + c)], t.w); // (a column sum is < 2^24: 255 x the row weights, whose sum is at most 2^16)
+				}
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					unsigned q = (unsigned)((float)h[r] * inv_scale_rcp); // within one of h / inv_scale_256 (the quotient is < 2^16, the estimate's error < 2^-7)
+					const int rem = (int)(h[r] - nnc_mul24(q, inv_scale_256)); // the true remainder lies in (-d, 2 d), d < 2^24: exact in wrapping 32-bit arithmetic
+					if (rem < 0) q--;
+					else if (rem >= (int)inv_scale_256) q++;
+					packed[r] |= (q > 255 ? 255u : q) << (8 * j);
+				}
 			}
 		}
-		if (t4 + 4 <= b_cols_ch) *(unsigned*)(brow + t4) = packed;
-		else for (int j = 0; t4 + j < b_cols_ch; j++) brow[t4 + j] = (unsigned char)(packed >> (8 * j));
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			if (dy0 + r >= b_rows) break;
+			unsigned char* const brow = b + img * b_image + (long)(dy0 + r) * b_step;
+			if (t4 + 4 <= b_cols_ch) *(unsigned*)(brow + t4) = packed[r];
+			else for (int j = 0; t4 + j < b_cols_ch; j++) brow[t4 + j] = (unsigned char)(packed[r] >> (8 * j));
+		}
 	}
 }
 
@@ -584,12 +612,14 @@ int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, 
 			const long a_cols_ch = (long)ad.cols * ch;
 			const bool al4 = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)ad.step | (uintptr_t)ad.image_stride | (uintptr_t)bd.step | (uintptr_t)bd.image_stride) & 3) == 0;
 			const bool al16 = (((uintptr_t)a | (uintptr_t)ad.step | (uintptr_t)ad.image_stride) & 15) == 0;
-			const size_t lds = (size_t)((a_cols_ch + 15) / 16 * 16) * sizeof(unsigned);
+			constexpr int AREA_R = 4; // output rows per workgroup
+			const size_t lds = (size_t)((a_cols_ch + 15) / 16 * 16) * sizeof(unsigned) * AREA_R;
 			static const int rows_kernel = getenv("NNC_MI355X_RESAMPLE_ROWS") ? atoi(getenv("NNC_MI355X_RESAMPLE_ROWS")) : 1;
-			if (rows_kernel && al4 && (ch == 1 || ch == 3 || ch == 4) && lds <= 48 * 1024 && (long)count * bd.rows < 0x7fffffffL && ad.step >= a_cols_ch) {
+			const int row_groups = (bd.rows + AREA_R - 1) / AREA_R;
+			if (rows_kernel && al4 && (ch == 1 || ch == 3 || ch == 4) && lds <= 64 * 1024 && (long)count * row_groups < 0x7fffffffL && ad.step >= a_cols_ch) {
 				const float rcp = (float)(1.0 / (double)inv_scale_256);
-				const dim3 g((unsigned)((long)count * bd.rows));
-#define AREA_ROWS(CH, VEC) hipLaunchKernelGGL(HIP_KERNEL_NAME(area_8u_rows_kernel<CH, VEC>), g, dim3(128), lds, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, (int)a_cols_ch, \
+				const dim3 g((unsigned)((long)count * row_groups));
+#define AREA_ROWS(CH, VEC) hipLaunchKernelGGL(HIP_KERNEL_NAME(area_8u_rows_kernel<CH, VEC, AREA_R>), g, dim3(128), lds, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, (int)a_cols_ch, row_groups, \
 					(const int*)(dev + oxs), (const tap_u32_t*)(dev + oxt), (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), inv_scale_256, rcp)
 				if (al16) { if (ch == 1) AREA_ROWS(1, 16); else if (ch == 3) AREA_ROWS(3, 16); else AREA_ROWS(4, 16); }
 				else { if (ch == 1) AREA_ROWS(1, 4); else if (ch == 3) AREA_ROWS(3, 4); else AREA_ROWS(4, 4); }

@@ -71,8 +71,12 @@ static inline void nnc_store_agent(unsigned* p, unsigned v) { *p = v; }
 static inline void nnc_store_granule(unsigned long long* p, unsigned tag, float value) { unsigned u; memcpy(&u, &value, 4); *p = ((unsigned long long)tag << 32) | u; }
 static inline unsigned long long nnc_load_granule(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
 #define NNC_SPIN_SLEEP() emu::spin_yield()
+// 24 x 24 -> low 32 bits of the product (v_mul_u32_u24 / v_mad_u32_u24: full rate, where the 32-bit v_mul_lo_u32 is quarter rate)
+static inline unsigned nnc_mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 
 #else
+
+__device__ __forceinline__ unsigned nnc_mul24(unsigned a, unsigned b) { return __umul24(a, b); }
 
 #define NNC_PIN_V(x) asm volatile("" : "+v"(x))
 #define NNC_PIN_S(x) asm volatile("" : "+s"(x))
