@@ -56,6 +56,16 @@ __device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_base, uns
 	float* const dst = (float*)((char*)lds_base + (lds_addr - wf_lds_addr(lds_base)));
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (unsigned)r[2], 0), (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
 }
+// 16-byte store through a raw buffer descriptor: per-lane byte offset voff (range-checked against the descriptor: an out-of-range lane stores nothing) plus a
+// wave-uniform byte offset soff (NOT part of the range check, as on the device)
+static inline void wf_store16(const wf_rsrc_t r, unsigned voff, unsigned soff, float x, float y, float z, float w)
+{
+	if ((unsigned long long)voff + 16 > (unsigned long long)(unsigned)r[2]) return;
+	const unsigned long long b = (unsigned long long)(unsigned)r[0] | (unsigned long long)(unsigned)r[1] << 32;
+	float* const p = (float*)(b + voff + soff);
+	p[0] = x; p[1] = y; p[2] = z; p[3] = w;
+}
+static inline float wf_max(float a, float b) { return a > b ? a : b; }
 static inline halfx4 tr_read4(const half_t* const blk, const int pitch, const int i) { return halfx4{ blk[i], blk[pitch + i], blk[2 * pitch + i], blk[3 * pitch + i] }; }
 static inline floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return emu_mfma_f32_32x32x16_f16(a, b, c); }
 #define NNC_PIN_VEC(v) ((void)0)
@@ -101,6 +111,15 @@ __device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float*, unsigned lds
   // (checked in the ISA: hipcc's LDS instructions do not read M0 on gfx950, the kernel has no other LDS-DMA and no s_movrel).
 	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
+// 16-byte store through a raw buffer descriptor kept in SGPRs: voff per lane (range-checked: an out-of-range lane stores nothing), soff wave-uniform
+__device__ __forceinline__ void wf_store16(const wf_rsrc_t r, unsigned voff, unsigned soff, float x, float y, float z, float w)
+{
+	typedef float f4 __attribute__((ext_vector_type(4)));
+	const f4 v = { x, y, z, w };
+	asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+// max without the canonicalising v_max x, x hipcc puts in front of fmaxf (the operands here are results of arithmetic: already canonical)
+__device__ __forceinline__ float wf_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ halfx4 tr_read4(const half_t* const blk, const int pitch, const int i)
 {
 	halfx4 v;

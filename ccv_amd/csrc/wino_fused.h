@@ -239,6 +239,12 @@ template <int GH, int GW, int DBG = 0, bool MASK = false, int SCHED = 0>
 __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs a)
 {
 	constexpr bool PAIR = SCHED > 0;
+	constexpr bool NEWST = (DBG & 8192) == 0; // the epilogue's stores with scalar address arithmetic (round 5; DBG bit 8192 = the previous form, for tools/wf5_probe.cpp)
+	// (also measured and NOT adopted: the output transform on packed pairs -- the two channel blocks of a position as one f2, 400 v_pk_* instead of 800 scalar
+	// operations per item -- makes hipcc spill around the epilogue: conv1_2 4.68 vs 3.07 ms.  profiles/r05_v3_wf5_probe.txt)
+	// (Round 5, measured and NOT adopted -- tools/wf5_probe.cpp, profiles/r05_v3_wf5_probe.txt: letting an item's last trip skip the next item's first transform
+	// and running it behind the epilogue instead (S and V dead across the epilogue, which hipcc otherwise parks in the emptying AGPRs) is 3 % SLOWER,
+	// conv1_2 3.21 vs 3.11 ms: the transform's patch reads are then waited for with nothing else to issue.)
 	typedef WfPair<(SCHED > 0 ? SCHED - 1 : 0)> PS;
 	typedef WfGeom<GH, GW> G;
 	constexpr int GWL = GW == 4 ? 2 : (GW == 8 ? 3 : (GW == 2 ? 1 : (GW == 16 ? 4 : 0)));
@@ -490,6 +496,15 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
 		for (int i = 0; i < 4; i++) bv[i] = (a.bias && kq < a.K) ? a.bias[kq + i] : 0.f;
 		const int dh4 = (int)a.d_sh * 4, dw4 = (int)a.d_sw * 4;
+		// (NEWST) the item's scalars: descriptor, byte offset of its origin + k block, rows / columns left in the image from its origin; the lane's offset or, for a
+		// lane whose channels are outside K (or a dead tile group), the out-of-range one
+		const wf_rsrc_t rs_item = wf_make_rsrc(a.dst + (long)it.n * a.d_sn, a.dst_image_bytes);
+		const int base_y = it.gy * GH * 4, base_x = it.gx * GW * 4;
+		const unsigned s_item = (unsigned)base_y * (unsigned)dh4 + (unsigned)base_x * (unsigned)dw4 + (unsigned)it.kb * (WF_KT * 4);
+		const int hy0 = a.OH - base_y, hx0 = a.OW - base_x;
+		const int ly = lane >> 5, lx = (lane >> 3) & 3;
+		const unsigned lane_off_item = kok ? (unsigned)(ly * dh4 + lx * dw4 + (lane & 7) * 16) : WF_OOB;
+		const float relu_lo = a.relu ? 0.f : -__builtin_inff();
 		// mask bits of the item's four rounds: four 4-byte loads per lane, issued here (nothing stored yet: they come back during round 0's
 		// transforms; the wait before the first store covers them)
 		unsigned mb[4] = { ~0u, ~0u, ~0u, ~0u };
@@ -530,6 +545,29 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 			if (r == 0) WF_WAIT_VMCNT(0);    // before the first store: every DMA piece of the item's last trip has landed, so the next trip
 			                                 // starts without a wait (a counted wait behind stores would not be safe)
 			// read back: 4 tiles x 16 pixels x 8 channel quads = 512 float4 = 8 per lane; lane -> (channel quad = lane & 7, pixel-in-wave-instruction = lane >> 3)
+			if constexpr (NEWST) {
+				// Round 5: everything about a store's address that does not depend on the lane is SCALAR -- store e of round r is pixel (e & 1) * 8 + (lane >> 3) of
+				// tile 4 (e >> 1) + r, so its row / column inside the item are compile-time constants plus the lane's (ly, lx) -- and goes into the instruction's
+				// scalar offset; the lane keeps ONE byte offset for the whole kernel and only swaps it for the out-of-range offset where its pixel is outside the
+				// image (two compares with scalars, one select).  Before: a 32 x 32 -> 64-bit multiply-add, a quarter-rate 32-bit multiply, an add-shift, five
+				// compares / selects and the descriptor's 64-bit base rebuilt on the scalar unit -- per store, 32 stores per item.
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					const int tile = 4 * (e >> 1) + r;
+					const int cy = (tile >> GWL) * 4 + (e & 1) * 2, cx = (tile & (GW - 1)) * 4; // the store's pixel = item origin + (cy + ly, cx + lx)
+					const float4 v = *(const float4*)(st + (e >> 1) * TS + ((e & 1) * 8 + (lane >> 3)) * 32 + (lane & 7) * 4);
+					const unsigned soff = s_item + (unsigned)cy * (unsigned)dh4 + (unsigned)cx * (unsigned)dw4;
+					const bool ok = (ly < hy0 - cy) & (lx < hx0 - cx);
+					const unsigned voff = ok ? lane_off_item : WF_OOB;
+					float o0 = wf_max(v.x + bv[0], relu_lo), o1 = wf_max(v.y + bv[1], relu_lo), o2 = wf_max(v.z + bv[2], relu_lo), o3 = wf_max(v.w + bv[3], relu_lo);
+					if constexpr (MASK) {
+						const unsigned m = mb[r] >> (4 * e);
+						o0 = (m & 1) ? o0 : 0.f; o1 = (m & 2) ? o1 : 0.f; o2 = (m & 4) ? o2 : 0.f; o3 = (m & 8) ? o3 : 0.f;
+					}
+					if constexpr (DBG & 128) { NNC_PIN_V(o0); NNC_PIN_V(o1); NNC_PIN_V(o2); NNC_PIN_V(o3); }
+					else wf_store16(rs_item, voff, soff, o0, o1, o2, o3);
+				}
+			} else {
 #pragma unroll
 			for (int e = 0; e < 8; e++) {
 				const int pid = e * 8 + (lane >> 3);   // 0..63: tile slot pid >> 4 (= g' of the writers), pixel pid & 15
@@ -546,6 +584,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 				}
 				if constexpr (DBG & 128) { NNC_PIN_V(o0); NNC_PIN_V(o1); NNC_PIN_V(o2); NNC_PIN_V(o3); }
 				else __builtin_amdgcn_raw_buffer_store_b128(u4{ __float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3) }, rs_dst, voff, 0, 0);
+			}
 			}
 			__builtin_amdgcn_wave_barrier(); // next round's writes after this round's reads
 		}
