@@ -358,8 +358,17 @@ extern "C" {
 // pair for every caller that launches its work after the allocation returns and frees after queueing its last use -- what the host does (cufree's callers:
 // ccv_nnc_tensor_free, the arena, xpu_alloc's drain) -- without the host-side stall.  Memory pressure: the host's registered callbacks (curegmp:
 // ccv_nnc_xpu_alloc's drain, the stream contexts' workspaces) run, the pool is trimmed to what is in use, the allocation is retried; the last resort is the
-// blocking hipMalloc.  NNC_MI355X_POOL_ALLOC=0 selects hipMalloc / hipFree.  With several devices visible the pool is opened to every peer that can be
-// reached (hipMemPoolSetAccess): peer copies and RCCL's in-process transports read it like plain allocations.
+// blocking hipMalloc.  With several devices visible the pool is opened to every peer that can be reached (hipMemPoolSetAccess): peer copies and RCCL's
+// in-process transports read it like plain allocations.
+//   NNC_MI355X_POOL_ALLOC=1 (default)  allocations from the pool; a free DRAINS THE DEVICE first, exactly as hipFree does, then hands the block to the pool.
+//                                      What is gained is the allocation side (1 GB behind a busy stream: 42 ms -> 28 us, profiles/r05_v2_alloc_bench.txt)
+//                                      and frees that no longer go to the driver (64 MB on an idle device: 224 -> 7 us).
+//   NNC_MI355X_POOL_ALLOC=2            the free is only QUEUED (no drain).  Measured on the MI355X with ROCm 7.2: the full-size convolution parity sequence
+//                                      (tests/test_parity_fullsize.py, nine layers back to back, tensors allocated and freed around every command) then reads
+//                                      back an output that still holds its initial fill -- a block handed out again while work that the blocking free would
+//                                      have waited for was still in flight; a drain before the free cures it, a drain after the allocation does not.  Until
+//                                      that ordering is understood the queued free is opt-in (tests/test_pool_alloc.py runs it on its own).
+//   NNC_MI355X_POOL_ALLOC=0            hipMalloc / hipFree.
 static int g_pool_mode = -1;
 static hipMemPool_t g_pools[MAX_DEVICES];
 static pthread_mutex_t g_pool_mutex = PTHREAD_MUTEX_INITIALIZER;
@@ -368,7 +377,7 @@ static hipMemPool_t pool_of(const int device)
 {
 	if (g_pool_mode < 0) {
 		const char* e = getenv("NNC_MI355X_POOL_ALLOC");
-		g_pool_mode = (e && *e == '0') ? 0 : 1;
+		g_pool_mode = (e && *e == '0') ? 0 : (e && *e == '2') ? 2 : 1;
 	}
 	if (!g_pool_mode || device < 0 || device >= MAX_DEVICES) return 0;
 	if (g_pools[device]) return g_pools[device];
@@ -430,7 +439,12 @@ void nnc_mi355x_free(int device, void* ptr)
 	nnc::comm_flush_if_pending(); // a recorded collective (or a recorded command and its trail) may still name this memory
 	if (!ptr) return;
 	HIP_ENFORCE(hipSetDevice(device));
-	if (pool_of(device)) HIP_ENFORCE(hipFreeAsync(ptr, (hipStream_t)0)); // (memory that came from the blocking hipMalloc is freed by it just the same)
+	if (pool_of(device)) {
+		// mode 1 (default): what hipFree guarantees -- nothing queued on the device can still touch the block -- is kept by draining the device first; the block
+		// then goes back to the POOL, not to the driver.  mode 2: the free is only queued (see the head of this section for why that is opt-in).
+		if (g_pool_mode == 1) HIP_ENFORCE(hipDeviceSynchronize());
+		HIP_ENFORCE(hipFreeAsync(ptr, (hipStream_t)0)); // (memory that came from the blocking hipMalloc is freed by it just the same)
+	}
 	else HIP_ENFORCE(hipFree(ptr));
 }
 // Test / measurement hooks: allocations served by the pool, allocations that needed the pressure path, bytes the pool holds (reserved) and has handed out (used)

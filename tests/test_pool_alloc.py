@@ -1,5 +1,5 @@
-"""Device memory behind cumalloc / cufree (nnc_mi355x_malloc / _free): the device's memory pool in stream order on the legacy NULL stream
-(ccv_amd/csrc/device_rt.cpp).  What the reference's allocator layer above it expects (lib/nnc/ccv_nnc_xpu_alloc.c, lib/nnc/gpu/ccv_nnc_compat.cu cumalloc /
+"""Device memory behind cumalloc / cufree (nnc_mi355x_malloc / _free): the device's memory pool (ccv_amd/csrc/device_rt.cpp; by default a free drains the
+device like hipFree and returns the block to the pool, NNC_MI355X_POOL_ALLOC=2 only queues it).  What the reference's allocator layer above it expects (lib/nnc/ccv_nnc_xpu_alloc.c, lib/nnc/gpu/ccv_nnc_compat.cu cumalloc /
 cufree / curegmp): memory that is safe to use by work queued after the allocation returned, a free that may be issued right behind queueing the last use, and
 the registered pressure callbacks run before an allocation is given up."""
 import ctypes as C
@@ -48,29 +48,38 @@ def test_freed_memory_is_reused_in_stream_order_across_streams(backend):
 
 
 @pytest.mark.gpu
-def test_free_does_not_wait_for_the_device_and_the_pool_keeps_the_memory(gpu_lib):
-    """hipFree waits for everything queued on the device; the pool's free is queued behind it and returns.  A free issued behind milliseconds of queued
-    fills returns in well under a millisecond (the queue is still draining when it does), and the pool's reserved bytes do not shrink when memory is
-    handed back."""
-    lib = gpu_lib
-    (big,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(64 << 20, F)])  # 256 MiB
-    (t,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(1 << 20, F)])
-    stream = lib.stream_new(0)
-    try:
-        lib.stream_wait(stream)
-        for _ in range(400):  # ~50 us each: the device is busy for ~20 ms, the launches take ~2 ms of host time
-            assert lib.cmd_exec(nnc.CMD_SET_FORWARD(2.0), nnc.NO_HINT, 0, [], [big], stream) == 0
-        reserved0 = pool_counts(lib)[2]
-        t1 = time.perf_counter()
-        t.free()
-        t2 = time.perf_counter()
-        lib.stream_wait(stream)
-        t3 = time.perf_counter()
-        assert t3 - t2 > 10 * (t2 - t1), "the queue had drained before the free returned: free %g s, rest of the queue %g s" % (t2 - t1, t3 - t2)
-        assert t2 - t1 < 2e-3, "free took %g s" % (t2 - t1)
-        assert pool_counts(lib)[2] >= reserved0 > 0
-    finally:
-        lib.stream_free(stream)
+def test_queued_free_mode_does_not_wait_for_the_device_and_the_pool_keeps_the_memory():
+    """NNC_MI355X_POOL_ALLOC=2 (opt-in: the free is only queued): a free issued behind milliseconds of queued fills returns in well under a millisecond (the
+    queue is still draining when it does), and the pool's reserved bytes do not shrink when memory is handed back.  Its own process: the mode is read once."""
+    code = r'''
+import ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from ccv_amd import nnc
+from harness import make_tensors
+lib = nnc.load()
+F = np.float32
+def reserved():
+    a, r, res, used = C.c_long(), C.c_long(), C.c_long(), C.c_long()
+    lib.dll.nnc_mi355x_debug_pool_counts(C.byref(a), C.byref(r), C.byref(res), C.byref(used))
+    return res.value
+(big,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(64 << 20, F)])
+(t,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(1 << 20, F)])
+stream = lib.stream_new(0)
+lib.stream_wait(stream)
+for _ in range(400):
+    assert lib.cmd_exec(nnc.CMD_SET_FORWARD(2.0), nnc.NO_HINT, 0, [], [big], stream) == 0
+r0 = reserved()
+t1 = time.perf_counter(); t.free(); t2 = time.perf_counter()
+lib.stream_wait(stream)
+t3 = time.perf_counter()
+assert t3 - t2 > 10 * (t2 - t1), "the queue had drained before the free returned: free %%g s, rest of the queue %%g s" %% (t2 - t1, t3 - t2)
+assert t2 - t1 < 2e-3, "free took %%g s" %% (t2 - t1)
+assert reserved() >= r0 > 0
+print("ok")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, NNC_MI355X_POOL_ALLOC="2"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_pressure_callbacks_run_before_an_allocation_is_given_up():
