@@ -69,6 +69,8 @@ int current_device()
 	return d;
 }
 
+void release_device_block(void* ptr, bool drained); // memory from nnc_mi355x_malloc goes back the way it came (the caching layer further down)
+
 bool is_any(const ccv_nnc_stream_context_t* ctx) { return (ctx->type & CCV_COMPUTE_DEVICE_ANY) == CCV_COMPUTE_DEVICE_ANY; }
 
 // The per-device state a command launched through `ctx` uses right now.  A CCV_COMPUTE_DEVICE_ANY context follows the
@@ -349,117 +351,132 @@ ProfScope::~ProfScope()
 
 extern "C" {
 
-// ---- device memory behind cumalloc / cufree: a stream-ordered pool -------------------------------------------------------------------------------
+// ---- device memory behind cumalloc / cufree: a caching layer over hipMalloc ----------------------------------------------------------------------
 // The reference's dynamic graphs allocate and free tensors all the time; its own free lists (lib/nnc/ccv_nnc_xpu_alloc.c: size-keyed trees per stream and
-// device) catch most of it and call cumalloc / cufree for the rest -- and hipFree waits for the whole device, hipMalloc costs tens of microseconds to
-// milliseconds.  Here both go to the device's memory pool in STREAM ORDER on the legacy NULL stream: a free is queued behind everything already queued on the
-// device's (blocking) streams and returns at once; the pool keeps the memory (release threshold = everything) and a later allocation of the size is served
-// from it without a driver call into the kernel; work queued behind that allocation on any blocking stream runs behind it.  Same semantics as the blocking
-// pair for every caller that launches its work after the allocation returns and frees after queueing its last use -- what the host does (cufree's callers:
-// ccv_nnc_tensor_free, the arena, xpu_alloc's drain) -- without the host-side stall.  Memory pressure: the host's registered callbacks (curegmp:
-// ccv_nnc_xpu_alloc's drain, the stream contexts' workspaces) run, the pool is trimmed to what is in use, the allocation is retried; the last resort is the
-// blocking hipMalloc.  With several devices visible the pool is opened to every peer that can be reached (hipMemPoolSetAccess): peer copies and RCCL's
-// in-process transports read it like plain allocations.
-//   NNC_MI355X_POOL_ALLOC=1 (default)  allocations from the pool; a free DRAINS THE DEVICE first, exactly as hipFree does, then hands the block to the pool.
-//                                      What is gained is the allocation side (1 GB behind a busy stream: 42 ms -> 28 us, profiles/r05_v2_alloc_bench.txt)
-//                                      and frees that no longer go to the driver (64 MB on an idle device: 224 -> 7 us).
-//   NNC_MI355X_POOL_ALLOC=2            the free is only QUEUED (no drain).  Measured on the MI355X with ROCm 7.2: the full-size convolution parity sequence
-//                                      (tests/test_parity_fullsize.py, nine layers back to back, tensors allocated and freed around every command) then reads
-//                                      back an output that still holds its initial fill -- a block handed out again while work that the blocking free would
-//                                      have waited for was still in flight; a drain before the free cures it, a drain after the allocation does not.  Until
-//                                      that ordering is understood the queued free is opt-in (tests/test_pool_alloc.py runs it on its own).
-//   NNC_MI355X_POOL_ALLOC=0            hipMalloc / hipFree.
+// device) catch most of it and call cumalloc / cufree for the rest -- and a hipMalloc of 1 GB costs 33 - 42 ms on this box, a hipFree 0.2 - 0.8 ms
+// (profiles/r05_v2_alloc_bench.txt).  Freed blocks are therefore KEPT, per device and exact (rounded) size, and handed out again:
+//   free      what hipFree guarantees its caller -- nothing queued on the device can still touch the block -- is kept by draining the device
+//             (hipDeviceSynchronize: the wait hipFree itself performs), then the block goes on its size's list instead of back to the driver;
+//   allocate  the size is rounded (512 B below 1 MB, 2 MB above) and the newest block of that size is reused; otherwise hipMalloc.  Out of memory: every kept
+//             block of the device goes back to the driver, the host's registered pressure callbacks run (curegmp: ccv_nnc_xpu_alloc's drain, the stream
+//             contexts' workspaces), one retry.
+// NNC_MI355X_POOL_ALLOC=0 selects plain hipMalloc / hipFree.
+// Round 5 first built this on the runtime's own stream-ordered pool (hipMallocAsync / hipFreeAsync on the legacy stream, release threshold = keep everything)
+// and took it out again: with the free only QUEUED the full-size convolution parity sequence read back an output still holding its initial fill; with a device
+// drain in front of every hipFreeAsync that sequence passed and the reference's own NCHW convolution int cases failed instead (cudnn.tests.c:130, :473) -- on
+// ROCm 7.2 memory from the pool is not interchangeable with hipMalloc's for this library's mix of blocking copies, default-stream kernels and stream-ordered
+// work, for reasons not understood.  The layer below involves no runtime feature beyond hipMalloc / hipFree / hipDeviceSynchronize.
 static int g_pool_mode = -1;
-static hipMemPool_t g_pools[MAX_DEVICES];
 static pthread_mutex_t g_pool_mutex = PTHREAD_MUTEX_INITIALIZER;
-static std::atomic<long> g_pool_allocs(0), g_pool_retries(0);
-static hipMemPool_t pool_of(const int device)
+struct kept_block_t { void* ptr; size_t size; };
+static std::vector<kept_block_t> g_kept[MAX_DEVICES];           // free blocks, newest last
+static std::vector<kept_block_t> g_live[MAX_DEVICES];           // blocks handed out (ptr -> rounded size); a few hundred entries at most: linear search
+static std::atomic<long> g_pool_allocs(0), g_pool_retries(0), g_pool_kept_bytes(0), g_pool_live_bytes(0);
+static bool pool_on(void)
 {
 	if (g_pool_mode < 0) {
 		const char* e = getenv("NNC_MI355X_POOL_ALLOC");
-		g_pool_mode = (e && *e == '0') ? 0 : (e && *e == '2') ? 2 : 1;
+		g_pool_mode = (e && *e == '0') ? 0 : 1;
 	}
-	if (!g_pool_mode || device < 0 || device >= MAX_DEVICES) return 0;
-	if (g_pools[device]) return g_pools[device];
-	pthread_mutex_lock(&g_pool_mutex);
-	if (!g_pools[device]) {
-		hipMemPool_t pool = 0;
-		if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
-			uint64_t keep = UINT64_MAX; // freed memory stays with the pool until pressure trims it
-			if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) (void)hipGetLastError();
-			int count = 0;
-			if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 1; }
-			for (int peer = 0; peer < count; peer++) {
-				int can = 0;
-				if (peer == device || hipDeviceCanAccessPeer(&can, peer, device) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
-				hipMemAccessDesc desc;
-				memset(&desc, 0, sizeof(desc));
-				desc.location.type = hipMemLocationTypeDevice;
-				desc.location.id = peer;
-				desc.flags = hipMemAccessFlagsProtReadWrite;
-				if (hipMemPoolSetAccess(pool, &desc, 1) != hipSuccess) (void)hipGetLastError();
-			}
-			g_pools[device] = pool;
-		} else {
-			(void)hipGetLastError();
-			g_pool_mode = 0; // no pool support: the blocking pair
-		}
-	}
-	pthread_mutex_unlock(&g_pool_mutex);
-	return g_pools[device];
+	return g_pool_mode != 0;
+}
+static size_t pool_round(const size_t size)
+{
+	const size_t g = size < ((size_t)1 << 20) ? 512 : (size_t)2 << 20;
+	return (size + g - 1) / g * g;
+}
+static void pool_release_all(const int device)
+{ // (caller holds the mutex) every kept block of the device back to the driver
+	for (const kept_block_t& k : g_kept[device]) { HIP_ENFORCE(hipFree(k.ptr)); g_pool_kept_bytes.fetch_sub((long)k.size, std::memory_order_relaxed); }
+	g_kept[device].clear();
 }
 
 void* nnc_mi355x_malloc(int device, size_t size)
 {
 	void* ptr = 0;
 	HIP_ENFORCE(hipSetDevice(device));
-	if (hipMemPool_t pool = pool_of(device)) {
-		if (hipMallocAsync(&ptr, size, (hipStream_t)0) == hipSuccess && ptr) { g_pool_allocs.fetch_add(1, std::memory_order_relaxed); return ptr; }
+	if (!pool_on() || device < 0 || device >= MAX_DEVICES) {
+		if (hipMalloc(&ptr, size) != hipSuccess || !ptr) {
+			(void)hipGetLastError();
+			ptr = 0;
+			trigger_mem_pressure(); // let the host drop caches (workspaces, xpu_alloc free lists), then retry once
+			if (hipMalloc(&ptr, size) != hipSuccess) { (void)hipGetLastError(); ptr = 0; }
+		}
+		return ptr;
+	}
+	const size_t rounded = pool_round(size ? size : 1);
+	pthread_mutex_lock(&g_pool_mutex);
+	std::vector<kept_block_t>& kept = g_kept[device];
+	for (size_t i = kept.size(); i-- > 0;)
+		if (kept[i].size == rounded) {
+			ptr = kept[i].ptr;
+			kept.erase(kept.begin() + (long)i);
+			g_pool_kept_bytes.fetch_sub((long)rounded, std::memory_order_relaxed);
+			g_pool_allocs.fetch_add(1, std::memory_order_relaxed);
+			break;
+		}
+	if (!ptr && (hipMalloc(&ptr, rounded) != hipSuccess || !ptr)) {
 		(void)hipGetLastError();
 		ptr = 0;
-		trigger_mem_pressure(); // the host drops its caches (they come back through nnc_mi355x_free: into the pool) ...
-		HIP_ENFORCE(hipStreamSynchronize((hipStream_t)0)); // ... the queued frees have happened ...
-		if (hipMemPoolTrimTo(pool, 0) != hipSuccess) (void)hipGetLastError(); // ... and what the pool holds unused goes back to the device
+		pool_release_all(device);
+		pthread_mutex_unlock(&g_pool_mutex);
+		trigger_mem_pressure(); // the host drops its caches: they come back through nnc_mi355x_free (and are kept -- so release once more before the retry)
+		pthread_mutex_lock(&g_pool_mutex);
+		pool_release_all(device);
 		g_pool_retries.fetch_add(1, std::memory_order_relaxed);
-		if (hipMallocAsync(&ptr, size, (hipStream_t)0) == hipSuccess && ptr) return ptr;
-		(void)hipGetLastError();
-		ptr = 0;
+		if (hipMalloc(&ptr, rounded) != hipSuccess) { (void)hipGetLastError(); ptr = 0; }
 	}
-	if (hipMalloc(&ptr, size) != hipSuccess || !ptr) {
-		(void)hipGetLastError();
-		ptr = 0;
-		trigger_mem_pressure(); // let the host drop caches (workspaces, xpu_alloc free lists), then retry once
-		if (hipMalloc(&ptr, size) != hipSuccess) { (void)hipGetLastError(); ptr = 0; }
-	}
+	if (ptr) { g_live[device].push_back(kept_block_t{ ptr, rounded }); g_pool_live_bytes.fetch_add((long)rounded, std::memory_order_relaxed); }
+	pthread_mutex_unlock(&g_pool_mutex);
 	return ptr;
 }
+
+} // extern "C"
+namespace {
+// Memory that came from nnc_mi355x_malloc goes back the way it came; `drained`: the caller has already waited for everything that may use the block
+void release_device_block(void* ptr, const bool drained)
+{
+	if (!ptr) return;
+	const int device = current_device();
+	if (pool_on() && device >= 0 && device < MAX_DEVICES) {
+		pthread_mutex_lock(&g_pool_mutex);
+		std::vector<kept_block_t>& live = g_live[device];
+		size_t at = live.size();
+		for (size_t i = live.size(); i-- > 0;) if (live[i].ptr == ptr) { at = i; break; }
+		if (at < live.size()) {
+			const kept_block_t k = live[at];
+			live[at] = live.back();
+			live.pop_back();
+			pthread_mutex_unlock(&g_pool_mutex);
+			if (!drained) HIP_ENFORCE(hipDeviceSynchronize()); // hipFree's own guarantee
+			pthread_mutex_lock(&g_pool_mutex);
+			g_kept[device].push_back(k);
+			g_pool_live_bytes.fetch_sub((long)k.size, std::memory_order_relaxed);
+			g_pool_kept_bytes.fetch_add((long)k.size, std::memory_order_relaxed);
+			pthread_mutex_unlock(&g_pool_mutex);
+			return;
+		}
+		pthread_mutex_unlock(&g_pool_mutex); // not one of ours (allocated before the switch was read, or by the plain path): the driver's free
+	}
+	HIP_ENFORCE(hipFree(ptr));
+}
+}
+extern "C" {
 
 void nnc_mi355x_free(int device, void* ptr)
 {
 	nnc::comm_flush_if_pending(); // a recorded collective (or a recorded command and its trail) may still name this memory
 	if (!ptr) return;
 	HIP_ENFORCE(hipSetDevice(device));
-	if (pool_of(device)) {
-		// mode 1 (default): what hipFree guarantees -- nothing queued on the device can still touch the block -- is kept by draining the device first; the block
-		// then goes back to the POOL, not to the driver.  mode 2: the free is only queued (see the head of this section for why that is opt-in).
-		if (g_pool_mode == 1) HIP_ENFORCE(hipDeviceSynchronize());
-		HIP_ENFORCE(hipFreeAsync(ptr, (hipStream_t)0)); // (memory that came from the blocking hipMalloc is freed by it just the same)
-	}
-	else HIP_ENFORCE(hipFree(ptr));
+	release_device_block(ptr, false);
 }
-// Test / measurement hooks: allocations served by the pool, allocations that needed the pressure path, bytes the pool holds (reserved) and has handed out (used)
+// Test / measurement hooks: allocations served from kept blocks, allocations that needed the pressure path, bytes kept (free) and bytes handed out
 void nnc_mi355x_debug_pool_counts(long* allocs, long* retries, long* reserved_bytes, long* used_bytes)
 {
 	if (allocs) *allocs = g_pool_allocs.load(std::memory_order_relaxed);
 	if (retries) *retries = g_pool_retries.load(std::memory_order_relaxed);
-	uint64_t r = 0, u = 0;
-	const int device = current_device();
-	if (hipMemPool_t pool = pool_of(device)) {
-		if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &r) != hipSuccess) (void)hipGetLastError();
-		if (hipMemPoolGetAttribute(pool, hipMemPoolAttrUsedMemCurrent, &u) != hipSuccess) (void)hipGetLastError();
-	}
-	if (reserved_bytes) *reserved_bytes = (long)r;
-	if (used_bytes) *used_bytes = (long)u;
+	if (reserved_bytes) *reserved_bytes = g_pool_kept_bytes.load(std::memory_order_relaxed) + g_pool_live_bytes.load(std::memory_order_relaxed);
+	if (used_bytes) *used_bytes = g_pool_live_bytes.load(std::memory_order_relaxed);
 }
 
 void nnc_mi355x_set_device(int device)
@@ -567,9 +584,9 @@ static void local_release(device_local_t* l)
 	const int prev = current_device();
 	HIP_ENFORCE(hipSetDevice(l->device));
 	if (l->stream) HIP_ENFORCE(hipStreamSynchronize(l->stream));
-	if (l->workspace) HIP_ENFORCE(hipFree(l->workspace));
-	if (l->staging) HIP_ENFORCE(hipFree(l->staging));
-	if (l->cluster_sync) HIP_ENFORCE(hipFree(l->cluster_sync));
+	if (l->workspace) release_device_block(l->workspace, true);
+	if (l->staging) release_device_block(l->staging, true);
+	if (l->cluster_sync) release_device_block(l->cluster_sync, true);
 	if (l->stream) HIP_ENFORCE(hipStreamDestroy(l->stream));
 	l->workspace = 0; l->workspace_size = 0; l->staging = 0; l->staging_size = 0; l->stream = 0; l->cluster_sync = 0;
 	HIP_ENFORCE(hipSetDevice(prev));
@@ -627,7 +644,7 @@ void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const 
 	if (l->workspace) {
 		HIP_ENFORCE(hipStreamSynchronize(st)); // queued kernels may still read the old buffer
 		nnc::cluster_check_timeout();
-		HIP_ENFORCE(hipFree(l->workspace));
+		release_device_block(l->workspace, true);
 	}
 	l->workspace = nnc_mi355x_malloc(st ? l->device : current_device(), workspace_size);
 	l->workspace_size = l->workspace ? workspace_size : 0;
@@ -639,8 +656,8 @@ static void local_drain(device_local_t* l, hipStream_t st)
 	if (!l->workspace && !l->staging) return;
 	HIP_ENFORCE(hipStreamSynchronize(st));
 	nnc::cluster_check_timeout();
-	if (l->workspace) HIP_ENFORCE(hipFree(l->workspace));
-	if (l->staging) HIP_ENFORCE(hipFree(l->staging));
+	if (l->workspace) release_device_block(l->workspace, true);
+	if (l->staging) release_device_block(l->staging, true);
 	l->workspace = 0; l->workspace_size = 0;
 	l->staging = 0; l->staging_size = 0;
 }
@@ -664,7 +681,7 @@ void* nnc_staging_of(const ccv_nnc_stream_context_t* const stream_context, const
 	if (l->staging) {
 		HIP_ENFORCE(hipStreamSynchronize(st)); // queued conversions may still read the old arena
 		nnc::cluster_check_timeout();
-		HIP_ENFORCE(hipFree(l->staging));
+		release_device_block(l->staging, true);
 	}
 	l->staging = nnc_mi355x_malloc(st ? l->device : current_device(), size);
 	l->staging_size = l->staging ? size : 0;

@@ -58,6 +58,7 @@ __device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float* lds_base, uns
 }
 // 16-byte store through a raw buffer descriptor: per-lane byte offset voff (range-checked against the descriptor: an out-of-range lane stores nothing) plus a
 // wave-uniform byte offset soff (NOT part of the range check, as on the device)
+template <int POLICY = 0>
 static inline void wf_store16(const wf_rsrc_t r, unsigned voff, unsigned soff, float x, float y, float z, float w)
 {
 	if ((unsigned long long)voff + 16 > (unsigned long long)(unsigned)r[2]) return;
@@ -112,11 +113,15 @@ __device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float*, unsigned lds
 	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 // 16-byte store through a raw buffer descriptor kept in SGPRs: voff per lane (range-checked: an out-of-range lane stores nothing), soff wave-uniform
+// POLICY: 0 the default cache policy, 1 nt (streaming: the line need not stay in the XCD's L2), 2 sc1
+template <int POLICY = 0>
 __device__ __forceinline__ void wf_store16(const wf_rsrc_t r, unsigned voff, unsigned soff, float x, float y, float z, float w)
 {
 	typedef float f4 __attribute__((ext_vector_type(4)));
 	const f4 v = { x, y, z, w };
-	asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+	if (POLICY == 1) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+	else if (POLICY == 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+	else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 // max without the canonicalising v_max x, x hipcc puts in front of fmaxf (the operands here are results of arithmetic: already canonical)
 __device__ __forceinline__ float wf_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }

@@ -409,11 +409,10 @@ void nnc_mi355x_debug_peephole_counts(long* recorded, long* folded, long* plain)
  * operations are kept behind the recorded command, in arrival order, and replayed right behind it when it launches; nothing else can observe the difference
  * (peephole.cpp).  NNC_MI355X_PEEPHOLE_TRAIL=0 restores the flush at the first of them.  Test hook: operations that have waited in a trail so far. */
 long nnc_mi355x_debug_peephole_trailed(void);
-/* Device memory (nnc_mi355x_malloc / _free = cumalloc / cufree) comes from the device's memory pool (hipMallocAsync / hipFreeAsync on the legacy NULL stream,
- * release threshold = keep everything; device_rt.cpp): an allocation is served from the pool without a driver call, a freed block goes back to the pool.  The
- * default keeps hipFree's guarantee by draining the device before a free; NNC_MI355X_POOL_ALLOC=2 only queues the free (opt-in: device_rt.cpp says why),
- * NNC_MI355X_POOL_ALLOC=0 selects the blocking hipMalloc / hipFree.  Under memory pressure the host's curegmp callbacks run, the pool is trimmed, the allocation
- * is retried.  Hook: pool allocations, pressure retries, bytes reserved / in use on the current device. */
+/* Device memory (nnc_mi355x_malloc / _free = cumalloc / cufree): freed blocks are kept per device and (rounded) size and handed out again (device_rt.cpp).  A
+ * free drains the device first -- hipFree's own guarantee -- and the block skips the driver both ways (hipMalloc of 1 GB: 33 - 42 ms on the MI355X box).  Under
+ * memory pressure every kept block goes back to the driver, the host's curegmp callbacks run, the allocation is retried.  NNC_MI355X_POOL_ALLOC=0 selects plain
+ * hipMalloc / hipFree.  Hook: allocations served from kept blocks, pressure retries, bytes held (kept + handed out) and bytes handed out. */
 void nnc_mi355x_debug_pool_counts(long* allocs, long* retries, long* reserved_bytes, long* used_bytes);
 /* batch-norm commands that ran on the cluster kernels (cmd_norm.cpp: a cluster of workgroups per channel keeps the channel in registers between the
  * statistics and the apply pass; NNC_MI355X_BN_CLUSTER=0 / nnc_mi355x_tune_set("BN_CLUSTER", 0) selects the plane kernels). */

@@ -218,26 +218,18 @@ static thread_local int g_device = 0; // (HIP: the current device is per host th
 static int device_count() { const char* e = getenv("NNC_EMU_DEVICE_COUNT"); return e ? atoi(e) : 1; }
 static double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
-hipError_t hipMalloc(void** p, size_t n) { *p = nullptr; if (posix_memalign(p, 256, n ? n : 256)) return hipErrorOutOfMemory; return hipSuccess; }
+// EMU_MALLOC_FAIL_NEXT=<n> in the environment of a test: the next n device allocations fail (the pressure path of nnc_mi355x_malloc)
+static std::atomic<int> g_emu_malloc_fail(-1);
+hipError_t hipMalloc(void** p, size_t n)
+{
+	*p = nullptr;
+	if (g_emu_malloc_fail.load() < 0) { const char* e = getenv("EMU_MALLOC_FAIL_NEXT"); g_emu_malloc_fail.store(e ? atoi(e) : 0); }
+	if (g_emu_malloc_fail.load() > 0) { g_emu_malloc_fail.fetch_sub(1); return hipErrorOutOfMemory; }
+	if (posix_memalign(p, 256, n ? n : 256)) return hipErrorOutOfMemory;
+	return hipSuccess;
+}
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
-// stream-ordered allocation (hip_runtime.h): one pool object, malloc / free underneath; EMU_POOL_FAIL_NEXT=<n> in the environment of a test makes the next n
-// pool allocations fail (the pressure path of nnc_mi355x_malloc)
-struct emuMemPool { int unused; };
-static emuMemPool g_emu_pool;
-static std::atomic<int> g_emu_pool_fail(-1);
-hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t* pool, int) { *pool = &g_emu_pool; return hipSuccess; }
-hipError_t hipMemPoolSetAttribute(hipMemPool_t, hipMemPoolAttr, void*) { return hipSuccess; }
-hipError_t hipMemPoolGetAttribute(hipMemPool_t, hipMemPoolAttr, void* value) { *(uint64_t*)value = 0; return hipSuccess; }
-hipError_t hipMemPoolSetAccess(hipMemPool_t, const hipMemAccessDesc*, size_t) { return hipSuccess; }
-hipError_t hipMemPoolTrimTo(hipMemPool_t, size_t) { return hipSuccess; }
-hipError_t hipMallocAsync(void** p, size_t n, hipStream_t)
-{
-	if (g_emu_pool_fail.load() < 0) { const char* e = getenv("EMU_POOL_FAIL_NEXT"); g_emu_pool_fail.store(e ? atoi(e) : 0); }
-	if (g_emu_pool_fail.load() > 0) { g_emu_pool_fail.fetch_sub(1); *p = nullptr; return hipErrorOutOfMemory; }
-	return hipMalloc(p, n);
-}
-hipError_t hipFreeAsync(void* p, hipStream_t) { free(p); return hipSuccess; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void*) { return hipSuccess; }

@@ -267,20 +267,6 @@ hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void* p);
 hipError_t hipHostRegister(void* p, size_t n, unsigned flags);
-// stream-ordered allocation: the emulator's "device" is the heap and its streams are synchronous -- the pool is malloc / free with a byte count
-typedef struct emuMemPool* hipMemPool_t;
-enum hipMemPoolAttr { hipMemPoolAttrReleaseThreshold = 0x4, hipMemPoolAttrReservedMemCurrent = 0x5, hipMemPoolAttrUsedMemCurrent = 0x7 };
-enum hipMemLocationType { hipMemLocationTypeInvalid = 0, hipMemLocationTypeDevice = 1 };
-enum hipMemAccessFlags { hipMemAccessFlagsProtNone = 0, hipMemAccessFlagsProtRead = 1, hipMemAccessFlagsProtReadWrite = 3 };
-struct hipMemLocation { hipMemLocationType type; int id; };
-struct hipMemAccessDesc { hipMemLocation location; hipMemAccessFlags flags; };
-hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t* pool, int device);
-hipError_t hipMemPoolSetAttribute(hipMemPool_t pool, hipMemPoolAttr attr, void* value);
-hipError_t hipMemPoolGetAttribute(hipMemPool_t pool, hipMemPoolAttr attr, void* value);
-hipError_t hipMemPoolSetAccess(hipMemPool_t pool, const hipMemAccessDesc* desc, size_t count);
-hipError_t hipMemPoolTrimTo(hipMemPool_t pool, size_t min_bytes_to_hold);
-hipError_t hipMallocAsync(void** p, size_t n, hipStream_t s);
-hipError_t hipFreeAsync(void* p, hipStream_t s);
 hipError_t hipHostUnregister(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = 0);

@@ -1,5 +1,5 @@
-"""Device memory behind cumalloc / cufree (nnc_mi355x_malloc / _free): the device's memory pool (ccv_amd/csrc/device_rt.cpp; by default a free drains the
-device like hipFree and returns the block to the pool, NNC_MI355X_POOL_ALLOC=2 only queues it).  What the reference's allocator layer above it expects (lib/nnc/ccv_nnc_xpu_alloc.c, lib/nnc/gpu/ccv_nnc_compat.cu cumalloc /
+"""Device memory behind cumalloc / cufree (nnc_mi355x_malloc / _free): a caching layer over hipMalloc (ccv_amd/csrc/device_rt.cpp: a free drains the device
+like hipFree and keeps the block; an allocation of the same rounded size reuses it).  What the reference's allocator layer above it expects (lib/nnc/ccv_nnc_xpu_alloc.c, lib/nnc/gpu/ccv_nnc_compat.cu cumalloc /
 cufree / curegmp): memory that is safe to use by work queued after the allocation returned, a free that may be issued right behind queueing the last use, and
 the registered pressure callbacks run before an allocation is given up."""
 import ctypes as C
@@ -41,49 +41,35 @@ def test_freed_memory_is_reused_in_stream_order_across_streams(backend):
             got = u.numpy()
             assert (got == F(-5.0 - trip)).all(), (trip, ptr == u.ptr)
             u.free()
-        assert pool_counts(lib)[0] - a0 >= 12
+        assert pool_counts(lib)[0] - a0 >= 10  # (all but the first allocation of the size come out of kept blocks)
     finally:
         lib.stream_free(s1)
         lib.stream_free(s2)
 
 
 @pytest.mark.gpu
-def test_queued_free_mode_does_not_wait_for_the_device_and_the_pool_keeps_the_memory():
-    """NNC_MI355X_POOL_ALLOC=2 (opt-in: the free is only queued): a free issued behind milliseconds of queued fills returns in well under a millisecond (the
-    queue is still draining when it does), and the pool's reserved bytes do not shrink when memory is handed back.  Its own process: the mode is read once."""
-    code = r'''
-import ctypes as C, os, sys, time
-import numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
-from ccv_amd import nnc
-from harness import make_tensors
-lib = nnc.load()
-F = np.float32
-def reserved():
-    a, r, res, used = C.c_long(), C.c_long(), C.c_long(), C.c_long()
-    lib.dll.nnc_mi355x_debug_pool_counts(C.byref(a), C.byref(r), C.byref(res), C.byref(used))
-    return res.value
-(big,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(64 << 20, F)])
-(t,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(1 << 20, F)])
-stream = lib.stream_new(0)
-lib.stream_wait(stream)
-for _ in range(400):
-    assert lib.cmd_exec(nnc.CMD_SET_FORWARD(2.0), nnc.NO_HINT, 0, [], [big], stream) == 0
-r0 = reserved()
-t1 = time.perf_counter(); t.free(); t2 = time.perf_counter()
-lib.stream_wait(stream)
-t3 = time.perf_counter()
-assert t3 - t2 > 10 * (t2 - t1), "the queue had drained before the free returned: free %%g s, rest of the queue %%g s" %% (t2 - t1, t3 - t2)
-assert t2 - t1 < 2e-3, "free took %%g s" %% (t2 - t1)
-assert reserved() >= r0 > 0
-print("ok")
-''' % (ROOT, ROOT)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, NNC_MI355X_POOL_ALLOC="2"))
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+def test_a_freed_gigabyte_comes_back_without_the_driver(gpu_lib):
+    """hipMalloc of 1 GB costs tens of milliseconds on the MI355X box (profiles/r05_v2_alloc_bench.txt); a block that has been freed once is handed out again
+    in microseconds, and the bytes the layer holds do not grow when the same size goes round."""
+    lib = gpu_lib
+    n = 1 << 30
+    p = lib.malloc(0, n)
+    assert p
+    lib.free(0, p)
+    held0 = pool_counts(lib)[2]
+    a0 = pool_counts(lib)[0]
+    t0 = time.perf_counter()
+    for _ in range(10):
+        q = lib.malloc(0, n)
+        assert q == p
+        lib.free(0, q)
+    dt = (time.perf_counter() - t0) / 10
+    assert dt < 2e-3, "allocate + free of a kept 1 GB block took %g s" % dt
+    assert pool_counts(lib)[0] - a0 == 10 and pool_counts(lib)[2] == held0
 
 
 def test_pressure_callbacks_run_before_an_allocation_is_given_up():
-    """CPU tier (emulator): the first pool allocation fails (EMU_POOL_FAIL_NEXT=1); the callback registered through nnc_mi355x_register_mem_pressure -- the
+    """CPU tier (emulator): the first device allocation fails (EMU_MALLOC_FAIL_NEXT=1); the callback registered through nnc_mi355x_register_mem_pressure -- the
     reference host registers ccv_nnc_xpu_alloc's drain and the stream contexts' workspace drains there (curegmp) -- runs once and the retry succeeds."""
     code = r'''
 import ctypes as C, os, sys
@@ -108,5 +94,5 @@ print("ok")
     so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
     if not os.path.exists(so):
         pytest.skip("emulator library not built")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, EMU_POOL_FAIL_NEXT="1"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, EMU_MALLOC_FAIL_NEXT="1"))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
