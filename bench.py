@@ -143,10 +143,20 @@ def resnet_config(args, half, dawn=False):
         if r.returncode != 0:
             raise SystemExit("host_resnet_bench failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
     h = json.loads(r.stdout.strip().splitlines()[-1])
+    dp_check = None
     if rank_lines:  # the slowest rank's clock (every rank brackets its timed steps with a cross-rank barrier + stream wait)
         h = dict(rank_lines[0], ms_per_step=max(l["ms_per_step"] for l in rank_lines))
         h["images_per_s"] = gpus * args.batch / (h["ms_per_step"] * 1e-3)
         devices = gpus
+        # the data-parallel check of this form: after the timed steps every rank holds the same parameters (the harness reads the first and the last parameter
+        # tensor back: sum of squares), and every rank's communicator has all the ranks in it
+        probes = [l.get("replica_probe_sumsq") for l in rank_lines]
+        if all(p for p in probes):
+            rep = max(abs(p[k] - probes[0][k]) / max(abs(probes[0][k]), 1e-30) for p in probes for k in range(2))
+            ranks_ok = all(l["process_per_gpu"]["rccl_ranks"] == gpus for l in rank_lines)
+            dp_check = {"replica_param_sumsq_max_rel_diff": rep, "rccl_ranks_per_rank": [l["process_per_gpu"]["rccl_ranks"] for l in rank_lines], "ok": bool(rep <= 1e-6 and ranks_ok)}
+            if not dp_check["ok"]:
+                print("bench.py: the ranks' replicas differ after the timed steps: %r" % (dp_check,), file=sys.stderr)
     gflop = 25.97  # ResNet-50 v1d forward + backward per image (1 MAC = 2 FLOP)
     if dawn:  # DawnNet: 3x3 convolutions 3->64 @32^2, 64->128 @32^2, 2 x 128->128 @16^2, 128->256 @16^2, 256->512 @8^2, 2 x 512->512 @4^2, dense 512->10; x3 for fwd + bwd
         macs = 9 * (3 * 64 * 1024 + 64 * 128 * 1024 + 2 * 128 * 128 * 256 + 128 * 256 * 256 + 256 * 512 * 64 + 2 * 512 * 512 * 16) + 5120
@@ -158,6 +168,10 @@ def resnet_config(args, half, dawn=False):
                                    "ResNet-50 v1d (bin/nnc/imagenet.c) NCHW forward+backward+Nesterov SGD, batch %d, random-init weights, driven by the reference host's ccv_cnnp_model_fit") % args.batch,
                       "global_batch": args.batch * devices, "parallelism": "dp%d%s" % (devices, (" (one process per GPU; the reference's evaluate / backward / parameter_gradients_map(COMM_ALLREDUCE) / apply_gradients; RCCL ranks %s)" % [l["process_per_gpu"]["rccl_ranks"] for l in rank_lines]) if rank_lines else (" (one process, ccv_cnnp_model_set_data_parallel; gradients all-reduced by the COMM_ALLREDUCE rows over RCCL)" if devices > 1 else "")), "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] / devices * gflop / 1e3,
                       "first_step_ms": h["first_step_ms"], "outputs_finite": h["outputs_finite"], "softmax_worst_row_sum_err": h["softmax_worst_row_sum_err"], "memory_gib": h["memory_gib"]}}
+    if rank_lines:
+        out["config"]["rccl_ranks"] = rank_lines[0]["process_per_gpu"]["rccl_ranks"]
+    if dp_check is not None:
+        out["config"]["data_parallel_check"] = dp_check
     ks = h.get("kernels", [])
     bn = [k for k in ks if k["bytes"] > 0 and k["ms"] > 0]
     import re

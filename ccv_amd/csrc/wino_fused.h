@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 						o0 = (m & 1) ? o0 : 0.f; o1 = (m & 2) ? o1 : 0.f; o2 = (m & 4) ? o2 : 0.f; o3 = (m & 8) ? o3 : 0.f;
 					}
 					if constexpr (DBG & 128) { NNC_PIN_V(o0); NNC_PIN_V(o1); NNC_PIN_V(o2); NNC_PIN_V(o3); }
-					else wf_store16<(DBG & 4096) ? 1 : (DBG & 16384) ? 2 : 0>(rs_item, voff, soff, o0, o1, o2, o3); // (experiment bits: nt / sc1 stores)
+					else wf_store16(rs_item, voff, soff, o0, o1, o2, o3); // (nt / sc1 cache policies on these stores: no difference, profiles/r05_v3_wf5_probe.txt)
 				}
 			} else {
 #pragma unroll

@@ -77,3 +77,4 @@ def test_process_per_gpu_form_of_configs_4_and_5_on_this_box(config):
     out = json.loads(lines[0])
     assert out["n_gpus"] == n and "one process per GPU" in out["config"]["parallelism"] and ("RCCL ranks %s" % ([n] * n)) in out["config"]["parallelism"], out["config"]["parallelism"]
     assert out["config"]["outputs_finite"] and out["value"] > 0
+    assert out["config"]["rccl_ranks"] == n and out["config"]["data_parallel_check"]["ok"], out["config"].get("data_parallel_check")  # (round 5: every config's N > 1 line carries both)

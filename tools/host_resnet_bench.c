@@ -588,7 +588,35 @@ int main(int argc, char** argv)
 	}
 	nnc_mi355x_profile_enable(0);
 	if (recf) fclose(recf);
-	printf("{\"kernels\": [");
+	/* replica probe (the process-per-GPU form's data-parallel check, bench.py compares it across the ranks): after the timed steps every rank must hold the
+	 * same parameters -- sum of squares of the first and the last parameter tensor, read back in the parameter's own precision */
+	double probe_sq[2] = { 0, 0 };
+	{
+		const int pc = ccv_cnnp_model_parameter_count(model);
+		int which;
+		for (which = 0; which < 2 && pc > 0; which++) {
+			const ccv_cnnp_model_io_t pio = ccv_cnnp_model_parameters(model, -1, which ? pc - 1 : 0);
+			ccv_nnc_tensor_param_t pp = ccv_cnnp_model_parameter_tensor_params(model, pio);
+			const int pdt = pp.datatype;
+			pp.type = CCV_TENSOR_CPU_MEMORY;
+			ccv_nnc_tensor_t* const hp = ccv_nnc_tensor_new(0, pp, 0);
+			ccv_cnnp_model_parameter_copy(model, pio, hp);
+			const size_t cnt = ccv_nnc_tensor_count(pp);
+			size_t jj;
+			double b = 0;
+			if (pdt == CCV_16F) {
+				float* const f = (float*)malloc(sizeof(float) * cnt);
+				ccv_half_precision_to_float((uint16_t*)hp->data.f16, f, cnt);
+				for (jj = 0; jj < cnt; jj++) b += (double)f[jj] * f[jj];
+				free(f);
+			} else
+				for (jj = 0; jj < cnt; jj++) b += (double)hp->data.f32[jj] * hp->data.f32[jj];
+			probe_sq[which] = b;
+			ccv_nnc_tensor_free(hp);
+		}
+	}
+	printf("{\"replica_probe_sumsq\": [%.17g, %.17g], ", probe_sq[0], probe_sq[1]);
+	printf("\"kernels\": [");
 	for (i = 0; i < nagg; i++) printf("%s{\"name\": \"%s\", \"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}", i ? ", " : "", agg[i].name, agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes);
 	printf("], ");
 	printf("\"device_out_sumsq\": [");

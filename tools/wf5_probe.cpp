@@ -75,10 +75,7 @@ int main(int argc, char** argv)
 		run<4, 4, 0>(a, grid, flops, "library");
 		run<4, 4, 8192>(a, grid, flops, "epilogue stores with per-store vector address arithmetic (before round 5)");
 		run<4, 4, 0>(a, grid, flops, "library (again)");
-		run<4, 4, 4096>(a, grid, flops, "epilogue stores nt");
-		run<4, 4, 16384>(a, grid, flops, "epilogue stores sc1");
-		run<4, 4, 4096>(a, grid, flops, "epilogue stores nt (again)");
-		run<4, 4, 16384>(a, grid, flops, "epilogue stores sc1 (again)");
+		run<4, 4, 8192>(a, grid, flops, "epilogue stores with per-store vector address arithmetic (again)");
 	} else {
 		run<2, 8, 0>(a, grid, flops, "library");
 		run<2, 8, 8192>(a, grid, flops, "epilogue stores with per-store vector address arithmetic (before round 5)");
