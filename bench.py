@@ -215,6 +215,39 @@ def resnet_config(args, half, dawn=False):
     emit(out)
 
 
+def lstm_config(args):
+    """The recurrent half of the reference's NLP trainer (test/int/nnc/imdb.tests.c:972-980, :1278): ccv_cnnp_lstm -- 2 layers, 128 hidden units, masked,
+    batch-first -- at the IMDB classifier's shape (batch 64, sequences of 512 steps, 128 embedding features), evaluate + backward through the reference
+    host's model API on this backend's LSTM rows (tools/host_lstm_check.c with HOST_LSTM_BENCH: wall clock between two blocking read-backs).  The reference
+    has NO CPU implementation of the row (lib/nnc/cmd/rnn registers the GPU backend only), so there is no cpu_baseline; the first pass of the same process is
+    replayed against the numpy restatement by tests/test_via_host.py (anchored to torch.nn.LSTM in float64)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_lstm_check.gpu")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/host_lstm_check.gpu not built (oracle/build_ref_host.sh)")
+    nnc.load()  # fail loudly without the HIP library / a GPU
+    B = args.batch if args.batch != 256 else 64
+    T, I, H, layers = 512, 128, 128, 2
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([exe, str(T), str(B), str(I), str(H), str(layers), "0", "1", "1", os.path.join(d, "lstm.bin")], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, HOST_LSTM_BENCH=str(max(args.steps, 1))))
+    if r.returncode != 0:
+        raise SystemExit("host_lstm_check failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
+    h = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    out = {"metric": "sequences/sec fwd+bwd ccv_cnnp_lstm (IMDB classifier shape) bs%d" % B, "value": h["sequences_per_s"], "unit": "sequences/s", "n_gpus": 1, "steps": h["steps"], "warmup": 2,
+           "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "ccv_cnnp_lstm (2 layers, 128 hidden, masked, batch-first) evaluate + backward, batch %d x 512 steps x 128 features (test/int/nnc/imdb.tests.c:972-980), through the reference host's model API" % B,
+                      "global_batch": B, "parallelism": "dp1", "timesteps_per_s": h["timesteps_per_s"], "gflop_per_step": h["gflop_per_step"]},
+           # the row is bound by the hand-over between the workgroups of the one-launch kernel once per time step (DESIGN.md section 3.4), not by a pipe: the
+           # line reports its algorithmic rate against the fp32 matrix peak for scale
+           "roofline": {"bound": "mfma", "achieved": h["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": h["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "lstm_seq_forw_kernel / lstm_seq_back_kernel + the batched input contractions", "launches": None, "avg_ms": None},
+           "cpu_baseline": None}
+    out["config"]["cpu_baseline_note"] = "the reference has no CPU LSTM (lib/nnc/cmd/rnn: GPU backend only): nothing to time beside it"
+    emit(out)
+
+
 def host_cpu_baseline(args, half, dawn):
     """configs 4 / 5 next to the reference's own CPU path on this box's host cores: the SAME harness built against the reference's
     CPU backend (oracle/_ref/host_resnet_bench.cpu: the reference's unmodified host, its CPU_REF rows, every tensor in CPU memory, fp32) -- timed on a
@@ -288,7 +321,7 @@ def pmc_traffic(symbol, batch):
     return tot / n if n else None
 
 
-EXTRA_CONFIGS = ["vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512"]
+EXTRA_CONFIGS = ["vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512", "imdb-lstm-bs64"]
 
 
 def extra_configs(args):
@@ -400,7 +433,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
-    ap.add_argument("--config", default="vggd-train-bs256", choices=["vggd-train-bs256", "vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512", "cifar10-dawn-f32-bs512"],
+    ap.add_argument("--config", default="vggd-train-bs256", choices=["vggd-train-bs256", "vggd-fwd-bs64", "resnet50-nchw-bs256", "resnet50-nchw-bs256-f16", "cifar10-dawn-f16-bs512", "cifar10-dawn-f32-bs512", "imdb-lstm-bs64"],
                     help="BASELINE.json configs: 3 (default, the metric), 2 (VGG-D forward only, batch 64), 4 (ResNet-50 v1d NCHW through the reference host; -f16 = the trainer's own precision), 5 (CIFAR-10 DawnNet fp16, batch 512, through the reference host)")
     ap.add_argument("--dp", default="process", choices=["process", "host"], help="configs 4 / 5 at --gpus N > 1: one harness process per GPU (default), or the reference host's own single-process data parallelism (one host thread enqueues for all N devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -418,6 +451,10 @@ def main():
         args.batch = 64
     if args.config.startswith("cifar10") and args.batch == 256:
         args.batch = 512
+    if args.config == "imdb-lstm-bs64":
+        if rank == 0:
+            lstm_config(args)
+        return
     if args.config.startswith("resnet50") or args.config.startswith("cifar10"):
         if world > 1 and rank != 0:  # started under torch.distributed.run: this path is ONE process driving all the GPUs (the reference host's own data parallelism)
             return
