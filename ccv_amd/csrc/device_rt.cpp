@@ -188,8 +188,12 @@ ClusterTurn::ClusterTurn(const ccv_nnc_stream_context_t* ctx) : stream(stream_of
 	pthread_once(&g_cluster_turn_once, cluster_turn_init);
 	if (device < 0 || device >= MAX_DEVICES) { device = -1; return; }
 	auto& t = g_cluster_turn[device];
-	pthread_mutex_lock(&t.mutex); // held across the command's launches: the order of the turns is the order of their events
+	pthread_mutex_lock(&t.mutex); // held across the command's launches: the order of the turns is the order in which they were taken
 	if (t.have && t.last != stream) {
+		// the previous turn was taken on ANOTHER stream: an event behind everything queued there so far (its spinning launches included), and this stream
+		// waits for it.  Nothing is recorded while one stream takes turn after turn -- the common case costs no runtime call at all.
+		if (!t.event) HIP_ENFORCE(hipEventCreateWithFlags(&t.event, hipEventDisableTiming));
+		HIP_ENFORCE(hipEventRecord(t.event, t.last));
 		HIP_ENFORCE(hipStreamWaitEvent(stream, t.event, 0));
 		__atomic_add_fetch(&g_cluster_turns_chained, 1, __ATOMIC_RELAXED);
 	}
@@ -198,10 +202,18 @@ ClusterTurn::~ClusterTurn()
 {
 	if (device < 0) return;
 	auto& t = g_cluster_turn[device];
-	if (!t.event) HIP_ENFORCE(hipEventCreateWithFlags(&t.event, hipEventDisableTiming));
-	HIP_ENFORCE(hipEventRecord(t.event, stream)); // (a wait already queued on another stream refers to the record it saw, not to this one)
 	t.last = stream;
 	t.have = 1;
+	pthread_mutex_unlock(&t.mutex);
+}
+// a stream is about to be destroyed: it must not be recorded on later (device_rt.cpp's local_release calls this after draining it -- nothing of its turns is left to wait for)
+static void cluster_turn_forget(const int device, hipStream_t stream)
+{
+	pthread_once(&g_cluster_turn_once, cluster_turn_init);
+	if (device < 0 || device >= MAX_DEVICES) return;
+	auto& t = g_cluster_turn[device];
+	pthread_mutex_lock(&t.mutex);
+	if (t.have && t.last == stream) t.have = 0;
 	pthread_mutex_unlock(&t.mutex);
 }
 
@@ -583,7 +595,7 @@ static void local_release(device_local_t* l)
 	nnc::comm_flush_if_pending();
 	const int prev = current_device();
 	HIP_ENFORCE(hipSetDevice(l->device));
-	if (l->stream) HIP_ENFORCE(hipStreamSynchronize(l->stream));
+	if (l->stream) { HIP_ENFORCE(hipStreamSynchronize(l->stream)); nnc::cluster_turn_forget(l->device, l->stream); }
 	if (l->workspace) release_device_block(l->workspace, true);
 	if (l->staging) release_device_block(l->staging, true);
 	if (l->cluster_sync) release_device_block(l->cluster_sync, true);
