@@ -7,7 +7,12 @@
 #include "../include/nnc_mi355x_pipeline.h"
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
+
+/* A failed stage must not hand the trainer an unwritten batch: these checks stay in NDEBUG builds and stop the process with the reason,
+ * as the reference's own *_ENFORCE macros do for device errors. */
+#define NNC_DF_ENFORCE(cond, what) do { if (!(cond)) { fprintf(stderr, "[nnc_mi355x dataframe] %s (%s:%d)\n", what, __FILE__, __LINE__); abort(); } } while (0)
 
 typedef struct {
 	sfmt_t sfmt;
@@ -152,7 +157,7 @@ static void jitter_batch_sample(void* const* const input_data, const int batch_s
 	for (i = 0; i < batch_size; i++) {
 		void* const* const tuple = (void* const*)input_data[i];
 		const ccv_dense_matrix_t* const image = (const ccv_dense_matrix_t*)tuple[0];
-		assert(CCV_GET_DATA_TYPE(image->type) == CCV_8U && CCV_GET_CHANNEL(image->type) == CCV_C3);
+		NNC_DF_ENFORCE(CCV_GET_DATA_TYPE(image->type) == CCV_8U && CCV_GET_CHANNEL(image->type) == CCV_C3, "the image column must hold 8-bit, 3-channel matrices");
 		items[i].offset = bytes; items[i].rows = image->rows; items[i].cols = image->cols; items[i].step = image->step;
 		bytes += ((size_t)image->step * image->rows + 15) & ~(size_t)15;
 		decide(ctx->jitter, &sfmt[i], image->rows, image->cols, &items[i]);
@@ -165,7 +170,7 @@ static void jitter_batch_sample(void* const* const input_data, const int batch_s
 		ctx->slot_bytes = bytes + bytes / 4 + 4096;
 		ctx->ring = nnc_mi355x_staging_ring_new(ctx->device_id, ctx->slots, ctx->slot_bytes);
 		ctx->next_slot = 0;
-		assert(ctx->ring);
+		NNC_DF_ENFORCE(ctx->ring, "the pinned staging ring could not be allocated");
 	}
 	const int slot = ctx->next_slot;
 	ctx->next_slot = (slot + 1) % ctx->slots;
@@ -176,19 +181,19 @@ static void jitter_batch_sample(void* const* const input_data, const int batch_s
 	}
 	int ok = nnc_mi355x_staging_ring_submit(ctx->ring, slot, bytes);
 	ok = ok && nnc_mi355x_staging_ring_acquire(ctx->ring, slot, stream_context);
-	assert(ok);
+	NNC_DF_ENFORCE(ok, "the staging ring refused the slot (submit / acquire out of order)");
 	nnc_mi355x_jitter_params_t params;
 	memset(&params, 0, sizeof(params));
 	params.out_rows = rows; params.out_cols = cols; params.channels = 3;
 	for (i = 0; i < 3; i++) { params.mean[i] = ctx->jitter.normalize.mean[i]; params.inv_std[i] = ctx->jitter.normalize.std[i]; }
 	params.format = ctx->format; params.datatype = ctx->datatype;
 	const int r = nnc_mi355x_jitter_batch(nnc_mi355x_staging_ring_device(ctx->ring, slot), items, batch_size, params, b->images->data.u8, stream_context);
-	assert(r == CCV_NNC_EXEC_SUCCESS);
+	NNC_DF_ENFORCE(r == CCV_NNC_EXEC_SUCCESS, "nnc_mi355x_jitter_batch failed: the batch tensor was not written");
 	ok = nnc_mi355x_staging_ring_release(ctx->ring, slot, stream_context);
-	assert(ok);
+	NNC_DF_ENFORCE(ok, "the staging ring refused the release");
 	if (b->one_hot) {
 		const int r2 = nnc_mi355x_one_hot_batch(labels, batch_size, ctx->range, ctx->onval, ctx->offval, ctx->datatype, b->one_hot->data.u8, stream_context);
-		assert(r2 == CCV_NNC_EXEC_SUCCESS);
+		NNC_DF_ENFORCE(r2 == CCV_NNC_EXEC_SUCCESS, "nnc_mi355x_one_hot_batch failed: the label tensor was not written");
 	}
 	free(items);
 	free(labels);
@@ -198,8 +203,8 @@ ccv_cnnp_dataframe_t* nnc_mi355x_dataframe_jitter_batch_new(ccv_cnnp_dataframe_t
 	const int batch_size, const ccv_cnnp_random_jitter_t random_jitter, const int one_hot_range, const float onval, const float offval,
 	const int datatype, const int format, const int device_id, const int slots)
 {
-	assert(random_jitter.resize.min > 0 && random_jitter.resize.max >= random_jitter.resize.min);
-	assert(random_jitter.size.rows > 0 && random_jitter.size.cols > 0); /* a batch tensor has ONE image size */
+	NNC_DF_ENFORCE(random_jitter.resize.min > 0 && random_jitter.resize.max >= random_jitter.resize.min, "random_jitter.resize: 0 < min <= max");
+	NNC_DF_ENFORCE(random_jitter.size.rows > 0 && random_jitter.size.cols > 0, "random_jitter.size: a batch tensor has ONE image size"); /* a batch tensor has ONE image size */
 	jitter_batch_context_t* const ctx = (jitter_batch_context_t*)calloc(1, sizeof(jitter_batch_context_t));
 	if (random_jitter.seed) sfmt_init_gen_rand(&ctx->sfmt, (uint32_t)random_jitter.seed);
 	else sfmt_init_gen_rand(&ctx->sfmt, ccv_nnc_stream_context_genrand_uint32(0));
