@@ -300,8 +300,11 @@ static void area_x_taps(int a_cols, int b_cols, int ch, double scale_x, W full, 
 // symbolically -- `sum` is kept as a list of (source row, weight) instead of a value.
 static void area_y_taps_8u(int a_rows, int b_rows, double scale_y, std::vector<int>& start, std::vector<tap_u32_t>& taps)
 {
-	std::vector<std::vector<tap_u32_t> > out(b_rows);
-	std::vector<tap_u32_t> sum;
+	// (output rows are finished in increasing order, so a row's taps -- the carried list `sum` plus the closing tap -- are appended as the row closes: no
+	// per-row lists; round 5: the vector of vectors this replaces was 224 allocations per image in the jitter path)
+	tap_u32_t sum[2 + 256];
+	int nsum = 0;
+	start.assign(b_rows + 1, 0);
 	int dy = 0, dy_weight_256 = 0;
 	for (int sy = 0; sy < a_rows; sy++) {
 		if (dy < b_rows && (dy + 1) * scale_y <= sy + 1) {
@@ -309,10 +312,12 @@ static void area_y_taps_8u(int a_rows, int b_rows, double scale_y, std::vector<i
 			const unsigned beta1 = 256 - beta;
 			if (sy == a_rows - 1) beta = (unsigned)(int)(scale_y * 256);
 			else dy_weight_256 = (int)beta;
-			out[dy] = sum;
+			start[dy] = (int)taps.size();
+			taps.insert(taps.end(), sum, sum + nsum);
 			tap_u32_t t; t.si = sy;
-			if ((int)beta <= 0) { t.w = 256; out[dy].push_back(t); sum.clear(); }
-			else { t.w = beta1; out[dy].push_back(t); sum.clear(); t.w = beta; sum.push_back(t); }
+			nsum = 0;
+			if ((int)beta <= 0) { t.w = 256; taps.push_back(t); }
+			else { t.w = beta1; taps.push_back(t); t.w = beta; sum[nsum++] = t; }
 			dy++;
 		} else if (dy >= b_rows) {
 			// the reference would write past b here; cannot happen for the scales it is called with (rows_scale = b/a)
@@ -321,19 +326,18 @@ static void area_y_taps_8u(int a_rows, int b_rows, double scale_y, std::vector<i
 			tap_u32_t t; t.si = sy;
 			if (sy == a_rows - 1) { dy_weight_256 = (int)(scale_y * 256) - dy_weight_256; t.w = (unsigned)dy_weight_256; }
 			else { dy_weight_256 += 256; t.w = 256; }
-			sum.push_back(t);
+			if (nsum < (int)(sizeof(sum) / sizeof(sum[0]))) sum[nsum++] = t;
 		}
 	}
-	for (; dy < b_rows; dy++) out[dy] = sum; // :125-130
-	start.assign(b_rows + 1, 0);
-	for (int i = 0; i < b_rows; i++) { start[i] = (int)taps.size(); taps.insert(taps.end(), out[i].begin(), out[i].end()); }
+	for (; dy < b_rows; dy++) { start[dy] = (int)taps.size(); taps.insert(taps.end(), sum, sum + nsum); } // :125-130
 	start[b_rows] = (int)taps.size();
 }
 // The float variant (lib/ccv_resample.c:186-243): weights 1 for full rows, beta carried into the next output row.
 static void area_y_taps_f32(int a_rows, int b_rows, double scale_y, std::vector<int>& start, std::vector<tap_f32_t>& taps)
 {
-	std::vector<std::vector<tap_f32_t> > out(b_rows);
-	std::vector<tap_f32_t> sum;
+	std::vector<tap_f32_t>& sum = *([]() { static thread_local std::vector<tap_f32_t> v; return &v; })();
+	sum.clear();
+	start.assign(b_rows + 1, 0);
 	int dy = 0;
 	float dy_weight = 0;
 	for (int sy = 0; sy < a_rows; sy++) {
@@ -342,10 +346,12 @@ static void area_y_taps_f32(int a_rows, int b_rows, double scale_y, std::vector<
 			const float beta1 = 1 - beta;
 			if (sy == a_rows - 1) beta = (float)scale_y;
 			else dy_weight = beta;
-			out[dy] = sum;
+			start[dy] = (int)taps.size();
+			taps.insert(taps.end(), sum.begin(), sum.end());
 			tap_f32_t t; t.si = sy;
-			if (fabsf(beta) < 1e-3f) { t.w = 1.f; out[dy].push_back(t); sum.clear(); }
-			else { t.w = beta1; out[dy].push_back(t); sum.clear(); t.w = beta; sum.push_back(t); }
+			sum.clear();
+			if (fabsf(beta) < 1e-3f) { t.w = 1.f; taps.push_back(t); }
+			else { t.w = beta1; taps.push_back(t); t.w = beta; sum.push_back(t); }
 			dy++;
 		} else if (dy >= b_rows) break;
 		else {
@@ -355,9 +361,7 @@ static void area_y_taps_f32(int a_rows, int b_rows, double scale_y, std::vector<
 			sum.push_back(t);
 		}
 	}
-	for (; dy < b_rows; dy++) out[dy] = sum;
-	start.assign(b_rows + 1, 0);
-	for (int i = 0; i < b_rows; i++) { start[i] = (int)taps.size(); taps.insert(taps.end(), out[i].begin(), out[i].end()); }
+	for (; dy < b_rows; dy++) { start[dy] = (int)taps.size(); taps.insert(taps.end(), sum.begin(), sum.end()); }
 	start[b_rows] = (int)taps.size();
 }
 
@@ -677,10 +681,16 @@ int nnc_mi355x_jitter_batch(const void* src, const nnc_mi355x_jitter_image_t* im
 	if ((odt != CCV_32F && odt != CCV_16F) || (params.format != CCV_TENSOR_FORMAT_NHWC && params.format != CCV_TENSOR_FORMAT_NCHW)) return CCV_NNC_EXEC_INVALID;
 	if (count == 0) return CCV_NNC_EXEC_SUCCESS;
 	const int ch = params.channels;
-	std::vector<jitter_dev_t> descs(count);
-	std::vector<int> mean_list; // images with a contrast operation
-	std::vector<int> starts;
-	std::vector<tap_f32_t> taps;
+	// (round 5: the per-image tables are built into buffers that live for the thread -- four vectors used to be constructed, grown and destroyed per image,
+	// a thousand allocations per batch of 256, most of the host's 4 ms per batch)
+	static thread_local std::vector<jitter_dev_t> descs;
+	static thread_local std::vector<int> mean_list; // images with a contrast operation
+	static thread_local std::vector<int> starts;
+	static thread_local std::vector<tap_f32_t> taps;
+	static thread_local std::vector<int> xs, ys;
+	static thread_local std::vector<tap_f32_t> xt, yt;
+	descs.assign(count, jitter_dev_t());
+	mean_list.clear(); starts.clear(); taps.clear();
 	for (int i = 0; i < count; i++) {
 		const nnc_mi355x_jitter_image_t& im = images[i];
 		if (im.slice_rows < 1 || im.slice_cols < 1 || im.resize_rows < 1 || im.resize_cols < 1 || im.slice_x < 0 || im.slice_y < 0 || im.slice_x + im.slice_cols > im.cols || im.slice_y + im.slice_rows > im.rows) return CCV_NNC_EXEC_INVALID;
@@ -698,8 +708,7 @@ int nnc_mi355x_jitter_batch(const void* src, const nnc_mi355x_jitter_image_t* im
 		}
 		if (contrasts > 1) return CCV_NNC_EXEC_INVALID; // (the reference applies each operation at most once)
 		if (contrasts) { d.mean_slot = (int)mean_list.size(); mean_list.push_back(i); }
-		std::vector<int> xs, ys;
-		std::vector<tap_f32_t> xt, yt;
+		xs.clear(); ys.clear(); xt.clear(); yt.clear();
 		const double scale_x = (double)im.slice_cols / im.resize_cols, scale_y = (double)im.slice_rows / im.resize_rows;
 		if (im.slice_rows >= im.resize_rows && im.slice_cols >= im.resize_cols && (im.slice_rows != im.resize_rows || im.slice_cols != im.resize_cols)) { // CCV_INTER_AREA (:335-338)
 			const double scale = 1.f / (scale_x * scale_y);
