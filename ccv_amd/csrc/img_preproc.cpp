@@ -11,13 +11,12 @@
 //   * area 8u -> 8u is integer-only on the device and BIT-EXACT (uint32 sums are order-independent);
 //   * float area / bicubic replay the reference's accumulation order per element (horizontal taps first, then rows);
 //   * the direct 8-bit filter is integer-only and bit-exact (replicated border, 2^14 fixed-point coefficients).
-// The float filter path of the reference goes through a tiled FFT (_ccv_filter_kissfft, ccv_numeric.c:771-): the kernel is
-// flipped into the tile, the tile is zero-filled around the image data and the output is read back at an offset of size / 2,
-// which makes the result   d[y][x] = sum_{i,j} a[y + i - (kh - 1) / 2][x + j - (kw - 1) / 2] * b[i][j],   a = 0 outside the image
-// (centre tap (size - 1) / 2 for even AND odd windows: test/unit/numeric.tests.c:112-150) -- wherever the tile is large enough
-// for the circular convolution to be linear (image + kernel - 1 <= the tile: small images, and the interior of large ones; at
-// the borders of an image larger than one tile the reference's rows wrap around within the tile, an artefact of the tiling).
-// Here the same sum is computed directly, with the zero border everywhere.
+// The float filter path of the reference goes through a TILED FFT (_ccv_filter_kissfft, ccv_numeric.c:771-): the kernel is flipped into a tile, the tile is
+// filled with an image window (zeros where it leaves the image), convolved circularly, and a block of the result is copied out at an offset of size / 2 --
+//   d[y][x] = sum_{i,j} a[y + i - (kh - 1) / 2][x + j - (kw - 1) / 2] * b[i][j],   a = 0 outside the image
+// (centre tap (size - 1) / 2 for even AND odd windows: test/unit/numeric.tests.c:112-150) wherever window + kernel fit the tile; at the borders of an image that
+// needs several tiles the far rows / columns of a tile's window wrap in.  Round 5: filter_f32_kernel reproduces that tiling (per-row / per-column maps of window
+// origin, extent and read position, filter_axis_map), so the whole image agrees with the reference, borders included -- the same sums, added directly.
 #include "common.h"
 #include "isa.h"
 #include <math.h>
@@ -249,9 +248,17 @@ __global__ void __launch_bounds__(256) filter_8u_kernel(const unsigned char* a, 
 		d[img * d_image + (long)y * d_step + x] = (unsigned char)(z < 0 ? 0 : z > 255 ? 255 : z);
 	}
 }
-// float correlation, zero border, centre tap (size - 1) / 2, any channel count (the kernel b has the image's channel count or 1)
+// float correlation with the reference's TILED circular semantics (round 5; _ccv_filter_kissfft, lib/ccv_numeric.c:771-958).  The reference cuts the image into
+// tiles of `trows x tcols`, fills a tile with the image window at (oy, ox) -- zeros where the window leaves the image --, convolves it CIRCULARLY with the
+// flipped kernel and copies a block of the result to the output.  Which tile serves an output row and where in the tile's result the row is read are functions
+// of the row alone (the same for columns), so the host hands over two small maps -- {window origin, rows of the window inside the image, row of the circular
+// result} per output row and per output column (filter_axis_map below replays the reference's loops, later tiles overwriting earlier ones as they do) -- and
+// an output element is   sum_{i, j} b[i][j] * T[(p_y - (kh - 1) + i) mod trows][(p_x - (kw - 1) + j) mod tcols],   T = the zero-filled window.
+// Where a window plus the kernel fits the tile this is the plain correlation with a zero border and centre tap (size - 1) / 2; at the borders of an image that
+// needs several tiles the window's far rows / columns wrap in, exactly as in the reference.  Same sums, added directly instead of through an FFT (fp32 rounding apart).
+struct filter_map_t { int o, end, p; }; // window origin, window extent inside the image, index into the circular result; p < 0: the reference writes nothing there
 __global__ void __launch_bounds__(256) filter_f32_kernel(const float* a, float* d, const long a_step, const long a_image, const long d_step, const long d_image,
-	const int rows, const int cols, const int ch, const float* coeff, const int kh, const int kw, const int kch, const size_t total)
+	const int rows, const int cols, const int ch, const float* coeff, const int kh, const int kw, const int kch, const filter_map_t* rowmap, const filter_map_t* colmap, const int trows, const int tcols, const size_t total)
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -261,17 +268,21 @@ __global__ void __launch_bounds__(256) filter_f32_kernel(const float* a, float* 
 		const size_t img = r / rows;
 		const int x = e / ch, c = e - x * ch;
 		const float* ai = (const float*)((const char*)a + img * a_image);
+		const filter_map_t rm = rowmap[y], cm = colmap[x];
 		float z = 0.f;
-		for (int i = 0; i < kh; i++) {
-			const int sy = y + i - (kh - 1) / 2;
-			if (sy < 0 || sy > rows - 1) continue;
-			const float* row = (const float*)((const char*)ai + (long)sy * a_step);
-			for (int j = 0; j < kw; j++) {
-				const int sx = x + j - (kw - 1) / 2;
-				if (sx < 0 || sx > cols - 1) continue;
-				z += row[sx * ch + c] * coeff[(i * kw + j) * kch + (kch > 1 ? c : 0)];
+		if (rm.p >= 0 && cm.p >= 0)
+			for (int i = 0; i < kh; i++) {
+				int ty = rm.p - (kh - 1) + i;
+				if (ty < 0) ty += trows; // (p < trows and kh <= trows: one wrap at most)
+				if (ty >= rm.end) continue;
+				const float* row = (const float*)((const char*)ai + (long)(rm.o + ty) * a_step);
+				for (int j = 0; j < kw; j++) {
+					int tx = cm.p - (kw - 1) + j;
+					if (tx < 0) tx += tcols;
+					if (tx >= cm.end) continue;
+					z += row[(cm.o + tx) * ch + c] * coeff[(i * kw + j) * kch + (kch > 1 ? c : 0)];
+				}
 			}
-		}
 		((float*)((char*)d + img * d_image + (long)y * d_step))[e] = z;
 	}
 }
@@ -536,6 +547,41 @@ __global__ void __launch_bounds__(256) one_hot_kernel(const int* labels, TO* out
 }
 
 } // namespace
+
+// One axis of _ccv_filter_kissfft's tiling (lib/ccv_numeric.c:775-776 tile size, :836-839 tile count, :846-925 the copy-out blocks): n = image extent, k = kernel
+// extent.  Returns the tile extent (0: the reference itself would divide by zero -- a one-pixel axis under an even kernel; the caller refuses) and fills map[0 .. n - 1].
+static int kiss_next_fast(int n)
+{ // kiss_fft_next_fast_size (lib/3rdparty/kissfft/kiss_fft.c:396-408)
+	for (;;) {
+		int m = n;
+		while (m % 2 == 0) m /= 2;
+		while (m % 3 == 0) m /= 3;
+		while (m % 5 == 0) m /= 5;
+		if (m <= 1) return n;
+		n++;
+	}
+}
+static int filter_axis_map(const int n, const int k, std::vector<filter_map_t>& map)
+{
+	const int fast = kiss_next_fast((k * 3 + 1) >> 1) << 1; // kiss_fftr_next_fast_size_real(k * 3)
+	const int t = ((imin(n + k - 1, fast) + 1) >> 1) << 1;
+	const int ke = k & ~1, k2 = k / 2;
+	map.assign(n, filter_map_t{ 0, 0, -1 });
+	if (t - ke <= 0) return 0;
+	const int tiles = imax(1, (n + t - 2 * ke) / (t - ke));
+	for (int i = 0; i < tiles; i++) {
+		const int o = imin(i * (t - ke), imax(n - t, 0));
+		const int end_in = imin(t, n - o);
+		const int out0 = o + (i > 0 ? k2 : 0);
+		const int end = imin(n - out0, (t - ke) + (i == 0 ? k2 : 0));
+		for (int y = 0; y < end; y++) map[out0 + y] = filter_map_t{ o, end_in, (1 + (i > 0 ? 1 : 0)) * k2 + y };
+		if (i + 1 == tiles && end + out0 < n) { // the last tile's edge block: read from the top of the circular result
+			const int end_tile = imin(k2, n - (out0 + end));
+			for (int y = 0; y < end_tile; y++) map[out0 + end + y] = filter_map_t{ o, end_in, y };
+		}
+	}
+	return t;
+}
 
 // ---- the 8-bit area path's tap tables, per geometry, resident on the device (a few KB each; the least recently used of 16 gives way)
 namespace {
@@ -814,10 +860,15 @@ int nnc_mi355x_filter_batch(const void* a, const nnc_mi355x_image_batch_t ad, co
 	} else if (adt == CCV_32F && ddt == CCV_32F) {
 		if (kernel_channels != 1 && kernel_channels != ad.channels) return CCV_NNC_EXEC_INVALID;
 		const size_t oc = u.add(kf, sizeof(float) * kernel_rows * kernel_cols * kernel_channels);
+		std::vector<filter_map_t> rowmap, colmap;
+		const int trows = filter_axis_map(ad.rows, kernel_rows, rowmap), tcols = filter_axis_map(ad.cols, kernel_cols, colmap);
+		if (trows <= 0 || tcols <= 0) return CCV_NNC_EXEC_INVALID; // (the reference divides by zero there)
+		const size_t orm = u.add(rowmap.data(), rowmap.size() * sizeof(filter_map_t)), ocm = u.add(colmap.data(), colmap.size() * sizeof(filter_map_t));
 		char* dev = upload(u, stream_context);
 		if (!dev) return CCV_NNC_EXEC_OOM;
 		const size_t total = (size_t)count * ad.rows * ad.cols * ad.channels;
-		hipLaunchKernelGGL(filter_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const float*)a, (float*)d, ad.step, ad.image_stride, dd.step, dd.image_stride, ad.rows, ad.cols, ad.channels, (const float*)(dev + oc), kernel_rows, kernel_cols, kernel_channels, total);
+		hipLaunchKernelGGL(filter_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const float*)a, (float*)d, ad.step, ad.image_stride, dd.step, dd.image_stride, ad.rows, ad.cols, ad.channels, (const float*)(dev + oc), kernel_rows, kernel_cols, kernel_channels,
+			(const filter_map_t*)(dev + orm), (const filter_map_t*)(dev + ocm), trows, tcols, total);
 	} else
 		return CCV_NNC_EXEC_INVALID;
 	HIP_ENFORCE(hipGetLastError());

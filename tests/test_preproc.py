@@ -250,6 +250,20 @@ def test_filter_f32_interior(backend, classic, shape, ksize):
     np.testing.assert_allclose(got[kh:-kh, kw:-kw], want[kh:-kh, kw:-kw], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape,ksize", [((30, 28), (3, 3)), ((44, 40), (11, 11)), ((25, 33), (5, 7)), ((64, 50), (4, 6)), ((37, 90), (7, 3)), ((100, 100), (9, 9)), ((23, 61), (8, 5)), ((19, 19), (2, 2))])
+def test_filter_f32_whole_image_with_the_reference_tiling(backend, classic, shape, ksize):
+    """Round 5: images that need SEVERAL tiles of the reference's FFT path.  At their borders the reference's circular
+    convolution wraps the far rows / columns of a tile's window in (lib/ccv_numeric.c:846-925); the kernel now reproduces that tiling (window origin, extent and
+    read position per output row / column, filter_axis_map in img_preproc.cpp), so EVERY output element is compared, borders included -- odd and even windows,
+    one and several tiles per axis, the clamped last tile and its edge block."""
+    rng = np.random.default_rng(12)
+    a = rng.random(shape + (1,), dtype=np.float32)
+    k = rng.random(ksize, dtype=np.float32)
+    got = our_filter(backend, [a], k)[0]
+    want = ref_filter(classic, a, k)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-4 * float(k.sum()))
+
+
 @pytest.mark.parametrize("shape,ksize", [((12, 14), (7, 7)), ((10, 10), (10, 10)), ((11, 11), (11, 11)), ((9, 13), (6, 7)), ((16, 12), (9, 8))])
 def test_filter_f32_whole_image_where_the_reference_fft_is_linear(backend, classic, shape, ksize):
     """Images that fit ONE tile of the reference's FFT path with room for the kernel (image + kernel - 1 <= tile:
