@@ -62,13 +62,14 @@ __global__ void __launch_bounds__(256) area_8u_kernel(const unsigned char* a, un
 // is fetched once per output row that taps it (neighbouring rows' workgroups find it in L2).  The quotient acc / inv_scale_256 is at most a few hundred: a float
 // estimate corrected by one exact multiply-compare replaces the 32-bit division.  Needs: 4-byte aligned source rows and destination rows, channels 1 / 3 / 4.
 // where column sum x of a row lives in LDS: a lane's sixteen sums are four 16-byte pieces; piece k of lane u sits at piece slot k ^ ((u >> 1) & 3)
-template <int VEC> __device__ __forceinline__ int area_col(const int x) { return VEC == 16 ? (x & ~12) | ((((x >> 2) ^ (x >> 5)) & 3) << 2) : x; }
+template <int VEC> __host__ __device__ __forceinline__ int area_col(const int x) { return VEC == 16 ? (x & ~12) | ((((x >> 2) ^ (x >> 5)) & 3) << 2) : x; }
 // R consecutive output rows per workgroup: the kernel is bound by the LATENCY of its dependent loads (tap tables -> source rows -> LDS -> taps again), not by
 // bytes or arithmetic -- one row per workgroup ran at 1.3 TB/s with every pipe idle most of the time -- so a workgroup issues the source loads of R rows back
 // to back and applies a lane's horizontal taps (loaded once) to all R rows' column sums.
-template <int CH, int VEC, int R>
+struct etap_t { unsigned off, w; };
+template <int VEC, int R>
 __global__ void __launch_bounds__(128) area_8u_rows_kernel(const unsigned char* __restrict__ a, unsigned char* __restrict__ b, const long a_step, const long a_image, const long b_step, const long b_image,
-	const int b_rows, const int b_cols_ch, const int a_cols_ch, const int row_groups, const int* __restrict__ xstart, const tap_u32_t* __restrict__ xtaps, const int* __restrict__ ystart, const tap_u32_t* __restrict__ ytaps, const unsigned inv_scale_256, const float inv_scale_rcp)
+	const int b_rows, const int b_cols_ch, const int a_cols_ch, const int row_groups, const etap_t* __restrict__ etab, const int e_pitch, const int maxt, const int* __restrict__ ystart, const tap_u32_t* __restrict__ ytaps, const unsigned inv_scale_256, const float inv_scale_rcp)
 {
 	HIP_DYNAMIC_SHARED(unsigned, area_v) // column sums of the R output rows: R x pitch (pitch = a_cols_ch rounded up to whole lanes' worth)
 	const int dy0 = (int)(blockIdx.x % (unsigned)row_groups) * R;
@@ -105,39 +106,38 @@ __global__ void __launch_bounds__(128) area_8u_rows_kernel(const unsigned char* 
 		}
 	}
 	__syncthreads();
+	// horizontal taps per OUTPUT ELEMENT, structure of arrays (etab[k][e] = {LDS column -- swizzled for this VEC --, weight}; missing taps have weight 0): a
+	// lane's four consecutive elements are 32 contiguous bytes per tap index -- two 16-byte loads, coalesced across the wave --, read once and applied to all R rows
 	for (int t4 = (int)threadIdx.x * 4; t4 < b_cols_ch; t4 += 128 * 4) {
-		unsigned packed[R];
+		unsigned h[R][4];
 #pragma unroll
-		for (int r = 0; r < R; r++) packed[r] = 0;
+		for (int r = 0; r < R; r++)
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int e = t4 + j;
-			if (e < b_cols_ch) {
-				const int dx = e / CH, c = e - dx * CH;
-				unsigned h[R];
+			for (int j = 0; j < 4; j++) h[r][j] = 0;
+		for (int k = 0; k < maxt; k++) {
+			const uint4* const tp = (const uint4*)(etab + (size_t)k * e_pitch + t4); // (e_pitch is a multiple of 4 elements: whole 32-byte groups, in range)
+			const uint4 t01 = tp[0], t23 = tp[1];
+			const unsigned off[4] = { t01.x, t01.z, t23.x, t23.z }, w[4] = { t01.y, t01.w, t23.y, t23.w };
 #pragma unroll
-				for (int r = 0; r < R; r++) h[r] = 0;
-				for (int kx = xstart[dx]; kx < xstart[dx + 1]; kx++) {
-					const tap_u32_t t = xtaps[kx];
+			for (int j = 0; j < 4; j++)
 #pragma unroll
-					for (int r = 0; r < R; r++) h[r] += nnc_mul24(area_v[r * pitch + area_col<VEC>(t.si + c)], t.w); // (a column sum is < 2^24: 255 x the row weights, whose sum is at most 2^16)
-				}
-#pragma unroll
-				for (int r = 0; r < R; r++) {
-					unsigned q = (unsigned)((float)h[r] * inv_scale_rcp); // within one of h / inv_scale_256 (the quotient is < 2^16, the estimate's error < 2^-7)
-					const int rem = (int)(h[r] - nnc_mul24(q, inv_scale_256)); // the true remainder lies in (-d, 2 d), d < 2^24: exact in wrapping 32-bit arithmetic
-					if (rem < 0) q--;
-					else if (rem >= (int)inv_scale_256) q++;
-					packed[r] |= (q > 255 ? 255u : q) << (8 * j);
-				}
-			}
+				for (int r = 0; r < R; r++) h[r][j] += nnc_mul24(area_v[r * pitch + off[j]], w[j]); // (a column sum is < 2^24: 255 x the row weights, whose sum is at most 2^16)
 		}
 #pragma unroll
 		for (int r = 0; r < R; r++) {
 			if (dy0 + r >= b_rows) break;
+			unsigned packed = 0;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				unsigned q = (unsigned)((float)h[r][j] * inv_scale_rcp); // within one of h / inv_scale_256 (the quotient is < 2^16, the estimate's error < 2^-7)
+				const int rem = (int)(h[r][j] - nnc_mul24(q, inv_scale_256)); // the true remainder lies in (-d, 2 d), d < 2^24: exact in wrapping 32-bit arithmetic
+				if (rem < 0) q--;
+				else if (rem >= (int)inv_scale_256) q++;
+				packed |= (q > 255 ? 255u : q) << (8 * j);
+			}
 			unsigned char* const brow = b + img * b_image + (long)(dy0 + r) * b_step;
-			if (t4 + 4 <= b_cols_ch) *(unsigned*)(brow + t4) = packed[r];
-			else for (int j = 0; t4 + j < b_cols_ch; j++) brow[t4 + j] = (unsigned char)(packed[r] >> (8 * j));
+			if (t4 + 4 <= b_cols_ch) *(unsigned*)(brow + t4) = packed;
+			else for (int j = 0; t4 + j < b_cols_ch; j++) brow[t4 + j] = (unsigned char)(packed >> (8 * j));
 		}
 	}
 }
@@ -585,11 +585,11 @@ static int filter_axis_map(const int n, const int k, std::vector<filter_map_t>& 
 
 // ---- the 8-bit area path's tap tables, per geometry, resident on the device (a few KB each; the least recently used of 16 gives way)
 namespace {
-struct area_tables_t { int a_rows, a_cols, b_rows, b_cols, ch, device, live; double sx, sy; char* dev; size_t oxs, oxt, oys, oyt; unsigned inv; unsigned long stamp; };
+struct area_tables_t { int a_rows, a_cols, b_rows, b_cols, ch, device, live; double sx, sy; char* dev; size_t oxs, oxt, oys, oyt, oe16, oe4; int e_pitch, maxt; unsigned inv; unsigned long stamp; };
 area_tables_t g_area_tables[16];
 unsigned long g_area_stamp = 0;
 pthread_mutex_t g_area_mutex = PTHREAD_MUTEX_INITIALIZER;
-char* area_8u_tables(const int a_rows, const int a_cols, const int b_rows, const int b_cols, const int ch, const double sx, const double sy, size_t* oxs, size_t* oxt, size_t* oys, size_t* oyt, unsigned* inv)
+char* area_8u_tables(const int a_rows, const int a_cols, const int b_rows, const int b_cols, const int ch, const double sx, const double sy, size_t* oxs, size_t* oxt, size_t* oys, size_t* oyt, unsigned* inv, size_t* oe16, size_t* oe4, int* e_pitch, int* maxt)
 {
 	int device = 0;
 	HIP_ENFORCE(hipGetDevice(&device));
@@ -610,6 +610,19 @@ char* area_8u_tables(const int a_rows, const int a_cols, const int b_rows, const
 		upload_t u;
 		area_tables_t e;
 		e.oxs = u.add(xs.data(), xs.size() * sizeof(int)); e.oxt = u.add(xt.data(), xt.size() * sizeof(tap_u32_t)); e.oys = u.add(ys.data(), ys.size() * sizeof(int)); e.oyt = u.add(yt.data(), yt.size() * sizeof(tap_u32_t));
+		// the rows kernel's per-element tables (see area_8u_rows_kernel): [tap index][output element], the LDS column pre-swizzled for the 16-byte and the 4-byte variant
+		e.maxt = 1;
+		for (int dx = 0; dx < b_cols; dx++) e.maxt = imax(e.maxt, xs[dx + 1] - xs[dx]);
+		e.e_pitch = (b_cols * ch + 3) & ~3;
+		std::vector<etap_t> e16((size_t)e.maxt * e.e_pitch, etap_t{ 0, 0 }), e4((size_t)e.maxt * e.e_pitch, etap_t{ 0, 0 });
+		for (int dx = 0; dx < b_cols; dx++)
+			for (int c = 0; c < ch; c++)
+				for (int kx = xs[dx]; kx < xs[dx + 1]; kx++) {
+					const size_t at = (size_t)(kx - xs[dx]) * e.e_pitch + dx * ch + c;
+					e16[at] = etap_t{ (unsigned)area_col<16>(xt[kx].si + c), xt[kx].w };
+					e4[at] = etap_t{ (unsigned)area_col<4>(xt[kx].si + c), xt[kx].w };
+				}
+		e.oe16 = u.add(e16.data(), e16.size() * sizeof(etap_t)); e.oe4 = u.add(e4.data(), e4.size() * sizeof(etap_t));
 		e.dev = (char*)nnc_mi355x_malloc(device, u.host.size());
 		if (!e.dev) { *inv = 1; pthread_mutex_unlock(&g_area_mutex); return 0; }
 		HIP_ENFORCE(hipMemcpy(e.dev, u.host.data(), u.host.size(), hipMemcpyHostToDevice)); // (once per geometry)
@@ -622,7 +635,7 @@ char* area_8u_tables(const int a_rows, const int a_cols, const int b_rows, const
 		hit = lru;
 	}
 	hit->stamp = ++g_area_stamp;
-	*oxs = hit->oxs; *oxt = hit->oxt; *oys = hit->oys; *oyt = hit->oyt; *inv = hit->inv;
+	*oxs = hit->oxs; *oxt = hit->oxt; *oys = hit->oys; *oyt = hit->oyt; *inv = hit->inv; *oe16 = hit->oe16; *oe4 = hit->oe4; *e_pitch = hit->e_pitch; *maxt = hit->maxt;
 	char* const dev = hit->dev;
 	pthread_mutex_unlock(&g_area_mutex);
 	return dev;
@@ -654,9 +667,10 @@ int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, 
 			if (ch > 4) return CCV_NNC_EXEC_INVALID; // the reference clamps the channel count to 4 on this path (:14)
 			// the tap tables depend on the geometry alone: built once per (sizes, channels, scales, device) and kept on the device -- a loader resamples
 			// thousands of batches to the same size, and the host-side building + upload used to be part of every call
-			size_t oxs, oxt, oys, oyt;
+			size_t oxs, oxt, oys, oyt, oe16, oe4;
+			int e_pitch, maxt;
 			unsigned inv_scale_256;
-			char* const dev = area_8u_tables(ad.rows, ad.cols, bd.rows, bd.cols, ch, scale_x, scale_y, &oxs, &oxt, &oys, &oyt, &inv_scale_256);
+			char* const dev = area_8u_tables(ad.rows, ad.cols, bd.rows, bd.cols, ch, scale_x, scale_y, &oxs, &oxt, &oys, &oyt, &inv_scale_256, &oe16, &oe4, &e_pitch, &maxt);
 			if (!dev) return inv_scale_256 == 0 ? CCV_NNC_EXEC_INVALID : CCV_NNC_EXEC_OOM;
 			// one workgroup per output row (area_8u_rows_kernel) when rows are dword-aligned on both sides and the row's column sums fit the LDS
 			const long a_cols_ch = (long)ad.cols * ch;
@@ -666,13 +680,12 @@ int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, 
 			const size_t lds = (size_t)((a_cols_ch + 15) / 16 * 16) * sizeof(unsigned) * AREA_R;
 			static const int rows_kernel = getenv("NNC_MI355X_RESAMPLE_ROWS") ? atoi(getenv("NNC_MI355X_RESAMPLE_ROWS")) : 1;
 			const int row_groups = (bd.rows + AREA_R - 1) / AREA_R;
-			if (rows_kernel && al4 && (ch == 1 || ch == 3 || ch == 4) && lds <= 64 * 1024 && (long)count * row_groups < 0x7fffffffL && ad.step >= a_cols_ch) {
+			if (rows_kernel && al4 && lds <= 64 * 1024 && (long)count * row_groups < 0x7fffffffL && ad.step >= a_cols_ch) {
 				const float rcp = (float)(1.0 / (double)inv_scale_256);
 				const dim3 g((unsigned)((long)count * row_groups));
-#define AREA_ROWS(CH, VEC) hipLaunchKernelGGL(HIP_KERNEL_NAME(area_8u_rows_kernel<CH, VEC, AREA_R>), g, dim3(128), lds, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, (int)a_cols_ch, row_groups, \
-					(const int*)(dev + oxs), (const tap_u32_t*)(dev + oxt), (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), inv_scale_256, rcp)
-				if (al16) { if (ch == 1) AREA_ROWS(1, 16); else if (ch == 3) AREA_ROWS(3, 16); else AREA_ROWS(4, 16); }
-				else { if (ch == 1) AREA_ROWS(1, 4); else if (ch == 3) AREA_ROWS(3, 4); else AREA_ROWS(4, 4); }
+#define AREA_ROWS(VEC, OE) hipLaunchKernelGGL(HIP_KERNEL_NAME(area_8u_rows_kernel<VEC, AREA_R>), g, dim3(128), lds, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, (int)a_cols_ch, row_groups, \
+					(const etap_t*)(dev + OE), e_pitch, maxt, (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), inv_scale_256, rcp)
+				if (al16) AREA_ROWS(16, oe16); else AREA_ROWS(4, oe4);
 #undef AREA_ROWS
 			} else
 			hipLaunchKernelGGL(area_8u_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, ch,
