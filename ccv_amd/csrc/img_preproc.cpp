@@ -69,7 +69,7 @@ template <int VEC> __host__ __device__ __forceinline__ int area_col(const int x)
 struct etap_t { unsigned off, w; };
 template <int VEC, int R>
 __global__ void __launch_bounds__(128) area_8u_rows_kernel(const unsigned char* __restrict__ a, unsigned char* __restrict__ b, const long a_step, const long a_image, const long b_step, const long b_image,
-	const int b_rows, const int b_cols_ch, const int a_cols_ch, const int row_groups, const etap_t* __restrict__ etab, const int e_pitch, const int maxt, const int* __restrict__ ystart, const tap_u32_t* __restrict__ ytaps, const unsigned inv_scale_256, const float inv_scale_rcp)
+	const int b_rows, const int b_cols_ch, const int a_cols_ch, const int row_groups, const etap_t* __restrict__ etab, const int e_pitch, const int maxt, const int* __restrict__ ystart, const tap_u32_t* __restrict__ ytaps, const double inv_scale_rcp, const double inv_scale_half)
 {
 	HIP_DYNAMIC_SHARED(unsigned, area_v) // column sums of the R output rows: R x pitch (pitch = a_cols_ch rounded up to whole lanes' worth)
 	const int dy0 = (int)(blockIdx.x % (unsigned)row_groups) * R;
@@ -129,10 +129,10 @@ __global__ void __launch_bounds__(128) area_8u_rows_kernel(const unsigned char* 
 			unsigned packed = 0;
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
-				unsigned q = (unsigned)((float)h[r][j] * inv_scale_rcp); // within one of h / inv_scale_256 (the quotient is < 2^16, the estimate's error < 2^-7)
-				const int rem = (int)(h[r][j] - nnc_mul24(q, inv_scale_256)); // the true remainder lies in (-d, 2 d), d < 2^24: exact in wrapping 32-bit arithmetic
-				if (rem < 0) q--;
-				else if (rem >= (int)inv_scale_256) q++;
+				// floor(h / d) exactly, in three fp64 instructions: (h + 1/2) / d is never an integer and sits at least 1 / (2 d) > 2^-25 away from one, the double
+				// product's error is below 2^-52 of the quotient (< 2^16): truncation cannot land on the wrong side.  (The 32-bit division is ~40 instructions, a float
+				// estimate needs a multiply-compare correction: 11.)
+				const unsigned q = (unsigned)__builtin_fma((double)h[r][j], inv_scale_rcp, inv_scale_half);
 				packed |= (q > 255 ? 255u : q) << (8 * j);
 			}
 			unsigned char* const brow = b + img * b_image + (long)(dy0 + r) * b_step;
@@ -681,10 +681,10 @@ int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, 
 			static const int rows_kernel = getenv("NNC_MI355X_RESAMPLE_ROWS") ? atoi(getenv("NNC_MI355X_RESAMPLE_ROWS")) : 1;
 			const int row_groups = (bd.rows + AREA_R - 1) / AREA_R;
 			if (rows_kernel && al4 && lds <= 64 * 1024 && (long)count * row_groups < 0x7fffffffL && ad.step >= a_cols_ch) {
-				const float rcp = (float)(1.0 / (double)inv_scale_256);
+				const double rcp = 1.0 / (double)inv_scale_256, half = 0.5 * rcp;
 				const dim3 g((unsigned)((long)count * row_groups));
 #define AREA_ROWS(VEC, OE) hipLaunchKernelGGL(HIP_KERNEL_NAME(area_8u_rows_kernel<VEC, AREA_R>), g, dim3(128), lds, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, (int)a_cols_ch, row_groups, \
-					(const etap_t*)(dev + OE), e_pitch, maxt, (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), inv_scale_256, rcp)
+					(const etap_t*)(dev + OE), e_pitch, maxt, (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), rcp, half)
 				if (al16) AREA_ROWS(16, oe16); else AREA_ROWS(4, oe4);
 #undef AREA_ROWS
 			} else
