@@ -65,7 +65,9 @@ __global__ void __launch_bounds__(256) area_8u_kernel(const unsigned char* a, un
 template <int VEC> __host__ __device__ __forceinline__ int area_col(const int x) { return VEC == 16 ? (x & ~12) | ((((x >> 2) ^ (x >> 5)) & 3) << 2) : x; }
 // R consecutive output rows per workgroup: the kernel is bound by the LATENCY of its dependent loads (tap tables -> source rows -> LDS -> taps again), not by
 // bytes or arithmetic -- one row per workgroup ran at 1.3 TB/s with every pipe idle most of the time -- so a workgroup issues the source loads of R rows back
-// to back and applies a lane's horizontal taps (loaded once) to all R rows' column sums.
+// to back and applies a lane's horizontal taps (loaded once) to all R rows' column sums.  (Measured and not adopted: dealing the (row, unit) and (element
+// group, row pair) tasks over ALL lanes -- a third of them idle in both stages at 480 -> 224 -- is slower, 0.105 / 0.092 vs 0.087 ms: what a lane has in flight
+// counts, not how many lanes work.)
 struct etap_t { unsigned off, w; };
 template <int VEC, int R>
 __global__ void __launch_bounds__(128) area_8u_rows_kernel(const unsigned char* __restrict__ a, unsigned char* __restrict__ b, const long a_step, const long a_image, const long b_step, const long b_image,
@@ -76,66 +78,66 @@ __global__ void __launch_bounds__(128) area_8u_rows_kernel(const unsigned char* 
 	const size_t img = blockIdx.x / (unsigned)row_groups;
 	const unsigned char* const ai = a + img * a_image;
 	const int units = (a_cols_ch + VEC - 1) / VEC, pitch = units * VEC;
-	// stage A: the R x units (row, 16-byte unit) tasks dealt round-robin over ALL lanes (a row has 90 units at 480 x 3 bytes: a lane per unit left a third of the
-	// workgroup idle through the whole stage)
-	for (int task = (int)threadIdx.x; task < R * units; task += 128) {
-		const int r = task / units, u = task - r * units;
-		const int dy = dy0 + r < b_rows ? dy0 + r : b_rows - 1;
-		const int ky0 = ystart[dy], ky1 = ystart[dy + 1];
-		unsigned acc[VEC];
+	int ky0[R], ky1[R];
 #pragma unroll
-		for (int j = 0; j < VEC; j++) acc[j] = 0;
-		for (int ky = ky0; ky < ky1; ky++) {
-			const unsigned char* const row = ai + (long)ytaps[ky].si * a_step + (long)u * VEC;
-			const unsigned w = ytaps[ky].w;
-			if (VEC == 16) {
-				const uint4 q = *(const uint4*)row; // (a row's last unit stays inside the row pitch: pitches are multiples of 16 here)
-				const unsigned d[4] = { q.x, q.y, q.z, q.w };
+	for (int r = 0; r < R; r++) { const int dy = dy0 + r < b_rows ? dy0 + r : b_rows - 1; ky0[r] = ystart[dy]; ky1[r] = ystart[dy + 1]; }
+	for (int u = (int)threadIdx.x; u < units; u += 128) {
 #pragma unroll
-				for (int j = 0; j < 16; j++) acc[j] += nnc_mul24((d[j >> 2] >> (8 * (j & 3))) & 0xffu, w); // (weights are at most 256: the 24-bit multiply-add, not the quarter-rate 32-bit one)
-			} else {
-				const unsigned q = *(const unsigned*)row;
+		for (int r = 0; r < R; r++) {
+			unsigned acc[VEC];
 #pragma unroll
-				for (int j = 0; j < 4; j++) acc[j] += nnc_mul24((q >> (8 * j)) & 0xffu, w);
+			for (int j = 0; j < VEC; j++) acc[j] = 0;
+			for (int ky = ky0[r]; ky < ky1[r]; ky++) {
+				const unsigned char* const row = ai + (long)ytaps[ky].si * a_step + (long)u * VEC;
+				const unsigned w = ytaps[ky].w;
+				if (VEC == 16) {
+					const uint4 q = *(const uint4*)row; // (a row's last unit stays inside the row pitch: pitches are multiples of 16 here)
+					const unsigned d[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+					for (int j = 0; j < 16; j++) acc[j] += nnc_mul24((d[j >> 2] >> (8 * (j & 3))) & 0xffu, w); // (weights are at most 256: the 24-bit multiply-add, not the quarter-rate 32-bit one)
+				} else {
+					const unsigned q = *(const unsigned*)row;
+#pragma unroll
+					for (int j = 0; j < 4; j++) acc[j] += nnc_mul24((q >> (8 * j)) & 0xffu, w);
+				}
 			}
-		}
-		// (16 sums per lane are four 16-byte pieces 64 bytes apart from the neighbouring lane's: unswizzled, the eight lanes of a ds_write_b128 group land on two
-		// bank quads -- the counters showed 85 % of the LDS cycles of this kernel were conflicts; area_col() spreads the pieces over all eight quads)
+			// (16 sums per lane are four 16-byte pieces 64 bytes apart from the neighbouring lane's: unswizzled, the eight lanes of a ds_write_b128 group land on two
+			// bank quads -- the counters showed 85 % of the LDS cycles of this kernel were conflicts; area_col() spreads the pieces over all eight quads)
 #pragma unroll
-		for (int j = 0; j < VEC; j += 4) *(uint4*)(area_v + r * pitch + area_col<VEC>(u * VEC + j)) = uint4{ acc[j], acc[j + 1], acc[j + 2], acc[j + 3] };
+			for (int j = 0; j < VEC; j += 4) *(uint4*)(area_v + r * pitch + area_col<VEC>(u * VEC + j)) = uint4{ acc[j], acc[j + 1], acc[j + 2], acc[j + 3] };
+		}
 	}
 	__syncthreads();
-	// stage B.  horizontal taps per OUTPUT ELEMENT, structure of arrays (etab[k][e] = {LDS column -- swizzled for this VEC --, weight}; missing taps have weight 0): a
-	// lane's four consecutive elements are 32 contiguous bytes per tap index -- two 16-byte loads, coalesced across the wave --, read once and applied to a PAIR of
-	// rows; the (element group, row pair) tasks are dealt over all lanes like stage A's (168 groups of four elements at 224 x 3: a lane per group idled 40 %)
-	static_assert(R % 2 == 0, "rows in pairs");
-	const int groups4 = (b_cols_ch + 3) >> 2;
-	for (int task = (int)threadIdx.x; task < groups4 * (R / 2); task += 128) {
-		const int rp = task / groups4, t4 = (task - rp * groups4) * 4;
-		const unsigned* const v0 = area_v + (2 * rp) * pitch;
-		const unsigned* const v1 = v0 + pitch;
-		unsigned h0[4] = { 0, 0, 0, 0 }, h1[4] = { 0, 0, 0, 0 };
+	// horizontal taps per OUTPUT ELEMENT, structure of arrays (etab[k][e] = {LDS column -- swizzled for this VEC --, weight}; missing taps have weight 0): a
+	// lane's four consecutive elements are 32 contiguous bytes per tap index -- two 16-byte loads, coalesced across the wave --, read once and applied to all R rows
+	for (int t4 = (int)threadIdx.x * 4; t4 < b_cols_ch; t4 += 128 * 4) {
+		unsigned h[R][4];
+#pragma unroll
+		for (int r = 0; r < R; r++)
+#pragma unroll
+			for (int j = 0; j < 4; j++) h[r][j] = 0;
 		for (int k = 0; k < maxt; k++) {
 			const uint4* const tp = (const uint4*)(etab + (size_t)k * e_pitch + t4); // (e_pitch is a multiple of 4 elements: whole 32-byte groups, in range)
 			const uint4 t01 = tp[0], t23 = tp[1];
 			const unsigned off[4] = { t01.x, t01.z, t23.x, t23.z }, w[4] = { t01.y, t01.w, t23.y, t23.w };
 #pragma unroll
-			for (int j = 0; j < 4; j++) { h0[j] += nnc_mul24(v0[off[j]], w[j]); h1[j] += nnc_mul24(v1[off[j]], w[j]); } // (a column sum is < 2^24: 255 x the row weights, whose sum is at most 2^16)
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int r = 0; r < R; r++) h[r][j] += nnc_mul24(area_v[r * pitch + off[j]], w[j]); // (a column sum is < 2^24: 255 x the row weights, whose sum is at most 2^16)
 		}
 #pragma unroll
-		for (int rr = 0; rr < 2; rr++) {
-			const int dy = dy0 + 2 * rp + rr;
-			if (dy >= b_rows) break;
+		for (int r = 0; r < R; r++) {
+			if (dy0 + r >= b_rows) break;
 			unsigned packed = 0;
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
 				// floor(h / d) exactly, in three fp64 instructions: (h + 1/2) / d is never an integer and sits at least 1 / (2 d) > 2^-25 away from one, the double
 				// product's error is below 2^-52 of the quotient (< 2^16): truncation cannot land on the wrong side.  (The 32-bit division is ~40 instructions, a float
 				// estimate needs a multiply-compare correction: 11.)
-				const unsigned q = (unsigned)__builtin_fma((double)(rr ? h1[j] : h0[j]), inv_scale_rcp, inv_scale_half);
+				const unsigned q = (unsigned)__builtin_fma((double)h[r][j], inv_scale_rcp, inv_scale_half);
 				packed |= (q > 255 ? 255u : q) << (8 * j);
 			}
-			unsigned char* const brow = b + img * b_image + (long)dy * b_step;
+			unsigned char* const brow = b + img * b_image + (long)(dy0 + r) * b_step;
 			if (t4 + 4 <= b_cols_ch) *(unsigned*)(brow + t4) = packed;
 			else for (int j = 0; t4 + j < b_cols_ch; j++) brow[t4 + j] = (unsigned char)(packed >> (8 * j));
 		}
