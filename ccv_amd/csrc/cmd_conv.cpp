@@ -236,10 +236,10 @@ static int conv_wino_fused_run(const char* name, const conv_geom_t& g, const win
 	a.dst_image_bytes = (unsigned)(((long)(dst.h - 1) * dst.sh + (long)(dst.w - 1) * dst.sw + dst.c) * 4);
 	a.src_image_bytes = (unsigned)(((long)(src.h - 1) * src.sh + (long)(src.w - 1) * src.sw + src.c) * 4);
 	a.uf_kb_bytes = (unsigned)((size_t)p.CCn * WF_U_FLOATS * 4);
-	// persistent: one workgroup per CU; teams of `team` workgroups (a divisor of KB, at most 4) share a range of tile-group quads
+	// persistent: one workgroup per CU; teams of `team` workgroups (a divisor of KB, at most 8) share a range of tile-group quads
 	// on one XCD (see the kernel); the grid is a multiple of 8 * team, workgroups beyond the work exit at once
 	long wgs = tune(TUNE_WINO_FUSED_GRID) > 0 ? tune(TUNE_WINO_FUSED_GRID) : device_cu_count();
-	int team = p.KB % 4 == 0 ? 4 : (p.KB % 2 == 0 ? 2 : 1);
+	int team = p.KB % 8 == 0 ? 8 : (p.KB % 4 == 0 ? 4 : (p.KB % 2 == 0 ? 2 : 1)); // (8 since round 5: 256 -> 256 at 56 x 56 0.81 -> 0.74 ms at batch 64, even at batch 256: tools/wf5_probe.cpp)
 	while (team > 1 && wgs < 8 * team) team >>= 1;
 	if (wgs < 8 * team) wgs = 8 * team;
 	const unsigned grid = (unsigned)(wgs / (8 * team) * (8 * team));

@@ -113,7 +113,7 @@ __device__ __forceinline__ void wf_dma16(const wf_rsrc_t r, float*, unsigned lds
 	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 // 16-byte store through a raw buffer descriptor kept in SGPRs: voff per lane (range-checked: an out-of-range lane stores nothing), soff wave-uniform
-// POLICY: 0 the default cache policy, 1 nt (streaming: the line need not stay in the XCD's L2), 2 sc1
+// POLICY: 0 the default cache policy, 1 nt (streaming: the line need not stay in the XCD's L2), 2 sc1, 3 sc1 nt, 4 sc0 sc1
 template <int POLICY = 0>
 __device__ __forceinline__ void wf_store16(const wf_rsrc_t r, unsigned voff, unsigned soff, float x, float y, float z, float w)
 {
@@ -121,6 +121,8 @@ __device__ __forceinline__ void wf_store16(const wf_rsrc_t r, unsigned voff, uns
 	const f4 v = { x, y, z, w };
 	if (POLICY == 1) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 	else if (POLICY == 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+	else if (POLICY == 3) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1 nt" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+	else if (POLICY == 4) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 	else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 // max without the canonicalising v_max x, x hipcc puts in front of fmaxf (the operands here are results of arithmetic: already canonical)

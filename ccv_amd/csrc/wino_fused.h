@@ -239,6 +239,12 @@ template <int GH, int GW, int DBG = 0, bool MASK = false, int SCHED = 0>
 __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs a)
 {
 	constexpr bool PAIR = SCHED > 0;
+	// The stores are STREAMING (nt).  Measured with the L2 -> fabric request counters (tools/r05_policy.sh, profiles/r05_v7_store_policy.txt): a patch line
+	// (128 bytes = 32 channels of a pixel) is consumed 32 bytes per trip, and with the default policy the output -- 2.1 MB per trip and XCD at conv1_2 -- pushes it
+	// out of the XCD's 4 MB L2 between its chunk pairs: conv1_2 read 6.67 GB per launch for a 3.29 GB input, conv2_1 2.03 GB for 0.82.  With nt the output lines
+	// leave first: 5.42 and 1.41 GB, the time unchanged at batch 256 (within 0.5 %) and 3..5 % better at batch 64.  (sc1, sc1 nt, sc0 sc1: the same reads as nt.)
+	// DBG bits 14..16 select another policy for the probe (5 = the default policy).
+	constexpr int ST_POLICY = ((DBG >> 14) & 7) == 0 ? 1 : (((DBG >> 14) & 7) == 5 ? 0 : ((DBG >> 14) & 7));
 	constexpr bool NEWST = (DBG & 8192) == 0; // the epilogue's stores with scalar address arithmetic (round 5; DBG bit 8192 = the previous form, for tools/wf5_probe.cpp)
 	// (also measured and NOT adopted: the output transform on packed pairs -- the two channel blocks of a position as one f2, 400 v_pk_* instead of 800 scalar
 	// operations per item -- makes hipcc spill around the epilogue: conv1_2 4.68 vs 3.07 ms.  profiles/r05_v3_wf5_probe.txt)
@@ -565,7 +571,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 						o0 = (m & 1) ? o0 : 0.f; o1 = (m & 2) ? o1 : 0.f; o2 = (m & 4) ? o2 : 0.f; o3 = (m & 8) ? o3 : 0.f;
 					}
 					if constexpr (DBG & 128) { NNC_PIN_V(o0); NNC_PIN_V(o1); NNC_PIN_V(o2); NNC_PIN_V(o3); }
-					else wf_store16(rs_item, voff, soff, o0, o1, o2, o3); // (nt / sc1 cache policies on these stores: no difference, profiles/r05_v3_wf5_probe.txt)
+					else wf_store16<ST_POLICY>(rs_item, voff, soff, o0, o1, o2, o3);
 				}
 			} else {
 #pragma unroll

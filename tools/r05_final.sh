@@ -14,6 +14,6 @@ for k, v in d.get("extra_configs", {}).items():
     print(k, {a: v.get(a) for a in ("value", "ms_per_step", "wall_s", "status", "via_host_images_per_s")}, (v.get("roofline") or {}).get("frac"))
 PY
 tools/gpu_round.sh prof profhost | tail -3
-PMC_BATCH=256 PMC_GROUPS="mfma wait inst lds fetch write" tools/pmc_pass.sh > gpurun_out/pmc_pass.log 2>&1; tail -12 gpurun_out/pmc_traffic.txt
+PMC_BATCH=256 PMC_GROUPS="mfma wait inst lds fetch write rdsize wrsize" tools/pmc_pass.sh > gpurun_out/pmc_pass.log 2>&1; tail -12 gpurun_out/pmc_traffic.txt
 tools/r05_preproc.sh | tail -8
 echo "total $(( $(date +%s) - S )) s"

@@ -4,6 +4,7 @@
 //   tools/bin/wf5_probe [batch] [hw] [C] [K] [team]
 #include "wino_fused.h"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CHECK(e) do { hipError_t s_ = (e); if (s_ != hipSuccess) { printf("HIP error %d at %d\n", (int)s_, __LINE__); return 1; } } while (0)
 using namespace nnc;
@@ -64,14 +65,24 @@ int main(int argc, char** argv)
 	a.src_image_bytes = (unsigned)(((long)(H - 1) * a.s_sh + (long)(W - 1) * a.s_sw + C) * 4);
 	a.uf_kb_bytes = (unsigned)((size_t)CCn * WF_U_FLOATS * 4);
 	const int items = (a.groups + 3) / 4 * KB;
-	const int team = argc > 5 ? atoi(argv[5]) : (KB % 4 == 0 ? 4 : (KB % 2 == 0 ? 2 : 1));
+	const int team = argc > 5 ? atoi(argv[5]) : (KB % 8 == 0 ? 8 : (KB % 4 == 0 ? 4 : (KB % 2 == 0 ? 2 : 1)));
 	a.team = team;
 	const unsigned grid = 256;
 	g_dst = dst; g_nd = nd;
 	const double flops = 2.0 * 36.0 * (double)a.groups * 16 * K * C; // issued MFMA work (padded tile groups included)
 	printf("fused Winograd 3x3: N=%d %dx%dx%d -> %d; %d work items of %d trips on %d persistent workgroups in teams of %d; MFMA floor %.3f ms\n", NB, H, W, C, K, items, CCn, grid, team, flops / 157.3e12 * 1e3);
 	const int gh = argc > 6 ? atoi(argv[6]) : 4;
-	if (gh == 4) {
+	if (gh == 4 && getenv("WF5_POLICY") && !getenv("WF5_NT")) { // the stores' cache policy against the patch lines' life in the XCD's L2 (run under rocprofv3 --pmc TCC_EA0_RDREQ_...)
+		run<4, 4, 5 << 14>(a, grid, flops, "stores with the default cache policy (before round 5)");
+		run<4, 4, 0>(a, grid, flops, "library: stores nt");
+		run<4, 4, 2 << 14>(a, grid, flops, "stores sc1");
+		run<4, 4, 3 << 14>(a, grid, flops, "stores sc1 nt");
+		run<4, 4, 4 << 14>(a, grid, flops, "stores sc0 sc1");
+	} else if (gh == 4 && getenv("WF5_NT")) {
+		for (int i = 0; i < 3; i++) { run<4, 4, 5 << 14>(a, grid, flops, "stores with the default cache policy"); run<4, 4, 0>(a, grid, flops, "library: stores nt"); }
+	} else if (getenv("WF5_POLICY") || getenv("WF5_NT")) {
+		for (int i = 0; i < 3; i++) { run<2, 8, 5 << 14>(a, grid, flops, "stores with the default cache policy"); run<2, 8, 0>(a, grid, flops, "library: stores nt"); }
+	} else if (gh == 4) {
 		run<4, 4, 0>(a, grid, flops, "library");
 		run<4, 4, 8192>(a, grid, flops, "epilogue stores with per-store vector address arithmetic (before round 5)");
 		run<4, 4, 0>(a, grid, flops, "library (again)");
