@@ -128,7 +128,7 @@ __device__ __forceinline__ void st4(float* p, const float4 v) { *(float4*)p = v;
 template <bool IS_MAX>
 __global__ void __launch_bounds__(256) pool_forw_v4_kernel(const pool_geom_t g, const float* a, float* b, const size_t total)
 {
-	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+	for (size_t idx64 = (size_t)nnc_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, oy, ox, c4;
 		unflatten<true>((int)idx64, g.d_oh, g.d_ow, g.d_c4, n, oy, ox, c4);
 		int y0 = oy * g.sy - g.pby, x0 = ox * g.sx - g.pbx;
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) pool_forw_v4_kernel(const pool_geom_t g, 
 template <bool IS_MAX>
 __global__ void __launch_bounds__(256) pool_back_v4_kernel(const pool_geom_t g, const float* gr, const float* a, const float* b, float* h, const size_t total)
 {
-	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+	for (size_t idx64 = (size_t)nnc_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, y, x, c4;
 		unflatten<true>((int)idx64, g.d_h, g.d_w, g.d_c4, n, y, x, c4);
 		// outputs whose window covers (y, x): oy in [ceil((y + p - k + 1) / s), floor((y + p) / s)].  The numerators are

@@ -57,6 +57,16 @@ struct FastDiv {
 	__host__ __device__ __forceinline__ int div(int n) const { return (int)(((unsigned long long)(unsigned)n * m) >> sh); }
 };
 
+// Workgroup b of a one-dimensional grid runs on XCD b % 8 (each XCD has its own 4 MB L2).  Kernels whose NEIGHBOURING blocks read overlapping lines -- the 6 x 6
+// patches of 4 x 4 Winograd tiles, the rows two 3 x 3 / 2 pooling windows share -- take their work from this LOGICAL block index instead: XCD x gets the x-th
+// contiguous eighth of the blocks, so the overlap is found in that XCD's L2 instead of being fetched by up to four XCDs (round 5: profiles/r05_v8_xcd_blocks.txt).
+// A bijection of 0 .. grid - 1 for any grid.
+__device__ __forceinline__ unsigned nnc_xcd_block(const unsigned bid, const unsigned grid)
+{
+	const unsigned x = bid & 7, q = grid >> 3, r = grid & 7;
+	return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
 // Order in which a conv contraction walks its reduction index k = (tap, channel), in K-steps of GEMM_BK channels.
 //   natural (taps == 0): tap-major -- a workgroup streams ALL channels of tap 0, then of tap 1, ...; the nine taps re-read
 //     the same pixels, but a tap apart lie channels/32 K-steps of the XCD's 64 resident workgroups, i.e. > 4 MB of other

@@ -138,7 +138,7 @@ struct WinoTiles {
 // 36 16-byte loads, 12 six-point transforms on float4, 36 16-byte stores (the c4 threads of a tile write contiguous runs).
 static __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ a, float* __restrict__ v, const WinoTiles g)
 {
-	const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const long idx = (long)nnc_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; // neighbouring tiles share 2 of their 6 rows / columns: same XCD
 	if (idx >= (long)g.T * g.C4) return;
 	const int t = g.d_c4.div((int)idx), c4 = (int)(idx - (long)t * g.C4);
 	const int tn = g.d_tw.div(t), tx = t - tn * g.TW;

@@ -714,6 +714,9 @@ def load(path=None):
     if path is None and _lib is not None:
         return _lib
     p = path or LIB_PATH
+    # multi-process GPU work (RCCL between ranks, device memory shared across processes): this image's host driver only supports dmabuf IPC; the
+    # variable must be in the environment before the HIP runtime starts (it is exported on the boxes; kept here for environments built by hand)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not os.path.exists(p):
         raise RuntimeError("libnnc_mi355x.so not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % p)
     lib = Lib(p, "mi355x")
