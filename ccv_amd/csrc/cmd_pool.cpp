@@ -48,7 +48,7 @@ __device__ __forceinline__ void unflatten(int idx, const FastDiv& d1, const Fast
 template <bool NHWC, bool IS_MAX, class T>
 __global__ void __launch_bounds__(256) pool_forw_kernel(const pool_geom_t g, const T* a, T* b, const size_t total)
 {
-	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+	for (size_t idx64 = (size_t)nnc_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, oy, ox, c;
 		unflatten<NHWC>((int)idx64, g.d_oh, g.d_ow, g.d_c, n, oy, ox, c);
 		int y0 = oy * g.sy - g.pby, x0 = ox * g.sx - g.pbx;
@@ -83,7 +83,7 @@ __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b :
 template <bool NHWC, bool IS_MAX, class T>
 __global__ void __launch_bounds__(256) pool_back_kernel(const pool_geom_t g, const T* gr, const T* a, const T* b, T* h, const size_t total)
 {
-	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+	for (size_t idx64 = (size_t)nnc_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, y, x, c;
 		unflatten<NHWC>((int)idx64, g.d_h, g.d_w, g.d_c, n, y, x, c);
 		// windows that contain (y, x): ceil((t - k + 1) / s) .. floor(t / s) with t = y + pb >= 0; the ceiling as a floor of a
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256) pool_back_tiled_kernel(const pool_geom_t 
 {
 	typedef typename packv<T, VEC>::type V;
 	const float cnt = (float)(g.kh * g.kw); // (divided by, like the general kernels: bit-identical averages)
-	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+	for (size_t idx64 = (size_t)nnc_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, oy, ox, c;
 		unflatten<NHWC>((int)idx64, g.d_oh, g.d_ow, d_cv, n, oy, ox, c);
 		c *= VEC;
@@ -324,7 +324,7 @@ template <bool IS_MAX, class T>
 __global__ void __launch_bounds__(256) pool_back_rows_kernel(const pool_geom_t g, const FastDiv d_w4, const T* __restrict__ gr, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ h, const size_t total)
 {
 	typedef typename row4<T>::type V;
-	for (size_t idx64 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
+	for (size_t idx64 = (size_t)nnc_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx64 < total; idx64 += (size_t)gridDim.x * blockDim.x) {
 		int n, y, xq, c;
 		unflatten<false>((int)idx64, g.d_h, d_w4, g.d_c, n, y, xq, c);
 		const int x0 = xq * PR;
