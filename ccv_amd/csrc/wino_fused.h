@@ -350,6 +350,9 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedArgs 
 		return f2{ v.x, v.y };
 	};
 
+	// (Round 5, measured and NOT adopted -- profiles/r05_v8_stagger_probe.txt: the teams started out of phase, spread over 0.5 / 1 / 2 items' durations, so that the
+	// chip's epilogues would not all store at once: slower by the idle time it adds (+0.3 .. +3 %), nothing recovered -- the epilogues' stores are not waiting for
+	// each other across workgroups.)
 	// ---- prologue (once per workgroup): the first item's chunk 0 transformed completely (S, then V columns 0..4; column 5 is
 	// the first work of the loop), its chunk 1 in flight
 	Item cur = item_of(first);
