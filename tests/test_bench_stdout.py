@@ -78,3 +78,23 @@ def test_process_per_gpu_form_of_configs_4_and_5_on_this_box(config):
     assert out["n_gpus"] == n and "one process per GPU" in out["config"]["parallelism"] and ("RCCL ranks %s" % ([n] * n)) in out["config"]["parallelism"], out["config"]["parallelism"]
     assert out["config"]["outputs_finite"] and out["value"] > 0
     assert out["config"]["rccl_ranks"] == n and out["config"]["data_parallel_check"]["ok"], out["config"].get("data_parallel_check")  # (round 5: every config's N > 1 line carries both)
+
+
+@pytest.mark.gpu
+def test_launched_by_torch_distributed_run_as_the_driver_does():
+    """The driver's own N > 1 spelling: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.
+    N = the devices this box has; with one device NNC_BENCH_FORCE_COMM=1 takes the rank through the N > 1 code (control plane over ccv_amd/ctl.py keyed by
+    MASTER_PORT, RCCL communicator, broadcast, overlapped all-reduce).  Exactly one JSON line on stdout, from rank 0."""
+    pytest.importorskip("torch")
+    from ccv_amd import nnc
+    n = nnc.load().device_count()
+    env = dict(os.environ, NNC_BENCH_FORCE_COMM="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-via-host", "--no-alt-leg", "--no-extra-configs"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["config"]["rccl_ranks"] == n and out["steps"] == 2 and out["value"] > 0
+    assert out["config"]["data_parallel_check"]["ok"], out["config"]["data_parallel_check"]
