@@ -66,6 +66,15 @@ static bool dense_f32(const ccv_nnc_tensor_t* const t, const size_t least)
 	return !t || (CCV_GET_DATA_TYPE(t->info.datatype) == CCV_32F && tensor_contiguous(t) && tensor_count(t->info) >= least);
 }
 
+// the reserved space: fp32 planes inside a dense fp32 tensor, or inside the CCV_16F tensor the host sized for a half-precision command (twice the elements:
+// half_stage.cpp hands it over untouched)
+static bool dense_reserve(const ccv_nnc_tensor_t* const t, const size_t least)
+{
+	if (!t || !tensor_contiguous(t)) return false;
+	const int dt = CCV_GET_DATA_TYPE(t->info.datatype);
+	return (dt == CCV_32F && tensor_count(t->info) >= least) || (dt == CCV_16F && tensor_count(t->info) >= 2 * least && ((uintptr_t)t->data.u8 & 15) == 0);
+}
+
 constexpr int LS_ROWS = 16; // batch rows per workgroup (4 groups of 4: a lane keeps 4 rows of its column in registers)
 constexpr int LS_KT = 64;   // the reduction index is staged through LDS in tiles of this many
 
@@ -567,7 +576,7 @@ static int _lstm_forw(EXEC_ARGS_L)
 	const size_t TB = (size_t)g.T * g.B, LD = (size_t)g.L * g.D;
 	if (!dense_f32(x, TB * g.I) || !dense_f32(y, TB * g.D * g.P) || !dense_f32(w, g.w_total()) || !dense_f32(hx, LD * g.B * g.P) || !dense_f32(cx, LD * g.B * g.H) || !dense_f32(hy, LD * g.B * g.P) || !dense_f32(cy, LD * g.B * g.H)) return CCV_NNC_EXEC_INVALID;
 	const bool train = !g.is_test;
-	if (train && (!r || !dense_f32(r, g.reserve_total()))) return CCV_NNC_EXEC_INVALID; // (ccv_nnc_lstm_gpu_cudnn.cu:114-119)
+	if (train && !dense_reserve(r, g.reserve_total())) return CCV_NNC_EXEC_INVALID; // (ccv_nnc_lstm_gpu_cudnn.cu:114-119)
 	MarkerScope marker(cmd.cmd);
 	hipStream_t stream = stream_of(stream_context);
 	const int DP = g.D * g.P;
@@ -600,7 +609,7 @@ static int _lstm_forw(EXEC_ARGS_L)
 	if (xs) { const int ret = lstm_lens(xs, g, lens, stream); if (ret != CCV_NNC_EXEC_SUCCESS) return ret; }
 	const float* xin = x->data.f32;
 	if (g.batch_first) { hipLaunchKernelGGL(lstm_swap01_kernel, dim3(blocks_of(TB * g.I)), dim3(256), 0, stream, x->data.f32, xseq, g.B, g.T, g.I); xin = xseq; }
-	float* const rsv = train ? r->data.f32 : 0;
+	float* const rsv = train ? (float*)r->data.u8 : 0;
 	const lstm_view_t view = lstm_view(g, rsv);
 	const float* const W = w->data.f32;
 	const dim3 step_grid((g.H + 63) / 64, (g.B + LS_ROWS - 1) / LS_ROWS), proj_grid((g.P + 63) / 64, (g.B + LS_ROWS - 1) / LS_ROWS);
@@ -683,7 +692,7 @@ static int _lstm_back(EXEC_ARGS_L)
 	if (dw && !x) return CCV_NNC_EXEC_INVALID;
 	const size_t TB = (size_t)g.T * g.B, LD = (size_t)g.L * g.D;
 	const int DP = g.D * g.P;
-	if (!dense_f32(dy, TB * DP) || !dense_f32(dx, TB * g.I) || !dense_f32(x, TB * g.I) || !dense_f32(w, g.w_total()) || !dense_f32(dw, g.w_total()) || !dense_f32(r, g.reserve_total())) return CCV_NNC_EXEC_INVALID;
+	if (!dense_f32(dy, TB * DP) || !dense_f32(dx, TB * g.I) || !dense_f32(x, TB * g.I) || !dense_f32(w, g.w_total()) || !dense_f32(dw, g.w_total()) || !dense_reserve(r, g.reserve_total())) return CCV_NNC_EXEC_INVALID;
 	if (!dense_f32(dhy, LD * g.B * g.P) || !dense_f32(dcy, LD * g.B * g.H) || !dense_f32(hx, LD * g.B * g.P) || !dense_f32(cx, LD * g.B * g.H) || !dense_f32(dhx, LD * g.B * g.P) || !dense_f32(dcx, LD * g.B * g.H)) return CCV_NNC_EXEC_INVALID;
 	MarkerScope marker(cmd.cmd);
 	hipStream_t stream = stream_of(stream_context);
@@ -728,8 +737,8 @@ static int _lstm_back(EXEC_ARGS_L)
 		dytop = dyseq;
 	}
 	float* const dx0 = g.batch_first ? dxseq : dx->data.f32;
-	const lstm_view_t view = lstm_view(g, r->data.f32);
-	const float* const rsv = r->data.f32;
+	const lstm_view_t view = lstm_view(g, (float*)r->data.u8);
+	const float* const rsv = (const float*)r->data.u8;
 	const float* const W = w->data.f32;
 	float* const DW = dw ? dw->data.f32 : 0;
 	const dim3 rec_grid((g.P + 63) / 64, (g.B + LS_ROWS - 1) / LS_ROWS), raw_grid((g.H + 63) / 64, (g.B + LS_ROWS - 1) / LS_ROWS);
@@ -842,7 +851,8 @@ static size_t _lstm_reserve_space_size(const ccv_nnc_cmd_t cmd, const int dataty
 	g.dropout = g.L < 2 ? 0.f : cmd.info.rnn.dropout;
 	g.proj = g.P != g.H;
 	g.S = 5 + g.proj + (g.dropout > 0.f ? 1 : 0);
-	return g.reserve_total() * datatype_size(datatype);
+	// (CCV_16F: the tape stays fp32 planes inside the half tensor -- dense_reserve above -- so the host is asked for the fp32 bytes)
+	return g.reserve_total() * (CCV_GET_DATA_TYPE(datatype) == CCV_16F ? sizeof(float) : datatype_size(datatype));
 }
 
 } // namespace

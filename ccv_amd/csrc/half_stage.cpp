@@ -297,7 +297,10 @@ int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_
 	};
 	// opaque tensors keep their own memory: the dropout mask is a byte buffer the host merely SIZES through a tensor of the data's
 	// type (ccv_nnc_dropout.c:21-45) -- output 1 of the forward command, input 4 of the backward one
-	const int opaque_in = cmd.cmd == CCV_NNC_DROPOUT_BACKWARD ? 4 : -1, opaque_out = cmd.cmd == CCV_NNC_DROPOUT_FORWARD ? 1 : -1;
+	// The LSTM's reserved space likewise (output 3 forward, input 12 backward): ccv_nnc_lstm.c:55-61 sizes it as `bytes` ELEMENTS of the data's type, so a CCV_16F
+	// one spans at least the bytes fp32 planes need and the kernels keep their tape (gates, tanh(c), cell states, dropout scales) in fp32 inside it -- nothing is
+	// rounded to half between the forward and the backward command, no cell state can overflow the half range, and the space is not converted twice per call
+	const int opaque_in = cmd.cmd == CCV_NNC_DROPOUT_BACKWARD ? 4 : (cmd.cmd == CCV_NNC_LSTM_BACKWARD ? 12 : -1), opaque_out = cmd.cmd == CCV_NNC_DROPOUT_FORWARD ? 1 : (cmd.cmd == CCV_NNC_LSTM_FORWARD ? 3 : -1);
 	const native_half_t* const native = native_half_row(cmd.cmd, flags, inputs, input_size, outputs, output_size);
 	for (int i = 0; i < input_size; i++) { if (i == opaque_in || (native && i < 32 && ((native->in >> i) & 1))) which[i] = -1; else visit(inputs[i], false, i); }
 	for (int i = 0; i < output_size; i++) { if (i == opaque_out || (native && i < 32 && ((native->out >> i) & 1))) which[input_size + i] = -1; else visit(outputs[i], true, input_size + i); }
