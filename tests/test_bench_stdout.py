@@ -85,7 +85,9 @@ def test_launched_by_torch_distributed_run_as_the_driver_does():
     """The driver's own N > 1 spelling: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.
     N = the devices this box has; with one device NNC_BENCH_FORCE_COMM=1 takes the rank through the N > 1 code (control plane over ccv_amd/ctl.py keyed by
     MASTER_PORT, RCCL communicator, broadcast, overlapped all-reduce).  Exactly one JSON line on stdout, from rank 0."""
-    pytest.importorskip("torch")
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:  # (found, NOT imported: torch's wheel brings a second HIP runtime into the process -- ccv_amd/ctl.py -- and this
+        pytest.skip("no torch.distributed.run here")  # process has the backend loaded; the launcher runs in a child)
     from ccv_amd import nnc
     n = nnc.load().device_count()
     env = dict(os.environ, NNC_BENCH_FORCE_COMM="1")
