@@ -658,7 +658,9 @@ def main():
             out["config"]["via_host"] = via_host(args, step1_losses, step1_params, fwd_only)
             # the drop-in number (the unmodified reference host driving this backend), next to `value` (ccv_amd/vgg.py, the command driver)
             out["via_host_images_per_s"] = out["config"]["via_host"].get("images_per_s")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world > 1:
+            out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "reference", "sample": "timed at N = 1 only (python bench.py --gpus 1)"}
+        elif not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], oracle_loss = cpu_baseline(image0, label0, fwd_only)
             except Exception as e:  # the checker is optional for the bench line, never for the parity tests
