@@ -372,6 +372,8 @@ extern "C" {
 //   allocate  the size is rounded (512 B below 1 MB, 2 MB above) and the newest block of that size is reused; otherwise hipMalloc.  Out of memory: every kept
 //             block of the device goes back to the driver, the host's registered pressure callbacks run (curegmp: ccv_nnc_xpu_alloc's drain, the stream
 //             contexts' workspaces), one retry.
+//   bound     the bytes KEPT per device never exceed a cap -- half the device's memory, NNC_MI355X_POOL_KEEP_MB overrides -- the oldest kept blocks go back to
+//             the driver first: a caller whose sizes never repeat (dynamic graphs over ragged batches) cannot grow the layer until allocations fail.
 // NNC_MI355X_POOL_ALLOC=0 selects plain hipMalloc / hipFree.
 // Round 5 first built this on the runtime's own stream-ordered pool (hipMallocAsync / hipFreeAsync on the legacy stream, release threshold = keep everything)
 // and took it out again: with the free only QUEUED the full-size convolution parity sequence read back an output still holding its initial fill; with a device
@@ -383,7 +385,20 @@ static pthread_mutex_t g_pool_mutex = PTHREAD_MUTEX_INITIALIZER;
 struct kept_block_t { void* ptr; size_t size; };
 static std::vector<kept_block_t> g_kept[MAX_DEVICES];           // free blocks, newest last
 static std::vector<kept_block_t> g_live[MAX_DEVICES];           // blocks handed out (ptr -> rounded size); a few hundred entries at most: linear search
-static std::atomic<long> g_pool_allocs(0), g_pool_retries(0), g_pool_kept_bytes(0), g_pool_live_bytes(0);
+static std::atomic<long> g_pool_allocs(0), g_pool_retries(0), g_pool_kept_bytes(0), g_pool_live_bytes(0), g_pool_trimmed(0);
+static size_t g_kept_dev_bytes[MAX_DEVICES]; // bytes on g_kept[device] (under the mutex)
+static size_t g_keep_cap[MAX_DEVICES];       // 0 = not read yet
+static size_t pool_keep_cap(const int device)
+{ // (caller holds the mutex; the device is current)
+	if (!g_keep_cap[device]) {
+		const char* e = getenv("NNC_MI355X_POOL_KEEP_MB");
+		size_t free_b = 0, total_b = 0;
+		if (e && *e) g_keep_cap[device] = ((size_t)strtoull(e, 0, 10) << 20) + 1; // (+ 1: "0 MB" is a cap too, not "unread")
+		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) g_keep_cap[device] = total_b / 2;
+		else { (void)hipGetLastError(); g_keep_cap[device] = (size_t)64 << 30; }
+	}
+	return g_keep_cap[device];
+}
 static bool pool_on(void)
 {
 	if (g_pool_mode < 0) {
@@ -401,6 +416,21 @@ static void pool_release_all(const int device)
 { // (caller holds the mutex) every kept block of the device back to the driver
 	for (const kept_block_t& k : g_kept[device]) { HIP_ENFORCE(hipFree(k.ptr)); g_pool_kept_bytes.fetch_sub((long)k.size, std::memory_order_relaxed); }
 	g_kept[device].clear();
+	g_kept_dev_bytes[device] = 0;
+}
+static void pool_trim(const int device)
+{ // (caller holds the mutex) oldest first, until the kept bytes fit the cap; every kept block was drained when it was freed
+	const size_t cap = pool_keep_cap(device);
+	std::vector<kept_block_t>& kept = g_kept[device];
+	size_t n = 0;
+	while (n < kept.size() && g_kept_dev_bytes[device] > cap) {
+		HIP_ENFORCE(hipFree(kept[n].ptr));
+		g_kept_dev_bytes[device] -= kept[n].size;
+		g_pool_kept_bytes.fetch_sub((long)kept[n].size, std::memory_order_relaxed);
+		g_pool_trimmed.fetch_add(1, std::memory_order_relaxed);
+		n++;
+	}
+	if (n) kept.erase(kept.begin(), kept.begin() + (long)n);
 }
 
 void* nnc_mi355x_malloc(int device, size_t size)
@@ -423,6 +453,7 @@ void* nnc_mi355x_malloc(int device, size_t size)
 		if (kept[i].size == rounded) {
 			ptr = kept[i].ptr;
 			kept.erase(kept.begin() + (long)i);
+			g_kept_dev_bytes[device] -= rounded;
 			g_pool_kept_bytes.fetch_sub((long)rounded, std::memory_order_relaxed);
 			g_pool_allocs.fetch_add(1, std::memory_order_relaxed);
 			break;
@@ -463,8 +494,10 @@ void release_device_block(void* ptr, const bool drained)
 			if (!drained) HIP_ENFORCE(hipDeviceSynchronize()); // hipFree's own guarantee
 			pthread_mutex_lock(&g_pool_mutex);
 			g_kept[device].push_back(k);
+			g_kept_dev_bytes[device] += k.size;
 			g_pool_live_bytes.fetch_sub((long)k.size, std::memory_order_relaxed);
 			g_pool_kept_bytes.fetch_add((long)k.size, std::memory_order_relaxed);
+			pool_trim(device);
 			pthread_mutex_unlock(&g_pool_mutex);
 			return;
 		}
@@ -490,6 +523,8 @@ void nnc_mi355x_debug_pool_counts(long* allocs, long* retries, long* reserved_by
 	if (reserved_bytes) *reserved_bytes = g_pool_kept_bytes.load(std::memory_order_relaxed) + g_pool_live_bytes.load(std::memory_order_relaxed);
 	if (used_bytes) *used_bytes = g_pool_live_bytes.load(std::memory_order_relaxed);
 }
+
+long nnc_mi355x_debug_pool_trimmed(void) { return g_pool_trimmed.load(std::memory_order_relaxed); }
 
 void nnc_mi355x_set_device(int device)
 {

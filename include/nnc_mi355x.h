@@ -414,6 +414,9 @@ long nnc_mi355x_debug_peephole_trailed(void);
  * memory pressure every kept block goes back to the driver, the host's curegmp callbacks run, the allocation is retried.  NNC_MI355X_POOL_ALLOC=0 selects plain
  * hipMalloc / hipFree.  Hook: allocations served from kept blocks, pressure retries, bytes held (kept + handed out) and bytes handed out. */
 void nnc_mi355x_debug_pool_counts(long* allocs, long* retries, long* reserved_bytes, long* used_bytes);
+/* The kept bytes are bounded per device (half the device's memory; NNC_MI355X_POOL_KEEP_MB overrides): beyond the cap the oldest kept blocks go back to the
+ * driver.  Hook: blocks returned that way so far. */
+long nnc_mi355x_debug_pool_trimmed(void);
 /* batch-norm commands that ran on the cluster kernels (cmd_norm.cpp: a cluster of workgroups per channel keeps the channel in registers between the
  * statistics and the apply pass; NNC_MI355X_BN_CLUSTER=0 / nnc_mi355x_tune_set("BN_CLUSTER", 0) selects the plane kernels). */
 long nnc_mi355x_debug_bn_cluster_launches(void);

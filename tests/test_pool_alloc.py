@@ -96,3 +96,37 @@ print("ok")
         pytest.skip("emulator library not built")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, EMU_MALLOC_FAIL_NEXT="1"))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_kept_bytes_are_bounded():
+    """CPU tier (emulator): a caller whose allocation sizes never repeat cannot grow the caching layer without bound -- beyond the cap (NNC_MI355X_POOL_KEEP_MB;
+    half the device's memory by default) the oldest kept blocks go back to the driver.  Own process: the cap is read once."""
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from ccv_amd import nnc
+lib = nnc.load(os.path.join(%r, "tests", "emu", "_build", "libnnc_mi355x_emu.so"))
+def counts():
+    a, r, res, used = C.c_long(), C.c_long(), C.c_long(), C.c_long()
+    lib.dll.nnc_mi355x_debug_pool_counts(C.byref(a), C.byref(r), C.byref(res), C.byref(used))
+    return a.value, r.value, res.value, used.value
+lib.dll.nnc_mi355x_debug_pool_trimmed.restype = C.c_long
+for i in range(64):  # sizes that never repeat: without the bound every freed block would stay on the layer's lists for good
+    p = lib.malloc(0, (1 << 20) * (3 + i))
+    assert p
+    lib.free(0, p)
+    held = counts()[2]
+    assert held <= (8 << 20) + (2 << 20) * 40, (i, held)  # the cap (8 MB) + at most the block just freed
+assert counts()[3] == 0
+assert lib.dll.nnc_mi355x_debug_pool_trimmed() >= 55, lib.dll.nnc_mi355x_debug_pool_trimmed()
+a0 = counts()[0]
+for i in range(4):  # a size that repeats within the cap is still served from its kept block
+    p = lib.malloc(0, 4 << 20); assert p; lib.free(0, p)
+assert counts()[0] - a0 >= 3
+print("ok")
+''' % (ROOT, ROOT, ROOT)
+    so = os.path.join(ROOT, "tests", "emu", "_build", "libnnc_mi355x_emu.so")
+    if not os.path.exists(so):
+        pytest.skip("emulator library not built")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, NNC_MI355X_POOL_KEEP_MB="8"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
