@@ -342,6 +342,156 @@ __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_
 	if (mine) { if (a.dhx) a.dhx[e] = dh; if (a.dcx) a.dcx[e] = dc; }
 }
 
+// ---- the whole sequence of one pseudo-layer in ONE launch WITHOUT any traffic between workgroups (TUNE_LSTM_ROWS; round 5; no projection, hidden size <= 128) ----
+// The one-launch kernels above split the HIDDEN units over workgroups, so every step ends with the tile's workgroups handing each other the new state through
+// tagged words in the L2: 5.8 us per step forward, 8.3 backward at the IMDB classifier's shape (64 x 512 x 128), of which the arithmetic is a tenth.  For H <= 128
+// all of R -- 4H x H floats, 256 KB at H = 128 -- fits the REGISTER FILE of one workgroup: 4H threads (eight waves at H = 128), thread n keeps row n of R (H
+// registers).  A workgroup then owns LS_RB = 2 batch rows and ALL hidden units for the whole sequence; the state never leaves its LDS, there is nothing to wait
+// for and nothing that can time out (no ClusterTurn, no co-residency condition: any number of these launches may share the device), and B / 2 workgroups run
+// side by side.  Per step: thread n forms pre[r][n] = sum_k h'[r][k] R[n][k] for its gate column -- the state read as one broadcast 8-byte LDS word per k, the
+// two rows in one packed multiply-add --, the columns meet in LDS, thread (r, u) does the gate arithmetic of its element, writes y and the tape and puts the new
+// state back into LDS.  Backward: thread (r, u) turns its state gradients into the four gate gradients (tape loads issued a step ahead), thread (q, k) holds
+// column k of gate q's block of R and reduces that block's 128 terms of dh' = dG R, the four partial sums meet in LDS.
+// Cost per step ~ the LDS broadcast of the state to eight waves (H x 512 bytes per wave) -- the register-resident multiply-adds run beside it.
+constexpr int LS_RB = 2;
+typedef float lstm_f2 __attribute__((ext_vector_type(2))); // the two rows of a workgroup in an aligned register pair: v_pk_fma_f32
+template <int HT>
+__global__ void __launch_bounds__(4 * HT) lstm_rows_forw_kernel(const lstm_seq_t a)
+{
+	__shared__ __attribute__((aligned(16))) float htile[HT][LS_RB];      // the state before the step, k-major: one 8-byte broadcast read per k
+	__shared__ float pre[LS_RB][4 * HT + 4];
+	const int tid = threadIdx.x, H = a.H, B = a.B, N4 = 4 * H, row0 = blockIdx.x * LS_RB;
+	const size_t BH = (size_t)B * H;
+	lstm_f2 rreg[HT / 2]; // row tid of R (zero past 4H / H), two consecutive k per register pair
+#pragma unroll
+	for (int k = 0; k < HT; k++) rreg[k >> 1][k & 1] = tid < N4 && k < H ? a.r[(size_t)tid * H + k] : 0.f;
+	const int rr = tid / H, u = tid - rr * H, b = row0 + rr; // (row, unit): the element whose cell and state this thread keeps for the whole sequence
+	const bool mine = rr < LS_RB && b < B;
+	const size_t e = (size_t)b * H + u;
+	float cst = mine && a.cx ? a.cx[e] : 0.f, hst = mine && a.hx ? a.hx[e] : 0.f;
+	const int len = mine && a.lens ? a.lens[b] : a.T;
+	float bias[4] = { 0.f, 0.f, 0.f, 0.f };
+	if (mine && a.bw)
+#pragma unroll
+		for (int g = 0; g < 4; g++) bias[g] = a.bw[g * H + u] + a.bw[4 * H + g * H + u];
+	for (int q = tid; q < HT * LS_RB; q += 4 * HT) (&htile[0][0])[q] = 0.f;
+	__syncthreads();
+	if (mine) htile[u][rr] = hst;
+	__syncthreads();
+	for (int s = 0; s < a.T; s++) {
+		const int t = a.dir ? a.T - 1 - s : s;
+		float gin[4] = { 0.f, 0.f, 0.f, 0.f };
+		if (mine) { // the input half: in flight during the products
+			const float* const gr = a.gx + ((size_t)t * B + b) * N4 + u;
+#pragma unroll
+			for (int g = 0; g < 4; g++) gin[g] = gr[g * H];
+		}
+		lstm_f2 acc4[4] = { { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f } }; // four chains: a packed multiply-add waits for its predecessor otherwise
+#pragma unroll
+		for (int k2 = 0; k2 < HT / 2; k2++) {
+			const float4 h4 = *(const float4*)&htile[2 * k2][0]; // rows 0, 1 of k = 2 k2 and of k = 2 k2 + 1
+			const lstm_f2 h0 = { h4.x, h4.y }, h1 = { h4.z, h4.w };
+			NNC_PK_FMA_LO(acc4[(2 * k2) & 3], h0, rreg[k2]);
+			NNC_PK_FMA_HI(acc4[(2 * k2 + 1) & 3], h1, rreg[k2]);
+		}
+		const lstm_f2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+		if (tid < N4) { pre[0][tid] = acc[0]; pre[1][tid] = acc[1]; }
+		NNC_LDS_BARRIER();
+		if (mine) {
+			float* const gates = a.rsv ? a.rsv + a.slot0 + (size_t)s * a.S * BH : 0;
+			float hnew = hst;
+			if (t < len) {
+				float p4[4];
+#pragma unroll
+				for (int g = 0; g < 4; g++) p4[g] = pre[rr][g * H + u] + gin[g] + bias[g];
+				const float i = lstm_sigmoid(p4[0]), f = lstm_sigmoid(p4[1]), g = tanhf(p4[2]), o = lstm_sigmoid(p4[3]);
+				cst = f * cst + i * g;
+				const float tc = tanhf(cst);
+				hnew = o * tc;
+				a.y[((size_t)t * B + b) * a.ldy + u] = hnew;
+				if (gates) { gates[e] = i; gates[BH + e] = f; gates[2 * BH + e] = g; gates[3 * BH + e] = o; gates[4 * BH + e] = tc; }
+			} else {
+				a.y[((size_t)t * B + b) * a.ldy + u] = 0.f;
+				if (gates) for (int k = 0; k < 5; k++) gates[k * BH + e] = 0.f;
+			}
+			hst = hnew;
+			htile[u][rr] = hnew;
+			if (s < a.T - 1 && a.rsv) a.rsv[a.cslot0 + (size_t)s * BH + e] = cst;
+		}
+		NNC_LDS_BARRIER();
+	}
+	if (mine) { if (a.hy) a.hy[e] = hst; if (a.cy) a.cy[e] = cst; }
+}
+
+template <int HT>
+__global__ void __launch_bounds__(4 * HT) lstm_rows_back_kernel(const lstm_seq_back_t a)
+{
+	__shared__ __attribute__((aligned(16))) float dgt[4 * HT][LS_RB];    // the step's gate gradients, column-major: one 8-byte broadcast read per column
+	__shared__ float part[4][LS_RB][HT + 1];
+	const int tid = threadIdx.x, H = a.H, B = a.B, N4 = 4 * H, row0 = blockIdx.x * LS_RB;
+	const size_t BH = (size_t)B * H;
+	const int q = tid / H, kc = tid - q * H; // (gate block, unit): column kc of R's rows q H .. q H + H - 1
+	lstm_f2 rreg[HT / 2];
+#pragma unroll
+	for (int i = 0; i < HT; i++) rreg[i >> 1][i & 1] = tid < N4 && i < H ? a.r[(size_t)(q * H + i) * H + kc] : 0.f;
+	const int rr = q, u = kc, b = row0 + rr; // the same split of the thread index names the element (row, unit) of dh / dc this thread keeps
+	const bool mine = rr < LS_RB && b < B;
+	const size_t e = (size_t)b * H + u;
+	float dh = mine && a.dhy ? a.dhy[e] : 0.f, dc = mine && a.dcy ? a.dcy[e] : 0.f;
+	const int len = mine && a.lens ? a.lens[b] : a.T;
+	for (int z = tid; z < 4 * HT * LS_RB; z += 4 * HT) (&dgt[0][0])[z] = 0.f; // (rows past the batch, columns past 4H: zero for good)
+	__syncthreads();
+	// the tape of the step about to be processed, loaded a step ahead
+	float ti = 0.f, tf = 0.f, tg = 0.f, to = 0.f, ttc = 0.f, tcp = 0.f, tdy = 0.f;
+	auto load_tape = [&](const int it) {
+		const int s = a.T - 1 - it, t = a.dir ? a.T - 1 - s : s;
+		if (mine && it < a.T && t < len) {
+			const float* const gates = a.rsv + a.slot0 + (size_t)s * a.S * BH;
+			ti = gates[e]; tf = gates[BH + e]; tg = gates[2 * BH + e]; to = gates[3 * BH + e]; ttc = gates[4 * BH + e];
+			tcp = s == 0 ? (a.cx ? a.cx[e] : 0.f) : a.rsv[a.cslot0 + (size_t)(s - 1) * BH + e];
+			tdy = a.dy[((size_t)t * B + b) * a.ldy + u];
+		}
+	};
+	load_tape(0);
+	for (int it = 0; it < a.T; it++) {
+		const int s = a.T - 1 - it, t = a.dir ? a.T - 1 - s : s;
+		if (mine) {
+			float d4[4] = { 0.f, 0.f, 0.f, 0.f };
+			if (t < len) {
+				const float i = ti, f = tf, g = tg, o = to, tc = ttc, cprev = tcp;
+				const float dht = dh + tdy;
+				const float dct = dc + dht * o * (1.f - tc * tc);
+				d4[0] = dct * g * i * (1.f - i);
+				d4[1] = dct * cprev * f * (1.f - f);
+				d4[2] = dct * i * (1.f - g * g);
+				d4[3] = dht * tc * o * (1.f - o);
+				dc = dct * f;
+			}
+			float* const dgo = a.dg + ((size_t)t * B + b) * N4 + u;
+#pragma unroll
+			for (int g = 0; g < 4; g++) { dgo[g * H] = d4[g]; dgt[g * H + u][rr] = d4[g]; }
+		}
+		load_tape(it + 1);
+		NNC_LDS_BARRIER();
+		lstm_f2 acc4[4] = { { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f } };
+		const int nb = tid < N4 ? q * H : 0;
+#pragma unroll
+		for (int i2 = 0; i2 < HT / 2; i2++) { // (nb + i < 3 H + HT <= 4 HT; past the block's H terms the coefficient is zero)
+			const lstm_f2 d0 = *(const lstm_f2*)&dgt[nb + 2 * i2][0], d1 = *(const lstm_f2*)&dgt[nb + 2 * i2 + 1][0];
+			NNC_PK_FMA_LO(acc4[(2 * i2) & 3], d0, rreg[i2]);
+			NNC_PK_FMA_HI(acc4[(2 * i2 + 1) & 3], d1, rreg[i2]);
+		}
+		const lstm_f2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+		if (tid < N4) { part[q][0][kc] = acc[0]; part[q][1][kc] = acc[1]; }
+		NNC_LDS_BARRIER();
+		if (mine) {
+			const float v = (part[0][rr][u] + part[1][rr][u]) + (part[2][rr][u] + part[3][rr][u]);
+			dh = t < len ? v : dh + v; // (past the end the gate gradients were zero: v == 0, the state gradient goes on unchanged)
+		}
+	}
+	if (mine) { if (a.dhx) a.dhx[e] = dh; if (a.dcx) a.dcx[e] = dc; }
+}
+
 // One step of one pseudo-layer: the four gates' recurrent products + the gate arithmetic.  direct = no projection (hout is the next state, P == H).
 __global__ void __launch_bounds__(256) lstm_step_forw_kernel(const float* const gx, const float* const rt, const float* const bw, const float* const br, const float* const hprev, const float* const cprev,
 	float* const hout, float* const cnext, float* const gates, float* const cstore, float* const y, const int ldy, const int* const lens, const int t, const int B, const int H, const int P, const int direct)
@@ -584,7 +734,9 @@ static int _lstm_forw(EXEC_ARGS_L)
 	const size_t n_len = (sizeof(int) * g.B + 255) & ~(size_t)255, n_xs = g.batch_first ? al(TB * g.I) : 0, n_ys = g.batch_first ? al(TB * DP) : 0, n_lay = g.L > 1 ? al(TB * DP) : 0;
 	const size_t n_gx = al(TB * 4 * g.H), n_rt = al((size_t)4 * g.H * g.P), n_wpt = g.proj ? al((size_t)g.P * g.H) : 0, n_h = al((size_t)g.B * g.P), n_c = al(g.BH()), n_raw = g.proj ? al(g.BH()) : 0;
 	// the whole sequence in one launch: every workgroup must be resident at once (they wait for each other) -- the grid stays within the CU count
-	const bool persistent = tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 512 && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
+	// hidden size <= 128: the whole of R fits one workgroup's registers -- two batch rows per workgroup, no traffic between workgroups (lstm_rows_forw_kernel)
+	const bool rows = tune(TUNE_LSTM_PERSISTENT) && tune(TUNE_LSTM_ROWS) && !g.proj && g.H <= 128;
+	const bool persistent = !rows && tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 512 && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
 	const size_t n_xch = persistent ? (sizeof(unsigned long long) * 2 * g.B * g.H + 255) & ~(size_t)255 : 0;
 	WorkspaceScope ws(stream_context, n_len + n_xs + n_ys + 2 * n_lay + n_gx + n_rt + n_wpt + 2 * n_h + 2 * n_c + n_raw + n_xch, lstm_inner_bytes(g));
 	char* at = (char*)ws.prefix();
@@ -628,8 +780,20 @@ static int _lstm_forw(EXEC_ARGS_L)
 			const GemmOut out = { gx, 4L * g.H, 1, 0, 1.f, 0, 0 };
 			const int ret = gemm_strided<float>("lstm_gx", A, Bm, out, 1, 0, 0, 0, 0, 0, stream_context);
 			if (ret != CCV_NNC_EXEC_SUCCESS) return ret;
-			if (!persistent) hipLaunchKernelGGL(lstm_transpose_kernel, dim3(blocks_of((size_t)4 * g.H * g.P)), dim3(256), 0, stream, Rc, rt, 4 * g.H, g.P);
+			if (!persistent && !rows) hipLaunchKernelGGL(lstm_transpose_kernel, dim3(blocks_of((size_t)4 * g.H * g.P)), dim3(256), 0, stream, Rc, rt, 4 * g.H, g.P);
 			if (g.proj) hipLaunchKernelGGL(lstm_transpose_kernel, dim3(blocks_of((size_t)g.P * g.H)), dim3(256), 0, stream, Wp, wpt, g.P, g.H);
+			if (rows) { // one launch for the whole sequence, nothing passes between its workgroups (lstm_rows_forw_kernel)
+				const lstm_seq_t a = { gx, Rc, bw, hx ? hx->data.f32 + (size_t)p * g.BH() : 0, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, yl + (size_t)d * g.P, hy ? hy->data.f32 + (size_t)p * g.BH() : 0, cy ? cy->data.f32 + (size_t)p * g.BH() : 0,
+					rsv, 0, lens, 0, g.T, g.B, g.H, d, DP, g.S, rsv ? g.slot(p, 0, 0) : 0, rsv && g.T > 1 ? g.cslot(p, 0) : 0 };
+				const dim3 rows_grid((g.B + LS_RB - 1) / LS_RB);
+				if (g.H <= 32) hipLaunchKernelGGL(lstm_rows_forw_kernel<32>, rows_grid, dim3(128), 0, stream, a);
+				else if (g.H <= 64) hipLaunchKernelGGL(lstm_rows_forw_kernel<64>, rows_grid, dim3(256), 0, stream, a);
+				else if (g.H <= 96) hipLaunchKernelGGL(lstm_rows_forw_kernel<96>, rows_grid, dim3(384), 0, stream, a);
+				else hipLaunchKernelGGL(lstm_rows_forw_kernel<128>, rows_grid, dim3(512), 0, stream, a);
+				HIP_ENFORCE(hipGetLastError());
+				note_kernel("lstm_rows_forw");
+				continue;
+			}
 			if (persistent) { // one launch for the whole sequence (lstm_seq_forw_kernel)
 				HIP_ENFORCE(hipMemsetAsync(xch, 0, n_xch, stream));
 				const lstm_seq_t a = { gx, Rc, bw, hx ? hx->data.f32 + (size_t)p * g.BH() : 0, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, yl + (size_t)d * g.P, hy ? hy->data.f32 + (size_t)p * g.BH() : 0, cy ? cy->data.f32 + (size_t)p * g.BH() : 0,
@@ -701,7 +865,8 @@ static int _lstm_back(EXEC_ARGS_L)
 	const size_t n_len = (sizeof(int) * g.B + 255) & ~(size_t)255, n_xs = g.batch_first ? al(TB * g.I) : 0, n_dys = g.batch_first ? al(TB * DP) : 0, n_lay = g.L > 1 ? al(TB * DP) : 0;
 	const size_t n_dg = al(TB * 4 * g.H), n_in = g.L > 1 ? al(TB * in_max) : 0, n_hp = al(TB * g.P), n_h = al((size_t)g.B * g.P), n_c = al(g.BH());
 	const size_t n_dhp = g.proj ? al(TB * g.P) : 0, n_draw = g.proj ? al(g.BH()) : 0, n_raw = g.proj ? al(TB * g.H) : 0;
-	const bool persistent = tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 512 && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
+	const bool rows = tune(TUNE_LSTM_PERSISTENT) && tune(TUNE_LSTM_ROWS) && !g.proj && g.H <= 128; // (lstm_rows_back_kernel: as the forward command)
+	const bool persistent = !rows && tune(TUNE_LSTM_PERSISTENT) && !g.proj && g.H <= 512 && (long)((g.H + 15) / 16) * ((g.B + 15) / 16) <= device_cu_count();
 	const size_t n_xch = persistent ? (sizeof(unsigned long long) * 2 * g.B * 4 * g.H + 255) & ~(size_t)255 : 0;
 	WorkspaceScope ws(stream_context, n_len + 2 * n_xs + n_dys + 2 * n_lay + n_dg + n_in + n_hp + 2 * n_h + 2 * n_c + n_dhp + n_draw + n_raw + n_xch, lstm_inner_bytes(g));
 	char* at = (char*)ws.prefix();
@@ -754,12 +919,22 @@ static int _lstm_back(EXEC_ARGS_L)
 			const float* const Wc = W + wo;
 			const float* const Rc = Wc + (size_t)4 * g.H * in;
 			const float* const Wp = Rc + (size_t)4 * g.H * g.P;
-			if (!persistent) {
+			if (!persistent && !rows) {
 				if (dhy) HIP_ENFORCE(hipMemcpyAsync(dh[g.T & 1], dhy->data.f32 + (size_t)p * g.B * g.P, sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
 				else HIP_ENFORCE(hipMemsetAsync(dh[g.T & 1], 0, sizeof(float) * g.B * g.P, stream));
 				if (dcy) HIP_ENFORCE(hipMemcpyAsync(dc, dcy->data.f32 + (size_t)p * g.BH(), sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
 				else HIP_ENFORCE(hipMemsetAsync(dc, 0, sizeof(float) * g.BH(), stream));
 			}
+			if (rows) { // one launch for the whole sequence, nothing passes between its workgroups (lstm_rows_back_kernel)
+				const lstm_seq_back_t a = { Rc, rsv, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, dyl + (size_t)d * g.P, dhy ? dhy->data.f32 + (size_t)p * g.BH() : 0, dcy ? dcy->data.f32 + (size_t)p * g.BH() : 0,
+					dG, dhx ? dhx->data.f32 + (size_t)p * g.BH() : 0, dcx ? dcx->data.f32 + (size_t)p * g.BH() : 0, 0, lens, 0, g.T, g.B, g.H, d, DP, g.S, g.slot(p, 0, 0), g.T > 1 ? g.cslot(p, 0) : 0 };
+				const dim3 rows_grid((g.B + LS_RB - 1) / LS_RB);
+				if (g.H <= 32) hipLaunchKernelGGL(lstm_rows_back_kernel<32>, rows_grid, dim3(128), 0, stream, a);
+				else if (g.H <= 64) hipLaunchKernelGGL(lstm_rows_back_kernel<64>, rows_grid, dim3(256), 0, stream, a);
+				else if (g.H <= 96) hipLaunchKernelGGL(lstm_rows_back_kernel<96>, rows_grid, dim3(384), 0, stream, a);
+				else hipLaunchKernelGGL(lstm_rows_back_kernel<128>, rows_grid, dim3(512), 0, stream, a);
+				HIP_ENFORCE(hipGetLastError());
+			} else
 			if (persistent) { // one launch for the whole sequence (lstm_seq_back_kernel)
 				HIP_ENFORCE(hipMemsetAsync(xch, 0, n_xch, stream));
 				const lstm_seq_back_t a = { Rc, rsv, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, dyl + (size_t)d * g.P, dhy ? dhy->data.f32 + (size_t)p * g.BH() : 0, dcy ? dcy->data.f32 + (size_t)p * g.BH() : 0,
@@ -795,8 +970,8 @@ static int _lstm_back(EXEC_ARGS_L)
 				hipLaunchKernelGGL(lstm_rowmat_kernel<2>, rec_grid, dim3(256), 0, stream, (const float*)dgt, 4 * g.H, Rc, g.P, 4 * g.H, g.P, g.B, dh[s & 1], g.P, dh_in, (float*)0, 0, (float*)0, 0, (const int*)lens, t);
 			}
 			HIP_ENFORCE(hipGetLastError());
-			if (!persistent && dhx) HIP_ENFORCE(hipMemcpyAsync(dhx->data.f32 + (size_t)p * g.B * g.P, dh[0], sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
-			if (!persistent && dcx) HIP_ENFORCE(hipMemcpyAsync(dcx->data.f32 + (size_t)p * g.BH(), dc, sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
+			if (!persistent && !rows && dhx) HIP_ENFORCE(hipMemcpyAsync(dhx->data.f32 + (size_t)p * g.B * g.P, dh[0], sizeof(float) * g.B * g.P, hipMemcpyDeviceToDevice, stream));
+			if (!persistent && !rows && dcx) HIP_ENFORCE(hipMemcpyAsync(dcx->data.f32 + (size_t)p * g.BH(), dc, sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
 			int ret;
 			{ // dX (+)= dG W: [T B][4H] x [4H][in]; the second direction adds to the first
 				const MatOperand A = { dG, 4L * g.H, 1, (int)TB, 4 * g.H };
@@ -836,7 +1011,7 @@ static int _lstm_back(EXEC_ARGS_L)
 	}
 	if (g.batch_first) hipLaunchKernelGGL(lstm_swap01_kernel, dim3(blocks_of(TB * g.I)), dim3(256), 0, stream, (const float*)dxseq, dx->data.f32, g.T, g.B, g.I);
 	HIP_ENFORCE(hipGetLastError());
-	note_kernel(persistent ? "lstm_seq_back" : "lstm_step_back");
+	note_kernel(rows ? "lstm_rows_back" : (persistent ? "lstm_seq_back" : "lstm_step_back"));
 	return CCV_NNC_EXEC_SUCCESS;
 }
 

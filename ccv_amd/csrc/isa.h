@@ -72,6 +72,10 @@ static inline floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx
 #define NNC_PIN_VEC(v) ((void)0)
 #define NNC_ASM_NOPS(text) ((void)0)
 #define NNC_WAIT_LGKM0() ((void)0)
+#define NNC_LDS_BARRIER() __syncthreads()
+// acc (a pair) += h (a pair) * the LOW / HIGH half of the pair rp: v_pk_fma_f32 with op_sel, so that a per-lane coefficient costs ONE register, not a splat pair
+#define NNC_PK_FMA_LO(acc, h, rp) do { (acc)[0] += (h)[0] * (rp)[0]; (acc)[1] += (h)[1] * (rp)[0]; } while (0)
+#define NNC_PK_FMA_HI(acc, h, rp) do { (acc)[0] += (h)[0] * (rp)[1]; (acc)[1] += (h)[1] * (rp)[1]; } while (0)
 #define NNC_WAIT_VM0_ONLY() ((void)0)
 // -- workgroups of ONE launch that hand each other a few words (cmd_norm.cpp's cluster kernels): agent-scope accesses of the words themselves, no fences.
 //    A granule is one naturally aligned 8-byte {tag, value} written by ONE store: the data is the flag.  The emulator keeps a window of workgroups resident
@@ -145,6 +149,12 @@ __device__ __forceinline__ unsigned long long nnc_load_granule(const unsigned lo
 #define NNC_PIN_VEC(v) asm volatile("" : "+v"(v))
 #define NNC_ASM_NOPS(text) asm volatile(text)
 #define NNC_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// a workgroup barrier that orders LDS traffic ONLY: __syncthreads() also waits for every global load and store the wave has in flight (vmcnt(0)) -- in a loop whose
+// steps hand data through LDS and stream results to HBM that wait is the stores' round trip, twice per step (lstm_rows_*_kernel: 4.5 -> ~1.5 us per step)
+#define NNC_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+// acc (a register pair) += h (a pair) * the LOW / HIGH half of the pair rp (hipcc splats a per-lane scalar into a pair of its own for v_pk_fma_f32: 2 x the registers)
+#define NNC_PK_FMA_LO(acc, h, rp) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(h), "v"(rp))
+#define NNC_PK_FMA_HI(acc, h, rp) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(h), "v"(rp))
 #define NNC_WAIT_VM0_ONLY() __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8)) // vmcnt(0), expcnt / lgkmcnt not waited for (gfx9 encoding)
 
 #endif
