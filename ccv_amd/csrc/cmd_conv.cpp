@@ -1420,6 +1420,7 @@ static int _conv_autotune(const ccv_nnc_cmd_t cmd, const size_t max_workspace_si
 {
 	(void)max_workspace_size;
 	if (any_half_tensor(inputs, input_size, outputs, output_size)) return -1; // half precision: the backend's own choice (the trials below time the fp32 kernels)
+	if (any_palettized(inputs, input_size)) return -1; // palettized filters: the trials below would read the byte stream as floats; the backend's own choice
 	const bool fwd = cmd.cmd == CCV_NNC_CONVOLUTION_FORWARD;
 	hipStream_t stream = stream_of(stream_context);
 	hipEvent_t e0, e1;
@@ -1460,6 +1461,7 @@ extern "C" void _register_command_CCV_NNC_CONVOLUTION_FORWARD_backend_CCV_NNC_BA
 	registry->algorithms = CONV_ALGO_COUNT;
 	registry->exec = _conv_forw_any;
 	registry->autotune = _conv_autotune;
+	NNC_DEPALETTIZED(registry, _conv_forw_any); // palettized filters (ccv_nnc_conv_gpu_cudnn.cu:79-95)
 }
 
 extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
@@ -1470,6 +1472,7 @@ extern "C" void _register_command_CCV_NNC_CONVOLUTION_BACKWARD_backend_CCV_NNC_B
 	registry->algorithms = CONV_ALGO_COUNT; // one choice for both gradients
 	registry->exec = _conv_back_any;
 	registry->autotune = _conv_autotune;
+	NNC_DEPALETTIZED(registry, _conv_back_any); // palettized filters under the data gradient (ccv_nnc_conv_gpu_cudnn.cu:328-345)
 }
 
 extern "C" void _register_command_CCV_NNC_CONVOLUTION_TRANSPOSE_FORWARD_backend_CCV_NNC_BACKEND_GPU_CUDNN(ccv_nnc_cmd_backend_registry_t* const registry)
@@ -1480,4 +1483,5 @@ extern "C" void _register_command_CCV_NNC_CONVOLUTION_TRANSPOSE_FORWARD_backend_
 	registry->algorithms = 1;
 	registry->exec = _conv_transpose_forw;
 	NNC_HALF_STAGED(registry, _conv_transpose_forw);
+	NNC_DEPALETTIZED(registry, nnc::half_staged<_conv_transpose_forw>); // palettized filters (ccv_nnc_conv_transpose_gpu_cudnn.cu:72-90)
 }

@@ -446,8 +446,14 @@ static int _data_transfer(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 		ccv_nnc_tensor_t* b = outputs[i];
 		if (!a || !b || a == b) continue;
 		if (!tensor_contiguous(a) || !tensor_contiguous(b) || tensor_count(a->info) != tensor_count(b->info)) return CCV_NNC_EXEC_INVALID;
-		if (datatype_size(a->info.datatype) != datatype_size(b->info.datatype)) return CCV_NNC_EXEC_INVALID;
-		const size_t size = tensor_count(a->info) * datatype_size(a->info.datatype);
+		size_t size;
+		if (CCV_GET_DATA_TYPE(a->info.datatype) == CCV_QX) { // a palettized tensor travels as its byte stream (ccv_nnc_util_gpu_ref.cu:22-26)
+			if (a->info.datatype != b->info.datatype || a->info.reserved != b->info.reserved) return CCV_NNC_EXEC_INVALID;
+			size = palettized_bytes((a->info.datatype & 0xff) << 12, tensor_count(a->info), (a->info.datatype & 0xf00) >> 8, a->info.reserved);
+		} else {
+			if (datatype_size(a->info.datatype) != datatype_size(b->info.datatype)) return CCV_NNC_EXEC_INVALID;
+			size = tensor_count(a->info) * datatype_size(a->info.datatype);
+		}
 		const int am = CCV_TENSOR_GET_MEMORY(a->info.type), bm = CCV_TENSOR_GET_MEMORY(b->info.type);
 		const int da = CCV_TENSOR_GET_DEVICE_ID(a->info.type), db = CCV_TENSOR_GET_DEVICE_ID(b->info.type);
 		if (stream_context) {
@@ -654,8 +660,8 @@ NNC_REG(CCV_NNC_DROPOUT_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32
 NNC_REG(CCV_NNC_SGD_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _sgd_forw)
 NNC_REG(CCV_NNC_SET_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_forw)
 NNC_REG(CCV_NNC_SET_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_back)
-NNC_REG(CCV_NNC_DATA_TRANSFER_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
-NNC_REG(CCV_NNC_DATA_TRANSFER_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
+NNC_REG(CCV_NNC_DATA_TRANSFER_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U | CCV_QX, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
+NNC_REG(CCV_NNC_DATA_TRANSFER_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U | CCV_QX, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
 NNC_REG(CCV_NNC_RANDOM_UNIFORM_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _random_exec)
 NNC_REG(CCV_NNC_RANDOM_UNIFORM_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _random_exec)
 NNC_REG(CCV_NNC_RANDOM_NORMAL_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _random_exec)

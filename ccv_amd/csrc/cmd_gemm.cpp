@@ -268,6 +268,7 @@ extern "C" void _register_command_CCV_NNC_GEMM_FORWARD_backend_CCV_NNC_BACKEND_G
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
 	registry->algorithms = 1;
 	registry->exec = _gemm_forw;
+	NNC_DEPALETTIZED(registry, _gemm_forw); // palettized a / w (ccv_nnc_gemm_gpu_cublas.cu:289-334)
 }
 
 extern "C" void _register_command_CCV_NNC_GEMM_BACKWARD_backend_CCV_NNC_BACKEND_GPU_CUBLAS(ccv_nnc_cmd_backend_registry_t* const registry)
@@ -277,4 +278,5 @@ extern "C" void _register_command_CCV_NNC_GEMM_BACKWARD_backend_CCV_NNC_BACKEND_
 	registry->tensor_memory = CCV_TENSOR_GPU_MEMORY;
 	registry->algorithms = 1;
 	registry->exec = _gemm_back;
+	NNC_DEPALETTIZED(registry, _gemm_back); // palettized a / w (ccv_nnc_gemm_gpu_cublas.cu:658-752)
 }

@@ -19,6 +19,7 @@
 } while (0)
 
 extern "C" void* nnc_staging_of(const ccv_nnc_stream_context_t* stream_context, size_t size); // device_rt.cpp
+extern "C" void* nnc_palette_of(const ccv_nnc_stream_context_t* stream_context, size_t size); // device_rt.cpp: dense images of palettized inputs
 
 namespace nnc {
 
@@ -274,6 +275,20 @@ int half_to_float(const void* in, float* out, size_t n, ccv_nnc_stream_context_t
 int float_to_half(const float* in, void* out, size_t n, ccv_nnc_stream_context_t* ctx);
 int chan_sum_planes_f16(const void* x, long outer, int C, long inner, void* out, int accumulate, ccv_nnc_stream_context_t* ctx);
 int colsum_f16(const void* x, long rows, int cols, long ld, void* out, int accumulate, ccv_nnc_stream_context_t* ctx); // halves: out[c] (+)= sum_r x[r * ld + c], fp32 sums
+
+// Palettized inputs (palette.cpp): rows whose reference counterparts list CCV_QX (GEMM, convolution, transposed convolution, attention's head projection) run
+// on dense images of their CCV_QX inputs.  NNC_DEPALETTIZED(registry, EXEC) adds CCV_QX to the row and routes it through the wrapper (a plain call of EXEC
+// when no input is palettized); EXEC is whatever the row's exec would have been (the half-staged form included).
+int depalettize(const void* input, int datatype, size_t input_length, int qbits, int number_in_blocks, void* output, size_t output_length, ccv_nnc_stream_context_t* ctx);
+size_t palettized_bytes(int palette_datatype, size_t count, int qbits, int number_in_blocks);
+bool any_palettized(ccv_nnc_tensor_t* const* const inputs, const int input_size);
+int depalettized_exec(nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx);
+template <nnc_exec_f F>
+static int depalettized(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
+{
+	return depalettized_exec(F, cmd, hint, flags, inputs, input_size, outputs, output_size, ctx);
+}
+#define NNC_DEPALETTIZED(registry, EXEC) do { (registry)->tensor_datatypes |= CCV_QX; (registry)->exec = nnc::depalettized<EXEC>; } while (0)
 
 // Registration table (registry.cpp).
 typedef void (*register_fn_t)(ccv_nnc_cmd_backend_registry_t* const);

@@ -17,6 +17,8 @@ struct device_local_t {
 	int device;
 	void* staging;        // second grow-only arena: the fp32 images of half-precision tensors (half_stage.cpp) -- they must survive
 	size_t staging_size;  // whatever the command underneath asks of the workspace (a growing workspace is freed and re-allocated)
+	void* palette;        // third grow-only arena: the dense images of palettized (CCV_QX) inputs (palette.cpp) -- the command underneath may grow
+	size_t palette_size;  // the workspace AND the staging arena (a half-precision GEMM with palettized weights does both)
 	void* cluster_sync;   // the words the workgroups of ONE launch on this stream hand each other (nnc::cluster_sync_of): never scratch, never moved
 	unsigned cluster_epoch;
 };
@@ -626,16 +628,17 @@ ccv_nnc_stream_context_t* ccv_nnc_init_stream_context(ccv_nnc_stream_context_t* 
 
 static void local_release(device_local_t* l)
 {
-	if (!l->stream && !l->workspace && !l->staging && !l->cluster_sync) return;
+	if (!l->stream && !l->workspace && !l->staging && !l->palette && !l->cluster_sync) return;
 	nnc::comm_flush_if_pending();
 	const int prev = current_device();
 	HIP_ENFORCE(hipSetDevice(l->device));
 	if (l->stream) { HIP_ENFORCE(hipStreamSynchronize(l->stream)); nnc::cluster_turn_forget(l->device, l->stream); }
 	if (l->workspace) release_device_block(l->workspace, true);
 	if (l->staging) release_device_block(l->staging, true);
+	if (l->palette) release_device_block(l->palette, true);
 	if (l->cluster_sync) release_device_block(l->cluster_sync, true);
 	if (l->stream) HIP_ENFORCE(hipStreamDestroy(l->stream));
-	l->workspace = 0; l->workspace_size = 0; l->staging = 0; l->staging_size = 0; l->stream = 0; l->cluster_sync = 0;
+	l->workspace = 0; l->workspace_size = 0; l->staging = 0; l->staging_size = 0; l->palette = 0; l->palette_size = 0; l->stream = 0; l->cluster_sync = 0;
 	HIP_ENFORCE(hipSetDevice(prev));
 }
 
@@ -700,13 +703,15 @@ void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const 
 
 static void local_drain(device_local_t* l, hipStream_t st)
 {
-	if (!l->workspace && !l->staging) return;
+	if (!l->workspace && !l->staging && !l->palette) return;
 	HIP_ENFORCE(hipStreamSynchronize(st));
 	nnc::cluster_check_timeout();
 	if (l->workspace) release_device_block(l->workspace, true);
 	if (l->staging) release_device_block(l->staging, true);
+	if (l->palette) release_device_block(l->palette, true);
 	l->workspace = 0; l->workspace_size = 0;
 	l->staging = 0; l->staging_size = 0;
+	l->palette = 0; l->palette_size = 0;
 }
 
 // The staging arena of the stream `stream_context` launches on (NULL = this thread's default context): grow-only like the
@@ -735,6 +740,32 @@ void* nnc_staging_of(const ccv_nnc_stream_context_t* const stream_context, const
 	return l->staging;
 }
 
+// The palette arena of the stream `stream_context` launches on: the dense images of a command's palettized inputs (palette.cpp).  Grow-only, apart from the
+// workspace and the staging arena -- the command that reads the images may grow either of those while it is being enqueued.
+void* nnc_palette_of(const ccv_nnc_stream_context_t* const stream_context, const size_t size)
+{
+	if (size == 0) return 0;
+	if (nnc::g_deferred_live) nnc::deferred_flush(stream_context);
+	device_local_t* l;
+	hipStream_t st = 0;
+	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = l->stream; }
+	else {
+		const int device = current_device();
+		if (device >= MAX_DEVICES) return 0;
+		l = &tl_default[device];
+		l->device = device;
+	}
+	if (l->palette_size >= size && l->palette) return l->palette;
+	if (l->palette) {
+		HIP_ENFORCE(hipStreamSynchronize(st)); // a queued command may still read the old images
+		nnc::cluster_check_timeout();
+		release_device_block(l->palette, true);
+	}
+	l->palette = nnc_mi355x_malloc(st ? l->device : current_device(), size);
+	l->palette_size = l->palette ? size : 0;
+	return l->palette;
+}
+
 void ccv_nnc_stream_compat_drain(ccv_nnc_stream_context_t* const stream_context)
 {
 	nnc::comm_flush_if_pending(); // drop the scratch buffers (the host calls this under memory pressure, ccv_nnc_stream.c:70-86)
@@ -751,9 +782,9 @@ void ccv_nnc_stream_compat_drain(ccv_nnc_stream_context_t* const stream_context)
 	if (CCV_STREAM_GET_CONTEXT(stream_context->type) != CCV_STREAM_CONTEXT_GPU) return;
 	stream_gpu_t* s = (stream_gpu_t*)stream_context;
 	const int prev = current_device();
-	if (s->one.workspace || s->one.staging) { HIP_ENFORCE(hipSetDevice(s->one.device)); local_drain(&s->one, s->one.stream); }
+	if (s->one.workspace || s->one.staging || s->one.palette) { HIP_ENFORCE(hipSetDevice(s->one.device)); local_drain(&s->one, s->one.stream); }
 	for (int i = 0; i < s->any_size; i++)
-		if (s->any[i].workspace || s->any[i].staging) { HIP_ENFORCE(hipSetDevice(s->any[i].device)); local_drain(s->any + i, s->any[i].stream); }
+		if (s->any[i].workspace || s->any[i].staging || s->any[i].palette) { HIP_ENFORCE(hipSetDevice(s->any[i].device)); local_drain(s->any + i, s->any[i].stream); }
 	HIP_ENFORCE(hipSetDevice(prev));
 }
 

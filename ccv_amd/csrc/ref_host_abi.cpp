@@ -4,7 +4,7 @@
 //   * device/memory compat calls            lib/nnc/gpu/ccv_nnc_compat.h:23-36
 //   * coroutine <-> stream rendezvous        lib/nnc/gpu/ccv_nnc_compat.cu:547-581, lib/nnc/co.h:12-46
 //   * the registration rows of the host's generated table we do not implement (empty: exec stays 0)
-//   * two symbols outside the nnc hot path the host still references (classic ccv_convnet accelerator, palettize)
+//   * ccv_nnc_compat_depalettize (palette.cpp) and the classic ccv_convnet accelerator's symbols, which are outside the nnc hot path
 #include "common.h"
 #include <pthread.h>
 
@@ -83,7 +83,11 @@ static void out_of_scope(const char* what)
 	fprintf(stderr, "libnnc_mi355x: %s is outside the nnc hot path this backend replaces (see DESIGN.md, out of scope)\n", what);
 	abort();
 }
-void ccv_nnc_compat_depalettize(const void* input, const int datatype, const size_t input_length, const int qbits, const int number_in_blocks, void* output, const size_t output_length, ccv_nnc_stream_context_t* const stream_context) { out_of_scope("ccv_nnc_compat_depalettize"); }
+void ccv_nnc_compat_depalettize(const void* input, const int datatype, const size_t input_length, const int qbits, const int number_in_blocks, void* output, const size_t output_length, ccv_nnc_stream_context_t* const stream_context)
+{ // lib/nnc/gpu/ccv_nnc_palettize.cu:321-469 (the host's ccv_nnc_depalettize of GPU memory, lib/nnc/ccv_nnc_palettize.c:958-966): palette.cpp
+	const int ret = nnc_mi355x_depalettize(input, datatype, input_length, qbits, number_in_blocks, output, output_length, stream_context);
+	if (ret != CCV_NNC_EXEC_SUCCESS) { fprintf(stderr, "libnnc_mi355x: ccv_nnc_compat_depalettize refused (%d): datatype 0x%x, %d bits, %d per block, %zu -> %zu\n", ret, datatype, qbits, number_in_blocks, input_length, output_length); abort(); } // (the reference asserts)
+}
 // classic ccv_convnet GPU accelerator (lib/cuda/cwc.h:11-14): only reached when a ccv_convnet_t was created with use_cwc_accel
 void cwc_convnet_encode(void* convnet, void** a, void** b, int batch) { out_of_scope("cwc_convnet_encode"); }
 void cwc_convnet_classify(void* convnet, void** a, int symmetric, void** ranks, int tops, int batch) { out_of_scope("cwc_convnet_classify"); }

@@ -18,6 +18,7 @@ NCHW, NHWC, CHWN = 0x01, 0x02, 0x04
 CPU_MEMORY, GPU_MEMORY = 0x1, 0x2
 TENSOR_VIEW = 0x01000000
 CCV_8U, CCV_32S, CCV_32F, CCV_64S, CCV_64F, CCV_16F = 0x01000, 0x02000, 0x04000, 0x08000, 0x10000, 0x20000
+CCV_QX = 0x40000  # palettized: CCV_QX | qbits << 8 | palette datatype >> 12, elements per block in info.reserved (lib/nnc/ccv_nnc_easy.h:210-218)
 ACCUMULATE_OUTPUT, ZERO_MEMORY_ALLOC = 0x01, 0x02
 EXEC_SUCCESS, EXEC_INVALID, EXEC_NO_KERNEL, EXEC_OOM = 0, -1, -2, -3
 STREAM_CONTEXT_CPU, STREAM_CONTEXT_GPU = 0x1, 0x2
@@ -593,6 +594,54 @@ class Tensor:
         return C.cast(C.pointer(self.struct), C.POINTER(TensorStruct))
 
 
+def tensor_palettize(params, qbits, number_in_blocks):
+    """ccv_nnc_tensor_palettize (lib/nnc/ccv_nnc_easy.h:210-218): the parameters of the palettized form of a 16F / 32F / 64F tensor."""
+    assert params.datatype in (CCV_16F, CCV_32F, CCV_64F) and 4 <= qbits <= 8
+    p = TensorParam()
+    C.memmove(C.byref(p), C.byref(params), C.sizeof(p))
+    p.datatype = ((params.datatype >> 12) & 0xff) | CCV_QX | ((qbits << 8) & 0xf00)
+    p.reserved = number_in_blocks
+    return p
+
+
+class PalettizedTensor(Tensor):
+    """A CCV_QX tensor: `stream` is the byte stream the host's ccv_nnc_palettize writes (per block: the palette, then the indices)."""
+
+    def __init__(self, lib, params, stream):
+        assert (params.datatype & 0xFF000) == CCV_QX
+        self.lib = lib
+        self.dims = param_dims(params)
+        self.datatype = params.datatype
+        self.np_dtype = np.dtype(np.uint8)
+        self.memory = params.type & 0x3
+        self.device = (params.type & 0xfff00) >> 8
+        self.owner = None
+        self._dptr = None
+        stream = np.ascontiguousarray(stream, dtype=np.uint8).reshape(-1)
+        self.nbytes = stream.nbytes
+        self.struct = TensorStruct()
+        if self.memory == CPU_MEMORY:
+            self.array = stream.copy()
+            self.ptr = self.array.ctypes.data
+        else:
+            self._dptr = lib.malloc(self.device, (max(stream.nbytes, 16) + 127) & ~127)
+            if not self._dptr:
+                raise MemoryError("device allocation of %d bytes failed" % stream.nbytes)
+            self.ptr = self._dptr
+            lib.memcpy(self.ptr, GPU_MEMORY | (self.device << 8), stream.ctypes.data, CPU_MEMORY, stream.nbytes)
+        self.struct.type = params.type
+        self.struct.data = self.ptr
+        self.struct.info = params
+        self.struct.refcount = 1
+
+    def numpy(self):
+        out = np.empty(self.nbytes, dtype=np.uint8)
+        if self.memory == CPU_MEMORY:
+            return self.array.copy()
+        self.lib.memcpy(out.ctypes.data, CPU_MEMORY, self.ptr, GPU_MEMORY | (self.device << 8), out.nbytes)
+        return out
+
+
 def _tensor_array(tensors):
     arr = (C.POINTER(TensorStruct) * max(1, len(tensors)))()
     for i, t in enumerate(tensors):
@@ -644,6 +693,9 @@ class Lib:
             d.nnc_mi355x_version.restype = C.c_char_p
             d.nnc_mi355x_lstm_reserve_space_size.restype = C.c_size_t
             d.nnc_mi355x_lstm_reserve_space_size.argtypes = [Cmd, C.c_int, C.c_int, C.c_int, C.c_int]
+            d.nnc_mi355x_depalettize.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+            d.nnc_mi355x_palettized_bytes.restype = C.c_size_t
+            d.nnc_mi355x_palettized_bytes.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int]
             d.nnc_mi355x_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)]
 
     # device runtime (product / emulator only)
@@ -661,6 +713,13 @@ class Lib:
     def signal_emit(self, stream, sig): self.dll.ccv_nnc_stream_compat_emit_signal(stream, sig)
     def signal_wait(self, stream, sig): self.dll.ccv_nnc_stream_compat_wait_signal(stream, sig)
     def cmd_ok(self, cmd, backend): return bool(self.dll.nnc_mi355x_cmd_ok(cmd, backend))
+
+    def depalettize(self, src, datatype, input_length, qbits, number_in_blocks, dst, output_length, stream=None):
+        """ccv_nnc_depalettize of device memory (lib/nnc/ccv_nnc_palettize.c:958-966): src / dst are Tensors (or raw device pointers)."""
+        sp, dp = getattr(src, "ptr", src), getattr(dst, "ptr", dst)
+        return self.dll.nnc_mi355x_depalettize(sp, datatype, input_length, qbits, number_in_blocks, dp, output_length, stream)
+
+    def palettized_bytes(self, datatype, count, qbits, number_in_blocks): return self.dll.nnc_mi355x_palettized_bytes(datatype, count, qbits, number_in_blocks)
 
     def profile_enable(self, on): self.dll.nnc_mi355x_profile_enable(int(on))
     def force_tile(self, wm, wn): self.dll.nnc_mi355x_debug_force_tile(int(wm), int(wn))

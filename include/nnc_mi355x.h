@@ -373,6 +373,15 @@ void nnc_mi355x_debug_force_splits(int splits);
  * which the host's shape inference calls through ccv_nnc_cmd_aux (lib/nnc/cmd/rnn/ccv_nnc_lstm.c:35,64-71); replaces
  * _ccv_nnc_lstm_reserve_space_size / cudnnGetRNNTempSpaceSizes (lib/nnc/cmd/rnn/gpu/ccv_nnc_lstm_gpu_cudnn.cu:17-48).  0 when cmd.info.rnn.is_test. */
 size_t nnc_mi355x_lstm_reserve_space_size(const ccv_nnc_cmd_t cmd, int datatype, int feature_size, int batch_count, int max_seq_count);
+/* Palettized tensors (datatype = CCV_QX | qbits << 8 | palette datatype >> 12, info.reserved = elements per block; lib/nnc/ccv_nnc_easy.h:210-238).
+ * nnc_mi355x_depalettize replaces ccv_nnc_compat_depalettize (lib/nnc/gpu/ccv_nnc_compat.h:59, lib/nnc/gpu/ccv_nnc_palettize.cu:321-469): `input` is the byte
+ * stream the host's ccv_nnc_palettize wrote (lib/nnc/ccv_nnc_palettize.c:9-208), in device memory; `output` receives output_length elements of `datatype`
+ * (CCV_16F / CCV_32F / CCV_64F), bit for bit what lib/nnc/ccv_nnc_palettize.c:211-956 produces on the CPU.  Returns CCV_NNC_EXEC_SUCCESS or _INVALID (qbits
+ * outside 4 .. 8, an input_length shorter than nnc_mi355x_palettized_bytes).  The GEMM, convolution and transposed-convolution rows accept CCV_QX inputs
+ * and run on dense images of them, DATA_TRANSFER moves the byte stream (the rows that list CCV_QX in the reference). */
+int nnc_mi355x_depalettize(const void* input, int datatype, size_t input_length, int qbits, int number_in_blocks, void* output, size_t output_length, ccv_nnc_stream_context_t* stream_context);
+/* ccv_nnc_tensor_data_size_without_padding of a palettized tensor (lib/nnc/ccv_nnc_easy.h:220-238). */
+size_t nnc_mi355x_palettized_bytes(int datatype, size_t count, int qbits, int number_in_blocks);
 /* Opt-in fusion for callers that know a CONVOLUTION_FORWARD's only consumer is the RELU_FORWARD behind it (the reference's graphs run
  * that ReLU in place, test/int/nnc/graph.vgg.d.tests.c:80): cmd.algorithm = NNC_MI355X_CONV_ALGO_FUSE_RELU | a, a = 0 .. 2 or 0xff for the
  * backend's choice, makes the command write max(0, conv + bias); the RELU_FORWARD may then be dropped.  Applied in the epilogue of the

@@ -29,7 +29,7 @@ if [ -f $ROOT/tests/emu/_build/libnnc_mi355x_emu.so ]; then
 fi
 # 3. the reference's int tests
 mkdir -p $OUT/int
-TESTS=${TESTS:-"cudnn cublas sgd tensor schedule datatype transform loss reduce adam rmsprop gelu leaky_relu swish smooth_l1 compare index pad upsample lamb random concat cnnp.core dynamic.graph parallel nccl nms roi_align compression lstm"}  # graph.vgg.d / symbolic.graph.vgg.d have no test case without libpng (their bodies are #ifdef HAVE_LIBPNG): nothing to link
+TESTS=${TESTS:-"cudnn cublas sgd tensor schedule datatype transform loss reduce adam rmsprop gelu leaky_relu swish smooth_l1 compare index pad upsample lamb random concat cnnp.core dynamic.graph parallel nccl nms roi_align compression lstm palettize"}  # graph.vgg.d / symbolic.graph.vgg.d have no test case without libpng (their bodies are #ifdef HAVE_LIBPNG): nothing to link
 TFLAGS="-O2 -fopenmp -I$REF/lib -I$REF/test -DHAVE_SSE2 -DHAVE_PTHREAD -DUSE_OPENMP -DHAVE_CUDA -DHAVE_CUDNN -DHAVE_NCCL -Wno-everything"
 # exact-name case selection for the reference's runner (oracle/case_exact.c)
 $CC -O2 -fPIC -c $HERE/case_exact.c -o $OUT/int/case_exact.o

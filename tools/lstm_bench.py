@@ -44,8 +44,9 @@ for (T, B, I, H, layers, bidir) in SHAPES:
     flops = sum(2.0 * T * B * 4 * H * ((I if l == 0 else D * H) + H) * D for l in range(layers))
     ok = lambda r: r == 0 or sys.exit("command returned %d" % r)
     steps = T * layers * D
-    for mode in (1, 0):
+    for mode, rows in ((1, 1), (1, 0), (0, 0)):  # rows of the batch per workgroup (H <= 128) / hidden units per workgroup with a hand-over per step / a launch per step
         L.tune_set("LSTM_PERSISTENT", mode)
+        L.tune_set("LSTM_ROWS", rows)
         f_ms = timed(lambda: ok(L.cmd_exec(fcmd, nnc.NO_HINT, 0, [x, None, hx, cx, w], [y, hy, cy, r], s)), 3)
         fk = L.dll.nnc_mi355x_last_kernel_name().decode()
         b_ms = timed(lambda: ok(L.cmd_exec(bcmd, nnc.NO_HINT, 0, [dy, None, None, None, x, None, hx, cx, w, y, hy, cy, r], [dx, None, dhx, dcx, dw], s)), 3)
@@ -53,3 +54,4 @@ for (T, B, I, H, layers, bidir) in SHAPES:
         print("T %4d B %4d in %4d hidden %4d layers %d %s: forward %8.3f ms (%5.1f us per step, %6.2f TFLOP/s, %s)   backward %8.3f ms (%5.1f us per step, %6.2f TFLOP/s, %s)"
               % (T, B, I, H, layers, "both directions" if bidir else "one direction  ", f_ms, f_ms * 1e3 / steps, flops / f_ms / 1e9, fk, b_ms, b_ms * 1e3 / steps, 3 * flops / b_ms / 1e9, bk), flush=True)
     L.tune_set("LSTM_PERSISTENT", 1)
+    L.tune_set("LSTM_ROWS", 1)
