@@ -10,12 +10,18 @@
 //   every block but the last is full; the last one's index bytes stop after the last whole group the quantiser wrote (2 elements for 4 bits, 8 for 5 and 7,
 //   4 for 6, 1 for 8), and every block's stride uses the reference's integer divisions (number_in_blocks / 8 * 5, ...), whatever number_in_blocks is.
 //
-// This is HBM-bound byte work -- q / 8 bytes read and 2 / 4 / 8 bytes written per element -- so the kernels are about the store side:
-//   * a lane owns a GROUP of eight consecutive elements: q consecutive index bytes in, 16 / 32 / 64 consecutive bytes out (16-byte stores), consecutive lanes
-//     consecutive groups, so a wave reads one contiguous run of index bytes and writes one contiguous run of values;
-//   * blocks of at least 2048 elements (a group for every lane of a workgroup) and PALETTE_LDS_REUSE uses per palette entry stage the palette in LDS once
-//     per workgroup (grid: block x chunk of its groups); smaller blocks (the reference's tests use 128 elements with up to 256-entry palettes: most entries
-//     are never looked up) read the palette through the vector cache instead -- one flat grid over all groups, no workgroup idles on a 16-group block.
+// This is HBM-bound byte work -- q / 8 bytes read and 2 / 4 / 8 bytes written per element, plus a palette per block -- so the kernel is about the store side:
+//   * a TASK is a 16-byte share of a group of eight consecutive elements (8 halves, 4 floats, 2 doubles): ONE 16-byte store per lane, consecutive lanes
+//     consecutive 16 bytes whatever the element size; the group's index bytes arrive in ONE 8-byte load (gfx950 global loads need no alignment; the lanes
+//     that share a group load the same bytes), get byte-swapped into a 64-bit big-endian window and cost a constant shift + mask per element;
+//   * a lane has four tasks' index loads in flight before it looks anything up;
+//   * palettes are staged in LDS: a workgroup expands 1024 tasks -- a chunk of one large block, or a run of consecutive small blocks with their palettes side
+//     by side (the reference's tests use 128-element blocks: up to 64 of them per workgroup), so no workgroup idles on a 16-group block and no look-up goes
+//     to the vector cache.
+// Measured on the MI355X (tools/palette_bench.py; profiles/r05_v9_palette_bench.txt = the first form of this file, r05_v10_palette_bench.txt = this one), 235 M
+// elements: 4.3 - 5.6 TB/s of algorithmic traffic = 0.54 - 0.70 of the 8 TB/s peak (the guide's achievable figure is 6.3).  On the way: byte-by-byte index loads
+// with a 64-bit shift per byte + one block per workgroup or the palette through the vector cache for small blocks 2.1 - 3.3 TB/s; the 8-byte load alone 3.1 - 5.7
+// (small blocks still slow); runs of blocks per workgroup 3.8 - 5.6 (floats low: a lane wrote 32 bytes as two stores 32 bytes apart); 16-byte shares: this.
 // A command that meets a CCV_QX input runs on a dense image of it: depalettized_exec() below.
 #include "common.h"
 
@@ -23,8 +29,9 @@ namespace nnc {
 namespace {
 
 constexpr int PAL_THREADS = 256;
-constexpr int PALETTE_LDS_REUSE = 4;   // stage the palette in LDS when a block has >= this many elements per palette entry
-constexpr int PAL_GROUPS_PER_LANE = 4; // LDS form: groups a lane walks (stride PAL_THREADS) per workgroup
+constexpr int PAL_GROUPS_PER_LANE = 4; // tasks a lane takes (PAL_THREADS apart): four independent index loads in flight
+constexpr int PAL_CHUNK = PAL_THREADS * PAL_GROUPS_PER_LANE; // 16-byte shares of groups (tasks) per workgroup
+constexpr int PAL_LDS_BYTES = 16384;   // palettes a workgroup may stage: 8 runs of blocks per CU stay resident
 
 // index bytes of a FULL block, as the host's quantiser lays them out (ccv_nnc_palettize.c: the `ui0` strides of each bit width)
 __host__ __device__ __forceinline__ size_t index_bytes_per_block(const int qbits, const int nib)
@@ -38,119 +45,142 @@ __host__ __device__ __forceinline__ size_t index_bytes_per_block(const int qbits
 	}
 }
 
-// One group: up to eight elements starting at element 8 g of a block.  `idx` points at the group's first index byte, `valid` (1 .. 8) elements exist,
-// only the index bytes those elements touch are read (the stream of the tensor's last block ends with them).
-template <typename ELEM, int Q, typename LUT>
-__device__ __forceinline__ void decode_group(const unsigned char* const idx, const int valid, const LUT palette, ELEM* const out, const bool vec)
-{
+// One group: up to eight elements starting at element 8 g of a block.  `idx` points at the group's first index byte, `valid` (1 .. 8) elements exist.
+// Fast path (a full group whose eight bytes idx[0 .. 7] all lie inside the stream -- every group but the stream's last one or two): ONE 8-byte load (gfx950
+// global loads need no alignment), a byte swap, and a constant shift + mask per element.  Otherwise byte by byte, and only the index bytes the group's
+// elements touch are read (the stream of the tensor's last block ends with them).
+template <int Q>
+__device__ __forceinline__ unsigned long long group_bits(const unsigned char* const idx, const int valid, const bool whole)
+{ // the group's Q bytes as one big-endian number in the TOP 8 Q bits of the result: element j = bits [64 - (j + 1) Q, 64 - j Q)
+	if (whole) {
+		unsigned long long raw;
+		__builtin_memcpy(&raw, idx, 8);
+		return __builtin_bswap64(raw);
+	}
 	const int nbytes = valid == 8 ? Q : (valid * Q + 7) >> 3;
-	unsigned long long w = 0; // the group's Q bytes as one big-endian number: element j = bits [(7 - j) Q, (8 - j) Q)
+	unsigned long long w = 0;
 #pragma unroll
 	for (int i = 0; i < Q; i++) {
 		const unsigned long long b = i < nbytes ? idx[i] : 0;
-		w |= b << (8 * (Q - 1 - i));
+		w |= b << (8 * (7 - i));
 	}
-	ELEM v[8];
+	return w;
+}
+// A lane's share of a group: EPL = 16 / sizeof(ELEM) consecutive elements (8 halves, 4 floats, 2 doubles) -- ONE 16-byte store per lane, consecutive lanes
+// consecutive 16 bytes, whatever the element size.  `w` holds the lane's first element in its top Q bits, `valid` counts the lane's elements that exist.
+template <typename ELEM, int Q, typename LUT>
+__device__ __forceinline__ void expand_share(const unsigned long long w, const int valid, const LUT palette, ELEM* const out, const bool vec)
+{
+	constexpr int EPL = 16 / (int)sizeof(ELEM);
+	ELEM v[EPL];
 #pragma unroll
-	for (int j = 0; j < 8; j++) v[j] = palette[(unsigned)(w >> (Q * (7 - j))) & ((1u << Q) - 1)];
-	if (valid == 8 && vec) { // 16-byte stores: 1 (halves), 2 (floats), 4 (doubles) per group
+	for (int j = 0; j < EPL; j++) v[j] = palette[(unsigned)(w >> (64 - Q * (j + 1))) & ((1u << Q) - 1)];
+	if (valid == EPL && vec) {
 		typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-		union { ELEM e[8]; u32x4 q[sizeof(ELEM) / 2]; } pack;
+		union { ELEM e[EPL]; u32x4 q; } pack;
 #pragma unroll
-		for (int j = 0; j < 8; j++) pack.e[j] = v[j];
-#pragma unroll
-		for (int k = 0; k < (int)sizeof(ELEM) / 2; k++) ((u32x4*)out)[k] = pack.q[k];
+		for (int j = 0; j < EPL; j++) pack.e[j] = v[j];
+		*(u32x4*)out = pack.q;
 	} else
 #pragma unroll
-		for (int j = 0; j < 8; j++) if (j < valid) out[j] = v[j];
+		for (int j = 0; j < EPL; j++) if (j < valid) out[j] = v[j];
 }
 
 struct pal_geom_t {
 	size_t count;        // elements of the tensor
+	size_t in_len;       // bytes of the palettized stream
 	size_t block_stride; // bytes from one block to the next in the palettized stream: palette + a full block's index bytes
+	size_t blocks;
 	int nib;             // elements per block
 	int gpb;             // groups of eight per block (the last one partial when nib is not a multiple of 8)
+	int bpw;             // consecutive blocks a workgroup expands (their palettes side by side in LDS); 1 when a block has PAL_CHUNK tasks or more
 	int vec;             // out is 16-byte aligned
+	unsigned div_m;      // L / gpb for the workgroup's local group index L < 2^31 as (L * div_m) >> div_sh (round-up reciprocal)
+	int div_sh;
 };
 
-// LDS form: blockIdx.x = block, blockIdx.y = chunk of PAL_THREADS * PAL_GROUPS_PER_LANE groups of it.
+// blockIdx.x = a run of g.bpw consecutive blocks, blockIdx.y = chunk of PAL_CHUNK tasks (more than one chunk only when bpw == 1).  The palettes of the run
+// are staged in LDS once; a lane then takes PAL_GROUPS_PER_LANE tasks, PAL_THREADS apart -- all its index loads first, then the look-ups and the stores.
 template <typename ELEM, int Q>
-__global__ void __launch_bounds__(PAL_THREADS) depalettize_lds_kernel(const unsigned char* const in, ELEM* const out, const pal_geom_t g)
+__global__ void __launch_bounds__(PAL_THREADS) depalettize_kernel(const unsigned char* const in, ELEM* const out, const pal_geom_t g)
 {
-	__shared__ ELEM palette[1 << Q];
-	const size_t block = blockIdx.x;
-	const unsigned char* const base = in + block * g.block_stride;
-	for (int i = threadIdx.x; i < (1 << Q); i += PAL_THREADS) palette[i] = ((const ELEM*)base)[i];
+	__shared__ __attribute__((aligned(16))) unsigned char lds[PAL_LDS_BYTES];
+	ELEM* const palette = (ELEM*)lds; // [bpw][1 << Q]
+	const size_t block0 = (size_t)blockIdx.x * (size_t)g.bpw;
+	const int nblk = g.blocks - block0 < (size_t)g.bpw ? (int)(g.blocks - block0) : g.bpw;
+	for (int i = threadIdx.x; i < nblk << Q; i += PAL_THREADS)
+		palette[i] = ((const ELEM*)(in + (block0 + (size_t)(i >> Q)) * g.block_stride))[i & ((1 << Q) - 1)];
 	__syncthreads();
-	const size_t e0 = block * (size_t)g.nib;
-	const size_t left = g.count - e0;
-	const int n = left < (size_t)g.nib ? (int)left : g.nib; // elements of this block
-	const int groups = (n + 7) >> 3;
-	const unsigned char* const idx = base + sizeof(ELEM) * (1 << Q);
-	const int g0 = blockIdx.y * (PAL_THREADS * PAL_GROUPS_PER_LANE);
+	constexpr int EPL = 16 / (int)sizeof(ELEM), LPG = 8 / EPL; // elements per lane, lanes per group (1 / 2 / 4)
+	const int t0 = blockIdx.y * PAL_CHUNK;
+	unsigned long long w[PAL_GROUPS_PER_LANE];
+	int valid[PAL_GROUPS_PER_LANE], slot[PAL_GROUPS_PER_LANE];
+	size_t first[PAL_GROUPS_PER_LANE]; // the lane's first element in the tensor
 #pragma unroll
 	for (int k = 0; k < PAL_GROUPS_PER_LANE; k++) {
-		const int gi = g0 + k * PAL_THREADS + (int)threadIdx.x;
-		if (gi >= groups) break;
-		const int valid = n - gi * 8 < 8 ? n - gi * 8 : 8;
-		decode_group<ELEM, Q>(idx + (size_t)gi * Q, valid, palette, out + e0 + (size_t)gi * 8, g.vec && (g.nib & 7) == 0);
+		const int t = t0 + k * PAL_THREADS + (int)threadIdx.x; // the task's index within the run: group t / LPG, share t % LPG
+		const int l = t / LPG, sub = t - l * LPG;
+		const int b = g.bpw == 1 ? 0 : (int)(((unsigned long long)(unsigned)l * g.div_m) >> g.div_sh);
+		const int gi = l - b * g.gpb;
+		valid[k] = 0; w[k] = 0; slot[k] = b << Q; first[k] = 0;
+		if (b < nblk) {
+			const size_t block = block0 + (size_t)b, e0 = block * (size_t)g.nib, left = g.count - e0;
+			const int n = left < (size_t)g.nib ? (int)left : g.nib; // elements of this block
+			const int in_group = n - gi * 8 < 8 ? n - gi * 8 : 8;   // elements of the group (<= 0: past the block's end)
+			const int mine = in_group - sub * EPL;
+			if (mine > 0) {
+				valid[k] = mine < EPL ? mine : EPL;
+				first[k] = e0 + (size_t)gi * 8 + sub * EPL;
+				const size_t off = block * g.block_stride + sizeof(ELEM) * (1 << Q) + (size_t)gi * Q;
+				w[k] = group_bits<Q>(in + off, in_group, in_group == 8 && off + 8 <= g.in_len) << (Q * EPL * sub); // (the lanes of a group load the same bytes: one request)
+			}
+		}
 	}
-}
-
-// Flat form: one lane per group over the whole tensor, the palette read through the vector cache.
-template <typename ELEM, int Q>
-__global__ void __launch_bounds__(PAL_THREADS) depalettize_flat_kernel(const unsigned char* const in, ELEM* const out, const pal_geom_t g, const size_t total_groups)
-{
-	const size_t stride = (size_t)gridDim.x * PAL_THREADS;
-	for (size_t G = (size_t)blockIdx.x * PAL_THREADS + threadIdx.x; G < total_groups; G += stride) {
-		const size_t block = G / (size_t)g.gpb;
-		const int gi = (int)(G - block * (size_t)g.gpb);
-		const size_t e0 = block * (size_t)g.nib;
-		const size_t left = g.count - e0;
-		const int n = left < (size_t)g.nib ? (int)left : g.nib;
-		if (gi * 8 >= n) continue; // (groups past the end of the tensor's last block)
-		const int valid = n - gi * 8 < 8 ? n - gi * 8 : 8;
-		const unsigned char* const base = in + block * g.block_stride;
-		decode_group<ELEM, Q>(base + sizeof(ELEM) * (1 << Q) + (size_t)gi * Q, valid, (const ELEM*)base, out + e0 + (size_t)gi * 8, g.vec && (g.nib & 7) == 0);
-	}
+#pragma unroll
+	for (int k = 0; k < PAL_GROUPS_PER_LANE; k++)
+		if (valid[k]) expand_share<ELEM, Q>(w[k], valid[k], palette + slot[k], out + first[k], g.vec && (g.nib & 7) == 0);
 }
 
 template <typename ELEM, int Q>
-int depalettize_launch(const unsigned char* const in, ELEM* const out, const size_t count, const int nib, hipStream_t stream)
+int depalettize_launch(const unsigned char* const in, const size_t in_len, ELEM* const out, const size_t count, const int nib, hipStream_t stream)
 {
 	pal_geom_t g;
 	g.count = count;
+	g.in_len = in_len;
 	g.nib = nib;
 	g.gpb = (nib + 7) / 8;
 	g.block_stride = sizeof(ELEM) * ((size_t)1 << Q) + index_bytes_per_block(Q, nib);
 	g.vec = (((uintptr_t)out) & 15) == 0;
-	const size_t blocks = (count + (size_t)nib - 1) / (size_t)nib;
-	if ((size_t)nib >= (size_t)PALETTE_LDS_REUSE << Q && g.gpb >= PAL_THREADS && blocks <= 0x7fffffffu) { // (a block must also give every lane of the workgroup a group)
-		const int chunk = PAL_THREADS * PAL_GROUPS_PER_LANE;
-		const unsigned chunks = (unsigned)((g.gpb + chunk - 1) / chunk);
-		if (chunks <= 65535u) {
-			hipLaunchKernelGGL((depalettize_lds_kernel<ELEM, Q>), dim3((unsigned)blocks, chunks), dim3(PAL_THREADS), 0, stream, in, out, g);
-			HIP_ENFORCE(hipGetLastError());
-			note_kernel("depalettize_lds");
-			return CCV_NNC_EXEC_SUCCESS;
-		}
-	}
-	const size_t total_groups = blocks * (size_t)g.gpb;
-	hipLaunchKernelGGL((depalettize_flat_kernel<ELEM, Q>), dim3(grid_for(total_groups, PAL_THREADS)), dim3(PAL_THREADS), 0, stream, in, out, g, total_groups);
+	g.blocks = (count + (size_t)nib - 1) / (size_t)nib;
+	// small blocks share a workgroup: as many as give every lane its PAL_GROUPS_PER_LANE groups, within the LDS the palettes may take
+	constexpr int LPG = (int)sizeof(ELEM) / 2; // lanes per group (a lane stores 16 bytes)
+	long bpw = PAL_CHUNK / ((long)g.gpb * LPG);
+	const long fit = PAL_LDS_BYTES / (long)(sizeof(ELEM) << Q);
+	if (bpw > fit) bpw = fit;
+	if (bpw < 1) bpw = 1;
+	g.bpw = (int)bpw;
+	int sh = 0;
+	while ((1ll << sh) < g.gpb) sh++;
+	g.div_sh = 31 + sh; // the reciprocal of gpb: m = ceil(2^(31 + s) / gpb), 2^s >= gpb; exact for the 31-bit numerators a run's local index has
+	g.div_m = (unsigned)(((1ull << g.div_sh) + (unsigned long long)g.gpb - 1) / (unsigned long long)g.gpb);
+	const size_t runs = (g.blocks + (size_t)g.bpw - 1) / (size_t)g.bpw;
+	const size_t chunks = g.bpw == 1 ? ((size_t)g.gpb * LPG + PAL_CHUNK - 1) / PAL_CHUNK : 1;
+	if (runs > 0x7fffffffu || chunks > 65535u) return CCV_NNC_EXEC_INVALID; // (2^31 runs of >= 1024 groups: no tensor is that large)
+	hipLaunchKernelGGL((depalettize_kernel<ELEM, Q>), dim3((unsigned)runs, (unsigned)chunks), dim3(PAL_THREADS), 0, stream, in, out, g);
 	HIP_ENFORCE(hipGetLastError());
-	note_kernel("depalettize_flat");
+	note_kernel("depalettize");
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
 template <typename ELEM>
-int depalettize_bits(const unsigned char* const in, ELEM* const out, const size_t count, const int qbits, const int nib, hipStream_t stream)
+int depalettize_bits(const unsigned char* const in, const size_t in_len, ELEM* const out, const size_t count, const int qbits, const int nib, hipStream_t stream)
 {
 	switch (qbits) {
-		case 4: return depalettize_launch<ELEM, 4>(in, out, count, nib, stream);
-		case 5: return depalettize_launch<ELEM, 5>(in, out, count, nib, stream);
-		case 6: return depalettize_launch<ELEM, 6>(in, out, count, nib, stream);
-		case 7: return depalettize_launch<ELEM, 7>(in, out, count, nib, stream);
-		case 8: return depalettize_launch<ELEM, 8>(in, out, count, nib, stream);
+		case 4: return depalettize_launch<ELEM, 4>(in, in_len, out, count, nib, stream);
+		case 5: return depalettize_launch<ELEM, 5>(in, in_len, out, count, nib, stream);
+		case 6: return depalettize_launch<ELEM, 6>(in, in_len, out, count, nib, stream);
+		case 7: return depalettize_launch<ELEM, 7>(in, in_len, out, count, nib, stream);
+		case 8: return depalettize_launch<ELEM, 8>(in, in_len, out, count, nib, stream);
 	}
 	return CCV_NNC_EXEC_INVALID;
 }
@@ -173,9 +203,9 @@ int depalettize(const void* const input, const int datatype, const size_t input_
 	hipStream_t stream = stream_of(ctx);
 	const unsigned char* const in = (const unsigned char*)input;
 	switch (CCV_GET_DATA_TYPE(datatype)) { // the values are moved, never interpreted: 2-, 4- and 8-byte words
-		case CCV_16F: return depalettize_bits<unsigned short>(in, (unsigned short*)output, output_length, qbits, nib, stream);
-		case CCV_32F: return depalettize_bits<unsigned int>(in, (unsigned int*)output, output_length, qbits, nib, stream);
-		case CCV_64F: return depalettize_bits<unsigned long long>(in, (unsigned long long*)output, output_length, qbits, nib, stream);
+		case CCV_16F: return depalettize_bits<unsigned short>(in, input_length, (unsigned short*)output, output_length, qbits, nib, stream);
+		case CCV_32F: return depalettize_bits<unsigned int>(in, input_length, (unsigned int*)output, output_length, qbits, nib, stream);
+		case CCV_64F: return depalettize_bits<unsigned long long>(in, input_length, (unsigned long long*)output, output_length, qbits, nib, stream);
 	}
 	return CCV_NNC_EXEC_INVALID;
 }
