@@ -242,7 +242,7 @@ def lstm_config(args):
            # the row is bound by the hand-over between the workgroups of the one-launch kernel once per time step, not by a pipe: the
            # line reports its algorithmic rate against the fp32 matrix peak for scale
            "roofline": {"bound": "mfma", "achieved": h["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": h["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "kernel": "lstm_rows_forw_kernel / lstm_rows_back_kernel (hidden size <= 128: a workgroup per two batch rows, R in registers) + the batched input contractions", "launches": None, "avg_ms": None},
+                        "kernel": "lstm_rows_forw_kernel / lstm_rows_back_kernel (hidden size <= 128: a workgroup per batch row, R in registers) + the batched input contractions", "launches": None, "avg_ms": None},
            "cpu_baseline": None}
     out["config"]["cpu_baseline_note"] = "the reference has no CPU LSTM (lib/nnc/cmd/rnn: GPU backend only): nothing to time beside it"
     emit(out)

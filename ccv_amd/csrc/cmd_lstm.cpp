@@ -79,6 +79,10 @@ constexpr int LS_ROWS = 16; // batch rows per workgroup (4 groups of 4: a lane k
 constexpr int LS_KT = 64;   // the reduction index is staged through LDS in tiles of this many
 
 __device__ __forceinline__ float lstm_sigmoid(const float x) { return 1.f / (1.f + expf(-x)); }
+// The rows kernels' step is a chain of dependent latencies (LDS round trips, barriers, the gate arithmetic): there the activations are the hardware's 2^x and
+// 1 / x (1 ulp each; sigmoid within ~2e-7, tanh = 2 sigmoid(2x) - 1 within ~2.5e-7 absolute; saturating to 0 / 1 / -1 through inf and 0 without a branch).
+__device__ __forceinline__ float lstm_fast_sigmoid(const float x) { return nnc_fast_rcp(1.f + nnc_fast_exp2(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float lstm_fast_tanh(const float x) { return 2.f * nnc_fast_rcp(1.f + nnc_fast_exp2(-2.8853900817779268f * x)) - 1.f; }
 
 // acc[g][r] = sum_k a[(row0 + 4 * grp + r) * lda + k] * mt[k * ldm + g * gstride + col] for NG column groups: the product both step kernels share.
 template <int NG>
@@ -353,12 +357,15 @@ __global__ void __launch_bounds__(256) lstm_seq_back_kernel(const lstm_seq_back_
 // state back into LDS.  Backward: thread (r, u) turns its state gradients into the four gate gradients (tape loads issued a step ahead), thread (q, k) holds
 // column k of gate q's block of R and reduces that block's 128 terms of dh' = dG R, the four partial sums meet in LDS.
 // Cost per step ~ the LDS broadcast of the state to eight waves (H x 512 bytes per wave) -- the register-resident multiply-adds run beside it.
-constexpr int LS_RB = 2;
-typedef float lstm_f2 __attribute__((ext_vector_type(2))); // the two rows of a workgroup in an aligned register pair: v_pk_fma_f32
-template <int HT>
+// LS_RB = 1 (round 5, second form; hidden sizes in multiples of four): ONE batch row per workgroup.  The step's cost is the LDS broadcast of the state to the
+// eight waves (every lane of a wave reads the same 16 bytes: the LDS charges the full 64 lanes' width for it) and the multiply-adds behind it, both per ROW of the
+// workgroup -- so a row per workgroup halves the step's latency and doubles the workgroups (the IMDB shape's 64 rows: 64 of the 256 CUs instead of 32); the packed
+// multiply-add then pairs two consecutive k of the one row (R's row is already laid out in pairs).
+typedef float lstm_f2 __attribute__((ext_vector_type(2))); // an aligned register pair: v_pk_fma_f32
+template <int HT, int LS_RB>
 __global__ void __launch_bounds__(4 * HT) lstm_rows_forw_kernel(const lstm_seq_t a)
 {
-	__shared__ __attribute__((aligned(16))) float htile[HT][LS_RB];      // the state before the step, k-major: one 8-byte broadcast read per k
+	__shared__ __attribute__((aligned(16))) float htile[HT][LS_RB];      // the state before the step, k-major: one 8-byte broadcast read per k (LS_RB = 2) / 16 bytes per four k (LS_RB = 1)
 	__shared__ float pre[LS_RB][4 * HT + 4];
 	const int tid = threadIdx.x, H = a.H, B = a.B, N4 = 4 * H, row0 = blockIdx.x * LS_RB;
 	const size_t BH = (size_t)B * H;
@@ -378,24 +385,43 @@ __global__ void __launch_bounds__(4 * HT) lstm_rows_forw_kernel(const lstm_seq_t
 	__syncthreads();
 	if (mine) htile[u][rr] = hst;
 	__syncthreads();
-	for (int s = 0; s < a.T; s++) {
+	float gnx[4] = { 0.f, 0.f, 0.f, 0.f };
+	auto load_gin = [&](const int s) {
 		const int t = a.dir ? a.T - 1 - s : s;
-		float gin[4] = { 0.f, 0.f, 0.f, 0.f };
-		if (mine) { // the input half: in flight during the products
+		if (mine && s < a.T) {
 			const float* const gr = a.gx + ((size_t)t * B + b) * N4 + u;
 #pragma unroll
-			for (int g = 0; g < 4; g++) gin[g] = gr[g * H];
+			for (int g = 0; g < 4; g++) gnx[g] = gr[g * H];
 		}
-		lstm_f2 acc4[4] = { { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f } }; // four chains: a packed multiply-add waits for its predecessor otherwise
+	};
+	load_gin(0);
+	for (int s = 0; s < a.T; s++) {
+		const int t = a.dir ? a.T - 1 - s : s;
+		float gin[4];
 #pragma unroll
-		for (int k2 = 0; k2 < HT / 2; k2++) {
-			const float4 h4 = *(const float4*)&htile[2 * k2][0]; // rows 0, 1 of k = 2 k2 and of k = 2 k2 + 1
-			const lstm_f2 h0 = { h4.x, h4.y }, h1 = { h4.z, h4.w };
-			NNC_PK_FMA_LO(acc4[(2 * k2) & 3], h0, rreg[k2]);
-			NNC_PK_FMA_HI(acc4[(2 * k2 + 1) & 3], h1, rreg[k2]);
+		for (int g = 0; g < 4; g++) gin[g] = gnx[g];
+		load_gin(s + 1); // the input half of the NEXT step (a ring of four steps ahead, unrolled, measured slower: profiles/r05_v10_lstm_forms.txt)
+		lstm_f2 acc4[4] = { { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f } }; // four chains: a packed multiply-add waits for its predecessor otherwise
+		if (LS_RB == 2) {
+#pragma unroll
+			for (int k2 = 0; k2 < HT / 2; k2++) {
+				const float4 hh = ((const float4*)&htile[0][0])[k2]; // rows 0, 1 of k = 2 k2 and of k = 2 k2 + 1
+				const lstm_f2 h0 = { hh.x, hh.y }, h1 = { hh.z, hh.w };
+				NNC_PK_FMA_LO(acc4[(2 * k2) & 3], h0, rreg[k2]);
+				NNC_PK_FMA_HI(acc4[(2 * k2 + 1) & 3], h1, rreg[k2]);
+			}
+			const lstm_f2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+			if (tid < N4) { pre[0][tid] = acc[0]; pre[LS_RB - 1][tid] = acc[1]; }
+		} else {
+#pragma unroll
+			for (int k4 = 0; k4 < HT / 4; k4++) { // the one row's state at k = 4 k4 .. 4 k4 + 3; a register pair of R = two consecutive k
+				const float4 hh = ((const float4*)&htile[0][0])[k4];
+				acc4[(2 * k4) & 3] += lstm_f2{ hh.x, hh.y } * rreg[2 * k4];
+				acc4[(2 * k4 + 1) & 3] += lstm_f2{ hh.z, hh.w } * rreg[2 * k4 + 1];
+			}
+			const lstm_f2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+			if (tid < N4) pre[0][tid] = acc[0] + acc[1];
 		}
-		const lstm_f2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-		if (tid < N4) { pre[0][tid] = acc[0]; pre[1][tid] = acc[1]; }
 		NNC_LDS_BARRIER();
 		if (mine) {
 			float* const gates = a.rsv ? a.rsv + a.slot0 + (size_t)s * a.S * BH : 0;
@@ -404,9 +430,9 @@ __global__ void __launch_bounds__(4 * HT) lstm_rows_forw_kernel(const lstm_seq_t
 				float p4[4];
 #pragma unroll
 				for (int g = 0; g < 4; g++) p4[g] = pre[rr][g * H + u] + gin[g] + bias[g];
-				const float i = lstm_sigmoid(p4[0]), f = lstm_sigmoid(p4[1]), g = tanhf(p4[2]), o = lstm_sigmoid(p4[3]);
+				const float i = lstm_fast_sigmoid(p4[0]), f = lstm_fast_sigmoid(p4[1]), g = lstm_fast_tanh(p4[2]), o = lstm_fast_sigmoid(p4[3]);
 				cst = f * cst + i * g;
-				const float tc = tanhf(cst);
+				const float tc = lstm_fast_tanh(cst);
 				hnew = o * tc;
 				a.y[((size_t)t * B + b) * a.ldy + u] = hnew;
 				if (gates) { gates[e] = i; gates[BH + e] = f; gates[2 * BH + e] = g; gates[3 * BH + e] = o; gates[4 * BH + e] = tc; }
@@ -423,7 +449,7 @@ __global__ void __launch_bounds__(4 * HT) lstm_rows_forw_kernel(const lstm_seq_t
 	if (mine) { if (a.hy) a.hy[e] = hst; if (a.cy) a.cy[e] = cst; }
 }
 
-template <int HT>
+template <int HT, int LS_RB>
 __global__ void __launch_bounds__(4 * HT) lstm_rows_back_kernel(const lstm_seq_back_t a)
 {
 	__shared__ __attribute__((aligned(16))) float dgt[4 * HT][LS_RB];    // the step's gate gradients, column-major: one 8-byte broadcast read per column
@@ -475,14 +501,26 @@ __global__ void __launch_bounds__(4 * HT) lstm_rows_back_kernel(const lstm_seq_b
 		NNC_LDS_BARRIER();
 		lstm_f2 acc4[4] = { { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f } };
 		const int nb = tid < N4 ? q * H : 0;
+		if (LS_RB == 2) {
 #pragma unroll
-		for (int i2 = 0; i2 < HT / 2; i2++) { // (nb + i < 3 H + HT <= 4 HT; past the block's H terms the coefficient is zero)
-			const lstm_f2 d0 = *(const lstm_f2*)&dgt[nb + 2 * i2][0], d1 = *(const lstm_f2*)&dgt[nb + 2 * i2 + 1][0];
-			NNC_PK_FMA_LO(acc4[(2 * i2) & 3], d0, rreg[i2]);
-			NNC_PK_FMA_HI(acc4[(2 * i2 + 1) & 3], d1, rreg[i2]);
+			for (int i2 = 0; i2 < HT / 2; i2++) { // (nb + i < 3 H + HT <= 4 HT; past the block's H terms the coefficient is zero)
+				const lstm_f2 d0 = *(const lstm_f2*)&dgt[nb + 2 * i2][0], d1 = *(const lstm_f2*)&dgt[nb + 2 * i2 + 1][0];
+				NNC_PK_FMA_LO(acc4[(2 * i2) & 3], d0, rreg[i2]);
+				NNC_PK_FMA_HI(acc4[(2 * i2 + 1) & 3], d1, rreg[i2]);
+			}
+			const lstm_f2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+			if (tid < N4) { part[q][0][kc] = acc[0]; part[q][LS_RB - 1][kc] = acc[1]; }
+		} else {
+			const float4* const d4 = (const float4*)&dgt[nb][0]; // (H in multiples of four: 16-byte aligned)
+#pragma unroll
+			for (int i4 = 0; i4 < HT / 4; i4++) { // the one row's gate gradients of columns nb + 4 i4 .. + 3; a register pair of R = two consecutive rows of the block
+				const float4 dd = d4[i4];
+				acc4[(2 * i4) & 3] += lstm_f2{ dd.x, dd.y } * rreg[2 * i4];
+				acc4[(2 * i4 + 1) & 3] += lstm_f2{ dd.z, dd.w } * rreg[2 * i4 + 1];
+			}
+			const lstm_f2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+			if (tid < N4) part[q][0][kc] = acc[0] + acc[1];
 		}
-		const lstm_f2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-		if (tid < N4) { part[q][0][kc] = acc[0]; part[q][1][kc] = acc[1]; }
 		NNC_LDS_BARRIER();
 		if (mine) {
 			const float v = (part[0][rr][u] + part[1][rr][u]) + (part[2][rr][u] + part[3][rr][u]);
@@ -491,6 +529,13 @@ __global__ void __launch_bounds__(4 * HT) lstm_rows_back_kernel(const lstm_seq_b
 	}
 	if (mine) { if (a.dhx) a.dhx[e] = dh; if (a.dcx) a.dcx[e] = dc; }
 }
+
+// Measured and not in the tree (profiles/r05_v10_lstm_forms.txt, the IMDB shape, forward / backward per launch of 512 steps): the one-row form above 0.556 / 0.746 ms;
+// the reduction split eight ways over lanes with the partial sums meeting in LDS and one gate column per thread for the activation (three barriers per
+// step) 0.628 / 0.893; split over the four lanes of a unit with two lane exchanges, the state double-buffered, one barrier per step 0.721 / 1.340 -- fewer LDS
+// cycles each time, a longer chain of dependent round trips each time: the step is a latency chain, not an LDS-throughput problem; the input half loaded
+// four steps ahead through an unrolled register ring 1.245 forward.  What did pay: a row per workgroup instead of two (1.026 / 1.670 -> 0.680 / 0.752: half
+// the per-step work on the chain, twice the workgroups) and the hardware's 2^x and 1 / x for the activations (0.659 -> 0.556 forward).
 
 // One step of one pseudo-layer: the four gates' recurrent products + the gate arithmetic.  direct = no projection (hout is the next state, P == H).
 __global__ void __launch_bounds__(256) lstm_step_forw_kernel(const float* const gx, const float* const rt, const float* const bw, const float* const br, const float* const hprev, const float* const cprev,
@@ -785,11 +830,19 @@ static int _lstm_forw(EXEC_ARGS_L)
 			if (rows) { // one launch for the whole sequence, nothing passes between its workgroups (lstm_rows_forw_kernel)
 				const lstm_seq_t a = { gx, Rc, bw, hx ? hx->data.f32 + (size_t)p * g.BH() : 0, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, yl + (size_t)d * g.P, hy ? hy->data.f32 + (size_t)p * g.BH() : 0, cy ? cy->data.f32 + (size_t)p * g.BH() : 0,
 					rsv, 0, lens, 0, g.T, g.B, g.H, d, DP, g.S, rsv ? g.slot(p, 0, 0) : 0, rsv && g.T > 1 ? g.cslot(p, 0) : 0 };
-				const dim3 rows_grid((g.B + LS_RB - 1) / LS_RB);
-				if (g.H <= 32) hipLaunchKernelGGL(lstm_rows_forw_kernel<32>, rows_grid, dim3(128), 0, stream, a);
-				else if (g.H <= 64) hipLaunchKernelGGL(lstm_rows_forw_kernel<64>, rows_grid, dim3(256), 0, stream, a);
-				else if (g.H <= 96) hipLaunchKernelGGL(lstm_rows_forw_kernel<96>, rows_grid, dim3(384), 0, stream, a);
-				else hipLaunchKernelGGL(lstm_rows_forw_kernel<128>, rows_grid, dim3(512), 0, stream, a);
+				const int rb = (g.H & 3) == 0 && tune(TUNE_LSTM_ROWS) != 2 ? 1 : 2; // rows per workgroup (tuning key LSTM_ROWS = 2: the two-row form for every size)
+				const dim3 rows_grid((g.B + rb - 1) / rb);
+				if (rb == 1) {
+					if (g.H <= 32) hipLaunchKernelGGL((lstm_rows_forw_kernel<32, 1>), rows_grid, dim3(128), 0, stream, a);
+					else if (g.H <= 64) hipLaunchKernelGGL((lstm_rows_forw_kernel<64, 1>), rows_grid, dim3(256), 0, stream, a);
+					else if (g.H <= 96) hipLaunchKernelGGL((lstm_rows_forw_kernel<96, 1>), rows_grid, dim3(384), 0, stream, a);
+					else hipLaunchKernelGGL((lstm_rows_forw_kernel<128, 1>), rows_grid, dim3(512), 0, stream, a);
+				} else {
+					if (g.H <= 32) hipLaunchKernelGGL((lstm_rows_forw_kernel<32, 2>), rows_grid, dim3(128), 0, stream, a);
+					else if (g.H <= 64) hipLaunchKernelGGL((lstm_rows_forw_kernel<64, 2>), rows_grid, dim3(256), 0, stream, a);
+					else if (g.H <= 96) hipLaunchKernelGGL((lstm_rows_forw_kernel<96, 2>), rows_grid, dim3(384), 0, stream, a);
+					else hipLaunchKernelGGL((lstm_rows_forw_kernel<128, 2>), rows_grid, dim3(512), 0, stream, a);
+				}
 				HIP_ENFORCE(hipGetLastError());
 				note_kernel("lstm_rows_forw");
 				continue;
@@ -928,11 +981,19 @@ static int _lstm_back(EXEC_ARGS_L)
 			if (rows) { // one launch for the whole sequence, nothing passes between its workgroups (lstm_rows_back_kernel)
 				const lstm_seq_back_t a = { Rc, rsv, cx ? cx->data.f32 + (size_t)p * g.BH() : 0, dyl + (size_t)d * g.P, dhy ? dhy->data.f32 + (size_t)p * g.BH() : 0, dcy ? dcy->data.f32 + (size_t)p * g.BH() : 0,
 					dG, dhx ? dhx->data.f32 + (size_t)p * g.BH() : 0, dcx ? dcx->data.f32 + (size_t)p * g.BH() : 0, 0, lens, 0, g.T, g.B, g.H, d, DP, g.S, g.slot(p, 0, 0), g.T > 1 ? g.cslot(p, 0) : 0 };
-				const dim3 rows_grid((g.B + LS_RB - 1) / LS_RB);
-				if (g.H <= 32) hipLaunchKernelGGL(lstm_rows_back_kernel<32>, rows_grid, dim3(128), 0, stream, a);
-				else if (g.H <= 64) hipLaunchKernelGGL(lstm_rows_back_kernel<64>, rows_grid, dim3(256), 0, stream, a);
-				else if (g.H <= 96) hipLaunchKernelGGL(lstm_rows_back_kernel<96>, rows_grid, dim3(384), 0, stream, a);
-				else hipLaunchKernelGGL(lstm_rows_back_kernel<128>, rows_grid, dim3(512), 0, stream, a);
+				const int rb = (g.H & 3) == 0 && tune(TUNE_LSTM_ROWS) != 2 ? 1 : 2; // (as the forward command)
+				const dim3 rows_grid((g.B + rb - 1) / rb);
+				if (rb == 1) {
+					if (g.H <= 32) hipLaunchKernelGGL((lstm_rows_back_kernel<32, 1>), rows_grid, dim3(128), 0, stream, a);
+					else if (g.H <= 64) hipLaunchKernelGGL((lstm_rows_back_kernel<64, 1>), rows_grid, dim3(256), 0, stream, a);
+					else if (g.H <= 96) hipLaunchKernelGGL((lstm_rows_back_kernel<96, 1>), rows_grid, dim3(384), 0, stream, a);
+					else hipLaunchKernelGGL((lstm_rows_back_kernel<128, 1>), rows_grid, dim3(512), 0, stream, a);
+				} else {
+					if (g.H <= 32) hipLaunchKernelGGL((lstm_rows_back_kernel<32, 2>), rows_grid, dim3(128), 0, stream, a);
+					else if (g.H <= 64) hipLaunchKernelGGL((lstm_rows_back_kernel<64, 2>), rows_grid, dim3(256), 0, stream, a);
+					else if (g.H <= 96) hipLaunchKernelGGL((lstm_rows_back_kernel<96, 2>), rows_grid, dim3(384), 0, stream, a);
+					else hipLaunchKernelGGL((lstm_rows_back_kernel<128, 2>), rows_grid, dim3(512), 0, stream, a);
+				}
 				HIP_ENFORCE(hipGetLastError());
 			} else
 			if (persistent) { // one launch for the whole sequence (lstm_seq_back_kernel)

@@ -77,6 +77,9 @@ static inline floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx
 #define NNC_PK_FMA_LO(acc, h, rp) do { (acc)[0] += (h)[0] * (rp)[0]; (acc)[1] += (h)[1] * (rp)[0]; } while (0)
 #define NNC_PK_FMA_HI(acc, h, rp) do { (acc)[0] += (h)[0] * (rp)[1]; (acc)[1] += (h)[1] * (rp)[1]; } while (0)
 #define NNC_WAIT_VM0_ONLY() ((void)0)
+// hardware transcendentals (v_exp_f32: 2^x, v_rcp_f32: 1 / x; both within 1 ulp): the emulator takes the C library's
+static inline float nnc_fast_exp2(const float x) { return exp2f(x); }
+static inline float nnc_fast_rcp(const float x) { return 1.f / x; }
 // -- workgroups of ONE launch that hand each other a few words (cmd_norm.cpp's cluster kernels): agent-scope accesses of the words themselves, no fences.
 //    A granule is one naturally aligned 8-byte {tag, value} written by ONE store: the data is the flag.  The emulator keeps a window of workgroups resident
 //    and runs them interleaved (tests/emu: launch_concurrent); a polling loop yields to them.
@@ -156,6 +159,10 @@ __device__ __forceinline__ unsigned long long nnc_load_granule(const unsigned lo
 #define NNC_PK_FMA_LO(acc, h, rp) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(h), "v"(rp))
 #define NNC_PK_FMA_HI(acc, h, rp) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(h), "v"(rp))
 #define NNC_WAIT_VM0_ONLY() __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8)) // vmcnt(0), expcnt / lgkmcnt not waited for (gfx9 encoding)
+// hardware transcendentals: v_exp_f32 (2^x) and v_rcp_f32 (1 / x), one instruction each, within 1 ulp -- where expf() and an IEEE division are chains of ten and
+// more dependent instructions each (the LSTM's per-step latency chain: cmd_lstm.cpp lstm_fast_sigmoid / lstm_fast_tanh)
+__device__ __forceinline__ float nnc_fast_exp2(const float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float nnc_fast_rcp(const float x) { return __builtin_amdgcn_rcpf(x); }
 
 #endif
 

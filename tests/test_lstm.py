@@ -76,10 +76,10 @@ CASES = [
 
 
 def _run(lib, case, dtype=F, tol=1e-4, persistent=2):
-    # 2: the defaults (hidden size <= 128 without projection: a workgroup per two batch rows, R in its registers); 1: hidden units split over workgroups that hand
-    # the state to each other; 0: a launch per step
+    # 2: the defaults (hidden size <= 128 without projection: a workgroup per batch row -- per two rows when the hidden size is no multiple of four --, R in its
+    # registers); 3: the two-row form of that for every size; 1: hidden units split over workgroups that hand the state to each other; 0: a launch per step
     lib.tune_set("LSTM_PERSISTENT", 1 if persistent else 0)
-    lib.tune_set("LSTM_ROWS", 1 if persistent == 2 else 0)
+    lib.tune_set("LSTM_ROWS", {2: 1, 3: 2}.get(persistent, 0))
     try:
         _run_inner(lib, case, dtype, tol, persistent)
     finally:
@@ -126,7 +126,7 @@ def _run_inner(lib, case, dtype, tol, persistent):
     assert lib.cmd_exec(fcmd, nnc.NO_HINT, 0, [x_t, xs_t, hx_t, cx_t, w_t], [y_t, hy_t, cy_t, r_t]) == 0
     if dtype == F:  # which forward ran: the whole sequence in one launch, or a launch per step (projection: always per step)
         one_launch = persistent and not (P and P != H)
-        assert lib.dll.nnc_mi355x_last_kernel_name().decode() == (("lstm_rows_forw" if persistent == 2 and H <= 128 else "lstm_seq_forw") if one_launch else "lstm_step_forw")
+        assert lib.dll.nnc_mi355x_last_kernel_name().decode() == (("lstm_rows_forw" if persistent >= 2 and H <= 128 else "lstm_seq_forw") if one_launch else "lstm_step_forw")
     # (the reserved space holds fp32 planes whatever the command's data type: a CCV_16F tensor is only the container the host sized)
     r = np.ascontiguousarray(r_t.numpy()).reshape(-1).view(np.float32).astype(np.float64)
     masks = None
@@ -168,7 +168,7 @@ def _run_inner(lib, case, dtype, tol, persistent):
     ins = [gpu(lay(gy)), gpu(ghy), gpu(gcy), None, x_t, xs_t, hx_t, cx_t, w_t, y_t, hy_t, cy_t, r_t]
     assert lib.cmd_exec(bcmd, nnc.NO_HINT, 0, ins, [dx_t, None, dhx_t, dcx_t, dw_t]) == 0
     if dtype == F:
-        assert lib.dll.nnc_mi355x_last_kernel_name().decode() == (("lstm_rows_back" if persistent == 2 and H <= 128 else "lstm_seq_back") if persistent and not (P and P != H) else "lstm_step_back")
+        assert lib.dll.nnc_mi355x_last_kernel_name().decode() == (("lstm_rows_back" if persistent >= 2 and H <= 128 else "lstm_seq_back") if persistent and not (P and P != H) else "lstm_step_back")
     dx, dhx, dcx, dw = oracle.backward(gy.astype(np.float64), tape, ghy, gcy)
     close(unlay(dx_t.numpy()), dx, tol)
     close(dw_t.numpy().reshape(-1), dw, tol)
@@ -177,13 +177,13 @@ def _run_inner(lib, case, dtype, tol, persistent):
         close(dcx_t.numpy(), dcx, tol)
 
 
-@pytest.mark.parametrize("persistent", [2, 1, 0], ids=["rows", "one-launch", "per-step"])
+@pytest.mark.parametrize("persistent", [2, 3, 1, 0], ids=["rows", "two-rows", "one-launch", "per-step"])
 @pytest.mark.parametrize("case", CASES, ids=[str(c[:9]) + ("+lens" if c[9] else "") + ("+drop" if c[10] else "") for c in CASES])
 def test_lstm_forward_backward(backend, case, persistent):
     """The three forms of the sweep (tuning keys LSTM_PERSISTENT, LSTM_ROWS): the whole sequence of a pseudo-layer in one launch with a workgroup per two batch rows
     and all of R in its registers (hidden size <= 128, nothing passes between workgroups); in one launch with the hidden units split over workgroups that hand the state
     to each other through tagged words; and a launch per step.  The backward command reads the reserved space any of them wrote."""
-    if persistent == 2 and case[3] > 128:
+    if persistent >= 2 and case[3] > 128:
         pytest.skip("hidden size > 128: the default is the split form (the next parameter)")
     if persistent and case[4] and case[4] != case[3]:
         pytest.skip("a projection always takes the per-step form")

@@ -44,7 +44,7 @@ for (T, B, I, H, layers, bidir) in SHAPES:
     flops = sum(2.0 * T * B * 4 * H * ((I if l == 0 else D * H) + H) * D for l in range(layers))
     ok = lambda r: r == 0 or sys.exit("command returned %d" % r)
     steps = T * layers * D
-    for mode, rows in ((1, 1), (1, 0), (0, 0)):  # rows of the batch per workgroup (H <= 128) / hidden units per workgroup with a hand-over per step / a launch per step
+    for mode, rows in ((1, 1), (1, 2), (1, 0), (0, 0)):  # a batch row per workgroup (H <= 128) / two rows per workgroup; hidden units per workgroup with a hand-over per step; a launch per step
         L.tune_set("LSTM_PERSISTENT", mode)
         L.tune_set("LSTM_ROWS", rows)
         f_ms = timed(lambda: ok(L.cmd_exec(fcmd, nnc.NO_HINT, 0, [x, None, hx, cx, w], [y, hy, cy, r], s)), 3)
