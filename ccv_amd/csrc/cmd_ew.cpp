@@ -126,6 +126,35 @@ __global__ void __launch_bounds__(EW_THREADS) sgd_kernel(const T* g, const T* a,
 		}
 	}
 }
+// The same for CCV_16F tensors in 16-byte accesses (eight halves per lane; round 5): the scalar form above moves 2 bytes per lane and access -- ResNet-50's 161
+// half-precision parameter tensors took 1.9 ms of its 48 ms step that way (profiles/r05_v8_resnet50-nchw-bs256-f16_rocprofv3_kernel_stats.md).  Same fp32
+// arithmetic and rounding per element: bit-identical results.
+__global__ void __launch_bounds__(EW_THREADS) sgd_kernel_h8(const pack16<half_t>::type* g, const pack16<half_t>::type* a, const pack16<half_t>::type* m, pack16<half_t>::type* b, pack16<half_t>::type* nm, const size_t n8, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening)
+{
+	typedef pack16<half_t>::type V;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+		const V gv = g[i], av = a[i], mv = m[i];
+		V bo, no;
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const float avf = (float)av[e];
+			if (nesterov) {
+				float grad = scale * (float)gv[e];
+				const float mom = momentum * (float)mv[e] + grad + decay * avf;
+				no[e] = (half_t)mom;
+				grad += momentum * mom;
+				bo[e] = (half_t)(avf - rate * grad);
+			} else {
+				const float mom = momentum * (float)mv[e] + inv_dampening * (scale * (float)gv[e] + decay * avf);
+				no[e] = (half_t)mom;
+				bo[e] = (half_t)(avf - rate * mom);
+			}
+		}
+		nm[i] = no;
+		b[i] = bo;
+	}
+}
 __global__ void __launch_bounds__(EW_THREADS) sgd_kernel_v4(const float4* g, const float4* a, const float4* m, float4* b, float4* nm, const size_t n4, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening)
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -388,6 +417,12 @@ static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	if (g_deferred_live && deferred_trail_cmd(_sgd_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context)) return CCV_NNC_EXEC_SUCCESS;
 	hipStream_t stream = stream_of(stream_context);
 	if (dt == CCV_16F) {
+		if ((cnt % 8 == 0) && aligned16(g->data.u8) && aligned16(a->data.u8) && aligned16(m->data.u8) && aligned16(b->data.u8) && aligned16(n->data.u8)) {
+			typedef pack16<half_t>::type V;
+			hipLaunchKernelGGL(sgd_kernel_h8, dim3(grid_for(cnt / 8, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const V*)g->data.u8, (const V*)a->data.u8, (const V*)m->data.u8, (V*)b->data.u8, (V*)n->data.u8, cnt / 8, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
+			HIP_ENFORCE(hipGetLastError());
+			return CCV_NNC_EXEC_SUCCESS;
+		}
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(sgd_kernel<half_t>), dim3(grid_for(cnt, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const half_t*)g->data.f16, (const half_t*)a->data.f16, (const half_t*)m->data.f16, (half_t*)b->data.f16, (half_t*)n->data.f16, cnt, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;

@@ -385,6 +385,36 @@ def test_native_half_sgd(backend, ref_lib, nesterov):
         _close(x, y, tol=1e-3)
 
 
+@pytest.mark.parametrize("nesterov", [0, 1])
+def test_native_half_sgd_in_16_byte_accesses_equals_the_scalar_kernel(backend, ref_lib, nesterov):
+    """Tensors of a multiple of eight halves on 16-byte boundaries take sgd_kernel_h8 (eight halves per lane); the same numbers one element further into the
+    same allocations are not aligned and take the scalar kernel: bit-identical updates, and both within tolerance of the reference's fp32 update."""
+    from harness import make_tensors
+    lib = backend
+    rng = np.random.default_rng(25)
+    n = 4104
+    g, a, m = hrnd(rng, n), hrnd(rng, n), hrnd(rng, n, scale=0.1)
+    cmd = nnc.CMD_SGD_FORWARD(nesterov, 0.01, 0.5, 0.0005, 0.9, 0.0 if nesterov else 0.1)
+    outs = {}
+    for off in (0, 1):
+        pad = lambda x: np.concatenate([np.zeros(off, H), x, np.zeros(8 - off, H)])
+        tg, ta, tm, tb, tn = make_tensors(lib, nnc.GPU_MEMORY, [pad(g), pad(a), pad(m), np.zeros(n + 8, H), np.zeros(n + 8, H)])
+        ins = [t.alias((n,), off) for t in (tg, ta, tm)]
+        ots = [t.alias((n,), off) for t in (tb, tn)]
+        assert lib.cmd_exec(cmd, nnc.NO_HINT, 0, ins, ots) == 0
+        lib.stream_wait(None)
+        full = [tb.numpy(), tn.numpy()]
+        for f in full:  # nothing outside the aliased range was written
+            assert (f[:off] == 0).all() and (f[off + n:] == 0).all()
+        outs[off] = [f[off:off + n] for f in full]
+    for x, y in zip(outs[0], outs[1]):
+        assert (x.view(np.uint16) == y.view(np.uint16)).all()
+    r2, want = exec_on(ref_lib, nnc.CPU_MEMORY, cmd, nnc.NO_HINT, 0, [g.astype(F), a.astype(F), m.astype(F)], [np.zeros(n, F), np.zeros(n, F)], backend=nnc.BACKEND_CPU_REF)
+    assert r2 == 0
+    for x, y in zip(outs[0], want):
+        _close(x, y, tol=1e-3)
+
+
 # ---- the half-precision contraction kernel's two staging widths (mfma_gemm_f16.h: TileFetchH, 8-byte chunks of four halves; TileFetchH8, 16-byte chunks of eight where
 # channel counts and strides are multiples of eight): the same LDS images, the same fragments -- bit-identical results
 @pytest.mark.parametrize("what", ["conv-nhwc", "conv-nchw", "conv-nchw-s2", "gemm"])
