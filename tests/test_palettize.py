@@ -142,6 +142,36 @@ def test_depalettize_expands_the_stream_bit_for_bit(backend, datatype, qbits, ni
     assert (got[count:] == sentinel[count:]).all()  # nothing past the tensor's last element
 
 
+@pytest.mark.parametrize("qbits,nib,count", [(5, 8, 13), (8, 16, 40), (4, 16, 64), (6, 4, 10), (7, 16, 17), (4, 128, 2839), (6, 4096, 9000)])
+def test_depalettize_reads_nothing_past_the_stream(emu_lib, qbits, nib, count):
+    """The stream of a tensor's last block ends with the last index byte its elements touch.  On the emulator device memory is host memory: the stream is placed
+    so that it ends exactly at a page boundary with an inaccessible page behind it -- an 8-byte index load that reached past the stream's end (the kernel's fast
+    path takes whole groups in one load) would fault."""
+    import ctypes, mmap
+    lib = emu_lib
+    rng = np.random.default_rng(qbits + nib + count)
+    palettes, indices = random_case(rng, count, qbits, nib, nnc.CCV_16F)
+    stream = pack_stream(palettes, indices, qbits, nib, nnc.CCV_16F)
+    n = int(lib.palettized_bytes(nnc.CCV_16F, count, qbits, nib))  # the tensor's own size: what a caller allocates (the quantiser may have written a longer tail)
+    assert n <= stream.nbytes
+    page = mmap.PAGESIZE
+    pages = (n + 1 + page - 1) // page
+    mm = mmap.mmap(-1, (pages + 1) * page)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    start = base + pages * page - n - (n & 1)  # (the palettes are read as 2-byte words: an odd-sized stream leaves one accessible byte behind it)
+    ctypes.memmove(start, stream.ctypes.data, n)
+    assert libc.mprotect(base + pages * page, page, 0) == 0  # PROT_NONE
+    try:
+        (dst,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(count, np.float16)])
+        assert lib.depalettize(start, nnc.CCV_16F, n, qbits, nib, dst, count) == 0
+        lib.stream_wait(None)
+        assert (dst.numpy().view(np.uint16) == expand(palettes, indices, nib, nnc.CCV_16F)).all()
+    finally:
+        libc.mprotect(base + pages * page, page, mmap.PROT_READ | mmap.PROT_WRITE)
+
+
 def test_depalettize_into_an_unaligned_destination(backend):
     """An output that does not start on 16 bytes (a tensor carved out of a larger allocation) takes the element-wise store path."""
     lib = backend
