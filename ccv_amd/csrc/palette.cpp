@@ -108,8 +108,11 @@ __global__ void __launch_bounds__(PAL_THREADS) depalettize_kernel(const unsigned
 	ELEM* const palette = (ELEM*)lds; // [bpw][1 << Q]
 	const size_t block0 = (size_t)blockIdx.x * (size_t)g.bpw;
 	const int nblk = g.blocks - block0 < (size_t)g.bpw ? (int)(g.blocks - block0) : g.bpw;
-	for (int i = threadIdx.x; i < nblk << Q; i += PAL_THREADS)
-		palette[i] = ((const ELEM*)(in + (block0 + (size_t)(i >> Q)) * g.block_stride))[i & ((1 << Q) - 1)];
+	for (int i = threadIdx.x; i < nblk << Q; i += PAL_THREADS) { // (a block's stride may be odd -- 5 index bytes for eight 5-bit elements --: the palettes are not aligned to their words)
+		ELEM v;
+		__builtin_memcpy(&v, in + (block0 + (size_t)(i >> Q)) * g.block_stride + sizeof(ELEM) * (size_t)(i & ((1 << Q) - 1)), sizeof(ELEM));
+		palette[i] = v;
+	}
 	__syncthreads();
 	constexpr int EPL = 16 / (int)sizeof(ELEM), LPG = 8 / EPL; // elements per lane, lanes per group (1 / 2 / 4)
 	const int t0 = blockIdx.y * PAL_CHUNK;
