@@ -485,6 +485,7 @@ static int _data_transfer(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 		if (CCV_GET_DATA_TYPE(a->info.datatype) == CCV_QX) { // a palettized tensor travels as its byte stream (ccv_nnc_util_gpu_ref.cu:22-26)
 			if (a->info.datatype != b->info.datatype || a->info.reserved != b->info.reserved) return CCV_NNC_EXEC_INVALID;
 			size = palettized_bytes((a->info.datatype & 0xff) << 12, tensor_count(a->info), (a->info.datatype & 0xf00) >> 8, a->info.reserved);
+			if (!size && tensor_count(a->info)) return CCV_NNC_EXEC_INVALID; // (no block size / a bit width outside 4 .. 8: not a stream anybody can size)
 		} else {
 			if (datatype_size(a->info.datatype) != datatype_size(b->info.datatype)) return CCV_NNC_EXEC_INVALID;
 			size = tensor_count(a->info) * datatype_size(a->info.datatype);

@@ -305,6 +305,14 @@ def test_attention_with_a_palettized_head_projection_equals_the_dense_command(ba
         assert (a.numpy().view(np.uint32) == b.numpy().view(np.uint32)).all()
 
 
+def test_data_transfer_refuses_a_palettized_tensor_without_a_block_size(backend):
+    lib = backend
+    stream = np.zeros(256, np.uint8)
+    bad = nnc.tensor_palettize(nnc.GPU_TENSOR_NHWC(0, nnc.CCV_32F, 8, 8), 4, 0)  # reserved = 0: no elements per block
+    a, b = nnc.PalettizedTensor(lib, bad, stream), nnc.PalettizedTensor(lib, bad, stream)
+    assert lib.cmd_exec(nnc.CMD_DATA_TRANSFER_FORWARD(), nnc.NO_HINT, 0, [a], [b]) == nnc.EXEC_INVALID
+
+
 def test_palettized_rows_are_listed_like_the_reference_lists_them(backend):
     """CCV_QX in tensor_datatypes of exactly the rows whose reference counterparts carry it (ccv_nnc_gemm_gpu_cublas.cu, ccv_nnc_conv_gpu_cudnn.cu:482,494,
     ccv_nnc_conv_transpose_gpu_cudnn.cu:185, ccv_nnc_util_gpu_ref.cu:67,76, ccv_nnc_scaled_dot_product_attention_flash_attn.cu:459,470): the host's backend lookup matches a command's datatypes against this mask."""
