@@ -2,7 +2,7 @@
 lib/nnc/gpu/ccv_nnc_palettize.cu) and the rows that take palettized inputs (GEMM, convolution, DATA_TRANSFER).
 
 The checker is the reference itself: its quantiser `ccv_nnc_palettize` writes the byte stream and its CPU reader `ccv_nnc_depalettize`
-(lib/nnc/ccv_nnc_palettize.c:9-208, 211-956, compiled into oracle/_ref/libccv_ref.so) says what the stream means; `pack_stream` below restates the layout in
+(lib/nnc/ccv_nnc_palettize.c:9-208, 211-956, compiled into oracle/_ref/libccv_ref.so) says what the stream means; `pack_stream` (oracle/palettize_numpy.py) restates the layout in
 numpy (any palette, any indices -- the quantiser only ever produces k-means palettes) and is pinned to both.  Results are moved bits: every comparison is exact."""
 import ctypes as C
 import numpy as np
@@ -10,40 +10,10 @@ import pytest
 from ccv_amd import nnc
 from harness import make_tensors
 
-_NP = {nnc.CCV_16F: np.uint16, nnc.CCV_32F: np.uint32, nnc.CCV_64F: np.uint64}  # values are moved, not interpreted: compare the words
-
-
-def index_bytes_per_block(qbits, nib):
-    return {4: nib // 2, 5: nib // 8 * 5, 6: nib // 4 * 3, 7: nib // 8 * 7, 8: nib}[qbits]
-
-
-def pack_stream(palettes, indices, qbits, nib, datatype):
-    """palettes: [blocks][2^qbits] words, indices: [count] ints < 2^qbits.  The stream ccv_nnc_palettize would have written for these choices:
-    per block the palette, then its elements' indices as a big-endian bit stream; the last block's indices end with its last whole group."""
-    count = len(indices)
-    blocks = (count + nib - 1) // nib
-    word = np.dtype(_NP[datatype])
-    group = {4: 2, 5: 8, 6: 4, 7: 8, 8: 1}[qbits]
-    out = bytearray()
-    for b in range(blocks):
-        out += np.asarray(palettes[b], dtype=word).tobytes()
-        idx = np.asarray(indices[b * nib:(b + 1) * nib], dtype=np.uint64)
-        full = len(idx) == nib
-        padded = (len(idx) + group - 1) // group * group
-        idx = np.concatenate([idx, np.zeros(padded - len(idx), np.uint64)])
-        bits = ((idx[:, None] >> np.arange(qbits - 1, -1, -1, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.uint8).reshape(-1)
-        packed = np.packbits(bits).tobytes()
-        if full:
-            assert len(packed) >= index_bytes_per_block(qbits, nib)
-            packed = packed[:index_bytes_per_block(qbits, nib)] + bytes(max(0, index_bytes_per_block(qbits, nib) - len(packed)))
-        out += packed
-    return np.frombuffer(bytes(out), dtype=np.uint8).copy()
-
-
-def expand(palettes, indices, nib, datatype):
-    idx = np.asarray(indices)
-    pal = np.asarray(palettes, dtype=_NP[datatype])
-    return pal[np.arange(len(idx)) // nib, idx]
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+from palettize_numpy import WORD as _NP, index_bytes_per_block, pack_stream, expand  # noqa: E402  (the numpy restatement of the stream's layout, pinned below)
 
 
 def random_case(rng, count, qbits, nib, datatype):
