@@ -35,7 +35,10 @@ pthread_mutex_t g_comm_mutex = PTHREAD_MUTEX_INITIALIZER;
 // the NULL stream).  The host's scheduler may place the all-reduce nodes of a data-parallel graph on different stream
 // contexts; through ONE communicator RCCL would serialise them and tie the streams together.  Released with the context.
 struct clique_t { const void* ctx; int device_count; ncclComm_t comm[MAX_CLIQUE]; };
-std::vector<clique_t*> g_cliques;
+// (never destroyed: the reference host frees stream contexts from threads it does not join -- its async-callback thread, ccv_nnc_stream.c -- and such a thread may
+// still be in comm_release_context while the main thread runs the exit handlers; a container with a destructor would be gone under it.  ThreadSanitizer found
+// exactly that on the reference's partial-schedule cases.  The same for every container of this library that a late thread can reach: device_rt.cpp, peephole.cpp.)
+std::vector<clique_t*>& g_cliques = *new std::vector<clique_t*>;
 ncclComm_t g_rank_comm = 0; // deployment (b)
 int g_rank = 0, g_world = 1;
 

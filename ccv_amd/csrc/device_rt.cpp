@@ -51,7 +51,7 @@ thread_local const char* tl_last_kernel = "";
 
 struct mem_pressure_t { int device_id; nnc_mi355x_mem_pressure_f func; void* ctx; };
 pthread_mutex_t g_mp_mutex = PTHREAD_MUTEX_INITIALIZER;
-std::vector<mem_pressure_t> g_mp;
+std::vector<mem_pressure_t>& g_mp = *new std::vector<mem_pressure_t>; // (never destroyed: a host thread the process does not join may still free memory while the exit handlers run; cmd_comm.cpp g_cliques)
 
 void trigger_mem_pressure()
 {
@@ -336,7 +336,7 @@ MarkerScope::~MarkerScope()
 
 struct prof_rec_t { char name[192]; double flops, bytes; int dims[5]; hipEvent_t e0, e1; };
 static pthread_mutex_t g_prof_mutex = PTHREAD_MUTEX_INITIALIZER;
-static std::vector<prof_rec_t*> g_prof;
+static std::vector<prof_rec_t*>& g_prof = *new std::vector<prof_rec_t*>; // (never destroyed, as above)
 static volatile int g_prof_on = 0;
 
 ProfScope::ProfScope(const char* name, double flops, double bytes, int M, int N, int K, int Z, int S, hipStream_t st) : rec(0), stream(st)
@@ -385,8 +385,8 @@ extern "C" {
 static int g_pool_mode = -1;
 static pthread_mutex_t g_pool_mutex = PTHREAD_MUTEX_INITIALIZER;
 struct kept_block_t { void* ptr; size_t size; };
-static std::vector<kept_block_t> g_kept[MAX_DEVICES];           // free blocks, newest last
-static std::vector<kept_block_t> g_live[MAX_DEVICES];           // blocks handed out (ptr -> rounded size); a few hundred entries at most: linear search
+static std::vector<kept_block_t>* const g_kept = new std::vector<kept_block_t>[MAX_DEVICES]; // free blocks, newest last (never destroyed: cufree may arrive from a thread that outlives the exit handlers)
+static std::vector<kept_block_t>* const g_live = new std::vector<kept_block_t>[MAX_DEVICES]; // blocks handed out (ptr -> rounded size); a few hundred entries at most: linear search
 static std::atomic<long> g_pool_allocs(0), g_pool_retries(0), g_pool_kept_bytes(0), g_pool_live_bytes(0), g_pool_trimmed(0);
 static size_t g_kept_dev_bytes[MAX_DEVICES]; // bytes on g_kept[device] (under the mutex)
 static size_t g_keep_cap[MAX_DEVICES];       // 0 = not read yet

@@ -84,15 +84,16 @@ struct Slot {
 };
 constexpr int SLOTS = 16;
 Slot g_slots[SLOTS];
-std::recursive_mutex g_mu;
-std::condition_variable_any g_launched; // a LAUNCHING slot became FREE
+// (never destroyed: a host thread the process does not join may still enqueue or flush while the exit handlers run; cmd_comm.cpp g_cliques)
+std::recursive_mutex& g_mu = *new std::recursive_mutex;
+std::condition_variable_any& g_launched = *new std::condition_variable_any; // a LAUNCHING slot became FREE
 // a flushed command failed at launch: the next recordable command ON THAT STREAM (context, device) reports it -- not whichever command of the process
 // comes next (a valid command on another stream or device used to be refused with somebody else's out-of-memory)
 struct StickyError { const ccv_nnc_stream_context_t* ctx; int device; int err; };
 constexpr int MAX_STICKY = 16;
 StickyError g_sticky[MAX_STICKY];
 std::atomic<int> g_sticky_live(0);
-std::unordered_set<uint64_t> g_good;
+std::unordered_set<uint64_t>& g_good = *new std::unordered_set<uint64_t>;
 int g_enabled = -1;
 long g_recorded = 0, g_folded = 0, g_plain = 0; // nnc_mi355x_debug_peephole_counts
 long g_trailed = 0;                             // operations that waited in a trail (nnc_mi355x_debug_peephole_trailed)
