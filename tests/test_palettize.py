@@ -254,6 +254,26 @@ def test_convolution_with_palettized_filters_equals_the_dense_command(backend, d
         assert (a.numpy().view(_NP[datatype]) == b.numpy().view(_NP[datatype])).all()
 
 
+@pytest.mark.parametrize("dtype,datatype", [(np.float32, nnc.CCV_32F), (np.float16, nnc.CCV_16F)])
+def test_transposed_convolution_with_palettized_filters_equals_the_dense_command(emu_lib, dtype, datatype):
+    """CONVOLUTION_TRANSPOSE_FORWARD with CCV_QX filters (ccv_nnc_conv_transpose_gpu_cudnn.cu:72-90).  In half precision the row underneath is itself a wrapper
+    (fp32 images of the half tensors, half_stage.cpp): the dense image of the filters sits in the palette arena while that wrapper grows its own.  CPU tier only
+    (the GEMM / convolution / attention cases above run in both tiers)."""
+    lib = emu_lib
+    rng = np.random.default_rng(12)
+    n, H, W, count, ca, k = 2, 9, 9, 16, 8, 3
+    a, w, bias = levels(rng, (n, H, W, ca), 4, dtype), levels(rng, (ca, k, k, count), 5, dtype), levels(rng, (count,), 4, dtype)
+    cmd = nnc.CMD_CONVOLUTION_TRANSPOSE_FORWARD(1, count, 0, k, k, ca)
+    hint = nnc.HINT((1, 1), (1, 1))
+    dev_q = nnc.PalettizedTensor(lib, nnc.tensor_palettize(nnc.GPU_TENSOR_NHWC(0, datatype, ca, k, k, count), 5, 128), lossless_stream(w, 5, 128, datatype))
+    ta, tw, tb = make_tensors(lib, nnc.GPU_MEMORY, [a, w, bias])
+    od, op = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros((n, H, W, count), dtype)] * 2)
+    assert lib.cmd_exec(cmd, hint, 0, [ta, tw, tb], [od]) == 0
+    assert lib.cmd_exec(cmd, hint, 0, [ta, dev_q, tb], [op]) == 0
+    assert np.abs(od.numpy().astype(np.float64)).max() > 0
+    assert (od.numpy().view(_NP[datatype]) == op.numpy().view(_NP[datatype])).all()
+
+
 def test_attention_with_a_palettized_head_projection_equals_the_dense_command(backend):
     """SCALED_DOT_PRODUCT_ATTENTION_FORWARD with the head-unifying projection's weights palettized (ccv_nnc_scaled_dot_product_attention_flash_attn.cu:123)."""
     lib = backend
