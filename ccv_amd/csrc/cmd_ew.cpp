@@ -413,6 +413,8 @@ static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	const float inv_dampening = 1 - cmd.info.sgd.dampening;
 	const int dt = CCV_GET_DATA_TYPE(a->info.datatype);
 	if (CCV_GET_DATA_TYPE(g->info.datatype) != dt || CCV_GET_DATA_TYPE(m->info.datatype) != dt || CCV_GET_DATA_TYPE(b->info.datatype) != dt || CCV_GET_DATA_TYPE(n->info.datatype) != dt) return CCV_NNC_EXEC_INVALID;
+	// an update of this stream that waited in a trail failed when it was replayed: its caller had been told "enqueued", this one is told (once)
+	if (const int e = deferred_take_error(stream_context)) return e;
 	// every parameter has been checked: behind a recorded CONVOLUTION_BACKWARD whose signal this stream waits for, the update waits with it (peephole.cpp, the trail)
 	if (g_deferred_live && deferred_trail_cmd(_sgd_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context)) return CCV_NNC_EXEC_SUCCESS;
 	hipStream_t stream = stream_of(stream_context);

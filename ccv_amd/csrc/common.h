@@ -227,6 +227,7 @@ enum {
 	TUNE_GEMM_HALF_CHUNK8,  // the half-precision contraction kernel stages its operands in 16-byte chunks of eight halves where strides and channel counts allow (1), or always in 8-byte chunks of four (0)
 	TUNE_LSTM_PERSISTENT,   // LSTM: one launch walks a pseudo-layer's whole sequence with its slice of R in registers, the state handed between workgroups through tagged words (1), or one launch per step (0)
 	TUNE_LSTM_ROWS,         // LSTM without projection, hidden size <= 128: a workgroup owns ONE batch row (two when the hidden size is no multiple of four; 2 = two for every size) and ALL hidden units for the whole sequence, R entirely in its registers, no word passes between workgroups (1), or the forms above (0)
+	TUNE_GEMM_BF16X3,       // fp32 plain-matrix contractions on the bf16 matrix pipe, every operand split exactly into three bf16 values and all nine partial products accumulated in fp32 (mfma_gemm_bf16x3.h): 0 = never (the fp32 matrix instructions), 1 = where the launcher's rules say it pays, 2 = wherever the kernel applies, 3 / 4 = as 2 with the 128 x 128 / 256 x 256 tile forced (measurements)
 	TUNE_COUNT
 };
 static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "mfma_gemm.h"
 #include "mfma_gemm_f16_buf.h"
+#include "mfma_gemm_bf16x3.h"
 
 namespace nnc {
 
@@ -40,8 +41,8 @@ static inline int gemm_auto_splits(long tiles, int K)
 inline size_t gemm_workspace_bound(long M, long N, long K)
 {
 	size_t worst = 0;
-	static const int shapes[4][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 }, { 1, 1 } };
-	for (int i = 0; i < 4; i++) {
+	static const int shapes[5][2] = { { 2, 2 }, { 2, 1 }, { 1, 2 }, { 1, 1 }, { 4, 4 } }; // (4, 4): the 256 x 256 tile of mfma_gemm_bf16x3.h
+	for (int i = 0; i < 5; i++) {
 		const long tiles = ((M + 64 * shapes[i][0] - 1) / (64 * shapes[i][0])) * ((N + 64 * shapes[i][1] - 1) / (64 * shapes[i][1]));
 		int s = gemm_auto_splits(tiles, (int)(K > 0x7fffffffL ? 0x7fffffffL : K));
 		if (s > 1) s = ((s < 8 ? 8 : s) + 7) & ~7;
@@ -138,6 +139,77 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// The same contraction on the bf16 matrix pipe with exactly split operands (mfma_gemm_bf16x3.h): tile grid, split-K policy, workspace and reduce pass as above.
+template <bool AKC, bool BKC, int TM, int TN, int WM, int WN>
+static int gemm_run_bf16x3_tile(const char* name, const BufMatLoader<AKC>& la, const BufMatLoader<BKC>& lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+	hipStream_t stream = stream_of(ctx);
+	const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+	const long tiles = (long)tiles_m * tiles_n;
+	if (tiles > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	if (splits <= 0) splits = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
+	int k_per_split = K;
+	if (splits > 1) {
+		if (splits < 8) splits = 8;
+		splits = (splits + 7) & ~7;
+		k_per_split = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+	}
+	note_kernel(name);
+	char prof_name[192];
+	snprintf(prof_name, sizeof(prof_name), "%s|bf16x3 %dx%d %s%s EPI = %s", name, BM, BN, AKC ? "k" : "r", BKC ? "k" : "r", splits <= 1 ? "EpiStore" : "EpiPartial");
+	const double flops = 2.0 * (double)M * (double)N * (double)K * (double)zcount;
+	if (splits <= 1) {
+		EpiStore epi;
+		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
+		epi.vec = epi_vec_ok(out.c, sizeof(float), out.ldm, out.ldn, N, zcount, c_z);
+		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_bf16x3_kernel<AKC, BKC, EpiStore, TM, TN, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(NT), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, 1, a_z, b_z, c_z, bias_z);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
+	const long slab = (long)M * N;
+	float* ws = (float*)workspace_of(ctx, sizeof(float) * (size_t)slab * splits * zcount);
+	if (!ws) return CCV_NNC_EXEC_OOM;
+	EpiPartial epi;
+	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
+	epi.vec = tune(TUNE_GEMM_VEC_EPILOGUE) && N % 4 == 0;
+	{
+		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_bf16x3_kernel<AKC, BKC, EpiPartial, TM, TN, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(NT), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L);
+	}
+	HIP_ENFORCE(hipGetLastError());
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(splitk_reduce_kernel<float>), dim3(grid_for((size_t)slab * 4, 256), (unsigned)zcount), dim3(256), 0, stream, (const float*)ws, splits, slab, out.c, out.ldm, out.ldn, out.bias, out.bias_ldm, out.alpha, out.accumulate, M, N, c_z, bias_z, out.bias_ldn);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+// Where the split form is taken (TUNE_GEMM_BF16X3 = 1; measured on the MI355X, tools/bf16x3_bench.py, profiles/r06_v2_bf16x3_bench.txt): only where its 256 x 256
+// tile fills the chip -- at 128 x 128 it merely equals the fp32 instructions (0.95 - 1.04 x) --, for two k-contiguous operands (the Winograd-domain forward /
+// data-gradient products 1.10 - 1.19 x, the fc layers' forward products 1.10 - 1.14 x) and for two row-contiguous ones with both outputs >= 512 (the filter
+// gradients of the 512-channel layers 1.05 x; at 256 x 256 / 512 x 256 outputs the split form loses 3 - 6 %).
+template <bool AKC, bool BKC>
+static inline bool gemm_bf16x3_wanted(const int M, const int N, const int K, const int zcount, const int splits, const int flags)
+{
+	const long mode = tune(TUNE_GEMM_BF16X3);
+	if (mode <= 0 || K % 16) return false;
+	if (mode >= 2) return true;
+	if (AKC != BKC || K < 128 || M < 256 || N < 256) return false;
+	if (!AKC && (M < 512 || N < 512)) return false;
+	long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+	int s = splits;
+	if (s <= 0) s = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
+	return tiles * zcount * (s > 1 ? s : 1) >= (long)device_cu_count();
+}
+template <bool AKC, bool BKC>
+static int gemm_run_bf16x3(const char* name, const BufMatLoader<AKC>& la, const BufMatLoader<BKC>& lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, const int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+{
+	const long mode = tune(TUNE_GEMM_BF16X3);
+	const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256) * zcount * (splits > 1 ? splits : 1);
+	const bool big = mode == 4 || mode == 1 || (mode != 3 && M >= 256 && N >= 256 && big_tiles >= (long)device_cu_count());
+	if (big) return gemm_run_bf16x3_tile<AKC, BKC, 4, 2, 2, 4>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+	return gemm_run_bf16x3_tile<AKC, BKC, 2, 2, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+}
+
 template <class LA, class LB>
 static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, int splits, const int flags, ccv_nnc_stream_context_t* const ctx, const KOrder ko = KOrder())
 {
@@ -157,6 +229,7 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 			ba.p = la.p; ba.zoff = 0; ba.ldr = la.ldr; ba.ldk = la.ldk; ba.R = la.R; ba.K = la.K;
 			bb.p = lb.p; bb.zoff = 0; bb.ldr = lb.ldr; bb.ldk = lb.ldk; bb.R = lb.R; bb.K = lb.K;
 			typedef BufMatLoader<LA::KCONTIG> BA; typedef BufMatLoader<LB::KCONTIG> BB;
+			if (!g_force_tile && gemm_bf16x3_wanted<LA::KCONTIG, LB::KCONTIG>(M, N, K, zcount, splits, flags)) return gemm_run_bf16x3<LA::KCONTIG, LB::KCONTIG>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 			if (wm == 2 && wn == 2) return gemm_run_tile<BA, BB, 2, 2>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 			if (wm == 2) return gemm_run_tile<BA, BB, 2, 1>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 			if (wn == 1) return gemm_run_tile<BA, BB, 1, 1>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);

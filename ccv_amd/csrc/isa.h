@@ -12,6 +12,7 @@ typedef _Float16 half_t;
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 typedef int wf_rsrc_t __attribute__((ext_vector_type(4)));
+typedef unsigned int bf16x8_t __attribute__((ext_vector_type(4))); // eight bf16 values, two per dword (element 2i in the low half of dword i)
 
 // Pin a value to its position in the instruction stream: an empty volatile asm that "rewrites" x is ordered against the
 // sched_barrier fences, so arithmetic that consumes x cannot be hoisted above the fence in front of it (pure address
@@ -69,6 +70,10 @@ static inline void wf_store16(const wf_rsrc_t r, unsigned voff, unsigned soff, f
 static inline float wf_max(float a, float b) { return a > b ? a : b; }
 static inline halfx4 tr_read4(const half_t* const blk, const int pitch, const int i) { return halfx4{ blk[i], blk[pitch + i], blk[2 * pitch + i], blk[3 * pitch + i] }; }
 static inline floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return emu_mfma_f32_32x32x16_f16(a, b, c); }
+// v_mfma_f32_32x32x16_bf16 on packed bf16 operands; nnc_pack_hi16(b, a) = the HIGH halves of a and b in one dword, a's in the low half (v_perm_b32):
+// two fp32 values truncated to bf16 and packed (mfma_gemm_bf16x3.h)
+static inline floatx16 nnc_mfma_bf16(const bf16x8_t a, const bf16x8_t b, const floatx16 c) { return emu_mfma_f32_32x32x16_bf16(a, b, c); }
+static inline unsigned nnc_pack_hi16(const unsigned b, const unsigned a) { return (a >> 16) | (b & 0xffff0000u); }
 #define NNC_PIN_VEC(v) ((void)0)
 #define NNC_ASM_NOPS(text) ((void)0)
 #define NNC_WAIT_LGKM0() ((void)0)
@@ -142,6 +147,12 @@ __device__ __forceinline__ halfx4 tr_read4(const half_t* const blk, const int pi
 	return v;
 }
 __device__ __forceinline__ floatx16 nnc_mfma_f16(const halfx8 a, const halfx8 b, const floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ floatx16 nnc_mfma_bf16(const bf16x8_t a, const bf16x8_t b, const floatx16 c)
+{
+	typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+	return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned nnc_pack_hi16(const unsigned b, const unsigned a) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 #define NNC_LAUNCH_CONCURRENT(kernel, grid, block, shmem, stream, ...) hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 // (global_atomic / global_load / global_store with sc1: served by the memory side of the L2s, never by a CU's L1 -- MI355X guide, inter-workgroup visibility)
 __device__ __forceinline__ unsigned nnc_fetch_add_agent(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -97,6 +97,7 @@ std::unordered_set<uint64_t>& g_good = *new std::unordered_set<uint64_t>;
 int g_enabled = -1;
 long g_recorded = 0, g_folded = 0, g_plain = 0; // nnc_mi355x_debug_peephole_counts
 long g_trailed = 0;                             // operations that waited in a trail (nnc_mi355x_debug_peephole_trailed)
+int g_debug_fail_trailed = 0;     // nnc_mi355x_debug_peephole_fail_trailed: the next command replayed out of a trail reports this instead of running (tests)
 int g_debug_launch_delay_us = 0; // nnc_mi355x_debug_peephole_launch_delay_us: tests widen the window between a slot's release and its launch
 thread_local int tl_running = 0; // inside a recorded command's launch: its own stream_of / nested commands must not touch the slots
 
@@ -218,7 +219,9 @@ int run(Slot& s, const int relu_bit, Lock& lk, const bool report)
 			ccv_nnc_tensor_t* tout[TRAIL_IO];
 			for (int i = 0; i < t.nin; i++) tin[i] = t.has_in[i] ? (ccv_nnc_tensor_t*)&t.in[i] : 0;
 			for (int i = 0; i < t.nout; i++) tout[i] = t.has_out[i] ? (ccv_nnc_tensor_t*)&t.out[i] : 0;
-			const int tr = t.fn(t.cmd, t.hint, t.flags, tin, t.nin, tout, t.nout, t.ctx);
+			int tr = g_debug_fail_trailed;
+			if (tr) g_debug_fail_trailed = 0;
+			else tr = t.fn(t.cmd, t.hint, t.flags, tin, t.nin, tout, t.nout, t.ctx);
 			if (tr != CCV_NNC_EXEC_SUCCESS) {
 				fprintf(stderr, "[nnc_mi355x] a command (0x%x) kept behind a recorded one failed at launch with %d after its caller was told it had been enqueued\n", t.cmd.cmd, tr);
 				lk.lock();
@@ -384,6 +387,22 @@ Slot* slot_with_signal(const ccv_nnc_stream_signal_t* const signal)
 	}
 	return 0;
 }
+// another thread is replaying a trail that names `signal` (without the slots' mutex): until it is through, the signal's emit may not have been recorded in
+// its stream yet -- a wait issued now, on a stream the trail does not hold, would find an event with nothing behind it and let that stream run ahead of the
+// recorded command (wait_launching() above only knows streams)
+void wait_launching_signal(const ccv_nnc_stream_signal_t* const signal, Lock& lk)
+{
+	for (;;) {
+		bool busy = false;
+		for (int i = 0; i < SLOTS && !busy; i++) {
+			const Slot& s = g_slots[i];
+			if (s.live != LAUNCHING) continue;
+			for (int k = 0; k < s.ntrail && !busy; k++) busy = s.trail[k].op != OP_CMD && s.trail[k].signal == signal;
+		}
+		if (!busy) return;
+		g_launched.wait(lk);
+	}
+}
 bool trailing_on() { static const int on = !(getenv("NNC_MI355X_PEEPHOLE_TRAIL") && *getenv("NNC_MI355X_PEEPHOLE_TRAIL") == '0'); return on; }
 }
 
@@ -393,9 +412,10 @@ bool deferred_signal_op(const int emit, const ccv_nnc_stream_context_t* const ct
 {
 	if (!g_deferred_live || tl_running) return false;
 	Lock lock(g_mu);
-	if (!ctx || !trailing_on()) { lock.unlock(); deferred_flush(0); return false; }
+	if (!ctx || !trailing_on()) { wait_launching_signal(signal, lock); lock.unlock(); deferred_flush(0); return false; }
 	const int device = device_for(ctx);
 	wait_launching(ctx, lock);
+	wait_launching_signal(signal, lock);
 	Slot* const by_stream = slot_with_stream(ctx, device);
 	Slot* const by_signal = slot_with_signal(signal);
 	if (!by_stream && !by_signal) return false; // neither the stream nor the signal has anything to do with a recorded command
@@ -481,6 +501,7 @@ extern "C" long nnc_mi355x_debug_peephole_trailed(void)
 }
 
 extern "C" void nnc_mi355x_debug_peephole_launch_delay_us(const int us) { nnc::g_debug_launch_delay_us = us; }
+extern "C" void nnc_mi355x_debug_peephole_fail_trailed(const int err) { nnc::g_debug_fail_trailed = err; }
 
 extern "C" void nnc_mi355x_debug_peephole_counts(long* const recorded, long* const folded, long* const plain)
 {

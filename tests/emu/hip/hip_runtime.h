@@ -178,6 +178,30 @@ static inline emu_floatx16 emu_mfma_f32_32x32x16_f16(emu_halfx8 a, emu_halfx8 b,
 	emu::wave_sync();
 	return c;
 }
+// The bf16 form on packed operands (two bf16 per dword, element 2i in the low half of dword i): products of two 8-bit significands are exact in fp32.
+typedef unsigned int emu_bf16x8 __attribute__((ext_vector_type(4)));
+static inline emu_floatx16 emu_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_floatx16 c)
+{
+	struct ab { emu_bf16x8 a, b; } mine = { a, b };
+	static_assert(sizeof(ab) == 32, "exchange slot");
+	memcpy(emu::xbuf(emu::lane()), &mine, sizeof(mine));
+	emu::wave_sync();
+	const int l = emu::lane(), j = l & 31, hi = l >> 5;
+	auto at = [](const emu_bf16x8& v, const int e) { const unsigned u = (e & 1) ? (v[e >> 1] & 0xffff0000u) : (v[e >> 1] << 16); float f; memcpy(&f, &u, 4); return f; };
+	for (int r = 0; r < 16; r++) {
+		const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+		float acc = c[r];
+		for (int h = 0; h < 2; h++) {
+			ab A, B;
+			memcpy(&A, emu::xbuf(i + 32 * h), sizeof(A));
+			memcpy(&B, emu::xbuf(j + 32 * h), sizeof(B));
+			for (int e = 0; e < 8; e++) acc += at(A.a, e) * at(B.b, e);
+		}
+		c[r] = acc;
+	}
+	emu::wave_sync();
+	return c;
+}
 // LDS-DMA (buffer_load ... lds): every lane copies `size` bytes from base + voffset + soffset + inst_offset to lds + lane * size;
 // a lane whose offset reaches past num_records writes zeros (raw-buffer range check).  Synchronous here: the emulator cannot
 // show a missing s_waitcnt vmcnt -- only the MI355X tier can.

@@ -438,3 +438,95 @@ def test_relu_backward_folds_across_the_schedules_signal_and_update_operations(l
             lib.stream_free(s)
         for s in sigs:
             lib.signal_free(s)
+
+
+def test_a_wait_on_an_outside_stream_does_not_overtake_a_trail_being_replayed(lib):
+    """a foreign thread's flush is replaying a trail (slot LAUNCHING, the slots' mutex released) whose EMIT has not been recorded in its
+    stream yet; a WAIT for that signal issued now on a stream the trail does not hold must block until the replay is through -- otherwise the event has
+    nothing behind it and the update on that stream reads the gradient before CONVOLUTION_BACKWARD has even been launched.  The window is widened with the
+    debug delay; the updated parameters equal the ones of the same sequence with the look-ahead off."""
+    import threading
+    import time
+    rng = np.random.default_rng(31)
+    n, h, w, c, k = 2, 11, 12, 16, 32
+    hint = nnc.HINT((1, 1), (1, 1))
+    a = np.maximum(srnd(rng, n, h, w, c), 0)
+    g, wt = srnd(rng, n, h, w, k), srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c))
+    cmd = nnc.CMD_CONVOLUTION_BACKWARD(1, k, 3, 3, c)
+    sgd = nnc.CMD_SGD_FORWARD(0, 0.01, 0.5, 0.0005, 0.9, 0.9)
+    A, Y = lib.stream_new(0), lib.stream_new(0)
+    S = lib.signal_new(0)
+    results = {}
+    try:
+        for mode in ("off", "on"):
+            lib.dll.nnc_mi355x_set_peephole(1 if mode == "on" else 0)
+            gt, at, wtt, ht, dwt, dbt, mw = make_tensors(lib, nnc.GPU_MEMORY, [g, a, wt, np.full_like(a, 7), np.zeros_like(wt), np.zeros(k, F), np.zeros_like(wt)])
+            for trip in range(3):  # trip 0: the signature's first occurrence runs on the spot
+                r0 = counts(lib)[0]
+                assert lib.cmd_exec(cmd, hint, 0, [gt, at, wtt], [ht, dwt, dbt], A) == 0
+                lib.signal_emit(A, S)                              # waits in the recorded command's trail
+                loader = None
+                if mode == "on" and trip > 0:
+                    assert counts(lib)[0] == r0 + 1
+                    lib.dll.nnc_mi355x_debug_peephole_launch_delay_us(300000)
+                    loader = threading.Thread(target=lambda: make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(16, F)]))  # a host-to-device copy: flushes every slot
+                    loader.start()
+                    time.sleep(0.1)                                # the loader is inside the launch window now: slot LAUNCHING, nothing enqueued yet
+                lib.signal_wait(Y, S)                              # an outside stream
+                assert lib.cmd_exec(sgd, nnc.NO_HINT, 0, [dwt, wtt, mw], [wtt, mw], Y) == 0
+                if loader:
+                    loader.join()
+                    lib.dll.nnc_mi355x_debug_peephole_launch_delay_us(0)
+                lib.stream_wait(A)
+                lib.stream_wait(Y)
+            results[mode] = [t.numpy().copy() for t in (ht, dwt, wtt, mw)]
+        for x, y in zip(results["off"], results["on"]):
+            assert np.array_equal(x, y)
+        assert np.abs(results["on"][3]).max() > 0
+    finally:
+        lib.dll.nnc_mi355x_debug_peephole_launch_delay_us(0)
+        lib.dll.nnc_mi355x_set_peephole(1)
+        lib.stream_free(A)
+        lib.stream_free(Y)
+        lib.signal_free(S)
+
+
+def test_a_failure_of_a_trailed_update_reaches_the_streams_next_update(lib):
+    """an SGD_FORWARD that waited in a trail has no caller left when its replay fails; the failure is kept for its stream and the
+    NEXT SGD_FORWARD on that stream returns it, once (peephole.cpp sticky / deferred_take_error) -- never a silent success.  The failure is injected
+    (nnc_mi355x_debug_peephole_fail_trailed): a real one needs a launch that runs out of memory."""
+    rng = np.random.default_rng(41)
+    n, h, w, c, k = 2, 11, 12, 16, 32
+    hint = nnc.HINT((1, 1), (1, 1))
+    a = np.maximum(srnd(rng, n, h, w, c), 0)
+    g, wt, b = srnd(rng, n, h, w, k), srnd(rng, k, 3, 3, c, scale=1.0 / (9 * c)), srnd(rng, k, scale=0.05)
+    streams = [lib.stream_new(0) for _ in range(3)]
+    sigs = [lib.signal_new(0) for _ in range(3)]
+    trailed = getattr(lib.dll, "nnc_mi355x_debug_peephole_trailed")
+    trailed.restype = C.c_long
+    sgd = nnc.CMD_SGD_FORWARD(0, 0.01, 0.5, 0.0005, 0.9, 0.9)
+    try:
+        tensors = make_tensors(lib, nnc.GPU_MEMORY, [g, a, wt, np.full_like(a, 7), np.zeros_like(wt), np.zeros(k, F), np.zeros_like(wt), np.zeros(k, F), b])
+        gt, at, wtt, ht, dwt, dbt, mw, mb, bt = tensors
+        for trip in range(2):
+            _host_schedule_step(lib, tensors, streams, sigs, k, c, hint)
+            for s in streams:
+                lib.stream_wait(s)
+        t0 = trailed()
+        lib.dll.nnc_mi355x_debug_peephole_fail_trailed(nnc.EXEC_OOM)
+        _host_schedule_step(lib, tensors, streams, sigs, k, c, hint)  # every call reports success: the updates waited in the trail
+        for s in streams:
+            lib.stream_wait(s)
+        assert trailed() - t0 == 7
+        X, Y = streams[1], streams[2]
+        assert lib.cmd_exec(sgd, nnc.NO_HINT, 0, [dbt, bt, mb], [bt, mb], Y) == 0               # the other update stream is not blamed
+        assert lib.cmd_exec(sgd, nnc.NO_HINT, 0, [dwt, wtt, mw], [wtt, mw], X) == nnc.EXEC_OOM  # the first trailed update ran on X
+        assert lib.cmd_exec(sgd, nnc.NO_HINT, 0, [dwt, wtt, mw], [wtt, mw], X) == 0             # reported once
+        for s in streams:
+            lib.stream_wait(s)
+    finally:
+        lib.dll.nnc_mi355x_debug_peephole_fail_trailed(0)
+        for s in streams:
+            lib.stream_free(s)
+        for s in sigs:
+            lib.signal_free(s)
