@@ -196,14 +196,27 @@ def resnet_config(args, half, dawn=False):
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                            "kernel": "batch norm forward + backward commands (%s)" % "; ".join(sorted(set(k["name"] for k in bn))), "launches": n, "avg_ms": ms / n,
                            "ms_per_step": ms, "recorded_kernels": {k["name"][-100:]: {"ms": k["ms"], "launches": k["launches"], "tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0)} for k in ks}}
-    # half precision: the f16 contraction kernel with the most time in that recorded step, against the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
+    # half precision: the f16 contractions of the recorded step, each LAUNCH against the bound of its own shape: algorithmic
+    # FLOP per algorithmic byte under the machine balance 2.5 PFLOP/s / 8 TB/s = 312 -> HBM-bound (the 1 x 1 convolutions with 64 .. 512 channels), else bound by
+    # the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s).  Both fractions are reported; `bound` names the class with more of the step's time.
     f16k = [k for k in ks if "mfma_gemm_f16" in k["name"] and k["ms"] > 0 and k["flops"] > 0]
     if half and f16k:
         top = max(f16k, key=lambda k: k["ms"])
-        ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
         allf = sum(k["flops"] for k in f16k) / (sum(k["ms"] for k in f16k) * 1e-3) / 1e12
-        out["roofline_f16_contractions"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "kernel": top["name"][-100:],
-                                            "launches": top["launches"], "avg_ms": top["ms"] / top["launches"], "all_f16_contractions": {"achieved": allf, "ms": sum(k["ms"] for k in f16k)}}
+        by = h.get("f16_contractions_by_bound") or {}
+        mf, hb = by.get("mfma") or {}, by.get("hbm") or {}
+        cls = {}
+        if mf.get("ms", 0) > 0:
+            a = mf["flops"] / (mf["ms"] * 1e-3) / 1e12
+            cls["mfma_bound"] = {"achieved": a, "peak": 2500.0, "unit": "TFLOP/s", "frac": a / 2500.0, "ms": mf["ms"], "launches": mf["launches"]}
+        if hb.get("ms", 0) > 0:
+            a = hb["bytes"] / (hb["ms"] * 1e-3) / 1e9
+            cls["hbm_bound"] = {"achieved": a, "peak": 8000.0, "unit": "GB/s", "frac": a / 8000.0, "ms": hb["ms"], "launches": hb["launches"], "tflops": hb["flops"] / (hb["ms"] * 1e-3) / 1e12}
+        lead = "hbm_bound" if hb.get("ms", 0) > mf.get("ms", 0) else "mfma_bound"
+        if lead in cls:
+            out["roofline_f16_contractions"] = dict(cls[lead], bound="hbm" if lead == "hbm_bound" else "mfma", traffic=None, kernel="every f16 contraction launch whose shape is %s (FLOP / byte %s 312)" % ("HBM-bound" if lead == "hbm_bound" else "MFMA-bound", "<" if lead == "hbm_bound" else ">="),
+                                                    by_bound=cls, top_kernel={"name": top["name"][-100:], "ms": top["ms"], "launches": top["launches"], "tflops": top["flops"] / (top["ms"] * 1e-3) / 1e12},
+                                                    all_f16_contractions={"achieved_tflops": allf, "ms": sum(k["ms"] for k in f16k)})
     # one host thread enqueues for every device of the reference's single-process data parallelism (lib/nnc/ccv_nnc_graph_run.c:581-675): N x the
     # enqueue time of a step must stay under the GPU time of a step for the N-device form to scale
     he = h.get("host_enqueue")
@@ -241,7 +254,7 @@ def lstm_config(args):
                       "global_batch": B, "parallelism": "dp1", "timesteps_per_s": h["timesteps_per_s"], "gflop_per_step": h["gflop_per_step"]},
            # the row is bound by the hand-over between the workgroups of the one-launch kernel once per time step, not by a pipe: the
            # line reports its algorithmic rate against the fp32 matrix peak for scale
-           "roofline": {"bound": "mfma", "achieved": h["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": h["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+           "roofline": {"bound": "latency (the per-step chain of dependent LDS round trips; the fp32 matrix peak is quoted for scale only)", "achieved": h["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": h["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                         "kernel": "lstm_rows_forw_kernel / lstm_rows_back_kernel (hidden size <= 128: a workgroup per batch row, R in registers) + the batched input contractions", "launches": None, "avg_ms": None},
            "cpu_baseline": None}
     out["config"]["cpu_baseline_note"] = "the reference has no CPU LSTM (lib/nnc/cmd/rnn: GPU backend only): nothing to time beside it"
@@ -353,7 +366,7 @@ def extra_configs(args):
         e["workload"] = cfg.get("workload")
         for rk in ("roofline", "roofline_f16_contractions"):
             if rk in d:
-                e[rk] = {k: d[rk].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_ms") if k in d[rk]}
+                e[rk] = {k: d[rk].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_ms", "by_bound", "ms") if k in d[rk]}
                 if isinstance(e[rk].get("kernel"), str):
                     e[rk]["kernel"] = e[rk]["kernel"][:120]
         if "cpu_baseline" in d and d["cpu_baseline"]:
@@ -383,9 +396,55 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
+LINE_LIMIT = 7400  # the driver keeps an 8 KB tail of stdout: the ONE JSON line must fit it whole (the head of an 11.6 KB line was cut)
+
+
+def compact(out):
+    """The line as printed: every contract key, `roofline`, `cpu_baseline` and `config` in full; the extra configurations reduced to their numbers (value,
+    ms_per_step, roofline fractions, CPU baseline value, oracle gate verdict).  The full record goes to stderr (`bench.py full record: {...}`)."""
+    def slim_roof(r):
+        keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_ms") if k in r}
+        if isinstance(r.get("kernel"), str):
+            keep["kernel"] = r["kernel"][:60]
+        if "by_bound" in r:
+            keep["by_bound"] = {k: {kk: v.get(kk) for kk in ("achieved", "unit", "frac", "ms")} for k, v in r["by_bound"].items()}
+        return keep
+    o = json.loads(json.dumps(out))
+    if len(json.dumps(o)) <= LINE_LIMIT:
+        return o
+    for name, e in (o.get("extra_configs") or {}).items():
+        if not isinstance(e, dict) or "value" not in e:
+            continue
+        n = {k: e[k] for k in ("value", "unit", "ms_per_step", "dtype", "via_host_images_per_s", "whole_step_tflops_per_gpu", "wall_s") if k in e}
+        for rk in ("roofline", "roofline_f16_contractions"):
+            if rk in e:
+                n[rk] = slim_roof(e[rk])
+        if e.get("cpu_baseline"):
+            n["cpu_baseline"] = {k: e["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind")}
+        g = e.get("oracle_gate")
+        if isinstance(g, dict):
+            n["oracle_gate"] = {k: g[k] for k in ("ok", "step1_loss_per_image_max_rel_err", "rel_err", "tolerance", "bound") if k in g}
+        he = e.get("host_enqueue")
+        if isinstance(he, dict):
+            n["host_enqueue"] = {k: he.get(k) for k in ("ms_per_step_median", "commands_per_step", "devices_one_thread_can_feed")}
+        o["extra_configs"][name] = n
+    if len(json.dumps(o)) > LINE_LIMIT and isinstance(o.get("roofline"), dict) and "all_contractions" in o["roofline"]:
+        ac = o["roofline"]["all_contractions"]
+        o["roofline"]["all_contractions"] = {k: ac[k] for k in ("achieved", "ms") if k in ac}
+    if len(json.dumps(o)) > LINE_LIMIT and isinstance(o.get("roofline"), dict) and "recorded_kernels" in o["roofline"]:
+        del o["roofline"]["recorded_kernels"]
+    if len(json.dumps(o)) > LINE_LIMIT and isinstance(o.get("cpu_baseline"), dict) and isinstance(o["cpu_baseline"].get("sample"), str):
+        o["cpu_baseline"]["sample"] = o["cpu_baseline"]["sample"][:200]
+    return o
+
+
 def emit(out):
     claim_stdout()
-    _RESULT.write(json.dumps(out) + "\n")
+    line = json.dumps(compact(out))
+    full = json.dumps(out)
+    if line != full:
+        print("bench.py full record: " + full, file=sys.stderr)
+    _RESULT.write(line + "\n")
     _RESULT.flush()
 
 
@@ -480,7 +539,7 @@ def main():
         # ranks torch.distributed.run started -- this process never imports torch (its wheel's second HIP runtime, see ctl.py)
         from ccv_amd.ctl import LocalControl
         from ccv_amd.comm import ProcessComm
-        dist = LocalControl(rank, world)
+        dist = LocalControl(rank, world, deadline_s=float(os.environ.get("NNC_MI355X_CTL_DEADLINE_S", "3000")))  # a bench run is a bounded job: a rank that is alive but stuck ends it (exit 71)
         comm = ProcessComm(L, dist, rank, world)
 
     # parameters, images and labels from the counter hash tools/host_vgg_bench.c uses too: the command driver (this process),
@@ -658,6 +717,7 @@ def main():
             out["config"]["via_host"] = via_host(args, step1_losses, step1_params, fwd_only)
             # the drop-in number (the unmodified reference host driving this backend), next to `value` (ccv_amd/vgg.py, the command driver)
             out["via_host_images_per_s"] = out["config"]["via_host"].get("images_per_s")
+            out["config"]["via_host_images_per_s"] = out["via_host_images_per_s"]  # (also inside `config`: the driver's parsed record keeps that object whole)
         if not args.no_cpu_baseline and world > 1:
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "reference", "sample": "timed at N = 1 only (python bench.py --gpus 1)"}
         elif not args.no_cpu_baseline:

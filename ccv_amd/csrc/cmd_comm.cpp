@@ -52,6 +52,7 @@ clique_t* clique_of(const void* ctx, int device_count)
 	for (int i = 0; i < device_count; i++) devs[i] = i;
 	int cur = 0;
 	HIP_ENFORCE(hipGetDevice(&cur));
+	nnc_mi355x_pool_trim(-1); // the communicators' buffers come from the driver: the blocks this library keeps for reuse go back first
 	RCCL_ENFORCE(ncclCommInitAll(c->comm, device_count, devs));
 	HIP_ENFORCE(hipSetDevice(cur));
 	g_cliques.push_back(c);
@@ -240,7 +241,7 @@ int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size
 	pthread_mutex_lock(&g_comm_mutex);
 	int ret = 0;
 	if (g_rank_comm) ret = -1;
-	else if (ncclCommInitRank(&g_rank_comm, world_size, id, rank) != ncclSuccess) { g_rank_comm = 0; ret = -2; }
+	else if ((nnc_mi355x_pool_trim(-1), ncclCommInitRank(&g_rank_comm, world_size, id, rank)) != ncclSuccess) { g_rank_comm = 0; ret = -2; }
 	else { g_rank = rank; g_world = world_size; }
 	pthread_mutex_unlock(&g_comm_mutex);
 	return ret;

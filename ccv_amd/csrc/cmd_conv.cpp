@@ -1051,8 +1051,11 @@ static bool conv_h_planar_ok(const conv_geom_t& g, const long M, const int N, co
 }
 
 // planar != 0: the result goes to that NCHW tensor [N][K][OH * OW] (b is not written)
+// what a half-precision convolution moves once: input, filter, output (the launch record's algorithmic bytes: bench.py's per-shape bound)
+static double conv_h_bytes(const conv_geom_t& g) { return 2.0 * ((double)g.N * g.H * g.W * g.C + (double)g.K * g.kh * g.kw * g.Cg + (double)g.N * g.OH * g.OW * g.K); }
 static int conv_forw_h(const conv_geom_t& g, const Image4& a, const void* w, const void* bias, const Image4& b, const int flags, ccv_nnc_stream_context_t* const ctx, void* const planar = 0)
 {
+	prof_next_bytes(conv_h_bytes(g));
 	const long M = (long)g.N * g.OH * g.OW;
 	const int Kred = g.kh * g.kw * g.Cg;
 	GemmOutH out = { (half_t*)b.p, b.sw, 1, (const half_t*)bias, 1.f, 0, 0 };
@@ -1074,6 +1077,7 @@ static int conv_forw_h(const conv_geom_t& g, const Image4& a, const void* w, con
 
 static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, const Image4& h, const int flags, ccv_nnc_stream_context_t* const ctx, void* const planar = 0)
 {
+	prof_next_bytes(conv_h_bytes(g));
 	const long M = (long)g.N * g.H * g.W;
 	const int Kred = g.kh * g.kw * g.Kg;
 	GemmOutH out = { (half_t*)h.p, h.sw, 1, 0, 1.f, 0, 0 };
@@ -1100,6 +1104,7 @@ static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, c
 
 static int conv_wgrad_h(const conv_geom_t& g, const Image4& gr, const Image4& a, void* dw, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
+	prof_next_bytes(conv_h_bytes(g));
 	const long P = (long)g.N * g.OH * g.OW;
 	const int NN = g.kh * g.kw * g.Cg;
 	GemmOutH out = { (half_t*)dw, (long)NN, 1, 0, 1.f, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0, 0 };

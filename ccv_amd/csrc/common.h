@@ -194,6 +194,8 @@ struct ProfScope {
 	~ProfScope();
 };
 
+void prof_next_bytes(double bytes); // the algorithmic bytes of this thread's next contraction record (a ProfScope given bytes < 0 takes them; else it uses -bytes)
+
 // Marker range around one command (device_rt.cpp; on after nnc_mi355x_set_profiler(1) / cusetprofiler(1) or NNC_MI355X_MARKERS=1).
 struct MarkerScope {
 	int active;

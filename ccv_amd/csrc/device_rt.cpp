@@ -6,6 +6,10 @@
 #include <pthread.h>
 #include <dlfcn.h>
 #include <vector>
+#include <list>
+#include <deque>
+#include <mutex>
+#include <unordered_map>
 
 namespace {
 
@@ -72,6 +76,8 @@ int current_device()
 }
 
 void release_device_block(void* ptr, bool drained); // memory from nnc_mi355x_malloc goes back the way it came (the caching layer further down)
+void pool_stream_created(int device, hipStream_t st);   // ... whose frees are ordered against every stream the library makes: each one is registered
+void pool_stream_destroyed(int device, hipStream_t st);
 
 bool is_any(const ccv_nnc_stream_context_t* ctx) { return (ctx->type & CCV_COMPUTE_DEVICE_ANY) == CCV_COMPUTE_DEVICE_ANY; }
 
@@ -96,6 +102,7 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 	if (!l->stream) {
 		l->device = device;
 		HIP_ENFORCE(hipStreamCreateWithFlags(&l->stream, hipStreamDefault)); // blocking w.r.t. the NULL stream, see ccv_nnc_init_stream_context
+		pool_stream_created(device, l->stream);
 	}
 	return l;
 }
@@ -266,7 +273,7 @@ const float* zero_page_of(const ccv_nnc_stream_context_t* ctx)
 			const int prev = current_device();
 			void* ptr = 0;
 			HIP_ENFORCE(hipSetDevice(device));
-			HIP_ENFORCE(hipMalloc(&ptr, 256));
+			if (hipMalloc(&ptr, 256) != hipSuccess) { (void)hipGetLastError(); nnc_mi355x_pool_trim(device); HIP_ENFORCE(hipMalloc(&ptr, 256)); } // (the kept blocks are this process's to give back)
 			HIP_ENFORCE(hipMemset(ptr, 0, 256));
 			HIP_ENFORCE(hipDeviceSynchronize());
 			HIP_ENFORCE(hipSetDevice(prev));
@@ -339,9 +346,14 @@ static pthread_mutex_t g_prof_mutex = PTHREAD_MUTEX_INITIALIZER;
 static std::vector<prof_rec_t*>& g_prof = *new std::vector<prof_rec_t*>; // (never destroyed, as above)
 static volatile int g_prof_on = 0;
 
+// Algorithmic bytes of the NEXT contraction record of this thread (a convolution knows its tensors; the launcher underneath only sees an implicit matrix
+// whose M x K counts every input pixel kh * kw times): taken by the next ProfScope that was given bytes < 0, cleared by it.
+static thread_local double tl_prof_next_bytes = 0;
+void prof_next_bytes(const double bytes) { if (g_prof_on) tl_prof_next_bytes = bytes; }
 ProfScope::ProfScope(const char* name, double flops, double bytes, int M, int N, int K, int Z, int S, hipStream_t st) : rec(0), stream(st)
 {
 	if (!g_prof_on) return;
+	if (bytes < 0) { bytes = tl_prof_next_bytes > 0 ? tl_prof_next_bytes : -bytes; tl_prof_next_bytes = 0; }
 	prof_rec_t* r = new prof_rec_t;
 	snprintf(r->name, sizeof(r->name), "%s", name);
 	r->flops = flops; r->bytes = bytes;
@@ -383,23 +395,39 @@ extern "C" {
 // ROCm 7.2 memory from the pool is not interchangeable with hipMalloc's for this library's mix of blocking copies, default-stream kernels and stream-ordered
 // work, for reasons not understood.  The layer below involves no runtime feature beyond hipMalloc / hipFree / hipDeviceSynchronize.
 static int g_pool_mode = -1;
-static pthread_mutex_t g_pool_mutex = PTHREAD_MUTEX_INITIALIZER;
-struct kept_block_t { void* ptr; size_t size; };
-static std::vector<kept_block_t>* const g_kept = new std::vector<kept_block_t>[MAX_DEVICES]; // free blocks, newest last (never destroyed: cufree may arrive from a thread that outlives the exit handlers)
-static std::vector<kept_block_t>* const g_live = new std::vector<kept_block_t>[MAX_DEVICES]; // blocks handed out (ptr -> rounded size); a few hundred entries at most: linear search
-static std::atomic<long> g_pool_allocs(0), g_pool_retries(0), g_pool_kept_bytes(0), g_pool_live_bytes(0), g_pool_trimmed(0);
-static size_t g_kept_dev_bytes[MAX_DEVICES]; // bytes on g_kept[device] (under the mutex)
-static size_t g_keep_cap[MAX_DEVICES];       // 0 = not read yet
+// Round 6: the free is STREAM-ORDERED, no device drain.  What hipFree guarantees its caller -- nothing queued on the device can still touch the block -- is
+// kept by a FENCE taken at the free: one event recorded on every stream of the device that still has work in flight (every stream this library ever makes
+// is registered below; the legacy NULL stream counts as one), attached to the kept block.  A block is handed out again when its fence has completed; if
+// only unfinished blocks of the size are kept, the allocation waits for the oldest one's events (the wait hipFree would have performed at the free, moved to
+// the one place that needs it and almost never reached).  Idle streams are skipped (hipStreamQuery), so a run of frees behind a synchronize records nothing.
+// (Why the runtime's own pool misbehaved in round 5: a hipFreeAsync queued on the legacy stream orders the block's reuse against THAT stream only -- and a block
+// reused by an allocation whose first user is a blocking copy or another stream is not ordered against the kernels still queued elsewhere.  The fence below
+// names every stream.)  Blocks go back to the driver through hipFree, which drains the device itself.
+struct pool_fence_t { std::vector<hipEvent_t> events; int refs; bool done; };
+struct kept_block_t { void* ptr; size_t size; pool_fence_t* fence; };
+typedef std::list<kept_block_t> kept_list_t;
+struct pool_device_t {
+	std::mutex mutex;                                                     // per device (one device's allocation no longer stalls the others)
+	kept_list_t kept;                                                     // free blocks, oldest first
+	std::unordered_map<size_t, std::deque<kept_list_t::iterator> > by_size; // the same blocks by rounded size, newest last
+	std::unordered_map<void*, size_t> live;                               // blocks handed out (ptr -> rounded size)
+	std::vector<hipStream_t> streams;                                     // the library's live streams on this device
+	std::vector<hipEvent_t> spare;                                        // events of completed fences
+	size_t kept_bytes, keep_cap;                                          // keep_cap 0 = not read yet
+};
+static pool_device_t* const g_pool = new pool_device_t[MAX_DEVICES](); // (never destroyed: cufree may arrive from a thread that outlives the exit handlers)
+static std::atomic<long> g_pool_allocs(0), g_pool_retries(0), g_pool_kept_bytes(0), g_pool_live_bytes(0), g_pool_trimmed(0), g_pool_fence_events(0), g_pool_fence_waits(0);
 static size_t pool_keep_cap(const int device)
-{ // (caller holds the mutex; the device is current)
-	if (!g_keep_cap[device]) {
+{ // (caller holds the device's mutex; the device is current)
+	pool_device_t& d = g_pool[device];
+	if (!d.keep_cap) {
 		const char* e = getenv("NNC_MI355X_POOL_KEEP_MB");
 		size_t free_b = 0, total_b = 0;
-		if (e && *e) g_keep_cap[device] = ((size_t)strtoull(e, 0, 10) << 20) + 1; // (+ 1: "0 MB" is a cap too, not "unread")
-		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) g_keep_cap[device] = total_b / 2;
-		else { (void)hipGetLastError(); g_keep_cap[device] = (size_t)64 << 30; }
+		if (e && *e) d.keep_cap = ((size_t)strtoull(e, 0, 10) << 20) + 1; // (+ 1: "0 MB" is a cap too, not "unread")
+		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) d.keep_cap = total_b / 4; // a quarter of the device (half starved the process's other allocators)
+		else { (void)hipGetLastError(); d.keep_cap = (size_t)32 << 30; }
 	}
-	return g_keep_cap[device];
+	return d.keep_cap;
 }
 static bool pool_on(void)
 {
@@ -414,25 +442,97 @@ static size_t pool_round(const size_t size)
 	const size_t g = size < ((size_t)1 << 20) ? 512 : (size_t)2 << 20;
 	return (size + g - 1) / g * g;
 }
+// -- fences (caller holds the device's mutex, the device is current)
+static void fence_unref(pool_device_t& d, pool_fence_t* const f)
+{
+	if (!f || --f->refs > 0) return;
+	for (hipEvent_t e : f->events) d.spare.push_back(e); // (an unfinished fence nobody refers to: its events are re-recorded when they are taken again)
+	delete f;
+}
+static bool fence_done(pool_device_t& d, pool_fence_t* const f)
+{
+	if (!f || f->done) return true;
+	while (!f->events.empty()) {
+		const hipError_t r = hipEventQuery(f->events.back());
+		if (r == hipErrorNotReady) { (void)hipGetLastError(); return false; }
+		HIP_ENFORCE(r);
+		d.spare.push_back(f->events.back());
+		f->events.pop_back();
+	}
+	f->done = true;
+	return true;
+}
+static void fence_wait(pool_device_t& d, pool_fence_t* const f)
+{
+	if (!f || f->done) return;
+	for (hipEvent_t e : f->events) { HIP_ENFORCE(hipEventSynchronize(e)); d.spare.push_back(e); }
+	f->events.clear();
+	f->done = true;
+	g_pool_fence_waits.fetch_add(1, std::memory_order_relaxed);
+}
+static pool_fence_t* fence_take(pool_device_t& d)
+{ // everything queued on the device so far: an event behind every stream that is not idle.  0 = the device is idle.
+	pool_fence_t* f = 0;
+	auto behind = [&](hipStream_t st) {
+		const hipError_t q = hipStreamQuery(st);
+		if (q == hipSuccess) return;
+		if (q != hipErrorNotReady) HIP_ENFORCE(q);
+		(void)hipGetLastError();
+		hipEvent_t e;
+		if (!d.spare.empty()) { e = d.spare.back(); d.spare.pop_back(); }
+		else HIP_ENFORCE(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		HIP_ENFORCE(hipEventRecord(e, st));
+		if (!f) { f = new pool_fence_t; f->refs = 0; f->done = false; }
+		f->events.push_back(e);
+		g_pool_fence_events.fetch_add(1, std::memory_order_relaxed);
+	};
+	for (hipStream_t st : d.streams) behind(st);
+	behind((hipStream_t)0);
+	return f;
+}
+static void pool_drop_kept(pool_device_t& d, kept_list_t::iterator it)
+{ // (caller holds the mutex) off both indexes; the caller owns the block now
+	std::deque<kept_list_t::iterator>& q = d.by_size[it->size];
+	for (size_t i = 0; i < q.size(); i++) if (q[i] == it) { q.erase(q.begin() + (long)i); break; }
+	if (q.empty()) d.by_size.erase(it->size);
+	d.kept_bytes -= it->size;
+	g_pool_kept_bytes.fetch_sub((long)it->size, std::memory_order_relaxed);
+	d.kept.erase(it);
+}
 static void pool_release_all(const int device)
-{ // (caller holds the mutex) every kept block of the device back to the driver
-	for (const kept_block_t& k : g_kept[device]) { HIP_ENFORCE(hipFree(k.ptr)); g_pool_kept_bytes.fetch_sub((long)k.size, std::memory_order_relaxed); }
-	g_kept[device].clear();
-	g_kept_dev_bytes[device] = 0;
+{ // (caller holds the mutex) every kept block of the device back to the driver (hipFree drains the device: the fences need not be waited for)
+	pool_device_t& d = g_pool[device];
+	for (kept_block_t& k : d.kept) { HIP_ENFORCE(hipFree(k.ptr)); fence_unref(d, k.fence); g_pool_kept_bytes.fetch_sub((long)k.size, std::memory_order_relaxed); }
+	d.kept.clear();
+	d.by_size.clear();
+	d.kept_bytes = 0;
 }
 static void pool_trim(const int device)
-{ // (caller holds the mutex) oldest first, until the kept bytes fit the cap; every kept block was drained when it was freed
+{ // (caller holds the mutex) oldest first, until the kept bytes fit the cap
+	pool_device_t& d = g_pool[device];
 	const size_t cap = pool_keep_cap(device);
-	std::vector<kept_block_t>& kept = g_kept[device];
-	size_t n = 0;
-	while (n < kept.size() && g_kept_dev_bytes[device] > cap) {
-		HIP_ENFORCE(hipFree(kept[n].ptr));
-		g_kept_dev_bytes[device] -= kept[n].size;
-		g_pool_kept_bytes.fetch_sub((long)kept[n].size, std::memory_order_relaxed);
+	while (!d.kept.empty() && d.kept_bytes > cap) {
+		const kept_block_t k = d.kept.front();
+		pool_drop_kept(d, d.kept.begin());
+		HIP_ENFORCE(hipFree(k.ptr));
+		fence_unref(d, k.fence);
 		g_pool_trimmed.fetch_add(1, std::memory_order_relaxed);
-		n++;
 	}
-	if (n) kept.erase(kept.begin(), kept.begin() + (long)n);
+}
+namespace {
+void pool_stream_created(const int device, hipStream_t st)
+{
+	if (device < 0 || device >= MAX_DEVICES || !st) return;
+	std::lock_guard<std::mutex> lock(g_pool[device].mutex);
+	g_pool[device].streams.push_back(st);
+}
+void pool_stream_destroyed(const int device, hipStream_t st)
+{ // (the caller has synchronized the stream: fences that name it are complete as far as it is concerned)
+	if (device < 0 || device >= MAX_DEVICES || !st) return;
+	std::lock_guard<std::mutex> lock(g_pool[device].mutex);
+	std::vector<hipStream_t>& v = g_pool[device].streams;
+	for (size_t i = 0; i < v.size(); i++) if (v[i] == st) { v[i] = v.back(); v.pop_back(); break; }
+}
 }
 
 void* nnc_mi355x_malloc(int device, size_t size)
@@ -449,31 +549,54 @@ void* nnc_mi355x_malloc(int device, size_t size)
 		return ptr;
 	}
 	const size_t rounded = pool_round(size ? size : 1);
-	pthread_mutex_lock(&g_pool_mutex);
-	std::vector<kept_block_t>& kept = g_kept[device];
-	for (size_t i = kept.size(); i-- > 0;)
-		if (kept[i].size == rounded) {
-			ptr = kept[i].ptr;
-			kept.erase(kept.begin() + (long)i);
-			g_kept_dev_bytes[device] -= rounded;
-			g_pool_kept_bytes.fetch_sub((long)rounded, std::memory_order_relaxed);
-			g_pool_allocs.fetch_add(1, std::memory_order_relaxed);
-			break;
-		}
-	if (!ptr && (hipMalloc(&ptr, rounded) != hipSuccess || !ptr)) {
-		(void)hipGetLastError();
-		ptr = 0;
-		pool_release_all(device);
-		pthread_mutex_unlock(&g_pool_mutex);
-		trigger_mem_pressure(); // the host drops its caches: they come back through nnc_mi355x_free (and are kept -- so release once more before the retry)
-		pthread_mutex_lock(&g_pool_mutex);
-		pool_release_all(device);
-		g_pool_retries.fetch_add(1, std::memory_order_relaxed);
-		if (hipMalloc(&ptr, rounded) != hipSuccess) { (void)hipGetLastError(); ptr = 0; }
+	pool_device_t& d = g_pool[device];
+	std::unique_lock<std::mutex> lock(d.mutex);
+	auto found = d.by_size.find(rounded);
+	if (found != d.by_size.end() && !found->second.empty()) {
+		std::deque<kept_list_t::iterator>& q = found->second;
+		kept_list_t::iterator take = d.kept.end();
+		for (size_t i = q.size(); i-- > 0;) if (fence_done(d, q[i]->fence)) { take = q[i]; break; } // the newest block nothing can touch any more
+		if (take == d.kept.end()) { take = q.front(); fence_wait(d, take->fence); }                    // none: wait for the oldest one's last users
+		ptr = take->ptr;
+		fence_unref(d, take->fence);
+		pool_drop_kept(d, take);
+		g_pool_allocs.fetch_add(1, std::memory_order_relaxed);
 	}
-	if (ptr) { g_live[device].push_back(kept_block_t{ ptr, rounded }); g_pool_live_bytes.fetch_add((long)rounded, std::memory_order_relaxed); }
-	pthread_mutex_unlock(&g_pool_mutex);
+	if (!ptr) {
+		lock.unlock(); // (the driver call runs without the lock: 33 - 42 ms for a gigabyte)
+		if (hipMalloc(&ptr, rounded) != hipSuccess || !ptr) {
+			(void)hipGetLastError();
+			ptr = 0;
+			lock.lock();
+			pool_release_all(device);
+			lock.unlock();
+			trigger_mem_pressure(); // the host drops its caches: they come back through nnc_mi355x_free (and are kept -- so release once more before the retry)
+			lock.lock();
+			pool_release_all(device);
+			lock.unlock();
+			g_pool_retries.fetch_add(1, std::memory_order_relaxed);
+			if (hipMalloc(&ptr, rounded) != hipSuccess) { (void)hipGetLastError(); ptr = 0; }
+		}
+		lock.lock();
+	}
+	if (ptr) { d.live[ptr] = rounded; g_pool_live_bytes.fetch_add((long)rounded, std::memory_order_relaxed); }
 	return ptr;
+}
+
+// Every kept block of the device (device < 0: of every device) back to the driver: before another allocator of the process needs the memory -- RCCL's
+// communicator buffers (cmd_comm.cpp), this library's own direct allocations when they fail -- and for hosts that want the bytes back.
+void nnc_mi355x_pool_trim(const int device)
+{
+	if (!pool_on()) return;
+	const int prev = current_device();
+	for (int dev = (device < 0 ? 0 : device); dev < (device < 0 ? MAX_DEVICES : device + 1) && dev < MAX_DEVICES; dev++) {
+		pool_device_t& d = g_pool[dev];
+		std::lock_guard<std::mutex> lock(d.mutex);
+		if (d.kept.empty()) continue;
+		HIP_ENFORCE(hipSetDevice(dev));
+		pool_release_all(dev);
+	}
+	HIP_ENFORCE(hipSetDevice(prev));
 }
 
 } // extern "C"
@@ -484,26 +607,26 @@ void release_device_block(void* ptr, const bool drained)
 	if (!ptr) return;
 	const int device = current_device();
 	if (pool_on() && device >= 0 && device < MAX_DEVICES) {
-		pthread_mutex_lock(&g_pool_mutex);
-		std::vector<kept_block_t>& live = g_live[device];
-		size_t at = live.size();
-		for (size_t i = live.size(); i-- > 0;) if (live[i].ptr == ptr) { at = i; break; }
-		if (at < live.size()) {
-			const kept_block_t k = live[at];
-			live[at] = live.back();
-			live.pop_back();
-			pthread_mutex_unlock(&g_pool_mutex);
-			if (!drained) HIP_ENFORCE(hipDeviceSynchronize()); // hipFree's own guarantee
-			pthread_mutex_lock(&g_pool_mutex);
-			g_kept[device].push_back(k);
-			g_kept_dev_bytes[device] += k.size;
+		pool_device_t& d = g_pool[device];
+		std::unique_lock<std::mutex> lock(d.mutex);
+		auto at = d.live.find(ptr);
+		if (at != d.live.end()) {
+			kept_block_t k = { ptr, at->second, 0 };
+			d.live.erase(at);
+			if (!drained && (k.fence = fence_take(d))) k.fence->refs++;
+			d.kept.push_back(k);
+			d.by_size[k.size].push_back(std::prev(d.kept.end()));
+			d.kept_bytes += k.size;
 			g_pool_live_bytes.fetch_sub((long)k.size, std::memory_order_relaxed);
 			g_pool_kept_bytes.fetch_add((long)k.size, std::memory_order_relaxed);
 			pool_trim(device);
-			pthread_mutex_unlock(&g_pool_mutex);
 			return;
 		}
-		pthread_mutex_unlock(&g_pool_mutex); // not one of ours (allocated before the switch was read, or by the plain path): the driver's free
+		// not handed out by the layer.  A block that is on the kept list is being freed TWICE: hipFree would take it from under the list, and the next
+		// allocation of its size would hand out unmapped memory -- stop here, as hipFree's own error used to
+		for (const kept_block_t& k : d.kept)
+			if (k.ptr == ptr) { fprintf(stderr, "[nnc_mi355x] double free of device memory %p (device %d, %zu bytes)\n", ptr, device, k.size); abort(); }
+		lock.unlock(); // allocated before the switch was read, or by the plain path: the driver's free
 	}
 	HIP_ENFORCE(hipFree(ptr));
 }
@@ -527,6 +650,12 @@ void nnc_mi355x_debug_pool_counts(long* allocs, long* retries, long* reserved_by
 }
 
 long nnc_mi355x_debug_pool_trimmed(void) { return g_pool_trimmed.load(std::memory_order_relaxed); }
+// events recorded by frees (0 for a free that found every stream idle) and allocations that had to wait for a kept block's last users
+void nnc_mi355x_debug_pool_fences(long* events, long* waits)
+{
+	if (events) *events = g_pool_fence_events.load(std::memory_order_relaxed);
+	if (waits) *waits = g_pool_fence_waits.load(std::memory_order_relaxed);
+}
 
 void nnc_mi355x_set_device(int device)
 {
@@ -621,6 +750,7 @@ ccv_nnc_stream_context_t* ccv_nnc_init_stream_context(ccv_nnc_stream_context_t* 
 		// directions -- cnnp initialises parameters and copies them between models on the NULL stream, then runs the compiled
 		// graph on its streams (a non-blocking stream let the first evaluate read uninitialised weights on the MI355X).
 		HIP_ENFORCE(hipStreamCreateWithFlags(&s->one.stream, hipStreamDefault));
+		pool_stream_created(s->one.device, s->one.stream);
 		HIP_ENFORCE(hipSetDevice(prev));
 	}
 	return (ccv_nnc_stream_context_t*)s;
@@ -637,7 +767,7 @@ static void local_release(device_local_t* l)
 	if (l->staging) release_device_block(l->staging, true);
 	if (l->palette) release_device_block(l->palette, true);
 	if (l->cluster_sync) release_device_block(l->cluster_sync, true);
-	if (l->stream) HIP_ENFORCE(hipStreamDestroy(l->stream));
+	if (l->stream) { pool_stream_destroyed(l->device, l->stream); HIP_ENFORCE(hipStreamDestroy(l->stream)); }
 	l->workspace = 0; l->workspace_size = 0; l->staging = 0; l->staging_size = 0; l->palette = 0; l->palette_size = 0; l->stream = 0; l->cluster_sync = 0;
 	HIP_ENFORCE(hipSetDevice(prev));
 }
@@ -930,6 +1060,7 @@ void* nnc_mi355x_staging_ring_new(int device, int slots, size_t slot_bytes)
 	r->state = new std::atomic<int>[slots]; r->copy_pending = new std::atomic<int>[slots]; r->consumed_set = new std::atomic<int>[slots];
 	for (int i = 0; i < slots; i++) { r->state[i] = RING_FREE; r->copy_pending[i] = 0; r->consumed_set[i] = 0; }
 	bool ok = hipStreamCreate(&r->copy_stream) == hipSuccess; // a blocking stream like every stream of this library: orders against the legacy NULL stream
+	if (ok) pool_stream_created(device, r->copy_stream);
 	for (int i = 0; ok && i < slots; i++) {
 		ok = hipHostMalloc(&r->host[i], slot_bytes, hipHostMallocDefault) == hipSuccess && (r->dev[i] = nnc_mi355x_malloc(device, slot_bytes)) != 0
 			&& hipEventCreateWithFlags(&r->copied[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r->consumed[i], hipEventDisableTiming) == hipSuccess;
@@ -996,7 +1127,7 @@ void nnc_mi355x_staging_ring_free(void* ring)
 	staging_ring_t* r = (staging_ring_t*)ring;
 	if (!r) return;
 	DeviceGuard guard(r->device);
-	if (r->copy_stream) { (void)hipStreamSynchronize(r->copy_stream); (void)hipStreamDestroy(r->copy_stream); }
+	if (r->copy_stream) { (void)hipStreamSynchronize(r->copy_stream); pool_stream_destroyed(r->device, r->copy_stream); (void)hipStreamDestroy(r->copy_stream); }
 	for (int i = 0; i < r->slots; i++) {
 		if (r->host && r->host[i]) (void)hipHostFree(r->host[i]);
 		if (r->dev && r->dev[i]) nnc_mi355x_free(r->device, r->dev[i]);

@@ -278,7 +278,8 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 		EpiStoreH epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
 		epi.vec = epi_vec_ok(out.c, sizeof(half_t), out.ldm, out.ldn, N, zcount, c_z);
-		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
+		if (epi.vec && tune(TUNE_GEMM_VEC_EPILOGUE) != 3 && out.ldm % 8 == 0 && N % 8 == 0 && ((uintptr_t)out.c & 15) == 0 && (zcount <= 1 || c_z % 8 == 0)) epi.vec = 2; // 16-byte stores (TUNE_GEMM_VEC_EPILOGUE = 3: 8-byte ones, measurements)
+		ProfScope prof(prof_name, flops, -2.0 * zcount * ((double)M * K + (double)N * K + (double)M * N), M, N, K, zcount, 1, stream);
 		if (v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN, 8>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
@@ -291,7 +292,7 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
 	epi.vec = tune(TUNE_GEMM_VEC_EPILOGUE) && N % 4 == 0;
 	{
-		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
+		ProfScope prof(prof_name, flops, -2.0 * zcount * ((double)M * K + (double)N * K + (double)M * N), M, N, K, zcount, splits, stream);
 		if (v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiPartialH, WM, WN, 8>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiPartialH, WM, WN>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L, ko);
 	}
@@ -321,6 +322,7 @@ static int gemm_run_h_planar(const char* name, LA la, LB lb, EpiStoreHT epi, con
 	la.finish();
 	lb.finish();
 	epi.d_p.init(epi.P);
+	epi.vec = (tune(TUNE_GEMM_VEC_EPILOGUE) != 3 && epi.P % 8 == 0 && M % 8 == 0 && (((uintptr_t)epi.c) & 15) == 0) ? 2 : 1; // eight pixels of a plane per store (16 bytes) where the planes allow
 	const half_t* zp = (const half_t*)zero_page_of(ctx);
 	la.zoff = zp - (const half_t*)la.p;
 	lb.zoff = zp - (const half_t*)lb.p;
@@ -330,7 +332,7 @@ static int gemm_run_h_planar(const char* name, LA la, LB lb, EpiStoreHT epi, con
 	const bool big = g_force_tile ? !((g_force_tile & 0xff) == 1 && (g_force_tile >> 8) == 1) : (!small_tiles && M > 64 && N > 64 && (big_tiles >= device_cu_count() || K >= 4096));
 	char prof_name[192];
 	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_kernel<%d, %d> EPI = EpiStoreHT", name, big ? 2 : 1, big ? 2 : 1);
-	ProfScope prof(prof_name, 2.0 * (double)M * (double)N * (double)K, 0, M, N, K, 1, 1, stream);
+	ProfScope prof(prof_name, 2.0 * (double)M * (double)N * (double)K, -2.0 * ((double)M * K + (double)N * K + (double)M * N), M, N, K, 1, 1, stream);
 	const bool v8 = tune(TUNE_GEMM_HALF_CHUNK8) && loader_vec8_ok(la) && loader_vec8_ok(lb);
 	if (big && v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 2, 2, 8>), dim3((unsigned)big_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 127) / 128, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
 	else if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 2, 2>), dim3((unsigned)big_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 127) / 128, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
@@ -375,7 +377,8 @@ static int gemm_run_buf_tile_h(const char* name, const BufMatLoader<AKC>& la, co
 		EpiStoreH epi;
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
 		epi.vec = epi_vec_ok(out.c, sizeof(half_t), out.ldm, out.ldn, N, zcount, c_z);
-		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
+		if (epi.vec && tune(TUNE_GEMM_VEC_EPILOGUE) != 3 && out.ldm % 8 == 0 && N % 8 == 0 && ((uintptr_t)out.c & 15) == 0 && (zcount <= 1 || c_z % 8 == 0)) epi.vec = 2; // 16-byte stores (TUNE_GEMM_VEC_EPILOGUE = 3: 8-byte ones, measurements)
+		ProfScope prof(prof_name, flops, -2.0 * zcount * ((double)M * K + (double)N * K + (double)M * N), M, N, K, zcount, 1, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiStoreH, TM, TN, WM, WN, BK>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(64 * WM * WN), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, 1, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
@@ -387,7 +390,7 @@ static int gemm_run_buf_tile_h(const char* name, const BufMatLoader<AKC>& la, co
 	epi.c = ws; epi.bias = 0; epi.slab = slab; epi.M = M; epi.N = N;
 	epi.vec = tune(TUNE_GEMM_VEC_EPILOGUE) && N % 4 == 0;
 	{
-		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, splits, stream);
+		ProfScope prof(prof_name, flops, -2.0 * zcount * ((double)M * K + (double)N * K + (double)M * N), M, N, K, zcount, splits, stream);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiPartialH, TM, TN, WM, WN, BK>), dim3((unsigned)(tiles * splits), 1, (unsigned)zcount), dim3(64 * WM * WN), 0, stream, la, lb, epi, tiles_m, tiles_n, K, k_per_split, splits, a_z, b_z, slab * splits, 0L);
 	}
 	HIP_ENFORCE(hipGetLastError());

@@ -587,21 +587,36 @@ static int filter_axis_map(const int n, const int k, std::vector<filter_map_t>& 
 
 // ---- the 8-bit area path's tap tables, per geometry, resident on the device (a few KB each; the least recently used of 16 gives way)
 namespace {
-struct area_tables_t { int a_rows, a_cols, b_rows, b_cols, ch, device, live; double sx, sy; char* dev; size_t oxs, oxt, oys, oyt, oe16, oe4; int e_pitch, maxt; unsigned inv; unsigned long stamp; };
+struct area_tables_t { int a_rows, a_cols, b_rows, b_cols, ch, device, live, pins; double sx, sy; char* dev; size_t oxs, oxt, oys, oyt, oe16, oe4; int e_pitch, maxt; unsigned inv; unsigned long stamp; };
 area_tables_t g_area_tables[16];
 unsigned long g_area_stamp = 0;
 pthread_mutex_t g_area_mutex = PTHREAD_MUTEX_INITIALIZER;
-char* area_8u_tables(const int a_rows, const int a_cols, const int b_rows, const int b_cols, const int ch, const double sx, const double sy, size_t* oxs, size_t* oxt, size_t* oys, size_t* oyt, unsigned* inv, size_t* oe16, size_t* oe4, int* e_pitch, int* maxt)
+// The caller holds the returned table PINNED until its kernel has been enqueued (area_8u_unpin): a concurrent thread that needs a slot takes the least recently
+// used UNPINNED one, and frees its table outside the mutex (the table could be evicted and freed between this function's return and the launch;
+// the free -- stream-ordered since round 6 -- covers only what has been enqueued).  All 16 slots pinned (17 threads resampling 17 geometries at once): the new
+// table is not cached, *one_shot tells the caller to free it behind its launch.
+void area_8u_unpin(char* const dev, const bool one_shot, const int device)
+{
+	if (one_shot) { nnc_mi355x_free(device, dev); return; }
+	pthread_mutex_lock(&g_area_mutex);
+	for (area_tables_t& e : g_area_tables) if (e.live && e.dev == dev) { if (e.pins > 0) e.pins--; break; }
+	pthread_mutex_unlock(&g_area_mutex);
+}
+char* area_8u_tables(bool* const one_shot, const int a_rows, const int a_cols, const int b_rows, const int b_cols, const int ch, const double sx, const double sy, size_t* oxs, size_t* oxt, size_t* oys, size_t* oyt, unsigned* inv, size_t* oe16, size_t* oe4, int* e_pitch, int* maxt)
 {
 	int device = 0;
 	HIP_ENFORCE(hipGetDevice(&device));
 	pthread_mutex_lock(&g_area_mutex);
+	*one_shot = false;
 	area_tables_t* hit = 0;
-	area_tables_t* lru = &g_area_tables[0];
+	area_tables_t* lru = 0;
 	for (area_tables_t& e : g_area_tables) {
 		if (e.live && e.a_rows == a_rows && e.a_cols == a_cols && e.b_rows == b_rows && e.b_cols == b_cols && e.ch == ch && e.device == device && e.sx == sx && e.sy == sy) { hit = &e; break; }
-		if (!e.live || (lru->live && e.stamp < lru->stamp)) lru = &e;
+		if (e.live && e.pins > 0) continue;
+		if (!lru || (lru->live && (!e.live || e.stamp < lru->stamp))) lru = &e;
 	}
+	char* evicted = 0;
+	int evicted_device = 0;
 	if (!hit) {
 		std::vector<int> xs, ys;
 		std::vector<tap_u32_t> xt, yt;
@@ -628,18 +643,26 @@ char* area_8u_tables(const int a_rows, const int a_cols, const int b_rows, const
 		e.dev = (char*)nnc_mi355x_malloc(device, u.host.size());
 		if (!e.dev) { *inv = 1; pthread_mutex_unlock(&g_area_mutex); return 0; }
 		HIP_ENFORCE(hipMemcpy(e.dev, u.host.data(), u.host.size(), hipMemcpyHostToDevice)); // (once per geometry)
-		if (lru->live) { // queued kernels may still read it: the free is stream-ordered behind them (or waits for the device)
-			nnc_mi355x_free(lru->device, lru->dev);
-			HIP_ENFORCE(hipSetDevice(device));
+		e.a_rows = a_rows; e.a_cols = a_cols; e.b_rows = b_rows; e.b_cols = b_cols; e.ch = ch; e.device = device; e.live = 1; e.pins = 0; e.sx = sx; e.sy = sy; e.inv = *inv;
+		if (!lru) { // every slot is pinned by a launch in progress: hand the table out uncached
+			*one_shot = true;
+			*oxs = e.oxs; *oxt = e.oxt; *oys = e.oys; *oyt = e.oyt; *oe16 = e.oe16; *oe4 = e.oe4; *e_pitch = e.e_pitch; *maxt = e.maxt;
+			pthread_mutex_unlock(&g_area_mutex);
+			return e.dev;
 		}
-		e.a_rows = a_rows; e.a_cols = a_cols; e.b_rows = b_rows; e.b_cols = b_cols; e.ch = ch; e.device = device; e.live = 1; e.sx = sx; e.sy = sy; e.inv = *inv;
+		if (lru->live) { evicted = lru->dev; evicted_device = lru->device; } // queued kernels may still read it: freed below, stream-ordered behind them
 		*lru = e;
 		hit = lru;
 	}
 	hit->stamp = ++g_area_stamp;
+	hit->pins++;
 	*oxs = hit->oxs; *oxt = hit->oxt; *oys = hit->oys; *oyt = hit->oyt; *inv = hit->inv; *oe16 = hit->oe16; *oe4 = hit->oe4; *e_pitch = hit->e_pitch; *maxt = hit->maxt;
 	char* const dev = hit->dev;
 	pthread_mutex_unlock(&g_area_mutex);
+	if (evicted) { // (outside the mutex: the free may flush recorded commands and take other locks)
+		nnc_mi355x_free(evicted_device, evicted);
+		HIP_ENFORCE(hipSetDevice(device));
+	}
 	return dev;
 }
 }
@@ -672,8 +695,11 @@ int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, 
 			size_t oxs, oxt, oys, oyt, oe16, oe4;
 			int e_pitch, maxt;
 			unsigned inv_scale_256;
-			char* const dev = area_8u_tables(ad.rows, ad.cols, bd.rows, bd.cols, ch, scale_x, scale_y, &oxs, &oxt, &oys, &oyt, &inv_scale_256, &oe16, &oe4, &e_pitch, &maxt);
+			bool one_shot = false;
+			char* const dev = area_8u_tables(&one_shot, ad.rows, ad.cols, bd.rows, bd.cols, ch, scale_x, scale_y, &oxs, &oxt, &oys, &oyt, &inv_scale_256, &oe16, &oe4, &e_pitch, &maxt);
 			if (!dev) return inv_scale_256 == 0 ? CCV_NNC_EXEC_INVALID : CCV_NNC_EXEC_OOM;
+			int tables_device = 0;
+			HIP_ENFORCE(hipGetDevice(&tables_device));
 			// one workgroup per output row (area_8u_rows_kernel) when rows are dword-aligned on both sides and the row's column sums fit the LDS
 			const long a_cols_ch = (long)ad.cols * ch;
 			const bool al4 = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)ad.step | (uintptr_t)ad.image_stride | (uintptr_t)bd.step | (uintptr_t)bd.image_stride) & 3) == 0;
@@ -692,6 +718,7 @@ int nnc_mi355x_resample_batch(const void* a, const nnc_mi355x_image_batch_t ad, 
 			} else
 			hipLaunchKernelGGL(area_8u_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned char*)a, (unsigned char*)b, ad.step, ad.image_stride, bd.step, bd.image_stride, bd.rows, bd.cols * ch, ch,
 				(const int*)(dev + oxs), (const tap_u32_t*)(dev + oxt), (const int*)(dev + oys), (const tap_u32_t*)(dev + oyt), inv_scale_256, total);
+			area_8u_unpin(dev, one_shot, tables_device); // the kernel is in the stream: the table may be evicted (its free is ordered behind the kernel)
 		} else {
 			std::vector<int> xs, ys;
 			std::vector<tap_f32_t> xt, yt;

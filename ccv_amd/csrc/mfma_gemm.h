@@ -518,9 +518,27 @@ struct EpiPartial {
 // The row-major read-back of a staged block-tile slice: `cs` holds ROWS x BN accumulators (row pitch BN + 8 floats: the two half-waves of a staging write --
 // four rows apart -- land 32 banks apart, and rows stay 16-byte aligned); thread t takes 16-byte vectors t, t + NT, ... and hands each to the epilogue's
 // store4 with the output row the staged row stands for (row_of) -- consecutive lanes = consecutive 16 bytes of one output row.
+// the same in vectors of EIGHT (half-precision outputs with vec == 2: one 16-byte store per lane)
+template <class EPI> struct epi_has_store8 { template <class E> static auto test(int) -> decltype(&E::store8, char()); template <class E> static long test(...); static constexpr bool value = sizeof(test<EPI>(0)) == 1; };
+template <int NT, int ROWS, int BN, class EPI, class ROWOF>
+__device__ __forceinline__ void epi_flush_rows8(const float* const cs, const EPI& epi, const int m0, const int n0, const int t, const ROWOF& row_of)
+{
+	constexpr int PITCH = BN + 8, V = BN / 8, TOTAL = ROWS * V;
+	static_assert(TOTAL % NT == 0, "whole vectors per thread");
+#pragma unroll EPI::FLUSH_UNROLL
+	for (int j = 0; j < TOTAL / NT; j++) {
+		const int id = t + NT * j;
+		const int sr = id / V, c8 = id - sr * V;
+		const float4 lo = *(const float4*)(cs + sr * PITCH + 8 * c8), hi = *(const float4*)(cs + sr * PITCH + 8 * c8 + 4);
+		epi.store8(m0 + row_of(sr), n0 + 8 * c8, lo, hi);
+	}
+}
 template <int NT, int ROWS, int BN, class EPI, class ROWOF>
 __device__ __forceinline__ void epi_flush_rows(const float* const cs, const EPI& epi, const int m0, const int n0, const int t, const ROWOF& row_of)
 {
+	if constexpr (epi_has_store8<EPI>::value) {
+		if (epi.vec == 2) { epi_flush_rows8<NT, ROWS, BN>(cs, epi, m0, n0, t, row_of); return; }
+	}
 	constexpr int PITCH = BN + 8, V = BN / 4, TOTAL = ROWS * V;
 	static_assert(TOTAL % NT == 0, "whole vectors per thread");
 	// (EPI::FLUSH_UNROLL vectors in flight per thread -- two where the epilogue loads a bias / the old value, one for the plain slab stores: fully unrolled, the eight read-backs of a 128-column slice and their bias / old-value loads cost ~20 more

@@ -12,11 +12,13 @@ A dead or stuck rank must not hang the job: a rank that has died leaves its peer
 host timeout reaches).  Every rank therefore keeps a second, otherwise silent connection in the same star (the LIVENESS socket) and a watchdog thread on it:
 end-of-file without the orderly goodbye byte means the peer's process is gone -- rank 0 sees any rank die, every rank sees rank 0 die, and rank 0 going down
 takes the rest with it -- and the watchdog ends the process at once (exit code 70, a line on stderr) instead of waiting on the GPU.  An overall deadline
-(NNC_MI355X_CTL_DEADLINE_S, default 3000 s) covers a rank that is alive but stuck (exit code 71).
+(NNC_MI355X_CTL_DEADLINE_S seconds, or `deadline_s`; OFF unless asked for -- a healthy job may run for days) covers a rank that is alive but stuck (exit code 71).
+A rank that ends normally says goodbye even if its caller forgot destroy_process_group() (an atexit hook): only a process that DIES reads as a death.
 
 The class answers the subset of torch.distributed's module interface ccv_amd.comm.ProcessComm uses (broadcast_object_list,
 barrier, all_gather_object), so either can be passed as its `dist`.
 """
+import atexit
 import os
 import pickle
 import select
@@ -70,9 +72,10 @@ class LocalControl:
         if watchdog:
             self.live = self._connect_liveness(rank, world, timeout)
             if deadline_s is None:
-                deadline_s = float(os.environ.get("NNC_MI355X_CTL_DEADLINE_S", "3000"))
+                deadline_s = float(os.environ.get("NNC_MI355X_CTL_DEADLINE_S", "0") or 0)  # 0 = no deadline (50 minutes by default killed healthy jobs)
             t = threading.Thread(target=self._watch, args=(time.time() + deadline_s if deadline_s > 0 else None,), daemon=True)
             t.start()
+            atexit.register(self._goodbye)  # a normal interpreter exit without destroy_process_group() is not a death
 
     def _connect(self, rank, world, timeout):
         if rank == 0:
@@ -185,13 +188,18 @@ class LocalControl:
     def reduce_max(self, x):
         return max(self.all_gather(float(x)))
 
-    def destroy_process_group(self):
+    def _goodbye(self):
+        if self._closing:
+            return
         self._closing = True
         for c in self.live:  # the orderly goodbye: end-of-file WITHOUT it is what the peers' watchdogs read as a death
             try:
                 c.sendall(b"Q")
             except OSError:
                 pass
+
+    def destroy_process_group(self):
+        self._goodbye()
         for p in self.peers:
             p.close()
         if self.sock:

@@ -418,14 +418,22 @@ void nnc_mi355x_debug_peephole_counts(long* recorded, long* folded, long* plain)
  * operations are kept behind the recorded command, in arrival order, and replayed right behind it when it launches; nothing else can observe the difference
  * (peephole.cpp).  NNC_MI355X_PEEPHOLE_TRAIL=0 restores the flush at the first of them.  Test hook: operations that have waited in a trail so far. */
 long nnc_mi355x_debug_peephole_trailed(void);
-/* Device memory (nnc_mi355x_malloc / _free = cumalloc / cufree): freed blocks are kept per device and (rounded) size and handed out again (device_rt.cpp).  A
- * free drains the device first -- hipFree's own guarantee -- and the block skips the driver both ways (hipMalloc of 1 GB: 33 - 42 ms on the MI355X box).  Under
- * memory pressure every kept block goes back to the driver, the host's curegmp callbacks run, the allocation is retried.  NNC_MI355X_POOL_ALLOC=0 selects plain
- * hipMalloc / hipFree.  Hook: allocations served from kept blocks, pressure retries, bytes held (kept + handed out) and bytes handed out. */
+/* Device memory (nnc_mi355x_malloc / _free = cumalloc / cufree, lib/nnc/gpu/ccv_nnc_compat.cu:101-141; the layer lib/nnc/ccv_nnc_xpu_alloc.c sits on): freed
+ * blocks are kept per device and (rounded) size and handed out again (device_rt.cpp).  The free is STREAM-ORDERED (round 6): it records an event behind every
+ * stream of the device that still has work in flight and returns -- no device drain --; the block is handed out again once those events have completed (an
+ * allocation that finds only unfinished blocks of its size waits for the oldest one's).  Under memory pressure every kept block goes back to the driver, the
+ * host's curegmp callbacks run, the allocation is retried.  Freeing a block twice aborts.  NNC_MI355X_POOL_ALLOC=0 selects plain hipMalloc / hipFree.
+ * Hook: allocations served from kept blocks, pressure retries, bytes held (kept + handed out) and bytes handed out. */
 void nnc_mi355x_debug_pool_counts(long* allocs, long* retries, long* reserved_bytes, long* used_bytes);
-/* The kept bytes are bounded per device (half the device's memory; NNC_MI355X_POOL_KEEP_MB overrides): beyond the cap the oldest kept blocks go back to the
- * driver.  Hook: blocks returned that way so far. */
+/* The kept bytes are bounded per device (a quarter of the device's memory; NNC_MI355X_POOL_KEEP_MB overrides): beyond the cap the oldest kept blocks go back to
+ * the driver.  Hook: blocks returned that way so far. */
 long nnc_mi355x_debug_pool_trimmed(void);
+/* Every kept block of `device` (< 0: of every device) back to the driver now: for a host that is about to let another allocator of the process (a communicator
+ * library, a second framework) use the device's memory.  The library calls it itself before it creates RCCL communicators and when one of its own direct
+ * allocations fails. */
+void nnc_mi355x_pool_trim(int device);
+/* Hook: events recorded by frees (a free that finds every stream idle records none) and allocations that had to wait for a kept block's last users. */
+void nnc_mi355x_debug_pool_fences(long* events, long* waits);
 /* batch-norm commands that ran on the cluster kernels (cmd_norm.cpp: a cluster of workgroups per channel keeps the channel in registers between the
  * statistics and the apply pass; NNC_MI355X_BN_CLUSTER=0 / nnc_mi355x_tune_set("BN_CLUSTER", 0) selects the plane kernels). */
 long nnc_mi355x_debug_bn_cluster_launches(void);

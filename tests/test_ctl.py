@@ -108,3 +108,34 @@ time.sleep(600)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE="2"), stderr=subprocess.PIPE, text=True) for r in range(2)]
     errs = [p.communicate(timeout=60)[1] for p in procs]
     assert sorted(p.returncode for p in procs)[-1] == 71 and all(p.returncode in (70, 71) for p in procs), ([p.returncode for p in procs], errs)
+
+
+GOING = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+from ccv_amd.ctl import LocalControl
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+c = LocalControl(rank, world, timeout=60)
+c.barrier()
+if rank == 1:
+    sys.exit(0)              # done early, and its caller forgot destroy_process_group(): a normal exit, not a death
+time.sleep(3)
+c.barrier() if False else None
+c.destroy_process_group()
+'''
+
+
+def test_a_rank_that_exits_normally_is_not_a_death_and_there_is_no_default_deadline(tmp_path):
+    """ADVICE round 5: (a) a rank that finishes and leaves the interpreter without destroy_process_group() says goodbye from an atexit hook -- its peers
+    keep running (they used to stop with exit code 70); (b) the job deadline is off unless asked for (it defaulted to 3000 s and killed healthy long jobs)."""
+    import time
+    from ccv_amd import ctl
+    import inspect
+    assert '"NNC_MI355X_CTL_DEADLINE_S", "0"' in inspect.getsource(ctl.LocalControl.__init__)
+    script = tmp_path / "g.py"
+    script.write_text(GOING % dict(root=ROOT))
+    env = dict(os.environ, MASTER_PORT="29661", TORCHELASTIC_RUN_ID="t4", TMPDIR=str(tmp_path))
+    env.pop("NNC_MI355X_CTL_DEADLINE_S", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE="3", LOCAL_RANK=str(r)), stderr=subprocess.PIPE, text=True) for r in range(3)]
+    errs = [p.communicate(timeout=60)[1] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0], ([p.returncode for p in procs], errs)

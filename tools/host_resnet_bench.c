@@ -571,6 +571,9 @@ int main(int argc, char** argv)
 	SYNC_ALL();
 	struct { char name[192]; double ms, flops, bytes; int n; } agg[64];
 	int nagg = 0;
+	/* the half-precision contractions of the step by what bounds each LAUNCH: algorithmic FLOP per algorithmic byte under the machine balance
+	 * (2.5 PFLOP/s / 8 TB/s = 312) = HBM-bound (the 1 x 1 convolutions with 64 .. 512 channels), else matrix-pipe-bound */
+	struct { double ms, flops, bytes; int n; } f16b[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } }; /* [0] mfma-bound, [1] hbm-bound */
 	const int nrec = nnc_mi355x_profile_count();
 	FILE* const recf = getenv("HOST_BENCH_RECORDS") ? fopen(getenv("HOST_BENCH_RECORDS"), "w") : 0; /* every launch of that step: name, dims, ms, TFLOP/s, GB/s */
 	for (i = 0; i < nrec; i++) {
@@ -580,6 +583,10 @@ int main(int argc, char** argv)
 		int dims[5], k;
 		nnc_mi355x_profile_get(i, name, 256, &fl, &by, &rms, dims);
 		if (recf) fprintf(recf, "%4d %-150s dims %d %d %d %d %d  %8.4f ms  %7.1f TFLOP/s  %7.1f GB/s\n", i, name, dims[0], dims[1], dims[2], dims[3], dims[4], rms, rms > 0 ? fl / (rms * 1e-3) / 1e12 : 0.0, rms > 0 ? by / (rms * 1e-3) / 1e9 : 0.0);
+		if (strstr(name, "mfma_gemm_f16") && fl > 0 && by > 0 && rms > 0) {
+			const int hb = fl / by < 2.5e15 / 8e12 ? 1 : 0;
+			f16b[hb].ms += rms; f16b[hb].flops += fl; f16b[hb].bytes += by; f16b[hb].n++;
+		}
 		char* bar = strchr(name, '|'); /* aggregate per KERNEL symbol (behind '|') */
 		const char* key = bar ? bar + 1 : name;
 		for (k = 0; k < nagg; k++) if (strncmp(agg[k].name, key, 191) == 0) break;
@@ -616,6 +623,8 @@ int main(int argc, char** argv)
 		}
 	}
 	printf("{\"replica_probe_sumsq\": [%.17g, %.17g], ", probe_sq[0], probe_sq[1]);
+	printf("\"f16_contractions_by_bound\": {\"mfma\": {\"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}, \"hbm\": {\"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}}, ",
+		f16b[0].n, f16b[0].ms, f16b[0].flops, f16b[0].bytes, f16b[1].n, f16b[1].ms, f16b[1].flops, f16b[1].bytes);
 	printf("\"kernels\": [");
 	for (i = 0; i < nagg; i++) printf("%s{\"name\": \"%s\", \"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}", i ? ", " : "", agg[i].name, agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes);
 	printf("], ");
