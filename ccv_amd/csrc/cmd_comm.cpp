@@ -18,6 +18,8 @@
 #include <pthread.h>
 #include <dlfcn.h>
 #include <vector>
+#include <unordered_map>
+#include <algorithm>
 
 using namespace nnc;
 
@@ -90,10 +92,93 @@ int g_pending_n = 0;
 long g_stat_collectives = 0, g_stat_groups = 0;
 thread_local int tl_in_comm = 0; // stream_of() calls made while recording / flushing must not recurse into the flush
 
+// ---- Overlap (round 6; deployment (b) only, opt-in).  The reference's own data parallelism puts an all-reduce node behind every gradient in ONE graph and its
+// scheduler runs them on other streams while backward continues (lib/nnc/ccv_nnc_symbolic_graph_parallel.c:545-575).  One process per GPU drives the
+// unmodified model API: ccv_cnnp_model_backward enqueues the whole backward pass, THEN the host issues one COMM_ALLREDUCE per parameter on the same stream --
+// issued immediately they would all run behind the last backward kernel.  With the mode on:
+//   * CONVOLUTION_ / GEMM_ / BATCH_NORM_BACKWARD record an event behind the kernels that wrote each weight / bias gradient (comm_gradient_written);
+//   * a flush sorts the recorded all-reduces by the order their gradients were WRITTEN (backward produces the last layer's first, the host lists the first
+//     layer's first), cuts them into buckets of ~NNC_MI355X_COMM_BUCKET_MB (default 32; xGMI is point-to-point: few large launches), and issues each bucket as
+//     one group on the COMMUNICATION stream behind its own gradients' events only -- the GPU is still in the forward pass at that moment, so every bucket
+//     starts the moment its last gradient lands and the rest of backward runs beside it;
+//   * every other stream joins the communication stream at its next order-observing point (device_rt.cpp joined(): launch, synchronise, signal, callback).
+// Every rank runs the same program, so every rank sorts and cuts alike: the collectives meet in the same order.  A gradient with no record (another command
+// wrote it: accumulation, a row without the hook) waits for the tail of the stream its all-reduce was issued on -- the order of immediate issue.
+struct ready_t { hipEvent_t ev; unsigned long seq; };
+std::unordered_map<const void*, ready_t>& g_ready = *new std::unordered_map<const void*, ready_t>;
+std::vector<hipEvent_t>& g_ready_pool = *new std::vector<hipEvent_t>;
+unsigned long g_ready_seq = 0;
+int g_overlap_set = -1; // nnc_mi355x_comm_overlap(): -1 = the environment decides
+hipStream_t g_overlap_stream = 0;
+hipEvent_t g_overlap_done = 0;
+long g_stat_buckets = 0, g_stat_overlapped = 0;
+bool overlap_wanted()
+{
+	static const int env = (getenv("NNC_MI355X_COMM_OVERLAP") && *getenv("NNC_MI355X_COMM_OVERLAP") == '1') ? 1 : 0;
+	return (g_overlap_set >= 0 ? g_overlap_set : env) != 0;
+}
+hipEvent_t ready_event()
+{ // g_comm_mutex held
+	hipEvent_t e;
+	if (!g_ready_pool.empty()) { e = g_ready_pool.back(); g_ready_pool.pop_back(); }
+	else HIP_ENFORCE(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	return e;
+}
+size_t bucket_bytes()
+{
+	static size_t b = 0;
+	if (!b) { const char* const e = getenv("NNC_MI355X_COMM_BUCKET_MB"); const double mb = e ? atof(e) : 32.0; b = mb > 0 ? (size_t)(mb * 1048576.0) + 1 : 1; }
+	return b;
+}
+bool overlapped_flush_locked()
+{ // g_comm_mutex held, g_pending_n > 0.  false: not this form (anything but in-process-rank all-reduces is pending) -- the caller issues everything in place
+	if (!g_rank_comm || !overlap_wanted()) return false;
+	for (int i = 0; i < g_pending_n; i++) if (g_pending[i].op != 0 || g_pending[i].comm != g_rank_comm) return false;
+	if (!g_overlap_stream) { // blocking, like every stream of this library: the legacy stream orders against it; known to the allocator's fences (device_rt.cpp)
+		HIP_ENFORCE(hipStreamCreateWithFlags(&g_overlap_stream, hipStreamDefault));
+		int dev = 0;
+		HIP_ENFORCE(hipGetDevice(&dev));
+		stream_registered(dev, g_overlap_stream);
+	}
+	struct item_t { int i; unsigned long seq; hipEvent_t ev; bool mine; };
+	std::vector<item_t> items((size_t)g_pending_n);
+	for (int i = 0; i < g_pending_n; i++) {
+		const pending_t& p = g_pending[i];
+		auto at = g_ready.find(p.in);
+		if (at != g_ready.end()) { items[i] = item_t{ i, at->second.seq, at->second.ev, true }; g_ready.erase(at); }
+		else { // unknown writer: the tail of the issuing stream, now
+			const hipEvent_t e = ready_event();
+			HIP_ENFORCE(hipEventRecord(e, p.stream));
+			items[i] = item_t{ i, ++g_ready_seq, e, true };
+		}
+	}
+	std::stable_sort(items.begin(), items.end(), [](const item_t& a, const item_t& b) { return a.seq < b.seq; });
+	size_t at = 0;
+	while (at < items.size()) {
+		size_t end = at, bytes = 0;
+		while (end < items.size() && (end == at || bytes < bucket_bytes())) { const pending_t& p = g_pending[items[end].i]; bytes += p.count * (p.dt == ncclHalf ? 2 : 4); end++; }
+		for (size_t k = at; k < end; k++) HIP_ENFORCE(hipStreamWaitEvent(g_overlap_stream, items[k].ev, 0));
+		RCCL_ENFORCE(ncclGroupStart());
+		for (size_t k = at; k < end; k++) { const pending_t& p = g_pending[items[k].i]; RCCL_ENFORCE(ncclAllReduce(p.in, p.out, p.count, p.dt, ncclSum, p.comm, g_overlap_stream)); }
+		RCCL_ENFORCE(ncclGroupEnd());
+		g_stat_groups++; g_stat_buckets++;
+		at = end;
+	}
+	for (const item_t& it : items) g_ready_pool.push_back(it.ev); // (the waits have been enqueued: an event may be re-recorded)
+	if (!g_overlap_done) HIP_ENFORCE(hipEventCreateWithFlags(&g_overlap_done, hipEventDisableTiming));
+	HIP_ENFORCE(hipEventRecord(g_overlap_done, g_overlap_stream));
+	g_stat_collectives += g_pending_n; g_stat_overlapped += g_pending_n;
+	g_pending_n = 0;
+	nnc::g_comm_pending = 0;
+	nnc::g_comm_overlap_epoch.fetch_add(1, std::memory_order_release);
+	return true;
+}
+
 void flush_locked()
 {
 	if (!g_pending_n) return;
 	tl_in_comm++;
+	if (overlapped_flush_locked()) { tl_in_comm--; return; }
 	int cur = 0;
 	HIP_ENFORCE(hipGetDevice(&cur));
 	RCCL_ENFORCE(ncclGroupStart());
@@ -242,7 +327,7 @@ int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size
 	int ret = 0;
 	if (g_rank_comm) ret = -1;
 	else if ((nnc_mi355x_pool_trim(-1), ncclCommInitRank(&g_rank_comm, world_size, id, rank)) != ncclSuccess) { g_rank_comm = 0; ret = -2; }
-	else { g_rank = rank; g_world = world_size; }
+	else { g_rank = rank; g_world = world_size; nnc::g_comm_overlap_on = overlap_wanted() ? 1 : 0; }
 	pthread_mutex_unlock(&g_comm_mutex);
 	return ret;
 }
@@ -260,10 +345,30 @@ void nnc_mi355x_comm_stats(long* collectives, long* groups)
 	*collectives = g_stat_collectives; *groups = g_stat_groups;
 	pthread_mutex_unlock(&g_comm_mutex);
 }
+/* Deployment (b): overlap the gradient all-reduces with the backward pass (see "Overlap" above).  on = 1 / 0; -1 = back to the environment's choice
+ * (NNC_MI355X_COMM_OVERLAP).  Call it between steps, with nothing in flight. */
+void nnc_mi355x_comm_overlap(const int on)
+{
+	nnc::comm_flush_if_pending();
+	pthread_mutex_lock(&g_comm_mutex);
+	g_overlap_set = on < 0 ? -1 : (on ? 1 : 0);
+	nnc::g_comm_overlap_on = (g_rank_comm && overlap_wanted()) ? 1 : 0;
+	pthread_mutex_unlock(&g_comm_mutex);
+}
+/* all-reduces that went out overlapped, and the buckets (group launches) they went out in */
+void nnc_mi355x_comm_overlap_stats(long* const collectives, long* const buckets)
+{
+	pthread_mutex_lock(&g_comm_mutex);
+	if (collectives) *collectives = g_stat_overlapped;
+	if (buckets) *buckets = g_stat_buckets;
+	pthread_mutex_unlock(&g_comm_mutex);
+}
 void nnc_mi355x_comm_destroy(void)
 {
 	pthread_mutex_lock(&g_comm_mutex);
 	flush_locked();
+	nnc::g_comm_overlap_on = 0;
+	if (g_overlap_stream) HIP_ENFORCE(hipStreamSynchronize(g_overlap_stream)); // the last buckets
 	if (g_rank_comm) { (void)ncclCommDestroy(g_rank_comm); g_rank_comm = 0; }
 	pthread_mutex_unlock(&g_comm_mutex);
 }
@@ -272,6 +377,35 @@ void nnc_mi355x_comm_destroy(void)
 
 namespace nnc {
 std::atomic<int> g_comm_pending(0);
+std::atomic<int> g_comm_overlap_on(0);
+std::atomic<unsigned long> g_comm_overlap_epoch(0);
+void comm_gradient_written(const ccv_nnc_tensor_t* const t, ccv_nnc_stream_context_t* const ctx)
+{
+	if (!t || !g_comm_overlap_on.load(std::memory_order_relaxed)) return;
+	const hipStream_t st = stream_peek(ctx);
+	pthread_mutex_lock(&g_comm_mutex);
+	ready_t& r = g_ready[(const void*)t->data.u8];
+	if (!r.ev) r.ev = ready_event();
+	HIP_ENFORCE(hipEventRecord(r.ev, st));
+	r.seq = ++g_ready_seq;
+	if (g_ready.size() > 65536) { for (auto& kv : g_ready) g_ready_pool.push_back(kv.second.ev); g_ready.clear(); } // (a caller that never all-reduces what it reports)
+	pthread_mutex_unlock(&g_comm_mutex);
+}
+void comm_gradient_touched(const ccv_nnc_tensor_t* const t)
+{
+	if (!t || !g_comm_overlap_on.load(std::memory_order_relaxed)) return;
+	pthread_mutex_lock(&g_comm_mutex);
+	auto at = g_ready.find((const void*)t->data.u8);
+	if (at != g_ready.end()) { g_ready_pool.push_back(at->second.ev); g_ready.erase(at); }
+	pthread_mutex_unlock(&g_comm_mutex);
+}
+void comm_overlap_join(hipStream_t stream, unsigned long* const seen)
+{
+	pthread_mutex_lock(&g_comm_mutex);
+	if (g_overlap_done && stream != g_overlap_stream) HIP_ENFORCE(hipStreamWaitEvent(stream, g_overlap_done, 0));
+	*seen = g_comm_overlap_epoch.load(std::memory_order_acquire);
+	pthread_mutex_unlock(&g_comm_mutex);
+}
 void comm_flush(void)
 { // called (through the g_comm_pending check) by stream_of, synchronise, signals, callbacks: see "Coalescing" above
 	if (tl_in_comm) return;

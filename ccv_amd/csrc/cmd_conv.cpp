@@ -1391,18 +1391,27 @@ static int _conv_back_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 	if (r == CCV_NNC_EXEC_SUCCESS) deferred_mark_good(sig);
 	return r;
 }
+// the weight / bias gradients of a backward command that has just been enqueued: the overlapped all-reduce of deployment (b) starts behind THEM, not behind
+// the rest of the backward pass (cmd_comm.cpp "Overlap"); an accumulating command is one of several writers: stream order for that gradient
+static int conv_back_report(const int r, const int flags, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
+{
+	if (r == CCV_NNC_EXEC_SUCCESS && g_comm_overlap_on.load(std::memory_order_relaxed))
+		for (int i = 1; i < output_size && i < 3; i++)
+			if (outputs[i]) { if (flags & CCV_NNC_ACCUMULATE_OUTPUT) comm_gradient_touched(outputs[i]); else comm_gradient_written(outputs[i], stream_context); }
+	return r;
+}
 static int conv_back_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	MarkerScope marker(cmd.cmd);
-	if (cmd.algorithm < 0 || !(cmd.algorithm & NNC_MI355X_CONV_ALGO_FUSE_RELU)) return conv_back_dispatch(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	if (cmd.algorithm < 0 || !(cmd.algorithm & NNC_MI355X_CONV_ALGO_FUSE_RELU)) return conv_back_report(conv_back_dispatch(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context), flags, outputs, output_size, stream_context);
 	ccv_nnc_cmd_t plain = cmd;
 	plain.algorithm = (cmd.algorithm & 0xff) == 0xff ? -1 : (cmd.algorithm & 0xff);
 	ccv_nnc_tensor_t* const h = output_size > 0 ? outputs[0] : 0;
 	const ccv_nnc_tensor_t* const a = input_size > 1 ? inputs[1] : 0;
-	if (!h) return conv_back_dispatch(plain, hint, flags, inputs, input_size, outputs, output_size, stream_context); // no data gradient asked for: nothing to mask
+	if (!h) return conv_back_report(conv_back_dispatch(plain, hint, flags, inputs, input_size, outputs, output_size, stream_context), flags, outputs, output_size, stream_context); // no data gradient asked for: nothing to mask
 	if ((flags & CCV_NNC_ACCUMULATE_OUTPUT) || !a || !tensor_contiguous(h) || !tensor_contiguous(a) || h->info.datatype != a->info.datatype || h->info.format != a->info.format || tensor_count(h->info) != tensor_count(a->info)) return CCV_NNC_EXEC_INVALID;
 	tl_mask_want = 1; tl_mask_done = 0;
-	const int r = conv_back_dispatch(plain, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	const int r = conv_back_report(conv_back_dispatch(plain, hint, flags, inputs, input_size, outputs, output_size, stream_context), flags, outputs, output_size, stream_context);
 	const int done = tl_mask_done;
 	tl_mask_want = 0; tl_mask_done = 0; tl_mask.p = 0;
 	if (r != CCV_NNC_EXEC_SUCCESS || done) return r;

@@ -181,6 +181,41 @@ __global__ void __launch_bounds__(EW_THREADS) sgd_kernel_v4(const float4* g, con
 	}
 }
 
+// ---- multi-tensor SGD (round 6): ONE launch updates up to SGD_MULTI_MAX parameter tensors.  ResNet-50's step ends with ~200 SGD_FORWARD commands (5 - 18 us
+// each, most of it launch latency: 4 % of the f16 step, and one host enqueue each); the look-ahead (peephole.cpp) keeps consecutive updates of a stream and
+// hands them over together.  A workgroup finds its tensor by walking the table of first-block indices (wave-uniform: scalar loads out of the kernel
+// arguments), then does exactly what sgd_kernel_h8 / sgd_kernel_v4 / sgd_kernel do for its vector -- the same expression per element, bit-identical results.
+constexpr int SGD_MULTI_MAX = 25; // = one recorded update + a full trail (peephole.cpp TRAIL_MAX)
+struct sgd_multi_t { const void* g[SGD_MULTI_MAX]; const void* a[SGD_MULTI_MAX]; const void* m[SGD_MULTI_MAX]; void* b[SGD_MULTI_MAX]; void* nm[SGD_MULTI_MAX]; size_t cnt[SGD_MULTI_MAX]; unsigned first[SGD_MULTI_MAX + 1]; };
+template <class T, int W> // W elements per thread: 8 halves / 4 floats (16-byte accesses; every tensor's count a multiple of W, pointers 16-byte aligned), or 1
+__global__ void __launch_bounds__(EW_THREADS) sgd_multi_kernel(const sgd_multi_t s, const int n, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening)
+{
+	int k = 0;
+	while (k + 1 < n && blockIdx.x >= s.first[k + 1]) k++;
+	const size_t i = (size_t)(blockIdx.x - s.first[k]) * EW_THREADS + threadIdx.x;
+	if (i * W >= s.cnt[k]) return;
+	typedef T V __attribute__((ext_vector_type(W)));
+	const V gv = ((const V*)s.g[k])[i], av = ((const V*)s.a[k])[i], mv = ((const V*)s.m[k])[i];
+	V bo, no;
+#pragma unroll
+	for (int e = 0; e < W; e++) {
+		const float avf = (float)av[e];
+		if (nesterov) {
+			float grad = scale * (float)gv[e];
+			const float mom = momentum * (float)mv[e] + grad + decay * avf;
+			no[e] = (T)mom;
+			grad += momentum * mom;
+			bo[e] = (T)(avf - rate * grad);
+		} else {
+			const float mom = momentum * (float)mv[e] + inv_dampening * (scale * (float)gv[e] + decay * avf);
+			no[e] = (T)mom;
+			bo[e] = (T)(avf - rate * mom);
+		}
+	}
+	((V*)s.nm[k])[i] = no;
+	((V*)s.b[k])[i] = bo;
+}
+
 // ---- column sum: out[c] (+)= sum_r x[r*ld + c].  Stage 1: grid (col tiles of 64, row slices); each wave owns one
 // row phase, lanes = 64 consecutive columns (256-byte coalesced rows); stage 2 folds the slices in fixed order. ------
 constexpr int CS_COLS = 64, CS_PHASES = 4;
@@ -282,6 +317,7 @@ static int _ewsum_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 {
 	// recorded when its like has run before: the in-place RELU_FORWARD behind a residual sum folds into the pass that writes the sum (peephole.cpp)
 	uint64_t sig;
+	if (g_comm_overlap_on.load(std::memory_order_relaxed) && output_size >= 1 && outputs[0]) comm_gradient_touched(outputs[0]); // a gradient summed over several uses: its all-reduce takes stream order (cmd_comm.cpp "Overlap")
 	if (const int e = deferred_take_error(stream_context)) return e;
 	const bool floats = output_size >= 1 && outputs[0] && (CCV_GET_DATA_TYPE(outputs[0]->info.datatype) == CCV_32F || CCV_GET_DATA_TYPE(outputs[0]->info.datatype) == CCV_16F); // (no ReLU row for CCV_32S: nothing to wait for)
 	sig = 0;
@@ -396,6 +432,53 @@ static int _scalar_mul_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, 
 	return ew_map<OpFill, 0>(f, outputs[0]->data.f32, 0, 0, 0, n, stream_context);
 }
 
+// n validated SGD_FORWARD commands of one stream (each passed _sgd_forw's checks when it arrived) in as few launches as their tensors allow: one per class
+// (half / float, 16-byte accesses or single elements).  > 0: not batchable as a whole (different hyper-parameters, or an update that reads what an earlier one
+// writes) -- the caller runs them one by one, in order.
+static int sgd_multi_run(const ccv_nnc_cmd_t* const* const cmds, ccv_nnc_tensor_t* const* const* const ins, ccv_nnc_tensor_t* const* const* const outs, const int n, ccv_nnc_stream_context_t* const ctx)
+{
+	if (n < 2 || n > SGD_MULTI_MAX) return 1;
+	for (int i = 1; i < n; i++) if (memcmp(&cmds[i]->info.sgd, &cmds[0]->info.sgd, sizeof(cmds[0]->info.sgd)) != 0) return 1;
+	for (int j = 1; j < n; j++) // order between the updates must not matter: nothing one writes is read or written by another (in place WITHIN an update is the rule)
+		for (int i = 0; i < j; i++)
+			for (int o = 0; o < 2; o++) {
+				const void* const wj = outs[j][o]->data.u8;
+				const void* const wi = outs[i][o]->data.u8;
+				for (int q = 0; q < 3; q++) if (ins[i][q]->data.u8 == wj || ins[j][q]->data.u8 == wi) return 1;
+				for (int q = 0; q < 2; q++) if (outs[i][q]->data.u8 == wj) return 1;
+			}
+	const ccv_nnc_cmd_t& cmd = *cmds[0];
+	const float inv_dampening = 1 - cmd.info.sgd.dampening;
+	hipStream_t stream = stream_of(ctx);
+	for (int cls = 0; cls < 4; cls++) { // 0: halves x 8, 1: halves, 2: floats x 4, 3: floats
+		sgd_multi_t s;
+		int k = 0;
+		unsigned blocks = 0;
+		for (int i = 0; i < n; i++) {
+			const ccv_nnc_tensor_t* const g = ins[i][0]; const ccv_nnc_tensor_t* const a = ins[i][1]; const ccv_nnc_tensor_t* const m = ins[i][2];
+			ccv_nnc_tensor_t* const b = outs[i][0]; ccv_nnc_tensor_t* const nn = outs[i][1];
+			const size_t cnt = tensor_count(a->info);
+			const bool half = CCV_GET_DATA_TYPE(a->info.datatype) == CCV_16F;
+			const bool al = aligned16(g->data.u8) && aligned16(a->data.u8) && aligned16(m->data.u8) && aligned16(b->data.u8) && aligned16(nn->data.u8);
+			const int mine = half ? ((cnt % 8 == 0 && al) ? 0 : 1) : ((cnt % 4 == 0 && al) ? 2 : 3);
+			if (mine != cls) continue;
+			const int W = cls == 0 ? 8 : cls == 2 ? 4 : 1;
+			const size_t nb = (cnt / W + EW_THREADS - 1) / EW_THREADS;
+			if (nb > 0x7fffffffu - blocks) return 1;
+			s.g[k] = g->data.u8; s.a[k] = a->data.u8; s.m[k] = m->data.u8; s.b[k] = b->data.u8; s.nm[k] = nn->data.u8; s.cnt[k] = cnt; s.first[k] = blocks;
+			blocks += (unsigned)nb;
+			k++;
+		}
+		if (!k) continue;
+		s.first[k] = blocks;
+#define SGD_MULTI(T, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgd_multi_kernel<T, W>), dim3(blocks), dim3(EW_THREADS), 0, stream, s, k, cmd.info.sgd.nesterov, cmd.info.sgd.rate, cmd.info.sgd.scale, cmd.info.sgd.decay, cmd.info.sgd.momentum, inv_dampening)
+		if (cls == 0) SGD_MULTI(half_t, 8); else if (cls == 1) SGD_MULTI(half_t, 1); else if (cls == 2) SGD_MULTI(float, 4); else SGD_MULTI(float, 1);
+#undef SGD_MULTI
+		HIP_ENFORCE(hipGetLastError());
+	}
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	if (input_size != 3 || output_size != 2) return CCV_NNC_EXEC_INVALID;
@@ -417,6 +500,9 @@ static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	if (const int e = deferred_take_error(stream_context)) return e;
 	// every parameter has been checked: behind a recorded CONVOLUTION_BACKWARD whose signal this stream waits for, the update waits with it (peephole.cpp, the trail)
 	if (g_deferred_live && deferred_trail_cmd(_sgd_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context)) return CCV_NNC_EXEC_SUCCESS;
+	// ... and an update with nothing recorded in front of it starts a batch of its own: the updates that follow it on this stream join it, one multi-tensor
+	// launch for all of them at the stream's next order-observing point (peephole.cpp, "SGD batches")
+	if (deferred_sgd_head(_sgd_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context)) return CCV_NNC_EXEC_SUCCESS;
 	hipStream_t stream = stream_of(stream_context);
 	if (dt == CCV_16F) {
 		if ((cnt % 8 == 0) && aligned16(g->data.u8) && aligned16(a->data.u8) && aligned16(m->data.u8) && aligned16(b->data.u8) && aligned16(n->data.u8)) {
@@ -634,6 +720,9 @@ static int _random_exec(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 } // namespace
 
 namespace nnc {
+
+bool sgd_is_exec(const exec_fn_t fn) { return fn == _sgd_forw; }
+int sgd_forw_multi(const ccv_nnc_cmd_t* const* cmds, ccv_nnc_tensor_t* const* const* ins, ccv_nnc_tensor_t* const* const* outs, int n, ccv_nnc_stream_context_t* ctx) { return sgd_multi_run(cmds, ins, outs, n, ctx); }
 
 int fill_f32(float* p, size_t n, float v, ccv_nnc_stream_context_t* ctx)
 {

@@ -688,6 +688,15 @@ static int bn_cluster_plan(const chan_view_t& v, const int chunks_per_thread, co
 	if (nv > 0xfffff || Q > 0x7fffffffL || (unsigned long long)Q * (unsigned long long)nv >= (1ull << 32)) return 0;
 	long cap = 256L * chunks_per_thread * (16 / CB); // chunks one workgroup holds
 	if (mode > 1 && mode < cap) cap = mode; // (tests: several workgroups per channel on small tensors)
+	// A tensor whose channels fit a few full shares gives a launch of a few hundred workgroups, each a chain of dependent steps -- ticket, a deep queue of loads,
+	// four barriers, the hand-over, the stores -- that nothing overlaps: 256 x 14 x 14 halves at batch 256 took 30 us for 51 MB (1.7 TB/s,
+	// profiles/r04_v2_bn_bench.txt).  Smaller shares, more workgroups: the chains shorten and the chip's slots fill (TUNE_BN_CLUSTER_SLOTS workgroups, about).
+	const long slots = tune(TUNE_BN_CLUSTER_SLOTS);
+	if (slots > 0 && mode == 1) {
+		const long share = (Q * (long)v.C + slots - 1) / slots; // chunks per workgroup that make `slots` workgroups
+		const long least = 256L * 2;
+		if (share < cap) cap = share > least ? share : least;
+	}
 	long G = (Q + cap - 1) / cap;
 	if (G > BN_CLUSTER_MAX_G) return 0;
 	const long per = (Q + G - 1) / G;
@@ -916,8 +925,13 @@ static int bnorm_back_t(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, cons
 }
 static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
-	if (input_size > 5 && inputs[5] && CCV_GET_DATA_TYPE(inputs[5]->info.datatype) == CCV_16F) return bnorm_back_t<half_t>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
-	return bnorm_back_t<float>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	const int r = (input_size > 5 && inputs[5] && CCV_GET_DATA_TYPE(inputs[5]->info.datatype) == CCV_16F) ? bnorm_back_t<half_t>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context)
+		: bnorm_back_t<float>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
+	// the scale / bias gradients just enqueued (cmd_comm.cpp "Overlap": deployment (b)'s all-reduce of each starts behind its own writer)
+	if (r == CCV_NNC_EXEC_SUCCESS && g_comm_overlap_on.load(std::memory_order_relaxed))
+		for (int i = 1; i < output_size && i < 3; i++)
+			if (outputs[i]) { if (flags & CCV_NNC_ACCUMULATE_OUTPUT) comm_gradient_touched(outputs[i]); else comm_gradient_written(outputs[i], stream_context); }
+	return r;
 }
 
 } // namespace

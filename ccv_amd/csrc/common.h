@@ -105,9 +105,18 @@ static inline bool image4(const ccv_nnc_tensor_t* t, Image4* o)
 extern std::atomic<int> g_comm_pending; // (atomics, not volatile ints: these are read outside their mutexes by every order-observing hook on any thread -- ThreadSanitizer run, round 4)
 void comm_flush(void);
 void comm_release_context(const void* ctx);
+// Deployment (b) with NNC_MI355X_COMM_OVERLAP=1 / nnc_mi355x_comm_overlap(1): the gradient all-reduces go out on a communication stream in buckets, each behind
+// the commands that WROTE its gradients (not behind the whole issuing stream), and every other stream joins them at its next order-observing point.
+extern std::atomic<int> g_comm_overlap_on;            // 1 while the mode is on and a rank communicator exists: the backward commands then report their gradient outputs
+extern std::atomic<unsigned long> g_comm_overlap_epoch; // bumped by every overlapped flush
+void comm_gradient_written(const ccv_nnc_tensor_t* t, ccv_nnc_stream_context_t* ctx); // a backward command has just enqueued the kernels that write this weight / bias gradient
+void comm_gradient_touched(const ccv_nnc_tensor_t* t); // some other command writes it too (accumulation): forget the record, the all-reduce takes stream order
+void comm_overlap_join(hipStream_t stream, unsigned long* seen);
+hipStream_t stream_peek(const ccv_nnc_stream_context_t* ctx); // device_rt.cpp: the context's stream, no hooks
+void stream_registered(int device, hipStream_t st); // device_rt.cpp: a stream this library made outside it -- the allocator's free fences must name it
 // Recorded-but-not-yet-launched commands waiting for the ReLU that may follow them (peephole.cpp): the same points flush them.
 typedef int (*exec_fn_t)(const ccv_nnc_cmd_t, const ccv_nnc_hint_t, const int, ccv_nnc_tensor_t* const*, const int, ccv_nnc_tensor_t* const*, const int, ccv_nnc_stream_context_t*);
-enum { DEFER_CONV_FORWARD = 1, DEFER_CONV_BACKWARD = 2, DEFER_POOL_BACKWARD = 3, DEFER_BNORM_FORWARD = 4, DEFER_EWSUM_FORWARD = 5 };
+enum { DEFER_CONV_FORWARD = 1, DEFER_CONV_BACKWARD = 2, DEFER_POOL_BACKWARD = 3, DEFER_BNORM_FORWARD = 4, DEFER_EWSUM_FORWARD = 5, DEFER_SGD_BATCH = 6 };
 extern std::atomic<int> g_deferred_live;
 bool deferred_try(exec_fn_t fn, int kind, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, int flags, ccv_nnc_tensor_t* const* inputs, int input_size, ccv_nnc_tensor_t* const* outputs, int output_size, ccv_nnc_stream_context_t* ctx, uint64_t* sig); // true: recorded, report success
 void deferred_mark_good(uint64_t sig); // this signature ran successfully on the spot: the next one like it may be recorded
@@ -115,6 +124,9 @@ int deferred_fuse_relu_forw(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_
 int deferred_fuse_relu_back(const ccv_nnc_tensor_t* g, const ccv_nnc_tensor_t* b, ccv_nnc_tensor_t* h, ccv_nnc_stream_context_t* ctx);
 bool deferred_signal_op(int emit, const ccv_nnc_stream_context_t* ctx, const ccv_nnc_stream_signal_t* signal); // true: kept in a recorded command's trail (peephole.cpp), not to be performed now
 bool deferred_trail_cmd(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, int flags, ccv_nnc_tensor_t* const* inputs, int input_size, ccv_nnc_tensor_t* const* outputs, int output_size, ccv_nnc_stream_context_t* ctx); // true: kept behind the trail operations of its stream
+bool deferred_sgd_head(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, int flags, ccv_nnc_tensor_t* const* inputs, int input_size, ccv_nnc_tensor_t* const* outputs, int output_size, ccv_nnc_stream_context_t* ctx); // true: kept as the first of a batch of updates on its stream
+bool sgd_is_exec(exec_fn_t fn); // cmd_ew.cpp: is this the SGD_FORWARD exec function (whose consecutive trail entries sgd_forw_multi can launch together)?
+int sgd_forw_multi(const ccv_nnc_cmd_t* const* cmds, ccv_nnc_tensor_t* const* const* ins, ccv_nnc_tensor_t* const* const* outs, int n, ccv_nnc_stream_context_t* ctx); // 0: launched; > 0: not batchable, run them one by one
 void signal_emit_now(const ccv_nnc_stream_context_t* ctx, const ccv_nnc_stream_signal_t* signal); // device_rt.cpp: the event record / stream wait themselves
 void signal_wait_now(const ccv_nnc_stream_context_t* ctx, const ccv_nnc_stream_signal_t* signal);
 void deferred_flush(const ccv_nnc_stream_context_t* ctx); // 0: every stream's
@@ -230,6 +242,7 @@ enum {
 	TUNE_LSTM_PERSISTENT,   // LSTM: one launch walks a pseudo-layer's whole sequence with its slice of R in registers, the state handed between workgroups through tagged words (1), or one launch per step (0)
 	TUNE_LSTM_ROWS,         // LSTM without projection, hidden size <= 128: a workgroup owns ONE batch row (two when the hidden size is no multiple of four; 2 = two for every size) and ALL hidden units for the whole sequence, R entirely in its registers, no word passes between workgroups (1), or the forms above (0)
 	TUNE_GEMM_BF16X3,       // fp32 plain-matrix contractions on the bf16 matrix pipe, every operand split exactly into three bf16 values and all nine partial products accumulated in fp32 (mfma_gemm_bf16x3.h): 0 = never (the fp32 matrix instructions), 1 = where the launcher's rules say it pays, 2 = wherever the kernel applies, 3 / 4 = as 2 with the 128 x 128 / 256 x 256 tile forced (measurements)
+	TUNE_BN_CLUSTER_SLOTS,  // the cluster batch-norm kernels on tensors too small to fill the chip with full workgroup shares: shares are cut down until the launch has about this many workgroups (never below two chunks per thread); 0 = always the largest share a workgroup's registers hold (rounds 4 - 5)
 	TUNE_COUNT
 };
 static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");

@@ -25,6 +25,7 @@ struct device_local_t {
 	size_t palette_size;  // the workspace AND the staging arena (a half-precision GEMM with palettized weights does both)
 	void* cluster_sync;   // the words the workgroups of ONE launch on this stream hand each other (nnc::cluster_sync_of): never scratch, never moved
 	unsigned cluster_epoch;
+	unsigned long comm_seen; // the overlapped gradient all-reduces this stream has been ordered behind (cmd_comm.cpp comm_overlap_join)
 };
 // Layout contract with the reference host (lib/nnc/ccv_nnc_stream.c:15-20, lib/nnc/gpu/ccv_nnc_compat.cu:286-299):
 // the host allocates `super` + a {size_t, void*} CPU-workspace tail for EVERY context (CPU contexts included) and, under
@@ -112,10 +113,10 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 namespace nnc {
 int g_force_tile = 0;
 int g_force_splits = 0;
-static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C", "WINO_FUSED_GRID", "GRID_WG_PER_CU", "WINO_WGRAD_FUSED_MAX", "GEMM_BUFFER_LOADS", "CONV_NCHW_HALF_F16", "BN_SMALL_PLANES", "SDPA_MFMA", "BN_CLUSTER", "GEMM_VEC_EPILOGUE", "POOL_ROWS", "GEMM_HALF_CHUNK8", "LSTM_PERSISTENT", "LSTM_ROWS", "GEMM_BF16X3" };
+static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C", "WINO_FUSED_GRID", "GRID_WG_PER_CU", "WINO_WGRAD_FUSED_MAX", "GEMM_BUFFER_LOADS", "CONV_NCHW_HALF_F16", "BN_SMALL_PLANES", "SDPA_MFMA", "BN_CLUSTER", "GEMM_VEC_EPILOGUE", "POOL_ROWS", "GEMM_HALF_CHUNK8", "LSTM_PERSISTENT", "LSTM_ROWS", "GEMM_BF16X3", "BN_CLUSTER_SLOTS" };
 // GRID_WG_PER_CU = 0: grid-stride kernels get one trip per thread.  tools/ew_bw_bench.py: a grid capped at 8 .. 64 workgroups per CU
 // striding a 3.3 GB tensor runs at 4.7 - 5.2 TB/s, the same kernel with the whole tensor as its grid at 6.2 TB/s.
-static long g_tune_values[TUNE_COUNT] = { 0, 128, 0, 0, 128, 1, 32, 1, 1, 1, 1, 1, 1, 1, 1, 1 }; // defaults: the measured best on the MI355X
+static long g_tune_values[TUNE_COUNT] = { 0, 128, 0, 0, 128, 1, 32, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0 }; // defaults: the measured best on the MI355X
 static int g_tune_env_read = 0;
 long tune(int key)
 {
@@ -133,12 +134,25 @@ long tune(int key)
 }
 namespace nnc {
 
+// Gradient all-reduces that went out on the communication stream (cmd_comm.cpp, "overlap"): whatever this stream does next comes behind them.
+static inline device_local_t* joined(device_local_t* const l)
+{
+	if (g_comm_overlap_epoch.load(std::memory_order_acquire) != l->comm_seen) comm_overlap_join(l->stream, &l->comm_seen);
+	return l;
+}
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
 {
 	if (g_comm_pending) comm_flush(); // a launch is about to be ordered on a stream: recorded collectives go first (cmd_comm.cpp)
 	if (g_deferred_live) deferred_flush(ctx); // ... and so does this stream's recorded command (peephole.cpp)
 	if (!ctx) return (hipStream_t)0;
 	if (CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU) return (hipStream_t)0;
+	return joined(bind(ctx))->stream;
+}
+void stream_registered(const int device, hipStream_t st) { pool_stream_created(device, st); }
+// the stream itself, no hooks: for recording "this buffer has been written" behind a command that has just been enqueued (cmd_comm.cpp comm_gradient_written)
+hipStream_t stream_peek(const ccv_nnc_stream_context_t* ctx)
+{
+	if (!ctx || CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU) return (hipStream_t)0;
 	return bind(ctx)->stream;
 }
 
@@ -788,7 +802,7 @@ void ccv_nnc_synchronize_stream_context(const ccv_nnc_stream_context_t* const st
 {
 	nnc::comm_flush_if_pending();
 	if (!stream_context) { HIP_ENFORCE(hipStreamSynchronize((hipStream_t)0)); nnc::cluster_check_timeout(); return; }
-	HIP_ENFORCE(hipStreamSynchronize(bind(stream_context)->stream));
+	HIP_ENFORCE(hipStreamSynchronize(nnc::joined(bind(stream_context))->stream));
 	nnc::cluster_check_timeout();
 }
 
@@ -934,7 +948,7 @@ static void host_async_trampoline(void* userdata)
 void ccv_nnc_stream_compat_add_callback(ccv_nnc_stream_context_t* const stream, const ccv_nnc_callback_f callback, const ccv_nnc_async_callback_f async_callback, void* const callback_context)
 {
 	nnc::comm_flush_if_pending();
-	device_local_t* s = bind(stream);
+	device_local_t* s = nnc::joined(bind(stream));
 	ccv_nnc_async_callback_t* async = (ccv_nnc_async_callback_t*)malloc(sizeof(ccv_nnc_async_callback_t));
 	async->fn = callback;
 	async->callback_context = callback_context;
@@ -963,7 +977,7 @@ void ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal)
 }
 } // extern "C"
 namespace nnc {
-void signal_emit_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal) { HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, bind(stream)->stream)); }
+void signal_emit_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal) { HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, joined(bind(stream))->stream)); }
 void signal_wait_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal) { HIP_ENFORCE(hipStreamWaitEvent(bind(stream)->stream, ((const signal_gpu_t*)signal)->event, 0)); }
 }
 extern "C" {

@@ -198,6 +198,9 @@ static inline bool gemm_bf16x3_wanted(const int M, const int N, const int K, con
 	long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
 	int s = splits;
 	if (s <= 0) s = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
+	// a row-contiguous pair with a short reduction is its epilogue (256 KB per workgroup): fc7's filter gradient, 4096 x 4096 x 256, ran 0.242 ms split against
+	// 0.189 ms on the fp32 instructions (profiles/r06_v2_contraction_records.txt); the Winograd filter gradients keep >= 512 of K per slice
+	if (!AKC && K / (s > 1 ? s : 1) < 512) return false;
 	return tiles * zcount * (s > 1 ? s : 1) >= (long)device_cu_count();
 }
 template <bool AKC, bool BKC>

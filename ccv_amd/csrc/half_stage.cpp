@@ -231,6 +231,23 @@ void warn_refused(const uint32_t cmd, const int ret)
 // cmd_ew.cpp, cmd_norm.cpp, cmd_pool.cpp).  Bit i of `in` / `out` = that input / output stays in its own memory when every tensor
 // named by the masks is a dense CCV_16F tensor; the row's small tensors (batch-norm statistics, ...) still get fp32 images.
 static long g_half_staged = 0, g_half_native = 0; // nnc_mi355x_debug_half_counts (test hook; not synchronised: counts, not control)
+// NNC_MI355X_HALF_STATS=1: one line per command at unload -- which rows of a run went through fp32 images of their half tensors (and how many tensors)
+static struct half_stats_t {
+	struct { uint32_t cmd; long calls, tensors; } row[64];
+	int n = 0, on = -1;
+	~half_stats_t()
+	{
+		if (on != 1) return;
+		for (int i = 0; i < n; i++) fprintf(stderr, "[nnc_mi355x] half tensors staged as fp32 images: %-48s %6ld calls, %6ld tensors\n", command_row_name(row[i].cmd), row[i].calls, row[i].tensors);
+	}
+} g_half_stats;
+static void half_stats_note(const uint32_t cmd, const int tensors)
+{
+	if (g_half_stats.on < 0) { const char* e = getenv("NNC_MI355X_HALF_STATS"); g_half_stats.on = (e && *e == '1') ? 1 : 0; }
+	if (g_half_stats.on != 1 || !tensors) return;
+	for (int i = 0; i < g_half_stats.n; i++) if (g_half_stats.row[i].cmd == cmd) { g_half_stats.row[i].calls++; g_half_stats.row[i].tensors += tensors; return; }
+	if (g_half_stats.n < 64) { g_half_stats.row[g_half_stats.n].cmd = cmd; g_half_stats.row[g_half_stats.n].calls = 1; g_half_stats.row[g_half_stats.n].tensors = tensors; g_half_stats.n++; }
+}
 struct native_half_t { uint32_t cmd; unsigned in, out; };
 static const native_half_t g_native_half[] = {
 	{ CCV_NNC_RELU_FORWARD, 1u << 0, 1u << 0 },
@@ -306,6 +323,7 @@ int half_staged_exec(const nnc_exec_f inner, const ccv_nnc_cmd_t cmd, const ccv_
 	for (int i = 0; i < output_size; i++) { if (i == opaque_out || (native && i < 32 && ((native->out >> i) & 1))) which[input_size + i] = -1; else visit(outputs[i], true, input_size + i); }
 	for (int i = 0; i < nst; i++) total += (st[i].span * sizeof(float) + 255) & ~(size_t)255;
 	g_half_staged += nst;
+	half_stats_note(cmd.cmd, nst);
 	if (native)
 		for (int i = 0; i < input_size + output_size; i++) {
 			ccv_nnc_tensor_t* const t = i < input_size ? inputs[i] : outputs[i - input_size];

@@ -32,6 +32,12 @@
 // signal order are what the host's schedule is made of, and both are kept; the kernels, their streams and their events are the same, only the ReLU's pass
 // over the gradient is gone.
 //
+// SGD BATCHES (round 6).  An SGD_FORWARD with nothing recorded in front of it on its stream becomes a recorded command of its own kind (DEFER_SGD_BATCH: the
+// update itself is the first entry of the slot's trail), the updates that follow it on that stream join the trail, and when the slot is launched -- at the
+// stream's next order-observing point, like every slot -- consecutive updates of one stream go out as ONE multi-tensor launch (cmd_ew.cpp sgd_forw_multi:
+// bit-identical arithmetic).  The reference's models end a step with one SGD_FORWARD per parameter tensor (~200 for ResNet-50, 5 - 18 us each, most of it
+// launch latency and one host enqueue each).  The same merge applies to the updates a CONVOLUTION_BACKWARD's trail holds.  NNC_MI355X_SGD_BATCH=0 turns it off.
+//
 // Threads.  Every order-observing hook flushes (stream_of, copies, frees, signals, callbacks), and some of them flush EVERY stream's slot from
 // whatever thread called (a loader thread's host-to-device copy).  A slot being launched stays visible in state LAUNCHING -- still counted in
 // g_deferred_live -- until its kernels have been enqueued; anything that would order itself against that stream (the matching ReLU, another
@@ -97,6 +103,7 @@ std::unordered_set<uint64_t>& g_good = *new std::unordered_set<uint64_t>;
 int g_enabled = -1;
 long g_recorded = 0, g_folded = 0, g_plain = 0; // nnc_mi355x_debug_peephole_counts
 long g_trailed = 0;                             // operations that waited in a trail (nnc_mi355x_debug_peephole_trailed)
+long g_sgd_batches = 0, g_sgd_batched = 0;      // multi-tensor launches, and the updates they carried (nnc_mi355x_debug_sgd_batches)
 int g_debug_fail_trailed = 0;     // nnc_mi355x_debug_peephole_fail_trailed: the next command replayed out of a trail reports this instead of running (tests)
 int g_debug_launch_delay_us = 0; // nnc_mi355x_debug_peephole_launch_delay_us: tests widen the window between a slot's release and its launch
 thread_local int tl_running = 0; // inside a recorded command's launch: its own stream_of / nested commands must not touch the slots
@@ -197,7 +204,7 @@ int run(Slot& s, const int relu_bit, Lock& lk, const bool report)
 	ccv_nnc_tensor_t* out[MAX_IO];
 	for (int i = 0; i < c.nin; i++) in[i] = c.has_in[i] ? (ccv_nnc_tensor_t*)&c.in[i] : 0;
 	for (int i = 0; i < c.nout; i++) out[i] = c.has_out[i] ? (ccv_nnc_tensor_t*)&c.out[i] : 0;
-	if (relu_bit) ++g_folded; else ++g_plain;
+	if (c.kind != DEFER_SGD_BATCH) { if (relu_bit) ++g_folded; else ++g_plain; } // (a batch of updates is not one of the ReLU pairs these count)
 	if (relu_bit) c.cmd.algorithm = relu_bit | (c.cmd.algorithm < 0 ? 0xff : (c.cmd.algorithm & 0xff));
 	int prev = 0;
 	HIP_ENFORCE(hipGetDevice(&prev));
@@ -205,13 +212,38 @@ int run(Slot& s, const int relu_bit, Lock& lk, const bool report)
 	++tl_running;
 	lk.unlock();
 	if (g_debug_launch_delay_us > 0) usleep(g_debug_launch_delay_us);
-	const int r = c.fn(c.cmd, c.hint, c.flags, in, c.nin, out, c.nout, c.ctx);
+	const int r = c.fn ? c.fn(c.cmd, c.hint, c.flags, in, c.nin, out, c.nout, c.ctx) : CCV_NNC_EXEC_SUCCESS; // (an SGD batch has no head: its first update is trail[0])
 	// the trail, in arrival order, right behind the command: its emits, the waits for them, the commands behind those waits
 	for (int k = 0; k < s.ntrail; k++) {
 		TrailOp& t = s.trail[k];
 		int dev = 0;
 		HIP_ENFORCE(hipGetDevice(&dev));
 		if (dev != t.device) HIP_ENFORCE(hipSetDevice(t.device));
+		if (t.op == OP_CMD && !g_debug_fail_trailed && sgd_is_exec(t.fn)) { // consecutive updates of one stream: one multi-tensor launch
+			int e = k + 1;
+			while (e < s.ntrail && s.trail[e].op == OP_CMD && s.trail[e].fn == t.fn && s.trail[e].ctx == t.ctx && s.trail[e].device == t.device) e++;
+			if (e - k >= 2) {
+				const ccv_nnc_cmd_t* cmds[TRAIL_MAX];
+				ccv_nnc_tensor_t* tin[TRAIL_MAX][TRAIL_IO];
+				ccv_nnc_tensor_t* tout[TRAIL_MAX][TRAIL_IO];
+				ccv_nnc_tensor_t* const* pin[TRAIL_MAX];
+				ccv_nnc_tensor_t* const* pout[TRAIL_MAX];
+				for (int j = k; j < e; j++) {
+					TrailOp& u = s.trail[j];
+					cmds[j - k] = &u.cmd;
+					for (int i = 0; i < u.nin; i++) tin[j - k][i] = u.has_in[i] ? (ccv_nnc_tensor_t*)&u.in[i] : 0;
+					for (int i = 0; i < u.nout; i++) tout[j - k][i] = u.has_out[i] ? (ccv_nnc_tensor_t*)&u.out[i] : 0;
+					pin[j - k] = tin[j - k]; pout[j - k] = tout[j - k];
+				}
+				if (sgd_forw_multi(cmds, pin, pout, e - k, t.ctx) == CCV_NNC_EXEC_SUCCESS) {
+					lk.lock();
+					++g_sgd_batches; g_sgd_batched += e - k;
+					lk.unlock();
+					k = e - 1;
+					continue;
+				}
+			}
+		}
 		if (t.op == OP_EMIT) signal_emit_now(t.ctx, t.signal);
 		else if (t.op == OP_WAIT) signal_wait_now(t.ctx, t.signal);
 		else {
@@ -445,7 +477,7 @@ bool deferred_trail_cmd(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hin
 	const int device = device_for(ctx);
 	wait_launching(ctx, lock);
 	Slot* const s = slot_with_stream(ctx, device);
-	if (!s || (s->ctx == ctx && s->device == device) || s->ntrail >= TRAIL_MAX) return false; // (on the recorded command's own stream only its ReLU may follow)
+	if (!s || (s->ctx == ctx && s->device == device && s->kind != DEFER_SGD_BATCH) || s->ntrail >= TRAIL_MAX) return false; // (on the recorded command's own stream only its ReLU may follow -- or, behind a recorded update, more updates)
 	for (int i = 0; i < SLOTS; i++) // ... and in no other trail
 		if (&g_slots[i] != s && g_slots[i].live == RECORDED && in_trail(g_slots[i], ctx)) return false;
 	TrailOp& t = s->trail[s->ntrail++];
@@ -453,6 +485,32 @@ bool deferred_trail_cmd(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hin
 	t.fn = fn; t.cmd = cmd; t.hint = hint; t.flags = flags; t.nin = input_size; t.nout = output_size;
 	for (int i = 0; i < input_size; i++) keep(&t.in[i], &t.has_in[i], inputs[i]);
 	for (int i = 0; i < output_size; i++) keep(&t.out[i], &t.has_out[i], outputs[i]);
+	++g_trailed;
+	return true;
+}
+
+// An SGD_FORWARD (parameters checked by the caller) on a stream with nothing recorded: it starts a batch (see the head of this file).  false: the caller launches it now.
+bool deferred_sgd_head(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
+{
+	static const int on = !(getenv("NNC_MI355X_SGD_BATCH") && *getenv("NNC_MI355X_SGD_BATCH") == '0');
+	if (!on || tl_running || !enabled() || !ctx || CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU || input_size > TRAIL_IO || output_size > TRAIL_IO || !trailing_on()) return false;
+	Lock lock(g_mu);
+	const int device = device_for(ctx);
+	wait_launching(ctx, lock);
+	if (slot_with_stream(ctx, device)) return false; // (deferred_trail_cmd has already declined to put it behind what is recorded there: the caller's stream_of launches that first)
+	Slot* s = 0;
+	for (int i = 0; i < SLOTS && !s; i++)
+		if (g_slots[i].live == FREE) s = &g_slots[i];
+	if (!s) return false;
+	s->fn = 0; s->kind = DEFER_SGD_BATCH; s->cmd = cmd; s->hint = hint; s->flags = flags; s->ctx = ctx; s->device = device;
+	s->nin = 0; s->nout = 0; s->ntrail = 1;
+	TrailOp& t = s->trail[0];
+	t.op = OP_CMD; t.ctx = ctx; t.device = device; t.signal = 0;
+	t.fn = fn; t.cmd = cmd; t.hint = hint; t.flags = flags; t.nin = input_size; t.nout = output_size;
+	for (int i = 0; i < input_size; i++) keep(&t.in[i], &t.has_in[i], inputs[i]);
+	for (int i = 0; i < output_size; i++) keep(&t.out[i], &t.has_out[i], outputs[i]);
+	s->live = RECORDED;
+	++g_deferred_live;
 	++g_trailed;
 	return true;
 }
@@ -498,6 +556,13 @@ extern "C" long nnc_mi355x_debug_peephole_trailed(void)
 {
 	std::lock_guard<std::recursive_mutex> lock(nnc::g_mu);
 	return nnc::g_trailed;
+}
+
+extern "C" void nnc_mi355x_debug_sgd_batches(long* const launches, long* const updates)
+{
+	std::lock_guard<std::recursive_mutex> lock(nnc::g_mu);
+	if (launches) *launches = nnc::g_sgd_batches;
+	if (updates) *updates = nnc::g_sgd_batched;
 }
 
 extern "C" void nnc_mi355x_debug_peephole_launch_delay_us(const int us) { nnc::g_debug_launch_delay_us = us; }

@@ -343,6 +343,15 @@ int nnc_mi355x_cmd_ok(const uint32_t cmd, const uint32_t backend); /* ccv_nnc_cm
 int nnc_mi355x_comm_unique_id(void* id_out_128_bytes);
 int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size);
 void nnc_mi355x_comm_destroy(void);
+/* Deployment (b) (one process per GPU): overlap the gradient all-reduces with the backward pass.  The reference's single-process data parallelism gets the
+ * overlap from its scheduler -- an all-reduce node behind every gradient, on other streams (lib/nnc/ccv_nnc_symbolic_graph_parallel.c:545-575) --; a process
+ * that drives the model API (ccv_cnnp_model_backward, then ccv_cnnp_model_parameter_gradients_map(COMM_ALLREDUCE_FORWARD)) issues them all behind the whole
+ * backward pass.  With the mode on (1; or NNC_MI355X_COMM_OVERLAP=1 in the environment; -1 = the environment decides) those all-reduces go out on a
+ * communication stream, sorted by the order their gradients were written and cut into buckets of NNC_MI355X_COMM_BUCKET_MB (32), each bucket behind its own
+ * gradients' writers only; every other stream joins them at its next launch / synchronise / signal.  Results are those of immediate issue (the same collectives,
+ * grouped differently).  Gradients must be written by CONVOLUTION_ / GEMM_ / BATCH_NORM_BACKWARD (anything else takes the issuing stream's order). */
+void nnc_mi355x_comm_overlap(int on);
+void nnc_mi355x_comm_overlap_stats(long* collectives, long* buckets);
 /* Ranks of the process communicator as RCCL counts them (ncclCommCount); 0 before nnc_mi355x_comm_init_rank.  bench.py prints it as `rccl_ranks`. */
 int nnc_mi355x_comm_count(void);
 /* Counters of the COMM commands' coalescing (cmd_comm.cpp): per-device collectives issued so far, and the RCCL groups they

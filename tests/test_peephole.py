@@ -530,3 +530,45 @@ def test_a_failure_of_a_trailed_update_reaches_the_streams_next_update(lib):
             lib.stream_free(s)
         for s in sigs:
             lib.signal_free(s)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_consecutive_updates_of_a_stream_go_out_as_multi_tensor_launches(lib, dtype):
+    """Round 6: the SGD_FORWARD commands that end a step (one per parameter tensor) are kept by the look-ahead and launched together -- one multi-tensor kernel
+    per batch and access class (cmd_ew.cpp sgd_multi_kernel).  Parameters, momenta: bit-identical to the same commands one by one (look-ahead off); sizes with
+    and without 16-byte vectors, an unaligned view, an update that reads what the previous one wrote (the batch must fall back to program order)."""
+    H = np.float16
+    T = F if dtype == "f32" else H
+    rng = np.random.default_rng(51)
+    sizes = [4096, 7, 1000, 64 * 3 * 3 * 3, 513, 8, 16384, 100, 2048, 31] * 3
+    sgd = nnc.CMD_SGD_FORWARD(1, 0.05, 1.0 / 16, 0.0005, 0.9, 0.0)
+    batches = getattr(lib.dll, "nnc_mi355x_debug_sgd_batches")
+    st = lib.stream_new(0)
+    results = {}
+    try:
+        for mode in ("off", "on"):
+            lib.dll.nnc_mi355x_set_peephole(1 if mode == "on" else 0)
+            rs = np.random.default_rng(52)
+            gs = make_tensors(lib, nnc.GPU_MEMORY, [srnd(rs, n).astype(T) for n in sizes])
+            ps = make_tensors(lib, nnc.GPU_MEMORY, [srnd(rs, n).astype(T) for n in sizes])
+            ms = make_tensors(lib, nnc.GPU_MEMORY, [srnd(rs, n, scale=0.1).astype(T) for n in sizes])
+            l0, u0 = C.c_long(), C.c_long()
+            batches(C.byref(l0), C.byref(u0))
+            for step in range(2):
+                for g, p, m in zip(gs, ps, ms):
+                    assert lib.cmd_exec(sgd, nnc.NO_HINT, 0, [g, p, m], [p, m], st) == 0
+                # an update that reads the parameter the previous command wrote (same tensors again): program order must hold
+                assert lib.cmd_exec(sgd, nnc.NO_HINT, 0, [gs[-1], ps[-1], ms[-1]], [ps[-1], ms[-1]], st) == 0
+                lib.stream_wait(st)
+            l1, u1 = C.c_long(), C.c_long()
+            batches(C.byref(l1), C.byref(u1))
+            if mode == "on":
+                assert u1.value - u0.value >= 2 * 24 and 0 < l1.value - l0.value <= (u1.value - u0.value) // 2, (l1.value - l0.value, u1.value - u0.value)
+            else:
+                assert u1.value == u0.value
+            results[mode] = [t.numpy().copy() for t in ps + ms]
+        for x, y in zip(results["off"], results["on"]):
+            assert np.array_equal(x, y)
+    finally:
+        lib.dll.nnc_mi355x_set_peephole(1)
+        lib.stream_free(st)

@@ -109,6 +109,7 @@ static long nnc_mi355x_debug_exec_count(void) { return 0; }
 static int nnc_mi355x_comm_init_rank(const void* id, int rank, int world) { return -1; }
 static int nnc_mi355x_comm_count(void) { return 0; }
 static void nnc_mi355x_comm_destroy(void) {}
+static void nnc_mi355x_comm_overlap_stats(long* collectives, long* buckets) { *collectives = *buckets = 0; }
 #else
 /* HOST_BENCH_DEVICE: the device this process trains on (the process-per-GPU form with every GPU visible: rank r takes device r) */
 static int g_device = 0;
@@ -122,6 +123,7 @@ long nnc_mi355x_debug_exec_count(void);
 int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size);
 int nnc_mi355x_comm_count(void);
 void nnc_mi355x_comm_destroy(void);
+void nnc_mi355x_comm_overlap_stats(long* collectives, long* buckets); /* NNC_MI355X_COMM_OVERLAP=1: the gradient all-reduces that went out in buckets beside the backward pass */
 #endif
 
 static float hash_unit(const uint64_t i, const uint64_t seed)
@@ -623,6 +625,11 @@ int main(int argc, char** argv)
 		}
 	}
 	printf("{\"replica_probe_sumsq\": [%.17g, %.17g], ", probe_sq[0], probe_sq[1]);
+	{
+		long ov_c = 0, ov_b = 0;
+		nnc_mi355x_comm_overlap_stats(&ov_c, &ov_b);
+		printf("\"comm_overlap\": {\"collectives\": %ld, \"buckets\": %ld}, ", ov_c, ov_b);
+	}
 	printf("\"f16_contractions_by_bound\": {\"mfma\": {\"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}, \"hbm\": {\"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}}, ",
 		f16b[0].n, f16b[0].ms, f16b[0].flops, f16b[0].bytes, f16b[1].n, f16b[1].ms, f16b[1].flops, f16b[1].bytes);
 	printf("\"kernels\": [");
