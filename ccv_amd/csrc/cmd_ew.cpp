@@ -107,23 +107,33 @@ struct OpAdd2ReluBack { __device__ float operator()(float a, float b, float m) c
 struct OpCopy { __device__ float operator()(float a, float, float) const { return a; } };
 
 // ---- SGD: n = mu*m + (1-damp)*(scale*g + decay*a); b = a - rate*n   (5|p| bytes: g, a, m in; b, n out) --------
+// ONE definition of the arithmetic for every kernel below (scalar, 16-byte, multi-tensor), with contraction off: each product and sum is rounded on its own, as
+// the reference's CPU loops do (lib/nnc/cmd/sgd/ccv_nnc_sgd_cpu_ref.c:16-126) -- and the forms are bit-identical to each other by construction.  (Round 6: left
+// to the compiler, the multi-tensor kernel fused a multiply-add the 16-byte half kernel did not, and the two differed in the last bit on the MI355X.)
+__device__ __forceinline__ void sgd_update(const float g, const float a, const float m, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening, float* const b, float* const n)
+{
+#pragma clang fp contract(off)
+	if (nesterov) {
+		float grad = scale * g;
+		const float mom = momentum * m + grad + decay * a;
+		*n = mom;
+		grad += momentum * mom;
+		*b = a - rate * grad;
+	} else {
+		const float mom = momentum * m + inv_dampening * (scale * g + decay * a);
+		*n = mom;
+		*b = a - rate * mom;
+	}
+}
 template <class T> // float, or _Float16 when the trainer keeps gradient, parameter and momentum in CCV_16F (arithmetic in fp32)
 __global__ void __launch_bounds__(EW_THREADS) sgd_kernel(const T* g, const T* a, const T* m, T* b, T* nm, const size_t n, const int nesterov, const float rate, const float scale, const float decay, const float momentum, const float inv_dampening)
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-		const float av = (float)a[i];
-		if (nesterov) {
-			float grad = scale * (float)g[i];
-			const float mom = momentum * (float)m[i] + grad + decay * av;
-			nm[i] = (T)mom;
-			grad += momentum * mom;
-			b[i] = (T)(av - rate * grad);
-		} else {
-			const float mom = momentum * (float)m[i] + inv_dampening * (scale * (float)g[i] + decay * av);
-			nm[i] = (T)mom;
-			b[i] = (T)(av - rate * mom);
-		}
+		float bo, no;
+		sgd_update((float)g[i], (float)a[i], (float)m[i], nesterov, rate, scale, decay, momentum, inv_dampening, &bo, &no);
+		nm[i] = (T)no;
+		b[i] = (T)bo;
 	}
 }
 // The same for CCV_16F tensors in 16-byte accesses (eight halves per lane; round 5): the scalar form above moves 2 bytes per lane and access -- ResNet-50's 161
@@ -138,18 +148,10 @@ __global__ void __launch_bounds__(EW_THREADS) sgd_kernel_h8(const pack16<half_t>
 		V bo, no;
 #pragma unroll
 		for (int e = 0; e < 8; e++) {
-			const float avf = (float)av[e];
-			if (nesterov) {
-				float grad = scale * (float)gv[e];
-				const float mom = momentum * (float)mv[e] + grad + decay * avf;
-				no[e] = (half_t)mom;
-				grad += momentum * mom;
-				bo[e] = (half_t)(avf - rate * grad);
-			} else {
-				const float mom = momentum * (float)mv[e] + inv_dampening * (scale * (float)gv[e] + decay * avf);
-				no[e] = (half_t)mom;
-				bo[e] = (half_t)(avf - rate * mom);
-			}
+			float bf, nf;
+			sgd_update((float)gv[e], (float)av[e], (float)mv[e], nesterov, rate, scale, decay, momentum, inv_dampening, &bf, &nf);
+			no[e] = (half_t)nf;
+			bo[e] = (half_t)bf;
 		}
 		nm[i] = no;
 		b[i] = bo;
@@ -163,19 +165,7 @@ __global__ void __launch_bounds__(EW_THREADS) sgd_kernel_v4(const float4* g, con
 		const float gs[4] = { gv.x, gv.y, gv.z, gv.w }, as[4] = { av.x, av.y, av.z, av.w }, ms[4] = { mv.x, mv.y, mv.z, mv.w };
 		float bo[4], no[4];
 #pragma unroll
-		for (int e = 0; e < 4; e++) {
-			if (nesterov) {
-				float grad = scale * gs[e];
-				const float mom = momentum * ms[e] + grad + decay * as[e];
-				no[e] = mom;
-				grad += momentum * mom;
-				bo[e] = as[e] - rate * grad;
-			} else {
-				const float mom = momentum * ms[e] + inv_dampening * (scale * gs[e] + decay * as[e]);
-				no[e] = mom;
-				bo[e] = as[e] - rate * mom;
-			}
-		}
+		for (int e = 0; e < 4; e++) sgd_update(gs[e], as[e], ms[e], nesterov, rate, scale, decay, momentum, inv_dampening, &bo[e], &no[e]);
 		nm[i] = make_float4(no[0], no[1], no[2], no[3]);
 		b[i] = make_float4(bo[0], bo[1], bo[2], bo[3]);
 	}
@@ -199,18 +189,10 @@ __global__ void __launch_bounds__(EW_THREADS) sgd_multi_kernel(const sgd_multi_t
 	V bo, no;
 #pragma unroll
 	for (int e = 0; e < W; e++) {
-		const float avf = (float)av[e];
-		if (nesterov) {
-			float grad = scale * (float)gv[e];
-			const float mom = momentum * (float)mv[e] + grad + decay * avf;
-			no[e] = (T)mom;
-			grad += momentum * mom;
-			bo[e] = (T)(avf - rate * grad);
-		} else {
-			const float mom = momentum * (float)mv[e] + inv_dampening * (scale * (float)gv[e] + decay * avf);
-			no[e] = (T)mom;
-			bo[e] = (T)(avf - rate * mom);
-		}
+		float bf, nf;
+		sgd_update((float)gv[e], (float)av[e], (float)mv[e], nesterov, rate, scale, decay, momentum, inv_dampening, &bf, &nf);
+		no[e] = (T)nf;
+		bo[e] = (T)bf;
 	}
 	((V*)s.nm[k])[i] = no;
 	((V*)s.b[k])[i] = bo;
@@ -540,6 +522,11 @@ static int _set_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 		const int dt = CCV_GET_DATA_TYPE(o->info.datatype);
 		if (cmd.info.blas.a[0] == 0) { HIP_ENFORCE(hipMemsetAsync(o->data.u8, 0, n * datatype_size(dt), stream_of(stream_context))); continue; }
 		if (dt == CCV_32F) { const int r = fill_f32(o->data.f32, n, cmd.info.blas.a[0], stream_context); if (r) return r; }
+		else if (dt == CCV_16F) { // natively (round 6: the trainers' ~50 SET commands per step used to fill an fp32 image and convert it down): pairs of the half value as one 32-bit pattern
+			OpFill f; f.v = cmd.info.blas.a[0];
+			const int r = ew_map_any<OpFill, 0>(f, o->info.datatype, o->data.u8, 0, 0, 0, n, stream_context);
+			if (r) return r;
+		}
 		else if (dt == CCV_32S) { union { int i; float f; } u; u.i = (int)cmd.info.blas.a[0]; const int r = fill_f32(o->data.f32, n, u.f, stream_context); if (r) return r; }
 		else if (dt == CCV_64F) { // a double is two 32-bit halves: fill pairs
 			union { double d; float f[2]; } u; u.d = (double)cmd.info.blas.a[0];
@@ -785,8 +772,8 @@ NNC_REG(CCV_NNC_SCALAR_MUL_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV
 NNC_REG(CCV_NNC_DROPOUT_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _dropout_forw)
 NNC_REG(CCV_NNC_DROPOUT_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _dropout_back)
 NNC_REG(CCV_NNC_SGD_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _sgd_forw)
-NNC_REG(CCV_NNC_SET_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_forw)
-NNC_REG(CCV_NNC_SET_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_back)
+NNC_REG(CCV_NNC_SET_FORWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_forw)   // (CCV_16F in the row: handled natively, no fp32 images)
+NNC_REG(CCV_NNC_SET_BACKWARD, CCV_NNC_BACKEND_GPU_CUDNN, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_32S, CCV_TENSOR_GPU_MEMORY, _set_back)
 NNC_REG(CCV_NNC_DATA_TRANSFER_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U | CCV_QX, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
 NNC_REG(CCV_NNC_DATA_TRANSFER_BACKWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_64F | CCV_32F | CCV_16F | CCV_64S | CCV_32S | CCV_8U | CCV_QX, CCV_TENSOR_CPU_MEMORY | CCV_TENSOR_GPU_MEMORY, _data_transfer)
 NNC_REG(CCV_NNC_RANDOM_UNIFORM_FORWARD, CCV_NNC_BACKEND_GPU_REF, ALL_FORMATS, CCV_32F, CCV_TENSOR_GPU_MEMORY, _random_exec)

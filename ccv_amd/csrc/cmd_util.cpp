@@ -11,6 +11,7 @@
 //     the global stores are 256-byte-per-wavefront coalesced; picked for dense NCHW <-> NHWC (R = channels, C = H*W or
 //     the reverse), the layout change conv uses for NCHW tensors.
 #include "common.h"
+#include "isa.h"
 #include <stdint.h>
 
 using namespace nnc;
@@ -139,6 +140,43 @@ __global__ void __launch_bounds__(256) transpose_convert_vec4_kernel(const TI* _
 	}
 }
 
+// Halves to halves in 16-byte accesses (round 6): the NCHW <-> NHWC re-layouts around the half-precision 3 x 3 convolutions were 3.6 - 6.2 % of the f16 trainers'
+// kernel time in 8-byte accesses through an fp32 tile (an 8-byte access moves 0.54 - 0.70 of the 16-byte rate on this chip).  A 64 x 64 tile of halves goes into
+// LDS as it arrives (one ds_write_b128 per lane, rows 192 bytes apart) and comes back out transposed through gfx950's LDS transpose read (ds_read_b64_tr_b16,
+// isa.h tr_read4: a 16-lane group reads a [4 rows][16 columns] block, lane i receives column i): two reads give a lane eight consecutive input rows of one
+// column = 16 contiguous bytes of an output row; a wave writes 16 output rows x 64 contiguous bytes per store.  R, C multiples of 8, 16-byte aligned tensors.
+constexpr int TH_PITCH = TT + 32; // halves per tile row: 192 bytes = 48 dwords (the four rows of a transpose-read block land 16 banks apart: mfma_gemm_f16.h gemm16_npitch)
+__global__ void __launch_bounds__(256) transpose_half8_kernel(const nnc::half_t* __restrict__ in, nnc::half_t* __restrict__ out, const int R, const int C)
+{
+	using namespace nnc;
+	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+	__shared__ __attribute__((aligned(16))) half_t tile[TT * TH_PITCH];
+	const int c0 = blockIdx.x * TT, r0 = blockIdx.y * TT;
+	const size_t base = (size_t)blockIdx.z * R * C;
+	const int t = threadIdx.x;
+#pragma unroll
+	for (int j = 0; j < 2; j++) {
+		const int id = t + 256 * j;
+		const int r = id >> 3, cc = (id & 7) << 3;
+		u4 v = { 0, 0, 0, 0 };
+		if (r0 + r < R && c0 + cc < C) v = *(const u4*)(in + base + (size_t)(r0 + r) * C + c0 + cc);
+		*(u4*)(tile + r * TH_PITCH + cc) = v;
+	}
+	__syncthreads();
+	const int lane = t & 63, w = t >> 6, g = lane >> 4, i = lane & 15;
+#pragma unroll
+	for (int p = 0; p < 2; p++) {
+		const int cblk = p * 2 + (w >> 1), rchunk = (w & 1) * 4 + g;
+		const half_t* const blk = tile + (rchunk * 8) * TH_PITCH + cblk * 16;
+		halfx4 lo = tr_read4(blk, TH_PITCH, i), hi = tr_read4(blk + 4 * TH_PITCH, TH_PITCH, i);
+		NNC_WAIT_LGKM0(); // (the transpose reads are asm: hipcc does not count them; the pins tie the uses below behind the wait)
+		NNC_PIN_VEC(lo); NNC_PIN_VEC(hi);
+		const halfx8 v = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+		const int c = c0 + cblk * 16 + i, r = r0 + rchunk * 8;
+		if (c < C && r < R) *(halfx8*)(out + base + (size_t)c * R + r) = v;
+	}
+}
+
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) convert_kernel(const TI* in, TO* out, const size_t n)
 {
@@ -230,6 +268,12 @@ static int launch_transpose(const void* in, void* out, int batch, int R, int C, 
 // transpose -- half -> float -> half is exact
 static int launch_transpose_half(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
 {
+	static const int wide = !(getenv("NNC_MI355X_TRANSPOSE_HALF8") && *getenv("NNC_MI355X_TRANSPOSE_HALF8") == '0');
+	if (wide && batch > 0 && R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+		hipLaunchKernelGGL(transpose_half8_kernel, dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, (half_t*)out, R, C);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
 	if (batch > 0 && R > 0 && C > 0 && R % 4 == 0 && C % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 7) == 0) {
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_convert_vec4_kernel<half_t, half_t>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, (half_t*)out, R, C);
 		HIP_ENFORCE(hipGetLastError());

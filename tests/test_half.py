@@ -445,3 +445,20 @@ def test_half_contraction_chunks_of_eight_equal_chunks_of_four(backend, what):
             backend.tune_set("GEMM_HALF_CHUNK8", 1)
         for x, y in zip(res[1], res[0]):
             assert np.array_equal(x.view(np.uint16), y.view(np.uint16))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8), (3, 72, 8, 16), (1, 128, 16, 16), (2, 8, 4, 2), (2, 200, 28, 28), (2, 12, 14, 14)])
+def test_half_layout_transposes_in_16_byte_accesses(backend, shape):
+    """Round 6: NCHW <-> NHWC of CCV_16F tensors (FORMAT_TRANSFORM, and the re-layouts around the f16 3 x 3 convolutions) through transpose_half8_kernel -- a 64 x 64
+    tile of halves in LDS, read back through the LDS transpose read, 16 bytes per lane both ways (ccv_amd/csrc/cmd_util.cpp).  Exact (a permutation of bits); sizes
+    with ragged tiles, and one (14 x 14 planes) that takes the 8-byte kernel.  lib/nnc/cmd/util/ccv_nnc_util_cpu_ref.c:996-1082 is the spec."""
+    L = backend
+    n, c, h, w = shape
+    x = np.random.default_rng(9).standard_normal((n, c, h, w)).astype(np.float16)
+    a = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NCHW, nnc.CCV_16F, (n, c, h, w), 0), x)
+    b = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NHWC, nnc.CCV_16F, (n, h, w, c), 0), np.zeros((n, h, w, c), np.float16))
+    assert L.cmd_exec(nnc.CMD_FORMAT_TRANSFORM_FORWARD(), nnc.NO_HINT, 0, [a], [b]) == 0
+    assert np.array_equal(b.numpy(), x.transpose(0, 2, 3, 1))
+    a2 = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NCHW, nnc.CCV_16F, (n, c, h, w), 0), np.zeros((n, c, h, w), np.float16))
+    assert L.cmd_exec(nnc.CMD_FORMAT_TRANSFORM_FORWARD(), nnc.NO_HINT, 0, [b], [a2]) == 0
+    assert np.array_equal(a2.numpy(), x)
