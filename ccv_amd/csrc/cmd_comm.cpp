@@ -104,9 +104,10 @@ thread_local int tl_in_comm = 0; // stream_of() calls made while recording / flu
 //   * every other stream joins the communication stream at its next order-observing point (device_rt.cpp joined(): launch, synchronise, signal, callback).
 // Every rank runs the same program, so every rank sorts and cuts alike: the collectives meet in the same order.  A gradient with no record (another command
 // wrote it: accumulation, a row without the hook) waits for the tail of the stream its all-reduce was issued on -- the order of immediate issue.
-struct ready_t { hipEvent_t ev; unsigned long seq; };
+struct ready_ev_t { hipEvent_t ev; int refs; }; // one event per backward COMMAND, shared by the gradients it wrote (weight + bias: one record, not two)
+struct ready_t { ready_ev_t* e; unsigned long seq; };
 std::unordered_map<const void*, ready_t>& g_ready = *new std::unordered_map<const void*, ready_t>;
-std::vector<hipEvent_t>& g_ready_pool = *new std::vector<hipEvent_t>;
+std::vector<ready_ev_t*>& g_ready_pool = *new std::vector<ready_ev_t*>;
 unsigned long g_ready_seq = 0;
 int g_overlap_set = -1; // nnc_mi355x_comm_overlap(): -1 = the environment decides
 hipStream_t g_overlap_stream = 0;
@@ -117,13 +118,15 @@ bool overlap_wanted()
 	static const int env = (getenv("NNC_MI355X_COMM_OVERLAP") && *getenv("NNC_MI355X_COMM_OVERLAP") == '1') ? 1 : 0;
 	return (g_overlap_set >= 0 ? g_overlap_set : env) != 0;
 }
-hipEvent_t ready_event()
-{ // g_comm_mutex held
-	hipEvent_t e;
+ready_ev_t* ready_event()
+{ // g_comm_mutex held; refs = 0
+	ready_ev_t* e;
 	if (!g_ready_pool.empty()) { e = g_ready_pool.back(); g_ready_pool.pop_back(); }
-	else HIP_ENFORCE(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	else { e = new ready_ev_t; HIP_ENFORCE(hipEventCreateWithFlags(&e->ev, hipEventDisableTiming)); }
+	e->refs = 0;
 	return e;
 }
+void ready_unref(ready_ev_t* const e) { if (e && --e->refs <= 0) g_ready_pool.push_back(e); }
 size_t bucket_bytes()
 {
 	static size_t b = 0;
@@ -140,16 +143,17 @@ bool overlapped_flush_locked()
 		HIP_ENFORCE(hipGetDevice(&dev));
 		stream_registered(dev, g_overlap_stream);
 	}
-	struct item_t { int i; unsigned long seq; hipEvent_t ev; bool mine; };
+	struct item_t { int i; unsigned long seq; ready_ev_t* e; };
 	std::vector<item_t> items((size_t)g_pending_n);
 	for (int i = 0; i < g_pending_n; i++) {
 		const pending_t& p = g_pending[i];
 		auto at = g_ready.find(p.in);
-		if (at != g_ready.end()) { items[i] = item_t{ i, at->second.seq, at->second.ev, true }; g_ready.erase(at); }
+		if (at != g_ready.end()) { items[i] = item_t{ i, at->second.seq, at->second.e }; g_ready.erase(at); } // (the map's reference becomes the item's)
 		else { // unknown writer: the tail of the issuing stream, now
-			const hipEvent_t e = ready_event();
-			HIP_ENFORCE(hipEventRecord(e, p.stream));
-			items[i] = item_t{ i, ++g_ready_seq, e, true };
+			ready_ev_t* const e = ready_event();
+			e->refs = 1;
+			HIP_ENFORCE(hipEventRecord(e->ev, p.stream));
+			items[i] = item_t{ i, ++g_ready_seq, e };
 		}
 	}
 	std::stable_sort(items.begin(), items.end(), [](const item_t& a, const item_t& b) { return a.seq < b.seq; });
@@ -157,14 +161,14 @@ bool overlapped_flush_locked()
 	while (at < items.size()) {
 		size_t end = at, bytes = 0;
 		while (end < items.size() && (end == at || bytes < bucket_bytes())) { const pending_t& p = g_pending[items[end].i]; bytes += p.count * (p.dt == ncclHalf ? 2 : 4); end++; }
-		for (size_t k = at; k < end; k++) HIP_ENFORCE(hipStreamWaitEvent(g_overlap_stream, items[k].ev, 0));
+		for (size_t k = at; k < end; k++) if (k == at || items[k].e != items[k - 1].e) HIP_ENFORCE(hipStreamWaitEvent(g_overlap_stream, items[k].e->ev, 0));
 		RCCL_ENFORCE(ncclGroupStart());
 		for (size_t k = at; k < end; k++) { const pending_t& p = g_pending[items[k].i]; RCCL_ENFORCE(ncclAllReduce(p.in, p.out, p.count, p.dt, ncclSum, p.comm, g_overlap_stream)); }
 		RCCL_ENFORCE(ncclGroupEnd());
 		g_stat_groups++; g_stat_buckets++;
 		at = end;
 	}
-	for (const item_t& it : items) g_ready_pool.push_back(it.ev); // (the waits have been enqueued: an event may be re-recorded)
+	for (const item_t& it : items) ready_unref(it.e); // (the waits have been enqueued: an event nobody else refers to may be re-recorded)
 	if (!g_overlap_done) HIP_ENFORCE(hipEventCreateWithFlags(&g_overlap_done, hipEventDisableTiming));
 	HIP_ENFORCE(hipEventRecord(g_overlap_done, g_overlap_stream));
 	g_stat_collectives += g_pending_n; g_stat_overlapped += g_pending_n;
@@ -379,16 +383,27 @@ namespace nnc {
 std::atomic<int> g_comm_pending(0);
 std::atomic<int> g_comm_overlap_on(0);
 std::atomic<unsigned long> g_comm_overlap_epoch(0);
-void comm_gradient_written(const ccv_nnc_tensor_t* const t, ccv_nnc_stream_context_t* const ctx)
-{
-	if (!t || !g_comm_overlap_on.load(std::memory_order_relaxed)) return;
+void comm_gradients_written(ccv_nnc_tensor_t* const* const ts, const int n, ccv_nnc_stream_context_t* const ctx)
+{ // ONE event behind the command for all the gradients it wrote
+	if (!g_comm_overlap_on.load(std::memory_order_relaxed)) return;
+	int any = 0;
+	for (int i = 0; i < n; i++) if (ts[i]) any = 1;
+	if (!any) return;
 	const hipStream_t st = stream_peek(ctx);
 	pthread_mutex_lock(&g_comm_mutex);
-	ready_t& r = g_ready[(const void*)t->data.u8];
-	if (!r.ev) r.ev = ready_event();
-	HIP_ENFORCE(hipEventRecord(r.ev, st));
-	r.seq = ++g_ready_seq;
-	if (g_ready.size() > 65536) { for (auto& kv : g_ready) g_ready_pool.push_back(kv.second.ev); g_ready.clear(); } // (a caller that never all-reduces what it reports)
+	ready_ev_t* const e = ready_event();
+	HIP_ENFORCE(hipEventRecord(e->ev, st));
+	const unsigned long seq = ++g_ready_seq;
+	for (int i = 0; i < n; i++) {
+		if (!ts[i]) continue;
+		ready_t& r = g_ready[(const void*)ts[i]->data.u8];
+		if (r.e == e) continue; // (two outputs on one buffer)
+		ready_unref(r.e);
+		r.e = e; r.seq = seq;
+		e->refs++;
+	}
+	if (e->refs == 0) g_ready_pool.push_back(e);
+	if (g_ready.size() > 65536) { for (auto& kv : g_ready) ready_unref(kv.second.e); g_ready.clear(); } // (a caller that never all-reduces what it reports)
 	pthread_mutex_unlock(&g_comm_mutex);
 }
 void comm_gradient_touched(const ccv_nnc_tensor_t* const t)
@@ -396,7 +411,7 @@ void comm_gradient_touched(const ccv_nnc_tensor_t* const t)
 	if (!t || !g_comm_overlap_on.load(std::memory_order_relaxed)) return;
 	pthread_mutex_lock(&g_comm_mutex);
 	auto at = g_ready.find((const void*)t->data.u8);
-	if (at != g_ready.end()) { g_ready_pool.push_back(at->second.ev); g_ready.erase(at); }
+	if (at != g_ready.end()) { ready_unref(at->second.e); g_ready.erase(at); }
 	pthread_mutex_unlock(&g_comm_mutex);
 }
 void comm_overlap_join(hipStream_t stream, unsigned long* const seen)

@@ -1396,8 +1396,10 @@ static int _conv_back_any(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, co
 static int conv_back_report(const int r, const int flags, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)
 {
 	if (r == CCV_NNC_EXEC_SUCCESS && g_comm_overlap_on.load(std::memory_order_relaxed))
-		for (int i = 1; i < output_size && i < 3; i++)
-			if (outputs[i]) { if (flags & CCV_NNC_ACCUMULATE_OUTPUT) comm_gradient_touched(outputs[i]); else comm_gradient_written(outputs[i], stream_context); }
+	{
+		if (flags & CCV_NNC_ACCUMULATE_OUTPUT) { for (int i = 1; i < output_size && i < 3; i++) comm_gradient_touched(outputs[i]); }
+		else if (output_size > 1) comm_gradients_written(outputs + 1, output_size > 3 ? 2 : output_size - 1, stream_context);
+	}
 	return r;
 }
 static int conv_back_entry(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const stream_context)

@@ -486,6 +486,7 @@ static int _sgd_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const i
 	// launch for all of them at the stream's next order-observing point (peephole.cpp, "SGD batches")
 	if (deferred_sgd_head(_sgd_forw, cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context)) return CCV_NNC_EXEC_SUCCESS;
 	hipStream_t stream = stream_of(stream_context);
+	deferred_sgd_launched(stream_context);
 	if (dt == CCV_16F) {
 		if ((cnt % 8 == 0) && aligned16(g->data.u8) && aligned16(a->data.u8) && aligned16(m->data.u8) && aligned16(b->data.u8) && aligned16(n->data.u8)) {
 			typedef pack16<half_t>::type V;

@@ -929,8 +929,10 @@ static int _bnorm_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const
 		: bnorm_back_t<float>(cmd, hint, flags, inputs, input_size, outputs, output_size, stream_context);
 	// the scale / bias gradients just enqueued (cmd_comm.cpp "Overlap": deployment (b)'s all-reduce of each starts behind its own writer)
 	if (r == CCV_NNC_EXEC_SUCCESS && g_comm_overlap_on.load(std::memory_order_relaxed))
-		for (int i = 1; i < output_size && i < 3; i++)
-			if (outputs[i]) { if (flags & CCV_NNC_ACCUMULATE_OUTPUT) comm_gradient_touched(outputs[i]); else comm_gradient_written(outputs[i], stream_context); }
+	{
+		if (flags & CCV_NNC_ACCUMULATE_OUTPUT) { for (int i = 1; i < output_size && i < 3; i++) comm_gradient_touched(outputs[i]); }
+		else if (output_size > 1) comm_gradients_written(outputs + 1, output_size > 3 ? 2 : output_size - 1, stream_context);
+	}
 	return r;
 }
 

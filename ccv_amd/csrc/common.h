@@ -109,7 +109,7 @@ void comm_release_context(const void* ctx);
 // the commands that WROTE its gradients (not behind the whole issuing stream), and every other stream joins them at its next order-observing point.
 extern std::atomic<int> g_comm_overlap_on;            // 1 while the mode is on and a rank communicator exists: the backward commands then report their gradient outputs
 extern std::atomic<unsigned long> g_comm_overlap_epoch; // bumped by every overlapped flush
-void comm_gradient_written(const ccv_nnc_tensor_t* t, ccv_nnc_stream_context_t* ctx); // a backward command has just enqueued the kernels that write this weight / bias gradient
+void comm_gradients_written(ccv_nnc_tensor_t* const* ts, int n, ccv_nnc_stream_context_t* ctx); // a backward command has just enqueued the kernels that write these weight / bias gradients (null entries skipped): one event for all of them
 void comm_gradient_touched(const ccv_nnc_tensor_t* t); // some other command writes it too (accumulation): forget the record, the all-reduce takes stream order
 void comm_overlap_join(hipStream_t stream, unsigned long* seen);
 hipStream_t stream_peek(const ccv_nnc_stream_context_t* ctx); // device_rt.cpp: the context's stream, no hooks
@@ -125,6 +125,8 @@ int deferred_fuse_relu_back(const ccv_nnc_tensor_t* g, const ccv_nnc_tensor_t* b
 bool deferred_signal_op(int emit, const ccv_nnc_stream_context_t* ctx, const ccv_nnc_stream_signal_t* signal); // true: kept in a recorded command's trail (peephole.cpp), not to be performed now
 bool deferred_trail_cmd(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, int flags, ccv_nnc_tensor_t* const* inputs, int input_size, ccv_nnc_tensor_t* const* outputs, int output_size, ccv_nnc_stream_context_t* ctx); // true: kept behind the trail operations of its stream
 bool deferred_sgd_head(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, int flags, ccv_nnc_tensor_t* const* inputs, int input_size, ccv_nnc_tensor_t* const* outputs, int output_size, ccv_nnc_stream_context_t* ctx); // true: kept as the first of a batch of updates on its stream
+extern std::atomic<unsigned long> g_launch_seq; // device_rt.cpp: stream_of() calls so far
+void deferred_sgd_launched(const ccv_nnc_stream_context_t* ctx); // an update has just been launched on the spot on this stream: the NEXT one, if it arrives with nothing launched in between, starts a batch
 bool sgd_is_exec(exec_fn_t fn); // cmd_ew.cpp: is this the SGD_FORWARD exec function (whose consecutive trail entries sgd_forw_multi can launch together)?
 int sgd_forw_multi(const ccv_nnc_cmd_t* const* cmds, ccv_nnc_tensor_t* const* const* ins, ccv_nnc_tensor_t* const* const* outs, int n, ccv_nnc_stream_context_t* ctx); // 0: launched; > 0: not batchable, run them one by one
 void signal_emit_now(const ccv_nnc_stream_context_t* ctx, const ccv_nnc_stream_signal_t* signal); // device_rt.cpp: the event record / stream wait themselves

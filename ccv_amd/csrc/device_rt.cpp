@@ -140,8 +140,10 @@ static inline device_local_t* joined(device_local_t* const l)
 	if (g_comm_overlap_epoch.load(std::memory_order_acquire) != l->comm_seen) comm_overlap_join(l->stream, &l->comm_seen);
 	return l;
 }
+std::atomic<unsigned long> g_launch_seq(0); // bumped by every stream_of(): "has anything been launched through this library since ...?" (peephole.cpp: SGD batches)
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
 {
+	g_launch_seq.fetch_add(1, std::memory_order_relaxed);
 	if (g_comm_pending) comm_flush(); // a launch is about to be ordered on a stream: recorded collectives go first (cmd_comm.cpp)
 	if (g_deferred_live) deferred_flush(ctx); // ... and so does this stream's recorded command (peephole.cpp)
 	if (!ctx) return (hipStream_t)0;

@@ -333,10 +333,20 @@ static int gemm_run_h_planar(const char* name, LA la, LB lb, EpiStoreHT epi, con
 	note_kernel(name);
 	const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
 	const bool big = g_force_tile ? !((g_force_tile & 0xff) == 1 && (g_force_tile >> 8) == 1) : (!small_tiles && M > 64 && N > 64 && (big_tiles >= device_cu_count() || K >= 4096));
-	char prof_name[192];
-	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_kernel<%d, %d> EPI = EpiStoreHT", name, big ? 2 : 1, big ? 2 : 1);
-	ProfScope prof(prof_name, 2.0 * (double)M * (double)N * (double)K, -2.0 * ((double)M * K + (double)N * K + (double)M * N), M, N, K, 1, 1, stream);
 	const bool v8 = tune(TUNE_GEMM_HALF_CHUNK8) && loader_vec8_ok(la) && loader_vec8_ok(lb);
+	// 256 x 128 block tiles, 128 x 64 per wave (round 6; nnc_mi355x_debug_force_tile(4, 2)): twice the MFMAs per K-step against 1.5 x the fragment reads and chunk
+	// addresses.  Measured (tools/conv_half_bench.py, profiles/r06_v11_conv_half_bench.txt): 1 - 6 % faster on every forward / data-gradient shape of the two trainers that
+	// fills the chip with such tiles (64 -> 128 at 32^2: 0.121 -> 0.118 / 0.176 -> 0.166 ms), equal on the rest -- the kernel is not bound by that ratio either.
+	const long tall_tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
+	const bool tall = v8 && (g_force_tile ? g_force_tile == (4 | (2 << 8)) : (big && tall_tiles >= 2L * device_cu_count()));
+	char prof_name[192];
+	snprintf(prof_name, sizeof(prof_name), "%s|nnc::mfma_gemm_f16_kernel<%d, %d> EPI = EpiStoreHT", name, tall ? 4 : (big ? 2 : 1), tall ? 2 : (big ? 2 : 1));
+	ProfScope prof(prof_name, 2.0 * (double)M * (double)N * (double)K, -2.0 * ((double)M * K + (double)N * K + (double)M * N), M, N, K, 1, 1, stream);
+	if (tall) {
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 4, 2, 8>), dim3((unsigned)tall_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 255) / 256, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
+		HIP_ENFORCE(hipGetLastError());
+		return CCV_NNC_EXEC_SUCCESS;
+	}
 	if (big && v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 2, 2, 8>), dim3((unsigned)big_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 127) / 128, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
 	else if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 2, 2>), dim3((unsigned)big_tiles, 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 127) / 128, (N + 127) / 128, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);
 	else if (v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreHT, 1, 1, 8>), dim3((unsigned)(((M + 63) / 64) * ((N + 63) / 64)), 1, 1), dim3(GEMM_THREADS), 0, stream, la, lb, epi, (M + 63) / 64, (N + 63) / 64, K, K > 0 ? K : 1, 1, 0L, 0L, 0L, 0L, ko);

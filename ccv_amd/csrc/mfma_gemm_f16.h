@@ -283,43 +283,34 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 	const int row_a = wm * (32 * WM), col_b = wn * (32 * WN);
-	// Two register sets (round 6): the loads of tile kt + 2 go out at the top of K-step kt (into the set tile kt came through); tile kt + 1 -- loaded a whole
-	// K-step ago -- is written to the other LDS buffer behind the MFMAs.  With ONE set (rounds 2 - 5) a tile's loads were issued at the top of the step that
-	// also had to store them: every K-step -- eight MFMAs per wave, 256 matrix-pipe cycles -- waited out a full global-load round trip, and three workgroups
-	// per CU could not cover it: the kernels sat at 0.20 - 0.25 of the f16 peak in the trainers' shapes (profiles/r05_v8_*, r06_v4_*), which is what
-	// (12 waves x 8 MFMAs x 32 cycles) / (4 SIMDs x one ~1.5 us round trip) predicts.  Pairs of K-steps with the set index a compile-time constant.
-	typedef typename FetchHOf<LA, WM, CW>::reg_t areg_t;
-	typedef typename FetchHOf<LB, WN, CW>::reg_t breg_t;
-	areg_t ra[2][FetchHOf<LA, WM, CW>::NCH];
-	breg_t rb[2][FetchHOf<LB, WN, CW>::NCH];
+	// (Round 6 measured a second register set here -- the loads of tile kt + 2 issued at the top of K-step kt, the buffer kernel's schedule -- on the trainers'
+	// shapes: no change for forward / data gradient (100.9 -> 100.3 us), the filter gradient 7 - 13 % slower, and the NHWC-output form lost a wave per SIMD to the
+	// 16 extra registers; profiles/r06_v10_*_kernel_stats.md.  The K-step is not waiting for its loads: per eight MFMAs a wave issues ~100 other instructions
+	// (the gather loaders' address arithmetic, fragment reads, LDS writes, the barrier), and three waves per SIMD make that the bound.  One set, as before.)
+	typename FetchHOf<LA, WM, CW>::reg_t ra[FetchHOf<LA, WM, CW>::NCH];
+	typename FetchHOf<LB, WN, CW>::reg_t rb[FetchHOf<LB, WN, CW>::NCH];
 	if (nk > 0) {
 		const int k0 = kmap(k_begin);
 		fa.template prep<true>(la, k0, klim);
 		fb.template prep<true>(lb, k0, klim);
-		fa.issue(la, ra[0]);
-		fb.issue(lb, rb[0]);
-		if (nk > 1) {
-			const int k1 = kmap(k_begin + GEMM_BK);
-			fa.template prep<true>(la, k1, klim);
-			fb.template prep<true>(lb, k1, klim);
-			fa.issue(la, ra[1]);
-			fb.issue(lb, rb[1]);
-		}
-		fa.store(lds[0], ra[0], t);
-		fb.store(lds[0] + A_HALVES, rb[0], t);
+		fa.issue(la, ra);
+		fb.issue(lb, rb);
+		fa.store(lds[0], ra, t);
+		fb.store(lds[0] + A_HALVES, rb, t);
 	}
 	__syncthreads();
-	auto kstep = [&](auto sid, const int kt) {
-		constexpr int S = decltype(sid)::value;
-		if (kt + 2 < nk) { // the tile after next: addresses, then the loads go out two K-steps ahead of their store
-			const int k2 = kmap(k_begin + (kt + 2) * GEMM_BK);
-			fa.template prep<true>(la, k2, klim);
-			fb.template prep<true>(lb, k2, klim);
-			fa.issue(la, ra[S]);
-			fb.issue(lb, rb[S]);
+	for (int kt = 0; kt < nk; kt++) {
+		const int cur = kt & 1;
+		const bool more = kt + 1 < nk;
+		if (more) { // next tile: addresses, then the loads go out ahead of this tile's MFMAs
+			const int k1 = kmap(k_begin + (kt + 1) * GEMM_BK);
+			fa.template prep<true>(la, k1, klim);
+			fb.template prep<true>(lb, k1, klim);
+			fa.issue(la, ra);
+			fb.issue(lb, rb);
 		}
-		const half_t* const sa = lds[S];
-		const half_t* const sb = lds[S] + A_HALVES;
+		const half_t* const sa = lds[cur];
+		const half_t* const sb = lds[cur] + A_HALVES;
 #pragma unroll
 		for (int s = 0; s < 2; s++) {
 			halfx8 fa8[WM], fb8[WN];
@@ -339,19 +330,11 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 #pragma unroll
 				for (int tj = 0; tj < WN; tj++) acc[ti][tj] = nnc_mfma_f16(fa8[ti], fb8[tj], acc[ti][tj]);
 		}
-		if (kt + 1 < nk) {
-			fa.store(lds[S ^ 1], ra[S ^ 1], t);
-			fb.store(lds[S ^ 1] + A_HALVES, rb[S ^ 1], t);
+		if (more) {
+			fa.store(lds[cur ^ 1], ra, t);
+			fb.store(lds[cur ^ 1] + A_HALVES, rb, t);
 		}
 		__syncthreads();
-	};
-	{
-		int kt = 0;
-		for (; kt + 1 < nk; kt += 2) {
-			kstep(GroupId<0>(), kt);
-			kstep(GroupId<1>(), kt + 1);
-		}
-		if (kt < nk) kstep(GroupId<0>(), kt);
 	}
 	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;

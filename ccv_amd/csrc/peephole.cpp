@@ -32,8 +32,9 @@
 // signal order are what the host's schedule is made of, and both are kept; the kernels, their streams and their events are the same, only the ReLU's pass
 // over the gradient is gone.
 //
-// SGD BATCHES (round 6).  An SGD_FORWARD with nothing recorded in front of it on its stream becomes a recorded command of its own kind (DEFER_SGD_BATCH: the
-// update itself is the first entry of the slot's trail), the updates that follow it on that stream join the trail, and when the slot is launched -- at the
+// SGD BATCHES (round 6).  An SGD_FORWARD that arrives right behind another update of its stream (nothing launched in between: deferred_sgd_head) with nothing
+// recorded in front of it becomes a recorded command of its own kind (DEFER_SGD_BATCH: the update itself is the first entry of the slot's trail), the updates
+// that follow it on that stream join the trail, and when the slot is launched -- at the
 // stream's next order-observing point, like every slot -- consecutive updates of one stream go out as ONE multi-tensor launch (cmd_ew.cpp sgd_forw_multi:
 // bit-identical arithmetic).  The reference's models end a step with one SGD_FORWARD per parameter tensor (~200 for ResNet-50, 5 - 18 us each, most of it
 // launch latency and one host enqueue each).  The same merge applies to the updates a CONVOLUTION_BACKWARD's trail holds.  NNC_MI355X_SGD_BATCH=0 turns it off.
@@ -489,11 +490,20 @@ bool deferred_trail_cmd(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hin
 	return true;
 }
 
+// Which updates start a batch: only one that arrives RIGHT BEHIND another update of the same stream launched by the same thread, with nothing launched through
+// the library in between -- the signature of a caller that issues its updates back to back (ccv_amd/vgg.py, a hand-written trainer).  The reference host's
+// scheduler spreads a model's updates over many streams, each between a wait and an emit of its own: no two ever meet in a batch there, and recording every one
+// of them anyway cost what the first form of this did on ResNet-50 -- all 16 slots held by lone updates, 830 of 2 435 foldable commands per run no longer
+// recorded (the EWSUM + RELU_BACKWARD folds gone: +1.1 ms per step), 1.3 ms more host time per step (profiles/r06_v10_resnet50-nchw-bs256-f16_kernel_stats.md).
+static thread_local const ccv_nnc_stream_context_t* tl_last_sgd_ctx = 0;
+static thread_local unsigned long tl_last_sgd_seq = 0;
+void deferred_sgd_launched(const ccv_nnc_stream_context_t* const ctx) { tl_last_sgd_ctx = ctx; tl_last_sgd_seq = g_launch_seq.load(std::memory_order_relaxed); }
 // An SGD_FORWARD (parameters checked by the caller) on a stream with nothing recorded: it starts a batch (see the head of this file).  false: the caller launches it now.
 bool deferred_sgd_head(exec_fn_t fn, const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size, ccv_nnc_stream_context_t* const ctx)
 {
 	static const int on = !(getenv("NNC_MI355X_SGD_BATCH") && *getenv("NNC_MI355X_SGD_BATCH") == '0');
 	if (!on || tl_running || !enabled() || !ctx || CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU || input_size > TRAIL_IO || output_size > TRAIL_IO || !trailing_on()) return false;
+	if (tl_last_sgd_ctx != ctx || tl_last_sgd_seq != g_launch_seq.load(std::memory_order_relaxed)) return false; // not back to back (see above)
 	Lock lock(g_mu);
 	const int device = device_for(ctx);
 	wait_launching(ctx, lock);

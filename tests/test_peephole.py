@@ -563,7 +563,7 @@ def test_consecutive_updates_of_a_stream_go_out_as_multi_tensor_launches(lib, dt
             l1, u1 = C.c_long(), C.c_long()
             batches(C.byref(l1), C.byref(u1))
             if mode == "on":
-                assert u1.value - u0.value >= 2 * 24 and 0 < l1.value - l0.value <= (u1.value - u0.value) // 2, (l1.value - l0.value, u1.value - u0.value)
+                assert u1.value - u0.value >= 2 * 20 and 0 < l1.value - l0.value <= (u1.value - u0.value) // 2, (l1.value - l0.value, u1.value - u0.value)
             else:
                 assert u1.value == u0.value
             results[mode] = [t.numpy().copy() for t in ps + ms]

@@ -10,7 +10,7 @@ from ccv_amd import nnc
 # (batch, C_in, C_out, H = W)
 SHAPES = [(512, 64, 128, 32), (512, 128, 128, 16), (512, 128, 256, 16), (512, 256, 512, 8), (512, 512, 512, 4),
           (256, 64, 64, 56), (256, 128, 128, 28), (256, 256, 256, 14), (256, 512, 512, 7)]
-MODES = [((0, 0), 0), ((1, 1), 0), ((2, 2), 8), ((2, 2), 16), ((1, 1), 8)]
+MODES = [((0, 0), 0), ((1, 1), 0), ((4, 2), 0), ((2, 2), 8), ((1, 1), 8)]
 
 
 def main():

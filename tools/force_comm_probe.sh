@@ -9,14 +9,15 @@ dt, model, batch, hw, steps, kind = sys.argv[1:7]
 root = os.getcwd()
 sys.path.insert(0, root)
 from ccv_amd import nnc
-if kind == "gpu":
-    b = C.create_string_buffer(128)
-    assert nnc.load().dll.nnc_mi355x_comm_unique_id(b) == 0
-    cid = b.raw.hex()
-else:
+def fresh_id():  # (an id makes ONE communicator)
+    if kind == "gpu":
+        b = C.create_string_buffer(128)
+        assert nnc.load().dll.nnc_mi355x_comm_unique_id(b) == 0
+        return b.raw.hex()
     import binascii
-    cid = binascii.hexlify(os.urandom(16)).decode() + "5a" * 112
+    return binascii.hexlify(os.urandom(16)).decode() + "5a" * 112
 for sgd, ov in (("0", "0"), ("1", "0"), ("1", "1")):
+    cid = fresh_id()
     env = dict(os.environ, HOST_BENCH_WORLD="1", HOST_BENCH_RANK="0", HOST_BENCH_DEVICE="0", HOST_BENCH_COMM_ID=cid, NNC_MI355X_SGD_BATCH=sgd, NNC_MI355X_COMM_OVERLAP=ov, OMP_NUM_THREADS="4")
     r = subprocess.run([os.path.join(root, "oracle", "_ref", "host_resnet_bench." + kind), batch, hw, steps, "1", dt, model], capture_output=True, text=True, timeout=900, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"replica')]

@@ -624,7 +624,12 @@ int main(int argc, char** argv)
 			ccv_nnc_tensor_free(hp);
 		}
 	}
-	printf("{\"replica_probe_sumsq\": [%.17g, %.17g], ", probe_sq[0], probe_sq[1]);
+	{ /* (a diverged half-precision run has no number to print: JSON has no NaN) */
+		char pb[2][40];
+		int w_;
+		for (w_ = 0; w_ < 2; w_++) { if (probe_sq[w_] == probe_sq[w_] && probe_sq[w_] - probe_sq[w_] == 0) snprintf(pb[w_], 40, "%.17g", probe_sq[w_]); else snprintf(pb[w_], 40, "null"); }
+		printf("{\"replica_probe_sumsq\": [%s, %s], ", pb[0], pb[1]);
+	}
 	{
 		long ov_c = 0, ov_b = 0;
 		nnc_mi355x_comm_overlap_stats(&ov_c, &ov_b);
