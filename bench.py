@@ -152,7 +152,10 @@ def resnet_config(args, half, dawn=False):
         # the data-parallel check of this form: after the timed steps every rank holds the same parameters (the harness reads the first and the last parameter
         # tensor back: sum of squares), and every rank's communicator has all the ranks in it
         probes = [l.get("replica_probe_sumsq") for l in rank_lines]
-        if all(p for p in probes):
+        if any(p is None or any(v is None for v in p) for p in probes):  # (the harness prints null for a non-finite probe: ResNet-50 in f16 diverges in its hand-made multi-stage step, tools/host_resnet_bench.c)
+            dp_check = {"replica_param_sumsq_max_rel_diff": None, "rccl_ranks_per_rank": [l["process_per_gpu"]["rccl_ranks"] for l in rank_lines], "ok": False, "note": "non-finite parameters after the timed steps"}
+            print("bench.py: a rank's parameters are not finite after the timed steps", file=sys.stderr)
+        elif all(p for p in probes):
             rep = max(abs(p[k] - probes[0][k]) / max(abs(probes[0][k]), 1e-30) for p in probes for k in range(2))
             ranks_ok = all(l["process_per_gpu"]["rccl_ranks"] == gpus for l in rank_lines)
             dp_check = {"replica_param_sumsq_max_rel_diff": rep, "rccl_ranks_per_rank": [l["process_per_gpu"]["rccl_ranks"] for l in rank_lines], "ok": bool(rep <= 1e-6 and ranks_ok)}
@@ -696,7 +699,9 @@ def main():
             "metric": "images/sec fwd VGG-D 224x224 bs%d" % args.batch if fwd_only else "images/sec fwd+bwd VGG-D 224x224 bs256",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            # fp32 tensors and fp32 accumulation everywhere; the plain-matrix products of the Winograd domain and the fc layers run on the bf16 matrix pipe with every
+            # operand split EXACTLY into three bf16 values and all nine partial products kept (mfma_gemm_bf16x3.h; NNC_MI355X_GEMM_BF16X3=0: the fp32 instructions)
+            "dtype": "f32 (Winograd-domain / fc GEMMs: exact bf16x3 split, all 9 products, fp32 accumulate)" if L.tune_get("GEMM_BF16X3") > 0 else "f32", "data": "synthetic",
             "config": {"workload": "VGG-D (ccv vgg_d_params, 225x225x3 crop, NHWC) %s, batch %d per GPU, random-init weights" % ("forward only" if fwd_only else "forward+backward+SGD", args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "gflop_per_image": (ff if fwd_only else fb) / 1e9, "whole_step_tflops_per_gpu": value / world * (ff if fwd_only else fb) / 1e12, "final_loss": loss,
