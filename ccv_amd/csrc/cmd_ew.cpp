@@ -591,8 +591,11 @@ __host__ __device__ __forceinline__ unsigned mix32(unsigned x)
 	x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
 	return x;
 }
-__global__ void __launch_bounds__(EW_THREADS) dropout_forw_kernel(const float* a, float* b, unsigned char* mask, const size_t n, const unsigned seed, const float p, const float inv_p)
+// `tick`: null, or (inside a captured step, device_rt.cpp "HIP-graph capture") the word the graph's first node increments -- the seed the host drew while the
+// step was being recorded is a kernel argument and would repeat with every replay
+__global__ void __launch_bounds__(EW_THREADS) dropout_forw_kernel(const float* a, float* b, unsigned char* mask, const size_t n, const unsigned seed0, const unsigned* tick, const float p, const float inv_p)
 {
+	const unsigned seed = tick ? seed0 + 0x9e3779b9U * tick[0] : seed0;
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
 		const unsigned r = mix32(mix32((unsigned)i ^ seed) + (unsigned)(i >> 32) + 0x9e3779b9U);
@@ -605,6 +608,10 @@ __global__ void __launch_bounds__(EW_THREADS) dropout_back_kernel(const float* g
 {
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) h[i] = mask[i] ? 0.f : g[i] * inv_p;
+}
+__global__ void __launch_bounds__(64) dropout_decide_kernel(int* decision, const unsigned seed0, const unsigned* tick, const float p)
+{ // the whole-tensor decision of a captured step: made on the device from the replay's tick (outside a capture the host decides and copies the word)
+	if (threadIdx.x == 0 && blockIdx.x == 0) decision[0] = (float)(mix32(seed0 + 0x9e3779b9U * tick[0]) >> 8) * (1.f / 16777216.f) <= p;
 }
 __global__ void __launch_bounds__(EW_THREADS) dropout_entire_kernel(const float* a, float* b, const int* decision, const size_t n, const float inv_p)
 {
@@ -633,15 +640,17 @@ static int _dropout_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, con
 	const size_t mask_bytes = tensor_count(outputs[1]->info) * datatype_size(outputs[1]->info.datatype);
 	hipStream_t stream = stream_of(stream_context);
 	const unsigned seed = dropout_seed(stream_context);
+	const unsigned* const tick = capture_tick_of(stream);
 	if (n == 0) return CCV_NNC_EXEC_SUCCESS;
 	if (cmd.info.dropout.entirety) {
 		if (mask_bytes < sizeof(int)) return CCV_NNC_EXEC_INVALID;
 		const int drop = (float)(mix32(seed) >> 8) * (1.f / 16777216.f) <= p;
-		HIP_ENFORCE(hipMemcpyAsync(outputs[1]->data.u8, &drop, sizeof(int), hipMemcpyHostToDevice, stream)); // pageable source: copied before return
+		if (tick) hipLaunchKernelGGL(dropout_decide_kernel, dim3(1), dim3(64), 0, stream, outputs[1]->data.i32, seed, tick, p); // (a captured copy node would re-read this stack word at every replay)
+		else HIP_ENFORCE(hipMemcpyAsync(outputs[1]->data.u8, &drop, sizeof(int), hipMemcpyHostToDevice, stream)); // pageable source: copied before return
 		hipLaunchKernelGGL(dropout_entire_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)a->data.f32, outputs[0]->data.f32, (const int*)outputs[1]->data.i32, n, inv_p);
 	} else {
 		if (mask_bytes < n) return CCV_NNC_EXEC_INVALID;
-		hipLaunchKernelGGL(dropout_forw_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)a->data.f32, outputs[0]->data.f32, outputs[1]->data.u8, n, seed, p, inv_p);
+		hipLaunchKernelGGL(dropout_forw_kernel, dim3(grid_for(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, (const float*)a->data.f32, outputs[0]->data.f32, outputs[1]->data.u8, n, seed, tick, p, inv_p);
 	}
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;

@@ -675,8 +675,9 @@ __host__ __device__ __forceinline__ unsigned lstm_mix32(unsigned x)
 }
 // forward: draw the scales of layer `layer`'s outputs (0 or 1 / (1 - p)), keep them in the reserved space, scale y in place; backward (DRAW = false): dy *= the kept scales
 template <bool DRAW>
-__global__ void __launch_bounds__(256) lstm_dropout_kernel(const lstm_view_t v, float* const r, const int layer, float* const y, const unsigned seed, const float p, const float inv_keep)
+__global__ void __launch_bounds__(256) lstm_dropout_kernel(const lstm_view_t v, float* const r, const int layer, float* const y, const unsigned seed0, const unsigned* const tick, const float p, const float inv_keep)
 {
+	const unsigned seed = tick ? seed0 + 0x9e3779b9U * tick[0] : seed0; // (a captured step: the replay's tick, common.h capture_tick_of)
 	const int W = v.D * v.P;
 	const size_t n = (size_t)v.T * v.B * W;
 	const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -879,7 +880,7 @@ static int _lstm_forw(EXEC_ARGS_L)
 			if (cy) HIP_ENFORCE(hipMemcpyAsync(cy->data.f32 + (size_t)p * g.BH(), cs[g.T & 1], sizeof(float) * g.BH(), hipMemcpyDeviceToDevice, stream));
 		}
 		if (l < g.L - 1 && g.dropout > 0.f)
-			hipLaunchKernelGGL(lstm_dropout_kernel<true>, dim3(blocks_of(TB * DP)), dim3(256), 0, stream, view, rsv, l, yl, lstm_seed(stream_context), g.dropout, 1.f / (1.f - g.dropout));
+			hipLaunchKernelGGL(lstm_dropout_kernel<true>, dim3(blocks_of(TB * DP)), dim3(256), 0, stream, view, rsv, l, yl, lstm_seed(stream_context), capture_tick_of(stream), g.dropout, 1.f / (1.f - g.dropout));
 		xin = yl;
 	}
 	if (g.batch_first) hipLaunchKernelGGL(lstm_swap01_kernel, dim3(blocks_of(TB * DP)), dim3(256), 0, stream, (const float*)yseq, y->data.f32, g.T, g.B, DP);
@@ -1068,7 +1069,7 @@ static int _lstm_back(EXEC_ARGS_L)
 			}
 		}
 		if (l > 0 && g.dropout > 0.f) // what layer l - 1 handed up was scaled: so is its gradient
-			hipLaunchKernelGGL(lstm_dropout_kernel<false>, dim3(blocks_of(TB * DP)), dim3(256), 0, stream, view, (float*)0, l - 1, dxl, 0u, 0.f, 0.f);
+			hipLaunchKernelGGL(lstm_dropout_kernel<false>, dim3(blocks_of(TB * DP)), dim3(256), 0, stream, view, (float*)0, l - 1, dxl, 0u, (const unsigned*)0, 0.f, 0.f);
 	}
 	if (g.batch_first) hipLaunchKernelGGL(lstm_swap01_kernel, dim3(blocks_of(TB * g.I)), dim3(256), 0, stream, (const float*)dxseq, dx->data.f32, g.T, g.B, g.I);
 	HIP_ENFORCE(hipGetLastError());

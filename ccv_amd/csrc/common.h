@@ -138,6 +138,9 @@ static inline void comm_flush_if_pending(void) { if (g_comm_pending) comm_flush(
 
 // The HIP stream a command must enqueue on, and that stream's scratch memory.
 hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx);
+// device_rt.cpp "HIP-graph capture": null, or -- `st` is recording a step -- the word (pinned host memory) the graph's first node increments at every replay:
+// kernels whose host-drawn seed would otherwise repeat mix it in
+const unsigned* capture_tick_of(hipStream_t st);
 void* workspace_of(const ccv_nnc_stream_context_t* ctx, size_t size);
 const float* zero_page_of(const ccv_nnc_stream_context_t* ctx); // 256 zero bytes in the HBM of the device `ctx` launches on
 int device_cu_count(void);

@@ -25,6 +25,7 @@ struct device_local_t {
 	size_t palette_size;  // the workspace AND the staging arena (a half-precision GEMM with palettized weights does both)
 	void* cluster_sync;   // the words the workgroups of ONE launch on this stream hand each other (nnc::cluster_sync_of): never scratch, never moved
 	unsigned cluster_epoch;
+	unsigned long cluster_capture; // the capture in which the area was last cleared (cluster_sync_of)
 	unsigned long comm_seen; // the overlapped gradient all-reduces this stream has been ordered behind (cmd_comm.cpp comm_overlap_join)
 };
 // Layout contract with the reference host (lib/nnc/ccv_nnc_stream.c:15-20, lib/nnc/gpu/ccv_nnc_compat.cu:286-299):
@@ -74,6 +75,21 @@ int current_device()
 	int d = 0;
 	HIP_ENFORCE(hipGetDevice(&d));
 	return d;
+}
+
+// -- stream capture (the section "HIP-graph capture of a compiled schedule" further down): what the rest of this file asks about it
+std::atomic<unsigned long> g_pool_seq(0);          // device allocations so far
+std::atomic<int> g_capture_active(0);              // captures in progress (process-wide: a data-parallel step's capture spans the devices)
+std::atomic<unsigned long> g_capture_id(0);        // the running capture's number (never 0 while one runs)
+std::atomic<unsigned long> g_graph_max_end_seq(0); // the newest allocation any LIVE captured graph may name (0: no graph alive)
+inline bool pool_pinned(const unsigned long seq) { return g_capture_active.load(std::memory_order_acquire) > 0 || seq <= g_graph_max_end_seq.load(std::memory_order_acquire); }
+// is THIS stream recording (a stream of the device that has not joined the capture is an ordinary stream)
+inline bool stream_capturing(hipStream_t st)
+{
+	if (!st || g_capture_active.load(std::memory_order_acquire) <= 0) return false;
+	hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+	HIP_ENFORCE(hipStreamIsCapturing(st, &status));
+	return status == hipStreamCaptureStatusActive;
 }
 
 void release_device_block(void* ptr, bool drained); // memory from nnc_mi355x_malloc goes back the way it came (the caching layer further down)
@@ -271,6 +287,13 @@ void* cluster_sync_of(const ccv_nnc_stream_context_t* ctx, size_t granule_bytes,
 		l->cluster_sync = p;
 		l->cluster_epoch = 0;
 	}
+	// A captured launch carries its epoch as a kernel argument: every replay of the graph presents the SAME tags, and the granules the previous replay left would
+	// match them.  The first cluster launch of a stream inside a capture is therefore preceded by a node that clears the area (2 MB, ~ a microsecond of HBM
+	// time per replay and stream); behind it the recorded epochs are as fresh at every replay as they were when they were recorded.
+	if (l->stream && stream_capturing(l->stream) && l->cluster_capture != g_capture_id.load(std::memory_order_acquire)) {
+		HIP_ENFORCE(hipMemsetAsync(l->cluster_sync, 0, CLUSTER_SYNC_BYTES, l->stream));
+		l->cluster_capture = g_capture_id.load(std::memory_order_acquire);
+	}
 	if (++l->cluster_epoch == 0) l->cluster_epoch = 1;
 	*epoch = l->cluster_epoch;
 	*timeout_word = g_cluster_timeout;
@@ -421,18 +444,21 @@ static int g_pool_mode = -1;
 // names every stream.)  Blocks go back to the driver through hipFree, which drains the device itself.
 struct pool_fence_t { std::vector<hipEvent_t> events; int refs; bool done; };
 struct kept_block_t { void* ptr; size_t size; pool_fence_t* fence; };
+struct live_block_t { size_t size; unsigned long seq; };   // seq: the allocation's number, process-wide (the capture section below: which graphs may name the block)
+struct parked_block_t { void* ptr; size_t size; unsigned long seq; };
 typedef std::list<kept_block_t> kept_list_t;
 struct pool_device_t {
 	std::mutex mutex;                                                     // per device (one device's allocation no longer stalls the others)
 	kept_list_t kept;                                                     // free blocks, oldest first
 	std::unordered_map<size_t, std::deque<kept_list_t::iterator> > by_size; // the same blocks by rounded size, newest last
-	std::unordered_map<void*, size_t> live;                               // blocks handed out (ptr -> rounded size)
+	std::unordered_map<void*, live_block_t> live;                         // blocks handed out (ptr -> rounded size, allocation number)
+	std::vector<parked_block_t> parked;                                   // freed while a capture was running or a captured graph that may name them is alive: not reusable yet
 	std::vector<hipStream_t> streams;                                     // the library's live streams on this device
 	std::vector<hipEvent_t> spare;                                        // events of completed fences
 	size_t kept_bytes, keep_cap;                                          // keep_cap 0 = not read yet
 };
 static pool_device_t* const g_pool = new pool_device_t[MAX_DEVICES](); // (never destroyed: cufree may arrive from a thread that outlives the exit handlers)
-static std::atomic<long> g_pool_allocs(0), g_pool_retries(0), g_pool_kept_bytes(0), g_pool_live_bytes(0), g_pool_trimmed(0), g_pool_fence_events(0), g_pool_fence_waits(0);
+static std::atomic<long> g_pool_allocs(0), g_pool_retries(0), g_pool_kept_bytes(0), g_pool_live_bytes(0), g_pool_trimmed(0), g_pool_fence_events(0), g_pool_fence_waits(0), g_pool_parked_bytes(0);
 static size_t pool_keep_cap(const int device)
 { // (caller holds the device's mutex; the device is current)
 	pool_device_t& d = g_pool[device];
@@ -526,6 +552,7 @@ static void pool_release_all(const int device)
 static void pool_trim(const int device)
 { // (caller holds the mutex) oldest first, until the kept bytes fit the cap
 	pool_device_t& d = g_pool[device];
+	if (g_capture_active.load(std::memory_order_acquire) > 0) return; // (hipFree drains the device: not while a stream captures -- the bound is enforced again by the next free after the capture)
 	const size_t cap = pool_keep_cap(device);
 	while (!d.kept.empty() && d.kept_bytes > cap) {
 		const kept_block_t k = d.kept.front();
@@ -595,7 +622,7 @@ void* nnc_mi355x_malloc(int device, size_t size)
 		}
 		lock.lock();
 	}
-	if (ptr) { d.live[ptr] = rounded; g_pool_live_bytes.fetch_add((long)rounded, std::memory_order_relaxed); }
+	if (ptr) { d.live[ptr] = live_block_t{ rounded, g_pool_seq.fetch_add(1, std::memory_order_acq_rel) + 1 }; g_pool_live_bytes.fetch_add((long)rounded, std::memory_order_relaxed); }
 	return ptr;
 }
 
@@ -627,13 +654,22 @@ void release_device_block(void* ptr, const bool drained)
 		std::unique_lock<std::mutex> lock(d.mutex);
 		auto at = d.live.find(ptr);
 		if (at != d.live.end()) {
-			kept_block_t k = { ptr, at->second, 0 };
+			kept_block_t k = { ptr, at->second.size, 0 };
+			const unsigned long seq = at->second.seq;
 			d.live.erase(at);
+			g_pool_live_bytes.fetch_sub((long)k.size, std::memory_order_relaxed);
+			if (pool_pinned(seq)) {
+				// A capture is running (its kernels have not executed: "drained" says nothing about them, and a capturing stream can be neither queried nor
+				// recorded on from here), or a captured graph that may name this block is alive: every replay touches the block again.  It waits on the side
+				// until nnc_mi355x_graph_free / the end of a failed capture looks at it again.
+				d.parked.push_back(parked_block_t{ ptr, k.size, seq });
+				g_pool_parked_bytes.fetch_add((long)k.size, std::memory_order_relaxed);
+				return;
+			}
 			if (!drained && (k.fence = fence_take(d))) k.fence->refs++;
 			d.kept.push_back(k);
 			d.by_size[k.size].push_back(std::prev(d.kept.end()));
 			d.kept_bytes += k.size;
-			g_pool_live_bytes.fetch_sub((long)k.size, std::memory_order_relaxed);
 			g_pool_kept_bytes.fetch_add((long)k.size, std::memory_order_relaxed);
 			pool_trim(device);
 			return;
@@ -642,6 +678,8 @@ void release_device_block(void* ptr, const bool drained)
 		// allocation of its size would hand out unmapped memory -- stop here, as hipFree's own error used to
 		for (const kept_block_t& k : d.kept)
 			if (k.ptr == ptr) { fprintf(stderr, "[nnc_mi355x] double free of device memory %p (device %d, %zu bytes)\n", ptr, device, k.size); abort(); }
+		for (const parked_block_t& k : d.parked)
+			if (k.ptr == ptr) { fprintf(stderr, "[nnc_mi355x] double free of device memory %p (device %d, %zu bytes, held for a captured graph)\n", ptr, device, k.size); abort(); }
 		lock.unlock(); // allocated before the switch was read, or by the plain path: the driver's free
 	}
 	HIP_ENFORCE(hipFree(ptr));
@@ -838,8 +876,8 @@ void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const 
 	}
 	if (l->workspace_size >= workspace_size && l->workspace) return l->workspace;
 	if (l->workspace) {
-		HIP_ENFORCE(hipStreamSynchronize(st)); // queued kernels may still read the old buffer
-		nnc::cluster_check_timeout();
+		// (inside a capture nothing can be waited for and nothing needs to be: the free below sets the old buffer aside for as long as the graph lives)
+		if (!stream_capturing(st)) { HIP_ENFORCE(hipStreamSynchronize(st)); nnc::cluster_check_timeout(); } // queued kernels may still read the old buffer
 		release_device_block(l->workspace, true);
 	}
 	l->workspace = nnc_mi355x_malloc(st ? l->device : current_device(), workspace_size);
@@ -877,8 +915,7 @@ void* nnc_staging_of(const ccv_nnc_stream_context_t* const stream_context, const
 	}
 	if (l->staging_size >= size && l->staging) return l->staging;
 	if (l->staging) {
-		HIP_ENFORCE(hipStreamSynchronize(st)); // queued conversions may still read the old arena
-		nnc::cluster_check_timeout();
+		if (!stream_capturing(st)) { HIP_ENFORCE(hipStreamSynchronize(st)); nnc::cluster_check_timeout(); } // queued conversions may still read the old arena
 		release_device_block(l->staging, true);
 	}
 	l->staging = nnc_mi355x_malloc(st ? l->device : current_device(), size);
@@ -903,8 +940,7 @@ void* nnc_palette_of(const ccv_nnc_stream_context_t* const stream_context, const
 	}
 	if (l->palette_size >= size && l->palette) return l->palette;
 	if (l->palette) {
-		HIP_ENFORCE(hipStreamSynchronize(st)); // a queued command may still read the old images
-		nnc::cluster_check_timeout();
+		if (!stream_capturing(st)) { HIP_ENFORCE(hipStreamSynchronize(st)); nnc::cluster_check_timeout(); } // a queued command may still read the old images
 		release_device_block(l->palette, true);
 	}
 	l->palette = nnc_mi355x_malloc(st ? l->device : current_device(), size);
@@ -1154,6 +1190,189 @@ void nnc_mi355x_staging_ring_free(void* ring)
 	delete[] r->state; delete[] r->copy_pending; delete[] r->consumed_set;
 	free(r);
 }
+
+// ---- HIP-graph capture of a compiled schedule ("HIP-graph capture of the static schedule to erase per-node launch latency") ----------
+// The reference's scheduler walks the compiled graph node by node on ONE host thread (lib/nnc/ccv_nnc_graph_run.c:581-675 _ccv_nnc_graph_exec_run_loop), for every
+// device of a data-parallel model: a step of the CIFAR-10 network is ~250 commands and a millisecond of host time for 4.6 ms of GPU time -- one thread cannot feed
+// eight devices.  A step is a fixed sequence of launches on fixed addresses once the graph is compiled and autotuned, so the host may record it once and replay it:
+//     nnc_mi355x_capture_begin(stream);
+//     ccv_cnnp_model_fit(model, ..., stream);          /* or ccv_nnc_graph_run(graph, ..., stream): enqueue-only, as always -- now into the capture */
+//     void* step = nnc_mi355x_capture_end(stream);
+//     for (...) nnc_mi355x_graph_launch(step, stream); /* one runtime call per step */
+//     nnc_mi355x_graph_free(step);
+// The schedule's other streams join the capture through the signals the host emits and waits for (the run forks from and joins back into the caller's stream:
+// ccv_nnc_graph_run.c:707-726, :819-839), the look-ahead's recorded commands launch into it (capture_end flushes them), and what this library keeps per launch
+// on the host side is made replayable:
+//   * the hand-over areas of the cluster kernels are cleared by a node in front of a stream's first cluster launch (cluster_sync_of), so recorded epochs stay fresh;
+//   * DROPOUT / the LSTM's dropout take a word of pinned host memory that the graph's first node increments: the masks differ from replay to replay
+//     (capture_tick_of; the host-side generator only runs while the step is recorded);
+//   * device memory freed while the capture runs, or later while a graph that may name it is alive, is set aside instead of being reused (release_device_block);
+//     a scratch buffer that grows inside the capture is replaced without the wait it needs outside one;
+//   * the turn order of spinning launches is re-established in front of every graph launch (ClusterTurn).
+// What cannot be recorded stops the process with the runtime's own message (HIP_ENFORCE): waiting for a capturing stream (ccv_nnc_stream_context_wait, a
+// while / case-of sub-graph's co_stream_await), a blocking copy out of it.  The tensors a recorded step names -- parameters, activations, the inputs the host
+// bound -- must keep their addresses while the graph lives: the host feeds new batches by copying INTO the bound input tensors, not by binding others.
+// Capture after a warm-up step (the first step compiles, autotunes and allocates).  One capture at a time per process.
+} // extern "C"
+namespace {
+struct graph_rec_t { hipGraph_t graph; hipGraphExec_t exec; unsigned long end_seq; size_t nodes; int device; hipStream_t last; long launches; };
+std::mutex& g_graph_mutex = *new std::mutex;                               // (never destroyed, like the allocator's lists)
+std::vector<graph_rec_t*>& g_graphs = *new std::vector<graph_rec_t*>;
+struct { hipStream_t origin; int device; } g_cap = { 0, 0 };
+unsigned* g_capture_tick = 0;                                              // pinned host memory, readable by every device: bumped once per replay
+__global__ void capture_tick_kernel(unsigned* const tick) { if (threadIdx.x == 0 && blockIdx.x == 0) tick[0] = tick[0] + 1; }
+
+// every block set aside that nothing pins any more goes back to the kept lists (the caller has made sure no graph that named them is running)
+void pool_unpark_all(void)
+{
+	const int prev = current_device();
+	for (int dev = 0; dev < MAX_DEVICES; dev++) {
+		pool_device_t& d = g_pool[dev];
+		std::unique_lock<std::mutex> lock(d.mutex);
+		if (d.parked.empty()) continue;
+		HIP_ENFORCE(hipSetDevice(dev));
+		size_t keep = 0;
+		for (size_t i = 0; i < d.parked.size(); i++) {
+			const parked_block_t b = d.parked[i];
+			if (pool_pinned(b.seq)) { d.parked[keep++] = b; continue; }
+			kept_block_t k = { b.ptr, b.size, 0 };
+			if ((k.fence = fence_take(d))) k.fence->refs++; // (ordinary work queued since then may not touch it -- but a fence costs nothing behind idle streams)
+			d.kept.push_back(k);
+			d.by_size[k.size].push_back(std::prev(d.kept.end()));
+			d.kept_bytes += k.size;
+			g_pool_kept_bytes.fetch_add((long)k.size, std::memory_order_relaxed);
+			g_pool_parked_bytes.fetch_sub((long)k.size, std::memory_order_relaxed);
+		}
+		d.parked.resize(keep);
+		pool_trim(dev);
+	}
+	HIP_ENFORCE(hipSetDevice(prev));
+}
+// spinning launches are one after the other per device (ClusterTurn): `st` is about to receive some -- behind the last turn taken elsewhere, and the last turn itself from now on
+void cluster_turn_take(const int device, hipStream_t st)
+{
+	pthread_once(&nnc::g_cluster_turn_once, nnc::cluster_turn_init);
+	if (device < 0 || device >= MAX_DEVICES) return;
+	auto& t = nnc::g_cluster_turn[device];
+	pthread_mutex_lock(&t.mutex);
+	if (t.have && t.last != st) {
+		if (!t.event) HIP_ENFORCE(hipEventCreateWithFlags(&t.event, hipEventDisableTiming));
+		HIP_ENFORCE(hipEventRecord(t.event, t.last));
+		HIP_ENFORCE(hipStreamWaitEvent(st, t.event, 0));
+	}
+	t.last = st;
+	t.have = 1;
+	pthread_mutex_unlock(&t.mutex);
+}
+}
+namespace nnc {
+const unsigned* capture_tick_of(hipStream_t st) { return stream_capturing(st) ? g_capture_tick : 0; }
+}
+extern "C" {
+
+int nnc_mi355x_capture_begin(ccv_nnc_stream_context_t* const stream_context)
+{
+	if (!stream_context || CCV_STREAM_GET_CONTEXT(stream_context->type) != CCV_STREAM_CONTEXT_GPU) { fprintf(stderr, "[nnc_mi355x] capture_begin: a GPU stream context is required (the NULL stream cannot record)\n"); return -1; }
+	if (!pool_on()) { fprintf(stderr, "[nnc_mi355x] capture_begin: NNC_MI355X_POOL_ALLOC=0 (plain hipFree drains the device: not possible inside a capture)\n"); return -1; }
+	nnc::comm_flush_if_pending(); // recorded collectives and recorded commands of EVERY stream belong in front of the capture
+	device_local_t* const l = nnc::joined(bind(stream_context));
+	std::lock_guard<std::mutex> lock(g_graph_mutex);
+	if (g_capture_active.load(std::memory_order_acquire) > 0) { fprintf(stderr, "[nnc_mi355x] capture_begin: a capture is already running\n"); return -1; }
+	if (!g_capture_tick) {
+		unsigned* w = 0;
+		HIP_ENFORCE(hipHostMalloc((void**)&w, 256, hipHostMallocDefault));
+		memset(w, 0, 256);
+		g_capture_tick = w;
+	}
+	cluster_turn_take(l->device, l->stream); // (outside the capture: an event of another stream's queue may still be waited for here)
+	g_cap.origin = l->stream;
+	g_cap.device = l->device;
+	g_capture_id.fetch_add(1, std::memory_order_acq_rel);
+	g_capture_active.store(1, std::memory_order_release);
+	// relaxed mode: allocations, event queries and the like stay legal on this and every other thread while the stream records (a loader thread keeps working)
+	const hipError_t r = hipStreamBeginCapture(l->stream, hipStreamCaptureModeRelaxed);
+	if (r != hipSuccess) {
+		(void)hipGetLastError();
+		g_capture_active.store(0, std::memory_order_release);
+		fprintf(stderr, "[nnc_mi355x] capture_begin: hipStreamBeginCapture: %s\n", hipGetErrorString(r));
+		return -1;
+	}
+	hipLaunchKernelGGL(capture_tick_kernel, dim3(1), dim3(64), 0, l->stream, g_capture_tick); // the graph's first node: every other stream forks behind it
+	return 0;
+}
+
+void* nnc_mi355x_capture_end(ccv_nnc_stream_context_t* const stream_context)
+{
+	if (!stream_context || g_capture_active.load(std::memory_order_acquire) <= 0) { fprintf(stderr, "[nnc_mi355x] capture_end: no capture is running\n"); return 0; }
+	nnc::comm_flush_if_pending(); // what the look-ahead still holds is part of the step: it launches INTO the capture
+	device_local_t* const l = bind(stream_context);
+	std::unique_lock<std::mutex> lock(g_graph_mutex);
+	if (l->stream != g_cap.origin) { fprintf(stderr, "[nnc_mi355x] capture_end: not the stream the capture began on\n"); return 0; }
+	hipGraph_t graph = 0;
+	const hipError_t r = hipStreamEndCapture(l->stream, &graph);
+	graph_rec_t* rec = 0;
+	if (r == hipSuccess && graph) {
+		rec = new graph_rec_t{ graph, 0, g_pool_seq.load(std::memory_order_acquire), 0, l->device, 0, 0 };
+		const hipError_t ri = hipGraphInstantiate(&rec->exec, graph, 0, 0, 0);
+		if (ri != hipSuccess) {
+			(void)hipGetLastError();
+			fprintf(stderr, "[nnc_mi355x] capture_end: hipGraphInstantiate: %s\n", hipGetErrorString(ri));
+			(void)hipGraphDestroy(graph);
+			delete rec;
+			rec = 0;
+		} else {
+			(void)hipGraphGetNodes(graph, 0, &rec->nodes);
+			g_graphs.push_back(rec);
+			if (rec->end_seq > g_graph_max_end_seq.load(std::memory_order_acquire)) g_graph_max_end_seq.store(rec->end_seq, std::memory_order_release);
+		}
+	} else {
+		(void)hipGetLastError();
+		fprintf(stderr, "[nnc_mi355x] capture_end: hipStreamEndCapture: %s (a stream of the step was not joined back into the capturing one, or an operation invalidated the capture)\n", hipGetErrorString(r));
+	}
+	g_capture_active.store(0, std::memory_order_release);
+	lock.unlock();
+	if (!rec) pool_unpark_all(); // nothing was recorded that could name the blocks set aside meanwhile
+	return rec;
+}
+
+int nnc_mi355x_graph_launch(void* const graph, ccv_nnc_stream_context_t* const stream_context)
+{
+	graph_rec_t* const rec = (graph_rec_t*)graph;
+	if (!rec || !rec->exec || !stream_context) return -1;
+	hipStream_t st = nnc::stream_of(stream_context); // (recorded commands of this stream go first, as in front of any launch)
+	cluster_turn_take(rec->device, st);
+	const hipError_t r = hipGraphLaunch(rec->exec, st);
+	if (r != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "[nnc_mi355x] graph_launch: %s\n", hipGetErrorString(r)); return -1; }
+	rec->last = st;
+	rec->launches++;
+	return 0;
+}
+
+int nnc_mi355x_graph_node_count(void* const graph) { return graph ? (int)((graph_rec_t*)graph)->nodes : 0; }
+
+void nnc_mi355x_graph_free(void* const graph)
+{
+	graph_rec_t* const rec = (graph_rec_t*)graph;
+	if (!rec) return;
+	const int prev = current_device();
+	HIP_ENFORCE(hipSetDevice(rec->device));
+	HIP_ENFORCE(hipDeviceSynchronize()); // its last replay may still be running (and on other devices' streams only behind this one's: the step joins back into its origin)
+	nnc::cluster_check_timeout();
+	HIP_ENFORCE(hipGraphExecDestroy(rec->exec));
+	HIP_ENFORCE(hipGraphDestroy(rec->graph));
+	{
+		std::lock_guard<std::mutex> lock(g_graph_mutex);
+		unsigned long mx = 0;
+		for (size_t i = 0; i < g_graphs.size(); i++) if (g_graphs[i] == rec) { g_graphs[i] = g_graphs.back(); g_graphs.pop_back(); break; }
+		for (graph_rec_t* g : g_graphs) if (g->end_seq > mx) mx = g->end_seq;
+		g_graph_max_end_seq.store(mx, std::memory_order_release);
+	}
+	delete rec;
+	HIP_ENFORCE(hipSetDevice(prev));
+	pool_unpark_all();
+}
+// bytes set aside for captured graphs (test / measurement hook)
+long nnc_mi355x_debug_pool_parked_bytes(void) { return g_pool_parked_bytes.load(std::memory_order_relaxed); }
 
 void* nnc_mi355x_event_new(void)
 {

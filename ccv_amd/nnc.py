@@ -30,7 +30,7 @@ CMD = dict(
     SCALED_DOT_PRODUCT_ATTENTION_FORWARD=0x284ed926, SCALED_DOT_PRODUCT_ATTENTION_BACKWARD=0x284ed927, LSTM_FORWARD=0xc5cb998c, LSTM_BACKWARD=0xc5cb998d,
     CMUL_FORWARD=0xead486e6, CMUL_BACKWARD=0xead486e7, NMS_FORWARD=0xdba26106, NMS_BACKWARD=0xdba26107,
     ROI_ALIGN_FORWARD=0xfef55168, ROI_ALIGN_BACKWARD=0xfef55169, COMPRESSION_LSSC_FORWARD=0x17ea8f72, COMPRESSION_LSSC_BACKWARD=0x17ea8f73,
-    ADD_FORWARD=0x58fb3664, ADD_BACKWARD=0x58fb3665,
+    ADD_FORWARD=0x58fb3664, ADD_BACKWARD=0x58fb3665, DROPOUT_FORWARD=0x7f2dc3e4, DROPOUT_BACKWARD=0x7f2dc3e5,
     AVERAGE_POOL_FORWARD=0x51267ab8, AVERAGE_POOL_BACKWARD=0x51267ab9,
     BATCH_NORM_FORWARD=0x5419819c, BATCH_NORM_BACKWARD=0x5419819d,
     CLAMP_FORWARD=0x2640d854, CLAMP_BACKWARD=0x2640d855,
@@ -175,10 +175,14 @@ class _Rnn(C.Structure):  # ccv_nnc.h:127-136
     _fields_ = [("hidden_size", C.c_int), ("proj_size", C.c_int), ("num_layers", C.c_int), ("bias", C.c_int), ("batch_first", C.c_int), ("bidirectional", C.c_int), ("dropout", C.c_float), ("is_test", C.c_int)]
 
 
+class _Dropout(C.Structure):  # ccv_nnc.h:235-238
+    _fields_ = [("p", C.c_float), ("entirety", C.c_int)]
+
+
 class _CmdUnion(C.Union):
     _fields_ = [("convolution", _Conv), ("convolution_transpose", _ConvTranspose), ("bnorm", _Bnorm), ("sgd", _Sgd), ("blas", _Blas), ("label_smoothing", _LabelSmoothing),
                 ("reduce", _Reduce), ("transpose", _Transpose), ("clamp", _Clamp), ("gelu", _Gelu), ("leaky_relu", _LeakyRelu),
-                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("upsample", _Upsample), ("lnorm", _Lnorm), ("gnorm", _Gnorm), ("rnn", _Rnn), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
+                ("adam", _Adam), ("rmsprop", _Rmsprop), ("f1", _F1), ("i1", _I1), ("pad", _Pad), ("upsample", _Upsample), ("lnorm", _Lnorm), ("gnorm", _Gnorm), ("rnn", _Rnn), ("dropout", _Dropout), ("_widest", C.c_char * 68), ("userdata", C.c_void_p)]
 
 
 class CmdParam(C.Structure):
@@ -299,6 +303,12 @@ def CMD_SGD_FORWARD(nesterov, rate, scale, decay, momentum, dampening):
     c = _cmd("SGD_FORWARD")
     s = c.info.sgd
     s.nesterov, s.rate, s.scale, s.decay, s.momentum, s.dampening = nesterov, rate, scale, decay, momentum, dampening
+    return c
+
+
+def CMD_DROPOUT_FORWARD(p, entirety=0):
+    c = _cmd("DROPOUT_FORWARD", (0, 0, 0))
+    c.info.dropout.p, c.info.dropout.entirety = p, entirety
     return c
 
 
@@ -697,6 +707,13 @@ class Lib:
             d.nnc_mi355x_palettized_bytes.restype = C.c_size_t
             d.nnc_mi355x_palettized_bytes.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int]
             d.nnc_mi355x_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+            d.nnc_mi355x_capture_begin.argtypes = [C.c_void_p]
+            d.nnc_mi355x_capture_end.restype = C.c_void_p
+            d.nnc_mi355x_capture_end.argtypes = [C.c_void_p]
+            d.nnc_mi355x_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+            d.nnc_mi355x_graph_node_count.argtypes = [C.c_void_p]
+            d.nnc_mi355x_graph_free.argtypes = [C.c_void_p]
+            d.nnc_mi355x_debug_pool_parked_bytes.restype = C.c_long
 
     # device runtime (product / emulator only)
     def malloc(self, device, size): return self.dll.nnc_mi355x_malloc(device, size)
@@ -713,6 +730,13 @@ class Lib:
     def signal_emit(self, stream, sig): self.dll.ccv_nnc_stream_compat_emit_signal(stream, sig)
     def signal_wait(self, stream, sig): self.dll.ccv_nnc_stream_compat_wait_signal(stream, sig)
     def cmd_ok(self, cmd, backend): return bool(self.dll.nnc_mi355x_cmd_ok(cmd, backend))
+    # HIP-graph capture of a step (include/nnc_mi355x.h "HIP-graph capture"): record the enqueue-only calls made on `stream` between begin and end, replay them
+    def capture_begin(self, stream): return self.dll.nnc_mi355x_capture_begin(stream)
+    def capture_end(self, stream): return self.dll.nnc_mi355x_capture_end(stream)
+    def graph_launch(self, graph, stream): return self.dll.nnc_mi355x_graph_launch(graph, stream)
+    def graph_node_count(self, graph): return self.dll.nnc_mi355x_graph_node_count(graph)
+    def graph_free(self, graph): self.dll.nnc_mi355x_graph_free(graph)
+    def pool_parked_bytes(self): return self.dll.nnc_mi355x_debug_pool_parked_bytes()
 
     def depalettize(self, src, datatype, input_length, qbits, number_in_blocks, dst, output_length, stream=None):
         """ccv_nnc_depalettize of device memory (lib/nnc/ccv_nnc_palettize.c:958-966): src / dst are Tensors (or raw device pointers)."""

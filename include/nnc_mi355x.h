@@ -441,6 +441,24 @@ long nnc_mi355x_debug_pool_trimmed(void);
  * library, a second framework) use the device's memory.  The library calls it itself before it creates RCCL communicators and when one of its own direct
  * allocations fails. */
 void nnc_mi355x_pool_trim(int device);
+/* ---- HIP-graph capture of a compiled schedule (the reference walks the schedule node by node on one host thread for every step and
+ * device: lib/nnc/ccv_nnc_graph_run.c:581-675 _ccv_nnc_graph_exec_run_loop, :686-843 _ccv_nnc_graph_topsorted_run_coro).  The host brackets ONE step -- any
+ * sequence of enqueue-only calls on `stream`: ccv_nnc_graph_run, ccv_cnnp_model_fit / _evaluate / _backward / _apply_gradients, ccv_nnc_cmd_exec -- and replays it:
+ *     nnc_mi355x_capture_begin(stream);  ccv_cnnp_model_fit(model, ..., stream);  void* step = nnc_mi355x_capture_end(stream);
+ *     for (...) nnc_mi355x_graph_launch(step, stream);          nnc_mi355x_graph_free(step);
+ * Nothing executes between begin and end; the schedule's other streams join through the signals the host emits and waits for.  Rules: capture after a warm-up
+ * step (compilation, autotune and first allocations are over); the tensors the step names keep their addresses while the graph lives (new batches are copied INTO
+ * the bound inputs); no wait for / blocking copy out of a recording stream (the runtime's error stops the process); one capture at a time.  Cluster batch norm,
+ * DROPOUT and the LSTM's dropout are replay-safe (a fresh mask per replay); device memory freed meanwhile is set aside until the graphs that may name it are freed.
+ * capture_begin: 0, or -1 (not a GPU stream context, a capture already running, NNC_MI355X_POOL_ALLOC=0).  capture_end: the graph, or NULL with the runtime's
+ * message on stderr (a stream of the step did not join back, an operation invalidated the capture).  graph_launch: 0 / -1. */
+int nnc_mi355x_capture_begin(ccv_nnc_stream_context_t* stream_context);
+void* nnc_mi355x_capture_end(ccv_nnc_stream_context_t* stream_context);
+int nnc_mi355x_graph_launch(void* graph, ccv_nnc_stream_context_t* stream_context);
+int nnc_mi355x_graph_node_count(void* graph);
+void nnc_mi355x_graph_free(void* graph);
+/* Hook: bytes of freed device memory currently set aside for captured graphs. */
+long nnc_mi355x_debug_pool_parked_bytes(void);
 /* Hook: events recorded by frees (a free that finds every stream idle records none) and allocations that had to wait for a kept block's last users. */
 void nnc_mi355x_debug_pool_fences(long* events, long* waits);
 /* batch-norm commands that ran on the cluster kernels (cmd_norm.cpp: a cluster of workgroups per channel keeps the channel in registers between the

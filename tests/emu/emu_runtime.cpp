@@ -212,8 +212,24 @@ void launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<
 }
 } // namespace emu
 
-struct emu_stream_s { int device; };
-struct emu_event_s { double t_ms; };
+// ---- streams, events and stream capture -----------------------------------------------------------------------------------------------------------
+struct emu_graph_s {
+	std::vector<std::function<void()> > nodes; // in the order they were recorded: a topological order
+	std::vector<emu_stream_s*> members;        // the origin first, then the streams that joined through an event
+	bool active = true;
+};
+struct emu_graph_exec_s { std::vector<std::function<void()> > nodes; };
+struct emu_stream_s { int device; emu_graph_s* cap = nullptr; unsigned long seq = 0, joined_seq = 0; };
+struct emu_event_s { double t_ms; emu_graph_s* cap = nullptr; emu_stream_s* on = nullptr; unsigned long rec_seq = 0; };
+static std::atomic<int> g_captures_active(0);
+namespace emu {
+bool capturing(hipStream_t st) { return st && st->cap; }
+void capture_push(hipStream_t st, std::function<void()> node) { st->cap->nodes.push_back(std::move(node)); st->seq++; }
+void legacy_stream_use(const char* what)
+{ // the real runtime (relaxed capture mode) runs NULL-stream work at once, outside the graph and unordered against it: almost never what a captured step wants
+	if (g_captures_active.load() > 0 && getenv("NNC_EMU_CAPTURE_NOTES")) fprintf(stderr, "emu: note: NULL-stream %s while a stream captures (runs now, outside the graph)\n", what);
+}
+}
 static thread_local int g_device = 0; // (HIP: the current device is per host thread -- found by the ThreadSanitizer run of the two-thread tests)
 static int device_count() { const char* e = getenv("NNC_EMU_DEVICE_COUNT"); return e ? atoi(e) : 1; }
 static double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
@@ -234,12 +250,18 @@ hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void*) { return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) { for (size_t y = 0; y < height; y++) memmove((char*)d + y * dpitch, (const char*)s + y * spitch, width); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) { if (emu::capturing(st)) { emu::capture_push(st, [=]() { memmove(d, s, n); }); return hipSuccess; } memmove(d, s, n); return hipSuccess; } // (a captured copy reads its SOURCE POINTER at every replay, as the real node does)
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t st)
+{
+	auto run = [=]() { for (size_t y = 0; y < height; y++) memmove((char*)d + y * dpitch, (const char*)s + y * spitch, width); };
+	if (emu::capturing(st)) { emu::capture_push(st, run); return hipSuccess; }
+	run();
+	return hipSuccess;
+}
 hipError_t hipMemcpyPeer(void* d, int, const void* s, int, size_t n) { memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t st) { if (emu::capturing(st)) { emu::capture_push(st, [=]() { memmove(d, s, n); }); return hipSuccess; } memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) { if (emu::capturing(st)) { emu::capture_push(st, [=]() { memset(d, v, n); }); return hipSuccess; } memset(d, v, n); return hipSuccess; }
 hipError_t hipSetDevice(int d) { if (d < 0 || d >= device_count()) return hipErrorInvalidValue; g_device = d; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = g_device; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = device_count(); return hipSuccess; }
@@ -248,20 +270,76 @@ hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = 1ull << 33; *t = 1ull << 34; return hipSuccess; }
-hipError_t hipStreamCreate(hipStream_t* s) { *s = new emu_stream_s{g_device}; return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = new emu_stream_s; (*s)->device = g_device; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
-hipError_t hipLaunchHostFunc(hipStream_t, hipHostFn_t fn, void* ud) { fn(ud); return hipSuccess; }
-hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event_s{0}; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { return emu::capturing(s) ? hipErrorStreamCaptureUnsupported : hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
+{
+	if (e->cap && e->cap->active) { // a captured event: the waiting stream joins the capture (or already belongs to it)
+		if (!s) return hipErrorStreamCaptureImplicit;
+		if (s->cap && s->cap != e->cap) return hipErrorStreamCaptureIsolation;
+		if (!s->cap) { s->cap = e->cap; e->cap->members.push_back(s); }
+		s->seq++;
+		if (e->on && e->rec_seq > e->on->joined_seq) e->on->joined_seq = e->rec_seq; // everything the recording stream had done up to the record is joined to somebody
+		return hipSuccess;
+	}
+	if (s && s->cap) return hipErrorStreamCaptureIsolation; // a capturing stream may not depend on work outside its graph
+	return hipSuccess;
+}
+hipError_t hipStreamQuery(hipStream_t s) { return emu::capturing(s) ? hipErrorStreamCaptureUnsupported : hipSuccess; }
+hipError_t hipLaunchHostFunc(hipStream_t st, hipHostFn_t fn, void* ud) { if (emu::capturing(st)) { emu::capture_push(st, [=]() { fn(ud); }); return hipSuccess; } fn(ud); return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event_s; (*e)->t_ms = 0; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t_ms = now_ms(); return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { e->t_ms = now_ms(); e->cap = s ? s->cap : nullptr; e->on = s; e->rec_seq = s ? s->seq : 0; return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t e) { return (e->cap && e->cap->active) ? hipErrorStreamCaptureUnsupported : hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t e) { return (e->cap && e->cap->active) ? hipErrorStreamCaptureUnsupported : hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode)
+{
+	if (!s || s->cap) return hipErrorInvalidValue;
+	s->cap = new emu_graph_s;
+	s->cap->members.push_back(s);
+	s->seq = s->joined_seq = 0;
+	g_captures_active.fetch_add(1);
+	return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* graph)
+{
+	*graph = nullptr;
+	if (!s || !s->cap || s->cap->members[0] != s) return hipErrorInvalidValue; // (only the origin stream ends a capture)
+	emu_graph_s* const g = s->cap;
+	bool unjoined = false;
+	for (size_t i = 1; i < g->members.size(); i++) if (g->members[i]->seq != g->members[i]->joined_seq) unjoined = true; // a stream that joined holds work (or a dependency) nobody waited for
+	for (emu_stream_s* m : g->members) { m->cap = nullptr; m->seq = m->joined_seq = 0; }
+	g->active = false;
+	g_captures_active.fetch_sub(1);
+	if (unjoined) { g->nodes.clear(); return hipErrorStreamCaptureUnjoined; } // (the graph object leaks: events may still point at it)
+	*graph = g;
+	return hipSuccess;
+}
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* status) { *status = emu::capturing(s) ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone; return hipSuccess; }
+hipError_t hipGraphInstantiate(hipGraphExec_t* exec, hipGraph_t graph, hipGraphNode_t*, char*, size_t) { *exec = new emu_graph_exec_s; (*exec)->nodes = graph->nodes; return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t s)
+{
+	if (emu::capturing(s)) return hipErrorStreamCaptureUnsupported; // (child graphs: not modelled)
+	for (const std::function<void()>& n : exec->nodes) n();
+	return hipSuccess;
+}
+hipError_t hipGraphGetNodes(hipGraph_t graph, hipGraphNode_t*, size_t* count) { *count = graph->nodes.size(); return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t exec) { delete exec; return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t graph) { graph->nodes.clear(); return hipSuccess; } // (the shell stays: an event recorded in the capture still points at it)
 hipError_t hipGetLastError() { return hipSuccess; }
 hipError_t hipPeekAtLastError() { return hipSuccess; }
-const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hip-emulator error"; }
+const char* hipGetErrorString(hipError_t e)
+{
+	switch (e) {
+	case hipSuccess: return "hipSuccess";
+	case hipErrorStreamCaptureUnsupported: return "hipErrorStreamCaptureUnsupported (emulator: the operation is not permitted on a capturing stream)";
+	case hipErrorStreamCaptureUnjoined: return "hipErrorStreamCaptureUnjoined (emulator: a stream that joined the capture was not joined back)";
+	case hipErrorStreamCaptureIsolation: return "hipErrorStreamCaptureIsolation (emulator: a capturing stream waited for an event recorded outside its capture)";
+	case hipErrorStreamCaptureImplicit: return "hipErrorStreamCaptureImplicit (emulator)";
+	default: return "hip-emulator error";
+	}
+}

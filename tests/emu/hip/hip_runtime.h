@@ -46,9 +46,19 @@ static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, 
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600,
+       hipErrorStreamCaptureUnsupported = 900, hipErrorStreamCaptureInvalidated = 901, hipErrorStreamCaptureUnjoined = 904, hipErrorStreamCaptureIsolation = 905, hipErrorStreamCaptureImplicit = 906 };
 typedef struct emu_stream_s* hipStream_t;
 typedef struct emu_event_s* hipEvent_t;
+// stream capture (the subset device_rt.cpp's "HIP-graph capture" uses): a capturing stream RECORDS its launches, copies and memsets instead of running them;
+// an event recorded on a capturing stream carries the capture, a stream that waits for such an event joins it; hipGraphLaunch runs the recorded nodes in
+// the order they were recorded (a topological order of the graph).  What the real runtime refuses during a capture is refused here too, with its codes:
+// synchronising / querying a capturing stream, waiting on an outside event from a capturing stream, ending a capture other streams have not rejoined.
+typedef struct emu_graph_s* hipGraph_t;
+typedef struct emu_graph_exec_s* hipGraphExec_t;
+typedef struct emu_graph_node_s* hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostRegisterDefault = 0 };
 typedef void (*hipHostFn_t)(void*);
@@ -65,17 +75,24 @@ int wave();
 void* xbuf(int lane); // 32 B per lane exchange slot of the calling fiber's wave
 void* dyn_smem();
 int wave_width();
+bool capturing(hipStream_t st);                                   // the stream records instead of running
+void capture_push(hipStream_t st, std::function<void()> node);    // (only on a capturing stream)
+void legacy_stream_use(const char* what);                         // work on the NULL stream: refused while a (blocking) stream of the device captures
 }
 
 template <typename K, typename... Args>
-static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args)
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args... args)
 {
+	if (st && emu::capturing(st)) { emu::capture_push(st, [=]() { emu::launch(grid, block, shmem, [&]() { kernel(args...); }); }); return; } // a kernel node: the arguments by value
+	if (!st) emu::legacy_stream_use("kernel launch");
 	emu::launch(grid, block, shmem, [&]() { kernel(args...); });
 }
 
 template <typename K, typename... Args>
-static inline void emuLaunchConcurrentKernel(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args)
+static inline void emuLaunchConcurrentKernel(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args... args)
 {
+	if (st && emu::capturing(st)) { emu::capture_push(st, [=]() { emu::launch_concurrent(grid, block, shmem, [&]() { kernel(args...); }); }); return; }
+	if (!st) emu::legacy_stream_use("kernel launch");
 	emu::launch_concurrent(grid, block, shmem, [&]() { kernel(args...); });
 }
 
@@ -321,6 +338,14 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = 0);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode mode);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* graph);
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* status);
+hipError_t hipGraphInstantiate(hipGraphExec_t* exec, hipGraph_t graph, hipGraphNode_t* error_node, char* log, size_t log_size);
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t s);
+hipError_t hipGraphGetNodes(hipGraph_t graph, hipGraphNode_t* nodes, size_t* count);
+hipError_t hipGraphExecDestroy(hipGraphExec_t exec);
+hipError_t hipGraphDestroy(hipGraph_t graph);
 hipError_t hipGetLastError();
 hipError_t hipPeekAtLastError();
 const char* hipGetErrorString(hipError_t e);

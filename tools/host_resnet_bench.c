@@ -110,6 +110,11 @@ static int nnc_mi355x_comm_init_rank(const void* id, int rank, int world) { retu
 static int nnc_mi355x_comm_count(void) { return 0; }
 static void nnc_mi355x_comm_destroy(void) {}
 static void nnc_mi355x_comm_overlap_stats(long* collectives, long* buckets) { *collectives = *buckets = 0; }
+static int nnc_mi355x_capture_begin(ccv_nnc_stream_context_t* s) { return -1; }
+static void* nnc_mi355x_capture_end(ccv_nnc_stream_context_t* s) { return 0; }
+static int nnc_mi355x_graph_launch(void* g, ccv_nnc_stream_context_t* s) { return -1; }
+static int nnc_mi355x_graph_node_count(void* g) { return 0; }
+static void nnc_mi355x_graph_free(void* g) {}
 #else
 /* HOST_BENCH_DEVICE: the device this process trains on (the process-per-GPU form with every GPU visible: rank r takes device r) */
 static int g_device = 0;
@@ -124,6 +129,12 @@ int nnc_mi355x_comm_init_rank(const void* id_128_bytes, int rank, int world_size
 int nnc_mi355x_comm_count(void);
 void nnc_mi355x_comm_destroy(void);
 void nnc_mi355x_comm_overlap_stats(long* collectives, long* buckets); /* NNC_MI355X_COMM_OVERLAP=1: the gradient all-reduces that went out in buckets beside the backward pass */
+/* HIP-graph capture of the step (include/nnc_mi355x.h; HOST_BENCH_CAPTURE=1): the two calls a host adds around ONE step, and the replay */
+int nnc_mi355x_capture_begin(ccv_nnc_stream_context_t* stream_context);
+void* nnc_mi355x_capture_end(ccv_nnc_stream_context_t* stream_context);
+int nnc_mi355x_graph_launch(void* graph, ccv_nnc_stream_context_t* stream_context);
+int nnc_mi355x_graph_node_count(void* graph);
+void nnc_mi355x_graph_free(void* graph);
 #endif
 
 static float hash_unit(const uint64_t i, const uint64_t seed)
@@ -531,8 +542,23 @@ int main(int argc, char** argv)
 	}
 	for (i = 1; i < warmup; i++) TRAIN_STEP();
 	SYNC_ALL();
+	/* HOST_BENCH_CAPTURE=1: the step -- whatever the branch above issues: ccv_cnnp_model_fit, or the CIFAR trainer's evaluate / loss / backward / apply_gradients
+	 * sequence -- is recorded ONCE between nnc_mi355x_capture_begin / _end (nothing executes meanwhile) and every timed step is one nnc_mi355x_graph_launch.
+	 * The same number of steps EXECUTES either way, so the probes below must not depend on the switch (tests/test_via_host.py). */
+	void* step_graph = 0;
+	double t_capture = 0;
+	if (getenv("HOST_BENCH_CAPTURE") && atoi(getenv("HOST_BENCH_CAPTURE"))) {
+		if (!step_stream || ranks) { fprintf(stderr, "host_resnet_bench: HOST_BENCH_CAPTURE needs the one-stream step (no process ranks, not the N-device DawnNet form)\n"); return 4; }
+		const double c0_ = now_ms();
+		if (nnc_mi355x_capture_begin(stream) != 0) { fprintf(stderr, "host_resnet_bench: nnc_mi355x_capture_begin failed\n"); return 4; }
+		TRAIN_STEP();
+		step_graph = nnc_mi355x_capture_end(stream);
+		if (!step_graph) { fprintf(stderr, "host_resnet_bench: nnc_mi355x_capture_end failed\n"); return 4; }
+		t_capture = now_ms() - c0_;
+	}
+#define RUN_STEP() do { if (step_graph) { if (nnc_mi355x_graph_launch(step_graph, stream) != 0) { fprintf(stderr, "host_resnet_bench: nnc_mi355x_graph_launch failed\n"); exit(4); } } else TRAIN_STEP(); } while (0)
 	const double t0 = now_ms();
-	for (i = 0; i < steps; i++) TRAIN_STEP();
+	for (i = 0; i < steps; i++) RUN_STEP();
 	SYNC_ALL();
 	const double ms = (now_ms() - t0) / (steps > 0 ? steps : 1);
 	/* per device: sum and sum of squares of the softmax outputs of the last timed step (replicas fed the same shard must agree
@@ -562,7 +588,7 @@ int main(int argc, char** argv)
 		SYNC_ALL();
 		const long c0 = nnc_mi355x_debug_exec_count();
 		const double e0 = now_ms();
-		TRAIN_STEP();
+		RUN_STEP();
 		const double e1 = now_ms();
 		SYNC_ALL();
 		enq_ms[i] = e1 - e0; enq_step_ms[i] = now_ms() - e0;
@@ -638,6 +664,7 @@ int main(int argc, char** argv)
 		nnc_mi355x_comm_overlap_stats(&ov_c, &ov_b);
 		printf("\"comm_overlap\": {\"collectives\": %ld, \"buckets\": %ld}, ", ov_c, ov_b);
 	}
+	printf("\"capture\": {\"on\": %s, \"graph_nodes\": %d, \"capture_ms\": %.2f}, ", step_graph ? "true" : "false", nnc_mi355x_graph_node_count(step_graph), t_capture);
 	printf("\"f16_contractions_by_bound\": {\"mfma\": {\"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}, \"hbm\": {\"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}}, ",
 		f16b[0].n, f16b[0].ms, f16b[0].flops, f16b[0].bytes, f16b[1].n, f16b[1].ms, f16b[1].flops, f16b[1].bytes);
 	printf("\"kernels\": [");
@@ -658,6 +685,7 @@ int main(int argc, char** argv)
 	ccv_nnc_tensor_free(hx);
 	ccv_nnc_tensor_free(hfit);
 	for (i = 0; i < devices; i++) { ccv_nnc_tensor_free(xs[i]); ccv_nnc_tensor_free(fits[i]); ccv_nnc_tensor_free(outs[i]); }
+	if (step_graph) nnc_mi355x_graph_free(step_graph); /* (before the tensors it names go) */
 	ccv_cnnp_model_free(model);
 	if (stream) ccv_nnc_stream_context_free(stream);
 	return 0;
