@@ -140,6 +140,10 @@ def resnet_config(args, half, dawn=False):
         r = type("R", (), {"stdout": outs[0][0], "stderr": outs[0][1], "returncode": 0})()
     else:
         devices = gpus  # the reference's single-process data parallelism (ccv_cnnp_model_set_data_parallel): `batch` per device, one host thread for all of them
+        if devices == 1 and not args.no_capture:
+            # SURVEY.md section 8(f)3, HIP-graph capture of the compiled schedule: BOTH forms are timed in the one process -- K steps issued command by command by the
+            # reference host's scheduler, then the same step recorded once (nnc_mi355x_capture_begin / _end around the host's step call) and replayed K times
+            env["HOST_BENCH_CAPTURE"] = "2"
         r = subprocess.run(cmd + (["dawn", str(devices)] if dawn else ["full", str(devices)]), capture_output=True, text=True, timeout=3000, env=env)
         if r.returncode != 0:
             raise SystemExit("host_resnet_bench failed (%d): %s" % (r.returncode, (r.stdout + r.stderr)[-600:]))
@@ -172,6 +176,15 @@ def resnet_config(args, half, dawn=False):
                                    "ResNet-50 v1d (bin/nnc/imagenet.c) NCHW forward+backward+Nesterov SGD, batch %d, random-init weights, driven by the reference host's ccv_cnnp_model_fit") % args.batch,
                       "global_batch": args.batch * devices, "parallelism": "dp%d%s" % (devices, (" (one process per GPU; the reference's evaluate / backward / parameter_gradients_map(COMM_ALLREDUCE) / apply_gradients; RCCL ranks %s)" % [l["process_per_gpu"]["rccl_ranks"] for l in rank_lines]) if rank_lines else (" (one process, ccv_cnnp_model_set_data_parallel; gradients all-reduced by the COMM_ALLREDUCE rows over RCCL)" if devices > 1 else "")), "gflop_per_image": gflop, "whole_step_tflops_per_gpu": h["images_per_s"] / devices * gflop / 1e3,
                       "first_step_ms": h["first_step_ms"], "outputs_finite": h["outputs_finite"], "softmax_worst_row_sum_err": h["softmax_worst_row_sum_err"], "memory_gib": h["memory_gib"]}}
+    cap = h.get("capture") or {}
+    if cap.get("on"):
+        # `value` / `ms_per_step` above are the REPLAYED step (every kernel of the step runs at every replay; parameters bit-identical to the issued form:
+        # tests/test_via_host.py); the step issued command by command is reported beside it
+        issued = cap.get("issued_per_command_ms_per_step") or 0.0
+        out["config"]["step_form"] = "HIP-graph replay of the captured step (nnc_mi355x_capture_begin / _end around the reference host's step call; one hipGraphLaunch per step)"
+        out["config"]["capture"] = {"graph_nodes": cap["graph_nodes"], "capture_ms": cap["capture_ms"], "launch_host_ms_median": cap.get("launch_host_ms_median"),
+                                    "issued_per_command_ms_per_step": issued, "issued_per_command_images_per_s": (args.batch * devices / (issued * 1e-3)) if issued > 0 else None,
+                                    "devices_one_thread_can_feed": (h["ms_per_step"] / cap["launch_host_ms_median"]) if cap.get("launch_host_ms_median") else None}
     if rank_lines:
         out["config"]["rccl_ranks"] = rank_lines[0]["process_per_gpu"]["rccl_ranks"]
         out["config"]["comm_overlap"] = rank_lines[0].get("comm_overlap")  # all-reduces that went out in buckets beside the backward pass (0 / 0: NNC_MI355X_COMM_OVERLAP=0)
@@ -230,7 +243,8 @@ def resnet_config(args, half, dawn=False):
     # enqueue time of a step must stay under the GPU time of a step for the N-device form to scale
     he = h.get("host_enqueue")
     if he and he.get("commands_per_step"):
-        out["config"]["host_enqueue"] = dict(he, devices_one_thread_can_feed=h["ms_per_step"] / he["ms_per_step_median"] if he["ms_per_step_median"] > 0 else None,
+        issued_ms = (cap.get("issued_per_command_ms_per_step") or 0.0) if cap.get("on") else 0.0
+        out["config"]["host_enqueue"] = dict(he, devices_one_thread_can_feed=(issued_ms or h["ms_per_step"]) / he["ms_per_step_median"] if he["ms_per_step_median"] > 0 else None,
                                              note="wall time of the step call on drained streams, one host thread, one device; the step's GPU time / this = how many devices that thread keeps busy")
     if not args.no_cpu_baseline and devices == 1:
         out["cpu_baseline"], out["config"]["oracle_gate"] = host_cpu_baseline(args, half, dawn)
@@ -383,7 +397,7 @@ def extra_configs(args):
         gate = cfg.get("oracle_gate") or cfg.get("step1_loss_image0")
         if gate:
             e["oracle_gate"] = gate
-        for k in ("relu_look_ahead", "host_enqueue", "whole_step_tflops_per_gpu", "memory_gib"):
+        for k in ("relu_look_ahead", "host_enqueue", "capture", "whole_step_tflops_per_gpu", "memory_gib"):
             if k in cfg:
                 e[k] = cfg[k]
         e["wall_s"] = time.time() - t0
@@ -436,6 +450,9 @@ def compact(out):
         he = e.get("host_enqueue")
         if isinstance(he, dict):
             n["host_enqueue"] = {k: he.get(k) for k in ("ms_per_step_median", "commands_per_step", "devices_one_thread_can_feed")}
+        cp = e.get("capture")
+        if isinstance(cp, dict):  # value / ms_per_step are the replayed step; the step issued command by command beside it
+            n["capture"] = {k: cp.get(k) for k in ("graph_nodes", "launch_host_ms_median", "issued_per_command_images_per_s", "devices_one_thread_can_feed")}
         o["extra_configs"][name] = n
     if len(json.dumps(o)) > LINE_LIMIT and isinstance(o.get("roofline"), dict) and "all_contractions" in o["roofline"]:
         ac = o["roofline"]["all_contractions"]
@@ -508,6 +525,7 @@ def main():
     ap.add_argument("--no-alt-leg", action="store_true", help="skip the second timed leg with the other ReLU setting (profiling runs: one kind of step in the trace)")
     ap.add_argument("--no-fuse-relu", action="store_true", help="issue RELU_FORWARD as its own command behind every convolution (the reference host's graph does) instead of letting the convolution's epilogue rectify (NNC_MI355X_CONV_ALGO_FUSE_RELU); the other setting is always timed beside the headline one")
     ap.add_argument("--no-extra-configs", action="store_true", help="the default run (config 3, one GPU) ends with a short run of configs 2, 4, 4-f16 and 5 whose lines it carries in `extra_configs`; this skips them")
+    ap.add_argument("--no-capture", action="store_true", help="skip the HIP-graph capture legs (SURVEY.md 8(f)3): time only the steps issued command by command")
     ap.add_argument("--no-via-host", action="store_true", help="skip the second driver: the same step through the reference host's symbolic graph / autotune / static schedule (tools/host_vgg_bench.c)")
     ap.add_argument("--records", default=None, help="also write the per-launch contraction records (name, dims, ms, TFLOP/s) of the roofline leg to this file")
     args = ap.parse_args()
@@ -641,6 +659,24 @@ def main():
         dt = dist.reduce_max(dt)
     loss = float(net.loss.numpy().mean())
 
+    # HIP-graph capture of the step: the same step recorded once and replayed K times -- one runtime call per step instead of ~150 commands.
+    # One GPU only here (the N-GPU form's gradient exchange goes through torch.distributed, outside this library's streams).  Reported beside the headline.
+    dt_cap = cap_nodes = None
+    if world == 1 and not args.no_capture:
+        if L.capture_begin(stream) == 0:
+            step()
+            graph = L.capture_end(stream)
+            if graph:
+                cap_nodes = L.graph_node_count(graph)
+                L.graph_launch(graph, stream)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    L.graph_launch(graph, stream)
+                barrier()
+                dt_cap = time.perf_counter() - t0
+                L.graph_free(graph)
+
     # the same K steps with the other ReLU setting (results are bit-identical: tests/test_vgg_step.py), reported beside the headline.
     # The library's look-ahead (peephole.cpp) would fold the separately issued ReLUs as well -- it is what gives the reference host the
     # same saving (via_host) -- so it is switched off for this leg: what is timed is the step with every ReLU as its own pass.
@@ -704,6 +740,7 @@ def main():
             "dtype": "f32 (Winograd-domain / fc GEMMs: exact bf16x3 split, all 9 products, fp32 accumulate)" if L.tune_get("GEMM_BF16X3") > 0 else "f32", "data": "synthetic",
             "config": {"workload": "VGG-D (ccv vgg_d_params, 225x225x3 crop, NHWC) %s, batch %d per GPU, random-init weights" % ("forward only" if fwd_only else "forward+backward+SGD", args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "captured_step": ({"images_per_s": world * args.batch * args.steps / dt_cap, "ms_per_step": 1e3 * dt_cap / args.steps, "graph_nodes": cap_nodes, "note": "the same K steps as ONE hipGraphLaunch each (nnc_mi355x_capture_begin / _end around one step); `value` is the step issued command by command"} if dt_cap else None),
                        "gflop_per_image": (ff if fwd_only else fb) / 1e9, "whole_step_tflops_per_gpu": value / world * (ff if fwd_only else fb) / 1e12, "final_loss": loss,
                        "conv_relu": "convolution epilogue (NNC_MI355X_CONV_ALGO_FUSE_RELU)" if net.fuse_relu else "separate RELU_FORWARD commands"},
         }

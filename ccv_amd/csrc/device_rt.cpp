@@ -26,6 +26,7 @@ struct device_local_t {
 	void* cluster_sync;   // the words the workgroups of ONE launch on this stream hand each other (nnc::cluster_sync_of): never scratch, never moved
 	unsigned cluster_epoch;
 	unsigned long cluster_capture; // the capture in which the area was last cleared (cluster_sync_of)
+	unsigned long capture_alias;   // the capture (its number) in which this stream's work goes to the recording stream instead (effective_stream)
 	unsigned long comm_seen; // the overlapped gradient all-reduces this stream has been ordered behind (cmd_comm.cpp comm_overlap_join)
 };
 // Layout contract with the reference host (lib/nnc/ccv_nnc_stream.c:15-20, lib/nnc/gpu/ccv_nnc_compat.cu:286-299):
@@ -47,6 +48,8 @@ struct stream_gpu_t {
 struct signal_gpu_t {
 	ccv_nnc_stream_signal_s super;
 	hipEvent_t event;
+	unsigned long capture_id; // the capture in which it was last emitted (0: outside any), and whether by a stream folded into the recording one
+	int capture_on_alias;
 };
 // stream_context == NULL: the device's default stream + a per-thread, per-device workspace
 // (lib/nnc/gpu/ccv_nnc_compat.cu:301-340).
@@ -82,6 +85,9 @@ std::atomic<unsigned long> g_pool_seq(0);          // device allocations so far
 std::atomic<int> g_capture_active(0);              // captures in progress (process-wide: a data-parallel step's capture spans the devices)
 std::atomic<unsigned long> g_capture_id(0);        // the running capture's number (never 0 while one runs)
 std::atomic<unsigned long> g_graph_max_end_seq(0); // the newest allocation any LIVE captured graph may name (0: no graph alive)
+hipStream_t g_cap_origin = 0;                      // the stream the running capture began on, its device,
+int g_cap_device = 0;
+int g_cap_keep_streams = -1;                       // and the capture's form: 0 = the step's streams of that device are folded into the recording one (default), 1 = kept (-1: environment not read yet)
 inline bool pool_pinned(const unsigned long seq) { return g_capture_active.load(std::memory_order_acquire) > 0 || seq <= g_graph_max_end_seq.load(std::memory_order_acquire); }
 // is THIS stream recording (a stream of the device that has not joined the capture is an ordinary stream)
 inline bool stream_capturing(hipStream_t st)
@@ -124,6 +130,14 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 	return l;
 }
 
+// The stream a context's work is enqueued on right now.  While a step is being recorded in the folded form (HIP-graph capture further down) every stream of
+// the recording device that the step reaches works on the recording stream: issue order on one stream IS a valid order of the step.
+inline hipStream_t effective_stream(device_local_t* const l)
+{
+	if (g_capture_active.load(std::memory_order_acquire) > 0 && l->capture_alias == g_capture_id.load(std::memory_order_acquire) && l->capture_alias) return g_cap_origin;
+	return l->stream;
+}
+
 } // namespace
 
 namespace nnc {
@@ -164,14 +178,14 @@ hipStream_t stream_of(const ccv_nnc_stream_context_t* ctx)
 	if (g_deferred_live) deferred_flush(ctx); // ... and so does this stream's recorded command (peephole.cpp)
 	if (!ctx) return (hipStream_t)0;
 	if (CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU) return (hipStream_t)0;
-	return joined(bind(ctx))->stream;
+	return effective_stream(joined(bind(ctx)));
 }
 void stream_registered(const int device, hipStream_t st) { pool_stream_created(device, st); }
 // the stream itself, no hooks: for recording "this buffer has been written" behind a command that has just been enqueued (cmd_comm.cpp comm_gradient_written)
 hipStream_t stream_peek(const ccv_nnc_stream_context_t* ctx)
 {
 	if (!ctx || CCV_STREAM_GET_CONTEXT(ctx->type) != CCV_STREAM_CONTEXT_GPU) return (hipStream_t)0;
-	return bind(ctx)->stream;
+	return effective_stream(bind(ctx));
 }
 
 static thread_local size_t tl_ws_prefix = 0;
@@ -290,8 +304,9 @@ void* cluster_sync_of(const ccv_nnc_stream_context_t* ctx, size_t granule_bytes,
 	// A captured launch carries its epoch as a kernel argument: every replay of the graph presents the SAME tags, and the granules the previous replay left would
 	// match them.  The first cluster launch of a stream inside a capture is therefore preceded by a node that clears the area (2 MB, ~ a microsecond of HBM
 	// time per replay and stream); behind it the recorded epochs are as fresh at every replay as they were when they were recorded.
-	if (l->stream && stream_capturing(l->stream) && l->cluster_capture != g_capture_id.load(std::memory_order_acquire)) {
-		HIP_ENFORCE(hipMemsetAsync(l->cluster_sync, 0, CLUSTER_SYNC_BYTES, l->stream));
+	hipStream_t const es = l->stream ? effective_stream(l) : (hipStream_t)0;
+	if (es && stream_capturing(es) && l->cluster_capture != g_capture_id.load(std::memory_order_acquire)) {
+		HIP_ENFORCE(hipMemsetAsync(l->cluster_sync, 0, CLUSTER_SYNC_BYTES, es));
 		l->cluster_capture = g_capture_id.load(std::memory_order_acquire);
 	}
 	if (++l->cluster_epoch == 0) l->cluster_epoch = 1;
@@ -867,7 +882,7 @@ void* ccv_nnc_stream_compat_get_workspace(const ccv_nnc_stream_context_t* const 
 	if (nnc::g_deferred_live) nnc::deferred_flush(stream_context);
 	device_local_t* l;
 	hipStream_t st = 0;
-	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = l->stream; }
+	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = effective_stream(l); }
 	else {
 		const int device = current_device();
 		if (device >= MAX_DEVICES) return 0;
@@ -906,7 +921,7 @@ void* nnc_staging_of(const ccv_nnc_stream_context_t* const stream_context, const
 	if (nnc::g_deferred_live) nnc::deferred_flush(stream_context); // as for the workspace: a recorded command may stage (and grow the arena) at its launch
 	device_local_t* l;
 	hipStream_t st = 0;
-	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = l->stream; }
+	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = effective_stream(l); }
 	else {
 		const int device = current_device();
 		if (device >= MAX_DEVICES) return 0;
@@ -931,7 +946,7 @@ void* nnc_palette_of(const ccv_nnc_stream_context_t* const stream_context, const
 	if (nnc::g_deferred_live) nnc::deferred_flush(stream_context);
 	device_local_t* l;
 	hipStream_t st = 0;
-	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = l->stream; }
+	if (stream_context && CCV_STREAM_GET_CONTEXT(stream_context->type) == CCV_STREAM_CONTEXT_GPU) { l = bind(stream_context); st = effective_stream(l); }
 	else {
 		const int device = current_device();
 		if (device >= MAX_DEVICES) return 0;
@@ -994,9 +1009,9 @@ void ccv_nnc_stream_compat_add_callback(ccv_nnc_stream_context_t* const stream, 
 		async_trampoline_t* t = (async_trampoline_t*)malloc(sizeof(async_trampoline_t));
 		t->async_callback = async_callback;
 		t->async = async;
-		HIP_ENFORCE(hipLaunchHostFunc(s->stream, host_async_trampoline, t));
+		HIP_ENFORCE(hipLaunchHostFunc(effective_stream(s), host_async_trampoline, t));
 	} else
-		HIP_ENFORCE(hipLaunchHostFunc(s->stream, host_callback_trampoline, async));
+		HIP_ENFORCE(hipLaunchHostFunc(effective_stream(s), host_callback_trampoline, async));
 }
 
 ccv_nnc_stream_signal_t* ccv_nnc_init_stream_signal(ccv_nnc_stream_signal_t* const signal)
@@ -1005,6 +1020,8 @@ ccv_nnc_stream_signal_t* ccv_nnc_init_stream_signal(ccv_nnc_stream_signal_t* con
 	const int dev = CCV_STREAM_GET_DEVICE_ID(g->super.type);
 	if ((g->super.type & CCV_COMPUTE_DEVICE_ANY) != CCV_COMPUTE_DEVICE_ANY) HIP_ENFORCE(hipSetDevice(dev));
 	HIP_ENFORCE(hipEventCreateWithFlags(&g->event, hipEventDisableTiming));
+	g->capture_id = 0;
+	g->capture_on_alias = 0;
 	return (ccv_nnc_stream_signal_t*)g;
 }
 void ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal)
@@ -1015,8 +1032,37 @@ void ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal)
 }
 } // extern "C"
 namespace nnc {
-void signal_emit_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal) { HIP_ENFORCE(hipEventRecord(((const signal_gpu_t*)signal)->event, joined(bind(stream))->stream)); }
-void signal_wait_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal) { HIP_ENFORCE(hipStreamWaitEvent(bind(stream)->stream, ((const signal_gpu_t*)signal)->event, 0)); }
+void signal_emit_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
+{
+	device_local_t* const l = joined(bind(stream));
+	signal_gpu_t* const g = (signal_gpu_t*)signal;
+	hipStream_t const es = effective_stream(l);
+	const bool recording = stream_capturing(es);
+	g->capture_id = recording ? g_capture_id.load(std::memory_order_acquire) : 0;
+	g->capture_on_alias = recording && es == g_cap_origin && !g_cap_keep_streams;
+	HIP_ENFORCE(hipEventRecord(g->event, es)); // (in the folded form too: a stream of ANOTHER device joins the capture through it)
+}
+void signal_wait_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
+{
+	device_local_t* const l = bind(stream);
+	signal_gpu_t* const g = (signal_gpu_t*)signal;
+	if (g_capture_active.load(std::memory_order_acquire) > 0 && !g_cap_keep_streams) {
+		const unsigned long id = g_capture_id.load(std::memory_order_acquire);
+		if (g->capture_id == id) {
+			// emitted inside the running capture: the waiting stream is part of the step.  On the recording device it is folded into the recording stream from
+			// here on -- and behind a signal that was emitted THERE the stream order already is the dependency.
+			if (l->device == g_cap_device && l->stream) {
+				l->capture_alias = id;
+				if (!g->capture_on_alias) HIP_ENFORCE(hipStreamWaitEvent(g_cap_origin, g->event, 0));
+				return;
+			}
+		} else if (l->capture_alias == id) {
+			fprintf(stderr, "[nnc_mi355x] a stream of the step being recorded waits for a signal that was emitted outside the capture: the step cannot be replayed\n");
+			abort();
+		}
+	}
+	HIP_ENFORCE(hipStreamWaitEvent(l->stream, g->event, 0));
+}
 }
 extern "C" {
 // A signal is a point where stream order becomes visible to other streams.  Recorded collectives go first; a recorded command's look-ahead decides whether the
@@ -1200,9 +1246,15 @@ void nnc_mi355x_staging_ring_free(void* ring)
 //     void* step = nnc_mi355x_capture_end(stream);
 //     for (...) nnc_mi355x_graph_launch(step, stream); /* one runtime call per step */
 //     nnc_mi355x_graph_free(step);
-// The schedule's other streams join the capture through the signals the host emits and waits for (the run forks from and joins back into the caller's stream:
-// ccv_nnc_graph_run.c:707-726, :819-839), the look-ahead's recorded commands launch into it (capture_end flushes them), and what this library keeps per launch
-// on the host side is made replayable:
+// The schedule's other streams reach the capture through the signals the host emits and waits for (the run forks from and joins back into the caller's stream:
+// ccv_nnc_graph_run.c:707-726, :819-839).  TWO FORMS.  Folded (default): a stream of the recording device that waits for a signal emitted inside the capture
+// works ON THE RECORDING STREAM from then on (effective_stream) -- the host issues a wait only after the matching emit, so issue order on one stream is a valid
+// order of the step; the graph is one chain.  Kept (NNC_MI355X_CAPTURE_STREAMS=1 / nnc_mi355x_capture_keep_streams): the streams join the capture as HIP
+// streams do, the graph keeps the schedule's branches.  The kept form is NOT usable with the reference's schedules on ROCm 7.2: the graph's own stream 0 is not
+// the recording stream, it and the side streams wait for each other's events, and hipStreamEndCapture's walk over its "parallel capture streams" then recurses
+// without end (stack overflow inside the runtime: profiles/r06_v13_capture_streams_fault.txt; the emulator models the bookkeeping and refuses such a capture).
+// Streams of OTHER devices always join as HIP streams.  The look-ahead's recorded commands launch into the capture (capture_end flushes them), and what this
+// library keeps per launch on the host side is made replayable:
 //   * the hand-over areas of the cluster kernels are cleared by a node in front of a stream's first cluster launch (cluster_sync_of), so recorded epochs stay fresh;
 //   * DROPOUT / the LSTM's dropout take a word of pinned host memory that the graph's first node increments: the masks differ from replay to replay
 //     (capture_tick_of; the host-side generator only runs while the step is recorded);
@@ -1285,9 +1337,12 @@ int nnc_mi355x_capture_begin(ccv_nnc_stream_context_t* const stream_context)
 		g_capture_tick = w;
 	}
 	cluster_turn_take(l->device, l->stream); // (outside the capture: an event of another stream's queue may still be waited for here)
+	if (g_cap_keep_streams < 0) { const char* e = getenv("NNC_MI355X_CAPTURE_STREAMS"); g_cap_keep_streams = (e && *e == '1') ? 1 : 0; }
 	g_cap.origin = l->stream;
 	g_cap.device = l->device;
-	g_capture_id.fetch_add(1, std::memory_order_acq_rel);
+	g_cap_origin = l->stream;
+	g_cap_device = l->device;
+	l->capture_alias = g_capture_id.fetch_add(1, std::memory_order_acq_rel) + 1;
 	g_capture_active.store(1, std::memory_order_release);
 	// relaxed mode: allocations, event queries and the like stay legal on this and every other thread while the stream records (a loader thread keeps working)
 	const hipError_t r = hipStreamBeginCapture(l->stream, hipStreamCaptureModeRelaxed);
@@ -1309,7 +1364,13 @@ void* nnc_mi355x_capture_end(ccv_nnc_stream_context_t* const stream_context)
 	std::unique_lock<std::mutex> lock(g_graph_mutex);
 	if (l->stream != g_cap.origin) { fprintf(stderr, "[nnc_mi355x] capture_end: not the stream the capture began on\n"); return 0; }
 	hipGraph_t graph = 0;
+	const char* const trace = getenv("NNC_MI355X_CAPTURE_TRACE"); // fault hunting: progress lines, and the captured graph as a DOT file (NNC_MI355X_CAPTURE_TRACE=<path>)
+	if (trace) fprintf(stderr, "[nnc_mi355x] capture_end: hipStreamEndCapture ...\n");
 	const hipError_t r = hipStreamEndCapture(l->stream, &graph);
+	if (trace) fprintf(stderr, "[nnc_mi355x] capture_end: ... %s, graph %p\n", hipGetErrorString(r), (void*)graph);
+#ifndef NNC_HIP_EMULATOR
+	if (trace && r == hipSuccess && graph) { const hipError_t rd = hipGraphDebugDotPrint(graph, trace, 0); fprintf(stderr, "[nnc_mi355x] capture_end: graph written to %s (%s)\n", trace, hipGetErrorString(rd)); }
+#endif
 	graph_rec_t* rec = 0;
 	if (r == hipSuccess && graph) {
 		rec = new graph_rec_t{ graph, 0, g_pool_seq.load(std::memory_order_acquire), 0, l->device, 0, 0 };
@@ -1348,6 +1409,8 @@ int nnc_mi355x_graph_launch(void* const graph, ccv_nnc_stream_context_t* const s
 	return 0;
 }
 
+// The form of the NEXT captures: 0 (default) the step's streams of the recording device are folded into the recording stream, 1 they are kept as they are.
+void nnc_mi355x_capture_keep_streams(const int on) { g_cap_keep_streams = on ? 1 : 0; }
 int nnc_mi355x_graph_node_count(void* const graph) { return graph ? (int)((graph_rec_t*)graph)->nodes : 0; }
 
 void nnc_mi355x_graph_free(void* const graph)

@@ -736,6 +736,7 @@ class Lib:
     def graph_launch(self, graph, stream): return self.dll.nnc_mi355x_graph_launch(graph, stream)
     def graph_node_count(self, graph): return self.dll.nnc_mi355x_graph_node_count(graph)
     def graph_free(self, graph): self.dll.nnc_mi355x_graph_free(graph)
+    def capture_keep_streams(self, on): self.dll.nnc_mi355x_capture_keep_streams(int(on))
     def pool_parked_bytes(self): return self.dll.nnc_mi355x_debug_pool_parked_bytes()
 
     def depalettize(self, src, datatype, input_length, qbits, number_in_blocks, dst, output_length, stream=None):

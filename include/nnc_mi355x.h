@@ -457,6 +457,11 @@ void* nnc_mi355x_capture_end(ccv_nnc_stream_context_t* stream_context);
 int nnc_mi355x_graph_launch(void* graph, ccv_nnc_stream_context_t* stream_context);
 int nnc_mi355x_graph_node_count(void* graph);
 void nnc_mi355x_graph_free(void* graph);
+/* The form of the next captures.  0 (default): the streams of the recording device that the step reaches are folded into the recording stream (issue order
+ * is a valid order of the step; the graph is one chain).  1 (also NNC_MI355X_CAPTURE_STREAMS=1): the streams join as HIP streams and the graph keeps the
+ * schedule's branches -- only for steps whose side streams never wait for one another's signals: with the reference's schedules ROCm 7.2's
+ * hipStreamEndCapture recurses without end (device_rt.cpp "HIP-graph capture"). */
+void nnc_mi355x_capture_keep_streams(int on);
 /* Hook: bytes of freed device memory currently set aside for captured graphs. */
 long nnc_mi355x_debug_pool_parked_bytes(void);
 /* Hook: events recorded by frees (a free that finds every stream idle records none) and allocations that had to wait for a kept block's last users. */

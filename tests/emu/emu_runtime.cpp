@@ -219,15 +219,25 @@ struct emu_graph_s {
 	bool active = true;
 };
 struct emu_graph_exec_s { std::vector<std::function<void()> > nodes; };
-struct emu_stream_s { int device; emu_graph_s* cap = nullptr; unsigned long seq = 0, joined_seq = 0; };
+struct emu_stream_s {
+	int device; emu_graph_s* cap = nullptr; unsigned long seq = 0, joined_seq = 0;
+	// ROCm 7.2's bookkeeping, modelled because it has a flaw this library must stay clear of: a NON-origin stream that waits for a captured event is filed under
+	// the stream the event was recorded on ("parallel capture streams"), at every wait; hipStreamEndCapture walks those lists recursively.  Two non-origin streams
+	// that wait for each other's events file each other -- the walk never ends (stack overflow inside hipStreamEndCapture: the first MI355X run of the
+	// reference host's ccv_cnnp_model_fit step, whose schedule's main stream and side streams do exactly that).  Here: the capture is refused with a message.
+	std::vector<emu_stream_s*> parallel;
+	int walk = 0;
+};
 struct emu_event_s { double t_ms; emu_graph_s* cap = nullptr; emu_stream_s* on = nullptr; unsigned long rec_seq = 0; };
 static std::atomic<int> g_captures_active(0);
 namespace emu {
 bool capturing(hipStream_t st) { return st && st->cap; }
-void capture_push(hipStream_t st, std::function<void()> node) { st->cap->nodes.push_back(std::move(node)); st->seq++; }
-void legacy_stream_use(const char* what)
-{ // the real runtime (relaxed capture mode) runs NULL-stream work at once, outside the graph and unordered against it: almost never what a captured step wants
-	if (g_captures_active.load() > 0 && getenv("NNC_EMU_CAPTURE_NOTES")) fprintf(stderr, "emu: note: NULL-stream %s while a stream captures (runs now, outside the graph)\n", what);
+void capture_push(hipStream_t st, std::function<void()> node) { st->cap->nodes.push_back(std::move(node)); st->seq++; if (getenv("NNC_EMU_CAPTURE_LOG")) fprintf(stderr, "emu-cap: NODE   stream %p seq %lu\n", (void*)st, st->seq); }
+bool legacy_stream_use(const char* what)
+{ // the streams this library makes are BLOCKING streams (ordered against the NULL stream): NULL-stream work while one of them records would be an implicit
+  // dependency on the capture -- the MI355X's runtime refuses it (a blocking hipMemcpy inside a capture aborted the first GPU run of tests/test_capture.py)
+	if (g_captures_active.load() > 0) { if (getenv("NNC_EMU_CAPTURE_NOTES")) fprintf(stderr, "emu: NULL-stream %s while a stream captures: refused\n", what); return false; }
+	return true;
 }
 }
 static thread_local int g_device = 0; // (HIP: the current device is per host thread -- found by the ThreadSanitizer run of the two-thread tests)
@@ -249,7 +259,7 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n);
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void*) { return hipSuccess; }
-hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (!emu::legacy_stream_use("blocking copy")) return hipErrorStreamCaptureImplicit; memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) { if (emu::capturing(st)) { emu::capture_push(st, [=]() { memmove(d, s, n); }); return hipSuccess; } memmove(d, s, n); return hipSuccess; } // (a captured copy reads its SOURCE POINTER at every replay, as the real node does)
 hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t st)
 {
@@ -260,7 +270,7 @@ hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch
 }
 hipError_t hipMemcpyPeer(void* d, int, const void* s, int, size_t n) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t st) { if (emu::capturing(st)) { emu::capture_push(st, [=]() { memmove(d, s, n); }); return hipSuccess; } memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { if (!emu::legacy_stream_use("blocking fill")) return hipErrorStreamCaptureImplicit; memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) { if (emu::capturing(st)) { emu::capture_push(st, [=]() { memset(d, v, n); }); return hipSuccess; } memset(d, v, n); return hipSuccess; }
 hipError_t hipSetDevice(int d) { if (d < 0 || d >= device_count()) return hipErrorInvalidValue; g_device = d; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = g_device; return hipSuccess; }
@@ -274,12 +284,15 @@ hipError_t hipStreamCreate(hipStream_t* s) { *s = new emu_stream_s; (*s)->device
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { return emu::capturing(s) ? hipErrorStreamCaptureUnsupported : hipSuccess; }
+static bool cap_log() { static int on = -1; if (on < 0) on = getenv("NNC_EMU_CAPTURE_LOG") ? 1 : 0; return on == 1; }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
+	if (cap_log() && g_captures_active.load() > 0) fprintf(stderr, "emu-cap: WAIT   stream %p (capturing %d, seq %lu) event %p (captured %d, recorded on %p at seq %lu)\n", (void*)s, s && s->cap ? 1 : 0, s ? s->seq : 0ul, (void*)e, e->cap && e->cap->active ? 1 : 0, (void*)e->on, e->rec_seq);
 	if (e->cap && e->cap->active) { // a captured event: the waiting stream joins the capture (or already belongs to it)
 		if (!s) return hipErrorStreamCaptureImplicit;
 		if (s->cap && s->cap != e->cap) return hipErrorStreamCaptureIsolation;
 		if (!s->cap) { s->cap = e->cap; e->cap->members.push_back(s); }
+		if (s != e->cap->members[0] && e->on && e->on != s) e->on->parallel.push_back(s);
 		s->seq++;
 		if (e->on && e->rec_seq > e->on->joined_seq) e->on->joined_seq = e->rec_seq; // everything the recording stream had done up to the record is joined to somebody
 		return hipSuccess;
@@ -292,7 +305,7 @@ hipError_t hipLaunchHostFunc(hipStream_t st, hipHostFn_t fn, void* ud) { if (emu
 hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event_s; (*e)->t_ms = 0; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { e->t_ms = now_ms(); e->cap = s ? s->cap : nullptr; e->on = s; e->rec_seq = s ? s->seq : 0; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { if (cap_log() && g_captures_active.load() > 0) fprintf(stderr, "emu-cap: RECORD stream %p (capturing %d, seq %lu) event %p\n", (void*)s, s && s->cap ? 1 : 0, s ? s->seq : 0ul, (void*)e); e->t_ms = now_ms(); e->cap = s ? s->cap : nullptr; e->on = s; e->rec_seq = s ? s->seq : 0; return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t e) { return (e->cap && e->cap->active) ? hipErrorStreamCaptureUnsupported : hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t e) { return (e->cap && e->cap->active) ? hipErrorStreamCaptureUnsupported : hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
@@ -310,6 +323,26 @@ hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* graph)
 	*graph = nullptr;
 	if (!s || !s->cap || s->cap->members[0] != s) return hipErrorInvalidValue; // (only the origin stream ends a capture)
 	emu_graph_s* const g = s->cap;
+	// the runtime's recursive walk over the "parallel capture streams": a cycle = endless recursion on the MI355X
+	std::function<bool(emu_stream_s*)> cyclic = [&](emu_stream_s* const m) {
+		if (m->walk == 1) return true;
+		if (m->walk == 2) return false;
+		m->walk = 1;
+		for (emu_stream_s* c : m->parallel) if (cyclic(c)) return true;
+		m->walk = 2;
+		return false;
+	};
+	bool endless = false;
+	for (emu_stream_s* m : g->members) if (cyclic(m)) endless = true;
+	for (emu_stream_s* m : g->members) { m->parallel.clear(); m->walk = 0; }
+	if (endless) {
+		fprintf(stderr, "emu: hipStreamEndCapture: two non-origin streams of the capture waited for each other's events -- ROCm 7.2's runtime recurses without end here (stack overflow on the MI355X); refused\n");
+		for (emu_stream_s* m : g->members) { m->cap = nullptr; m->seq = m->joined_seq = 0; }
+		g->active = false;
+		g_captures_active.fetch_sub(1);
+		g->nodes.clear();
+		return hipErrorStreamCaptureInvalidated;
+	}
 	bool unjoined = false;
 	for (size_t i = 1; i < g->members.size(); i++) if (g->members[i]->seq != g->members[i]->joined_seq) unjoined = true; // a stream that joined holds work (or a dependency) nobody waited for
 	for (emu_stream_s* m : g->members) { m->cap = nullptr; m->seq = m->joined_seq = 0; }

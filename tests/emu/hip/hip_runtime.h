@@ -77,14 +77,14 @@ void* dyn_smem();
 int wave_width();
 bool capturing(hipStream_t st);                                   // the stream records instead of running
 void capture_push(hipStream_t st, std::function<void()> node);    // (only on a capturing stream)
-void legacy_stream_use(const char* what);                         // work on the NULL stream: refused while a (blocking) stream of the device captures
+bool legacy_stream_use(const char* what);                         // work on the NULL stream: false (refused) while a blocking stream captures
 }
 
 template <typename K, typename... Args>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args... args)
 {
 	if (st && emu::capturing(st)) { emu::capture_push(st, [=]() { emu::launch(grid, block, shmem, [&]() { kernel(args...); }); }); return; } // a kernel node: the arguments by value
-	if (!st) emu::legacy_stream_use("kernel launch");
+	if (!st && !emu::legacy_stream_use("kernel launch")) { fprintf(stderr, "emu: kernel launch on the NULL stream while a stream captures\n"); abort(); }
 	emu::launch(grid, block, shmem, [&]() { kernel(args...); });
 }
 
@@ -92,7 +92,7 @@ template <typename K, typename... Args>
 static inline void emuLaunchConcurrentKernel(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args... args)
 {
 	if (st && emu::capturing(st)) { emu::capture_push(st, [=]() { emu::launch_concurrent(grid, block, shmem, [&]() { kernel(args...); }); }); return; }
-	if (!st) emu::legacy_stream_use("kernel launch");
+	if (!st && !emu::legacy_stream_use("kernel launch")) { fprintf(stderr, "emu: kernel launch on the NULL stream while a stream captures\n"); abort(); }
 	emu::launch_concurrent(grid, block, shmem, [&]() { kernel(args...); });
 }
 

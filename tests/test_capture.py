@@ -84,7 +84,10 @@ class Step:
 NAMES = ("y", "pool", "h", "dw", "db", "w", "bias", "momentum w", "momentum b", "bn y", "running mean", "running var", "saved mean", "saved inv std")
 
 
-def test_a_captured_step_replayed_equals_the_step_issued_directly(lib):
+@pytest.mark.parametrize("form", ["folded", "streams"])
+def test_a_captured_step_replayed_equals_the_step_issued_directly(lib, form):
+    """Both forms of a capture (device_rt.cpp): the step's side streams folded into the recording stream (default), or kept as HIP streams that join it."""
+    lib.capture_keep_streams(form == "streams")
     old = lib.tune_get("BN_CLUSTER")
     lib.tune_set("BN_CLUSTER", 16)  # chunks per workgroup forced down: several workgroups per channel at this size
     n0 = lib.dll.nnc_mi355x_debug_bn_cluster_launches()
@@ -112,6 +115,7 @@ def test_a_captured_step_replayed_equals_the_step_issued_directly(lib):
         cap.close()
     finally:
         lib.tune_set("BN_CLUSTER", old)
+        lib.capture_keep_streams(0)
     for a, b, name in zip(got, want, NAMES):
         assert np.array_equal(a, b), name
     assert not np.array_equal(got[5], after_one[5])  # (the parameters did move with every replay)
@@ -153,7 +157,8 @@ def test_memory_freed_under_a_capture_is_set_aside_until_the_graph_is_freed(lib)
         lib.stream_wait(s)
         parked0 = lib.pool_parked_bytes()
         assert lib.capture_begin(s) == 0
-        (tmp,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(n, F)])     # allocated AND freed inside the capture: the recorded kernel still names it
+        from harness import _param
+        tmp = lib.tensor(_param(nnc.GPU_MEMORY, "NHWC", np.zeros(n, F)))  # allocated AND freed inside the capture (no upload: a blocking copy is NULL-stream work, which the runtime refuses while a stream records): the recorded kernel still names it
         assert lib.cmd_exec(nnc.CMD_SET_FORWARD(3.0), nnc.NO_HINT, 0, [], [tmp], s) == 0
         assert lib.cmd_exec(nnc.CMD_SET_FORWARD(4.0), nnc.NO_HINT, 0, [], [old], s) == 0
         assert lib.cmd_exec(nnc.CMD_SET_FORWARD(2.0), nnc.NO_HINT, 0, [], [t], s) == 0
@@ -225,10 +230,14 @@ def test_a_scratch_buffer_may_grow_inside_a_capture(lib):
         lib.stream_free(s)
 
 
-def test_a_step_that_leaves_a_stream_unjoined_is_refused(lib, capfd):
+def test_a_step_that_leaves_a_stream_unjoined_is_refused(emu_lib, capfd):
+    """(Emulator only: on the MI355X the runtime leaves the unjoined stream in its recording state after the refused hipStreamEndCapture -- it can be neither
+    synchronised nor used again; the first GPU run of this test stopped in that stream's hipStreamSynchronize.)"""
+    lib = emu_lib
     (t, u) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(256, F), np.zeros(256, F)])
     A, B = lib.stream_new(0), lib.stream_new(0)
     S = lib.signal_new(0)
+    lib.capture_keep_streams(1)                                # (in the folded form B's work is on the recording stream: nothing to join)
     try:
         assert lib.capture_begin(A) == 0
         assert lib.capture_begin(B) == -1                      # one capture at a time
@@ -248,6 +257,72 @@ def test_a_step_that_leaves_a_stream_unjoined_is_refused(lib, capfd):
         assert (t.numpy() == F(5)).all()
         lib.graph_free(graph)
     finally:
+        lib.capture_keep_streams(0)
         lib.stream_free(A)
         lib.stream_free(B)
         lib.signal_free(S)
+
+
+def test_side_streams_that_wait_for_each_other_are_recorded_in_the_folded_form(lib):
+    """The reference's schedules run on the graph's OWN streams, none of which is the caller's (recording) stream: its stream 0 and the side streams wait for
+    each other's signals.  ROCm 7.2's hipStreamEndCapture recurses without end on that pattern (device_rt.cpp "HIP-graph capture"; the emulator models the
+    runtime's bookkeeping and refuses), so the default form folds the step's streams into the recording one.  Origin O; M and N wait for each other."""
+    (t, u) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(1024, F), np.zeros(1024, F)])
+    O, M, N = lib.stream_new(0), lib.stream_new(0), lib.stream_new(0)
+    S0, Sm, Sn, Se = (lib.signal_new(0) for _ in range(4))
+
+    def step():
+        lib.signal_emit(O, S0)
+        lib.signal_wait(M, S0)
+        assert lib.cmd_exec(nnc.CMD_SET_FORWARD(2.0), nnc.NO_HINT, 0, [], [t], M) == 0
+        lib.signal_emit(M, Sm)
+        lib.signal_wait(N, Sm)                                                   # N waits for M ...
+        assert lib.cmd_exec(nnc.CMD_SCALAR_MUL_FORWARD(3.0), nnc.NO_HINT, 0, [t], [u], N) == 0
+        lib.signal_emit(N, Sn)
+        lib.signal_wait(M, Sn)                                                   # ... and M for N
+        assert lib.cmd_exec(nnc.CMD_SCALAR_MUL_FORWARD(5.0), nnc.NO_HINT, 0, [u], [t], M) == 0
+        lib.signal_emit(M, Se)
+        lib.signal_wait(O, Se)
+
+    try:
+        assert lib.capture_begin(O) == 0
+        step()
+        graph = lib.capture_end(O)
+        assert graph and lib.graph_node_count(graph) == 4                        # tick + three kernels, one chain
+        assert (t.numpy() == 0).all()
+        assert lib.graph_launch(graph, O) == 0
+        lib.stream_wait(O)
+        assert (t.numpy() == F(30)).all() and (u.numpy() == F(6)).all()
+        lib.graph_free(graph)
+        step()                                                                   # and the same streams work as streams again afterwards
+        lib.stream_wait(O)
+        assert (t.numpy() == F(30)).all()
+    finally:
+        for s_ in (O, M, N):
+            lib.stream_free(s_)
+        for g_ in (S0, Sm, Sn, Se):
+            lib.signal_free(g_)
+
+
+def test_the_kept_form_is_refused_for_mutually_waiting_side_streams_on_the_emulator(emu_lib, capfd):
+    """What the MI355X's runtime does with that pattern is a stack overflow inside hipStreamEndCapture; the emulator, which keeps the same books, says so."""
+    lib = emu_lib
+    (t,) = make_tensors(lib, nnc.GPU_MEMORY, [np.zeros(64, F)])
+    O, M, N = lib.stream_new(0), lib.stream_new(0), lib.stream_new(0)
+    S0, Sm, Sn, Se = (lib.signal_new(0) for _ in range(4))
+    lib.capture_keep_streams(1)
+    try:
+        assert lib.capture_begin(O) == 0
+        lib.signal_emit(O, S0); lib.signal_wait(M, S0)
+        assert lib.cmd_exec(nnc.CMD_SET_FORWARD(2.0), nnc.NO_HINT, 0, [], [t], M) == 0
+        lib.signal_emit(M, Sm); lib.signal_wait(N, Sm)
+        lib.signal_emit(N, Sn); lib.signal_wait(M, Sn)
+        lib.signal_emit(M, Se); lib.signal_wait(O, Se)
+        assert lib.capture_end(O) is None
+        assert "recurses without end" in capfd.readouterr().err
+    finally:
+        lib.capture_keep_streams(0)
+        for s_ in (O, M, N):
+            lib.stream_free(s_)
+        for g_ in (S0, Sm, Sn, Se):
+            lib.signal_free(g_)

@@ -25,5 +25,6 @@ PY
   done
 }
 run dawn-f16-bs512 512 32 30 3 16 dawn
+NNC_MI355X_CAPTURE_STREAMS=1 run dawn-f16-bs512-kept-streams 512 32 30 3 16 dawn
 run resnet50-f16-bs256 256 224 8 2 16 full
 run resnet50-f32-bs256 256 224 6 2 32 full

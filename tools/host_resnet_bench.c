@@ -546,8 +546,15 @@ int main(int argc, char** argv)
 	 * sequence -- is recorded ONCE between nnc_mi355x_capture_begin / _end (nothing executes meanwhile) and every timed step is one nnc_mi355x_graph_launch.
 	 * The same number of steps EXECUTES either way, so the probes below must not depend on the switch (tests/test_via_host.py). */
 	void* step_graph = 0;
-	double t_capture = 0;
-	if (getenv("HOST_BENCH_CAPTURE") && atoi(getenv("HOST_BENCH_CAPTURE"))) {
+	double t_capture = 0, ms_issued = 0, cap_host_ms[5] = { 0, 0, 0, 0, 0 };
+	const int capmode = getenv("HOST_BENCH_CAPTURE") ? atoi(getenv("HOST_BENCH_CAPTURE")) : 0; /* 1: every timed step is a replay; 2: BOTH forms are timed, command by command first (bench.py) */
+	if (capmode == 2) {
+		const double p0_ = now_ms();
+		for (i = 0; i < steps; i++) TRAIN_STEP();
+		SYNC_ALL();
+		ms_issued = (now_ms() - p0_) / (steps > 0 ? steps : 1);
+	}
+	if (capmode) {
 		if (!step_stream || ranks) { fprintf(stderr, "host_resnet_bench: HOST_BENCH_CAPTURE needs the one-stream step (no process ranks, not the N-device DawnNet form)\n"); return 4; }
 		const double c0_ = now_ms();
 		if (nnc_mi355x_capture_begin(stream) != 0) { fprintf(stderr, "host_resnet_bench: nnc_mi355x_capture_begin failed\n"); return 4; }
@@ -588,12 +595,20 @@ int main(int argc, char** argv)
 		SYNC_ALL();
 		const long c0 = nnc_mi355x_debug_exec_count();
 		const double e0 = now_ms();
-		RUN_STEP();
+		if (capmode == 2) TRAIN_STEP(); else RUN_STEP(); /* (both forms: this leg is the step issued command by command, the replay's host time follows) */
 		const double e1 = now_ms();
 		SYNC_ALL();
 		enq_ms[i] = e1 - e0; enq_step_ms[i] = now_ms() - e0;
 		enq_cmds = nnc_mi355x_debug_exec_count() - c0;
 	}
+	for (i = 0; i < 5 && step_graph; i++) { /* host time of ONE nnc_mi355x_graph_launch on drained streams */
+		SYNC_ALL();
+		const double e0 = now_ms();
+		RUN_STEP();
+		cap_host_ms[i] = now_ms() - e0;
+		SYNC_ALL();
+	}
+	{ int a_, b_; for (a_ = 0; a_ < 5; a_++) for (b_ = a_ + 1; b_ < 5; b_++) if (cap_host_ms[b_] < cap_host_ms[a_]) { const double t_ = cap_host_ms[a_]; cap_host_ms[a_] = cap_host_ms[b_]; cap_host_ms[b_] = t_; } }
 #endif
 	{ int a_, b_; for (a_ = 0; a_ < 5; a_++) for (b_ = a_ + 1; b_ < 5; b_++) if (enq_ms[b_] < enq_ms[a_]) { double t_ = enq_ms[a_]; enq_ms[a_] = enq_ms[b_]; enq_ms[b_] = t_; t_ = enq_step_ms[a_]; enq_step_ms[a_] = enq_step_ms[b_]; enq_step_ms[b_] = t_; } }
 	/* roofline leg: one more step with the backend's per-launch HIP-event records on (contractions and batch norm) */
@@ -664,7 +679,7 @@ int main(int argc, char** argv)
 		nnc_mi355x_comm_overlap_stats(&ov_c, &ov_b);
 		printf("\"comm_overlap\": {\"collectives\": %ld, \"buckets\": %ld}, ", ov_c, ov_b);
 	}
-	printf("\"capture\": {\"on\": %s, \"graph_nodes\": %d, \"capture_ms\": %.2f}, ", step_graph ? "true" : "false", nnc_mi355x_graph_node_count(step_graph), t_capture);
+	printf("\"capture\": {\"on\": %s, \"graph_nodes\": %d, \"capture_ms\": %.2f, \"issued_per_command_ms_per_step\": %.4f, \"launch_host_ms_median\": %.4f}, ", step_graph ? "true" : "false", nnc_mi355x_graph_node_count(step_graph), t_capture, ms_issued, cap_host_ms[2]);
 	printf("\"f16_contractions_by_bound\": {\"mfma\": {\"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}, \"hbm\": {\"launches\": %d, \"ms\": %.4f, \"flops\": %.6g, \"bytes\": %.6g}}, ",
 		f16b[0].n, f16b[0].ms, f16b[0].flops, f16b[0].bytes, f16b[1].n, f16b[1].ms, f16b[1].flops, f16b[1].bytes);
 	printf("\"kernels\": [");
