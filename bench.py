@@ -740,7 +740,7 @@ def main():
             "dtype": "f32 (Winograd-domain / fc GEMMs: exact bf16x3 split, all 9 products, fp32 accumulate)" if L.tune_get("GEMM_BF16X3") > 0 else "f32", "data": "synthetic",
             "config": {"workload": "VGG-D (ccv vgg_d_params, 225x225x3 crop, NHWC) %s, batch %d per GPU, random-init weights" % ("forward only" if fwd_only else "forward+backward+SGD", args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "captured_step": ({"images_per_s": world * args.batch * args.steps / dt_cap, "ms_per_step": 1e3 * dt_cap / args.steps, "graph_nodes": cap_nodes, "note": "the same K steps as ONE hipGraphLaunch each (nnc_mi355x_capture_begin / _end around one step); `value` is the step issued command by command"} if dt_cap else None),
+                       "captured_step": ({"images_per_s": world * args.batch * args.steps / dt_cap, "ms_per_step": 1e3 * dt_cap / args.steps, "graph_nodes": cap_nodes, "note": "one hipGraphLaunch per step; `value` is the step issued command by command"} if dt_cap else None),
                        "gflop_per_image": (ff if fwd_only else fb) / 1e9, "whole_step_tflops_per_gpu": value / world * (ff if fwd_only else fb) / 1e12, "final_loss": loss,
                        "conv_relu": "convolution epilogue (NNC_MI355X_CONV_ALGO_FUSE_RELU)" if net.fuse_relu else "separate RELU_FORWARD commands"},
         }

@@ -1437,6 +1437,12 @@ static int _conv_autotune(const ccv_nnc_cmd_t cmd, const size_t max_workspace_si
 	(void)max_workspace_size;
 	if (any_half_tensor(inputs, input_size, outputs, output_size)) return -1; // half precision: the backend's own choice (the trials below time the fp32 kernels)
 	if (any_palettized(inputs, input_size)) return -1; // palettized filters: the trials below would read the byte stream as floats; the backend's own choice
+	{ // NNC_MI355X_CONV_AUTOTUNE=0: no timed trials, the backend's own choice -- runs that must be reproducible bit for bit from process to process (the timing of
+	  // near-equal algorithms flips with the machine's load: two emulator processes side by side picked differently, tests/test_via_host.py's captured 2-device step)
+		static int trials = -1;
+		if (trials < 0) { const char* e = getenv("NNC_MI355X_CONV_AUTOTUNE"); trials = (e && *e == '0') ? 0 : 1; }
+		if (!trials) return -1;
+	}
 	const bool fwd = cmd.cmd == CCV_NNC_CONVOLUTION_FORWARD;
 	hipStream_t stream = stream_of(stream_context);
 	hipEvent_t e0, e1;

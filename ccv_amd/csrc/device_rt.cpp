@@ -48,8 +48,8 @@ struct stream_gpu_t {
 struct signal_gpu_t {
 	ccv_nnc_stream_signal_s super;
 	hipEvent_t event;
-	unsigned long capture_id; // the capture in which it was last emitted (0: outside any), and whether by a stream folded into the recording one
-	int capture_on_alias;
+	unsigned long capture_id; // the capture in which it was last emitted (0: outside any), and -- folded form -- the device whose recording stream it was emitted on (-1: none)
+	int capture_dev;
 };
 // stream_context == NULL: the device's default stream + a per-thread, per-device workspace
 // (lib/nnc/gpu/ccv_nnc_compat.cu:301-340).
@@ -87,6 +87,9 @@ std::atomic<unsigned long> g_capture_id(0);        // the running capture's numb
 std::atomic<unsigned long> g_graph_max_end_seq(0); // the newest allocation any LIVE captured graph may name (0: no graph alive)
 hipStream_t g_cap_origin = 0;                      // the stream the running capture began on, its device,
 int g_cap_device = 0;
+constexpr int CAP_MAX_DEVICES = 64;
+hipStream_t g_cap_rep[CAP_MAX_DEVICES];            // folded form: the ONE recording stream per device (the origin on its device; elsewhere the first stream of the device the step reached)
+hipEvent_t g_cap_relay[CAP_MAX_DEVICES];           // ... and an event per device for dependencies between two non-origin devices, which are routed through the origin
 int g_cap_keep_streams = -1;                       // and the capture's form: 0 = the step's streams of that device are folded into the recording one (default), 1 = kept (-1: environment not read yet)
 inline bool pool_pinned(const unsigned long seq) { return g_capture_active.load(std::memory_order_acquire) > 0 || seq <= g_graph_max_end_seq.load(std::memory_order_acquire); }
 // is THIS stream recording (a stream of the device that has not joined the capture is an ordinary stream)
@@ -134,7 +137,7 @@ device_local_t* bind(const ccv_nnc_stream_context_t* ctx)
 // the recording device that the step reaches works on the recording stream: issue order on one stream IS a valid order of the step.
 inline hipStream_t effective_stream(device_local_t* const l)
 {
-	if (g_capture_active.load(std::memory_order_acquire) > 0 && l->capture_alias == g_capture_id.load(std::memory_order_acquire) && l->capture_alias) return g_cap_origin;
+	if (g_capture_active.load(std::memory_order_acquire) > 0 && l->capture_alias == g_capture_id.load(std::memory_order_acquire) && l->capture_alias && l->device >= 0 && l->device < CAP_MAX_DEVICES && g_cap_rep[l->device]) return g_cap_rep[l->device];
 	return l->stream;
 }
 
@@ -1021,7 +1024,7 @@ ccv_nnc_stream_signal_t* ccv_nnc_init_stream_signal(ccv_nnc_stream_signal_t* con
 	if ((g->super.type & CCV_COMPUTE_DEVICE_ANY) != CCV_COMPUTE_DEVICE_ANY) HIP_ENFORCE(hipSetDevice(dev));
 	HIP_ENFORCE(hipEventCreateWithFlags(&g->event, hipEventDisableTiming));
 	g->capture_id = 0;
-	g->capture_on_alias = 0;
+	g->capture_dev = -1;
 	return (ccv_nnc_stream_signal_t*)g;
 }
 void ccv_nnc_deinit_stream_signal(ccv_nnc_stream_signal_t* const signal)
@@ -1039,8 +1042,27 @@ void signal_emit_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc
 	hipStream_t const es = effective_stream(l);
 	const bool recording = stream_capturing(es);
 	g->capture_id = recording ? g_capture_id.load(std::memory_order_acquire) : 0;
-	g->capture_on_alias = recording && es == g_cap_origin && !g_cap_keep_streams;
-	HIP_ENFORCE(hipEventRecord(g->event, es)); // (in the folded form too: a stream of ANOTHER device joins the capture through it)
+	g->capture_dev = (recording && !g_cap_keep_streams && l->device >= 0 && l->device < CAP_MAX_DEVICES && g_cap_rep[l->device] == es) ? l->device : -1;
+	HIP_ENFORCE(hipEventRecord(g->event, es));
+}
+// Folded form, the dependency "device `to`'s recording stream continues behind `event`, which was recorded on device `from`'s recording stream".  ROCm 7.2 files a
+// NON-origin stream that waits for a captured event under the stream the event was recorded on and walks those lists recursively when the capture ends -- two
+// non-origin streams that wait for each other make that walk endless (capture section below).  So a non-origin stream only ever waits for events recorded ON THE
+// ORIGIN: a dependency between two other devices goes origin-waits-for-it, origin-records-a-relay, the target waits for the relay.  (The origin then carries a
+// dependency it does not need: its later kernels start behind the signalled work of `from` -- the price of the detour, paid only by steps that span devices.)
+static void capture_cross_device(const int from, const int to, hipEvent_t event)
+{
+	if (to == g_cap_device) { HIP_ENFORCE(hipStreamWaitEvent(g_cap_origin, event, 0)); return; }
+	if (from == g_cap_device) { HIP_ENFORCE(hipStreamWaitEvent(g_cap_rep[to], event, 0)); return; }
+	HIP_ENFORCE(hipStreamWaitEvent(g_cap_origin, event, 0));
+	if (!g_cap_relay[to]) { // (an event is recorded on streams of the device it was made on: the origin's)
+		const int prev = current_device();
+		HIP_ENFORCE(hipSetDevice(g_cap_device));
+		HIP_ENFORCE(hipEventCreateWithFlags(&g_cap_relay[to], hipEventDisableTiming));
+		HIP_ENFORCE(hipSetDevice(prev));
+	}
+	HIP_ENFORCE(hipEventRecord(g_cap_relay[to], g_cap_origin));
+	HIP_ENFORCE(hipStreamWaitEvent(g_cap_rep[to], g_cap_relay[to], 0));
 }
 void signal_wait_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc_stream_signal_t* const signal)
 {
@@ -1048,15 +1070,16 @@ void signal_wait_now(const ccv_nnc_stream_context_t* const stream, const ccv_nnc
 	signal_gpu_t* const g = (signal_gpu_t*)signal;
 	if (g_capture_active.load(std::memory_order_acquire) > 0 && !g_cap_keep_streams) {
 		const unsigned long id = g_capture_id.load(std::memory_order_acquire);
-		if (g->capture_id == id) {
-			// emitted inside the running capture: the waiting stream is part of the step.  On the recording device it is folded into the recording stream from
-			// here on -- and behind a signal that was emitted THERE the stream order already is the dependency.
-			if (l->device == g_cap_device && l->stream) {
-				l->capture_alias = id;
-				if (!g->capture_on_alias) HIP_ENFORCE(hipStreamWaitEvent(g_cap_origin, g->event, 0));
-				return;
-			}
-		} else if (l->capture_alias == id) {
+		if (g->capture_id == id && g->capture_dev >= 0 && l->stream && l->device >= 0 && l->device < CAP_MAX_DEVICES) {
+			// emitted inside the running capture: the waiting stream is part of the step and works on its device's recording stream from here on (the first
+			// stream of a device the step reaches BECOMES that device's recording stream).  Behind a signal of the same device stream order is the dependency.
+			const int d = l->device;
+			if (!g_cap_rep[d]) g_cap_rep[d] = l->stream;
+			l->capture_alias = id;
+			if (g->capture_dev != d) capture_cross_device(g->capture_dev, d, g->event);
+			return;
+		}
+		if (g->capture_id != id && l->capture_alias == id) {
 			fprintf(stderr, "[nnc_mi355x] a stream of the step being recorded waits for a signal that was emitted outside the capture: the step cannot be replayed\n");
 			abort();
 		}
@@ -1342,6 +1365,8 @@ int nnc_mi355x_capture_begin(ccv_nnc_stream_context_t* const stream_context)
 	g_cap.device = l->device;
 	g_cap_origin = l->stream;
 	g_cap_device = l->device;
+	for (int i = 0; i < CAP_MAX_DEVICES; i++) g_cap_rep[i] = 0;
+	if (l->device >= 0 && l->device < CAP_MAX_DEVICES) g_cap_rep[l->device] = l->stream;
 	l->capture_alias = g_capture_id.fetch_add(1, std::memory_order_acq_rel) + 1;
 	g_capture_active.store(1, std::memory_order_release);
 	// relaxed mode: allocations, event queries and the like stay legal on this and every other thread while the stream records (a loader thread keeps working)

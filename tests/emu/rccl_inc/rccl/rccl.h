@@ -124,7 +124,13 @@ static inline ncclResult_t ncclCommDestroy(ncclComm_t c)
 }
 static inline ncclResult_t ncclGroupStart() { return ncclSuccess; }
 static inline ncclResult_t ncclGroupEnd() { return ncclSuccess; }
-static inline ncclResult_t ncclAllReduce(const void* s, void* r, size_t count, ncclDataType_t dt, ncclRedOp_t, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 0, s, r, count, 0, dt); }
-static inline ncclResult_t ncclBroadcast(const void* s, void* r, size_t count, ncclDataType_t dt, int root, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 1, s, r, count, root, dt); }
-static inline ncclResult_t ncclReduce(const void* s, void* r, size_t count, ncclDataType_t dt, ncclRedOp_t, int root, ncclComm_t c, hipStream_t) { return emu_nccl_post(c, 2, s, r, count, root, dt); }
+// (a collective on a CAPTURING stream is recorded like any other node: the ranks' posts replay in the order they were issued, the last one runs the collective)
+static inline ncclResult_t emu_nccl_call(ncclComm_t c, int kind, const void* s, void* r, size_t count, int root, int dt, hipStream_t st)
+{
+	if (st && emu::capturing(st)) { emu::capture_push(st, [=]() { (void)emu_nccl_post(c, kind, s, r, count, root, dt); }); return ncclSuccess; }
+	return emu_nccl_post(c, kind, s, r, count, root, dt);
+}
+static inline ncclResult_t ncclAllReduce(const void* s, void* r, size_t count, ncclDataType_t dt, ncclRedOp_t, ncclComm_t c, hipStream_t st) { return emu_nccl_call(c, 0, s, r, count, 0, dt, st); }
+static inline ncclResult_t ncclBroadcast(const void* s, void* r, size_t count, ncclDataType_t dt, int root, ncclComm_t c, hipStream_t st) { return emu_nccl_call(c, 1, s, r, count, root, dt, st); }
+static inline ncclResult_t ncclReduce(const void* s, void* r, size_t count, ncclDataType_t dt, ncclRedOp_t, int root, ncclComm_t c, hipStream_t st) { return emu_nccl_call(c, 2, s, r, count, root, dt, st); }
 static inline const char* ncclGetErrorString(ncclResult_t) { return "emu-nccl error"; }
