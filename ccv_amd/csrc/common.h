@@ -248,6 +248,7 @@ enum {
 	TUNE_LSTM_ROWS,         // LSTM without projection, hidden size <= 128: a workgroup owns ONE batch row (two when the hidden size is no multiple of four; 2 = two for every size) and ALL hidden units for the whole sequence, R entirely in its registers, no word passes between workgroups (1), or the forms above (0)
 	TUNE_GEMM_BF16X3,       // fp32 plain-matrix contractions on the bf16 matrix pipe, every operand split exactly into three bf16 values and all nine partial products accumulated in fp32 (mfma_gemm_bf16x3.h): 0 = never (the fp32 matrix instructions), 1 = where the launcher's rules say it pays, 2 = wherever the kernel applies, 3 / 4 = as 2 with the 128 x 128 / 256 x 256 tile forced (measurements)
 	TUNE_BN_CLUSTER_SLOTS,  // the cluster batch-norm kernels on tensors too small to fill the chip with full workgroup shares: shares are cut down until the launch has about this many workgroups (never below two chunks per thread); 0 = always the largest share a workgroup's registers hold (rounds 4 - 5)
+	TUNE_GEMM_BATCH_XCD,    // batched contractions without split-K (a 1 x 1 convolution on NCHW tensors: one matrix product per image) launch ONE grid dimension over (entry, tile) and give every batch entry to one XCD: the tiles of an entry meet in ONE L2, so its B operand -- the image's planes, which every row block of the output reads -- leaves HBM once, not once per XCD (1); 0 = entries on grid z, tiles dealt round-robin over the XCDs (rounds 1 - 5)
 	TUNE_COUNT
 };
 static_assert(TUNE_GRID_WG_PER_CU == 3, "grid_for() above names this key by value");

@@ -146,10 +146,10 @@ inline hipStream_t effective_stream(device_local_t* const l)
 namespace nnc {
 int g_force_tile = 0;
 int g_force_splits = 0;
-static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C", "WINO_FUSED_GRID", "GRID_WG_PER_CU", "WINO_WGRAD_FUSED_MAX", "GEMM_BUFFER_LOADS", "CONV_NCHW_HALF_F16", "BN_SMALL_PLANES", "SDPA_MFMA", "BN_CLUSTER", "GEMM_VEC_EPILOGUE", "POOL_ROWS", "GEMM_HALF_CHUNK8", "LSTM_PERSISTENT", "LSTM_ROWS", "GEMM_BF16X3", "BN_CLUSTER_SLOTS" };
+static const char* const g_tune_names[TUNE_COUNT] = { "WINO_SLICE_KB", "WINO_FUSED_MAX_C", "WINO_FUSED_GRID", "GRID_WG_PER_CU", "WINO_WGRAD_FUSED_MAX", "GEMM_BUFFER_LOADS", "CONV_NCHW_HALF_F16", "BN_SMALL_PLANES", "SDPA_MFMA", "BN_CLUSTER", "GEMM_VEC_EPILOGUE", "POOL_ROWS", "GEMM_HALF_CHUNK8", "LSTM_PERSISTENT", "LSTM_ROWS", "GEMM_BF16X3", "BN_CLUSTER_SLOTS", "GEMM_BATCH_XCD" };
 // GRID_WG_PER_CU = 0: grid-stride kernels get one trip per thread.  tools/ew_bw_bench.py: a grid capped at 8 .. 64 workgroups per CU
 // striding a 3.3 GB tensor runs at 4.7 - 5.2 TB/s, the same kernel with the whole tensor as its grid at 6.2 TB/s.
-static long g_tune_values[TUNE_COUNT] = { 0, 128, 0, 0, 128, 1, 32, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0 }; // defaults: the measured best on the MI355X
+static long g_tune_values[TUNE_COUNT] = { 0, 128, 0, 0, 128, 1, 32, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1 }; // defaults: the measured best on the MI355X
 static int g_tune_env_read = 0;
 long tune(int key)
 {

@@ -7,6 +7,18 @@
 
 namespace nnc {
 
+// The grid of a batched contraction without split-K and the kernel's `splits` argument that goes with it (mfma_gemm.h gemm_batch_xcd_map): one dimension over
+// (entry, tile) with every batch entry on ONE XCD, or -- a batch of one, TUNE_GEMM_BATCH_XCD = 0, a grid beyond 2^31 -- the entries on grid z.
+static inline dim3 gemm_batch_grid(const long tiles, const int zcount, int* const splits_arg)
+{
+	const long flat = (long)((zcount + 7) / 8) * 8 * tiles;
+	// (few entries would leave XCDs without work: 64 or more, or whole rounds of eight)
+	if ((zcount >= 64 || (zcount >= 16 && zcount % 8 == 0)) && tune(TUNE_GEMM_BATCH_XCD) > 0 && flat <= 0x7fffffffL) { *splits_arg = -zcount; return dim3((unsigned)flat, 1, 1); }
+	*splits_arg = 1;
+	return dim3((unsigned)tiles, 1, (unsigned)zcount);
+}
+
+
 struct GemmOut {
 	float* c;
 	long ldm, ldn;
@@ -119,7 +131,9 @@ static int gemm_run_tile(const char* name, const LA& la, const LB& lb, const Gem
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
 		epi.vec = epi_vec_ok(out.c, sizeof(float), out.ldm, out.ldn, N, zcount, c_z);
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
+		int sarg;
+		const dim3 grid = gemm_batch_grid(tiles, zcount, &sarg);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f32_kernel<LA, LB, EpiStore, WM, WN>), grid, dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, sarg, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -283,8 +297,10 @@ static int gemm_run_tile_h(const char* name, const LA& la, const LB& lb, const G
 		epi.vec = epi_vec_ok(out.c, sizeof(half_t), out.ldm, out.ldn, N, zcount, c_z);
 		if (epi.vec && tune(TUNE_GEMM_VEC_EPILOGUE) != 3 && out.ldm % 8 == 0 && N % 8 == 0 && ((uintptr_t)out.c & 15) == 0 && (zcount <= 1 || c_z % 8 == 0)) epi.vec = 2; // 16-byte stores (TUNE_GEMM_VEC_EPILOGUE = 3: 8-byte ones, measurements)
 		ProfScope prof(prof_name, flops, -2.0 * zcount * ((double)M * K + (double)N * K + (double)M * N), M, N, K, zcount, 1, stream);
-		if (v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN, 8>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, 1, a_z, b_z, c_z, bias_z, ko);
+		int sarg;
+		const dim3 grid = gemm_batch_grid(tiles, zcount, &sarg);
+		if (v8) hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN, 8>), grid, dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, sarg, a_z, b_z, c_z, bias_z, ko);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_kernel<LA, LB, EpiStoreH, WM, WN>), grid, dim3(GEMM_THREADS), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K > 0 ? K : 1, sarg, a_z, b_z, c_z, bias_z, ko);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -392,7 +408,9 @@ static int gemm_run_buf_tile_h(const char* name, const BufMatLoader<AKC>& la, co
 		epi.vec = epi_vec_ok(out.c, sizeof(half_t), out.ldm, out.ldn, N, zcount, c_z);
 		if (epi.vec && tune(TUNE_GEMM_VEC_EPILOGUE) != 3 && out.ldm % 8 == 0 && N % 8 == 0 && ((uintptr_t)out.c & 15) == 0 && (zcount <= 1 || c_z % 8 == 0)) epi.vec = 2; // 16-byte stores (TUNE_GEMM_VEC_EPILOGUE = 3: 8-byte ones, measurements)
 		ProfScope prof(prof_name, flops, -2.0 * zcount * ((double)M * K + (double)N * K + (double)M * N), M, N, K, zcount, 1, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiStoreH, TM, TN, WM, WN, BK>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(64 * WM * WN), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, 1, a_z, b_z, c_z, bias_z);
+		int sarg;
+		const dim3 grid = gemm_batch_grid(tiles, zcount, &sarg);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_f16_buf_kernel<AKC, BKC, EpiStoreH, TM, TN, WM, WN, BK>), grid, dim3(64 * WM * WN), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, sarg, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}

@@ -786,6 +786,20 @@ __device__ __forceinline__ long M_N_slab(const EpiPartial& e) { return e.slab; }
 // grid: x = tiles (* split-K slices), XCD-swizzled; z = batch / conv group.  WM / WN = 32x32 MFMA tiles per wave.
 // DBG (tools/kprobe.cpp only; the library always instantiates DBG = 0): knock out parts of the steady state to attribute time.
 //   1 no global loads, 2 no LDS writes, 4 no barrier, 8 no address prep, 16 no MFMAs, 32 no A loads, 64 no B loads
+
+// Batched launches without split-K (`splits` < 0: the batch has -splits entries and the grid is ONE dimension of 8 * ceil(entries / 8) * tiles workgroups).
+// Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x walks the entries x, x + 8, ... tile by tile, so the tiles of one entry -- which share its operands:
+// every row block of a 1 x 1 convolution's output reads the same image planes -- meet in ONE L2 and the entry leaves HBM once.  (With the entries on grid z the
+// tiles of an entry were dealt over all eight XCDs: ResNet-50's 14^2 layers, 16 tiles per image, fetched each image's planes up to eight times --
+// tools/store_probe.cpp, profiles/r06_v14_store_probe.txt.)  false: no entry for this workgroup (the last round of eight).
+__device__ __forceinline__ bool gemm_batch_xcd_map(const int bid, const int tiles, const int entries, int* const tile, int* const z)
+{
+	const int xcd = bid & 7, idx = bid >> 3;
+	const int round = idx / tiles;
+	*tile = idx - round * tiles;
+	*z = round * 8 + xcd;
+	return *z < entries;
+}
 template <class LA, class LB, class EPI, int WM, int WN, int DBG = 0>
 __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB lb, EPI epi, const int tiles_m, const int tiles_n, const int K, const int k_per_split, const int splits, const long a_zoff, const long b_zoff, const long c_zoff, const long bias_zoff, const KOrder ko)
 {
@@ -804,8 +818,10 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	//                XCD's L2 once while every tile of the slice reads it in lockstep (wgrad: 36-144 tiles per slice)
 	const int nwg = gridDim.x;
 	const int bid = blockIdx.x;
-	int tile, slice = 0;
-	{
+	int tile, slice = 0, zi = (int)blockIdx.z;
+	if (splits < 0) {
+		if (!gemm_batch_xcd_map(bid, tiles_m * tiles_n, -splits, &tile, &zi)) return;
+	} else {
 		const int xcd = bid & 7, idx = bid >> 3;
 		if (splits > 1) {
 			const int tiles = tiles_m * tiles_n;
@@ -820,9 +836,9 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 	(void)tiles_m;
 	const int m0 = tile_m * BM, n0 = tile_n * BN;
-	la.p += (long)blockIdx.z * a_zoff; la.zoff -= (long)blockIdx.z * a_zoff;
-	lb.p += (long)blockIdx.z * b_zoff; lb.zoff -= (long)blockIdx.z * b_zoff;
-	epi.c += (long)blockIdx.z * c_zoff;
+	la.p += (long)zi * a_zoff; la.zoff -= (long)zi * a_zoff;
+	lb.p += (long)zi * b_zoff; lb.zoff -= (long)zi * b_zoff;
+	epi.c += (long)zi * c_zoff;
 	if (splits > 1) epi.c += (long)slice * M_N_slab(epi);
 	const int k_begin = slice * k_per_split;
 	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
@@ -928,7 +944,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f32_kernel(LA la, LB l
 	}
 	// D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), both in fragment-lane terms
 	// (frag_row maps a tile's lane to the row / column of the wave's span it stands for).
-	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
+	if (epi.bias) epi.bias += (long)zi * bias_zoff;
 	if (epi.vec) {
 		// through LDS, one tile row of every wave per pass: 64 staged rows (wave row wm, fragment row q) x BN columns, read back row-major (epi_flush_rows)
 		constexpr int PITCH = BN + 8;

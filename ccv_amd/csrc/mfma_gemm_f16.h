@@ -239,8 +239,10 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 	const int li = lane & 31, lh = lane >> 5;
 	const int nwg = gridDim.x;
 	const int bid = blockIdx.x;
-	int tile, slice = 0;
-	{
+	int tile, slice = 0, zi = (int)blockIdx.z;
+	if (splits < 0) {
+		if (!gemm_batch_xcd_map(bid, tiles_m * tiles_n, -splits, &tile, &zi)) return;
+	} else {
 		const int xcd = bid & 7, idx = bid >> 3;
 		if (splits > 1) {
 			const int tiles = tiles_m * tiles_n;
@@ -256,9 +258,9 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 	(void)tiles_m;
 	const int m0 = tile_m * BM, n0 = tile_n * BN;
 	// the loaders' base pointers are typed float* (mfma_gemm.h) but address halves here: offsets are in ELEMENTS
-	la.p = (const float*)((const half_t*)la.p + (long)blockIdx.z * a_zoff); la.zoff -= (long)blockIdx.z * a_zoff;
-	lb.p = (const float*)((const half_t*)lb.p + (long)blockIdx.z * b_zoff); lb.zoff -= (long)blockIdx.z * b_zoff;
-	epi.c += (long)blockIdx.z * c_zoff;
+	la.p = (const float*)((const half_t*)la.p + (long)zi * a_zoff); la.zoff -= (long)zi * a_zoff;
+	lb.p = (const float*)((const half_t*)lb.p + (long)zi * b_zoff); lb.zoff -= (long)zi * b_zoff;
+	epi.c += (long)zi * c_zoff;
 	if (splits > 1) epi.c += (long)slice * M_N_slab(epi);
 	const int k_begin = slice * k_per_split;
 	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
@@ -337,7 +339,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) mfma_gemm_f16_kernel(LA la, LB l
 		__syncthreads();
 	}
 	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
+	if (epi.bias) epi.bias += (long)zi * bias_zoff;
 	if constexpr (EPI::PLANAR) { // NCHW output: each 64-row slice staged transposed ([n][m], pitch 65), read back along m (EpiStoreHT above)
 		constexpr int PM = 65;
 		static_assert(BN * PM * 2 <= 2 * (A_HALVES + B_HALVES), "the transposed slice (fp32) fits the operand buffers");

@@ -668,7 +668,8 @@ def test_batch_norm_with_one_dimensional_statistics(backend, ref_lib, fmt, shape
         np.testing.assert_allclose(a.reshape(-1), b.reshape(-1), rtol=2e-4, atol=2e-5, err_msg=what)
 
 
-@pytest.mark.parametrize("case", [(3, 8, 6, 6, 12, True), (2, 16, 4, 8, 8, False), (2, 64, 14, 14, 128, True)], ids=["8to12", "16to8", "64to128"])
+@pytest.mark.parametrize("case", [(3, 8, 6, 6, 12, True), (2, 16, 4, 8, 8, False), (2, 64, 14, 14, 128, True), (16, 64, 14, 14, 160, True), (68, 8, 6, 6, 12, False)],
+                         ids=["8to12", "16to8", "64to128", "64to160-batch16-one-image-per-xcd", "8to12-batch68-ragged-last-round"])
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_conv_1x1_on_nchw_tensors_without_layout_passes(backend, ref_lib, case, dtype):
     """ResNet's bottleneck convolutions as the reference's trainer issues them (NCHW, 1x1, stride 1: bin/nnc/imagenet.c): forward,
@@ -709,6 +710,14 @@ def test_conv_1x1_on_nchw_tensors_without_layout_passes(backend, ref_lib, case, 
     np.testing.assert_allclose(hh.astype(F), want_h, **tol)
     np.testing.assert_allclose(dw.astype(F), want_dw, rtol=tol["rtol"], atol=tol["atol"] * max(1.0, float(np.abs(want_dw).max())))
     np.testing.assert_allclose(db.astype(F), want_db, rtol=tol["rtol"], atol=tol["atol"] * max(1.0, float(np.abs(want_db).max())))
+    if n >= 16:  # round 6: the batch entries on ONE grid dimension, an image per XCD (gemm_batch_xcd_map) -- the same arithmetic as with the images on grid z: EQUAL
+        backend.tune_set("GEMM_BATCH_XCD", 0)
+        try:
+            b0, = gpu(nnc.CMD_CONVOLUTION_FORWARD(1, k, 1, 1, c), [a, wt] + ([bias] if with_bias else []), [np.zeros((n, k, h, w_), T)])
+            h0, dw0, db0 = gpu(nnc.CMD_CONVOLUTION_BACKWARD(1, k, 1, 1, c), [g, a, wt], [np.zeros_like(a), np.zeros_like(wt), np.zeros(k, T)])
+        finally:
+            backend.tune_set("GEMM_BATCH_XCD", 1)
+        assert np.array_equal(b0, b) and np.array_equal(h0, hh) and np.array_equal(dw0, dw) and np.array_equal(db0, db)
     native = (h * w_) % 4 == 0 and c % 4 == 0 and k % 4 == 0
     if native:
         assert any(x.startswith("conv1x1_nchw_fwd") for x in names) and any(x.startswith("conv1x1_nchw_dgrad") for x in names) and any(x.startswith("conv1x1_nchw_wgrad") for x in names), names
