@@ -65,6 +65,16 @@ static bool pixel_linear(const Image4& t)
 	return t.sc == 1 && t.sh == (long)t.w * t.sw && (t.n == 1 || t.sn == (long)t.h * t.sh);
 }
 
+// A 1 x 1, stride-1, unpadded, ungrouped convolution over pixel-linear NHWC images IS a product of plain matrices -- [pixels][C] . [K][C]^T -- and goes to the
+// contraction launcher as such: buffer loads without address arithmetic in the K loop and, in fp32, the split form on the bf16 matrix pipe (gemm_launch.h
+// gemm_bf16x3_tile), neither of which the im2col loaders can take.  (Round 6: ResNet-50's 7 x 7 maps -- 49 pixels, no multiple of four, so the NCHW-native
+// route of conv1x1_nchw_* does not apply -- ran their 512 <-> 2048 layers through the im2col walk at 77 - 87 TFLOP/s, 5.8 ms of the fp32 step.)
+static bool conv_pointwise(const conv_geom_t& g, const Image4& in, const Image4& out)
+{
+	return g.kh == 1 && g.kw == 1 && g.sy == 1 && g.sx == 1 && g.pby == 0 && g.pbx == 0 && g.groups == 1 && g.OH == g.H && g.OW == g.W && pixel_linear(in) && pixel_linear(out)
+		&& (long)g.N * g.H * g.W <= 0x7fffffffL;
+}
+
 // ---- Winograd F(4x4, 3x3) (winograd.h) --------------------------------------------------------------------------------
 // Algorithm numbers of the two conv rows (ccv_nnc_cmd_t.algorithm; -1 = the backend's own choice; what autotune returns).
 // 2 = the fused Winograd kernel (wino_fused.h) for forward and the data gradient; the filter gradient under 2 is algorithm 1's.
@@ -534,6 +544,12 @@ static int conv_forw_nhwc(const conv_geom_t& g, const Image4& a, const float* w,
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const bool vec = (g.Cg % 4 == 0) && aligned16(a.p) && aligned16(w) && a.sw % 4 == 0 && a.sh % 4 == 0 && (a.n == 1 || a.sn % 4 == 0);
 	GemmOut out = { b.p, b.sw, 1, bias, 1.f, 0 };
+	if (vec && conv_pointwise(g, a, b)) { // b [pixels][K] = a [pixels][C] . w [K][C]^T
+		MatLoader<true, true> la, lb;
+		la.p = a.p; la.ldr = a.sw; la.ldk = 1; la.R = (int)M; la.K = g.C;
+		lb.p = w; lb.ldr = g.C; lb.ldk = 1; lb.R = g.K; lb.K = g.C;
+		return gemm_run("conv_fwd_pointwise", la, lb, out, (int)M, g.K, g.C, 1, 0L, 0L, 0L, 0L, 1, flags, ctx);
+	}
 	KOrder ko; // taps of one 32-channel chunk in consecutive K-steps (L2 reuse of the re-read pixels), see mfma_gemm.h
 	if (g.kh * g.kw > 1 && g.Cg % GEMM_BK == 0) ko.init(g.kh * g.kw, g.Cg);
 #define CONV_FWD(VEC, INC) do { \
@@ -665,6 +681,13 @@ static int conv_dgrad_nhwc(const conv_geom_t& g, const Image4& gr, const float* 
 	if (M > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
 	const bool vec = (g.Kg % 4 == 0) && (g.Cg % 4 == 0) && aligned16(gr.p) && aligned16(w) && gr.sw % 4 == 0 && gr.sh % 4 == 0 && (gr.n == 1 || gr.sn % 4 == 0);
 	GemmOut out = { h.p, h.sw, 1, 0, 1.f, 0 };
+	if (vec && conv_pointwise(g, h, gr)) { // h [pixels][C] = g [pixels][K] . w [K][C]: B(c, k) = w[k C + c], rows contiguous
+		MatLoader<true, true> la;
+		la.p = gr.p; la.ldr = gr.sw; la.ldk = 1; la.R = (int)M; la.K = g.K;
+		MatLoader<false, true> lb;
+		lb.p = w; lb.ldr = 1; lb.ldk = g.C; lb.R = g.C; lb.K = g.K;
+		return gemm_run("conv_dgrad_pointwise", la, lb, out, (int)M, g.C, g.K, 1, 0L, 0L, 0L, 0L, 1, flags, ctx);
+	}
 	KOrder ko;
 	if (g.kh * g.kw > 1 && g.Kg % GEMM_BK == 0) ko.init(g.kh * g.kw, g.Kg);
 #define CONV_DGRAD(VEC, STRIDED, INC) do { \
@@ -708,6 +731,12 @@ static int conv_wgrad_nhwc(const conv_geom_t& g, const Image4& gr, const Image4&
 	const int NN = g.kh * g.kw * g.Cg;
 	const bool vec = (g.Cg % 4 == 0) && (g.Kg % 4 == 0) && aligned16(a.p) && aligned16(gr.p) && a.sw % 4 == 0 && a.sh % 4 == 0 && (a.n == 1 || a.sn % 4 == 0) && gr.sw % 4 == 0;
 	GemmOut out = { dw, (long)NN, 1, 0, 1.f, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0 };
+	if (vec && conv_pointwise(g, a, gr)) { // dw [K][C] = g^T [K][pixels] . a [pixels][C]: both operands with their rows (k / c) contiguous, the reduction over the pixels
+		MatLoader<false, true> la, lb;
+		la.p = gr.p; la.ldr = 1; la.ldk = gr.sw; la.R = g.K; la.K = (int)P;
+		lb.p = a.p; lb.ldr = 1; lb.ldk = a.sw; lb.R = g.C; lb.K = (int)P;
+		return gemm_run("conv_wgrad_pointwise", la, lb, out, g.K, g.C, (int)P, 1, 0L, 0L, 0L, 0L, 0, flags, ctx);
+	}
 #define CONV_WGRAD(VEC, INC) do { \
 		MatLoader<false, VEC> la; \
 		la.p = gr.p; la.ldr = 1; la.ldk = gr.sw; la.R = g.Kg; la.K = (int)P; \
@@ -1067,6 +1096,11 @@ static int conv_forw_h(const conv_geom_t& g, const Image4& a, const void* w, con
 	la.my = g.sy; la.mx = g.sx; la.oy_off = -g.pby; la.ox_off = -g.pbx; la.ty = g.dy; la.tx = g.dx; la.dv_y = 1; la.dv_x = 1;
 	MatLoader<true, true> lb;
 	lb.p = (const float*)w; lb.ldr = Kred; lb.ldk = 1; lb.R = g.Kg; lb.K = Kred;
+	if (!planar && g.C % 8 == 0 && a.sw % 8 == 0 && conv_pointwise(g, a, b)) { // two plain matrices (conv_pointwise above): the buffer-load kernel
+		MatLoader<true, true> pa;
+		pa.p = a.p; pa.ldr = a.sw; pa.ldk = 1; pa.R = (int)M; pa.K = g.C;
+		return gemm_run_h("conv_fwd_h_pointwise", pa, lb, out, (int)M, g.K, g.C, 1, 0L, 0L, 0L, 0L, 1, flags, ctx);
+	}
 	if (planar) {
 		EpiStoreHT epi;
 		epi.c = (half_t*)planar; epi.bias = (const half_t*)bias; epi.M = (int)M; epi.N = g.Kg; epi.P = g.OH * g.OW;
@@ -1081,6 +1115,13 @@ static int conv_dgrad_h(const conv_geom_t& g, const Image4& gr, const void* w, c
 	const long M = (long)g.N * g.H * g.W;
 	const int Kred = g.kh * g.kw * g.Kg;
 	GemmOutH out = { (half_t*)h.p, h.sw, 1, 0, 1.f, 0, 0 };
+	if (!planar && g.C % 8 == 0 && g.K % 8 == 0 && gr.sw % 8 == 0 && conv_pointwise(g, h, gr)) { // h [pixels][C] = g [pixels][K] . w [K][C]
+		MatLoader<true, true> pa;
+		pa.p = gr.p; pa.ldr = gr.sw; pa.ldk = 1; pa.R = (int)M; pa.K = g.K;
+		MatLoader<false, true> pb;
+		pb.p = (const float*)w; pb.ldr = 1; pb.ldk = g.C; pb.R = g.C; pb.K = g.K;
+		return gemm_run_h("conv_dgrad_h_pointwise", pa, pb, out, (int)M, g.C, g.K, 1, 0L, 0L, 0L, 0L, 1, flags, ctx);
+	}
 	KOrder ko;
 	if (g.kh * g.kw > 1 && g.Kg % GEMM_BK == 0) ko.init(g.kh * g.kw, g.Kg);
 #define CONV_DGRAD_H(STRIDED) do { \
@@ -1110,6 +1151,11 @@ static int conv_wgrad_h(const conv_geom_t& g, const Image4& gr, const Image4& a,
 	GemmOutH out = { (half_t*)dw, (long)NN, 1, 0, 1.f, (flags & CCV_NNC_ACCUMULATE_OUTPUT) ? 1 : 0, 0 };
 	MatLoader<false, true> la;
 	la.p = gr.p; la.ldr = 1; la.ldk = gr.sw; la.R = g.Kg; la.K = (int)P;
+	if (g.C % 8 == 0 && g.K % 8 == 0 && a.sw % 8 == 0 && gr.sw % 8 == 0 && conv_pointwise(g, a, gr)) { // dw [K][C] = g^T . a: both operands with their rows contiguous
+		MatLoader<false, true> pb;
+		pb.p = a.p; pb.ldr = 1; pb.ldk = a.sw; pb.R = g.C; pb.K = (int)P;
+		return gemm_run_h("conv_wgrad_h_pointwise", la, pb, out, g.K, g.C, (int)P, 1, 0L, 0L, 0L, 0L, 0, flags, ctx);
+	}
 	Im2colNC<true, false> lb;
 	lb.p = a.p; lb.s_n = a.sn; lb.s_h = (int)a.sh; lb.s_w = (int)a.sw; lb.H = g.H; lb.W = g.W; lb.OW = g.OW; lb.OHW = g.OH * g.OW;
 	lb.C = g.Cg; lb.KWC = g.kw * g.Cg; lb.NN = NN; lb.K = (int)P; lb.sy = g.sy; lb.sx = g.sx; lb.py = g.pby; lb.px = g.pbx; lb.dy = g.dy; lb.dx = g.dx;

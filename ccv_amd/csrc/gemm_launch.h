@@ -178,7 +178,9 @@ static int gemm_run_bf16x3_tile(const char* name, const BufMatLoader<AKC>& la, c
 		epi.c = out.c; epi.ldm = out.ldm; epi.ldn = out.ldn; epi.bias = out.bias; epi.alpha = out.alpha; epi.accumulate = out.accumulate; epi.M = M; epi.N = N; epi.bias_ldm = out.bias_ldm; epi.bias_ldn = out.bias_ldn;
 		epi.vec = epi_vec_ok(out.c, sizeof(float), out.ldm, out.ldn, N, zcount, c_z);
 		ProfScope prof(prof_name, flops, 0, M, N, K, zcount, 1, stream);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_bf16x3_kernel<AKC, BKC, EpiStore, TM, TN, WM, WN>), dim3((unsigned)tiles, 1, (unsigned)zcount), dim3(NT), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, 1, a_z, b_z, c_z, bias_z);
+		int sarg;
+		const dim3 grid = gemm_batch_grid(tiles, zcount, &sarg);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(mfma_gemm_bf16x3_kernel<AKC, BKC, EpiStore, TM, TN, WM, WN>), grid, dim3(NT), 0, stream, la, lb, epi, tiles_m, tiles_n, K, K, sarg, a_z, b_z, c_z, bias_z);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -201,29 +203,42 @@ static int gemm_run_bf16x3_tile(const char* name, const BufMatLoader<AKC>& la, c
 // tile fills the chip -- at 128 x 128 it merely equals the fp32 instructions (0.95 - 1.04 x) --, for two k-contiguous operands (the Winograd-domain forward /
 // data-gradient products 1.10 - 1.19 x, the fc layers' forward products 1.10 - 1.14 x) and for two row-contiguous ones with both outputs >= 512 (the filter
 // gradients of the 512-channel layers 1.05 x; at 256 x 256 / 512 x 256 outputs the split form loses 3 - 6 %).
+// 0: the fp32 matrix instructions; 128 / 256: the split form with that block tile.
 template <bool AKC, bool BKC>
-static inline bool gemm_bf16x3_wanted(const int M, const int N, const int K, const int zcount, const int splits, const int flags)
+static inline int gemm_bf16x3_tile(const int M, const int N, const int K, const int zcount, const int splits, const int flags)
 {
 	const long mode = tune(TUNE_GEMM_BF16X3);
-	if (mode <= 0 || K % 16) return false;
-	if (mode >= 2) return true;
-	if (AKC != BKC || K < 128 || M < 256 || N < 256) return false;
-	if (!AKC && (M < 512 || N < 512)) return false;
-	long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+	if (mode <= 0 || K % 16) return 0;
+	const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
 	int s = splits;
-	if (s <= 0) s = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(tiles, K) : 1;
+	if (s <= 0) s = (zcount == 1 && !(flags & CCV_NNC_ZERO_MEMORY_ALLOC)) ? gemm_auto_splits(t256, K) : 1;
+	if (s < 1) s = 1;
+	const long cus = (long)device_cu_count();
+	if (mode == 3) return 128;
+	if (mode == 4) return 256;
+	if (mode == 2) return (M >= 256 && N >= 256 && t256 * zcount * s >= cus) ? 256 : 128;
+	// Batched products without split-K whose B operand is row-contiguous -- the 1 x 1 convolutions on NCHW tensors, one product per image (forward: w . planes,
+	// data gradient: w^T . planes) -- with 256 or more of K and 128 or more output rows: 1.09 - 1.39 x on ResNet-50's layers at batch 256 (1024 -> 512 at 14^2
+	// 0.519 -> 0.381 ms, 256 -> 1024 data gradient 0.259 -> 0.191; with K = 64 / 128 or 64 rows the split form loses: profiles/r06_v14_conv1x1_f32_bf16x3.txt);
+	// the 128 x 128 tile (N = 196 / 784 pixels: 0.371 against 0.407 ms for 512 -> 256 at 28^2).
+	if (!BKC && zcount >= 8 && splits == 1) return (K >= 256 && M >= 128 && N >= 128) ? 128 : 0;
+	// One product of a k-contiguous and a row-contiguous operand (the data gradient of a 1 x 1 convolution over NHWC images, conv_pointwise in cmd_conv.cpp):
+	// the larger tile that fills the chip
+	if (AKC != BKC) {
+		if (K < 256 || M < 256 || N < 256 || s > 1) return 0;
+		return t256 * zcount >= cus ? 256 : (t128 * zcount >= cus ? 128 : 0);
+	}
+	if (K < 128 || M < 256 || N < 256) return 0;
+	if (!AKC && (M < 512 || N < 512)) return 0;
 	// a row-contiguous pair with a short reduction is its epilogue (256 KB per workgroup): fc7's filter gradient, 4096 x 4096 x 256, ran 0.242 ms split against
 	// 0.189 ms on the fp32 instructions (profiles/r06_v2_contraction_records.txt); the Winograd filter gradients keep >= 512 of K per slice
-	if (!AKC && K / (s > 1 ? s : 1) < 512) return false;
-	return tiles * zcount * (s > 1 ? s : 1) >= (long)device_cu_count();
+	if (!AKC && K / s < 512) return 0;
+	return t256 * zcount * s >= cus ? 256 : 0;
 }
 template <bool AKC, bool BKC>
-static int gemm_run_bf16x3(const char* name, const BufMatLoader<AKC>& la, const BufMatLoader<BKC>& lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, const int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
+static int gemm_run_bf16x3(const int tile, const char* name, const BufMatLoader<AKC>& la, const BufMatLoader<BKC>& lb, const GemmOut out, const int M, const int N, const int K, const int zcount, const long a_z, const long b_z, const long c_z, const long bias_z, const int splits, const int flags, ccv_nnc_stream_context_t* const ctx)
 {
-	const long mode = tune(TUNE_GEMM_BF16X3);
-	const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256) * zcount * (splits > 1 ? splits : 1);
-	const bool big = mode == 4 || mode == 1 || (mode != 3 && M >= 256 && N >= 256 && big_tiles >= (long)device_cu_count());
-	if (big) return gemm_run_bf16x3_tile<AKC, BKC, 4, 2, 2, 4>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+	if (tile == 256) return gemm_run_bf16x3_tile<AKC, BKC, 4, 2, 2, 4>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 	return gemm_run_bf16x3_tile<AKC, BKC, 2, 2, 2, 2>(name, la, lb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 }
 
@@ -246,7 +261,8 @@ static int gemm_run(const char* name, LA la, LB lb, const GemmOut out, const int
 			ba.p = la.p; ba.zoff = 0; ba.ldr = la.ldr; ba.ldk = la.ldk; ba.R = la.R; ba.K = la.K;
 			bb.p = lb.p; bb.zoff = 0; bb.ldr = lb.ldr; bb.ldk = lb.ldk; bb.R = lb.R; bb.K = lb.K;
 			typedef BufMatLoader<LA::KCONTIG> BA; typedef BufMatLoader<LB::KCONTIG> BB;
-			if (!g_force_tile && gemm_bf16x3_wanted<LA::KCONTIG, LB::KCONTIG>(M, N, K, zcount, splits, flags)) return gemm_run_bf16x3<LA::KCONTIG, LB::KCONTIG>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
+			const int split_tile = g_force_tile ? 0 : gemm_bf16x3_tile<LA::KCONTIG, LB::KCONTIG>(M, N, K, zcount, splits, flags);
+			if (split_tile) return gemm_run_bf16x3<LA::KCONTIG, LB::KCONTIG>(split_tile, name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx);
 			if (wm == 2 && wn == 2) return gemm_run_tile<BA, BB, 2, 2>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 			if (wm == 2) return gemm_run_tile<BA, BB, 2, 1>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);
 			if (wn == 1) return gemm_run_tile<BA, BB, 1, 1>(name, ba, bb, out, M, N, K, zcount, a_z, b_z, c_z, bias_z, splits, flags, ctx, ko);

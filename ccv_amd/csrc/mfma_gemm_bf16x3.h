@@ -118,8 +118,10 @@ __global__ void __launch_bounds__(64 * WM * WN) mfma_gemm_bf16x3_kernel(BufMatLo
 	const int li = lane & 31, lh = lane >> 5;
 	const int nwg = gridDim.x;
 	const int bid = blockIdx.x;
-	int tile, slice = 0;
-	{
+	int tile, slice = 0, zi = (int)blockIdx.z;
+	if (splits < 0) {
+		if (!gemm_batch_xcd_map(bid, tiles_m * tiles_n, -splits, &tile, &zi)) return;
+	} else {
 		const int xcd = bid & 7, idx = bid >> 3;
 		if (splits > 1) {
 			const int tiles = tiles_m * tiles_n;
@@ -134,9 +136,9 @@ __global__ void __launch_bounds__(64 * WM * WN) mfma_gemm_bf16x3_kernel(BufMatLo
 	const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 	(void)tiles_m;
 	const int m0 = tile_m * BM, n0 = tile_n * BN;
-	la.p += (long)blockIdx.z * a_zoff;
-	lb.p += (long)blockIdx.z * b_zoff;
-	epi.c += (long)blockIdx.z * c_zoff;
+	la.p += (long)zi * a_zoff;
+	lb.p += (long)zi * b_zoff;
+	epi.c += (long)zi * c_zoff;
 	if (splits > 1) epi.c += (long)slice * M_N_slab(epi);
 	const int k_begin = slice * k_per_split;
 	const int k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(64 * WM * WN) mfma_gemm_bf16x3_kernel(BufMatLo
 		if (kt < nk) kstep(GroupId<0>(), kt);
 	}
 	// D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-	if (epi.bias) epi.bias += (long)blockIdx.z * bias_zoff;
+	if (epi.bias) epi.bias += (long)zi * bias_zoff;
 	if (epi.vec) { // through LDS, one tile row of every wave per pass (mfma_gemm.h: "epilogues", epi_flush_rows)
 		constexpr int PITCH = BN + 8;
 		static_assert(32 * WM * PITCH * 2 <= 2 * (A_HALVES + B_HALVES), "the staged slice (fp32) fits the operand buffers");

@@ -205,6 +205,7 @@ CONV_H = [
     (1, 12, 11, 32, 20, 3, 3, (1, 1), (1, 1), 1, True),     # chunk-major K order (C % 32 == 0)
     (2, 11, 9, 12, 8, 5, 5, (2, 2), (2, 2), 1, True),       # stride 2: strided dgrad loader
     (2, 7, 7, 16, 24, 1, 1, (1, 1), (0, 0), 2, True),       # 1x1, two groups
+    (8, 7, 7, 96, 160, 1, 1, (1, 1), (0, 0), 1, True),      # 1x1, one group: two plain matrices (conv_pointwise), 392 pixels -- ResNet-50's 7 x 7 maps
     (3, 16, 16, 64, 64, 3, 3, (1, 1), (1, 1), 1, True),     # several K-steps, 64 x 64 tiles
     (2, 9, 9, 3, 8, 3, 3, (1, 1), (1, 1), 1, False),        # 3 input channels: fp32 kernels on fp32 images
 ]

@@ -22,6 +22,7 @@ CONV_CASES = [
     (2, 9, 10, 8, 16, 3, 3, (1, 1), (1, 1), 1, None, True),      # vectorised gather, ragged M
     (1, 12, 11, 3, 5, 5, 5, (2, 2), (2, 2), 1, None, True),      # C=3 scalar gather, stride 2, ragged K
     (2, 7, 7, 12, 8, 1, 1, (1, 1), (0, 0), 1, None, False),      # 1x1, no bias
+    (8, 7, 7, 256, 264, 1, 1, (1, 1), (0, 0), 1, None, True),    # 1x1 as two plain matrices (conv_pointwise), forward on the bf16 pipe's exact split (K >= 128, 256 x 256 outputs)
     (1, 15, 13, 4, 6, 7, 7, (2, 2), (3, 3), 1, None, True),      # 7x7 s2 (ResNet stem shape class)
     (2, 8, 8, 8, 8, 3, 3, (1, 1), (1, 1), 2, None, True),        # groups
     (1, 11, 11, 4, 4, 3, 3, (1, 1), (2, 2), 1, (2, 2), True),    # dilation
@@ -668,8 +669,8 @@ def test_batch_norm_with_one_dimensional_statistics(backend, ref_lib, fmt, shape
         np.testing.assert_allclose(a.reshape(-1), b.reshape(-1), rtol=2e-4, atol=2e-5, err_msg=what)
 
 
-@pytest.mark.parametrize("case", [(3, 8, 6, 6, 12, True), (2, 16, 4, 8, 8, False), (2, 64, 14, 14, 128, True), (16, 64, 14, 14, 160, True), (68, 8, 6, 6, 12, False)],
-                         ids=["8to12", "16to8", "64to128", "64to160-batch16-one-image-per-xcd", "8to12-batch68-ragged-last-round"])
+@pytest.mark.parametrize("case", [(3, 8, 6, 6, 12, True), (2, 16, 4, 8, 8, False), (2, 64, 14, 14, 128, True), (16, 64, 14, 14, 160, True), (68, 8, 6, 6, 12, False), (8, 256, 14, 14, 128, True)],
+                         ids=["8to12", "16to8", "64to128", "64to160-batch16-one-image-per-xcd", "8to12-batch68-ragged-last-round", "256to128-batch8-fp32-on-the-bf16-pipe"])
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_conv_1x1_on_nchw_tensors_without_layout_passes(backend, ref_lib, case, dtype):
     """ResNet's bottleneck convolutions as the reference's trainer issues them (NCHW, 1x1, stride 1: bin/nnc/imagenet.c): forward,
