@@ -13,6 +13,8 @@ using namespace nnc;
 
 namespace {
 
+typedef _Float16 half_t;
+
 enum { LABEL_F32_INDEX = 0, LABEL_I32_INDEX = 1, LABEL_DENSE = 2, LABEL_NONE = 3 };
 
 __device__ __forceinline__ float wave_max(float v)
@@ -34,53 +36,64 @@ __device__ __forceinline__ float wave_sum_f(float v)
 	return v;
 }
 
-// 4 waves per workgroup, one row per wave.
-__global__ void __launch_bounds__(256) softmax_ce_forw_kernel(const float* a, const void* label, const int label_kind, float* loss, float* d, const int rows, const int count, const float trim0, const float trim1)
+// 4 waves per workgroup, one row per wave.  T = float, or half_t: the logits and the softmax stay CCV_16F in their own memory (loads / stores of halves, the arithmetic
+// below in fp32 / double as ever, ONE rounding per stored value -- bit for bit what the row computed on fp32 images of the two tensors and converted down: half_stage.cpp
+// g_native_half); the loss and the labels are fp32 (or int32) either way.
+template <class T>
+__global__ void __launch_bounds__(256) softmax_ce_forw_kernel(const T* a, const void* label, const int label_kind, float* loss, T* d, const int rows, const int count, const float trim0, const float trim1)
 {
 	const int lane = threadIdx.x & 63;
 	const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (row >= rows) return; // whole wave exits together
-	const float* ap = a + (size_t)row * count;
-	float* dp = d + (size_t)row * count;
+	const T* ap = a + (size_t)row * count;
+	T* dp = d + (size_t)row * count;
 	float m = -3.402823466e+38f;
-	for (int j = lane; j < count; j += 64) { const float v = ap[j]; m = v > m ? v : m; }
+	for (int j = lane; j < count; j += 64) { const float v = (float)ap[j]; m = v > m ? v : m; }
 	m = wave_max(m);
 	if (loss) {
 		float p = 0.f;
 		if (label_kind == LABEL_DENSE) {
 			const float* bp = (const float*)label + (size_t)row * count;
-			for (int j = lane; j < count; j += 64) p += bp[j] * (m - ap[j]);
+			for (int j = lane; j < count; j += 64) p += bp[j] * (m - (float)ap[j]);
 			p = wave_sum_f(p);
 		} else {
 			const int lb = label_kind == LABEL_F32_INDEX ? (int)(((const float*)label)[row] + 0.5f) : ((const int*)label)[row];
 			// a label outside [0, count) is an assert in the reference (softmax_crossentropy_cpu_ref.c); here it must not become a read outside
 			// the row: the loss of that row is NaN, which no caller can mistake for a result
-			if (trim0 == 0.f && trim1 == 1.f) p = (unsigned)lb < (unsigned)count ? m - ap[lb] : __builtin_nanf("");
+			if (trim0 == 0.f && trim1 == 1.f) p = (unsigned)lb < (unsigned)count ? m - (float)ap[lb] : __builtin_nanf("");
 			else {
-				for (int j = lane; j < count; j += 64) p += (j == lb ? trim1 : trim0) * (m - ap[j]);
+				for (int j = lane; j < count; j += 64) p += (j == lb ? trim1 : trim0) * (m - (float)ap[j]);
 				p = wave_sum_f(p);
 			}
 		}
 		if (lane == 0) loss[row] = p;
 	}
 	double s = 0;
-	for (int j = lane; j < count; j += 64) { const float e = expf(ap[j] - m); dp[j] = e; s += (double)e; }
-	s = wave_sum_d(s);
-	const double inv = 1.0 / s;
-	for (int j = lane; j < count; j += 64) dp[j] = (float)((double)dp[j] * inv);
+	if (sizeof(T) == sizeof(float)) {
+		for (int j = lane; j < count; j += 64) { const float e = expf((float)ap[j] - m); dp[j] = (T)e; s += (double)e; }
+		s = wave_sum_d(s);
+		const double inv = 1.0 / s;
+		for (int j = lane; j < count; j += 64) dp[j] = (T)(float)((double)(float)dp[j] * inv);
+	} else { // (a half cannot hold the unnormalised exponential between the passes: it is computed again -- the same value)
+		for (int j = lane; j < count; j += 64) s += (double)expf((float)ap[j] - m);
+		s = wave_sum_d(s);
+		const double inv = 1.0 / s;
+		for (int j = lane; j < count; j += 64) dp[j] = (T)(float)((double)expf((float)ap[j] - m) * inv);
+	}
 }
 
-__global__ void __launch_bounds__(256) softmax_ce_back_kernel(const float* g, const void* label, const int label_kind, const float* d, float* h, const int rows, const int count, const float trim0, const float trim1)
+template <class T>
+__global__ void __launch_bounds__(256) softmax_ce_back_kernel(const float* g, const void* label, const int label_kind, const T* d, T* h, const int rows, const int count, const float trim0, const float trim1)
 {
 	const int lane = threadIdx.x & 63;
 	const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (row >= rows) return;
-	const float* dp = d + (size_t)row * count;
-	float* hp = h + (size_t)row * count;
+	const T* dp = d + (size_t)row * count;
+	T* hp = h + (size_t)row * count;
 	if (label_kind == LABEL_DENSE) {
 		const float* bp = (const float*)label + (size_t)row * count;
-		if (g) { const float gv = g[row]; for (int j = lane; j < count; j += 64) hp[j] = gv * (dp[j] - bp[j]); }
-		else for (int j = lane; j < count; j += 64) hp[j] = dp[j] - bp[j];
+		if (g) { const float gv = g[row]; for (int j = lane; j < count; j += 64) hp[j] = (T)(gv * ((float)dp[j] - bp[j])); }
+		else for (int j = lane; j < count; j += 64) hp[j] = (T)((float)dp[j] - bp[j]);
 		return;
 	}
 	const int lb = label_kind == LABEL_F32_INDEX ? (int)(((const float*)label)[row] + 0.5f) : ((const int*)label)[row];
@@ -89,16 +102,16 @@ __global__ void __launch_bounds__(256) softmax_ce_back_kernel(const float* g, co
 		const float gv = g[row];
 		for (int j = lane; j < count; j += 64) {
 			float v;
-			if (plain) { v = gv * dp[j]; if (j == lb) v -= gv; } // hp[j] = g*d[j]; hp[label] -= g  (:213-215)
-			else v = gv * (dp[j] - (j == lb ? trim1 : trim0));
-			hp[j] = v;
+			if (plain) { v = gv * (float)dp[j]; if (j == lb) v -= gv; } // hp[j] = g*d[j]; hp[label] -= g  (:213-215)
+			else v = gv * ((float)dp[j] - (j == lb ? trim1 : trim0));
+			hp[j] = (T)v;
 		}
 	} else {
 		for (int j = lane; j < count; j += 64) {
-			float v = dp[j];
+			float v = (float)dp[j];
 			if (plain) { if (j == lb) v -= 1.f; }
 			else v -= (j == lb ? trim1 : trim0);
-			hp[j] = v;
+			hp[j] = (T)v;
 		}
 	}
 }
@@ -137,7 +150,10 @@ static int _softmax_ce_forw(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, 
 		if (kind < 0) return CCV_NNC_EXEC_INVALID;
 	}
 	if (batch == 0 || count == 0) return CCV_NNC_EXEC_SUCCESS;
-	hipLaunchKernelGGL(softmax_ce_forw_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream_of(stream_context), (const float*)a->data.f32, (const void*)(b ? b->data.ptr : 0), kind, c ? c->data.f32 : (float*)0, d->data.f32, batch, count, cmd.info.label_smoothing.trim0, cmd.info.label_smoothing.trim1);
+	const bool half = CCV_GET_DATA_TYPE(a->info.datatype) == CCV_16F; // (half_stage.cpp hands logits and softmax over as they are when BOTH are dense CCV_16F tensors)
+	if (half != (CCV_GET_DATA_TYPE(d->info.datatype) == CCV_16F) || (c && CCV_GET_DATA_TYPE(c->info.datatype) != CCV_32F)) return CCV_NNC_EXEC_INVALID;
+	if (half) hipLaunchKernelGGL(HIP_KERNEL_NAME(softmax_ce_forw_kernel<half_t>), dim3((batch + 3) / 4), dim3(256), 0, stream_of(stream_context), (const half_t*)a->data.u8, (const void*)(b ? b->data.ptr : 0), kind, c ? c->data.f32 : (float*)0, (half_t*)d->data.u8, batch, count, cmd.info.label_smoothing.trim0, cmd.info.label_smoothing.trim1);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(softmax_ce_forw_kernel<float>), dim3((batch + 3) / 4), dim3(256), 0, stream_of(stream_context), (const float*)a->data.f32, (const void*)(b ? b->data.ptr : 0), kind, c ? c->data.f32 : (float*)0, d->data.f32, batch, count, cmd.info.label_smoothing.trim0, cmd.info.label_smoothing.trim1);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
@@ -158,7 +174,10 @@ static int _softmax_ce_back(const ccv_nnc_cmd_t cmd, const ccv_nnc_hint_t hint, 
 	const int kind = label_kind_of(b, batch, count);
 	if (kind < 0) return CCV_NNC_EXEC_INVALID;
 	if (batch == 0 || count == 0) return CCV_NNC_EXEC_SUCCESS;
-	hipLaunchKernelGGL(softmax_ce_back_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream_of(stream_context), g ? (const float*)g->data.f32 : (const float*)0, (const void*)b->data.ptr, kind, (const float*)d->data.f32, h->data.f32, batch, count, cmd.info.label_smoothing.trim0, cmd.info.label_smoothing.trim1);
+	const bool half = CCV_GET_DATA_TYPE(d->info.datatype) == CCV_16F;
+	if (half != (CCV_GET_DATA_TYPE(h->info.datatype) == CCV_16F) || (g && CCV_GET_DATA_TYPE(g->info.datatype) != CCV_32F)) return CCV_NNC_EXEC_INVALID;
+	if (half) hipLaunchKernelGGL(HIP_KERNEL_NAME(softmax_ce_back_kernel<half_t>), dim3((batch + 3) / 4), dim3(256), 0, stream_of(stream_context), g ? (const float*)g->data.f32 : (const float*)0, (const void*)b->data.ptr, kind, (const half_t*)d->data.u8, (half_t*)h->data.u8, batch, count, cmd.info.label_smoothing.trim0, cmd.info.label_smoothing.trim1);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(softmax_ce_back_kernel<float>), dim3((batch + 3) / 4), dim3(256), 0, stream_of(stream_context), g ? (const float*)g->data.f32 : (const float*)0, (const void*)b->data.ptr, kind, (const float*)d->data.f32, h->data.f32, batch, count, cmd.info.label_smoothing.trim0, cmd.info.label_smoothing.trim1);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }

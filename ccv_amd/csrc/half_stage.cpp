@@ -261,6 +261,8 @@ static const native_half_t g_native_half[] = {
 	{ CCV_NNC_AVERAGE_POOL_FORWARD, 1u << 0, 1u << 0 },
 	{ CCV_NNC_AVERAGE_POOL_BACKWARD, 1u << 0, 1u << 0 },
 	{ CCV_NNC_SGD_FORWARD, (1u << 0) | (1u << 1) | (1u << 2), (1u << 0) | (1u << 1) }, // g, a, m -> b, n
+	{ CCV_NNC_SOFTMAX_CROSSENTROPY_FORWARD, 1u << 0, 1u << 1 },           // logits -> softmax (labels and the loss: fp32 images, a value per row)
+	{ CCV_NNC_SOFTMAX_CROSSENTROPY_BACKWARD, 1u << 5, 1u << 0 },          // softmax -> h
 };
 static const native_half_t* native_half_row(const uint32_t cmd, const int flags, ccv_nnc_tensor_t* const* const inputs, const int input_size, ccv_nnc_tensor_t* const* const outputs, const int output_size)
 {

@@ -463,3 +463,40 @@ def test_half_layout_transposes_in_16_byte_accesses(backend, shape):
     a2 = L.tensor(nnc.tensor_param(nnc.GPU_MEMORY, nnc.NCHW, nnc.CCV_16F, (n, c, h, w), 0), np.zeros((n, c, h, w), np.float16))
     assert L.cmd_exec(nnc.CMD_FORMAT_TRANSFORM_FORWARD(), nnc.NO_HINT, 0, [b], [a2]) == 0
     assert np.array_equal(a2.numpy(), x)
+
+
+@pytest.mark.parametrize("label_kind", ["f32", "i32", "dense", "half"])
+@pytest.mark.parametrize("trim", [(0.0, 1.0), (0.1, 0.9)])
+def test_native_half_softmax_crossentropy(backend, ref_lib, label_kind, trim):
+    """Round 6: SOFTMAX_CROSSENTROPY forward / backward keep the logits, the softmax and the gradient as CCV_16F in their own memory (cmd_loss.cpp templated on the
+    element type; g_native_half) -- the last rows of the trainers' steps that went through fp32 images.  The arithmetic is the fp32 kernel's with ONE rounding per
+    stored value, so the result EQUALS the reference's fp32 result on the same half inputs rounded to half; the loss (fp32 per row, or half when the host's loss
+    tensor is half) and the labels keep their small images."""
+    rng = np.random.default_rng(31)
+    n, c = 7, 45
+    a = hrnd(rng, n, c, scale=3)
+    idx = rng.integers(0, c, n)
+    if label_kind == "f32":
+        label = idx.astype(F)
+    elif label_kind == "i32":
+        label = idx.astype(np.int32)
+    elif label_kind == "half":
+        label = idx.astype(H)  # the half trainers' label tensors (exact up to 2048 classes)
+    else:
+        label = rng.random((n, c), dtype=F)
+        label /= label.sum(1, keepdims=True)
+    s0, n0 = _half_counts(backend)
+    got, want = _pair(backend, ref_lib, nnc.CMD_SOFTMAX_CROSSENTROPY_FORWARD(*trim), nnc.NO_HINT, 0, [a, label], [np.zeros(n, F), np.zeros((n, c), H)])
+    s1, n1 = _half_counts(backend)
+    assert n1 == n0 + 2 and s1 - s0 == (1 if label_kind == "half" else 0)  # logits and softmax as halves; only a half label tensor gets an image
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-5)
+    assert got[1].dtype == H and np.array_equal(got[1], want[1].astype(H))
+    g = ((rng.random(n, dtype=F) - 0.5) * 2).astype(F)
+    d = got[1]
+    got, want = _pair(backend, ref_lib, nnc.CMD_SOFTMAX_CROSSENTROPY_BACKWARD(*trim), nnc.NO_HINT, 0, [g, None, None, label, None, d], [np.zeros((n, c), H)])
+    assert _half_counts(backend)[1] == n1 + 2
+    assert got[0].dtype == H
+    # (the reference's label-smoothing backward multiplies in another order: one half ulp at most)
+    np.testing.assert_allclose(got[0].astype(F), want[0].astype(H).astype(F), rtol=1e-3, atol=1e-6)
+    if trim == (0.0, 1.0):
+        assert np.array_equal(got[0], want[0].astype(H))
