@@ -146,7 +146,9 @@ __global__ void __launch_bounds__(256) transpose_convert_vec4_kernel(const TI* _
 // isa.h tr_read4: a 16-lane group reads a [4 rows][16 columns] block, lane i receives column i): two reads give a lane eight consecutive input rows of one
 // column = 16 contiguous bytes of an output row; a wave writes 16 output rows x 64 contiguous bytes per store.  R, C multiples of 8, 16-byte aligned tensors.
 constexpr int TH_PITCH = TT + 32; // halves per tile row: 192 bytes = 48 dwords (the four rows of a transpose-read block land 16 banks apart: mfma_gemm_f16.h gemm16_npitch)
-__global__ void __launch_bounds__(256) transpose_half8_kernel(const nnc::half_t* __restrict__ in, nnc::half_t* __restrict__ out, const int R, const int C)
+// SUM: every input row's sum over the tile's columns goes to row_partial[(batch entry * tile columns + tile column) * R + row] (fp32; common.h transpose_half_rowsum)
+template <bool SUM>
+__global__ void __launch_bounds__(256) transpose_half8_kernel(const nnc::half_t* __restrict__ in, nnc::half_t* __restrict__ out, const int R, const int C, float* __restrict__ row_partial)
 {
 	using namespace nnc;
 	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -161,6 +163,15 @@ __global__ void __launch_bounds__(256) transpose_half8_kernel(const nnc::half_t*
 		u4 v = { 0, 0, 0, 0 };
 		if (r0 + r < R && c0 + cc < C) v = *(const u4*)(in + base + (size_t)(r0 + r) * C + c0 + cc);
 		*(u4*)(tile + r * TH_PITCH + cc) = v;
+		if (SUM) { // the eight lanes id & 7 hold the 64 columns of row r (an out-of-range chunk is zeros)
+			typedef half_t h8 __attribute__((ext_vector_type(8)));
+			const h8 hv = __builtin_bit_cast(h8, v);
+			float sum = (((float)hv[0] + (float)hv[1]) + ((float)hv[2] + (float)hv[3])) + (((float)hv[4] + (float)hv[5]) + ((float)hv[6] + (float)hv[7]));
+			sum += __shfl_xor(sum, 1, 64);
+			sum += __shfl_xor(sum, 2, 64);
+			sum += __shfl_xor(sum, 4, 64);
+			if ((id & 7) == 0 && r0 + r < R) row_partial[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * R + r0 + r] = sum;
+		}
 	}
 	__syncthreads();
 	const int lane = t & 63, w = t >> 6, g = lane >> 4, i = lane & 15;
@@ -270,7 +281,7 @@ static int launch_transpose_half(const void* in, void* out, int batch, int R, in
 {
 	static const int wide = !(getenv("NNC_MI355X_TRANSPOSE_HALF8") && *getenv("NNC_MI355X_TRANSPOSE_HALF8") == '0');
 	if (wide && batch > 0 && R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
-		hipLaunchKernelGGL(transpose_half8_kernel, dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, (half_t*)out, R, C);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_half8_kernel<false>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, (half_t*)out, R, C, (float*)0);
 		HIP_ENFORCE(hipGetLastError());
 		return CCV_NNC_EXEC_SUCCESS;
 	}
@@ -340,6 +351,14 @@ int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_str
 // Dense weight layout change [K][C][kh][kw] (NCHW-format weights) -> [K][kh][kw][C] (the layout the kernels read).
 // in[batch][R][C] -> out[batch][C][R], halves in / floats out and the reverse
 int transpose_half(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx) { return launch_transpose_half(in, out, batch, R, C, ctx); }
+int transpose_half_rowsum(const void* in, void* out, int batch, int R, int C, float* row_partial, ccv_nnc_stream_context_t* ctx)
+{
+	static_assert(TT == 64, "transpose_half_rowsum_slices (common.h) counts 64-column tiles");
+	if (!(batch > 0 && R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) || !row_partial) return CCV_NNC_EXEC_NO_KERNEL;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_half8_kernel<true>), dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, stream_of(ctx), (const half_t*)in, (half_t*)out, R, C, row_partial);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
 int transpose_half_to_float(const void* in, float* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx)
 {
 	if (batch <= 0 || R <= 0 || C <= 0) return CCV_NNC_EXEC_SUCCESS;

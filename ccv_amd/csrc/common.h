@@ -192,6 +192,11 @@ int format_transform(const ccv_nnc_tensor_t* a, ccv_nnc_tensor_t* b, ccv_nnc_str
 int transpose_half_to_float(const void* in, float* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx); // in[batch][R][C] halves -> out[batch][C][R] floats
 int transpose_float_to_half(const float* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx);
 int transpose_half(const void* in, void* out, int batch, int R, int C, ccv_nnc_stream_context_t* ctx); // in[batch][R][C] halves -> out[batch][C][R] halves
+// The same pass that also SUMS every input row (fp32) over its tile's 64 columns: row_partial[(b * ceil(C / 64) + tile) * R + r].  A convolution's backward pass re-lays the NCHW output
+// gradient anyway; with the sums taken on the way, the bias gradient is a fold of these partials (colsum_partials_f16) instead of another pass over the gradient.
+// CCV_NNC_EXEC_NO_KERNEL: the tensor is not in whole 16-byte chunks -- nothing was launched, the caller takes the two separate passes.
+int transpose_half_rowsum(const void* in, void* out, int batch, int R, int C, float* row_partial, ccv_nnc_stream_context_t* ctx);
+inline long transpose_half_rowsum_slices(const int batch, const int C) { return (long)batch * ((C + 63) / 64); }
 int relu_inplace(ccv_nnc_tensor_t* t, ccv_nnc_stream_context_t* ctx); // t = max(t, 0), dense CCV_32F / CCV_16F (cmd_ew.cpp)
 int relu_back_inplace(ccv_nnc_tensor_t* h, const ccv_nnc_tensor_t* b, ccv_nnc_stream_context_t* ctx); // h = b > 0 ? h : 0, dense, same type and count
 int weights_nchw_to_nhwc(const float* w, float* out, int K, int C, int khw, ccv_nnc_stream_context_t* ctx);
@@ -297,6 +302,7 @@ int half_to_float(const void* in, float* out, size_t n, ccv_nnc_stream_context_t
 int float_to_half(const float* in, void* out, size_t n, ccv_nnc_stream_context_t* ctx);
 int chan_sum_planes_f16(const void* x, long outer, int C, long inner, void* out, int accumulate, ccv_nnc_stream_context_t* ctx);
 int colsum_f16(const void* x, long rows, int cols, long ld, void* out, int accumulate, ccv_nnc_stream_context_t* ctx); // halves: out[c] (+)= sum_r x[r * ld + c], fp32 sums
+int colsum_partials_f16(const float* partial, long slices, int cols, void* out, int accumulate, ccv_nnc_stream_context_t* ctx); // out[c] (+)= sum_s partial[s * cols + c], slices in a fixed order, rounded to half once; `partial` has room for (slices + 256) * cols floats (a second, grouped level)
 
 // Palettized inputs (palette.cpp): rows whose reference counterparts list CCV_QX (GEMM, convolution, transposed convolution, attention's head projection) run
 // on dense images of their CCV_QX inputs.  NNC_DEPALETTIZED(registry, EXEC) adds CCV_QX to the row and routes it through the wrapper (a plain call of EXEC

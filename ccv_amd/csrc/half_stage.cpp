@@ -140,6 +140,43 @@ int colsum_f16(const void* xv, long rows, int cols, long ld, void* outv, int acc
 	return CCV_NNC_EXEC_SUCCESS;
 }
 
+// Many slices (one per image and 64-pixel tile: thousands) are first folded in groups -- a workgroup per (64 columns, group of slices), four slices in flight per
+// column, coalesced rows -- so that the final kernel's per-column chains stay a few loads long.  Fixed order throughout: deterministic.
+static __global__ void __launch_bounds__(256) partials_group_kernel(const float* __restrict__ in, const long slices, const int cols, const int group, float* __restrict__ out)
+{
+	__shared__ float red[4][64];
+	const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+	const int c = blockIdx.x * 64 + cl;
+	const long s0 = (long)blockIdx.y * group, s1 = s0 + group < slices ? s0 + group : slices;
+	float a = 0.f, b = 0.f;
+	if (c < cols) {
+		long i = s0 + ph;
+		for (; i + 4 < s1; i += 8) { a += in[i * cols + c]; b += in[(i + 4) * cols + c]; }
+		if (i < s1) a += in[i * cols + c];
+	}
+	red[ph][cl] = a + b;
+	__syncthreads();
+	if (ph == 0 && c < cols) out[(long)blockIdx.y * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+int colsum_partials_f16(const float* partial, long slices, const int cols, void* out, const int accumulate, ccv_nnc_stream_context_t* ctx)
+{
+	if (cols <= 0) return CCV_NNC_EXEC_SUCCESS;
+	if (slices > 0x7fffffffL) return CCV_NNC_EXEC_INVALID;
+	hipStream_t stream = stream_of(ctx);
+	if (slices > 512) { // (the grouped sums go to a second area right behind the partials)
+		const int group = (int)((slices + 255) / 256 < 16 ? 16 : (slices + 255) / 256);
+		const long groups = (slices + group - 1) / group;
+		float* const folded = (float*)partial + (size_t)slices * cols;
+		hipLaunchKernelGGL(partials_group_kernel, dim3((cols + 63) / 64, (unsigned)groups), dim3(256), 0, stream, partial, slices, cols, group, folded);
+		HIP_ENFORCE(hipGetLastError());
+		partial = folded;
+		slices = groups;
+	}
+	hipLaunchKernelGGL(colsum_h_final_kernel, dim3((cols + FOLD_CH - 1) / FOLD_CH), dim3(256), 0, stream, partial, (int)slices, cols, (half_t*)out, accumulate);
+	HIP_ENFORCE(hipGetLastError());
+	return CCV_NNC_EXEC_SUCCESS;
+}
+
 // out[c] (+)= sum over (o, i) of x[(o * C + c) * inner + i] for halves (bias gradient of an NCHW convolution): one workgroup per
 // plane, fp32 partials in the workspace, folded per channel in a fixed order.
 static __global__ void __launch_bounds__(256) plane_sum_h_kernel(const half_t* __restrict__ x, const long planes, const long inner, float* __restrict__ partial)
