@@ -225,14 +225,19 @@ static inline int gemm_bf16x3_tile(const int M, const int N, const int K, const 
 	// One product of a k-contiguous and a row-contiguous operand (the data gradient of a 1 x 1 convolution over NHWC images, conv_pointwise in cmd_conv.cpp):
 	// the larger tile that fills the chip
 	if (AKC != BKC) {
-		if (K < 256 || M < 256 || N < 256 || s > 1) return 0;
+		if (K < 256 || M < 256 || N < 256) return 0;
+		// in K-slices (the fc layers' data gradients, 256 x 18432 x 4096 in 8 slices: 0.421 -> 0.335 ms with the 128 x 128 tile, 0.363 with 256 x 256;
+		// profiles/r06_v18_bf16x3_bench_tile128.txt)
+		if (s > 1) return K / s >= 256 ? 128 : 0;
 		return t256 * zcount >= cus ? 256 : (t128 * zcount >= cus ? 128 : 0);
 	}
+	if (!AKC && K >= 128 && M >= 128 && N >= 128 && t128 * zcount * s >= cus) return 128; // (see below)
 	if (K < 128 || M < 256 || N < 256) return 0;
-	if (!AKC && (M < 512 || N < 512)) return 0;
-	// a row-contiguous pair with a short reduction is its epilogue (256 KB per workgroup): fc7's filter gradient, 4096 x 4096 x 256, ran 0.242 ms split against
-	// 0.189 ms on the fp32 instructions (profiles/r06_v2_contraction_records.txt); the Winograd filter gradients keep >= 512 of K per slice
-	if (!AKC && K / s < 512) return 0;
+	// Two row-contiguous operands (filter gradients): the 128 x 128 tile.  With 256 x 256 a short reduction was all epilogue (256 KB per workgroup: fc7's filter gradient,
+	// 4096 x 4096 x 256, 0.242 ms against 0.189 on the fp32 instructions in round 6's first half) and 256 x 256 outputs lost 3 - 8 %; with 128 x 128 the same product runs
+	// 0.145 against 0.170 ms, the Winograd filter gradient of a 256-channel layer (256 x 256 x 50176 x 36 in 16 slices) 1.656 against 1.770, of the 512-channel layers
+	// 1.629 / 0.596 against 1.683 / 0.639 (256 x 256 tile: 1.647 / 0.606), 512 x 256 outputs the same as the fp32 instructions (same file)
+	if (!AKC) return t128 * zcount * s >= cus ? 128 : 0;
 	return t256 * zcount * s >= cus ? 256 : 0;
 }
 template <bool AKC, bool BKC>
