@@ -236,12 +236,33 @@ static int launch_permute(const void* in, void* out, const perm4_t& p, ccv_nnc_s
 // call on ResNet-50's filters, three calls per convolution per step (forward, data gradient, filter gradient back) -- 1.5 ms of config 4's step for 100 MB.
 // Here: one workgroup per filter; the R * S contiguous words come in as they lie (coalesced), cross through LDS, and leave as they will lie (coalesced).
 constexpr int WT_BYTES = 65536; // one matrix in LDS: 512 x 9 or 1024 x 9 floats, 128 x 49 floats, 512 x 49 halves ...
-template <typename T>
+// Round 6, last session: the LDS a workgroup takes follows the matrix (8 / 16 / 32 / 64 KB instances; one static 64 KB kept two workgroups on a CU), the matrix comes in 16 bytes per lane
+// where it is whole chunks, and leaves 16 bytes per lane as well: EIGHT (four for 4-byte elements) consecutive outputs gathered from LDS, one division per chunk instead of one per element.  ResNet-50's 97 (fp32: 143) launches per step ran 10.5 us each for 0.1 - 4.7 MB.
+template <typename T, int BYTES>
 __global__ void __launch_bounds__(256) filter_transpose_kernel(const T* __restrict__ in, T* __restrict__ out, const int R, const int S)
 {
-	__shared__ T buf[WT_BYTES / sizeof(T)];
+	__shared__ __attribute__((aligned(16))) T buf[BYTES / sizeof(T)];
+	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+	constexpr int PER = 16 / (int)sizeof(T);
 	const int n = R * S;
 	const size_t base = (size_t)blockIdx.x * n;
+	const bool wide = (n % PER) == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0; // (whole 16-byte chunks per matrix: every matrix of the batch starts on one)
+	if (wide) {
+		for (int i = threadIdx.x; i < n / PER; i += 256) ((u4*)buf)[i] = ((const u4*)(in + base))[i];
+		__syncthreads();
+		for (int c = threadIdx.x; c < n / PER; c += 256) { // outputs o = s * R + r, PER consecutive ones per lane: out[o] <- buf[r * S + s]
+			const int o0 = c * PER;
+			int s_ = o0 / R, r = o0 - s_ * R;
+			union { u4 q; T v[PER]; } u;
+#pragma unroll
+			for (int e = 0; e < PER; e++) {
+				u.v[e] = buf[r * S + s_];
+				if (++r == R) { r = 0; ++s_; }
+			}
+			*(u4*)(out + base + o0) = u.q;
+		}
+		return;
+	}
 	for (int i = threadIdx.x; i < n; i += 256) buf[i] = in[base + i];
 	__syncthreads();
 	for (int o = threadIdx.x; o < n; o += 256) { // o = s * R + r  <-  r * S + s
@@ -254,7 +275,12 @@ static bool filter_transpose_fits(const int R, const int S) { return (R < 64 || 
 template <typename T>
 static int filter_transpose(const void* in, void* out, int K, int R, int S, ccv_nnc_stream_context_t* ctx)
 {
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_transpose_kernel<T>), dim3(K), dim3(256), 0, stream_of(ctx), (const T*)in, (T*)out, R, S);
+	const size_t bytes = (size_t)R * S * sizeof(T);
+	hipStream_t stream = stream_of(ctx);
+	if (bytes <= 8192) hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_transpose_kernel<T, 8192>), dim3(K), dim3(256), 0, stream, (const T*)in, (T*)out, R, S);
+	else if (bytes <= 16384) hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_transpose_kernel<T, 16384>), dim3(K), dim3(256), 0, stream, (const T*)in, (T*)out, R, S);
+	else if (bytes <= 32768) hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_transpose_kernel<T, 32768>), dim3(K), dim3(256), 0, stream, (const T*)in, (T*)out, R, S);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_transpose_kernel<T, WT_BYTES>), dim3(K), dim3(256), 0, stream, (const T*)in, (T*)out, R, S);
 	HIP_ENFORCE(hipGetLastError());
 	return CCV_NNC_EXEC_SUCCESS;
 }
